@@ -1,0 +1,233 @@
+/*
+ * thunder_amd.h -- C ABI of the MI355X-native E/M hot path (libthunder_amd.so).
+ *
+ * Drop-in boundary for thuem/THUNDER v1.4.14's GPU plug-in surface gpu/interface/Interface.h:16-528
+ * and, through it, the Projector / Reconstructor methods on the per-iteration hot path
+ * (include/Projector.h:293-299, include/Reconstructor.h:530,550,610,703,720).  Every entry point
+ * names the reference interface it replaces (paths relative to the reference tree).  The C++
+ * marshalling stub a THUNDER maintainer adds on the reference side (Volume& / vec / vector<> ->
+ * plain pointers) is shown in INTEGRATION.md; header-only Projector / Reconstructor mirrors live in
+ * include/thunder_amd/.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  All functions return 0 on success, non-zero on
+ *     failure; thx_last_error() gives the message (the reference's own style is void + abort --
+ *     the C++ mirrors restore that).
+ *   - RFLOAT is float (SINGLE_PRECISION build, CMakeLists.txt:48); Complex is {float re, im}
+ *     (include/Precision.h:100-109) and is passed as float* with interleaved re,im.
+ *   - Rotation matrices are 9 doubles, column-major (Eigen dmat33, include/Typedef.h:149).
+ *   - Volume FT layout: [P][P][P/2+1] complex, index (k<0?k+P:k)*(P/2+1)*P + (j<0?j+P:j)*(P/2+1) + i
+ *     (include/Image/Volume.h:567-575).  T volumes are REAL float on this side of the boundary
+ *     (the reference stores T complex with a never-written imaginary part; its own GPU interface
+ *     also passes RFLOAT* T3D, Interface.h:337-344).
+ *   - *_dev functions: every pointer is a DEVICE pointer unless the parameter is documented
+ *     "host"; work is enqueued on `stream` (a hipStream_t, NULL = default stream) and the call
+ *     returns without synchronising unless stated.
+ *   - *_host functions (the Interface.h-shaped ones): every pointer is a caller-owned HOST pointer,
+ *     results are written back into the caller's buffers before return, exactly as
+ *     gpu/src/cuthunder.cu does.
+ */
+#ifndef THUNDER_AMD_H
+#define THUNDER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* struct CTFAttr, include/Database.h:302-330 (7 RFLOATs, same order) */
+typedef struct thx_ctf_attr {
+    float voltage;
+    float defocusU;
+    float defocusV;
+    float defocusTheta;
+    float Cs;
+    float amplitudeContrast;
+    float phaseShift;
+} thx_ctf_attr;
+
+const char* thx_last_error(void);
+int thx_version(void);
+
+/* getAviDevice(std::vector<int>&), Interface.h:16 -- number of visible gfx950 devices */
+int thx_device_count(int* count);
+/* selects the device later calls on this thread use (the reference passes gpuIdx per call) */
+int thx_set_device(int gpuIdx);
+
+/* ---------------------------------------------------------------------------------------------
+ * E-step building blocks
+ * ------------------------------------------------------------------------------------------- */
+
+/* rotate3D(dmat33&, const dvec4&), src/Geometry/Euler.cpp:181-189 (kernel_getRotMat):
+ * quat [n][4] -> mat [n][9] column-major. */
+int thx_rotmat_dev(const double* quat, double* mat, int n, void* stream);
+
+/* translate(Complex* dst, tx, ty, nCol, nRow, iCol, iRow, nPxl), src/Image/ImageFunctions.cpp:233-252
+ * for nT shifts at once (ExpectRotran, Interface.h:199-208): trans [nT][2] doubles -> traP [nT][nPxl]. */
+int thx_translate_dev(float* traP, const double* trans, int nT, const int* iCol, const int* iRow, int nPxl, int idim,
+                      void* stream);
+
+/* CTF(RFLOAT* dst, pixelSize, V, dU, dV, theta, Cs, A, phi, nCol, nRow, iCol, iRow, nPxl), src/CTF.cpp:113-151,
+ * for nImg images (GCTFinit Interface.h:524 / allocPreCal src/Optimiser.cpp:8083-8110).
+ * dfac (optional, may be NULL) [nImg] multiplies defocusU/V as src/Optimiser.cpp:7183-7202 does. */
+int thx_ctf_dev(float* ctfP, const thx_ctf_attr* attr, const double* dfac, float pixelSize, const int* iCol,
+                const int* iRow, int nPxl, int idim, int nImg, void* stream);
+
+/* Optimiser::allocPreCal gather (src/Optimiser.cpp:8055-8075): packs full image FTs
+ * img [nImg][idim][idim/2+1] into datP [nImg][nPxl] through iPxl. */
+int thx_gather_pixels_dev(float* datP, const float* img, const int* iPxl, int nPxl, int idim, int nImg, void* stream);
+
+/* Projector::project(Complex* dst, const dmat33&, iCol, iRow, nPxl, nThread) const, src/Projector.cpp:356-374,
+ * for nR matrices at once (ExpectProject, Interface.h:210-219; kernel_Project3D).  volume = padded, grid-corrected
+ * FT held by the Projector (vdim = P = pf*N); out [nR][nPxl].  Trilinear only (interp == LINEAR_INTERP).
+ * Results are bit-identical to the reference's arithmetic (fp64 matmul -> fp32 trilinear, no contraction). */
+int thx_project_dev(const float* volume, float* rotP, const double* rotMat, const int* iCol, const int* iRow, int nR,
+                    int pf, int vdim, int nPxl, void* stream);
+
+/* logDataVSPrior(dat, pri, ctf, sigRcp, m), src/Optimiser.cpp:9187-9213 for n (pri) rows against one image row:
+ * out[i] = sum_pix |dat - ctf*pri_i|^2 * sigRcp.  Wave-tree summation (the reference's own scalar and AVX
+ * variants already differ in order). */
+int thx_logdatavsprior_dev(float* out, const float* dat, const float* pri, const float* ctf, const float* sigRcp,
+                           int nPri, int nPxl, void* stream);
+
+/* One particle-filter phase for a batch of images: the body of HOT LOOP B, src/Optimiser.cpp:1225-1406
+ * (ExpectLocalP/RTD/PreI3D/M, Interface.h:50-145, collapsed into one batched call).
+ *   volumes      [nVol] padded FTs back to back (vdim^3 half-complex each); volIdx [nImg] (NULL = 0)
+ *   datP, ctfP, sigRcpP  image-major rows [nImg][nPxl]; when nD > 1 ctfP is [nImg][nD][nPxl]
+ *                (rows built as src/Optimiser.cpp:1263-1287)
+ *   rotMat [nImg][nR][9], trans [nImg][nT][2] (pixels, double as Particle::t)
+ *   pC [nImg], pR [nImg][nR], pT [nImg][nT], pD [nImg][nD]  priors (Particle::wC/wR/wT/wD, double)
+ * outputs (RFLOAT): wC [nImg], wR [nImg][nR], wT [nImg][nT], wD [nImg][nD], baseLine [nImg],
+ *   logW (optional, may be NULL) [nImg][nD][nT][nR] every log-likelihood.
+ * Weights are relative to the per-image maximum exactly as the reference's running-baseline rescale leaves
+ * them (mathematically identical; float rounding differs -- tolerance in tests/test_parity_gpu.py).
+ * workspace: thx_expect_local_workspace() bytes of device scratch. */
+size_t thx_expect_local_workspace(int nImg, int nR, int nT, int nD);
+int thx_expect_local_dev(const float* volumes, const int* volIdx, int vdim, int pf, int idim, const int* iCol,
+                         const int* iRow, int nPxl, int nImg, const float* datP, const float* ctfP,
+                         const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
+                         const double* pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR,
+                         float* wT, float* wD, float* baseLine, float* logW, void* workspace, void* stream);
+
+/* Global scanning phase for class kIdx: src/Optimiser.cpp:756-894 (ExpectGlobal3D, Interface.h:221-237).
+ *   rotP [nR][nPxl] slices (thx_project_dev), traP [nT][nPxl] ramps (thx_translate_dev)
+ *   datP/ctfP/sigRcpP image-major [nImg][nPxl]; pR [nImg][nR], pT [nImg][nT] priors
+ *   wC [nImg][nK], wR [nK][nImg][nR], wT [nK][nImg][nT], baseL [nImg] are READ-MODIFY-WRITE and carry over
+ *   from class to class as in the reference (baseL = NaN means "unset", :737-745). */
+size_t thx_expect_global_workspace(int nImg, int nR, int nT);
+int thx_expect_global_dev(const float* rotP, const float* traP, const float* datP, const float* ctfP,
+                          const float* sigRcpP, const double* pR, const double* pT, float* wC, float* wR, float* wT,
+                          float* baseL, int kIdx, int nK, int nR, int nT, int nPxl, int nImg, void* workspace,
+                          void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * M-step
+ * ------------------------------------------------------------------------------------------- */
+
+/* HOT LOOP C + Reconstructor::insertP/insertDir, src/Optimiser.cpp:7038-7241, src/Reconstructor.cpp:407-422,
+ * 782-863 (InsertFT, Interface.h:267-318; kernel_InsertT/InsertF).
+ *   F [nK] complex volumes, T [nK] real volumes (dim^3 half grids, dim = pf*size), accumulated in place
+ *   datP [nImg][nPxl] (UNMASKED images, _imgOri), ctfP [nImg][nPxl]; w [nImg] per-image weight (already / mReco)
+ *   rotMat [nImg][mReco][9], trans [nImg][mReco][2], offS [nImg][2] (NULL = 0): image shifted by -(tran - offS)
+ *   cls [nImg][mReco] (NULL = class 0); iCol/iRow UNPADDED pixel indices, opf = padding factor
+ *   cSearch != 0: CTF recomputed per draw from attr [nImg] with defocus * dfac [nImg][mReco] (:7183-7202)
+ *   O (3 doubles) += -R*(tran-offS) and counter += 1 per draw (insertDir).
+ * fp32 hardware atomics: summation order differs run to run exactly as the reference's `omp atomic`. */
+int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK, const float* datP,
+                   const float* ctfP, const float* w, const double* rotMat, const double* trans, const double* offS,
+                   const int* cls, const thx_ctf_attr* attr, const double* dfac, int cSearch, float pixelSize,
+                   const int* iCol, const int* iRow, int opf, int nPxl, int mReco, int idim, int nImg, void* stream);
+
+/* Reconstructor::allReduceT tail (RECONSTRUCTOR_NORMALISE_T_F), src/Reconstructor.cpp:2455-2476:
+ * sf = 1/T[0]; T *= sf; F *= sf.  (The sum over ranks itself is RCCL, done by the caller on F/T.) */
+int thx_normalise_tf_dev(float* F, float* T, int dim, void* stream);
+
+/* Reconstructor::symmetrizeF / symmetrizeT = SYMMETRIZE_FT, include/Geometry/Transformation.h:105-131,170-194,
+ * src/Reconstructor.cpp:2676-2690 (PrepareTF, Interface.h:320-326; kernel_SymmetrizeF/T).
+ * dst = src + sum_s interp(src, R_s k) inside |R_s k| < r (r = maxRadius*pf + 1); dst != src.
+ * symMat host pointer [nSym][9]. isComplex: 1 for F, 0 for T. */
+int thx_symmetrize_dev(float* dst, const float* src, int dim, int isComplex, const double* symMat_host, int nSym,
+                       double r, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Reconstructor state (allocSpace / freeSpace, src/Reconstructor.cpp:92-160: FFT plans + W, C volumes)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct thx_reco thx_reco;
+
+/* Reconstructor(mode=MODE_3D, size, N, pf, sym, a, alpha) + allocSpace: include/Reconstructor.h ctor,
+ * src/Reconstructor.cpp:43-90,92-136.  Builds the MKB_RL_R2 table (_kernelRL, 1e5 steps), hipFFT plans for
+ * (pf*size)^3 and the W / C / scratch volumes. */
+int thx_reco_create(thx_reco** out, int size, int N, int pf, float a, float alpha);
+int thx_reco_destroy(thx_reco* r);
+
+/* Reconstructor::reconstruct(Volume& dst, nThread), src/Reconstructor.cpp:1129-1831, MODE_3D
+ * (ExposePT + ExposeWT + ExposePFW/ExposePF + ExposeCorrF, Interface.h:337-505).
+ *   F, T: device volumes AFTER prepareTF (T is modified in place as in the reference: Wiener term, 1e-25 floor)
+ *   FSC host pointer [nFSC] (used when MAP != 0), joinHalf, gridCorr as setMAP/setJoinHalf/setGridCorr
+ *   dstRL device real volume [N][N][N] (wrapped index layout, origin at [0][0][0])
+ *   nIterOut / diffCOut (host, optional): balancing rounds done and last distance.
+ * Synchronises the stream once per balancing round (the convergence test of :1530-1551 runs on the host). */
+int thx_reco_reconstruct_dev(thx_reco* r, const float* F, float* T, int maxRadius, const float* FSC_host, int nFSC,
+                             int joinHalf, int MAP, int gridCorr, float* dstRL, int* nIterOut, float* diffCOut,
+                             void* stream);
+
+/* Projector::setProjectee(Volume src, nThread), src/Projector.cpp:123-148 + gridCorrection :524-606, starting from
+ * the real-space map (the reference first fft.bw's the FT it is handed): zero-pad x pf, divide by TIK_RL,
+ * forward FFT.  refRL device [N][N][N]; volume out [pf*N]^3 half-complex. */
+int thx_reco_set_projectee_dev(thx_reco* r, const float* refRL, float* volume, void* stream);
+
+/* forward / backward FFT of an N^3 map on the device (FFT::fw / FFT::bw, src/FFT.cpp:176-232; 1/size on bw) */
+int thx_fft3d_fw_dev(const float* rl, float* ft, int n, void* stream);
+int thx_fft3d_bw_dev(float* ft, float* rl, int n, void* stream);
+
+/* FSC(vec&, const Volume& A, const Volume& B), src/Functions/Spectrum.cpp:302-337: two half-complex FTs of
+ * dim^3 maps -> fsc [nShell] (device). */
+int thx_fsc_dev(float* fsc, int nShell, const float* A, const float* B, int dim, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Interface.h-shaped HOST-pointer entry points (what -DGPU_VERSION call sites bind to)
+ * ------------------------------------------------------------------------------------------- */
+
+/* void ExpectProject(Complex* volume, Complex* rotP, double* rotMat, const int* iCol, const int* iRow,
+ *                    int nR, int pf, int interp, int vdim, int npxl)            Interface.h:210-219 */
+int thx_ExpectProject_host(const float* volume, float* rotP, const double* rotMat, const int* iCol, const int* iRow,
+                           int nR, int pf, int interp, int vdim, int npxl);
+
+/* void ExpectRotran(Complex* traP, double* trans, double* rot, double* rotMat, const int* iCol, const int* iRow,
+ *                   int nR, int nT, int idim, int npxl)                          Interface.h:199-208
+ * rot = quaternions [nR][4] in, rotMat [nR][9] out, traP [nT][npxl] out. */
+int thx_ExpectRotran_host(float* traP, const double* trans, const double* rot, double* rotMat, const int* iCol,
+                          const int* iRow, int nR, int nT, int idim, int npxl);
+
+/* void InsertFT(Volume& F3D, Volume& T3D, double* O3D, int* counter, MPI_Comm& hemi, MPI_Comm& slav, Complex* datP,
+ *               RFLOAT* ctfP, RFLOAT* sigRcpP, CTFAttr* ctfaData, double* offS, RFLOAT* w, double* nR, double* nT,
+ *               double* nD, [int* nC,] const int* iCol, const int* iRow, RFLOAT pixelSize, bool cSearch, int opf,
+ *               int npxl, int mReco, int idim, int dimSize, int imgNum)          Interface.h:267-318
+ * F3D/T3D are passed as the raw half-complex arrays (&F3D[0], complex T with unused imaginary part as the
+ * reference holds it); nR are QUATERNIONS [imgNum][mReco][4] as in the reference.  The MPI communicators of
+ * the reference signature are replaced by the caller doing the hemisphere reduction (thx has no MPI dependency):
+ * this call accumulates the LOCAL contribution into F3D/T3D/O3D/counter. */
+int thx_InsertFT_host(float* F3D, float* T3D_complex, double* O3D, int* counter, const float* datP, const float* ctfP,
+                      const thx_ctf_attr* ctfaData, const double* offS, const float* w, const double* nR,
+                      const double* nT, const double* nD, const int* nC, const int* iCol, const int* iRow,
+                      float pixelSize, int cSearch, int opf, int npxl, int mReco, int idim, int vdim, int nK,
+                      int imgNum);
+
+/* void PrepareTF(int gpuIdx, Volume& F3D, Volume& T3D, double* symMat, int nSymmetryElement, int maxRadius, int pf)
+ *                                                                                Interface.h:320-326
+ * normalise by 1/T[0] + symmetrise both, on host arrays (T complex as the reference holds it). */
+int thx_PrepareTF_host(int gpuIdx, float* F3D, float* T3D_complex, int vdim, const double* symMat,
+                       int nSymmetryElement, int maxRadius, int pf);
+
+/* Reconstructor::reconstructG(Volume& dst, int gpuIdx, nThread) (src/Reconstructor.cpp:1835-2315: ExposePT, ExposeWT,
+ * ExposePFW, ExposeCorrF chained) on host arrays: F3D complex, T3D complex, dst real [N]^3. */
+int thx_ReconstructG_host(int gpuIdx, const float* F3D, const float* T3D_complex, int size, int N, int pf,
+                          int maxRadius, float a, float alpha, const float* FSC, int nFSC, int joinHalf, int MAP,
+                          int gridCorr, float* dstRL);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THUNDER_AMD_H */

@@ -1,0 +1,300 @@
+"""ctypes front-end of the CPU oracle (oracle/thunder_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by anything under thunder_amd/.
+
+PARITY UNPINNED (see the header of thunder_oracle.c and DESIGN.md section 3): the reference is not
+buildable in this image, and its tests hold no golden vectors for this path.
+
+The 3-D FFT stages of Projector::setProjectee (src/Projector.cpp:123-148) and
+Reconstructor::reconstruct (src/Reconstructor.cpp:1129-1831) use FFTW single precision in the
+reference (src/FFT.cpp:176-232: unnormalised forward, 1/size on backward); here they go through
+scipy.fft on float32 data (same convention, pocketfft single precision).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import scipy.fft as sfft
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_f = C.POINTER(C.c_float)
+c_d = C.POINTER(C.c_double)
+c_i = C.POINTER(C.c_int)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libthunder_oracle.so")
+    src = os.path.join(_HERE, "thunder_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libthunder_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_TIK_RL.restype = C.c_float
+        _LIB.orc_TIK_RL.argtypes = [C.c_float]
+        _LIB.orc_MKB_RL.restype = C.c_float
+        _LIB.orc_MKB_RL.argtypes = [C.c_float] * 3
+        _LIB.orc_logDataVSPrior.restype = C.c_float
+        _LIB.orc_logDataVSPrior_f64.restype = C.c_double
+        _LIB.orc_update_W_checkC.restype = C.c_float
+        _LIB.orc_pixel_list.restype = C.c_int
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def c64(a):
+    return np.ascontiguousarray(a, dtype=np.complex64)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+# ---------------------------------------------------------------------------------------------
+def pixel_list(N, rU, rL, pf=2):
+    """Optimiser::allocPreCalIdx (src/Optimiser.cpp:7991-8041) -> dict of int32 arrays."""
+    cap = (N // 2 + 1) * N
+    arrs = [np.zeros(cap, np.int32) for _ in range(6)]
+    n = lib().orc_pixel_list(C.c_int(N), C.c_float(rU), C.c_float(rL), C.c_int(pf), *[_p(a, c_i) for a in arrs])
+    names = ["iCol", "iRow", "iPxl", "iSig", "iColPad", "iRowPad"]
+    out = {k: a[:n].copy() for k, a in zip(names, arrs)}
+    out["nPxl"] = n
+    return out
+
+
+def ctf(pixelSize, voltage, defU, defV, theta, Cs, ampC, phaseShift, N, iCol, iRow):
+    """CTF(RFLOAT* dst, ...) src/CTF.cpp:113-151."""
+    iCol, iRow = i32(iCol), i32(iRow)
+    dst = np.zeros(len(iCol), np.float32)
+    lib().orc_ctf(_p(dst, c_f), C.c_float(pixelSize), C.c_float(voltage), C.c_float(defU), C.c_float(defV),
+                  C.c_float(theta), C.c_float(Cs), C.c_float(ampC), C.c_float(phaseShift), C.c_int(N), C.c_int(N),
+                  _p(iCol, c_i), _p(iRow, c_i), C.c_int(len(iCol)))
+    return dst
+
+
+def translate(tx, ty, N, iCol, iRow, src=None):
+    """translate(Complex* dst, tx, ty, ...) src/Image/ImageFunctions.cpp:233-252 (:471-492 with src)."""
+    iCol, iRow = i32(iCol), i32(iRow)
+    dst = np.zeros(len(iCol), np.complex64)
+    if src is None:
+        lib().orc_translate(_p(dst, c_f), C.c_float(tx), C.c_float(ty), C.c_int(N), C.c_int(N), _p(iCol, c_i),
+                            _p(iRow, c_i), C.c_int(len(iCol)))
+    else:
+        src = c64(src)
+        lib().orc_translate_src(_p(dst, c_f), _p(src, c_f), C.c_float(tx), C.c_float(ty), C.c_int(N), C.c_int(N),
+                                _p(iCol, c_i), _p(iRow, c_i), C.c_int(len(iCol)))
+    return dst
+
+
+def rotate3D(q):
+    """rotate3D(dmat33&, dvec4) src/Geometry/Euler.cpp:181-189 -> 9 doubles column-major."""
+    q = f64(q)
+    out = np.zeros(9, np.float64)
+    lib().orc_rotate3D(_p(out, c_d), _p(q, c_d))
+    return out
+
+
+def project(vol, P, pf, mat, iCol, iRow):
+    """Projector::project(Complex*, dmat33, iCol, iRow, nPxl) src/Projector.cpp:356-374."""
+    vol, mat, iCol, iRow = c64(vol), f64(mat), i32(iCol), i32(iRow)
+    dst = np.zeros(len(iCol), np.complex64)
+    lib().orc_project(_p(dst, c_f), _p(vol, c_f), C.c_int(P), C.c_int(pf), _p(mat, c_d), _p(iCol, c_i),
+                      _p(iRow, c_i), C.c_int(len(iCol)))
+    return dst
+
+
+def interp_ft(vol, P, x, y, z):
+    vol = c64(vol)
+    out = np.zeros(1, np.complex64)
+    lib().orc_interp_ft(_p(vol, c_f), C.c_int(P), C.c_float(x), C.c_float(y), C.c_float(z), _p(out, c_f))
+    return out[0]
+
+
+def logDataVSPrior(dat, pri, ctf_, sigRcp):
+    dat, pri, ctf_, sigRcp = c64(dat), c64(pri), f32(ctf_), f32(sigRcp)
+    return float(lib().orc_logDataVSPrior(_p(dat, c_f), _p(pri, c_f), _p(ctf_, c_f), _p(sigRcp, c_f),
+                                          C.c_int(len(ctf_))))
+
+
+def logDataVSPrior_f64(dat, pri, ctf_, sigRcp):
+    dat, pri, ctf_, sigRcp = c64(dat), c64(pri), f32(ctf_), f32(sigRcp)
+    return float(lib().orc_logDataVSPrior_f64(_p(dat, c_f), _p(pri, c_f), _p(ctf_, c_f), _p(sigRcp, c_f),
+                                              C.c_int(len(ctf_))))
+
+
+def expect_local(vol, P, pf, N, iCol, iRow, dat, ctfP, sigRcp, rot, tran, nD=1, pC=1.0, pR=None, pT=None, pD=None,
+                 cSearch=False):
+    """One particle-filter phase of one image, src/Optimiser.cpp:1225-1406.
+    rot [nR][9] column-major, tran [nT][2]; returns dict(wC, wR, wT, wD, baseLine, logW[nR][nT][nD])."""
+    vol, iCol, iRow = c64(vol), i32(iCol), i32(iRow)
+    dat, ctfP, sigRcp = c64(dat), f32(ctfP), f32(sigRcp)
+    rot, tran = f64(rot).reshape(-1, 9), f64(tran).reshape(-1, 2)
+    nR, nT, nPxl = len(rot), len(tran), len(iCol)
+    pR = f64(np.ones(nR) if pR is None else pR)
+    pT = f64(np.ones(nT) if pT is None else pT)
+    pD = f64(np.ones(nD) if pD is None else pD)
+    wC = np.zeros(1, np.float32)
+    wR = np.zeros(nR, np.float32)
+    wT = np.zeros(nT, np.float32)
+    wD = np.zeros(nD, np.float32)
+    base = np.zeros(1, np.float32)
+    logW = np.zeros((nR, nT, nD), np.float32)
+    lib().orc_expect_local(_p(vol, c_f), C.c_int(P), C.c_int(pf), C.c_int(N), _p(iCol, c_i), _p(iRow, c_i),
+                           C.c_int(nPxl), _p(dat, c_f), _p(ctfP, c_f), C.c_int(1 if cSearch else 0), _p(sigRcp, c_f),
+                           _p(rot, c_d), C.c_int(nR), _p(tran, c_d), C.c_int(nT), C.c_int(nD), C.c_double(pC),
+                           _p(pR, c_d), _p(pT, c_d), _p(pD, c_d), _p(wC, c_f), _p(wR, c_f), _p(wT, c_f), _p(wD, c_f),
+                           _p(base, c_f), _p(logW, c_f))
+    return dict(wC=wC, wR=wR, wT=wT, wD=wD, baseLine=float(base[0]), logW=logW)
+
+
+def expect_global(rotP, traP, datP, ctfP, sigRcpP, nK, kIdx, pR, pT, wC, wR, wT, baseLine):
+    """Scanning phase for class kIdx, src/Optimiser.cpp:756-894 (in-place on wC/wR/wT/baseLine).
+    rotP [nR][nPxl], traP [nT][nPxl], datP/ctfP/sigRcpP pixel-major [nPxl][nImg];
+    wC [nImg][nK], wR [nK][nImg][nR], wT [nK][nImg][nT], baseLine [nImg] (NaN = unset)."""
+    rotP, traP, datP = c64(rotP), c64(traP), c64(datP)
+    ctfP, sigRcpP, pR, pT = f32(ctfP), f32(sigRcpP), f64(pR), f64(pT)
+    nR, nPxl = rotP.shape
+    nT = traP.shape[0]
+    nImg = datP.shape[1]
+    for a in (wC, wR, wT, baseLine):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    lib().orc_expect_global(_p(rotP, c_f), _p(traP, c_f), _p(datP, c_f), _p(ctfP, c_f), _p(sigRcpP, c_f),
+                            C.c_int(nImg), C.c_int(nPxl), C.c_int(nK), C.c_int(kIdx), C.c_int(nR), C.c_int(nT),
+                            _p(pR, c_d), _p(pT, c_d), _p(wC, c_f), _p(wR, c_f), _p(wT, c_f), _p(baseLine, c_f))
+
+
+def insertP(F, T, P, src, ctf_, rot, w, iColPad, iRowPad):
+    """Reconstructor::insertP src/Reconstructor.cpp:782-863 (in place; F complex64, T float32)."""
+    assert F.dtype == np.complex64 and T.dtype == np.float32 and F.flags.c_contiguous and T.flags.c_contiguous
+    src, ctf_, rot, iColPad, iRowPad = c64(src), f32(ctf_), f64(rot), i32(iColPad), i32(iRowPad)
+    lib().orc_insertP(_p(F, c_f), _p(T, c_f), C.c_int(P), _p(src, c_f), _p(ctf_, c_f), _p(rot, c_d), C.c_float(w),
+                      _p(iColPad, c_i), _p(iRowPad, c_i), C.c_int(len(iColPad)))
+
+
+def normalise_TF(F, T, P):
+    lib().orc_normalise_TF(_p(F, c_f), _p(T, c_f), C.c_int(P))
+
+
+def symmetrize(vol, P, symMat, r):
+    """SYMMETRIZE_FT include/Geometry/Transformation.h:170-194; symMat [nSym][9] column-major."""
+    symMat = f64(symMat).reshape(-1, 9)
+    is_c = 1 if vol.dtype == np.complex64 else 0
+    out = np.empty_like(vol)
+    lib().orc_symmetrize(_p(out, c_f), _p(np.ascontiguousarray(vol), c_f), C.c_int(P), C.c_int(is_c), _p(symMat, c_d),
+                         C.c_int(len(symMat)), C.c_double(r))
+    return out
+
+
+def kernelRL_table(a=1.9, alpha=15.0, n=100000):
+    tab = np.zeros(n + 1, np.float32)
+    lib().orc_kernelRL_table(_p(tab, c_f), C.c_int(n), C.c_float(a), C.c_float(alpha))
+    return tab
+
+
+def fsc(A, B, P, nShell):
+    """FSC(vec&, Volume, Volume) src/Functions/Spectrum.cpp:302-337 on two half-complex FTs."""
+    A, B = c64(A), c64(B)
+    out = np.zeros(nShell, np.float32)
+    lib().orc_fsc(_p(out, c_f), C.c_int(nShell), _p(A, c_f), _p(B, c_f), C.c_int(P))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+def set_projectee(ref_rl, pf=2):
+    """Projector::setProjectee(Volume) src/Projector.cpp:123-148 starting from the real-space map
+    (the reference first does fft.bw on the FT it is handed): zero-pad x pf, divide by TIK_RL, r2c.
+    ref_rl: float32 [N][N][N] in wrapped-index layout (index (k<0?k+N:k), ...: origin at [0,0,0]).
+    Returns the complex64 padded FT [P][P][P/2+1]."""
+    ref_rl = f32(ref_rl)
+    N = ref_rl.shape[0]
+    P = N * pf
+    pad = np.zeros((P, P, P), np.float32)
+    lib().orc_pad_gridcorr(_p(pad, c_f), _p(ref_rl, c_f), C.c_int(N), C.c_int(pf))
+    return sfft.rfftn(pad).astype(np.complex64)
+
+
+def reconstruct(F, T, P, N, pf, maxRadius, FSC=None, joinHalf=False, MAP=True, gridCorr=True, a=1.9, alpha=15.0,
+                return_iters=False):
+    """Reconstructor::reconstruct(Volume&) src/Reconstructor.cpp:1129-1831, MODE_3D, _size == _N.
+    F complex64 [P][P][P/2+1], T float32 same grid (both AFTER prepareTF); returns float32 [N][N][N]
+    (wrapped-index layout)."""
+    L = lib()
+    F = c64(F).copy()
+    T = f32(T).copy()
+    n = T.size
+    if MAP:
+        FSC = f32(FSC)
+        L.orc_wiener_T(_p(T, c_f), C.c_int(P), C.c_int(pf), C.c_int(maxRadius), _p(FSC, c_f), C.c_int(len(FSC)),
+                       C.c_int(1 if joinHalf else 0))
+    W = np.zeros(n, np.float32)
+    L.orc_init_W_floor_T(_p(W, c_f), _p(T, c_f), C.c_int(P), C.c_int(pf), C.c_int(maxRadius))
+    iters = 0
+    diffs = []
+    if gridCorr:
+        tab = kernelRL_table(a, alpha)
+        nf = float(L.orc_MKB_RL(C.c_float(0), C.c_float(a), C.c_float(alpha)))
+        Cv = np.zeros((P, P, P // 2 + 1), np.complex64)
+        diffC = diffCPrev = np.float32(np.finfo(np.float32).max)
+        nNoDec = 0
+        for m in range(30):  # MAX_N_ITER_BALANCE
+            L.orc_calc_C(_p(Cv, c_f), _p(T, c_f), _p(W, c_f), C.c_int(P))
+            crl = sfft.irfftn(Cv, s=(P, P, P)).astype(np.float32)  # bwExecutePlan incl. 1/size
+            crl = np.ascontiguousarray(crl)
+            L.orc_convolute_rl(_p(crl, c_f), C.c_int(P), C.c_int(N * pf), _p(tab, c_f), C.c_int(100000), C.c_float(nf))
+            Cv = np.ascontiguousarray(sfft.rfftn(crl).astype(np.complex64))
+            diffCPrev = diffC
+            diffC = np.float32(L.orc_update_W_checkC(_p(W, c_f), _p(Cv, c_f), C.c_int(P), C.c_int(pf),
+                                                     C.c_int(maxRadius)))
+            diffs.append(float(diffC))
+            iters = m + 1
+            if diffC > diffCPrev * np.float32(0.95):
+                nNoDec += 1
+            else:
+                nNoDec = 0
+            if (diffC < 1e-2) or ((m >= 10) and (nNoDec == 2)):
+                break
+    else:
+        L.orc_W_nogridcorr(_p(W, c_f), _p(T, c_f), C.c_int(P), C.c_int(pf), C.c_int(maxRadius))
+    pad = np.zeros((P, P, P // 2 + 1), np.complex64)
+    L.orc_FW(_p(pad, c_f), _p(F, c_f), _p(W, c_f), C.c_int(P), C.c_int(pf), C.c_int(maxRadius))
+    prl = np.ascontiguousarray(sfft.irfftn(pad, s=(P, P, P)).astype(np.float32))
+    dst = np.zeros((N, N, N), np.float32)
+    L.orc_extract_tik(_p(dst, c_f), _p(prl, c_f), C.c_int(P), C.c_int(N), C.c_int(pf), C.c_int(1))
+    if return_iters:
+        return dst, iters, diffs, W
+    return dst
+
+
+def baseline_block(vol, P, pf, N, pl, dat, ctf_, sigRcp, rot, tran, recoRot, recoTran, F, T):
+    """bench.py cpu_baseline: fixed-work E (nPhase x nR x nT) + M (mReco inserts) for a block."""
+    vol, dat, ctf_, sigRcp = c64(vol), c64(dat), f32(ctf_), f32(sigRcp)
+    rot, tran, recoRot, recoTran = f64(rot), f64(tran), f64(recoRot), f64(recoTran)
+    nImg, nPhase, nR = rot.shape[0], rot.shape[1], rot.shape[2]
+    nT = tran.shape[2]
+    mReco = recoRot.shape[1]
+    wR = np.zeros((nImg, nR), np.float32)
+    lib().orc_baseline_block(_p(vol, c_f), C.c_int(P), C.c_int(pf), C.c_int(N), _p(i32(pl["iCol"]), c_i),
+                             _p(i32(pl["iRow"]), c_i), _p(i32(pl["iColPad"]), c_i), _p(i32(pl["iRowPad"]), c_i),
+                             C.c_int(pl["nPxl"]), C.c_int(nImg), _p(dat, c_f), _p(ctf_, c_f), _p(sigRcp, c_f),
+                             _p(rot, c_d), _p(tran, c_d), C.c_int(nPhase), C.c_int(nR), C.c_int(nT), _p(recoRot, c_d),
+                             _p(recoTran, c_d), C.c_int(mReco), _p(F, c_f), _p(T, c_f), _p(wR, c_f))
+    return wR

@@ -1,0 +1,819 @@
+/*
+ * thunder_oracle.c -- CPU restatement of thuem/THUNDER v1.4.14's per-iteration E/M hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under thunder_amd/ may include, link or call this file;
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as the
+ * checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED: the reference cannot be compiled in this image under the build rules
+ * (every translation unit reaches include/Precision.h:26-46, which needs GSL, FFTW3 and the
+ * cmake-generated THUNDERConfig.h; boost 1.60 is a missing blob), and the reference's own tests
+ * hold no golden vector for this path.  Every function below therefore
+ * restates the reference source line by line (file:line cited, paths relative to
+ * /root/reference) including its float/double cast points; the GSL 2.4 routines it relies on
+ * (gsl_hypot, gsl_hypot3, gsl_sf_bessel_j0) are restated from the vendored source
+ * external/packages/gsl-2.4/{sys/hypot.c:24-76, specfunc/bessel_j.c:35-58}.
+ *
+ * Build flags that matter: -ffp-contract=off (the reference is built -O2 -mavx, CMakeLists.txt:95,
+ * 132-133: no FMA contraction on x86-64), RFLOAT == float (SINGLE_PRECISION, CMakeLists.txt:48).
+ *
+ * Layouts (include/Image/Volume.h:567-575, include/Image/Image.h iFTHalf):
+ *   volume FT : complex64 [P][P][P/2+1], index (k<0?k+P:k)*(P/2+1)*P + (j<0?j+P:j)*(P/2+1) + i
+ *   image  FT : complex64 [N][N/2+1]
+ *   dmat33    : 9 doubles, column-major (Eigen default, include/Typedef.h:149)
+ *   T volume  : kept as a REAL float volume here; the reference stores it complex with the
+ *               imaginary part never written (src/Image/Volume.cpp:676-677 adds to dat[0] only).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+typedef float RFLOAT;
+
+/* ------------------------------------------------------------------------------------------ */
+/* GSL 2.4 restatements                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+
+/* external/packages/gsl-2.4/sys/hypot.c:24-55 (NORM, include/Functions/Functions.h:70) */
+static double gsl_hypot_(double x, double y)
+{
+    double xabs = fabs(x), yabs = fabs(y), min, max;
+    if (isinf(x) || isinf(y)) return INFINITY;
+    if (xabs < yabs) { min = xabs; max = yabs; } else { min = yabs; max = xabs; }
+    if (min == 0) return max;
+    {
+        double u = min / max;
+        return max * sqrt(1 + u * u);
+    }
+}
+
+/* external/packages/gsl-2.4/sys/hypot.c:57-76 (NORM_3, include/Functions/Functions.h:80) */
+static double gsl_hypot3_(double x, double y, double z)
+{
+    double xabs = fabs(x), yabs = fabs(y), zabs = fabs(z);
+    double w = xabs > (yabs > zabs ? yabs : zabs) ? xabs : (yabs > zabs ? yabs : zabs);
+    if (w == 0.0) return 0.0;
+    return w * sqrt((xabs / w) * (xabs / w) + (yabs / w) * (yabs / w) + (zabs / w) * (zabs / w));
+}
+
+/* external/packages/gsl-2.4/specfunc/bessel_j.c:35-58 */
+static double gsl_sf_bessel_j0_(double x)
+{
+    double ax = fabs(x);
+    if (ax < 0.5) {
+        const double y = x * x;
+        const double c1 = -1.0 / 6.0, c2 = 1.0 / 120.0, c3 = -1.0 / 5040.0, c4 = 1.0 / 362880.0,
+                     c5 = -1.0 / 39916800.0, c6 = 1.0 / 6227020800.0;
+        return 1.0 + y * (c1 + y * (c2 + y * (c3 + y * (c4 + y * (c5 + y * c6)))));
+    }
+    return sin(x) / x;
+}
+
+/* AROUND(a) = (int)rint(a), include/Functions/Functions.h:30 */
+static inline int AROUND_(double a) { return (int)rint(a); }
+
+/* TSGSL_pow_2/3/4 : RFLOAT in, gsl_pow_N in double, RFLOAT out (src/Precision.cpp:263-276) */
+static inline RFLOAT pow2f_(RFLOAT x) { double d = x; return (RFLOAT)(d * d); }
+static inline RFLOAT pow3f_(RFLOAT x) { double d = x; return (RFLOAT)(d * d * d); }
+static inline RFLOAT pow4f_(RFLOAT x) { double d = x; double d2 = d * d; return (RFLOAT)(d2 * d2); }
+
+/* TIK_RL, src/Functions/Functions.cpp:236-239; TSGSL_sf_bessel_j0 takes RFLOAT (src/Precision.cpp:362) */
+RFLOAT orc_TIK_RL(RFLOAT r)
+{
+    RFLOAT x = (RFLOAT)(M_PI * r);
+    RFLOAT j = (RFLOAT)gsl_sf_bessel_j0_((double)x);
+    return pow2f_(j);
+}
+
+/* Bessel pieces of MKB_RL (order 0): I0 by its power series, I_{3/2} in closed form.
+ * The reference calls gsl_sf_bessel_I0 / gsl_sf_bessel_Inu(1.5, v) (src/Functions/Functions.cpp:
+ * 160-176); both are accurate to double rounding, as are these, and the result is narrowed to
+ * float, so the table agrees to <= 1 float ulp. */
+static double bessel_I0_(double x)
+{
+    double q = x * x / 4.0, term = 1.0, sum = 1.0;
+    for (int k = 1; k < 500; k++) {
+        term *= q / ((double)k * (double)k);
+        sum += term;
+        if (term < sum * 1e-17) break;
+    }
+    return sum;
+}
+static double bessel_I15_(double v) { return sqrt(2.0 / (M_PI * v)) * (cosh(v) - sinh(v) / v); }
+static double bessel_J15_(double v) { return sqrt(2.0 / (M_PI * v)) * (sin(v) / v - cos(v)); }
+
+/* MKB_RL, src/Functions/Functions.cpp:143-176 (FUNCTIONS_MKB_ORDER_0, include/Config.h) */
+RFLOAT orc_MKB_RL(RFLOAT r, RFLOAT a, RFLOAT alpha)
+{
+    RFLOAT u = (RFLOAT)(2 * M_PI * a * r);
+    RFLOAT v = (u <= alpha) ? (RFLOAT)sqrt(pow2f_(alpha) - pow2f_(u)) : (RFLOAT)sqrt(pow2f_(u) - pow2f_(alpha));
+    RFLOAT I0a = (RFLOAT)bessel_I0_((double)alpha);
+    RFLOAT w = (RFLOAT)(pow(2 * M_PI, 1.5) * pow3f_(a) / I0a / pow((double)v, 1.5));
+    if (u <= alpha) return w * (RFLOAT)bessel_I15_((double)v);
+    return w * (RFLOAT)bessel_J15_((double)v);
+}
+
+/* MKB_RL_R2, src/Functions/Functions.cpp:178-214 */
+RFLOAT orc_MKB_RL_R2(RFLOAT r2, RFLOAT a, RFLOAT alpha)
+{
+    RFLOAT u2 = pow2f_((RFLOAT)(2 * M_PI * a)) * r2;
+    RFLOAT v = (u2 <= pow2f_(alpha)) ? (RFLOAT)sqrt(pow2f_(alpha) - u2) : (RFLOAT)sqrt(u2 - pow2f_(alpha));
+    RFLOAT I0a = (RFLOAT)bessel_I0_((double)alpha);
+    RFLOAT w = (RFLOAT)(pow(2 * M_PI, 1.5) * pow3f_(a) / I0a / pow((double)v, 1.5));
+    if (u2 <= pow2f_(alpha)) return w * (RFLOAT)bessel_I15_((double)v);
+    return w * (RFLOAT)bessel_J15_((double)v);
+}
+
+/* TabFunction::init over [a,b] with n steps, src/TabFunction.cpp:26-39; Reconstructor::init builds
+ * _kernelRL = MKB_RL_R2(., a, alpha) on [0,1] with 1e5 steps (src/Reconstructor.cpp:77-86).
+ * tab must hold n+1 floats. */
+void orc_kernelRL_table(RFLOAT* tab, int n, RFLOAT a, RFLOAT alpha)
+{
+    RFLOAT ta = 0, tb = 1;
+    RFLOAT s = (tb - ta) / n;
+    for (int i = 0; i <= n; i++) tab[i] = orc_MKB_RL_R2(ta + i * s, a, alpha);
+}
+
+/* TabFunction::operator(), src/TabFunction.cpp:42-45 (nearest sample) */
+static inline RFLOAT tab_lookup_(const RFLOAT* tab, int n, RFLOAT x)
+{
+    RFLOAT ta = 0, tb = 1;
+    RFLOAT s = (tb - ta) / n;
+    return tab[AROUND_((x - ta) / s)];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a1: pixel list  -- Optimiser::allocPreCalIdx, src/Optimiser.cpp:7991-8041                   */
+/* ------------------------------------------------------------------------------------------ */
+int orc_pixel_list(int N, RFLOAT rU, RFLOAT rL, int pf, int* iCol, int* iRow, int* iPxl, int* iSig,
+                   int* iColPad, int* iRowPad)
+{
+    RFLOAT rU2 = pow2f_(rU), rL2 = pow2f_(rL);
+    int n = 0;
+    /* IMAGE_FOR_PIXEL_R_FT(rU + 1), include/Image/Image.h:68-70 */
+    for (long j = (long)(-(rU + 1)); j < (rU + 1); j++)
+        for (long i = 0; i <= (rU + 1); i++) {
+            if ((i == 0) && (j < 0)) continue;
+            RFLOAT u = (RFLOAT)((double)i * (double)i + (double)j * (double)j); /* QUAD */
+            if ((u < rU2) && (u >= rL2)) {
+                int v = AROUND_(gsl_hypot_((double)i, (double)j));
+                if ((v < rU) && (v >= rL)) {
+                    if (iPxl) iPxl[n] = (int)((j >= 0 ? j : j + N) * (N / 2 + 1) + i); /* Image::iFTHalf */
+                    if (iCol) iCol[n] = (int)i;
+                    if (iRow) iRow[n] = (int)j;
+                    if (iSig) iSig[n] = v;
+                    if (iColPad) iColPad[n] = (int)i * pf;
+                    if (iRowPad) iRowPad[n] = (int)j * pf;
+                    n++;
+                }
+            }
+        }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a3: CTF on a pixel list -- src/CTF.cpp:113-151                                              */
+/* ------------------------------------------------------------------------------------------ */
+void orc_ctf(RFLOAT* dst, RFLOAT pixelSize, RFLOAT voltage, RFLOAT defocusU, RFLOAT defocusV, RFLOAT theta,
+             RFLOAT Cs, RFLOAT amplitudeContrast, RFLOAT phaseShift, int nCol, int nRow, const int* iCol,
+             const int* iRow, int nPxl)
+{
+    RFLOAT lambda = (RFLOAT)(12.2643247 / sqrt(voltage * (1 + voltage * 0.978466e-6)));
+    RFLOAT w1 = sqrtf(1 - pow2f_(amplitudeContrast));
+    RFLOAT w2 = amplitudeContrast;
+    RFLOAT K1 = (RFLOAT)(M_PI * lambda);
+    RFLOAT K2 = (RFLOAT)(M_PI_2 * Cs * pow3f_(lambda));
+    for (int i = 0; i < nPxl; i++) {
+        RFLOAT u = (RFLOAT)gsl_hypot_((double)(iCol[i] / (pixelSize * nCol)), (double)(iRow[i] / (pixelSize * nRow)));
+        RFLOAT angle = (RFLOAT)(atan2((double)iRow[i], (double)iCol[i]) - theta);
+        RFLOAT defocus = -(defocusU + defocusV + (defocusU - defocusV) * cosf(2 * angle)) / 2;
+        RFLOAT ki = K1 * defocus * pow2f_(u) + K2 * pow4f_(u) - phaseShift;
+        dst[i] = -w1 * sinf(ki) + w2 * cosf(ki);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a4: phase ramps -- translate(), src/Image/ImageFunctions.cpp:233-252 and :471-492          */
+/* M_2X_PI = 6.28318530717959 (include/Macro.h:14); COMPLEX_POLAR(-phase), include/Complex.h   */
+/* ------------------------------------------------------------------------------------------ */
+void orc_translate(RFLOAT* dst, RFLOAT nTransCol, RFLOAT nTransRow, int nCol, int nRow, const int* iCol,
+                   const int* iRow, int nPxl)
+{
+    RFLOAT rCol = nTransCol / nCol, rRow = nTransRow / nRow;
+    for (int i = 0; i < nPxl; i++) {
+        RFLOAT phase = (RFLOAT)(6.28318530717959 * (iCol[i] * rCol + iRow[i] * rRow));
+        dst[2 * i] = cosf(-phase);
+        dst[2 * i + 1] = sinf(-phase);
+    }
+}
+
+void orc_translate_src(RFLOAT* dst, const RFLOAT* src, RFLOAT nTransCol, RFLOAT nTransRow, int nCol, int nRow,
+                       const int* iCol, const int* iRow, int nPxl)
+{
+    RFLOAT rCol = nTransCol / nCol, rRow = nTransRow / nRow;
+    for (int i = 0; i < nPxl; i++) {
+        RFLOAT phase = (RFLOAT)(6.28318530717959 * (iCol[i] * rCol + iRow[i] * rRow));
+        RFLOAT c = cosf(-phase), s = sinf(-phase);
+        RFLOAT a0 = src[2 * i], a1 = src[2 * i + 1];
+        dst[2 * i] = a0 * c - a1 * s;     /* Complex * Complex, include/Complex.h operator* */
+        dst[2 * i + 1] = a0 * s + a1 * c;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a15: rotate3D(quaternion) -- src/Geometry/Euler.cpp:181-189; dst column-major              */
+/* ------------------------------------------------------------------------------------------ */
+void orc_rotate3D(double* dst, const double* q)
+{
+    double A[3][3] = {{0, -q[3], q[2]}, {q[3], 0, -q[1]}, {-q[2], q[1], 0}};
+    double AA[3][3];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += A[r][k] * A[k][c];
+            AA[r][c] = s;
+        }
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) dst[c * 3 + r] = (r == c ? 1.0 : 0.0) + 2 * q[0] * A[r][c] + 2 * AA[r][c];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a7: trilinear gather / scatter on the half-Hermitian volume                                 */
+/* conjHalf include/Image/Volume.h:135-147; WG_TRI_INTERP_LINEAR include/Functions/           */
+/* Interpolation.h:152-200; getFTHalf(w,x0) src/Image/Volume.cpp:491-563 -- the box fast path   */
+/* (x0[1]!=-1 && x0[2]!=-1) and the per-neighbour-wrap slow path visit the same 8 voxels in     */
+/* the same order (k outer, j, i inner) with the same arithmetic, so one wrapped loop restates  */
+/* both.                                                                                        */
+/* ------------------------------------------------------------------------------------------ */
+static inline size_t iFTHalf3_(long i, long j, long k, long P)
+{
+    long nColFT = P / 2 + 1;
+    return (size_t)((k >= 0 ? k : k + P) * nColFT * P + (j >= 0 ? j : j + P) * nColFT + i);
+}
+
+static inline void tri_weights_(RFLOAT w[2][2][2], long x0[3], RFLOAT x, RFLOAT y, RFLOAT z)
+{
+    RFLOAT xs[3] = {x, y, z}, xd[3], v[3][2];
+    for (int a = 0; a < 3; a++) {
+        x0[a] = (long)floor(xs[a]);
+        xd[a] = xs[a] - x0[a];
+        v[a][0] = 1 - xd[a];
+        v[a][1] = xd[a];
+    }
+    for (int k = 0; k < 2; k++)
+        for (int j = 0; j < 2; j++)
+            for (int i = 0; i < 2; i++) w[k][j][i] = v[0][i] * v[1][j] * v[2][k];
+}
+
+/* Volume::getByInterpolationFT (LINEAR_INTERP), src/Image/Volume.cpp:314-338 */
+void orc_interp_ft(const RFLOAT* vol, int P, RFLOAT x, RFLOAT y, RFLOAT z, RFLOAT* out)
+{
+    int conj = 0;
+    if (!(x >= 0)) { x *= -1; y *= -1; z *= -1; conj = 1; }
+    RFLOAT w[2][2][2];
+    long x0[3];
+    tri_weights_(w, x0, x, y, z);
+    RFLOAT re = 0, im = 0;
+    for (int k = 0; k < 2; k++)
+        for (int j = 0; j < 2; j++)
+            for (int i = 0; i < 2; i++) {
+                size_t idx = iFTHalf3_(x0[0] + i, x0[1] + j, x0[2] + k, P);
+                RFLOAT tr = vol[2 * idx] * w[k][j][i], ti = vol[2 * idx + 1] * w[k][j][i];
+                re = re + tr;
+                im = im + ti;
+            }
+    out[0] = re;
+    out[1] = conj ? -im : im;
+}
+
+/* a6: Projector::project(Complex*, dmat33, iCol, iRow, nPxl), src/Projector.cpp:356-374.
+ * dvec3 oldCor = mat * dvec3(iCol*pf, iRow*pf, 0) in double, narrowed to RFLOAT at the call
+ * to getByInterpolationFT(RFLOAT, ...) (include/Image/Volume.h:442). */
+void orc_project(RFLOAT* dst, const RFLOAT* vol, int P, int pf, const double* mat, const int* iCol,
+                 const int* iRow, int nPxl)
+{
+#pragma omp parallel for
+    for (int i = 0; i < nPxl; i++) {
+        double nx = (double)(iCol[i] * pf), ny = (double)(iRow[i] * pf), nz = 0;
+        double ox = mat[0] * nx + mat[3] * ny + mat[6] * nz;
+        double oy = mat[1] * nx + mat[4] * ny + mat[7] * nz;
+        double oz = mat[2] * nx + mat[5] * ny + mat[8] * nz;
+        orc_interp_ft(vol, P, (RFLOAT)ox, (RFLOAT)oy, (RFLOAT)oz, dst + 2 * i);
+    }
+}
+
+/* Volume::addFT(Complex value, x, y, z) / addFT(RFLOAT value, ...), src/Image/Volume.cpp:340-375,
+ * 565-712.  Single-threaded here, so the reference's `omp atomic` adds become plain adds in
+ * pixel order (the reference's multi-thread order is non-deterministic). */
+static inline void add_ft_(RFLOAT* F, RFLOAT* T, int P, RFLOAT vre, RFLOAT vim, RFLOAT tval, RFLOAT x, RFLOAT y,
+                           RFLOAT z)
+{
+    if (!(x >= 0)) { x *= -1; y *= -1; z *= -1; vim = -vim; }
+    RFLOAT w[2][2][2];
+    long x0[3];
+    tri_weights_(w, x0, x, y, z);
+    for (int k = 0; k < 2; k++)
+        for (int j = 0; j < 2; j++)
+            for (int i = 0; i < 2; i++) {
+                size_t idx = iFTHalf3_(x0[0] + i, x0[1] + j, x0[2] + k, P);
+                if (F) {
+                    F[2 * idx] += vre * w[k][j][i];
+                    F[2 * idx + 1] += vim * w[k][j][i];
+                }
+                if (T) T[idx] += tval * w[k][j][i];
+            }
+}
+
+/* a12: Reconstructor::insertP(src, ctf, rot, w, sig=NULL), src/Reconstructor.cpp:782-863
+ * (RECONSTRUCTOR_TRILINEAR_KERNEL + RECONSTRUCTOR_ADD_T_DURING_INSERT, include/Config.h).
+ * iCol/iRow here are the PADDED indices handed over by setPreCal (src/Optimiser.cpp:6741). */
+void orc_insertP(RFLOAT* F, RFLOAT* T, int P, const RFLOAT* src, const RFLOAT* ctf, const double* rot, RFLOAT w,
+                 const int* iColPad, const int* iRowPad, int nPxl)
+{
+    for (int i = 0; i < nPxl; i++) {
+        int iCol = iColPad[i], iRow = iRowPad[i];
+        double ox = rot[0] * iCol + rot[3] * iRow;
+        double oy = rot[1] * iCol + rot[4] * iRow;
+        double oz = rot[2] * iCol + rot[5] * iRow;
+        /* src[i] * ctf[i] * (sig == NULL ? 1 : ...) * w, left to right (Complex*RFLOAT) */
+        RFLOAT vre = src[2 * i] * ctf[i], vim = src[2 * i + 1] * ctf[i];
+        vre = vre * 1.0f; vim = vim * 1.0f;
+        vre = vre * w; vim = vim * w;
+        RFLOAT tv = pow2f_(ctf[i]) * 1.0f * w;
+        add_ft_(F, T, P, vre, vim, tv, (RFLOAT)ox, (RFLOAT)oy, (RFLOAT)oz);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a8/a9: likelihood -- src/Optimiser.cpp:9187-9213 and :9931-9973                             */
+/* ------------------------------------------------------------------------------------------ */
+RFLOAT orc_logDataVSPrior(const RFLOAT* dat, const RFLOAT* pri, const RFLOAT* ctf, const RFLOAT* sigRcp, int m)
+{
+    RFLOAT result2 = 0.0;
+    for (int i = 0; i < m; i++) {
+        RFLOAT tmpReal = ctf[i] * pri[2 * i];
+        RFLOAT tmpImag = ctf[i] * pri[2 * i + 1];
+        RFLOAT tmp1Real = dat[2 * i] - tmpReal;
+        RFLOAT tmp1Imag = dat[2 * i + 1] - tmpImag;
+        RFLOAT tmp2 = tmp1Real * tmp1Real + tmp1Imag * tmp1Imag;
+        result2 += (tmp2 * sigRcp[i]);
+    }
+    return result2;
+}
+
+/* pixel-major batch form: dat/ctf/sigRcp indexed [i*n + j] (i pixel, j image) */
+void orc_logDataVSPrior_mn(const RFLOAT* dat, const RFLOAT* pri, const RFLOAT* ctf, const RFLOAT* sigRcp, int n, int m,
+                           RFLOAT* result)
+{
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < n; j++) {
+            int idx = i * n + j;
+            RFLOAT a = ctf[idx] * pri[2 * i], b = ctf[idx] * pri[2 * i + 1];
+            RFLOAT c = dat[2 * idx] - a, d = dat[2 * idx + 1] - b;
+            RFLOAT t = c * c + d * d;
+            result[j] += (t * sigRcp[idx]);
+        }
+}
+
+/* same sum carried in double: NOT a reference function; the error yard-stick the parity tests
+ * use to bound both the reference's float summation order and the GPU's tree reduction. */
+double orc_logDataVSPrior_f64(const RFLOAT* dat, const RFLOAT* pri, const RFLOAT* ctf, const RFLOAT* sigRcp, int m)
+{
+    double r = 0;
+    for (int i = 0; i < m; i++) {
+        double a = (double)ctf[i] * pri[2 * i], b = (double)ctf[i] * pri[2 * i + 1];
+        double c = dat[2 * i] - a, d = dat[2 * i + 1] - b;
+        r += (c * c + d * d) * sigRcp[i];
+    }
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a10 (local): one particle-filter phase of one image -- src/Optimiser.cpp:1225-1406          */
+/* Support points are inputs (Particle stays host-side): nR rotation matrices (column-major),   */
+/* nT translations, nD defocus factors; priors pC (scalar, one class), pR, pT, pD (double, as   */
+/* Particle::wR etc).  ctfP: [nD][nPxl] when cSearch (computed by the caller as :1263-1287),     */
+/* else one row.  Outputs wC (1), wR, wT, wD (RFLOAT, Eigen vec) and the final baseLine.         */
+/* logW (optional, [nR][nT][nD]) receives every logDataVSPrior value for diagnostics.           */
+/* ------------------------------------------------------------------------------------------ */
+void orc_expect_local(const RFLOAT* vol, int P, int pf, int N, const int* iCol, const int* iRow, int nPxl,
+                      const RFLOAT* dat, const RFLOAT* ctfP, int cSearch, const RFLOAT* sigRcp, const double* rot,
+                      int nR, const double* tran, int nT, int nD, double pC, const double* pR, const double* pT,
+                      const double* pD, RFLOAT* wC, RFLOAT* wR, RFLOAT* wT, RFLOAT* wD, RFLOAT* baseLineOut,
+                      RFLOAT* logW)
+{
+    RFLOAT* traP = (RFLOAT*)malloc((size_t)nT * nPxl * 2 * sizeof(RFLOAT));
+    RFLOAT* priRotP = (RFLOAT*)malloc((size_t)nPxl * 2 * sizeof(RFLOAT));
+    RFLOAT* priAllP = (RFLOAT*)malloc((size_t)nPxl * 2 * sizeof(RFLOAT));
+    RFLOAT baseLine = NAN;
+    wC[0] = 0;
+    for (int i = 0; i < nR; i++) wR[i] = 0;
+    for (int i = 0; i < nT; i++) wT[i] = 0;
+    for (int i = 0; i < nD; i++) wD[i] = 0;
+
+    for (int iT = 0; iT < nT; iT++) /* :1236-1250; t(0),t(1) are double, narrowed at the call */
+        orc_translate(traP + (size_t)iT * nPxl * 2, (RFLOAT)tran[2 * iT], (RFLOAT)tran[2 * iT + 1], N, N, iCol, iRow,
+                      nPxl);
+
+    for (int iR = 0; iR < nR; iR++) {
+        orc_project(priRotP, vol, P, pf, rot + 9 * iR, iCol, iRow, nPxl); /* :1303-1310 */
+        for (int iT = 0; iT < nT; iT++) {
+            const RFLOAT* tp = traP + (size_t)iT * nPxl * 2;
+            for (int i = 0; i < nPxl; i++) { /* priAllP = traP * priRotP, :1319-1320 */
+                RFLOAT a0 = tp[2 * i], a1 = tp[2 * i + 1], b0 = priRotP[2 * i], b1 = priRotP[2 * i + 1];
+                priAllP[2 * i] = a0 * b0 - a1 * b1;
+                priAllP[2 * i + 1] = a0 * b1 + a1 * b0;
+            }
+            for (int iD = 0; iD < nD; iD++) {
+                const RFLOAT* ctf = cSearch ? ctfP + (size_t)iD * nPxl : ctfP;
+                RFLOAT w = orc_logDataVSPrior(dat, priAllP, ctf, sigRcp, nPxl); /* :1366-1380 scalar form */
+                if (logW) logW[((size_t)iR * nT + iT) * nD + iD] = w;
+                baseLine = isnan(baseLine) ? w : baseLine; /* :1383 */
+                if (w > baseLine) {                         /* :1385-1395 */
+                    RFLOAT nf = expf(baseLine - w); /* exp(float) resolves to the float overload under libstdc++'s <math.h> */
+                    wC[0] *= nf;
+                    for (int q = 0; q < nR; q++) wR[q] *= nf;
+                    for (int q = 0; q < nT; q++) wT[q] *= nf;
+                    for (int q = 0; q < nD; q++) wD[q] *= nf;
+                    baseLine = w;
+                }
+                RFLOAT s = expf(w - baseLine); /* :1397 */
+                /* :1399-1402 -- RFLOAT * (double products) evaluated in double, += into RFLOAT */
+                wC[0] = (RFLOAT)(wC[0] + s * (pR[iR] * pT[iT] * pD[iD]));
+                wR[iR] = (RFLOAT)(wR[iR] + s * (pC * pT[iT] * pD[iD]));
+                wT[iT] = (RFLOAT)(wT[iT] + s * (pC * pR[iR] * pD[iD]));
+                wD[iD] = (RFLOAT)(wD[iD] + s * (pC * pR[iR] * pT[iT]));
+            }
+        }
+    }
+    if (baseLineOut) *baseLineOut = baseLine;
+    free(traP); free(priRotP); free(priAllP);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a10 (global): the scanning phase -- src/Optimiser.cpp:756-894 for one class index t.        */
+/* datP/ctfP/sigRcpP pixel-major [pix][img]; slices rotP [nR][nPxl] (already projected) and     */
+/* ramps traP [nT][nPxl] as the reference precomputes them (:710-724, :781).  wC [nImg][nK],    */
+/* wR [nImg][nR] and wT [nImg][nT] are the matrices for THIS class; baseLine [nImg] is carried  */
+/* across classes (NaN = unset).  pR [nImg][nR], pT [nImg][nT] priors (Particle::wR/wT).        */
+/* The reference's thread interleaving is arbitrary; this is the sequential (m, n) order.       */
+/* ------------------------------------------------------------------------------------------ */
+void orc_expect_global(const RFLOAT* rotP, const RFLOAT* traP, const RFLOAT* datP, const RFLOAT* ctfP,
+                       const RFLOAT* sigRcpP, int nImg, int nPxl, int nK, int kIdx, int nR, int nT,
+                       const double* pR, const double* pT, RFLOAT* wC, RFLOAT* wRall, RFLOAT* wTall,
+                       RFLOAT* baseLine)
+{
+    /* wRall [nK][nImg][nR], wTall [nK][nImg][nT]: rescaling touches every class (:849-853) */
+    RFLOAT* priAllP = (RFLOAT*)malloc((size_t)nPxl * 2 * sizeof(RFLOAT));
+    RFLOAT* dvp = (RFLOAT*)malloc((size_t)nImg * sizeof(RFLOAT));
+    for (int m = 0; m < nR; m++) {
+        const RFLOAT* pr = rotP + (size_t)m * nPxl * 2;
+        for (int n = 0; n < nT; n++) {
+            const RFLOAT* tp = traP + (size_t)n * nPxl * 2;
+            for (int i = 0; i < nPxl; i++) {
+                RFLOAT a0 = tp[2 * i], a1 = tp[2 * i + 1], b0 = pr[2 * i], b1 = pr[2 * i + 1];
+                priAllP[2 * i] = a0 * b0 - a1 * b1;
+                priAllP[2 * i + 1] = a0 * b1 + a1 * b0;
+            }
+            memset(dvp, 0, (size_t)nImg * sizeof(RFLOAT));
+            orc_logDataVSPrior_mn(datP, priAllP, ctfP, sigRcpP, nImg, nPxl, dvp);
+            for (int l = 0; l < nImg; l++) {
+                if (isnan(baseLine[l]))
+                    baseLine[l] = dvp[l];
+                else if (dvp[l] > baseLine[l]) {
+                    RFLOAT offset = dvp[l] - baseLine[l];
+                    RFLOAT nf = expf(-offset);
+                    for (int q = 0; q < nK; q++) wC[(size_t)l * nK + q] *= nf;
+                    for (int td = 0; td < nK; td++) {
+                        RFLOAT* a = wRall + ((size_t)td * nImg + l) * nR;
+                        RFLOAT* b = wTall + ((size_t)td * nImg + l) * nT;
+                        for (int q = 0; q < nR; q++) a[q] *= nf;
+                        for (int q = 0; q < nT; q++) b[q] *= nf;
+                    }
+                    baseLine[l] += offset;
+                }
+                RFLOAT w = expf(dvp[l] - baseLine[l]);
+                double prm = pR[(size_t)l * nR + m], ptn = pT[(size_t)l * nT + n];
+                wC[(size_t)l * nK + kIdx] = (RFLOAT)(wC[(size_t)l * nK + kIdx] + w * (prm * ptn));
+                RFLOAT* a = wRall + ((size_t)kIdx * nImg + l) * nR;
+                RFLOAT* b = wTall + ((size_t)kIdx * nImg + l) * nT;
+                a[m] = (RFLOAT)(a[m] + w * ptn);
+                b[n] = (RFLOAT)(b[n] + w * prm);
+            }
+        }
+    }
+    free(priAllP); free(dvp);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a13: prepareTF pieces                                                                        */
+/* ------------------------------------------------------------------------------------------ */
+/* allReduceT tail, RECONSTRUCTOR_NORMALISE_T_F: sf = 1.0 / REAL(T[0]); SCALE_FT(T), SCALE_FT(F)
+ * (src/Reconstructor.cpp:2455-2476; `RFLOAT sf = 1.0 / REAL(_T3D[0])` is a double division narrowed) */
+void orc_normalise_TF(RFLOAT* F, RFLOAT* T, int P)
+{
+    size_t n = (size_t)P * P * (P / 2 + 1);
+    RFLOAT sf = (RFLOAT)(1.0 / T[0]);
+    for (size_t i = 0; i < n; i++) T[i] = T[i] * sf;
+    for (size_t i = 0; i < 2 * n; i++) F[i] = F[i] * sf;
+}
+
+/* SYMMETRIZE_FT(dst = src + sum_s VOL_TRANSFORM_MAT_FT(src, R_s, r, LINEAR)),
+ * include/Geometry/Transformation.h:105-131,170-194; called with r = maxRadius*pf + 1
+ * (src/Reconstructor.cpp:2676-2690).  symMat: nSym column-major 3x3.  isComplex selects F / T. */
+void orc_symmetrize(RFLOAT* dst, const RFLOAT* src, int P, int isComplex, const double* symMat, int nSym, double r)
+{
+    size_t n = (size_t)P * P * (P / 2 + 1);
+    size_t nf = isComplex ? 2 * n : n;
+    RFLOAT* se = (RFLOAT*)malloc(nf * sizeof(RFLOAT));
+    RFLOAT* tmpc = NULL;
+    if (!isComplex) { /* interpolate T through the complex path with a zero imaginary part */
+        tmpc = (RFLOAT*)calloc(2 * n, sizeof(RFLOAT));
+        for (size_t i = 0; i < n; i++) tmpc[2 * i] = src[i];
+    }
+    const RFLOAT* srcc = isComplex ? src : tmpc;
+    RFLOAT* result = (RFLOAT*)malloc(nf * sizeof(RFLOAT));
+    memcpy(result, src, nf * sizeof(RFLOAT));
+    for (int s = 0; s < nSym; s++) {
+        const double* mat = symMat + 9 * s;
+        memset(se, 0, nf * sizeof(RFLOAT));
+#pragma omp parallel for
+        for (long k = -P / 2; k < P / 2; k++)
+            for (long j = -P / 2; j < P / 2; j++)
+                for (long i = 0; i <= P / 2; i++) {
+                    double nx = (double)i, ny = (double)j, nz = (double)k;
+                    double ox = mat[0] * nx + mat[3] * ny + mat[6] * nz;
+                    double oy = mat[1] * nx + mat[4] * ny + mat[7] * nz;
+                    double oz = mat[2] * nx + mat[5] * ny + mat[8] * nz;
+                    if (ox * ox + oy * oy + oz * oz < r * r) {
+                        RFLOAT o[2];
+                        orc_interp_ft(srcc, P, (RFLOAT)ox, (RFLOAT)oy, (RFLOAT)oz, o);
+                        size_t idx = iFTHalf3_(i, j, k, P);
+                        if (isComplex) { se[2 * idx] = o[0]; se[2 * idx + 1] = o[1]; }
+                        else se[idx] = o[0];
+                    }
+                }
+        for (size_t i = 0; i < nf; i++) result[i] = result[i] + se[i]; /* ADD_FT */
+    }
+    memcpy(dst, result, nf * sizeof(RFLOAT));
+    free(se); free(result); if (tmpc) free(tmpc);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a14: reconstruct() element-wise stages, src/Reconstructor.cpp:1129-1831 (MODE_3D)           */
+/* ------------------------------------------------------------------------------------------ */
+/* [MAP] T /= FSC'(shell), :1242-1270.  FSC vector has nFSC entries (Eigen vec of RFLOAT). */
+void orc_wiener_T(RFLOAT* T, int P, int pf, int maxRadius, const RFLOAT* FSC, int nFSC, int joinHalf)
+{
+#pragma omp parallel for
+    for (long k = -P / 2; k < P / 2; k++)
+        for (long j = -P / 2; j < P / 2; j++)
+            for (long i = 0; i <= P / 2; i++) {
+                double q = (double)i * i + (double)j * j + (double)k * k;
+                if ((q >= pow2f_((RFLOAT)(5 * pf))) && (q < pow2f_((RFLOAT)(maxRadius * pf)))) {
+                    int u = AROUND_(gsl_hypot3_((double)i, (double)j, (double)k));
+                    RFLOAT f = (u / pf >= nFSC) ? 0 : FSC[u / pf];
+                    RFLOAT lo = (RFLOAT)1e-3, hi = (RFLOAT)(1 - 1e-3);
+                    RFLOAT mn = hi < f ? hi : f;       /* TSGSL_MIN_RFLOAT(FSC_BASE_H, FSC) */
+                    f = lo > mn ? lo : mn;             /* TSGSL_MAX_RFLOAT(FSC_BASE_L, .) */
+                    if (joinHalf) f = (RFLOAT)sqrt((double)(2 * f / (1 + f)));
+                    size_t idx = iFTHalf3_(i, j, k, P);
+                    T[idx] = T[idx] / f;
+                }
+            }
+}
+
+/* W = 1 inside |k| < maxRadius*pf else 0 (:1299-1304); T = max(T, 1e-25) (:1322-1324) */
+void orc_init_W_floor_T(RFLOAT* W, RFLOAT* T, int P, int pf, int maxRadius)
+{
+    size_t n = (size_t)P * P * (P / 2 + 1);
+    for (long k = -P / 2; k < P / 2; k++)
+        for (long j = -P / 2; j < P / 2; j++)
+            for (long i = 0; i <= P / 2; i++) {
+                double q = (double)i * i + (double)j * j + (double)k * k;
+                W[iFTHalf3_(i, j, k, P)] = (q < pow2f_((RFLOAT)(maxRadius * pf))) ? 1.0f : 0.0f;
+            }
+    for (size_t i = 0; i < n; i++) T[i] = T[i] > (RFLOAT)1e-25 ? T[i] : (RFLOAT)1e-25;
+}
+
+/* C = T * REAL(W) (:1389-1391); C is complex with imaginary part T.im*W = 0 */
+void orc_calc_C(RFLOAT* C, const RFLOAT* T, const RFLOAT* W, int P)
+{
+    size_t n = (size_t)P * P * (P / 2 + 1);
+    for (size_t i = 0; i < n; i++) { C[2 * i] = T[i] * W[i]; C[2 * i + 1] = 0.0f * W[i]; }
+}
+
+/* convoluteC real-space stage (:2635-2652): C_RL(i,j,k) *= kernelRL(QUAD_3/pow2(N*pf)) / nf.
+ * crl is the real P^3 volume [k][j][i] (wrapped indices, Volume::iRL include/Image/Volume.h:520-528).
+ * NP = _N * _pf. */
+void orc_convolute_rl(RFLOAT* crl, int P, int NP, const RFLOAT* tab, int ntab, RFLOAT nf)
+{
+#pragma omp parallel for
+    for (long k = -P / 2; k < P / 2; k++)
+        for (long j = -P / 2; j < P / 2; j++)
+            for (long i = -P / 2; i < P / 2; i++) {
+                size_t idx = (size_t)((k >= 0 ? k : k + P) * (long)P * P + (j >= 0 ? j : j + P) * (long)P +
+                                      (i >= 0 ? i : i + P));
+                double q = (double)i * i + (double)j * j + (double)k * k;
+                RFLOAT x = (RFLOAT)(q / pow2f_((RFLOAT)NP));
+                crl[idx] = crl[idx] * tab_lookup_(tab, ntab, x) / nf;
+            }
+}
+
+/* ts_hypot, include/Complex.h (ABS) */
+static inline RFLOAT ts_hypot_(RFLOAT x, RFLOAT y)
+{
+    RFLOAT xabs = fabsf(x), yabs = fabsf(y), min, max;
+    if (xabs < yabs) { min = xabs; max = yabs; } else { min = yabs; max = xabs; }
+    if (min == 0) return max;
+    RFLOAT u = min / max;
+    return max * sqrtf(1 + u * u);
+}
+
+/* W /= max(ABS(C), 1e-6) inside the sphere (:1487-1496), then checkC (RECONSTRUCTOR_CHECK_C_MAX,
+ * :2563-2592): max over the sphere of | ABS(C) - 1 |.  Returns diffC. */
+RFLOAT orc_update_W_checkC(RFLOAT* W, const RFLOAT* C, int P, int pf, int maxRadius)
+{
+    RFLOAT diff = 0;
+    for (long k = -P / 2; k < P / 2; k++)
+        for (long j = -P / 2; j < P / 2; j++)
+            for (long i = 0; i <= P / 2; i++) {
+                double q = (double)i * i + (double)j * j + (double)k * k;
+                if (q < pow2f_((RFLOAT)(maxRadius * pf))) {
+                    size_t idx = iFTHalf3_(i, j, k, P);
+                    RFLOAT a = ts_hypot_(C[2 * idx], C[2 * idx + 1]);
+                    RFLOAT m = a > (RFLOAT)1e-6 ? a : (RFLOAT)1e-6;
+                    W[idx] = W[idx] / m;
+                    RFLOAT d = (RFLOAT)fabs((double)(a - 1));
+                    if (d > diff) diff = d;
+                }
+            }
+    return diff;
+}
+
+/* no-grid-correction branch: W = 1 / max(ABS(T), 1e-6) inside the sphere (:1566-1578) */
+void orc_W_nogridcorr(RFLOAT* W, const RFLOAT* T, int P, int pf, int maxRadius)
+{
+    for (long k = -P / 2; k < P / 2; k++)
+        for (long j = -P / 2; j < P / 2; j++)
+            for (long i = 0; i <= P / 2; i++) {
+                double q = (double)i * i + (double)j * j + (double)k * k;
+                if (q < pow2f_((RFLOAT)(maxRadius * pf))) {
+                    size_t idx = iFTHalf3_(i, j, k, P);
+                    RFLOAT a = ts_hypot_(T[idx], 0.0f);
+                    W[idx] = (RFLOAT)(1.0 / (a > (RFLOAT)1e-6 ? a : (RFLOAT)1e-6));
+                }
+            }
+}
+
+/* padDst = F * W inside the sphere, zero elsewhere (:1678-1701). padDst has the same PAD size
+ * here (the reference allocates (_N*_pf)^3; equal to PAD_SIZE when _size == _N). */
+void orc_FW(RFLOAT* padDst, const RFLOAT* F, const RFLOAT* W, int P, int pf, int maxRadius)
+{
+    size_t n = (size_t)P * P * (P / 2 + 1);
+    memset(padDst, 0, 2 * n * sizeof(RFLOAT));
+    for (long k = -P / 2; k < P / 2; k++)
+        for (long j = -P / 2; j < P / 2; j++)
+            for (long i = 0; i <= P / 2; i++) {
+                double q = (double)i * i + (double)j * j + (double)k * k;
+                if (q < pow2f_((RFLOAT)(maxRadius * pf))) {
+                    size_t idx = iFTHalf3_(i, j, k, P);
+                    /* Complex * Complex with W = (w, 0) */
+                    RFLOAT a0 = F[2 * idx], a1 = F[2 * idx + 1], b0 = W[idx], b1 = 0.0f;
+                    padDst[2 * idx] = a0 * b0 - a1 * b1;
+                    padDst[2 * idx + 1] = a0 * b1 + a1 * b0;
+                }
+            }
+}
+
+/* VOL_EXTRACT_RL (include/Image/ImageFunctions.h:51-64) followed by the TIK correction
+ * (RECONSTRUCTOR_CORRECT_CONVOLUTION_KERNEL, :1781-1802): dst(i,j,k) = pad(i,j,k) /
+ * TIK_RL(NORM_3(i,j,k) / (pf * N)).  pad: real P^3, dst: real N^3, both wrapped-index layout. */
+void orc_extract_tik(RFLOAT* dst, const RFLOAT* pad, int P, int N, int pf, int corr)
+{
+    for (long k = -N / 2; k < N / 2; k++)
+        for (long j = -N / 2; j < N / 2; j++)
+            for (long i = -N / 2; i < N / 2; i++) {
+                size_t ip = (size_t)((k >= 0 ? k : k + P) * (long)P * P + (j >= 0 ? j : j + P) * (long)P +
+                                     (i >= 0 ? i : i + P));
+                size_t id = (size_t)((k >= 0 ? k : k + N) * (long)N * N + (j >= 0 ? j : j + N) * (long)N +
+                                     (i >= 0 ? i : i + N));
+                RFLOAT v = pad[ip];
+                if (corr) v = v / orc_TIK_RL((RFLOAT)(gsl_hypot3_((double)i, (double)j, (double)k) / (pf * N)));
+                dst[id] = v;
+            }
+}
+
+/* a5: Projector::setProjectee real-space stages: VOL_PAD_RL (include/Image/ImageFunctions.h:
+ * 176-192) + gridCorrection LINEAR branch (src/Projector.cpp:573-583): pad(i,j,k) = src(i,j,k) /
+ * TIK_RL(NORM_3(i,j,k) / (pf * P)) for the N^3 core, zero elsewhere.  NB the divisor uses the
+ * PADDED size times pf.  Every padded voxel is divided (zeros stay zero). */
+void orc_pad_gridcorr(RFLOAT* pad, const RFLOAT* src, int N, int pf)
+{
+    int P = N * pf;
+    memset(pad, 0, (size_t)P * P * P * sizeof(RFLOAT));
+    for (long k = -N / 2; k < N / 2; k++)
+        for (long j = -N / 2; j < N / 2; j++)
+            for (long i = -N / 2; i < N / 2; i++) {
+                size_t ip = (size_t)((k >= 0 ? k : k + P) * (long)P * P + (j >= 0 ? j : j + P) * (long)P +
+                                     (i >= 0 ? i : i + P));
+                size_t is = (size_t)((k >= 0 ? k : k + N) * (long)N * N + (j >= 0 ? j : j + N) * (long)N +
+                                     (i >= 0 ? i : i + N));
+                pad[ip] = src[is] / orc_TIK_RL((RFLOAT)(gsl_hypot3_((double)i, (double)j, (double)k) / (pf * P)));
+            }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a16: FSC(A, B) -- src/Functions/Spectrum.cpp:302-337 (Eigen vec = RFLOAT accumulators;       */
+/* sequential order here, the reference's omp-atomic order is arbitrary)                        */
+/* ------------------------------------------------------------------------------------------ */
+void orc_fsc(RFLOAT* dst, int nShell, const RFLOAT* A, const RFLOAT* B, int P)
+{
+    RFLOAT* vS = (RFLOAT*)calloc(nShell, sizeof(RFLOAT));
+    RFLOAT* vA = (RFLOAT*)calloc(nShell, sizeof(RFLOAT));
+    RFLOAT* vB = (RFLOAT*)calloc(nShell, sizeof(RFLOAT));
+    for (long k = -P / 2; k < P / 2; k++)
+        for (long j = -P / 2; j < P / 2; j++)
+            for (long i = 0; i <= P / 2; i++) {
+                int u = AROUND_(gsl_hypot3_((double)i, (double)j, (double)k));
+                if (u < nShell) {
+                    size_t idx = iFTHalf3_(i, j, k, P);
+                    RFLOAT a0 = A[2 * idx], a1 = A[2 * idx + 1], b0 = B[2 * idx], b1 = -B[2 * idx + 1];
+                    vS[u] += a0 * b0 - a1 * b1; /* REAL(A * CONJUGATE(B)) */
+                    vA[u] += A[2 * idx] * A[2 * idx] + A[2 * idx + 1] * A[2 * idx + 1];
+                    vB[u] += B[2 * idx] * B[2 * idx] + B[2 * idx + 1] * B[2 * idx + 1];
+                }
+            }
+    for (int i = 0; i < nShell; i++) {
+        RFLOAT AB = (RFLOAT)sqrt((double)(vA[i] * vB[i]));
+        dst[i] = (AB == 0) ? 0 : vS[i] / AB;
+    }
+    free(vS); free(vA); free(vB);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* CPU-baseline driver (bench.py cpu_baseline leg): the fixed-work iteration of SURVEY 8(d) for  */
+/* a block of particles, OpenMP over images exactly as HOT LOOP B / HOT LOOP C                   */
+/* (src/Optimiser.cpp:1162, :7038).  Returns nothing; the caller times it.                       */
+/* ------------------------------------------------------------------------------------------ */
+void orc_baseline_block(const RFLOAT* vol, int P, int pf, int N, const int* iCol, const int* iRow, const int* iColPad,
+                        const int* iRowPad, int nPxl, int nImg, const RFLOAT* dat, const RFLOAT* ctf,
+                        const RFLOAT* sigRcp, const double* rot /*[nImg][nPhase][nR][9]*/, const double* tran
+                        /*[nImg][nPhase][nT][2]*/, int nPhase, int nR, int nT, const double* recoRot /*[nImg][mReco][9]*/,
+                        const double* recoTran /*[nImg][mReco][2]*/, int mReco, RFLOAT* F, RFLOAT* T, RFLOAT* wRout)
+{
+#pragma omp parallel for schedule(dynamic)
+    for (int l = 0; l < nImg; l++) {
+        double* pR = (double*)malloc(nR * sizeof(double));
+        double* pT = (double*)malloc(nT * sizeof(double));
+        double pD = 1.0;
+        for (int i = 0; i < nR; i++) pR[i] = 1.0;
+        for (int i = 0; i < nT; i++) pT[i] = 1.0;
+        RFLOAT wC, wD, base;
+        RFLOAT* wR = (RFLOAT*)malloc(nR * sizeof(RFLOAT));
+        RFLOAT* wT = (RFLOAT*)malloc(nT * sizeof(RFLOAT));
+        for (int ph = 0; ph < nPhase; ph++) {
+            orc_expect_local(vol, P, pf, N, iCol, iRow, nPxl, dat + (size_t)l * nPxl * 2, ctf + (size_t)l * nPxl, 0,
+                             sigRcp + (size_t)l * nPxl, rot + ((size_t)l * nPhase + ph) * nR * 9, nR,
+                             tran + ((size_t)l * nPhase + ph) * nT * 2, nT, 1, 1.0, pR, pT, &pD, &wC, wR, wT, &wD,
+                             &base, NULL);
+        }
+        if (wRout) memcpy(wRout + (size_t)l * nR, wR, nR * sizeof(RFLOAT));
+        RFLOAT* transImg = (RFLOAT*)malloc((size_t)nPxl * 2 * sizeof(RFLOAT));
+        RFLOAT w = 1.0f / mReco; /* w = 1; w /= mReco (src/Optimiser.cpp:7051-7056) */
+        for (int m = 0; m < mReco; m++) {
+            const double* tr = recoTran + ((size_t)l * mReco + m) * 2;
+            orc_translate_src(transImg, dat + (size_t)l * nPxl * 2, (RFLOAT)(-tr[0]), (RFLOAT)(-tr[1]), N, N, iCol, iRow,
+                              nPxl);
+            /* insertP with atomic adds (the reference's `omp atomic`) */
+            const double* R = recoRot + ((size_t)l * mReco + m) * 9;
+            for (int i = 0; i < nPxl; i++) {
+                int ic = iColPad[i], ir = iRowPad[i];
+                double ox = R[0] * ic + R[3] * ir, oy = R[1] * ic + R[4] * ir, oz = R[2] * ic + R[5] * ir;
+                RFLOAT c = ctf[(size_t)l * nPxl + i];
+                RFLOAT vre = transImg[2 * i] * c * 1.0f * w, vim = transImg[2 * i + 1] * c * 1.0f * w;
+                RFLOAT tv = pow2f_(c) * 1.0f * w;
+                RFLOAT x = (RFLOAT)ox, y = (RFLOAT)oy, z = (RFLOAT)oz;
+                if (!(x >= 0)) { x = -x; y = -y; z = -z; vim = -vim; }
+                RFLOAT wt[2][2][2];
+                long x0[3];
+                tri_weights_(wt, x0, x, y, z);
+                for (int kk = 0; kk < 2; kk++)
+                    for (int jj = 0; jj < 2; jj++)
+                        for (int ii = 0; ii < 2; ii++) {
+                            size_t idx = iFTHalf3_(x0[0] + ii, x0[1] + jj, x0[2] + kk, P);
+                            RFLOAT a = vre * wt[kk][jj][ii], b = vim * wt[kk][jj][ii], t = tv * wt[kk][jj][ii];
+#pragma omp atomic
+                            F[2 * idx] += a;
+#pragma omp atomic
+                            F[2 * idx + 1] += b;
+#pragma omp atomic
+                            T[idx] += t;
+                        }
+            }
+        }
+        free(transImg); free(pR); free(pT); free(wR); free(wT);
+    }
+}

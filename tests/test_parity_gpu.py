@@ -1,0 +1,458 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars:
+  * integer / index work and the trilinear gather (project, symmetrise, normalise): bit-exact;
+  * transcendental rows (CTF, ramps): |delta| <= 5e-7 (device sincosf / cosf vs glibc, <= 2 ulp);
+  * sums whose order the reference itself does not fix (likelihood, atomically inserted F/T, FSC, FFT pipelines):
+    tolerance stated at each assert.  The only tolerance the reference states for this path is |delta| < 1e-5 between its
+    own scalar and SIMD likelihoods (src/Optimiser.cpp:25-79).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.fft as sfft
+
+from _util import edge_rotations, make_case, make_images, quat_to_mat
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.int32 if a.dtype.itemsize in (4, 8) and a.dtype.kind != "c" else np.int32)
+
+
+def assert_bit_equal(a, b, what):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, what
+    same = (a.view(np.uint8) == b.view(np.uint8))
+    if not same.all():
+        # +0 / -0 are the same number; anything else is a failure
+        assert np.array_equal(a, b), "%s: %d differing elements, max |d| %g" % (
+            what, int((a != b).sum()), float(np.abs(a.astype(np.complex128) - b.astype(np.complex128)).max()))
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [16, 32, 64])
+def test_project_bit_exact(oracle, dev, N):
+    from thunder_amd import ops
+    O = oracle
+    rng = np.random.default_rng(100 + N)
+    ref, vol, pl = make_case(O, N)
+    P = 2 * N
+    # a dense random volume exercises every voxel, not only the smooth blob spectrum
+    vol = (vol + (rng.normal(size=vol.shape) + 1j * rng.normal(size=vol.shape)).astype(np.complex64)).astype(np.complex64)
+    mats = edge_rotations(rng, n_random=10)
+    want = np.stack([O.project(vol, P, 2, m, pl["iCol"], pl["iRow"]) for m in mats])
+    got = ops.project(T(vol, dev), T(mats, dev), T(pl["iCol"], dev), T(pl["iRow"], dev), 2).cpu().numpy()
+    assert_bit_equal(got, want, "project N=%d" % N)
+
+
+def test_project_empty_and_ragged(oracle, dev):
+    from thunder_amd import ops
+    O = oracle
+    ref, vol, pl = make_case(O, 16, rU=6, rL=2)
+    assert pl["nPxl"] > 0 and pl["nPxl"] % 64 != 0
+    mats = edge_rotations(np.random.default_rng(1), 2)[:3]
+    got = ops.project(T(vol, dev), T(mats, dev), T(pl["iCol"], dev), T(pl["iRow"], dev), 2).cpu().numpy()
+    want = np.stack([O.project(vol, 32, 2, m, pl["iCol"], pl["iRow"]) for m in mats])
+    assert_bit_equal(got, want, "ragged pixel list")
+    # zero rotations: a no-op that must not fail
+    out = ops.project(T(vol, dev), torch.empty((0, 9), dtype=torch.float64, device=dev), T(pl["iCol"], dev),
+                      T(pl["iRow"], dev), 2)
+    assert out.shape[0] == 0
+
+
+def test_rotmat_translate_ctf(oracle, dev):
+    from thunder_amd import ops, synth
+    O = oracle
+    rng = np.random.default_rng(3)
+    N = 64
+    pl = O.pixel_list(N, N // 2 - 2, 0)
+    q = synth.random_quats(50, rng)
+    got = ops.rotmat(T(q, dev)).cpu().numpy()
+    want = np.stack([O.rotate3D(x) for x in q])
+    np.testing.assert_allclose(got, want, rtol=0, atol=4e-16)
+    shifts = np.concatenate([rng.normal(0, 3, size=(6, 2)), [[0, 0], [N / 2, -N / 2]]])
+    got = ops.translate(T(shifts, dev), T(pl["iCol"], dev), T(pl["iRow"], dev), N).cpu().numpy()
+    want = np.stack([O.translate(np.float32(s[0]), np.float32(s[1]), N, pl["iCol"], pl["iRow"]) for s in shifts])
+    assert np.abs(got - want).max() <= 5e-7
+    attr = synth.ctf_params(5, rng)
+    attr[4, 6] = 0.3  # phase plate
+    got = ops.ctf(T(attr, dev), 1.32, T(pl["iCol"], dev), T(pl["iRow"], dev), N).cpu().numpy()
+    want = np.stack([O.ctf(1.32, *a, N, pl["iCol"], pl["iRow"]) for a in attr])
+    # chi reaches ~1e3 rad at Nyquist: one float ulp of chi is 6e-5, so the bar is set on the phase, not the value
+    assert np.abs(got - want).max() <= 2e-4
+    assert np.abs(got - want).mean() <= 1e-5
+
+
+def test_gather_pixels(oracle, dev):
+    from thunder_amd import ops
+    N = 32
+    pl = oracle.pixel_list(N, 12, 1)
+    rng = np.random.default_rng(0)
+    img = (rng.normal(size=(3, N, N // 2 + 1)) + 1j * rng.normal(size=(3, N, N // 2 + 1))).astype(np.complex64)
+    got = ops.gather_pixels(T(img, dev), T(pl["iPxl"], dev), N).cpu().numpy()
+    want = img.reshape(3, -1)[:, pl["iPxl"]]
+    assert_bit_equal(got, want, "allocPreCal gather")
+
+
+def test_logDataVSPrior(oracle, dev):
+    from thunder_amd import ops
+    O = oracle
+    rng = np.random.default_rng(11)
+    N = 64
+    ref, vol, pl = make_case(O, N)
+    im = make_images(O, vol, pl, N, 2, rng)
+    pri = np.stack([O.project(vol, 2 * N, 2, im["rot"][k % 2], pl["iCol"], pl["iRow"]) for k in range(5)])
+    got = ops.logDataVSPrior(T(im["dat"][0], dev), T(pri, dev), T(im["ctf"][0], dev), T(im["sigRcp"][0], dev)).cpu().numpy()
+    for k in range(5):
+        exact = O.logDataVSPrior_f64(im["dat"][0], pri[k], im["ctf"][0], im["sigRcp"][0])
+        ref32 = O.logDataVSPrior(im["dat"][0], pri[k], im["ctf"][0], im["sigRcp"][0])
+        # the device tree sum must be at least as close to the exact value as the reference's own
+        # sequential float sum, up to 2 ulp of the result
+        tol = abs(ref32 - exact) + 2 * np.spacing(np.float32(abs(exact)))
+        assert abs(got[k] - exact) <= max(tol, 1e-6 * abs(exact))
+
+
+@pytest.mark.parametrize("N,nR,nT", [(32, 20, 9), (64, 125, 9), (32, 70, 3), (32, 5, 12)])
+def test_expect_local(oracle, dev, N, nR, nT):
+    from thunder_amd import ops, synth
+    O = oracle
+    rng = np.random.default_rng(200 + N + nR)
+    ref, vol, pl = make_case(O, N, rL=1)
+    P = 2 * N
+    nImg = 3
+    im = make_images(O, vol, pl, N, nImg, rng, snr_sigma=2.0)
+    quat = synth.perturb_quats(im["quat"], nR, 0.04, rng)            # [nImg][nR][4]
+    rot = np.stack([[O.rotate3D(q) for q in qs] for qs in quat])      # [nImg][nR][9]
+    tran = im["shift"][:, None, :] + rng.normal(0, 0.5, size=(nImg, nT, 2))
+    pR = rng.uniform(0.5, 1.5, size=(nImg, nR))
+    pT = rng.uniform(0.5, 1.5, size=(nImg, nT))
+    pC = rng.uniform(0.5, 1.5, size=nImg)
+    res = ops.expect_local(T(vol, dev), P, 2, N, T(pl["iCol"], dev), T(pl["iRow"], dev), T(im["dat"], dev),
+                           T(im["ctf"], dev), T(im["sigRcp"], dev), T(rot, dev), T(tran, dev), nD=1, pC=T(pC, dev),
+                           pR=T(pR, dev), pT=T(pT, dev), want_logW=True)
+    logW = res.logW.cpu().numpy()  # [nImg][1][nT][nR]
+    for l in range(nImg):
+        want = O.expect_local(vol, P, 2, N, pl["iCol"], pl["iRow"], im["dat"][l], im["ctf"][l], im["sigRcp"][l],
+                              rot[l], tran[l], nD=1, pC=pC[l], pR=pR[l], pT=pT[l])
+        wl = want["logW"][:, :, 0].T  # [nT][nR]
+        scale = np.abs(wl).max()
+        # log-likelihoods: float sums of nPxl terms; 1e-5 relative covers both summation orders
+        np.testing.assert_allclose(logW[l, 0], wl, rtol=0, atol=1e-5 * scale)
+        assert abs(res.baseLine[l].item() - want["baseLine"]) <= 1e-5 * scale
+        # weights are exp(L - max): an absolute error e in L is a relative error e in the weight
+        tolw = max(2e-5 * scale, 1e-4)
+        for name in ("wR", "wT", "wC"):
+            g = getattr(res, name)[l].cpu().numpy().reshape(-1)
+            w = want[name].reshape(-1)
+            np.testing.assert_allclose(g, w, rtol=3 * tolw, atol=1e-30, err_msg=name)
+        np.testing.assert_allclose(res.wD[l].cpu().numpy(), want["wD"], rtol=3 * tolw)
+
+
+def test_expect_local_dsearch_and_volidx(oracle, dev):
+    """nD > 1 (CTF search rows) and two reference volumes selected per image"""
+    from thunder_amd import ops, synth
+    O = oracle
+    rng = np.random.default_rng(5)
+    N, nR, nT, nD, nImg = 32, 10, 4, 3, 2
+    ref, vol, pl = make_case(O, N)
+    _, vol2, _ = make_case(O, N, seed=99)
+    P = 2 * N
+    im = make_images(O, vol, pl, N, nImg, rng)
+    rot = np.stack([[O.rotate3D(q) for q in qs] for qs in synth.perturb_quats(im["quat"], nR, 0.05, rng)])
+    tran = im["shift"][:, None, :] + rng.normal(0, 0.5, size=(nImg, nT, 2))
+    dfac = 1.0 + rng.normal(0, 0.02, size=(nImg, nD))
+    ctfD = np.stack([[O.ctf(1.32, a[0], np.float32(a[1] * d), np.float32(a[2] * d), *a[3:], N, pl["iCol"], pl["iRow"])
+                      for d in dfac[l]] for l, a in enumerate(im["attr"])])  # [nImg][nD][nPxl]
+    pD = rng.uniform(0.5, 1.5, size=(nImg, nD))
+    vols = np.stack([vol, vol2])
+    volIdx = np.array([1, 0], np.int32)
+    res = ops.expect_local(T(vols, dev), P, 2, N, T(pl["iCol"], dev), T(pl["iRow"], dev), T(im["dat"], dev),
+                           T(ctfD, dev), T(im["sigRcp"], dev), T(rot, dev), T(tran, dev), nD=nD, volIdx=T(volIdx, dev),
+                           pD=T(pD, dev), want_logW=True)
+    for l in range(nImg):
+        want = O.expect_local(vols[volIdx[l]], P, 2, N, pl["iCol"], pl["iRow"], im["dat"][l], ctfD[l], im["sigRcp"][l],
+                              rot[l], tran[l], nD=nD, pD=pD[l], cSearch=True)
+        wl = np.transpose(want["logW"], (2, 1, 0))  # [nD][nT][nR]
+        scale = np.abs(wl).max()
+        np.testing.assert_allclose(res.logW[l].cpu().numpy(), wl, rtol=0, atol=1e-5 * scale)
+        for name in ("wR", "wT", "wD", "wC"):
+            np.testing.assert_allclose(getattr(res, name)[l].cpu().numpy().reshape(-1), want[name].reshape(-1),
+                                       rtol=1e-3, err_msg=name)
+
+
+def test_expect_global(oracle, dev):
+    from thunder_amd import ops, synth
+    O = oracle
+    rng = np.random.default_rng(17)
+    N, nR, nT, nImg, nK = 32, 70, 11, 5, 2
+    ref, vol, pl = make_case(O, N, rU=10)
+    _, vol2, _ = make_case(O, N, seed=31, rU=10)
+    P = 2 * N
+    im = make_images(O, vol, pl, N, nImg, rng)
+    mats = np.stack([O.rotate3D(q) for q in synth.random_quats(nR, rng)])
+    mats[:nImg] = im["rot"]
+    shifts = rng.normal(0, 2, size=(nT, 2))
+    pR = rng.uniform(0.5, 1.5, size=(nImg, nR))
+    pT = rng.uniform(0.5, 1.5, size=(nImg, nT))
+    traP_h = np.stack([O.translate(np.float32(s[0]), np.float32(s[1]), N, pl["iCol"], pl["iRow"]) for s in shifts])
+    wC = np.zeros((nImg, nK), np.float32)
+    wR = np.zeros((nK, nImg, nR), np.float32)
+    wT = np.zeros((nK, nImg, nT), np.float32)
+    base = np.full(nImg, np.nan, np.float32)
+    d_wC, d_wR, d_wT, d_base = T(wC, dev), T(wR, dev), T(wT, dev), T(base, dev)
+    dat_pm = np.ascontiguousarray(im["dat"].T)
+    ctf_pm = np.ascontiguousarray(im["ctf"].T)
+    sig_pm = np.ascontiguousarray(im["sigRcp"].T)
+    iCol, iRow = T(pl["iCol"], dev), T(pl["iRow"], dev)
+    traP = ops.translate(T(shifts, dev), iCol, iRow, N)
+    for k, v in enumerate((vol, vol2)):
+        rotP_h = np.stack([O.project(v, P, 2, m, pl["iCol"], pl["iRow"]) for m in mats])
+        O.expect_global(rotP_h, traP_h, dat_pm, ctf_pm, sig_pm, nK, k, pR, pT, wC, wR, wT, base)
+        rotP = ops.project(T(v, dev), T(mats, dev), iCol, iRow, 2)
+        ops.expect_global(rotP, traP, T(im["dat"], dev), T(im["ctf"], dev), T(im["sigRcp"], dev), T(pR, dev), T(pT, dev),
+                          d_wC, d_wR, d_wT, d_base, k, nK)
+    scale = np.abs(base).max()
+    assert np.abs(d_base.cpu().numpy() - base).max() <= 1e-5 * scale
+    tol = max(6e-5 * scale, 3e-4)
+    np.testing.assert_allclose(d_wC.cpu().numpy(), wC, rtol=tol)
+    np.testing.assert_allclose(d_wR.cpu().numpy(), wR, rtol=tol, atol=1e-30)
+    np.testing.assert_allclose(d_wT.cpu().numpy(), wT, rtol=tol, atol=1e-30)
+
+
+# ---------------------------------------------------------------------------------------------
+def _insert_case(O, N, nImg, mReco, rng, nK=1):
+    from thunder_amd import synth
+    ref, vol, pl = make_case(O, N)
+    im = make_images(O, vol, pl, N, nImg, rng, snr_sigma=0.2)
+    quat = synth.perturb_quats(im["quat"], mReco, 0.03, rng)
+    tran = im["shift"][:, None, :] + rng.normal(0, 0.3, size=(nImg, mReco, 2))
+    offS = rng.normal(0, 0.2, size=(nImg, 2))
+    w = (rng.uniform(0.5, 1.0, size=nImg) / mReco).astype(np.float32)
+    cls = rng.integers(0, nK, size=(nImg, mReco)).astype(np.int32)
+    return ref, vol, pl, im, quat, tran, offS, w, cls
+
+
+def _oracle_insert(O, P, N, pl, im, quat, tran, offS, w, cls, nK):
+    F = np.zeros((nK, P, P, P // 2 + 1), np.complex64)
+    Tt = np.zeros((nK, P, P, P // 2 + 1), np.float32)
+    Osum = np.zeros(3)
+    for l in range(len(w)):
+        for m in range(quat.shape[1]):
+            R = O.rotate3D(quat[l, m])
+            t = tran[l, m] - offS[l]
+            src = O.translate(np.float32(-t[0]), np.float32(-t[1]), N, pl["iCol"], pl["iRow"], src=im["dat"][l])
+            O.insertP(F[cls[l, m]], Tt[cls[l, m]], P, src, im["ctf"][l], R, w[l], pl["iColPad"], pl["iRowPad"])
+            Rm = R.reshape(3, 3).T
+            Osum += -(Rm @ np.array([t[0], t[1], 0.0]))
+    return F, Tt, Osum
+
+
+@pytest.mark.parametrize("N,nK", [(32, 1), (32, 3), (64, 1)])
+def test_insert(oracle, dev, N, nK):
+    from thunder_amd import ops
+    O = oracle
+    rng = np.random.default_rng(300 + N + nK)
+    nImg, mReco = 6, 8
+    P = 2 * N
+    ref, vol, pl, im, quat, tran, offS, w, cls = _insert_case(O, N, nImg, mReco, rng, nK)
+    Fw, Tw, Ow = _oracle_insert(O, P, N, pl, im, quat, tran, offS, w, cls, nK)
+    F = torch.zeros((nK, P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
+    Tt = torch.zeros((nK, P, P, P // 2 + 1), dtype=torch.float32, device=dev)
+    Od = torch.zeros(3, dtype=torch.float64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    rot = ops.rotmat(T(quat.reshape(-1, 4), dev))
+    ops.insert(F, Tt, P, T(im["dat"], dev), T(im["ctf"], dev), T(w, dev), rot, T(tran, dev), T(pl["iCol"], dev),
+               T(pl["iRow"], dev), 2, N, O=Od, counter=cnt, offS=T(offS, dev), cls=T(cls, dev), nK=nK)
+    Fg, Tg = F.cpu().numpy(), Tt.cpu().numpy()
+    # atomic summation order differs run to run; each voxel sums <= nImg*mReco*few terms of like magnitude.
+    # bar: 1e-5 of the largest accumulated magnitude -- the ramp sincosf adds ~1e-7 relative.
+    assert np.abs(Fg - Fw).max() <= 1e-5 * np.abs(Fw).max()
+    assert np.abs(Tg - Tw).max() <= 1e-5 * np.abs(Tw).max()
+    # untouched voxels stay exactly zero
+    assert np.array_equal(Fw == 0, Fg == 0) and np.array_equal(Tw == 0, Tg == 0)
+    assert cnt.item() == nImg * mReco
+    np.testing.assert_allclose(Od.cpu().numpy(), Ow, rtol=1e-12, atol=1e-12)
+
+
+def test_insert_linearity_and_csearch(oracle, dev):
+    """size-independent properties: insert(a)+insert(b) == insert(a and b); cSearch with dfac == 1 equals the
+    precomputed-CTF path to rounding of the on-device CTF"""
+    from thunder_amd import ops
+    O = oracle
+    rng = np.random.default_rng(9)
+    N, nImg, mReco = 32, 4, 5
+    P = 2 * N
+    ref, vol, pl, im, quat, tran, offS, w, cls = _insert_case(O, N, nImg, mReco, rng)
+    iCol, iRow = T(pl["iCol"], dev), T(pl["iRow"], dev)
+    rot = ops.rotmat(T(quat.reshape(-1, 4), dev)).reshape(nImg, mReco, 9)
+    dat, ctf, wd, trd = T(im["dat"], dev), T(im["ctf"], dev), T(w, dev), T(tran, dev)
+
+    def run(sel, **kw):
+        F = torch.zeros((P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
+        Tt = torch.zeros((P, P, P // 2 + 1), dtype=torch.float32, device=dev)
+        ops.insert(F, Tt, P, dat[sel].contiguous(), ctf[sel].contiguous(), wd[sel].contiguous(), rot[sel].contiguous(),
+                   trd[sel].contiguous(), iCol, iRow, 2, N, **kw)
+        return F, Tt
+    Fa, Ta = run(slice(0, 2))
+    Fb, Tb = run(slice(2, 4))
+    Fab, Tab = run(slice(0, 4))
+    assert (Fa + Fb - Fab).abs().max().item() <= 1e-5 * Fab.abs().max().item()
+    assert (Ta + Tb - Tab).abs().max().item() <= 1e-5 * Tab.abs().max().item()
+    attr = T(im["attr"], dev)
+    dfac = torch.ones((nImg, mReco), dtype=torch.float64, device=dev)
+    Fc, Tc = run(slice(0, 4), attr=attr, dfac=dfac, cSearch=True, pixelSize=1.32)
+    assert (Fc - Fab).abs().max().item() <= 1e-3 * Fab.abs().max().item()
+
+
+def test_prepareTF_bit_exact(oracle, dev):
+    from thunder_amd import ops, synth
+    O = oracle
+    rng = np.random.default_rng(21)
+    N, P = 32, 64
+    maxRadius = N // 2 - 2
+    ref, vol, pl, im, quat, tran, offS, w, cls = _insert_case(O, N, 10, 6, rng)
+    F, Tt, _ = _oracle_insert(O, P, N, pl, im, quat, tran, offS, w, cls, 1)
+    F, Tt = F[0].copy(), Tt[0].copy()
+    Fd, Td = T(F, dev), T(Tt, dev)
+    O.normalise_TF(F, Tt, P)
+    ops.normalise_TF(Fd, Td, P)
+    assert_bit_equal(Fd.cpu().numpy(), F, "normalise F")
+    assert_bit_equal(Td.cpu().numpy(), Tt, "normalise T")
+    for nsym in (1, 4, 7):
+        sym = synth.cn_symmetry(nsym)
+        r = maxRadius * 2 + 1
+        Fs = O.symmetrize(F, P, sym, r) if nsym > 1 else F
+        Ts = O.symmetrize(Tt, P, sym, r) if nsym > 1 else Tt
+        assert_bit_equal(ops.symmetrize(Fd, P, sym, r).cpu().numpy(), Fs, "symmetrize F C%d" % nsym)
+        assert_bit_equal(ops.symmetrize(Td, P, sym, r).cpu().numpy(), Ts, "symmetrize T C%d" % nsym)
+
+
+def _fsc_np(O, a, b, N):
+    return O.fsc(sfft.rfftn(a).astype(np.complex64), sfft.rfftn(b).astype(np.complex64), N, N // 2)
+
+
+@pytest.mark.parametrize("MAP,gridCorr,joinHalf", [(False, True, False), (True, True, True), (True, False, False),
+                                                   (False, False, False)])
+def test_reconstruct(oracle, dev, MAP, gridCorr, joinHalf):
+    from thunder_amd import ops
+    O = oracle
+    rng = np.random.default_rng(33)
+    N, P = 32, 64
+    maxRadius = N // 2 - 2
+    ref, vol, pl = make_case(O, N)
+    F = np.zeros((P, P, P // 2 + 1), np.complex64)
+    Tt = np.zeros((P, P, P // 2 + 1), np.float32)
+    ctf1 = np.ones(pl["nPxl"], np.float32)
+    from thunder_amd import synth
+    for q in synth.random_quats(400, rng):
+        R = O.rotate3D(q)
+        O.insertP(F, Tt, P, O.project(vol, P, 2, R, pl["iCol"], pl["iRow"]), ctf1, R, 1.0, pl["iColPad"], pl["iRowPad"])
+    O.normalise_TF(F, Tt, P)
+    fscv = np.clip(np.linspace(1.0, 0.05, N // 2), 0, 1).astype(np.float32)
+    want, it_w, diffs, _ = O.reconstruct(F, Tt, P, N, 2, maxRadius, FSC=fscv, joinHalf=joinHalf, MAP=MAP,
+                                         gridCorr=gridCorr, return_iters=True)
+    plan = ops.RecoPlan(N, N, 2)
+    got = plan.reconstruct(T(F, dev), T(Tt, dev), maxRadius, FSC=fscv, joinHalf=joinHalf, MAP=MAP,
+                           gridCorr=gridCorr).cpu().numpy()
+    if gridCorr:
+        assert plan.last_iters == it_w
+        assert abs(plan.last_diffC - diffs[-1]) <= 1e-3 * max(1.0, diffs[-1])
+    # voxel-wise <= 1e-4 max|map| and FSC >= 0.9999 on every shell
+    assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+    assert _fsc_np(O, got, want, N)[: maxRadius].min() >= 0.9999
+    plan.close()
+
+
+def test_set_projectee_and_roundtrip(oracle, dev):
+    """Projector::setProjectee parity, then the reference-sanctioned self-consistency check
+    (thunder_project -> thunder_reconstruct) entirely on the device at N = 64."""
+    from thunder_amd import ops, synth
+    O = oracle
+    rng = np.random.default_rng(44)
+    N, P = 64, 128
+    maxRadius = N // 2 - 2
+    ref, vol_w, pl = make_case(O, N)
+    plan = ops.RecoPlan(N, N, 2)
+    vol = plan.set_projectee(T(ref, dev))
+    assert (vol.cpu() - torch.from_numpy(vol_w)).abs().max().item() <= 2e-6 * np.abs(vol_w).max()
+    nImg = 1500
+    quat = synth.random_quats(nImg, rng)
+    rot = ops.rotmat(T(quat, dev))
+    iCol, iRow = T(pl["iCol"], dev), T(pl["iRow"], dev)
+    slices = ops.project(vol, rot, iCol, iRow, 2)
+    F = torch.zeros((P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
+    Tt = torch.zeros((P, P, P // 2 + 1), dtype=torch.float32, device=dev)
+    ones = torch.ones((nImg, pl["nPxl"]), dtype=torch.float32, device=dev)
+    w = torch.ones(nImg, dtype=torch.float32, device=dev)
+    ops.insert(F, Tt, P, slices, ones, w, rot.reshape(nImg, 1, 9), torch.zeros((nImg, 1, 2), dtype=torch.float64, device=dev),
+               iCol, iRow, 2, N)
+    ops.normalise_TF(F, Tt, P)
+    rec = plan.reconstruct(F, Tt, maxRadius, MAP=False, gridCorr=True).cpu().numpy()
+    f = _fsc_np(O, rec, ref, N)
+    assert f[:20].min() >= 0.995, f
+    scale = float((rec * ref).sum() / (ref * ref).sum())
+    assert 0.9 < scale < 1.1
+    plan.close()
+
+
+def test_fsc(oracle, dev):
+    from thunder_amd import ops
+    rng = np.random.default_rng(2)
+    N = 32
+    a = rng.normal(size=(N, N, N)).astype(np.float32)
+    b = (a + 0.5 * rng.normal(size=(N, N, N))).astype(np.float32)
+    A, B = sfft.rfftn(a).astype(np.complex64), sfft.rfftn(b).astype(np.complex64)
+    want = oracle.fsc(A, B, N, N // 2)
+    got = ops.fsc(T(A, dev), T(B, dev), N, N // 2).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=2e-6)
+
+
+def test_host_interface_entry_points(oracle, dev):
+    """the Interface.h-shaped host-pointer entry points agree with the device path"""
+    from thunder_amd import capi, ops, synth
+    O = oracle
+    rng = np.random.default_rng(8)
+    N, P = 32, 64
+    ref, vol, pl = make_case(O, N)
+    mats = edge_rotations(rng, 4)
+    out = np.zeros((len(mats), pl["nPxl"]), np.complex64)
+    capi.call("thx_ExpectProject_host", vol.ctypes.data, out.ctypes.data, mats.ctypes.data, pl["iCol"].ctypes.data,
+              pl["iRow"].ctypes.data, len(mats), 2, 1, P, pl["nPxl"])
+    want = np.stack([O.project(vol, P, 2, m, pl["iCol"], pl["iRow"]) for m in mats])
+    assert_bit_equal(out, want, "ExpectProject_host")
+    # InsertFT -> PrepareTF -> reconstructG on host arrays
+    nImg, mReco = 5, 4
+    _, _, _, im, quat, tran, offS, w, cls = _insert_case(O, N, nImg, mReco, rng)
+    Fw, Tw, _ = _oracle_insert(O, P, N, pl, im, quat, tran, offS, w, np.zeros_like(cls), 1)
+    F = np.zeros((P, P, P // 2 + 1), np.complex64)
+    Tc = np.zeros((P, P, P // 2 + 1), np.complex64)
+    O3 = np.zeros(3)
+    cnt = np.zeros(1, np.int32)
+    quat_c, tran_c = np.ascontiguousarray(quat), np.ascontiguousarray(tran)
+    capi.call("thx_InsertFT_host", F.ctypes.data, Tc.ctypes.data, O3.ctypes.data, cnt.ctypes.data, im["dat"].ctypes.data,
+              im["ctf"].ctypes.data, None, offS.ctypes.data, w.ctypes.data, quat_c.ctypes.data, tran_c.ctypes.data, None,
+              None, pl["iCol"].ctypes.data, pl["iRow"].ctypes.data, 1.32, 0, 2, pl["nPxl"], mReco, N, P, 1, nImg)
+    assert np.abs(F - Fw[0]).max() <= 1e-5 * np.abs(Fw).max()
+    assert np.abs(Tc.real - Tw[0]).max() <= 1e-5 * np.abs(Tw).max() and np.all(Tc.imag == 0)
+    assert cnt[0] == nImg * mReco
+    sym = synth.cn_symmetry(2)
+    capi.call("thx_PrepareTF_host", 0, F.ctypes.data, Tc.ctypes.data, P, sym.ctypes.data, len(sym), N // 2 - 2, 2)
+    Fo, To = Fw[0].copy(), Tw[0].copy()
+    O.normalise_TF(Fo, To, P)
+    Fo, To = O.symmetrize(Fo, P, sym, (N // 2 - 2) * 2 + 1), O.symmetrize(To, P, sym, (N // 2 - 2) * 2 + 1)
+    assert np.abs(F - Fo).max() <= 2e-5 * np.abs(Fo).max()
+    dst = np.zeros((N, N, N), np.float32)
+    capi.call("thx_ReconstructG_host", 0, F.ctypes.data, Tc.ctypes.data, N, N, 2, N // 2 - 2, 1.9, 15.0, None, 0, 0, 0, 1,
+              dst.ctypes.data)
+    want = O.reconstruct(Fo, To, P, N, 2, N // 2 - 2, MAP=False, gridCorr=True)
+    assert np.abs(dst - want).max() <= 2e-3 * np.abs(want).max()

@@ -1,0 +1,121 @@
+"""ctypes binding of libthunder_amd.so -- the C ABI declared in include/thunder_amd.h.
+
+There is no CPU fallback: importing this module without the built HIP library raises, and every call
+raises ThxError on a non-zero status (the reference's own style is REPORT_ERROR + abort).
+torch is used only as a device-memory / stream provider (tensor.data_ptr()).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libthunder_amd.so")
+
+
+class ThxError(RuntimeError):
+    pass
+
+
+class CtfAttr(C.Structure):
+    """struct CTFAttr, include/Database.h:302-330 (reference) == thx_ctf_attr."""
+    _fields_ = [("voltage", C.c_float), ("defocusU", C.c_float), ("defocusV", C.c_float),
+                ("defocusTheta", C.c_float), ("Cs", C.c_float), ("amplitudeContrast", C.c_float),
+                ("phaseShift", C.c_float)]
+
+
+_vp = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_d = C.c_double
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/thunder_amd.h one to one
+SIGNATURES = {
+    "thx_last_error": (C.c_char_p, []),
+    "thx_version": (_i, []),
+    "thx_device_count": (_i, [C.POINTER(_i)]),
+    "thx_set_device": (_i, [_i]),
+    "thx_rotmat_dev": (_i, [_vp, _vp, _i, _vp]),
+    "thx_translate_dev": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
+    "thx_ctf_dev": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp]),
+    "thx_gather_pixels_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "thx_project_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "thx_logdatavsprior_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "thx_expect_local_workspace": (_sz, [_i, _i, _i, _i]),
+    "thx_expect_local_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "thx_expect_global_workspace": (_sz, [_i, _i, _i]),
+    "thx_expect_global_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i,
+                                   _vp, _vp]),
+    "thx_insert_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp,
+                            _vp, _i, _i, _i, _i, _i, _vp]),
+    "thx_normalise_tf_dev": (_i, [_vp, _vp, _i, _vp]),
+    "thx_symmetrize_dev": (_i, [_vp, _vp, _i, _i, _vp, _i, _d, _vp]),
+    "thx_reco_create": (_i, [C.POINTER(_vp), _i, _i, _i, _f, _f]),
+    "thx_reco_destroy": (_i, [_vp]),
+    "thx_reco_reconstruct_dev": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, C.POINTER(_i), C.POINTER(_f),
+                                      _vp]),
+    "thx_reco_set_projectee_dev": (_i, [_vp, _vp, _vp, _vp]),
+    "thx_fft3d_fw_dev": (_i, [_vp, _vp, _i, _vp]),
+    "thx_fft3d_bw_dev": (_i, [_vp, _vp, _i, _vp]),
+    "thx_fsc_dev": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
+    "thx_ExpectProject_host": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "thx_ExpectRotran_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "thx_InsertFT_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i,
+                               _i, _i, _i, _i, _i, _i, _i]),
+    "thx_PrepareTF_host": (_i, [_i, _vp, _vp, _i, _vp, _i, _i, _i]),
+    "thx_ReconstructG_host": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _i, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def load(path=None):
+    """dlopen the HIP library (import torch first so its bundled libamdhip64 / hipFFT are the ones bound)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ThxError("libthunder_amd.so is not built (%s missing): run `python -m thunder_amd.build`; "
+                       "there is no CPU fallback for the hot path" % path)
+    try:
+        import torch  # noqa: F401  (loads the ROCm runtime torch ships, so both share one HIP context)
+    except Exception:  # pragma: no cover
+        pass
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI symbol missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise ThxError("thunder_amd: %s (status %d)" % (load().thx_last_error().decode(errors="replace"), rc))
+
+
+def ptr(x):
+    """device/host pointer of a torch tensor, numpy array, int or None"""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):
+        assert x.is_contiguous(), "tensor must be contiguous"
+        return x.data_ptr()
+    if hasattr(x, "ctypes"):
+        assert x.flags.c_contiguous, "array must be contiguous"
+        return x.ctypes.data
+    raise TypeError(type(x))
+
+
+def stream_ptr(stream=None):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return s.cuda_stream
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))

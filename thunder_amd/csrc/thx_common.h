@@ -1,0 +1,233 @@
+// thx_common.h -- shared host/device helpers of libthunder_amd (gfx950 only).
+//
+// The whole library is compiled with -ffp-contract=off: every product and sum below is a separately
+// rounded IEEE operation unless fmaf()/fma() is written out.  That is what makes the trilinear
+// gather/scatter arithmetic bit-identical to the reference's x86 build (-O2 -mavx, no FMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/thunder_amd.h"
+
+namespace thx {
+
+void set_error(const char* fmt, ...);
+
+#define THX_CHECK(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            thx::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return (int)_e;                                                                      \
+        }                                                                                        \
+    } while (0)
+
+#define THX_REQUIRE(cond, msg)                                      \
+    do {                                                            \
+        if (!(cond)) {                                              \
+            thx::set_error("%s (%s:%d)", msg, __FILE__, __LINE__);  \
+            return -1;                                              \
+        }                                                           \
+    } while (0)
+
+#define THX_LAUNCH_CHECK() THX_CHECK(hipGetLastError())
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr double kM2xPi = 6.28318530717959;  // M_2X_PI, include/Macro.h:14
+
+// ---------------------------------------------------------------------------------------------
+// Trilinear cell on the half-Hermitian volume: conjHalf (include/Image/Volume.h:135-147),
+// WG_TRI_INTERP_LINEAR (include/Functions/Interpolation.h:152-200), index wrap of iFTHalf
+// (include/Image/Volume.h:567-575).  The 8 neighbours are visited k-outer, j, i-inner, as
+// getFTHalf(w, x0) / addFTHalf(value, w, x0) do (src/Image/Volume.cpp:491-712); the box fast path and
+// the wrapped slow path of the reference are the same arithmetic.
+// ---------------------------------------------------------------------------------------------
+struct TriCell {
+    long rowOff[2][2];  // element offset of (k, j) row start + i0
+    float w[8];         // w[k*4 + j*2 + i]
+    bool conj;
+};
+
+__device__ __forceinline__ void tri_cell(TriCell& c, float x, float y, float z, int P)
+{
+    c.conj = false;
+    if (!(x >= 0.0f)) {
+        x *= -1.0f;
+        y *= -1.0f;
+        z *= -1.0f;
+        c.conj = true;
+    }
+    const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float xd = x - fx, yd = y - fy, zd = z - fz;
+    const float vx[2] = {1.0f - xd, xd}, vy[2] = {1.0f - yd, yd}, vz[2] = {1.0f - zd, zd};
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) c.w[k * 4 + j * 2 + i] = vx[i] * vy[j] * vz[k];
+    const long nc = P / 2 + 1;
+    const int ja[2] = {y0 >= 0 ? y0 : y0 + P, (y0 + 1) >= 0 ? y0 + 1 : y0 + 1 + P};
+    const int ka[2] = {z0 >= 0 ? z0 : z0 + P, (z0 + 1) >= 0 ? z0 + 1 : z0 + 1 + P};
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) c.rowOff[k][j] = ((long)ka[k] * P + ja[j]) * nc + x0;
+}
+
+// coordinates are valid for the stored half grid when every neighbour index is in range
+__device__ __forceinline__ bool coord_in_grid(float x, float y, float z, int P)
+{
+    const float h = (float)(P / 2);
+    const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+    return (ax < h) && (ay < h - 1.0f) && (az < h - 1.0f);
+}
+
+// Volume::getByInterpolationFT, src/Image/Volume.cpp:314-338 (complex volume)
+__device__ __forceinline__ float2 interp_ft(const float2* __restrict__ vol, int P, float x, float y, float z)
+{
+    TriCell c;
+    tri_cell(c, x, y, z, P);
+    float re = 0.0f, im = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const float2* p = vol + c.rowOff[k][j];
+            const float2 a = p[0], b = p[1];
+            re = re + a.x * c.w[k * 4 + j * 2];
+            im = im + a.y * c.w[k * 4 + j * 2];
+            re = re + b.x * c.w[k * 4 + j * 2 + 1];
+            im = im + b.y * c.w[k * 4 + j * 2 + 1];
+        }
+    return make_float2(re, c.conj ? -im : im);
+}
+
+// same for a real volume (T): conjugation is a no-op
+__device__ __forceinline__ float interp_ft_real(const float* __restrict__ vol, int P, float x, float y, float z)
+{
+    TriCell c;
+    tri_cell(c, x, y, z, P);
+    float re = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const float* p = vol + c.rowOff[k][j];
+            re = re + p[0] * c.w[k * 4 + j * 2];
+            re = re + p[1] * c.w[k * 4 + j * 2 + 1];
+        }
+    return re;
+}
+
+// TSGSL_pow_2/3/4 (src/Precision.cpp:263-276): RFLOAT -> double power -> RFLOAT
+__device__ __host__ __forceinline__ float pow2f_(float x) { double d = x; return (float)(d * d); }
+__device__ __host__ __forceinline__ float pow3f_(float x) { double d = x; return (float)(d * d * d); }
+__device__ __host__ __forceinline__ float pow4f_(float x) { double d = x; double d2 = d * d; return (float)(d2 * d2); }
+
+// gsl_hypot (external/packages/gsl-2.4/sys/hypot.c:24-55)
+__device__ __host__ __forceinline__ double gsl_hypot_(double x, double y)
+{
+    double xabs = fabs(x), yabs = fabs(y), mn, mx;
+    if (xabs < yabs) { mn = xabs; mx = yabs; } else { mn = yabs; mx = xabs; }
+    if (mn == 0) return mx;
+    double u = mn / mx;
+    return mx * sqrt(1 + u * u);
+}
+
+// gsl_hypot3 (external/packages/gsl-2.4/sys/hypot.c:57-76)
+__device__ __host__ __forceinline__ double gsl_hypot3_(double x, double y, double z)
+{
+    double xabs = fabs(x), yabs = fabs(y), zabs = fabs(z);
+    double w = xabs > (yabs > zabs ? yabs : zabs) ? xabs : (yabs > zabs ? yabs : zabs);
+    if (w == 0.0) return 0.0;
+    return w * sqrt((xabs / w) * (xabs / w) + (yabs / w) * (yabs / w) + (zabs / w) * (zabs / w));
+}
+
+// TIK_RL(r) = j0(pi r)^2, src/Functions/Functions.cpp:236-239 with gsl_sf_bessel_j0
+// (external/packages/gsl-2.4/specfunc/bessel_j.c:35-58)
+__device__ __host__ __forceinline__ float tik_rl(float r)
+{
+    float x = (float)(3.14159265358979323846 * r);
+    double xd = x, ax = fabs(xd), j;
+    if (ax < 0.5) {
+        const double y = xd * xd;
+        const double c1 = -1.0 / 6.0, c2 = 1.0 / 120.0, c3 = -1.0 / 5040.0, c4 = 1.0 / 362880.0,
+                     c5 = -1.0 / 39916800.0, c6 = 1.0 / 6227020800.0;
+        j = 1.0 + y * (c1 + y * (c2 + y * (c3 + y * (c4 + y * (c5 + y * c6)))));
+    } else {
+        j = sin(xd) / xd;
+    }
+    return pow2f_((float)j);
+}
+
+// Per-image CTF constants of src/CTF.cpp:129-135
+struct CtfConst {
+    float w1, w2, K1, K2, dU, dV, theta, phaseShift;
+};
+
+__device__ __host__ __forceinline__ CtfConst ctf_const(const thx_ctf_attr& a, double dfac)
+{
+    CtfConst c;
+    float lambda = (float)(12.2643247 / sqrt(a.voltage * (1 + a.voltage * 0.978466e-6)));
+    c.w1 = sqrtf(1 - pow2f_(a.amplitudeContrast));
+    c.w2 = a.amplitudeContrast;
+    c.K1 = (float)(3.14159265358979323846 * lambda);
+    c.K2 = (float)(1.57079632679489661923 * a.Cs * pow3f_(lambda));
+    // defocusU * d : RFLOAT * double evaluated in double, narrowed at the CTF() call (src/Optimiser.cpp:7188-7189)
+    c.dU = (float)(a.defocusU * dfac);
+    c.dV = (float)(a.defocusV * dfac);
+    c.theta = a.defocusTheta;
+    c.phaseShift = a.phaseShift;
+    return c;
+}
+
+// one CTF value, src/CTF.cpp:140-150
+__device__ __forceinline__ float ctf_value(const CtfConst& c, float pixelSize, int nCol, int nRow, int iCol, int iRow)
+{
+    float u = (float)gsl_hypot_((double)(iCol / (pixelSize * nCol)), (double)(iRow / (pixelSize * nRow)));
+    float angle = (float)(atan2((double)iRow, (double)iCol) - c.theta);
+    float defocus = -(c.dU + c.dV + (c.dU - c.dV) * cosf(2 * angle)) / 2;
+    float ki = c.K1 * defocus * pow2f_(u) + c.K2 * pow4f_(u) - c.phaseShift;
+    return -c.w1 * sinf(ki) + c.w2 * cosf(ki);
+}
+
+// phase ramp of translate(), src/Image/ImageFunctions.cpp:243-251: COMPLEX_POLAR(-phase)
+__device__ __forceinline__ float2 ramp_value(float rCol, float rRow, int iCol, int iRow)
+{
+    float phase = (float)(kM2xPi * (iCol * rCol + iRow * rRow));
+    float s, c;
+    sincosf(-phase, &s, &c);
+    return make_float2(c, s);
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// 64-lane wave reductions (DPP through __shfl_xor)
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace thx

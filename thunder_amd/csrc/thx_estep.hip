@@ -1,0 +1,691 @@
+// thx_estep.hip -- E-step kernels: rotation matrices, phase ramps, CTF rows, pixel gather,
+// Fourier-slice extraction, likelihood and the particle-filter weight marginals.
+// Reference behaviour: src/Optimiser.cpp:622-1681 (expectation), src/Projector.cpp:356-374,
+// src/CTF.cpp:113-151, src/Image/ImageFunctions.cpp:233-252.  gfx950 only; wavefront = 64.
+#include <stdarg.h>
+
+#include "thx_common.h"
+
+namespace thx {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------------------------------------
+// rotate3D(quaternion), src/Geometry/Euler.cpp:181-189: R = I + 2 q0 A + 2 A*A, column-major out
+// ---------------------------------------------------------------------------------------------
+__global__ void k_rotmat(const double* __restrict__ quat, double* __restrict__ mat, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double q0 = quat[4 * i], q1 = quat[4 * i + 1], q2 = quat[4 * i + 2], q3 = quat[4 * i + 3];
+    const double A[3][3] = {{0, -q3, q2}, {q3, 0, -q1}, {-q2, q1, 0}};
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += A[r][k] * A[k][c];
+            mat[9 * (size_t)i + c * 3 + r] = (r == c ? 1.0 : 0.0) + 2 * q0 * A[r][c] + 2 * s;
+        }
+}
+
+// translate(), src/Image/ImageFunctions.cpp:233-252, nT ramps at once: grid (ceil(nPxl/256), nT)
+__global__ void k_translate(float2* __restrict__ traP, const double* __restrict__ trans, const int* __restrict__ iCol,
+                            const int* __restrict__ iRow, int nPxl, int idim)
+{
+    const int t = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nPxl) return;
+    const float rCol = (float)trans[2 * t] / idim, rRow = (float)trans[2 * t + 1] / idim;
+    traP[(size_t)t * nPxl + p] = ramp_value(rCol, rRow, iCol[p], iRow[p]);
+}
+
+// CTF rows, src/CTF.cpp:113-151: grid (ceil(nPxl/256), nImg)
+__global__ void k_ctf(float* __restrict__ ctfP, const thx_ctf_attr* __restrict__ attr, const double* __restrict__ dfac,
+                      float pixelSize, const int* __restrict__ iCol, const int* __restrict__ iRow, int nPxl, int idim)
+{
+    const int l = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nPxl) return;
+    const CtfConst c = ctf_const(attr[l], dfac ? dfac[l] : 1.0);
+    ctfP[(size_t)l * nPxl + p] = ctf_value(c, pixelSize, idim, idim, iCol[p], iRow[p]);
+}
+
+// allocPreCal gather, src/Optimiser.cpp:8055-8075
+__global__ void k_gather_pixels(float2* __restrict__ datP, const float2* __restrict__ img, const int* __restrict__ iPxl,
+                                int nPxl, size_t imgSize)
+{
+    const int l = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nPxl) return;
+    datP[(size_t)l * nPxl + p] = img[(size_t)l * imgSize + iPxl[p]];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Projector::project, src/Projector.cpp:356-374: one thread per (pixel, rotation).
+// grid (ceil(nPxl/256), nR).  64 B gathered + 8 B written per thread: HBM/L2-bound gather.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_project(const float2* __restrict__ vol, float2* __restrict__ out,
+                                                 const double* __restrict__ rotMat, const int* __restrict__ iCol,
+                                                 const int* __restrict__ iRow, int pf, int P, int nPxl)
+{
+    const int r = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nPxl) return;
+    const double* m = rotMat + 9 * (size_t)r;
+    const double nx = (double)(iCol[p] * pf), ny = (double)(iRow[p] * pf);
+    // dvec3 oldCor = mat * dvec3(nx, ny, 0): the z column contributes +-0
+    const double ox = m[0] * nx + m[3] * ny;
+    const double oy = m[1] * nx + m[4] * ny;
+    const double oz = m[2] * nx + m[5] * ny;
+    const float x = (float)ox, y = (float)oy, z = (float)oz;
+    float2 v = make_float2(0.f, 0.f);
+    if (coord_in_grid(x, y, z, P)) v = interp_ft(vol, P, x, y, z);
+    out[(size_t)r * nPxl + p] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// logDataVSPrior for nPri prior rows against one image row: one wave per row, lanes stride pixels.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_logdvp(float* __restrict__ out, const float2* __restrict__ dat,
+                                                const float2* __restrict__ pri, const float* __restrict__ ctf,
+                                                const float* __restrict__ sigRcp, int nPri, int nPxl)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= nPri) return;
+    const float2* pr = pri + (size_t)row * nPxl;
+    float acc = 0.f;
+    for (int i = lane; i < nPxl; i += 64) {
+        const float c = ctf[i];
+        const float2 d = dat[i], q = pr[i];
+        const float a = d.x - c * q.x, b = d.y - c * q.y;
+        acc += (a * a + b * b) * sigRcp[i];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[row] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Local particle-filter phase (HOT LOOP B body, src/Optimiser.cpp:1225-1406), batched over images.
+//
+// For one image:  L[r][t] = sum_pix | dat - ctf * tra_t * pri_r |^2 * sigRcp
+//                         = sum_pix s|dat|^2  +  sum_pix B |pri_r|^2  -  2 sum_pix Re(A_t pri_r)
+//   with s = sigRcp, B = s ctf^2, A_t = s ctf conj(dat) tra_t  (|tra_t| = 1).
+// The constant first term is summed once; the per-(r,t) part V[r][t] costs 2 FMAs per pixel-sample
+// instead of the reference's 15 flops, and is accumulated without the large constant, so exp(V - Vmax)
+// carries less rounding noise than the reference's float sum does.
+//
+// Mapping: lane <-> rotation (no cross-lane reduction in the hot loop); each wave walks a
+// sub-stream of the chunk's pixels; the per-pixel A_t / B table is staged in LDS once per chunk and
+// read back as wave-uniform broadcasts.  grid (nSplit, nImg, nD), block 256.
+// ---------------------------------------------------------------------------------------------
+constexpr int kChunk = 256;  // pixels staged per LDS table
+
+struct ExpectLocalArgs {
+    const float2* volumes;
+    const int* volIdx;
+    int P, pf, idim;
+    const int* iCol;
+    const int* iRow;
+    int nPxl, nImg;
+    const float2* datP;
+    const float* ctfP;
+    const float* sigRcpP;
+    const double* rotMat;
+    int nR;
+    const double* trans;
+    int nT, nD;
+    int nSplit;
+    float* partV;  // [nImg][nD][nSplit][nT][nRpad]
+    float* partC;  // [nImg][nD][nSplit]
+    int nRpad;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* sA = reinterpret_cast<float2*>(smem_raw);                 // [kChunk][NT]
+    float* sB = reinterpret_cast<float*>(sA + kChunk * NT);           // [kChunk]
+    int* sIc = reinterpret_cast<int*>(sB + kChunk);                   // [kChunk]
+    int* sIr = sIc + kChunk;                                          // [kChunk]
+    float* sRed = reinterpret_cast<float*>(sIr + kChunk);             // [4 waves] block-reduce scratch
+
+    const int split = blockIdx.x, img = blockIdx.y, d = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.P;
+    const float2* vol = a.volumes + (size_t)(a.volIdx ? a.volIdx[img] : 0) * ((size_t)P * P * (P / 2 + 1));
+    const float2* dat = a.datP + (size_t)img * a.nPxl;
+    const float* ctf = a.ctfP + ((size_t)img * a.nD + d) * a.nPxl;
+    const float* sig = a.sigRcpP + (size_t)img * a.nPxl;
+    const double* tr = a.trans + (size_t)img * a.nT * 2;
+
+    // rotation groups: nRG waves cover 64*nRG rotation slots per pass, the other waves are pixel sub-streams
+    const int nRG0 = (a.nR + 63) >> 6;
+    const int nRGp = nRG0 >= 4 ? 4 : (nRG0 >= 2 ? 2 : 1);
+    const int nSub = 4 / nRGp;
+    const int rg = wave % nRGp, sub = wave / nRGp;
+    const int nPass = (nRG0 + nRGp - 1) / nRGp;
+
+    // this block's pixel range (whole chunks)
+    const int nChunks = (a.nPxl + kChunk - 1) / kChunk;
+    const int c0 = (int)(((long)nChunks * split) / a.nSplit), c1 = (int)(((long)nChunks * (split + 1)) / a.nSplit);
+
+    float cpart = 0.f;
+
+    for (int pass = 0; pass < nPass; pass++) {
+        const int r = (pass * nRGp + rg) * 64 + lane;
+        const bool rvalid = r < a.nR;
+        double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
+        if (rvalid) {
+            const double* m = a.rotMat + ((size_t)img * a.nR + r) * 9;
+            m0 = m[0]; m1 = m[1]; m2 = m[2]; m3 = m[3]; m4 = m[4]; m5 = m[5];
+        }
+        float acc[NT];
+        float accB = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = 0.f;
+
+        for (int c = c0; c < c1; c++) {
+            const int pbase = c * kChunk;
+            const int clen = min(kChunk, a.nPxl - pbase);
+            __syncthreads();  // previous chunk's readers are done
+            // ---- stage the per-pixel table ----
+            for (int e = tid; e < clen; e += 256) {
+                const int p = pbase + e;
+                const int ic = a.iCol[p], ir = a.iRow[p];
+                sIc[e] = ic * a.pf;
+                sIr[e] = ir * a.pf;
+                const float s = sig[p], cf = ctf[p];
+                const float2 dv = dat[p];
+                const float g = s * cf;
+                sB[e] = g * cf;
+                if (pass == 0) cpart = fmaf(s, fmaf(dv.x, dv.x, dv.y * dv.y), cpart);
+                const float2 cd = make_float2(dv.x * g, -dv.y * g);  // s ctf conj(dat)
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    if (t < a.nT) {
+                        const float rCol = (float)tr[2 * t] / a.idim, rRow = (float)tr[2 * t + 1] / a.idim;
+                        sA[e * NT + t] = cmul(cd, ramp_value(rCol, rRow, ic, ir));
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- hot loop: lane = rotation, walk this wave's pixel sub-stream ----
+            if (rvalid) {
+                for (int e = sub; e < clen; e += nSub) {
+                    const double nx = (double)sIc[e], ny = (double)sIr[e];
+                    const float x = (float)(m0 * nx + m3 * ny);
+                    const float y = (float)(m1 * nx + m4 * ny);
+                    const float z = (float)(m2 * nx + m5 * ny);
+                    float2 q = make_float2(0.f, 0.f);
+                    if (coord_in_grid(x, y, z, P)) q = interp_ft(vol, P, x, y, z);
+                    accB = fmaf(sB[e], fmaf(q.x, q.x, q.y * q.y), accB);
+                    const float2* Ap = sA + e * NT;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) {
+                        const float2 A = Ap[t];
+                        acc[t] = fmaf(A.x, q.x, acc[t]);
+                        acc[t] = fmaf(-A.y, q.y, acc[t]);
+                    }
+                }
+            }
+        }
+        // ---- combine pixel sub-streams (fixed order) and write V for this split ----
+        __syncthreads();
+        float* sAcc = reinterpret_cast<float*>(smem_raw);  // reuse: [nSub][NT+1][64*nRGp]
+        const int slots = 64 * nRGp;
+        const int slot = rg * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < NT; t++) sAcc[(sub * (NT + 1) + t) * slots + slot] = acc[t];
+        sAcc[(sub * (NT + 1) + NT) * slots + slot] = accB;
+        __syncthreads();
+        if (sub == 0 && rvalid) {
+            float b = 0.f;
+            for (int s2 = 0; s2 < nSub; s2++) b += sAcc[(s2 * (NT + 1) + NT) * slots + slot];
+            float* outV = a.partV + ((((size_t)img * a.nD + d) * a.nSplit + split) * a.nT) * a.nRpad;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                if (t < a.nT) {
+                    float v = 0.f;
+                    for (int s2 = 0; s2 < nSub; s2++) v += sAcc[(s2 * (NT + 1) + t) * slots + slot];
+                    outV[(size_t)t * a.nRpad + r] = b - 2.0f * v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- constant term: block reduce ----
+    cpart = wave_sum(cpart);
+    if (lane == 0) sRed[wave] = cpart;
+    __syncthreads();
+    if (tid == 0) a.partC[((size_t)img * a.nD + d) * a.nSplit + split] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+}
+
+// Finalise: L = C + V, per-image maximum, exp, marginals (src/Optimiser.cpp:1383-1402 in closed form).
+// grid (nImg), block 256, dynamic LDS nD*nT*nR floats.
+struct ExpectFinalArgs {
+    const float* partV;
+    const float* partC;
+    int nSplit, nR, nRpad, nT, nD;
+    const double* pC;
+    const double* pR;
+    const double* pT;
+    const double* pD;
+    float* wC;
+    float* wR;
+    float* wT;
+    float* wD;
+    float* baseLine;
+    float* logW;
+};
+
+__device__ __forceinline__ double block_sum_256(double v, double* sred)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
+
+__global__ __launch_bounds__(256) void k_expect_final(ExpectFinalArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sL = reinterpret_cast<float*>(smem_raw);  // [nD][nT][nR] log-likelihoods
+    __shared__ double sred[4];
+    __shared__ float sfred[4];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int n = a.nD * a.nT * a.nR;
+    float lmax = -INFINITY;
+    for (int e = tid; e < n; e += 256) {
+        const int r = e % a.nR, t = (e / a.nR) % a.nT, d = e / (a.nR * a.nT);
+        float v = 0.f, c = 0.f;
+        for (int s = 0; s < a.nSplit; s++) {
+            v += a.partV[((((size_t)img * a.nD + d) * a.nSplit + s) * a.nT + t) * a.nRpad + r];
+            c += a.partC[((size_t)img * a.nD + d) * a.nSplit + s];
+        }
+        const float L = c + v;
+        sL[e] = L;
+        if (a.logW) a.logW[(size_t)img * n + e] = L;
+        lmax = fmaxf(lmax, L);
+    }
+    lmax = wave_max(lmax);
+    if ((tid & 63) == 0) sfred[tid >> 6] = lmax;
+    __syncthreads();
+    const float base = fmaxf(fmaxf(sfred[0], sfred[1]), fmaxf(sfred[2], sfred[3]));
+    // s = exp(w - baseLine) (src/Optimiser.cpp:1397, float)
+    for (int e = tid; e < n; e += 256) sL[e] = expf(sL[e] - base);
+    __syncthreads();
+    const double pC = a.pC ? a.pC[img] : 1.0;
+    const double* pR = a.pR + (size_t)img * a.nR;
+    const double* pT = a.pT + (size_t)img * a.nT;
+    const double* pD = a.pD + (size_t)img * a.nD;
+    // wR
+    for (int r = tid; r < a.nR; r += 256) {
+        double s = 0;
+        for (int d = 0; d < a.nD; d++)
+            for (int t = 0; t < a.nT; t++) s += (double)sL[(d * a.nT + t) * a.nR + r] * (pC * pT[t] * pD[d]);
+        a.wR[(size_t)img * a.nR + r] = (float)s;
+    }
+    for (int t = tid; t < a.nT; t += 256) {
+        double s = 0;
+        for (int d = 0; d < a.nD; d++)
+            for (int r = 0; r < a.nR; r++) s += (double)sL[(d * a.nT + t) * a.nR + r] * (pC * pR[r] * pD[d]);
+        a.wT[(size_t)img * a.nT + t] = (float)s;
+    }
+    for (int d = tid; d < a.nD; d += 256) {
+        double s = 0;
+        for (int t = 0; t < a.nT; t++)
+            for (int r = 0; r < a.nR; r++) s += (double)sL[(d * a.nT + t) * a.nR + r] * (pC * pR[r] * pT[t]);
+        a.wD[(size_t)img * a.nD + d] = (float)s;
+    }
+    double sc = 0;
+    for (int e = tid; e < n; e += 256) {
+        const int r = e % a.nR, t = (e / a.nR) % a.nT, d = e / (a.nR * a.nT);
+        sc += (double)sL[e] * (pR[r] * pT[t] * pD[d]);
+    }
+    sc = block_sum_256(sc, sred);
+    if (tid == 0) {
+        a.wC[img] = (float)sc;
+        a.baseLine[img] = base;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Global scanning phase (src/Optimiser.cpp:756-894): every image against every (rotation, shift)
+// of one class.  Slices and ramps are shared by all images (projected once), so the per-sample cost
+// is streaming dat/ctf/sigRcp (16 B per pixel) against L2-resident slices.
+// Stage 1: dvp[l][m][n] via the same expansion as above; grid (ceil(nR/64), nImg), lane <-> rotation,
+//          pixels walked sequentially, ramps for NT shifts folded into A_t per pixel in LDS.
+// Stage 2: per image, fold (baseline, weights) into the carried wC / wR / wT exactly as the reference's
+//          running rescale does, but with one maximum per class sweep.
+// ---------------------------------------------------------------------------------------------
+struct ExpectGlobalArgs {
+    const float2* rotP;
+    const float2* traP;
+    const float2* datP;
+    const float* ctfP;
+    const float* sigRcpP;
+    int nR, nT, nPxl, nImg;
+    float* dvp;  // [nImg][nT][nR]
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_expect_global(ExpectGlobalArgs a, int t0)
+{
+    __shared__ float2 sA[kChunk * NT];
+    __shared__ float sB[kChunk];
+    __shared__ float sRed[4];
+    const int img = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int r = blockIdx.x * 256 + tid;
+    const bool rvalid = r < a.nR;
+    const float2* dat = a.datP + (size_t)img * a.nPxl;
+    const float* ctf = a.ctfP + (size_t)img * a.nPxl;
+    const float* sig = a.sigRcpP + (size_t)img * a.nPxl;
+    const int nt = min(NT, a.nT - t0);
+    float acc[NT];
+    float accB = 0.f, cpart = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = 0.f;
+    for (int pbase = 0; pbase < a.nPxl; pbase += kChunk) {
+        const int clen = min(kChunk, a.nPxl - pbase);
+        __syncthreads();
+        for (int e = tid; e < clen; e += 256) {
+            const int p = pbase + e;
+            const float s = sig[p], cf = ctf[p];
+            const float2 dv = dat[p];
+            const float g = s * cf;
+            sB[e] = g * cf;
+            cpart = fmaf(s, fmaf(dv.x, dv.x, dv.y * dv.y), cpart);
+            const float2 cd = make_float2(dv.x * g, -dv.y * g);
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+                if (t < nt) sA[e * NT + t] = cmul(cd, a.traP[(size_t)(t0 + t) * a.nPxl + p]);
+        }
+        __syncthreads();
+        if (rvalid) {
+            const float2* pr = a.rotP + (size_t)r * a.nPxl + pbase;
+            for (int e = 0; e < clen; e++) {
+                const float2 q = pr[e];
+                accB = fmaf(sB[e], fmaf(q.x, q.x, q.y * q.y), accB);
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const float2 A = sA[e * NT + t];
+                    acc[t] = fmaf(A.x, q.x, acc[t]);
+                    acc[t] = fmaf(-A.y, q.y, acc[t]);
+                }
+            }
+        }
+    }
+    cpart = wave_sum(cpart);
+    if ((tid & 63) == 0) sRed[tid >> 6] = cpart;
+    __syncthreads();
+    const float C = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+    if (rvalid) {
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+            if (t < nt) a.dvp[((size_t)img * a.nT + t0 + t) * a.nR + r] = C + (accB - 2.0f * acc[t]);
+    }
+}
+
+// stage 2: grid (nImg), block 256
+__global__ __launch_bounds__(256) void k_expect_global_fold(const float* __restrict__ dvp, const double* __restrict__ pR,
+                                                            const double* __restrict__ pT, float* __restrict__ wC,
+                                                            float* __restrict__ wR, float* __restrict__ wT,
+                                                            float* __restrict__ baseL, int kIdx, int nK, int nR, int nT,
+                                                            int nImg)
+{
+    __shared__ float sfred[4];
+    __shared__ double sred[4];
+    const int l = blockIdx.x, tid = threadIdx.x;
+    const float* d = dvp + (size_t)l * nT * nR;
+    const int n = nT * nR;
+    float lmax = -INFINITY;
+    for (int e = tid; e < n; e += 256) lmax = fmaxf(lmax, d[e]);
+    lmax = wave_max(lmax);
+    if ((tid & 63) == 0) sfred[tid >> 6] = lmax;
+    __syncthreads();
+    lmax = fmaxf(fmaxf(sfred[0], sfred[1]), fmaxf(sfred[2], sfred[3]));
+    const float old = baseL[l];
+    const bool unset = isnan(old);
+    const float base = unset ? lmax : fmaxf(old, lmax);
+    // rescale what earlier classes / sweeps accumulated (src/Optimiser.cpp:843-871)
+    const float nf = unset ? 1.0f : expf(old - base);
+    if (!unset && base > old) {
+        for (int q = tid; q < nK; q += 256) wC[(size_t)l * nK + q] *= nf;
+        for (int td = 0; td < nK; td++) {
+            float* a = wR + ((size_t)td * nImg + l) * nR;
+            float* b = wT + ((size_t)td * nImg + l) * nT;
+            for (int q = tid; q < nR; q += 256) a[q] *= nf;
+            for (int q = tid; q < nT; q += 256) b[q] *= nf;
+        }
+    }
+    __syncthreads();
+    const double* pr = pR + (size_t)l * nR;
+    const double* pt = pT + (size_t)l * nT;
+    float* a = wR + ((size_t)kIdx * nImg + l) * nR;
+    float* b = wT + ((size_t)kIdx * nImg + l) * nT;
+    // wR[m] += sum_n w * pT[n]
+    for (int m = tid; m < nR; m += 256) {
+        double s = 0;
+        for (int t = 0; t < nT; t++) s += (double)expf(d[(size_t)t * nR + m] - base) * pt[t];
+        a[m] = (float)((double)a[m] + s);
+    }
+    // wT[n] += sum_m w * pR[m]; wC += sum w pR pT
+    double sc = 0;
+    for (int t = 0; t < nT; t++) {
+        double s = 0;
+        for (int m = tid; m < nR; m += 256) s += (double)expf(d[(size_t)t * nR + m] - base) * pr[m];
+        s = block_sum_256(s, sred);
+        if (tid == 0) b[t] = (float)((double)b[t] + s);
+        sc += s * pt[t];
+    }
+    if (tid == 0) {
+        wC[(size_t)l * nK + kIdx] = (float)((double)wC[(size_t)l * nK + kIdx] + sc);
+        baseL[l] = base;
+    }
+}
+
+}  // namespace thx
+
+using namespace thx;
+
+static int expect_local_nsplit(int nImg)
+{
+    // enough blocks to fill 256 CUs x ~6 resident blocks when the batch is small
+    int s = 1;
+    while (s < 16 && (long)nImg * s < 2048) s *= 2;
+    return s;
+}
+
+template <int NT>
+static int launch_expect_local(const ExpectLocalArgs& a, hipStream_t st)
+{
+    const int nRG0 = (a.nR + 63) >> 6;
+    const int nRGp = nRG0 >= 4 ? 4 : (nRG0 >= 2 ? 2 : 1);
+    const int nSub = 4 / nRGp;
+    size_t stage = (size_t)kChunk * NT * sizeof(float2) + kChunk * (sizeof(float) + 2 * sizeof(int)) + 4 * sizeof(float);
+    size_t red = (size_t)nSub * (NT + 1) * 64 * nRGp * sizeof(float);
+    size_t lds = stage > red ? stage : red;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expect_local<NT>), dim3(a.nSplit, a.nImg, a.nD), dim3(256), lds, st, a);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char* thx_last_error(void) { return thx::g_err; }
+int thx_version(void) { return 100; }
+
+int thx_device_count(int* count)
+{
+    THX_REQUIRE(count, "count is NULL");
+    THX_CHECK(hipGetDeviceCount(count));
+    return 0;
+}
+
+int thx_set_device(int gpuIdx)
+{
+    THX_CHECK(hipSetDevice(gpuIdx));
+    return 0;
+}
+
+int thx_rotmat_dev(const double* quat, double* mat, int n, void* stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_rotmat, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), quat, mat, n);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_translate_dev(float* traP, const double* trans, int nT, const int* iCol, const int* iRow, int nPxl, int idim,
+                      void* stream)
+{
+    if (nT <= 0 || nPxl <= 0) return 0;
+    hipLaunchKernelGGL(k_translate, dim3((nPxl + 255) / 256, nT), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<float2*>(traP), trans, iCol, iRow, nPxl, idim);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_ctf_dev(float* ctfP, const thx_ctf_attr* attr, const double* dfac, float pixelSize, const int* iCol,
+                const int* iRow, int nPxl, int idim, int nImg, void* stream)
+{
+    if (nImg <= 0 || nPxl <= 0) return 0;
+    for (int l0 = 0; l0 < nImg; l0 += 65535) {
+        const int nl = nImg - l0 < 65535 ? nImg - l0 : 65535;
+        hipLaunchKernelGGL(k_ctf, dim3((nPxl + 255) / 256, nl), dim3(256), 0, as_stream(stream),
+                           ctfP + (size_t)l0 * nPxl, attr + l0, dfac ? dfac + l0 : nullptr, pixelSize, iCol, iRow, nPxl,
+                           idim);
+    }
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_gather_pixels_dev(float* datP, const float* img, const int* iPxl, int nPxl, int idim, int nImg, void* stream)
+{
+    if (nImg <= 0 || nPxl <= 0) return 0;
+    const size_t imgSize = (size_t)idim * (idim / 2 + 1);
+    for (int l0 = 0; l0 < nImg; l0 += 65535) {
+        const int nl = nImg - l0 < 65535 ? nImg - l0 : 65535;
+        hipLaunchKernelGGL(k_gather_pixels, dim3((nPxl + 255) / 256, nl), dim3(256), 0, as_stream(stream),
+                           reinterpret_cast<float2*>(datP) + (size_t)l0 * nPxl,
+                           reinterpret_cast<const float2*>(img) + (size_t)l0 * imgSize, iPxl, nPxl, imgSize);
+    }
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_project_dev(const float* volume, float* rotP, const double* rotMat, const int* iCol, const int* iRow, int nR,
+                    int pf, int vdim, int nPxl, void* stream)
+{
+    if (nR <= 0 || nPxl <= 0) return 0;
+    THX_REQUIRE(volume && rotP && rotMat && iCol && iRow, "NULL pointer");
+    for (int r0 = 0; r0 < nR; r0 += 65535) {
+        const int nr = nR - r0 < 65535 ? nR - r0 : 65535;
+        hipLaunchKernelGGL(k_project, dim3((nPxl + 255) / 256, nr), dim3(256), 0, as_stream(stream),
+                           reinterpret_cast<const float2*>(volume), reinterpret_cast<float2*>(rotP) + (size_t)r0 * nPxl,
+                           rotMat + (size_t)r0 * 9, iCol, iRow, pf, vdim, nPxl);
+    }
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_logdatavsprior_dev(float* out, const float* dat, const float* pri, const float* ctf, const float* sigRcp,
+                           int nPri, int nPxl, void* stream)
+{
+    if (nPri <= 0) return 0;
+    hipLaunchKernelGGL(k_logdvp, dim3((nPri + 3) / 4), dim3(256), 0, as_stream(stream), out,
+                       reinterpret_cast<const float2*>(dat), reinterpret_cast<const float2*>(pri), ctf, sigRcp, nPri,
+                       nPxl);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t thx_expect_local_workspace(int nImg, int nR, int nT, int nD)
+{
+    const int nSplit = expect_local_nsplit(nImg);
+    const size_t nRpad = (size_t)((nR + 63) / 64) * 64;
+    return ((size_t)nImg * nD * nSplit * nT * nRpad + (size_t)nImg * nD * nSplit) * sizeof(float) + 256;
+}
+
+int thx_expect_local_dev(const float* volumes, const int* volIdx, int vdim, int pf, int idim, const int* iCol,
+                         const int* iRow, int nPxl, int nImg, const float* datP, const float* ctfP,
+                         const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
+                         const double* pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR,
+                         float* wT, float* wD, float* baseLine, float* logW, void* workspace, void* stream)
+{
+    if (nImg <= 0) return 0;
+    THX_REQUIRE(volumes && iCol && iRow && datP && ctfP && sigRcpP && rotMat && trans, "NULL input pointer");
+    THX_REQUIRE(pR && pT && pD && wC && wR && wT && wD && baseLine && workspace, "NULL prior/output/workspace pointer");
+    THX_REQUIRE(nR > 0 && nT > 0 && nD > 0 && nPxl > 0, "nR, nT, nD, nPxl must be positive");
+    THX_REQUIRE(nT <= 32, "nT > 32 translations per phase is not supported");
+    THX_REQUIRE(nImg <= 65535 && nD <= 65535, "nImg and nD must be <= 65535 per call");
+    THX_REQUIRE((size_t)nD * nT * nR * sizeof(float) <= 64 * 1024, "nD*nT*nR too large for the finalise kernel");
+    hipStream_t st = as_stream(stream);
+    ExpectLocalArgs a;
+    a.volumes = reinterpret_cast<const float2*>(volumes);
+    a.volIdx = volIdx;
+    a.P = vdim; a.pf = pf; a.idim = idim;
+    a.iCol = iCol; a.iRow = iRow; a.nPxl = nPxl; a.nImg = nImg;
+    a.datP = reinterpret_cast<const float2*>(datP);
+    a.ctfP = ctfP; a.sigRcpP = sigRcpP; a.rotMat = rotMat; a.nR = nR; a.trans = trans; a.nT = nT; a.nD = nD;
+    a.nSplit = expect_local_nsplit(nImg);
+    a.nRpad = ((nR + 63) / 64) * 64;
+    a.partV = reinterpret_cast<float*>(workspace);
+    a.partC = a.partV + (size_t)nImg * nD * a.nSplit * nT * a.nRpad;
+    int rc;
+    if (nT <= 9) rc = launch_expect_local<9>(a, st);
+    else if (nT <= 16) rc = launch_expect_local<16>(a, st);
+    else rc = launch_expect_local<32>(a, st);
+    if (rc) return rc;
+    ExpectFinalArgs f;
+    f.partV = a.partV; f.partC = a.partC; f.nSplit = a.nSplit; f.nR = nR; f.nRpad = a.nRpad; f.nT = nT; f.nD = nD;
+    f.pC = pC; f.pR = pR; f.pT = pT; f.pD = pD; f.wC = wC; f.wR = wR; f.wT = wT; f.wD = wD; f.baseLine = baseLine;
+    f.logW = logW;
+    hipLaunchKernelGGL(k_expect_final, dim3(nImg), dim3(256), (size_t)nD * nT * nR * sizeof(float), st, f);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t thx_expect_global_workspace(int nImg, int nR, int nT) { return (size_t)nImg * nR * nT * sizeof(float) + 256; }
+
+int thx_expect_global_dev(const float* rotP, const float* traP, const float* datP, const float* ctfP,
+                          const float* sigRcpP, const double* pR, const double* pT, float* wC, float* wR, float* wT,
+                          float* baseL, int kIdx, int nK, int nR, int nT, int nPxl, int nImg, void* workspace,
+                          void* stream)
+{
+    if (nImg <= 0) return 0;
+    THX_REQUIRE(rotP && traP && datP && ctfP && sigRcpP && pR && pT && wC && wR && wT && baseL && workspace,
+                "NULL pointer");
+    THX_REQUIRE(nImg <= 65535, "nImg must be <= 65535 per call");
+    hipStream_t st = as_stream(stream);
+    ExpectGlobalArgs a;
+    a.rotP = reinterpret_cast<const float2*>(rotP);
+    a.traP = reinterpret_cast<const float2*>(traP);
+    a.datP = reinterpret_cast<const float2*>(datP);
+    a.ctfP = ctfP; a.sigRcpP = sigRcpP; a.nR = nR; a.nT = nT; a.nPxl = nPxl; a.nImg = nImg;
+    a.dvp = reinterpret_cast<float*>(workspace);
+    constexpr int NT = 8;
+    for (int t0 = 0; t0 < nT; t0 += NT) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expect_global<NT>), dim3((nR + 255) / 256, nImg), dim3(256), 0, st, a, t0);
+    }
+    THX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_expect_global_fold, dim3(nImg), dim3(256), 0, st, a.dvp, pR, pT, wC, wR, wT, baseL, kIdx, nK, nR,
+                       nT, nImg);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

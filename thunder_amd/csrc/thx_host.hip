@@ -1,0 +1,186 @@
+// thx_host.hip -- Interface.h-shaped entry points on caller-owned HOST buffers
+// (gpu/interface/Interface.h:199-219,267-326; Reconstructor::reconstructG src/Reconstructor.cpp:1835-2315).
+// Each one uploads, runs the *_dev path, and writes results back into the caller's arrays before returning,
+// which is the contract the reference's -DGPU_VERSION call sites rely on.
+#include <vector>
+
+#include "thx_common.h"
+
+namespace thx {
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 4);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            return (int)e;
+        }
+        return 0;
+    }
+    int upload(const void* h, size_t bytes)
+    {
+        int rc = alloc(bytes);
+        if (rc) return rc;
+        hipError_t e = hipMemcpy(p, h, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("hipMemcpy H2D failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        return 0;
+    }
+    template <typename T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+#define THX_RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+}  // namespace thx
+
+using namespace thx;
+
+extern "C" {
+
+int thx_ExpectProject_host(const float* volume, float* rotP, const double* rotMat, const int* iCol, const int* iRow,
+                           int nR, int pf, int interp, int vdim, int npxl)
+{
+    THX_REQUIRE(interp == 1, "only LINEAR_INTERP (1) is implemented, as used by the 3D refinement path");
+    const size_t nvol = (size_t)vdim * vdim * (vdim / 2 + 1);
+    DevBuf dVol, dOut, dMat, dCol, dRow;
+    THX_RC(dVol.upload(volume, nvol * 2 * sizeof(float)));
+    THX_RC(dOut.alloc((size_t)nR * npxl * 2 * sizeof(float)));
+    THX_RC(dMat.upload(rotMat, (size_t)nR * 9 * sizeof(double)));
+    THX_RC(dCol.upload(iCol, npxl * sizeof(int)));
+    THX_RC(dRow.upload(iRow, npxl * sizeof(int)));
+    THX_RC(thx_project_dev(dVol.as<float>(), dOut.as<float>(), dMat.as<double>(), dCol.as<int>(), dRow.as<int>(), nR, pf,
+                           vdim, npxl, nullptr));
+    THX_CHECK(hipMemcpy(rotP, dOut.p, (size_t)nR * npxl * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int thx_ExpectRotran_host(float* traP, const double* trans, const double* rot, double* rotMat, const int* iCol,
+                          const int* iRow, int nR, int nT, int idim, int npxl)
+{
+    DevBuf dTra, dTrans, dQuat, dMat, dCol, dRow;
+    THX_RC(dTra.alloc((size_t)nT * npxl * 2 * sizeof(float)));
+    THX_RC(dTrans.upload(trans, (size_t)nT * 2 * sizeof(double)));
+    THX_RC(dQuat.upload(rot, (size_t)nR * 4 * sizeof(double)));
+    THX_RC(dMat.alloc((size_t)nR * 9 * sizeof(double)));
+    THX_RC(dCol.upload(iCol, npxl * sizeof(int)));
+    THX_RC(dRow.upload(iRow, npxl * sizeof(int)));
+    THX_RC(thx_translate_dev(dTra.as<float>(), dTrans.as<double>(), nT, dCol.as<int>(), dRow.as<int>(), npxl, idim, nullptr));
+    THX_RC(thx_rotmat_dev(dQuat.as<double>(), dMat.as<double>(), nR, nullptr));
+    THX_CHECK(hipMemcpy(traP, dTra.p, (size_t)nT * npxl * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    THX_CHECK(hipMemcpy(rotMat, dMat.p, (size_t)nR * 9 * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int thx_InsertFT_host(float* F3D, float* T3D_complex, double* O3D, int* counter, const float* datP, const float* ctfP,
+                      const thx_ctf_attr* ctfaData, const double* offS, const float* w, const double* nR,
+                      const double* nT, const double* nD, const int* nC, const int* iCol, const int* iRow,
+                      float pixelSize, int cSearch, int opf, int npxl, int mReco, int idim, int vdim, int nK,
+                      int imgNum)
+{
+    THX_REQUIRE(F3D && T3D_complex && datP && ctfP && w && nR && nT && iCol && iRow, "NULL pointer");
+    const size_t nvol = (size_t)vdim * vdim * (vdim / 2 + 1);
+    const size_t nd = (size_t)imgNum * mReco;
+    DevBuf dF, dT, dO, dCnt, dDat, dCtf, dW, dQuat, dMat, dTran, dOff, dCls, dAttr, dDf, dCol, dRow;
+    THX_RC(dF.upload(F3D, nvol * nK * 2 * sizeof(float)));
+    {   // T: complex on the host (imaginary part unused) -> real on the device
+        std::vector<float> t(nvol * nK);
+        for (size_t i = 0; i < nvol * nK; i++) t[i] = T3D_complex[2 * i];
+        THX_RC(dT.upload(t.data(), nvol * nK * sizeof(float)));
+    }
+    double O0[3] = {0, 0, 0};
+    int c0 = 0;
+    THX_RC(dO.upload(O0, sizeof(O0)));
+    THX_RC(dCnt.upload(&c0, sizeof(int)));
+    THX_RC(dDat.upload(datP, (size_t)imgNum * npxl * 2 * sizeof(float)));
+    THX_RC(dCtf.upload(ctfP, (size_t)imgNum * npxl * sizeof(float)));
+    THX_RC(dW.upload(w, imgNum * sizeof(float)));
+    THX_RC(dQuat.upload(nR, nd * 4 * sizeof(double)));
+    THX_RC(dMat.alloc(nd * 9 * sizeof(double)));
+    THX_RC(dTran.upload(nT, nd * 2 * sizeof(double)));
+    if (offS) THX_RC(dOff.upload(offS, (size_t)imgNum * 2 * sizeof(double)));
+    if (nC) THX_RC(dCls.upload(nC, nd * sizeof(int)));
+    if (cSearch) {
+        THX_REQUIRE(ctfaData && nD, "cSearch needs ctfaData and nD");
+        THX_RC(dAttr.upload(ctfaData, imgNum * sizeof(thx_ctf_attr)));
+        THX_RC(dDf.upload(nD, nd * sizeof(double)));
+    }
+    THX_RC(dCol.upload(iCol, npxl * sizeof(int)));
+    THX_RC(dRow.upload(iRow, npxl * sizeof(int)));
+    THX_RC(thx_rotmat_dev(dQuat.as<double>(), dMat.as<double>(), (int)nd, nullptr));
+    THX_RC(thx_insert_dev(dF.as<float>(), dT.as<float>(), dO.as<double>(), dCnt.as<int>(), vdim, nK, dDat.as<float>(),
+                          dCtf.as<float>(), dW.as<float>(), dMat.as<double>(), dTran.as<double>(),
+                          offS ? dOff.as<double>() : nullptr, nC ? dCls.as<int>() : nullptr,
+                          cSearch ? dAttr.as<thx_ctf_attr>() : nullptr, cSearch ? dDf.as<double>() : nullptr, cSearch,
+                          pixelSize, dCol.as<int>(), dRow.as<int>(), opf, npxl, mReco, idim, imgNum, nullptr));
+    THX_CHECK(hipMemcpy(F3D, dF.p, nvol * nK * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    {
+        std::vector<float> t(nvol * nK);
+        THX_CHECK(hipMemcpy(t.data(), dT.p, nvol * nK * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < nvol * nK; i++) T3D_complex[2 * i] = t[i];
+    }
+    if (O3D) {
+        double o[3];
+        THX_CHECK(hipMemcpy(o, dO.p, sizeof(o), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 3; i++) O3D[i] += o[i];
+    }
+    if (counter) {
+        int c;
+        THX_CHECK(hipMemcpy(&c, dCnt.p, sizeof(int), hipMemcpyDeviceToHost));
+        counter[0] += c;
+    }
+    return 0;
+}
+
+int thx_PrepareTF_host(int gpuIdx, float* F3D, float* T3D_complex, int vdim, const double* symMat,
+                       int nSymmetryElement, int maxRadius, int pf)
+{
+    THX_CHECK(hipSetDevice(gpuIdx));
+    const size_t nvol = (size_t)vdim * vdim * (vdim / 2 + 1);
+    DevBuf dF, dT, dF2, dT2;
+    THX_RC(dF.upload(F3D, nvol * 2 * sizeof(float)));
+    std::vector<float> t(nvol);
+    for (size_t i = 0; i < nvol; i++) t[i] = T3D_complex[2 * i];
+    THX_RC(dT.upload(t.data(), nvol * sizeof(float)));
+    THX_RC(dF2.alloc(nvol * 2 * sizeof(float)));
+    THX_RC(dT2.alloc(nvol * sizeof(float)));
+    THX_RC(thx_normalise_tf_dev(dF.as<float>(), dT.as<float>(), vdim, nullptr));
+    const double r = (double)(maxRadius * pf + 1);
+    THX_RC(thx_symmetrize_dev(dT2.as<float>(), dT.as<float>(), vdim, 0, symMat, nSymmetryElement, r, nullptr));
+    THX_RC(thx_symmetrize_dev(dF2.as<float>(), dF.as<float>(), vdim, 1, symMat, nSymmetryElement, r, nullptr));
+    THX_CHECK(hipMemcpy(F3D, dF2.p, nvol * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    THX_CHECK(hipMemcpy(t.data(), dT2.p, nvol * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nvol; i++) { T3D_complex[2 * i] = t[i]; T3D_complex[2 * i + 1] = 0.f; }
+    return 0;
+}
+
+int thx_ReconstructG_host(int gpuIdx, const float* F3D, const float* T3D_complex, int size, int N, int pf,
+                          int maxRadius, float a, float alpha, const float* FSC, int nFSC, int joinHalf, int MAP,
+                          int gridCorr, float* dstRL)
+{
+    THX_CHECK(hipSetDevice(gpuIdx));
+    const int PF = pf * size;
+    const size_t nvol = (size_t)PF * PF * (PF / 2 + 1);
+    DevBuf dF, dT, dDst;
+    THX_RC(dF.upload(F3D, nvol * 2 * sizeof(float)));
+    std::vector<float> t(nvol);
+    for (size_t i = 0; i < nvol; i++) t[i] = T3D_complex[2 * i];
+    THX_RC(dT.upload(t.data(), nvol * sizeof(float)));
+    THX_RC(dDst.alloc((size_t)N * N * N * sizeof(float)));
+    thx_reco* r = nullptr;
+    THX_RC(thx_reco_create(&r, size, N, pf, a, alpha));
+    int rc = thx_reco_reconstruct_dev(r, dF.as<float>(), dT.as<float>(), maxRadius, FSC, nFSC, joinHalf, MAP, gridCorr,
+                                      dDst.as<float>(), nullptr, nullptr, nullptr);
+    if (!rc) {
+        hipError_t e = hipMemcpy(dstRL, dDst.p, (size_t)N * N * N * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { set_error("hipMemcpy D2H failed: %s", hipGetErrorString(e)); rc = (int)e; }
+    }
+    thx_reco_destroy(r);
+    return rc;
+}
+
+}  // extern "C"

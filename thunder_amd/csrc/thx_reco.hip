@@ -1,0 +1,463 @@
+// thx_reco.hip -- Reconstructor state and the reconstruct() pipeline on the device:
+// Wiener term, iterative gridding weights (hipFFT/rocFFT 3-D c2r/r2c), F*W, inverse FFT, crop, TIK correction;
+// Projector::setProjectee; FSC.  Reference behaviour: src/Reconstructor.cpp:43-160,1129-1831,2563-2674,
+// src/Projector.cpp:123-148,524-606, src/Functions/Spectrum.cpp:302-337, src/FFT.cpp:176-232.  gfx950 only.
+#include <hipfft/hipfft.h>
+#include <math.h>
+
+#include <vector>
+
+#include "thx_common.h"
+
+namespace thx {
+
+#define THX_FFT_CHECK(expr)                                                                  \
+    do {                                                                                     \
+        hipfftResult _r = (expr);                                                            \
+        if (_r != HIPFFT_SUCCESS) {                                                          \
+            thx::set_error("%s failed: hipfftResult %d (%s:%d)", #expr, (int)_r, __FILE__, __LINE__); \
+            return 1000 + (int)_r;                                                           \
+        }                                                                                    \
+    } while (0)
+
+// ---- host: MKB_RL / MKB_RL_R2 (src/Functions/Functions.cpp:143-214, FUNCTIONS_MKB_ORDER_0) ----
+static double bessel_I0(double x)
+{
+    double q = x * x / 4.0, term = 1.0, sum = 1.0;
+    for (int k = 1; k < 500; k++) {
+        term *= q / ((double)k * (double)k);
+        sum += term;
+        if (term < sum * 1e-17) break;
+    }
+    return sum;
+}
+static double bessel_I15(double v) { return sqrt(2.0 / (M_PI * v)) * (cosh(v) - sinh(v) / v); }
+static double bessel_J15(double v) { return sqrt(2.0 / (M_PI * v)) * (sin(v) / v - cos(v)); }
+
+static float mkb_rl(float r, float a, float alpha)
+{
+    float u = (float)(2 * M_PI * a * r);
+    float v = (u <= alpha) ? sqrtf(pow2f_(alpha) - pow2f_(u)) : sqrtf(pow2f_(u) - pow2f_(alpha));
+    float I0a = (float)bessel_I0((double)alpha);
+    float w = (float)(pow(2 * M_PI, 1.5) * pow3f_(a) / I0a / pow((double)v, 1.5));
+    return (u <= alpha) ? w * (float)bessel_I15((double)v) : w * (float)bessel_J15((double)v);
+}
+static float mkb_rl_r2(float r2, float a, float alpha)
+{
+    float u2 = pow2f_((float)(2 * M_PI * a)) * r2;
+    float v = (u2 <= pow2f_(alpha)) ? sqrtf(pow2f_(alpha) - u2) : sqrtf(u2 - pow2f_(alpha));
+    float I0a = (float)bessel_I0((double)alpha);
+    float w = (float)(pow(2 * M_PI, 1.5) * pow3f_(a) / I0a / pow((double)v, 1.5));
+    return (u2 <= pow2f_(alpha)) ? w * (float)bessel_I15((double)v) : w * (float)bessel_J15((double)v);
+}
+
+constexpr int kTabN = 100000;  // _kernelRL.init(..., 0, 1, 1e5), src/Reconstructor.cpp:77-86
+
+// ---- device kernels ----
+__device__ __forceinline__ void unpack_half(size_t e, int P, int& i, int& j, int& k)
+{
+    const int nc = P / 2 + 1;
+    i = (int)(e % nc);
+    const int jw = (int)((e / nc) % P), kw = (int)(e / ((size_t)nc * P));
+    j = jw >= P / 2 ? jw - P : jw;
+    k = kw >= P / 2 ? kw - P : kw;
+}
+
+// [MAP] T /= FSC'(shell), src/Reconstructor.cpp:1242-1270
+__global__ __launch_bounds__(256) void k_wiener_T(float* __restrict__ T, int P, int pf, int maxRadius,
+                                                  const float* __restrict__ FSC, int nFSC, int joinHalf)
+{
+    const size_t n = (size_t)P * P * (P / 2 + 1);
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    int i, j, k;
+    unpack_half(e, P, i, j, k);
+    const double q = (double)i * i + (double)j * j + (double)k * k;
+    if ((q >= pow2f_((float)(5 * pf))) && (q < pow2f_((float)(maxRadius * pf)))) {
+        const int u = (int)rint(gsl_hypot3_((double)i, (double)j, (double)k));
+        float f = (u / pf >= nFSC) ? 0.f : FSC[u / pf];
+        const float lo = (float)1e-3, hi = (float)(1 - 1e-3);
+        const float mn = hi < f ? hi : f;
+        f = lo > mn ? lo : mn;
+        if (joinHalf) f = sqrtf(2 * f / (1 + f));
+        T[e] = T[e] / f;
+    }
+}
+
+// W = 1 in the sphere else 0 (:1299-1304); T = max(T, 1e-25) (:1322-1324)
+__global__ __launch_bounds__(256) void k_initW_floorT(float* __restrict__ W, float* __restrict__ T, int P, int pf,
+                                                      int maxRadius)
+{
+    const size_t n = (size_t)P * P * (P / 2 + 1);
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    int i, j, k;
+    unpack_half(e, P, i, j, k);
+    const double q = (double)i * i + (double)j * j + (double)k * k;
+    W[e] = (q < pow2f_((float)(maxRadius * pf))) ? 1.0f : 0.0f;
+    const float t = T[e];
+    T[e] = t > (float)1e-25 ? t : (float)1e-25;
+}
+
+// C = T * REAL(W) (:1389-1391)
+__global__ __launch_bounds__(256) void k_calcC(float2* __restrict__ C, const float* __restrict__ T,
+                                               const float* __restrict__ W, size_t n)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float w = W[e];
+    C[e] = make_float2(T[e] * w, 0.0f * w);
+}
+
+// convoluteC real-space stage (:2635-2652) fused with bwExecutePlan's 1/size scaling (src/FFT.cpp:355-367)
+__global__ __launch_bounds__(256) void k_convolute_rl(float* __restrict__ rl, int P, int NP, const float* __restrict__ tab,
+                                                      float nf)
+{
+    const size_t n = (size_t)P * P * P;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int iw = (int)(e % P), jw = (int)((e / P) % P), kw = (int)(e / ((size_t)P * P));
+    const int i = iw >= P / 2 ? iw - P : iw, j = jw >= P / 2 ? jw - P : jw, k = kw >= P / 2 ? kw - P : kw;
+    float v = (float)((double)rl[e] * (1.0 / (double)n));
+    const double q = (double)i * i + (double)j * j + (double)k * k;
+    const float x = (float)(q / pow2f_((float)NP));
+    const float s = 1.0f / kTabN;  // _s = (_b - _a) / _n in RFLOAT, src/TabFunction.cpp:34
+    const int idx = (int)rint((double)((x - 0.0f) / s));
+    rl[e] = v * tab[idx < kTabN ? idx : kTabN] / nf;
+}
+
+__device__ __forceinline__ float ts_hypot(float x, float y)
+{
+    float xabs = fabsf(x), yabs = fabsf(y), mn, mx;
+    if (xabs < yabs) { mn = xabs; mx = yabs; } else { mn = yabs; mx = xabs; }
+    if (mn == 0) return mx;
+    float u = mn / mx;
+    return mx * sqrtf(1 + u * u);
+}
+
+// W /= max(|C|, 1e-6) in the sphere (:1487-1496) + checkC max (RECONSTRUCTOR_CHECK_C_MAX, :2563-2592)
+__global__ __launch_bounds__(256) void k_updateW_checkC(float* __restrict__ W, const float2* __restrict__ C, int P, int pf,
+                                                        int maxRadius, unsigned* __restrict__ diffBits)
+{
+    __shared__ float sred[4];
+    const size_t n = (size_t)P * P * (P / 2 + 1);
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float d = 0.f;
+    if (e < n) {
+        int i, j, k;
+        unpack_half(e, P, i, j, k);
+        const double q = (double)i * i + (double)j * j + (double)k * k;
+        if (q < pow2f_((float)(maxRadius * pf))) {
+            const float2 c = C[e];
+            const float a = ts_hypot(c.x, c.y);
+            const float m = a > (float)1e-6 ? a : (float)1e-6;
+            W[e] = W[e] / m;
+            d = fabsf(a - 1);
+        }
+    }
+    d = wave_max(d);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        d = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+        atomicMax(diffBits, __float_as_uint(d));  // d >= 0: uint order == float order
+    }
+}
+
+// no grid correction: W = 1 / max(|T|, 1e-6) in the sphere (:1566-1578)
+__global__ __launch_bounds__(256) void k_W_nogridcorr(float* __restrict__ W, const float* __restrict__ T, int P, int pf,
+                                                      int maxRadius)
+{
+    const size_t n = (size_t)P * P * (P / 2 + 1);
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    int i, j, k;
+    unpack_half(e, P, i, j, k);
+    const double q = (double)i * i + (double)j * j + (double)k * k;
+    if (q < pow2f_((float)(maxRadius * pf))) {
+        const float a = ts_hypot(T[e], 0.f);
+        W[e] = (float)(1.0 / (double)(a > (float)1e-6 ? a : (float)1e-6));
+    }
+}
+
+// padDst = F * W in the sphere, 0 elsewhere (:1678-1701).  pad grid PN = _N*_pf, F grid PF = _pf*_size.
+__global__ __launch_bounds__(256) void k_FW(float2* __restrict__ pad, int PN, const float2* __restrict__ F,
+                                            const float* __restrict__ W, int PF, int pf, int maxRadius)
+{
+    const size_t n = (size_t)PN * PN * (PN / 2 + 1);
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    int i, j, k;
+    unpack_half(e, PN, i, j, k);
+    float2 o = make_float2(0.f, 0.f);
+    const double q = (double)i * i + (double)j * j + (double)k * k;
+    const int h = PF / 2;
+    if ((q < pow2f_((float)(maxRadius * pf))) && i <= h && j >= -h && j < h && k >= -h && k < h) {
+        const size_t f = ((size_t)(k >= 0 ? k : k + PF) * PF + (j >= 0 ? j : j + PF)) * (PF / 2 + 1) + i;
+        const float2 a = F[f];
+        const float b0 = W[f], b1 = 0.f;
+        o = make_float2(a.x * b0 - a.y * b1, a.x * b1 + a.y * b0);
+    }
+    pad[e] = o;
+}
+
+// fft.bw 1/size + VOL_EXTRACT_RL + TIK correction (:1716-1802)
+__global__ __launch_bounds__(256) void k_extract_tik(float* __restrict__ dst, const float* __restrict__ pad, int P, int N,
+                                                     int pf, int corr)
+{
+    const size_t n = (size_t)N * N * N;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int iw = (int)(e % N), jw = (int)((e / N) % N), kw = (int)(e / ((size_t)N * N));
+    const int i = iw >= N / 2 ? iw - N : iw, j = jw >= N / 2 ? jw - N : jw, k = kw >= N / 2 ? kw - N : kw;
+    const size_t ip = ((size_t)(k >= 0 ? k : k + P) * P + (j >= 0 ? j : j + P)) * P + (i >= 0 ? i : i + P);
+    float v = (float)((double)pad[ip] * (1.0 / ((double)P * P * P)));
+    if (corr) v = v / tik_rl((float)(gsl_hypot3_((double)i, (double)j, (double)k) / (pf * N)));
+    dst[e] = v;
+}
+
+// VOL_PAD_RL + gridCorrection LINEAR branch (src/Projector.cpp:573-583): pad = src / TIK_RL(|x| / (pf * P))
+__global__ __launch_bounds__(256) void k_pad_gridcorr(float* __restrict__ pad, const float* __restrict__ src, int N, int pf)
+{
+    const int P = N * pf;
+    const size_t n = (size_t)P * P * P;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int iw = (int)(e % P), jw = (int)((e / P) % P), kw = (int)(e / ((size_t)P * P));
+    const int i = iw >= P / 2 ? iw - P : iw, j = jw >= P / 2 ? jw - P : jw, k = kw >= P / 2 ? kw - P : kw;
+    float v = 0.f;
+    const int h = N / 2;
+    if (i >= -h && i < h && j >= -h && j < h && k >= -h && k < h) {
+        const size_t is = ((size_t)(k >= 0 ? k : k + N) * N + (j >= 0 ? j : j + N)) * N + (i >= 0 ? i : i + N);
+        v = src[is] / tik_rl((float)(gsl_hypot3_((double)i, (double)j, (double)k) / (pf * P)));
+    }
+    pad[e] = v;
+}
+
+__global__ __launch_bounds__(256) void k_scale_rl(float* __restrict__ rl, size_t n)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) rl[e] = (float)((double)rl[e] * (1.0 / (double)n));
+}
+
+// FSC shell sums (src/Functions/Spectrum.cpp:302-337): LDS-privatised per block, fp64 global atomics
+__global__ __launch_bounds__(256) void k_fsc_accum(double* __restrict__ acc, int nShell, const float2* __restrict__ A,
+                                                   const float2* __restrict__ B, int P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* s = reinterpret_cast<float*>(smem_raw);  // [3][nShell]
+    for (int q = threadIdx.x; q < 3 * nShell; q += blockDim.x) s[q] = 0.f;
+    __syncthreads();
+    const size_t n = (size_t)P * P * (P / 2 + 1);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        int i, j, k;
+        unpack_half(e, P, i, j, k);
+        const int u = (int)rint(gsl_hypot3_((double)i, (double)j, (double)k));
+        if (u < nShell) {
+            const float2 a = A[e], b = B[e];
+            atomicAdd(&s[u], a.x * b.x + a.y * b.y);
+            atomicAdd(&s[nShell + u], a.x * a.x + a.y * a.y);
+            atomicAdd(&s[2 * nShell + u], b.x * b.x + b.y * b.y);
+        }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < 3 * nShell; q += blockDim.x)
+        if (s[q] != 0.f) unsafeAtomicAdd(&acc[q], (double)s[q]);
+}
+
+__global__ void k_fsc_final(float* __restrict__ fsc, const double* __restrict__ acc, int nShell)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nShell) return;
+    const float vS = (float)acc[u], vA = (float)acc[nShell + u], vB = (float)acc[2 * nShell + u];
+    const float AB = sqrtf(vA * vB);
+    fsc[u] = (AB == 0) ? 0.f : vS / AB;
+}
+
+static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace thx
+
+using namespace thx;
+
+struct thx_reco {
+    int size, N, pf, PF, PN;
+    float a, alpha, nf;
+    float* tab;       // device, kTabN + 1
+    float* W;         // device, PF half grid (real)
+    float2* C;        // device, max(PF, PN) half grid
+    float* rl;        // device, max(PF, PN)^3
+    unsigned* diff;   // device scalar
+    float* fscDev;    // device, up to 4096 shells
+    hipfftHandle r2cF, c2rF, r2cN, c2rN;
+    bool haveN;
+};
+
+extern "C" {
+
+int thx_reco_create(thx_reco** out, int size, int N, int pf, float a, float alpha)
+{
+    THX_REQUIRE(out, "out is NULL");
+    THX_REQUIRE(size > 0 && N >= size && pf >= 1 && (size % 2 == 0) && (N % 2 == 0), "bad size / N / pf");
+    thx_reco* r = new thx_reco();
+    memset(r, 0, sizeof(*r));
+    r->size = size; r->N = N; r->pf = pf; r->PF = pf * size; r->PN = pf * N; r->a = a; r->alpha = alpha;
+    r->nf = mkb_rl(0.f, a, alpha);  // nf = MKB_RL(0, _a, _alpha), src/Reconstructor.cpp:2600
+    std::vector<float> tab(kTabN + 1);
+    {
+        const float ta = 0.f, tb = 1.f;
+        const float s = (tb - ta) / kTabN;
+        for (int i = 0; i <= kTabN; i++) tab[i] = mkb_rl_r2(ta + i * s, a, alpha);
+    }
+    const int PM = r->PN > r->PF ? r->PN : r->PF;
+    const size_t nHalfF = (size_t)r->PF * r->PF * (r->PF / 2 + 1);
+    const size_t nHalfM = (size_t)PM * PM * (PM / 2 + 1);
+    THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->tab), (kTabN + 1) * sizeof(float)));
+    THX_CHECK(hipMemcpy(r->tab, tab.data(), (kTabN + 1) * sizeof(float), hipMemcpyHostToDevice));
+    THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->W), nHalfF * sizeof(float)));
+    THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->C), nHalfM * sizeof(float2)));
+    THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->rl), (size_t)PM * PM * PM * sizeof(float)));
+    THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->diff), sizeof(unsigned)));
+    THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->fscDev), 4096 * sizeof(float)));
+    THX_FFT_CHECK(hipfftPlan3d(&r->r2cF, r->PF, r->PF, r->PF, HIPFFT_R2C));
+    THX_FFT_CHECK(hipfftPlan3d(&r->c2rF, r->PF, r->PF, r->PF, HIPFFT_C2R));
+    r->haveN = r->PN != r->PF;
+    if (r->haveN) {
+        THX_FFT_CHECK(hipfftPlan3d(&r->r2cN, r->PN, r->PN, r->PN, HIPFFT_R2C));
+        THX_FFT_CHECK(hipfftPlan3d(&r->c2rN, r->PN, r->PN, r->PN, HIPFFT_C2R));
+    } else {
+        r->r2cN = r->r2cF;
+        r->c2rN = r->c2rF;
+    }
+    *out = r;
+    return 0;
+}
+
+int thx_reco_destroy(thx_reco* r)
+{
+    if (!r) return 0;
+    (void)hipfftDestroy(r->r2cF);
+    (void)hipfftDestroy(r->c2rF);
+    if (r->haveN) {
+        (void)hipfftDestroy(r->r2cN);
+        (void)hipfftDestroy(r->c2rN);
+    }
+    (void)hipFree(r->tab); (void)hipFree(r->W); (void)hipFree(r->C); (void)hipFree(r->rl); (void)hipFree(r->diff); (void)hipFree(r->fscDev);
+    delete r;
+    return 0;
+}
+
+int thx_reco_reconstruct_dev(thx_reco* r, const float* F, float* T, int maxRadius, const float* FSC_host, int nFSC,
+                             int joinHalf, int MAP, int gridCorr, float* dstRL, int* nIterOut, float* diffCOut,
+                             void* stream)
+{
+    THX_REQUIRE(r && F && T && dstRL, "NULL pointer");
+    THX_REQUIRE(!MAP || (FSC_host && nFSC > 0 && nFSC <= 4096), "MAP needs an FSC vector (<= 4096 shells)");
+    THX_REQUIRE(maxRadius * r->pf < r->PF / 2 - 1, "maxRadius too large for the reconstruction grid");
+    hipStream_t st = as_stream(stream);
+    const int PF = r->PF, PN = r->PN, pf = r->pf;
+    const size_t nHalfF = (size_t)PF * PF * (PF / 2 + 1);
+    const size_t nHalfN = (size_t)PN * PN * (PN / 2 + 1);
+    THX_FFT_CHECK(hipfftSetStream(r->r2cF, st));
+    THX_FFT_CHECK(hipfftSetStream(r->c2rF, st));
+    if (r->haveN) {
+        THX_FFT_CHECK(hipfftSetStream(r->r2cN, st));
+        THX_FFT_CHECK(hipfftSetStream(r->c2rN, st));
+    }
+    if (MAP) {
+        THX_CHECK(hipMemcpyAsync(r->fscDev, FSC_host, nFSC * sizeof(float), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_wiener_T, dim3(nblk(nHalfF)), dim3(256), 0, st, T, PF, pf, maxRadius, r->fscDev, nFSC,
+                           joinHalf);
+    }
+    hipLaunchKernelGGL(k_initW_floorT, dim3(nblk(nHalfF)), dim3(256), 0, st, r->W, T, PF, pf, maxRadius);
+    int iters = 0;
+    float diffC = 3.402823466e+38f, diffCPrev = 3.402823466e+38f;
+    if (gridCorr) {
+        int nNoDec = 0;
+        for (int m = 0; m < 30; m++) {  // MAX_N_ITER_BALANCE
+            hipLaunchKernelGGL(k_calcC, dim3(nblk(nHalfF)), dim3(256), 0, st, r->C, T, r->W, nHalfF);
+            THX_FFT_CHECK(hipfftExecC2R(r->c2rF, reinterpret_cast<hipfftComplex*>(r->C), r->rl));
+            hipLaunchKernelGGL(k_convolute_rl, dim3(nblk((size_t)PF * PF * PF)), dim3(256), 0, st, r->rl, PF, r->N * pf,
+                               r->tab, r->nf);
+            THX_FFT_CHECK(hipfftExecR2C(r->r2cF, r->rl, reinterpret_cast<hipfftComplex*>(r->C)));
+            THX_CHECK(hipMemsetAsync(r->diff, 0, sizeof(unsigned), st));
+            hipLaunchKernelGGL(k_updateW_checkC, dim3(nblk(nHalfF)), dim3(256), 0, st, r->W, r->C, PF, pf, maxRadius,
+                               r->diff);
+            unsigned bits = 0;
+            THX_CHECK(hipMemcpyAsync(&bits, r->diff, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            THX_CHECK(hipStreamSynchronize(st));
+            diffCPrev = diffC;
+            memcpy(&diffC, &bits, sizeof(float));
+            iters = m + 1;
+            // src/Reconstructor.cpp:1542-1550 (DIFF_C_DECREASE_THRES 0.95, DIFF_C_THRES 1e-2, MIN_N_ITER_BALANCE 10,
+            // N_DIFF_C_NO_DECREASE 2); the comparisons run in double against RFLOAT operands as in the reference
+            if ((double)diffC > (double)diffCPrev * 0.95) nNoDec += 1; else nNoDec = 0;
+            if (((double)diffC < 1e-2) || ((m >= 10) && (nNoDec == 2))) break;
+        }
+    } else {
+        hipLaunchKernelGGL(k_W_nogridcorr, dim3(nblk(nHalfF)), dim3(256), 0, st, r->W, T, PF, pf, maxRadius);
+    }
+    hipLaunchKernelGGL(k_FW, dim3(nblk(nHalfN)), dim3(256), 0, st, r->C, PN, reinterpret_cast<const float2*>(F), r->W, PF, pf,
+                       maxRadius);
+    THX_FFT_CHECK(hipfftExecC2R(r->c2rN, reinterpret_cast<hipfftComplex*>(r->C), r->rl));
+    hipLaunchKernelGGL(k_extract_tik, dim3(nblk((size_t)r->N * r->N * r->N)), dim3(256), 0, st, dstRL, r->rl, PN, r->N, pf, 1);
+    THX_LAUNCH_CHECK();
+    if (nIterOut) *nIterOut = iters;
+    if (diffCOut) *diffCOut = diffC;
+    return 0;
+}
+
+int thx_reco_set_projectee_dev(thx_reco* r, const float* refRL, float* volume, void* stream)
+{
+    THX_REQUIRE(r && refRL && volume, "NULL pointer");
+    hipStream_t st = as_stream(stream);
+    const int PN = r->PN;
+    THX_FFT_CHECK(hipfftSetStream(r->r2cN, st));
+    hipLaunchKernelGGL(k_pad_gridcorr, dim3(nblk((size_t)PN * PN * PN)), dim3(256), 0, st, r->rl, refRL, r->N, r->pf);
+    THX_LAUNCH_CHECK();
+    THX_FFT_CHECK(hipfftExecR2C(r->r2cN, r->rl, reinterpret_cast<hipfftComplex*>(volume)));
+    return 0;
+}
+
+int thx_fft3d_fw_dev(const float* rl, float* ft, int n, void* stream)
+{
+    THX_REQUIRE(rl && ft, "NULL pointer");
+    hipfftHandle p;
+    THX_FFT_CHECK(hipfftPlan3d(&p, n, n, n, HIPFFT_R2C));
+    THX_FFT_CHECK(hipfftSetStream(p, as_stream(stream)));
+    THX_FFT_CHECK(hipfftExecR2C(p, const_cast<float*>(rl), reinterpret_cast<hipfftComplex*>(ft)));
+    THX_CHECK(hipStreamSynchronize(as_stream(stream)));
+    (void)hipfftDestroy(p);
+    return 0;
+}
+
+int thx_fft3d_bw_dev(float* ft, float* rl, int n, void* stream)
+{
+    THX_REQUIRE(rl && ft, "NULL pointer");
+    hipfftHandle p;
+    THX_FFT_CHECK(hipfftPlan3d(&p, n, n, n, HIPFFT_C2R));
+    THX_FFT_CHECK(hipfftSetStream(p, as_stream(stream)));
+    THX_FFT_CHECK(hipfftExecC2R(p, reinterpret_cast<hipfftComplex*>(ft), rl));
+    hipLaunchKernelGGL(k_scale_rl, dim3(nblk((size_t)n * n * n)), dim3(256), 0, as_stream(stream), rl, (size_t)n * n * n);
+    THX_CHECK(hipStreamSynchronize(as_stream(stream)));
+    (void)hipfftDestroy(p);
+    return 0;
+}
+
+int thx_fsc_dev(float* fsc, int nShell, const float* A, const float* B, int dim, void* stream)
+{
+    THX_REQUIRE(fsc && A && B && nShell > 0 && nShell <= 4096, "bad arguments");
+    hipStream_t st = as_stream(stream);
+    double* acc = nullptr;
+    THX_CHECK(hipMallocAsync(reinterpret_cast<void**>(&acc), 3 * nShell * sizeof(double), st));
+    THX_CHECK(hipMemsetAsync(acc, 0, 3 * nShell * sizeof(double), st));
+    hipLaunchKernelGGL(k_fsc_accum, dim3(1024), dim3(256), 3 * nShell * sizeof(float), st, acc, nShell,
+                       reinterpret_cast<const float2*>(A), reinterpret_cast<const float2*>(B), dim);
+    hipLaunchKernelGGL(k_fsc_final, dim3((nShell + 255) / 256), dim3(256), 0, st, fsc, acc, nShell);
+    THX_LAUNCH_CHECK();
+    THX_CHECK(hipFreeAsync(acc, st));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,226 @@
+"""Torch-tensor front-end of the C ABI: thin argument marshalling only (no arithmetic happens here).
+
+Every function takes CUDA(HIP) tensors already resident in HBM and enqueues on torch's current stream.
+Names follow the reference (thuem/THUNDER): project, translate, CTF, logDataVSPrior, insert, prepareTF ...
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+from .capi import CtfAttr, ptr, stream_ptr
+
+_F32, _F64, _I32, _C64 = torch.float32, torch.float64, torch.int32, torch.complex64
+
+
+def _chk(t, dtype, name):
+    assert t.is_cuda, name + " must be a device tensor"
+    assert t.dtype == dtype, "%s must be %s, got %s" % (name, dtype, t.dtype)
+    assert t.is_contiguous(), name + " must be contiguous"
+    return t
+
+
+def device_count():
+    n = C.c_int(0)
+    capi.call("thx_device_count", C.byref(n))
+    return n.value
+
+
+def ctf_attr_tensor(attrs, device):
+    """list of 7-tuples (voltage, defocusU, defocusV, theta, Cs, ampContrast, phaseShift) -> [n][7] float32"""
+    a = np.asarray(attrs, dtype=np.float32).reshape(-1, 7)
+    return torch.from_numpy(a).to(device)
+
+
+def rotmat(quat):
+    """rotate3D(dmat33&, dvec4) src/Geometry/Euler.cpp:181-189: [n][4] f64 -> [n][9] f64 column-major"""
+    _chk(quat, _F64, "quat")
+    n = quat.numel() // 4
+    out = torch.empty((n, 9), dtype=_F64, device=quat.device)
+    capi.call("thx_rotmat_dev", ptr(quat), ptr(out), n, stream_ptr())
+    return out
+
+
+def translate(trans, iCol, iRow, idim):
+    """translate() src/Image/ImageFunctions.cpp:233-252: trans [nT][2] f64 -> [nT][nPxl] complex64"""
+    _chk(trans, _F64, "trans"); _chk(iCol, _I32, "iCol"); _chk(iRow, _I32, "iRow")
+    nT, nPxl = trans.numel() // 2, iCol.numel()
+    out = torch.empty((nT, nPxl), dtype=_C64, device=trans.device)
+    capi.call("thx_translate_dev", ptr(out), ptr(trans), nT, ptr(iCol), ptr(iRow), nPxl, idim, stream_ptr())
+    return out
+
+
+def ctf(attr, pixelSize, iCol, iRow, idim, dfac=None):
+    """CTF(RFLOAT* dst, ...) src/CTF.cpp:113-151 for nImg images: attr [nImg][7] f32 -> [nImg][nPxl] f32"""
+    _chk(attr, _F32, "attr"); _chk(iCol, _I32, "iCol"); _chk(iRow, _I32, "iRow")
+    nImg, nPxl = attr.shape[0], iCol.numel()
+    if dfac is not None:
+        _chk(dfac, _F64, "dfac")
+    out = torch.empty((nImg, nPxl), dtype=_F32, device=attr.device)
+    capi.call("thx_ctf_dev", ptr(out), ptr(attr), ptr(dfac), float(pixelSize), ptr(iCol), ptr(iRow), nPxl, idim, nImg,
+              stream_ptr())
+    return out
+
+
+def gather_pixels(img, iPxl, idim):
+    """allocPreCal gather src/Optimiser.cpp:8055-8075: img [nImg][idim][idim/2+1] c64 -> [nImg][nPxl] c64"""
+    _chk(img, _C64, "img"); _chk(iPxl, _I32, "iPxl")
+    nImg, nPxl = img.shape[0], iPxl.numel()
+    out = torch.empty((nImg, nPxl), dtype=_C64, device=img.device)
+    capi.call("thx_gather_pixels_dev", ptr(out), ptr(img), ptr(iPxl), nPxl, idim, nImg, stream_ptr())
+    return out
+
+
+def project(volume, rotMat, iCol, iRow, pf, out=None):
+    """Projector::project src/Projector.cpp:356-374 for [nR][9] matrices -> [nR][nPxl] complex64"""
+    _chk(volume, _C64, "volume"); _chk(rotMat, _F64, "rotMat"); _chk(iCol, _I32, "iCol"); _chk(iRow, _I32, "iRow")
+    vdim = volume.shape[0]
+    nR, nPxl = rotMat.numel() // 9, iCol.numel()
+    if out is None:
+        out = torch.empty((nR, nPxl), dtype=_C64, device=volume.device)
+    capi.call("thx_project_dev", ptr(volume), ptr(out), ptr(rotMat), ptr(iCol), ptr(iRow), nR, pf, vdim, nPxl,
+              stream_ptr())
+    return out
+
+
+def logDataVSPrior(dat, pri, ctf_, sigRcp):
+    """logDataVSPrior_m_huabin src/Optimiser.cpp:9187-9213 for pri rows [n][nPxl] against one image row"""
+    _chk(dat, _C64, "dat"); _chk(pri, _C64, "pri"); _chk(ctf_, _F32, "ctf"); _chk(sigRcp, _F32, "sigRcp")
+    nPxl = dat.numel()
+    n = pri.numel() // nPxl
+    out = torch.empty(n, dtype=_F32, device=dat.device)
+    capi.call("thx_logdatavsprior_dev", ptr(out), ptr(dat), ptr(pri), ptr(ctf_), ptr(sigRcp), n, nPxl, stream_ptr())
+    return out
+
+
+class ExpectLocalResult:
+    __slots__ = ("wC", "wR", "wT", "wD", "baseLine", "logW")
+
+
+def expect_local(volumes, vdim, pf, idim, iCol, iRow, datP, ctfP, sigRcpP, rotMat, trans, nD=1, volIdx=None, pC=None,
+                 pR=None, pT=None, pD=None, want_logW=False, workspace=None):
+    """One particle-filter phase for a batch of images (src/Optimiser.cpp:1225-1406); see thunder_amd.h."""
+    dev = datP.device
+    _chk(volumes, _C64, "volumes"); _chk(datP, _C64, "datP"); _chk(ctfP, _F32, "ctfP"); _chk(sigRcpP, _F32, "sigRcpP")
+    _chk(rotMat, _F64, "rotMat"); _chk(trans, _F64, "trans")
+    nImg, nPxl = datP.shape[0], datP.shape[1]
+    nR = rotMat.numel() // (9 * nImg)
+    nT = trans.numel() // (2 * nImg)
+    ones = lambda *s: torch.ones(s, dtype=_F64, device=dev)
+    pC = ones(nImg) if pC is None else _chk(pC, _F64, "pC")
+    pR = ones(nImg, nR) if pR is None else _chk(pR, _F64, "pR")
+    pT = ones(nImg, nT) if pT is None else _chk(pT, _F64, "pT")
+    pD = ones(nImg, nD) if pD is None else _chk(pD, _F64, "pD")
+    if volIdx is not None:
+        _chk(volIdx, _I32, "volIdx")
+    res = ExpectLocalResult()
+    res.wC = torch.empty(nImg, dtype=_F32, device=dev)
+    res.wR = torch.empty((nImg, nR), dtype=_F32, device=dev)
+    res.wT = torch.empty((nImg, nT), dtype=_F32, device=dev)
+    res.wD = torch.empty((nImg, nD), dtype=_F32, device=dev)
+    res.baseLine = torch.empty(nImg, dtype=_F32, device=dev)
+    res.logW = torch.empty((nImg, nD, nT, nR), dtype=_F32, device=dev) if want_logW else None
+    need = capi.load().thx_expect_local_workspace(nImg, nR, nT, nD)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    capi.call("thx_expect_local_dev", ptr(volumes), ptr(volIdx), vdim, pf, idim, ptr(iCol), ptr(iRow), nPxl, nImg,
+              ptr(datP), ptr(ctfP), ptr(sigRcpP), ptr(rotMat), nR, ptr(trans), nT, nD, ptr(pC), ptr(pR), ptr(pT),
+              ptr(pD), ptr(res.wC), ptr(res.wR), ptr(res.wT), ptr(res.wD), ptr(res.baseLine), ptr(res.logW),
+              ptr(workspace), stream_ptr())
+    return res
+
+
+def expect_global(rotP, traP, datP, ctfP, sigRcpP, pR, pT, wC, wR, wT, baseL, kIdx, nK, workspace=None):
+    """Scanning phase for class kIdx (src/Optimiser.cpp:756-894); wC/wR/wT/baseL updated in place."""
+    nR, nPxl = rotP.shape
+    nT = traP.shape[0]
+    nImg = datP.shape[0]
+    need = capi.load().thx_expect_global_workspace(nImg, nR, nT)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=datP.device)
+    capi.call("thx_expect_global_dev", ptr(rotP), ptr(traP), ptr(datP), ptr(ctfP), ptr(sigRcpP), ptr(pR), ptr(pT),
+              ptr(wC), ptr(wR), ptr(wT), ptr(baseL), kIdx, nK, nR, nT, nPxl, nImg, ptr(workspace), stream_ptr())
+
+
+def insert(F, T, dim, datP, ctfP, w, rotMat, trans, iCol, iRow, opf, idim, O=None, counter=None, offS=None, cls=None,
+           attr=None, dfac=None, cSearch=False, pixelSize=1.0, nK=1):
+    """HOT LOOP C / Reconstructor::insertP for a batch (src/Optimiser.cpp:7038-7241); F, T accumulated in place."""
+    _chk(F, _C64, "F"); _chk(T, _F32, "T"); _chk(datP, _C64, "datP"); _chk(ctfP, _F32, "ctfP"); _chk(w, _F32, "w")
+    _chk(rotMat, _F64, "rotMat"); _chk(trans, _F64, "trans")
+    nImg, nPxl = datP.shape[0], datP.shape[1]
+    mReco = rotMat.numel() // (9 * nImg)
+    capi.call("thx_insert_dev", ptr(F), ptr(T), ptr(O), ptr(counter), dim, nK, ptr(datP), ptr(ctfP), ptr(w),
+              ptr(rotMat), ptr(trans), ptr(offS), ptr(cls), ptr(attr), ptr(dfac), 1 if cSearch else 0,
+              float(pixelSize), ptr(iCol), ptr(iRow), opf, nPxl, mReco, idim, nImg, stream_ptr())
+
+
+def normalise_TF(F, T, dim):
+    capi.call("thx_normalise_tf_dev", ptr(F), ptr(T), dim, stream_ptr())
+
+
+def symmetrize(src, dim, symMat, r):
+    """SYMMETRIZE_FT; symMat: host numpy [nSym][9] f64 column-major; returns a new tensor"""
+    symMat = np.ascontiguousarray(np.asarray(symMat, dtype=np.float64).reshape(-1, 9))
+    dst = torch.empty_like(src)
+    capi.call("thx_symmetrize_dev", ptr(dst), ptr(src), dim, 1 if src.dtype == _C64 else 0,
+              symMat.ctypes.data if len(symMat) else None, len(symMat), float(r), stream_ptr())
+    return dst
+
+
+def fsc(A, B, dim, nShell):
+    out = torch.empty(nShell, dtype=_F32, device=A.device)
+    capi.call("thx_fsc_dev", ptr(out), nShell, ptr(A), ptr(B), dim, stream_ptr())
+    return out
+
+
+def fft3d_fw(rl):
+    n = rl.shape[0]
+    ft = torch.empty((n, n, n // 2 + 1), dtype=_C64, device=rl.device)
+    capi.call("thx_fft3d_fw_dev", ptr(rl), ptr(ft), n, stream_ptr())
+    return ft
+
+
+class RecoPlan:
+    """thx_reco handle: Reconstructor::allocSpace state (FFT plans, W, C, kernel table)."""
+
+    def __init__(self, size, N, pf=2, a=1.9, alpha=15.0):
+        self.size, self.N, self.pf = size, N, pf
+        h = C.c_void_p()
+        capi.call("thx_reco_create", C.byref(h), size, N, pf, a, alpha)
+        self._h = h
+
+    def close(self):
+        if self._h is not None:
+            capi.call("thx_reco_destroy", self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reconstruct(self, F, T, maxRadius, FSC=None, joinHalf=False, MAP=True, gridCorr=True):
+        """Reconstructor::reconstruct (src/Reconstructor.cpp:1129-1831). T is modified in place (as the reference)."""
+        _chk(F, _C64, "F"); _chk(T, _F32, "T")
+        dst = torch.empty((self.N,) * 3, dtype=_F32, device=F.device)
+        fsc_h = None
+        nF = 0
+        if MAP:
+            fsc_h = np.ascontiguousarray(np.asarray(FSC, dtype=np.float32))
+            nF = len(fsc_h)
+        it, dc = C.c_int(0), C.c_float(0)
+        capi.call("thx_reco_reconstruct_dev", self._h, ptr(F), ptr(T), maxRadius,
+                  fsc_h.ctypes.data if fsc_h is not None else None, nF, 1 if joinHalf else 0, 1 if MAP else 0,
+                  1 if gridCorr else 0, ptr(dst), C.byref(it), C.byref(dc), stream_ptr())
+        self.last_iters, self.last_diffC = it.value, dc.value
+        return dst
+
+    def set_projectee(self, refRL):
+        """Projector::setProjectee (src/Projector.cpp:123-148) from the real-space map -> padded FT"""
+        _chk(refRL, _F32, "refRL")
+        P = self.N * self.pf
+        vol = torch.empty((P, P, P // 2 + 1), dtype=_C64, device=refRL.device)
+        capi.call("thx_reco_set_projectee_dev", self._h, ptr(refRL), ptr(vol), stream_ptr())
+        return vol
