@@ -451,8 +451,19 @@ def test_host_interface_entry_points(oracle, dev):
     O.normalise_TF(Fo, To, P)
     Fo, To = O.symmetrize(Fo, P, sym, (N // 2 - 2) * 2 + 1), O.symmetrize(To, P, sym, (N // 2 - 2) * 2 + 1)
     assert np.abs(F - Fo).max() <= 2e-5 * np.abs(Fo).max()
+    # reconstructG on a well-covered data set (20 sparse inserts leave the W iteration ill-conditioned: its output then
+    # amplifies last-bit differences of the FFTs), identical host inputs on both sides
+    Fo = np.zeros((P, P, P // 2 + 1), np.complex64)
+    To = np.zeros((P, P, P // 2 + 1), np.float32)
+    one = np.ones(pl["nPxl"], np.float32)
+    for q in synth.random_quats(400, rng):
+        R = O.rotate3D(q)
+        O.insertP(Fo, To, P, O.project(vol, P, 2, R, pl["iCol"], pl["iRow"]), one, R, 1.0, pl["iColPad"], pl["iRowPad"])
+    O.normalise_TF(Fo, To, P)
+    Tin = np.zeros((P, P, P // 2 + 1), np.complex64)
+    Tin.real = To
     dst = np.zeros((N, N, N), np.float32)
-    capi.call("thx_ReconstructG_host", 0, F.ctypes.data, Tc.ctypes.data, N, N, 2, N // 2 - 2, 1.9, 15.0, None, 0, 0, 0, 1,
-              dst.ctypes.data)
+    capi.call("thx_ReconstructG_host", 0, Fo.ctypes.data, Tin.ctypes.data, N, N, 2, N // 2 - 2, 1.9, 15.0, None, 0, 0, 0,
+              1, dst.ctypes.data)
     want = O.reconstruct(Fo, To, P, N, 2, N // 2 - 2, MAP=False, gridCorr=True)
-    assert np.abs(dst - want).max() <= 2e-3 * np.abs(want).max()
+    assert np.abs(dst - want).max() <= 1e-4 * np.abs(want).max()

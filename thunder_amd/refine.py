@@ -1,0 +1,265 @@
+"""One refinement iteration of the hot path on one GPU's shard of particles.
+
+Host-side mirror of the reference's per-iteration control flow, restricted to the path in scope:
+    Optimiser::expectation   (src/Optimiser.cpp:1141-1660, local particle-filter phases)
+    Optimiser::maximization  -> reconstructRef (src/Optimiser.cpp:6711-7766): insert, prepareTF, reconstruct x2
+    Model::compareTwoHemispheres FSC (src/Functions/Spectrum.cpp:302) and Model::refreshProj (src/Model.cpp:1013-1044)
+All arithmetic is in the HIP library (thunder_amd.ops -> C ABI); this file only sequences launches, owns the
+HBM-resident particle shard and does the half-set exchange over torch.distributed (RCCL on the GPU box, gloo in
+the CPU tests -- where `backend` is injected so the orchestration can be exercised without a GPU).
+
+The particle filter proper (Particle::perturb / resample, src/Particle.cpp) is host-side stochastic control and out of
+scope: the support points of every phase are fixed, seeded inputs (SURVEY 8d "fixed-work variant").
+Sharding: particle i belongs to half i mod 2; with world >= 2, rank r owns half r mod 2 (mirrors the
+reference's odd/even MPI hemispheres, src/Parallel.cpp:26-36) and the ranks of a half all-reduce F and T
+(MPI_Allreduce_Large over _hemi, src/Reconstructor.cpp:2383,2436); every rank of the half then reconstructs
+redundantly, as the reference's ranks do.
+"""
+import numpy as np
+import torch
+
+from . import synth
+
+
+class HalfGroups:
+    """the two hemisphere communicators (src/Parallel.cpp:38-57) on top of torch.distributed"""
+
+    def __init__(self, rank=0, world=1):
+        self.rank, self.world = rank, world
+        self.half = rank % 2
+        self.group = None
+        if world > 1:
+            import torch.distributed as dist
+            groups = []
+            for h in (0, 1):
+                ranks = [r for r in range(world) if r % 2 == h]
+                groups.append(dist.new_group(ranks=ranks))
+            self.group = groups[self.half]
+            self.leaders = (0, 1)
+
+    def local_halves(self):
+        return (0, 1) if self.world == 1 else (self.half,)
+
+    def allreduce_half(self, t):
+        if self.world > 2:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def exchange_half_maps(self, maps):
+        """every rank ends up with both half maps (the reference sends them to the master for FSC,
+        src/Model.cpp:375-391; here they are broadcast from the two half leaders)"""
+        if self.world == 1:
+            return maps[0], maps[1]
+        import torch.distributed as dist
+        own = maps[self.half]
+        a = own.clone() if self.half == 0 else torch.empty_like(own)
+        b = own.clone() if self.half == 1 else torch.empty_like(own)
+        dist.broadcast(a, src=0)
+        dist.broadcast(b, src=1)
+        return a, b
+
+
+class RefineShard:
+    """HBM-resident shard of synthetic particles + one EM iteration over it (SURVEY 8d inputs)."""
+
+    def __init__(self, N, nImg, device, rank=0, world=1, pf=2, mLR=125, mLT=9, nPhase=3, mReco=100, seed=1000,
+                 batch=2048, pixelSize=1.32, snr=0.01, rL=2, ops=None, oracle_pixel_list=None):
+        if ops is None:
+            from . import ops as _ops
+            ops = _ops
+        self.ops = ops
+        self.N, self.pf, self.P = N, pf, N * pf
+        self.nImg, self.dev, self.rank, self.world = nImg, device, rank, world
+        self.mLR, self.mLT, self.nPhase, self.mReco, self.batch = mLR, mLT, nPhase, mReco, batch
+        self.rU = N // 2 - 2
+        self.maxRadius = self.rU
+        self.groups = HalfGroups(rank, world)
+        self.halves = self.groups.local_halves()
+        rng = np.random.default_rng(seed + 7919 * rank)
+        # ---- pixel list (Optimiser::allocPreCalIdx): integer work, built on the host ----
+        # expectation: allocPreCalIdx(_r, _rL) (src/Optimiser.cpp:631); reconstruction: allocPreCalIdx(rU, 0) (:6722)
+        pl = pixel_list(N, self.rU, rL, pf)
+        plM = pixel_list(N, self.rU, 0, pf)
+        self.pl, self.plM = pl, plM
+        self.nPxl, self.nPxlM = pl["nPxl"], plM["nPxl"]
+        self.iCol = torch.from_numpy(pl["iCol"]).to(device)
+        self.iRow = torch.from_numpy(pl["iRow"]).to(device)
+        self.iColM = torch.from_numpy(plM["iCol"]).to(device)
+        self.iRowM = torch.from_numpy(plM["iRow"]).to(device)
+        pos = {(int(i), int(j)): k for k, (i, j) in enumerate(zip(plM["iCol"], plM["iRow"]))}
+        e2m = torch.from_numpy(np.asarray([pos[(int(i), int(j))] for i, j in zip(pl["iCol"], pl["iRow"])],
+                                          np.int64)).to(device)
+        # ---- reference map and its projector volumes (one per local half) ----
+        self.ref = torch.from_numpy(synth.blob_map(N)).to(device)
+        self.plan = ops.RecoPlan(N, N, pf)
+        v = self.plan.set_projectee(self.ref)
+        self.vols = torch.stack([v] * len(self.halves)).contiguous()
+        # ---- particles: pose, shift, CTF, noisy image on the pixel list ----
+        self.quat = synth.random_quats(nImg, rng)
+        self.shift = rng.normal(0, 2.0, size=(nImg, 2))
+        self.attr = torch.from_numpy(synth.ctf_params(nImg, rng)).to(device)
+        gidx = np.arange(nImg)
+        self.half_of = (gidx % 2).astype(np.int32) if world == 1 else np.full(nImg, self.groups.half, np.int32)
+        self.volIdx = torch.from_numpy(self.half_of if world == 1 else np.zeros(nImg, np.int32)).to(device)
+        # M-step rows (_imgOri on the rL = 0 list); the E-step rows are the subset on the (r, rL) list
+        self.datM = torch.empty((nImg, self.nPxlM), dtype=torch.complex64, device=device)
+        self.ctfM = ops.ctf(self.attr, pixelSize, self.iColM, self.iRowM, N)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed + 31 * rank)
+        for b0 in range(0, nImg, batch):
+            b1 = min(nImg, b0 + batch)
+            rot = ops.rotmat(torch.from_numpy(self.quat[b0:b1]).to(device))
+            sl = ops.project(v, rot, self.iColM, self.iRowM, pf)
+            ramp = ops.translate(torch.from_numpy(self.shift[b0:b1]).to(device), self.iColM, self.iRowM, N)
+            sig = sl * ramp * self.ctfM[b0:b1]
+            if b0 == 0:
+                p_sig = float((sig.abs() ** 2).mean().item())
+                self.sigma2 = p_sig / snr / 2.0  # per real component
+            noise = torch.randn((b1 - b0, self.nPxlM, 2), generator=gen, device=device, dtype=torch.float32)
+            self.datM[b0:b1] = sig + torch.view_as_complex(noise) * float(np.sqrt(self.sigma2))
+        self.datP = self.datM[:, e2m].contiguous()
+        self.ctfP = self.ctfM[:, e2m].contiguous()
+        self.sigRcpP = torch.full((nImg, self.nPxl), -0.5 / self.sigma2, dtype=torch.float32, device=device)
+        # ---- fixed-work support points for every phase (seeded) ----
+        stds = [0.02 / (2 ** p) for p in range(nPhase)]
+        self.rotP, self.tranP = [], []
+        for p in range(nPhase):
+            q = synth.perturb_quats(self.quat, mLR, stds[p], rng)
+            self.rotP.append(ops.rotmat(torch.from_numpy(q.reshape(-1, 4)).to(device)).reshape(nImg, mLR, 9))
+            t = self.shift[:, None, :] + rng.normal(0, 0.5 / (2 ** p), size=(nImg, mLT, 2))
+            t[:, 0, :] = self.shift
+            self.tranP.append(torch.from_numpy(np.ascontiguousarray(t)).to(device))
+        self.w = torch.full((nImg,), 1.0 / mReco, dtype=torch.float32, device=device)
+        nV = len(self.halves)
+        self.F = torch.zeros((nV, self.P, self.P, self.P // 2 + 1), dtype=torch.complex64, device=device)
+        self.T = torch.zeros((nV, self.P, self.P, self.P // 2 + 1), dtype=torch.float32, device=device)
+        self.cls = torch.from_numpy(np.repeat(self.half_of[:, None] if world == 1 else np.zeros((nImg, 1), np.int32),
+                                              mReco, axis=1).astype(np.int32)).contiguous().to(device)
+        need = 0
+        from . import capi
+        need = capi.load().thx_expect_local_workspace(min(batch, nImg), mLR, mLT, 1)
+        self.ws = torch.empty(need, dtype=torch.uint8, device=device)
+        self.gen = gen
+        self.insert_ms = []   # per-launch durations of the insertion kernel (HIP events on the launch stream)
+        self.expect_ms = []
+        self.last = {}
+
+    # -----------------------------------------------------------------------------------------
+    def expectation(self, timed=False):
+        """nPhase particle-filter phases over all local images (HOT LOOP B)"""
+        ops = self.ops
+        res_last = None
+        wR = torch.empty((self.nImg, self.mLR), dtype=torch.float32, device=self.dev)
+        wT = torch.empty((self.nImg, self.mLT), dtype=torch.float32, device=self.dev)
+        for p in range(self.nPhase):
+            for b0 in range(0, self.nImg, self.batch):
+                b1 = min(self.nImg, b0 + self.batch)
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                r = ops.expect_local(self.vols, self.P, self.pf, self.N, self.iCol, self.iRow, self.datP[b0:b1],
+                                     self.ctfP[b0:b1], self.sigRcpP[b0:b1], self.rotP[p][b0:b1], self.tranP[p][b0:b1],
+                                     nD=1, volIdx=self.volIdx[b0:b1], workspace=self.ws)
+                if timed:
+                    e1.record()
+                    self.expect_ms.append((e0, e1, b1 - b0))
+                if p == self.nPhase - 1:
+                    wR[b0:b1] = r.wR
+                    wT[b0:b1] = r.wT
+        self.last["wR"], self.last["wT"] = wR, wT
+        return wR, wT
+
+    def draw_reco(self, wR, wT):
+        """mReco draws per image from the last phase's support points by posterior weight (seeded); the reference's
+        Particle::rand picks uniformly among RESAMPLED points (src/Particle.cpp:2109-2178), which is the same law."""
+        p = self.nPhase - 1
+        iR = torch.multinomial(wR.clamp_min(1e-30), self.mReco, replacement=True, generator=self.gen)
+        iT = torch.multinomial(wT.clamp_min(1e-30), self.mReco, replacement=True, generator=self.gen)
+        rot = torch.gather(self.rotP[p], 1, iR[:, :, None].expand(-1, -1, 9)).contiguous()
+        tran = torch.gather(self.tranP[p], 1, iT[:, :, None].expand(-1, -1, 2)).contiguous()
+        return rot, tran
+
+    def insertion(self, rot, tran, timed=False):
+        """HOT LOOP C: mReco trilinear insertions per image into the local half volumes"""
+        ops = self.ops
+        self.F.zero_()
+        self.T.zero_()
+        for b0 in range(0, self.nImg, self.batch):
+            b1 = min(self.nImg, b0 + self.batch)
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            ops.insert(self.F, self.T, self.P, self.datM[b0:b1], self.ctfM[b0:b1], self.w[b0:b1], rot[b0:b1],
+                       tran[b0:b1], self.iColM, self.iRowM, self.pf, self.N, cls=self.cls[b0:b1], nK=self.F.shape[0])
+            if timed:
+                e1.record()
+                self.insert_ms.append((e0, e1, b1 - b0))
+
+    def maximization_tail(self):
+        """reduce within the half, prepareTF, reconstruct (MAP off) -> FSC -> reconstruct (MAP on), refresh projector"""
+        ops, g = self.ops, self.groups
+        maps = {}
+        for vi, h in enumerate(self.halves):
+            g.allreduce_half(self.T[vi])
+            g.allreduce_half(self.F[vi])
+            ops.normalise_TF(self.F[vi], self.T[vi], self.P)   # symmetry C1: no symmetrisation sweep
+            maps[h] = self.plan.reconstruct(self.F[vi], self.T[vi], self.maxRadius, MAP=False, gridCorr=True)
+        a, b = g.exchange_half_maps(maps)
+        fa, fb = ops.fft3d_fw(a), ops.fft3d_fw(b)
+        fsc = ops.fsc(fa, fb, self.N, self.N // 2).cpu().numpy()
+        self.last["fsc"] = fsc
+        for vi, h in enumerate(self.halves):
+            m = self.plan.reconstruct(self.F[vi], self.T[vi], self.maxRadius, FSC=fsc, joinHalf=False, MAP=True,
+                                      gridCorr=True)
+            maps[h] = m
+            self.vols[vi] = self.plan.set_projectee(m)   # Model::refreshProj
+        self.last["maps"] = maps
+        return fsc
+
+    def iteration(self, timed=False):
+        wR, wT = self.expectation(timed)
+        rot, tran = self.draw_reco(wR, wT)
+        self.insertion(rot, tran, timed)
+        return self.maximization_tail()
+
+    def reset_reference(self):
+        v = self.plan.set_projectee(self.ref)
+        for vi in range(self.vols.shape[0]):
+            self.vols[vi] = v
+
+
+def pixel_list(N, rU, rL, pf=2):
+    """Optimiser::allocPreCalIdx (src/Optimiser.cpp:7991-8041) -- host-side integer work of the product path
+    (its oracle twin is orc_pixel_list; tests compare the two)."""
+    iCol, iRow, iPxl, iSig = [], [], [], []
+    rU2, rL2 = np.float32(rU) ** 2, np.float32(rL) ** 2
+    lim = int(rU + 1)
+    for j in range(-lim, lim):
+        for i in range(0, lim + 1):
+            if i == 0 and j < 0:
+                continue
+            u = np.float32(i * i + j * j)
+            if u < rU2 and u >= rL2:
+                v = int(np.rint(np.hypot(float(i), float(j))))
+                if v < rU and v >= rL:
+                    iPxl.append((j if j >= 0 else j + N) * (N // 2 + 1) + i)
+                    iCol.append(i)
+                    iRow.append(j)
+                    iSig.append(v)
+    a = lambda x: np.asarray(x, np.int32)
+    return dict(iCol=a(iCol), iRow=a(iRow), iPxl=a(iPxl), iSig=a(iSig), iColPad=a(iCol) * pf, iRowPad=a(iRow) * pf,
+                nPxl=len(iCol))
+
+
+def shard_indices(nTotal, rank, world):
+    """global particle indices owned by `rank`: particle i belongs to half i mod 2 (gold-standard split); with
+    world >= 2 the ranks r with r mod 2 == h share half h round-robin (mirrors src/Parallel.cpp:26-36 +
+    Database::assign).  world == 1 owns everything."""
+    idx = np.arange(nTotal)
+    if world == 1:
+        return idx
+    h = rank % 2
+    mine = idx[idx % 2 == h]
+    peers = [r for r in range(world) if r % 2 == h]
+    return mine[peers.index(rank)::len(peers)]
