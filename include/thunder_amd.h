@@ -56,6 +56,15 @@ int thx_device_count(int* count);
 /* selects the device later calls on this thread use (the reference passes gpuIdx per call) */
 int thx_set_device(int gpuIdx);
 
+/* device-memory plumbing for hosts that do not link a HIP runtime themselves (the C++ Projector / Reconstructor
+ * mirrors in include/thunder_amd/ use only these; cuthunder.cu does the same job with cudaMalloc / cudaMemcpy) */
+int thx_malloc_dev(void** ptr, size_t bytes);
+int thx_free_dev(void* ptr);
+int thx_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int thx_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+int thx_memset_dev(void* dst_dev, int value, size_t bytes);
+int thx_device_sync(void);
+
 /* ---------------------------------------------------------------------------------------------
  * E-step building blocks
  * ------------------------------------------------------------------------------------------- */

@@ -1,0 +1,136 @@
+// Projector.hpp -- header-only C++ mirror of thuem/THUNDER's Projector (include/Projector.h:85-379) over the C ABI
+// of libthunder_amd.so.  Same method names, argument meaning and error behaviour (void + abort) for the methods on the
+// E-step hot path; host pointers in and out, the padded FT stays resident in HBM between calls.
+//
+// Types: `Complex` is {float dat[2]} as in include/Precision.h:100-109; `dmat33` arguments are passed as 9 doubles,
+// column-major (Eigen's default layout -- on the reference side pass mat.data()).
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../thunder_amd.h"
+
+namespace thunder_amd {
+
+struct Complex {
+    float dat[2];
+};
+
+#define THX_ABORT_ON(rc)                                                                     \
+    do {                                                                                     \
+        if ((rc) != 0) {                                                                     \
+            std::fprintf(stderr, "thunder_amd FATAL: %s (%s:%d)\n", thx_last_error(), __FILE__, __LINE__); \
+            std::abort(); /* REPORT_ERROR + abort(), include/Logging.h:28-34 */              \
+        }                                                                                    \
+    } while (0)
+
+class Projector {
+public:
+    Projector() : _mode(1), _maxRadius(-1), _interp(1), _pf(2), _N(0), _vol(nullptr), _plan(nullptr) {}
+    ~Projector() { clear(); }
+    Projector(const Projector&) = delete;             // BOOST_MOVABLE_BUT_NOT_COPYABLE, include/Projector.h:87
+    Projector& operator=(const Projector&) = delete;
+    Projector(Projector&& o) noexcept { steal(o); }
+    Projector& operator=(Projector&& o) noexcept { if (this != &o) { clear(); steal(o); } return *this; }
+    void swap(Projector& o) { Projector t(std::move(o)); o = std::move(*this); *this = std::move(t); }
+
+    int mode() const { return _mode; }
+    void setMode(int mode) { _mode = mode; }
+    int maxRadius() const { return _maxRadius; }
+    void setMaxRadius(int r) { _maxRadius = r; }
+    int interp() const { return _interp; }
+    void setInterp(int interp) { _interp = interp; }
+    int pf() const { return _pf; }
+    void setPf(int pf) { _pf = pf; }
+    int vdim() const { return _pf * _N; }
+    const float* projectee3D_dev() const { return _vol; }   // device pointer of the padded FT
+
+    // setProjectee(Volume src, nThread), src/Projector.cpp:123-148: src = FT of the N^3 reference (half-complex
+    // [N][N][N/2+1]); inverse FFT, zero-pad x pf, TIK grid correction, forward FFT -- all on the device.
+    void setProjectee(const Complex* srcFT, int N, unsigned int /*nThread*/ = 1)
+    {
+        alloc(N);
+        const size_t nh = (size_t)N * N * (N / 2 + 1);
+        void *ft = nullptr, *rl = nullptr;
+        THX_ABORT_ON(thx_malloc_dev(&ft, nh * 2 * sizeof(float)));
+        THX_ABORT_ON(thx_malloc_dev(&rl, (size_t)N * N * N * sizeof(float)));
+        THX_ABORT_ON(thx_memcpy_h2d(ft, srcFT, nh * 2 * sizeof(float)));
+        THX_ABORT_ON(thx_fft3d_bw_dev((float*)ft, (float*)rl, N, nullptr));
+        THX_ABORT_ON(thx_reco_set_projectee_dev(_plan, (const float*)rl, _vol, nullptr));
+        THX_ABORT_ON(thx_device_sync());
+        thx_free_dev(ft);
+        thx_free_dev(rl);
+        _maxRadius = (_pf * N) / _pf / 2 - 1;   // floor(MIN_3(nCol,nRow,nSlc) / pf / 2 - 1), :131-133
+    }
+
+    // same, starting from the real-space map [N][N][N] (wrapped index layout)
+    void setProjecteeRL(const float* srcRL, int N)
+    {
+        alloc(N);
+        void* rl = nullptr;
+        THX_ABORT_ON(thx_malloc_dev(&rl, (size_t)N * N * N * sizeof(float)));
+        THX_ABORT_ON(thx_memcpy_h2d(rl, srcRL, (size_t)N * N * N * sizeof(float)));
+        THX_ABORT_ON(thx_reco_set_projectee_dev(_plan, (const float*)rl, _vol, nullptr));
+        THX_ABORT_ON(thx_device_sync());
+        thx_free_dev(rl);
+        _maxRadius = N / 2 - 1;
+    }
+
+    // project(Complex* dst, const dmat33& mat, const int* iCol, const int* iRow, int nPxl, unsigned nThread) const,
+    // include/Projector.h:293-299, src/Projector.cpp:356-374.  const + stateless: callable from many OpenMP threads.
+    void project(Complex* dst, const double* mat, const int* iCol, const int* iRow, int nPxl,
+                 unsigned int /*nThread*/ = 1) const
+    {
+        projectBatch(dst, mat, 1, iCol, iRow, nPxl);
+    }
+
+    // nR matrices at once (what ExpectProject does, Interface.h:210-219): dst [nR][nPxl]
+    void projectBatch(Complex* dst, const double* mats, int nR, const int* iCol, const int* iRow, int nPxl) const
+    {
+        if (!_vol) { std::fprintf(stderr, "thunder_amd FATAL: Projector has no projectee\n"); std::abort(); }
+        void *dOut = nullptr, *dMat = nullptr, *dCol = nullptr, *dRow = nullptr;
+        THX_ABORT_ON(thx_malloc_dev(&dOut, (size_t)nR * nPxl * 2 * sizeof(float)));
+        THX_ABORT_ON(thx_malloc_dev(&dMat, (size_t)nR * 9 * sizeof(double)));
+        THX_ABORT_ON(thx_malloc_dev(&dCol, (size_t)nPxl * sizeof(int)));
+        THX_ABORT_ON(thx_malloc_dev(&dRow, (size_t)nPxl * sizeof(int)));
+        THX_ABORT_ON(thx_memcpy_h2d(dMat, mats, (size_t)nR * 9 * sizeof(double)));
+        THX_ABORT_ON(thx_memcpy_h2d(dCol, iCol, (size_t)nPxl * sizeof(int)));
+        THX_ABORT_ON(thx_memcpy_h2d(dRow, iRow, (size_t)nPxl * sizeof(int)));
+        THX_ABORT_ON(thx_project_dev(_vol, (float*)dOut, (const double*)dMat, (const int*)dCol, (const int*)dRow, nR, _pf,
+                                     _pf * _N, nPxl, nullptr));
+        THX_ABORT_ON(thx_memcpy_d2h(dst, dOut, (size_t)nR * nPxl * 2 * sizeof(float)));
+        thx_free_dev(dOut); thx_free_dev(dMat); thx_free_dev(dCol); thx_free_dev(dRow);
+    }
+
+private:
+    void alloc(int N)
+    {
+        if (_plan && N == _N) return;
+        clear();
+        _N = N;
+        THX_ABORT_ON(thx_reco_create(&_plan, N, N, _pf, 1.9f, 15.0f));
+        const int P = _pf * N;
+        void* v = nullptr;
+        THX_ABORT_ON(thx_malloc_dev(&v, (size_t)P * P * (P / 2 + 1) * 2 * sizeof(float)));
+        _vol = (float*)v;
+    }
+    void clear()
+    {
+        if (_vol) thx_free_dev(_vol);
+        if (_plan) thx_reco_destroy(_plan);
+        _vol = nullptr;
+        _plan = nullptr;
+    }
+    void steal(Projector& o)
+    {
+        _mode = o._mode; _maxRadius = o._maxRadius; _interp = o._interp; _pf = o._pf; _N = o._N;
+        _vol = o._vol; _plan = o._plan;
+        o._vol = nullptr; o._plan = nullptr;
+    }
+    int _mode, _maxRadius, _interp, _pf, _N;
+    float* _vol;
+    thx_reco* _plan;
+};
+
+}  // namespace thunder_amd

@@ -1,0 +1,210 @@
+// Reconstructor.hpp -- header-only C++ mirror of thuem/THUNDER's Reconstructor (include/Reconstructor.h:86-781) over
+// the C ABI of libthunder_amd.so, MODE_3D.  Same method names, argument meaning and error behaviour (void + abort) for
+// the methods on the M-step hot path: allocSpace / freeSpace / reset, setPreCal, insertP, insertDir, prepareTF,
+// reconstruct, the set* flags.  F and T live in HBM between allocSpace and freeSpace, as the reference's volumes live in
+// host memory between the same calls.
+//
+// insertP() is thread-safe like the reference's (atomic adds); it buffers nothing and pays one launch per call, so a
+// caller that owns whole images x draws should prefer insertBatch() (= InsertFT, Interface.h:267-318).
+// The MPI all-reduce inside the reference's prepareTF (MPI_Allreduce_Large over _hemi, src/Reconstructor.cpp:2383,2436)
+// is injected as a callback so that this header needs neither MPI nor RCCL headers.
+#pragma once
+#include <functional>
+#include <mutex>
+#include <vector>
+
+#include "Projector.hpp"
+
+namespace thunder_amd {
+
+class Reconstructor {
+public:
+    typedef std::function<void(float* dev, size_t nFloats)> AllReduce;  // in-place sum over the hemisphere
+
+    Reconstructor() : _plan(nullptr), _F(nullptr), _T(nullptr), _iCol(nullptr), _iRow(nullptr) { defaults(); }
+    // Reconstructor(mode, size, N, pf = 2, sym = NULL, a = 1.9, alpha = 15), include/Reconstructor.h ctor
+    Reconstructor(int mode, int size, int N, int pf = 2, const double* symMat = nullptr, int nSym = 0, float a = 1.9f,
+                  float alpha = 15.0f)
+        : _plan(nullptr), _F(nullptr), _T(nullptr), _iCol(nullptr), _iRow(nullptr)
+    {
+        defaults();
+        init(mode, size, N, pf, symMat, nSym, a, alpha);
+    }
+    ~Reconstructor() { freeSpace(); }
+    Reconstructor(const Reconstructor&) = delete;
+    Reconstructor& operator=(const Reconstructor&) = delete;
+
+    void init(int mode, int size, int N, int pf = 2, const double* symMat = nullptr, int nSym = 0, float a = 1.9f,
+              float alpha = 15.0f)
+    {
+        if (mode != 1) { std::fprintf(stderr, "thunder_amd FATAL: only MODE_3D is implemented\n"); std::abort(); }
+        _size = size; _N = N; _pf = pf; _a = a; _alpha = alpha;
+        _sym.assign(symMat, symMat + 9 * (size_t)nSym);
+        _maxRadius = size / 2 - (int)std::ceil(a);   // src/Reconstructor.cpp:89
+    }
+
+    // allocSpace(nThread), src/Reconstructor.cpp:92-136: FFT plans + F, W, C, T volumes, then reset()
+    void allocSpace(unsigned int /*nThread*/ = 1)
+    {
+        freeSpace();
+        THX_ABORT_ON(thx_reco_create(&_plan, _size, _N, _pf, _a, _alpha));
+        void* p = nullptr;
+        THX_ABORT_ON(thx_malloc_dev(&p, nVox() * 2 * sizeof(float)));
+        _F = (float*)p;
+        THX_ABORT_ON(thx_malloc_dev(&p, nVox() * sizeof(float)));
+        _T = (float*)p;
+        reset();
+    }
+    void freeSpace()
+    {
+        if (_plan) thx_reco_destroy(_plan);
+        if (_F) thx_free_dev(_F);
+        if (_T) thx_free_dev(_T);
+        if (_iCol) thx_free_dev(_iCol);
+        if (_iRow) thx_free_dev(_iRow);
+        _plan = nullptr; _F = _T = nullptr; _iCol = _iRow = nullptr;
+    }
+    void resizeSpace(int size) { _size = size; }   // src/Reconstructor.cpp:162-176 (allocSpace must follow)
+    // reset(nThread), src/Reconstructor.cpp:178-250
+    void reset(unsigned int /*nThread*/ = 1)
+    {
+        _MAP = true; _gridCorr = true; _joinHalf = false;
+        _ox = _oy = _oz = 0; _counter = 0; _nPxl = 0;
+        if (_F) THX_ABORT_ON(thx_memset_dev(_F, 0, nVox() * 2 * sizeof(float)));
+        if (_T) THX_ABORT_ON(thx_memset_dev(_T, 0, nVox() * sizeof(float)));
+    }
+
+    void setSymmetry(const double* symMat, int nSym) { _sym.assign(symMat, symMat + 9 * (size_t)nSym); }
+    void setFSC(const float* fsc, int n) { _FSC.assign(fsc, fsc + n); }
+    void setMAP(bool v) { _MAP = v; }
+    void setGridCorr(bool v) { _gridCorr = v; }
+    void setJoinHalf(bool v) { _joinHalf = v; }
+    int maxRadius() const { return _maxRadius; }
+    void setMaxRadius(int r) { _maxRadius = r; }
+    double ox() const { return _ox; }
+    double oy() const { return _oy; }
+    double oz() const { return _oz; }
+    int counter() const { return _counter; }
+    void setAllReduce(AllReduce f) { _allreduce = f; }
+    float* getF_dev() { return _F; }
+    float* getT_dev() { return _T; }
+    int getModelDim() const { return _pf * _size; }
+
+    // setPreCal(nPxl, iCol, iRow, iPxl, iSig), src/Reconstructor.cpp:381-395.  The reference BORROWS the caller's PADDED
+    // index arrays (_iColPad/_iRowPad, src/Optimiser.cpp:6741); they are copied to the device here, so the caller may
+    // free them right after (as src/Optimiser.cpp:7760 does).
+    void setPreCal(int nPxl, const int* iColPad, const int* iRowPad, const int* /*iPxl*/, const int* /*iSig*/)
+    {
+        _nPxl = nPxl;
+        std::vector<int> c(nPxl), r(nPxl);
+        for (int i = 0; i < nPxl; i++) { c[i] = iColPad[i] / _pf; r[i] = iRowPad[i] / _pf; }
+        if (_iCol) thx_free_dev(_iCol);
+        if (_iRow) thx_free_dev(_iRow);
+        void* p = nullptr;
+        THX_ABORT_ON(thx_malloc_dev(&p, nPxl * sizeof(int))); _iCol = (int*)p;
+        THX_ABORT_ON(thx_malloc_dev(&p, nPxl * sizeof(int))); _iRow = (int*)p;
+        THX_ABORT_ON(thx_memcpy_h2d(_iCol, c.data(), nPxl * sizeof(int)));
+        THX_ABORT_ON(thx_memcpy_h2d(_iRow, r.data(), nPxl * sizeof(int)));
+    }
+
+    // insertDir(ox, oy, oz), src/Reconstructor.cpp:407-422
+    void insertDir(double ox, double oy, double oz)
+    {
+        std::lock_guard<std::mutex> g(_mtx);
+        _ox += ox; _oy += oy; _oz += oz; _counter += 1;
+    }
+
+    // insertP(const Complex* src, const RFLOAT* ctf, const dmat33& rot, RFLOAT w, const vec* sig = NULL),
+    // src/Reconstructor.cpp:782-863: src is the ALREADY TRANSLATED image row on the pixel list.
+    void insertP(const Complex* src, const float* ctf, const double* rot, float w)
+    {
+        const double zero2[2] = {0, 0};
+        insertBatch(src, ctf, &w, rot, zero2, 1, 1);
+    }
+
+    // nImg images x mReco draws in one launch (InsertFT): datP [nImg][nPxl] untranslated rows, rot [nImg][mReco][9],
+    // tran [nImg][mReco][2] (the image is shifted by -tran on the device), w [nImg] (already divided by mReco)
+    void insertBatch(const Complex* datP, const float* ctfP, const float* w, const double* rot, const double* tran,
+                     int nImg, int mReco)
+    {
+        if (!_F || !_iCol) { std::fprintf(stderr, "thunder_amd FATAL: allocSpace/setPreCal not called\n"); std::abort(); }
+        void *dDat, *dCtf, *dW, *dRot, *dTran;
+        const size_t nd = (size_t)nImg * mReco;
+        THX_ABORT_ON(thx_malloc_dev(&dDat, (size_t)nImg * _nPxl * 2 * sizeof(float)));
+        THX_ABORT_ON(thx_malloc_dev(&dCtf, (size_t)nImg * _nPxl * sizeof(float)));
+        THX_ABORT_ON(thx_malloc_dev(&dW, nImg * sizeof(float)));
+        THX_ABORT_ON(thx_malloc_dev(&dRot, nd * 9 * sizeof(double)));
+        THX_ABORT_ON(thx_malloc_dev(&dTran, nd * 2 * sizeof(double)));
+        THX_ABORT_ON(thx_memcpy_h2d(dDat, datP, (size_t)nImg * _nPxl * 2 * sizeof(float)));
+        THX_ABORT_ON(thx_memcpy_h2d(dCtf, ctfP, (size_t)nImg * _nPxl * sizeof(float)));
+        THX_ABORT_ON(thx_memcpy_h2d(dW, w, nImg * sizeof(float)));
+        THX_ABORT_ON(thx_memcpy_h2d(dRot, rot, nd * 9 * sizeof(double)));
+        THX_ABORT_ON(thx_memcpy_h2d(dTran, tran, nd * 2 * sizeof(double)));
+        THX_ABORT_ON(thx_insert_dev(_F, _T, nullptr, nullptr, _pf * _size, 1, (const float*)dDat, (const float*)dCtf,
+                                    (const float*)dW, (const double*)dRot, (const double*)dTran, nullptr, nullptr, nullptr,
+                                    nullptr, 0, 1.0f, _iCol, _iRow, _pf, _nPxl, mReco, _N, nImg, nullptr));
+        THX_ABORT_ON(thx_device_sync());
+        thx_free_dev(dDat); thx_free_dev(dCtf); thx_free_dev(dW); thx_free_dev(dRot); thx_free_dev(dTran);
+    }
+
+    // prepareTF(nThread), src/Reconstructor.cpp:1056-1091: allReduceT (+ 1/T[0] normalisation of T and F), symmetrizeT,
+    // allReduceF, symmetrizeF
+    void prepareTF(unsigned int /*nThread*/ = 1)
+    {
+        const int dim = _pf * _size;
+        if (_allreduce) _allreduce(_T, nVox());
+        THX_ABORT_ON(thx_normalise_tf_dev(_F, _T, dim, nullptr));
+        const double r = (double)(_maxRadius * _pf + 1);
+        const int nSym = (int)(_sym.size() / 9);
+        if (nSym > 0) symm(_T, nVox(), 0, r);
+        if (_allreduce) _allreduce(_F, 2 * nVox());
+        if (nSym > 0) symm(_F, 2 * nVox(), 1, r);
+        THX_ABORT_ON(thx_device_sync());
+    }
+
+    // prepareO(), src/Reconstructor.cpp:1104-1127 (symmetry sweep of O omitted: C1 or caller-side)
+    void prepareO() { if (_counter) { _ox /= _counter; _oy /= _counter; _oz /= _counter; } }
+
+    // reconstruct(Volume& dst, nThread), src/Reconstructor.cpp:1129-1831 -> dst [N][N][N] real, host
+    void reconstruct(float* dstRL, unsigned int /*nThread*/ = 1)
+    {
+        void* d = nullptr;
+        THX_ABORT_ON(thx_malloc_dev(&d, (size_t)_N * _N * _N * sizeof(float)));
+        THX_ABORT_ON(thx_reco_reconstruct_dev(_plan, _F, _T, _maxRadius, _FSC.empty() ? nullptr : _FSC.data(),
+                                              (int)_FSC.size(), _joinHalf ? 1 : 0, (_MAP && !_FSC.empty()) ? 1 : 0,
+                                              _gridCorr ? 1 : 0, (float*)d, nullptr, nullptr, nullptr));
+        THX_ABORT_ON(thx_memcpy_d2h(dstRL, d, (size_t)_N * _N * _N * sizeof(float)));
+        thx_free_dev(d);
+    }
+
+private:
+    size_t nVox() const { const size_t P = (size_t)_pf * _size; return P * P * (P / 2 + 1); }
+    void defaults()
+    {
+        _size = _N = 0; _pf = 2; _a = 1.9f; _alpha = 15.0f; _maxRadius = 0; _nPxl = 0;
+        _MAP = true; _gridCorr = true; _joinHalf = false; _ox = _oy = _oz = 0; _counter = 0;
+    }
+    void symm(float*& vol, size_t nFloats, int isComplex, double r)
+    {
+        void* tmp = nullptr;
+        THX_ABORT_ON(thx_malloc_dev(&tmp, nFloats * sizeof(float)));
+        THX_ABORT_ON(thx_symmetrize_dev((float*)tmp, vol, _pf * _size, isComplex, _sym.data(), (int)(_sym.size() / 9), r,
+                                        nullptr));
+        THX_ABORT_ON(thx_device_sync());
+        thx_free_dev(vol);
+        vol = (float*)tmp;
+    }
+    thx_reco* _plan;
+    float *_F, *_T;
+    int *_iCol, *_iRow;
+    int _size, _N, _pf, _maxRadius, _nPxl, _counter;
+    float _a, _alpha;
+    bool _MAP, _gridCorr, _joinHalf;
+    double _ox, _oy, _oz;
+    std::vector<double> _sym;
+    std::vector<float> _FSC;
+    AllReduce _allreduce;
+    std::mutex _mtx;
+};
+
+}  // namespace thunder_amd

@@ -1,0 +1,83 @@
+// mirror_roundtrip.cpp -- C++ host code in the reference's own style (Projector / Reconstructor objects, host arrays)
+// linked against libthunder_amd.so: thunder_project -> thunder_reconstruct round trip
+// (appsrc/thunder_project.cpp:146-236, appsrc/thunder_reconstruct.cpp:194-284) at N = 32.
+// Prints "OK <correlation>" when the reconstruction correlates with the input map.
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <vector>
+
+#include "thunder_amd/Reconstructor.hpp"
+
+using namespace thunder_amd;
+
+static void quat2mat(const double q[4], double* m)  // rotate3D, column-major
+{
+    const double A[3][3] = {{0, -q[3], q[2]}, {q[3], 0, -q[1]}, {-q[2], q[1], 0}};
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += A[r][k] * A[k][c];
+            m[c * 3 + r] = (r == c ? 1.0 : 0.0) + 2 * q[0] * A[r][c] + 2 * s;
+        }
+}
+
+int main()
+{
+    const int N = 32, pf = 2, rU = N / 2 - 2;
+    std::mt19937 rng(7);
+    std::normal_distribution<double> g(0, 1);
+    // a few Gaussian blobs, wrapped-index layout
+    std::vector<float> ref((size_t)N * N * N, 0.f);
+    for (int b = 0; b < 6; b++) {
+        double c[3] = {g(rng) * 3, g(rng) * 3, g(rng) * 3}, s = 2.0 + 0.3 * b;
+        for (int k = -N / 2; k < N / 2; k++)
+            for (int j = -N / 2; j < N / 2; j++)
+                for (int i = -N / 2; i < N / 2; i++) {
+                    double d2 = (i - c[0]) * (i - c[0]) + (j - c[1]) * (j - c[1]) + (k - c[2]) * (k - c[2]);
+                    ref[((size_t)((k + N) % N) * N + (j + N) % N) * N + (i + N) % N] += (float)std::exp(-d2 / (2 * s * s));
+                }
+    }
+    // pixel list as Optimiser::allocPreCalIdx
+    std::vector<int> iCol, iRow, iColPad, iRowPad;
+    for (int j = -(rU + 1); j < rU + 1; j++)
+        for (int i = 0; i <= rU + 1; i++) {
+            if (i == 0 && j < 0) continue;
+            double u = (double)i * i + (double)j * j;
+            int v = (int)std::rint(std::hypot((double)i, (double)j));
+            if (u < (double)rU * rU && v < rU) { iCol.push_back(i); iRow.push_back(j); iColPad.push_back(i * pf); iRowPad.push_back(j * pf); }
+        }
+    const int nPxl = (int)iCol.size();
+    Projector proj;
+    proj.setPf(pf);
+    proj.setProjecteeRL(ref.data(), N);
+    Reconstructor reco(1, N, N, pf, nullptr, 0, 1.9f, 15.0f);
+    reco.setMaxRadius(rU);
+    reco.allocSpace(1);
+    reco.setPreCal(nPxl, iColPad.data(), iRowPad.data(), nullptr, nullptr);
+    const int nImg = 300;
+    std::vector<double> rot((size_t)nImg * 9), tran((size_t)nImg * 2, 0.0);
+    for (int l = 0; l < nImg; l++) {
+        double q[4] = {g(rng), g(rng), g(rng), g(rng)};
+        double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        for (double& x : q) x /= n;
+        quat2mat(q, &rot[(size_t)l * 9]);
+    }
+    std::vector<Complex> slices((size_t)nImg * nPxl);
+    proj.projectBatch(slices.data(), rot.data(), nImg, iCol.data(), iRow.data(), nPxl);
+    std::vector<float> ctf((size_t)nImg * nPxl, 1.0f), w(nImg, 1.0f);
+    // first image through the per-call reference-style method, the rest batched
+    reco.insertP(slices.data(), ctf.data(), rot.data(), 1.0f);
+    reco.insertBatch(slices.data() + nPxl, ctf.data() + nPxl, w.data() + 1, rot.data() + 9, tran.data() + 2, nImg - 1, 1);
+    reco.prepareTF(1);
+    reco.setMAP(false);
+    reco.setGridCorr(true);
+    std::vector<float> out((size_t)N * N * N);
+    reco.reconstruct(out.data(), 1);
+    double sab = 0, saa = 0, sbb = 0;
+    for (size_t i = 0; i < out.size(); i++) { sab += (double)out[i] * ref[i]; saa += (double)out[i] * out[i]; sbb += (double)ref[i] * ref[i]; }
+    const double cc = sab / std::sqrt(saa * sbb);
+    std::printf("%s %.5f\n", cc > 0.99 ? "OK" : "FAIL", cc);
+    reco.freeSpace();
+    return cc > 0.99 ? 0 : 1;
+}

@@ -34,6 +34,12 @@ SIGNATURES = {
     "thx_version": (_i, []),
     "thx_device_count": (_i, [C.POINTER(_i)]),
     "thx_set_device": (_i, [_i]),
+    "thx_malloc_dev": (_i, [C.POINTER(_vp), _sz]),
+    "thx_free_dev": (_i, [_vp]),
+    "thx_memcpy_h2d": (_i, [_vp, _vp, _sz]),
+    "thx_memcpy_d2h": (_i, [_vp, _vp, _sz]),
+    "thx_memset_dev": (_i, [_vp, _i, _sz]),
+    "thx_device_sync": (_i, []),
     "thx_rotmat_dev": (_i, [_vp, _vp, _i, _vp]),
     "thx_translate_dev": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "thx_ctf_dev": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp]),

@@ -42,6 +42,38 @@ using namespace thx;
 
 extern "C" {
 
+int thx_malloc_dev(void** ptr, size_t bytes)
+{
+    THX_REQUIRE(ptr, "ptr is NULL");
+    THX_CHECK(hipMalloc(ptr, bytes ? bytes : 4));
+    return 0;
+}
+int thx_free_dev(void* ptr)
+{
+    if (ptr) THX_CHECK(hipFree(ptr));
+    return 0;
+}
+int thx_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes)
+{
+    THX_CHECK(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+int thx_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes)
+{
+    THX_CHECK(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+int thx_memset_dev(void* dst_dev, int value, size_t bytes)
+{
+    THX_CHECK(hipMemset(dst_dev, value, bytes));
+    return 0;
+}
+int thx_device_sync(void)
+{
+    THX_CHECK(hipDeviceSynchronize());
+    return 0;
+}
+
 int thx_ExpectProject_host(const float* volume, float* rotP, const double* rotMat, const int* iCol, const int* iRow,
                            int nR, int pf, int interp, int vdim, int npxl)
 {

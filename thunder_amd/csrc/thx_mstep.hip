@@ -113,6 +113,260 @@ __global__ __launch_bounds__(256) void k_insert(InsertArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Insertion, LDS-brick form (the production path; k_insert above is the plain reference form kept for cSearch-free
+// A/B checks and as the fallback when a brick would not fit).
+//
+// Measured on MI355X (tools/atomic_bench.hip): fp32 global atomics retire ~19 G *transactions*/s chip-wide (one per
+// XCD per clock) and a transaction may carry up to 16 consecutive floats, so scattered 4-byte atomics (k_insert) reach
+// 2 % of the HBM roofline while runs of 16 consecutive floats are 16x faster.  All mReco draws of one image are
+// nearby orientations, so the samples of an 8x8-pixel tile land in a thin slab of the volume.  One workgroup
+// therefore owns (image, tile): it accumulates all draws into an LDS brick that follows the slab ("sheared brick":
+// columns along the plane's dominant axis, kTz voxels thick, based at the plane of the first draw) with ds_add_f32,
+// then flushes the brick to F/T walking the volume's contiguous x axis, so each global atomic transaction carries a
+// run of voxels.  Samples that fall outside the brick take the direct global-atomic path: correctness never depends on
+// the geometry estimate.
+//
+// Hermitian fold in brick coordinates: a folded sample (x < 0 -> (X,Y,Z) = -(x,y,z), conjugated) addresses the brick
+// at (-1-X, -Y, -Z); non-folded samples at (X, Y, Z).  The two half-spaces stay disjoint (X = 0 of a folded sample is
+// brick x = -1, so F(0,j,k) and F(0,-j,-k) remain independent accumulators, SURVEY 8a note H) and adjacent.
+// grid (nTiles, nImg), block 256 = 64 pixels x 4 draw groups.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTB = 8;            // tile edge, image pixels
+constexpr int kTz = 8;            // brick thickness along the dominant axis, voxels
+constexpr int kBrickCap = 6144;   // brick voxels (x 12 B = 72 KB of LDS -> 2 workgroups per CU)
+
+struct InsertTileArgs {
+    InsertArgs a;
+    const int* pixIndex;  // [idim][idim/2+1] pixel-list position of (iRow + idim/2, iCol) or -1
+    int tilesI;           // tiles along iCol
+    int debug;            // THX_INSERT_DEBUG bit mask (profiling only): 1 skip LDS adds, 2 skip flush, 4 skip fallback
+    unsigned long long* stats;  // optional [2]: in-brick voxel adds, fallback voxel adds
+};
+
+__device__ __forceinline__ int sel3(int axis, int x, int y, int z) { return axis == 0 ? x : (axis == 1 ? y : z); }
+
+__global__ __launch_bounds__(256) void k_insert_tiles(InsertTileArgs ta)
+{
+    const InsertArgs& a = ta.a;
+    extern __shared__ __attribute__((aligned(16))) int brick[];  // sRe | sIm | sT, kBrickCap fixed-point words each
+    int* sRe = brick;
+    int* sIm = brick + kBrickCap;
+    int* sT = brick + 2 * kBrickCap;
+    __shared__ int sMin[3], sMax[3], sAny;
+    __shared__ float sAmax[4], sCmax[4];
+
+    const int img = blockIdx.y, tile = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
+    const int P = a.P, half = a.idim / 2;
+    const size_t volSize = (size_t)P * P * (P / 2 + 1);
+    const long nc = P / 2 + 1;
+    const int i0 = (tile % ta.tilesI) * kTB, j0 = (tile / ta.tilesI) * kTB - half;
+    const double offx = a.offS ? a.offS[2 * img] : 0.0, offy = a.offS ? a.offS[2 * img + 1] : 0.0;
+
+    // insertDir (src/Reconstructor.cpp:407-422), once per image
+    if (tile == 0 && tid == 0 && a.O) {
+        double ox = 0, oy = 0, oz = 0;
+        for (int m = 0; m < a.mReco; m++) {
+            const size_t dm = (size_t)img * a.mReco + m;
+            const double* R = a.rotMat + dm * 9;
+            const double tx = a.trans[2 * dm] - offx, ty = a.trans[2 * dm + 1] - offy;
+            ox += -(R[0] * tx + R[3] * ty);
+            oy += -(R[1] * tx + R[4] * ty);
+            oz += -(R[2] * tx + R[5] * ty);
+        }
+        unsafeAtomicAdd(&a.O[0], ox);
+        unsafeAtomicAdd(&a.O[1], oy);
+        unsafeAtomicAdd(&a.O[2], oz);
+        if (a.counter) atomicAdd(a.counter, a.mReco);
+    }
+
+    // this lane's pixel
+    const int pi = i0 + (lane & (kTB - 1)), pj = j0 + (lane >> 3);
+    int k = -1;
+    if (pi <= half && pj < half) k = ta.pixIndex[(pj + half) * (half + 1) + pi];
+    if (tid == 0) sAny = 0;
+    if (tid < 3) { sMin[tid] = INT_MAX; sMax[tid] = INT_MIN; }
+    __syncthreads();
+    if (k >= 0 && grp == 0) sAny = 1;
+    __syncthreads();
+    if (!sAny) return;
+
+    float2 dv = make_float2(0.f, 0.f);
+    float cf = 0.f;
+    if (k >= 0) {
+        dv = a.datP[(size_t)img * a.nPxl + k];
+        cf = a.ctfP[(size_t)img * a.nPxl + k];
+    }
+    const int icp = pi * a.opf, irp = pj * a.opf;
+    const float wgt = a.w[img];
+
+    // ---- fixed-point scale of the LDS accumulators ----
+    // Measured on MI355X (tools/lds_atomic_bench.hip): ds_add_f32 retires 0.33 lanes/clk/CU whatever the address
+    // pattern, ds_add_u32 6-8 lanes/clk/CU.  The brick therefore accumulates in 32-bit fixed point: every added term
+    // is bounded by B = max|dat| * max|ctf| * |w| over the tile (|ramp| = 1, trilinear weights <= 1), a voxel receives
+    // at most ~4*mReco terms from one tile, so the scale 2^s / B with s = 30 - ceil(log2(4 mReco)) cannot overflow.
+    // Quantisation is 2^-(s+1) B per term (2.4e-7 B at mReco = 100) -- below the rounding of a float accumulator
+    // holding a sum of that many terms -- and the integer sum is order-independent, i.e. deterministic.
+    {
+        float am = fabsf(dv.x) + fabsf(dv.y), cm = fabsf(cf);
+        am = wave_max(am);
+        cm = wave_max(cm);
+        if (lane == 0) { sAmax[grp] = am; sCmax[grp] = cm; }
+    }
+    __syncthreads();
+    const float amax = fmaxf(fmaxf(sAmax[0], sAmax[1]), fmaxf(sAmax[2], sAmax[3]));
+    const float cmax = a.cSearch ? 1.0f : fmaxf(fmaxf(sCmax[0], sCmax[1]), fmaxf(sCmax[2], sCmax[3]));
+    const float boundF = amax * cmax * fabsf(wgt), boundT = cmax * cmax * fabsf(wgt);
+    if (!(boundF > 0.f) && !(boundT > 0.f)) return;
+    int sbits = 30 - (32 - __clz(4 * a.mReco - 1));
+    sbits = sbits < 8 ? 8 : sbits;
+    const float q = ldexpf(1.0f, sbits);
+    const float scaleF = boundF > 0.f ? q / boundF : 0.f, scaleT = boundT > 0.f ? q / boundT : 0.f;
+    const float invF = boundF / q, invT = boundT / q;
+
+    // ---- slab geometry from the first draw: dominant axis of the plane normal, column slopes ----
+    const double* R0 = a.rotMat + (size_t)img * a.mReco * 9;
+    const float n0 = (float)R0[6], n1 = (float)R0[7], n2 = (float)R0[8];
+    const float an0 = fabsf(n0), an1 = fabsf(n1), an2 = fabsf(n2);
+    const int ax = (an0 >= an1 && an0 >= an2) ? 0 : (an1 >= an2 ? 1 : 2);   // dominant axis
+    const int pa = ax == 0 ? 1 : 0;                                           // p = x unless the dominant axis is x
+    const int qa = ax == 2 ? 1 : 2;
+    const float na = ax == 0 ? n0 : (ax == 1 ? n1 : n2);
+    const float sp = -(pa == 0 ? n0 : n1) / na, sq = -(qa == 1 ? n1 : n2) / na;
+    constexpr int M = (kTz - 2) / 2;
+
+    // ---- footprint bounding box from the tile corners over all draws ----
+    for (int t = tid; t < 4 * a.mReco; t += 256) {
+        const int m = t >> 2, c = t & 3;
+        const double* R = a.rotMat + ((size_t)img * a.mReco + m) * 9;
+        const int ci = (i0 + ((c & 1) ? kTB - 1 : 0)) * a.opf, cj = (j0 + ((c & 2) ? kTB - 1 : 0)) * a.opf;
+        const float x = (float)(R[0] * ci + R[3] * cj), y = (float)(R[1] * ci + R[4] * cj),
+                    z = (float)(R[2] * ci + R[5] * cj);
+        const int fx = (int)floorf(x), fy = (int)floorf(y), fz = (int)floorf(z);
+        atomicMin(&sMin[0], fx); atomicMax(&sMax[0], fx);
+        atomicMin(&sMin[1], fy); atomicMax(&sMax[1], fy);
+        atomicMin(&sMin[2], fz); atomicMax(&sMax[2], fz);
+    }
+    __syncthreads();
+    const int pmin = sMin[pa] - 1, qmin = sMin[qa] - 1;
+    int Wp = sMax[pa] + 1 - pmin + 1, Wq = sMax[qa] + 1 - qmin + 1;
+    if (Wp * kTz > kBrickCap) Wp = kBrickCap / kTz;
+    if (Wp * Wq * kTz > kBrickCap) Wq = kBrickCap / (Wp * kTz);
+    const int total = Wp * Wq * kTz;
+    const bool axisX = (ax == 0);
+
+    const int nPass = a.cls ? a.nK : 1;
+    for (int pass = 0; pass < nPass; pass++) {
+        // does any draw of this image go to class `pass`?
+        if (a.cls) {
+            __syncthreads();
+            if (tid == 0) sAny = 0;
+            __syncthreads();
+            for (int m = tid; m < a.mReco; m += 256)
+                if (a.cls[(size_t)img * a.mReco + m] == pass) sAny = 1;
+            __syncthreads();
+            if (!sAny) continue;
+        }
+        float2* F = a.F + (size_t)pass * volSize;
+        float* T = a.T + (size_t)pass * volSize;
+        for (int e = tid; e < total; e += 256) { sRe[e] = 0; sIm[e] = 0; sT[e] = 0; }
+        __syncthreads();
+
+        // ---- accumulate: wave `grp` takes draws grp, grp+4, ... ; lanes are the tile's pixels ----
+        if (k >= 0) {
+            for (int m = grp; m < a.mReco; m += 4) {
+                const size_t dm = (size_t)img * a.mReco + m;
+                if (a.cls && a.cls[dm] != pass) continue;
+                const double* R = a.rotMat + dm * 9;
+                const double tx = a.trans[2 * dm] - offx, ty = a.trans[2 * dm + 1] - offy;
+                const float rCol = (float)(-tx) / a.idim, rRow = (float)(-ty) / a.idim;
+                const float2 tv = cmul(dv, ramp_value(rCol, rRow, pi, pj));
+                float c = cf;
+                if (a.cSearch) {
+                    const CtfConst cc = ctf_const(a.attr[img], a.dfac[dm]);
+                    c = ctf_value(cc, a.pixelSize, a.idim, a.idim, pi, pj);
+                }
+                float vre = tv.x * c, vim = tv.y * c;
+                vre = vre * 1.0f; vim = vim * 1.0f;
+                vre = vre * wgt; vim = vim * wgt;
+                const float tval = pow2f_(c) * 1.0f * wgt;
+                float x = (float)(R[0] * icp + R[3] * irp);
+                float y = (float)(R[1] * icp + R[4] * irp);
+                float z = (float)(R[2] * icp + R[5] * irp);
+                if (!coord_in_grid(x, y, z, P)) continue;
+                bool conj = false;
+                if (!(x >= 0.0f)) { x *= -1.0f; y *= -1.0f; z *= -1.0f; conj = true; vim = -vim; }
+                const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+                const int X0 = (int)fx, Y0 = (int)fy, Z0 = (int)fz;
+                const float xd = x - fx, yd = y - fy, zd = z - fz;
+                const float vx[2] = {1.0f - xd, xd}, vy[2] = {1.0f - yd, yd}, vz[2] = {1.0f - zd, zd};
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+                    for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                        for (int ii = 0; ii < 2; ii++) {
+                            const float wv = vx[ii] * vy[jj] * vz[kk];
+                            const int X = X0 + ii, Y = Y0 + jj, Z = Z0 + kk;
+                            const int bx = conj ? -1 - X : X, by = conj ? -Y : Y, bz = conj ? -Z : Z;
+                            const int bp = sel3(pa, bx, by, bz), bq = sel3(qa, bx, by, bz), ba = sel3(ax, bx, by, bz);
+                            const int p_i = bp - pmin, q_i = bq - qmin;
+                            const int off = ba - ((int)floorf(sp * (float)bp + sq * (float)bq) - M);
+                            if ((unsigned)p_i < (unsigned)Wp && (unsigned)q_i < (unsigned)Wq && (unsigned)off < (unsigned)kTz) {
+                                const int idx = axisX ? ((q_i * Wp + p_i) * kTz + off) : ((q_i * kTz + off) * Wp + p_i);
+                                if (ta.debug & 1) continue;
+                                atomicAdd(&sRe[idx], __float2int_rn((vre * wv) * scaleF));
+                                atomicAdd(&sIm[idx], __float2int_rn((vim * wv) * scaleF));
+                                atomicAdd(&sT[idx], __float2int_rn((tval * wv) * scaleT));
+                                if (ta.stats) atomicAdd(&ta.stats[0], 1ULL);
+                            } else {
+                                if (ta.stats) atomicAdd(&ta.stats[1], 1ULL);
+                                if (ta.debug & 4) continue;
+                                const long gi = ((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X;
+                                unsafeAtomicAdd(&F[gi].x, vre * wv);
+                                unsafeAtomicAdd(&F[gi].y, vim * wv);
+                                unsafeAtomicAdd(&T[gi], tval * wv);
+                            }
+                        }
+            }
+        }
+        __syncthreads();
+
+        // ---- flush: consecutive threads walk the brick's fastest axis = the volume's x axis ----
+        if (ta.debug & 2) continue;
+        for (int e = tid; e < total; e += 256) {
+            const int ire = sRe[e], iim = sIm[e], itt = sT[e];
+            if ((ire | iim | itt) == 0) continue;
+            const float re = (float)ire * invF, im = (float)iim * invF, tt = (float)itt * invT;
+            int p_i, q_i, off;
+            if (axisX) { off = e % kTz; p_i = (e / kTz) % Wp; q_i = e / (kTz * Wp); }
+            else { p_i = e % Wp; off = (e / Wp) % kTz; q_i = e / (Wp * kTz); }
+            const int bp = p_i + pmin, bq = q_i + qmin;
+            const int ba = off + ((int)floorf(sp * (float)bp + sq * (float)bq) - M);
+            int X = pa == 0 ? bp : ba;                       // x is either the p axis or the dominant axis
+            int Y = pa == 1 ? bp : (qa == 1 ? bq : ba);
+            int Z = qa == 2 ? bq : ba;
+            if (X < 0) { X = -1 - X; Y = -Y; Z = -Z; }
+            const long gi = ((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X;
+            unsafeAtomicAdd(&F[gi].x, re);
+            unsafeAtomicAdd(&F[gi].y, im);
+            unsafeAtomicAdd(&T[gi], tt);
+        }
+    }
+}
+
+// pixel-list position of every (iRow, iCol): table [idim][idim/2+1], -1 where the pixel is not listed
+__global__ void k_pix_index(int* __restrict__ pixIndex, const int* __restrict__ iCol, const int* __restrict__ iRow,
+                            int nPxl, int idim)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nPxl) return;
+    const int half = idim / 2;
+    const int i = iCol[p], j = iRow[p];
+    if (i >= 0 && i <= half && j >= -half && j < half) pixIndex[(j + half) * (half + 1) + i] = p;
+}
+
+// ---------------------------------------------------------------------------------------------
 // RECONSTRUCTOR_NORMALISE_T_F: sf = 1/T[0]; T *= sf; F *= sf  (src/Reconstructor.cpp:2455-2476)
 // ---------------------------------------------------------------------------------------------
 __global__ void k_read_sf(const float* T, float* sf) { *sf = (float)(1.0 / (double)T[0]); }
@@ -197,7 +451,17 @@ __global__ __launch_bounds__(256) void k_symmetrize(float* __restrict__ dst, con
 
 using namespace thx;
 
+static unsigned long long* g_insert_stats = nullptr;  // profiling only (THX_INSERT_DEBUG & 8)
+
 extern "C" {
+
+// profiling aid, not part of the public ABI: in-brick / fallback voxel-add counts of the last tiled insert launch
+int thx_debug_insert_stats(unsigned long long* out2)
+{
+    if (!g_insert_stats) { out2[0] = out2[1] = 0; return 0; }
+    THX_CHECK(hipMemcpy(out2, g_insert_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
 
 int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK, const float* datP,
                    const float* ctfP, const float* w, const double* rotMat, const double* trans, const double* offS,
@@ -212,6 +476,21 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
     a.datP = reinterpret_cast<const float2*>(datP); a.ctfP = ctfP; a.w = w; a.rotMat = rotMat; a.trans = trans;
     a.offS = offS; a.cls = cls; a.attr = attr; a.dfac = dfac; a.cSearch = cSearch; a.pixelSize = pixelSize;
     a.iCol = iCol; a.iRow = iRow; a.opf = opf; a.nPxl = nPxl; a.mReco = mReco; a.idim = idim;
+    const char* plain = getenv("THX_INSERT_PLAIN");
+    const bool tiles = !(plain && plain[0] == '1');
+    hipStream_t st = as_stream(stream);
+    int* pixIndex = nullptr;
+    const int half = idim / 2;
+    const int tilesI = (half + 1 + kTB - 1) / kTB, tilesJ = (idim + kTB - 1) / kTB;
+    const size_t ldsBytes = 3 * (size_t)kBrickCap * sizeof(float);
+    if (tiles) {
+        const size_t tb = (size_t)idim * (half + 1) * sizeof(int);
+        THX_CHECK(hipMallocAsync(reinterpret_cast<void**>(&pixIndex), tb, st));
+        THX_CHECK(hipMemsetAsync(pixIndex, 0xFF, tb, st));
+        hipLaunchKernelGGL(k_pix_index, dim3((nPxl + 255) / 256), dim3(256), 0, st, pixIndex, iCol, iRow, nPxl, idim);
+        THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_insert_tiles),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+    }
     for (int l0 = 0; l0 < nImg; l0 += 65535) {
         const int nl = nImg - l0 < 65535 ? nImg - l0 : 65535;
         InsertArgs b = a;
@@ -221,9 +500,24 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
         if (b.cls) b.cls += (size_t)l0 * mReco;
         if (b.attr) b.attr += l0;
         if (b.dfac) b.dfac += (size_t)l0 * mReco;
-        hipLaunchKernelGGL(k_insert, dim3((nPxl + 255) / 256, nl), dim3(256), 0, as_stream(stream), b);
+        if (tiles) {
+            InsertTileArgs ta;
+            ta.a = b; ta.pixIndex = pixIndex; ta.tilesI = tilesI;
+            const char* dbg = getenv("THX_INSERT_DEBUG");
+            ta.debug = dbg ? atoi(dbg) : 0;
+            ta.stats = nullptr;
+            if (ta.debug & 8) {
+                if (!g_insert_stats) THX_CHECK(hipMalloc(reinterpret_cast<void**>(&g_insert_stats), 2 * sizeof(unsigned long long)));
+                THX_CHECK(hipMemsetAsync(g_insert_stats, 0, 2 * sizeof(unsigned long long), st));
+                ta.stats = g_insert_stats;
+            }
+            hipLaunchKernelGGL(k_insert_tiles, dim3(tilesI * tilesJ, nl), dim3(256), ldsBytes, st, ta);
+        } else {
+            hipLaunchKernelGGL(k_insert, dim3((nPxl + 255) / 256, nl), dim3(256), 0, st, b);
+        }
     }
     THX_LAUNCH_CHECK();
+    if (pixIndex) THX_CHECK(hipFreeAsync(pixIndex, st));
     return 0;
 }
 
