@@ -492,3 +492,18 @@ def test_host_interface_entry_points(oracle, dev):
               1, dst.ctypes.data)
     want = O.reconstruct(Fo, To, P, N, 2, N // 2 - 2, MAP=False, gridCorr=True)
     assert np.abs(dst - want).max() <= 1e-4 * np.abs(want).max()
+
+
+def test_cpp_mirror_roundtrip(dev, tmp_path):
+    """host code in the reference's own style (include/thunder_amd/Projector.hpp + Reconstructor.hpp over the C ABI),
+    compiled with g++ and run as a separate process: thunder_project -> thunder_reconstruct round trip"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "mirror_rt")
+    libdir = os.path.join(root, "thunder_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "mirror_roundtrip.cpp"), "-o", exe, "-L" + libdir,
+                           "-lthunder_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), (out.stdout, out.stderr[-2000:])

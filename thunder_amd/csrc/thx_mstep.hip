@@ -134,6 +134,8 @@ __global__ __launch_bounds__(256) void k_insert(InsertArgs a)
 constexpr int kTB = 8;            // tile edge, image pixels
 constexpr int kTz = 8;            // brick thickness along the dominant axis, voxels
 constexpr int kBrickCap = 6144;   // brick voxels (x 12 B = 72 KB of LDS -> 2 workgroups per CU)
+constexpr int kInsThreads = 512;  // 64 pixels x 8 draw groups: 16 waves per CU at 2 workgroups per CU
+constexpr int kInsWaves = kInsThreads / 64;
 
 struct InsertTileArgs {
     InsertArgs a;
@@ -145,15 +147,17 @@ struct InsertTileArgs {
 
 __device__ __forceinline__ int sel3(int axis, int x, int y, int z) { return axis == 0 ? x : (axis == 1 ? y : z); }
 
-__global__ __launch_bounds__(256) void k_insert_tiles(InsertTileArgs ta)
+__global__ __launch_bounds__(kInsThreads) void k_insert_tiles(InsertTileArgs ta)
 {
     const InsertArgs& a = ta.a;
     extern __shared__ __attribute__((aligned(16))) int brick[];  // sRe | sIm | sT, kBrickCap fixed-point words each
     int* sRe = brick;
     int* sIm = brick + kBrickCap;
     int* sT = brick + 2 * kBrickCap;
+    // per-draw parameters staged once per workgroup: R[0..5] (the two columns that matter) + the ramp slopes
+    double* sDraw = reinterpret_cast<double*>(brick + 3 * kBrickCap);  // [mReco][8]
     __shared__ int sMin[3], sMax[3], sAny;
-    __shared__ float sAmax[4], sCmax[4];
+    __shared__ float sAmax[kInsWaves], sCmax[kInsWaves];
 
     const int img = blockIdx.y, tile = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
@@ -214,8 +218,10 @@ __global__ __launch_bounds__(256) void k_insert_tiles(InsertTileArgs ta)
         if (lane == 0) { sAmax[grp] = am; sCmax[grp] = cm; }
     }
     __syncthreads();
-    const float amax = fmaxf(fmaxf(sAmax[0], sAmax[1]), fmaxf(sAmax[2], sAmax[3]));
-    const float cmax = a.cSearch ? 1.0f : fmaxf(fmaxf(sCmax[0], sCmax[1]), fmaxf(sCmax[2], sCmax[3]));
+    float amax = 0.f, cmaxT = 0.f;
+#pragma unroll
+    for (int g = 0; g < kInsWaves; g++) { amax = fmaxf(amax, sAmax[g]); cmaxT = fmaxf(cmaxT, sCmax[g]); }
+    const float cmax = a.cSearch ? 1.0f : cmaxT;
     const float boundF = amax * cmax * fabsf(wgt), boundT = cmax * cmax * fabsf(wgt);
     if (!(boundF > 0.f) && !(boundT > 0.f)) return;
     int sbits = 30 - (32 - __clz(4 * a.mReco - 1));
@@ -236,7 +242,18 @@ __global__ __launch_bounds__(256) void k_insert_tiles(InsertTileArgs ta)
     constexpr int M = (kTz - 2) / 2;
 
     // ---- footprint bounding box from the tile corners over all draws ----
-    for (int t = tid; t < 4 * a.mReco; t += 256) {
+    for (int m = tid; m < a.mReco; m += kInsThreads) {
+        const size_t dm = (size_t)img * a.mReco + m;
+        const double* R = a.rotMat + dm * 9;
+        double* d = sDraw + 8 * m;
+        d[0] = R[0]; d[1] = R[1]; d[2] = R[2]; d[3] = R[3]; d[4] = R[4]; d[5] = R[5];
+        // translate(transImgP, orignImgP, -(tran - offset)(0), -(tran - offset)(1), ...), src/Optimiser.cpp:7160-7169
+        const double tx = a.trans[2 * dm] - offx, ty = a.trans[2 * dm + 1] - offy;
+        float* f = reinterpret_cast<float*>(d + 6);
+        f[0] = (float)(-tx) / a.idim;
+        f[1] = (float)(-ty) / a.idim;
+    }
+    for (int t = tid; t < 4 * a.mReco; t += kInsThreads) {
         const int m = t >> 2, c = t & 3;
         const double* R = a.rotMat + ((size_t)img * a.mReco + m) * 9;
         const int ci = (i0 + ((c & 1) ? kTB - 1 : 0)) * a.opf, cj = (j0 + ((c & 2) ? kTB - 1 : 0)) * a.opf;
@@ -262,24 +279,23 @@ __global__ __launch_bounds__(256) void k_insert_tiles(InsertTileArgs ta)
             __syncthreads();
             if (tid == 0) sAny = 0;
             __syncthreads();
-            for (int m = tid; m < a.mReco; m += 256)
+            for (int m = tid; m < a.mReco; m += kInsThreads)
                 if (a.cls[(size_t)img * a.mReco + m] == pass) sAny = 1;
             __syncthreads();
             if (!sAny) continue;
         }
         float2* F = a.F + (size_t)pass * volSize;
         float* T = a.T + (size_t)pass * volSize;
-        for (int e = tid; e < total; e += 256) { sRe[e] = 0; sIm[e] = 0; sT[e] = 0; }
+        for (int e = tid; e < total; e += kInsThreads) { sRe[e] = 0; sIm[e] = 0; sT[e] = 0; }
         __syncthreads();
 
         // ---- accumulate: wave `grp` takes draws grp, grp+4, ... ; lanes are the tile's pixels ----
         if (k >= 0) {
-            for (int m = grp; m < a.mReco; m += 4) {
+            for (int m = grp; m < a.mReco; m += kInsWaves) {
                 const size_t dm = (size_t)img * a.mReco + m;
                 if (a.cls && a.cls[dm] != pass) continue;
-                const double* R = a.rotMat + dm * 9;
-                const double tx = a.trans[2 * dm] - offx, ty = a.trans[2 * dm + 1] - offy;
-                const float rCol = (float)(-tx) / a.idim, rRow = (float)(-ty) / a.idim;
+                const double* R = sDraw + 8 * m;
+                const float rCol = reinterpret_cast<const float*>(R + 6)[0], rRow = reinterpret_cast<const float*>(R + 6)[1];
                 const float2 tv = cmul(dv, ramp_value(rCol, rRow, pi, pj));
                 float c = cf;
                 if (a.cSearch) {
@@ -334,7 +350,7 @@ __global__ __launch_bounds__(256) void k_insert_tiles(InsertTileArgs ta)
 
         // ---- flush: consecutive threads walk the brick's fastest axis = the volume's x axis ----
         if (ta.debug & 2) continue;
-        for (int e = tid; e < total; e += 256) {
+        for (int e = tid; e < total; e += kInsThreads) {
             const int ire = sRe[e], iim = sIm[e], itt = sT[e];
             if ((ire | iim | itt) == 0) continue;
             const float re = (float)ire * invF, im = (float)iim * invF, tt = (float)itt * invT;
@@ -482,7 +498,8 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
     int* pixIndex = nullptr;
     const int half = idim / 2;
     const int tilesI = (half + 1 + kTB - 1) / kTB, tilesJ = (idim + kTB - 1) / kTB;
-    const size_t ldsBytes = 3 * (size_t)kBrickCap * sizeof(float);
+    const size_t ldsBytes = 3 * (size_t)kBrickCap * sizeof(int) + (size_t)mReco * 8 * sizeof(double);
+    THX_REQUIRE(!tiles || ldsBytes <= 160 * 1024, "mReco too large for the LDS draw table");
     if (tiles) {
         const size_t tb = (size_t)idim * (half + 1) * sizeof(int);
         THX_CHECK(hipMallocAsync(reinterpret_cast<void**>(&pixIndex), tb, st));
@@ -511,7 +528,7 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
                 THX_CHECK(hipMemsetAsync(g_insert_stats, 0, 2 * sizeof(unsigned long long), st));
                 ta.stats = g_insert_stats;
             }
-            hipLaunchKernelGGL(k_insert_tiles, dim3(tilesI * tilesJ, nl), dim3(256), ldsBytes, st, ta);
+            hipLaunchKernelGGL(k_insert_tiles, dim3(tilesI * tilesJ, nl), dim3(kInsThreads), ldsBytes, st, ta);
         } else {
             hipLaunchKernelGGL(k_insert, dim3((nPxl + 255) / 256, nl), dim3(256), 0, st, b);
         }

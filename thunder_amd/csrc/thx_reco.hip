@@ -5,6 +5,9 @@
 #include <hipfft/hipfft.h>
 #include <math.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "thx_common.h"
@@ -56,11 +59,13 @@ constexpr int kTabN = 100000;  // _kernelRL.init(..., 0, 1, 1e5), src/Reconstruc
 // ---- device kernels ----
 __device__ __forceinline__ void unpack_half(size_t e, int P, int& i, int& j, int& k)
 {
-    const int nc = P / 2 + 1;
-    i = (int)(e % nc);
-    const int jw = (int)((e / nc) % P), kw = (int)(e / ((size_t)nc * P));
-    j = jw >= P / 2 ? jw - P : jw;
-    k = kw >= P / 2 ? kw - P : kw;
+    // the half grid has < 2^32 voxels up to P = 2048: 32-bit div/mod (64-bit ones cost ~10x more on the VALU)
+    const unsigned nc = P / 2 + 1, e32 = (unsigned)e;
+    const unsigned row = e32 / nc;
+    i = (int)(e32 - row * nc);
+    const unsigned kw = row / (unsigned)P, jw = row - kw * (unsigned)P;
+    j = (int)jw >= P / 2 ? (int)jw - P : (int)jw;
+    k = (int)kw >= P / 2 ? (int)kw - P : (int)kw;
 }
 
 // [MAP] T /= FSC'(shell), src/Reconstructor.cpp:1242-1270
@@ -113,17 +118,22 @@ __global__ __launch_bounds__(256) void k_calcC(float2* __restrict__ C, const flo
 __global__ __launch_bounds__(256) void k_convolute_rl(float* __restrict__ rl, int P, int NP, const float* __restrict__ tab,
                                                       float nf)
 {
+    // grid (jw, kw): one row of the real P^3 volume per workgroup, threads stride over i (no index div/mod)
     const size_t n = (size_t)P * P * P;
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const int iw = (int)(e % P), jw = (int)((e / P) % P), kw = (int)(e / ((size_t)P * P));
-    const int i = iw >= P / 2 ? iw - P : iw, j = jw >= P / 2 ? jw - P : jw, k = kw >= P / 2 ? kw - P : kw;
-    float v = (float)((double)rl[e] * (1.0 / (double)n));
-    const double q = (double)i * i + (double)j * j + (double)k * k;
-    const float x = (float)(q / pow2f_((float)NP));
+    const int jw = blockIdx.x, kw = blockIdx.y;
+    const int j = jw >= P / 2 ? jw - P : jw, k = kw >= P / 2 ? kw - P : kw;
+    const double qjk = (double)j * j + (double)k * k;
+    const double np2 = (double)pow2f_((float)NP);
+    const double rn = 1.0 / (double)n;
     const float s = 1.0f / kTabN;  // _s = (_b - _a) / _n in RFLOAT, src/TabFunction.cpp:34
-    const int idx = (int)rint((double)((x - 0.0f) / s));
-    rl[e] = v * tab[idx < kTabN ? idx : kTabN] / nf;
+    float* row = rl + ((size_t)kw * P + jw) * P;
+    for (int iw = threadIdx.x; iw < P; iw += blockDim.x) {
+        const int i = iw >= P / 2 ? iw - P : iw;
+        const float v = (float)((double)row[iw] * rn);
+        const float x = (float)(((double)i * i + qjk) / np2);
+        const int idx = (int)rint((double)((x - 0.0f) / s));
+        row[iw] = v * tab[idx < kTabN ? idx : kTabN] / nf;
+    }
 }
 
 __device__ __forceinline__ float ts_hypot(float x, float y)
@@ -139,20 +149,24 @@ __device__ __forceinline__ float ts_hypot(float x, float y)
 __global__ __launch_bounds__(256) void k_updateW_checkC(float* __restrict__ W, const float2* __restrict__ C, int P, int pf,
                                                         int maxRadius, unsigned* __restrict__ diffBits)
 {
+    // grid (jw, kw): one row of the half grid per workgroup
     __shared__ float sred[4];
-    const size_t n = (size_t)P * P * (P / 2 + 1);
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nc = P / 2 + 1;
+    const int jw = blockIdx.x, kw = blockIdx.y;
+    const int j = jw >= P / 2 ? jw - P : jw, k = kw >= P / 2 ? kw - P : kw;
+    const double qjk = (double)j * j + (double)k * k;
+    const double r2 = (double)pow2f_((float)(maxRadius * pf));
     float d = 0.f;
-    if (e < n) {
-        int i, j, k;
-        unpack_half(e, P, i, j, k);
-        const double q = (double)i * i + (double)j * j + (double)k * k;
-        if (q < pow2f_((float)(maxRadius * pf))) {
-            const float2 c = C[e];
-            const float a = ts_hypot(c.x, c.y);
-            const float m = a > (float)1e-6 ? a : (float)1e-6;
-            W[e] = W[e] / m;
-            d = fabsf(a - 1);
+    if (qjk < r2) {
+        const size_t base = ((size_t)kw * P + jw) * nc;
+        for (int i = threadIdx.x; i < nc; i += blockDim.x) {
+            if ((double)i * i + qjk < r2) {
+                const float2 c = C[base + i];
+                const float a = ts_hypot(c.x, c.y);
+                const float m = a > (float)1e-6 ? a : (float)1e-6;
+                W[base + i] = W[base + i] / m;
+                d = fmaxf(d, fabsf(a - 1));
+            }
         }
     }
     d = wave_max(d);
@@ -160,7 +174,10 @@ __global__ __launch_bounds__(256) void k_updateW_checkC(float* __restrict__ W, c
     __syncthreads();
     if (threadIdx.x == 0) {
         d = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
-        atomicMax(diffBits, __float_as_uint(d));  // d >= 0: uint order == float order
+        // d >= 0: uint order == float order.  One hot word retires only ~88 atomics/us, so a workgroup whose maximum
+        // cannot raise the current value (plain L2 read) skips the atomic.
+        const unsigned bitsd = __float_as_uint(d);
+        if (bitsd > __hip_atomic_load(diffBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(diffBits, bitsd);
     }
 }
 
@@ -378,11 +395,11 @@ int thx_reco_reconstruct_dev(thx_reco* r, const float* F, float* T, int maxRadiu
         for (int m = 0; m < 30; m++) {  // MAX_N_ITER_BALANCE
             hipLaunchKernelGGL(k_calcC, dim3(nblk(nHalfF)), dim3(256), 0, st, r->C, T, r->W, nHalfF);
             THX_FFT_CHECK(hipfftExecC2R(r->c2rF, reinterpret_cast<hipfftComplex*>(r->C), r->rl));
-            hipLaunchKernelGGL(k_convolute_rl, dim3(nblk((size_t)PF * PF * PF)), dim3(256), 0, st, r->rl, PF, r->N * pf,
+            hipLaunchKernelGGL(k_convolute_rl, dim3(PF, PF), dim3(256), 0, st, r->rl, PF, r->N * pf,
                                r->tab, r->nf);
             THX_FFT_CHECK(hipfftExecR2C(r->r2cF, r->rl, reinterpret_cast<hipfftComplex*>(r->C)));
             THX_CHECK(hipMemsetAsync(r->diff, 0, sizeof(unsigned), st));
-            hipLaunchKernelGGL(k_updateW_checkC, dim3(nblk(nHalfF)), dim3(256), 0, st, r->W, r->C, PF, pf, maxRadius,
+            hipLaunchKernelGGL(k_updateW_checkC, dim3(PF, PF), dim3(256), 0, st, r->W, r->C, PF, pf, maxRadius,
                                r->diff);
             unsigned bits = 0;
             THX_CHECK(hipMemcpyAsync(&bits, r->diff, sizeof(unsigned), hipMemcpyDeviceToHost, st));
@@ -420,15 +437,32 @@ int thx_reco_set_projectee_dev(thx_reco* r, const float* refRL, float* volume, v
     return 0;
 }
 
+// FFT plans of the small N^3 transforms are cached per (size, direction): plan creation costs far more than the
+// transform (the reference's FFT::fw re-plans every call with FFTW_ESTIMATE, src/FFT.cpp:176-199)
+static int cached_plan(hipfftHandle* out, int n, hipfftType type)
+{
+    static std::mutex mtx;
+    static std::map<std::pair<int, int>, hipfftHandle> cache;
+    std::lock_guard<std::mutex> g(mtx);
+    auto key = std::make_pair(n, (int)type);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        hipfftHandle p;
+        THX_FFT_CHECK(hipfftPlan3d(&p, n, n, n, type));
+        it = cache.emplace(key, p).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
 int thx_fft3d_fw_dev(const float* rl, float* ft, int n, void* stream)
 {
     THX_REQUIRE(rl && ft, "NULL pointer");
     hipfftHandle p;
-    THX_FFT_CHECK(hipfftPlan3d(&p, n, n, n, HIPFFT_R2C));
+    int rc = cached_plan(&p, n, HIPFFT_R2C);
+    if (rc) return rc;
     THX_FFT_CHECK(hipfftSetStream(p, as_stream(stream)));
     THX_FFT_CHECK(hipfftExecR2C(p, const_cast<float*>(rl), reinterpret_cast<hipfftComplex*>(ft)));
-    THX_CHECK(hipStreamSynchronize(as_stream(stream)));
-    (void)hipfftDestroy(p);
     return 0;
 }
 
@@ -436,12 +470,12 @@ int thx_fft3d_bw_dev(float* ft, float* rl, int n, void* stream)
 {
     THX_REQUIRE(rl && ft, "NULL pointer");
     hipfftHandle p;
-    THX_FFT_CHECK(hipfftPlan3d(&p, n, n, n, HIPFFT_C2R));
+    int rc = cached_plan(&p, n, HIPFFT_C2R);
+    if (rc) return rc;
     THX_FFT_CHECK(hipfftSetStream(p, as_stream(stream)));
     THX_FFT_CHECK(hipfftExecC2R(p, reinterpret_cast<hipfftComplex*>(ft), rl));
     hipLaunchKernelGGL(k_scale_rl, dim3(nblk((size_t)n * n * n)), dim3(256), 0, as_stream(stream), rl, (size_t)n * n * n);
-    THX_CHECK(hipStreamSynchronize(as_stream(stream)));
-    (void)hipfftDestroy(p);
+    THX_LAUNCH_CHECK();
     return 0;
 }
 

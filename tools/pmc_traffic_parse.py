@@ -1,0 +1,39 @@
+"""parse the two counter_collection.csv files of tools/pmc_traffic.sh into profiles-ready JSON"""
+import csv, glob, json, sys, collections
+out = sys.argv[1]
+res = {}
+for which in ("fetch", "write"):
+    fs = glob.glob("%s/%s/**/*counter_collection.csv" % (out, which), recursive=True)
+    rows = list(csv.DictReader(open(fs[0])))
+    per = collections.defaultdict(list)
+    for r in rows:
+        per[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    res[which] = {k: v for k, v in per.items()}
+GiB = 1024.0 ** 3
+def find(d, key):
+    return [(k, v) for k, v in d.items() if key in k]
+summary = {}
+# calibration: the 1 GiB copy is the largest elementwise/copy dispatch
+cal = {}
+for which in ("fetch", "write"):
+    best = None
+    for k, v in res[which].items():
+        if ("elementwise" in k or "copy" in k.lower()) and max(v) > 0:
+            if best is None or max(v) > best[1]:
+                best = (k, max(v))
+    cal[which] = best
+summary["calibration"] = {w: {"kernel": cal[w][0][:80], "raw": cal[w][1], "bytes_per_unit": GiB / cal[w][1]} for w in cal if cal[w]}
+for name in ("k_insert_tiles", "k_expect_local"):
+    ent = {}
+    for which in ("fetch", "write"):
+        f = find(res[which], name)
+        if f:
+            vals = f[0][1]
+            ent[which + "_raw_per_launch"] = sum(vals) / len(vals)
+            ent[which + "_bytes_per_launch"] = ent[which + "_raw_per_launch"] * summary["calibration"][which]["bytes_per_unit"]
+            ent["launches"] = len(vals)
+    if ent:
+        ent["hbm_bytes_per_launch"] = ent.get("fetch_bytes_per_launch", 0) + ent.get("write_bytes_per_launch", 0)
+        summary[name] = ent
+print(json.dumps(summary, indent=1))
+json.dump(summary, open(out + "/summary.json", "w"), indent=1)
