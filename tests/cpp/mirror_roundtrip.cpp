@@ -65,15 +65,28 @@ int main()
     }
     std::vector<Complex> slices((size_t)nImg * nPxl);
     proj.projectBatch(slices.data(), rot.data(), nImg, iCol.data(), iRow.data(), nPxl);
+    double sl2 = 0;
+    for (const Complex& c : slices) sl2 += (double)c.dat[0] * c.dat[0] + (double)c.dat[1] * c.dat[1];
+    std::fprintf(stderr, "nPxl %d  sum|slice|^2 %.6g\n", nPxl, sl2);
     std::vector<float> ctf((size_t)nImg * nPxl, 1.0f), w(nImg, 1.0f);
     // first image through the per-call reference-style method, the rest batched
     reco.insertP(slices.data(), ctf.data(), rot.data(), 1.0f);
     reco.insertBatch(slices.data() + nPxl, ctf.data() + nPxl, w.data() + 1, rot.data() + 9, tran.data() + 2, nImg - 1, 1);
+    {
+        const size_t nv = (size_t)(pf * N) * (pf * N) * (pf * N / 2 + 1);
+        std::vector<float> Th(nv);
+        thx_memcpy_d2h(Th.data(), reco.getT_dev(), nv * sizeof(float));
+        double ts = 0;
+        for (float t : Th) ts += t;
+        std::fprintf(stderr, "sum T %.6g (expect %d)  T[0] %.6g\n", ts, nImg * nPxl, Th[0]);
+        if (std::fabs(ts - (double)nImg * nPxl) > 1e-3 * nImg * nPxl) { std::printf("FAIL sumT %.6g\n", ts); return 2; }
+    }
     reco.prepareTF(1);
     reco.setMAP(false);
     reco.setGridCorr(true);
     std::vector<float> out((size_t)N * N * N);
     reco.reconstruct(out.data(), 1);
+    std::fprintf(stderr, "out[0] %.6g ref[0] %.6g\n", out[0], ref[0]);
     double sab = 0, saa = 0, sbb = 0;
     for (size_t i = 0; i < out.size(); i++) { sab += (double)out[i] * ref[i]; saa += (double)out[i] * out[i]; sbb += (double)ref[i] * ref[i]; }
     const double cc = sab / std::sqrt(saa * sbb);

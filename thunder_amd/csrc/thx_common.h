@@ -36,6 +36,12 @@ void set_error(const char* fmt, ...);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Grow-only device scratch, one buffer per (stream, slot): valid until the next request for the same (stream, slot).
+// Work on one stream is ordered, so reuse across calls needs no synchronisation.  (hipMallocAsync/hipFreeAsync were
+// dropped: after a hipDeviceSynchronize the ROCm 7 pool hands released blocks to plain hipMalloc while still reusing
+// them, which corrupted caller buffers in a torch-free process -- tests/cpp/mirror_roundtrip.cpp exercises that.)
+void* scratch(hipStream_t stream, int slot, size_t bytes);
+
 constexpr double kM2xPi = 6.28318530717959;  // M_2X_PI, include/Macro.h:14
 
 // ---------------------------------------------------------------------------------------------

@@ -4,6 +4,10 @@
 // src/CTF.cpp:113-151, src/Image/ImageFunctions.cpp:233-252.  gfx950 only; wavefront = 64.
 #include <stdarg.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "thx_common.h"
 
 namespace thx {
@@ -15,6 +19,27 @@ void set_error(const char* fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+void* scratch(hipStream_t stream, int slot, size_t bytes)
+{
+    struct Buf { void* p = nullptr; size_t n = 0; };
+    static std::mutex mtx;
+    static std::map<std::pair<hipStream_t, int>, Buf> bufs;
+    std::lock_guard<std::mutex> g(mtx);
+    Buf& b = bufs[std::make_pair(stream, slot)];
+    if (b.n < bytes) {
+        if (b.p) {
+            (void)hipStreamSynchronize(stream);   // the old buffer may still be in use by queued work
+            (void)hipFree(b.p);
+        }
+        b.p = nullptr;
+        b.n = 0;
+        const size_t want = bytes < 4096 ? 4096 : bytes;
+        if (hipMalloc(&b.p, want) != hipSuccess) { b.p = nullptr; return nullptr; }
+        b.n = want;
+    }
+    return b.p;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_insert(InsertArgs a)
 // Hermitian fold in brick coordinates: a folded sample (x < 0 -> (X,Y,Z) = -(x,y,z), conjugated) addresses the brick
 // at (-1-X, -Y, -Z); non-folded samples at (X, Y, Z).  The two half-spaces stay disjoint (X = 0 of a folded sample is
 // brick x = -1, so F(0,j,k) and F(0,-j,-k) remain independent accumulators, SURVEY 8a note H) and adjacent.
-// grid (nTiles, nImg), block 256 = 64 pixels x 4 draw groups.
+// grid (tile rows, nImg), block 512 = 64 pixels x 8 draw groups; a workgroup walks the tiles of its row.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTB = 8;            // tile edge, image pixels
 constexpr int kTz = 8;            // brick thickness along the dominant axis, voxels
@@ -145,30 +145,178 @@ struct InsertTileArgs {
     unsigned long long* stats;  // optional [2]: in-brick voxel adds, fallback voxel adds
 };
 
-__device__ __forceinline__ int sel3(int axis, int x, int y, int z) { return axis == 0 ? x : (axis == 1 ? y : z); }
+template <int W>
+__device__ __forceinline__ int comp3(int x, int y, int z) { return W == 0 ? x : (W == 1 ? y : z); }
 
-__global__ __launch_bounds__(kInsThreads) void k_insert_tiles(InsertTileArgs ta)
+// Per-tile work of k_insert_tiles for a compile-time dominant axis AX (so the axis shuffles fold away):
+// accumulate this lane's pixel over the wave's share of the draws, then flush (and re-zero) the brick.
+struct TileGeom {
+    int pmin, qmin, Wp, Wq, total;
+    float sp, sq;          // column slopes: base(p, q) = floor(sp p + sq q) - M
+    float scaleF, scaleT, invF, invT;
+};
+
+template <int AX, bool DBG>
+__device__ __forceinline__ void insert_tile_body(const InsertTileArgs& ta, const TileGeom& g, int* sRe, int* sIm, int* sT,
+                                                 const double* sDraw, int img, int pass, int k, int pi, int pj, float2 dv,
+                                                 float cf, float wgt, float2* F, float* T, int* sSync)
+{
+    const InsertArgs& a = ta.a;
+    constexpr int pa = AX == 0 ? 1 : 0;   // p = x unless the dominant axis is x
+    constexpr int qa = AX == 2 ? 1 : 2;
+    constexpr int M = (kTz - 2) / 2;
+    const int tid = threadIdx.x, grp = tid >> 6;
+    const int P = a.P;
+    const long nc = P / 2 + 1;
+    const int icp = pi * a.opf, irp = pj * a.opf;
+
+    if (k >= 0) {
+        for (int m = grp; m < a.mReco; m += kInsWaves) {
+            const size_t dm = (size_t)img * a.mReco + m;
+            if (a.cls && a.cls[dm] != pass) continue;
+            const double* R = sDraw + 8 * m;
+            const float rCol = reinterpret_cast<const float*>(R + 6)[0], rRow = reinterpret_cast<const float*>(R + 6)[1];
+            const float2 tv = cmul(dv, ramp_value(rCol, rRow, pi, pj));
+            float c = cf;
+            if (a.cSearch) {
+                const CtfConst cc = ctf_const(a.attr[img], a.dfac[dm]);
+                c = ctf_value(cc, a.pixelSize, a.idim, a.idim, pi, pj);
+            }
+            // src[i] * ctf[i] * 1 * w, left to right (src/Reconstructor.cpp:830-833)
+            float vre = tv.x * c, vim = tv.y * c;
+            vre = vre * 1.0f; vim = vim * 1.0f;
+            vre = vre * wgt; vim = vim * wgt;
+            const float tval = pow2f_(c) * 1.0f * wgt;
+            float x = (float)(R[0] * icp + R[3] * irp);
+            float y = (float)(R[1] * icp + R[4] * irp);
+            float z = (float)(R[2] * icp + R[5] * irp);
+            if (!coord_in_grid(x, y, z, P)) continue;
+            bool conj = false;
+            if (!(x >= 0.0f)) { x *= -1.0f; y *= -1.0f; z *= -1.0f; conj = true; vim = -vim; }
+            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+            const int X0 = (int)fx, Y0 = (int)fy, Z0 = (int)fz;
+            const float xd = x - fx, yd = y - fy, zd = z - fz;
+            const float vx[2] = {1.0f - xd, xd}, vy[2] = {1.0f - yd, yd}, vz[2] = {1.0f - zd, zd};
+            // brick coordinates of the cell origin; a folded cell runs backwards (sg = -1)
+            const int sg = conj ? -1 : 1;
+            const int b0x = conj ? -1 - X0 : X0, b0y = conj ? -Y0 : Y0, b0z = conj ? -Z0 : Z0;
+            const int bp0 = comp3<pa>(b0x, b0y, b0z), bq0 = comp3<qa>(b0x, b0y, b0z), ba0 = comp3<AX>(b0x, b0y, b0z);
+            int pI[2], qI[2], offA[2][2];
+            bool pin[2], qin[2];
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                pI[d] = bp0 + sg * d - g.pmin;
+                qI[d] = bq0 + sg * d - g.qmin;
+                pin[d] = (unsigned)pI[d] < (unsigned)g.Wp;
+                qin[d] = (unsigned)qI[d] < (unsigned)g.Wq;
+            }
+#pragma unroll
+            for (int dq = 0; dq < 2; dq++)
+#pragma unroll
+                for (int dp = 0; dp < 2; dp++)
+                    offA[dq][dp] = ba0 - ((int)floorf(g.sp * (float)(bp0 + sg * dp) + g.sq * (float)(bq0 + sg * dq)) - M);
+            unsigned outside = 0;
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                    for (int ii = 0; ii < 2; ii++) {
+                        const int dp = comp3<pa>(ii, jj, kk), dq = comp3<qa>(ii, jj, kk), da = comp3<AX>(ii, jj, kk);
+                        const float wv = vx[ii] * vy[jj] * vz[kk];
+                        const int off = offA[dq][dp] + sg * da;
+                        const bool in = pin[dp] && qin[dq] && ((unsigned)off < (unsigned)kTz);
+                        // outside voxels add 0 to a dummy slot: the hot path stays branch-free
+                        const int idx = in ? (AX == 0 ? ((qI[dq] * g.Wp + pI[dp]) * kTz + off)
+                                                      : ((qI[dq] * kTz + off) * g.Wp + pI[dp]))
+                                           : kBrickCap - 1;
+                        const float m1 = in ? g.scaleF : 0.f, m2 = in ? g.scaleT : 0.f;
+                        if (!(DBG && (ta.debug & 1))) {
+                            atomicAdd(&sRe[idx], __float2int_rn((vre * wv) * m1));
+                            atomicAdd(&sIm[idx], __float2int_rn((vim * wv) * m1));
+                            atomicAdd(&sT[idx], __float2int_rn((tval * wv) * m2));
+                        }
+                        if (!in) outside |= 1u << (kk * 4 + jj * 2 + ii);
+                    }
+            if (DBG && ta.stats) {
+                atomicAdd(&ta.stats[0], (unsigned long long)(8 - __popc(outside)));
+                atomicAdd(&ta.stats[1], (unsigned long long)__popc(outside));
+            }
+            if (outside && !(DBG && (ta.debug & 4))) {
+                // rare: samples that left the brick go straight to the volume
+#pragma unroll
+                for (int v = 0; v < 8; v++) {   // compile-time v: no runtime-indexed register arrays
+                    if (!((outside >> v) & 1)) continue;
+                    const float wv = vx[v & 1] * vy[(v >> 1) & 1] * vz[v >> 2];
+                    const int X = X0 + (v & 1), Y = Y0 + ((v >> 1) & 1), Z = Z0 + (v >> 2);
+                    const long gi = ((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X;
+                    unsafeAtomicAdd(&F[gi].x, vre * wv);
+                    unsafeAtomicAdd(&F[gi].y, vim * wv);
+                    unsafeAtomicAdd(&T[gi], tval * wv);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- flush and re-zero: consecutive threads walk the brick's fastest axis = the volume's x axis ----
+    if (tid == 0) sRe[kBrickCap - 1] = sIm[kBrickCap - 1] = sT[kBrickCap - 1] = 0;
+    for (int e = tid; e < g.total; e += kInsThreads) {
+        const int ire = sRe[e], iim = sIm[e], itt = sT[e];
+        if ((ire | iim | itt) == 0) continue;
+        sRe[e] = 0; sIm[e] = 0; sT[e] = 0;
+        if (DBG && (ta.debug & 2)) continue;
+        const float re = (float)ire * g.invF, im = (float)iim * g.invF, tt = (float)itt * g.invT;
+        int p_i, q_i, off;
+        if (AX == 0) { off = e % kTz; const int r = e / kTz; q_i = r / g.Wp; p_i = r - q_i * g.Wp; }
+        else { const int r = e / g.Wp; p_i = e - r * g.Wp; off = r % kTz; q_i = r / kTz; }
+        const int bp = p_i + g.pmin, bq = q_i + g.qmin;
+        const int ba = off + ((int)floorf(g.sp * (float)bp + g.sq * (float)bq) - M);
+        int X = pa == 0 ? bp : ba;
+        int Y = pa == 1 ? bp : (qa == 1 ? bq : ba);
+        int Z = qa == 2 ? bq : ba;
+        if (X < 0) { X = -1 - X; Y = -Y; Z = -Z; }
+        const long gi = ((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X;
+        unsafeAtomicAdd(&F[gi].x, re);
+        unsafeAtomicAdd(&F[gi].y, im);
+        unsafeAtomicAdd(&T[gi], tt);
+    }
+    (void)sSync;
+}
+
+// grid (tilesJ, nImg): one workgroup owns a strip of tiles of one image (all tiles of one 8-row band), so the per-draw
+// table is staged once per strip; per tile: pixel loads + bounds (sync) -> accumulate (sync) -> flush.
+template <bool DBG>
+__global__ __launch_bounds__(kInsThreads, 4) void k_insert_tiles(InsertTileArgs ta)
 {
     const InsertArgs& a = ta.a;
     extern __shared__ __attribute__((aligned(16))) int brick[];  // sRe | sIm | sT, kBrickCap fixed-point words each
     int* sRe = brick;
     int* sIm = brick + kBrickCap;
     int* sT = brick + 2 * kBrickCap;
-    // per-draw parameters staged once per workgroup: R[0..5] (the two columns that matter) + the ramp slopes
-    double* sDraw = reinterpret_cast<double*>(brick + 3 * kBrickCap);  // [mReco][8]
-    __shared__ int sMin[3], sMax[3], sAny;
+    double* sDraw = reinterpret_cast<double*>(brick + 3 * kBrickCap);  // [mReco][8]: R[0..5], ramp slopes
+    __shared__ int sMin[3], sMax[3], sAny, sCls;
     __shared__ float sAmax[kInsWaves], sCmax[kInsWaves];
 
-    const int img = blockIdx.y, tile = blockIdx.x;
+    const int img = blockIdx.y, tj = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
     const int P = a.P, half = a.idim / 2;
     const size_t volSize = (size_t)P * P * (P / 2 + 1);
-    const long nc = P / 2 + 1;
-    const int i0 = (tile % ta.tilesI) * kTB, j0 = (tile / ta.tilesI) * kTB - half;
+    const int j0 = tj * kTB - half;
     const double offx = a.offS ? a.offS[2 * img] : 0.0, offy = a.offS ? a.offS[2 * img + 1] : 0.0;
 
-    // insertDir (src/Reconstructor.cpp:407-422), once per image
-    if (tile == 0 && tid == 0 && a.O) {
+    // ---- stage the draws; insertDir (src/Reconstructor.cpp:407-422) once per image ----
+    for (int m = tid; m < a.mReco; m += kInsThreads) {
+        const size_t dm = (size_t)img * a.mReco + m;
+        const double* R = a.rotMat + dm * 9;
+        double* d = sDraw + 8 * m;
+        d[0] = R[0]; d[1] = R[1]; d[2] = R[2]; d[3] = R[3]; d[4] = R[4]; d[5] = R[5];
+        // translate(transImgP, orignImgP, -(tran - offset)(0), -(tran - offset)(1), ...), src/Optimiser.cpp:7160-7169
+        const double tx = a.trans[2 * dm] - offx, ty = a.trans[2 * dm + 1] - offy;
+        float* f = reinterpret_cast<float*>(d + 6);
+        f[0] = (float)(-tx) / a.idim;
+        f[1] = (float)(-ty) / a.idim;
+    }
+    if (tj == 0 && tid == 0 && a.O) {
         double ox = 0, oy = 0, oz = 0;
         for (int m = 0; m < a.mReco; m++) {
             const size_t dm = (size_t)img * a.mReco + m;
@@ -183,190 +331,100 @@ __global__ __launch_bounds__(kInsThreads) void k_insert_tiles(InsertTileArgs ta)
         unsafeAtomicAdd(&a.O[2], oz);
         if (a.counter) atomicAdd(a.counter, a.mReco);
     }
-
-    // this lane's pixel
-    const int pi = i0 + (lane & (kTB - 1)), pj = j0 + (lane >> 3);
-    int k = -1;
-    if (pi <= half && pj < half) k = ta.pixIndex[(pj + half) * (half + 1) + pi];
-    if (tid == 0) sAny = 0;
+    for (int e = tid; e < kBrickCap; e += kInsThreads) { sRe[e] = 0; sIm[e] = 0; sT[e] = 0; }
     if (tid < 3) { sMin[tid] = INT_MAX; sMax[tid] = INT_MIN; }
+    if (tid == 0) sAny = 0;
     __syncthreads();
-    if (k >= 0 && grp == 0) sAny = 1;
-    __syncthreads();
-    if (!sAny) return;
 
-    float2 dv = make_float2(0.f, 0.f);
-    float cf = 0.f;
-    if (k >= 0) {
-        dv = a.datP[(size_t)img * a.nPxl + k];
-        cf = a.ctfP[(size_t)img * a.nPxl + k];
-    }
-    const int icp = pi * a.opf, irp = pj * a.opf;
+    // ---- slab geometry from the first draw: dominant axis of the plane normal, column slopes ----
+    // (only the first two columns of R are staged; the normal is their cross product)
+    const double* R0 = sDraw;
+    const float n0 = (float)(R0[1] * R0[5] - R0[2] * R0[4]);
+    const float n1 = (float)(R0[2] * R0[3] - R0[0] * R0[5]);
+    const float n2 = (float)(R0[0] * R0[4] - R0[1] * R0[3]);
+    const float an0 = fabsf(n0), an1 = fabsf(n1), an2 = fabsf(n2);
+    const int ax = (an0 >= an1 && an0 >= an2) ? 0 : (an1 >= an2 ? 1 : 2);
+    const int pa = ax == 0 ? 1 : 0, qa = ax == 2 ? 1 : 2;
+    const float na = ax == 0 ? n0 : (ax == 1 ? n1 : n2);
+    TileGeom g;
+    g.sp = -(pa == 0 ? n0 : n1) / na;
+    g.sq = -(qa == 1 ? n1 : n2) / na;
     const float wgt = a.w[img];
-
-    // ---- fixed-point scale of the LDS accumulators ----
-    // Measured on MI355X (tools/lds_atomic_bench.hip): ds_add_f32 retires 0.33 lanes/clk/CU whatever the address
-    // pattern, ds_add_u32 6-8 lanes/clk/CU.  The brick therefore accumulates in 32-bit fixed point: every added term
-    // is bounded by B = max|dat| * max|ctf| * |w| over the tile (|ramp| = 1, trilinear weights <= 1), a voxel receives
-    // at most ~4*mReco terms from one tile, so the scale 2^s / B with s = 30 - ceil(log2(4 mReco)) cannot overflow.
-    // Quantisation is 2^-(s+1) B per term (2.4e-7 B at mReco = 100) -- below the rounding of a float accumulator
-    // holding a sum of that many terms -- and the integer sum is order-independent, i.e. deterministic.
-    {
-        float am = fabsf(dv.x) + fabsf(dv.y), cm = fabsf(cf);
-        am = wave_max(am);
-        cm = wave_max(cm);
-        if (lane == 0) { sAmax[grp] = am; sCmax[grp] = cm; }
-    }
-    __syncthreads();
-    float amax = 0.f, cmaxT = 0.f;
-#pragma unroll
-    for (int g = 0; g < kInsWaves; g++) { amax = fmaxf(amax, sAmax[g]); cmaxT = fmaxf(cmaxT, sCmax[g]); }
-    const float cmax = a.cSearch ? 1.0f : cmaxT;
-    const float boundF = amax * cmax * fabsf(wgt), boundT = cmax * cmax * fabsf(wgt);
-    if (!(boundF > 0.f) && !(boundT > 0.f)) return;
     int sbits = 30 - (32 - __clz(4 * a.mReco - 1));
     sbits = sbits < 8 ? 8 : sbits;
     const float q = ldexpf(1.0f, sbits);
-    const float scaleF = boundF > 0.f ? q / boundF : 0.f, scaleT = boundT > 0.f ? q / boundT : 0.f;
-    const float invF = boundF / q, invT = boundT / q;
-
-    // ---- slab geometry from the first draw: dominant axis of the plane normal, column slopes ----
-    const double* R0 = a.rotMat + (size_t)img * a.mReco * 9;
-    const float n0 = (float)R0[6], n1 = (float)R0[7], n2 = (float)R0[8];
-    const float an0 = fabsf(n0), an1 = fabsf(n1), an2 = fabsf(n2);
-    const int ax = (an0 >= an1 && an0 >= an2) ? 0 : (an1 >= an2 ? 1 : 2);   // dominant axis
-    const int pa = ax == 0 ? 1 : 0;                                           // p = x unless the dominant axis is x
-    const int qa = ax == 2 ? 1 : 2;
-    const float na = ax == 0 ? n0 : (ax == 1 ? n1 : n2);
-    const float sp = -(pa == 0 ? n0 : n1) / na, sq = -(qa == 1 ? n1 : n2) / na;
-    constexpr int M = (kTz - 2) / 2;
-
-    // ---- footprint bounding box from the tile corners over all draws ----
-    for (int m = tid; m < a.mReco; m += kInsThreads) {
-        const size_t dm = (size_t)img * a.mReco + m;
-        const double* R = a.rotMat + dm * 9;
-        double* d = sDraw + 8 * m;
-        d[0] = R[0]; d[1] = R[1]; d[2] = R[2]; d[3] = R[3]; d[4] = R[4]; d[5] = R[5];
-        // translate(transImgP, orignImgP, -(tran - offset)(0), -(tran - offset)(1), ...), src/Optimiser.cpp:7160-7169
-        const double tx = a.trans[2 * dm] - offx, ty = a.trans[2 * dm + 1] - offy;
-        float* f = reinterpret_cast<float*>(d + 6);
-        f[0] = (float)(-tx) / a.idim;
-        f[1] = (float)(-ty) / a.idim;
-    }
-    for (int t = tid; t < 4 * a.mReco; t += kInsThreads) {
-        const int m = t >> 2, c = t & 3;
-        const double* R = a.rotMat + ((size_t)img * a.mReco + m) * 9;
-        const int ci = (i0 + ((c & 1) ? kTB - 1 : 0)) * a.opf, cj = (j0 + ((c & 2) ? kTB - 1 : 0)) * a.opf;
-        const float x = (float)(R[0] * ci + R[3] * cj), y = (float)(R[1] * ci + R[4] * cj),
-                    z = (float)(R[2] * ci + R[5] * cj);
-        const int fx = (int)floorf(x), fy = (int)floorf(y), fz = (int)floorf(z);
-        atomicMin(&sMin[0], fx); atomicMax(&sMax[0], fx);
-        atomicMin(&sMin[1], fy); atomicMax(&sMax[1], fy);
-        atomicMin(&sMin[2], fz); atomicMax(&sMax[2], fz);
-    }
-    __syncthreads();
-    const int pmin = sMin[pa] - 1, qmin = sMin[qa] - 1;
-    int Wp = sMax[pa] + 1 - pmin + 1, Wq = sMax[qa] + 1 - qmin + 1;
-    if (Wp * kTz > kBrickCap) Wp = kBrickCap / kTz;
-    if (Wp * Wq * kTz > kBrickCap) Wq = kBrickCap / (Wp * kTz);
-    const int total = Wp * Wq * kTz;
-    const bool axisX = (ax == 0);
 
     const int nPass = a.cls ? a.nK : 1;
     for (int pass = 0; pass < nPass; pass++) {
-        // does any draw of this image go to class `pass`?
-        if (a.cls) {
+        if (a.cls) {  // does any draw of this image go to class `pass`?
             __syncthreads();
-            if (tid == 0) sAny = 0;
+            if (tid == 0) sCls = 0;
             __syncthreads();
             for (int m = tid; m < a.mReco; m += kInsThreads)
-                if (a.cls[(size_t)img * a.mReco + m] == pass) sAny = 1;
+                if (a.cls[(size_t)img * a.mReco + m] == pass) sCls = 1;
             __syncthreads();
-            if (!sAny) continue;
+            if (!sCls) continue;
         }
         float2* F = a.F + (size_t)pass * volSize;
         float* T = a.T + (size_t)pass * volSize;
-        for (int e = tid; e < total; e += kInsThreads) { sRe[e] = 0; sIm[e] = 0; sT[e] = 0; }
-        __syncthreads();
-
-        // ---- accumulate: wave `grp` takes draws grp, grp+4, ... ; lanes are the tile's pixels ----
-        if (k >= 0) {
-            for (int m = grp; m < a.mReco; m += kInsWaves) {
-                const size_t dm = (size_t)img * a.mReco + m;
-                if (a.cls && a.cls[dm] != pass) continue;
-                const double* R = sDraw + 8 * m;
-                const float rCol = reinterpret_cast<const float*>(R + 6)[0], rRow = reinterpret_cast<const float*>(R + 6)[1];
-                const float2 tv = cmul(dv, ramp_value(rCol, rRow, pi, pj));
-                float c = cf;
-                if (a.cSearch) {
-                    const CtfConst cc = ctf_const(a.attr[img], a.dfac[dm]);
-                    c = ctf_value(cc, a.pixelSize, a.idim, a.idim, pi, pj);
-                }
-                float vre = tv.x * c, vim = tv.y * c;
-                vre = vre * 1.0f; vim = vim * 1.0f;
-                vre = vre * wgt; vim = vim * wgt;
-                const float tval = pow2f_(c) * 1.0f * wgt;
-                float x = (float)(R[0] * icp + R[3] * irp);
-                float y = (float)(R[1] * icp + R[4] * irp);
-                float z = (float)(R[2] * icp + R[5] * irp);
-                if (!coord_in_grid(x, y, z, P)) continue;
-                bool conj = false;
-                if (!(x >= 0.0f)) { x *= -1.0f; y *= -1.0f; z *= -1.0f; conj = true; vim = -vim; }
-                const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
-                const int X0 = (int)fx, Y0 = (int)fy, Z0 = (int)fz;
-                const float xd = x - fx, yd = y - fy, zd = z - fz;
-                const float vx[2] = {1.0f - xd, xd}, vy[2] = {1.0f - yd, yd}, vz[2] = {1.0f - zd, zd};
-#pragma unroll
-                for (int kk = 0; kk < 2; kk++)
-#pragma unroll
-                    for (int jj = 0; jj < 2; jj++)
-#pragma unroll
-                        for (int ii = 0; ii < 2; ii++) {
-                            const float wv = vx[ii] * vy[jj] * vz[kk];
-                            const int X = X0 + ii, Y = Y0 + jj, Z = Z0 + kk;
-                            const int bx = conj ? -1 - X : X, by = conj ? -Y : Y, bz = conj ? -Z : Z;
-                            const int bp = sel3(pa, bx, by, bz), bq = sel3(qa, bx, by, bz), ba = sel3(ax, bx, by, bz);
-                            const int p_i = bp - pmin, q_i = bq - qmin;
-                            const int off = ba - ((int)floorf(sp * (float)bp + sq * (float)bq) - M);
-                            if ((unsigned)p_i < (unsigned)Wp && (unsigned)q_i < (unsigned)Wq && (unsigned)off < (unsigned)kTz) {
-                                const int idx = axisX ? ((q_i * Wp + p_i) * kTz + off) : ((q_i * kTz + off) * Wp + p_i);
-                                if (ta.debug & 1) continue;
-                                atomicAdd(&sRe[idx], __float2int_rn((vre * wv) * scaleF));
-                                atomicAdd(&sIm[idx], __float2int_rn((vim * wv) * scaleF));
-                                atomicAdd(&sT[idx], __float2int_rn((tval * wv) * scaleT));
-                                if (ta.stats) atomicAdd(&ta.stats[0], 1ULL);
-                            } else {
-                                if (ta.stats) atomicAdd(&ta.stats[1], 1ULL);
-                                if (ta.debug & 4) continue;
-                                const long gi = ((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X;
-                                unsafeAtomicAdd(&F[gi].x, vre * wv);
-                                unsafeAtomicAdd(&F[gi].y, vim * wv);
-                                unsafeAtomicAdd(&T[gi], tval * wv);
-                            }
-                        }
+        for (int ti = 0; ti < ta.tilesI; ti++) {
+            __syncthreads();   // the shared bounds / flags were reset by the previous tile (also on its `continue` paths)
+            const int i0 = ti * kTB;
+            // this lane's pixel of the tile
+            const int pi = i0 + (lane & (kTB - 1)), pj = j0 + (lane >> 3);
+            int k = -1;
+            if (pi <= half && pj < half) k = ta.pixIndex[(pj + half) * (half + 1) + pi];
+            float2 dv = make_float2(0.f, 0.f);
+            float cf = 0.f;
+            if (k >= 0) {
+                dv = a.datP[(size_t)img * a.nPxl + k];
+                cf = a.ctfP[(size_t)img * a.nPxl + k];
             }
-        }
-        __syncthreads();
-
-        // ---- flush: consecutive threads walk the brick's fastest axis = the volume's x axis ----
-        if (ta.debug & 2) continue;
-        for (int e = tid; e < total; e += kInsThreads) {
-            const int ire = sRe[e], iim = sIm[e], itt = sT[e];
-            if ((ire | iim | itt) == 0) continue;
-            const float re = (float)ire * invF, im = (float)iim * invF, tt = (float)itt * invT;
-            int p_i, q_i, off;
-            if (axisX) { off = e % kTz; p_i = (e / kTz) % Wp; q_i = e / (kTz * Wp); }
-            else { p_i = e % Wp; off = (e / Wp) % kTz; q_i = e / (Wp * kTz); }
-            const int bp = p_i + pmin, bq = q_i + qmin;
-            const int ba = off + ((int)floorf(sp * (float)bp + sq * (float)bq) - M);
-            int X = pa == 0 ? bp : ba;                       // x is either the p axis or the dominant axis
-            int Y = pa == 1 ? bp : (qa == 1 ? bq : ba);
-            int Z = qa == 2 ? bq : ba;
-            if (X < 0) { X = -1 - X; Y = -Y; Z = -Z; }
-            const long gi = ((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X;
-            unsafeAtomicAdd(&F[gi].x, re);
-            unsafeAtomicAdd(&F[gi].y, im);
-            unsafeAtomicAdd(&T[gi], tt);
+            // bounds for the fixed-point scale (see the header comment) and the footprint box of the tile corners
+            {
+                float am = wave_max(fabsf(dv.x) + fabsf(dv.y)), cm = wave_max(fabsf(cf));
+                if (lane == 0) { sAmax[grp] = am; sCmax[grp] = cm; }
+                if (k >= 0 && grp == 0) sAny = 1;
+            }
+            for (int t = tid; t < 4 * a.mReco; t += kInsThreads) {
+                const int m = t >> 2, c = t & 3;
+                const double* R = sDraw + 8 * m;
+                const int ci = (i0 + ((c & 1) ? kTB - 1 : 0)) * a.opf, cj = (j0 + ((c & 2) ? kTB - 1 : 0)) * a.opf;
+                const float x = (float)(R[0] * ci + R[3] * cj), y = (float)(R[1] * ci + R[4] * cj),
+                            z = (float)(R[2] * ci + R[5] * cj);
+                const int fx = (int)floorf(x), fy = (int)floorf(y), fz = (int)floorf(z);
+                atomicMin(&sMin[0], fx); atomicMax(&sMax[0], fx);
+                atomicMin(&sMin[1], fy); atomicMax(&sMax[1], fy);
+                atomicMin(&sMin[2], fz); atomicMax(&sMax[2], fz);
+            }
+            __syncthreads();
+            const bool any = sAny != 0;
+            float amax = 0.f, cmaxT = 0.f;
+#pragma unroll
+            for (int w = 0; w < kInsWaves; w++) { amax = fmaxf(amax, sAmax[w]); cmaxT = fmaxf(cmaxT, sCmax[w]); }
+            g.pmin = sMin[pa] - 1;
+            g.qmin = sMin[qa] - 1;
+            g.Wp = sMax[pa] + 1 - g.pmin + 1;
+            g.Wq = sMax[qa] + 1 - g.qmin + 1;
+            __syncthreads();   // everyone has read the shared bounds: reset them for the next tile
+            if (tid < 3) { sMin[tid] = INT_MAX; sMax[tid] = INT_MIN; }
+            if (tid == 0) sAny = 0;
+            const float cmax = a.cSearch ? 1.0f : cmaxT;
+            const float boundF = amax * cmax * fabsf(wgt), boundT = cmax * cmax * fabsf(wgt);
+            if (!any || (!(boundF > 0.f) && !(boundT > 0.f))) continue;
+            if (g.Wp < 0) g.Wp = 0;
+            if (g.Wq < 0) g.Wq = 0;
+            if (g.Wp * kTz > kBrickCap - 1) g.Wp = (kBrickCap - 1) / kTz;
+            if (g.Wp * g.Wq * kTz > kBrickCap - 1) g.Wq = (kBrickCap - 1) / (g.Wp * kTz);
+            g.total = g.Wp * g.Wq * kTz;
+            g.scaleF = boundF > 0.f ? q / boundF : 0.f;
+            g.scaleT = boundT > 0.f ? q / boundT : 0.f;
+            g.invF = boundF / q;
+            g.invT = boundT / q;
+            if (ax == 0) insert_tile_body<0, DBG>(ta, g, sRe, sIm, sT, sDraw, img, pass, k, pi, pj, dv, cf, wgt, F, T, &sAny);
+            else if (ax == 1) insert_tile_body<1, DBG>(ta, g, sRe, sIm, sT, sDraw, img, pass, k, pi, pj, dv, cf, wgt, F, T, &sAny);
+            else insert_tile_body<2, DBG>(ta, g, sRe, sIm, sT, sDraw, img, pass, k, pi, pj, dv, cf, wgt, F, T, &sAny);
+            __syncthreads();   // brick re-zeroed before the next tile accumulates
         }
     }
 }
@@ -502,10 +560,13 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
     THX_REQUIRE(!tiles || ldsBytes <= 160 * 1024, "mReco too large for the LDS draw table");
     if (tiles) {
         const size_t tb = (size_t)idim * (half + 1) * sizeof(int);
-        THX_CHECK(hipMallocAsync(reinterpret_cast<void**>(&pixIndex), tb, st));
+        pixIndex = reinterpret_cast<int*>(scratch(st, 0, tb));
+        THX_REQUIRE(pixIndex, "device scratch allocation failed");
         THX_CHECK(hipMemsetAsync(pixIndex, 0xFF, tb, st));
         hipLaunchKernelGGL(k_pix_index, dim3((nPxl + 255) / 256), dim3(256), 0, st, pixIndex, iCol, iRow, nPxl, idim);
-        THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_insert_tiles),
+        THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_insert_tiles<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+        THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_insert_tiles<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
     }
     for (int l0 = 0; l0 < nImg; l0 += 65535) {
@@ -528,13 +589,15 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
                 THX_CHECK(hipMemsetAsync(g_insert_stats, 0, 2 * sizeof(unsigned long long), st));
                 ta.stats = g_insert_stats;
             }
-            hipLaunchKernelGGL(k_insert_tiles, dim3(tilesI * tilesJ, nl), dim3(kInsThreads), ldsBytes, st, ta);
+            if (ta.debug)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_insert_tiles<true>), dim3(tilesJ, nl), dim3(kInsThreads), ldsBytes, st, ta);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_insert_tiles<false>), dim3(tilesJ, nl), dim3(kInsThreads), ldsBytes, st, ta);
         } else {
             hipLaunchKernelGGL(k_insert, dim3((nPxl + 255) / 256, nl), dim3(256), 0, st, b);
         }
     }
     THX_LAUNCH_CHECK();
-    if (pixIndex) THX_CHECK(hipFreeAsync(pixIndex, st));
     return 0;
 }
 
@@ -544,14 +607,14 @@ int thx_normalise_tf_dev(float* F, float* T, int dim, void* stream)
     hipStream_t st = as_stream(stream);
     const size_t n = (size_t)dim * dim * (dim / 2 + 1);
     float* sf = nullptr;
-    THX_CHECK(hipMallocAsync(reinterpret_cast<void**>(&sf), sizeof(float), st));
+    sf = reinterpret_cast<float*>(scratch(st, 1, sizeof(float)));
+    THX_REQUIRE(sf, "device scratch allocation failed");
     hipLaunchKernelGGL(k_read_sf, dim3(1), dim3(1), 0, st, T, sf);
     const size_t nF = 2 * n, nT = n;
     const size_t nF4 = nF / 4, nT4 = nT / 4;
     hipLaunchKernelGGL(k_scale_tf, dim3(2048), dim3(256), 0, st, reinterpret_cast<float4*>(F), reinterpret_cast<float4*>(T),
                        nF4, nT4, F + nF4 * 4, T + nT4 * 4, (int)(nF - nF4 * 4), (int)(nT - nT4 * 4), sf);
     THX_LAUNCH_CHECK();
-    THX_CHECK(hipFreeAsync(sf, st));
     return 0;
 }
 

@@ -484,13 +484,13 @@ int thx_fsc_dev(float* fsc, int nShell, const float* A, const float* B, int dim,
     THX_REQUIRE(fsc && A && B && nShell > 0 && nShell <= 4096, "bad arguments");
     hipStream_t st = as_stream(stream);
     double* acc = nullptr;
-    THX_CHECK(hipMallocAsync(reinterpret_cast<void**>(&acc), 3 * nShell * sizeof(double), st));
+    acc = reinterpret_cast<double*>(scratch(st, 2, 3 * nShell * sizeof(double)));
+    THX_REQUIRE(acc, "device scratch allocation failed");
     THX_CHECK(hipMemsetAsync(acc, 0, 3 * nShell * sizeof(double), st));
     hipLaunchKernelGGL(k_fsc_accum, dim3(1024), dim3(256), 3 * nShell * sizeof(float), st, acc, nShell,
                        reinterpret_cast<const float2*>(A), reinterpret_cast<const float2*>(B), dim);
     hipLaunchKernelGGL(k_fsc_final, dim3((nShell + 255) / 256), dim3(256), 0, st, fsc, acc, nShell);
     THX_LAUNCH_CHECK();
-    THX_CHECK(hipFreeAsync(acc, st));
     return 0;
 }
 
