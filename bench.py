@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--mLT", type=int, default=9)
     ap.add_argument("--phases", type=int, default=3)
     ap.add_argument("--mReco", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=2048)
+    ap.add_argument("--batch", type=int, default=10240, help="max images per kernel launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles", type=int, default=0)
     args = ap.parse_args()
@@ -132,13 +132,19 @@ def main():
         else:
             kname, kms, kbytes = "k_expect_local", exp_ms, exp_bytes
         achieved = kbytes / (kms * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel from the committed PMC profile (FETCH_SIZE + WRITE_SIZE, separate rocprofv3
+        # passes, corrected as MI355X_MICROARCH.md prescribes), scaled to this run's images per launch; null if absent
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                if j.get("kernel") == kname and j.get("box") == args.box and j.get("batch") == args.batch:
-                    traffic = j.get("hbm_bytes_per_launch")
+                if j.get("box") == args.box:
+                    nper = float(np.mean([n for _, n in (exp if kname == "k_expect_local" else ins)]))
+                    if kname == "k_expect_local":
+                        traffic = j["hbm_bytes_per_image_phase"] * nper
+                    else:
+                        traffic = j["k_insert_tiles_hbm_bytes_per_image"] * nper
             except Exception:
                 traffic = None
         out = {

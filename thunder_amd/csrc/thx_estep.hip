@@ -3,6 +3,7 @@
 // Reference behaviour: src/Optimiser.cpp:622-1681 (expectation), src/Projector.cpp:356-374,
 // src/CTF.cpp:113-151, src/Image/ImageFunctions.cpp:233-252.  gfx950 only; wavefront = 64.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <map>
 #include <mutex>
@@ -170,6 +171,7 @@ struct ExpectLocalArgs {
     float* partV;  // [nImg][nD][nSplit][nT][nRpad]
     float* partC;  // [nImg][nD][nSplit]
     int nRpad;
+    float dbgScale;  // 1 in production; THX_EXPECT_DEBUG shrinks the sampled region (cache-resident) for profiling
 };
 
 template <int NT>
@@ -246,9 +248,9 @@ __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
             if (rvalid) {
                 for (int e = sub; e < clen; e += nSub) {
                     const double nx = (double)sIc[e], ny = (double)sIr[e];
-                    const float x = (float)(m0 * nx + m3 * ny);
-                    const float y = (float)(m1 * nx + m4 * ny);
-                    const float z = (float)(m2 * nx + m5 * ny);
+                    const float x = (float)(m0 * nx + m3 * ny) * a.dbgScale;
+                    const float y = (float)(m1 * nx + m4 * ny) * a.dbgScale;
+                    const float z = (float)(m2 * nx + m5 * ny) * a.dbgScale;
                     float2 q = make_float2(0.f, 0.f);
                     if (coord_in_grid(x, y, z, P)) q = interp_ft(vol, P, x, y, z);
                     accB = fmaf(sB[e], fmaf(q.x, q.x, q.y * q.y), accB);
@@ -667,6 +669,10 @@ int thx_expect_local_dev(const float* volumes, const int* volIdx, int vdim, int 
     a.datP = reinterpret_cast<const float2*>(datP);
     a.ctfP = ctfP; a.sigRcpP = sigRcpP; a.rotMat = rotMat; a.nR = nR; a.trans = trans; a.nT = nT; a.nD = nD;
     a.nSplit = expect_local_nsplit(nImg);
+    {
+        const char* dbg = getenv("THX_EXPECT_DEBUG");
+        a.dbgScale = (dbg && dbg[0] == '1') ? 0.0625f : 1.0f;   // x * 1.0f is exact: production results unchanged
+    }
     a.nRpad = ((nR + 63) / 64) * 64;
     a.partV = reinterpret_cast<float*>(workspace);
     a.partC = a.partV + (size_t)nImg * nD * a.nSplit * nT * a.nRpad;

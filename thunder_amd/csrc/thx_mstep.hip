@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void k_insert(InsertArgs a)
 // ---------------------------------------------------------------------------------------------
 constexpr int kTB = 8;            // tile edge, image pixels
 constexpr int kTz = 8;            // brick thickness along the dominant axis, voxels
-constexpr int kBrickCap = 6144;   // brick voxels (x 12 B = 72 KB of LDS -> 2 workgroups per CU)
+constexpr int kBrickCap = 5376;   // brick voxels (x 12 B = 63 KB of LDS; with the draw tables 2 workgroups per CU)
+constexpr int kMaxU = 16;         // unique shifts whose per-pixel ramps are tabulated in LDS (else computed per member)
 constexpr int kInsThreads = 512;  // 64 pixels x 8 draw groups: 16 waves per CU at 2 workgroups per CU
 constexpr int kInsWaves = kInsThreads / 64;
 
@@ -141,9 +142,75 @@ struct InsertTileArgs {
     InsertArgs a;
     const int* pixIndex;  // [idim][idim/2+1] pixel-list position of (iRow + idim/2, iCol) or -1
     int tilesI;           // tiles along iCol
+    const int* plan;      // k_insert_plan output, plan_stride(mReco) ints per image
     int debug;            // THX_INSERT_DEBUG bit mask (profiling only): 1 skip LDS adds, 2 skip flush, 4 skip fallback
     unsigned long long* stats;  // optional [2]: in-brick voxel adds, fallback voxel adds
 };
+
+// ---------------------------------------------------------------------------------------------
+// Insert plan.  The mReco draws of one image come from a resampled particle filter (Particle::rand picks among
+// resampled support points, src/Particle.cpp:2109-2178), so many draws share the same rotation and the shifts take
+// only ~mLT distinct values.  Draws with bit-identical (rotation[, class][, defocus factor]) form a GROUP: their
+// trilinear cell and weights are identical, so  sum_m (img * ramp_m) * ctf * w * wv  is inserted once as
+// (img * sum_m ramp_m) * ctf * w * wv  (distributivity: results equal to rounding) and T gets n_g * ctf^2 * w * wv.
+// Per image: [0] G, [1] U, gStart[mReco+1], ord[mReco] (draws sorted by group), uid[mReco] (unique-shift id per draw),
+// gRep[mReco] (representative draw of group g), tRep[mReco] (representative draw of unique shift u).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline int plan_stride(int mReco) { return 5 * mReco + 3; }
+
+__global__ __launch_bounds__(128) void k_insert_plan(int* __restrict__ plan, const double* __restrict__ rotMat,
+                                                     const double* __restrict__ trans, const int* __restrict__ cls,
+                                                     const double* __restrict__ dfac, int cSearch, int mReco)
+{
+    extern __shared__ int sp[];   // first[mReco] | firstT[mReco] | gid[mReco] | uid[mReco] | cnt[mReco]
+    int* first = sp;
+    int* firstT = sp + mReco;
+    int* gid = sp + 2 * mReco;
+    int* uid = sp + 3 * mReco;
+    int* cnt = sp + 4 * mReco;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const long long* R = reinterpret_cast<const long long*>(rotMat) + (size_t)img * mReco * 9;
+    const long long* Tt = reinterpret_cast<const long long*>(trans) + (size_t)img * mReco * 2;
+    const int* c = cls ? cls + (size_t)img * mReco : nullptr;
+    const long long* D = (cSearch && dfac) ? reinterpret_cast<const long long*>(dfac) + (size_t)img * mReco : nullptr;
+    for (int m = tid; m < mReco; m += blockDim.x) {
+        int f = m, ft = m;
+        for (int q = 0; q < m; q++) {
+            bool same = true;
+            for (int e = 0; e < 6; e++) same = same && (R[9 * q + e] == R[9 * m + e]);
+            if (c) same = same && (c[q] == c[m]);
+            if (D) same = same && (D[q] == D[m]);
+            if (same) { f = q; break; }
+        }
+        for (int q = 0; q < m; q++)
+            if (Tt[2 * q] == Tt[2 * m] && Tt[2 * q + 1] == Tt[2 * m + 1]) { ft = q; break; }
+        first[m] = f;
+        firstT[m] = ft;
+    }
+    __syncthreads();
+    int* out = plan + (size_t)img * plan_stride(mReco);
+    int* gStart = out + 2;
+    int* ord = gStart + mReco + 1;
+    int* ouid = ord + mReco;
+    int* gRep = ouid + mReco;
+    int* tRep = gRep + mReco;
+    if (tid == 0) {
+        int G = 0, U = 0;
+        for (int m = 0; m < mReco; m++) {
+            if (first[m] == m) { gid[m] = G; gRep[G] = m; cnt[G] = 0; G++; } else gid[m] = gid[first[m]];
+            if (firstT[m] == m) { uid[m] = U; tRep[U] = m; U++; } else uid[m] = uid[firstT[m]];
+        }
+        for (int m = 0; m < mReco; m++) cnt[gid[m]]++;
+        int run = 0;
+        for (int g = 0; g < G; g++) { gStart[g] = run; run += cnt[g]; cnt[g] = gStart[g]; }
+        gStart[G] = run;
+        for (int m = 0; m < mReco; m++) { const int pos = cnt[gid[m]]++; ord[pos] = m; }
+        out[0] = G;
+        out[1] = U;
+    }
+    __syncthreads();
+    for (int m = tid; m < mReco; m += blockDim.x) ouid[m] = uid[m];
+}
 
 template <int W>
 __device__ __forceinline__ int comp3(int x, int y, int z) { return W == 0 ? x : (W == 1 ? y : z); }
@@ -156,10 +223,20 @@ struct TileGeom {
     float scaleF, scaleT, invF, invT;
 };
 
+struct DrawTables {      // LDS-resident per-image tables built from the insert plan
+    const double* R;     // [G][6] rotation columns of each group's representative draw
+    const int* gStart;   // [G+1]
+    const int* mUid;     // [mReco] unique-shift id of the members, grouped
+    const int* gInfo;    // [G][2]: class, representative draw
+    const float* slope;  // [U][2] ramp slopes of the unique shifts
+    const float2* ramp;  // [U][64] per-pixel ramps of this tile (valid when U <= kMaxU)
+    int G, U;
+};
+
 template <int AX, bool DBG>
 __device__ __forceinline__ void insert_tile_body(const InsertTileArgs& ta, const TileGeom& g, int* sRe, int* sIm, int* sT,
-                                                 const double* sDraw, int img, int pass, int k, int pi, int pj, float2 dv,
-                                                 float cf, float wgt, float2* F, float* T, int* sSync)
+                                                 const DrawTables& dt, int img, int pass, int k, int pi, int pj, float2 dv,
+                                                 float cf, float wgt, float2* F, float* T)
 {
     const InsertArgs& a = ta.a;
     constexpr int pa = AX == 0 ? 1 : 0;   // p = x unless the dominant axis is x
@@ -170,23 +247,32 @@ __device__ __forceinline__ void insert_tile_body(const InsertTileArgs& ta, const
     const long nc = P / 2 + 1;
     const int icp = pi * a.opf, irp = pj * a.opf;
 
+    const int lane = tid & 63;
     if (k >= 0) {
-        for (int m = grp; m < a.mReco; m += kInsWaves) {
-            const size_t dm = (size_t)img * a.mReco + m;
-            if (a.cls && a.cls[dm] != pass) continue;
-            const double* R = sDraw + 8 * m;
-            const float rCol = reinterpret_cast<const float*>(R + 6)[0], rRow = reinterpret_cast<const float*>(R + 6)[1];
-            const float2 tv = cmul(dv, ramp_value(rCol, rRow, pi, pj));
+        for (int gi_ = grp; gi_ < dt.G; gi_ += kInsWaves) {
+            if (a.cls && dt.gInfo[2 * gi_] != pass) continue;
+            const double* R = dt.R + 6 * gi_;
+            // sum of the members' phase ramps; n = number of members
+            const int m0 = dt.gStart[gi_], m1 = dt.gStart[gi_ + 1];
+            float2 S = make_float2(0.f, 0.f);
+            for (int i = m0; i < m1; i++) {
+                const int u = dt.mUid[i];
+                const float2 r = dt.U <= kMaxU ? dt.ramp[u * 64 + lane] : ramp_value(dt.slope[2 * u], dt.slope[2 * u + 1], pi, pj);
+                S.x += r.x;
+                S.y += r.y;
+            }
+            const float nmem = (float)(m1 - m0);
+            const float2 tv = cmul(dv, S);
             float c = cf;
             if (a.cSearch) {
-                const CtfConst cc = ctf_const(a.attr[img], a.dfac[dm]);
+                const CtfConst cc = ctf_const(a.attr[img], a.dfac[(size_t)img * a.mReco + dt.gInfo[2 * gi_ + 1]]);
                 c = ctf_value(cc, a.pixelSize, a.idim, a.idim, pi, pj);
             }
-            // src[i] * ctf[i] * 1 * w, left to right (src/Reconstructor.cpp:830-833)
+            // src[i] * ctf[i] * 1 * w, left to right (src/Reconstructor.cpp:830-833), summed over the group's members
             float vre = tv.x * c, vim = tv.y * c;
             vre = vre * 1.0f; vim = vim * 1.0f;
             vre = vre * wgt; vim = vim * wgt;
-            const float tval = pow2f_(c) * 1.0f * wgt;
+            const float tval = (pow2f_(c) * 1.0f * wgt) * nmem;
             float x = (float)(R[0] * icp + R[3] * irp);
             float y = (float)(R[1] * icp + R[4] * irp);
             float z = (float)(R[2] * icp + R[5] * irp);
@@ -280,7 +366,6 @@ __device__ __forceinline__ void insert_tile_body(const InsertTileArgs& ta, const
         unsafeAtomicAdd(&F[gi].y, im);
         unsafeAtomicAdd(&T[gi], tt);
     }
-    (void)sSync;
 }
 
 // grid (tilesJ, nImg): one workgroup owns a strip of tiles of one image (all tiles of one 8-row band), so the per-draw
@@ -293,7 +378,13 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_tiles(InsertTileArgs 
     int* sRe = brick;
     int* sIm = brick + kBrickCap;
     int* sT = brick + 2 * kBrickCap;
-    double* sDraw = reinterpret_cast<double*>(brick + 3 * kBrickCap);  // [mReco][8]: R[0..5], ramp slopes
+    // LDS tables after the brick: group rotations | gStart | member shift ids | group info | shift slopes | tile ramps
+    double* sR = reinterpret_cast<double*>(brick + 3 * kBrickCap);          // [mReco][6]
+    int* sGStart = reinterpret_cast<int*>(sR + 6 * a.mReco);                // [mReco+1]
+    int* sMUid = sGStart + a.mReco + 1;                                      // [mReco]
+    int* sGInfo = sMUid + a.mReco;                                           // [mReco][2]
+    float* sSlope = reinterpret_cast<float*>(sGInfo + 2 * a.mReco);          // [mReco][2]
+    float2* sRamp = reinterpret_cast<float2*>(sSlope + 2 * a.mReco + ((a.mReco & 1) ? 0 : 1));  // 8-byte aligned, [kMaxU][64]
     __shared__ int sMin[3], sMax[3], sAny, sCls;
     __shared__ float sAmax[kInsWaves], sCmax[kInsWaves];
 
@@ -304,17 +395,30 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_tiles(InsertTileArgs 
     const int j0 = tj * kTB - half;
     const double offx = a.offS ? a.offS[2 * img] : 0.0, offy = a.offS ? a.offS[2 * img + 1] : 0.0;
 
-    // ---- stage the draws; insertDir (src/Reconstructor.cpp:407-422) once per image ----
-    for (int m = tid; m < a.mReco; m += kInsThreads) {
-        const size_t dm = (size_t)img * a.mReco + m;
-        const double* R = a.rotMat + dm * 9;
-        double* d = sDraw + 8 * m;
+    // ---- stage the insert plan of this image; insertDir (src/Reconstructor.cpp:407-422) once per image ----
+    const int* plan = ta.plan + (size_t)img * plan_stride(a.mReco);
+    const int G = plan[0], U = plan[1];
+    const int* pGStart = plan + 2;
+    const int* pOrd = pGStart + a.mReco + 1;
+    const int* pUid = pOrd + a.mReco;
+    const int* pGRep = pUid + a.mReco;
+    const int* pTRep = pGRep + a.mReco;
+    for (int gi_ = tid; gi_ < G; gi_ += kInsThreads) {
+        const int rep = pGRep[gi_];
+        const double* R = a.rotMat + ((size_t)img * a.mReco + rep) * 9;
+        double* d = sR + 6 * gi_;
         d[0] = R[0]; d[1] = R[1]; d[2] = R[2]; d[3] = R[3]; d[4] = R[4]; d[5] = R[5];
+        sGInfo[2 * gi_] = a.cls ? a.cls[(size_t)img * a.mReco + rep] : 0;
+        sGInfo[2 * gi_ + 1] = rep;
+    }
+    for (int i = tid; i <= G; i += kInsThreads) sGStart[i] = pGStart[i];
+    for (int i = tid; i < a.mReco; i += kInsThreads) sMUid[i] = pUid[pOrd[i]];
+    for (int u = tid; u < U; u += kInsThreads) {
+        const size_t dm = (size_t)img * a.mReco + pTRep[u];
         // translate(transImgP, orignImgP, -(tran - offset)(0), -(tran - offset)(1), ...), src/Optimiser.cpp:7160-7169
         const double tx = a.trans[2 * dm] - offx, ty = a.trans[2 * dm + 1] - offy;
-        float* f = reinterpret_cast<float*>(d + 6);
-        f[0] = (float)(-tx) / a.idim;
-        f[1] = (float)(-ty) / a.idim;
+        sSlope[2 * u] = (float)(-tx) / a.idim;
+        sSlope[2 * u + 1] = (float)(-ty) / a.idim;
     }
     if (tj == 0 && tid == 0 && a.O) {
         double ox = 0, oy = 0, oz = 0;
@@ -338,7 +442,7 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_tiles(InsertTileArgs 
 
     // ---- slab geometry from the first draw: dominant axis of the plane normal, column slopes ----
     // (only the first two columns of R are staged; the normal is their cross product)
-    const double* R0 = sDraw;
+    const double* R0 = sR;
     const float n0 = (float)(R0[1] * R0[5] - R0[2] * R0[4]);
     const float n1 = (float)(R0[2] * R0[3] - R0[0] * R0[5]);
     const float n2 = (float)(R0[0] * R0[4] - R0[1] * R0[3]);
@@ -350,6 +454,8 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_tiles(InsertTileArgs 
     g.sp = -(pa == 0 ? n0 : n1) / na;
     g.sq = -(qa == 1 ? n1 : n2) / na;
     const float wgt = a.w[img];
+    DrawTables dt;
+    dt.R = sR; dt.gStart = sGStart; dt.mUid = sMUid; dt.gInfo = sGInfo; dt.slope = sSlope; dt.ramp = sRamp; dt.G = G; dt.U = U;
     int sbits = 30 - (32 - __clz(4 * a.mReco - 1));
     sbits = sbits < 8 ? 8 : sbits;
     const float q = ldexpf(1.0f, sbits);
@@ -360,8 +466,8 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_tiles(InsertTileArgs 
             __syncthreads();
             if (tid == 0) sCls = 0;
             __syncthreads();
-            for (int m = tid; m < a.mReco; m += kInsThreads)
-                if (a.cls[(size_t)img * a.mReco + m] == pass) sCls = 1;
+            for (int gi_ = tid; gi_ < G; gi_ += kInsThreads)
+                if (sGInfo[2 * gi_] == pass) sCls = 1;
             __syncthreads();
             if (!sCls) continue;
         }
@@ -386,9 +492,11 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_tiles(InsertTileArgs 
                 if (lane == 0) { sAmax[grp] = am; sCmax[grp] = cm; }
                 if (k >= 0 && grp == 0) sAny = 1;
             }
-            for (int t = tid; t < 4 * a.mReco; t += kInsThreads) {
+            if (U <= kMaxU)   // per-pixel ramps of the unique shifts, shared by all groups of this tile
+                for (int u = grp; u < U; u += kInsWaves) sRamp[u * 64 + lane] = ramp_value(sSlope[2 * u], sSlope[2 * u + 1], pi, pj);
+            for (int t = tid; t < 4 * G; t += kInsThreads) {
                 const int m = t >> 2, c = t & 3;
-                const double* R = sDraw + 8 * m;
+                const double* R = sR + 6 * m;
                 const int ci = (i0 + ((c & 1) ? kTB - 1 : 0)) * a.opf, cj = (j0 + ((c & 2) ? kTB - 1 : 0)) * a.opf;
                 const float x = (float)(R[0] * ci + R[3] * cj), y = (float)(R[1] * ci + R[4] * cj),
                             z = (float)(R[2] * ci + R[5] * cj);
@@ -421,9 +529,9 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_tiles(InsertTileArgs 
             g.scaleT = boundT > 0.f ? q / boundT : 0.f;
             g.invF = boundF / q;
             g.invT = boundT / q;
-            if (ax == 0) insert_tile_body<0, DBG>(ta, g, sRe, sIm, sT, sDraw, img, pass, k, pi, pj, dv, cf, wgt, F, T, &sAny);
-            else if (ax == 1) insert_tile_body<1, DBG>(ta, g, sRe, sIm, sT, sDraw, img, pass, k, pi, pj, dv, cf, wgt, F, T, &sAny);
-            else insert_tile_body<2, DBG>(ta, g, sRe, sIm, sT, sDraw, img, pass, k, pi, pj, dv, cf, wgt, F, T, &sAny);
+            if (ax == 0) insert_tile_body<0, DBG>(ta, g, sRe, sIm, sT, dt, img, pass, k, pi, pj, dv, cf, wgt, F, T);
+            else if (ax == 1) insert_tile_body<1, DBG>(ta, g, sRe, sIm, sT, dt, img, pass, k, pi, pj, dv, cf, wgt, F, T);
+            else insert_tile_body<2, DBG>(ta, g, sRe, sIm, sT, dt, img, pass, k, pi, pj, dv, cf, wgt, F, T);
             __syncthreads();   // brick re-zeroed before the next tile accumulates
         }
     }
@@ -554,9 +662,12 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
     const bool tiles = !(plain && plain[0] == '1');
     hipStream_t st = as_stream(stream);
     int* pixIndex = nullptr;
+    int* plan = nullptr;
     const int half = idim / 2;
     const int tilesI = (half + 1 + kTB - 1) / kTB, tilesJ = (idim + kTB - 1) / kTB;
-    const size_t ldsBytes = 3 * (size_t)kBrickCap * sizeof(int) + (size_t)mReco * 8 * sizeof(double);
+    const size_t ldsBytes = 3 * (size_t)kBrickCap * sizeof(int) + (size_t)mReco * 6 * sizeof(double) +
+                            ((size_t)(mReco + 1) + mReco + 2 * mReco) * sizeof(int) + (2 * (size_t)mReco + 2) * sizeof(float) +
+                            (size_t)kMaxU * 64 * sizeof(float2) + 16;
     THX_REQUIRE(!tiles || ldsBytes <= 160 * 1024, "mReco too large for the LDS draw table");
     if (tiles) {
         const size_t tb = (size_t)idim * (half + 1) * sizeof(int);
@@ -564,6 +675,10 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
         THX_REQUIRE(pixIndex, "device scratch allocation failed");
         THX_CHECK(hipMemsetAsync(pixIndex, 0xFF, tb, st));
         hipLaunchKernelGGL(k_pix_index, dim3((nPxl + 255) / 256), dim3(256), 0, st, pixIndex, iCol, iRow, nPxl, idim);
+        plan = reinterpret_cast<int*>(scratch(st, 3, (size_t)nImg * plan_stride(mReco) * sizeof(int)));
+        THX_REQUIRE(plan, "device scratch allocation failed");
+        hipLaunchKernelGGL(k_insert_plan, dim3(nImg), dim3(128), 5 * (size_t)mReco * sizeof(int), st, plan, rotMat, trans, cls, dfac,
+                           cSearch, mReco);
         THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_insert_tiles<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
         THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_insert_tiles<true>),
@@ -581,6 +696,7 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
         if (tiles) {
             InsertTileArgs ta;
             ta.a = b; ta.pixIndex = pixIndex; ta.tilesI = tilesI;
+            ta.plan = plan + (size_t)l0 * plan_stride(mReco);
             const char* dbg = getenv("THX_INSERT_DEBUG");
             ta.debug = dbg ? atoi(dbg) : 0;
             ta.stats = nullptr;

@@ -64,13 +64,16 @@ class RefineShard:
     """HBM-resident shard of synthetic particles + one EM iteration over it (SURVEY 8d inputs)."""
 
     def __init__(self, N, nImg, device, rank=0, world=1, pf=2, mLR=125, mLT=9, nPhase=3, mReco=100, seed=1000,
-                 batch=2048, pixelSize=1.32, snr=0.01, rL=2, ops=None, oracle_pixel_list=None):
+                 batch=10240, pixelSize=1.32, snr=0.01, rL=2, ops=None, oracle_pixel_list=None):
         if ops is None:
             from . import ops as _ops
             ops = _ops
         self.ops = ops
         self.N, self.pf, self.P = N, pf, N * pf
         self.nImg, self.dev, self.rank, self.world = nImg, device, rank, world
+        # images per launch: balanced batches of at most `batch` (a short last batch leaves the chip half empty)
+        nb = max(1, -(-nImg // max(1, batch)))
+        batch = -(-nImg // nb)
         self.mLR, self.mLT, self.nPhase, self.mReco, self.batch = mLR, mLT, nPhase, mReco, batch
         self.rU = N // 2 - 2
         self.maxRadius = self.rU
@@ -171,11 +174,16 @@ class RefineShard:
         return wR, wT
 
     def draw_reco(self, wR, wT):
-        """mReco draws per image from the last phase's support points by posterior weight (seeded); the reference's
-        Particle::rand picks uniformly among RESAMPLED points (src/Particle.cpp:2109-2178), which is the same law."""
+        """mReco draws per image for the insertion, as the reference makes them: the particle filter is first RESAMPLED
+        by weight to mLR / mLT support points (Particle::resample at the end of the phase, src/Optimiser.cpp:1470-1488),
+        then Particle::rand picks uniformly among the resampled points (src/Particle.cpp:2109-2178).  Seeded."""
         p = self.nPhase - 1
-        iR = torch.multinomial(wR.clamp_min(1e-30), self.mReco, replacement=True, generator=self.gen)
-        iT = torch.multinomial(wT.clamp_min(1e-30), self.mReco, replacement=True, generator=self.gen)
+        rsR = torch.multinomial(wR.clamp_min(1e-30), self.mLR, replacement=True, generator=self.gen)   # resample
+        rsT = torch.multinomial(wT.clamp_min(1e-30), self.mLT, replacement=True, generator=self.gen)
+        uR = torch.randint(0, self.mLR, (self.nImg, self.mReco), device=self.dev, generator=self.gen)  # rand
+        uT = torch.randint(0, self.mLT, (self.nImg, self.mReco), device=self.dev, generator=self.gen)
+        iR = torch.gather(rsR, 1, uR)
+        iT = torch.gather(rsT, 1, uT)
         rot = torch.gather(self.rotP[p], 1, iR[:, :, None].expand(-1, -1, 9)).contiguous()
         tran = torch.gather(self.tranP[p], 1, iT[:, :, None].expand(-1, -1, 2)).contiguous()
         return rot, tran
