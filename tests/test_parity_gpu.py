@@ -507,3 +507,116 @@ def test_cpp_mirror_roundtrip(dev, tmp_path):
                            "-lthunder_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("OK"), (out.stdout, out.stderr[-2000:])
+
+
+def test_insert_grouped_duplicates(oracle, dev):
+    """draws that repeat rotations / shifts (a resampled particle filter) go through the insert plan's grouping:
+    the result must equal the oracle's draw-by-draw insertion; with cSearch the defocus factor is part of the key"""
+    from thunder_amd import ops, synth
+    O = oracle
+    rng = np.random.default_rng(123)
+    N, nImg, mReco = 32, 4, 24
+    P = 2 * N
+    ref, vol, pl, im, quat, tran, offS, w, cls = _insert_case(O, N, nImg, mReco, rng, nK=2)
+    # 5 distinct rotations, 3 distinct shifts per image, classes tied to the rotation index parity
+    base_q = synth.perturb_quats(im["quat"], 5, 0.03, rng)
+    base_t = im["shift"][:, None, :] + rng.normal(0, 0.4, size=(nImg, 3, 2))
+    iR = rng.integers(0, 5, size=(nImg, mReco))
+    iT = rng.integers(0, 3, size=(nImg, mReco))
+    quat = np.take_along_axis(base_q, iR[:, :, None], axis=1)
+    tran = np.take_along_axis(base_t, iT[:, :, None], axis=1)
+    cls = (iR % 2).astype(np.int32)
+    Fw, Tw, Ow = _oracle_insert(O, P, N, pl, im, quat, tran, offS, w, cls, 2)
+    F = torch.zeros((2, P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
+    Tt = torch.zeros((2, P, P, P // 2 + 1), dtype=torch.float32, device=dev)
+    rot = ops.rotmat(T(quat.reshape(-1, 4), dev))
+    ops.insert(F, Tt, P, T(im["dat"], dev), T(im["ctf"], dev), T(w, dev), rot, T(tran, dev), T(pl["iCol"], dev),
+               T(pl["iRow"], dev), 2, N, offS=T(offS, dev), cls=T(cls, dev), nK=2)
+    assert np.abs(F.cpu().numpy() - Fw).max() <= 1e-5 * np.abs(Fw).max()
+    assert np.abs(Tt.cpu().numpy() - Tw).max() <= 1e-5 * np.abs(Tw).max()
+    # cSearch: same rotation, different defocus factors must NOT be merged
+    dfac = 1.0 + 0.05 * rng.integers(0, 2, size=(nImg, mReco)).astype(np.float64)
+    F2 = torch.zeros((P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
+    T2 = torch.zeros((P, P, P // 2 + 1), dtype=torch.float32, device=dev)
+    ops.insert(F2, T2, P, T(im["dat"], dev), T(im["ctf"], dev), T(w, dev), rot, T(tran, dev), T(pl["iCol"], dev),
+               T(pl["iRow"], dev), 2, N, offS=T(offS, dev), attr=T(im["attr"], dev), dfac=T(dfac, dev), cSearch=True,
+               pixelSize=1.32)
+    Fo = np.zeros((P, P, P // 2 + 1), np.complex64)
+    To = np.zeros((P, P, P // 2 + 1), np.float32)
+    for l in range(nImg):
+        for m in range(mReco):
+            a = im["attr"][l]
+            c = O.ctf(1.32, a[0], np.float32(a[1] * dfac[l, m]), np.float32(a[2] * dfac[l, m]), *a[3:], N, pl["iCol"], pl["iRow"])
+            t = tran[l, m] - offS[l]
+            src = O.translate(np.float32(-t[0]), np.float32(-t[1]), N, pl["iCol"], pl["iRow"], src=im["dat"][l])
+            O.insertP(Fo, To, P, src, c, O.rotate3D(quat[l, m]), w[l], pl["iColPad"], pl["iRowPad"])
+    assert np.abs(F2.cpu().numpy() - Fo).max() <= 2e-4 * np.abs(Fo).max()   # on-device CTF: chi rounding (see CTF test)
+    assert np.abs(T2.cpu().numpy() - To).max() <= 2e-4 * np.abs(To).max()
+
+
+def test_full_size_properties_n256(oracle, dev):
+    """BASELINE box size (256^3, P = 512, nPxl = 24747): slices bit-exact against the oracle, log-likelihoods within the
+    stated bar, and the size-independent properties of insertion (mass conservation, linearity)"""
+    from thunder_amd import ops, synth
+    from thunder_amd.refine import pixel_list
+    O = oracle
+    rng = np.random.default_rng(256)
+    N, P = 256, 512
+    pl = pixel_list(N, N // 2 - 2, 0)
+    assert pl["nPxl"] == 24747
+    ref = synth.blob_map(N, nblob=8)
+    plan = ops.RecoPlan(N, N, 2)
+    vol = plan.set_projectee(T(ref, dev))
+    vol_h = vol.cpu().numpy()
+    iCol, iRow = T(pl["iCol"], dev), T(pl["iRow"], dev)
+    quat = synth.perturb_quats(synth.random_quats(1, rng), 6, 0.01, rng)[0]
+    mats = np.stack([O.rotate3D(q) for q in quat])
+    sl = ops.project(vol, T(mats, dev), iCol, iRow, 2).cpu().numpy()
+    want = np.stack([O.project(vol_h, P, 2, m, pl["iCol"], pl["iRow"]) for m in mats])
+    assert_bit_equal(sl, want, "project at N=256")
+    # one image = slice 0 + noise; 6 rotations x 3 shifts
+    dat = (sl[0] + 0.5 * np.abs(sl[0]).mean() * (rng.normal(size=sl[0].shape) + 1j * rng.normal(size=sl[0].shape))).astype(np.complex64)
+    ctf = np.ones(pl["nPxl"], np.float32)
+    sig = np.full(pl["nPxl"], -0.5 / float(np.mean(np.abs(dat) ** 2)), np.float32)
+    tran = np.array([[0.0, 0.0], [0.4, -0.3], [-1.0, 0.7]])
+    res = ops.expect_local(vol, P, 2, N, iCol, iRow, T(dat[None], dev), T(ctf[None], dev), T(sig[None], dev),
+                           T(mats[None], dev), T(tran[None], dev), want_logW=True)
+    w = O.expect_local(vol_h, P, 2, N, pl["iCol"], pl["iRow"], dat, ctf, sig, mats, tran)
+    wl = w["logW"][:, :, 0].T
+    exact = np.array([[O.logDataVSPrior_f64(dat, O.translate(np.float32(t[0]), np.float32(t[1]), N, pl["iCol"], pl["iRow"]) * s_, ctf, sig)
+                       for s_ in want] for t in tran])
+    got = res.logW[0, 0].cpu().numpy()
+    # float sums of ~25k terms: the error scale is eps * sum|terms| ~ eps * |C|, C = sum sigRcp |dat|^2 (the expanded form
+    # of the device kernel carries C explicitly; at cryo-EM SNR |L| ~ |C|).  Bar: 5e-7 |C| on L, and -- what the particle
+    # filter consumes -- the DIFFERENCES L - max L to 2e-7 |C| (C is kept out of the exponent on the device).
+    Cabs = abs(float(np.sum(sig.astype(np.float64) * np.abs(dat.astype(np.complex128)) ** 2)))
+    assert np.abs(got - exact).max() <= 5e-7 * Cabs
+    assert np.abs(wl - exact).max() <= 5e-7 * Cabs      # the oracle's (= reference's) own float sum meets the same bar
+    dg, de = got - got.max(), exact - exact.max()
+    assert np.abs(dg - de).max() <= 5e-7 * Cabs
+    wRx = np.exp(de).sum(axis=0)
+    np.testing.assert_allclose(res.wR[0].cpu().numpy(), wRx, rtol=max(2e-6 * Cabs, 1e-4))
+    assert int(res.wR[0].argmax()) == 0 and int(res.wT[0].argmax()) == 0
+    # insertion: mass conservation (every in-grid sample adds weights summing to 1) and linearity
+    nImg, mReco = 3, 10
+    q2 = synth.perturb_quats(synth.random_quats(nImg, rng), mReco, 0.01, rng)
+    rot = ops.rotmat(T(q2.reshape(-1, 4), dev)).reshape(nImg, mReco, 9)
+    ones_c = torch.ones((nImg, pl["nPxl"]), dtype=torch.complex64, device=dev)
+    ones_f = torch.ones((nImg, pl["nPxl"]), dtype=torch.float32, device=dev)
+    wgt = torch.full((nImg,), 0.5, dtype=torch.float32, device=dev)
+    tr0 = torch.zeros((nImg, mReco, 2), dtype=torch.float64, device=dev)
+
+    def run(sel):
+        F = torch.zeros((P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
+        Tt = torch.zeros((P, P, P // 2 + 1), dtype=torch.float32, device=dev)
+        ops.insert(F, Tt, P, ones_c[sel].contiguous(), ones_f[sel].contiguous(), wgt[sel].contiguous(), rot[sel].contiguous(),
+                   tr0[sel].contiguous(), iCol, iRow, 2, N)
+        return F, Tt
+    Fa, Ta = run(slice(0, 1))
+    Fb, Tb = run(slice(1, 3))
+    Fab, Tab = run(slice(0, 3))
+    assert abs(Tab.sum(dtype=torch.float64).item() - 0.5 * nImg * mReco * pl["nPxl"]) <= 1e-4 * 0.5 * nImg * mReco * pl["nPxl"]
+    assert (Ta + Tb - Tab).abs().max().item() <= 1e-5 * Tab.abs().max().item()
+    assert (Fa + Fb - Fab).abs().max().item() <= 1e-5 * Fab.abs().max().item()
+    assert abs(Fab.real.sum(dtype=torch.float64).item() - Tab.sum(dtype=torch.float64).item()) <= 1e-4 * Tab.sum().item()
+    plan.close()

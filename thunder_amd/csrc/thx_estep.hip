@@ -327,10 +327,10 @@ __global__ __launch_bounds__(256) void k_expect_final(ExpectFinalArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sL = reinterpret_cast<float*>(smem_raw);  // [nD][nT][nR] log-likelihoods
     __shared__ double sred[4];
-    __shared__ float sfred[4];
+    __shared__ float sfred[5];
     const int img = blockIdx.x, tid = threadIdx.x;
     const int n = a.nD * a.nT * a.nR;
-    float lmax = -INFINITY;
+    float lmax = -INFINITY, cconst = 0.f;
     for (int e = tid; e < n; e += 256) {
         const int r = e % a.nR, t = (e / a.nR) % a.nT, d = e / (a.nR * a.nT);
         float v = 0.f, c = 0.f;
@@ -338,18 +338,23 @@ __global__ __launch_bounds__(256) void k_expect_final(ExpectFinalArgs a)
             v += a.partV[((((size_t)img * a.nD + d) * a.nSplit + s) * a.nT + t) * a.nRpad + r];
             c += a.partC[((size_t)img * a.nD + d) * a.nSplit + s];
         }
-        const float L = c + v;
-        sL[e] = L;
-        if (a.logW) a.logW[(size_t)img * n + e] = L;
-        lmax = fmaxf(lmax, L);
+        // L = C + V.  The weights only need V - max V: keeping the (large, sample-independent) constant C out of the
+        // exponent's argument avoids losing eps*|C| of every log-likelihood difference.
+        sL[e] = v;
+        if (a.logW) a.logW[(size_t)img * n + e] = c + v;
+        lmax = fmaxf(lmax, v);
+        cconst = c;
     }
     lmax = wave_max(lmax);
     if ((tid & 63) == 0) sfred[tid >> 6] = lmax;
     __syncthreads();
-    const float base = fmaxf(fmaxf(sfred[0], sfred[1]), fmaxf(sfred[2], sfred[3]));
-    // s = exp(w - baseLine) (src/Optimiser.cpp:1397, float)
-    for (int e = tid; e < n; e += 256) sL[e] = expf(sL[e] - base);
+    const float vmax = fmaxf(fmaxf(sfred[0], sfred[1]), fmaxf(sfred[2], sfred[3]));
+    if (tid == 0) sfred[4] = cconst;   // C = sum s|dat|^2 does not depend on (r, t, d)
     __syncthreads();
+    // s = exp(w - baseLine) (src/Optimiser.cpp:1397, float)
+    for (int e = tid; e < n; e += 256) sL[e] = expf(sL[e] - vmax);
+    __syncthreads();
+    const float base = sfred[4] + vmax;
     const double pC = a.pC ? a.pC[img] : 1.0;
     const double* pR = a.pR + (size_t)img * a.nR;
     const double* pT = a.pT + (size_t)img * a.nT;
