@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void k_expect_final(ExpectFinalArgs a)
 //          running rescale does, but with one maximum per class sweep.
 // ---------------------------------------------------------------------------------------------
 struct ExpectGlobalArgs {
-    const float2* rotP;
+    const float2* rotPT;   // slices transposed to pixel-major [nPxl][nR]: lanes (= rotations) read consecutive addresses
     const float2* traP;
     const float2* datP;
     const float* ctfP;
@@ -444,9 +444,9 @@ __global__ __launch_bounds__(256) void k_expect_global(ExpectGlobalArgs a, int t
         }
         __syncthreads();
         if (rvalid) {
-            const float2* pr = a.rotP + (size_t)r * a.nPxl + pbase;
+            const float2* pr = a.rotPT + (size_t)pbase * a.nR + r;
             for (int e = 0; e < clen; e++) {
-                const float2 q = pr[e];
+                const float2 q = pr[(size_t)e * a.nR];
                 accB = fmaf(sB[e], fmaf(q.x, q.x, q.y * q.y), accB);
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
@@ -466,6 +466,19 @@ __global__ __launch_bounds__(256) void k_expect_global(ExpectGlobalArgs a, int t
         for (int t = 0; t < NT; t++)
             if (t < nt) a.dvp[((size_t)img * a.nT + t0 + t) * a.nR + r] = C + (accB - 2.0f * acc[t]);
     }
+}
+
+// [nR][nPxl] -> [nPxl][nR] through a padded 32x32 LDS tile (coalesced on both sides)
+__global__ __launch_bounds__(256) void k_transpose_c64(float2* __restrict__ dst, const float2* __restrict__ src, int nR, int nPxl)
+{
+    __shared__ float2 tile[32][33];
+    const int p0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int k = ty; k < 32; k += 8)
+        if (r0 + k < nR && p0 + tx < nPxl) tile[k][tx] = src[(size_t)(r0 + k) * nPxl + p0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (p0 + k < nPxl && r0 + tx < nR) dst[(size_t)(p0 + k) * nR + r0 + tx] = tile[tx][k];
 }
 
 // stage 2: grid (nImg), block 256
@@ -696,6 +709,7 @@ int thx_expect_local_dev(const float* volumes, const int* volIdx, int vdim, int 
 }
 
 size_t thx_expect_global_workspace(int nImg, int nR, int nT) { return (size_t)nImg * nR * nT * sizeof(float) + 256; }
+// (the transposed slices live in the library's own per-stream scratch: nR * nPxl * 8 B)
 
 int thx_expect_global_dev(const float* rotP, const float* traP, const float* datP, const float* ctfP,
                           const float* sigRcpP, const double* pR, const double* pT, float* wC, float* wR, float* wT,
@@ -708,7 +722,11 @@ int thx_expect_global_dev(const float* rotP, const float* traP, const float* dat
     THX_REQUIRE(nImg <= 65535, "nImg must be <= 65535 per call");
     hipStream_t st = as_stream(stream);
     ExpectGlobalArgs a;
-    a.rotP = reinterpret_cast<const float2*>(rotP);
+    float2* rotPT = reinterpret_cast<float2*>(scratch(st, 4, (size_t)nR * nPxl * sizeof(float2)));
+    THX_REQUIRE(rotPT, "device scratch allocation failed");
+    hipLaunchKernelGGL(k_transpose_c64, dim3((nPxl + 31) / 32, (nR + 31) / 32), dim3(256), 0, st, rotPT,
+                       reinterpret_cast<const float2*>(rotP), nR, nPxl);
+    a.rotPT = rotPT;
     a.traP = reinterpret_cast<const float2*>(traP);
     a.datP = reinterpret_cast<const float2*>(datP);
     a.ctfP = ctfP; a.sigRcpP = sigRcpP; a.nR = nR; a.nT = nT; a.nPxl = nPxl; a.nImg = nImg;

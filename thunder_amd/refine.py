@@ -15,6 +15,8 @@ reference's odd/even MPI hemispheres, src/Parallel.cpp:26-36) and the ranks of a
 (MPI_Allreduce_Large over _hemi, src/Reconstructor.cpp:2383,2436); every rank of the half then reconstructs
 redundantly, as the reference's ranks do.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -84,6 +86,14 @@ class RefineShard:
         # expectation: allocPreCalIdx(_r, _rL) (src/Optimiser.cpp:631); reconstruction: allocPreCalIdx(rU, 0) (:6722)
         pl = pixel_list(N, self.rU, rL, pf)
         plM = pixel_list(N, self.rU, 0, pf)
+        # The E-step does not care in which order the listed pixels are visited.  Visiting them tile by tile (TxT image
+        # pixels) instead of row by row keeps the volume lines a chunk touches compact (better L1/L2 reuse across the
+        # rotations of a chunk).  THX_TILE_ORDER=0 restores the reference's row-major order.
+        tile = int(os.environ.get("THX_TILE_ORDER", "16"))
+        if tile > 0:
+            order = np.lexsort((pl["iCol"], pl["iRow"], pl["iCol"] // tile, (pl["iRow"] + N) // tile))
+            for k in ("iCol", "iRow", "iPxl", "iSig", "iColPad", "iRowPad"):
+                pl[k] = np.ascontiguousarray(pl[k][order])
         self.pl, self.plM = pl, plM
         self.nPxl, self.nPxlM = pl["nPxl"], plM["nPxl"]
         self.iCol = torch.from_numpy(pl["iCol"]).to(device)
