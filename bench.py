@@ -33,6 +33,7 @@ def cpu_baseline(args, shard):
     n = min(shard.nImg, max(4, int(args.cpu_particles) if args.cpu_particles else cores))
     pl = O.pixel_list(shard.N, shard.rU, 2, shard.pf)
     assert pl["nPxl"] == shard.nPxl
+    shard.reset_reference()
     vol = shard.vols[0].cpu().numpy()
     dat = shard.datP[:n].cpu().numpy()
     ctf = shard.ctfP[:n].cpu().numpy()
@@ -98,16 +99,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    if args.warmup:
         shard.reset_reference()
-        shard.iteration()
+        shard.run(args.warmup)
     shard.reset_reference()
     shard.insert_ms.clear()
     shard.expect_ms.clear()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        fsc = shard.iteration(timed=True)
+    fsc = shard.run(args.steps, timed=True)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -620,3 +620,22 @@ def test_full_size_properties_n256(oracle, dev):
     assert (Fa + Fb - Fab).abs().max().item() <= 1e-5 * Fab.abs().max().item()
     assert abs(Fab.real.sum(dtype=torch.float64).item() - Tab.sum(dtype=torch.float64).item()) <= 1e-4 * Tab.sum().item()
     plan.close()
+
+
+def test_insert_then_reconstruct_matches_float_path(dev, monkeypatch):
+    """The gridding reconstruction is ill-conditioned where coverage is thin, so the bar on the inserted F/T (1e-5 max)
+    does not by itself bound the map.  The LDS-brick kernel (fixed-point accumulation, tiny terms routed as floats) must
+    give the same MAP-off, grid-corrected map as the plain float-atomic kernel (the reference's own arithmetic)."""
+    from thunder_amd import ops
+    from thunder_amd.refine import RefineShard
+    sh = RefineShard(64, 1200, dev)
+    wR, wT = sh.expectation(0)
+    rot, tran = sh.draw_reco(0, wR, wT)
+    maps = {}
+    for plain in ("1", "0"):
+        monkeypatch.setenv("THX_INSERT_PLAIN", plain)
+        sh.insertion(0, rot, tran)
+        ops.normalise_TF(sh.F[0], sh.T[0], sh.P)
+        maps[plain] = sh.plans[0].reconstruct(sh.F[0].clone(), sh.T[0].clone(), sh.maxRadius, MAP=False, gridCorr=True)
+    d = (maps["0"] - maps["1"]).abs().max().item() / maps["1"].abs().max().item()
+    assert d <= 5e-4, d

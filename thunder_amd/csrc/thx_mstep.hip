@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void k_insert(InsertArgs a)
 constexpr int kTB = 8;            // tile edge, image pixels
 constexpr int kTz = 8;            // brick thickness along the dominant axis, voxels
 constexpr int kBrickCap = 5376;   // brick voxels (x 12 B = 63 KB of LDS; with the draw tables 2 workgroups per CU)
+constexpr float kMinQuanta = 64.f;  // smallest T term (in fixed-point quanta) accumulated in the LDS brick
 constexpr int kMaxU = 16;         // unique shifts whose per-pixel ramps are tabulated in LDS (else computed per member)
 constexpr int kInsThreads = 512;  // 64 pixels x 8 draw groups: 16 waves per CU at 2 workgroups per CU
 constexpr int kInsWaves = kInsThreads / 64;
@@ -143,6 +144,7 @@ struct InsertTileArgs {
     const int* pixIndex;  // [idim][idim/2+1] pixel-list position of (iRow + idim/2, iCol) or -1
     int tilesI;           // tiles along iCol
     const int* plan;      // k_insert_plan output, plan_stride(mReco) ints per image
+    float minQuanta;      // smallest T term (in fixed-point quanta) that is accumulated in the LDS brick
     int debug;            // THX_INSERT_DEBUG bit mask (profiling only): 1 skip LDS adds, 2 skip flush, 4 skip fallback
     unsigned long long* stats;  // optional [2]: in-brick voxel adds, fallback voxel adds
 };
@@ -220,7 +222,7 @@ __device__ __forceinline__ int comp3(int x, int y, int z) { return W == 0 ? x : 
 struct TileGeom {
     int pmin, qmin, Wp, Wq, total;
     float sp, sq;          // column slopes: base(p, q) = floor(sp p + sq q) - M
-    float scaleF, scaleT, invF, invT;
+    float scaleF, scaleT, invF, invT, minQ;
 };
 
 struct DrawTables {      // LDS-resident per-image tables built from the insert plan
@@ -311,16 +313,21 @@ __device__ __forceinline__ void insert_tile_body(const InsertTileArgs& ta, const
                         const int dp = comp3<pa>(ii, jj, kk), dq = comp3<qa>(ii, jj, kk), da = comp3<AX>(ii, jj, kk);
                         const float wv = vx[ii] * vy[jj] * vz[kk];
                         const int off = offA[dq][dp] + sg * da;
-                        const bool in = pin[dp] && qin[dq] && ((unsigned)off < (unsigned)kTz);
+                        // A term enters the fixed-point brick only if its T part is at least kMinQuanta quanta, i.e. is
+                        // represented to better than 1 %; smaller terms (trilinear weight ~1e-6, or a CTF zero) go to
+                        // the volume as floats.  F and T of a term always travel together, so T can never round to zero
+                        // where F does not -- which would let the gridding weights W ~ 1 / (T*W conv K) explode.
+                        const float tq = (tval * wv) * g.scaleT;
+                        const bool in = pin[dp] && qin[dq] && ((unsigned)off < (unsigned)kTz) && (tq >= g.minQ);
                         // outside voxels add 0 to a dummy slot: the hot path stays branch-free
                         const int idx = in ? (AX == 0 ? ((qI[dq] * g.Wp + pI[dp]) * kTz + off)
                                                       : ((qI[dq] * kTz + off) * g.Wp + pI[dp]))
                                            : kBrickCap - 1;
-                        const float m1 = in ? g.scaleF : 0.f, m2 = in ? g.scaleT : 0.f;
+                        const float m1 = in ? g.scaleF : 0.f;
                         if (!(DBG && (ta.debug & 1))) {
                             atomicAdd(&sRe[idx], __float2int_rn((vre * wv) * m1));
                             atomicAdd(&sIm[idx], __float2int_rn((vim * wv) * m1));
-                            atomicAdd(&sT[idx], __float2int_rn((tval * wv) * m2));
+                            atomicAdd(reinterpret_cast<unsigned*>(&sT[idx]), __float2uint_rn(in ? tq : 0.f));
                         }
                         if (!in) outside |= 1u << (kk * 4 + jj * 2 + ii);
                     }
@@ -351,7 +358,7 @@ __device__ __forceinline__ void insert_tile_body(const InsertTileArgs& ta, const
         if ((ire | iim | itt) == 0) continue;
         sRe[e] = 0; sIm[e] = 0; sT[e] = 0;
         if (DBG && (ta.debug & 2)) continue;
-        const float re = (float)ire * g.invF, im = (float)iim * g.invF, tt = (float)itt * g.invT;
+        const float re = (float)ire * g.invF, im = (float)iim * g.invF, tt = (float)(unsigned)itt * g.invT;
         int p_i, q_i, off;
         if (AX == 0) { off = e % kTz; const int r = e / kTz; q_i = r / g.Wp; p_i = r - q_i * g.Wp; }
         else { const int r = e / g.Wp; p_i = e - r * g.Wp; off = r % kTz; q_i = r / kTz; }
@@ -456,9 +463,12 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_tiles(InsertTileArgs 
     const float wgt = a.w[img];
     DrawTables dt;
     dt.R = sR; dt.gStart = sGStart; dt.mUid = sMUid; dt.gInfo = sGInfo; dt.slope = sSlope; dt.ramp = sRamp; dt.G = G; dt.U = U;
-    int sbits = 30 - (32 - __clz(4 * a.mReco - 1));
-    sbits = sbits < 8 ? 8 : sbits;
-    const float q = ldexpf(1.0f, sbits);
+    // Fixed-point scales.  For one rotation the trilinear weights a voxel collects from all pixels sum to <= 1 (pixels are
+    // 2 voxels apart, the hat functions 1 voxel wide), so a voxel's T total is <= mReco * boundT and |F| total <= mReco *
+    // boundF; with a safety factor 2:  T (unsigned) scale 2^(32 - ceil(log2(2 mReco))), F (signed) one bit less.
+    int lg = 32 - __clz(2 * a.mReco - 1);
+    lg = lg > 20 ? 20 : lg;
+    const float qT = ldexpf(1.0f, 32 - lg), qF = ldexpf(1.0f, 31 - lg);
 
     const int nPass = a.cls ? a.nK : 1;
     for (int pass = 0; pass < nPass; pass++) {
@@ -525,10 +535,11 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_tiles(InsertTileArgs 
             if (g.Wp * kTz > kBrickCap - 1) g.Wp = (kBrickCap - 1) / kTz;
             if (g.Wp * g.Wq * kTz > kBrickCap - 1) g.Wq = (kBrickCap - 1) / (g.Wp * kTz);
             g.total = g.Wp * g.Wq * kTz;
-            g.scaleF = boundF > 0.f ? q / boundF : 0.f;
-            g.scaleT = boundT > 0.f ? q / boundT : 0.f;
-            g.invF = boundF / q;
-            g.invT = boundT / q;
+            g.scaleF = boundF > 0.f ? qF / boundF : 0.f;
+            g.scaleT = boundT > 0.f ? qT / boundT : 0.f;
+            g.invF = boundF / qF;
+            g.invT = boundT / qT;
+            g.minQ = ta.minQuanta;
             if (ax == 0) insert_tile_body<0, DBG>(ta, g, sRe, sIm, sT, dt, img, pass, k, pi, pj, dv, cf, wgt, F, T);
             else if (ax == 1) insert_tile_body<1, DBG>(ta, g, sRe, sIm, sT, dt, img, pass, k, pi, pj, dv, cf, wgt, F, T);
             else insert_tile_body<2, DBG>(ta, g, sRe, sIm, sT, dt, img, pass, k, pi, pj, dv, cf, wgt, F, T);
@@ -697,6 +708,8 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
             InsertTileArgs ta;
             ta.a = b; ta.pixIndex = pixIndex; ta.tilesI = tilesI;
             ta.plan = plan + (size_t)l0 * plan_stride(mReco);
+            const char* mq = getenv("THX_MIN_QUANTA");   // profiling knob
+            ta.minQuanta = mq ? (float)atof(mq) : kMinQuanta;
             const char* dbg = getenv("THX_INSERT_DEBUG");
             ta.debug = dbg ? atoi(dbg) : 0;
             ta.stats = nullptr;

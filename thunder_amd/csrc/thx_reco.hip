@@ -114,25 +114,36 @@ __global__ __launch_bounds__(256) void k_calcC(float2* __restrict__ C, const flo
     C[e] = make_float2(T[e] * w, 0.0f * w);
 }
 
-// convoluteC real-space stage (:2635-2652) fused with bwExecutePlan's 1/size scaling (src/FFT.cpp:355-367)
-__global__ __launch_bounds__(256) void k_convolute_rl(float* __restrict__ rl, int P, int NP, const float* __restrict__ tab,
+// convoluteC real-space stage (:2635-2652) fused with bwExecutePlan's 1/size scaling (src/FFT.cpp:355-367).
+// grid (jw, kw): one row of the real P^3 volume per workgroup; each thread owns 4 consecutive voxels (16-byte accesses).
+// POW2: (N*pf)^2 is a power of two, so q / (N*pf)^2 == q * 2^-k exactly and the fp64 division disappears.
+template <bool POW2>
+__global__ __launch_bounds__(128) void k_convolute_rl(float* __restrict__ rl, int P, int NP, const float* __restrict__ tab,
                                                       float nf)
 {
-    // grid (jw, kw): one row of the real P^3 volume per workgroup, threads stride over i (no index div/mod)
     const size_t n = (size_t)P * P * P;
     const int jw = blockIdx.x, kw = blockIdx.y;
     const int j = jw >= P / 2 ? jw - P : jw, k = kw >= P / 2 ? kw - P : kw;
     const double qjk = (double)j * j + (double)k * k;
     const double np2 = (double)pow2f_((float)NP);
+    const double inp2 = 1.0 / np2;
     const double rn = 1.0 / (double)n;
     const float s = 1.0f / kTabN;  // _s = (_b - _a) / _n in RFLOAT, src/TabFunction.cpp:34
-    float* row = rl + ((size_t)kw * P + jw) * P;
-    for (int iw = threadIdx.x; iw < P; iw += blockDim.x) {
-        const int i = iw >= P / 2 ? iw - P : iw;
-        const float v = (float)((double)row[iw] * rn);
-        const float x = (float)(((double)i * i + qjk) / np2);
-        const int idx = (int)rint((double)((x - 0.0f) / s));
-        row[iw] = v * tab[idx < kTabN ? idx : kTabN] / nf;
+    float4* row = reinterpret_cast<float4*>(rl + ((size_t)kw * P + jw) * P);
+    for (int i4 = threadIdx.x; i4 < P / 4; i4 += blockDim.x) {
+        float4 v4 = row[i4];
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int iw = 4 * i4 + c;
+            const int i = iw >= P / 2 ? iw - P : iw;
+            const float vv = (float)((double)v[c] * rn);
+            const double q = (double)i * i + qjk;
+            const float x = POW2 ? (float)(q * inp2) : (float)(q / np2);
+            const int idx = (int)rint((double)((x - 0.0f) / s));
+            v[c] = vv * tab[idx < kTabN ? idx : kTabN] / nf;
+        }
+        row[i4] = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -317,6 +328,7 @@ int thx_reco_create(thx_reco** out, int size, int N, int pf, float a, float alph
 {
     THX_REQUIRE(out, "out is NULL");
     THX_REQUIRE(size > 0 && N >= size && pf >= 1 && (size % 2 == 0) && (N % 2 == 0), "bad size / N / pf");
+    THX_REQUIRE((pf * size) % 4 == 0, "pf * size must be a multiple of 4");
     thx_reco* r = new thx_reco();
     memset(r, 0, sizeof(*r));
     r->size = size; r->N = N; r->pf = pf; r->PF = pf * size; r->PN = pf * N; r->a = a; r->alpha = alpha;
@@ -395,8 +407,13 @@ int thx_reco_reconstruct_dev(thx_reco* r, const float* F, float* T, int maxRadiu
         for (int m = 0; m < 30; m++) {  // MAX_N_ITER_BALANCE
             hipLaunchKernelGGL(k_calcC, dim3(nblk(nHalfF)), dim3(256), 0, st, r->C, T, r->W, nHalfF);
             THX_FFT_CHECK(hipfftExecC2R(r->c2rF, reinterpret_cast<hipfftComplex*>(r->C), r->rl));
-            hipLaunchKernelGGL(k_convolute_rl, dim3(PF, PF), dim3(256), 0, st, r->rl, PF, r->N * pf,
-                               r->tab, r->nf);
+            {
+                const long np = (long)r->N * pf;
+                if ((np & (np - 1)) == 0)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_convolute_rl<true>), dim3(PF, PF), dim3(128), 0, st, r->rl, PF, r->N * pf, r->tab, r->nf);
+                else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_convolute_rl<false>), dim3(PF, PF), dim3(128), 0, st, r->rl, PF, r->N * pf, r->tab, r->nf);
+            }
             THX_FFT_CHECK(hipfftExecR2C(r->r2cF, r->rl, reinterpret_cast<hipfftComplex*>(r->C)));
             THX_CHECK(hipMemsetAsync(r->diff, 0, sizeof(unsigned), st));
             hipLaunchKernelGGL(k_updateW_checkC, dim3(PF, PF), dim3(256), 0, st, r->W, r->C, PF, pf, maxRadius,

@@ -7,16 +7,17 @@ from thunder_amd.refine import RefineShard
 dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 sh = RefineShard(256, n, dev, batch=2048)
-wR, wT = sh.expectation()
-rot, tran = sh.draw_reco(wR, wT)
+wR, wT = sh.expectation(0)
+rot, tran = sh.draw_reco(0, wR, wT)
+n = rot.shape[0]
 # distinct rotations per image among the draws
 r = rot.reshape(n, sh.mReco, 9)
 distinct = np.mean([len(np.unique(r[i].cpu().numpy(), axis=0)) for i in range(0, n, max(1, n // 64))])
 print("avg distinct rotations per image among %d draws: %.1f" % (sh.mReco, distinct))
 for dbg in (8, 0, 1, 2, 3, 4):
     os.environ["THX_INSERT_DEBUG"] = str(dbg)
-    sh.insertion(rot, tran); torch.cuda.synchronize()
-    t0 = time.perf_counter(); sh.insertion(rot, tran); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    sh.insertion(0, rot, tran); torch.cuda.synchronize()
+    t0 = time.perf_counter(); sh.insertion(0, rot, tran); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     msg = "debug=%d  %.1f ms for %d images = %.1f us/particle" % (dbg, dt * 1e3, n, dt / n * 1e6)
     if dbg == 8:
         out = (ctypes.c_ulonglong * 2)()

@@ -12,8 +12,9 @@ torch.cuda.synchronize()
 b.copy_(a)            # calibration dispatch: 1 GiB in, 1 GiB out
 torch.cuda.synchronize()
 sh = RefineShard(256, n, dev, batch=2048, nPhase=1)
-wR, wT = sh.expectation()
-rot, tran = sh.draw_reco(wR, wT)
-sh.insertion(rot, tran)
+for vi in (0, 1):
+    wR, wT = sh.expectation(vi)
+    rot, tran = sh.draw_reco(vi, wR, wT)
+    sh.insertion(vi, rot, tran)
 torch.cuda.synchronize()
 print("probe done", n)
