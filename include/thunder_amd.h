@@ -196,6 +196,56 @@ int thx_fft3d_bw_dev(float* ft, float* rl, int n, void* stream);
 int thx_fsc_dev(float* fsc, int nShell, const float* A, const float* B, int dim, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Callers either side of the E/M loop
+ * ------------------------------------------------------------------------------------------- */
+
+/* Optimiser::reMaskImg, src/Optimiser.cpp:6093-6149 (ReMask, Interface.h:517-522; cuthunder::reMask
+ * gpu/src/cuthunder.cu:9406-9631): for every image FFT::bwExecutePlan (c2r, x 1/size, src/FFT.cpp:346-360),
+ * MUL_RL by softMask(mask, r, ew) (src/Functions/Mask.cpp:334-350), FFT::fwExecutePlan (r2c).
+ * imgFT [nImg][idim][idim/2+1] complex64 on the device, transformed IN PLACE (the real rows overlay the complex
+ * rows, so no second image stack is needed).  maskRadiusPx = maskRadius / pixelSize; ew = EDGE_WIDTH_RL = 6
+ * (include/Macro.h:99).  2-D FFTs by rocFFT (batched plans, cached). */
+int thx_remask_dev(float* imgFT, int nImg, int idim, float maskRadiusPx, float ew, void* stream);
+
+/* translate(Image& dst, const Image& src, tx, ty, nThread), src/Image/ImageFunctions.cpp:269-284 (r < 0: every
+ * stored pixel; Optimiser::reCentreImg src/Optimiser.cpp:6078-6082) and the radius form :322-339 (r >= 0:
+ * only i^2+j^2 < r^2 is written; TranslateI2D Interface.h:504-508) for nImg images: trans [nImg][2] doubles on
+ * the device.  dst may alias src. */
+int thx_translate_image_dev(float* dst, const float* src, const double* trans, int nImg, int idim, float r,
+                            void* stream);
+
+/* translate(Volume& dst, const Volume& src, r, tx, ty, tz, nThread), src/Image/ImageFunctions.cpp:363-384
+ * (TranslateI, Interface.h:510-515; reference re-centring src/Optimiser.cpp:7418-7428) on a dim^3 half-complex FT;
+ * voxels outside r are not written.  dst may alias src. */
+int thx_translate_volume_dev(float* dst, const float* src, int dim, float r, double ox, double oy, double oz,
+                             void* stream);
+
+/* Per-image part of Optimiser::allReduceSigma, src/Optimiser.cpp:6443-6565, as include/Config.h configures it
+ * (OPTIMISER_SIGMA_RANK1ST, _SIGMA_WHOLE_FREQUENCY, _RECENTRE_IMAGE_EACH_ITERATION, _CTF_ON_THE_FLY; w = 1):
+ * with P = the top pose's slice (radius projR = Projector::_maxRadius), spec [nImg][4][rSig] receives the shell
+ * power spectra (powerSpectrum, src/Functions/Spectrum.cpp:161-190) of
+ *   0: ctf.P.ramp(t)   1: img   2: img - ctf.P.ramp(t)   3: imgOri - ctf.P.ramp(t - offset).
+ * img/imgOri [nImg][idim][idim/2+1] full image FTs (masked / unmasked), rotMat [nImg][9], trans [nImg][2],
+ * offset [nImg][2] or NULL, dfac [nImg] or NULL (defocus factor of SEARCH_TYPE_CTF), volumes/volIdx as in
+ * thx_expect_local_dev.  All device pointers. */
+int thx_sigma_spectra_dev(float* spec, const float* volumes, const int* volIdx, int vdim, int pf, int idim, int projR,
+                          int rSig, const float* img, const float* imgOri, const thx_ctf_attr* attr,
+                          const double* dfac, float pixelSize, const double* rotMat, const double* trans,
+                          const double* offset, int nImg, void* stream);
+
+/* Group accumulation of allReduceSigma, src/Optimiser.cpp:6567-6597: sigM/sigN/svd [nGroup][rSig+1] (device,
+ * READ-MODIFY-WRITE; last column = weight sum) += this rank's images.  groupID_host [nImg] is the HOST array
+ * Optimiser::_groupID (1-based); group == 0 pools everything into row 0.  The caller all-reduces the three
+ * tables over the hemisphere (:6608-6650) before thx_sigma_final_dev. */
+int thx_sigma_accum_dev(float* sigM, float* sigN, float* svd, const float* spec, const int* groupID_host, int nImg,
+                        int nGroup, int rSig, int group, void* stream);
+
+/* Closing arithmetic of allReduceSigma, src/Optimiser.cpp:6654-6707: sig, sigRcp [nGroup][rSig] (device) from the
+ * reduced tables; maskRadius (Angstrom), size, pixelSize feed alpha (:6683). */
+int thx_sigma_final_dev(float* sig, float* sigRcp, const float* sigM, const float* sigN, const float* svd, int nGroup,
+                        int rSig, int group, float maskRadius, int size, float pixelSize, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Interface.h-shaped HOST-pointer entry points (what -DGPU_VERSION call sites bind to)
  * ------------------------------------------------------------------------------------------- */
 
@@ -235,6 +285,17 @@ int thx_PrepareTF_host(int gpuIdx, float* F3D, float* T3D_complex, int vdim, con
 int thx_ReconstructG_host(int gpuIdx, const float* F3D, const float* T3D_complex, int size, int N, int pf,
                           int maxRadius, float a, float alpha, const float* FSC, int nFSC, int joinHalf, int MAP,
                           int gridCorr, float* dstRL);
+
+/* void ReMask(vector<Image>& img, RFLOAT maskRadius, RFLOAT pixelSize, RFLOAT ew, int idim, int imgNum)
+ *                                                                                Interface.h:517-522
+ * imgFT = imgNum host pointers (&img[l][0]), each idim*(idim/2+1) complex64, rewritten in place. */
+int thx_ReMask_host(float* const* imgFT, float maskRadius, float pixelSize, float ew, int idim, int imgNum);
+
+/* void TranslateI2D(int gpuIdx, Image& img, double ox, double oy, int r)        Interface.h:504-508 */
+int thx_TranslateI2D_host(int gpuIdx, float* imgFT, double ox, double oy, int r, int idim);
+
+/* void TranslateI(int gpuIdx, Volume& ref, double ox, double oy, double oz, int r)  Interface.h:510-515 */
+int thx_TranslateI_host(int gpuIdx, float* volFT, double ox, double oy, double oz, int r, int dim);
 
 #ifdef __cplusplus
 }

@@ -298,3 +298,103 @@ def baseline_block(vol, P, pf, N, pl, dat, ctf_, sigRcp, rot, tran, recoRot, rec
                              _p(rot, c_d), _p(tran, c_d), C.c_int(nPhase), C.c_int(nR), C.c_int(nT), _p(recoRot, c_d),
                              _p(recoTran, c_d), C.c_int(mReco), _p(F, c_f), _p(T, c_f), _p(wR, c_f))
     return wR
+
+
+# ---------------------------------------------------------------------------------------------
+# SURVEY 8 "next" rows f1 / f2
+def soft_mask(N, r, ew):
+    """softMask(Image& mask, r, ew) src/Functions/Mask.cpp:334-350 -> float32 [N][N] (wrapped index)."""
+    m = np.zeros((N, N), np.float32)
+    lib().orc_soft_mask(_p(m, c_f), C.c_int(N), C.c_float(r), C.c_float(ew))
+    return m
+
+
+def remask(imgs, maskRadius, pixelSize, ew=6.0):
+    """Optimiser::reMaskImg src/Optimiser.cpp:6093-6149 (zeroMask): per image c2r (1/size), x mask, r2c.
+    imgs complex64 [nImg][N][N/2+1]; returns a new array."""
+    imgs = c64(imgs)
+    N = imgs.shape[1]
+    mask = soft_mask(N, np.float32(maskRadius) / np.float32(pixelSize), ew)
+    out = np.empty_like(imgs)
+    for l in range(imgs.shape[0]):
+        rl = np.ascontiguousarray(sfft.irfft2(imgs[l], s=(N, N), norm="forward").astype(np.float32))
+        lib().orc_scale_mul_rl(_p(rl, c_f), _p(mask, c_f), C.c_size_t(rl.size))
+        out[l] = sfft.rfft2(rl).astype(np.complex64)
+    return out
+
+
+def translate_image(src, tx, ty, r=-1.0, dst=None):
+    """translate(Image&, const Image&, [r,] tx, ty) src/Image/ImageFunctions.cpp:269-284 / :322-339."""
+    src = c64(src)
+    N = src.shape[0]
+    out = src.copy() if dst is None else dst
+    lib().orc_translate_image(_p(out, c_f), _p(src, c_f), C.c_int(N), C.c_float(r), C.c_float(tx), C.c_float(ty))
+    return out
+
+
+def translate_volume(src, r, tx, ty, tz):
+    """translate(Volume&, const Volume&, r, tx, ty, tz) src/Image/ImageFunctions.cpp:363-384 (dst = copy of src)."""
+    src = c64(src)
+    P = src.shape[0]
+    out = src.copy()
+    lib().orc_translate_volume(_p(out, c_f), _p(src, c_f), C.c_int(P), C.c_float(r), C.c_float(tx), C.c_float(ty),
+                               C.c_float(tz))
+    return out
+
+
+def disc_list(N, r):
+    """Pixel set of Projector::project(Image&, mat) / powerSpectrum (keeps (0, j<0))."""
+    lib().orc_disc_list.restype = C.c_int
+    cap = (2 * r + 1) * (r + 1)
+    arrs = [np.zeros(cap, np.int32) for _ in range(4)]
+    n = lib().orc_disc_list(C.c_int(N), C.c_int(r), *[_p(a, c_i) for a in arrs])
+    out = {k: a[:n].copy() for k, a in zip(["iCol", "iRow", "iPxl", "iSig"], arrs)}
+    out["nPxl"] = n
+    return out
+
+
+def power_spectrum(img, r):
+    """powerSpectrum(vec&, const Image&, r, 1) src/Functions/Spectrum.cpp:161-190."""
+    img = c64(img)
+    out = np.zeros(r, np.float32)
+    lib().orc_power_spectrum(_p(out, c_f), _p(img, c_f), C.c_int(img.shape[0]), C.c_int(r))
+    return out
+
+
+def sigma_image(vol, P, pf, N, projR, rSig, rot, tran, offset, pixelSize, attr, img, imgOri):
+    """Per-image part of Optimiser::allReduceSigma (src/Optimiser.cpp:6443-6565).
+    attr = (voltage, defocusU, defocusV, theta, Cs, ampContrast, phaseShift); returns float32 [4][rSig]
+    = sSVD, dSVD, vSigM, vSigN."""
+    vol, img, imgOri = c64(vol), c64(img), c64(imgOri)
+    rot, tran = f64(rot), f64(tran)
+    offset = None if offset is None else f64(offset)
+    out = np.zeros((4, rSig), np.float32)
+    lib().orc_sigma_image(_p(vol, c_f), C.c_int(P), C.c_int(pf), C.c_int(N), C.c_int(projR), C.c_int(rSig),
+                          _p(rot, c_d), _p(tran, c_d), _p(offset, c_d), C.c_float(pixelSize),
+                          *[C.c_float(a) for a in attr], _p(img, c_f), _p(imgOri, c_f), _p(out[0], c_f),
+                          _p(out[1], c_f), _p(out[2], c_f), _p(out[3], c_f))
+    return out
+
+
+def sigma_accum(spec, groupID, nGroup, group=True):
+    """Group accumulation of allReduceSigma (src/Optimiser.cpp:6567-6597); groupID 1-based.
+    Returns sigM, sigN, svd as float32 [nGroup][rSig+1]."""
+    spec, groupID = f32(spec), i32(groupID)
+    nImg, _, rSig = spec.shape
+    acc = [np.zeros((nGroup, rSig + 1), np.float32) for _ in range(3)]
+    lib().orc_sigma_accum(_p(acc[0], c_f), _p(acc[1], c_f), _p(acc[2], c_f), _p(spec, c_f), _p(groupID, c_i),
+                          C.c_int(nImg), C.c_int(nGroup), C.c_int(rSig), C.c_int(1 if group else 0))
+    return acc
+
+
+def sigma_final(sigM, sigN, svd, maskRadius, size, pixelSize, group=True):
+    """Closing arithmetic of allReduceSigma (src/Optimiser.cpp:6654-6707) -> sig, sigRcp [nGroup][rSig]."""
+    sigM, sigN, svd = f32(sigM).copy(), f32(sigN).copy(), f32(svd).copy()
+    nGroup, nc = sigM.shape
+    rSig = nc - 1
+    sig = np.zeros((nGroup, rSig), np.float32)
+    rcp = np.zeros((nGroup, rSig), np.float32)
+    lib().orc_sigma_final(_p(sig, c_f), _p(rcp, c_f), _p(sigM, c_f), _p(sigN, c_f), _p(svd, c_f), C.c_int(nGroup),
+                          C.c_int(rSig), C.c_int(1 if group else 0), C.c_float(maskRadius), C.c_int(size),
+                          C.c_float(pixelSize))
+    return sig, rcp

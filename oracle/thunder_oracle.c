@@ -817,3 +817,223 @@ void orc_baseline_block(const RFLOAT* vol, int P, int pf, int N, const int* iCol
         free(transImg); free(pR); free(pT); free(wR); free(wT);
     }
 }
+
+/* ========================================================================================== */
+/* SURVEY 8 "next" rows f1/f2: re-centre, re-mask, sigma update                               */
+/* ========================================================================================== */
+
+/* f2: softMask(Image& mask, r, ew), src/Functions/Mask.cpp:334-350.  mask is [N][N] real with the
+ * wrap-around indexing of Image::iRL (include/Image/Image.h:388-394). */
+void orc_soft_mask(RFLOAT* mask, int N, RFLOAT r, RFLOAT ew)
+{
+    for (long j = -N / 2; j < N / 2; j++)
+        for (long i = -N / 2; i < N / 2; i++) {
+            RFLOAT u = (RFLOAT)gsl_hypot_((double)i, (double)j);
+            size_t idx = (size_t)(j >= 0 ? j : j + N) * N + (size_t)(i >= 0 ? i : i + N);
+            if (u > r + ew) mask[idx] = 0;
+            else if (u >= r) mask[idx] = (RFLOAT)(0.5 + 0.5 * cos((u - r) / ew * M_PI));
+            else mask[idx] = 1;
+        }
+}
+
+/* f2: the real-space part of Optimiser::reMaskImg, src/Optimiser.cpp:6133-6141: the 1/size scale of
+ * FFT::bwExecutePlan (src/FFT.cpp:353-354, SCALE_RL multiplies a float by a double) followed by
+ * MUL_RL(img, mask) (include/Image/ImageBase.h:178-180).  The two FFTs either side are done by the
+ * caller (oracle.py uses scipy.fft in float32; the reference uses FFTW). */
+void orc_scale_mul_rl(RFLOAT* rl, const RFLOAT* mask, size_t n)
+{
+    double s = 1.0 / (double)n;
+    for (size_t i = 0; i < n; i++) {
+        rl[i] = (RFLOAT)(rl[i] * s);
+        rl[i] *= mask[i];
+    }
+}
+
+/* f2: translate(Image& dst, const Image& src, [r,] tx, ty), src/Image/ImageFunctions.cpp:269-284
+ * (whole image; Optimiser::reCentreImg, src/Optimiser.cpp:6078-6082) and :322-339 (inside radius r;
+ * r < 0 here selects the whole-image form).  Pixels outside r are not written. */
+void orc_translate_image(RFLOAT* dst, const RFLOAT* src, int N, RFLOAT r, RFLOAT nTransCol, RFLOAT nTransRow)
+{
+    RFLOAT rCol = nTransCol / N, rRow = nTransRow / N;
+    int nc = N / 2 + 1;
+    for (long j = -N / 2; j < N / 2; j++)
+        for (long i = 0; i <= N / 2; i++) {
+            if (r >= 0 && !((double)i * (double)i + (double)j * (double)j < pow2f_(r))) continue;
+            RFLOAT phase = (RFLOAT)(6.28318530717959 * (i * rCol + j * rRow));
+            RFLOAT c = cosf(-phase), s = sinf(-phase);
+            size_t idx = (size_t)(j >= 0 ? j : j + N) * nc + i;
+            RFLOAT a0 = src[2 * idx], a1 = src[2 * idx + 1];
+            dst[2 * idx] = a0 * c - a1 * s;
+            dst[2 * idx + 1] = a0 * s + a1 * c;
+        }
+}
+
+/* f3: translate(Volume& dst, const Volume& src, r, tx, ty, tz), src/Image/ImageFunctions.cpp:363-384
+ * (reference re-centring in Optimiser::reconstructRef, src/Optimiser.cpp:7418-7428 / TranslateI,
+ * gpu/interface/Interface.h:510). */
+void orc_translate_volume(RFLOAT* dst, const RFLOAT* src, int P, RFLOAT r, RFLOAT tx, RFLOAT ty, RFLOAT tz)
+{
+    RFLOAT rCol = tx / P, rRow = ty / P, rSlc = tz / P;
+    for (long k = -P / 2; k < P / 2; k++)
+        for (long j = -P / 2; j < P / 2; j++)
+            for (long i = 0; i <= P / 2; i++) {
+                if (!((double)i * i + (double)j * j + (double)k * k < pow2f_(r))) continue;
+                RFLOAT phase = (RFLOAT)(6.28318530717959 * (i * rCol + j * rRow + k * rSlc));
+                RFLOAT c = cosf(-phase), s = sinf(-phase);
+                size_t idx = iFTHalf3_(i, j, k, P);
+                RFLOAT a0 = src[2 * idx], a1 = src[2 * idx + 1];
+                dst[2 * idx] = a0 * c - a1 * s;
+                dst[2 * idx + 1] = a0 * s + a1 * c;
+            }
+}
+
+/* f1: the pixel set shared by Projector::project(Image&, mat) (src/Projector.cpp:276-294:
+ * IMAGE_FOR_PIXEL_R_FT(r) with QUAD < r*r) and powerSpectrum (src/Functions/Spectrum.cpp:171-184).
+ * Unlike allocPreCalIdx it keeps (0, j<0).  Returns the count; arrays may be NULL. */
+int orc_disc_list(int N, int r, int* iCol, int* iRow, int* iPxl, int* iSig)
+{
+    int n = 0;
+    for (long j = -r; j < r; j++)
+        for (long i = 0; i <= r; i++) {
+            if (!((double)i * i + (double)j * j < (double)r * r)) continue;
+            if (iCol) iCol[n] = (int)i;
+            if (iRow) iRow[n] = (int)j;
+            if (iPxl) iPxl[n] = (int)((j >= 0 ? j : j + N) * (N / 2 + 1) + i);
+            if (iSig) iSig[n] = AROUND_(gsl_hypot_((double)i, (double)j));
+            n++;
+        }
+    return n;
+}
+
+/* powerSpectrum(vec&, const Image&, r, 1), src/Functions/Spectrum.cpp:161-190 (serial order). */
+static void power_spectrum_(RFLOAT* dst, const RFLOAT* img, int N, int r)
+{
+    unsigned* cnt = (unsigned*)calloc(r, sizeof(unsigned));
+    int nc = N / 2 + 1;
+    for (int i = 0; i < r; i++) dst[i] = 0;
+    for (long j = -N / 2; j < N / 2; j++)
+        for (long i = 0; i <= N / 2; i++)
+            if ((double)i * i + (double)j * j < pow2f_((RFLOAT)r)) {
+                int u = AROUND_(gsl_hypot_((double)i, (double)j));
+                if (u < r) {
+                    size_t idx = (size_t)(j >= 0 ? j : j + N) * nc + i;
+                    dst[u] += img[2 * idx] * img[2 * idx] + img[2 * idx + 1] * img[2 * idx + 1]; /* ABS2 */
+                    cnt[u] += 1;
+                }
+            }
+    for (int i = 0; i < r; i++) dst[i] /= cnt[i];
+    free(cnt);
+}
+void orc_power_spectrum(RFLOAT* dst, const RFLOAT* img, int N, int r) { power_spectrum_(dst, img, N, r); }
+
+/* f1: per-image part of Optimiser::allReduceSigma, src/Optimiser.cpp:6443-6565, as configured by
+ * include/Config.h (OPTIMISER_SIGMA_RANK1ST: one draw = the top pose; OPTIMISER_SIGMA_WHOLE_FREQUENCY:
+ * rSig = size/2-1; OPTIMISER_RECENTRE_IMAGE_EACH_ITERATION; OPTIMISER_CTF_ON_THE_FLY; w = 1).
+ * projR = the Projector's _maxRadius (Model sets it to _r, src/Model.cpp:1042).
+ * Outputs four vec(rSig): sSVD, dSVD, vSigM, vSigN. */
+void orc_sigma_image(const RFLOAT* vol, int P, int pf, int N, int projR, int rSig, const double* rot,
+                     const double* tran, const double* offset, RFLOAT pixelSize, RFLOAT voltage, RFLOAT defocusU,
+                     RFLOAT defocusV, RFLOAT theta, RFLOAT Cs, RFLOAT amplitudeContrast, RFLOAT phaseShift,
+                     const RFLOAT* img, const RFLOAT* imgOri, RFLOAT* sSVD, RFLOAT* dSVD, RFLOAT* vSigM,
+                     RFLOAT* vSigN)
+{
+    size_t nFT = (size_t)N * (N / 2 + 1);
+    RFLOAT* imgM = (RFLOAT*)calloc(nFT * 2, sizeof(RFLOAT)); /* SET_0_FT */
+    RFLOAT* imgN = (RFLOAT*)calloc(nFT * 2, sizeof(RFLOAT));
+    int cap = (2 * projR + 1) * (projR + 1);
+    int* iCol = (int*)malloc(cap * sizeof(int));
+    int* iRow = (int*)malloc(cap * sizeof(int));
+    int* iPxl = (int*)malloc(cap * sizeof(int));
+    int n = orc_disc_list(N, projR, iCol, iRow, iPxl, NULL);
+    RFLOAT* prj = (RFLOAT*)malloc((size_t)n * 2 * sizeof(RFLOAT));
+    /* project(imgM, rot3D, tran): slice then translate(dst, dst, _maxRadius, t0, t1), src/Projector.cpp:456-464 */
+    orc_project(prj, vol, P, pf, rot, iCol, iRow, n);
+    for (int p = 0; p < n; p++) { imgM[2 * iPxl[p]] = prj[2 * p]; imgM[2 * iPxl[p] + 1] = prj[2 * p + 1]; }
+    memcpy(imgN, imgM, nFT * 2 * sizeof(RFLOAT));
+    orc_translate_image(imgM, imgM, N, (RFLOAT)projR, (RFLOAT)tran[0], (RFLOAT)tran[1]);
+    {
+        double t0 = tran[0] - (offset ? offset[0] : 0.0), t1 = tran[1] - (offset ? offset[1] : 0.0);
+        orc_translate_image(imgN, imgN, N, (RFLOAT)projR, (RFLOAT)t0, (RFLOAT)t1);
+    }
+    free(iCol); free(iRow); free(iPxl); free(prj);
+    /* CTF(ctf, ..., CEIL(rSig) + 1, 1), src/CTF.cpp:68-111, then imgM[i] *= REAL(ctf[i]) */
+    {
+        int rc = rSig + 1;
+        int capc = (2 * rc + 3) * (rc + 2);
+        int* cCol = (int*)malloc(capc * sizeof(int));
+        int* cRow = (int*)malloc(capc * sizeof(int));
+        int* cPxl = (int*)malloc(capc * sizeof(int));
+        int m = 0;
+        for (long j = -(rc + 1); j < (rc + 1); j++) /* IMAGE_FOR_PIXEL_R_FT(r + 1) */
+            for (long i = 0; i <= (rc + 1); i++) {
+                RFLOAT v = (RFLOAT)((double)i * i + (double)j * j);
+                if (v < pow2f_((RFLOAT)rc) && j >= -N / 2 && j < N / 2 && i <= N / 2) {
+                    cCol[m] = (int)i; cRow[m] = (int)j; cPxl[m] = (int)((j >= 0 ? j : j + N) * (N / 2 + 1) + i); m++;
+                }
+            }
+        RFLOAT* c = (RFLOAT*)malloc((size_t)m * sizeof(RFLOAT));
+        orc_ctf(c, pixelSize, voltage, defocusU, defocusV, theta, Cs, amplitudeContrast, phaseShift, N, N, cCol, cRow, m);
+        for (int p = 0; p < m; p++) {
+            imgM[2 * cPxl[p]] *= c[p]; imgM[2 * cPxl[p] + 1] *= c[p];
+            imgN[2 * cPxl[p]] *= c[p]; imgN[2 * cPxl[p] + 1] *= c[p];
+        }
+        free(cCol); free(cRow); free(cPxl); free(c);
+    }
+    power_spectrum_(sSVD, imgM, N, rSig);
+    power_spectrum_(dSVD, img, N, rSig);
+    /* NEG_FT; ADD_FT(imgM, _img[l]); ADD_FT(imgN, _imgOri[l]) */
+    for (size_t i = 0; i < nFT * 2; i++) { imgM[i] = imgM[i] * -1 + img[i]; imgN[i] = imgN[i] * -1 + imgOri[i]; }
+    power_spectrum_(vSigM, imgM, N, rSig);
+    power_spectrum_(vSigN, imgN, N, rSig);
+    free(imgM); free(imgN);
+}
+
+/* f1: group accumulation + closing arithmetic of allReduceSigma, src/Optimiser.cpp:6567-6707.
+ * spec = [nImg][4][rSig] as written by orc_sigma_image (sSVD, dSVD, vSigM, vSigN); groupID is 1-based
+ * as in the reference.  sigM/sigN/svd are [nGroup][rSig+1] accumulators (last column = weight sum) that
+ * the caller all-reduces between accum and final; sig/sigRcp are [nGroup][rSig]. */
+void orc_sigma_accum(RFLOAT* sigM, RFLOAT* sigN, RFLOAT* svd, const RFLOAT* spec, const int* groupID, int nImg,
+                     int nGroup, int rSig, int group)
+{
+    (void)nGroup;
+    int nc = rSig + 1;
+    for (int l = 0; l < nImg; l++) {
+        int g = group ? groupID[l] - 1 : 0;
+        const RFLOAT *s = spec + (size_t)l * 4 * rSig, *d = s + rSig, *vm = d + rSig, *vn = vm + rSig;
+        RFLOAT w = 1;
+        for (int i = 0; i < rSig; i++) sigM[g * nc + i] += w * vm[i] / 2;
+        sigM[g * nc + rSig] += w;
+        for (int i = 0; i < rSig; i++) sigN[g * nc + i] += w * vn[i] / 2;
+        sigN[g * nc + rSig] += w;
+        for (int i = 0; i < rSig; i++) svd[g * nc + i] += (RFLOAT)(w * sqrt(s[i] / d[i]));
+        svd[g * nc + rSig] += w;
+    }
+}
+
+void orc_sigma_final(RFLOAT* sig, RFLOAT* sigRcp, RFLOAT* sigM, RFLOAT* sigN, RFLOAT* svd, int nGroup, int rSig,
+                     int group, RFLOAT maskRadius, int size, RFLOAT pixelSize)
+{
+    int nc = rSig + 1;
+    for (int g = 0; g < nGroup; g++) {
+        int src = group ? g : 0;
+        for (int i = 0; i < rSig; i++) {
+            if (group || g == 0) {
+                sigM[g * nc + i] /= sigM[g * nc + rSig];
+                sigN[g * nc + i] /= sigN[g * nc + rSig];
+                svd[g * nc + i] /= svd[g * nc + rSig];
+            } else {
+                sigM[g * nc + i] = sigM[src * nc + i];
+                sigN[g * nc + i] = sigN[src * nc + i];
+                svd[g * nc + i] = svd[src * nc + i];
+            }
+        }
+    }
+    RFLOAT q = maskRadius / (size * pixelSize);
+    RFLOAT alpha = (RFLOAT)sqrt(M_PI * (double)q * (double)q);
+    for (int g = 0; g < nGroup; g++)
+        for (int j = 0; j < rSig; j++) {
+            RFLOAT ratio = (RFLOAT)(1.0 < (double)svd[g * nc + j] ? 1.0 : (double)svd[g * nc + j]); /* GSL_MIN_DBL */
+            sig[g * rSig + j] = ratio * sigM[g * nc + j] + (1 - ratio) * alpha * sigN[g * nc + j];
+            sigRcp[g * rSig + j] = (RFLOAT)(-0.5 / sig[g * rSig + j]);
+        }
+}

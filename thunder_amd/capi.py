@@ -64,12 +64,22 @@ SIGNATURES = {
     "thx_fft3d_fw_dev": (_i, [_vp, _vp, _i, _vp]),
     "thx_fft3d_bw_dev": (_i, [_vp, _vp, _i, _vp]),
     "thx_fsc_dev": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
+    "thx_remask_dev": (_i, [_vp, _i, _i, _f, _f, _vp]),
+    "thx_translate_image_dev": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
+    "thx_translate_volume_dev": (_i, [_vp, _vp, _i, _f, _d, _d, _d, _vp]),
+    "thx_sigma_spectra_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i,
+                                   _vp]),
+    "thx_sigma_accum_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "thx_sigma_final_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp]),
     "thx_ExpectProject_host": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "thx_ExpectRotran_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "thx_InsertFT_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i,
                                _i, _i, _i, _i, _i, _i, _i]),
     "thx_PrepareTF_host": (_i, [_i, _vp, _vp, _i, _vp, _i, _i, _i]),
     "thx_ReconstructG_host": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _i, _i, _i, _i, _vp]),
+    "thx_ReMask_host": (_i, [_vp, _f, _f, _f, _i, _i]),
+    "thx_TranslateI2D_host": (_i, [_i, _vp, _d, _d, _i, _i]),
+    "thx_TranslateI_host": (_i, [_i, _vp, _d, _d, _d, _i, _i]),
 }
 
 _lib = None

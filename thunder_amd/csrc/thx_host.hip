@@ -215,4 +215,51 @@ int thx_ReconstructG_host(int gpuIdx, const float* F3D, const float* T3D_complex
     return rc;
 }
 
+int thx_ReMask_host(float* const* imgFT, float maskRadius, float pixelSize, float ew, int idim, int imgNum)
+{
+    THX_REQUIRE(imgFT && idim > 0 && imgNum >= 0, "bad arguments");
+    const size_t imgBytes = (size_t)idim * (idim / 2 + 1) * 2 * sizeof(float);
+    const int kChunk = 1024;  // images staged per round trip (the reference streams BUFF_SIZE images per stream)
+    DevBuf d;
+    THX_RC(d.alloc((size_t)(imgNum < kChunk ? imgNum : kChunk) * imgBytes));
+    for (int b = 0; b < imgNum; b += kChunk) {
+        const int nb = imgNum - b < kChunk ? imgNum - b : kChunk;
+        for (int l = 0; l < nb; l++)
+            THX_CHECK(hipMemcpyAsync(d.as<char>() + (size_t)l * imgBytes, imgFT[b + l], imgBytes, hipMemcpyHostToDevice,
+                                     nullptr));
+        THX_RC(thx_remask_dev(d.as<float>(), nb, idim, maskRadius / pixelSize, ew, nullptr));
+        for (int l = 0; l < nb; l++)
+            THX_CHECK(hipMemcpyAsync(imgFT[b + l], d.as<char>() + (size_t)l * imgBytes, imgBytes, hipMemcpyDeviceToHost,
+                                     nullptr));
+        THX_CHECK(hipStreamSynchronize(nullptr));
+    }
+    return 0;
+}
+
+int thx_TranslateI2D_host(int gpuIdx, float* imgFT, double ox, double oy, int r, int idim)
+{
+    THX_REQUIRE(imgFT && idim > 0 && r >= 0, "bad arguments");
+    THX_CHECK(hipSetDevice(gpuIdx));
+    const size_t bytes = (size_t)idim * (idim / 2 + 1) * 2 * sizeof(float);
+    const double t[2] = {ox, oy};
+    DevBuf d, dt;
+    THX_RC(d.upload(imgFT, bytes));
+    THX_RC(dt.upload(t, sizeof(t)));
+    THX_RC(thx_translate_image_dev(d.as<float>(), d.as<float>(), dt.as<double>(), 1, idim, (float)r, nullptr));
+    THX_CHECK(hipMemcpy(imgFT, d.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int thx_TranslateI_host(int gpuIdx, float* volFT, double ox, double oy, double oz, int r, int dim)
+{
+    THX_REQUIRE(volFT && dim > 0 && r >= 0, "bad arguments");
+    THX_CHECK(hipSetDevice(gpuIdx));
+    const size_t bytes = (size_t)dim * dim * (dim / 2 + 1) * 2 * sizeof(float);
+    DevBuf d;
+    THX_RC(d.upload(volFT, bytes));
+    THX_RC(thx_translate_volume_dev(d.as<float>(), d.as<float>(), dim, (float)r, ox, oy, oz, nullptr));
+    THX_CHECK(hipMemcpy(volFT, d.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 }  // extern "C"

@@ -181,6 +181,67 @@ def fft3d_fw(rl):
     return ft
 
 
+# ---------------------------------------------------------------------------------------------
+# callers either side of the E/M loop
+def remask(imgFT, maskRadiusPx, ew=6.0):
+    """Optimiser::reMaskImg src/Optimiser.cpp:6093-6149 (ReMask Interface.h:517) IN PLACE on [nImg][N][N/2+1] c64"""
+    _chk(imgFT, _C64, "imgFT")
+    nImg, idim = imgFT.shape[0], imgFT.shape[1]
+    capi.call("thx_remask_dev", ptr(imgFT), nImg, idim, float(maskRadiusPx), float(ew), stream_ptr())
+    return imgFT
+
+
+def translate_image(src, trans, r=-1.0, out=None):
+    """translate(Image&, const Image&, [r,] tx, ty) src/Image/ImageFunctions.cpp:269-284 / :322-339; trans [nImg][2] f64"""
+    _chk(src, _C64, "src"); _chk(trans, _F64, "trans")
+    nImg, idim = src.shape[0], src.shape[1]
+    if out is None:
+        out = src.clone() if r >= 0 else torch.empty_like(src)
+    capi.call("thx_translate_image_dev", ptr(out), ptr(src), ptr(trans), nImg, idim, float(r), stream_ptr())
+    return out
+
+
+def translate_volume(vol, r, ox, oy, oz):
+    """translate(Volume&, const Volume&, r, tx, ty, tz) src/Image/ImageFunctions.cpp:363-384, in place (TranslateI)"""
+    _chk(vol, _C64, "vol")
+    capi.call("thx_translate_volume_dev", ptr(vol), ptr(vol), vol.shape[0], float(r), float(ox), float(oy), float(oz),
+              stream_ptr())
+    return vol
+
+
+def sigma_spectra(volumes, vdim, pf, projR, rSig, img, imgOri, attr, pixelSize, rotMat, trans, offset=None,
+                  dfac=None, volIdx=None):
+    """Per-image shell spectra of Optimiser::allReduceSigma (src/Optimiser.cpp:6443-6565) -> [nImg][4][rSig] f32"""
+    _chk(volumes, _C64, "volumes"); _chk(img, _C64, "img"); _chk(imgOri, _C64, "imgOri"); _chk(attr, _F32, "attr")
+    _chk(rotMat, _F64, "rotMat"); _chk(trans, _F64, "trans")
+    nImg, idim = img.shape[0], img.shape[1]
+    spec = torch.empty((nImg, 4, rSig), dtype=_F32, device=img.device)
+    capi.call("thx_sigma_spectra_dev", ptr(spec), ptr(volumes), ptr(volIdx), vdim, pf, idim, projR, rSig, ptr(img),
+              ptr(imgOri), ptr(attr), ptr(dfac), float(pixelSize), ptr(rotMat), ptr(trans), ptr(offset), nImg,
+              stream_ptr())
+    return spec
+
+
+def sigma_accum(acc, spec, groupID, group=True):
+    """acc = (sigM, sigN, svd) device [nGroup][rSig+1] f32, updated in place; groupID host int32 (1-based)"""
+    sigM, sigN, svd = acc
+    nGroup, rSig = sigM.shape[0], sigM.shape[1] - 1
+    g = None if groupID is None else np.ascontiguousarray(np.asarray(groupID, dtype=np.int32))
+    capi.call("thx_sigma_accum_dev", ptr(sigM), ptr(sigN), ptr(svd), ptr(spec), ptr(g), spec.shape[0], nGroup, rSig,
+              1 if group else 0, stream_ptr())
+
+
+def sigma_final(acc, maskRadius, size, pixelSize, group=True):
+    """closing arithmetic of allReduceSigma (src/Optimiser.cpp:6654-6707) -> sig, sigRcp [nGroup][rSig]"""
+    sigM, sigN, svd = acc
+    nGroup, rSig = sigM.shape[0], sigM.shape[1] - 1
+    sig = torch.empty((nGroup, rSig), dtype=_F32, device=sigM.device)
+    rcp = torch.empty_like(sig)
+    capi.call("thx_sigma_final_dev", ptr(sig), ptr(rcp), ptr(sigM), ptr(sigN), ptr(svd), nGroup, rSig,
+              1 if group else 0, float(maskRadius), int(size), float(pixelSize), stream_ptr())
+    return sig, rcp
+
+
 class RecoPlan:
     """thx_reco handle: Reconstructor::allocSpace state (FFT plans, W, C, kernel table)."""
 
