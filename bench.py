@@ -2,8 +2,9 @@
 """bench.py -- particles/sec of one refinement iteration of the E/M hot path on N MI355X GPUs.
 
 One "step" = one full iteration over the rank's HBM-resident shard of synthetic particles:
-  nPhase particle-filter phases (mLR rotations x mLT shifts each), mReco insertions per particle,
-  half-set reduce (RCCL when N > 2), prepareTF, reconstruct (MAP off) -> FSC -> reconstruct (MAP on), projector refresh.
+  row gathers from the masked image stack, nPhase particle-filter phases (mLR rotations x mLT shifts each), sigma
+  update, mReco insertions per particle, half-set reduce (RCCL when N > 2), prepareTF, reconstruct (MAP off) -> FSC ->
+  reconstruct (MAP on), projector refresh, re-centring and re-masking (rocFFT 2-D) of the particle images.
 Workload = BASELINE.json configs[1] ("10k synthetic 256^3 particles, 3D refinement, 1xMI355X") per GPU, weak scaling.
 Launch: `python bench.py` (N=1) or
   `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`
@@ -105,6 +106,7 @@ def main():
     shard.reset_reference()
     shard.insert_ms.clear()
     shard.expect_ms.clear()
+    shard.stage_ms.clear()
     barrier()
     t0 = time.perf_counter()
     fsc = shard.run(args.steps, timed=True)
@@ -165,6 +167,8 @@ def main():
                                      "total_ms": t_ins},
                         "k_expect_local": {"avg_launch_ms": exp_ms,
                                            "GBps_algorithmic": exp_bytes / (exp_ms * 1e-3) / 1e9, "total_ms": t_exp}},
+            "stages_ms_per_step": {k: round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 2)
+                                   for k, v in shard.stage_ms.items()},
             "fsc_half_maps": [round(float(x), 4) for x in fsc[: 8]],
         }
         if not args.no_cpu_baseline and world == 1:

@@ -4,6 +4,8 @@ Host-side mirror of the reference's per-iteration control flow, restricted to th
     Optimiser::expectation   (src/Optimiser.cpp:1141-1660, local particle-filter phases)
     Optimiser::maximization  -> reconstructRef (src/Optimiser.cpp:6711-7766): insert, prepareTF, reconstruct x2
     Model::compareTwoHemispheres FSC (src/Functions/Spectrum.cpp:302) and Model::refreshProj (src/Model.cpp:1013-1044)
+and the callers either side of it, in the reference's order (src/Optimiser.cpp:3405-3480,3800-3835):
+    allocPreCal row gathers (:8043-8171), allReduceSigma (:6395-6710), reCentreImg (:6065-6090), reMaskImg (:6093-6149)
 All arithmetic is in the HIP library (thunder_amd.ops -> C ABI); this file only sequences launches, owns the
 HBM-resident particle shard and does the half-set exchange over torch.distributed (RCCL on the GPU box, gloo in
 the CPU tests -- where `backend` is injected so the orchestration can be exercised without a GPU).
@@ -66,7 +68,8 @@ class RefineShard:
     """HBM-resident shard of synthetic particles + one EM iteration over it (SURVEY 8d inputs)."""
 
     def __init__(self, N, nImg, device, rank=0, world=1, pf=2, mLR=125, mLT=9, nPhase=3, mReco=100, seed=1000,
-                 batch=10240, pixelSize=1.32, snr=0.01, rL=2, ops=None, oracle_pixel_list=None):
+                 batch=10240, pixelSize=1.32, snr=0.01, rL=2, ops=None, oracle_pixel_list=None, nGroup=8, groupSig=True,
+                 maskFrac=0.45):
         if ops is None:
             from . import ops as _ops
             ops = _ops
@@ -120,8 +123,23 @@ class RefineShard:
             self.ranges = {0: (0, nA), 1: (nA, nImg)}
         else:
             self.ranges = {self.groups.half: (0, nImg)}
-        # M-step rows (_imgOri on the rL = 0 list); the E-step rows are the subset on the (r, rL) list
-        self.datM = torch.empty((nImg, self.nPxlM), dtype=torch.complex64, device=device)
+        # ---- full image stacks, as the reference holds them: _imgOri (as read) and _img (re-centred + masked) ----
+        # signal = CTF x slice x ramp on the rL = 0 list (+ the Hermitian mirror of the kx = 0 column, which the list
+        # drops) + white noise generated in real space so that the FT is that of a real image
+        self.pixelSize, self.rSig = pixelSize, N // 2 - 1
+        self.maskRadiusPx = float(np.float32(maskFrac * N))
+        self.nGroup, self.groupSig = nGroup, groupSig
+        self.gid = rng.integers(1, nGroup + 1, nImg).astype(np.int32)          # Optimiser::_groupID (1-based, host)
+        self.gid0 = torch.from_numpy(self.gid.astype(np.int64) - 1).to(device)
+        nc = N // 2 + 1
+        iPxlM = torch.from_numpy(plM["iPxl"].astype(np.int64)).to(device)
+        col0 = np.nonzero((plM["iCol"] == 0) & (plM["iRow"] > 0))[0]
+        mirror_src = torch.from_numpy(col0.astype(np.int64)).to(device)
+        mirror_dst = torch.from_numpy(((N - plM["iRow"][col0]).astype(np.int64)) * nc).to(device)
+        self.iPxlE = torch.from_numpy(pl["iPxl"]).to(device)
+        self.iPxlM = torch.from_numpy(plM["iPxl"]).to(device)
+        self.iSigE = torch.from_numpy(pl["iSig"].astype(np.int64)).to(device)
+        self.imgOri = torch.zeros((nImg, N, nc), dtype=torch.complex64, device=device)
         self.ctfM = ops.ctf(self.attr, pixelSize, self.iColM, self.iRowM, N)
         gen = torch.Generator(device=device)
         gen.manual_seed(seed + 31 * rank)
@@ -133,12 +151,22 @@ class RefineShard:
             sig = sl * ramp * self.ctfM[b0:b1]
             if b0 == 0:
                 p_sig = float((sig.abs() ** 2).mean().item())
-                self.sigma2 = p_sig / snr / 2.0  # per real component
-            noise = torch.randn((b1 - b0, self.nPxlM, 2), generator=gen, device=device, dtype=torch.float32)
-            self.datM[b0:b1] = sig + torch.view_as_complex(noise) * float(np.sqrt(self.sigma2))
-        self.datP = self.datM[:, e2m].contiguous()
+                self.sigma2 = p_sig / snr / 2.0  # per real component of an FT coefficient
+            flat = self.imgOri[b0:b1].view(b1 - b0, -1)
+            flat[:, iPxlM] = sig
+            flat[:, mirror_dst] = sig[:, mirror_src].conj()
+            for c0 in range(b0, b1, 1024):   # var(FT component) = N^2 var(pixel) / 2
+                c1 = min(b1, c0 + 1024)
+                rl = torch.randn((c1 - c0, N, N), generator=gen, device=device, dtype=torch.float32)
+                self.imgOri[c0:c1] += torch.fft.rfft2(rl) * float(np.sqrt(2.0 * self.sigma2) / N)
+            del sig, sl, ramp, flat
+        # M-step rows (_imgOri on the rL = 0 list) never change; E-step rows are re-gathered from _img every iteration
+        self.datM = ops.gather_pixels(self.imgOri, self.iPxlM, N)
         self.ctfP = self.ctfM[:, e2m].contiguous()
-        self.sigRcpP = torch.full((nImg, self.nPxl), -0.5 / self.sigma2, dtype=torch.float32, device=device)
+        self.img = torch.empty_like(self.imgOri)
+        self.datP = torch.empty((nImg, self.nPxl), dtype=torch.complex64, device=device)
+        self.sigRcpP = torch.empty((nImg, self.nPxl), dtype=torch.float32, device=device)
+        self.offset = torch.zeros((nImg, 2), dtype=torch.float64, device=device)
         # ---- fixed-work support points for every phase (seeded) ----
         stds = [0.02 / (2 ** p) for p in range(nPhase)]
         self.rotP, self.tranP = [], []
@@ -148,6 +176,7 @@ class RefineShard:
             t = self.shift[:, None, :] + rng.normal(0, 0.5 / (2 ** p), size=(nImg, mLT, 2))
             t[:, 0, :] = self.shift
             self.tranP.append(torch.from_numpy(np.ascontiguousarray(t)).to(device))
+        self.tranP0 = [t.clone() for t in self.tranP]
         self.w = torch.full((nImg,), 1.0 / mReco, dtype=torch.float32, device=device)
         nV = len(self.halves)
         self.F = torch.zeros((nV, self.P, self.P, self.P // 2 + 1), dtype=torch.complex64, device=device)
@@ -167,7 +196,68 @@ class RefineShard:
         self.plans = [self.plan] + [ops.RecoPlan(N, N, pf) for _ in range(nV - 1)]
         self.insert_ms = []   # per-launch durations of the insertion kernel (HIP events on the launch stream)
         self.expect_ms = []
+        self.stage_ms = {}    # name -> list of (event, event): coarse per-stage timing of the timed run
         self.last = {}
+        self.sig = torch.empty((nV, nGroup, self.rSig), dtype=torch.float32, device=device)
+        self.sigRcp = torch.empty_like(self.sig)
+        self.reset_reference()
+
+    # -----------------------------------------------------------------------------------------
+    def _stage(self, name, timed):
+        """context manager recording a HIP-event pair around a stage on the current stream when `timed`"""
+        shard = self
+
+        class _S:
+            def __enter__(self_):
+                if timed:
+                    self_.e0 = torch.cuda.Event(enable_timing=True)
+                    self_.e0.record()
+
+            def __exit__(self_, *a):
+                if timed:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    shard.stage_ms.setdefault(name, []).append((self_.e0, e1))
+                return False
+        return _S()
+
+    def refresh_rows(self, vi):
+        """Optimiser::allocPreCal(mask = true, ...) rows of local half `vi` (src/Optimiser.cpp:8043-8171): _datP from
+        the masked stack through iPxl, _sigRcpP[l][p] = _sigRcp(groupID[l] - 1, iSig[p])"""
+        lo, hi = self.ranges[self.halves[vi]]
+        self.datP[lo:hi] = self.ops.gather_pixels(self.img[lo:hi], self.iPxlE, self.N)
+        self.sigRcpP[lo:hi] = self.sigRcp[vi][self.gid0[lo:hi]][:, self.iSigE]
+
+    def top_pose(self, vi, wR, wT):
+        """Particle::rank1st of the last phase: the support point with the largest weight"""
+        p = self.nPhase - 1
+        lo, hi = self.ranges[self.halves[vi]]
+        ar = torch.arange(hi - lo, device=self.dev)
+        return (self.rotP[p][lo:hi][ar, wR.argmax(1)].contiguous(), self.tranP[p][lo:hi][ar, wT.argmax(1)].contiguous())
+
+    def sigma_update(self, vi, rotTop, tranTop):
+        """Optimiser::allReduceSigma (src/Optimiser.cpp:6395-6710) for local half `vi`"""
+        ops = self.ops
+        lo, hi = self.ranges[self.halves[vi]]
+        spec = ops.sigma_spectra(self.vols[vi:vi + 1], self.P, self.pf, self.rU, self.rSig, self.img[lo:hi],
+                                 self.imgOri[lo:hi], self.attr[lo:hi], self.pixelSize, rotTop, tranTop,
+                                 self.offset[lo:hi])
+        acc = tuple(torch.zeros((self.nGroup, self.rSig + 1), dtype=torch.float32, device=self.dev) for _ in range(3))
+        ops.sigma_accum(acc, spec, self.gid[lo:hi], self.groupSig)
+        for a in acc:
+            self.groups.allreduce_half(a)
+        sig, rcp = ops.sigma_final(acc, self.maskRadiusPx * self.pixelSize, self.N, self.pixelSize, self.groupSig)
+        self.sig[vi], self.sigRcp[vi] = sig, rcp
+
+    def recentre_and_remask(self, vi, tranTop):
+        """Optimiser::reCentreImg (src/Optimiser.cpp:6065-6090) + reMaskImg (:6093-6149) for local half `vi`"""
+        ops = self.ops
+        lo, hi = self.ranges[self.halves[vi]]
+        self.offset[lo:hi] -= tranTop
+        for t in self.tranP:                              # _par[l].setT(t - tran)
+            t[lo:hi] -= tranTop[:, None, :]
+        ops.translate_image(self.imgOri[lo:hi], self.offset[lo:hi], out=self.img[lo:hi])
+        ops.remask(self.img[lo:hi], self.maskRadiusPx, 6.0)
 
     # -----------------------------------------------------------------------------------------
     def expectation(self, vi, timed=False):
@@ -225,7 +315,7 @@ class RefineShard:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             ops.insert(F, T, self.P, self.datM[b0:b1], self.ctfM[b0:b1], self.w[b0:b1], rot[b0 - lo:b1 - lo],
-                       tran[b0 - lo:b1 - lo], self.iColM, self.iRowM, self.pf, self.N)
+                       tran[b0 - lo:b1 - lo], self.iColM, self.iRowM, self.pf, self.N, offS=self.offset[b0:b1])
             if timed:
                 e1.record()
                 self.insert_ms.append((e0, e1, b1 - b0))
@@ -248,19 +338,35 @@ class RefineShard:
         self.vols[vi] = self.plans[vi].set_projectee(m)   # Model::refreshProj
         return m
 
-    def iteration(self, timed=False):
-        """one EM iteration, the local halves one after the other on the current stream"""
-        maps = {}
-        for vi, h in enumerate(self.halves):
+    def em_stage(self, vi, timed=False):
+        """rows -> expectation -> sigma update -> draws -> insertion for local half `vi`; returns the top shifts"""
+        with self._stage("rows", timed):
+            self.refresh_rows(vi)
+        with self._stage("expectation", timed):
             wR, wT = self.expectation(vi, timed)
+        with self._stage("sigma", timed):
+            rotTop, tranTop = self.top_pose(vi, wR, wT)
+            self.sigma_update(vi, rotTop, tranTop)
+        with self._stage("insertion", timed):
             rot, tran = self.draw_reco(vi, wR, wT)
             self.insertion(vi, rot, tran, timed)
+        return tranTop
+
+    def iteration(self, timed=False):
+        """one EM iteration, the local halves one after the other on the current stream"""
+        maps, top = {}, {}
         for vi, h in enumerate(self.halves):
-            maps[h] = self.reduce_and_first_map(vi)
-        a, b = self.groups.exchange_half_maps(maps)
-        fsc = self.fsc_of(a, b)
-        for vi, h in enumerate(self.halves):
-            maps[h] = self.final_map_and_refresh(vi, fsc)
+            top[vi] = self.em_stage(vi, timed)
+        with self._stage("reconstruct", timed):
+            for vi, h in enumerate(self.halves):
+                maps[h] = self.reduce_and_first_map(vi)
+            a, b = self.groups.exchange_half_maps(maps)
+            fsc = self.fsc_of(a, b)
+            for vi, h in enumerate(self.halves):
+                maps[h] = self.final_map_and_refresh(vi, fsc)
+        with self._stage("recentre_remask", timed):
+            for vi, h in enumerate(self.halves):
+                self.recentre_and_remask(vi, top[vi])
         self.last["fsc"], self.last["maps"] = fsc, maps
         return fsc
 
@@ -294,10 +400,13 @@ class RefineShard:
                         if vi == 1:   # stay one stage behind half 0
                             e_done[0][it].wait()
                             streams[vi].wait_event(e_evt[0][it])
+                        self.refresh_rows(vi)
                         wR, wT = self.expectation(vi, timed)
                         e_evt[vi][it] = torch.cuda.Event()
                         e_evt[vi][it].record()
                         e_done[vi][it].set()
+                        rotTop, tranTop = self.top_pose(vi, wR, wT)
+                        self.sigma_update(vi, rotTop, tranTop)
                         rot, tran = self.draw_reco(vi, wR, wT)
                         self.insertion(vi, rot, tran, timed)
                         maps1[vi][it] = self.reduce_and_first_map(vi)
@@ -307,6 +416,7 @@ class RefineShard:
                         streams[vi].wait_event(r1_evt[1 - vi][it])
                         fsc = self.fsc_of(maps1[0][it], maps1[1][it])
                         m = self.final_map_and_refresh(vi, fsc)
+                        self.recentre_and_remask(vi, tranTop)
                         meet.wait()                                   # keep the two chains in the same iteration
                         out[vi] = (fsc, m)
                     streams[vi].synchronize()
@@ -332,9 +442,20 @@ class RefineShard:
         return out[0][0]
 
     def reset_reference(self):
+        """back to the state before the first iteration: initial reference, no re-centring offset, masked copies of the
+        images as read (Optimiser::initImg masks them on load), flat initial noise model, initial support points"""
         v = self.plan.set_projectee(self.ref)
         for vi in range(self.vols.shape[0]):
             self.vols[vi] = v
+        self.offset.zero_()
+        for t, t0 in zip(self.tranP, self.tranP0):
+            t.copy_(t0)
+        self.img.copy_(self.imgOri)
+        self.ops.remask(self.img, self.maskRadiusPx, 6.0)
+        self.sig.fill_(self.sigma2)
+        self.sigRcp.fill_(-0.5 / self.sigma2)
+        for vi in range(len(self.halves)):
+            self.refresh_rows(vi)
 
 
 def pixel_list(N, rU, rL, pf=2):
