@@ -84,6 +84,22 @@ int thx_translate_dev(float* traP, const double* trans, int nT, const int* iCol,
 int thx_ctf_dev(float* ctfP, const thx_ctf_attr* attr, const double* dfac, float pixelSize, const int* iCol,
                 const int* iRow, int nPxl, int idim, int nImg, void* stream);
 
+/* Optimiser::allocPreCal, ctf = true branch, src/Optimiser.cpp:8124-8169 (ExpectPrecal, Interface.h:166-174;
+ * kernel_ExpectPrectf): freq [nPxl] (may be NULL), def [nImg][nPxl], k1/k2 [nImg] for the defocus search.
+ * (lambda's constant on this branch is 12.2643274, :8164, unlike CTF()'s 12.2643247.) */
+int thx_expect_precal_dev(float* freq, float* def, float* k1, float* k2, const thx_ctf_attr* attr, int idim,
+                          float pixelSize, const int* iCol, const int* iRow, int nPxl, int nImg, void* stream);
+
+/* CTF rows of the defocus search, src/Optimiser.cpp:1246-1272: ctfP [nImg][nD][nPxl] from the rows of
+ * thx_expect_precal_dev and the defocus factors dpara [nImg][nD] (Particle::d, double) -- the ctfP layout
+ * thx_expect_local_dev takes when nD > 1. */
+int thx_ctf_dsearch_dev(float* ctfP, const float* freq, const float* def, const float* k1, const float* k2,
+                        const thx_ctf_attr* attr, const double* dpara, int nD, int nPxl, int nImg, void* stream);
+
+/* CTF(Image& dst, pixelSize, ...), src/CTF.cpp:31-66, for nImg images (Optimiser::initCTF / GCTFinit,
+ * Interface.h:524-528): ctfFT [nImg][idim][idim/2+1] complex64, CTF in the real part. */
+int thx_ctf_image_dev(float* ctfFT, const thx_ctf_attr* attr, float pixelSize, int idim, int nImg, void* stream);
+
 /* Optimiser::allocPreCal gather (src/Optimiser.cpp:8055-8075): packs full image FTs
  * img [nImg][idim][idim/2+1] into datP [nImg][nPxl] through iPxl. */
 int thx_gather_pixels_dev(float* datP, const float* img, const int* iPxl, int nPxl, int idim, int nImg, void* stream);
@@ -296,6 +312,26 @@ int thx_TranslateI2D_host(int gpuIdx, float* imgFT, double ox, double oy, int r,
 
 /* void TranslateI(int gpuIdx, Volume& ref, double ox, double oy, double oz, int r)  Interface.h:510-515 */
 int thx_TranslateI_host(int gpuIdx, float* volFT, double ox, double oy, double oz, int r, int dim);
+
+/* void ExpectPrecal(vector<CTFAttr>& ctfAttr, RFLOAT* def, RFLOAT* k1, RFLOAT* k2, const int* iCol, const int* iRow,
+ *                   int idim, int npxl, int imgNum)                              Interface.h:166-174
+ * ctfAttr = &ctfAttr[0] (imgNum contiguous CTFAttr); pixelSize is not a parameter of the reference call because def
+ * does not depend on it. */
+int thx_ExpectPrecal_host(const thx_ctf_attr* ctfAttr, float* def, float* k1, float* k2, const int* iCol,
+                          const int* iRow, int idim, int npxl, int imgNum);
+
+/* void ExpectGlobal3D(Complex* rotP, Complex* traP, Complex* datP, RFLOAT* ctfP, RFLOAT* sigRcpP, RFLOAT* wC,
+ *                     RFLOAT* wR, RFLOAT* wT, double* pR, double* pT, RFLOAT* baseL, int kIdx, int nK, int nR, int nT,
+ *                     int npxl, int imgNum)                                      Interface.h:221-237
+ * layouts as thx_expect_global_dev; wC/wR/wT/baseL are read-modify-write host arrays. */
+int thx_ExpectGlobal3D_host(const float* rotP, const float* traP, const float* datP, const float* ctfP,
+                            const float* sigRcpP, float* wC, float* wR, float* wT, const double* pR, const double* pT,
+                            float* baseL, int kIdx, int nK, int nR, int nT, int npxl, int imgNum);
+
+/* void GCTFinit(vector<Image>& img, vector<CTFAttr>& ctfAttr, RFLOAT pixelSize, int idim, int imgNum)
+ *                                                                                Interface.h:524-528
+ * ctfFT = imgNum host pointers (&_ctf[l][0]), each idim*(idim/2+1) complex64. */
+int thx_GCTFinit_host(float* const* ctfFT, const thx_ctf_attr* ctfAttr, float pixelSize, int idim, int imgNum);
 
 #ifdef __cplusplus
 }

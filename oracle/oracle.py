@@ -398,3 +398,32 @@ def sigma_final(sigM, sigN, svd, maskRadius, size, pixelSize, group=True):
                           C.c_int(rSig), C.c_int(1 if group else 0), C.c_float(maskRadius), C.c_int(size),
                           C.c_float(pixelSize))
     return sig, rcp
+
+
+def expect_precal(attr, N, pixelSize, iCol, iRow):
+    """allocPreCal ctf=true branch (src/Optimiser.cpp:8124-8169): -> freq [nPxl], def [nImg][nPxl], K1, K2 [nImg]"""
+    attr, iCol, iRow = f32(attr).reshape(-1, 7), i32(iCol), i32(iRow)
+    nImg, nPxl = len(attr), len(iCol)
+    freq = np.zeros(nPxl, np.float32)
+    de = np.zeros((nImg, nPxl), np.float32)
+    k1 = np.zeros(nImg, np.float32)
+    k2 = np.zeros(nImg, np.float32)
+    lib().orc_expect_precal(_p(freq, c_f), _p(de, c_f), _p(k1, c_f), _p(k2, c_f), _p(attr, c_f), C.c_int(nImg),
+                            C.c_int(N), C.c_float(pixelSize), _p(iCol, c_i), _p(iRow, c_i), C.c_int(nPxl))
+    return freq, de, k1, k2
+
+
+def ctf_dsearch(freq, de, K1, K2, phaseShift, ampC, d):
+    """defocus-search CTF rows of one image (src/Optimiser.cpp:1246-1272) -> [nD][nPxl]"""
+    freq, de, d = f32(freq), f32(de), f64(d)
+    out = np.zeros((len(d), len(freq)), np.float32)
+    lib().orc_ctf_dsearch(_p(out, c_f), _p(freq, c_f), _p(de, c_f), C.c_float(K1), C.c_float(K2),
+                          C.c_float(phaseShift), C.c_float(ampC), _p(d, c_d), C.c_int(len(d)), C.c_int(len(freq)))
+    return out
+
+
+def ctf_image(N, pixelSize, attr):
+    """CTF(Image&, ...) src/CTF.cpp:31-66 -> complex64 [N][N/2+1]"""
+    out = np.zeros((N, N // 2 + 1), np.complex64)
+    lib().orc_ctf_image(_p(out, c_f), C.c_int(N), C.c_float(pixelSize), *[C.c_float(a) for a in attr])
+    return out

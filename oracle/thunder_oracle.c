@@ -1037,3 +1037,59 @@ void orc_sigma_final(RFLOAT* sig, RFLOAT* sigRcp, RFLOAT* sigM, RFLOAT* sigN, RF
             sigRcp[g * rSig + j] = (RFLOAT)(-0.5 / sig[g * rSig + j]);
         }
 }
+
+/* a2 (ctf = true branch): Optimiser::allocPreCal, src/Optimiser.cpp:8124-8169 (ExpectPrecal, Interface.h:166-174):
+ * _frequency [nPxl], _defocusP [nImg][nPxl] (image-major), _K1/_K2 [nImg].  attr = [nImg][7] floats in CTFAttr order
+ * (voltage, defocusU, defocusV, defocusTheta, Cs, amplitudeContrast, phaseShift).  Note lambda's constant here is
+ * 12.2643274 (:8164), not CTF.cpp's 12.2643247, and cos() resolves to the float overload (RFLOAT argument). */
+void orc_expect_precal(RFLOAT* freq, RFLOAT* def, RFLOAT* k1, RFLOAT* k2, const RFLOAT* attr, int nImg, int size,
+                       RFLOAT pixelSize, const int* iCol, const int* iRow, int nPxl)
+{
+    for (int i = 0; i < nPxl; i++)
+        freq[i] = (RFLOAT)(gsl_hypot_((double)iCol[i], (double)iRow[i]) / size / pixelSize);
+    for (int l = 0; l < nImg; l++) {
+        const RFLOAT* a = attr + 7 * (size_t)l;
+        RFLOAT voltage = a[0], dU = a[1], dV = a[2], theta = a[3], Cs = a[4];
+        for (int i = 0; i < nPxl; i++) {
+            RFLOAT angle = (RFLOAT)(atan2((double)iRow[i], (double)iCol[i]) - theta);
+            def[(size_t)l * nPxl + i] = -(dU + dV + (dU - dV) * cosf(2 * angle)) / 2;
+        }
+        RFLOAT lambda = (RFLOAT)(12.2643274 / sqrt(voltage * (1 + voltage * 0.978466e-6)));
+        k1[l] = (RFLOAT)(M_PI * lambda);
+        k2[l] = (RFLOAT)(M_PI_2 * Cs * pow3f_(lambda));
+    }
+}
+
+/* CTF rows of the defocus search, src/Optimiser.cpp:1246-1272: ctfP [nD][nPxl] for one image from the
+ * pre-calculated rows and the nD defocus factors d (double, Particle::d). */
+void orc_ctf_dsearch(RFLOAT* ctfP, const RFLOAT* freq, const RFLOAT* def, RFLOAT K1, RFLOAT K2, RFLOAT phaseShift,
+                     RFLOAT amplitudeContrast, const double* d, int nD, int nPxl)
+{
+    for (int iD = 0; iD < nD; iD++)
+        for (int i = 0; i < nPxl; i++) {
+            RFLOAT ki = (RFLOAT)(K1 * def[i] * d[iD] * pow2f_(freq[i]) + K2 * pow4f_(freq[i]) - phaseShift);
+            ctfP[(size_t)nPxl * iD + i] = -sqrtf(1 - pow2f_(amplitudeContrast)) * sinf(ki) + amplitudeContrast * cosf(ki);
+        }
+}
+
+/* CTF(Image& dst, ...) whole-image form, src/CTF.cpp:31-66 (initCTF / GCTFinit, Interface.h:524-528): complex
+ * image [N][N/2+1] with the CTF in the real part. */
+void orc_ctf_image(RFLOAT* dst, int N, RFLOAT pixelSize, RFLOAT voltage, RFLOAT defocusU, RFLOAT defocusV, RFLOAT theta,
+                   RFLOAT Cs, RFLOAT amplitudeContrast, RFLOAT phaseShift)
+{
+    int nc = N / 2 + 1;
+    int n = N * nc;
+    int* iCol = (int*)malloc(n * sizeof(int));
+    int* iRow = (int*)malloc(n * sizeof(int));
+    RFLOAT* c = (RFLOAT*)malloc(n * sizeof(RFLOAT));
+    int m = 0;
+    for (long j = -N / 2; j < N / 2; j++)
+        for (long i = 0; i <= N / 2; i++) { iCol[m] = (int)i; iRow[m] = (int)j; m++; }
+    orc_ctf(c, pixelSize, voltage, defocusU, defocusV, theta, Cs, amplitudeContrast, phaseShift, N, N, iCol, iRow, n);
+    for (int p = 0; p < n; p++) {
+        size_t idx = (size_t)(iRow[p] >= 0 ? iRow[p] : iRow[p] + N) * nc + iCol[p];
+        dst[2 * idx] = c[p];
+        dst[2 * idx + 1] = 0;
+    }
+    free(iCol); free(iRow); free(c);
+}

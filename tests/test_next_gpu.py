@@ -143,3 +143,80 @@ def test_sigma_update(oracle, dev, N, projR, rSig):
         sigW, rcpW = O.sigma_final(*[2 * w for w in accW], 100.0, N, im["pixelSize"], group)
         sig, rcp = ops.sigma_final(acc, 100.0, N, im["pixelSize"], group)
         assert np.allclose(sig.cpu().numpy(), sigW, rtol=5e-6) and np.allclose(rcp.cpu().numpy(), rcpW, rtol=5e-6)
+
+
+def test_expect_precal_and_dsearch_rows(oracle, dev):
+    """allocPreCal's ctf = true branch + the defocus-search CTF rows (src/Optimiser.cpp:8124-8169, 1246-1272)"""
+    from thunder_amd import capi, ops, synth
+    O = oracle
+    rng = np.random.default_rng(15)
+    N, nImg, nD = 32, 5, 4
+    pl = O.pixel_list(N, N // 2 - 2, 2)
+    attr = synth.ctf_params(nImg, rng)
+    attr[:, 6] = rng.uniform(0, 0.5, nImg)              # phase shift
+    fq, de, k1, k2 = O.expect_precal(attr, N, 1.32, pl["iCol"], pl["iRow"])
+    d_attr = ops.ctf_attr_tensor(attr, dev)
+    gfq, gde, gk1, gk2 = ops.expect_precal(d_attr, 1.32, T(pl["iCol"], dev), T(pl["iRow"], dev), N)
+    assert np.array_equal(gfq.cpu().numpy(), fq) and np.array_equal(gk1.cpu().numpy(), k1)
+    assert np.array_equal(gk2.cpu().numpy(), k2)
+    # defocus: device atan2 / cosf vs glibc, <= 2 ulp of a ~1e4 Angstrom value
+    assert np.all(np.abs(gde.cpu().numpy() - de) <= 4e-7 * np.abs(de))
+    dpara = rng.normal(1.0, 0.02, size=(nImg, nD))
+    want = np.stack([O.ctf_dsearch(fq, de[l], k1[l], k2[l], attr[l, 6], attr[l, 5], dpara[l]) for l in range(nImg)])
+    got = ops.ctf_dsearch(T(fq, dev), T(de, dev), T(k1, dev), T(k2, dev), d_attr, T(dpara, dev)).cpu().numpy()
+    # the phase ki reaches ~1e2 rad: 1 ulp of ki is 8e-6 rad, and sinf/cosf add <= 2 ulp of the result
+    assert np.abs(got - want).max() <= 2e-5
+    # Interface-shaped host entry
+    hde = np.zeros_like(de); hk1 = np.zeros_like(k1); hk2 = np.zeros_like(k2)
+    a = np.ascontiguousarray(attr)
+    capi.call("thx_ExpectPrecal_host", a.ctypes.data, hde.ctypes.data, hk1.ctypes.data, hk2.ctypes.data,
+              pl["iCol"].ctypes.data, pl["iRow"].ctypes.data, N, pl["nPxl"], nImg)
+    assert np.array_equal(hde, gde.cpu().numpy()) and np.array_equal(hk1, k1) and np.array_equal(hk2, k2)
+
+
+def test_ctf_image_and_gctfinit(oracle, dev):
+    import ctypes as C
+    from thunder_amd import capi, ops, synth
+    O = oracle
+    rng = np.random.default_rng(16)
+    N, nImg = 32, 3
+    attr = synth.ctf_params(nImg, rng)
+    want = np.stack([O.ctf_image(N, 1.32, attr[l]) for l in range(nImg)])
+    got = ops.ctf_image(ops.ctf_attr_tensor(attr, dev), 1.32, N).cpu().numpy()
+    assert np.all(got.imag == 0) and np.abs(got.real - want.real).max() <= 1e-5
+    bufs = [np.zeros((N, N // 2 + 1), np.complex64) for _ in range(nImg)]
+    ptrs = (C.c_void_p * nImg)(*[b.ctypes.data for b in bufs])
+    a = np.ascontiguousarray(attr)
+    capi.call("thx_GCTFinit_host", C.cast(ptrs, C.c_void_p), a.ctypes.data, 1.32, N, nImg)
+    assert np.array_equal(np.stack(bufs), got)
+
+
+def test_expect_global3d_host_entry(oracle, dev):
+    """ExpectGlobal3D on host arrays == the device path on the same inputs (which test_parity_gpu checks vs the oracle)"""
+    from thunder_amd import capi, ops
+    from _util import make_images
+    O = oracle
+    rng = np.random.default_rng(17)
+    N, P, nImg, nR, nT, nK = 16, 32, 6, 20, 5, 2
+    _, vol, pl = make_case(O, N)
+    im = make_images(O, vol, pl, N, nImg, rng)
+    from thunder_amd import synth
+    rot = np.stack([O.rotate3D(q) for q in synth.random_quats(nR, rng)])
+    tr = rng.normal(0, 1.5, size=(nT, 2))
+    rotP = np.stack([O.project(vol, P, 2, r, pl["iCol"], pl["iRow"]) for r in rot])
+    traP = np.stack([O.translate(t[0], t[1], N, pl["iCol"], pl["iRow"]) for t in tr])
+    pR = rng.uniform(0.5, 1.5, size=(nImg, nR))
+    pT = rng.uniform(0.5, 1.5, size=(nImg, nT))
+    state = lambda: (np.zeros((nImg, nK), np.float32), np.zeros((nK, nImg, nR), np.float32),
+                     np.zeros((nK, nImg, nT), np.float32), np.full(nImg, np.nan, np.float32))
+    hC, hR, hT, hB = state()
+    dC, dR, dT, dB = [T(x, dev) for x in state()]
+    for k in range(nK):
+        capi.call("thx_ExpectGlobal3D_host", rotP.ctypes.data, traP.ctypes.data, im["dat"].ctypes.data,
+                  im["ctf"].ctypes.data, im["sigRcp"].ctypes.data, hC.ctypes.data, hR.ctypes.data, hT.ctypes.data,
+                  pR.ctypes.data, pT.ctypes.data, hB.ctypes.data, k, nK, nR, nT, pl["nPxl"], nImg)
+        ops.expect_global(T(rotP, dev), T(traP, dev), T(im["dat"], dev), T(im["ctf"], dev), T(im["sigRcp"], dev),
+                          T(pR, dev), T(pT, dev), dC, dR, dT, dB, k, nK)
+    for h, d in ((hC, dC), (hR, dR), (hT, dT), (hB, dB)):
+        assert np.array_equal(h, d.cpu().numpy())
+    assert np.all(np.isfinite(hB)) and np.all(hC > 0)

@@ -43,6 +43,9 @@ SIGNATURES = {
     "thx_rotmat_dev": (_i, [_vp, _vp, _i, _vp]),
     "thx_translate_dev": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "thx_ctf_dev": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp]),
+    "thx_expect_precal_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _vp]),
+    "thx_ctf_dsearch_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "thx_ctf_image_dev": (_i, [_vp, _vp, _f, _i, _i, _vp]),
     "thx_gather_pixels_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "thx_project_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "thx_logdatavsprior_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
@@ -77,6 +80,9 @@ SIGNATURES = {
                                _i, _i, _i, _i, _i, _i, _i]),
     "thx_PrepareTF_host": (_i, [_i, _vp, _vp, _i, _vp, _i, _i, _i]),
     "thx_ReconstructG_host": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _i, _i, _i, _i, _vp]),
+    "thx_ExpectPrecal_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
+    "thx_ExpectGlobal3D_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
+    "thx_GCTFinit_host": (_i, [_vp, _vp, _f, _i, _i]),
     "thx_ReMask_host": (_i, [_vp, _f, _f, _f, _i, _i]),
     "thx_TranslateI2D_host": (_i, [_i, _vp, _d, _d, _i, _i]),
     "thx_TranslateI_host": (_i, [_i, _vp, _d, _d, _d, _i, _i]),

@@ -82,6 +82,50 @@ __global__ void k_ctf(float* __restrict__ ctfP, const thx_ctf_attr* __restrict__
     ctfP[(size_t)l * nPxl + p] = ctf_value(c, pixelSize, idim, idim, iCol[p], iRow[p]);
 }
 
+// allocPreCal, ctf = true branch, src/Optimiser.cpp:8124-8169 (ExpectPrecal / kernel_ExpectPrectf): grid (ceil(nPxl/256), nImg)
+__global__ void k_expect_precal(float* __restrict__ freq, float* __restrict__ def, float* __restrict__ k1,
+                                float* __restrict__ k2, const thx_ctf_attr* __restrict__ attr, int size,
+                                float pixelSize, const int* __restrict__ iCol, const int* __restrict__ iRow, int nPxl)
+{
+    const int l = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const thx_ctf_attr a = attr[l];
+    if (p == 0) {
+        const float lambda = (float)(12.2643274 / sqrt(a.voltage * (1 + a.voltage * 0.978466e-6)));  // sic, :8164
+        k1[l] = (float)(3.14159265358979323846 * lambda);
+        k2[l] = (float)(1.57079632679489661923 * a.Cs * pow3f_(lambda));
+    }
+    if (p >= nPxl) return;
+    if (l == 0 && freq) freq[p] = (float)(gsl_hypot_((double)iCol[p], (double)iRow[p]) / size / pixelSize);
+    const float angle = (float)(atan2((double)iRow[p], (double)iCol[p]) - a.defocusTheta);
+    def[(size_t)l * nPxl + p] = -(a.defocusU + a.defocusV + (a.defocusU - a.defocusV) * cosf(2 * angle)) / 2;
+}
+
+// defocus-search CTF rows, src/Optimiser.cpp:1246-1272: grid (ceil(nPxl/256), nD, nImg); ctfP [nImg][nD][nPxl]
+__global__ void k_ctf_dsearch(float* __restrict__ ctfP, const float* __restrict__ freq, const float* __restrict__ def,
+                              const float* __restrict__ k1, const float* __restrict__ k2,
+                              const thx_ctf_attr* __restrict__ attr, const double* __restrict__ dpara, int nD, int nPxl)
+{
+    const int l = blockIdx.z, iD = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nPxl) return;
+    const float f = freq[p], ac = attr[l].amplitudeContrast;
+    const float ki = (float)(k1[l] * def[(size_t)l * nPxl + p] * dpara[(size_t)l * nD + iD] * pow2f_(f) +
+                             k2[l] * pow4f_(f) - attr[l].phaseShift);
+    ctfP[((size_t)l * nD + iD) * nPxl + p] = -sqrtf(1 - pow2f_(ac)) * sinf(ki) + ac * cosf(ki);
+}
+
+// CTF(Image& dst, ...), src/CTF.cpp:31-66 (GCTFinit): grid (idim, nImg), row per block; complex output, imaginary part 0
+__global__ __launch_bounds__(128) void k_ctf_image(float2* __restrict__ dst, const thx_ctf_attr* __restrict__ attr,
+                                                   float pixelSize, int idim)
+{
+    const int row = blockIdx.x, l = blockIdx.y, nc = idim / 2 + 1;
+    const int j = row < idim / 2 ? row : row - idim;
+    const CtfConst c = ctf_const(attr[l], 1.0);
+    for (int i = threadIdx.x; i < nc; i += blockDim.x)
+        dst[((size_t)l * idim + row) * nc + i] = make_float2(ctf_value(c, pixelSize, idim, idim, i, j), 0.f);
+}
+
 // allocPreCal gather, src/Optimiser.cpp:8055-8075
 __global__ void k_gather_pixels(float2* __restrict__ datP, const float2* __restrict__ img, const int* __restrict__ iPxl,
                                 int nPxl, size_t imgSize)
@@ -612,6 +656,51 @@ int thx_ctf_dev(float* ctfP, const thx_ctf_attr* attr, const double* dfac, float
         const int nl = nImg - l0 < 65535 ? nImg - l0 : 65535;
         hipLaunchKernelGGL(k_ctf, dim3((nPxl + 255) / 256, nl), dim3(256), 0, as_stream(stream),
                            ctfP + (size_t)l0 * nPxl, attr + l0, dfac ? dfac + l0 : nullptr, pixelSize, iCol, iRow, nPxl,
+                           idim);
+    }
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_expect_precal_dev(float* freq, float* def, float* k1, float* k2, const thx_ctf_attr* attr, int idim,
+                          float pixelSize, const int* iCol, const int* iRow, int nPxl, int nImg, void* stream)
+{
+    if (nImg <= 0 || nPxl <= 0) return 0;
+    THX_REQUIRE(def && k1 && k2 && attr && iCol && iRow, "NULL pointer");
+    for (int l0 = 0; l0 < nImg; l0 += 65535) {
+        const int nl = nImg - l0 < 65535 ? nImg - l0 : 65535;
+        hipLaunchKernelGGL(k_expect_precal, dim3((nPxl + 255) / 256, nl), dim3(256), 0, as_stream(stream),
+                           l0 == 0 ? freq : nullptr, def + (size_t)l0 * nPxl, k1 + l0, k2 + l0, attr + l0, idim, pixelSize,
+                           iCol, iRow, nPxl);
+    }
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_ctf_dsearch_dev(float* ctfP, const float* freq, const float* def, const float* k1, const float* k2,
+                        const thx_ctf_attr* attr, const double* dpara, int nD, int nPxl, int nImg, void* stream)
+{
+    if (nImg <= 0 || nPxl <= 0 || nD <= 0) return 0;
+    THX_REQUIRE(ctfP && freq && def && k1 && k2 && attr && dpara, "NULL pointer");
+    THX_REQUIRE(nD <= 65535, "nD too large");
+    for (int l0 = 0; l0 < nImg; l0 += 65535) {
+        const int nl = nImg - l0 < 65535 ? nImg - l0 : 65535;
+        hipLaunchKernelGGL(k_ctf_dsearch, dim3((nPxl + 255) / 256, nD, nl), dim3(256), 0, as_stream(stream),
+                           ctfP + (size_t)l0 * nD * nPxl, freq, def + (size_t)l0 * nPxl, k1 + l0, k2 + l0, attr + l0,
+                           dpara + (size_t)l0 * nD, nD, nPxl);
+    }
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_ctf_image_dev(float* ctfFT, const thx_ctf_attr* attr, float pixelSize, int idim, int nImg, void* stream)
+{
+    if (nImg <= 0) return 0;
+    THX_REQUIRE(ctfFT && attr && idim > 0, "bad arguments");
+    for (int l0 = 0; l0 < nImg; l0 += 65535) {
+        const int nl = nImg - l0 < 65535 ? nImg - l0 : 65535;
+        hipLaunchKernelGGL(k_ctf_image, dim3(idim, nl), dim3(128), 0, as_stream(stream),
+                           reinterpret_cast<float2*>(ctfFT) + (size_t)l0 * idim * (idim / 2 + 1), attr + l0, pixelSize,
                            idim);
     }
     THX_LAUNCH_CHECK();

@@ -262,4 +262,85 @@ int thx_TranslateI_host(int gpuIdx, float* volFT, double ox, double oy, double o
     return 0;
 }
 
+int thx_ExpectPrecal_host(const thx_ctf_attr* ctfAttr, float* def, float* k1, float* k2, const int* iCol,
+                          const int* iRow, int idim, int npxl, int imgNum)
+{
+    THX_REQUIRE(ctfAttr && def && k1 && k2 && iCol && iRow, "NULL pointer");
+    if (imgNum <= 0 || npxl <= 0) return 0;
+    DevBuf dA, dDef, dK1, dK2, dC, dR;
+    THX_RC(dA.upload(ctfAttr, (size_t)imgNum * sizeof(thx_ctf_attr)));
+    THX_RC(dC.upload(iCol, (size_t)npxl * sizeof(int)));
+    THX_RC(dR.upload(iRow, (size_t)npxl * sizeof(int)));
+    THX_RC(dDef.alloc((size_t)imgNum * npxl * sizeof(float)));
+    THX_RC(dK1.alloc((size_t)imgNum * sizeof(float)));
+    THX_RC(dK2.alloc((size_t)imgNum * sizeof(float)));
+    THX_RC(thx_expect_precal_dev(nullptr, dDef.as<float>(), dK1.as<float>(), dK2.as<float>(), dA.as<thx_ctf_attr>(), idim,
+                                 1.0f, dC.as<int>(), dR.as<int>(), npxl, imgNum, nullptr));
+    THX_CHECK(hipMemcpy(def, dDef.p, (size_t)imgNum * npxl * sizeof(float), hipMemcpyDeviceToHost));
+    THX_CHECK(hipMemcpy(k1, dK1.p, (size_t)imgNum * sizeof(float), hipMemcpyDeviceToHost));
+    THX_CHECK(hipMemcpy(k2, dK2.p, (size_t)imgNum * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int thx_ExpectGlobal3D_host(const float* rotP, const float* traP, const float* datP, const float* ctfP,
+                            const float* sigRcpP, float* wC, float* wR, float* wT, const double* pR, const double* pT,
+                            float* baseL, int kIdx, int nK, int nR, int nT, int npxl, int imgNum)
+{
+    THX_REQUIRE(rotP && traP && datP && ctfP && sigRcpP && wC && wR && wT && pR && pT && baseL, "NULL pointer");
+    if (imgNum <= 0) return 0;
+    const size_t nI = (size_t)imgNum;
+    DevBuf dRot, dTra, dDat, dCtf, dSig, dWC, dWR, dWT, dPR, dPT, dBase, dWs;
+    THX_RC(dRot.upload(rotP, (size_t)nR * npxl * 2 * sizeof(float)));
+    THX_RC(dTra.upload(traP, (size_t)nT * npxl * 2 * sizeof(float)));
+    THX_RC(dDat.upload(datP, nI * npxl * 2 * sizeof(float)));
+    THX_RC(dCtf.upload(ctfP, nI * npxl * sizeof(float)));
+    THX_RC(dSig.upload(sigRcpP, nI * npxl * sizeof(float)));
+    THX_RC(dWC.upload(wC, nI * nK * sizeof(float)));
+    THX_RC(dWR.upload(wR, (size_t)nK * nI * nR * sizeof(float)));
+    THX_RC(dWT.upload(wT, (size_t)nK * nI * nT * sizeof(float)));
+    THX_RC(dPR.upload(pR, nI * nR * sizeof(double)));
+    THX_RC(dPT.upload(pT, nI * nT * sizeof(double)));
+    THX_RC(dBase.upload(baseL, nI * sizeof(float)));
+    // images in slabs of <= 65535 (grid.y limit of the scan kernel)
+    for (int l0 = 0; l0 < imgNum; l0 += 65535) {
+        const int nl = imgNum - l0 < 65535 ? imgNum - l0 : 65535;
+        DevBuf ws;
+        THX_RC(ws.alloc(thx_expect_global_workspace(nl, nR, nT)));
+        // wR / wT are [nK][imgNum][.]: a slab of images is not contiguous across classes, so only kIdx's plane is offset
+        THX_REQUIRE(l0 == 0 || nK == 1, "more than 65535 images per call needs nK == 1");
+        THX_RC(thx_expect_global_dev(dRot.as<float>(), dTra.as<float>(), dDat.as<float>() + (size_t)l0 * npxl * 2,
+                                     dCtf.as<float>() + (size_t)l0 * npxl, dSig.as<float>() + (size_t)l0 * npxl,
+                                     dPR.as<double>() + (size_t)l0 * nR, dPT.as<double>() + (size_t)l0 * nT,
+                                     dWC.as<float>() + (size_t)l0 * nK, dWR.as<float>() + (size_t)l0 * nR,
+                                     dWT.as<float>() + (size_t)l0 * nT, dBase.as<float>() + l0, kIdx, nK, nR, nT, npxl, nl,
+                                     ws.p, nullptr));
+        THX_CHECK(hipStreamSynchronize(nullptr));
+    }
+    THX_CHECK(hipMemcpy(wC, dWC.p, nI * nK * sizeof(float), hipMemcpyDeviceToHost));
+    THX_CHECK(hipMemcpy(wR, dWR.p, (size_t)nK * nI * nR * sizeof(float), hipMemcpyDeviceToHost));
+    THX_CHECK(hipMemcpy(wT, dWT.p, (size_t)nK * nI * nT * sizeof(float), hipMemcpyDeviceToHost));
+    THX_CHECK(hipMemcpy(baseL, dBase.p, nI * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int thx_GCTFinit_host(float* const* ctfFT, const thx_ctf_attr* ctfAttr, float pixelSize, int idim, int imgNum)
+{
+    THX_REQUIRE(ctfFT && ctfAttr && idim > 0, "bad arguments");
+    if (imgNum <= 0) return 0;
+    const size_t imgBytes = (size_t)idim * (idim / 2 + 1) * 2 * sizeof(float);
+    const int kChunk = 1024;
+    DevBuf d, dA;
+    THX_RC(dA.upload(ctfAttr, (size_t)imgNum * sizeof(thx_ctf_attr)));
+    THX_RC(d.alloc((size_t)(imgNum < kChunk ? imgNum : kChunk) * imgBytes));
+    for (int b = 0; b < imgNum; b += kChunk) {
+        const int nb = imgNum - b < kChunk ? imgNum - b : kChunk;
+        THX_RC(thx_ctf_image_dev(d.as<float>(), dA.as<thx_ctf_attr>() + b, pixelSize, idim, nb, nullptr));
+        for (int l = 0; l < nb; l++)
+            THX_CHECK(hipMemcpyAsync(ctfFT[b + l], d.as<char>() + (size_t)l * imgBytes, imgBytes, hipMemcpyDeviceToHost,
+                                     nullptr));
+        THX_CHECK(hipStreamSynchronize(nullptr));
+    }
+    return 0;
+}
+
 }  // extern "C"

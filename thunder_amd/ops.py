@@ -63,11 +63,45 @@ def ctf(attr, pixelSize, iCol, iRow, idim, dfac=None):
     return out
 
 
-def gather_pixels(img, iPxl, idim):
+def expect_precal(attr, pixelSize, iCol, iRow, idim):
+    """allocPreCal ctf=true branch (src/Optimiser.cpp:8124-8169 / ExpectPrecal) -> freq, def, k1, k2"""
+    _chk(attr, _F32, "attr"); _chk(iCol, _I32, "iCol"); _chk(iRow, _I32, "iRow")
+    nImg, nPxl, dev = attr.shape[0], iCol.numel(), attr.device
+    freq = torch.empty(nPxl, dtype=_F32, device=dev)
+    de = torch.empty((nImg, nPxl), dtype=_F32, device=dev)
+    k1 = torch.empty(nImg, dtype=_F32, device=dev)
+    k2 = torch.empty(nImg, dtype=_F32, device=dev)
+    capi.call("thx_expect_precal_dev", ptr(freq), ptr(de), ptr(k1), ptr(k2), ptr(attr), idim, float(pixelSize),
+              ptr(iCol), ptr(iRow), nPxl, nImg, stream_ptr())
+    return freq, de, k1, k2
+
+
+def ctf_dsearch(freq, de, k1, k2, attr, dpara):
+    """defocus-search CTF rows (src/Optimiser.cpp:1246-1272): dpara [nImg][nD] f64 -> [nImg][nD][nPxl] f32"""
+    _chk(dpara, _F64, "dpara")
+    nImg, nD, nPxl = dpara.shape[0], dpara.shape[1], freq.numel()
+    out = torch.empty((nImg, nD, nPxl), dtype=_F32, device=freq.device)
+    capi.call("thx_ctf_dsearch_dev", ptr(out), ptr(freq), ptr(de), ptr(k1), ptr(k2), ptr(attr), ptr(dpara), nD, nPxl,
+              nImg, stream_ptr())
+    return out
+
+
+def ctf_image(attr, pixelSize, idim):
+    """CTF(Image&, ...) src/CTF.cpp:31-66 for nImg images -> [nImg][idim][idim/2+1] complex64"""
+    _chk(attr, _F32, "attr")
+    out = torch.empty((attr.shape[0], idim, idim // 2 + 1), dtype=_C64, device=attr.device)
+    capi.call("thx_ctf_image_dev", ptr(out), ptr(attr), float(pixelSize), idim, attr.shape[0], stream_ptr())
+    return out
+
+
+def gather_pixels(img, iPxl, idim, out=None):
     """allocPreCal gather src/Optimiser.cpp:8055-8075: img [nImg][idim][idim/2+1] c64 -> [nImg][nPxl] c64"""
     _chk(img, _C64, "img"); _chk(iPxl, _I32, "iPxl")
     nImg, nPxl = img.shape[0], iPxl.numel()
-    out = torch.empty((nImg, nPxl), dtype=_C64, device=img.device)
+    if out is None:
+        out = torch.empty((nImg, nPxl), dtype=_C64, device=img.device)
+    else:
+        _chk(out, _C64, "out")
     capi.call("thx_gather_pixels_dev", ptr(out), ptr(img), ptr(iPxl), nPxl, idim, nImg, stream_ptr())
     return out
 

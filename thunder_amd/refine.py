@@ -225,7 +225,7 @@ class RefineShard:
         """Optimiser::allocPreCal(mask = true, ...) rows of local half `vi` (src/Optimiser.cpp:8043-8171): _datP from
         the masked stack through iPxl, _sigRcpP[l][p] = _sigRcp(groupID[l] - 1, iSig[p])"""
         lo, hi = self.ranges[self.halves[vi]]
-        self.datP[lo:hi] = self.ops.gather_pixels(self.img[lo:hi], self.iPxlE, self.N)
+        self.ops.gather_pixels(self.img[lo:hi], self.iPxlE, self.N, out=self.datP[lo:hi])
         self.sigRcpP[lo:hi] = self.sigRcp[vi][self.gid0[lo:hi]][:, self.iSigE]
 
     def top_pose(self, vi, wR, wT):
