@@ -366,13 +366,14 @@ def _fsc_np(O, a, b, N):
     return O.fsc(sfft.rfftn(a).astype(np.complex64), sfft.rfftn(b).astype(np.complex64), N, N // 2)
 
 
-@pytest.mark.parametrize("MAP,gridCorr,joinHalf", [(False, True, False), (True, True, True), (True, False, False),
-                                                   (False, False, False)])
-def test_reconstruct(oracle, dev, MAP, gridCorr, joinHalf):
+@pytest.mark.parametrize("MAP,gridCorr,joinHalf,N", [(False, True, False, 32), (True, True, True, 32),
+                                                     (True, False, False, 32), (False, False, False, 32),
+                                                     (True, True, False, 24)])   # N = 24: non-power-of-two grid
+def test_reconstruct(oracle, dev, MAP, gridCorr, joinHalf, N):
     from thunder_amd import ops
     O = oracle
     rng = np.random.default_rng(33)
-    N, P = 32, 64
+    P = 2 * N
     maxRadius = N // 2 - 2
     ref, vol, pl = make_case(O, N)
     F = np.zeros((P, P, P // 2 + 1), np.complex64)

@@ -104,44 +104,76 @@ __global__ __launch_bounds__(256) void k_initW_floorT(float* __restrict__ W, flo
     T[e] = t > (float)1e-25 ? t : (float)1e-25;
 }
 
-// C = T * REAL(W) (:1389-1391)
-__global__ __launch_bounds__(256) void k_calcC(float2* __restrict__ C, const float* __restrict__ T,
-                                               const float* __restrict__ W, size_t n)
+// Row length of the library-internal complex work grid C: rocFFT's strided passes over a [P][P][P/2+1] grid run at
+// 1.8 TB/s because rows of 257 complex values start on odd 8-byte boundaries; with the rows padded to a multiple of 8
+// elements (64 B) the same transforms take 1.05 ms instead of 1.44 ms at P = 512 (tools/fft_layout_probe.hip).
+__host__ __device__ __forceinline__ int padded_nc(int P) { return ((P / 2 + 1) + 7) & ~7; }
+
+// correctly rounded a / b from the correctly rounded reciprocal rb = RN(1 / b) (Markstein): q0 = a rb, r = a - q0 b
+// (exact, fma), q = q0 + r rb.  Replaces the ~12-instruction IEEE division sequence for divisors that are launch constants.
+__device__ __forceinline__ float div_by_const(float a, float b, float rb)
 {
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const float w = W[e];
-    C[e] = make_float2(T[e] * w, 0.0f * w);
+    const float q0 = a * rb;
+    const float rem = fmaf(-q0, b, a);
+    return fmaf(rem, rb, q0);
 }
 
 // convoluteC real-space stage (:2635-2652) fused with bwExecutePlan's 1/size scaling (src/FFT.cpp:355-367).
-// grid (jw, kw): one row of the real P^3 volume per workgroup; each thread owns 4 consecutive voxels (16-byte accesses).
-// POW2: (N*pf)^2 is a power of two, so q / (N*pf)^2 == q * 2^-k exactly and the fp64 division disappears.
+// The tabulated kernel value depends only on q = i^2 + j^2 + k^2, and a lookup per voxel is bound by L2->L1 line traffic
+// (each 4-byte gather from the 400 KB table pulls a whole line: 635 us at P = 512).  One workgroup therefore takes a
+// canonical pair 0 <= j <= k <= P/2, looks the P/2+1 values of its rows up ONCE into LDS, and streams every row that
+// shares them -- (+-j, +-k) and (+-k, +-j), up to 8 rows, each using a value for +i and -i: 16x fewer gathers.
+// POW2: P^3 and (N*pf)^2 are powers of two, so v / size and q / (N*pf)^2 are exact float scalings (q < 2^24 is an exact
+// float) and the reference's double-precision detours produce the same bits as the float operations used here.
+constexpr int kMaxHalfP = 1024;  // P <= 2048
 template <bool POW2>
-__global__ __launch_bounds__(128) void k_convolute_rl(float* __restrict__ rl, int P, int NP, const float* __restrict__ tab,
-                                                      float nf)
+__global__ __launch_bounds__(256) void k_convolute_rl(float* __restrict__ rl, int P, int NP, const float* __restrict__ tab,
+                                                      float nf, float rnf, float rs)
 {
+    __shared__ float sval[kMaxHalfP + 1];
+    const int h = P / 2;
+    const int j = blockIdx.x, k = blockIdx.y;
+    if (j > k) return;
     const size_t n = (size_t)P * P * P;
-    const int jw = blockIdx.x, kw = blockIdx.y;
-    const int j = jw >= P / 2 ? jw - P : jw, k = kw >= P / 2 ? kw - P : kw;
-    const double qjk = (double)j * j + (double)k * k;
+    const int qjk = j * j + k * k;
     const double np2 = (double)pow2f_((float)NP);
-    const double inp2 = 1.0 / np2;
+    const float inp2f = (float)(1.0 / np2);
     const double rn = 1.0 / (double)n;
+    const float rnf32 = (float)rn;
     const float s = 1.0f / kTabN;  // _s = (_b - _a) / _n in RFLOAT, src/TabFunction.cpp:34
-    float4* row = reinterpret_cast<float4*>(rl + ((size_t)kw * P + jw) * P);
-    for (int i4 = threadIdx.x; i4 < P / 4; i4 += blockDim.x) {
+    for (int i = threadIdx.x; i <= h; i += blockDim.x) {
+        const int qi = i * i + qjk;
+        const float x = POW2 ? (float)qi * inp2f : (float)((double)qi / np2);
+        const int idx = (int)rintf(div_by_const(x - 0.0f, s, rs));
+        sval[i] = tab[idx < kTabN ? idx : kTabN];
+    }
+    // the rows sharing these values (uniform across the workgroup); +P/2 is not a stored index, -P/2 is
+    int rowOff[8], nRows = 0;
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+        const int swap = v >> 2, sj = (v >> 1) & 1, sk = v & 1;
+        if ((swap && j == k) || (sj && j == 0) || (sk && k == 0)) continue;
+        const int ja = sj ? -j : j, kb = sk ? -k : k;
+        const int a = swap ? kb : ja, b = swap ? ja : kb;  // a = row (j') index, b = slice (k') index
+        if (a == h || b == h) continue;
+        rowOff[nRows++] = (b < 0 ? b + P : b) * P + (a < 0 ? a + P : a);
+    }
+    __syncthreads();
+    const int per = P / 4;
+    for (int item = threadIdx.x; item < nRows * per; item += blockDim.x) {
+        const int rsel = item / per, i4 = item - rsel * per;
+        int off = rowOff[0];
+#pragma unroll
+        for (int v = 1; v < 8; v++) off = (rsel == v) ? rowOff[v] : off;
+        float4* row = reinterpret_cast<float4*>(rl + (size_t)off * P);
         float4 v4 = row[i4];
         float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const int iw = 4 * i4 + c;
-            const int i = iw >= P / 2 ? iw - P : iw;
-            const float vv = (float)((double)v[c] * rn);
-            const double q = (double)i * i + qjk;
-            const float x = POW2 ? (float)(q * inp2) : (float)(q / np2);
-            const int idx = (int)rint((double)((x - 0.0f) / s));
-            v[c] = vv * tab[idx < kTabN ? idx : kTabN] / nf;
+            const int ai = iw >= h ? P - iw : iw;  // |i|
+            const float vv = POW2 ? v[c] * rnf32 : (float)((double)v[c] * rn);
+            v[c] = div_by_const(vv * sval[ai], nf, rnf);
         }
         row[i4] = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -156,39 +188,46 @@ __device__ __forceinline__ float ts_hypot(float x, float y)
     return mx * sqrtf(1 + u * u);
 }
 
-// W /= max(|C|, 1e-6) in the sphere (:1487-1496) + checkC max (RECONSTRUCTOR_CHECK_C_MAX, :2563-2592)
-__global__ __launch_bounds__(256) void k_updateW_checkC(float* __restrict__ W, const float2* __restrict__ C, int P, int pf,
-                                                        int maxRadius, unsigned* __restrict__ diffBits)
+// One sweep per balancing round over the half grid, row (jw, kw) per workgroup:
+//   UPDATE: W /= max(|C|, 1e-6) in the sphere (:1487-1496) + checkC max (RECONSTRUCTOR_CHECK_C_MAX, :2563-2592), then
+//   always: C = T * REAL(W) for the next round (:1389-1391) -- fused so that W is read once and the next round's
+//   input is written while the row is in registers.  C rows are ncp long (padded_nc), T / W rows P/2+1.
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void k_updateW_calcC(float* __restrict__ W, float2* __restrict__ C,
+                                                       const float* __restrict__ T, int P, int ncp, int pf, int maxRadius,
+                                                       unsigned* __restrict__ diffBits)
 {
-    // grid (jw, kw): one row of the half grid per workgroup
     __shared__ float sred[4];
     const int nc = P / 2 + 1;
     const int jw = blockIdx.x, kw = blockIdx.y;
     const int j = jw >= P / 2 ? jw - P : jw, k = kw >= P / 2 ? kw - P : kw;
     const double qjk = (double)j * j + (double)k * k;
     const double r2 = (double)pow2f_((float)(maxRadius * pf));
+    const size_t base = ((size_t)kw * P + jw) * nc, baseC = ((size_t)kw * P + jw) * ncp;
     float d = 0.f;
-    if (qjk < r2) {
-        const size_t base = ((size_t)kw * P + jw) * nc;
-        for (int i = threadIdx.x; i < nc; i += blockDim.x) {
-            if ((double)i * i + qjk < r2) {
-                const float2 c = C[base + i];
-                const float a = ts_hypot(c.x, c.y);
-                const float m = a > (float)1e-6 ? a : (float)1e-6;
-                W[base + i] = W[base + i] / m;
-                d = fmaxf(d, fabsf(a - 1));
-            }
+    for (int i = threadIdx.x; i < nc; i += blockDim.x) {
+        float w = W[base + i];
+        if (UPDATE && ((double)i * i + qjk < r2)) {
+            const float2 c = C[baseC + i];
+            const float a = ts_hypot(c.x, c.y);
+            const float m = a > (float)1e-6 ? a : (float)1e-6;
+            w = w / m;
+            W[base + i] = w;
+            d = fmaxf(d, fabsf(a - 1));
         }
+        C[baseC + i] = make_float2(T[base + i] * w, 0.0f * w);
     }
-    d = wave_max(d);
-    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = d;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        d = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
-        // d >= 0: uint order == float order.  One hot word retires only ~88 atomics/us, so a workgroup whose maximum
-        // cannot raise the current value (plain L2 read) skips the atomic.
-        const unsigned bitsd = __float_as_uint(d);
-        if (bitsd > __hip_atomic_load(diffBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(diffBits, bitsd);
+    if (UPDATE) {
+        d = wave_max(d);
+        if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = d;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            d = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+            // d >= 0: uint order == float order.  One hot word retires only ~88 atomics/us, so a workgroup whose maximum
+            // cannot raise the current value (plain L2 read) skips the atomic.
+            const unsigned bitsd = __float_as_uint(d);
+            if (bitsd > __hip_atomic_load(diffBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(diffBits, bitsd);
+        }
     }
 }
 
@@ -209,7 +248,7 @@ __global__ __launch_bounds__(256) void k_W_nogridcorr(float* __restrict__ W, con
 }
 
 // padDst = F * W in the sphere, 0 elsewhere (:1678-1701).  pad grid PN = _N*_pf, F grid PF = _pf*_size.
-__global__ __launch_bounds__(256) void k_FW(float2* __restrict__ pad, int PN, const float2* __restrict__ F,
+__global__ __launch_bounds__(256) void k_FW(float2* __restrict__ pad, int PN, int ncp, const float2* __restrict__ F,
                                             const float* __restrict__ W, int PF, int pf, int maxRadius)
 {
     const size_t n = (size_t)PN * PN * (PN / 2 + 1);
@@ -217,6 +256,7 @@ __global__ __launch_bounds__(256) void k_FW(float2* __restrict__ pad, int PN, co
     if (e >= n) return;
     int i, j, k;
     unpack_half(e, PN, i, j, k);
+    const size_t eo = (size_t)((unsigned)e / (unsigned)(PN / 2 + 1)) * ncp + i;  // padded row of the work grid
     float2 o = make_float2(0.f, 0.f);
     const double q = (double)i * i + (double)j * j + (double)k * k;
     const int h = PF / 2;
@@ -226,7 +266,7 @@ __global__ __launch_bounds__(256) void k_FW(float2* __restrict__ pad, int PN, co
         const float b0 = W[f], b1 = 0.f;
         o = make_float2(a.x * b0 - a.y * b1, a.x * b1 + a.y * b0);
     }
-    pad[e] = o;
+    pad[eo] = o;
 }
 
 // fft.bw 1/size + VOL_EXTRACT_RL + TIK correction (:1716-1802)
@@ -318,7 +358,10 @@ struct thx_reco {
     float* rl;        // device, max(PF, PN)^3
     unsigned* diff;   // device scalar
     float* fscDev;    // device, up to 4096 shells
-    hipfftHandle r2cF, c2rF, r2cN, c2rN;
+    float rnf, rs;    // RN(1 / nf), RN(1 / table step): launch constants of k_convolute_rl
+    // r2cF / c2rF / c2rN work on the padded C grid (rows of padded_nc); r2cStd writes the standard [P][P][P/2+1] layout
+    // (Projector volume)
+    hipfftHandle r2cF, c2rF, c2rN, r2cStd;
     bool haveN;
 };
 
@@ -329,6 +372,7 @@ int thx_reco_create(thx_reco** out, int size, int N, int pf, float a, float alph
     THX_REQUIRE(out, "out is NULL");
     THX_REQUIRE(size > 0 && N >= size && pf >= 1 && (size % 2 == 0) && (N % 2 == 0), "bad size / N / pf");
     THX_REQUIRE((pf * size) % 4 == 0, "pf * size must be a multiple of 4");
+    THX_REQUIRE(pf * size <= 2 * kMaxHalfP && pf * N <= 2 * kMaxHalfP, "grids above 2048 are not supported");
     thx_reco* r = new thx_reco();
     memset(r, 0, sizeof(*r));
     r->size = size; r->N = N; r->pf = pf; r->PF = pf * size; r->PN = pf * N; r->a = a; r->alpha = alpha;
@@ -341,7 +385,9 @@ int thx_reco_create(thx_reco** out, int size, int N, int pf, float a, float alph
     }
     const int PM = r->PN > r->PF ? r->PN : r->PF;
     const size_t nHalfF = (size_t)r->PF * r->PF * (r->PF / 2 + 1);
-    const size_t nHalfM = (size_t)PM * PM * (PM / 2 + 1);
+    const size_t nHalfM = (size_t)PM * PM * padded_nc(PM);
+    r->rnf = (float)(1.0 / (double)r->nf);
+    r->rs = (float)(1.0 / (double)(1.0f / kTabN));
     THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->tab), (kTabN + 1) * sizeof(float)));
     THX_CHECK(hipMemcpy(r->tab, tab.data(), (kTabN + 1) * sizeof(float), hipMemcpyHostToDevice));
     THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->W), nHalfF * sizeof(float)));
@@ -349,16 +395,18 @@ int thx_reco_create(thx_reco** out, int size, int N, int pf, float a, float alph
     THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->rl), (size_t)PM * PM * PM * sizeof(float)));
     THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->diff), sizeof(unsigned)));
     THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->fscDev), 4096 * sizeof(float)));
-    THX_FFT_CHECK(hipfftPlan3d(&r->r2cF, r->PF, r->PF, r->PF, HIPFFT_R2C));
-    THX_FFT_CHECK(hipfftPlan3d(&r->c2rF, r->PF, r->PF, r->PF, HIPFFT_C2R));
+    auto plan_padded = [](hipfftHandle* h, int P, hipfftType type) -> hipfftResult {
+        int n[3] = {P, P, P};
+        int cE[3] = {P, P, padded_nc(P)}, rE[3] = {P, P, P};
+        if (type == HIPFFT_C2R) return hipfftPlanMany(h, 3, n, cE, 1, P * P * padded_nc(P), rE, 1, P * P * P, type, 1);
+        return hipfftPlanMany(h, 3, n, rE, 1, P * P * P, cE, 1, P * P * padded_nc(P), type, 1);
+    };
+    THX_FFT_CHECK(plan_padded(&r->r2cF, r->PF, HIPFFT_R2C));
+    THX_FFT_CHECK(plan_padded(&r->c2rF, r->PF, HIPFFT_C2R));
     r->haveN = r->PN != r->PF;
-    if (r->haveN) {
-        THX_FFT_CHECK(hipfftPlan3d(&r->r2cN, r->PN, r->PN, r->PN, HIPFFT_R2C));
-        THX_FFT_CHECK(hipfftPlan3d(&r->c2rN, r->PN, r->PN, r->PN, HIPFFT_C2R));
-    } else {
-        r->r2cN = r->r2cF;
-        r->c2rN = r->c2rF;
-    }
+    if (r->haveN) THX_FFT_CHECK(plan_padded(&r->c2rN, r->PN, HIPFFT_C2R));
+    else r->c2rN = r->c2rF;
+    THX_FFT_CHECK(hipfftPlan3d(&r->r2cStd, r->PN, r->PN, r->PN, HIPFFT_R2C));
     *out = r;
     return 0;
 }
@@ -368,10 +416,8 @@ int thx_reco_destroy(thx_reco* r)
     if (!r) return 0;
     (void)hipfftDestroy(r->r2cF);
     (void)hipfftDestroy(r->c2rF);
-    if (r->haveN) {
-        (void)hipfftDestroy(r->r2cN);
-        (void)hipfftDestroy(r->c2rN);
-    }
+    (void)hipfftDestroy(r->r2cStd);
+    if (r->haveN) (void)hipfftDestroy(r->c2rN);
     (void)hipFree(r->tab); (void)hipFree(r->W); (void)hipFree(r->C); (void)hipFree(r->rl); (void)hipFree(r->diff); (void)hipFree(r->fscDev);
     delete r;
     return 0;
@@ -390,10 +436,8 @@ int thx_reco_reconstruct_dev(thx_reco* r, const float* F, float* T, int maxRadiu
     const size_t nHalfN = (size_t)PN * PN * (PN / 2 + 1);
     THX_FFT_CHECK(hipfftSetStream(r->r2cF, st));
     THX_FFT_CHECK(hipfftSetStream(r->c2rF, st));
-    if (r->haveN) {
-        THX_FFT_CHECK(hipfftSetStream(r->r2cN, st));
-        THX_FFT_CHECK(hipfftSetStream(r->c2rN, st));
-    }
+    if (r->haveN) THX_FFT_CHECK(hipfftSetStream(r->c2rN, st));
+    const int ncpF = padded_nc(PF), ncpN = padded_nc(PN);
     if (MAP) {
         THX_CHECK(hipMemcpyAsync(r->fscDev, FSC_host, nFSC * sizeof(float), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_wiener_T, dim3(nblk(nHalfF)), dim3(256), 0, st, T, PF, pf, maxRadius, r->fscDev, nFSC,
@@ -404,20 +448,22 @@ int thx_reco_reconstruct_dev(thx_reco* r, const float* F, float* T, int maxRadiu
     float diffC = 3.402823466e+38f, diffCPrev = 3.402823466e+38f;
     if (gridCorr) {
         int nNoDec = 0;
+        const long np = (long)r->N * pf;
+        const bool pow2 = ((np & (np - 1)) == 0) && ((PF & (PF - 1)) == 0);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_updateW_calcC<false>), dim3(PF, PF), dim3(256), 0, st, r->W, r->C, T, PF, ncpF,
+                           pf, maxRadius, r->diff);
         for (int m = 0; m < 30; m++) {  // MAX_N_ITER_BALANCE
-            hipLaunchKernelGGL(k_calcC, dim3(nblk(nHalfF)), dim3(256), 0, st, r->C, T, r->W, nHalfF);
             THX_FFT_CHECK(hipfftExecC2R(r->c2rF, reinterpret_cast<hipfftComplex*>(r->C), r->rl));
-            {
-                const long np = (long)r->N * pf;
-                if ((np & (np - 1)) == 0)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_convolute_rl<true>), dim3(PF, PF), dim3(128), 0, st, r->rl, PF, r->N * pf, r->tab, r->nf);
-                else
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_convolute_rl<false>), dim3(PF, PF), dim3(128), 0, st, r->rl, PF, r->N * pf, r->tab, r->nf);
-            }
+            if (pow2)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_convolute_rl<true>), dim3(PF / 2 + 1, PF / 2 + 1), dim3(256), 0, st, r->rl,
+                                   PF, r->N * pf, r->tab, r->nf, r->rnf, r->rs);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_convolute_rl<false>), dim3(PF / 2 + 1, PF / 2 + 1), dim3(256), 0, st, r->rl,
+                                   PF, r->N * pf, r->tab, r->nf, r->rnf, r->rs);
             THX_FFT_CHECK(hipfftExecR2C(r->r2cF, r->rl, reinterpret_cast<hipfftComplex*>(r->C)));
             THX_CHECK(hipMemsetAsync(r->diff, 0, sizeof(unsigned), st));
-            hipLaunchKernelGGL(k_updateW_checkC, dim3(PF, PF), dim3(256), 0, st, r->W, r->C, PF, pf, maxRadius,
-                               r->diff);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_updateW_calcC<true>), dim3(PF, PF), dim3(256), 0, st, r->W, r->C, T, PF, ncpF,
+                               pf, maxRadius, r->diff);
             unsigned bits = 0;
             THX_CHECK(hipMemcpyAsync(&bits, r->diff, sizeof(unsigned), hipMemcpyDeviceToHost, st));
             THX_CHECK(hipStreamSynchronize(st));
@@ -432,8 +478,8 @@ int thx_reco_reconstruct_dev(thx_reco* r, const float* F, float* T, int maxRadiu
     } else {
         hipLaunchKernelGGL(k_W_nogridcorr, dim3(nblk(nHalfF)), dim3(256), 0, st, r->W, T, PF, pf, maxRadius);
     }
-    hipLaunchKernelGGL(k_FW, dim3(nblk(nHalfN)), dim3(256), 0, st, r->C, PN, reinterpret_cast<const float2*>(F), r->W, PF, pf,
-                       maxRadius);
+    hipLaunchKernelGGL(k_FW, dim3(nblk(nHalfN)), dim3(256), 0, st, r->C, PN, ncpN, reinterpret_cast<const float2*>(F), r->W, PF,
+                       pf, maxRadius);
     THX_FFT_CHECK(hipfftExecC2R(r->c2rN, reinterpret_cast<hipfftComplex*>(r->C), r->rl));
     hipLaunchKernelGGL(k_extract_tik, dim3(nblk((size_t)r->N * r->N * r->N)), dim3(256), 0, st, dstRL, r->rl, PN, r->N, pf, 1);
     THX_LAUNCH_CHECK();
@@ -447,10 +493,10 @@ int thx_reco_set_projectee_dev(thx_reco* r, const float* refRL, float* volume, v
     THX_REQUIRE(r && refRL && volume, "NULL pointer");
     hipStream_t st = as_stream(stream);
     const int PN = r->PN;
-    THX_FFT_CHECK(hipfftSetStream(r->r2cN, st));
+    THX_FFT_CHECK(hipfftSetStream(r->r2cStd, st));
     hipLaunchKernelGGL(k_pad_gridcorr, dim3(nblk((size_t)PN * PN * PN)), dim3(256), 0, st, r->rl, refRL, r->N, r->pf);
     THX_LAUNCH_CHECK();
-    THX_FFT_CHECK(hipfftExecR2C(r->r2cN, r->rl, reinterpret_cast<hipfftComplex*>(volume)));
+    THX_FFT_CHECK(hipfftExecR2C(r->r2cStd, r->rl, reinterpret_cast<hipfftComplex*>(volume)));
     return 0;
 }
 

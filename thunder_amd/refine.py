@@ -47,7 +47,10 @@ class HalfGroups:
     def allreduce_half(self, t):
         if self.world > 2:
             import torch.distributed as dist
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            # complex volumes go over the wire as their float pairs (same bytes; no reliance on complex support
+            # of the collective backend)
+            buf = torch.view_as_real(t) if t.is_complex() else t
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def exchange_half_maps(self, maps):
