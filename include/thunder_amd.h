@@ -262,6 +262,52 @@ int thx_sigma_final_dev(float* sig, float* sigRcp, const float* sigM, const floa
                         int rSig, int group, float maskRadius, int size, float pixelSize, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Data formats either side of the path
+ * ------------------------------------------------------------------------------------------- */
+
+/* ImageFile::readMetaDataMRC, src/Image/ImageFile.cpp:209-228 (header = include/Image/MRCHeader.h, 1024 bytes). */
+int thx_mrc_info(const char* path, int* nx, int* ny, int* nz, int* mode, int* nsymbt);
+
+/* ImageFile::readImageMRC(Image&, iSlc), src/Image/ImageFile.cpp:248-264, for slices [first, first+count):
+ * dst HOST float [count][ny][nx] in the reference's in-memory layout (origin at index 0: IMAGE_READ_CAST moves the
+ * file's centre-origin samples with MESH_IMAGE_INDEX, include/Image/ImageFile.h:383-388,418-435).  Modes 0, 1, 2. */
+int thx_mrc_read_images(const char* path, int first, int count, float* dst);
+
+/* ImageFile::readVolumeMRC, src/Image/ImageFile.cpp:289-303 (VOLUME_READ_CAST + MESH_VOLUME_INDEX): dst HOST [nz][ny][nx]. */
+int thx_mrc_read_volume(const char* path, float* dst);
+
+/* ImageFile::writeVolumeMRC (src/Image/ImageFile.cpp:332-357) and openStack/writeStack/closeStack (:359-404):
+ * mode 2, header as ImageFile::fillMRCHeader (:171-207), cell dimensions scaled by pixelSize.  src HOST arrays in the
+ * in-memory layout; a stack's slices are images (meshed in x, y only). */
+int thx_mrc_write_volume(const char* path, const float* src, int nx, int ny, int nz, float pixelSize);
+int thx_mrc_write_stack(const char* path, const float* src, int size, int nSlc, float pixelSize);
+
+/* The .thu particle table (include/Database.h:22-287; Database::nParticle/nGroup/ctf/path/groupID/cls/quat/tran/...,
+ * src/Database.cpp:137-640): one particle per line, blank-separated columns; blank and '#' lines are skipped as
+ * Database::reGenDatabase does (:40-100).  thx_thu_load fills whichever HOST arrays are non-NULL:
+ * ctf [n], particlePath [n][pathStride] ("000001@stack.mrcs" syntax left to the caller, src/Optimiser.cpp:4646-4660),
+ * groupID / classID [n], quat [n][4], tran / stdT [n][2], defocusFactor / score [n]. */
+int thx_thu_count(const char* path, int* nParticle, int* nGroup);
+int thx_thu_load(const char* path, int nParticle, thx_ctf_attr* ctf, char* particlePath, int pathStride, int* groupID,
+                 int* classID, double* quat, double* tran, double* stdT, double* defocusFactor, double* score);
+
+/* Optimiser::substractBgImg, src/Optimiser.cpp:4928-4962 (OPTIMISER_INIT_IMG_NORMALISE_OUT_MASK_REGION): per image
+ * (x - bgMean) / bgStddev over the pixels outside maskRadiusPx (bgMeanStddev, src/Image/ImageFunctions.cpp:607-621).
+ * imgRL DEVICE float [nImg][idim][idim], in-memory layout, in place. */
+int thx_img_subtract_bg_dev(float* imgRL, int nImg, int idim, float maskRadiusPx, void* stream);
+
+/* Per-image terms of Optimiser::statImg, src/Optimiser.cpp:4838-4870: stat DEVICE double [nImg][4] =
+ * {regionMean(img, r, 0), bgStddev(0, img, r), stddev(0, img), bgStddev^2}; the caller sums them over its images,
+ * all-reduces over the hemisphere and divides by N as :4877-4915 does. */
+int thx_img_stats_dev(double* stat, const float* imgRL, int nImg, int idim, float maskRadiusPx, void* stream);
+
+/* Optimiser::maskImg (zeroMask) + normaliseImg + fwImg, src/Optimiser.cpp:4964-5024: imgOriFT = FFT(x * scale),
+ * imgFT = FFT(softMask(x, r, ew, bg = 0) * scale), scale = 1 / stdN.  imgRL is scaled in place; scratchRL holds
+ * min(nImg, 1024) images.  Both outputs DEVICE complex64 [nImg][idim][idim/2+1]; batched rocFFT 2-D r2c. */
+int thx_img_mask_normalise_fft_dev(float* imgFT, float* imgOriFT, float* imgRL, float* scratchRL, int nImg, int idim,
+                                   float maskRadiusPx, float ew, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Interface.h-shaped HOST-pointer entry points (what -DGPU_VERSION call sites bind to)
  * ------------------------------------------------------------------------------------------- */
 

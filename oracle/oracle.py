@@ -427,3 +427,60 @@ def ctf_image(N, pixelSize, attr):
     out = np.zeros((N, N // 2 + 1), np.complex64)
     lib().orc_ctf_image(_p(out, c_f), C.c_int(N), C.c_float(pixelSize), *[C.c_float(a) for a in attr])
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# MRC stacks and image ingestion
+def mrc_read(path):
+    """ImageFile::readMetaDataMRC / readImageMRC / readVolumeMRC (src/Image/ImageFile.cpp:209-300): returns float32
+    [nz][ny][nx] in the reference's in-memory (wrapped-origin) layout: IMAGE_READ_CAST / VOLUME_READ_CAST move the file's
+    centre-origin samples with MESH_*_INDEX (include/Image/ImageFile.h:383-388,418-435)."""
+    with open(path, "rb") as f:
+        head = f.read(1024)
+        nx, ny, nz, mode = np.frombuffer(head, np.int32, 4)
+        nsymbt = int(np.frombuffer(head, np.int32, 1, 92)[0])
+        f.seek(1024 + nsymbt)
+        dt = {0: np.int8, 1: np.int16, 2: np.float32}[int(mode)]
+        raw = np.fromfile(f, dt, int(nx) * int(ny) * int(nz)).reshape(nz, ny, nx)
+    return raw.astype(np.float32), (int(nx), int(ny), int(nz), int(mode), nsymbt)
+
+
+def mrc_images(path):
+    """every slice read as an Image: dst(i, j) = file[(j + nRow/2) % nRow][(i + nCol/2) % nCol]"""
+    raw, _ = mrc_read(path)
+    return np.ascontiguousarray(np.roll(raw, (-(raw.shape[1] // 2), -(raw.shape[2] // 2)), axis=(1, 2)))
+
+
+def mrc_volume(path):
+    raw, _ = mrc_read(path)
+    return np.ascontiguousarray(np.roll(raw, tuple(-(s // 2) for s in raw.shape), axis=(0, 1, 2)))
+
+
+def init_images(rl, r, ew=6.0):
+    """Optimiser::initImg after reading (src/Optimiser.cpp:4700-4800) for one rank holding all N images:
+    substractBgImg -> statImg -> maskImg (zeroMask) -> normaliseImg -> fwImg.  rl float32 [n][N][N] wrapped layout.
+    Returns imgFT, imgOriFT (complex64 [n][N][N/2+1]) and dict(mean, stdN, stdD, stdS, stdStdN)."""
+    lib().orc_stddev.restype = C.c_float
+    rl = f32(rl).copy()
+    n, N = rl.shape[0], rl.shape[1]
+    st = np.zeros((n, 4), np.float64)
+    for l in range(n):
+        lib().orc_subtract_bg(_p(rl[l], c_f), C.c_int(N), C.c_float(r))
+        lib().orc_stat_img(_p(st[l], c_d), _p(rl[l], c_f), C.c_int(N), C.c_float(r))
+    # RFLOAT accumulators of the OpenMP reduction (:4815-4821), then /N (:4902-4912)
+    acc = [np.float32(0)] * 4
+    for l in range(n):
+        for q in range(4):
+            acc[q] = np.float32(acc[q] + np.float32(st[l, q]))
+    mean, stdN, stdD, stdStdN = [np.float32(a / np.float32(n)) for a in acc]
+    stdS = np.float32(stdD - stdN)
+    stdStdN = np.float32(np.sqrt(np.float64(stdStdN) - np.float64(np.float32(np.float64(stdN) ** 2))))
+    ori = rl.copy()
+    msk = np.empty_like(rl)
+    for l in range(n):
+        lib().orc_soft_mask_bg(_p(msk[l], c_f), _p(rl[l], c_f), C.c_int(N), C.c_float(r), C.c_float(ew), C.c_float(0))
+    scale = np.float32(1.0 / np.float64(stdN))
+    msk *= scale
+    ori *= scale
+    return (sfft.rfft2(msk).astype(np.complex64), sfft.rfft2(ori).astype(np.complex64),
+            dict(mean=float(mean), stdN=float(stdN), stdD=float(stdD), stdS=float(stdS), stdStdN=float(stdStdN)))

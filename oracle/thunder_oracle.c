@@ -1093,3 +1093,110 @@ void orc_ctf_image(RFLOAT* dst, int N, RFLOAT pixelSize, RFLOAT voltage, RFLOAT 
     }
     free(iCol); free(iRow); free(c);
 }
+
+/* ========================================================================================== */
+/* image ingestion (Optimiser::initImg, src/Optimiser.cpp:4608-4800)          */
+/* ========================================================================================== */
+
+/* gsl_stats_float_mean / gsl_stats_float_sd_m, external/packages/gsl-2.4/statistics/mean_source.c:21-36 and
+ * variance_source.c:29-45,95-102 (long double recurrences), through TSGSL_stats_mean / TSGSL_stats_sd_m
+ * (src/Precision.cpp:435-481) which narrow the result to RFLOAT. */
+static RFLOAT stats_mean_(const RFLOAT* d, size_t n)
+{
+    long double mean = 0;
+    for (size_t i = 0; i < n; i++) mean += (d[i] - mean) / (i + 1);
+    return (RFLOAT)(double)mean;
+}
+static RFLOAT stats_sd_m_(const RFLOAT* d, size_t n, RFLOAT meanf)
+{
+    const double mean = meanf;
+    long double variance = 0;
+    for (size_t i = 0; i < n; i++) {
+        const long double delta = (d[i] - mean);
+        variance += (delta * delta - variance) / (i + 1);
+    }
+    return (RFLOAT)sqrt((double)variance * ((double)n / (double)(n - 1)));
+}
+
+/* collects img.getRL(i, j) over IMAGE_FOR_EACH_PIXEL_RL (j outer, i inner, both from -N/2) where sel(i, j) holds */
+static size_t collect_(RFLOAT* out, const RFLOAT* img, int N, int outside, RFLOAT r)
+{
+    size_t m = 0;
+    for (long j = -N / 2; j < N / 2; j++)
+        for (long i = -N / 2; i < N / 2; i++) {
+            double q = (double)i * i + (double)j * j;
+            int in = outside ? (q > pow2f_(r)) : 1;
+            if (in) out[m++] = img[(size_t)(j >= 0 ? j : j + N) * N + (size_t)(i >= 0 ? i : i + N)];
+        }
+    return m;
+}
+
+/* bgMeanStddev(mean, stddev, const Image&, r), src/Image/ImageFunctions.cpp:607-621 */
+void orc_bg_mean_stddev(RFLOAT* mean, RFLOAT* sd, const RFLOAT* img, int N, RFLOAT r)
+{
+    RFLOAT* bg = (RFLOAT*)malloc((size_t)N * N * sizeof(RFLOAT));
+    size_t m = collect_(bg, img, N, 1, r);
+    *mean = stats_mean_(bg, m);
+    *sd = stats_sd_m_(bg, m, *mean);
+    free(bg);
+}
+
+/* bgStddev(mean, const Image&, r) :585-596 and stddev(mean, const Image&) :543-547 */
+RFLOAT orc_bg_stddev(RFLOAT mean, const RFLOAT* img, int N, RFLOAT r)
+{
+    RFLOAT* bg = (RFLOAT*)malloc((size_t)N * N * sizeof(RFLOAT));
+    size_t m = collect_(bg, img, N, 1, r);
+    RFLOAT s = stats_sd_m_(bg, m, mean);
+    free(bg);
+    return s;
+}
+RFLOAT orc_stddev(RFLOAT mean, const RFLOAT* img, int N) { return stats_sd_m_(img, (size_t)N * N, mean); }
+
+/* regionMean(const Image&, rU, rL, nThread), src/Functions/Mask.cpp:102-127 (serial order) */
+RFLOAT orc_region_mean(const RFLOAT* img, int N, RFLOAT rU, RFLOAT rL)
+{
+    RFLOAT weightSum = 0, sum = 0;
+    for (long j = -N / 2; j < N / 2; j++)
+        for (long i = -N / 2; i < N / 2; i++) {
+            RFLOAT u = (RFLOAT)gsl_hypot_((double)i, (double)j);
+            if ((u < rU) && (u >= rL)) {
+                weightSum += 1;
+                sum += img[(size_t)(j >= 0 ? j : j + N) * N + (size_t)(i >= 0 ? i : i + N)];
+            }
+        }
+    return sum / weightSum;
+}
+
+/* Optimiser::substractBgImg, src/Optimiser.cpp:4928-4962 (OPTIMISER_INIT_IMG_NORMALISE_OUT_MASK_REGION): in place */
+void orc_subtract_bg(RFLOAT* img, int N, RFLOAT r)
+{
+    RFLOAT m, s;
+    orc_bg_mean_stddev(&m, &s, img, N, r);
+    for (size_t i = 0; i < (size_t)N * N; i++) { img[i] -= m; img[i] /= s; }
+}
+
+/* per-image terms of Optimiser::statImg, src/Optimiser.cpp:4810-4875: out = {regionMean(img, r, 0), bgStddev(0, img, r),
+ * stddev(0, img), bgStddev(0, img, r)^2 (gsl_pow_2 in double)} as doubles */
+void orc_stat_img(double* out, const RFLOAT* img, int N, RFLOAT r)
+{
+    out[0] = orc_region_mean(img, N, r, 0);
+    RFLOAT b = orc_bg_stddev(0, img, N, r);
+    out[1] = b;
+    out[2] = orc_stddev(0, img, N);
+    out[3] = (double)b * (double)b;
+}
+
+/* softMask(dst, src, r, ew, bg, nThread), src/Functions/Mask.cpp:363-385 (Optimiser::maskImg passes bg = 0) */
+void orc_soft_mask_bg(RFLOAT* dst, const RFLOAT* src, int N, RFLOAT r, RFLOAT ew, RFLOAT bg)
+{
+    for (long j = -N / 2; j < N / 2; j++)
+        for (long i = -N / 2; i < N / 2; i++) {
+            RFLOAT u = (RFLOAT)gsl_hypot_((double)i, (double)j);
+            size_t idx = (size_t)(j >= 0 ? j : j + N) * N + (size_t)(i >= 0 ? i : i + N);
+            if (u > r + ew) dst[idx] = bg;
+            else if (u >= r) {
+                RFLOAT w = (RFLOAT)(0.5 - 0.5 * cos((u - r) / ew * M_PI));
+                dst[idx] = bg * w + src[idx] * (1 - w);
+            } else dst[idx] = src[idx];
+        }
+}

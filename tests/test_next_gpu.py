@@ -220,3 +220,48 @@ def test_expect_global3d_host_entry(oracle, dev):
     for h, d in ((hC, dC), (hR, dR), (hT, dT), (hB, dB)):
         assert np.array_equal(h, d.cpu().numpy())
     assert np.all(np.isfinite(hB)) and np.all(hC > 0)
+
+
+@pytest.mark.parametrize("N,n", [(32, 9), (64, 1030)])
+def test_image_ingestion(oracle, dev, N, n, tmp_path):
+    """MRC stack -> HBM image stacks: thx_mrc_read_images + Optimiser::initImg's device stages vs the oracle"""
+    from thunder_amd import capi, ops
+    O = oracle
+    rng = np.random.default_rng(N)
+    jj, ii = np.meshgrid(np.arange(N) - N // 2, np.arange(N) - N // 2, indexing="ij")
+    blob = 8.0 * np.exp(-(ii * ii + jj * jj) / (2 * (0.12 * N) ** 2))
+    n_or = n if N == 32 else 12                        # the oracle's long-double loops are slow: check a subset at N = 64
+    data = (3.0 + blob[None] * rng.uniform(0.5, 1.5, (n, 1, 1)) + rng.standard_normal((n, N, N))).astype(np.float32)
+    path = str(tmp_path / "p.mrcs")
+    mem = np.ascontiguousarray(np.fft.ifftshift(data, axes=(1, 2)))     # in-memory (wrapped-origin) layout
+    capi.call("thx_mrc_write_stack", path.encode(), mem.ctypes.data, N, n, 1.32)
+    rl = np.zeros((n, N, N), np.float32)
+    capi.call("thx_mrc_read_images", path.encode(), 0, n, rl.ctypes.data)
+    assert np.array_equal(rl, O.mrc_images(path)) and np.array_equal(rl, mem)
+    r = 0.36 * N
+    imgFT, oriFT, st = ops.init_images(T(rl, dev), r)
+    if n_or == n:
+        wI, wO, wst = O.init_images(rl, r)
+        for k in wst:                                   # fp64 two-pass sums vs GSL's running long-double recurrences
+            assert abs(st[k] - wst[k]) <= 2e-5 * max(1.0, abs(wst[k])), (k, st[k], wst[k])
+        gI, gO = imgFT.cpu().numpy(), oriFT.cpu().numpy()
+    else:
+        # same global scale (from all n images) applied to the subset through the oracle's per-image functions
+        import ctypes as C
+        sub = rl[:n_or].copy()
+        for l in range(n_or):
+            O.lib().orc_subtract_bg(sub[l].ctypes.data_as(O.c_f), N, C.c_float(r))
+        msk = np.empty_like(sub)
+        for l in range(n_or):
+            O.lib().orc_soft_mask_bg(msk[l].ctypes.data_as(O.c_f), sub[l].ctypes.data_as(O.c_f), N, C.c_float(r),
+                                     C.c_float(6.0), C.c_float(0))
+        scale = np.float32(1.0 / np.float64(np.float32(st["stdN"])))
+        import scipy.fft as sfft
+        wI, wO = sfft.rfft2(msk * scale).astype(np.complex64), sfft.rfft2(sub * scale).astype(np.complex64)
+        gI, gO = imgFT[:n_or].cpu().numpy(), oriFT[:n_or].cpu().numpy()
+        assert abs(st["stdN"] - 1.0) < 0.02 and abs(st["mean"]) < 2.0
+    # single-precision statistics + one FFT on each side
+    for g, w in ((gI, wI), (gO, wO)):
+        scale_ = np.abs(w).reshape(len(w), -1).max(1)[:, None, None]
+        assert (np.abs(g - w) / scale_).max() <= 2e-5
+    assert np.isfinite(imgFT.abs().sum().item())

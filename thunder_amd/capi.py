@@ -74,6 +74,16 @@ SIGNATURES = {
                                    _vp]),
     "thx_sigma_accum_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "thx_sigma_final_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp]),
+    "thx_mrc_info": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "thx_mrc_read_images": (_i, [C.c_char_p, _i, _i, _vp]),
+    "thx_mrc_read_volume": (_i, [C.c_char_p, _vp]),
+    "thx_mrc_write_volume": (_i, [C.c_char_p, _vp, _i, _i, _i, _f]),
+    "thx_mrc_write_stack": (_i, [C.c_char_p, _vp, _i, _i, _f]),
+    "thx_thu_count": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i)]),
+    "thx_thu_load": (_i, [C.c_char_p, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "thx_img_subtract_bg_dev": (_i, [_vp, _i, _i, _f, _vp]),
+    "thx_img_stats_dev": (_i, [_vp, _vp, _i, _i, _f, _vp]),
+    "thx_img_mask_normalise_fft_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _vp]),
     "thx_ExpectProject_host": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "thx_ExpectRotran_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "thx_InsertFT_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i,

@@ -276,6 +276,34 @@ def sigma_final(acc, maskRadius, size, pixelSize, group=True):
     return sig, rcp
 
 
+# ---------------------------------------------------------------------------------------------
+# image ingestion
+def init_images(imgRL, maskRadiusPx, ew=6.0, reduce_stats=None):
+    """Optimiser::initImg after reading (src/Optimiser.cpp:4700-4800): substractBgImg -> statImg -> maskImg (zeroMask)
+    -> normaliseImg -> fwImg for a DEVICE stack imgRL float32 [n][N][N] (in-memory layout; modified in place).
+    reduce_stats(sums[4] float64 tensor, n) -> (sums, N) lets the caller all-reduce over the hemisphere.
+    Returns imgFT, imgOriFT (complex64 [n][N][N/2+1]) and the statistics dict."""
+    _chk(imgRL, _F32, "imgRL")
+    n, N, dev = imgRL.shape[0], imgRL.shape[1], imgRL.device
+    capi.call("thx_img_subtract_bg_dev", ptr(imgRL), n, N, float(maskRadiusPx), stream_ptr())
+    stat = torch.empty((n, 4), dtype=_F64, device=dev)
+    capi.call("thx_img_stats_dev", ptr(stat), ptr(imgRL), n, N, float(maskRadiusPx), stream_ptr())
+    sums, cnt = stat.sum(0), n
+    if reduce_stats is not None:
+        sums, cnt = reduce_stats(sums, n)
+    mean, stdN, stdD, q = [np.float32(x / cnt) for x in sums.cpu().numpy()]
+    stdS = np.float32(stdD - stdN)
+    stdStdN = np.float32(np.sqrt(max(0.0, float(q) - float(np.float32(float(stdN) ** 2)))))
+    scale = np.float32(1.0 / np.float64(stdN))
+    imgFT = torch.empty((n, N, N // 2 + 1), dtype=_C64, device=dev)
+    oriFT = torch.empty_like(imgFT)
+    scratch = torch.empty((min(n, 1024), N, N), dtype=_F32, device=dev)
+    capi.call("thx_img_mask_normalise_fft_dev", ptr(imgFT), ptr(oriFT), ptr(imgRL), ptr(scratch), n, N,
+              float(maskRadiusPx), float(ew), float(scale), stream_ptr())
+    return imgFT, oriFT, dict(mean=float(mean), stdN=float(stdN), stdD=float(stdD), stdS=float(stdS),
+                              stdStdN=float(stdStdN))
+
+
 class RecoPlan:
     """thx_reco handle: Reconstructor::allocSpace state (FFT plans, W, C, kernel table)."""
 
