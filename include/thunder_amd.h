@@ -307,6 +307,33 @@ int thx_img_stats_dev(double* stat, const float* imgRL, int nImg, int idim, floa
 int thx_img_mask_normalise_fft_dev(float* imgFT, float* imgOriFT, float* imgRL, float* scratchRL, int nImg, int idim,
                                    float maskRadiusPx, float ew, float scale, void* stream);
 
+/* The particle filter of the local search (src/Particle.cpp, src/Geometry/DirectionalStat.cpp), MODE_3D, one wave per
+ * image.  State, all DEVICE doubles owned by the caller: r [nImg][nR][4] quaternions, t [nImg][nT][2] shifts (pixels),
+ * wR [nImg][nR] / wT [nImg][nT] priors (Particle::_wR/_wT: the pR / pT of thx_expect_local_dev), k123 [nImg][3]
+ * (Particle::_k1.._k3), s01 [nImg][2] (_s0, _s1), topR [nImg][4], topT [nImg][2].  nR, nT <= 256.
+ * Randomness: Philox4x32-10 keyed by (seed, image, call, purpose, index); give every call of one run a distinct `call`.
+ *
+ * thx_pf_perturb_dev = Particle::perturb(pfR, PAR_R) + perturb(pfT, PAR_T), src/Particle.cpp:1149-1272: ACG
+ *   perturbation of the rotations (sampleACG with pf^2 min(1, k), DirectionalStat.cpp:39-91), Gaussian perturbation of
+ *   the shifts, reCentre (:2473-2495, transM = transS chi2inv_Q(transQ, 2)), balanceWeight for both (:2309-2376). */
+int thx_pf_perturb_dev(double* r, double* t, double* wR, double* wT, const double* k123, const double* s01, int nImg,
+                       int nR, int nT, double pfR, double pfT, double transS, double transQ, unsigned long long seed,
+                       unsigned call, void* stream);
+
+/* thx_pf_update_dev = what follows the likelihood of a phase, src/Optimiser.cpp:1410-1475: setUR/setUT from the E-step's
+ *   wR / wT (uR, uT: DEVICE floats), keepHalfHeightPeak(PAR_R) (peakFactorR < 0 disables it), calRank1st, calVari (ACG
+ *   k1..k3 in the mean frame; per-column sd of the shifts), shuffle + systematic resample with PARTICLE_PRIOR_ONE
+ *   (src/Particle.cpp:990-1143,1291-1480,1964-1990,2202-2300). */
+int thx_pf_update_dev(double* r, double* t, double* wR, double* wT, const float* uR, const float* uT, double* k123,
+                      double* s01, double* topR, double* topT, int nImg, int nR, int nT, double peakFactorR,
+                      unsigned long long seed, unsigned call, void* stream);
+
+/* The deterministic ACG statistics on their own (parity probe): for quat [nImg][n][4] -> A [nImg][16] (inferACG,
+ * DirectionalStat.cpp:93-145), mean [nImg][4] (:224-262), k123 [nImg][3] (calVari's mean-frame ratios), wBal [nImg][n]
+ * (balanceWeight(PAR_R)), rounds [nImg][2] fixed-point rounds of the two inferACG calls (may be NULL). */
+int thx_pf_acg_stats_dev(double* A, double* mean, double* k123, double* wBal, int* rounds, const double* quat, int nImg,
+                         int n, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Interface.h-shaped HOST-pointer entry points (what -DGPU_VERSION call sites bind to)
  * ------------------------------------------------------------------------------------------- */

@@ -1200,3 +1200,227 @@ void orc_soft_mask_bg(RFLOAT* dst, const RFLOAT* src, int N, RFLOAT r, RFLOAT ew
             } else dst[idx] = src[idx];
         }
 }
+
+/* ========================================================================================== */
+/* the particle filter's deterministic arithmetic (src/Particle.cpp,           */
+/* src/Geometry/DirectionalStat.cpp); random draws (perturbation, shuffle, u0) are inputs here. */
+/* ========================================================================================== */
+
+/* 4x4 inverse by cofactors (Eigen's fixed-size dmat44::inverse() is the same closed form) */
+static void inv4_(double* o, const double* m)
+{
+    double inv[16];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    for (int i = 0; i < 16; i++) o[i] = inv[i] / det;
+}
+static double det4_(const double* m)
+{
+    double c0 = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    double c1 = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    double c2 = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    double c3 = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    return m[0] * c0 + m[1] * c1 + m[2] * c2 + m[3] * c3;
+}
+static double quad4_(const double* x, const double* M)
+{
+    double s = 0;
+    for (int j = 0; j < 4; j++) {
+        double t = 0;
+        for (int k = 0; k < 4; k++) t += M[j * 4 + k] * x[k];
+        s += x[j] * t;
+    }
+    return s;
+}
+
+/* inferACG(dmat44& dst, const dmat4& src), src/Geometry/DirectionalStat.cpp:93-145; A row-major [4][4]; returns the
+ * number of fixed-point rounds */
+int orc_infer_acg(double* A, const double* q, int n)
+{
+    double B[16], Ainv[16];
+    for (int i = 0; i < 16; i++) B[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    int rounds = 0;
+    double diff;
+    do {
+        memcpy(A, B, sizeof(B));
+        memset(B, 0, sizeof(B));
+        double nf = 0;
+        inv4_(Ainv, A);
+        for (int i = 0; i < n; i++) {
+            const double* x = q + 4 * (size_t)i;
+            double u = quad4_(x, Ainv);
+            for (int j = 0; j < 4; j++)
+                for (int k = 0; k < 4; k++) B[j * 4 + k] += (x[j] * x[k]) / u;
+            nf += 1.0 / u;
+        }
+        for (int i = 0; i < 16; i++) B[i] *= 4.0 / nf;
+        diff = 0;
+        for (int i = 0; i < 16; i++) diff += fabs(A[i] - B[i]);
+        rounds++;
+    } while (diff > 1e-3 && rounds < 100000);
+    return rounds;
+}
+
+/* pdfACG(x, sig), :19-24 */
+double orc_pdf_acg(const double* x, const double* sig)
+{
+    double inv[16];
+    inv4_(inv, sig);
+    return pow(det4_(sig), -0.5) * pow(quad4_(x, inv), -2);
+}
+
+/* eigenvector of the largest eigenvalue of a symmetric 4x4 (inferACG(dvec4& mean, ...), :224-262 uses Eigen's
+ * SelfAdjointEigenSolver; cyclic Jacobi here -- same vector up to sign and rounding) */
+void orc_sym4_top_eigvec(double* v, const double* Ain)
+{
+    double A[16], V[16];
+    memcpy(A, Ain, sizeof(A));
+    for (int i = 0; i < 16; i++) V[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; sweep++) {
+        double off = 0;
+        for (int p = 0; p < 4; p++) for (int r = p + 1; r < 4; r++) off += A[p * 4 + r] * A[p * 4 + r];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 4; p++)
+            for (int r = p + 1; r < 4; r++) {
+                if (fabs(A[p * 4 + r]) < 1e-300) continue;
+                double theta = (A[r * 4 + r] - A[p * 4 + p]) / (2 * A[p * 4 + r]);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                double c = 1 / sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < 4; k++) {
+                    double akp = A[k * 4 + p], akr = A[k * 4 + r];
+                    A[k * 4 + p] = c * akp - s * akr; A[k * 4 + r] = s * akp + c * akr;
+                }
+                for (int k = 0; k < 4; k++) {
+                    double apk = A[p * 4 + k], ark = A[r * 4 + k];
+                    A[p * 4 + k] = c * apk - s * ark; A[r * 4 + k] = s * apk + c * ark;
+                }
+                for (int k = 0; k < 4; k++) {
+                    double vkp = V[k * 4 + p], vkr = V[k * 4 + r];
+                    V[k * 4 + p] = c * vkp - s * vkr; V[k * 4 + r] = s * vkp + c * vkr;
+                }
+            }
+    }
+    int im = 0;
+    for (int i = 1; i < 4; i++) if (A[i * 4 + i] > A[im * 4 + im]) im = i;
+    double nrm = 0;
+    for (int k = 0; k < 4; k++) nrm += V[k * 4 + im] * V[k * 4 + im];
+    nrm = sqrt(nrm);
+    for (int k = 0; k < 4; k++) v[k] = V[k * 4 + im] / nrm;
+}
+
+/* quaternion_mul(dst, a, b) and quaternion_conj, src/Geometry/Euler.cpp (Hamilton product) */
+static void qmul_(double* d, const double* a, const double* b)
+{
+    double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+    d[0] = w; d[1] = x; d[2] = y; d[3] = z;
+}
+
+/* Particle::calVari(PAR_R), MODE_3D with PARTICLE_ROT_MEAN_USING_STAT_CAL_VARI, src/Particle.cpp:1020-1080:
+ * k[3] = (k1, k2, k3); q [n][4] is rotated to the mean frame and back (in place, as the reference does) */
+void orc_cal_vari_R(double* k, double* mean, double* q, int n)
+{
+    double A[16], cm[4];
+    orc_infer_acg(A, q, n);
+    orc_sym4_top_eigvec(mean, A);
+    cm[0] = mean[0]; cm[1] = -mean[1]; cm[2] = -mean[2]; cm[3] = -mean[3];
+    for (int i = 0; i < n; i++) { double t[4]; qmul_(t, q + 4 * i, cm); memcpy(q + 4 * i, t, sizeof(t)); }
+    orc_infer_acg(A, q, n);
+    k[0] = A[5] / A[0]; k[1] = A[10] / A[0]; k[2] = A[15] / A[0];
+    for (int i = 0; i < n; i++) { double t[4]; qmul_(t, q + 4 * i, mean); memcpy(q + 4 * i, t, sizeof(t)); }
+}
+
+/* gsl_stats_mean / gsl_stats_sd_m on doubles (statistics/mean_source.c, variance_source.c) */
+static double dmean_(const double* d, size_t stride, size_t n)
+{
+    long double mean = 0;
+    for (size_t i = 0; i < n; i++) mean += (d[i * stride] - mean) / (i + 1);
+    return (double)mean;
+}
+static double dsd_m_(const double* d, size_t stride, size_t n, double mean)
+{
+    long double variance = 0;
+    for (size_t i = 0; i < n; i++) {
+        const long double delta = (d[i * stride] - mean);
+        variance += (delta * delta - variance) / (i + 1);
+    }
+    return sqrt((double)variance * ((double)n / (double)(n - 1)));
+}
+
+/* Particle::calVari(PAR_T), :1096-1112 (gsl_stats_sd per column; PARTICLE_RHO off) */
+void orc_cal_vari_T(double* s, const double* t, int n)
+{
+    s[0] = dsd_m_(t, 2, n, dmean_(t, 2, n));
+    s[1] = dsd_m_(t + 1, 2, n, dmean_(t + 1, 2, n));
+}
+
+/* Particle::balanceWeight(PAR_R) MODE_3D, :2333-2343 + normW: w_i = 1 / pdfACG(r_i, inferACG(r)), normalised */
+void orc_balance_weight_R(double* w, const double* q, int n)
+{
+    double A[16], sum = 0;
+    orc_infer_acg(A, q, n);
+    for (int i = 0; i < n; i++) { w[i] = 1.0 / orc_pdf_acg(q + 4 * i, A); sum += w[i]; }
+    for (int i = 0; i < n; i++) w[i] /= sum;
+}
+
+/* Particle::balanceWeight(PAR_T), :2345-2376 + normW; gsl_ran_bivariate_gaussian_pdf (randist/bigauss.c) with rho = 0 */
+void orc_balance_weight_T(double* w, const double* t, int n)
+{
+    double m0 = dmean_(t, 2, n), m1 = dmean_(t + 1, 2, n);
+    double s0 = dsd_m_(t, 2, n, m0), s1 = dsd_m_(t + 1, 2, n, m1), rho = 0, sum = 0;
+    for (int i = 0; i < n; i++) {
+        double u = (t[2 * i] - m0) / s0, v = (t[2 * i + 1] - m1) / s1, c = 1 - rho * rho;
+        double p = (1 / (2 * M_PI * s0 * s1 * sqrt(c))) * exp(-(u * u - 2 * rho * u * v + v * v) / (2 * c));
+        w[i] = 1.0 / p;
+        sum += w[i];
+    }
+    for (int i = 0; i < n; i++) w[i] /= sum;
+}
+
+/* Particle::keepHalfHeightPeak, :1964-2011 */
+void orc_keep_half_height_peak(double* u, int n, double peakFactor)
+{
+    int im = 0;
+    for (int i = 1; i < n; i++) if (u[i] > u[im]) im = i;
+    double hh = u[im] * peakFactor;
+    for (int i = 0; i < n; i++) { if (u[i] < hh) u[i] = 0; else u[i] -= hh; }
+}
+
+/* the systematic resampling of Particle::resample(n, pt), :1333-1372 (PARTICLE_PRIOR_ONE), AFTER the shuffle: inputs
+ * are the shuffled w, u and the draw u0 in [0, 1/nOut); idx[j] = source index, wOut normalised (normW) */
+void orc_resample(int* idx, double* wOut, const double* w, const double* u, int nIn, int nOut, double u0)
+{
+    double* cdf = (double*)malloc(nIn * sizeof(double));
+    double sum = 0, acc = 0;
+    for (int i = 0; i < nIn; i++) sum += w[i] * u[i];
+    for (int i = 0; i < nIn; i++) { acc += (w[i] * u[i]) / sum; cdf[i] = acc; }
+    for (int i = 0; i < nIn; i++) cdf[i] /= cdf[nIn - 1];
+    int i = 0;
+    double ws = 0;
+    for (int j = 0; j < nOut; j++) {
+        double uj = u0 + j * 1.0 / nOut;
+        while (uj > cdf[i]) i++;
+        idx[j] = i;
+        wOut[j] = 1.0 / u[i];
+        ws += wOut[j];
+    }
+    for (int j = 0; j < nOut; j++) wOut[j] /= ws;
+    free(cdf);
+}

@@ -1,0 +1,110 @@
+"""CPU checks of the particle-filter restatements in the oracle (src/Particle.cpp, src/Geometry/DirectionalStat.cpp) and of
+the Philox replica the GPU tests replay the device's draws with."""
+import ctypes as C
+
+import numpy as np
+
+import _philox as PH
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def test_philox_known_answers():
+    """Random123 known-answer vectors for philox4x32-10 (kat_vectors: zero, all-ones and pi-digits inputs)"""
+    z = PH.philox(0, 0, 0, 0, 0)
+    assert [int(x) for x in z] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    f = 0xFFFFFFFF
+    o = PH.philox((f << 32) | f, f, f, f, f)
+    assert [int(x) for x in o] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    p = PH.philox((0x299f31d0 << 32) | 0xa4093822, 0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344)
+    assert [int(x) for x in p] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    u = PH.draw_u4(123, np.arange(1000), 0, 0, 0)
+    assert all(0 < x.min() and x.max() < 1 for x in u) and abs(np.mean(u[0]) - 0.5) < 0.05
+    n = np.concatenate(PH.draw_n4(7, np.arange(5000), 1, 2, 3))
+    assert abs(n.mean()) < 0.03 and abs(n.std() - 1) < 0.03
+    r = PH.shuffle_ranks(9, 4, 2, 2, 125)
+    assert sorted(r.tolist()) == list(range(125))
+
+
+def test_infer_acg_fixed_point_and_moments(oracle):
+    O = oracle
+    O.lib().orc_infer_acg.restype = C.c_int
+    O.lib().orc_pdf_acg.restype = C.c_double
+    rng = np.random.default_rng(2)
+    n = 4000
+    sig = np.diag([1.0, 0.02, 0.008, 0.002])
+    x = rng.multivariate_normal(np.zeros(4), sig, n)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    A = np.zeros(16)
+    rounds = O.lib().orc_infer_acg(_dp(A), _dp(np.ascontiguousarray(x)), n)
+    A = A.reshape(4, 4)
+    assert rounds > 2 and np.allclose(A, A.T, atol=1e-12)
+    # Tyler's fixed point: A ~ 4 sum(x x^T / u) / sum(1 / u), u = x^T A^-1 x (one more round moves it by < 1e-3)
+    u = np.einsum("ni,ij,nj->n", x, np.linalg.inv(A), x)
+    B = 4 * (x[:, :, None] * x[:, None, :] / u[:, None, None]).sum(0) / (1 / u).sum()
+    assert np.abs(A - B).sum() <= 1e-3
+    # shape recovered up to scale
+    assert np.allclose(np.diag(A)[1:] / A[0, 0], np.diag(sig)[1:], rtol=0.15)
+    v = np.zeros(4)
+    O.lib().orc_sym4_top_eigvec(_dp(v), _dp(np.ascontiguousarray(A)))
+    w, V = np.linalg.eigh(A)
+    assert min(np.abs(v - V[:, -1]).max(), np.abs(v + V[:, -1]).max()) < 1e-9
+    p = O.lib().orc_pdf_acg(_dp(np.ascontiguousarray(x[0])), _dp(np.ascontiguousarray(A)))
+    assert np.isclose(p, np.linalg.det(A) ** -0.5 * (x[0] @ np.linalg.inv(A) @ x[0]) ** -2, rtol=1e-10)
+
+
+def test_cal_vari_and_weights(oracle):
+    O = oracle
+    from thunder_amd import synth
+    rng = np.random.default_rng(3)
+    n = 125
+    mean = synth.random_quats(1, rng)[0]
+    d = rng.standard_normal((n, 4)) * np.array([1, 0.05, 0.03, 0.01])
+    d[:, 0] = 1
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    q = np.ascontiguousarray(synth.quat_mul(d, mean[None, :]))
+    q0 = q.copy()
+    k, m = np.zeros(3), np.zeros(4)
+    O.lib().orc_cal_vari_R(_dp(k), _dp(m), _dp(q), n)
+    assert np.abs(q - q0).max() < 1e-14                        # rotated to the mean frame and back
+    assert min(np.abs(m - mean).max(), np.abs(m + mean).max()) < 0.02
+    # (the cloud is Gaussian in the tangent plane, not ACG: Tyler's estimator sees ~0.5-0.7 of sigma^2)
+    assert np.all(k < [0.05 ** 2, 0.03 ** 2, 0.01 ** 2]) and np.all(k > 0.3 * np.array([0.05 ** 2, 0.03 ** 2, 0.01 ** 2]))
+    assert k[0] > k[1] > k[2]
+    t = rng.normal(0, [1.5, 0.7], size=(9, 2))
+    s = np.zeros(2)
+    O.lib().orc_cal_vari_T(_dp(s), _dp(np.ascontiguousarray(t)), 9)
+    assert np.allclose(s, t.std(0, ddof=1), rtol=1e-12)
+    w = np.zeros(9)
+    O.lib().orc_balance_weight_T(_dp(w), _dp(np.ascontiguousarray(t)), 9)
+    z = (t - t.mean(0)) / t.std(0, ddof=1)
+    want = np.exp((z ** 2).sum(1) / 2)
+    assert np.allclose(w, want / want.sum(), rtol=1e-10)
+    wr = np.zeros(n)
+    O.lib().orc_balance_weight_R(_dp(wr), _dp(q0), n)
+    assert abs(wr.sum() - 1) < 1e-12 and np.all(wr > 0)
+    # points far from the mode get the larger weight (1 / pdf)
+    dist = 1 - np.abs(q0 @ m)
+    assert np.corrcoef(dist, wr)[0, 1] > 0.5
+
+
+def test_resample_and_peak(oracle):
+    O = oracle
+    rng = np.random.default_rng(4)
+    n = 50
+    u = rng.uniform(0, 1, n) ** 4
+    u2 = u.copy()
+    O.lib().orc_keep_half_height_peak(_dp(u2), n, C.c_double(0.2))
+    hh = 0.2 * u.max()
+    assert np.allclose(u2, np.where(u < hh, 0, u - hh))
+    w = np.full(n, 1.0 / n)
+    idx = np.zeros(n, np.int32)
+    wo = np.zeros(n)
+    O.lib().orc_resample(idx.ctypes.data_as(C.POINTER(C.c_int)), _dp(wo), _dp(w), _dp(u2), n, n, C.c_double(0.5 / n))
+    assert np.all(np.diff(idx) >= 0) and np.all(u2[idx] > 0)
+    cnt = np.bincount(idx, minlength=n)
+    expect = n * u2 / u2.sum()
+    assert np.all(np.abs(cnt - expect) <= 1.0 + 1e-9)          # systematic resampling: counts within 1 of n * p
+    assert np.allclose(wo, (1 / u2[idx]) / (1 / u2[idx]).sum())

@@ -1,0 +1,179 @@
+"""The device particle filter (thx_pf.hip) against the oracle's restatement of src/Particle.cpp /
+src/Geometry/DirectionalStat.cpp.  The device's Philox draws are replayed in numpy (tests/_philox.py), so the perturbation,
+shuffle and resampling are compared element by element; summation orders differ (wave tree vs serial): 1e-9 relative."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _philox as PH
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _cloud(rng, nImg, n, spread):
+    """n unit quaternions per image scattered around a random mean with anisotropic spread"""
+    from thunder_amd import synth
+    mean = synth.random_quats(nImg, rng)
+    d = rng.standard_normal((nImg, n, 4)) * np.array([1.0, spread, 0.6 * spread, 0.3 * spread])
+    d[..., 0] = 1.0
+    d /= np.linalg.norm(d, axis=2, keepdims=True)
+    q = synth.quat_mul(d, mean[:, None, :])
+    return q / np.linalg.norm(q, axis=2, keepdims=True)
+
+
+def _o(O, name, *args):
+    getattr(O.lib(), name)(*args)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def test_acg_statistics(oracle, dev):
+    from thunder_amd import capi
+    O = oracle
+    O.lib().orc_infer_acg.restype = C.c_int
+    rng = np.random.default_rng(21)
+    nImg, n = 12, 125
+    q = _cloud(rng, nImg, n, 0.05)
+    A = torch.empty((nImg, 16), dtype=torch.float64, device=dev)
+    mean = torch.empty((nImg, 4), dtype=torch.float64, device=dev)
+    k = torch.empty((nImg, 3), dtype=torch.float64, device=dev)
+    wb = torch.empty((nImg, n), dtype=torch.float64, device=dev)
+    rounds = torch.zeros((nImg, 2), dtype=torch.int32, device=dev)
+    dq = T(q, dev)
+    capi.call("thx_pf_acg_stats_dev", A.data_ptr(), mean.data_ptr(), k.data_ptr(), wb.data_ptr(), rounds.data_ptr(),
+              dq.data_ptr(), nImg, n, capi.stream_ptr())
+    A, mean, k, wb, rounds = [x.cpu().numpy() for x in (A, mean, k, wb, rounds)]
+    same = 0
+    for l in range(nImg):
+        Aw = np.zeros(16)
+        rw = O.lib().orc_infer_acg(_dp(Aw), _dp(np.ascontiguousarray(q[l])), n)
+        # the fixed point stops on sum|A - B| <= 1e-3: a rounding-level difference can move the stop by one round
+        tol = 1e-9 if rw == rounds[l, 0] else 2e-3
+        same += rw == rounds[l, 0]
+        assert np.abs(A[l] - Aw).sum() <= tol * max(1.0, np.abs(Aw).sum())
+        mw = np.zeros(4)
+        _o(O, "orc_sym4_top_eigvec", _dp(mw), _dp(Aw))
+        assert min(np.abs(mean[l] - mw).max(), np.abs(mean[l] + mw).max()) <= max(tol, 1e-9) * 10
+        kw, mw2, qq = np.zeros(3), np.zeros(4), np.ascontiguousarray(q[l].copy())
+        _o(O, "orc_cal_vari_R", _dp(kw), _dp(mw2), _dp(qq), n)
+        assert np.allclose(k[l], kw, rtol=1e-7 if (rw == rounds[l, 0]) else 5e-2)
+        ww = np.zeros(n)
+        _o(O, "orc_balance_weight_R", _dp(ww), _dp(np.ascontiguousarray(q[l])), n)
+        assert np.allclose(wb[l], ww, rtol=1e-7 if rw == rounds[l, 0] else 5e-2) and abs(wb[l].sum() - 1) < 1e-12
+    assert same >= nImg - 2
+    # the estimated concentration follows the spread of the cloud: k ~ spread^2 ordering k1 > k2 > k3
+    assert np.all(k[:, 0] > k[:, 1]) and np.all(k[:, 1] > k[:, 2]) and np.all(k > 0) and np.all(k < 0.05)
+
+
+def _state(rng, nImg, nR, nT):
+    q = _cloud(rng, nImg, nR, 0.03)
+    t = rng.normal(0, 1.2, size=(nImg, nT, 2))
+    wR = rng.uniform(0.5, 1.5, size=(nImg, nR)); wR /= wR.sum(1, keepdims=True)
+    wT = rng.uniform(0.5, 1.5, size=(nImg, nT)); wT /= wT.sum(1, keepdims=True)
+    k = rng.uniform(1e-4, 2e-3, size=(nImg, 3))
+    s = rng.uniform(0.5, 1.5, size=(nImg, 2))
+    return q, t, wR, wT, k, s
+
+
+def test_perturb(oracle, dev):
+    from thunder_amd import capi, synth
+    O = oracle
+    rng = np.random.default_rng(22)
+    nImg, nR, nT, seed, call = 7, 125, 9, 0x1234567890ABCDEF, 5
+    q, t, wR, wT, k, s = _state(rng, nImg, nR, nT)
+    k[0] = (3.0, 0.5, 2.0)                               # exercises min(PERTURB_K_MAX = 1, k)
+    pfR, pfT, transS, transQ = 2.0, 0.5, 2.0, 0.05
+    dq, dt, dwR, dwT, dk, ds = T(q, dev), T(t, dev), T(wR, dev), T(wT, dev), T(k, dev), T(s, dev)
+    capi.call("thx_pf_perturb_dev", dq.data_ptr(), dt.data_ptr(), dwR.data_ptr(), dwT.data_ptr(), dk.data_ptr(),
+              ds.data_ptr(), nImg, nR, nT, pfR, pfT, transS, transQ, seed, call, capi.stream_ptr())
+    gq, gt, gwR, gwT = [x.cpu().numpy() for x in (dq, dt, dwR, dwT)]
+    img = np.arange(nImg)[:, None]
+    g = PH.draw_n4(seed, img, call, 0, np.arange(nR)[None, :])
+    L = np.sqrt(pfR ** 2 * np.minimum(1.0, k))            # [nImg][3]
+    v = np.stack([g[0], L[:, 0:1] * g[1], L[:, 1:2] * g[2], L[:, 2:3] * g[3]], axis=2)
+    v /= np.linalg.norm(v, axis=2, keepdims=True)
+    want_q = synth.quat_mul(v, q)                         # pert * r
+    assert np.abs(gq - want_q).max() <= 1e-12 and np.abs(np.linalg.norm(gq, axis=2) - 1).max() < 1e-12
+    g = PH.draw_n4(seed, img, call, 1, np.arange(nT)[None, :])
+    want_t = t + np.stack([s[:, 0:1] * g[0], s[:, 1:2] * g[1]], axis=2) * pfT
+    transM = transS * (-2.0 * np.log(transQ))
+    far = np.hypot(want_t[..., 0], want_t[..., 1]) > transM
+    want_t[far] = np.stack([transS * g[2], transS * g[3]], axis=2)[far]
+    assert np.abs(gt - want_t).max() <= 1e-12
+    for l in range(nImg):
+        ww = np.zeros(nR)
+        O.lib().orc_balance_weight_R(_dp(ww), _dp(np.ascontiguousarray(gq[l])), nR)
+        assert np.allclose(gwR[l], ww, rtol=5e-2) and abs(gwR[l].sum() - 1) < 1e-12
+        wt = np.zeros(nT)
+        O.lib().orc_balance_weight_T(_dp(wt), _dp(np.ascontiguousarray(gt[l])), nT)
+        assert np.allclose(gwT[l], wt, rtol=1e-9)
+    # the angular size of the perturbation follows pf * sqrt(min(1, k)): the vector part is L g_c / |g_0| (a scaled Cauchy
+    # ratio for small L), whose median magnitude is L
+    rel = synth.quat_mul(gq, q * np.array([1, -1, -1, -1.0]))
+    for c in range(3):
+        got = np.median(np.abs(rel[1:, :, c + 1]), axis=1)
+        assert np.allclose(got, pfR * np.sqrt(k[1:, c]), rtol=0.4)
+
+
+def test_update_resample(oracle, dev):
+    from thunder_amd import capi
+    O = oracle
+    rng = np.random.default_rng(23)
+    nImg, nR, nT, seed, call, peak = 6, 125, 9, 987654321, 11, 1e-3
+    q, t, wR, wT, k, s = _state(rng, nImg, nR, nT)
+    uR = (rng.uniform(0, 1, (nImg, nR)) ** 8).astype(np.float32)      # peaked likelihood weights
+    uT = rng.uniform(0.05, 1, (nImg, nT)).astype(np.float32)
+    dq, dt, dwR, dwT, dk, ds = [T(x, dev) for x in (q, t, wR, wT, k, s)]
+    topR = torch.zeros((nImg, 4), dtype=torch.float64, device=dev)
+    topT = torch.zeros((nImg, 2), dtype=torch.float64, device=dev)
+    duR, duT = T(uR, dev), T(uT, dev)
+    capi.call("thx_pf_update_dev", dq.data_ptr(), dt.data_ptr(), dwR.data_ptr(), dwT.data_ptr(), duR.data_ptr(),
+              duT.data_ptr(), dk.data_ptr(), ds.data_ptr(), topR.data_ptr(), topT.data_ptr(), nImg, nR, nT, peak,
+              seed, call, capi.stream_ptr())
+    gq, gt, gwR, gwT, gk, gs, gtopR, gtopT = [x.cpu().numpy() for x in (dq, dt, dwR, dwT, dk, ds, topR, topT)]
+    for l in range(nImg):
+        # rank-1st, variances
+        assert np.array_equal(gtopR[l], q[l, uR[l].argmax()]) and np.array_equal(gtopT[l], t[l, uT[l].argmax()])
+        kw, mw, qq = np.zeros(3), np.zeros(4), np.ascontiguousarray(q[l].copy())
+        O.lib().orc_cal_vari_R(_dp(kw), _dp(mw), _dp(qq), nR)
+        assert np.allclose(gk[l], kw, rtol=5e-2)
+        sw = np.zeros(2)
+        O.lib().orc_cal_vari_T(_dp(sw), _dp(np.ascontiguousarray(t[l])), nT)
+        assert np.allclose(gs[l], sw, rtol=1e-12)
+        # rotations: keepHalfHeightPeak, shuffle (replayed), systematic resampling with the replayed u0
+        u = uR[l].astype(np.float64)
+        O.lib().orc_keep_half_height_peak(_dp(u), nR, C.c_double(peak))
+        rank = PH.shuffle_ranks(seed, l, call, 2, nR)
+        inv = np.empty(nR, np.int64); inv[rank] = np.arange(nR)       # shuffled[j] = original[inv[j]]
+        u0 = PH.draw_u4(seed, l, call, 3, 0)[0] / nR
+        idx = np.zeros(nR, np.int32); wo = np.zeros(nR)
+        O.lib().orc_resample(idx.ctypes.data_as(C.POINTER(C.c_int)), _dp(wo), _dp(np.ascontiguousarray(wR[l][inv])),
+                             _dp(np.ascontiguousarray(u[inv])), nR, nR, C.c_double(float(u0)))
+        src = inv[idx]
+        # (calVari's round trip through the mean frame perturbs the quaternions at 1e-16)
+        assert np.abs(gq[l] - q[l][src]).max() <= 1e-13
+        assert np.allclose(gwR[l], wo, rtol=1e-10) and abs(gwR[l].sum() - 1) < 1e-12
+        assert np.all(u[src] > 0)                                     # nothing below the half-height cut survives
+        # shifts
+        rank = PH.shuffle_ranks(seed, l, call, 4, nT)
+        inv = np.empty(nT, np.int64); inv[rank] = np.arange(nT)
+        u0 = PH.draw_u4(seed, l, call, 5, 0)[0] / nT
+        idx = np.zeros(nT, np.int32); wo = np.zeros(nT)
+        uu = uT[l].astype(np.float64)
+        O.lib().orc_resample(idx.ctypes.data_as(C.POINTER(C.c_int)), _dp(wo), _dp(np.ascontiguousarray(wT[l][inv])),
+                             _dp(np.ascontiguousarray(uu[inv])), nT, nT, C.c_double(float(u0)))
+        assert np.array_equal(gt[l], t[l][inv[idx]]) and np.allclose(gwT[l], wo, rtol=1e-10)
+    # reproducible: same seed / call -> same result; another call id -> another shuffle
+    dq2, dt2, dwR2, dwT2, dk2, ds2 = [T(x, dev) for x in (q, t, wR, wT, k, s)]
+    capi.call("thx_pf_update_dev", dq2.data_ptr(), dt2.data_ptr(), dwR2.data_ptr(), dwT2.data_ptr(),
+              duR.data_ptr(), duT.data_ptr(), dk2.data_ptr(), ds2.data_ptr(), topR.data_ptr(),
+              topT.data_ptr(), nImg, nR, nT, peak, seed, call, capi.stream_ptr())
+    assert np.array_equal(dq2.cpu().numpy(), gq) and np.array_equal(dwT2.cpu().numpy(), gwT)

@@ -84,6 +84,10 @@ SIGNATURES = {
     "thx_img_subtract_bg_dev": (_i, [_vp, _i, _i, _f, _vp]),
     "thx_img_stats_dev": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "thx_img_mask_normalise_fft_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _vp]),
+    "thx_pf_perturb_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _d, _d, C.c_ulonglong, C.c_uint, _vp]),
+    "thx_pf_update_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, C.c_ulonglong,
+                               C.c_uint, _vp]),
+    "thx_pf_acg_stats_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "thx_ExpectProject_host": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "thx_ExpectRotran_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "thx_InsertFT_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i,

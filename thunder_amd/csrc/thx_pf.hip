@@ -1,0 +1,522 @@
+// thx_pf.hip -- the particle filter of the local search on the device:
+// Particle::perturb / balanceWeight / reCentre / keepHalfHeightPeak / calRank1st / calVari / shuffle / resample
+// (src/Particle.cpp:990-1480,1880-2012,2202-2420,2473-2495) and the angular-central-Gaussian statistics they rest on
+// (src/Geometry/DirectionalStat.cpp:19-262), MODE_3D, as include/Config.h configures them (PARTICLE_PRIOR_ONE,
+// PARTICLE_RECENTRE(_TRANSQ), PARTICLE_ROT_MEAN_USING_STAT_*, PARTICLE_BALANCE_WEIGHT_R/T, OPTIMISER_PEAK_FACTOR_R).
+//
+// One wave per image: the support sets are tiny (mLR = 125 rotations, mLT = 9 shifts), the work is thousands of images.
+// The reference draws from GSL's global mt19937 under OpenMP (unordered, so not reproducible run to run); here every
+// draw comes from a counter-based Philox4x32-10 stream keyed by (seed, image, call, purpose, index): reproducible and
+// independent of launch geometry.  Deterministic arithmetic is checked against the oracle, draws statistically.
+#include <math.h>
+
+#include "thx_common.h"
+
+namespace thx {
+
+constexpr int kPfMax = 256;  // support points per image and parameter (mLR, mLT <= 256)
+
+// ---- Philox4x32-10 (Salmon et al., SC'11) ----
+struct Philox {
+    unsigned k0, k1;
+    __device__ __forceinline__ void round(unsigned c[4], unsigned ka, unsigned kb) const
+    {
+        const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ ka, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ kb, n3 = (unsigned)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    }
+    __device__ __forceinline__ void operator()(unsigned c[4]) const
+    {
+        unsigned ka = k0, kb = k1;
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            round(c, ka, kb);
+            ka += 0x9E3779B9u;
+            kb += 0xBB67AE85u;
+        }
+    }
+};
+
+// four uniforms in (0, 1) / four standard normals for (image, call, purpose, index)
+__device__ __forceinline__ void draw_u4(double u[4], unsigned long long seed, unsigned img, unsigned call, unsigned purpose,
+                                        unsigned index)
+{
+    Philox g{(unsigned)seed, (unsigned)(seed >> 32)};
+    unsigned c[4] = {img, call, purpose, index};
+    g(c);
+#pragma unroll
+    for (int i = 0; i < 4; i++) u[i] = ((double)c[i] + 0.5) * (1.0 / 4294967296.0);
+}
+__device__ __forceinline__ void draw_n4(double n[4], unsigned long long seed, unsigned img, unsigned call, unsigned purpose,
+                                        unsigned index)
+{
+    double u[4];
+    draw_u4(u, seed, img, call, purpose, index);
+    const double r0 = sqrt(-2.0 * log(u[0])), r1 = sqrt(-2.0 * log(u[2]));
+    double s, c;
+    sincos(6.283185307179586476925 * u[1], &s, &c);
+    n[0] = r0 * c; n[1] = r0 * s;
+    sincos(6.283185307179586476925 * u[3], &s, &c);
+    n[2] = r1 * c; n[3] = r1 * s;
+}
+
+// ---- 4x4 helpers (double); matrices row-major ----
+__device__ void inv4(double* o, const double* m, double* detOut)
+{
+    double inv[16];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    const double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    for (int i = 0; i < 16; i++) o[i] = inv[i] / det;
+    if (detOut) *detOut = det;
+}
+__device__ __forceinline__ double quad4(const double* x, const double* M)
+{
+    double s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        double t = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) t += M[j * 4 + k] * x[k];
+        s += x[j] * t;
+    }
+    return s;
+}
+__device__ __forceinline__ void qmul(double* d, const double* a, const double* b)
+{   // quaternion_mul, src/Geometry/Euler.cpp:13-26
+    const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    const double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    const double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    const double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+    d[0] = w; d[1] = x; d[2] = y; d[3] = z;
+}
+
+// inferACG(dmat44&, const dmat4&), src/Geometry/DirectionalStat.cpp:93-145: fixed point B = 4 sum(x x^T / u) / sum(1 / u),
+// u = x^T A^-1 x, until sum|A - B| <= 1e-3; returns the LAST-BUT-ONE iterate A as the reference does.  Wave-cooperative:
+// lanes stride over the quaternions in LDS, 11 wave sums per round, every lane ends with the same A.
+__device__ void infer_acg(double* A, const double* q /*LDS [n][4]*/, int n, int lane, int* roundsOut)
+{
+    double B[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) B[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    int rounds = 0;
+    double diff;
+    do {
+#pragma unroll
+        for (int i = 0; i < 16; i++) A[i] = B[i];
+        double Ainv[16];
+        inv4(Ainv, A, nullptr);
+        double s[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, nf = 0;
+        for (int i = lane; i < n; i += 64) {
+            const double* x = q + 4 * i;
+            const double u = quad4(x, Ainv), ru = 1.0 / u;
+            int e = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int k = j; k < 4; k++) s[e++] += (x[j] * x[k]) / u;
+            nf += ru;
+        }
+#pragma unroll
+        for (int e = 0; e < 10; e++) s[e] = wave_sum(s[e]);
+        nf = wave_sum(nf);
+        int e = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = j; k < 4; k++) { B[j * 4 + k] = s[e] * (4.0 / nf); B[k * 4 + j] = B[j * 4 + k]; e++; }
+        diff = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) diff += fabs(A[i] - B[i]);
+        rounds++;
+    } while (diff > 1e-3 && rounds < 100000);
+    if (roundsOut) *roundsOut = rounds;
+}
+
+// eigenvector of the largest eigenvalue of a symmetric 4x4 (cyclic Jacobi), for inferACG(dvec4& mean, ...) :224-262
+__device__ void sym4_top_eigvec(double* v, const double* Ain)
+{
+    double A[16], V[16];
+    for (int i = 0; i < 16; i++) { A[i] = Ain[i]; V[i] = (i % 5 == 0) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 64; sweep++) {
+        double off = 0;
+        for (int p = 0; p < 4; p++) for (int r = p + 1; r < 4; r++) off += A[p * 4 + r] * A[p * 4 + r];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 4; p++)
+            for (int r = p + 1; r < 4; r++) {
+                if (fabs(A[p * 4 + r]) < 1e-300) continue;
+                const double theta = (A[r * 4 + r] - A[p * 4 + p]) / (2 * A[p * 4 + r]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < 4; k++) {
+                    const double akp = A[k * 4 + p], akr = A[k * 4 + r];
+                    A[k * 4 + p] = c * akp - s * akr; A[k * 4 + r] = s * akp + c * akr;
+                }
+                for (int k = 0; k < 4; k++) {
+                    const double apk = A[p * 4 + k], ark = A[r * 4 + k];
+                    A[p * 4 + k] = c * apk - s * ark; A[r * 4 + k] = s * apk + c * ark;
+                }
+                for (int k = 0; k < 4; k++) {
+                    const double vkp = V[k * 4 + p], vkr = V[k * 4 + r];
+                    V[k * 4 + p] = c * vkp - s * vkr; V[k * 4 + r] = s * vkp + c * vkr;
+                }
+            }
+    }
+    int im = 0;
+    for (int i = 1; i < 4; i++) if (A[i * 4 + i] > A[im * 4 + im]) im = i;
+    double nrm = 0;
+    for (int k = 0; k < 4; k++) nrm += V[k * 4 + im] * V[k * 4 + im];
+    nrm = sqrt(nrm);
+    for (int k = 0; k < 4; k++) v[k] = V[k * 4 + im] / nrm;
+}
+
+// balanceWeight(PAR_R) + normW (src/Particle.cpp:2333-2343,815-822): w_i = 1 / pdfACG(r_i, A) normalised
+__device__ void balance_weight_R(double* w /*LDS*/, const double* q /*LDS*/, int n, int lane)
+{
+    double A[16], Ainv[16], det;
+    infer_acg(A, q, n, lane, nullptr);
+    inv4(Ainv, A, &det);
+    const double pd = pow(det, -0.5);
+    double sum = 0;
+    for (int i = lane; i < n; i += 64) {
+        const double p = pd * pow(quad4(q + 4 * i, Ainv), -2.0);
+        w[i] = 1.0 / p;
+        sum += w[i];
+    }
+    sum = wave_sum(sum);
+    for (int i = lane; i < n; i += 64) w[i] /= sum;
+}
+
+// column mean / sd (gsl_stats_mean, gsl_stats_sd_m) as two-pass fp64 wave sums
+__device__ void col_mean_sd(double& m, double& sd, const double* t /*LDS [n][2]*/, int col, int n, int lane)
+{
+    double s = 0;
+    for (int i = lane; i < n; i += 64) s += t[2 * i + col];
+    m = wave_sum(s) / n;
+    double ss = 0;
+    for (int i = lane; i < n; i += 64) { const double d = t[2 * i + col] - m; ss += d * d; }
+    ss = wave_sum(ss);
+    sd = sqrt(ss / n * ((double)n / (double)(n - 1)));
+}
+
+// balanceWeight(PAR_T) + normW (:2345-2376): w_i = 1 / N2(t_i - m; s0, s1, rho = 0) normalised
+__device__ void balance_weight_T(double* w, const double* t, int n, int lane)
+{
+    double m0, m1, s0, s1;
+    col_mean_sd(m0, s0, t, 0, n, lane);
+    col_mean_sd(m1, s1, t, 1, n, lane);
+    double sum = 0;
+    for (int i = lane; i < n; i += 64) {
+        const double u = (t[2 * i] - m0) / s0, v = (t[2 * i + 1] - m1) / s1;
+        const double p = (1 / (2 * 3.14159265358979323846 * s0 * s1)) * exp(-(u * u + v * v) / 2);
+        w[i] = 1.0 / p;
+        sum += w[i];
+    }
+    sum = wave_sum(sum);
+    for (int i = lane; i < n; i += 64) w[i] /= sum;
+}
+
+// shuffle + systematic resampling of Particle::resample(n, pt) (:1340-1372 with PARTICLE_PRIOR_ONE): elements of width
+// W doubles in LDS `val`, weights w, likelihoods u; results written back in place (n points in, n points out).
+template <int W>
+__device__ void resample(double* val, double* w, double* u, double* tmpVal, double* tmpW, double* tmpU, double* cdf,
+                         unsigned* keys, int n, int lane, unsigned long long seed, unsigned img, unsigned call,
+                         unsigned purpose)
+{
+    // gsl_ran_shuffle: a uniformly random permutation -- rank of a random key per element (ties broken by index)
+    for (int i = lane; i < n; i += 64) {
+        Philox g{(unsigned)seed, (unsigned)(seed >> 32)};
+        unsigned c[4] = {img, call, purpose, (unsigned)i};
+        g(c);
+        keys[i] = c[0];
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < n; i += 64) {
+        const unsigned ki = keys[i];
+        int rank = 0;
+        for (int j = 0; j < n; j++) rank += (keys[j] < ki) || (keys[j] == ki && j < i);
+#pragma unroll
+        for (int c = 0; c < W; c++) tmpVal[W * rank + c] = val[W * i + c];
+        tmpW[rank] = w[i];
+        tmpU[rank] = u[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // w *= u; w /= sum; cdf = cumsum(w); cdf /= cdf[n-1]
+    double sum = 0;
+    for (int i = lane; i < n; i += 64) sum += tmpW[i] * tmpU[i];
+    sum = wave_sum(sum);
+    if (lane == 0) {
+        double acc = 0;
+        for (int i = 0; i < n; i++) { acc += (tmpW[i] * tmpU[i]) / sum; cdf[i] = acc; }
+        const double last = cdf[n - 1];
+        for (int i = 0; i < n; i++) cdf[i] /= last;
+    }
+    __builtin_amdgcn_wave_barrier();
+    double u4[4];
+    draw_u4(u4, seed, img, call, purpose + 1, 0);
+    const double u0 = u4[0] * (1.0 / n);  // gsl_ran_flat(engine, 0, 1.0 / n)
+    double ws = 0;
+    for (int j = lane; j < n; j += 64) {
+        const double uj = u0 + j * 1.0 / n;
+        int lo = 0, hi = n - 1;  // smallest i with !(uj > cdf[i])
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (uj > cdf[mid]) lo = mid + 1; else hi = mid; }
+#pragma unroll
+        for (int c = 0; c < W; c++) val[W * j + c] = tmpVal[W * lo + c];
+        w[j] = 1.0 / tmpU[lo];
+        ws += w[j];
+    }
+    ws = wave_sum(ws);
+    for (int j = lane; j < n; j += 64) w[j] /= ws;
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct PfArgs {
+    double* r;        // [nImg][nR][4] quaternions
+    double* t;        // [nImg][nT][2] shifts
+    double* wR;       // [nImg][nR] priors
+    double* wT;       // [nImg][nT]
+    double* k123;     // [nImg][3]
+    double* s01;      // [nImg][2]
+    double* topR;     // [nImg][4]
+    double* topT;     // [nImg][2]
+    const float* uR;  // [nImg][nR] likelihood weights from the E-step
+    const float* uT;  // [nImg][nT]
+    int nR, nT;
+    double pfR, pfT, transS, transM, peakFactorR;
+    unsigned long long seed;
+    unsigned call;
+};
+
+// Particle::perturb(pf, PAR_R) + perturb(pf, PAR_T), src/Particle.cpp:1149-1272 (MODE_3D)
+__global__ __launch_bounds__(64) void k_pf_perturb(PfArgs a)
+{
+    __shared__ double sq[kPfMax * 4], st[kPfMax * 2], sw[kPfMax];
+    const int img = blockIdx.x, lane = threadIdx.x;
+    const int nR = a.nR, nT = a.nT;
+    if (nR > 0) {
+        double* r = a.r + (size_t)img * nR * 4;
+        const double* k = a.k123 + 3 * (size_t)img;
+        // sampleACG(d, pf^2 min(1, k1), pf^2 min(1, k2), pf^2 min(1, k3), nR): L = chol(diag(1, ...)) = sqrt of the diagonal
+        const double pf2 = a.pfR * a.pfR;
+        const double l1 = sqrt(pf2 * fmin(1.0, k[0])), l2 = sqrt(pf2 * fmin(1.0, k[1])), l3 = sqrt(pf2 * fmin(1.0, k[2]));
+        for (int i = lane; i < nR; i += 64) {
+            double g[4];
+            draw_n4(g, a.seed, img, a.call, 0, i);
+            double v[4] = {g[0], l1 * g[1], l2 * g[2], l3 * g[3]};
+            const double nrm = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[c] /= nrm;
+            // ((r conj(mean)) -> pert * . -> . * mean) == pert * r: the mean frame cancels (:1196-1230)
+            double o[4];
+            qmul(o, v, r + 4 * i);
+#pragma unroll
+            for (int c = 0; c < 4; c++) { r[4 * i + c] = o[c]; sq[4 * i + c] = o[c]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        balance_weight_R(sw, sq, nR, lane);
+        for (int i = lane; i < nR; i += 64) a.wR[(size_t)img * nR + i] = sw[i];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (nT > 0) {
+        double* t = a.t + (size_t)img * nT * 2;
+        const double s0 = a.s01[2 * (size_t)img], s1 = a.s01[2 * (size_t)img + 1];
+        for (int i = lane; i < nT; i += 64) {
+            double g[4];
+            draw_n4(g, a.seed, img, a.call, 1, i);
+            // gsl_ran_bivariate_gaussian(engine, s0, s1, rho = 0, &x, &y); t += (x, y) * pf
+            double x = t[2 * i] + s0 * g[0] * a.pfT, y = t[2 * i + 1] + s1 * g[1] * a.pfT;
+            // reCentre (:2473-2495): points beyond transM are redrawn from N(0, transS^2 I)
+            if (gsl_hypot_(x, y) > a.transM) { x = a.transS * g[2]; y = a.transS * g[3]; }
+            t[2 * i] = x; t[2 * i + 1] = y;
+            st[2 * i] = x; st[2 * i + 1] = y;
+        }
+        __builtin_amdgcn_wave_barrier();
+        balance_weight_T(sw, st, nT, lane);
+        for (int i = lane; i < nT; i += 64) a.wT[(size_t)img * nT + i] = sw[i];
+    }
+}
+
+// after the likelihood: setUR/setUT (+ keepHalfHeightPeak(PAR_R)), calRank1st, calVari, resample for R and T
+// (src/Optimiser.cpp:1410-1475)
+__global__ __launch_bounds__(64) void k_pf_update(PfArgs a)
+{
+    __shared__ double sq[kPfMax * 4], sw[kPfMax], su[kPfMax], tq[kPfMax * 4], tw[kPfMax], tu[kPfMax], cdf[kPfMax];
+    __shared__ unsigned keys[kPfMax];
+    const int img = blockIdx.x, lane = threadIdx.x;
+    const int nR = a.nR, nT = a.nT;
+    if (nR > 0) {
+        double* r = a.r + (size_t)img * nR * 4;
+        double umax = -1.0;
+        int imax = 0;
+        for (int i = lane; i < nR; i += 64) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) sq[4 * i + c] = r[4 * i + c];
+            sw[i] = a.wR[(size_t)img * nR + i];
+            const double u = (double)a.uR[(size_t)img * nR + i];
+            su[i] = u;
+            if (u > umax) { umax = u; imax = i; }
+        }
+        // d_value_max_index: first index of the maximum
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ou = __shfl_xor(umax, o, 64);
+            const int oi = __shfl_xor(imax, o, 64);
+            if (ou > umax || (ou == umax && oi < imax)) { umax = ou; imax = oi; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (a.peakFactorR >= 0) {  // keepHalfHeightPeak(PAR_R), :1964-1990
+            const double hh = umax * a.peakFactorR;
+            for (int i = lane; i < nR; i += 64) su[i] = (su[i] < hh) ? 0.0 : su[i] - hh;
+        }
+        if (lane < 4) a.topR[4 * (size_t)img + lane] = sq[4 * imax + lane];  // calRank1st
+        __builtin_amdgcn_wave_barrier();
+        // calVari(PAR_R), :1020-1080
+        double A[16], mean[4], cm[4];
+        infer_acg(A, sq, nR, lane, nullptr);
+        sym4_top_eigvec(mean, A);
+        cm[0] = mean[0]; cm[1] = -mean[1]; cm[2] = -mean[2]; cm[3] = -mean[3];
+        for (int i = lane; i < nR; i += 64) { double o[4]; qmul(o, sq + 4 * i, cm); for (int c = 0; c < 4; c++) sq[4 * i + c] = o[c]; }
+        __builtin_amdgcn_wave_barrier();
+        infer_acg(A, sq, nR, lane, nullptr);
+        if (lane == 0) {
+            a.k123[3 * (size_t)img] = A[5] / A[0];
+            a.k123[3 * (size_t)img + 1] = A[10] / A[0];
+            a.k123[3 * (size_t)img + 2] = A[15] / A[0];
+        }
+        for (int i = lane; i < nR; i += 64) { double o[4]; qmul(o, sq + 4 * i, mean); for (int c = 0; c < 4; c++) sq[4 * i + c] = o[c]; }
+        __builtin_amdgcn_wave_barrier();
+        resample<4>(sq, sw, su, tq, tw, tu, cdf, keys, nR, lane, a.seed, img, a.call, 2);
+        for (int i = lane; i < nR; i += 64) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) r[4 * i + c] = sq[4 * i + c];
+            a.wR[(size_t)img * nR + i] = sw[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (nT > 0) {
+        double* t = a.t + (size_t)img * nT * 2;
+        double umax = -1.0;
+        int imax = 0;
+        for (int i = lane; i < nT; i += 64) {
+            sq[2 * i] = t[2 * i]; sq[2 * i + 1] = t[2 * i + 1];
+            sw[i] = a.wT[(size_t)img * nT + i];
+            const double u = (double)a.uT[(size_t)img * nT + i];
+            su[i] = u;
+            if (u > umax) { umax = u; imax = i; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ou = __shfl_xor(umax, o, 64);
+            const int oi = __shfl_xor(imax, o, 64);
+            if (ou > umax || (ou == umax && oi < imax)) { umax = ou; imax = oi; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 2) a.topT[2 * (size_t)img + lane] = sq[2 * imax + lane];
+        double m, s0, s1;  // calVari(PAR_T): gsl_stats_sd per column
+        col_mean_sd(m, s0, sq, 0, nT, lane);
+        col_mean_sd(m, s1, sq, 1, nT, lane);
+        if (lane == 0) { a.s01[2 * (size_t)img] = s0; a.s01[2 * (size_t)img + 1] = s1; }
+        __builtin_amdgcn_wave_barrier();
+        resample<2>(sq, sw, su, tq, tw, tu, cdf, keys, nT, lane, a.seed, img, a.call, 4);
+        for (int i = lane; i < nT; i += 64) {
+            t[2 * i] = sq[2 * i]; t[2 * i + 1] = sq[2 * i + 1];
+            a.wT[(size_t)img * nT + i] = sw[i];
+        }
+    }
+}
+
+// inferACG / statistics probe for the parity tests: A [nImg][16], mean [nImg][4], k123 [nImg][3], wBal [nImg][n]
+__global__ __launch_bounds__(64) void k_pf_acg_stats(double* __restrict__ Aout, double* __restrict__ meanOut,
+                                                     double* __restrict__ kOut, double* __restrict__ wBal,
+                                                     int* __restrict__ roundsOut, const double* __restrict__ q, int n)
+{
+    __shared__ double sq[kPfMax * 4], sw[kPfMax];
+    const int img = blockIdx.x, lane = threadIdx.x;
+    for (int i = lane; i < n * 4; i += 64) sq[i] = q[(size_t)img * n * 4 + i];
+    __builtin_amdgcn_wave_barrier();
+    double A[16], mean[4], cm[4];
+    int rounds = 0;
+    infer_acg(A, sq, n, lane, &rounds);
+    if (lane == 0 && roundsOut) roundsOut[2 * (size_t)img] = rounds;
+    if (lane < 16) Aout[16 * (size_t)img + lane] = A[lane];
+    sym4_top_eigvec(mean, A);
+    if (lane < 4) meanOut[4 * (size_t)img + lane] = mean[lane];
+    balance_weight_R(sw, sq, n, lane);
+    for (int i = lane; i < n; i += 64) wBal[(size_t)img * n + i] = sw[i];
+    cm[0] = mean[0]; cm[1] = -mean[1]; cm[2] = -mean[2]; cm[3] = -mean[3];
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < n; i += 64) { double o[4]; qmul(o, sq + 4 * i, cm); for (int c = 0; c < 4; c++) sq[4 * i + c] = o[c]; }
+    __builtin_amdgcn_wave_barrier();
+    infer_acg(A, sq, n, lane, &rounds);
+    if (lane == 0 && roundsOut) roundsOut[2 * (size_t)img + 1] = rounds;
+    if (lane == 0) { kOut[3 * (size_t)img] = A[5] / A[0]; kOut[3 * (size_t)img + 1] = A[10] / A[0]; kOut[3 * (size_t)img + 2] = A[15] / A[0]; }
+}
+
+}  // namespace thx
+
+using namespace thx;
+
+extern "C" {
+
+int thx_pf_perturb_dev(double* r, double* t, double* wR, double* wT, const double* k123, const double* s01, int nImg,
+                       int nR, int nT, double pfR, double pfT, double transS, double transQ, unsigned long long seed,
+                       unsigned call, void* stream)
+{
+    if (nImg <= 0) return 0;
+    THX_REQUIRE(nR >= 0 && nT >= 0 && nR <= kPfMax && nT <= kPfMax, "nR / nT must be <= 256");
+    THX_REQUIRE((nR == 0 || (r && wR && k123)) && (nT == 0 || (t && wT && s01)), "NULL pointer");
+    THX_REQUIRE(nR == 0 || nR >= 5, "the ACG statistics need at least 5 rotations");
+    THX_REQUIRE(nT == 0 || nT >= 2, "the shift statistics need at least 2 points");
+    PfArgs a;
+    memset(&a, 0, sizeof(a));
+    a.r = r; a.t = t; a.wR = wR; a.wT = wT; a.k123 = const_cast<double*>(k123); a.s01 = const_cast<double*>(s01);
+    a.nR = nR; a.nT = nT; a.pfR = pfR; a.pfT = pfT; a.transS = transS;
+    // PARTICLE_RECENTRE_TRANSQ: transM = transS * gsl_cdf_chisq_Qinv(transQ, 2); for 2 degrees of freedom Q(x) = exp(-x/2)
+    a.transM = transS * (-2.0 * log(transQ));
+    a.seed = seed; a.call = call;
+    hipLaunchKernelGGL(k_pf_perturb, dim3(nImg), dim3(64), 0, as_stream(stream), a);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_pf_update_dev(double* r, double* t, double* wR, double* wT, const float* uR, const float* uT, double* k123,
+                      double* s01, double* topR, double* topT, int nImg, int nR, int nT, double peakFactorR,
+                      unsigned long long seed, unsigned call, void* stream)
+{
+    if (nImg <= 0) return 0;
+    THX_REQUIRE(nR >= 0 && nT >= 0 && nR <= kPfMax && nT <= kPfMax, "nR / nT must be <= 256");
+    THX_REQUIRE((nR == 0 || (r && wR && uR && k123 && topR)) && (nT == 0 || (t && wT && uT && s01 && topT)), "NULL pointer");
+    THX_REQUIRE((nR == 0 || nR >= 5) && (nT == 0 || nT >= 2), "too few support points");
+    PfArgs a;
+    memset(&a, 0, sizeof(a));
+    a.r = r; a.t = t; a.wR = wR; a.wT = wT; a.uR = uR; a.uT = uT; a.k123 = k123; a.s01 = s01; a.topR = topR; a.topT = topT;
+    a.nR = nR; a.nT = nT; a.peakFactorR = peakFactorR; a.seed = seed; a.call = call;
+    hipLaunchKernelGGL(k_pf_update, dim3(nImg), dim3(64), 0, as_stream(stream), a);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_pf_acg_stats_dev(double* A, double* mean, double* k123, double* wBal, int* rounds, const double* quat, int nImg,
+                         int n, void* stream)
+{
+    if (nImg <= 0) return 0;
+    THX_REQUIRE(A && mean && k123 && wBal && quat && n >= 5 && n <= kPfMax, "bad arguments");
+    hipLaunchKernelGGL(k_pf_acg_stats, dim3(nImg), dim3(64), 0, as_stream(stream), A, mean, k123, wBal, rounds, quat, n);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"
