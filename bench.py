@@ -39,8 +39,14 @@ def cpu_baseline(args, shard):
     dat = shard.datP[:n].cpu().numpy()
     ctf = shard.ctfP[:n].cpu().numpy()
     sig = shard.sigRcpP[:n].cpu().numpy()
-    rot = torch.stack([r[:n] for r in shard.rotP], dim=1).cpu().numpy()      # [n][nPhase][mLR][9]
-    tran = torch.stack([t[:n] for t in shard.tranP], dim=1).cpu().numpy()    # [n][nPhase][mLT][2]
+    if shard.use_pf:   # the particle filter's current support points, the same work in every phase
+        st = shard.pf_state
+        r1 = shard.ops.rotmat(st["r"][:n].reshape(-1, 4)).reshape(n, shard.mLR, 9)
+        rot = torch.stack([r1] * shard.nPhase, dim=1).cpu().numpy()
+        tran = torch.stack([st["t"][:n]] * shard.nPhase, dim=1).cpu().numpy()
+    else:
+        rot = torch.stack([r[:n] for r in shard.rotP], dim=1).cpu().numpy()      # [n][nPhase][mLR][9]
+        tran = torch.stack([t[:n] for t in shard.tranP], dim=1).cpu().numpy()    # [n][nPhase][mLT][2]
     rng = np.random.default_rng(1)
     iR = rng.integers(0, shard.mLR, size=(n, shard.mReco))
     iT = rng.integers(0, shard.mLT, size=(n, shard.mReco))
@@ -70,6 +76,8 @@ def main():
     ap.add_argument("--phases", type=int, default=3)
     ap.add_argument("--mReco", type=int, default=100)
     ap.add_argument("--batch", type=int, default=10240, help="max images per kernel launch")
+    ap.add_argument("--fixed-support", action="store_true",
+                    help="feed fixed, tightly clustered support points instead of running the particle filter")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles", type=int, default=0)
     args = ap.parse_args()
@@ -92,7 +100,7 @@ def main():
     capi.load()
 
     shard = RefineShard(args.box, args.particles, dev, rank=rank, world=world, mLR=args.mLR, mLT=args.mLT,
-                        nPhase=args.phases, mReco=args.mReco, batch=args.batch)
+                        nPhase=args.phases, mReco=args.mReco, batch=args.batch, particle_filter=not args.fixed_support)
 
     def barrier():
         if world > 1:
@@ -159,6 +167,8 @@ def main():
                                    "2x reconstruct per half, FSC, projector refresh)" % (
                                        args.particles, args.box, args.phases, args.mLR, args.mLT, args.mReco),
                        "box": args.box, "particles_per_gpu": args.particles, "nPxl": shard.nPxl, "pf": 2,
+                       "search_state": "fixed seeded support points" if args.fixed_support else
+                                       "device particle filter (perturb / resample every phase, Philox-seeded)",
                        "parallelism": "particles sharded over %d GPU(s); half-set F/T all-reduce" % world},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kms,

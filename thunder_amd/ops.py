@@ -304,6 +304,35 @@ def init_images(imgRL, maskRadiusPx, ew=6.0, reduce_stats=None):
                               stdStdN=float(stdStdN))
 
 
+# ---------------------------------------------------------------------------------------------
+# particle filter
+def pf_perturb(r, t, wR, wT, k123, s01, pfR, pfT, transS, transQ, seed, call):
+    """Particle::perturb(pf, PAR_R) + perturb(pf, PAR_T) (src/Particle.cpp:1149-1272) for [n][nR][4] / [n][nT][2] f64"""
+    for x, nm in ((r, "r"), (t, "t"), (wR, "wR"), (wT, "wT"), (k123, "k123"), (s01, "s01")):
+        _chk(x, _F64, nm)
+    capi.call("thx_pf_perturb_dev", ptr(r), ptr(t), ptr(wR), ptr(wT), ptr(k123), ptr(s01), r.shape[0], r.shape[1],
+              t.shape[1], float(pfR), float(pfT), float(transS), float(transQ), int(seed), int(call), stream_ptr())
+
+
+def pf_update(r, t, wR, wT, uR, uT, k123, s01, topR, topT, peakFactorR, seed, call):
+    """setUR/UT, keepHalfHeightPeak, calRank1st, calVari, resample (src/Optimiser.cpp:1410-1475)"""
+    _chk(uR, _F32, "uR"); _chk(uT, _F32, "uT")
+    capi.call("thx_pf_update_dev", ptr(r), ptr(t), ptr(wR), ptr(wT), ptr(uR), ptr(uT), ptr(k123), ptr(s01), ptr(topR),
+              ptr(topT), r.shape[0], r.shape[1], t.shape[1], float(peakFactorR), int(seed), int(call), stream_ptr())
+
+
+def pf_acg_stats(quat):
+    """inferACG / mean / k1..k3 / balance weights of [n][m][4] f64 clouds -> (A [n][16], mean [n][4], k [n][3], w [n][m])"""
+    _chk(quat, _F64, "quat")
+    n, m, dev = quat.shape[0], quat.shape[1], quat.device
+    A = torch.empty((n, 16), dtype=_F64, device=dev)
+    mean = torch.empty((n, 4), dtype=_F64, device=dev)
+    k = torch.empty((n, 3), dtype=_F64, device=dev)
+    w = torch.empty((n, m), dtype=_F64, device=dev)
+    capi.call("thx_pf_acg_stats_dev", ptr(A), ptr(mean), ptr(k), ptr(w), None, ptr(quat), n, m, stream_ptr())
+    return A, mean, k, w
+
+
 class RecoPlan:
     """thx_reco handle: Reconstructor::allocSpace state (FFT plans, W, C, kernel table)."""
 

@@ -72,7 +72,7 @@ class RefineShard:
 
     def __init__(self, N, nImg, device, rank=0, world=1, pf=2, mLR=125, mLT=9, nPhase=3, mReco=100, seed=1000,
                  batch=10240, pixelSize=1.32, snr=0.01, rL=2, ops=None, oracle_pixel_list=None, nGroup=8, groupSig=True,
-                 maskFrac=0.45):
+                 maskFrac=0.45, particle_filter=True, transS=2.0):
         if ops is None:
             from . import ops as _ops
             ops = _ops
@@ -180,6 +180,17 @@ class RefineShard:
             t[:, 0, :] = self.shift
             self.tranP.append(torch.from_numpy(np.ascontiguousarray(t)).to(device))
         self.tranP0 = [t.clone() for t in self.tranP]
+        # ---- particle filter state (Particle, src/Particle.cpp), used instead of the fixed support points ----
+        self.use_pf = particle_filter
+        self.pf_seed, self.pf_call = seed + 104729 * rank, 0
+        self.transS, self.transQ = transS, 0.05                       # TRANS_Q, include/Optimiser.h:67
+        self.pfL, self.pfS, self.peakFactorR = 2.0, 0.5, 1e-3         # script/demo_3D.json:71-73, PEAK_FACTOR_MIN
+        if self.use_pf:
+            q0 = synth.perturb_quats(self.quat, mLR, 0.02, rng)
+            t0 = self.shift[:, None, :] + rng.normal(0, 0.5, size=(nImg, mLT, 2))
+            self.pf0 = dict(r=torch.from_numpy(np.ascontiguousarray(q0)).to(device),
+                            t=torch.from_numpy(np.ascontiguousarray(t0)).to(device))
+            self.pf_state = {}
         self.w = torch.full((nImg,), 1.0 / mReco, dtype=torch.float32, device=device)
         nV = len(self.halves)
         self.F = torch.zeros((nV, self.P, self.P, self.P // 2 + 1), dtype=torch.complex64, device=device)
@@ -235,6 +246,9 @@ class RefineShard:
         """Particle::rank1st of the last phase: the support point with the largest weight"""
         p = self.nPhase - 1
         lo, hi = self.ranges[self.halves[vi]]
+        if self.use_pf:   # Particle::calRank1st already stored them (thx_pf_update_dev)
+            st = self.pf_state
+            return self.ops.rotmat(st["topR"][lo:hi].contiguous()), st["topT"][lo:hi].clone()
         ar = torch.arange(hi - lo, device=self.dev)
         return (self.rotP[p][lo:hi][ar, wR.argmax(1)].contiguous(), self.tranP[p][lo:hi][ar, wT.argmax(1)].contiguous())
 
@@ -259,6 +273,9 @@ class RefineShard:
         self.offset[lo:hi] -= tranTop
         for t in self.tranP:                              # _par[l].setT(t - tran)
             t[lo:hi] -= tranTop[:, None, :]
+        if self.use_pf:
+            self.pf_state["t"][lo:hi] -= tranTop[:, None, :]
+            self.pf_state["topT"][lo:hi] -= tranTop       # setTopT(topT - tran)
         ops.translate_image(self.imgOri[lo:hi], self.offset[lo:hi], out=self.img[lo:hi])
         ops.remask(self.img[lo:hi], self.maskRadiusPx, 6.0)
 
@@ -271,18 +288,35 @@ class RefineShard:
         wR = torch.empty((n, self.mLR), dtype=torch.float32, device=self.dev)
         wT = torch.empty((n, self.mLT), dtype=torch.float32, device=self.dev)
         vol = self.vols[vi:vi + 1]
+        st = self.pf_state if self.use_pf else None
         for p in range(self.nPhase):
             for b0 in range(lo, hi, self.batch):
                 b1 = min(hi, b0 + self.batch)
+                pR = pT = None
+                if self.use_pf:
+                    # Particle::perturb, then the phase's support points are the filter's own (src/Optimiser.cpp:1186-1208)
+                    sl = slice(b0, b1)
+                    self.pf_call += 1
+                    f = self.pfL if p == 0 else self.pfS
+                    ops.pf_perturb(st["r"][sl], st["t"][sl], st["wR"][sl], st["wT"][sl], st["k"][sl], st["s"][sl], f, f,
+                                   self.transS, self.transQ, self.pf_seed, self.pf_call)
+                    rotB = ops.rotmat(st["r"][sl].reshape(-1, 4)).reshape(b1 - b0, self.mLR, 9)
+                    tranB, pR, pT = st["t"][sl], st["wR"][sl], st["wT"][sl]
+                else:
+                    rotB, tranB = self.rotP[p][b0:b1], self.tranP[p][b0:b1]
                 if timed:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                 r = ops.expect_local(vol, self.P, self.pf, self.N, self.iCol, self.iRow, self.datP[b0:b1],
-                                     self.ctfP[b0:b1], self.sigRcpP[b0:b1], self.rotP[p][b0:b1], self.tranP[p][b0:b1],
-                                     nD=1, workspace=self.ws[vi])
+                                     self.ctfP[b0:b1], self.sigRcpP[b0:b1], rotB, tranB, nD=1, pR=pR, pT=pT,
+                                     workspace=self.ws[vi])
                 if timed:
                     e1.record()
                     self.expect_ms.append((e0, e1, b1 - b0))
+                if self.use_pf:
+                    self.pf_call += 1
+                    ops.pf_update(st["r"][sl], st["t"][sl], st["wR"][sl], st["wT"][sl], r.wR, r.wT, st["k"][sl], st["s"][sl],
+                                  st["topR"][sl], st["topT"][sl], self.peakFactorR, self.pf_seed, self.pf_call)
                 if p == self.nPhase - 1:
                     wR[b0 - lo:b1 - lo] = r.wR
                     wT[b0 - lo:b1 - lo] = r.wT
@@ -295,6 +329,14 @@ class RefineShard:
         p = self.nPhase - 1
         lo, hi = self.ranges[self.halves[vi]]
         n, gen = hi - lo, self.gens[vi]
+        if self.use_pf:   # the filter has been resampled by thx_pf_update_dev: Particle::rand = a uniform pick
+            st = self.pf_state
+            uR = torch.randint(0, self.mLR, (n, self.mReco), device=self.dev, generator=gen)
+            uT = torch.randint(0, self.mLT, (n, self.mReco), device=self.dev, generator=gen)
+            q = torch.gather(st["r"][lo:hi], 1, uR[:, :, None].expand(-1, -1, 4)).contiguous()
+            rot = self.ops.rotmat(q.reshape(-1, 4)).reshape(n, self.mReco, 9)
+            tran = torch.gather(st["t"][lo:hi], 1, uT[:, :, None].expand(-1, -1, 2)).contiguous()
+            return rot, tran
         rsR = torch.multinomial(wR.clamp_min(1e-30), self.mLR, replacement=True, generator=gen)   # resample
         rsT = torch.multinomial(wT.clamp_min(1e-30), self.mLT, replacement=True, generator=gen)
         uR = torch.randint(0, self.mLR, (n, self.mReco), device=self.dev, generator=gen)          # rand
@@ -457,6 +499,16 @@ class RefineShard:
         self.ops.remask(self.img, self.maskRadiusPx, 6.0)
         self.sig.fill_(self.sigma2)
         self.sigRcp.fill_(-0.5 / self.sigma2)
+        if self.use_pf:
+            st, n = self.pf_state, self.nImg
+            st["r"], st["t"] = self.pf0["r"].clone(), self.pf0["t"].clone()
+            st["wR"] = torch.full((n, self.mLR), 1.0 / self.mLR, dtype=torch.float64, device=self.dev)
+            st["wT"] = torch.full((n, self.mLT), 1.0 / self.mLT, dtype=torch.float64, device=self.dev)
+            st["k"] = self.ops.pf_acg_stats(st["r"])[2]                       # Particle::load -> calVari
+            st["s"] = st["t"].std(dim=1, unbiased=True).contiguous()
+            st["topR"] = st["r"][:, 0].contiguous()
+            st["topT"] = st["t"][:, 0].contiguous()
+            self.pf_call = 0
         for vi in range(len(self.halves)):
             self.refresh_rows(vi)
 
