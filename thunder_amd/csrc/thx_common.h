@@ -223,6 +223,21 @@ __device__ __forceinline__ float wave_sum(float v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// 64-lane sum with DPP row operations (6 full-rate VALU adds, no LDS crossbar): every lane of the result holds the total
+// (read back from lane 63 through an SGPR).  Summation order differs from wave_sum's butterfly.
+__device__ __forceinline__ float wave_sum_dpp(float v)
+{
+#define THX_DPP_ADD(ctrl, rmask)                                                                                      \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xF, false))
+    THX_DPP_ADD(0xB1, 0xF);   // quad_perm [1,0,3,2]
+    THX_DPP_ADD(0x4E, 0xF);   // quad_perm [2,3,0,1]
+    THX_DPP_ADD(0x141, 0xF);  // row_half_mirror
+    THX_DPP_ADD(0x140, 0xF);  // row_mirror: every lane holds its 16-lane row sum
+    THX_DPP_ADD(0x142, 0xA);  // row_bcast15 into rows 1 and 3
+    THX_DPP_ADD(0x143, 0xC);  // row_bcast31 into rows 2 and 3: lane 63 holds the total
+#undef THX_DPP_ADD
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
