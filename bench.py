@@ -138,7 +138,7 @@ def main():
         exp_bytes = float(np.mean([n for _, n in exp])) * shard.mLR * shard.nPxl * EXPECT_BYTES_PER_PIXEL_SAMPLE
         t_ins, t_exp = sum(m for m, _ in ins), sum(m for m, _ in exp)
         if t_ins >= t_exp:
-            kname, kms, kbytes = "k_insert", ins_ms, ins_bytes
+            kname, kms, kbytes = "k_insert_win", ins_ms, ins_bytes
         else:
             kname, kms, kbytes = "k_expect_local", exp_ms, exp_bytes
         achieved = kbytes / (kms * 1e-3) / 1e9
@@ -154,7 +154,7 @@ def main():
                     if kname == "k_expect_local":
                         traffic = j["hbm_bytes_per_image_phase"] * nper
                     else:
-                        traffic = j["k_insert_tiles_hbm_bytes_per_image"] * nper
+                        traffic = j["insert_hbm_bytes_per_image"] * nper
             except Exception:
                 traffic = None
         out = {
@@ -173,7 +173,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kms,
                          "algorithmic_bytes_per_launch": kbytes},
-            "kernels": {"k_insert": {"avg_launch_ms": ins_ms, "GBps_algorithmic": ins_bytes / (ins_ms * 1e-3) / 1e9,
+            "kernels": {"k_insert_win": {"avg_launch_ms": ins_ms, "GBps_algorithmic": ins_bytes / (ins_ms * 1e-3) / 1e9,
                                      "total_ms": t_ins},
                         "k_expect_local": {"avg_launch_ms": exp_ms,
                                            "GBps_algorithmic": exp_bytes / (exp_ms * 1e-3) / 1e9, "total_ms": t_exp}},

@@ -485,6 +485,7 @@ struct ExpectWinArgs {
     const int* pixIndex;
     int nW, pOrg;
     float rMax2;
+    int debug;   // THX_EXPECT_WIN_DEBUG (profiling only): 1 skip the rotation loops, 2 skip the volume staging
 };
 
 __global__ void k_pix_index_e(int* __restrict__ pixIndex, const int* __restrict__ iCol, const int* __restrict__ iRow,
@@ -800,7 +801,7 @@ __global__ __launch_bounds__(kEThreads, 4) void k_expect_win(ExpectWinArgs wa)
             for (int sl = sLo; sl <= sHi; sl++) {
                 g.w0 = sl * kEWz - kEWz / 2;
                 __syncthreads();   // the previous slab's readers are done with sVol (and the tables are written)
-                for (int e = tid; e < kEVox; e += kEThreads) {
+                for (int e = tid; e < ((wa.debug & 2) ? 0 : kEVox); e += kEThreads) {
                     int pI, qI, of;
                     if (ax == 0) { of = e % kEHz; const int r = e / kEHz; qI = r / kEHp; pI = r - qI * kEHp; }
                     else { const int r = e / kEHp; pI = e - r * kEHp; of = r % kEHz; qI = r / kEHz; }
@@ -817,7 +818,7 @@ __global__ __launch_bounds__(kEThreads, 4) void k_expect_win(ExpectWinArgs wa)
                     sVol[e] = v;
                 }
                 __syncthreads();
-                for (int r = wave; r < nR; r += kEWaves) {
+                for (int r = wave; r < ((wa.debug & 1) ? 0 : nR); r += kEWaves) {
                     const short* box = sBox + 4 * r;
                     if (box[1] <= 0) continue;
                     if (sWr[2 * r + 1] < (float)g.w0 || sWr[2 * r] > (float)(g.w0 + kEWz)) continue;
@@ -1027,6 +1028,10 @@ static int launch_expect_win(ExpectLocalArgs a, hipStream_t st, ExpectFinalArgs&
     hipLaunchKernelGGL(k_expect_const, dim3(a.nImg), dim3(256), 0, st, a.partC, a.datP, a.sigRcpP, a.nPxl, a.nD, a.nSplit);
     wa.a = a;
     wa.pixIndex = pixIndex;
+    {
+        const char* dbg = getenv("THX_EXPECT_WIN_DEBUG");
+        wa.debug = dbg ? atoi(dbg) : 0;
+    }
     const size_t lds = (size_t)kEVox * sizeof(float2) + (size_t)kEPix * kEPix * sizeof(float4) + (size_t)a.nR * 6 * sizeof(double) +
                        2 * (size_t)NT * kEPix * sizeof(float2) + (size_t)a.nR * (NT + 1) * sizeof(float) +
                        2 * (size_t)a.nR * sizeof(float) + 4 * (size_t)a.nR * sizeof(short) + 16;

@@ -564,6 +564,7 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_tiles(InsertTileArgs 
 constexpr int kWd = 16;                     // window edge in (p, q), voxels
 constexpr int kWz = 16;                     // slab thickness along the sheared axis, voxels
 constexpr int kWinVox = kWd * kWd * kWz;    // 4096 voxels x 12 B = 48 KB
+constexpr int kIPix = 24;                   // per-window tabulated pixel range per axis (pixel data, separable ramps)
 
 struct InsertWinArgs {
     InsertArgs a;
@@ -574,6 +575,7 @@ struct InsertWinArgs {
     int nW;                 // windows per side; window w covers [pOrg + w kWd, pOrg + (w+1) kWd)
     int pOrg;
     float rMax2;            // (largest sample radius + 2)^2, voxels
+    int debug;              // THX_INSERT_DEBUG (profiling only): 1 skip LDS adds, 2 skip flush, 4 skip the group loop
 };
 
 __global__ __launch_bounds__(256) void k_insert_bounds(float2* __restrict__ bounds, const float2* __restrict__ datP,
@@ -596,6 +598,10 @@ __global__ __launch_bounds__(256) void k_insert_bounds(float2* __restrict__ boun
 
 struct WinGeom {
     int p0, q0, w0;        // window origin in brick coordinates (w0 = slab base relative to the sheared plane)
+    int ui0, uj0;          // origin of the tabulated pixel range
+    const float4* pix;     // LDS [kIPix][kIPix]: re, im, ctf, listed
+    const float2* ecol;    // LDS [kMaxU][kIPix] exp(-i 2 pi i tx_u / N) (valid when U <= kMaxU)
+    const float2* erow;    // LDS [kMaxU][kIPix]
     float sp, sq;
     float scaleF, scaleT, invF, invT, minQ;
 };
@@ -617,11 +623,26 @@ __device__ __forceinline__ void insert_win_group(const InsertWinArgs& wa, const 
     const float nmem = (float)(m1 - m0);
     const int nCand = nI * nJ;
     const float rnI = 1.0f / (float)nI;
+    // float pre-test on (p, q) of the sample (rows pa, qa of R; the margin covers float rounding and the cell extent)
+    const float A00 = (float)R[pa] * (float)a.opf, A01 = (float)R[3 + pa] * (float)a.opf, A10 = (float)R[qa] * (float)a.opf,
+                A11 = (float)R[3 + qa] * (float)a.opf;
+    const float plo = (float)g.p0 - 2.5f, phi = (float)(g.p0 + kWd) + 1.5f, qlo = (float)g.q0 - 2.5f, qhi = (float)(g.q0 + kWd) + 1.5f;
     for (int c = lane; c < nCand; c += 64) {
         const int jr = (int)(((float)c + 0.5f) * rnI);
         const int pi = i0 + (c - jr * nI), pj = j0 + jr;
-        const int k = wa.pixIndex[(pj + half) * (half + 1) + pi];
-        if (k < 0) continue;
+        const float pf_ = A00 * (float)pi + A01 * (float)pj, qf_ = A10 * (float)pi + A11 * (float)pj;
+        if (!(pf_ >= plo && pf_ < phi && qf_ >= qlo && qf_ < qhi)) continue;
+        const int ti = pi - g.ui0, tj = pj - g.uj0;
+        const bool tab = (unsigned)ti < (unsigned)kIPix && (unsigned)tj < (unsigned)kIPix;
+        int k = 0;
+        float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tab) {
+            px = g.pix[tj * kIPix + ti];
+            if (px.w == 0.f) continue;
+        } else {
+            k = wa.pixIndex[(pj + half) * (half + 1) + pi];
+            if (k < 0) continue;
+        }
         const int icp = pi * a.opf, irp = pj * a.opf;
         float x = (float)(R[0] * icp + R[3] * irp);
         float y = (float)(R[1] * icp + R[4] * irp);
@@ -660,14 +681,25 @@ __device__ __forceinline__ void insert_win_group(const InsertWinArgs& wa, const 
         }
         if (!inMask) continue;
         // the value of this pixel for the group: (img * sum of the members' ramps) * ctf * w, T: n * ctf^2 * w
-        const float2 dv = a.datP[(size_t)img * a.nPxl + k];
-        float cf = a.ctfP[(size_t)img * a.nPxl + k];
+        float2 dv;
+        float cf;
+        if (tab) { dv = make_float2(px.x, px.y); cf = px.z; }
+        else { dv = a.datP[(size_t)img * a.nPxl + k]; cf = a.ctfP[(size_t)img * a.nPxl + k]; }
         float2 S = make_float2(0.f, 0.f);
-        for (int i = m0; i < m1; i++) {
-            const int u = dt.mUid[i];
-            const float2 r = ramp_value(dt.slope[2 * u], dt.slope[2 * u + 1], pi, pj);
-            S.x += r.x;
-            S.y += r.y;
+        if (tab && dt.U <= kMaxU) {
+            for (int i = m0; i < m1; i++) {   // separable ramp exp(-i a_u i) exp(-i b_u j) from the window's tables
+                const int u = dt.mUid[i];
+                const float2 ec = g.ecol[u * kIPix + ti], er = g.erow[u * kIPix + tj];
+                S.x += ec.x * er.x - ec.y * er.y;
+                S.y += ec.x * er.y + ec.y * er.x;
+            }
+        } else {
+            for (int i = m0; i < m1; i++) {
+                const int u = dt.mUid[i];
+                const float2 r = ramp_value(dt.slope[2 * u], dt.slope[2 * u + 1], pi, pj);
+                S.x += r.x;
+                S.y += r.y;
+            }
         }
         const float2 tv = cmul(dv, S);
         if (a.cSearch) {
@@ -691,6 +723,7 @@ __device__ __forceinline__ void insert_win_group(const InsertWinArgs& wa, const 
             const float tq = (tval * wv) * g.scaleT;
             if (tq >= g.minQ) {
                 const int idx = AX == 0 ? ((qI[dq] * kWd + pI[dp]) * kWz + off) : ((qI[dq] * kWz + off) * kWd + pI[dp]);
+                if (wa.debug & 1) { if (idx < 0) sRe[0] = 1; continue; }
                 atomicAdd(&sRe[idx], __float2int_rn((vre * wv) * g.scaleF));
                 atomicAdd(&sIm[idx], __float2int_rn((vim * wv) * g.scaleF));
                 atomicAdd(reinterpret_cast<unsigned*>(&sT[idx]), __float2uint_rn(tq));
@@ -750,7 +783,10 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_win(InsertWinArgs wa)
     float* sSlope = reinterpret_cast<float*>(sGInfo + 2 * a.mReco);          // [mReco][2]
     short* sBox = reinterpret_cast<short*>(sSlope + 2 * a.mReco);            // [mReco][4]: i0, nI, j0, nJ (nI = 0: no candidates)
     float* sWr = reinterpret_cast<float*>(sBox + 4 * a.mReco);               // [mReco][2]: w range of the group in this window
-    __shared__ int sWlo, sWhi, sCls;
+    float4* sPix = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(sWr + 2 * a.mReco) + 15) & ~(uintptr_t)15);  // [kIPix][kIPix]
+    float2* sEc = reinterpret_cast<float2*>(sPix + kIPix * kIPix);           // [kMaxU][kIPix]
+    float2* sEr = sEc + kMaxU * kIPix;                                       // [kMaxU][kIPix]
+    __shared__ int sWlo, sWhi, sCls, sUi0, sUi1, sUj0, sUj1;
 
     const int img = blockIdx.y, wqI = blockIdx.x;
     const int tid = threadIdx.x, grp = tid >> 6;
@@ -827,6 +863,7 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_win(InsertWinArgs wa)
     g.invT = boundT / qT;
     g.minQ = wa.minQuanta;
     g.q0 = wa.pOrg + wqI * kWd;
+    g.pix = sPix; g.ecol = sEc; g.erow = sEr;
 
     const int nPass = a.cls ? a.nK : 1;
     for (int pass = 0; pass < nPass; pass++) {
@@ -850,7 +887,7 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_win(InsertWinArgs wa)
                 if (dp * dp + dq * dq > wa.rMax2) continue;
             }
             __syncthreads();   // previous window's readers of sBox / sWr / sWlo are done
-            if (tid == 0) { sWlo = INT_MAX; sWhi = INT_MIN; }
+            if (tid == 0) { sWlo = INT_MAX; sWhi = INT_MIN; sUi0 = INT_MAX; sUi1 = INT_MIN; sUj0 = INT_MAX; sUj1 = INT_MIN; }
             __syncthreads();
             // ---- per group: candidate pixel box (inverse 2x2 map of the padded window corners) and sheared-w range ----
             for (int gi_ = tid; gi_ < G; gi_ += kInsThreads) {
@@ -877,6 +914,7 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_win(InsertWinArgs wa)
                     j0 = j0 < -half ? -half : j0; j1 = j1 > half - 1 ? half - 1 : j1;
                     if (i1 < i0 || j1 < j0) continue;
                     box[0] = (short)i0; box[1] = (short)(i1 - i0 + 1); box[2] = (short)j0; box[3] = (short)(j1 - j0 + 1);
+                    atomicMin(&sUi0, i0); atomicMax(&sUi1, i1); atomicMin(&sUj0, j0); atomicMax(&sUj1, j1);
                 }
                 // height of the group's plane above the reference shear at the window corners
                 const float gn0 = (float)(R[1] * R[5] - R[2] * R[4]), gn1 = (float)(R[2] * R[3] - R[0] * R[5]),
@@ -897,19 +935,45 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_win(InsertWinArgs wa)
             }
             __syncthreads();
             if (sWlo > sWhi) continue;
+            // ---- pixel data and separable ramps of the unique shifts for the pixel range in play ----
+            g.ui0 = sUi0 <= sUi1 ? sUi0 - ((kIPix - (sUi1 - sUi0 + 1)) > 0 ? (kIPix - (sUi1 - sUi0 + 1)) / 2 : 0) : 0;
+            g.uj0 = sUj0 <= sUj1 ? sUj0 - ((kIPix - (sUj1 - sUj0 + 1)) > 0 ? (kIPix - (sUj1 - sUj0 + 1)) / 2 : 0) : -half;
+            for (int e = tid; e < kIPix * kIPix; e += kInsThreads) {
+                const int tj = e / kIPix, ti = e - tj * kIPix;
+                const int pi = g.ui0 + ti, pj = g.uj0 + tj;
+                float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pi >= 0 && pi <= half && pj >= -half && pj < half) {
+                    const int k = wa.pixIndex[(pj + half) * (half + 1) + pi];
+                    if (k >= 0) {
+                        const float2 dv = a.datP[(size_t)img * a.nPxl + k];
+                        px = make_float4(dv.x, dv.y, a.ctfP[(size_t)img * a.nPxl + k], 1.f);
+                    }
+                }
+                sPix[e] = px;
+            }
+            if (U <= kMaxU)
+                for (int e = tid; e < 2 * U * kIPix; e += kInsThreads) {
+                    const int which = e / (U * kIPix), rem = e - which * U * kIPix, u = rem / kIPix, o = rem - u * kIPix;
+                    const double ph = kM2xPi * ((double)((which ? g.uj0 : g.ui0) + o) * (double)sSlope[2 * u + which]);
+                    double sn, cs;
+                    sincos(-ph, &sn, &cs);
+                    (which ? sEr : sEc)[u * kIPix + o] = make_float2((float)cs, (float)sn);
+                }
+            __syncthreads();
             const int sLo = (sWlo + kWz / 2) >= 0 ? (sWlo + kWz / 2) / kWz : -((-(sWlo + kWz / 2) + kWz - 1) / kWz);
             const int sHi = (sWhi + kWz / 2) >= 0 ? (sWhi + kWz / 2) / kWz : -((-(sWhi + kWz / 2) + kWz - 1) / kWz);
             for (int sl = sLo; sl <= sHi; sl++) {
                 g.w0 = sl * kWz - kWz / 2;
                 for (int gi_ = grp; gi_ < G; gi_ += kInsWaves) {
                     const short* box = sBox + 4 * gi_;
-                    if (box[1] == 0) continue;
+                    if (box[1] == 0 || (wa.debug & 4)) continue;
                     if (sWr[2 * gi_ + 1] < (float)g.w0 || sWr[2 * gi_] > (float)(g.w0 + kWz)) continue;
                     if (ax == 0) insert_win_group<0>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T);
                     else if (ax == 1) insert_win_group<1>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T);
                     else insert_win_group<2>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T);
                 }
                 __syncthreads();
+                if (wa.debug & 2) { __syncthreads(); continue; }
                 if (ax == 0) insert_win_flush<0>(a, g, sRe, sIm, sT, F, T);
                 else if (ax == 1) insert_win_flush<1>(a, g, sRe, sIm, sT, F, T);
                 else insert_win_flush<2>(a, g, sRe, sIm, sT, F, T);
@@ -1078,7 +1142,8 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
         hipLaunchKernelGGL(k_insert_bounds, dim3(nImg), dim3(256), 0, st, bounds, a.datP, a.ctfP, nPxl);
         ldsWin = 3 * (size_t)kWinVox * sizeof(int) + (size_t)mReco * 6 * sizeof(double) +
                  ((size_t)(mReco + 1) + mReco + 2 * mReco) * sizeof(int) + 2 * (size_t)mReco * sizeof(float) +
-                 4 * (size_t)mReco * sizeof(short) + 2 * (size_t)mReco * sizeof(float) + 16;
+                 4 * (size_t)mReco * sizeof(short) + 2 * (size_t)mReco * sizeof(float) + 32 +
+                 (size_t)kIPix * kIPix * sizeof(float4) + 2 * (size_t)kMaxU * kIPix * sizeof(float2);
         THX_REQUIRE(ldsWin <= 160 * 1024, "mReco too large for the LDS draw table");
         THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_insert_win), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)ldsWin));
@@ -1102,6 +1167,8 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
             wa.nW = 2 * hw;
             wa.pOrg = -hw * kWd;
             wa.rMax2 = (float)(half * opf + 2) * (float)(half * opf + 2);
+            const char* dbgw = getenv("THX_INSERT_DEBUG");
+            wa.debug = dbgw ? atoi(dbgw) : 0;
             hipLaunchKernelGGL(k_insert_win, dim3(wa.nW, nl), dim3(kInsThreads), ldsWin, st, wa);
         } else if (tiles) {
             InsertTileArgs ta;

@@ -28,7 +28,7 @@ summary["note"] = ("FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tal
                    "bytes (MI355X_MICROARCH.md, HBM section): the 1 GiB copy reads 524288 KiB by the counter. bytes_per_unit "
                    "below therefore applies the same x2 to the kernels' fetch counts (an upper bound for their mixed-width "
                    "gathers); WRITE_SIZE is exact (1 GiB -> 1048576 KiB).")
-for name in ("k_insert_tiles", "k_expect_local"):
+for name in ("k_insert_win", "k_insert_tiles", "k_expect_local<"):
     ent = {}
     for which in ("fetch", "write"):
         f = find(res[which], name)
@@ -42,3 +42,16 @@ for name in ("k_insert_tiles", "k_expect_local"):
         summary[name] = ent
 print(json.dumps(summary, indent=1))
 json.dump(summary, open(out + "/summary.json", "w"), indent=1)
+# per-image figures bench.py scales into roofline.traffic (tools/traffic_probe.py launches 1024 images per kernel)
+import os
+n_per_launch = int(os.environ.get("THX_PROBE_PARTICLES", "2048")) // 2
+pm = {"box": 256, "images_per_launch": n_per_launch,
+      "source": "tools/pmc_traffic.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+                "tools/traffic_probe.py (particle-filter support points, one phase); KiB units; FETCH_SIZE x2 (gfx950 "
+                "wide-read correction, calibrated on a 1 GiB device copy in the same passes); WRITE_SIZE exact"}
+if "k_expect_local<" in summary:
+    pm["hbm_bytes_per_image_phase"] = summary["k_expect_local<"]["hbm_bytes_per_launch"] / n_per_launch
+ins = summary.get("k_insert_win") or summary.get("k_insert_tiles")
+if ins:
+    pm["insert_hbm_bytes_per_image"] = ins["hbm_bytes_per_launch"] / n_per_launch
+json.dump(pm, open(out + "/pmc_traffic.json", "w"), indent=1)
