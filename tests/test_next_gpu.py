@@ -265,3 +265,77 @@ def test_image_ingestion(oracle, dev, N, n, tmp_path):
         scale_ = np.abs(w).reshape(len(w), -1).max(1)[:, None, None]
         assert (np.abs(g - w) / scale_).max() <= 2e-5
     assert np.isfinite(imgFT.abs().sum().item())
+
+
+def test_end_to_end_from_files(oracle, dev, tmp_path):
+    """MRC stack + .thu table on disk -> thx_thu_load / thx_mrc_read_images -> initImg stages -> two full iterations
+    (particle filter, E-step, sigma, insertion, reconstruction, re-centre / re-mask): the half maps agree with each other
+    and with the map the particles were made from."""
+    import ctypes as C
+    import scipy.fft as sfft
+    from thunder_amd import capi, ops, synth
+    from thunder_amd.capi import CtfAttr
+    from thunder_amd.refine import RefineShard
+    O = oracle
+    rng = np.random.default_rng(31)
+    N, n, pixelSize = 32, 600, 1.32
+    ref = synth.blob_map(N, nblob=12)
+    vol = O.set_projectee(ref, 2)
+    dl = O.disc_list(N, N // 2 - 2)
+    quat = synth.random_quats(n, rng)
+    shift = rng.normal(0, 1.0, size=(n, 2))
+    attr = synth.ctf_params(n, rng)
+    # real-space particle images: IFFT(CTF x slice x ramp) + white noise, written centre-origin as micrograph cut-outs are
+    ft = np.zeros((n, N, N // 2 + 1), np.complex64)
+    for l in range(n):
+        s = O.project(vol, 2 * N, 2, O.rotate3D(quat[l]), dl["iCol"], dl["iRow"])
+        s = s * O.ctf(pixelSize, *attr[l], N, dl["iCol"], dl["iRow"]) * O.translate(shift[l, 0], shift[l, 1], N, dl["iCol"], dl["iRow"])
+        ft[l].reshape(-1)[dl["iPxl"]] = s
+    rl = sfft.irfft2(ft, s=(N, N)).astype(np.float32)
+    rl += rng.normal(0, 0.5 * rl.std(), size=rl.shape).astype(np.float32)      # SNR 4 per pixel: a 32-pixel box must be
+                                                                               # this clean for poses to be informative
+    rl = rl * 37.0 + 100.0                                                     # arbitrary detector gain / offset
+    stack = str(tmp_path / "particles.mrcs")
+    capi.call("thx_mrc_write_stack", stack.encode(), rl.ctypes.data, N, n, pixelSize)
+    q0 = synth.perturb_quats(quat, 2, 0.03, rng)[:, 1]                        # starting poses: truth perturbed by ~2 degrees
+    thu = str(tmp_path / "particles.thu")
+    with open(thu, "w") as f:
+        f.write("# synthetic data set\n")
+        for l in range(n):
+            cols = ["%18.9f" % x for x in attr[l]] + ["%06d@particles.mrcs" % (l + 1), "mic.mrc", "%18.9f" % 0, "%18.9f" % 0]
+            cols += ["%6d" % (l % 3 + 1), "%6d" % 0] + ["%18.9f" % x for x in q0[l]] + ["%18.9f" % 0.0] * 3
+            cols += ["%18.9f" % x for x in (shift[l, 0] + rng.normal(0, 0.5), shift[l, 1] + rng.normal(0, 0.5))]
+            cols += ["%18.9f" % x for x in (1.0, 1.0, 1.0, 0.0, 0.0)]
+            f.write(" ".join(cols) + "\n")
+    # ---- read back through the C ABI ----
+    cnt, grp = C.c_int(), C.c_int()
+    capi.call("thx_thu_count", thu.encode(), C.byref(cnt), C.byref(grp))
+    assert (cnt.value, grp.value) == (n, 3)
+    ctf = (CtfAttr * n)()
+    paths = C.create_string_buffer(n * 64)
+    gid = np.zeros(n, np.int32); q_in = np.zeros((n, 4)); t_in = np.zeros((n, 2))
+    capi.call("thx_thu_load", thu.encode(), n, C.cast(ctf, C.c_void_p), C.cast(paths, C.c_void_p), 64, gid.ctypes.data, None,
+              q_in.ctypes.data, t_in.ctypes.data, None, None, None)
+    attr_in = np.array([[getattr(c, f) for f, _ in CtfAttr._fields_] for c in ctf], np.float32)
+    assert np.allclose(attr_in, attr, rtol=1e-6) and np.allclose(q_in, q0, atol=1e-9)
+    imgs = np.zeros((n, N, N), np.float32)
+    for l in range(n):                                                        # "000017@particles.mrcs" -> slice 16
+        name = paths.raw[l * 64:(l + 1) * 64].split(b"\0")[0].decode()
+        sl, fn = int(name.split("@")[0]) - 1, name.split("@")[1]
+        capi.call("thx_mrc_read_images", str(tmp_path / fn).encode(), sl, 1, imgs[l].ctypes.data)
+    assert np.array_equal(imgs, rl)
+    imgFT, oriFT, st = ops.init_images(T(imgs, dev), 0.45 * N)
+    assert abs(st["stdN"] - 1.0) < 0.05
+    # ---- refine ----
+    sh = RefineShard(N, n, dev, mLR=64, mLT=9, nPhase=3, mReco=20, pixelSize=pixelSize, transS=1.5,
+                     data=dict(imgOri=oriFT, attr=attr_in, quat=q_in, shift=t_in, gid=gid, ref=ref))
+    for it in range(2):
+        fsc = sh.iteration()
+    assert np.all(fsc[1:6] > 0.8), fsc[:8]                                    # the two half maps agree at low resolution
+    avg = 0.5 * (sh.last["maps"][0] + sh.last["maps"][1]).cpu().numpy()
+    fsc_truth = O.fsc(sfft.rfftn(avg).astype(np.complex64), sfft.rfftn(ref).astype(np.complex64), N, N // 2)
+    assert np.all(fsc_truth[1:6] > 0.8), fsc_truth[:8]                        # and with the map the particles came from
+    # the filter kept the poses: median angular error of the top pose stays within a few degrees
+    top = sh.pf_state["topR"].cpu().numpy()
+    ang = np.degrees(2 * np.arccos(np.clip(np.abs((top * quat).sum(1)), 0, 1)))
+    assert np.median(ang) < 8.0, np.median(ang)

@@ -72,7 +72,10 @@ class RefineShard:
 
     def __init__(self, N, nImg, device, rank=0, world=1, pf=2, mLR=125, mLT=9, nPhase=3, mReco=100, seed=1000,
                  batch=10240, pixelSize=1.32, snr=0.01, rL=2, ops=None, oracle_pixel_list=None, nGroup=8, groupSig=True,
-                 maskFrac=0.45, particle_filter=True, transS=2.0):
+                 maskFrac=0.45, particle_filter=True, transS=2.0, data=None):
+        """data (optional): particles read from files instead of synthesised here -- dict(imgOri complex64 device stack
+        [nImg][N][N/2+1] as Optimiser::initImg leaves _imgOri, attr float32 [nImg][7], quat [nImg][4], shift [nImg][2]
+        (initial poses, e.g. the .thu columns), gid int32 [nImg] 1-based group ids, ref float32 [N]^3 initial map)."""
         if ops is None:
             from . import ops as _ops
             ops = _ops
@@ -110,14 +113,19 @@ class RefineShard:
         e2m = torch.from_numpy(np.asarray([pos[(int(i), int(j))] for i, j in zip(pl["iCol"], pl["iRow"])],
                                           np.int64)).to(device)
         # ---- reference map and its projector volumes (one per local half) ----
-        self.ref = torch.from_numpy(synth.blob_map(N)).to(device)
+        self.ref = (torch.from_numpy(synth.blob_map(N)) if data is None else torch.as_tensor(data["ref"])).to(device).contiguous()
         self.plan = ops.RecoPlan(N, N, pf)
         v = self.plan.set_projectee(self.ref)
         self.vols = torch.stack([v] * len(self.halves)).contiguous()
         # ---- particles: pose, shift, CTF, noisy image on the pixel list ----
-        self.quat = synth.random_quats(nImg, rng)
-        self.shift = rng.normal(0, 2.0, size=(nImg, 2))
-        self.attr = torch.from_numpy(synth.ctf_params(nImg, rng)).to(device)
+        if data is None:
+            self.quat = synth.random_quats(nImg, rng)
+            self.shift = rng.normal(0, 2.0, size=(nImg, 2))
+            self.attr = torch.from_numpy(synth.ctf_params(nImg, rng)).to(device)
+        else:
+            self.quat = np.ascontiguousarray(np.asarray(data["quat"], np.float64).reshape(nImg, 4))
+            self.shift = np.ascontiguousarray(np.asarray(data["shift"], np.float64).reshape(nImg, 2))
+            self.attr = torch.as_tensor(np.asarray(data["attr"], np.float32).reshape(nImg, 7)).to(device).contiguous()
         # particle -> half-set.  With one rank both halves live here: the first ceil(n/2) particles are half 0, the rest
         # half 1 (contiguous ranges, so each half is one slice of every per-particle array); with world >= 2 the whole
         # shard belongs to half rank mod 2.
@@ -133,6 +141,9 @@ class RefineShard:
         self.maskRadiusPx = float(np.float32(maskFrac * N))
         self.nGroup, self.groupSig = nGroup, groupSig
         self.gid = rng.integers(1, nGroup + 1, nImg).astype(np.int32)          # Optimiser::_groupID (1-based, host)
+        if data is not None:
+            self.gid = np.ascontiguousarray(np.asarray(data["gid"], np.int32).reshape(nImg))
+            self.nGroup = nGroup = int(self.gid.max())
         self.gid0 = torch.from_numpy(self.gid.astype(np.int64) - 1).to(device)
         nc = N // 2 + 1
         iPxlM = torch.from_numpy(plM["iPxl"].astype(np.int64)).to(device)
@@ -146,7 +157,12 @@ class RefineShard:
         self.ctfM = ops.ctf(self.attr, pixelSize, self.iColM, self.iRowM, N)
         gen = torch.Generator(device=device)
         gen.manual_seed(seed + 31 * rank)
-        for b0 in range(0, nImg, batch):
+        if data is not None:
+            self.imgOri = torch.as_tensor(data["imgOri"]).to(device).contiguous()
+            flat = self.imgOri.view(nImg, -1)[:, iPxlM]
+            self.sigma2 = float((flat.abs() ** 2).mean().item()) / 2.0     # initial noise model: the images' own power
+            del flat
+        for b0 in range(0, nImg if data is None else 0, batch):
             b1 = min(nImg, b0 + batch)
             rot = ops.rotmat(torch.from_numpy(self.quat[b0:b1]).to(device))
             sl = ops.project(v, rot, self.iColM, self.iRowM, pf)
