@@ -642,3 +642,25 @@ def test_insert_then_reconstruct_matches_float_path(dev, monkeypatch):
         maps[plain] = sh.plans[0].reconstruct(sh.F[0].clone(), sh.T[0].clone(), sh.maxRadius, MAP=False, gridCorr=True)
     d = (maps["0"] - maps["1"]).abs().max().item() / maps["1"].abs().max().item()
     assert d <= 5e-4, d
+
+
+def test_expect_local_packed_projector_is_bit_identical(oracle, dev):
+    """the cell-packed projector layout changes where the 8 neighbours are read from, not what is computed"""
+    from thunder_amd import ops, synth
+    O = oracle
+    rng = np.random.default_rng(77)
+    N, P, nImg, nR, nT = 32, 64, 5, 70, 9
+    ref, vol, pl = make_case(O, N, rL=2)
+    im = make_images(O, vol, pl, N, nImg, rng)
+    q = synth.perturb_quats(im["quat"], nR, 0.05, rng)
+    rot = ops.rotmat(T(q.reshape(-1, 4), dev)).reshape(nImg, nR, 9)
+    tr = T(im["shift"][:, None, :] + rng.normal(0, 0.7, size=(nImg, nT, 2)), dev)
+    v2 = torch.stack([T(vol, dev), T(vol[::-1].copy(), dev)]).contiguous()          # two "classes"
+    volIdx = T(np.array([0, 1, 1, 0, 1], np.int32), dev)
+    args = (P, 2, N, T(pl["iCol"], dev), T(pl["iRow"], dev), T(im["dat"], dev), T(im["ctf"], dev), T(im["sigRcp"], dev), rot, tr)
+    a = ops.expect_local(v2, *args, volIdx=volIdx, want_logW=True)
+    cells = ops.pack_projector(v2, P)
+    assert cells.shape == (2, P, P, P // 2 + 1, 16)
+    b = ops.expect_local(cells, *args, volIdx=volIdx, want_logW=True, packed=True)
+    for k in ("wR", "wT", "wC", "baseLine", "logW"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k

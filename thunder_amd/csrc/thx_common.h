@@ -113,6 +113,35 @@ __device__ __forceinline__ float2 interp_ft(const float2* __restrict__ vol, int 
     return make_float2(re, c.conj ? -im : im);
 }
 
+// Cell-packed projector volume: for every cell origin (z, y, x) of the half grid the 8 corner values of its trilinear cell
+// stored contiguously -- k outer, j, i inner, 8 x complex64 = 64 bytes, 64-byte aligned -- so that one sample's gather is
+// ONE contiguous 64-byte read instead of four 16-byte reads from four different 128-byte lines.  8x the memory of the
+// volume (4.3 GB at P = 512, of 288 GB).  Same values, same operation order as interp_ft: bit-identical results.
+__device__ __forceinline__ float2 interp_ft_packed(const float4* __restrict__ cells, int P, float x, float y, float z)
+{
+    bool conj = false;
+    if (!(x >= 0.0f)) { x *= -1.0f; y *= -1.0f; z *= -1.0f; conj = true; }
+    const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float xd = x - fx, yd = y - fy, zd = z - fz;
+    const float vx[2] = {1.0f - xd, xd}, vy[2] = {1.0f - yd, yd}, vz[2] = {1.0f - zd, zd};
+    const long nc = P / 2 + 1;
+    const float4* c = cells + (((long)(z0 >= 0 ? z0 : z0 + P) * P + (y0 >= 0 ? y0 : y0 + P)) * nc + x0) * 4;
+    float re = 0.0f, im = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const float4 ab = c[k * 2 + j];   // (i = 0: .x .y), (i = 1: .z .w)
+            const float w0 = vx[0] * vy[j] * vz[k], w1 = vx[1] * vy[j] * vz[k];
+            re = re + ab.x * w0;
+            im = im + ab.y * w0;
+            re = re + ab.z * w1;
+            im = im + ab.w * w1;
+        }
+    return make_float2(re, conj ? -im : im);
+}
+
 // same for a real volume (T): conjugation is a no-op
 __device__ __forceinline__ float interp_ft_real(const float* __restrict__ vol, int P, float x, float y, float z)
 {

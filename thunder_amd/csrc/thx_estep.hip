@@ -195,6 +195,25 @@ __global__ __launch_bounds__(256) void k_logdvp(float* __restrict__ out, const f
 // sub-stream of the chunk's pixels; the per-pixel A_t / B table is staged in LDS once per chunk and
 // read back as wave-uniform broadcasts.  grid (nSplit, nImg, nD), block 256.
 // ---------------------------------------------------------------------------------------------
+// cell-packed copy of a projector volume (see interp_ft_packed): one thread per (cell, row pair)
+__global__ __launch_bounds__(256) void k_pack_cells(float4* __restrict__ cells, const float2* __restrict__ vol, int P)
+{
+    const long nc = P / 2 + 1;
+    const size_t n = (size_t)P * P * nc * 4;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int kj = (int)(e & 3);
+    const size_t cell = e >> 2;
+    const int x0 = (int)(cell % nc);
+    const size_t row = cell / nc;
+    const int yw = (int)(row % P), zw = (int)(row / P);
+    const int y1 = (yw + (kj & 1)) % P, z1 = (zw + (kj >> 1)) % P;
+    const float2* r = vol + ((size_t)z1 * P + y1) * nc;
+    const float2 a = r[x0];
+    const float2 b = x0 + 1 < nc ? r[x0 + 1] : make_float2(0.f, 0.f);
+    cells[e] = make_float4(a.x, a.y, b.x, b.y);
+}
+
 constexpr int kChunk = 256;  // pixels staged per LDS table
 
 struct ExpectLocalArgs {
@@ -218,7 +237,7 @@ struct ExpectLocalArgs {
     float dbgScale;  // 1 in production; THX_EXPECT_DEBUG shrinks the sampled region (cache-resident) for profiling
 };
 
-template <int NT>
+template <int NT, bool PACKED>
 __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -231,7 +250,7 @@ __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
     const int split = blockIdx.x, img = blockIdx.y, d = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.P;
-    const float2* vol = a.volumes + (size_t)(a.volIdx ? a.volIdx[img] : 0) * ((size_t)P * P * (P / 2 + 1));
+    const float2* vol = a.volumes + (size_t)(a.volIdx ? a.volIdx[img] : 0) * ((size_t)P * P * (P / 2 + 1)) * (PACKED ? 8 : 1);
     const float2* dat = a.datP + (size_t)img * a.nPxl;
     const float* ctf = a.ctfP + ((size_t)img * a.nD + d) * a.nPxl;
     const float* sig = a.sigRcpP + (size_t)img * a.nPxl;
@@ -296,7 +315,8 @@ __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
                     const float y = (float)(m1 * nx + m4 * ny) * a.dbgScale;
                     const float z = (float)(m2 * nx + m5 * ny) * a.dbgScale;
                     float2 q = make_float2(0.f, 0.f);
-                    if (coord_in_grid(x, y, z, P)) q = interp_ft(vol, P, x, y, z);
+                    if (coord_in_grid(x, y, z, P))
+                        q = PACKED ? interp_ft_packed(reinterpret_cast<const float4*>(vol), P, x, y, z) : interp_ft(vol, P, x, y, z);
                     accB = fmaf(sB[e], fmaf(q.x, q.x, q.y * q.y), accB);
                     const float2* Ap = sA + e * NT;
 #pragma unroll
@@ -1045,7 +1065,7 @@ static int launch_expect_win(ExpectLocalArgs a, hipStream_t st, ExpectFinalArgs&
 }
 
 template <int NT>
-static int launch_expect_local(const ExpectLocalArgs& a, hipStream_t st)
+static int launch_expect_local(const ExpectLocalArgs& a, hipStream_t st, bool packed)
 {
     const int nRG0 = (a.nR + 63) >> 6;
     const int nRGp = nRG0 >= 4 ? 4 : (nRG0 >= 2 ? 2 : 1);
@@ -1053,7 +1073,10 @@ static int launch_expect_local(const ExpectLocalArgs& a, hipStream_t st)
     size_t stage = (size_t)kChunk * NT * sizeof(float2) + kChunk * (sizeof(float) + 2 * sizeof(int)) + 4 * sizeof(float);
     size_t red = (size_t)nSub * (NT + 1) * 64 * nRGp * sizeof(float);
     size_t lds = stage > red ? stage : red;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expect_local<NT>), dim3(a.nSplit, a.nImg, a.nD), dim3(256), lds, st, a);
+    if (packed)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expect_local<NT, true>), dim3(a.nSplit, a.nImg, a.nD), dim3(256), lds, st, a);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expect_local<NT, false>), dim3(a.nSplit, a.nImg, a.nD), dim3(256), lds, st, a);
     THX_LAUNCH_CHECK();
     return 0;
 }
@@ -1203,11 +1226,11 @@ size_t thx_expect_local_workspace(int nImg, int nR, int nT, int nD)
     return ((size_t)nImg * nD * nSplit * nT * nRpad + (size_t)nImg * nD * nSplit) * sizeof(float) + 256;
 }
 
-int thx_expect_local_dev(const float* volumes, const int* volIdx, int vdim, int pf, int idim, const int* iCol,
-                         const int* iRow, int nPxl, int nImg, const float* datP, const float* ctfP,
-                         const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
-                         const double* pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR,
-                         float* wT, float* wD, float* baseLine, float* logW, void* workspace, void* stream)
+static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, int pf, int idim, const int* iCol,
+                             const int* iRow, int nPxl, int nImg, const float* datP, const float* ctfP,
+                             const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
+                             const double* pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR,
+                             float* wT, float* wD, float* baseLine, float* logW, void* workspace, void* stream, bool packed)
 {
     if (nImg <= 0) return 0;
     THX_REQUIRE(volumes && iCol && iRow && datP && ctfP && sigRcpP && rotMat && trans, "NULL input pointer");
@@ -1238,16 +1261,51 @@ int thx_expect_local_dev(const float* volumes, const int* volIdx, int vdim, int 
     // THX_EXPECT_KERNEL: "win" = volume-window kernel (LDS-staged sub-volumes, robust to the spread of the rotations),
     // "rot" = rotation-major kernel gathering from global memory (fastest when the rotations of an image nearly coincide)
     const char* kv = getenv("THX_EXPECT_KERNEL");
-    const bool winK = kv && kv[0] == 'w' && nT <= 16 && nR <= 256;
+    const bool winK = kv && kv[0] == 'w' && nT <= 16 && nR <= 256 && !packed;
     if (winK) rc = nT <= 9 ? launch_expect_win<9>(a, st, f) : launch_expect_win<16>(a, st, f);
-    else if (nT <= 9) rc = launch_expect_local<9>(a, st);
-    else if (nT <= 16) rc = launch_expect_local<16>(a, st);
-    else rc = launch_expect_local<32>(a, st);
+    else if (nT <= 9) rc = launch_expect_local<9>(a, st, packed);
+    else if (nT <= 16) rc = launch_expect_local<16>(a, st, packed);
+    else rc = launch_expect_local<32>(a, st, packed);
     if (rc) return rc;
     f.nR = nR; f.nRpad = a.nRpad; f.nT = nT; f.nD = nD;
     f.pC = pC; f.pR = pR; f.pT = pT; f.pD = pD; f.wC = wC; f.wR = wR; f.wT = wT; f.wD = wD; f.baseLine = baseLine;
     f.logW = logW;
     hipLaunchKernelGGL(k_expect_final, dim3(nImg), dim3(256), (size_t)nD * nT * nR * sizeof(float), st, f);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_expect_local_dev(const float* volumes, const int* volIdx, int vdim, int pf, int idim, const int* iCol,
+                         const int* iRow, int nPxl, int nImg, const float* datP, const float* ctfP,
+                         const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
+                         const double* pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR,
+                         float* wT, float* wD, float* baseLine, float* logW, void* workspace, void* stream)
+{
+    return expect_local_impl(volumes, volIdx, vdim, pf, idim, iCol, iRow, nPxl, nImg, datP, ctfP, sigRcpP, rotMat, nR, trans, nT,
+                             nD, pC, pR, pT, pD, wC, wR, wT, wD, baseLine, logW, workspace, stream, false);
+}
+
+int thx_expect_local_packed_dev(const float* cells, const int* volIdx, int vdim, int pf, int idim, const int* iCol,
+                                const int* iRow, int nPxl, int nImg, const float* datP, const float* ctfP,
+                                const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
+                                const double* pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR,
+                                float* wT, float* wD, float* baseLine, float* logW, void* workspace, void* stream)
+{
+    return expect_local_impl(cells, volIdx, vdim, pf, idim, iCol, iRow, nPxl, nImg, datP, ctfP, sigRcpP, rotMat, nR, trans, nT,
+                             nD, pC, pR, pT, pD, wC, wR, wT, wD, baseLine, logW, workspace, stream, true);
+}
+
+size_t thx_projector_packed_bytes(int vdim) { return (size_t)vdim * vdim * (vdim / 2 + 1) * 64; }
+
+int thx_projector_pack_dev(float* cells, const float* volumes, int vdim, int nVol, void* stream)
+{
+    THX_REQUIRE(cells && volumes && vdim > 0 && nVol >= 0, "bad arguments");
+    const size_t nCell = (size_t)vdim * vdim * (vdim / 2 + 1);
+    for (int v = 0; v < nVol; v++) {
+        hipLaunchKernelGGL(k_pack_cells, dim3((unsigned)((nCell * 4 + 255) / 256)), dim3(256), 0, as_stream(stream),
+                           reinterpret_cast<float4*>(cells) + (size_t)v * nCell * 4,
+                           reinterpret_cast<const float2*>(volumes) + (size_t)v * nCell, vdim);
+    }
     THX_LAUNCH_CHECK();
     return 0;
 }

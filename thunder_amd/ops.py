@@ -132,11 +132,21 @@ class ExpectLocalResult:
     __slots__ = ("wC", "wR", "wT", "wD", "baseLine", "logW")
 
 
+def pack_projector(volumes, vdim):
+    """cell-packed copies of [nVol] projector volumes (thx_projector_pack_dev): float32 [nVol][P][P][P/2+1][16]"""
+    _chk(volumes, _C64, "volumes")
+    nVol = volumes.numel() // (vdim * vdim * (vdim // 2 + 1))
+    cells = torch.empty((nVol, vdim, vdim, vdim // 2 + 1, 16), dtype=_F32, device=volumes.device)
+    capi.call("thx_projector_pack_dev", ptr(cells), ptr(volumes), vdim, nVol, stream_ptr())
+    return cells
+
+
 def expect_local(volumes, vdim, pf, idim, iCol, iRow, datP, ctfP, sigRcpP, rotMat, trans, nD=1, volIdx=None, pC=None,
-                 pR=None, pT=None, pD=None, want_logW=False, workspace=None):
-    """One particle-filter phase for a batch of images (src/Optimiser.cpp:1225-1406); see thunder_amd.h."""
+                 pR=None, pT=None, pD=None, want_logW=False, workspace=None, packed=False):
+    """One particle-filter phase for a batch of images (src/Optimiser.cpp:1225-1406); see thunder_amd.h.
+    packed=True: `volumes` is the output of pack_projector."""
     dev = datP.device
-    _chk(volumes, _C64, "volumes"); _chk(datP, _C64, "datP"); _chk(ctfP, _F32, "ctfP"); _chk(sigRcpP, _F32, "sigRcpP")
+    _chk(volumes, _F32 if packed else _C64, "volumes"); _chk(datP, _C64, "datP"); _chk(ctfP, _F32, "ctfP"); _chk(sigRcpP, _F32, "sigRcpP")
     _chk(rotMat, _F64, "rotMat"); _chk(trans, _F64, "trans")
     nImg, nPxl = datP.shape[0], datP.shape[1]
     nR = rotMat.numel() // (9 * nImg)
@@ -158,7 +168,7 @@ def expect_local(volumes, vdim, pf, idim, iCol, iRow, datP, ctfP, sigRcpP, rotMa
     need = capi.load().thx_expect_local_workspace(nImg, nR, nT, nD)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=dev)
-    capi.call("thx_expect_local_dev", ptr(volumes), ptr(volIdx), vdim, pf, idim, ptr(iCol), ptr(iRow), nPxl, nImg,
+    capi.call("thx_expect_local_packed_dev" if packed else "thx_expect_local_dev", ptr(volumes), ptr(volIdx), vdim, pf, idim, ptr(iCol), ptr(iRow), nPxl, nImg,
               ptr(datP), ptr(ctfP), ptr(sigRcpP), ptr(rotMat), nR, ptr(trans), nT, nD, ptr(pC), ptr(pR), ptr(pT),
               ptr(pD), ptr(res.wC), ptr(res.wR), ptr(res.wT), ptr(res.wD), ptr(res.baseLine), ptr(res.logW),
               ptr(workspace), stream_ptr())

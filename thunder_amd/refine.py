@@ -117,6 +117,9 @@ class RefineShard:
         self.plan = ops.RecoPlan(N, N, pf)
         v = self.plan.set_projectee(self.ref)
         self.vols = torch.stack([v] * len(self.halves)).contiguous()
+        # cell-packed copies for the E-step gathers (8x the memory, one contiguous 64-byte read per sample)
+        self.use_packed = os.environ.get("THX_PACKED", "1") == "1"
+        self.cells = None
         # ---- particles: pose, shift, CTF, noisy image on the pixel list ----
         if data is None:
             self.quat = synth.random_quats(nImg, rng)
@@ -304,6 +307,8 @@ class RefineShard:
         wR = torch.empty((n, self.mLR), dtype=torch.float32, device=self.dev)
         wT = torch.empty((n, self.mLT), dtype=torch.float32, device=self.dev)
         vol = self.vols[vi:vi + 1]
+        if self.use_packed and self.cells is None:
+            self.cells = ops.pack_projector(self.vols, self.P)
         st = self.pf_state if self.use_pf else None
         for p in range(self.nPhase):
             for b0 in range(lo, hi, self.batch):
@@ -323,9 +328,9 @@ class RefineShard:
                 if timed:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                r = ops.expect_local(vol, self.P, self.pf, self.N, self.iCol, self.iRow, self.datP[b0:b1],
-                                     self.ctfP[b0:b1], self.sigRcpP[b0:b1], rotB, tranB, nD=1, pR=pR, pT=pT,
-                                     workspace=self.ws[vi])
+                r = ops.expect_local(self.cells[vi:vi + 1] if self.use_packed else vol, self.P, self.pf, self.N, self.iCol,
+                                     self.iRow, self.datP[b0:b1], self.ctfP[b0:b1], self.sigRcpP[b0:b1], rotB, tranB, nD=1,
+                                     pR=pR, pT=pT, workspace=self.ws[vi], packed=self.use_packed)
                 if timed:
                     e1.record()
                     self.expect_ms.append((e0, e1, b1 - b0))
@@ -397,6 +402,8 @@ class RefineShard:
         m = self.plans[vi].reconstruct(self.F[vi], self.T[vi], self.maxRadius, FSC=fsc, joinHalf=False, MAP=True,
                                        gridCorr=True)
         self.vols[vi] = self.plans[vi].set_projectee(m)   # Model::refreshProj
+        if self.use_packed and self.cells is not None:
+            self.cells[vi] = self.ops.pack_projector(self.vols[vi:vi + 1], self.P)[0]
         return m
 
     def em_stage(self, vi, timed=False):
@@ -508,6 +515,7 @@ class RefineShard:
         v = self.plan.set_projectee(self.ref)
         for vi in range(self.vols.shape[0]):
             self.vols[vi] = v
+        self.cells = None   # rebuilt on the next expectation
         self.offset.zero_()
         for t, t0 in zip(self.tranP, self.tranP0):
             t.copy_(t0)
