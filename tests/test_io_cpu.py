@@ -141,3 +141,17 @@ def test_ingestion_oracle_statistics(oracle):
     m = np.zeros_like(x)
     O.lib().orc_soft_mask_bg(m.ctypes.data_as(O.c_f), x.ctypes.data_as(O.c_f), N, C.c_float(r), C.c_float(6.0), C.c_float(0))
     assert np.array_equal(m, x * O.soft_mask(N, r, 6.0)) or np.abs(m - x * O.soft_mask(N, r, 6.0)).max() < 1e-6
+
+
+def test_cpp_io_mirrors(tmp_path, lib):
+    """ImageFile / Database mirrors (include/thunder_amd/ImageFile.hpp) compiled with g++ against the C ABI: host only"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "io_rt")
+    libdir = os.path.join(root, "thunder_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "io_roundtrip.cpp"), "-o", exe, "-L" + libdir, "-lthunder_amd",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), (out.stdout, out.stderr[-2000:])
