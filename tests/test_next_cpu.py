@@ -132,3 +132,22 @@ def test_sigma_accum_final(oracle):
     sigM, sigN, svd = O.sigma_accum(spec, gid, nGroup, False)
     sig, _ = O.sigma_final(sigM, sigN, svd, 100.0, 64, 1.32, False)
     assert np.array_equal(sig[0], sig[1]) and np.array_equal(sig[0], sig[2]) and sigM[0, rSig] == nImg
+
+
+def test_golden_regression_next(oracle):
+    """the oracle reproduces the committed vectors of tests/golden/oracle_next_n16.npz (see make_golden_next.py)"""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden_next as G
+    want = np.load(os.path.join(here, "golden", "oracle_next_n16.npz"))
+    got = G.compute()
+    assert sorted(got.keys()) == sorted(want.files)
+    for k in want.files:
+        a, b = np.asarray(got[k]), want[k]
+        assert a.shape == b.shape, k
+        if a.dtype.kind in "iu":
+            assert np.array_equal(a, b), k
+        else:   # same machine arithmetic up to libm / FFT-library rounding
+            assert np.allclose(a, b, rtol=2e-6, atol=1e-7 * max(1.0, float(np.abs(b).max()))), k

@@ -339,3 +339,54 @@ def test_end_to_end_from_files(oracle, dev, tmp_path):
     top = sh.pf_state["topR"].cpu().numpy()
     ang = np.degrees(2 * np.arccos(np.clip(np.abs((top * quat).sum(1)), 0, 1)))
     assert np.median(ang) < 8.0, np.median(ang)
+
+
+def test_against_committed_golden_next(dev):
+    """the HIP path against the committed fixtures tests/golden/oracle_next_n16.npz (no oracle call on this path)"""
+    import os
+    from thunder_amd import capi, ops
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_next_n16.npz"))
+    N, P = 16, 32
+    # re-mask, ramps
+    d = T(g["remask_in"], dev)
+    ops.remask(d, float(np.float32(6.6) / np.float32(1.32)), 6.0)
+    assert np.abs(d.cpu().numpy() - g["remask_out"]).max() <= 5e-6 * np.abs(g["remask_out"]).max()
+    tr = T(np.array([[1.25, -0.75]]), dev)
+    got = ops.translate_image(T(g["remask_in"][:1], dev), tr).cpu().numpy()[0]
+    assert np.all(np.abs(got - g["translate_image"]) <= 5e-7 * np.abs(g["remask_in"][0]) + 1e-30)
+    # sigma update
+    attr = ops.ctf_attr_tensor(g["sig_attr"], dev)
+    vol = None
+    import thunder_amd.synth as synth
+    plan = ops.RecoPlan(N, N, 2)
+    volD = plan.set_projectee(T(synth.blob_map(N, seed=3, nblob=6), dev))
+    spec = ops.sigma_spectra(volD, P, 2, N // 2 - 2, N // 2 - 1, T(g["sig_img"], dev), T(g["sig_imgOri"], dev), attr, 1.32,
+                             T(g["sig_rot"], dev), T(g["sig_tran"], dev), T(g["sig_offset"], dev))
+    # the projector volume here comes from rocFFT, the fixture's from pocketfft: 1e-4 on the spectra
+    assert np.all(np.abs(spec.cpu().numpy() - g["sig_spec"]) <= 2e-4 * np.abs(g["sig_spec"]) + 1e-9)
+    acc = tuple(torch.zeros((2, N // 2), dtype=torch.float32, device=dev) for _ in range(3))
+    ops.sigma_accum(acc, T(g["sig_spec"], dev), g["sig_gid"], True)
+    for a, k in zip(acc, ("sigM", "sigN", "svd")):
+        assert np.allclose(a.cpu().numpy(), g[k], rtol=2e-6)
+    sig, rcp = ops.sigma_final(acc, 9.0, N, 1.32, True)
+    assert np.allclose(sig.cpu().numpy(), g["sig"], rtol=5e-6) and np.allclose(rcp.cpu().numpy(), g["sigRcp"], rtol=5e-6)
+    # defocus-search rows
+    pl_attr = ops.ctf_attr_tensor(g["pre_attr"], dev)
+    from thunder_amd.refine import pixel_list
+    pl = pixel_list(N, N // 2 - 2, 2)
+    fq, de, k1, k2 = ops.expect_precal(pl_attr, 1.32, T(pl["iCol"], dev), T(pl["iRow"], dev), N)
+    assert np.array_equal(fq.cpu().numpy(), g["pre_freq"]) and np.array_equal(k1.cpu().numpy(), g["pre_k1"])
+    assert np.all(np.abs(de.cpu().numpy() - g["pre_def"]) <= 4e-7 * np.abs(g["pre_def"]))
+    rows = ops.ctf_dsearch(fq, T(g["pre_def"], dev), k1, k2, pl_attr, T(np.tile(g["pre_d"], (2, 1)), dev)).cpu().numpy()
+    assert np.abs(rows[0] - g["pre_rows"]).max() <= 2e-5
+    # ingestion
+    iF, oF, st = ops.init_images(T(g["ing_raw"], dev), 5.5)
+    want = g["ing_stats"]
+    got_st = np.array([st[k] for k in ("mean", "stdN", "stdD", "stdS", "stdStdN")])
+    assert np.all(np.abs(got_st - want) <= 2e-5 * np.maximum(1.0, np.abs(want)))
+    assert np.abs(oF.cpu().numpy() - g["ing_ori"]).max() <= 2e-5 * np.abs(g["ing_ori"]).max()
+    # particle-filter statistics
+    A, mean, k, wb = ops.pf_acg_stats(T(g["pf_q"][None], dev))
+    assert np.abs(A.cpu().numpy()[0] - g["pf_A"]).sum() <= 2e-3
+    assert np.allclose(k.cpu().numpy()[0], g["pf_k"], rtol=5e-2) and np.allclose(wb.cpu().numpy()[0], g["pf_wbal"], rtol=5e-2)
+    plan.close()
