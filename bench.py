@@ -86,6 +86,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook: THX_BENCH_ONE_DEVICE=1 runs every rank on GPU 0 with the gloo backend, so the multi-rank control flow
+    # (half-set groups, F/T all-reduce, half-map exchange, max-over-ranks timing) can be exercised on a 1-GPU box
+    one_dev = os.environ.get("THX_BENCH_ONE_DEVICE", "0") == "1"
+    if one_dev:
+        local = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -93,7 +98,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if one_dev:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from thunder_amd import capi
     from thunder_amd.refine import RefineShard

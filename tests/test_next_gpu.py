@@ -390,3 +390,28 @@ def test_against_committed_golden_next(dev):
     assert np.abs(A.cpu().numpy()[0] - g["pf_A"]).sum() <= 2e-3
     assert np.allclose(k.cpu().numpy()[0], g["pf_k"], rtol=5e-2) and np.allclose(wb.cpu().numpy()[0], g["pf_wbal"], rtol=5e-2)
     plan.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_multirank_bench_control_flow_on_one_device(dev, world):
+    """bench.py under torch.distributed.run with every rank on GPU 0 (gloo instead of RCCL: THX_BENCH_ONE_DEVICE=1):
+    half-set groups, the F/T all-reduce within a half (world 4), the half-map exchange and the max-over-ranks timing"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, THX_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "1",
+           "--warmup", "1", "--box", "32", "--particles", "300", "--mReco", "20"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 prints ONE line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == world and j["scaling"] == "weak" and j["value"] > 0 and j["cpu_baseline"] is None
+    assert abs(j["value"] - 300 * world / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+    assert all(f > 0.5 for f in j["fsc_half_maps"][1:4]), j["fsc_half_maps"]
