@@ -422,6 +422,118 @@ int thx_ExpectGlobal3D_host(const float* rotP, const float* traP, const float* d
  * ctfFT = imgNum host pointers (&_ctf[l][0]), each idim*(idim/2+1) complex64. */
 int thx_GCTFinit_host(float* const* ctfFT, const thx_ctf_attr* ctfAttr, float pixelSize, int idim, int imgNum);
 
+/* ---------------------------------------------------------------------------------------------
+ * The remaining 3-D entry points of gpu/interface/Interface.h, at the reference's own (per-image / per-stage)
+ * granularity, so that a replacement Interface.cpp forwards one to one and src/Optimiser.cpp / src/Reconstructor.cpp
+ * stay untouched.  They run the same kernels as the batched calls above on one image / one stage at a time;
+ * use the batched calls for throughput.  2-D mode twins (ExpectGlobal2D, ExpectLocalV2D/PreI2D, InsertI2D,
+ * ExposePT2D/WT2D/PF2D/CorrF2D) are out of scope.
+ * ------------------------------------------------------------------------------------------- */
+
+/* ManagedArrayTexture (gpu/include/ManagedArrayTexture.h: Init(mode, vdim, gpuIdx), getDeviceId) and ManagedCalPoint
+ * (gpu/include/ManagedCalPoint.h: Init(mode, cSearch, gpuIdx, nR, nT, mD, npxl)) as opaque handles; mode 1 = MODE_3D. */
+typedef struct thx_texture thx_texture;
+typedef struct thx_calpoint thx_calpoint;
+int thx_texture_create(thx_texture** out, int mode, int vdim, int gpuIdx);
+int thx_texture_destroy(thx_texture* t);
+int thx_texture_device(const thx_texture* t);
+int thx_calpoint_create(thx_calpoint** out, int mode, int cSearch, int gpuIdx, int nR, int nT, int mD, int npxl);
+int thx_calpoint_destroy(thx_calpoint* c);
+
+/* void ExpectPreidx(int gpuIdx, int** deviCol, int** deviRow, int* iCol, int* iRow, int npxl)      Interface.h:18-23 */
+int thx_ExpectPreidx_host(int gpuIdx, int** deviCol, int** deviRow, const int* iCol, const int* iRow, int npxl);
+/* void ExpectPrefre(int gpuIdx, RFLOAT** devfreQ, RFLOAT* freQ, int npxl)                           Interface.h:26-29 */
+int thx_ExpectPrefre_host(int gpuIdx, float** devfreQ, const float* freQ, int npxl);
+/* void ExpectLocalIn(gpuIdx, Complex** devdatP, RFLOAT** devctfP, RFLOAT** devdefO, RFLOAT** devsigP, nPxl, cpyNumL,
+ *                    searchType)                                                                    Interface.h:31-38 */
+int thx_ExpectLocalIn_host(int gpuIdx, float** devdatP, float** devctfP, float** devdefO, float** devsigP, int nPxl,
+                           int cpyNumL, int searchType);
+/* void ExpectLocalV3D(int gpuIdx, ManagedArrayTexture* mgr, Complex* volume, int vdim)              Interface.h:45-48 */
+int thx_ExpectLocalV3D_host(int gpuIdx, thx_texture* mgr, const float* volume, int vdim);
+/* void ExpectLocalP(gpuIdx, devdatP, devctfP, devdefO, devsigP, datP, ctfP, defO, sigP, threadId, imgId, npxl, cSearch)
+ *                                                                                                   Interface.h:50-62 */
+int thx_ExpectLocalP_host(int gpuIdx, float* devdatP, float* devctfP, float* devdefO, float* devsigP, const float* datP,
+                          const float* ctfP, const float* defO, const float* sigP, int threadId, int imgId, int npxl,
+                          int cSearch);
+/* void ExpectLocalHostA(gpuIdx, RFLOAT** wC, wR, wT, wD, double** oldR, oldT, oldD, trans, rot, dpara, mR, mT, mD,
+ *                       cSearch)                                                                    Interface.h:64-78 */
+int thx_ExpectLocalHostA_host(int gpuIdx, float** wC, float** wR, float** wT, float** wD, double** oldR, double** oldT,
+                              double** oldD, double** trans, double** rot, double** dpara, int mR, int mT, int mD,
+                              int cSearch);
+/* void ExpectLocalRTD(gpuIdx, ManagedCalPoint* mcp, oldR, oldT, oldD, trans, rot, dpara)            Interface.h:80-87
+ * rot = nR quaternions, trans = nT shifts, oldR/oldT/oldD = Particle::wR/wT/wD. */
+int thx_ExpectLocalRTD_host(int gpuIdx, thx_calpoint* mcp, const double* oldR, const double* oldT, const double* oldD,
+                            const double* trans, const double* rot, const double* dpara);
+/* void ExpectLocalPreI3D(gpuIdx, datShift, mgr, mcp, devdefO, devfreQ, deviCol, deviRow, phaseShift, conT, k1, k2, pf,
+ *                        idim, vdim, npxl, interp)                                                  Interface.h:107-123 */
+int thx_ExpectLocalPreI3D_host(int gpuIdx, int datShift, const thx_texture* mgr, thx_calpoint* mcp, const float* devdefO,
+                               const float* devfreQ, const int* deviCol, const int* deviRow, float phaseShift, float conT,
+                               float k1, float k2, int pf, int idim, int vdim, int npxl, int interp);
+/* void ExpectLocalM(gpuIdx, datShift, mcp, devdatP, devctfP, devsigP, wC, wR, wT, wD, oldC, npxl)   Interface.h:125-139
+ * one particle-filter phase of one image (src/Optimiser.cpp:1225-1406): wC [1], wR [nR], wT [nT], wD [mD or 1] on the
+ * host; results equal to thx_expect_local_dev on a batch of one. */
+int thx_ExpectLocalM_host(int gpuIdx, int datShift, thx_calpoint* mcp, const float* devdatP, const float* devctfP,
+                          const float* devsigP, float* wC, float* wR, float* wT, float* wD, double oldC, int npxl);
+/* void ExpectLocalHostF(...)                                                                        Interface.h:141-152 */
+int thx_ExpectLocalHostF_host(int gpuIdx, float** wC, float** wR, float** wT, float** wD, double** oldR, double** oldT,
+                              double** oldD, double** trans, double** rot, double** dpara, int cSearch);
+/* void ExpectLocalFin(gpuIdx, devdatP, devctfP, devdefO, devfreQ, devsigP, cSearch)                 Interface.h:154-160 */
+int thx_ExpectLocalFin_host(int gpuIdx, float** devdatP, float** devctfP, float** devdefO, float** devfreQ, float** devsigP,
+                            int cSearch);
+/* void ExpectFreeIdx(int gpuIdx, int** deviCol, int** deviRow)                                      Interface.h:162-164 */
+int thx_ExpectFreeIdx_host(int gpuIdx, int** deviCol, int** deviRow);
+
+/* Staged Reconstructor::reconstructG (src/Reconstructor.cpp:1835-2330).  T3D / W3D are the REAL copies the reference
+ * makes (volumeT / volumeW, :1858-1880), dim = the FT grid's edge (_T3D.nSlcFT()), all arrays on the host. */
+
+/* void ExposePT(gpuIdx, RFLOAT* T3D, maxRadius, pf, dim, vec FSC, bool joinHalf, const int wienerF)  Interface.h:337-344
+ * T /= FSC'(shell) between wienerF*pf and maxRadius*pf (the MAP branch, src/Reconstructor.cpp:1242-1270). */
+int thx_ExposePT_host(int gpuIdx, float* T3D, int maxRadius, int pf, int dim, const float* FSC, int nFSC, int joinHalf,
+                      int wienerF);
+/* void ExposeWT(gpuIdx, T3D, W3D, TabFunction& kernelRL, nf, maxRadius, pf, dim, maxIter, minIter, size)
+ *                                                                                                   Interface.h:438-448
+ * the whole gridding-weight iteration on the device (FFTs by rocFFT); tab = kernelRL.getData(), tabSize entries of the
+ * 1e5-step table on [0, 1]; size = _N.  W3D receives the balanced weights. */
+int thx_ExposeWT_host(int gpuIdx, const float* T3D, float* W3D, const float* tab, int tabSize, float nf, int maxRadius,
+                      int pf, int dim, int maxIter, int minIter, int size);
+/* void ExposeWT(gpuIdx, T3D, W3D, maxRadius, pf, dim)  (no grid correction)                          Interface.h:457-462 */
+int thx_ExposeWT_plain_host(int gpuIdx, const float* T3D, float* W3D, int maxRadius, int pf, int dim);
+/* AllocDevicePoint / HostDeviceInit / ExposeC / ExposeForConvC / ExposeWC / FreeDevHostPoint        Interface.h:358-436
+ * the same iteration with the two FFTs left to the caller (src/Reconstructor.cpp:1985-2087).  stream[] receives
+ * streamNum opaque stream handles.  devDiff / devCount (RECONSTRUCTOR_CHECK_C_AVERAGE) come back NULL: the reference
+ * is configured for RECONSTRUCTOR_CHECK_C_MAX (include/Config.h:101-103). */
+int thx_AllocDevicePoint_host(int gpuIdx, float** dev_C, float** dev_W, float** dev_T, float** dev_tab, float** devDiff,
+                              float** devMax, int** devCount, void** stream, int streamNum, int tabSize, int dim);
+int thx_HostDeviceInit_host(int gpuIdx, const float* T3D, const float* tab, float* dev_W, float* dev_T, float* dev_tab,
+                            void** stream, int streamNum, int tabSize, int maxRadius, int pf, int dim);
+/* C3D (complex, FT layout) = T * W */
+int thx_ExposeC_host(int gpuIdx, float* C3D, float* dev_C, const float* dev_T, float* dev_W, void** stream, int streamNum,
+                     int dim);
+/* C3D_rl (real, dim^3, after the caller's inverse FFT incl. its 1/size) *= kernelRL(|x|^2 / (pf*size)^2) / nf;
+ * step = kernelRL.getStep(), dim = C3D.nSlcRL() (both read from the objects in the reference's wrapper) */
+int thx_ExposeForConvC_host(int gpuIdx, float* C3D_rl, float* dev_C, const float* dev_tab, void** stream, float step,
+                            float nf, int streamNum, int tabSize, int pf, int size, int dim);
+/* C3D (complex, after the caller's forward FFT): W /= max(|C|, 1e-6) in the sphere; *diffC = max ||C| - 1| there */
+int thx_ExposeWC_host(int gpuIdx, const float* C3D, float* dev_C, float* cmax, float* dev_W, float* devMax, void** stream,
+                      float* diffC, int streamNum, int maxRadius, int pf, int dim);
+/* copies dev_W into volumeW, then frees everything AllocDevicePoint made */
+int thx_FreeDevHostPoint_host(int gpuIdx, float** dev_C, float** dev_W, float** dev_T, float** dev_tab, float** devDiff,
+                              float** devMax, int** devCount, void** stream, float* volumeW, int streamNum, int dim);
+/* void ExposePFW(gpuIdx, Volume& padDst, Volume& F3D, RFLOAT* W3D, maxRadius, pf)                   Interface.h:472-477
+ * padDst (complex, pdim grid) = F * W inside the sphere, 0 elsewhere; fdim = F3D's grid. */
+int thx_ExposePFW_host(int gpuIdx, float* padDst, const float* F3D, const float* W3D, int maxRadius, int pf, int pdim,
+                       int fdim);
+/* void ExposePF(gpuIdx, Volume& padDst, Volume& padDstR, Volume& F3D, RFLOAT* W3D, maxRadius, pf)   Interface.h:479-485
+ * as ExposePFW, then the inverse FFT (incl. 1/size) into padDstR (real, pdim^3); padDst may be NULL. */
+int thx_ExposePF_host(int gpuIdx, float* padDst, float* padDstR, const float* F3D, const float* W3D, int maxRadius, int pf,
+                      int pdim, int fdim);
+/* void ExposeCorrF(gpuIdx, Volume& dst, RFLOAT* mkbRL, RFLOAT nf)                                   Interface.h:493-496
+ * dst (real, dim^3) /= mkbRL[|k|][|j|][|i|] (the RECONSTRUCTOR_TRILINEAR_KERNEL table, include/Config.h:97). */
+int thx_ExposeCorrF_host(int gpuIdx, float* dst, const float* mkbRL, float nf, int dim);
+/* void ExposeCorrF(gpuIdx, Volume& dstN, Volume& dst, RFLOAT* mkbRL, RFLOAT nf)                     Interface.h:498-502
+ * the same correction of dstN followed by the forward FFT into dstFT (complex, dim grid). */
+int thx_ExposeCorrF_fft_host(int gpuIdx, const float* dstN, float* dstFT, const float* mkbRL, float nf, int dim);
+
 #ifdef __cplusplus
 }
 #endif

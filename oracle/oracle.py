@@ -210,6 +210,18 @@ def kernelRL_table(a=1.9, alpha=15.0, n=100000):
     return tab
 
 
+def mkb_rl(r, a=1.9, alpha=15.0):
+    """MKB_RL, src/Functions/Functions.cpp (nf = MKB_RL(0, a, alpha), src/Reconstructor.cpp:2600)"""
+    return float(lib().orc_MKB_RL(C.c_float(r), C.c_float(a), C.c_float(alpha)))
+
+
+def tik_rl(r):
+    """TIK_RL, src/Functions/Functions.cpp:236-239, elementwise on a float32 array"""
+    L = lib()
+    r = f32(r).reshape(-1)
+    return np.array([L.orc_TIK_RL(C.c_float(float(x))) for x in r], np.float32)
+
+
 def fsc(A, B, P, nShell):
     """FSC(vec&, Volume, Volume) src/Functions/Spectrum.cpp:302-337 on two half-complex FTs."""
     A, B = c64(A), c64(B)

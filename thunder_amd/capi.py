@@ -101,6 +101,37 @@ SIGNATURES = {
     "thx_ExpectPrecal_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
     "thx_ExpectGlobal3D_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "thx_GCTFinit_host": (_i, [_vp, _vp, _f, _i, _i]),
+    # per-image / per-stage Interface.h entries (thx_iface.hip, staged reconstructG in thx_reco.hip)
+    "thx_texture_create": (_i, [C.POINTER(_vp), _i, _i, _i]),
+    "thx_texture_destroy": (_i, [_vp]),
+    "thx_texture_device": (_i, [_vp]),
+    "thx_calpoint_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _i, _i]),
+    "thx_calpoint_destroy": (_i, [_vp]),
+    "thx_ExpectPreidx_host": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _i]),
+    "thx_ExpectPrefre_host": (_i, [_i, C.POINTER(_vp), _vp, _i]),
+    "thx_ExpectLocalIn_host": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i]),
+    "thx_ExpectLocalV3D_host": (_i, [_i, _vp, _vp, _i]),
+    "thx_ExpectLocalP_host": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "thx_ExpectLocalHostA_host": (_i, [_i] + [C.POINTER(_vp)] * 10 + [_i, _i, _i, _i]),
+    "thx_ExpectLocalRTD_host": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "thx_ExpectLocalPreI3D_host": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _i, _i, _i, _i]),
+    "thx_ExpectLocalM_host": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _i]),
+    "thx_ExpectLocalHostF_host": (_i, [_i] + [C.POINTER(_vp)] * 10 + [_i]),
+    "thx_ExpectLocalFin_host": (_i, [_i] + [C.POINTER(_vp)] * 5 + [_i]),
+    "thx_ExpectFreeIdx_host": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp)]),
+    "thx_ExposePT_host": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _i, _i]),
+    "thx_ExposeWT_host": (_i, [_i, _vp, _vp, _vp, _i, _f, _i, _i, _i, _i, _i, _i]),
+    "thx_ExposeWT_plain_host": (_i, [_i, _vp, _vp, _i, _i, _i]),
+    "thx_AllocDevicePoint_host": (_i, [_i] + [C.POINTER(_vp)] * 7 + [C.POINTER(_vp), _i, _i, _i]),
+    "thx_HostDeviceInit_host": (_i, [_i, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), _i, _i, _i, _i, _i]),
+    "thx_ExposeC_host": (_i, [_i, _vp, _vp, _vp, _vp, C.POINTER(_vp), _i, _i]),
+    "thx_ExposeForConvC_host": (_i, [_i, _vp, _vp, _vp, C.POINTER(_vp), _f, _f, _i, _i, _i, _i, _i]),
+    "thx_ExposeWC_host": (_i, [_i, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_f), _i, _i, _i, _i]),
+    "thx_FreeDevHostPoint_host": (_i, [_i] + [C.POINTER(_vp)] * 7 + [C.POINTER(_vp), _vp, _i, _i]),
+    "thx_ExposePFW_host": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "thx_ExposePF_host": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "thx_ExposeCorrF_host": (_i, [_i, _vp, _vp, _f, _i]),
+    "thx_ExposeCorrF_fft_host": (_i, [_i, _vp, _vp, _vp, _f, _i]),
     "thx_ReMask_host": (_i, [_vp, _f, _f, _f, _i, _i]),
     "thx_TranslateI2D_host": (_i, [_i, _vp, _d, _d, _i, _i]),
     "thx_TranslateI_host": (_i, [_i, _vp, _d, _d, _d, _i, _i]),

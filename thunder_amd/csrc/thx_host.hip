@@ -6,38 +6,6 @@
 
 #include "thx_common.h"
 
-namespace thx {
-
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes)
-    {
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 4);
-        if (e != hipSuccess) {
-            set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-            return (int)e;
-        }
-        return 0;
-    }
-    int upload(const void* h, size_t bytes)
-    {
-        int rc = alloc(bytes);
-        if (rc) return rc;
-        hipError_t e = hipMemcpy(p, h, bytes, hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            set_error("hipMemcpy H2D failed: %s", hipGetErrorString(e));
-            return (int)e;
-        }
-        return 0;
-    }
-    template <typename T> T* as() { return reinterpret_cast<T*>(p); }
-};
-
-#define THX_RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
-
-}  // namespace thx
-
 using namespace thx;
 
 extern "C" {

@@ -70,7 +70,7 @@ __device__ __forceinline__ void unpack_half(size_t e, int P, int& i, int& j, int
 
 // [MAP] T /= FSC'(shell), src/Reconstructor.cpp:1242-1270
 __global__ __launch_bounds__(256) void k_wiener_T(float* __restrict__ T, int P, int pf, int maxRadius,
-                                                  const float* __restrict__ FSC, int nFSC, int joinHalf)
+                                                  const float* __restrict__ FSC, int nFSC, int joinHalf, int wienerF)
 {
     const size_t n = (size_t)P * P * (P / 2 + 1);
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_wiener_T(float* __restrict__ T, int P, 
     int i, j, k;
     unpack_half(e, P, i, j, k);
     const double q = (double)i * i + (double)j * j + (double)k * k;
-    if ((q >= pow2f_((float)(5 * pf))) && (q < pow2f_((float)(maxRadius * pf)))) {
+    if ((q >= pow2f_((float)(wienerF * pf))) && (q < pow2f_((float)(maxRadius * pf)))) {
         const int u = (int)rint(gsl_hypot3_((double)i, (double)j, (double)k));
         float f = (u / pf >= nFSC) ? 0.f : FSC[u / pf];
         const float lo = (float)1e-3, hi = (float)(1 - 1e-3);
@@ -128,7 +128,7 @@ __device__ __forceinline__ float div_by_const(float a, float b, float rb)
 constexpr int kMaxHalfP = 1024;  // P <= 2048
 template <bool POW2>
 __global__ __launch_bounds__(256) void k_convolute_rl(float* __restrict__ rl, int P, int NP, const float* __restrict__ tab,
-                                                      float nf, float rnf, float rs)
+                                                      float nf, float rnf, float rs, int applyScale)
 {
     __shared__ float sval[kMaxHalfP + 1];
     const int h = P / 2;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_convolute_rl(float* __restrict__ rl, in
         for (int c = 0; c < 4; c++) {
             const int iw = 4 * i4 + c;
             const int ai = iw >= h ? P - iw : iw;  // |i|
-            const float vv = POW2 ? v[c] * rnf32 : (float)((double)v[c] * rn);
+            const float vv = !applyScale ? v[c] : (POW2 ? v[c] * rnf32 : (float)((double)v[c] * rn));
             v[c] = div_by_const(vv * sval[ai], nf, rnf);
         }
         row[i4] = make_float4(v[0], v[1], v[2], v[3]);
@@ -343,6 +343,47 @@ __global__ void k_fsc_final(float* __restrict__ fsc, const double* __restrict__ 
     fsc[u] = (AB == 0) ? 0.f : vS / AB;
 }
 
+// Staged form (ExposeWC, Interface.h:392-406; kernel_RecalculateW + kernel_CheckCMAX): W /= max(|C|, 1e-6) in the sphere
+// and the checkC maximum, without producing the next round's C (the caller's ExposeC does).  Row (jw, kw) per workgroup.
+__global__ __launch_bounds__(256) void k_recalcW_max(float* __restrict__ W, const float2* __restrict__ C, int P, int r2i,
+                                                     unsigned* __restrict__ diffBits)
+{
+    __shared__ float sred[4];
+    const int nc = P / 2 + 1;
+    const int jw = blockIdx.x, kw = blockIdx.y;
+    const int j = jw >= P / 2 ? jw - P : jw, k = kw >= P / 2 ? kw - P : kw;
+    const double qjk = (double)j * j + (double)k * k;
+    const double r2 = (double)pow2f_((float)r2i);
+    const size_t base = ((size_t)kw * P + jw) * nc;
+    float d = 0.f;
+    for (int i = threadIdx.x; i < nc; i += blockDim.x) {
+        if ((double)i * i + qjk < r2) {
+            const float2 c = C[base + i];
+            const float a = ts_hypot(c.x, c.y);
+            W[base + i] = W[base + i] / (a > (float)1e-6 ? a : (float)1e-6);
+            d = fmaxf(d, fabsf(a - 1));
+        }
+    }
+    d = wave_max(d);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(diffBits, __float_as_uint(fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]))));
+}
+
+// ExposeCorrF (Interface.h:492-501; kernel_CorrectF, RECONSTRUCTOR_TRILINEAR_KERNEL form): dst /= tik[|k|][|j|][|i|]
+__global__ __launch_bounds__(256) void k_correctF(float* __restrict__ dst, const float* __restrict__ tik, int dim)
+{
+    const size_t n = (size_t)dim * dim * dim;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    int i = (int)(e % dim), j = (int)((e / dim) % dim), k = (int)(e / ((size_t)dim * dim));
+    if (i >= dim / 2) i = dim - i;
+    if (j >= dim / 2) j = dim - j;
+    if (k >= dim / 2) k = dim - k;
+    const int h = dim / 2 + 1;
+    dst[e] = dst[e] / tik[((size_t)k * h + j) * h + i];
+}
+
 static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace thx
@@ -423,6 +464,47 @@ int thx_reco_destroy(thx_reco* r)
     return 0;
 }
 
+// The gridding-weight iteration of Reconstructor::reconstruct (src/Reconstructor.cpp:1379-1551): W (r->W) must hold the
+// initial weights, T the floored T; the device-resident loop of C2R -> kernel multiply -> R2C -> W update + checkC.
+static int balance_W(thx_reco* r, const float* T, int maxRadius, int maxIter, int minIter, int* itersOut, float* diffCOut,
+                     hipStream_t st)
+{
+    const int PF = r->PF, pf = r->pf, ncpF = padded_nc(PF);
+    int iters = 0, nNoDec = 0;
+    float diffC = 3.402823466e+38f, diffCPrev = 3.402823466e+38f;
+    const long np = (long)r->N * pf;
+    const bool pow2 = ((np & (np - 1)) == 0) && ((PF & (PF - 1)) == 0);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_updateW_calcC<false>), dim3(PF, PF), dim3(256), 0, st, r->W, r->C, T, PF, ncpF, pf,
+                       maxRadius, r->diff);
+    for (int m = 0; m < maxIter; m++) {
+        THX_FFT_CHECK(hipfftExecC2R(r->c2rF, reinterpret_cast<hipfftComplex*>(r->C), r->rl));
+        if (pow2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_convolute_rl<true>), dim3(PF / 2 + 1, PF / 2 + 1), dim3(256), 0, st, r->rl,
+                               PF, r->N * pf, r->tab, r->nf, r->rnf, r->rs, 1);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_convolute_rl<false>), dim3(PF / 2 + 1, PF / 2 + 1), dim3(256), 0, st, r->rl,
+                               PF, r->N * pf, r->tab, r->nf, r->rnf, r->rs, 1);
+        THX_FFT_CHECK(hipfftExecR2C(r->r2cF, r->rl, reinterpret_cast<hipfftComplex*>(r->C)));
+        THX_CHECK(hipMemsetAsync(r->diff, 0, sizeof(unsigned), st));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_updateW_calcC<true>), dim3(PF, PF), dim3(256), 0, st, r->W, r->C, T, PF, ncpF, pf,
+                           maxRadius, r->diff);
+        unsigned bits = 0;
+        THX_CHECK(hipMemcpyAsync(&bits, r->diff, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        THX_CHECK(hipStreamSynchronize(st));
+        diffCPrev = diffC;
+        memcpy(&diffC, &bits, sizeof(float));
+        iters = m + 1;
+        // src/Reconstructor.cpp:1542-1550 (DIFF_C_DECREASE_THRES 0.95, DIFF_C_THRES 1e-2, N_DIFF_C_NO_DECREASE 2); the
+        // comparisons run in double against RFLOAT operands as in the reference
+        if ((double)diffC > (double)diffCPrev * 0.95) nNoDec += 1; else nNoDec = 0;
+        if (((double)diffC < 1e-2) || ((m >= minIter) && (nNoDec == 2))) break;
+    }
+    THX_LAUNCH_CHECK();
+    *itersOut = iters;
+    *diffCOut = diffC;
+    return 0;
+}
+
 int thx_reco_reconstruct_dev(thx_reco* r, const float* F, float* T, int maxRadius, const float* FSC_host, int nFSC,
                              int joinHalf, int MAP, int gridCorr, float* dstRL, int* nIterOut, float* diffCOut,
                              void* stream)
@@ -437,44 +519,17 @@ int thx_reco_reconstruct_dev(thx_reco* r, const float* F, float* T, int maxRadiu
     THX_FFT_CHECK(hipfftSetStream(r->r2cF, st));
     THX_FFT_CHECK(hipfftSetStream(r->c2rF, st));
     if (r->haveN) THX_FFT_CHECK(hipfftSetStream(r->c2rN, st));
-    const int ncpF = padded_nc(PF), ncpN = padded_nc(PN);
+    const int ncpN = padded_nc(PN);
     if (MAP) {
         THX_CHECK(hipMemcpyAsync(r->fscDev, FSC_host, nFSC * sizeof(float), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_wiener_T, dim3(nblk(nHalfF)), dim3(256), 0, st, T, PF, pf, maxRadius, r->fscDev, nFSC,
-                           joinHalf);
+                           joinHalf, 5);  // WIENER_FACTOR_MIN_R
     }
     hipLaunchKernelGGL(k_initW_floorT, dim3(nblk(nHalfF)), dim3(256), 0, st, r->W, T, PF, pf, maxRadius);
     int iters = 0;
-    float diffC = 3.402823466e+38f, diffCPrev = 3.402823466e+38f;
+    float diffC = 3.402823466e+38f;
     if (gridCorr) {
-        int nNoDec = 0;
-        const long np = (long)r->N * pf;
-        const bool pow2 = ((np & (np - 1)) == 0) && ((PF & (PF - 1)) == 0);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_updateW_calcC<false>), dim3(PF, PF), dim3(256), 0, st, r->W, r->C, T, PF, ncpF,
-                           pf, maxRadius, r->diff);
-        for (int m = 0; m < 30; m++) {  // MAX_N_ITER_BALANCE
-            THX_FFT_CHECK(hipfftExecC2R(r->c2rF, reinterpret_cast<hipfftComplex*>(r->C), r->rl));
-            if (pow2)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_convolute_rl<true>), dim3(PF / 2 + 1, PF / 2 + 1), dim3(256), 0, st, r->rl,
-                                   PF, r->N * pf, r->tab, r->nf, r->rnf, r->rs);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_convolute_rl<false>), dim3(PF / 2 + 1, PF / 2 + 1), dim3(256), 0, st, r->rl,
-                                   PF, r->N * pf, r->tab, r->nf, r->rnf, r->rs);
-            THX_FFT_CHECK(hipfftExecR2C(r->r2cF, r->rl, reinterpret_cast<hipfftComplex*>(r->C)));
-            THX_CHECK(hipMemsetAsync(r->diff, 0, sizeof(unsigned), st));
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_updateW_calcC<true>), dim3(PF, PF), dim3(256), 0, st, r->W, r->C, T, PF, ncpF,
-                               pf, maxRadius, r->diff);
-            unsigned bits = 0;
-            THX_CHECK(hipMemcpyAsync(&bits, r->diff, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-            THX_CHECK(hipStreamSynchronize(st));
-            diffCPrev = diffC;
-            memcpy(&diffC, &bits, sizeof(float));
-            iters = m + 1;
-            // src/Reconstructor.cpp:1542-1550 (DIFF_C_DECREASE_THRES 0.95, DIFF_C_THRES 1e-2, MIN_N_ITER_BALANCE 10,
-            // N_DIFF_C_NO_DECREASE 2); the comparisons run in double against RFLOAT operands as in the reference
-            if ((double)diffC > (double)diffCPrev * 0.95) nNoDec += 1; else nNoDec = 0;
-            if (((double)diffC < 1e-2) || ((m >= 10) && (nNoDec == 2))) break;
-        }
+        THX_RC(balance_W(r, T, maxRadius, 30, 10, &iters, &diffC, st));  // MAX_N_ITER_BALANCE, MIN_N_ITER_BALANCE
     } else {
         hipLaunchKernelGGL(k_W_nogridcorr, dim3(nblk(nHalfF)), dim3(256), 0, st, r->W, T, PF, pf, maxRadius);
     }
@@ -554,6 +609,259 @@ int thx_fsc_dev(float* fsc, int nShell, const float* A, const float* B, int dim,
                        reinterpret_cast<const float2*>(A), reinterpret_cast<const float2*>(B), dim);
     hipLaunchKernelGGL(k_fsc_final, dim3((nShell + 255) / 256), dim3(256), 0, st, fsc, acc, nShell);
     THX_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Staged form of Reconstructor::reconstructG (src/Reconstructor.cpp:1835-2330): the reference strings these calls
+// together with host FFTs in between; each entry keeps that contract on caller-owned host arrays.  The arithmetic is that
+// of the CPU statement (Reconstructor::reconstruct), i.e. of thx_reco_reconstruct_dev, stage by stage.
+// ---------------------------------------------------------------------------------------------
+static inline size_t half_grid(int dim) { return (size_t)dim * dim * (dim / 2 + 1); }
+
+int thx_ExposePT_host(int gpuIdx, float* T3D, int maxRadius, int pf, int dim, const float* FSC, int nFSC, int joinHalf,
+                      int wienerF)
+{
+    THX_REQUIRE(T3D && FSC && nFSC > 0 && dim > 0, "bad arguments");
+    THX_CHECK(hipSetDevice(gpuIdx));
+    DevBuf dT, dF;
+    THX_RC(dT.upload(T3D, half_grid(dim) * sizeof(float)));
+    THX_RC(dF.upload(FSC, nFSC * sizeof(float)));
+    hipLaunchKernelGGL(k_wiener_T, dim3(nblk(half_grid(dim))), dim3(256), 0, nullptr, dT.as<float>(), dim, pf, maxRadius,
+                       dF.as<float>(), nFSC, joinHalf, wienerF);
+    THX_LAUNCH_CHECK();
+    THX_CHECK(hipMemcpy(T3D, dT.p, half_grid(dim) * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int thx_ExposeWT_host(int gpuIdx, const float* T3D, float* W3D, const float* tab, int tabSize, float nf, int maxRadius,
+                      int pf, int dim, int maxIter, int minIter, int size)
+{
+    THX_REQUIRE(T3D && W3D && tab && tabSize > 0 && tabSize <= kTabN + 1 && dim > 0 && pf > 0 && dim % pf == 0,
+                "bad arguments (the kernel table has at most 1e5 + 1 entries)");
+    THX_CHECK(hipSetDevice(gpuIdx));
+    thx_reco* r = nullptr;
+    THX_RC(thx_reco_create(&r, dim / pf, size, pf, 1.9f, 15.f));
+    // the caller's tabulated kernel and normalisation replace the ones thx_reco_create derived from (a, alpha)
+    int rc = 0;
+    DevBuf dT;
+    hipError_t e = hipMemset(r->tab, 0, (kTabN + 1) * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(r->tab, tab, tabSize * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { set_error("table upload failed: %s", hipGetErrorString(e)); rc = (int)e; }
+    r->nf = nf;
+    r->rnf = (float)(1.0 / (double)nf);
+    if (!rc) rc = dT.upload(T3D, half_grid(dim) * sizeof(float));
+    if (!rc) {
+        hipLaunchKernelGGL(k_initW_floorT, dim3(nblk(half_grid(dim))), dim3(256), 0, nullptr, r->W, dT.as<float>(), dim, pf,
+                           maxRadius);
+        int iters = 0;
+        float diffC = 0.f;
+        (void)hipfftSetStream(r->r2cF, nullptr);
+        (void)hipfftSetStream(r->c2rF, nullptr);
+        rc = balance_W(r, dT.as<float>(), maxRadius, maxIter, minIter, &iters, &diffC, nullptr);
+    }
+    if (!rc) {
+        e = hipMemcpy(W3D, r->W, half_grid(dim) * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { set_error("hipMemcpy D2H failed: %s", hipGetErrorString(e)); rc = (int)e; }
+    }
+    thx_reco_destroy(r);
+    return rc;
+}
+
+int thx_ExposeWT_plain_host(int gpuIdx, const float* T3D, float* W3D, int maxRadius, int pf, int dim)
+{
+    THX_REQUIRE(T3D && W3D && dim > 0, "bad arguments");
+    THX_CHECK(hipSetDevice(gpuIdx));
+    DevBuf dT, dW;
+    THX_RC(dT.upload(T3D, half_grid(dim) * sizeof(float)));
+    THX_RC(dW.alloc(half_grid(dim) * sizeof(float)));
+    hipLaunchKernelGGL(k_initW_floorT, dim3(nblk(half_grid(dim))), dim3(256), 0, nullptr, dW.as<float>(), dT.as<float>(), dim,
+                       pf, maxRadius);
+    hipLaunchKernelGGL(k_W_nogridcorr, dim3(nblk(half_grid(dim))), dim3(256), 0, nullptr, dW.as<float>(), dT.as<float>(), dim,
+                       pf, maxRadius);
+    THX_LAUNCH_CHECK();
+    THX_CHECK(hipMemcpy(W3D, dW.p, half_grid(dim) * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int thx_AllocDevicePoint_host(int gpuIdx, float** dev_C, float** dev_W, float** dev_T, float** dev_tab, float** devDiff,
+                              float** devMax, int** devCount, void** stream, int streamNum, int tabSize, int dim)
+{
+    THX_REQUIRE(dev_C && dev_W && dev_T && dev_tab && devMax && stream && streamNum >= 1 && dim > 0 && tabSize > 0,
+                "bad arguments");
+    THX_CHECK(hipSetDevice(gpuIdx));
+    const size_t n = half_grid(dim);
+    const size_t nTab = (size_t)(tabSize > kTabN + 1 ? tabSize : kTabN + 1);
+    THX_CHECK(hipMalloc(reinterpret_cast<void**>(dev_C), n * 2 * sizeof(float)));  // also holds the dim^3 real grid
+    THX_CHECK(hipMalloc(reinterpret_cast<void**>(dev_W), n * sizeof(float)));
+    THX_CHECK(hipMalloc(reinterpret_cast<void**>(dev_T), n * sizeof(float)));
+    THX_CHECK(hipMalloc(reinterpret_cast<void**>(dev_tab), nTab * sizeof(float)));
+    THX_CHECK(hipMemset(*dev_tab, 0, nTab * sizeof(float)));
+    THX_CHECK(hipMalloc(reinterpret_cast<void**>(devMax), (size_t)dim * sizeof(float)));  // RECONSTRUCTOR_CHECK_C_MAX
+    if (devDiff) *devDiff = nullptr;   // RECONSTRUCTOR_CHECK_C_AVERAGE is off (include/Config.h:101)
+    if (devCount) *devCount = nullptr;
+    for (int i = 0; i < streamNum; i++) {
+        hipStream_t st;
+        THX_CHECK(hipStreamCreate(&st));
+        stream[i] = reinterpret_cast<void*>(st);
+    }
+    return 0;
+}
+
+int thx_HostDeviceInit_host(int gpuIdx, const float* T3D, const float* tab, float* dev_W, float* dev_T, float* dev_tab,
+                            void** stream, int streamNum, int tabSize, int maxRadius, int pf, int dim)
+{
+    THX_REQUIRE(T3D && tab && dev_W && dev_T && dev_tab && stream && streamNum >= 1, "bad arguments");
+    THX_CHECK(hipSetDevice(gpuIdx));
+    hipStream_t st = as_stream(stream[0]);
+    THX_CHECK(hipMemcpyAsync(dev_tab, tab, (size_t)tabSize * sizeof(float), hipMemcpyHostToDevice, st));
+    THX_CHECK(hipMemcpyAsync(dev_T, T3D, half_grid(dim) * sizeof(float), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_initW_floorT, dim3(nblk(half_grid(dim))), dim3(256), 0, st, dev_W, dev_T, dim, pf, maxRadius);
+    THX_LAUNCH_CHECK();
+    THX_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int thx_ExposeC_host(int gpuIdx, float* C3D, float* dev_C, const float* dev_T, float* dev_W, void** stream, int streamNum,
+                     int dim)
+{
+    THX_REQUIRE(C3D && dev_C && dev_T && dev_W && stream && streamNum >= 1, "bad arguments");
+    THX_CHECK(hipSetDevice(gpuIdx));
+    hipStream_t st = as_stream(stream[0]);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_updateW_calcC<false>), dim3(dim, dim), dim3(256), 0, st, dev_W,
+                       reinterpret_cast<float2*>(dev_C), dev_T, dim, dim / 2 + 1, 1, 0, nullptr);
+    THX_LAUNCH_CHECK();
+    THX_CHECK(hipMemcpyAsync(C3D, dev_C, half_grid(dim) * 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+    THX_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int thx_ExposeForConvC_host(int gpuIdx, float* C3D_rl, float* dev_C, const float* dev_tab, void** stream, float step,
+                            float nf, int streamNum, int tabSize, int pf, int size, int dim)
+{
+    THX_REQUIRE(C3D_rl && dev_C && dev_tab && stream && streamNum >= 1, "bad arguments");
+    THX_REQUIRE(dim % 4 == 0 && dim <= 2 * kMaxHalfP, "dim must be a multiple of 4, at most 2048");
+    THX_REQUIRE(step == 1.0f / kTabN && tabSize <= kTabN + 1, "the tabulated kernel must be the 1e5-step table on [0, 1]");
+    THX_CHECK(hipSetDevice(gpuIdx));
+    hipStream_t st = as_stream(stream[0]);
+    const size_t n = (size_t)dim * dim * dim;
+    THX_CHECK(hipMemcpyAsync(dev_C, C3D_rl, n * sizeof(float), hipMemcpyHostToDevice, st));
+    const long np = (long)size * pf;
+    const bool pow2 = ((np & (np - 1)) == 0) && ((dim & (dim - 1)) == 0);
+    const float rnf = (float)(1.0 / (double)nf), rs = (float)(1.0 / (double)(1.0f / kTabN));
+    if (pow2)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_convolute_rl<true>), dim3(dim / 2 + 1, dim / 2 + 1), dim3(256), 0, st, dev_C, dim,
+                           size * pf, dev_tab, nf, rnf, rs, 0);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_convolute_rl<false>), dim3(dim / 2 + 1, dim / 2 + 1), dim3(256), 0, st, dev_C, dim,
+                           size * pf, dev_tab, nf, rnf, rs, 0);
+    THX_LAUNCH_CHECK();
+    THX_CHECK(hipMemcpyAsync(C3D_rl, dev_C, n * sizeof(float), hipMemcpyDeviceToHost, st));
+    THX_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int thx_ExposeWC_host(int gpuIdx, const float* C3D, float* dev_C, float* cmax, float* dev_W, float* devMax, void** stream,
+                      float* diffC, int streamNum, int maxRadius, int pf, int dim)
+{
+    THX_REQUIRE(C3D && dev_C && dev_W && devMax && stream && diffC && streamNum >= 1, "bad arguments");
+    THX_CHECK(hipSetDevice(gpuIdx));
+    hipStream_t st = as_stream(stream[0]);
+    THX_CHECK(hipMemcpyAsync(dev_C, C3D, half_grid(dim) * 2 * sizeof(float), hipMemcpyHostToDevice, st));
+    THX_CHECK(hipMemsetAsync(devMax, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(k_recalcW_max, dim3(dim, dim), dim3(256), 0, st, dev_W, reinterpret_cast<const float2*>(dev_C), dim,
+                       maxRadius * pf, reinterpret_cast<unsigned*>(devMax));
+    THX_LAUNCH_CHECK();
+    THX_CHECK(hipMemcpyAsync(diffC, devMax, sizeof(float), hipMemcpyDeviceToHost, st));
+    THX_CHECK(hipStreamSynchronize(st));
+    if (cmax) cmax[0] = *diffC;   // the reference leaves per-slice maxima here; their maximum is diffC
+    return 0;
+}
+
+int thx_FreeDevHostPoint_host(int gpuIdx, float** dev_C, float** dev_W, float** dev_T, float** dev_tab, float** devDiff,
+                              float** devMax, int** devCount, void** stream, float* volumeW, int streamNum, int dim)
+{
+    THX_REQUIRE(dev_C && dev_W && dev_T && dev_tab && devMax && stream && volumeW, "bad arguments");
+    THX_CHECK(hipSetDevice(gpuIdx));
+    THX_CHECK(hipMemcpy(volumeW, *dev_W, half_grid(dim) * sizeof(float), hipMemcpyDeviceToHost));
+    for (int i = 0; i < streamNum; i++) {
+        THX_CHECK(hipStreamDestroy(as_stream(stream[i])));
+        stream[i] = nullptr;
+    }
+    THX_CHECK(hipFree(*dev_C)); *dev_C = nullptr;
+    THX_CHECK(hipFree(*dev_W)); *dev_W = nullptr;
+    THX_CHECK(hipFree(*dev_T)); *dev_T = nullptr;
+    THX_CHECK(hipFree(*dev_tab)); *dev_tab = nullptr;
+    THX_CHECK(hipFree(*devMax)); *devMax = nullptr;
+    if (devDiff && *devDiff) { THX_CHECK(hipFree(*devDiff)); *devDiff = nullptr; }
+    if (devCount && *devCount) { THX_CHECK(hipFree(*devCount)); *devCount = nullptr; }
+    return 0;
+}
+
+static int expose_pf(int gpuIdx, float* padDst, float* padDstR, const float* F3D, const float* W3D, int maxRadius, int pf,
+                     int pdim, int fdim)
+{
+    THX_REQUIRE(F3D && W3D && pdim >= fdim && fdim > 0, "bad arguments");
+    THX_CHECK(hipSetDevice(gpuIdx));
+    DevBuf dF, dW, dP, dR;
+    THX_RC(dF.upload(F3D, half_grid(fdim) * 2 * sizeof(float)));
+    THX_RC(dW.upload(W3D, half_grid(fdim) * sizeof(float)));
+    THX_RC(dP.alloc(half_grid(pdim) * 2 * sizeof(float)));
+    hipLaunchKernelGGL(k_FW, dim3(nblk(half_grid(pdim))), dim3(256), 0, nullptr, dP.as<float2>(), pdim, pdim / 2 + 1,
+                       dF.as<float2>(), dW.as<float>(), fdim, pf, maxRadius);
+    THX_LAUNCH_CHECK();
+    if (padDst) THX_CHECK(hipMemcpy(padDst, dP.p, half_grid(pdim) * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    if (padDstR) {
+        THX_RC(dR.alloc((size_t)pdim * pdim * pdim * sizeof(float)));
+        THX_RC(thx_fft3d_bw_dev(dP.as<float>(), dR.as<float>(), pdim, nullptr));
+        THX_CHECK(hipMemcpy(padDstR, dR.p, (size_t)pdim * pdim * pdim * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+int thx_ExposePFW_host(int gpuIdx, float* padDst, const float* F3D, const float* W3D, int maxRadius, int pf, int pdim,
+                       int fdim)
+{
+    THX_REQUIRE(padDst, "padDst is NULL");
+    return expose_pf(gpuIdx, padDst, nullptr, F3D, W3D, maxRadius, pf, pdim, fdim);
+}
+
+int thx_ExposePF_host(int gpuIdx, float* padDst, float* padDstR, const float* F3D, const float* W3D, int maxRadius, int pf,
+                      int pdim, int fdim)
+{
+    THX_REQUIRE(padDstR, "padDstR is NULL");
+    return expose_pf(gpuIdx, padDst, padDstR, F3D, W3D, maxRadius, pf, pdim, fdim);
+}
+
+int thx_ExposeCorrF_host(int gpuIdx, float* dst, const float* mkbRL, float nf, int dim)
+{
+    (void)nf;  // only the RECONSTRUCTOR_MKB_KERNEL build uses it; include/Config.h:95-97 selects the trilinear kernel
+    THX_REQUIRE(dst && mkbRL && dim > 0, "bad arguments");
+    THX_CHECK(hipSetDevice(gpuIdx));
+    const size_t n = (size_t)dim * dim * dim, h = dim / 2 + 1;
+    DevBuf dD, dM;
+    THX_RC(dD.upload(dst, n * sizeof(float)));
+    THX_RC(dM.upload(mkbRL, h * h * h * sizeof(float)));
+    hipLaunchKernelGGL(k_correctF, dim3(nblk(n)), dim3(256), 0, nullptr, dD.as<float>(), dM.as<float>(), dim);
+    THX_LAUNCH_CHECK();
+    THX_CHECK(hipMemcpy(dst, dD.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int thx_ExposeCorrF_fft_host(int gpuIdx, const float* dstN, float* dstFT, const float* mkbRL, float nf, int dim)
+{
+    (void)nf;
+    THX_REQUIRE(dstN && dstFT && mkbRL && dim > 0, "bad arguments");
+    THX_CHECK(hipSetDevice(gpuIdx));
+    const size_t n = (size_t)dim * dim * dim, h = dim / 2 + 1;
+    DevBuf dD, dM, dF;
+    THX_RC(dD.upload(dstN, n * sizeof(float)));
+    THX_RC(dM.upload(mkbRL, h * h * h * sizeof(float)));
+    THX_RC(dF.alloc(half_grid(dim) * 2 * sizeof(float)));
+    hipLaunchKernelGGL(k_correctF, dim3(nblk(n)), dim3(256), 0, nullptr, dD.as<float>(), dM.as<float>(), dim);
+    THX_LAUNCH_CHECK();
+    THX_RC(thx_fft3d_fw_dev(dD.as<float>(), dF.as<float>(), dim, nullptr));
+    THX_CHECK(hipMemcpy(dstFT, dF.p, half_grid(dim) * 2 * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 
