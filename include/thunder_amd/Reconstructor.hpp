@@ -147,6 +147,65 @@ public:
         thx_free_dev(dDat); thx_free_dev(dCtf); thx_free_dev(dW); thx_free_dev(dRot); thx_free_dev(dTran);
     }
 
+    // ---- members of the -DGPU_VERSION build (include/Reconstructor.h:611-659, 676-680) ----
+    // insertI(datP, ctfP, sigP, w, offS, nr, nt, nd, [nc,] ctfaData, pixelSize, cSearch, opf, mReco, idim, imgNum),
+    // src/Reconstructor.cpp:865-976 -> InsertFT: whole batches of images x draws; nr = QUATERNIONS [imgNum][mReco][4],
+    // nt = shifts [imgNum][mReco][2], nd = defocus factors [imgNum][mReco], offS [imgNum][2]; the orientation sum and the
+    // counter advance as insertDir does per draw.  nc (classes) must be NULL or all zero: one Reconstructor is one class.
+    void insertI(const Complex* datP, const float* ctfP, const float* /*sigP*/, const float* w, const double* offS,
+                 const double* nr, const double* nt, const double* nd, const int* /*nc*/, const thx_ctf_attr* ctfaData,
+                 float pixelSize, bool cSearch, int opf, int mReco, int idim, int imgNum)
+    {
+        if (!_F || !_iCol) { std::fprintf(stderr, "thunder_amd FATAL: allocSpace/setPreCal not called\n"); std::abort(); }
+        const size_t nd_ = (size_t)imgNum * mReco;
+        void *dDat, *dCtf, *dW, *dQ, *dRot, *dTran, *dOff = nullptr, *dAttr = nullptr, *dDf = nullptr, *dO, *dCnt;
+        auto up = [](void** d, const void* h, size_t bytes) {
+            THX_ABORT_ON(thx_malloc_dev(d, bytes));
+            THX_ABORT_ON(thx_memcpy_h2d(*d, h, bytes));
+        };
+        up(&dDat, datP, (size_t)imgNum * _nPxl * 2 * sizeof(float));
+        up(&dCtf, ctfP, (size_t)imgNum * _nPxl * sizeof(float));
+        up(&dW, w, imgNum * sizeof(float));
+        up(&dQ, nr, nd_ * 4 * sizeof(double));
+        up(&dTran, nt, nd_ * 2 * sizeof(double));
+        if (offS) up(&dOff, offS, (size_t)imgNum * 2 * sizeof(double));
+        if (cSearch) { up(&dAttr, ctfaData, imgNum * sizeof(thx_ctf_attr)); up(&dDf, nd, nd_ * sizeof(double)); }
+        THX_ABORT_ON(thx_malloc_dev(&dRot, nd_ * 9 * sizeof(double)));
+        THX_ABORT_ON(thx_malloc_dev(&dO, 3 * sizeof(double)));
+        THX_ABORT_ON(thx_malloc_dev(&dCnt, sizeof(int)));
+        THX_ABORT_ON(thx_memset_dev(dO, 0, 3 * sizeof(double)));
+        THX_ABORT_ON(thx_memset_dev(dCnt, 0, sizeof(int)));
+        THX_ABORT_ON(thx_rotmat_dev((const double*)dQ, (double*)dRot, (int)nd_, nullptr));
+        THX_ABORT_ON(thx_insert_dev(_F, _T, (double*)dO, (int*)dCnt, _pf * _size, 1, (const float*)dDat, (const float*)dCtf,
+                                    (const float*)dW, (const double*)dRot, (const double*)dTran, (const double*)dOff, nullptr,
+                                    (const thx_ctf_attr*)dAttr, (const double*)dDf, cSearch ? 1 : 0, pixelSize, _iCol, _iRow,
+                                    opf, _nPxl, mReco, idim, imgNum, nullptr));
+        double o[3];
+        int c = 0;
+        THX_ABORT_ON(thx_memcpy_d2h(o, dO, sizeof(o)));
+        THX_ABORT_ON(thx_memcpy_d2h(&c, dCnt, sizeof(int)));
+        {
+            std::lock_guard<std::mutex> g(_mtx);
+            _ox += o[0]; _oy += o[1]; _oz += o[2]; _counter += c;
+        }
+        for (void* q : {dDat, dCtf, dW, dQ, dRot, dTran, dOff, dAttr, dDf, dO, dCnt}) if (q) thx_free_dev(q);
+    }
+    void insertI(const Complex* datP, const float* ctfP, const float* sigP, const float* w, const double* offS,
+                 const double* nr, const double* nt, const double* nd, const thx_ctf_attr* ctfaData, float pixelSize,
+                 bool cSearch, int opf, int mReco, int idim, int imgNum)
+    {
+        insertI(datP, ctfP, sigP, w, offS, nr, nt, nd, nullptr, ctfaData, pixelSize, cSearch, opf, mReco, idim, imgNum);
+    }
+    int getModelSize() const { return (int)nVox(); }
+    // prepareTFG(gpuIdx), src/Reconstructor.cpp:1012-1054: prepareTF with the symmetrisation on the device -- here both are
+    void prepareTFG(int gpuIdx) { THX_ABORT_ON(thx_set_device(gpuIdx)); prepareTF(1); }
+    // reconstructG(dst, gpuIdx, nThread), src/Reconstructor.cpp:1835-2330
+    void reconstructG(float* dstRL, int gpuIdx, unsigned int nThread = 1)
+    {
+        THX_ABORT_ON(thx_set_device(gpuIdx));
+        reconstruct(dstRL, nThread);
+    }
+
     // prepareTF(nThread), src/Reconstructor.cpp:1056-1091: allReduceT (+ 1/T[0] normalisation of T and F), symmetrizeT,
     // allReduceF, symmetrizeF
     void prepareTF(unsigned int /*nThread*/ = 1)
