@@ -415,3 +415,102 @@ def test_multirank_bench_control_flow_on_one_device(dev, world):
     assert j["n_gpus"] == world and j["scaling"] == "weak" and j["value"] > 0 and j["cpu_baseline"] is None
     assert abs(j["value"] - 300 * world / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
     assert all(f > 0.5 for f in j["fsc_half_maps"][1:4]), j["fsc_half_maps"]
+
+
+def test_classification_k4_multi_reference(oracle, dev):
+    """BASELINE config (3) in small: 3-D classification with K = 4 references.  Scanning phase over the classes
+    (ExpectGlobal3D, wC carried from class to class) -> class assignment -> local phase against the assigned reference
+    (volIdx) -> multi-reference insertion (cls per draw, nK volumes in one launch) -> K reconstructions.
+    Checks: assignment recovers the true classes; the multi-reference insert equals K single-class inserts of the
+    subsets; every class map matches its own truth and not the others'."""
+    import torch
+    from thunder_amd import ops, synth
+    from thunder_amd.refine import pixel_list
+    rng = np.random.default_rng(44)
+    N, K, nImg, nR, nT, mReco = 32, 4, 320, 60, 5, 4
+    P = 2 * N
+    pl, plM = pixel_list(N, N // 2 - 2, 1), pixel_list(N, N // 2 - 2, 0)
+    iCol, iRow, iColM, iRowM = (T(pl["iCol"], dev), T(pl["iRow"], dev), T(plM["iCol"], dev), T(plM["iRow"], dev))
+    plan = ops.RecoPlan(N, N, 2)
+    refs = [synth.blob_map(N, seed=100 + k, nblob=10) for k in range(K)]
+    vols = torch.stack([plan.set_projectee(T(r, dev)) for r in refs]).contiguous()
+    # the scan's grid of rotations / shifts; every particle sits on one grid point of one class
+    quat = synth.random_quats(nR, rng)
+    mats = ops.rotmat(T(quat, dev))
+    shifts = np.ascontiguousarray(rng.normal(0, 1.5, size=(nT, 2)))
+    cls_true = rng.integers(0, K, nImg)
+    r_true, t_true = rng.integers(0, nR, nImg), rng.integers(0, nT, nImg)
+    attr = ops.ctf_attr_tensor(synth.ctf_params(nImg, rng), dev)
+
+    def rows(icol, irow, npx):
+        ctf = ops.ctf(attr, 1.32, icol, irow, N)
+        dat = torch.empty((nImg, npx), dtype=torch.complex64, device=dev)
+        ramps = ops.translate(T(shifts, dev), icol, irow, N)
+        for k in range(K):
+            sl = ops.project(vols[k], mats, icol, irow, 2)
+            sel = np.nonzero(cls_true == k)[0]
+            s = T(sel, dev)
+            dat[s] = sl[T(r_true[sel], dev)] * ramps[T(t_true[sel], dev)] * ctf[s]
+        return dat, ctf, ramps
+    datE, ctfE, traP = rows(iCol, iRow, pl["nPxl"])
+    datM, ctfM, _ = rows(iColM, iRowM, plM["nPxl"])
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    sd = 0.3 * float(datE.abs().pow(2).mean().sqrt())      # noise amplitude 0.3 x signal rms per coefficient
+    nzE = torch.view_as_complex(torch.randn((nImg, pl["nPxl"], 2), generator=g, device=dev)) * (sd / np.sqrt(2))
+    datE = (datE + nzE).contiguous()
+    sigRcp = torch.full((nImg, pl["nPxl"]), -0.5 / (sd * sd / 2), dtype=torch.float32, device=dev)
+    # ---- scanning phase, class after class (src/Optimiser.cpp:756-894) ----
+    pR = torch.ones((nImg, nR), dtype=torch.float64, device=dev)
+    pT = torch.ones((nImg, nT), dtype=torch.float64, device=dev)
+    wC = torch.zeros((nImg, K), dtype=torch.float32, device=dev)
+    wR = torch.zeros((K, nImg, nR), dtype=torch.float32, device=dev)
+    wT = torch.zeros((K, nImg, nT), dtype=torch.float32, device=dev)
+    base = torch.full((nImg,), float("nan"), dtype=torch.float32, device=dev)
+    for k in range(K):
+        rotP = ops.project(vols[k], mats, iCol, iRow, 2)
+        ops.expect_global(rotP, traP, datE, ctfE, sigRcp, pR, pT, wC, wR, wT, base, k, K)
+    cls = wC.argmax(1)
+    assert (cls.cpu().numpy() == cls_true).mean() >= 0.99
+    ar = torch.arange(nImg, device=dev)
+    assert (wR[cls, ar].argmax(1).cpu().numpy() == r_true).mean() >= 0.99
+    # ---- local phase against the assigned reference ----
+    qloc = synth.perturb_quats(quat[r_true], 12, 0.15, rng)      # ~10 degrees: distinguishable at N = 32
+    qloc[:, 0] = quat[r_true]
+    rotL = ops.rotmat(T(qloc.reshape(-1, 4), dev)).reshape(nImg, 12, 9)
+    tranL = T(np.ascontiguousarray(shifts[t_true][:, None, :] + np.concatenate(
+        [np.zeros((nImg, 1, 2)), rng.normal(0, 2.0, size=(nImg, 3, 2))], axis=1)), dev)
+    res = ops.expect_local(vols, P, 2, N, iCol, iRow, datE, ctfE, sigRcp, rotL, tranL, volIdx=cls.to(torch.int32))
+    # the winning support point is the true pose or a perturbation too small to tell apart at N = 32
+    best = res.wR.argmax(1).cpu().numpy()
+    dots = np.abs(np.sum(qloc[np.arange(nImg), best] * quat[r_true], axis=1)).clip(0, 1)
+    assert np.mean(2 * np.arccos(dots) <= 0.08) >= 0.95
+    bt = res.wT.argmax(1).cpu().numpy()
+    dt = np.linalg.norm(tranL.cpu().numpy()[np.arange(nImg), bt] - shifts[t_true], axis=1)
+    assert np.mean(dt <= 0.5) >= 0.95
+    # ---- multi-reference insertion: nK volumes in one launch == K single-class launches on the subsets ----
+    qM = synth.perturb_quats(quat[r_true], mReco, 0.005, rng)    # the filter's draws after convergence
+    rotM = ops.rotmat(T(qM.reshape(-1, 4), dev)).reshape(nImg, mReco, 9)
+    tranM = tranL[:, :1].expand(-1, mReco, -1).contiguous()
+    clsD = cls.to(torch.int32)[:, None].expand(-1, mReco).contiguous()
+    w = torch.full((nImg,), 1.0 / mReco, dtype=torch.float32, device=dev)
+    F = torch.zeros((K, P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
+    Tt = torch.zeros((K, P, P, P // 2 + 1), dtype=torch.float32, device=dev)
+    ops.insert(F, Tt, P, datM, ctfM, w, rotM, tranM, iColM, iRowM, 2, N, cls=clsD, nK=K)
+    for k in range(K):
+        s = torch.nonzero(cls == k)[:, 0]
+        Fk = torch.zeros((P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
+        Tk = torch.zeros((P, P, P // 2 + 1), dtype=torch.float32, device=dev)
+        ops.insert(Fk, Tk, P, datM[s].contiguous(), ctfM[s].contiguous(), w[s].contiguous(), rotM[s].contiguous(),
+                   tranM[s].contiguous(), iColM, iRowM, 2, N)
+        assert (F[k] - Fk).abs().max().item() <= 1e-5 * Fk.abs().max().item()
+        assert (Tt[k] - Tk).abs().max().item() <= 1e-5 * Tk.abs().max().item()
+    # ---- K reconstructions: each class map resembles its own truth, not the other classes' ----
+    fts = [ops.fft3d_fw(T(r, dev)) for r in refs]
+    for k in range(K):
+        ops.normalise_TF(F[k], Tt[k], P)
+        m = plan.reconstruct(F[k], Tt[k], N // 2 - 2, MAP=False, gridCorr=True)
+        A = ops.fft3d_fw(m.contiguous())
+        own = ops.fsc(A, fts[k], N, 8).cpu().numpy()
+        other = ops.fsc(A, fts[(k + 1) % K], N, 8).cpu().numpy()
+        assert own[1:8].min() >= 0.9 and own[1:8].mean() > other[1:8].mean() + 0.2, (k, own, other)
+    plan.close()
