@@ -514,3 +514,28 @@ def test_classification_k4_multi_reference(oracle, dev):
         other = ops.fsc(A, fts[(k + 1) % K], N, 8).cpu().numpy()
         assert own[1:8].min() >= 0.9 and own[1:8].mean() > other[1:8].mean() + 0.2, (k, own, other)
     plan.close()
+
+
+def test_config0_demo3d_128_box_iterations(dev):
+    """BASELINE config (0) on the GPU path: script/demo_3D.json's search sizes (mLR 125, mLT 9, mReco 100) on 1 000
+    synthetic 128^3 particles, both half sets, two full EM iterations (rows, 3 particle-filter phases, sigma update,
+    insertion, reduce, reconstruct, FSC, projector refresh, re-centre + re-mask).  The gold-standard FSC between the
+    halves and the agreement of each half map with the generating map are the domain's own acceptance measures."""
+    import torch
+    from thunder_amd import ops
+    from thunder_amd.refine import RefineShard
+    N = 128
+    sh = RefineShard(N, 1000, dev, snr=0.05)
+    assert sh.nPxlM == 5941 and sh.mLR == 125 and sh.mLT == 9 and sh.mReco == 100
+    for _ in range(2):
+        fsc = sh.iteration()
+    torch.cuda.synchronize()
+    assert np.all(np.isfinite(fsc)) and fsc[1:10].min() >= 0.9, fsc[:16]
+    truth = ops.fft3d_fw(sh.ref)
+    for h, m in sh.last["maps"].items():
+        assert torch.isfinite(m).all()
+        f = ops.fsc(ops.fft3d_fw(m.contiguous()), truth, N, 12).cpu().numpy()
+        assert f[1:8].min() >= 0.9, (h, f)
+    # poses: the filter's top rotation stays within a few degrees of the generating pose for most particles
+    d = np.abs((sh.pf_state["topR"].cpu().numpy() * sh.quat).sum(1)).clip(0, 1)
+    assert np.median(np.degrees(2 * np.arccos(d))) <= 3.0
