@@ -32,14 +32,14 @@ class HalfGroups:
         self.rank, self.world = rank, world
         self.half = rank % 2
         self.group = None
-        if world > 1:
+        self.leaders = (0, 1)
+        if world > 2:   # with two ranks each half is one rank: nothing to reduce, no sub-communicator to build
             import torch.distributed as dist
             groups = []
-            for h in (0, 1):
+            for h in (0, 1):   # every rank creates both groups, in the same order (new_group is collective)
                 ranks = [r for r in range(world) if r % 2 == h]
                 groups.append(dist.new_group(ranks=ranks))
             self.group = groups[self.half]
-            self.leaders = (0, 1)
 
     def local_halves(self):
         return (0, 1) if self.world == 1 else (self.half,)
