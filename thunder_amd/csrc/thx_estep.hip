@@ -473,412 +473,6 @@ struct ExpectGlobalArgs {
     float* dvp;  // [nImg][nT][nR]
 };
 
-// ---------------------------------------------------------------------------------------------
-// Volume-window form of the same phase (the gather dual of k_insert_win, thx_mstep.hip).
-//
-// k_expect_local gathers straight from the 514 MB volume with lane = rotation: fast while the rotations of an image lie
-// within a voxel or two of each other (the 64 lanes then hit the same few cache lines), but a particle-filter cloud
-// (~1 degree: 4-16 voxels at radius 250) makes every lane pull its own 4 lines and the kernel becomes bound by L1/L2
-// line traffic (4x slower on MI355X).  Here a workgroup owns (image, row of volume WINDOWS): for each window and slab
-// it stages the sub-volume (kEWd x kEWd across, kEWz thick along the sheared dominant axis of the image's reference
-// plane, plus the halo a trilinear cell needs) into LDS with coalesced row reads, then every rotation (one wave each)
-// enumerates the pixels whose cell ORIGIN lies in the window (inverse 2x2 map of the window corners -> candidates, cheap
-// float pre-test, exact ownership test), interpolates from LDS with the reference's arithmetic and accumulates the
-// likelihood terms.  Each sample is owned by exactly one window and slab.  The phase ramps of the shifts are separable,
-// exp(-i a_t i) exp(-i b_t j), and tabulated per window for the pixel range in play (their product differs from a direct
-// sincosf by ~1e-7: inside the tolerance of a 25 000-pixel float sum).  Per-rotation sums are reduced with DPP and kept
-// in LDS until the row is done; the row's partial V goes to partV[img][d][row] and k_expect_final adds the rows up.
-// ---------------------------------------------------------------------------------------------
-constexpr int kEWd = 16;                        // window edge in (p, q)
-constexpr int kEWz = 12;                        // slab thickness
-constexpr int kEHp = kEWd + 2;                  // staged columns: origin - 1 .. origin + kEWd
-constexpr int kEHz = kEWz + 6;                  // staged layers: off in [-3, kEWz + 3)
-constexpr int kEVox = kEHp * kEHp * kEHz;       // 5832 voxels x 8 B = 46.7 KB
-constexpr int kEPix = 24;                       // tabulated pixel range per axis (pixel data and ramps)
-constexpr int kEThreads = 512;
-constexpr int kEWaves = kEThreads / 64;
-constexpr float kEOutlier = 2.0f * kEWz;        // a rotation whose plane leaves the reference shear by more than this
-                                                // over the disc gathers from global memory instead of staged slabs
-
-struct ExpectWinArgs {
-    ExpectLocalArgs a;
-    const int* pixIndex;
-    int nW, pOrg;
-    float rMax2;
-    int debug;   // THX_EXPECT_WIN_DEBUG (profiling only): 1 skip the rotation loops, 2 skip the volume staging
-};
-
-__global__ void k_pix_index_e(int* __restrict__ pixIndex, const int* __restrict__ iCol, const int* __restrict__ iRow,
-                              int nPxl, int idim)
-{
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= nPxl) return;
-    const int half = idim / 2;
-    const int i = iCol[p], j = iRow[p];
-    if (i >= 0 && i <= half && j >= -half && j < half) pixIndex[(j + half) * (half + 1) + i] = p;
-}
-
-// C = sum_p s |dat|^2 per (image, d) into split 0 of partC (the other splits stay 0)
-__global__ __launch_bounds__(256) void k_expect_const(float* __restrict__ partC, const float2* __restrict__ datP,
-                                                      const float* __restrict__ sigRcpP, int nPxl, int nD, int nSplit)
-{
-    __shared__ float sr[4];
-    const int img = blockIdx.x;
-    float c = 0.f;
-    for (int p = threadIdx.x; p < nPxl; p += 256) {
-        const float2 dv = datP[(size_t)img * nPxl + p];
-        c = fmaf(sigRcpP[(size_t)img * nPxl + p], fmaf(dv.x, dv.x, dv.y * dv.y), c);
-    }
-    c = wave_sum(c);
-    if ((threadIdx.x & 63) == 0) sr[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        for (int d = 0; d < nD; d++) partC[((size_t)img * nD + d) * nSplit] = (sr[0] + sr[1]) + (sr[2] + sr[3]);
-}
-
-template <int W>
-__device__ __forceinline__ int ecomp3(int x, int y, int z) { return W == 0 ? x : (W == 1 ? y : z); }
-
-struct EWinGeom {
-    int p0, q0, w0;
-    float sp, sq;
-    int ui0, uj0;   // origin of the tabulated pixel range
-};
-
-// one rotation (one wave) against one window.  STAGED: the sub-volume of the current slab is in LDS and the sample must
-// be owned by the slab; otherwise (outlier rotation) the sample is owned by the window's columns only and gathers from
-// global memory.  acc[] / accB are this lane's partial sums.
-template <int NT, int AX, bool STAGED>
-__device__ __forceinline__ void expect_win_rot(const ExpectWinArgs& wa, const EWinGeom& g, const float2* sVol,
-                                               const float2* vol, const float2* sEcol, const float2* sErow,
-                                               const float4* sPix, const double* R, int i0, int nI, int j0, int nJ,
-                                               const float2* dat, const float* ctf, const float* sig, float acc[NT],
-                                               float& accB)
-{
-    const ExpectLocalArgs& a = wa.a;
-    constexpr int pa = AX == 0 ? 1 : 0;
-    constexpr int qa = AX == 2 ? 1 : 2;
-    const int lane = threadIdx.x & 63;
-    const int P = a.P, half = a.idim / 2;
-    // float pre-test: (p, q) of the sample from the rows pa, qa of R (margin covers the float rounding and the fold's -1)
-    const float A00 = (float)R[pa] * (float)a.pf, A01 = (float)R[3 + pa] * (float)a.pf, A10 = (float)R[qa] * (float)a.pf,
-                A11 = (float)R[3 + qa] * (float)a.pf;
-    const float plo = (float)g.p0 - 1.5f, phi = (float)(g.p0 + kEWd) + 0.5f, qlo = (float)g.q0 - 1.5f, qhi = (float)(g.q0 + kEWd) + 0.5f;
-    const int nCand = nI * nJ;
-    const float rnI = 1.0f / (float)nI;
-    for (int c = lane; c < nCand; c += 64) {
-        const int jr = (int)(((float)c + 0.5f) * rnI);
-        const int pi = i0 + (c - jr * nI), pj = j0 + jr;
-        const float pf_ = A00 * (float)pi + A01 * (float)pj, qf_ = A10 * (float)pi + A11 * (float)pj;
-        if (!(pf_ >= plo && pf_ < phi && qf_ >= qlo && qf_ < qhi)) continue;
-        // pixel data: s ctf conj(dat), s ctf^2 -- staged per window for the tabulated range, else from the rows
-        const int ti = pi - g.ui0, tj = pj - g.uj0;
-        const bool tab = (unsigned)ti < (unsigned)kEPix && (unsigned)tj < (unsigned)kEPix;
-        float2 cd;
-        float B;
-        if (tab) {
-            const float4 px = sPix[tj * kEPix + ti];
-            if (px.w == 0.f) continue;   // not a listed pixel
-            cd = make_float2(px.x, px.y);
-            B = px.z;
-        } else {
-            const int k = wa.pixIndex[(pj + half) * (half + 1) + pi];
-            if (k < 0) continue;
-            const float s = sig[k], cf = ctf[k];
-            const float2 dv = dat[k];
-            const float gq = s * cf;
-            cd = make_float2(dv.x * gq, -dv.y * gq);
-            B = gq * cf;
-        }
-        const double nx = (double)(pi * a.pf), ny = (double)(pj * a.pf);
-        float x = (float)(R[0] * nx + R[3] * ny) * a.dbgScale;
-        float y = (float)(R[1] * nx + R[4] * ny) * a.dbgScale;
-        float z = (float)(R[2] * nx + R[5] * ny) * a.dbgScale;
-        if (!coord_in_grid(x, y, z, P)) continue;
-        const float ux = x, uy = y, uz = z;   // unfolded position (for the global path)
-        bool conj = false;
-        if (!(x >= 0.0f)) { x *= -1.0f; y *= -1.0f; z *= -1.0f; conj = true; }
-        const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
-        const int X0 = (int)fx, Y0 = (int)fy, Z0 = (int)fz;
-        const int sg = conj ? -1 : 1;
-        const int b0x = conj ? -1 - X0 : X0, b0y = conj ? -Y0 : Y0, b0z = conj ? -Z0 : Z0;
-        const int bp0 = ecomp3<pa>(b0x, b0y, b0z), bq0 = ecomp3<qa>(b0x, b0y, b0z), ba0 = ecomp3<AX>(b0x, b0y, b0z);
-        // exact ownership: the cell origin lies in this window's core (and, when staged, in this slab)
-        if ((unsigned)(bp0 - g.p0) >= (unsigned)kEWd || (unsigned)(bq0 - g.q0) >= (unsigned)kEWd) continue;
-        float2 q;
-        if (STAGED) {
-            int offA[2][2];
-#pragma unroll
-            for (int dq = 0; dq < 2; dq++)
-#pragma unroll
-                for (int dp = 0; dp < 2; dp++)
-                    offA[dq][dp] = ba0 - ((int)floorf(g.sp * (float)(bp0 + sg * dp) + g.sq * (float)(bq0 + sg * dq)) + g.w0);
-            if ((unsigned)offA[0][0] >= (unsigned)kEWz) continue;
-            const float xd = x - fx, yd = y - fy, zd = z - fz;
-            const float vx[2] = {1.0f - xd, xd}, vy[2] = {1.0f - yd, yd}, vz[2] = {1.0f - zd, zd};
-            const int pI0 = bp0 - (g.p0 - 1), qI0 = bq0 - (g.q0 - 1);
-            // Volume::getByInterpolationFT from the staged window: k outer, j, i inner as getFTHalf (src/Image/Volume.cpp:491-563)
-            float re = 0.0f, im = 0.0f;
-#pragma unroll
-            for (int kk = 0; kk < 2; kk++)
-#pragma unroll
-                for (int jj = 0; jj < 2; jj++)
-#pragma unroll
-                    for (int ii = 0; ii < 2; ii++) {
-                        const int dp = ecomp3<pa>(ii, jj, kk), dq = ecomp3<qa>(ii, jj, kk), da = ecomp3<AX>(ii, jj, kk);
-                        const int pI = pI0 + sg * dp, qI = qI0 + sg * dq, of = offA[dq][dp] + sg * da + 3;
-                        const int idx = AX == 0 ? ((qI * kEHp + pI) * kEHz + of) : ((qI * kEHz + of) * kEHp + pI);
-                        const float2 v = sVol[idx];
-                        const float wv = vx[ii] * vy[jj] * vz[kk];
-                        re = re + v.x * wv;
-                        im = im + v.y * wv;
-                    }
-            q = make_float2(re, conj ? -im : im);
-        } else {
-            q = interp_ft(vol, P, ux, uy, uz);
-        }
-        accB = fmaf(B, fmaf(q.x, q.x, q.y * q.y), accB);
-        const float zr = cd.x * q.x - cd.y * q.y, zi = cd.x * q.y + cd.y * q.x;
-        if (tab) {
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const float2 ec = sEcol[t * kEPix + ti], er = sErow[t * kEPix + tj];
-                const float rx = ec.x * er.x - ec.y * er.y, ry = ec.x * er.y + ec.y * er.x;
-                acc[t] = fmaf(zr, rx, acc[t]);
-                acc[t] = fmaf(-zi, ry, acc[t]);
-            }
-        } else {
-            const double* tr = a.trans + (size_t)blockIdx.y * a.nT * 2;
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                if (t < a.nT) {
-                    const float2 rt = ramp_value((float)tr[2 * t] / a.idim, (float)tr[2 * t + 1] / a.idim, pi, pj);
-                    acc[t] = fmaf(zr, rt.x, acc[t]);
-                    acc[t] = fmaf(-zi, rt.y, acc[t]);
-                }
-            }
-        }
-    }
-}
-
-// wave totals of one rotation's partial sums, added by lane j to slot j of the rotation's LDS row (the wave owns the row)
-template <int NT>
-__device__ __forceinline__ void expect_win_commit(float* row, float acc[NT], float accB)
-{
-    const int lane = threadIdx.x & 63;
-    float mine = wave_sum_dpp(accB);
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-        const float tot = wave_sum_dpp(acc[t]);
-        mine = (lane == t + 1) ? tot : mine;
-    }
-    if (lane <= NT) row[lane == 0 ? NT : lane - 1] += mine;
-}
-
-// grid (nW, nImg, nD): one workgroup owns a row of windows (fixed q range) of one image
-template <int NT>
-__global__ __launch_bounds__(kEThreads, 4) void k_expect_win(ExpectWinArgs wa)
-{
-    const ExpectLocalArgs& a = wa.a;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float2* sVol = reinterpret_cast<float2*>(smem_raw);                          // [kEVox]
-    float4* sPix = reinterpret_cast<float4*>(sVol + kEVox);                      // [kEPix][kEPix]: cd.x, cd.y, B, listed
-    double* sM = reinterpret_cast<double*>(sPix + kEPix * kEPix);                // [nR][6]
-    float2* sEcol = reinterpret_cast<float2*>(sM + (size_t)a.nR * 6);            // [NT][kEPix]
-    float2* sErow = sEcol + NT * kEPix;                                          // [NT][kEPix]
-    float* sAcc = reinterpret_cast<float*>(sErow + NT * kEPix);                  // [nR][NT + 1]
-    float* sWr = sAcc + (size_t)a.nR * (NT + 1);                                 // [nR][2]
-    short* sBox = reinterpret_cast<short*>(sWr + 2 * (size_t)a.nR);              // [nR][4]: i0, nI (0: none, < 0: outlier), j0, nJ
-    __shared__ int sWlo, sWhi, sUi0, sUi1, sUj0, sUj1;
-
-    const int wqI = blockIdx.x, img = blockIdx.y, d = blockIdx.z;
-    const int tid = threadIdx.x, wave = tid >> 6;
-    const int P = a.P, nR = a.nR, half = a.idim / 2;
-    const float2* vol = a.volumes + (size_t)(a.volIdx ? a.volIdx[img] : 0) * ((size_t)P * P * (P / 2 + 1));
-    const float2* dat = a.datP + (size_t)img * a.nPxl;
-    const float* ctf = a.ctfP + ((size_t)img * a.nD + d) * a.nPxl;
-    const float* sig = a.sigRcpP + (size_t)img * a.nPxl;
-    const double* tr = a.trans + (size_t)img * a.nT * 2;
-    const long nc = P / 2 + 1;
-
-    for (int e = tid; e < nR * 6; e += kEThreads) {
-        const int r = e / 6, c = e - r * 6;
-        sM[e] = a.rotMat[((size_t)img * nR + r) * 9 + c];
-    }
-    for (int e = tid; e < nR * (NT + 1); e += kEThreads) sAcc[e] = 0.f;
-    __syncthreads();
-
-    // reference plane = rotation 0's: dominant axis of its normal, shear slopes
-    const float n0 = (float)(sM[1] * sM[5] - sM[2] * sM[4]);
-    const float n1 = (float)(sM[2] * sM[3] - sM[0] * sM[5]);
-    const float n2 = (float)(sM[0] * sM[4] - sM[1] * sM[3]);
-    const float an0 = fabsf(n0), an1 = fabsf(n1), an2 = fabsf(n2);
-    const int ax = (an0 >= an1 && an0 >= an2) ? 0 : (an1 >= an2 ? 1 : 2);
-    const int pa = ax == 0 ? 1 : 0, qa = ax == 2 ? 1 : 2;
-    const float na = ax == 0 ? n0 : (ax == 1 ? n1 : n2);
-    EWinGeom g;
-    g.sp = -(pa == 0 ? n0 : n1) / na;
-    g.sq = -(qa == 1 ? n1 : n2) / na;
-    g.q0 = wa.pOrg + wqI * kEWd;
-    const float rmax = sqrtf(wa.rMax2);
-
-    for (int wpI = 0; wpI < wa.nW; wpI++) {
-        g.p0 = wa.pOrg + wpI * kEWd;
-        {
-            const float lo_p = (float)(g.p0 - 2), hi_p = (float)(g.p0 + kEWd + 1), lo_q = (float)(g.q0 - 2), hi_q = (float)(g.q0 + kEWd + 1);
-            const float dp = lo_p > 0.f ? lo_p : (hi_p < 0.f ? -hi_p : 0.f), dq = lo_q > 0.f ? lo_q : (hi_q < 0.f ? -hi_q : 0.f);
-            if (dp * dp + dq * dq > wa.rMax2) continue;
-        }
-        __syncthreads();
-        if (tid == 0) { sWlo = INT_MAX; sWhi = INT_MIN; sUi0 = INT_MAX; sUi1 = INT_MIN; sUj0 = INT_MAX; sUj1 = INT_MIN; }
-        __syncthreads();
-        // ---- per rotation: candidate pixel box, outlier flag, sheared-w range over this window ----
-        for (int r = tid; r < nR; r += kEThreads) {
-            const double* R = sM + 6 * r;
-            short* box = sBox + 4 * r;
-            box[1] = 0;
-            const float A00 = (float)R[pa], A01 = (float)R[3 + pa], A10 = (float)R[qa], A11 = (float)R[3 + qa];
-            const float det = A00 * A11 - A01 * A10;
-            const float gn0 = (float)(R[1] * R[5] - R[2] * R[4]), gn1 = (float)(R[2] * R[3] - R[0] * R[5]),
-                        gn2 = (float)(R[0] * R[4] - R[1] * R[3]);
-            const float gna = ax == 0 ? gn0 : (ax == 1 ? gn1 : gn2);
-            int i0, i1, j0, j1;
-            bool outlier = fabsf(det) < 0.2f;
-            if (outlier) { i0 = 0; i1 = half; j0 = -half; j1 = half - 1; }
-            else {
-                const float s = 1.0f / (det * (float)a.pf);
-                float imin = 1e30f, imax = -1e30f, jmin = 1e30f, jmax = -1e30f;
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const float pc = (float)((c & 1) ? g.p0 + kEWd + 1 : g.p0 - 2), qc = (float)((c & 2) ? g.q0 + kEWd + 1 : g.q0 - 2);
-                    const float fi = (A11 * pc - A01 * qc) * s, fj = (-A10 * pc + A00 * qc) * s;
-                    imin = fminf(imin, fi); imax = fmaxf(imax, fi); jmin = fminf(jmin, fj); jmax = fmaxf(jmax, fj);
-                }
-                i0 = (int)floorf(imin); i1 = (int)ceilf(imax); j0 = (int)floorf(jmin); j1 = (int)ceilf(jmax);
-                i0 = i0 < 0 ? 0 : i0; i1 = i1 > half ? half : i1;
-                j0 = j0 < -half ? -half : j0; j1 = j1 > half - 1 ? half - 1 : j1;
-            }
-            if (i1 < i0 || j1 < j0) continue;
-            float gsp = 0.f, gsq = 0.f;
-            if (!outlier) {
-                gsp = -(pa == 0 ? gn0 : gn1) / gna;
-                gsq = -(qa == 1 ? gn1 : gn2) / gna;
-                // does this rotation's plane leave the reference shear by more than kEOutlier anywhere on the disc?
-                outlier = (fabsf(gsp - g.sp) + fabsf(gsq - g.sq)) * rmax > kEOutlier;
-            }
-            box[0] = (short)i0; box[2] = (short)j0; box[3] = (short)(j1 - j0 + 1);
-            box[1] = (short)(outlier ? -(i1 - i0 + 1) : (i1 - i0 + 1));
-            if (outlier) continue;
-            atomicMin(&sUi0, i0); atomicMax(&sUi1, i1); atomicMin(&sUj0, j0); atomicMax(&sUj1, j1);
-            float wmin = 1e30f, wmax = -1e30f;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const float pc = (float)((c & 1) ? g.p0 + kEWd + 1 : g.p0 - 2), qc = (float)((c & 2) ? g.q0 + kEWd + 1 : g.q0 - 2);
-                const float wv = (gsp - g.sp) * pc + (gsq - g.sq) * qc;
-                wmin = fminf(wmin, wv); wmax = fmaxf(wmax, wv);
-            }
-            sWr[2 * r] = wmin - 3.0f;
-            sWr[2 * r + 1] = wmax + 3.0f;
-            atomicMin(&sWlo, (int)floorf(wmin - 3.0f));
-            atomicMax(&sWhi, (int)ceilf(wmax + 3.0f));
-        }
-        __syncthreads();
-        const bool anyStaged = sWlo <= sWhi;
-        // centre the tabulated pixel range on the candidates of the staged rotations
-        g.ui0 = anyStaged ? sUi0 - ((kEPix - (sUi1 - sUi0 + 1)) > 0 ? (kEPix - (sUi1 - sUi0 + 1)) / 2 : 0) : 0;
-        g.uj0 = anyStaged ? sUj0 - ((kEPix - (sUj1 - sUj0 + 1)) > 0 ? (kEPix - (sUj1 - sUj0 + 1)) / 2 : 0) : -half;
-        // ---- pixel data and separable ramps for the tabulated range ----
-        for (int e = tid; e < kEPix * kEPix; e += kEThreads) {
-            const int tj = e / kEPix, ti = e - tj * kEPix;
-            const int pi = g.ui0 + ti, pj = g.uj0 + tj;
-            float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pi >= 0 && pi <= half && pj >= -half && pj < half) {
-                const int k = wa.pixIndex[(pj + half) * (half + 1) + pi];
-                if (k >= 0) {
-                    const float s = sig[k], cf = ctf[k];
-                    const float2 dv = dat[k];
-                    const float gq = s * cf;
-                    px = make_float4(dv.x * gq, -dv.y * gq, gq * cf, 1.f);
-                }
-            }
-            sPix[e] = px;
-        }
-        for (int e = tid; e < 2 * NT * kEPix; e += kEThreads) {
-            const int which = e / (NT * kEPix), rem = e - which * NT * kEPix, t = rem / kEPix, o = rem - t * kEPix;
-            float2 v = make_float2(1.f, 0.f);
-            if (t < a.nT) {
-                const float sl = (float)tr[2 * t + which] / a.idim;
-                const double ph = kM2xPi * ((double)((which ? g.uj0 : g.ui0) + o) * (double)sl);
-                double sn, cs;
-                sincos(-ph, &sn, &cs);
-                v = make_float2((float)cs, (float)sn);
-            }
-            (which ? sErow : sEcol)[t * kEPix + o] = v;
-        }
-        if (anyStaged) {
-            const int sLo = (sWlo + kEWz / 2) >= 0 ? (sWlo + kEWz / 2) / kEWz : -((-(sWlo + kEWz / 2) + kEWz - 1) / kEWz);
-            const int sHi = (sWhi + kEWz / 2) >= 0 ? (sWhi + kEWz / 2) / kEWz : -((-(sWhi + kEWz / 2) + kEWz - 1) / kEWz);
-            for (int sl = sLo; sl <= sHi; sl++) {
-                g.w0 = sl * kEWz - kEWz / 2;
-                __syncthreads();   // the previous slab's readers are done with sVol (and the tables are written)
-                for (int e = tid; e < ((wa.debug & 2) ? 0 : kEVox); e += kEThreads) {
-                    int pI, qI, of;
-                    if (ax == 0) { of = e % kEHz; const int r = e / kEHz; qI = r / kEHp; pI = r - qI * kEHp; }
-                    else { const int r = e / kEHp; pI = e - r * kEHp; of = r % kEHz; qI = r / kEHz; }
-                    const int bp = pI + g.p0 - 1, bq = qI + g.q0 - 1;
-                    const int ba = of - 3 + g.w0 + (int)floorf(g.sp * (float)bp + g.sq * (float)bq);
-                    int X = pa == 0 ? bp : ba;
-                    int Y = pa == 1 ? bp : (qa == 1 ? bq : ba);
-                    int Z = qa == 2 ? bq : ba;
-                    if (X < 0) { X = -1 - X; Y = -Y; Z = -Z; }
-                    float2 v = make_float2(0.f, 0.f);
-                    const int h = P / 2;
-                    if (X <= h && Y >= -h && Y < h && Z >= -h && Z < h)
-                        v = vol[((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X];
-                    sVol[e] = v;
-                }
-                __syncthreads();
-                for (int r = wave; r < ((wa.debug & 1) ? 0 : nR); r += kEWaves) {
-                    const short* box = sBox + 4 * r;
-                    if (box[1] <= 0) continue;
-                    if (sWr[2 * r + 1] < (float)g.w0 || sWr[2 * r] > (float)(g.w0 + kEWz)) continue;
-                    float acc[NT];
-                    float accB = 0.f;
-#pragma unroll
-                    for (int t = 0; t < NT; t++) acc[t] = 0.f;
-                    const double* R = sM + 6 * r;
-                    if (ax == 0) expect_win_rot<NT, 0, true>(wa, g, sVol, vol, sEcol, sErow, sPix, R, box[0], box[1], box[2], box[3], dat, ctf, sig, acc, accB);
-                    else if (ax == 1) expect_win_rot<NT, 1, true>(wa, g, sVol, vol, sEcol, sErow, sPix, R, box[0], box[1], box[2], box[3], dat, ctf, sig, acc, accB);
-                    else expect_win_rot<NT, 2, true>(wa, g, sVol, vol, sEcol, sErow, sPix, R, box[0], box[1], box[2], box[3], dat, ctf, sig, acc, accB);
-                    expect_win_commit<NT>(sAcc + (size_t)r * (NT + 1), acc, accB);
-                }
-            }
-        } else {
-            __syncthreads();   // tables written
-        }
-        // ---- outlier rotations of this window: global gathers ----
-        for (int r = wave; r < nR; r += kEWaves) {
-            const short* box = sBox + 4 * r;
-            if (box[1] >= 0) continue;
-            float acc[NT];
-            float accB = 0.f;
-#pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = 0.f;
-            const double* R = sM + 6 * r;
-            if (ax == 0) expect_win_rot<NT, 0, false>(wa, g, sVol, vol, sEcol, sErow, sPix, R, box[0], -box[1], box[2], box[3], dat, ctf, sig, acc, accB);
-            else if (ax == 1) expect_win_rot<NT, 1, false>(wa, g, sVol, vol, sEcol, sErow, sPix, R, box[0], -box[1], box[2], box[3], dat, ctf, sig, acc, accB);
-            else expect_win_rot<NT, 2, false>(wa, g, sVol, vol, sEcol, sErow, sPix, R, box[0], -box[1], box[2], box[3], dat, ctf, sig, acc, accB);
-            expect_win_commit<NT>(sAcc + (size_t)r * (NT + 1), acc, accB);
-        }
-    }
-    __syncthreads();
-    float* outV = a.partV + ((((size_t)img * a.nD + d) * a.nSplit + wqI) * a.nT) * a.nRpad;
-    for (int e = tid; e < nR * a.nT; e += kEThreads) {
-        const int t = e / nR, r = e - t * nR;
-        outV[(size_t)t * a.nRpad + r] = sAcc[(size_t)r * (NT + 1) + NT] - 2.0f * sAcc[(size_t)r * (NT + 1) + t];
-    }
-}
-
 template <int NT>
 __global__ __launch_bounds__(256) void k_expect_global(ExpectGlobalArgs a, int t0)
 {
@@ -1019,49 +613,6 @@ static int expect_local_nsplit(int nImg)
     int s = 1;
     while (s < 16 && (long)nImg * s < 2048) s *= 2;
     return s;
-}
-
-template <int NT>
-static int launch_expect_win(ExpectLocalArgs a, hipStream_t st, ExpectFinalArgs& f)
-{
-    const int half = a.idim / 2;
-    ExpectWinArgs wa;
-    const int rc = half * a.pf + 3;
-    const int hw = (rc + kEWd - 1) / kEWd;
-    wa.nW = 2 * hw;
-    wa.pOrg = -hw * kEWd;
-    wa.rMax2 = (float)(half * a.pf + 2) * (float)(half * a.pf + 2);
-    // partial sums per window row live in the library's own scratch (the caller's workspace is sized for the
-    // rotation-major kernel's splits)
-    a.nSplit = wa.nW;
-    const size_t nV = (size_t)a.nImg * a.nD * a.nSplit * a.nT * a.nRpad, nC = (size_t)a.nImg * a.nD * a.nSplit;
-    float* ws = reinterpret_cast<float*>(scratch(st, 7, (nV + nC) * sizeof(float)));
-    THX_REQUIRE(ws, "device scratch allocation failed");
-    a.partV = ws;
-    a.partC = ws + nV;
-    const size_t tb = (size_t)a.idim * (half + 1) * sizeof(int);
-    int* pixIndex = reinterpret_cast<int*>(scratch(st, 8, tb));
-    THX_REQUIRE(pixIndex, "device scratch allocation failed");
-    THX_CHECK(hipMemsetAsync(pixIndex, 0xFF, tb, st));
-    hipLaunchKernelGGL(k_pix_index_e, dim3((a.nPxl + 255) / 256), dim3(256), 0, st, pixIndex, a.iCol, a.iRow, a.nPxl, a.idim);
-    THX_CHECK(hipMemsetAsync(a.partC, 0, nC * sizeof(float), st));
-    hipLaunchKernelGGL(k_expect_const, dim3(a.nImg), dim3(256), 0, st, a.partC, a.datP, a.sigRcpP, a.nPxl, a.nD, a.nSplit);
-    wa.a = a;
-    wa.pixIndex = pixIndex;
-    {
-        const char* dbg = getenv("THX_EXPECT_WIN_DEBUG");
-        wa.debug = dbg ? atoi(dbg) : 0;
-    }
-    const size_t lds = (size_t)kEVox * sizeof(float2) + (size_t)kEPix * kEPix * sizeof(float4) + (size_t)a.nR * 6 * sizeof(double) +
-                       2 * (size_t)NT * kEPix * sizeof(float2) + (size_t)a.nR * (NT + 1) * sizeof(float) +
-                       2 * (size_t)a.nR * sizeof(float) + 4 * (size_t)a.nR * sizeof(short) + 16;
-    if (lds > 160 * 1024) { set_error("window E-step: nR = %d needs %zu B of LDS", a.nR, lds); return -1; }
-    THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_expect_win<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expect_win<NT>), dim3(wa.nW, a.nImg, a.nD), dim3(kEThreads), lds, st, wa);
-    THX_LAUNCH_CHECK();
-    f.partV = a.partV; f.partC = a.partC; f.nSplit = a.nSplit;
-    return 0;
 }
 
 template <int NT>
@@ -1258,12 +809,7 @@ static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, 
     int rc;
     ExpectFinalArgs f;
     f.partV = a.partV; f.partC = a.partC; f.nSplit = a.nSplit;
-    // THX_EXPECT_KERNEL: "win" = volume-window kernel (LDS-staged sub-volumes, robust to the spread of the rotations),
-    // "rot" = rotation-major kernel gathering from global memory (fastest when the rotations of an image nearly coincide)
-    const char* kv = getenv("THX_EXPECT_KERNEL");
-    const bool winK = kv && kv[0] == 'w' && nT <= 16 && nR <= 256 && !packed;
-    if (winK) rc = nT <= 9 ? launch_expect_win<9>(a, st, f) : launch_expect_win<16>(a, st, f);
-    else if (nT <= 9) rc = launch_expect_local<9>(a, st, packed);
+    if (nT <= 9) rc = launch_expect_local<9>(a, st, packed);
     else if (nT <= 16) rc = launch_expect_local<16>(a, st, packed);
     else rc = launch_expect_local<32>(a, st, packed);
     if (rc) return rc;
