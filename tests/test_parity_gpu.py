@@ -751,3 +751,35 @@ def test_full_size_properties_n512(oracle, dev):
     # falls steeply with r, so the (fixed) interpolation error weighs more from shell to shell
     assert fsc[1:32].min() >= 0.999 and fsc[1:64].min() >= 0.97, fsc[:64]
     plan.close()
+
+
+def test_hand_fft_passes_match_rocfft_n256(dev, monkeypatch):
+    """The gridding iteration at the BASELINE grid (P = 512) runs on the hand-written FFT passes of thx_fft8.h (strided
+    radix-8^3 passes, x transform fused with the kernel multiply, z transform fused with the weight update); at P = 64 the
+    same code is checked against the oracle by test_reconstruct.  Here: identical inputs through THX_FFT=rocfft (library
+    transforms + separate elementwise kernels) and the default path must give the same number of rounds, the same diffC
+    and the same map.  The inputs are analytic (T = a smooth sampling density, F = reference x T), so that the run is
+    deterministic and well conditioned: with sparse inserted data the max-norm stop rule amplifies last-bit differences
+    (of the FFTs, or of the atomics' order from run to run) into different round counts -- for rocFFT against itself too."""
+    from thunder_amd import ops, synth
+    N, P = 256, 512
+    plan = ops.RecoPlan(N, N, 2)
+    vol = plan.set_projectee(T(synth.blob_map(N, nblob=12), dev))
+    ax = torch.fft.fftfreq(P, d=1.0 / P, device=dev)
+    r = torch.sqrt(ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :P // 2 + 1] ** 2)
+    Tt = (1.0 / (1.0 + r / 8.0)).to(torch.float32).contiguous()        # ~ the 1/r density of randomly oriented slices
+    Tt[r >= (N // 2 - 2) * 2 + 1] = 0
+    F = (vol * Tt).contiguous()
+    fscv = np.clip(np.linspace(1.0, 0.1, N // 2), 0, 1).astype(np.float32)
+    out = {}
+    for mode in ("rocfft", "hand"):
+        if mode == "rocfft":
+            monkeypatch.setenv("THX_FFT", "rocfft")
+        else:
+            monkeypatch.delenv("THX_FFT", raising=False)
+        m = plan.reconstruct(F.clone(), Tt.clone(), N // 2 - 2, FSC=fscv, MAP=True, gridCorr=True)
+        out[mode] = (m, plan.last_iters, plan.last_diffC)
+    (ma, ia, da), (mb, ib, db) = out["rocfft"], out["hand"]
+    assert ia == ib and abs(da - db) <= 1e-3 * max(1.0, da), (ia, ib, da, db)
+    assert (ma - mb).abs().max().item() <= 1e-4 * ma.abs().max().item()
+    plan.close()

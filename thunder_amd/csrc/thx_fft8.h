@@ -1,0 +1,274 @@
+// thx_fft8.h -- hand-written FFT passes of the gridding-weight iteration (Reconstructor::reconstruct's balancing loop,
+// src/Reconstructor.cpp:1379-1551) for grids of 8^NS points per axis (64, 512).
+//
+// Why: rocFFT's strided passes over the [P][P][P/2+1] grid run at 2.25 TB/s (0.48 ms per pass at P = 512); a pass that
+// stages 512 points x TX adjacent columns in LDS and does the three radix-8 stages there runs at 4.3 TB/s (0.25 ms,
+// tools/fft_pass_probe.hip).  Owning the passes also lets the loop's elementwise steps ride along for free:
+//   k_fft_x_conv    inverse x transform -> x 1/size x tabulated kernel / nf (convoluteC's real-space stage) -> forward x
+//                   transform, one read and one write of C instead of five sweeps over C and the real grid;
+//   k_fft_z_update  forward z transform -> W /= max(|C|, 1e-6), checkC maximum, C = T W -> inverse z transform of the
+//                   next round, one read and one write of C instead of three.
+// Per round: 4 sweeps of C (0.54 GB each way) + W, T once, against 12 sweeps before.
+//
+// Decomposition (N = 8^3): n = 64 n2 + 8 n1 + n0, k = k0 + 8 k1 + 64 k2, w = exp(DIR 2 pi i / N):
+//   A[k0; n1, n0]   = sum_n2 w8^(n2 k0) x[n2, n1, n0]                      thread t = 8 n1 + n0 holds x[t + 64 n2]
+//   B[k0, k1; n0]   = sum_n1 w8^(n1 k1) w^(8 n1 k0) A[k0; n1, n0]          thread t = n0 + 8 k0
+//   X[k0, k1, k2]   = sum_n0 w8^(n0 k2) w^(n0 (k0 + 8 k1)) B[k0, k1; n0]   thread t = k0 + 8 k1 ends with X[t + 64 k2]
+// so a thread ends a transform holding exactly the elements it would load to start the next one: forward and inverse
+// transforms chain through registers.  LDS tile: element-major, one padding row per 64 elements (keeps the stride-64
+// reads of the last stage off a single bank group).
+#pragma once
+#include "thx_common.h"
+
+namespace thx {
+
+__device__ __forceinline__ float2 f8_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 f8_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+template <int DIR> __device__ __forceinline__ float2 f8_mul_i(float2 a) { return DIR > 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
+template <int DIR> __device__ __forceinline__ float2 f8_tw(float2 w) { return DIR > 0 ? make_float2(w.x, -w.y) : w; }  // table holds exp(-i)
+
+// y[k] = sum_n v[n] exp(DIR 2 pi i n k / 8), in place, natural order (decimation in frequency)
+template <int DIR>
+__device__ __forceinline__ void fft8(float2 v[8])
+{
+    const float h = 0.70710678118654752f;
+    const float2 s0 = f8_add(v[0], v[4]), s1 = f8_add(v[1], v[5]), s2 = f8_add(v[2], v[6]), s3 = f8_add(v[3], v[7]);
+    float2 d0 = f8_sub(v[0], v[4]), d1 = f8_sub(v[1], v[5]), d2 = f8_sub(v[2], v[6]), d3 = f8_sub(v[3], v[7]);
+    {
+        const float2 t1 = f8_mul_i<DIR>(d1);
+        d1 = make_float2((d1.x + t1.x) * h, (d1.y + t1.y) * h);   // d1 (1 + DIR i) / sqrt 2
+        d2 = f8_mul_i<DIR>(d2);
+        const float2 t3 = f8_mul_i<DIR>(d3);
+        d3 = make_float2((t3.x - d3.x) * h, (t3.y - d3.y) * h);   // d3 (-1 + DIR i) / sqrt 2
+    }
+    {
+        const float2 e0 = f8_add(s0, s2), e1 = f8_sub(s0, s2), o0 = f8_add(s1, s3), o1 = f8_mul_i<DIR>(f8_sub(s1, s3));
+        v[0] = f8_add(e0, o0); v[4] = f8_sub(e0, o0); v[2] = f8_add(e1, o1); v[6] = f8_sub(e1, o1);
+    }
+    {
+        const float2 e0 = f8_add(d0, d2), e1 = f8_sub(d0, d2), o0 = f8_add(d1, d3), o1 = f8_mul_i<DIR>(f8_sub(d1, d3));
+        v[1] = f8_add(e0, o0); v[5] = f8_sub(e0, o0); v[3] = f8_add(e1, o1); v[7] = f8_sub(e1, o1);
+    }
+}
+
+// LDS slot of element e of column c: element-major with `pitch` slots per element, one padding row per 64 elements
+__device__ __forceinline__ int f8_slot(int e, int c, int pitch) { return (e + (e >> 6)) * pitch + c; }
+template <int NS> __host__ __device__ constexpr int f8_n() { return NS == 3 ? 512 : 64; }
+template <int NS> __host__ __device__ constexpr int f8_rows() { return f8_n<NS>() + (f8_n<NS>() >> 6); }
+
+// The stages after the first butterfly's operands are in registers: in v[n] = x[t + (N/8) n], out v[k] = X[t + (N/8) k].
+// s: the column tile (f8_rows x pitch), sTw: exp(-2 pi i m / N), m < N.  All threads of the workgroup must call it.
+template <int NS, int DIR>
+__device__ __forceinline__ void fft8n(float2 v[8], int t, int c, int pitch, float2* s, const float2* sTw)
+{
+    fft8<DIR>(v);
+    if (NS == 3) {
+        {
+            const int n1 = t >> 3;
+#pragma unroll
+            for (int k0 = 0; k0 < 8; k0++) s[f8_slot(k0 * 64 + t, c, pitch)] = cmul(v[k0], f8_tw<DIR>(sTw[(8 * n1 * k0) & 511]));
+        }
+        __syncthreads();
+        {
+            const int n0 = t & 7, k0 = t >> 3;
+#pragma unroll
+            for (int n1 = 0; n1 < 8; n1++) v[n1] = s[f8_slot(k0 * 64 + n1 * 8 + n0, c, pitch)];
+            fft8<DIR>(v);
+#pragma unroll
+            for (int k1 = 0; k1 < 8; k1++) s[f8_slot(k0 * 64 + k1 * 8 + n0, c, pitch)] = cmul(v[k1], f8_tw<DIR>(sTw[n0 * (k0 + 8 * k1)]));
+        }
+        __syncthreads();
+        {
+            const int k0 = t & 7, k1 = t >> 3;
+#pragma unroll
+            for (int n0 = 0; n0 < 8; n0++) v[n0] = s[f8_slot(k0 * 64 + k1 * 8 + n0, c, pitch)];
+            fft8<DIR>(v);
+        }
+    } else {   // N = 64: t = n0, then t = k0
+#pragma unroll
+        for (int k0 = 0; k0 < 8; k0++) s[f8_slot(k0 * 8 + t, c, pitch)] = cmul(v[k0], f8_tw<DIR>(sTw[t * k0]));
+        __syncthreads();
+#pragma unroll
+        for (int n0 = 0; n0 < 8; n0++) v[n0] = s[f8_slot(t * 8 + n0, c, pitch)];
+        fft8<DIR>(v);
+    }
+    __syncthreads();   // the tile may be rewritten by the caller (next transform, staging for the store)
+}
+
+// ---------------------------------------------------------------------------------------------
+// Strided pass, in place: data[b strideB + e strideE + x], e < N, x = blockIdx.x TX + c < nx.  grid (ceil(nx / TX), nBatch).
+// ---------------------------------------------------------------------------------------------
+template <int NS, int TX, int DIR>
+__global__ __launch_bounds__((f8_n<NS>() / 8) * TX) void k_fft_strided(float2* __restrict__ data, long strideE, long strideB, int nx,
+                                                                     const float2* __restrict__ tw)
+{
+    constexpr int N = f8_n<NS>(), NT8 = N / 8;
+    extern __shared__ float2 f8_lds[];
+    float2* sTw = f8_lds + f8_rows<NS>() * TX;
+    const int c = threadIdx.x % TX, t = threadIdx.x / TX;
+    const int x = blockIdx.x * TX + c;
+    const bool ok = x < nx;
+    float2* base = data + (long)blockIdx.y * strideB + x;
+    for (int i = threadIdx.x; i < N; i += NT8 * TX) sTw[i] = tw[i];
+    float2 v[8];
+#pragma unroll
+    for (int n = 0; n < 8; n++) v[n] = ok ? base[(long)(t + NT8 * n) * strideE] : make_float2(0.f, 0.f);
+    __syncthreads();
+    fft8n<NS, DIR>(v, t, c, TX, f8_lds, sTw);
+    if (ok) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) base[(long)(t + NT8 * k) * strideE] = v[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// x direction, fused: per row of the half-complex grid (P/2+1 values, Hermitian), inverse transform -> real row ->
+// x 1/size x kernel(|x|^2 / (N pf)^2) / nf (k_convolute_rl's arithmetic, thx_reco.hip) -> forward transform -> same row.
+// One workgroup = one canonical pair 0 <= j <= k <= P/2 and the up to 8 rows (+-j, +-k) / (+-k, +-j) that share the
+// P/2+1 tabulated kernel values (looked up once, kept in LDS).  grid (P/2+1, P/2+1), (P/8) x 8 threads.
+// ---------------------------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__((f8_n<NS>() / 8) * 8) void k_fft_x_conv(float2* __restrict__ C, int ncp, int NP,
+                                                                   const float* __restrict__ tab, int tabN, float nf, float rnf,
+                                                                   float rs, const float2* __restrict__ tw)
+{
+    constexpr int P = f8_n<NS>(), NT8 = P / 8, h = P / 2, PITCH = 9, NTHR = NT8 * 8;
+    extern __shared__ float2 f8_lds[];
+    float2* sTw = f8_lds + f8_rows<NS>() * PITCH;
+    float* sval = reinterpret_cast<float*>(sTw + P);   // [h + 1]
+    __shared__ int rowOff[8];
+    __shared__ int sNRows;
+    const int j = blockIdx.x, k = blockIdx.y;
+    if (j > k) return;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < P; i += NTHR) sTw[i] = tw[i];
+    {
+        const int qjk = j * j + k * k;
+        const float inp2f = (float)(1.0 / (double)pow2f_((float)NP));
+        const float s = 1.0f / (float)tabN;
+        for (int i = tid; i <= h; i += NTHR) {
+            const float xq = (float)(i * i + qjk) * inp2f;
+            const int idx = (int)rintf(div_by_const(xq - 0.0f, s, rs));
+            sval[i] = tab[idx < tabN ? idx : tabN];
+        }
+    }
+    if (tid == 0) {
+        int n = 0;
+        for (int v = 0; v < 8; v++) {
+            const int swap = v >> 2, sj = (v >> 1) & 1, sk = v & 1;
+            if ((swap && j == k) || (sj && j == 0) || (sk && k == 0)) continue;
+            const int ja = sj ? -j : j, kb = sk ? -k : k;
+            const int a = swap ? kb : ja, b = swap ? ja : kb;   // a = row (j') index, b = slice (k') index
+            if (a == h || b == h) continue;                     // +P/2 is not a stored index, -P/2 is
+            rowOff[n++] = (b < 0 ? b + P : b) * P + (a < 0 ? a + P : a);
+        }
+        sNRows = n;
+    }
+    __syncthreads();
+    const int nRows = sNRows;
+    // coalesced load of the stored half rows, Hermitian extension into the tile
+    for (int idx = tid; idx < nRows * (h + 1); idx += NTHR) {
+        const int r = idx / (h + 1), i = idx - r * (h + 1);
+        const float2 val = C[(size_t)rowOff[r] * ncp + i];
+        f8_lds[f8_slot(i, r, PITCH)] = val;
+        if (i > 0 && i < h) f8_lds[f8_slot(P - i, r, PITCH)] = make_float2(val.x, -val.y);
+    }
+    __syncthreads();
+    const int c = tid & 7, t = tid >> 3;
+    float2 v[8];
+#pragma unroll
+    for (int n = 0; n < 8; n++) v[n] = f8_lds[f8_slot(t + NT8 * n, c, PITCH)];
+    __syncthreads();
+    fft8n<NS, 1>(v, t, c, PITCH, f8_lds, sTw);
+    {
+        const float rn = (float)(1.0 / ((double)P * P * P));   // P^3 is a power of two: exact
+#pragma unroll
+        for (int n = 0; n < 8; n++) {
+            const int iw = t + NT8 * n;
+            const int ai = iw >= h ? P - iw : iw;
+            v[n] = make_float2(div_by_const((v[n].x * rn) * sval[ai], nf, rnf), 0.f);
+        }
+    }
+    fft8n<NS, -1>(v, t, c, PITCH, f8_lds, sTw);
+#pragma unroll
+    for (int n = 0; n < 8; n++) f8_lds[f8_slot(t + NT8 * n, c, PITCH)] = v[n];
+    __syncthreads();
+    for (int idx = tid; idx < nRows * (h + 1); idx += NTHR) {
+        const int r = idx / (h + 1), i = idx - r * (h + 1);
+        C[(size_t)rowOff[r] * ncp + i] = f8_lds[f8_slot(i, r, PITCH)];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// z direction, fused with the weight update.  Column (ky = blockIdx.y, x = blockIdx.x TX + c), all kz.
+//   FIRST:  C = T W                                   -> inverse z transform        (before round 0)
+//   else :  forward z transform -> W /= max(|C|, 1e-6) inside the sphere, checkC max |(|C| - 1)|, C = T W -> inverse z
+// W, T rows are P/2+1 long, C rows ncp.  diffBits: float bits of the running maximum (>= 0: uint order == float order).
+// ---------------------------------------------------------------------------------------------
+template <int NS, int TX, bool FIRST>
+__global__ __launch_bounds__((f8_n<NS>() / 8) * TX) void k_fft_z_update(float2* __restrict__ C, float* __restrict__ W,
+                                                                      const float* __restrict__ T, int ncp, int r2i,
+                                                                      unsigned* __restrict__ diffBits,
+                                                                      const float2* __restrict__ tw)
+{
+    constexpr int P = f8_n<NS>(), NT8 = P / 8, nc = P / 2 + 1, NTHR = NT8 * TX;
+    extern __shared__ float2 f8_lds[];
+    float2* sTw = f8_lds + f8_rows<NS>() * TX;
+    __shared__ float sred[16];
+    const int c = threadIdx.x % TX, t = threadIdx.x / TX;
+    const int x = blockIdx.x * TX + c, jw = blockIdx.y;
+    const bool ok = x < nc;
+    for (int i = threadIdx.x; i < P; i += NTHR) sTw[i] = tw[i];
+    float2 v[8];
+    float d = 0.f;
+    const long strideE = (long)P * ncp;
+    float2* base = C + (long)jw * ncp + x;
+    if (!FIRST) {
+#pragma unroll
+        for (int n = 0; n < 8; n++) v[n] = ok ? base[(long)(t + NT8 * n) * strideE] : make_float2(0.f, 0.f);
+        __syncthreads();
+        fft8n<NS, -1>(v, t, c, TX, f8_lds, sTw);
+    } else {
+        __syncthreads();
+    }
+    {
+        const int j = jw >= P / 2 ? jw - P : jw;
+        const double qij = (double)x * x + (double)j * j;
+        const double r2 = (double)pow2f_((float)r2i);
+#pragma unroll
+        for (int n = 0; n < 8; n++) {
+            const int kw = t + NT8 * n;
+            const int k = kw >= P / 2 ? kw - P : kw;
+            float2 o = make_float2(0.f, 0.f);
+            if (ok) {
+                const size_t e = ((size_t)kw * P + jw) * nc + x;
+                float w = W[e];
+                if (!FIRST && (qij + (double)k * k < r2)) {
+                    const float a = ts_hypot(v[n].x, v[n].y);
+                    w = w / (a > (float)1e-6 ? a : (float)1e-6);
+                    W[e] = w;
+                    d = fmaxf(d, fabsf(a - 1));
+                }
+                o = make_float2(T[e] * w, 0.0f * w);
+            }
+            v[n] = o;
+        }
+    }
+    fft8n<NS, 1>(v, t, c, TX, f8_lds, sTw);
+    if (ok) {
+#pragma unroll
+        for (int n = 0; n < 8; n++) base[(long)(t + NT8 * n) * strideE] = v[n];
+    }
+    if (!FIRST) {
+        d = wave_max(d);
+        if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = d;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < (NTHR + 63) / 64; w++) d = fmaxf(d, sred[w]);
+            const unsigned bitsd = __float_as_uint(d);
+            if (bitsd > __hip_atomic_load(diffBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(diffBits, bitsd);
+        }
+    }
+}
+
+}  // namespace thx

@@ -231,6 +231,10 @@ __global__ __launch_bounds__(256) void k_updateW_calcC(float* __restrict__ W, fl
     }
 }
 
+}  // namespace thx
+#include "thx_fft8.h"
+namespace thx {
+
 // no grid correction: W = 1 / max(|T|, 1e-6) in the sphere (:1566-1578)
 __global__ __launch_bounds__(256) void k_W_nogridcorr(float* __restrict__ W, const float* __restrict__ T, int P, int pf,
                                                       int maxRadius)
@@ -404,6 +408,8 @@ struct thx_reco {
     // (Projector volume)
     hipfftHandle r2cF, c2rF, c2rN, r2cStd;
     bool haveN;
+    float2* tw;       // device, exp(-2 pi i m / PF), m < PF, when PF is 64 or 512 (hand-written FFT passes, thx_fft8.h)
+    int handNS;       // 0: rocFFT only; 2 / 3: PF = 8^handNS
 };
 
 extern "C" {
@@ -442,6 +448,16 @@ int thx_reco_create(thx_reco** out, int size, int N, int pf, float a, float alph
         if (type == HIPFFT_C2R) return hipfftPlanMany(h, 3, n, cE, 1, P * P * padded_nc(P), rE, 1, P * P * P, type, 1);
         return hipfftPlanMany(h, 3, n, rE, 1, P * P * P, cE, 1, P * P * padded_nc(P), type, 1);
     };
+    r->handNS = r->PF == 512 ? 3 : (r->PF == 64 ? 2 : 0);
+    if (r->handNS) {
+        std::vector<float2> tw(r->PF);
+        for (int m = 0; m < r->PF; m++) {
+            const double a = 2.0 * M_PI * m / (double)r->PF;
+            tw[m] = make_float2((float)cos(a), (float)-sin(a));
+        }
+        THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->tw), r->PF * sizeof(float2)));
+        THX_CHECK(hipMemcpy(r->tw, tw.data(), r->PF * sizeof(float2), hipMemcpyHostToDevice));
+    }
     THX_FFT_CHECK(plan_padded(&r->r2cF, r->PF, HIPFFT_R2C));
     THX_FFT_CHECK(plan_padded(&r->c2rF, r->PF, HIPFFT_C2R));
     r->haveN = r->PN != r->PF;
@@ -459,10 +475,65 @@ int thx_reco_destroy(thx_reco* r)
     (void)hipfftDestroy(r->c2rF);
     (void)hipfftDestroy(r->r2cStd);
     if (r->haveN) (void)hipfftDestroy(r->c2rN);
-    (void)hipFree(r->tab); (void)hipFree(r->W); (void)hipFree(r->C); (void)hipFree(r->rl); (void)hipFree(r->diff); (void)hipFree(r->fscDev);
+    (void)hipFree(r->tw); (void)hipFree(r->tab); (void)hipFree(r->W); (void)hipFree(r->C); (void)hipFree(r->rl); (void)hipFree(r->diff); (void)hipFree(r->fscDev);
     delete r;
     return 0;
 }
+
+}  // extern "C"
+
+// The same iteration with the hand-written passes of thx_fft8.h (PF = 64 or 512, power-of-two N pf): per round
+// y inverse -> fused x (inverse, kernel multiply, forward) -> y forward -> fused z (forward, W update + checkC, C = T W,
+// inverse of the next round).  C stays in its padded half-complex grid; the real grid is never materialised.
+template <int NS>
+static int balance_W_hand(thx_reco* r, const float* T, int maxRadius, int maxIter, int minIter, int* itersOut,
+                          float* diffCOut, hipStream_t st)
+{
+    constexpr int P = f8_n<NS>(), NT8 = P / 8, TXZ = 16, TXY = 8, nc = P / 2 + 1;
+    const int pf = r->pf, ncp = padded_nc(P);
+    const size_t ldsZ = (size_t)(f8_rows<NS>() * TXZ + P) * sizeof(float2);
+    const size_t ldsY = (size_t)(f8_rows<NS>() * TXY + P) * sizeof(float2);
+    const size_t ldsX = (size_t)(f8_rows<NS>() * 9 + P) * sizeof(float2) + (P / 2 + 1) * sizeof(float);
+    static std::once_flag once;
+    static hipError_t attrErr = hipSuccess;
+    std::call_once(once, [&]() {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fft_z_update<NS, TXZ, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsZ);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fft_z_update<NS, TXZ, false>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsZ);
+        attrErr = e;
+    });
+    THX_CHECK(attrErr);
+    const dim3 gZ((nc + TXZ - 1) / TXZ, P), bZ(NT8 * TXZ), gY((nc + TXY - 1) / TXY, P), bY(NT8 * TXY);
+    const int r2i = maxRadius * pf;
+    int iters = 0, nNoDec = 0;
+    float diffC = 3.402823466e+38f, diffCPrev = 3.402823466e+38f;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, TXZ, true>), gZ, bZ, ldsZ, st, r->C, r->W, T, ncp, r2i, r->diff, r->tw);
+    for (int m = 0; m < maxIter; m++) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_strided<NS, TXY, 1>), gY, bY, ldsY, st, r->C, (long)ncp, (long)P * ncp, nc, r->tw);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_x_conv<NS>), dim3(P / 2 + 1, P / 2 + 1), dim3(NT8 * 8), ldsX, st, r->C, ncp,
+                           r->N * pf, r->tab, kTabN, r->nf, r->rnf, r->rs, r->tw);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_strided<NS, TXY, -1>), gY, bY, ldsY, st, r->C, (long)ncp, (long)P * ncp, nc, r->tw);
+        THX_CHECK(hipMemsetAsync(r->diff, 0, sizeof(unsigned), st));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, TXZ, false>), gZ, bZ, ldsZ, st, r->C, r->W, T, ncp, r2i, r->diff,
+                           r->tw);
+        unsigned bits = 0;
+        THX_CHECK(hipMemcpyAsync(&bits, r->diff, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        THX_CHECK(hipStreamSynchronize(st));
+        diffCPrev = diffC;
+        memcpy(&diffC, &bits, sizeof(float));
+        iters = m + 1;
+        if (getenv("THX_RECO_TRACE")) fprintf(stderr, "hand round %d diffC %g\n", m, diffC);
+        if ((double)diffC > (double)diffCPrev * 0.95) nNoDec += 1; else nNoDec = 0;   // as balance_W below
+        if (((double)diffC < 1e-2) || ((m >= minIter) && (nNoDec == 2))) break;
+    }
+    THX_LAUNCH_CHECK();
+    *itersOut = iters;
+    *diffCOut = diffC;
+    return 0;
+}
+
+extern "C" {
 
 // The gridding-weight iteration of Reconstructor::reconstruct (src/Reconstructor.cpp:1379-1551): W (r->W) must hold the
 // initial weights, T the floored T; the device-resident loop of C2R -> kernel multiply -> R2C -> W update + checkC.
@@ -474,6 +545,12 @@ static int balance_W(thx_reco* r, const float* T, int maxRadius, int maxIter, in
     float diffC = 3.402823466e+38f, diffCPrev = 3.402823466e+38f;
     const long np = (long)r->N * pf;
     const bool pow2 = ((np & (np - 1)) == 0) && ((PF & (PF - 1)) == 0);
+    {
+        const char* fv = getenv("THX_FFT");   // "rocfft": library transforms for every size (A/B and fallback)
+        if (r->handNS && pow2 && !(fv && fv[0] == 'r'))
+            return r->handNS == 3 ? balance_W_hand<3>(r, T, maxRadius, maxIter, minIter, itersOut, diffCOut, st)
+                                  : balance_W_hand<2>(r, T, maxRadius, maxIter, minIter, itersOut, diffCOut, st);
+    }
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_updateW_calcC<false>), dim3(PF, PF), dim3(256), 0, st, r->W, r->C, T, PF, ncpF, pf,
                        maxRadius, r->diff);
     for (int m = 0; m < maxIter; m++) {
@@ -494,6 +571,7 @@ static int balance_W(thx_reco* r, const float* T, int maxRadius, int maxIter, in
         diffCPrev = diffC;
         memcpy(&diffC, &bits, sizeof(float));
         iters = m + 1;
+        if (getenv("THX_RECO_TRACE")) fprintf(stderr, "rocfft round %d diffC %g\n", m, diffC);
         // src/Reconstructor.cpp:1542-1550 (DIFF_C_DECREASE_THRES 0.95, DIFF_C_THRES 1e-2, N_DIFF_C_NO_DECREASE 2); the
         // comparisons run in double against RFLOAT operands as in the reference
         if ((double)diffC > (double)diffCPrev * 0.95) nNoDec += 1; else nNoDec = 0;
