@@ -125,14 +125,17 @@ __global__ __launch_bounds__((f8_n<NS>() / 8) * TX) void k_fft_strided(float2* _
 // x direction, fused: per row of the half-complex grid (P/2+1 values, Hermitian), inverse transform -> real row ->
 // x 1/size x kernel(|x|^2 / (N pf)^2) / nf (k_convolute_rl's arithmetic, thx_reco.hip) -> forward transform -> same row.
 // One workgroup = one canonical pair 0 <= j <= k <= P/2 and the up to 8 rows (+-j, +-k) / (+-k, +-j) that share the
-// P/2+1 tabulated kernel values (looked up once, kept in LDS).  grid (P/2+1, P/2+1), (P/8) x 8 threads.
+// P/2+1 tabulated kernel values (looked up once, kept in LDS).  Two real rows a, b ride in ONE complex transform:
+// Z = A + i B (A, B Hermitian-extended) -> z = a + i b -> multiply -> Z' -> A' = (Z'[k] + conj Z'[P-k]) / 2,
+// B' = (Z'[k] - conj Z'[P-k]) / 2i; the imaginary parts of A[0], A[P/2] are dropped on load as a c2r transform ignores
+// them.  grid (P/2+1, P/2+1), (P/8) x 4 threads.
 // ---------------------------------------------------------------------------------------------
 template <int NS>
-__global__ __launch_bounds__((f8_n<NS>() / 8) * 8) void k_fft_x_conv(float2* __restrict__ C, int ncp, int NP,
+__global__ __launch_bounds__((f8_n<NS>() / 8) * 4) void k_fft_x_conv(float2* __restrict__ C, int ncp, int NP,
                                                                    const float* __restrict__ tab, int tabN, float nf, float rnf,
                                                                    float rs, const float2* __restrict__ tw)
 {
-    constexpr int P = f8_n<NS>(), NT8 = P / 8, h = P / 2, PITCH = 9, NTHR = NT8 * 8;
+    constexpr int P = f8_n<NS>(), NT8 = P / 8, h = P / 2, NCOL = 4, PITCH = NCOL + 1, NTHR = NT8 * NCOL;
     extern __shared__ float2 f8_lds[];
     float2* sTw = f8_lds + f8_rows<NS>() * PITCH;
     float* sval = reinterpret_cast<float*>(sTw + P);   // [h + 1]
@@ -165,19 +168,22 @@ __global__ __launch_bounds__((f8_n<NS>() / 8) * 8) void k_fft_x_conv(float2* __r
         sNRows = n;
     }
     __syncthreads();
-    const int nRows = sNRows;
-    // coalesced load of the stored half rows, Hermitian extension into the tile
-    for (int idx = tid; idx < nRows * (h + 1); idx += NTHR) {
-        const int r = idx / (h + 1), i = idx - r * (h + 1);
-        const float2 val = C[(size_t)rowOff[r] * ncp + i];
-        f8_lds[f8_slot(i, r, PITCH)] = val;
-        if (i > 0 && i < h) f8_lds[f8_slot(P - i, r, PITCH)] = make_float2(val.x, -val.y);
+    const int nRows = sNRows, nPairs = (nRows + 1) >> 1;
+    // coalesced loads of the stored half rows; Z = A + i B with the Hermitian extension of both
+    for (int idx = tid; idx < nPairs * (h + 1); idx += NTHR) {
+        const int p = idx / (h + 1), i = idx - p * (h + 1);
+        float2 A = C[(size_t)rowOff[2 * p] * ncp + i];
+        float2 B = (2 * p + 1 < nRows) ? C[(size_t)rowOff[2 * p + 1] * ncp + i] : make_float2(0.f, 0.f);
+        if (i == 0 || i == h) { A.y = 0.f; B.y = 0.f; }
+        f8_lds[f8_slot(i, p, PITCH)] = make_float2(A.x - B.y, A.y + B.x);
+        if (i > 0 && i < h) f8_lds[f8_slot(P - i, p, PITCH)] = make_float2(A.x + B.y, B.x - A.y);
     }
     __syncthreads();
-    const int c = tid & 7, t = tid >> 3;
+    const int c = tid & (NCOL - 1), t = tid / NCOL;
+    const bool live = c < nPairs;   // idle columns still take part in the barriers
     float2 v[8];
 #pragma unroll
-    for (int n = 0; n < 8; n++) v[n] = f8_lds[f8_slot(t + NT8 * n, c, PITCH)];
+    for (int n = 0; n < 8; n++) v[n] = live ? f8_lds[f8_slot(t + NT8 * n, c, PITCH)] : make_float2(0.f, 0.f);
     __syncthreads();
     fft8n<NS, 1>(v, t, c, PITCH, f8_lds, sTw);
     {
@@ -185,17 +191,20 @@ __global__ __launch_bounds__((f8_n<NS>() / 8) * 8) void k_fft_x_conv(float2* __r
 #pragma unroll
         for (int n = 0; n < 8; n++) {
             const int iw = t + NT8 * n;
-            const int ai = iw >= h ? P - iw : iw;
-            v[n] = make_float2(div_by_const((v[n].x * rn) * sval[ai], nf, rnf), 0.f);
+            const float sv = sval[iw >= h ? P - iw : iw];
+            v[n] = make_float2(div_by_const((v[n].x * rn) * sv, nf, rnf), div_by_const((v[n].y * rn) * sv, nf, rnf));
         }
     }
     fft8n<NS, -1>(v, t, c, PITCH, f8_lds, sTw);
 #pragma unroll
     for (int n = 0; n < 8; n++) f8_lds[f8_slot(t + NT8 * n, c, PITCH)] = v[n];
     __syncthreads();
-    for (int idx = tid; idx < nRows * (h + 1); idx += NTHR) {
-        const int r = idx / (h + 1), i = idx - r * (h + 1);
-        C[(size_t)rowOff[r] * ncp + i] = f8_lds[f8_slot(i, r, PITCH)];
+    for (int idx = tid; idx < nPairs * (h + 1); idx += NTHR) {
+        const int p = idx / (h + 1), i = idx - p * (h + 1);
+        const float2 U = f8_lds[f8_slot(i, p, PITCH)];
+        const float2 Vr = f8_lds[f8_slot((P - i) & (P - 1), p, PITCH)];   // conj(V) = (Vr.x, -Vr.y)
+        C[(size_t)rowOff[2 * p] * ncp + i] = make_float2(0.5f * (U.x + Vr.x), 0.5f * (U.y - Vr.y));
+        if (2 * p + 1 < nRows) C[(size_t)rowOff[2 * p + 1] * ncp + i] = make_float2(0.5f * (U.y + Vr.y), 0.5f * (Vr.x - U.x));
     }
 }
 
@@ -206,7 +215,7 @@ __global__ __launch_bounds__((f8_n<NS>() / 8) * 8) void k_fft_x_conv(float2* __r
 // W, T rows are P/2+1 long, C rows ncp.  diffBits: float bits of the running maximum (>= 0: uint order == float order).
 // ---------------------------------------------------------------------------------------------
 template <int NS, int TX, bool FIRST>
-__global__ __launch_bounds__((f8_n<NS>() / 8) * TX) void k_fft_z_update(float2* __restrict__ C, float* __restrict__ W,
+__global__ __launch_bounds__((f8_n<NS>() / 8) * TX, 8) void k_fft_z_update(float2* __restrict__ C, float* __restrict__ W,
                                                                       const float* __restrict__ T, int ncp, int r2i,
                                                                       unsigned* __restrict__ diffBits,
                                                                       const float2* __restrict__ tw)

@@ -493,7 +493,7 @@ static int balance_W_hand(thx_reco* r, const float* T, int maxRadius, int maxIte
     const int pf = r->pf, ncp = padded_nc(P);
     const size_t ldsZ = (size_t)(f8_rows<NS>() * TXZ + P) * sizeof(float2);
     const size_t ldsY = (size_t)(f8_rows<NS>() * TXY + P) * sizeof(float2);
-    const size_t ldsX = (size_t)(f8_rows<NS>() * 9 + P) * sizeof(float2) + (P / 2 + 1) * sizeof(float);
+    const size_t ldsX = (size_t)(f8_rows<NS>() * 5 + P) * sizeof(float2) + (P / 2 + 1) * sizeof(float);
     static std::once_flag once;
     static hipError_t attrErr = hipSuccess;
     std::call_once(once, [&]() {
@@ -511,7 +511,7 @@ static int balance_W_hand(thx_reco* r, const float* T, int maxRadius, int maxIte
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, TXZ, true>), gZ, bZ, ldsZ, st, r->C, r->W, T, ncp, r2i, r->diff, r->tw);
     for (int m = 0; m < maxIter; m++) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_strided<NS, TXY, 1>), gY, bY, ldsY, st, r->C, (long)ncp, (long)P * ncp, nc, r->tw);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_x_conv<NS>), dim3(P / 2 + 1, P / 2 + 1), dim3(NT8 * 8), ldsX, st, r->C, ncp,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_x_conv<NS>), dim3(P / 2 + 1, P / 2 + 1), dim3(NT8 * 4), ldsX, st, r->C, ncp,
                            r->N * pf, r->tab, kTabN, r->nf, r->rnf, r->rs, r->tw);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_strided<NS, TXY, -1>), gY, bY, ldsY, st, r->C, (long)ncp, (long)P * ncp, nc, r->tw);
         THX_CHECK(hipMemsetAsync(r->diff, 0, sizeof(unsigned), st));
