@@ -954,10 +954,13 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_win(InsertWinArgs wa)
             if (U <= kMaxU)
                 for (int e = tid; e < 2 * U * kIPix; e += kInsThreads) {
                     const int which = e / (U * kIPix), rem = e - which * U * kIPix, u = rem / kIPix, o = rem - u * kIPix;
-                    const double ph = kM2xPi * ((double)((which ? g.uj0 : g.ui0) + o) * (double)sSlope[2 * u + which]);
-                    double sn, cs;
-                    sincos(-ph, &sn, &cs);
-                    (which ? sEr : sEc)[u * kIPix + o] = make_float2((float)cs, (float)sn);
+                    // exp(-2 pi i n slope): the whole turns are removed in double (n slope is exact to 1e-13), the
+                    // remaining fraction of a turn goes through sincospif -- within 1e-7 of the double-precision value
+                    double cyc = (double)((which ? g.uj0 : g.ui0) + o) * (double)sSlope[2 * u + which];
+                    cyc -= rint(cyc);
+                    float sn, cs;
+                    sincospif(-2.0f * (float)cyc, &sn, &cs);
+                    (which ? sEr : sEc)[u * kIPix + o] = make_float2(cs, sn);
                 }
             __syncthreads();
             const int sLo = (sWlo + kWz / 2) >= 0 ? (sWlo + kWz / 2) / kWz : -((-(sWlo + kWz / 2) + kWz - 1) / kWz);
