@@ -561,10 +561,15 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_tiles(InsertTileArgs 
 // a neighbouring window or slab takes them -- then flushes along the volume's x axis.  Every term is added exactly once,
 // the flush traffic is that of one large brick, and only ~40 % of the candidates are hits (cheap: positions only).
 // ---------------------------------------------------------------------------------------------
-constexpr int kWd = 16;                     // window edge in (p, q), voxels
-constexpr int kWz = 16;                     // slab thickness along the sheared axis, voxels
+#ifndef THX_KWD   // window geometry; overridable at compile time for parameter sweeps (tools/insert_probe.py)
+#define THX_KWD 16
+#define THX_KWZ 16
+#define THX_KIPIX 24
+#endif
+constexpr int kWd = THX_KWD;                // window edge in (p, q), voxels
+constexpr int kWz = THX_KWZ;                // slab thickness along the sheared axis, voxels
 constexpr int kWinVox = kWd * kWd * kWz;    // 4096 voxels x 12 B = 48 KB
-constexpr int kIPix = 24;                   // per-window tabulated pixel range per axis (pixel data, separable ramps)
+constexpr int kIPix = THX_KIPIX;            // per-window tabulated pixel range per axis (pixel data, separable ramps)
 
 struct InsertWinArgs {
     InsertArgs a;
