@@ -14,7 +14,7 @@ n = rot.shape[0]
 r = rot.reshape(n, sh.mReco, 9)
 distinct = np.mean([len(np.unique(r[i].cpu().numpy(), axis=0)) for i in range(0, n, max(1, n // 64))])
 print("avg distinct rotations per image among %d draws: %.1f" % (sh.mReco, distinct))
-for dbg in (8, 0, 1, 2, 3, 4):
+for dbg in [int(x) for x in os.environ.get("DBGS", "8,0,1,2,3,4").split(",")]:
     os.environ["THX_INSERT_DEBUG"] = str(dbg)
     sh.insertion(0, rot, tran); torch.cuda.synchronize()
     t0 = time.perf_counter(); sh.insertion(0, rot, tran); torch.cuda.synchronize(); dt = time.perf_counter() - t0
