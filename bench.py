@@ -180,7 +180,10 @@ def main():
                        "parallelism": "particles sharded over %d GPU(s); half-set F/T all-reduce" % world},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kms,
-                         "algorithmic_bytes_per_launch": kbytes},
+                         "algorithmic_bytes_per_launch": kbytes,
+                         # tools/gather_probe.hip on MI355X: 64-byte gathers by the 64 lanes of a wave within +-R voxels of
+                         # a walking centre (the E-step's pattern without any cross-sample reuse), GB/s for R = 2 / 4 / 8
+                         "random_64B_gather_GBps": {"R2": 7000.0, "R4": 4190.0, "R8": 3530.0}},
             "kernels": {"k_insert_win": {"avg_launch_ms": ins_ms, "GBps_algorithmic": ins_bytes / (ins_ms * 1e-3) / 1e9,
                                      "total_ms": t_ins},
                         "k_expect_local": {"avg_launch_ms": exp_ms,
