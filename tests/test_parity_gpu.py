@@ -368,7 +368,8 @@ def _fsc_np(O, a, b, N):
 
 @pytest.mark.parametrize("MAP,gridCorr,joinHalf,N", [(False, True, False, 32), (True, True, True, 32),
                                                      (True, False, False, 32), (False, False, False, 32),
-                                                     (True, True, False, 24)])   # N = 24: non-power-of-two grid
+                                                     (True, True, False, 24),    # N = 24: non-power-of-two grid (rocFFT)
+                                                     (True, True, False, 64)])   # P = 128: radix-2 pre-stage + 8 x 8
 def test_reconstruct(oracle, dev, MAP, gridCorr, joinHalf, N):
     from thunder_amd import ops
     O = oracle
@@ -753,16 +754,18 @@ def test_full_size_properties_n512(oracle, dev):
     plan.close()
 
 
-def test_hand_fft_passes_match_rocfft_n256(dev, monkeypatch):
-    """The gridding iteration at the BASELINE grid (P = 512) runs on the hand-written FFT passes of thx_fft8.h (strided
-    radix-8^3 passes, x transform fused with the kernel multiply, z transform fused with the weight update); at P = 64 the
-    same code is checked against the oracle by test_reconstruct.  Here: identical inputs through THX_FFT=rocfft (library
+@pytest.mark.parametrize("N", [64, 128, 256, 512])
+def test_hand_fft_passes_match_rocfft(dev, monkeypatch, N):
+    """The gridding iteration on power-of-two grids (P = 128 ... 1024 here; the BASELINE grid is P = 512) runs on the
+    hand-written FFT passes of thx_fft8.h (strided radix-8 passes with a radix-2 / 4 pre-stage where needed, x transform
+    fused with the kernel multiply, z transform fused with the weight update); at P = 64 and 128 the same code is checked
+    against the oracle by test_reconstruct.  Here: identical inputs through THX_FFT=rocfft (library
     transforms + separate elementwise kernels) and the default path must give the same number of rounds, the same diffC
     and the same map.  The inputs are analytic (T = a smooth sampling density, F = reference x T), so that the run is
     deterministic and well conditioned: with sparse inserted data the max-norm stop rule amplifies last-bit differences
     (of the FFTs, or of the atomics' order from run to run) into different round counts -- for rocFFT against itself too."""
     from thunder_amd import ops, synth
-    N, P = 256, 512
+    P = 2 * N
     plan = ops.RecoPlan(N, N, 2)
     vol = plan.set_projectee(T(synth.blob_map(N, nblob=12), dev))
     ax = torch.fft.fftfreq(P, d=1.0 / P, device=dev)

@@ -1,5 +1,5 @@
 // thx_fft8.h -- hand-written FFT passes of the gridding-weight iteration (Reconstructor::reconstruct's balancing loop,
-// src/Reconstructor.cpp:1379-1551) for grids of 8^NS points per axis (64, 512).
+// src/Reconstructor.cpp:1379-1551) for power-of-two grids of 64 ... 2048 points per axis (R 8^NS, R = 1, 2, 4).
 //
 // Why: rocFFT's strided passes over the [P][P][P/2+1] grid run at 2.25 TB/s (0.48 ms per pass at P = 512); a pass that
 // stages 512 points x TX adjacent columns in LDS and does the three radix-8 stages there runs at 4.3 TB/s (0.25 ms,
@@ -53,58 +53,123 @@ __device__ __forceinline__ void fft8(float2 v[8])
 
 // LDS slot of element e of column c: element-major with `pitch` slots per element, one padding row per 64 elements
 __device__ __forceinline__ int f8_slot(int e, int c, int pitch) { return (e + (e >> 6)) * pitch + c; }
-template <int NS> __host__ __device__ constexpr int f8_n() { return NS == 3 ? 512 : 64; }
-template <int NS> __host__ __device__ constexpr int f8_rows() { return f8_n<NS>() + (f8_n<NS>() >> 6); }
+// Grid sizes: N = R * 8^NS with R in {1, 2, 4}: 64, 128, 256 (NS = 2) and 512, 1024, 2048 (NS = 3)
+template <int NS> __host__ __device__ constexpr int f8_m() { return NS == 3 ? 512 : 64; }
+template <int NS, int R> __host__ __device__ constexpr int f8_n() { return R * f8_m<NS>(); }
+template <int NS, int R> __host__ __device__ constexpr int f8_rows() { return f8_n<NS, R>() + (f8_n<NS, R>() >> 6); }
 
-// The stages after the first butterfly's operands are in registers: in v[n] = x[t + (N/8) n], out v[k] = X[t + (N/8) k].
-// s: the column tile (f8_rows x pitch), sTw: exp(-2 pi i m / N), m < N.  All threads of the workgroup must call it.
-template <int NS, int DIR>
-__device__ __forceinline__ void fft8n(float2 v[8], int t, int c, int pitch, float2* s, const float2* sTw)
+// The radix-8 stages of an M = 8^NS point transform whose first butterfly's operands are in registers:
+// in v[n] = x[t + (M/8) n], out v[k] = X[t + (M/8) k], t < M/8.  The sequence lives at elements [eoff, eoff + M) of the
+// tile s; sTw holds exp(-2 pi i m / (TWS M)), so w_M^j = sTw[TWS j].  All threads of the workgroup must call it.
+template <int NS, int DIR, int TWS>
+__device__ __forceinline__ void fft8n(float2 v[8], int t, int c, int pitch, float2* s, const float2* sTw, int eoff)
 {
     fft8<DIR>(v);
     if (NS == 3) {
         {
             const int n1 = t >> 3;
 #pragma unroll
-            for (int k0 = 0; k0 < 8; k0++) s[f8_slot(k0 * 64 + t, c, pitch)] = cmul(v[k0], f8_tw<DIR>(sTw[(8 * n1 * k0) & 511]));
+            for (int k0 = 0; k0 < 8; k0++)
+                s[f8_slot(eoff + k0 * 64 + t, c, pitch)] = cmul(v[k0], f8_tw<DIR>(sTw[((8 * n1 * k0) & 511) * TWS]));
         }
         __syncthreads();
         {
             const int n0 = t & 7, k0 = t >> 3;
 #pragma unroll
-            for (int n1 = 0; n1 < 8; n1++) v[n1] = s[f8_slot(k0 * 64 + n1 * 8 + n0, c, pitch)];
+            for (int n1 = 0; n1 < 8; n1++) v[n1] = s[f8_slot(eoff + k0 * 64 + n1 * 8 + n0, c, pitch)];
             fft8<DIR>(v);
 #pragma unroll
-            for (int k1 = 0; k1 < 8; k1++) s[f8_slot(k0 * 64 + k1 * 8 + n0, c, pitch)] = cmul(v[k1], f8_tw<DIR>(sTw[n0 * (k0 + 8 * k1)]));
+            for (int k1 = 0; k1 < 8; k1++)
+                s[f8_slot(eoff + k0 * 64 + k1 * 8 + n0, c, pitch)] = cmul(v[k1], f8_tw<DIR>(sTw[(n0 * (k0 + 8 * k1)) * TWS]));
         }
         __syncthreads();
         {
             const int k0 = t & 7, k1 = t >> 3;
 #pragma unroll
-            for (int n0 = 0; n0 < 8; n0++) v[n0] = s[f8_slot(k0 * 64 + k1 * 8 + n0, c, pitch)];
+            for (int n0 = 0; n0 < 8; n0++) v[n0] = s[f8_slot(eoff + k0 * 64 + k1 * 8 + n0, c, pitch)];
             fft8<DIR>(v);
         }
-    } else {   // N = 64: t = n0, then t = k0
+    } else {   // M = 64: t = n0, then t = k0
 #pragma unroll
-        for (int k0 = 0; k0 < 8; k0++) s[f8_slot(k0 * 8 + t, c, pitch)] = cmul(v[k0], f8_tw<DIR>(sTw[t * k0]));
+        for (int k0 = 0; k0 < 8; k0++) s[f8_slot(eoff + k0 * 8 + t, c, pitch)] = cmul(v[k0], f8_tw<DIR>(sTw[(t * k0) * TWS]));
         __syncthreads();
 #pragma unroll
-        for (int n0 = 0; n0 < 8; n0++) v[n0] = s[f8_slot(t * 8 + n0, c, pitch)];
+        for (int n0 = 0; n0 < 8; n0++) v[n0] = s[f8_slot(eoff + t * 8 + n0, c, pitch)];
         fft8<DIR>(v);
     }
     __syncthreads();   // the tile may be rewritten by the caller (next transform, staging for the store)
 }
 
+// Element held in register q of thread tau (tau < N/8) BEFORE a transform, and in register k AFTER it.
+//   N = R M:  X[k0 + R k1] = sum_b w_M^(b k1) [ w_N^(b k0) sum_a w_R^(a k0) x[M a + b] ],  a, k0 < R,  b, k1 < M
+// before: q = a + R i  ->  element M a + (tau + (N/8) i)          (the R-point butterflies of 8/R values of b)
+// after : thread tau = (k0, t), k0 = tau / (M/8)  ->  element k0 + R (t + (M/8) k)
+// For R = 1 both are tau + (N/8) q: transforms chain through registers; otherwise through one pass over the tile.
+template <int NS, int R> __device__ __forceinline__ int f8_epre(int tau, int q)
+{
+    return f8_m<NS>() * (q % R) + tau + (f8_n<NS, R>() / 8) * (q / R);
+}
+template <int NS, int R> __device__ __forceinline__ int f8_eout(int tau, int k)
+{
+    constexpr int M8 = f8_m<NS>() / 8;
+    return (tau / M8) + R * ((tau % M8) + M8 * k);
+}
+
+// N = R 8^NS point transform: in v[q] = x[f8_epre(tau, q)], out v[k] = X[f8_eout(tau, k)].  s: tile of f8_rows<NS, R>() rows,
+// sTw: exp(-2 pi i m / N), m < N.
+template <int NS, int R, int DIR>
+__device__ __forceinline__ void fftN(float2 v[8], int tau, int c, int pitch, float2* s, const float2* sTw)
+{
+    constexpr int M = f8_m<NS>(), M8 = M / 8, T = f8_n<NS, R>() / 8;
+    if (R == 1) {
+        fft8n<NS, DIR, 1>(v, tau, c, pitch, s, sTw, 0);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8 / R; i++) {
+        float2* u = v + R * i;
+        if (R == 2) {
+            const float2 a0 = u[0], a1 = u[1];
+            u[0] = f8_add(a0, a1); u[1] = f8_sub(a0, a1);
+        } else {
+            const float2 e0 = f8_add(u[0], u[2]), e1 = f8_sub(u[0], u[2]), o0 = f8_add(u[1], u[3]), o1 = f8_mul_i<DIR>(f8_sub(u[1], u[3]));
+            u[0] = f8_add(e0, o0); u[2] = f8_sub(e0, o0); u[1] = f8_add(e1, o1); u[3] = f8_sub(e1, o1);
+        }
+        const int b = tau + T * i;
+#pragma unroll
+        for (int k0 = 0; k0 < R; k0++) s[f8_slot(k0 * M + b, c, pitch)] = cmul(u[k0], f8_tw<DIR>(sTw[b * k0]));
+    }
+    __syncthreads();
+    const int k0 = tau / M8, t = tau % M8;
+#pragma unroll
+    for (int n = 0; n < 8; n++) v[n] = s[f8_slot(k0 * M + t + M8 * n, c, pitch)];
+    // the first stage below writes exactly the slots this thread has just read: no barrier needed in between
+    fft8n<NS, DIR, R>(v, t, c, pitch, s, sTw, k0 * M);
+}
+
+// registers after one transform -> registers before the next one (a no-op for R = 1)
+template <int NS, int R>
+__device__ __forceinline__ void f8_rearrange(float2 v[8], int tau, int c, int pitch, float2* s)
+{
+    if (R == 1) return;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[f8_slot(f8_eout<NS, R>(tau, k), c, pitch)] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = s[f8_slot(f8_epre<NS, R>(tau, q), c, pitch)];
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
 // Strided pass, in place: data[b strideB + e strideE + x], e < N, x = blockIdx.x TX + c < nx.  grid (ceil(nx / TX), nBatch).
 // ---------------------------------------------------------------------------------------------
-template <int NS, int TX, int DIR>
-__global__ __launch_bounds__((f8_n<NS>() / 8) * TX) void k_fft_strided(float2* __restrict__ data, long strideE, long strideB, int nx,
-                                                                     const float2* __restrict__ tw)
+template <int NS, int R, int TX, int DIR>
+__global__ __launch_bounds__((f8_n<NS, R>() / 8) * TX) void k_fft_strided(float2* __restrict__ data, long strideE, long strideB,
+                                                                        int nx, const float2* __restrict__ tw)
 {
-    constexpr int N = f8_n<NS>(), NT8 = N / 8;
+    constexpr int N = f8_n<NS, R>(), NT8 = N / 8;
     extern __shared__ float2 f8_lds[];
-    float2* sTw = f8_lds + f8_rows<NS>() * TX;
+    float2* sTw = f8_lds + f8_rows<NS, R>() * TX;
     const int c = threadIdx.x % TX, t = threadIdx.x / TX;
     const int x = blockIdx.x * TX + c;
     const bool ok = x < nx;
@@ -112,12 +177,12 @@ __global__ __launch_bounds__((f8_n<NS>() / 8) * TX) void k_fft_strided(float2* _
     for (int i = threadIdx.x; i < N; i += NT8 * TX) sTw[i] = tw[i];
     float2 v[8];
 #pragma unroll
-    for (int n = 0; n < 8; n++) v[n] = ok ? base[(long)(t + NT8 * n) * strideE] : make_float2(0.f, 0.f);
+    for (int q = 0; q < 8; q++) v[q] = ok ? base[(long)f8_epre<NS, R>(t, q) * strideE] : make_float2(0.f, 0.f);
     __syncthreads();
-    fft8n<NS, DIR>(v, t, c, TX, f8_lds, sTw);
+    fftN<NS, R, DIR>(v, t, c, TX, f8_lds, sTw);
     if (ok) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) base[(long)(t + NT8 * k) * strideE] = v[k];
+        for (int k = 0; k < 8; k++) base[(long)f8_eout<NS, R>(t, k) * strideE] = v[k];
     }
 }
 
@@ -130,14 +195,14 @@ __global__ __launch_bounds__((f8_n<NS>() / 8) * TX) void k_fft_strided(float2* _
 // B' = (Z'[k] - conj Z'[P-k]) / 2i; the imaginary parts of A[0], A[P/2] are dropped on load as a c2r transform ignores
 // them.  grid (P/2+1, P/2+1), (P/8) x 4 threads.
 // ---------------------------------------------------------------------------------------------
-template <int NS>
-__global__ __launch_bounds__((f8_n<NS>() / 8) * 4) void k_fft_x_conv(float2* __restrict__ C, int ncp, int NP,
-                                                                   const float* __restrict__ tab, int tabN, float nf, float rnf,
-                                                                   float rs, const float2* __restrict__ tw)
+template <int NS, int R>
+__global__ __launch_bounds__((f8_n<NS, R>() / 8) * 4) void k_fft_x_conv(float2* __restrict__ C, int ncp, int NP,
+                                                                      const float* __restrict__ tab, int tabN, float nf,
+                                                                      float rnf, float rs, const float2* __restrict__ tw)
 {
-    constexpr int P = f8_n<NS>(), NT8 = P / 8, h = P / 2, NCOL = 4, PITCH = NCOL + 1, NTHR = NT8 * NCOL;
+    constexpr int P = f8_n<NS, R>(), NT8 = P / 8, h = P / 2, NCOL = 4, PITCH = NCOL + 1, NTHR = NT8 * NCOL;
     extern __shared__ float2 f8_lds[];
-    float2* sTw = f8_lds + f8_rows<NS>() * PITCH;
+    float2* sTw = f8_lds + f8_rows<NS, R>() * PITCH;
     float* sval = reinterpret_cast<float*>(sTw + P);   // [h + 1]
     __shared__ int rowOff[8];
     __shared__ int sNRows;
@@ -183,21 +248,22 @@ __global__ __launch_bounds__((f8_n<NS>() / 8) * 4) void k_fft_x_conv(float2* __r
     const bool live = c < nPairs;   // idle columns still take part in the barriers
     float2 v[8];
 #pragma unroll
-    for (int n = 0; n < 8; n++) v[n] = live ? f8_lds[f8_slot(t + NT8 * n, c, PITCH)] : make_float2(0.f, 0.f);
+    for (int q = 0; q < 8; q++) v[q] = live ? f8_lds[f8_slot(f8_epre<NS, R>(t, q), c, PITCH)] : make_float2(0.f, 0.f);
     __syncthreads();
-    fft8n<NS, 1>(v, t, c, PITCH, f8_lds, sTw);
+    fftN<NS, R, 1>(v, t, c, PITCH, f8_lds, sTw);
     {
         const float rn = (float)(1.0 / ((double)P * P * P));   // P^3 is a power of two: exact
 #pragma unroll
         for (int n = 0; n < 8; n++) {
-            const int iw = t + NT8 * n;
+            const int iw = f8_eout<NS, R>(t, n);
             const float sv = sval[iw >= h ? P - iw : iw];
             v[n] = make_float2(div_by_const((v[n].x * rn) * sv, nf, rnf), div_by_const((v[n].y * rn) * sv, nf, rnf));
         }
     }
-    fft8n<NS, -1>(v, t, c, PITCH, f8_lds, sTw);
+    f8_rearrange<NS, R>(v, t, c, PITCH, f8_lds);
+    fftN<NS, R, -1>(v, t, c, PITCH, f8_lds, sTw);
 #pragma unroll
-    for (int n = 0; n < 8; n++) f8_lds[f8_slot(t + NT8 * n, c, PITCH)] = v[n];
+    for (int n = 0; n < 8; n++) f8_lds[f8_slot(f8_eout<NS, R>(t, n), c, PITCH)] = v[n];
     __syncthreads();
     for (int idx = tid; idx < nPairs * (h + 1); idx += NTHR) {
         const int p = idx / (h + 1), i = idx - p * (h + 1);
@@ -214,15 +280,15 @@ __global__ __launch_bounds__((f8_n<NS>() / 8) * 4) void k_fft_x_conv(float2* __r
 //   else :  forward z transform -> W /= max(|C|, 1e-6) inside the sphere, checkC max |(|C| - 1)|, C = T W -> inverse z
 // W, T rows are P/2+1 long, C rows ncp.  diffBits: float bits of the running maximum (>= 0: uint order == float order).
 // ---------------------------------------------------------------------------------------------
-template <int NS, int TX, bool FIRST>
-__global__ __launch_bounds__((f8_n<NS>() / 8) * TX, 8) void k_fft_z_update(float2* __restrict__ C, float* __restrict__ W,
-                                                                      const float* __restrict__ T, int ncp, int r2i,
-                                                                      unsigned* __restrict__ diffBits,
-                                                                      const float2* __restrict__ tw)
+template <int NS, int R, int TX, bool FIRST>
+__global__ __launch_bounds__((f8_n<NS, R>() / 8) * TX, 8) void k_fft_z_update(float2* __restrict__ C, float* __restrict__ W,
+                                                                         const float* __restrict__ T, int ncp, int r2i,
+                                                                         unsigned* __restrict__ diffBits,
+                                                                         const float2* __restrict__ tw)
 {
-    constexpr int P = f8_n<NS>(), NT8 = P / 8, nc = P / 2 + 1, NTHR = NT8 * TX;
+    constexpr int P = f8_n<NS, R>(), NT8 = P / 8, nc = P / 2 + 1, NTHR = NT8 * TX;
     extern __shared__ float2 f8_lds[];
-    float2* sTw = f8_lds + f8_rows<NS>() * TX;
+    float2* sTw = f8_lds + f8_rows<NS, R>() * TX;
     __shared__ float sred[16];
     const int c = threadIdx.x % TX, t = threadIdx.x / TX;
     const int x = blockIdx.x * TX + c, jw = blockIdx.y;
@@ -234,9 +300,9 @@ __global__ __launch_bounds__((f8_n<NS>() / 8) * TX, 8) void k_fft_z_update(float
     float2* base = C + (long)jw * ncp + x;
     if (!FIRST) {
 #pragma unroll
-        for (int n = 0; n < 8; n++) v[n] = ok ? base[(long)(t + NT8 * n) * strideE] : make_float2(0.f, 0.f);
+        for (int q = 0; q < 8; q++) v[q] = ok ? base[(long)f8_epre<NS, R>(t, q) * strideE] : make_float2(0.f, 0.f);
         __syncthreads();
-        fft8n<NS, -1>(v, t, c, TX, f8_lds, sTw);
+        fftN<NS, R, -1>(v, t, c, TX, f8_lds, sTw);
     } else {
         __syncthreads();
     }
@@ -246,7 +312,7 @@ __global__ __launch_bounds__((f8_n<NS>() / 8) * TX, 8) void k_fft_z_update(float
         const double r2 = (double)pow2f_((float)r2i);
 #pragma unroll
         for (int n = 0; n < 8; n++) {
-            const int kw = t + NT8 * n;
+            const int kw = f8_eout<NS, R>(t, n);
             const int k = kw >= P / 2 ? kw - P : kw;
             float2 o = make_float2(0.f, 0.f);
             if (ok) {
@@ -263,10 +329,11 @@ __global__ __launch_bounds__((f8_n<NS>() / 8) * TX, 8) void k_fft_z_update(float
             v[n] = o;
         }
     }
-    fft8n<NS, 1>(v, t, c, TX, f8_lds, sTw);
+    f8_rearrange<NS, R>(v, t, c, TX, f8_lds);
+    fftN<NS, R, 1>(v, t, c, TX, f8_lds, sTw);
     if (ok) {
 #pragma unroll
-        for (int n = 0; n < 8; n++) base[(long)(t + NT8 * n) * strideE] = v[n];
+        for (int n = 0; n < 8; n++) base[(long)f8_eout<NS, R>(t, n) * strideE] = v[n];
     }
     if (!FIRST) {
         d = wave_max(d);

@@ -408,8 +408,8 @@ struct thx_reco {
     // (Projector volume)
     hipfftHandle r2cF, c2rF, c2rN, r2cStd;
     bool haveN;
-    float2* tw;       // device, exp(-2 pi i m / PF), m < PF, when PF is 64 or 512 (hand-written FFT passes, thx_fft8.h)
-    int handNS;       // 0: rocFFT only; 2 / 3: PF = 8^handNS
+    float2* tw;       // device, exp(-2 pi i m / PF), m < PF, when PF is a power of two in 64 .. 2048 (thx_fft8.h)
+    int handNS;       // 0: rocFFT only; 2: PF = 64, 128, 256; 3: PF = 512, 1024, 2048
 };
 
 extern "C" {
@@ -448,7 +448,7 @@ int thx_reco_create(thx_reco** out, int size, int N, int pf, float a, float alph
         if (type == HIPFFT_C2R) return hipfftPlanMany(h, 3, n, cE, 1, P * P * padded_nc(P), rE, 1, P * P * P, type, 1);
         return hipfftPlanMany(h, 3, n, rE, 1, P * P * P, cE, 1, P * P * padded_nc(P), type, 1);
     };
-    r->handNS = r->PF == 512 ? 3 : (r->PF == 64 ? 2 : 0);
+    r->handNS = (r->PF == 512 || r->PF == 1024 || r->PF == 2048) ? 3 : ((r->PF == 64 || r->PF == 128 || r->PF == 256) ? 2 : 0);
     if (r->handNS) {
         std::vector<float2> tw(r->PF);
         for (int m = 0; m < r->PF; m++) {
@@ -482,40 +482,44 @@ int thx_reco_destroy(thx_reco* r)
 
 }  // extern "C"
 
-// The same iteration with the hand-written passes of thx_fft8.h (PF = 64 or 512, power-of-two N pf): per round
+// The same iteration with the hand-written passes of thx_fft8.h (PF = R 8^NS: 64 ... 2048, power-of-two N pf): per round
 // y inverse -> fused x (inverse, kernel multiply, forward) -> y forward -> fused z (forward, W update + checkC, C = T W,
 // inverse of the next round).  C stays in its padded half-complex grid; the real grid is never materialised.
-template <int NS>
+template <int NS, int R>
 static int balance_W_hand(thx_reco* r, const float* T, int maxRadius, int maxIter, int minIter, int* itersOut,
                           float* diffCOut, hipStream_t st)
 {
-    constexpr int P = f8_n<NS>(), NT8 = P / 8, TXZ = 16, TXY = 8, nc = P / 2 + 1;
+    constexpr int P = f8_n<NS, R>(), NT8 = P / 8, nc = P / 2 + 1;
+    constexpr int TXZ = NT8 * 16 <= 1024 ? 16 : (NT8 * 8 <= 1024 ? 8 : 4), TXY = NT8 * 8 <= 1024 ? 8 : 4;
     const int pf = r->pf, ncp = padded_nc(P);
-    const size_t ldsZ = (size_t)(f8_rows<NS>() * TXZ + P) * sizeof(float2);
-    const size_t ldsY = (size_t)(f8_rows<NS>() * TXY + P) * sizeof(float2);
-    const size_t ldsX = (size_t)(f8_rows<NS>() * 5 + P) * sizeof(float2) + (P / 2 + 1) * sizeof(float);
+    const size_t ldsZ = (size_t)(f8_rows<NS, R>() * TXZ + P) * sizeof(float2);
+    const size_t ldsY = (size_t)(f8_rows<NS, R>() * TXY + P) * sizeof(float2);
+    const size_t ldsX = (size_t)(f8_rows<NS, R>() * 5 + P) * sizeof(float2) + (P / 2 + 1) * sizeof(float);
     static std::once_flag once;
     static hipError_t attrErr = hipSuccess;
     std::call_once(once, [&]() {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fft_z_update<NS, TXZ, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsZ);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_fft_z_update<NS, TXZ, false>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsZ);
-        attrErr = e;
+        const void* fn[5] = {reinterpret_cast<const void*>(k_fft_z_update<NS, R, TXZ, true>),
+                             reinterpret_cast<const void*>(k_fft_z_update<NS, R, TXZ, false>),
+                             reinterpret_cast<const void*>(k_fft_strided<NS, R, TXY, 1>),
+                             reinterpret_cast<const void*>(k_fft_strided<NS, R, TXY, -1>),
+                             reinterpret_cast<const void*>(k_fft_x_conv<NS, R>)};
+        const size_t sz[5] = {ldsZ, ldsZ, ldsY, ldsY, ldsX};
+        for (int i = 0; i < 5 && attrErr == hipSuccess; i++)
+            attrErr = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)sz[i]);
     });
     THX_CHECK(attrErr);
     const dim3 gZ((nc + TXZ - 1) / TXZ, P), bZ(NT8 * TXZ), gY((nc + TXY - 1) / TXY, P), bY(NT8 * TXY);
     const int r2i = maxRadius * pf;
     int iters = 0, nNoDec = 0;
     float diffC = 3.402823466e+38f, diffCPrev = 3.402823466e+38f;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, TXZ, true>), gZ, bZ, ldsZ, st, r->C, r->W, T, ncp, r2i, r->diff, r->tw);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, R, TXZ, true>), gZ, bZ, ldsZ, st, r->C, r->W, T, ncp, r2i, r->diff, r->tw);
     for (int m = 0; m < maxIter; m++) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_strided<NS, TXY, 1>), gY, bY, ldsY, st, r->C, (long)ncp, (long)P * ncp, nc, r->tw);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_x_conv<NS>), dim3(P / 2 + 1, P / 2 + 1), dim3(NT8 * 4), ldsX, st, r->C, ncp,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_strided<NS, R, TXY, 1>), gY, bY, ldsY, st, r->C, (long)ncp, (long)P * ncp, nc, r->tw);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_x_conv<NS, R>), dim3(P / 2 + 1, P / 2 + 1), dim3(NT8 * 4), ldsX, st, r->C, ncp,
                            r->N * pf, r->tab, kTabN, r->nf, r->rnf, r->rs, r->tw);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_strided<NS, TXY, -1>), gY, bY, ldsY, st, r->C, (long)ncp, (long)P * ncp, nc, r->tw);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_strided<NS, R, TXY, -1>), gY, bY, ldsY, st, r->C, (long)ncp, (long)P * ncp, nc, r->tw);
         THX_CHECK(hipMemsetAsync(r->diff, 0, sizeof(unsigned), st));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, TXZ, false>), gZ, bZ, ldsZ, st, r->C, r->W, T, ncp, r2i, r->diff,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, R, TXZ, false>), gZ, bZ, ldsZ, st, r->C, r->W, T, ncp, r2i, r->diff,
                            r->tw);
         unsigned bits = 0;
         THX_CHECK(hipMemcpyAsync(&bits, r->diff, sizeof(unsigned), hipMemcpyDeviceToHost, st));
@@ -547,9 +551,19 @@ static int balance_W(thx_reco* r, const float* T, int maxRadius, int maxIter, in
     const bool pow2 = ((np & (np - 1)) == 0) && ((PF & (PF - 1)) == 0);
     {
         const char* fv = getenv("THX_FFT");   // "rocfft": library transforms for every size (A/B and fallback)
-        if (r->handNS && pow2 && !(fv && fv[0] == 'r'))
-            return r->handNS == 3 ? balance_W_hand<3>(r, T, maxRadius, maxIter, minIter, itersOut, diffCOut, st)
-                                  : balance_W_hand<2>(r, T, maxRadius, maxIter, minIter, itersOut, diffCOut, st);
+        if (r->handNS && pow2 && !(fv && fv[0] == 'r')) {
+#define THX_HAND(ns, rr) return balance_W_hand<ns, rr>(r, T, maxRadius, maxIter, minIter, itersOut, diffCOut, st)
+            switch (PF) {
+                case 64: THX_HAND(2, 1);
+                case 128: THX_HAND(2, 2);
+                case 256: THX_HAND(2, 4);
+                case 512: THX_HAND(3, 1);
+                case 1024: THX_HAND(3, 2);
+                case 2048: THX_HAND(3, 4);
+                default: break;
+            }
+#undef THX_HAND
+        }
     }
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_updateW_calcC<false>), dim3(PF, PF), dim3(256), 0, st, r->W, r->C, T, PF, ncpF, pf,
                        maxRadius, r->diff);

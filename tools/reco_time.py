@@ -1,0 +1,29 @@
+"""timing aid: one grid-corrected reconstruction (gridding-weight iteration + final transform) on analytic inputs,
+hand-written FFT passes vs THX_FFT=rocfft, for a given box size"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from thunder_amd import ops, synth
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+dev = torch.device("cuda:0")
+P = 2 * N
+plan = ops.RecoPlan(N, N, 2)
+vol = plan.set_projectee(torch.from_numpy(synth.blob_map(N, nblob=12)).to(dev))
+ax = torch.fft.fftfreq(P, d=1.0 / P, device=dev)
+r = torch.sqrt(ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :P // 2 + 1] ** 2)
+Tt = (1.0 / (1.0 + r / 8.0)).to(torch.float32).contiguous()
+Tt[r >= (N // 2 - 2) * 2 + 1] = 0
+F = (vol * Tt).contiguous()
+del r
+for mode in ("rocfft", "hand"):
+    if mode == "rocfft":
+        os.environ["THX_FFT"] = "rocfft"
+    else:
+        os.environ.pop("THX_FFT", None)
+    plan.reconstruct(F.clone(), Tt.clone(), N // 2 - 2, MAP=False, gridCorr=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan.reconstruct(F.clone(), Tt.clone(), N // 2 - 2, MAP=False, gridCorr=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("N = %d  %s: %.1f ms, %d rounds -> %.2f ms per round" % (N, mode, dt * 1e3, plan.last_iters, dt * 1e3 / plan.last_iters))
