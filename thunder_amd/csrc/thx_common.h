@@ -280,6 +280,12 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release fence, i.e.
+// s_waitcnt vmcnt(0): every wave would sit at the barrier until its outstanding GLOBAL operations -- here thousands of
+// fire-and-forget atomics of a brick flush, microseconds each -- have completed.  Use where only LDS contents are handed
+// over between the phases.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // caller-owned host buffer <-> device staging of the Interface.h-shaped *_host entry points
 struct DevBuf {
     void* p = nullptr;

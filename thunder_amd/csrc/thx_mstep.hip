@@ -611,6 +611,34 @@ struct WinGeom {
     float scaleF, scaleT, invF, invT, minQ;
 };
 
+// Rarely taken branches of insert_win_group, kept out of line: inlined, their temporaries (sincos / atan2 sequences, 64-bit
+// address arithmetic) set the register peak of the hot loop and push its live values into scratch.
+__device__ __attribute__((noinline)) float2 insert_ramp_sum_slow(const float* slope, const int* mUid, int m0, int m1, int pi, int pj)
+{
+    float2 S = make_float2(0.f, 0.f);
+    for (int i = m0; i < m1; i++) {
+        const int u = mUid[i];
+        const float2 r = ramp_value(slope[2 * u], slope[2 * u + 1], pi, pj);
+        S.x += r.x;
+        S.y += r.y;
+    }
+    return S;
+}
+__device__ __attribute__((noinline)) float insert_ctf_search(const thx_ctf_attr* attr, const double* dfac, int img, int mReco, int rep,
+                                                             float pixelSize, int idim, int pi, int pj)
+{
+    const CtfConst cc = ctf_const(attr[img], dfac[(size_t)img * mReco + rep]);
+    return ctf_value(cc, pixelSize, idim, idim, pi, pj);
+}
+__device__ __forceinline__ void insert_tiny_term(float2* F, float* T, int P, int X, int Y, int Z, float re, float im, float tt)
+{
+    const long nc = P / 2 + 1;
+    const long gi = ((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X;
+    unsafeAtomicAdd(&F[gi].x, re);
+    unsafeAtomicAdd(&F[gi].y, im);
+    unsafeAtomicAdd(&T[gi], tt);
+}
+
 // accumulate group gi_'s candidates of this window/slab (one wave), AX = dominant axis of the reference plane
 template <int AX>
 __device__ __forceinline__ void insert_win_group(const InsertWinArgs& wa, const WinGeom& g, int* sRe, int* sIm, int* sT,
@@ -699,18 +727,10 @@ __device__ __forceinline__ void insert_win_group(const InsertWinArgs& wa, const 
                 S.y += ec.x * er.y + ec.y * er.x;
             }
         } else {
-            for (int i = m0; i < m1; i++) {
-                const int u = dt.mUid[i];
-                const float2 r = ramp_value(dt.slope[2 * u], dt.slope[2 * u + 1], pi, pj);
-                S.x += r.x;
-                S.y += r.y;
-            }
+            S = insert_ramp_sum_slow(dt.slope, dt.mUid, m0, m1, pi, pj);
         }
         const float2 tv = cmul(dv, S);
-        if (a.cSearch) {
-            const CtfConst cc = ctf_const(a.attr[img], a.dfac[(size_t)img * a.mReco + dt.gInfo[2 * gi_ + 1]]);
-            cf = ctf_value(cc, a.pixelSize, a.idim, a.idim, pi, pj);
-        }
+        if (a.cSearch) cf = insert_ctf_search(a.attr, a.dfac, img, a.mReco, dt.gInfo[2 * gi_ + 1], a.pixelSize, a.idim, pi, pj);
         float vre = tv.x * cf, vim = tv.y * cf;
         vre = vre * 1.0f; vim = vim * 1.0f;
         vre = vre * wgt; vim = vim * wgt;
@@ -734,11 +754,7 @@ __device__ __forceinline__ void insert_win_group(const InsertWinArgs& wa, const 
                 atomicAdd(reinterpret_cast<unsigned*>(&sT[idx]), __float2uint_rn(tq));
             } else {
                 // tiny term (see k_insert_tiles): F and T travel together as floats
-                const int X = X0 + ii, Y = Y0 + jj, Z = Z0 + kk;
-                const long gi = ((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X;
-                unsafeAtomicAdd(&F[gi].x, vre * wv);
-                unsafeAtomicAdd(&F[gi].y, vim * wv);
-                unsafeAtomicAdd(&T[gi], tval * wv);
+                insert_tiny_term(F, T, P, X0 + ii, Y0 + jj, Z0 + kk, vre * wv, vim * wv, tval * wv);
             }
         }
     }
@@ -791,7 +807,7 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_win(InsertWinArgs wa)
     float4* sPix = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(sWr + 2 * a.mReco) + 15) & ~(uintptr_t)15);  // [kIPix][kIPix]
     float2* sEc = reinterpret_cast<float2*>(sPix + kIPix * kIPix);           // [kMaxU][kIPix]
     float2* sEr = sEc + kMaxU * kIPix;                                       // [kMaxU][kIPix]
-    __shared__ int sWlo, sWhi, sCls, sUi0, sUi1, sUj0, sUj1;
+    __shared__ int sWlo, sWhi, sCls, sUi0, sUi1, sUj0, sUj1, sNext;
 
     const int img = blockIdx.y, wqI = blockIdx.x;
     const int tid = threadIdx.x, grp = tid >> 6;
@@ -892,7 +908,7 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_win(InsertWinArgs wa)
                 if (dp * dp + dq * dq > wa.rMax2) continue;
             }
             __syncthreads();   // previous window's readers of sBox / sWr / sWlo are done
-            if (tid == 0) { sWlo = INT_MAX; sWhi = INT_MIN; sUi0 = INT_MAX; sUi1 = INT_MIN; sUj0 = INT_MAX; sUj1 = INT_MIN; }
+            if (tid == 0) { sWlo = INT_MAX; sWhi = INT_MIN; sUi0 = INT_MAX; sUi1 = INT_MIN; sUj0 = INT_MAX; sUj1 = INT_MIN; sNext = 0; }
             __syncthreads();
             // ---- per group: candidate pixel box (inverse 2x2 map of the padded window corners) and sheared-w range ----
             for (int gi_ = tid; gi_ < G; gi_ += kInsThreads) {
@@ -972,7 +988,13 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_win(InsertWinArgs wa)
             const int sHi = (sWhi + kWz / 2) >= 0 ? (sWhi + kWz / 2) / kWz : -((-(sWhi + kWz / 2) + kWz - 1) / kWz);
             for (int sl = sLo; sl <= sHi; sl++) {
                 g.w0 = sl * kWz - kWz / 2;
-                for (int gi_ = grp; gi_ < G; gi_ += kInsWaves) {
+                // the waves draw groups from a shared counter: the work per group varies (candidate box, slab overlap) and
+                // every slab ends in a barrier, so a static split leaves waves idle at it
+                for (;;) {
+                    int gi_ = 0;
+                    if ((tid & 63) == 0) gi_ = atomicAdd(&sNext, 1);
+                    gi_ = __builtin_amdgcn_readfirstlane(gi_);
+                    if (gi_ >= G) break;
                     const short* box = sBox + 4 * gi_;
                     if (box[1] == 0 || (wa.debug & 4)) continue;
                     if (sWr[2 * gi_ + 1] < (float)g.w0 || sWr[2 * gi_] > (float)(g.w0 + kWz)) continue;
@@ -980,12 +1002,13 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_win(InsertWinArgs wa)
                     else if (ax == 1) insert_win_group<1>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T);
                     else insert_win_group<2>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T);
                 }
-                __syncthreads();
-                if (wa.debug & 2) { __syncthreads(); continue; }
+                lds_barrier();
+                if (tid == 0) sNext = 0;   // nobody draws between this barrier and the one after the flush
+                if (wa.debug & 2) { lds_barrier(); continue; }
                 if (ax == 0) insert_win_flush<0>(a, g, sRe, sIm, sT, F, T);
                 else if (ax == 1) insert_win_flush<1>(a, g, sRe, sIm, sT, F, T);
                 else insert_win_flush<2>(a, g, sRe, sIm, sT, F, T);
-                __syncthreads();
+                lds_barrier();   // the flush's global atomics stay in flight
             }
         }
     }
