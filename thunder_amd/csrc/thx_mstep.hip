@@ -570,6 +570,10 @@ constexpr int kWd = THX_KWD;                // window edge in (p, q), voxels
 constexpr int kWz = THX_KWZ;                // slab thickness along the sheared axis, voxels
 constexpr int kWinVox = kWd * kWd * kWz;    // 4096 voxels x 12 B = 48 KB
 constexpr int kIPix = THX_KIPIX;            // per-window tabulated pixel range per axis (pixel data, separable ramps)
+#ifndef THX_KWINTHREADS
+#define THX_KWINTHREADS 512
+#endif
+constexpr int kWinThreads = THX_KWINTHREADS; // 2 workgroups per CU (LDS): 512 threads = 4 waves per SIMD at <= 128 VGPRs
 
 struct InsertWinArgs {
     InsertArgs a;
@@ -768,7 +772,7 @@ __device__ __forceinline__ void insert_win_flush(const InsertArgs& a, const WinG
     constexpr int qa = AX == 2 ? 1 : 2;
     const int P = a.P;
     const long nc = P / 2 + 1;
-    for (int e = threadIdx.x; e < kWinVox; e += kInsThreads) {
+    for (int e = threadIdx.x; e < kWinVox; e += kWinThreads) {
         const int ire = sRe[e], iim = sIm[e], itt = sT[e];
         if ((ire | iim | itt) == 0) continue;
         sRe[e] = 0; sIm[e] = 0; sT[e] = 0;
@@ -790,7 +794,7 @@ __device__ __forceinline__ void insert_win_flush(const InsertArgs& a, const WinG
 }
 
 // grid (nW, nImg): one workgroup owns a row of windows (fixed q range) of one image
-__global__ __launch_bounds__(kInsThreads, 4) void k_insert_win(InsertWinArgs wa)
+__global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(InsertWinArgs wa)
 {
     const InsertArgs& a = wa.a;
     extern __shared__ __attribute__((aligned(16))) int brick[];
@@ -822,7 +826,7 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_win(InsertWinArgs wa)
     const int* pUid = pOrd + a.mReco;
     const int* pGRep = pUid + a.mReco;
     const int* pTRep = pGRep + a.mReco;
-    for (int gi_ = tid; gi_ < G; gi_ += kInsThreads) {
+    for (int gi_ = tid; gi_ < G; gi_ += kWinThreads) {
         const int rep = pGRep[gi_];
         const double* R = a.rotMat + ((size_t)img * a.mReco + rep) * 9;
         double* d = sR + 6 * gi_;
@@ -830,9 +834,9 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_win(InsertWinArgs wa)
         sGInfo[2 * gi_] = a.cls ? a.cls[(size_t)img * a.mReco + rep] : 0;
         sGInfo[2 * gi_ + 1] = rep;
     }
-    for (int i = tid; i <= G; i += kInsThreads) sGStart[i] = pGStart[i];
-    for (int i = tid; i < a.mReco; i += kInsThreads) sMUid[i] = pUid[pOrd[i]];
-    for (int u = tid; u < U; u += kInsThreads) {
+    for (int i = tid; i <= G; i += kWinThreads) sGStart[i] = pGStart[i];
+    for (int i = tid; i < a.mReco; i += kWinThreads) sMUid[i] = pUid[pOrd[i]];
+    for (int u = tid; u < U; u += kWinThreads) {
         const size_t dm = (size_t)img * a.mReco + pTRep[u];
         const double tx = a.trans[2 * dm] - offx, ty = a.trans[2 * dm + 1] - offy;
         sSlope[2 * u] = (float)(-tx) / a.idim;
@@ -853,7 +857,7 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_win(InsertWinArgs wa)
         unsafeAtomicAdd(&a.O[2], oz);
         if (a.counter) atomicAdd(a.counter, a.mReco);
     }
-    for (int e = tid; e < 3 * kWinVox; e += kInsThreads) brick[e] = 0;
+    for (int e = tid; e < 3 * kWinVox; e += kWinThreads) brick[e] = 0;
     __syncthreads();
 
     // reference plane = the first group's: dominant axis of its normal, column slopes of the shear
@@ -892,7 +896,7 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_win(InsertWinArgs wa)
             __syncthreads();
             if (tid == 0) sCls = 0;
             __syncthreads();
-            for (int gi_ = tid; gi_ < G; gi_ += kInsThreads)
+            for (int gi_ = tid; gi_ < G; gi_ += kWinThreads)
                 if (sGInfo[2 * gi_] == pass) sCls = 1;
             __syncthreads();
             if (!sCls) continue;
@@ -911,7 +915,7 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_win(InsertWinArgs wa)
             if (tid == 0) { sWlo = INT_MAX; sWhi = INT_MIN; sUi0 = INT_MAX; sUi1 = INT_MIN; sUj0 = INT_MAX; sUj1 = INT_MIN; sNext = 0; }
             __syncthreads();
             // ---- per group: candidate pixel box (inverse 2x2 map of the padded window corners) and sheared-w range ----
-            for (int gi_ = tid; gi_ < G; gi_ += kInsThreads) {
+            for (int gi_ = tid; gi_ < G; gi_ += kWinThreads) {
                 const double* R = sR + 6 * gi_;
                 short* box = sBox + 4 * gi_;
                 box[1] = 0;
@@ -959,7 +963,7 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_win(InsertWinArgs wa)
             // ---- pixel data and separable ramps of the unique shifts for the pixel range in play ----
             g.ui0 = sUi0 <= sUi1 ? sUi0 - ((kIPix - (sUi1 - sUi0 + 1)) > 0 ? (kIPix - (sUi1 - sUi0 + 1)) / 2 : 0) : 0;
             g.uj0 = sUj0 <= sUj1 ? sUj0 - ((kIPix - (sUj1 - sUj0 + 1)) > 0 ? (kIPix - (sUj1 - sUj0 + 1)) / 2 : 0) : -half;
-            for (int e = tid; e < kIPix * kIPix; e += kInsThreads) {
+            for (int e = tid; e < kIPix * kIPix; e += kWinThreads) {
                 const int tj = e / kIPix, ti = e - tj * kIPix;
                 const int pi = g.ui0 + ti, pj = g.uj0 + tj;
                 float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -973,7 +977,7 @@ __global__ __launch_bounds__(kInsThreads, 4) void k_insert_win(InsertWinArgs wa)
                 sPix[e] = px;
             }
             if (U <= kMaxU)
-                for (int e = tid; e < 2 * U * kIPix; e += kInsThreads) {
+                for (int e = tid; e < 2 * U * kIPix; e += kWinThreads) {
                     const int which = e / (U * kIPix), rem = e - which * U * kIPix, u = rem / kIPix, o = rem - u * kIPix;
                     // exp(-2 pi i n slope): the whole turns are removed in double (n slope is exact to 1e-13), the
                     // remaining fraction of a turn goes through sincospif -- within 1e-7 of the double-precision value
@@ -1200,7 +1204,7 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
             wa.rMax2 = (float)(half * opf + 2) * (float)(half * opf + 2);
             const char* dbgw = getenv("THX_INSERT_DEBUG");
             wa.debug = dbgw ? atoi(dbgw) : 0;
-            hipLaunchKernelGGL(k_insert_win, dim3(wa.nW, nl), dim3(kInsThreads), ldsWin, st, wa);
+            hipLaunchKernelGGL(k_insert_win, dim3(wa.nW, nl), dim3(kWinThreads), ldsWin, st, wa);
         } else if (tiles) {
             InsertTileArgs ta;
             ta.a = b; ta.pixIndex = pixIndex; ta.tilesI = tilesI;
