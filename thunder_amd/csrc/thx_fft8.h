@@ -160,6 +160,18 @@ __device__ __forceinline__ void f8_rearrange(float2 v[8], int tau, int c, int pi
     __syncthreads();
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin in launch order, and each XCD has its own L2.  Adjacent x tiles share
+// 128-byte lines (64-byte segments; rows of 257 / 264 values are not line-aligned), so the linear workgroup id is
+// remapped to give every XCD a CONTIGUOUS run of tiles: a line is then fetched into one L2 instead of two.
+__device__ __forceinline__ void f8_xcd_tile(int& bx, int& by)
+{
+    const unsigned nx = gridDim.x, nT = gridDim.x * gridDim.y;
+    unsigned L = blockIdx.x + nx * blockIdx.y;
+    if ((nT & 7) == 0) L = (L & 7) * (nT >> 3) + (L >> 3);
+    bx = (int)(L % nx);
+    by = (int)(L / nx);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Strided pass, in place: data[b strideB + e strideE + x], e < N, x = blockIdx.x TX + c < nx.  grid (ceil(nx / TX), nBatch).
 // ---------------------------------------------------------------------------------------------
@@ -171,9 +183,11 @@ __global__ __launch_bounds__((f8_n<NS, R>() / 8) * TX) void k_fft_strided(float2
     extern __shared__ float2 f8_lds[];
     float2* sTw = f8_lds + f8_rows<NS, R>() * TX;
     const int c = threadIdx.x % TX, t = threadIdx.x / TX;
-    const int x = blockIdx.x * TX + c;
+    int bx, by;
+    f8_xcd_tile(bx, by);
+    const int x = bx * TX + c;
     const bool ok = x < nx;
-    float2* base = data + (long)blockIdx.y * strideB + x;
+    float2* base = data + (long)by * strideB + x;
     for (int i = threadIdx.x; i < N; i += NT8 * TX) sTw[i] = tw[i];
     float2 v[8];
 #pragma unroll
@@ -291,7 +305,9 @@ __global__ __launch_bounds__((f8_n<NS, R>() / 8) * TX, 8) void k_fft_z_update(fl
     float2* sTw = f8_lds + f8_rows<NS, R>() * TX;
     __shared__ float sred[16];
     const int c = threadIdx.x % TX, t = threadIdx.x / TX;
-    const int x = blockIdx.x * TX + c, jw = blockIdx.y;
+    int bx, jw;
+    f8_xcd_tile(bx, jw);
+    const int x = bx * TX + c;
     const bool ok = x < nc;
     for (int i = threadIdx.x; i < P; i += NTHR) sTw[i] = tw[i];
     float2 v[8];
