@@ -612,6 +612,7 @@ static int expect_local_nsplit(int nImg)
     // enough blocks to fill 256 CUs x ~6 resident blocks when the batch is small
     int s = 1;
     while (s < 16 && (long)nImg * s < 2048) s *= 2;
+    if (const char* e = getenv("THX_EXPECT_NSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 16) s = v; }
     return s;
 }
 
