@@ -10,7 +10,7 @@
 //                   next round, one read and one write of C instead of three.
 // Per round: 4 sweeps of C (0.54 GB each way) + W, T once, against 12 sweeps before.
 //
-// Decomposition (N = 8^3): n = 64 n2 + 8 n1 + n0, k = k0 + 8 k1 + 64 k2, w = exp(DIR 2 pi i / N):
+// Decomposition (N = 8^3; N = 8^2 drops the middle stage, R = 2, 4 add a radix-R pre-stage, see fftN): n = 64 n2 + 8 n1 + n0, k = k0 + 8 k1 + 64 k2, w = exp(DIR 2 pi i / N):
 //   A[k0; n1, n0]   = sum_n2 w8^(n2 k0) x[n2, n1, n0]                      thread t = 8 n1 + n0 holds x[t + 64 n2]
 //   B[k0, k1; n0]   = sum_n1 w8^(n1 k1) w^(8 n1 k0) A[k0; n1, n0]          thread t = n0 + 8 k0
 //   X[k0, k1, k2]   = sum_n0 w8^(n0 k2) w^(n0 (k0 + 8 k1)) B[k0, k1; n0]   thread t = k0 + 8 k1 ends with X[t + 64 k2]
