@@ -1,5 +1,6 @@
 // thx_fft8.h -- hand-written FFT passes of the gridding-weight iteration (Reconstructor::reconstruct's balancing loop,
-// src/Reconstructor.cpp:1379-1551) for power-of-two grids of 64 ... 2048 points per axis (R 8^NS, R = 1, 2, 4).
+// src/Reconstructor.cpp:1379-1551) for power-of-two grids of 64 ... 1024 points per axis (R 8^NS, R = 1, 2, 4;
+// 2048 = 4 x 8^3 is instantiable but not enabled: untested).
 //
 // Why: rocFFT's strided passes over the [P][P][P/2+1] grid run at 2.25 TB/s (0.48 ms per pass at P = 512); a pass that
 // stages 512 points x TX adjacent columns in LDS and does the three radix-8 stages there runs at 4.3 TB/s (0.25 ms,

@@ -408,8 +408,8 @@ struct thx_reco {
     // (Projector volume)
     hipfftHandle r2cF, c2rF, c2rN, r2cStd;
     bool haveN;
-    float2* tw;       // device, exp(-2 pi i m / PF), m < PF, when PF is a power of two in 64 .. 2048 (thx_fft8.h)
-    int handNS;       // 0: rocFFT only; 2: PF = 64, 128, 256; 3: PF = 512, 1024, 2048
+    float2* tw;       // device, exp(-2 pi i m / PF), m < PF, when PF is a power of two in 64 .. 1024 (thx_fft8.h)
+    int handNS;       // 0: rocFFT only; 2: PF = 64, 128, 256; 3: PF = 512, 1024
 };
 
 extern "C" {
@@ -448,7 +448,7 @@ int thx_reco_create(thx_reco** out, int size, int N, int pf, float a, float alph
         if (type == HIPFFT_C2R) return hipfftPlanMany(h, 3, n, cE, 1, P * P * padded_nc(P), rE, 1, P * P * P, type, 1);
         return hipfftPlanMany(h, 3, n, rE, 1, P * P * P, cE, 1, P * P * padded_nc(P), type, 1);
     };
-    r->handNS = (r->PF == 512 || r->PF == 1024 || r->PF == 2048) ? 3 : ((r->PF == 64 || r->PF == 128 || r->PF == 256) ? 2 : 0);
+    r->handNS = (r->PF == 512 || r->PF == 1024) ? 3 : ((r->PF == 64 || r->PF == 128 || r->PF == 256) ? 2 : 0);
     if (r->handNS) {
         std::vector<float2> tw(r->PF);
         for (int m = 0; m < r->PF; m++) {
@@ -482,7 +482,7 @@ int thx_reco_destroy(thx_reco* r)
 
 }  // extern "C"
 
-// The same iteration with the hand-written passes of thx_fft8.h (PF = R 8^NS: 64 ... 2048, power-of-two N pf): per round
+// The same iteration with the hand-written passes of thx_fft8.h (PF = R 8^NS: 64 ... 1024, power-of-two N pf; 2048 stays on rocFFT: untested): per round
 // y inverse -> fused x (inverse, kernel multiply, forward) -> y forward -> fused z (forward, W update + checkC, C = T W,
 // inverse of the next round).  C stays in its padded half-complex grid; the real grid is never materialised.
 template <int NS, int R>
@@ -559,7 +559,6 @@ static int balance_W(thx_reco* r, const float* T, int maxRadius, int maxIter, in
                 case 256: THX_HAND(2, 4);
                 case 512: THX_HAND(3, 1);
                 case 1024: THX_HAND(3, 2);
-                case 2048: THX_HAND(3, 4);
                 default: break;
             }
 #undef THX_HAND
