@@ -786,3 +786,48 @@ def test_hand_fft_passes_match_rocfft(dev, monkeypatch, N):
     assert ia == ib and abs(da - db) <= 1e-3 * max(1.0, da), (ia, ib, da, db)
     assert (ma - mb).abs().max().item() <= 1e-4 * ma.abs().max().item()
     plan.close()
+
+
+def test_expect_local_fused_defocus_search(oracle, dev, monkeypatch):
+    """CTF search at the reference's sizes (mLR 125, mLT 9, mLD 9): the fused kernel (one gather serves the 9 defocus
+    factors) against one sweep per factor (THX_EXPECT_ND=sweep) and, for one image, against the oracle"""
+    import time
+    from thunder_amd import ops, synth
+    O = oracle
+    rng = np.random.default_rng(91)
+    N, nR, nT, nD, nImg = 64, 125, 9, 9, 6
+    ref, vol, pl = make_case(O, N, rL=2)
+    P = 2 * N
+    im = make_images(O, vol, pl, N, nImg, rng)
+    rot_h = np.stack([[O.rotate3D(q) for q in qs] for qs in synth.perturb_quats(im["quat"], nR, 0.03, rng)])
+    tran_h = im["shift"][:, None, :] + rng.normal(0, 0.5, size=(nImg, nT, 2))
+    dfac = 1.0 + rng.normal(0, 0.02, size=(nImg, nD))
+    ctfD = np.stack([[O.ctf(1.32, a[0], np.float32(a[1] * d), np.float32(a[2] * d), *a[3:], N, pl["iCol"], pl["iRow"])
+                      for d in dfac[l]] for l, a in enumerate(im["attr"])])  # [nImg][nD][nPxl]
+    pD = rng.uniform(0.5, 1.5, size=(nImg, nD))
+    pR = rng.uniform(0.5, 1.5, size=(nImg, nR))
+    args = (T(vol, dev), P, 2, N, T(pl["iCol"], dev), T(pl["iRow"], dev), T(im["dat"], dev), T(ctfD, dev), T(im["sigRcp"], dev),
+            T(rot_h, dev), T(tran_h, dev))
+    out = {}
+    for mode in ("sweep", "fused"):
+        if mode == "sweep":
+            monkeypatch.setenv("THX_EXPECT_ND", "sweep")
+        else:
+            monkeypatch.delenv("THX_EXPECT_ND", raising=False)
+        ops.expect_local(*args, nD=nD, pD=T(pD, dev), pR=T(pR, dev), want_logW=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out[mode] = ops.expect_local(*args, nD=nD, pD=T(pD, dev), pR=T(pR, dev), want_logW=True)
+        torch.cuda.synchronize()
+        print("expect_local nD = 9, %s: %.3f ms" % (mode, (time.perf_counter() - t0) * 1e3))
+    a, b = out["sweep"], out["fused"]
+    scale = a.logW.abs().max().item()
+    assert (a.logW - b.logW).abs().max().item() <= 1e-5 * scale
+    for k in ("wR", "wT", "wD", "wC"):
+        np.testing.assert_allclose(getattr(b, k).cpu().numpy(), getattr(a, k).cpu().numpy(), rtol=max(3e-5 * scale, 3e-4), err_msg=k)
+    want = O.expect_local(vol, P, 2, N, pl["iCol"], pl["iRow"], im["dat"][0], ctfD[0], im["sigRcp"][0], rot_h[0], tran_h[0],
+                          nD=nD, pD=pD[0], pR=pR[0], cSearch=True)
+    wl = np.transpose(want["logW"], (2, 1, 0))  # [nD][nT][nR]
+    np.testing.assert_allclose(b.logW[0].cpu().numpy(), wl, rtol=0, atol=1e-5 * np.abs(wl).max())
+    for k in ("wR", "wT", "wD", "wC"):
+        np.testing.assert_allclose(getattr(b, k)[0].cpu().numpy().reshape(-1), want[k].reshape(-1), rtol=2e-3, err_msg=k)

@@ -359,6 +359,147 @@ __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
     if (tid == 0) a.partC[((size_t)img * a.nD + d) * a.nSplit + split] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
 }
 
+// CTF search (nD > 1, src/Optimiser.cpp:1246-1287): the same phase with the defocus factors fused.  The gather of a
+// sample does not depend on the defocus factor, so one pass serves all of them:
+//   L[r][t][d] - C = sum_p  c_d(p)^2 s(p) |q|^2  - 2 c_d(p) Re(A'_t(p) q),   A'_t = s conj(dat) ramp_t,  q = slice_r(p)
+// per sample: u_t = Re(A'_t q) (NT terms), then ND x (NT + 1) FMAs with the ND CTF values of the pixel (LDS broadcasts).
+// 9 x fewer gathers than one sweep per defocus factor at nD = 9.  grid (nSplit, nImg), block 256; nT <= NT, nD <= ND.
+template <int NT, int ND, bool PACKED>
+__global__ __launch_bounds__(256) void k_expect_local_nd(ExpectLocalArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* sA = reinterpret_cast<float2*>(smem_raw);                 // [kChunk][NT]  s conj(dat) ramp_t
+    float* sC = reinterpret_cast<float*>(sA + kChunk * NT);           // [kChunk][ND]  ctf of the ND defocus factors
+    float* sS = sC + kChunk * ND;                                     // [kChunk]      sigRcp
+    int* sIc = reinterpret_cast<int*>(sS + kChunk);                   // [kChunk]
+    int* sIr = sIc + kChunk;                                          // [kChunk]
+    float* sRed = reinterpret_cast<float*>(sIr + kChunk);             // [4 waves]
+
+    const int split = blockIdx.x, img = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.P;
+    const float2* vol = a.volumes + (size_t)(a.volIdx ? a.volIdx[img] : 0) * ((size_t)P * P * (P / 2 + 1)) * (PACKED ? 8 : 1);
+    const float2* dat = a.datP + (size_t)img * a.nPxl;
+    const float* ctf = a.ctfP + (size_t)img * a.nD * a.nPxl;   // [nD][nPxl]
+    const float* sig = a.sigRcpP + (size_t)img * a.nPxl;
+    const double* tr = a.trans + (size_t)img * a.nT * 2;
+    const int nRG0 = (a.nR + 63) >> 6;
+    const int nRGp = nRG0 >= 4 ? 4 : (nRG0 >= 2 ? 2 : 1);
+    const int nSub = 4 / nRGp;
+    const int rg = wave % nRGp, sub = wave / nRGp;
+    const int nPass = (nRG0 + nRGp - 1) / nRGp;
+    const int nChunks = (a.nPxl + kChunk - 1) / kChunk;
+    const int c0 = (int)(((long)nChunks * split) / a.nSplit), c1 = (int)(((long)nChunks * (split + 1)) / a.nSplit);
+    float cpart = 0.f;
+
+    for (int pass = 0; pass < nPass; pass++) {
+        const int r = (pass * nRGp + rg) * 64 + lane;
+        const bool rvalid = r < a.nR;
+        double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
+        if (rvalid) {
+            const double* m = a.rotMat + ((size_t)img * a.nR + r) * 9;
+            m0 = m[0]; m1 = m[1]; m2 = m[2]; m3 = m[3]; m4 = m[4]; m5 = m[5];
+        }
+        float acc[ND][NT];
+        float accB[ND];
+#pragma unroll
+        for (int d = 0; d < ND; d++) {
+            accB[d] = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[d][t] = 0.f;
+        }
+        for (int c = c0; c < c1; c++) {
+            const int pbase = c * kChunk;
+            const int clen = min(kChunk, a.nPxl - pbase);
+            __syncthreads();
+            for (int e = tid; e < clen; e += 256) {
+                const int p = pbase + e;
+                const int ic = a.iCol[p], ir = a.iRow[p];
+                sIc[e] = ic * a.pf;
+                sIr[e] = ir * a.pf;
+                const float sv = sig[p];
+                const float2 dv = dat[p];
+                sS[e] = sv;
+                if (pass == 0) cpart = fmaf(sv, fmaf(dv.x, dv.x, dv.y * dv.y), cpart);
+                const float2 cd = make_float2(dv.x * sv, -dv.y * sv);  // s conj(dat)
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    if (t < a.nT) {
+                        const float rCol = (float)tr[2 * t] / a.idim, rRow = (float)tr[2 * t + 1] / a.idim;
+                        sA[e * NT + t] = cmul(cd, ramp_value(rCol, rRow, ic, ir));
+                    } else {
+                        sA[e * NT + t] = make_float2(0.f, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < ND; d++) sC[e * ND + d] = d < a.nD ? ctf[(size_t)d * a.nPxl + p] : 0.f;
+            }
+            __syncthreads();
+            if (rvalid) {
+                for (int e = sub; e < clen; e += nSub) {
+                    const double nx = (double)sIc[e], ny = (double)sIr[e];
+                    const float x = (float)(m0 * nx + m3 * ny) * a.dbgScale;
+                    const float y = (float)(m1 * nx + m4 * ny) * a.dbgScale;
+                    const float z = (float)(m2 * nx + m5 * ny) * a.dbgScale;
+                    float2 q = make_float2(0.f, 0.f);
+                    if (coord_in_grid(x, y, z, P))
+                        q = PACKED ? interp_ft_packed(reinterpret_cast<const float4*>(vol), P, x, y, z) : interp_ft(vol, P, x, y, z);
+                    const float sq = sS[e] * fmaf(q.x, q.x, q.y * q.y);
+                    float u[NT];
+                    const float2* Ap = sA + e * NT;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) {
+                        const float2 A = Ap[t];
+                        u[t] = fmaf(-A.y, q.y, A.x * q.x);
+                    }
+                    const float* Cp = sC + e * ND;
+#pragma unroll
+                    for (int d = 0; d < ND; d++) {
+                        const float cv = Cp[d];
+                        accB[d] = fmaf(cv * cv, sq, accB[d]);
+#pragma unroll
+                        for (int t = 0; t < NT; t++) acc[d][t] = fmaf(cv, u[t], acc[d][t]);
+                    }
+                }
+            }
+        }
+        // ---- combine the pixel sub-streams (fixed order), one defocus factor at a time through the same LDS scratch ----
+        float* sAcc = reinterpret_cast<float*>(smem_raw);  // [nSub][NT+1][64*nRGp]
+        const int slots = 64 * nRGp;
+        const int slot = rg * 64 + lane;
+#pragma unroll
+        for (int d = 0; d < ND; d++) {
+            if (d >= a.nD) break;
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < NT; t++) sAcc[(sub * (NT + 1) + t) * slots + slot] = acc[d][t];
+            sAcc[(sub * (NT + 1) + NT) * slots + slot] = accB[d];
+            __syncthreads();
+            if (sub == 0 && rvalid) {
+                float b = 0.f;
+                for (int s2 = 0; s2 < nSub; s2++) b += sAcc[(s2 * (NT + 1) + NT) * slots + slot];
+                float* outV = a.partV + ((((size_t)img * a.nD + d) * a.nSplit + split) * a.nT) * a.nRpad;
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    if (t < a.nT) {
+                        float v = 0.f;
+                        for (int s2 = 0; s2 < nSub; s2++) v += sAcc[(s2 * (NT + 1) + t) * slots + slot];
+                        outV[(size_t)t * a.nRpad + r] = b - 2.0f * v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    cpart = wave_sum(cpart);
+    if (lane == 0) sRed[wave] = cpart;
+    __syncthreads();
+    if (tid == 0) {
+        const float cs = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+        for (int d = 0; d < a.nD; d++) a.partC[((size_t)img * a.nD + d) * a.nSplit + split] = cs;
+    }
+}
+
 // Finalise: L = C + V, per-image maximum, exp, marginals (src/Optimiser.cpp:1383-1402 in closed form).
 // grid (nImg), block 256, dynamic LDS nD*nT*nR floats.
 struct ExpectFinalArgs {
@@ -625,6 +766,22 @@ static int launch_expect_local(const ExpectLocalArgs& a, hipStream_t st, bool pa
     size_t stage = (size_t)kChunk * NT * sizeof(float2) + kChunk * (sizeof(float) + 2 * sizeof(int)) + 4 * sizeof(float);
     size_t red = (size_t)nSub * (NT + 1) * 64 * nRGp * sizeof(float);
     size_t lds = stage > red ? stage : red;
+    // defocus search: one pass serves all nD factors when the accumulators fit (nT, nD <= 9); THX_EXPECT_ND=sweep keeps the
+    // one-sweep-per-factor form for A/B runs
+    {
+        const char* ev = getenv("THX_EXPECT_ND");
+        if (NT == 9 && a.nD > 1 && a.nD <= 9 && !(ev && ev[0] == 's')) {
+            constexpr int ND = 9;
+            size_t stageN = (size_t)kChunk * (NT * sizeof(float2) + ND * sizeof(float) + sizeof(float) + 2 * sizeof(int)) + 4 * sizeof(float);
+            size_t ldsN = stageN > red ? stageN : red;
+            if (packed)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expect_local_nd<9, ND, true>), dim3(a.nSplit, a.nImg), dim3(256), ldsN, st, a);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expect_local_nd<9, ND, false>), dim3(a.nSplit, a.nImg), dim3(256), ldsN, st, a);
+            THX_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (packed)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expect_local<NT, true>), dim3(a.nSplit, a.nImg, a.nD), dim3(256), lds, st, a);
     else
