@@ -144,6 +144,12 @@ int thx_expect_local_dev(const float* volumes, const int* volIdx, int vdim, int 
 size_t thx_projector_packed_bytes(int vdim);
 int thx_projector_pack_dev(float* cells, const float* volumes, int vdim, int nVol, void* stream);
 
+/* Occupancy of the local-search kernel: workgroups (4 waves each) per CU, 0 = unlimited.  Default 2: with the
+ * particle filter's clouds of support points (rotations ~1 degree apart, the reference's production case) the
+ * kernel is bound by scattered 64-byte reads and is 17 % faster with 8 waves per CU than with 20; callers that
+ * feed tightly clustered rotations (all within ~0.2 degree) should set 0.  Results do not depend on it. */
+int thx_expect_local_set_occupancy(int workgroupsPerCU);
+
 /* thx_expect_local_dev gathering from cell-packed volumes (bit-identical results). */
 int thx_expect_local_packed_dev(const float* cells, const int* volIdx, int vdim, int pf, int idim, const int* iCol,
                                 const int* iRow, int nPxl, int nImg, const float* datP, const float* ctfP,

@@ -54,6 +54,7 @@ SIGNATURES = {
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "thx_expect_local_packed_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i,
                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "thx_expect_local_set_occupancy": (_i, [_i]),
     "thx_projector_packed_bytes": (_sz, [_i]),
     "thx_projector_pack_dev": (_i, [_vp, _vp, _i, _i, _vp]),
     "thx_expect_global_workspace": (_sz, [_i, _i, _i]),

@@ -757,6 +757,23 @@ static int expect_local_nsplit(int nImg)
     return s;
 }
 
+// Workgroups of k_expect_local per CU.  With particle-filter clouds (rotations ~1 degree apart) every wave-load is 64
+// scattered 64-byte requests and the kernel runs FASTER with fewer waves in flight: 8 waves per CU (2 workgroups) 162 ms,
+// 12 waves 182 ms, 16-20 waves 194 ms, 4 waves 237 ms per 5 000-image launch on MI355X -- beyond ~2 waves per SIMD the
+// extra requests only thrash L2 / the memory queues.  With tightly clustered rotations the loads coalesce and the
+// kernel wants every wave it can get (82 ms unlimited, 113 ms at 2 workgroups).  The cap is applied by rounding the
+// dynamic LDS request up so that one more workgroup does not fit the CU's 160 KB.  0 = unlimited.
+static int g_expectWgPerCU = 2;
+
+static size_t expect_lds_floor()
+{
+    int wg = g_expectWgPerCU;
+    if (const char* e = getenv("THX_EXPECT_WG_PER_CU")) wg = atoi(e);
+    if (wg <= 0 || wg > 8) return 0;
+    const size_t f = (size_t)(160 * 1024) / (wg + 1) + 1024;
+    return f > 64 * 1024 ? 64 * 1024 : f;   // one workgroup per CU would need > 80 KB: not offered (it is the slowest)
+}
+
 template <int NT>
 static int launch_expect_local(const ExpectLocalArgs& a, hipStream_t st, bool packed)
 {
@@ -766,6 +783,10 @@ static int launch_expect_local(const ExpectLocalArgs& a, hipStream_t st, bool pa
     size_t stage = (size_t)kChunk * NT * sizeof(float2) + kChunk * (sizeof(float) + 2 * sizeof(int)) + 4 * sizeof(float);
     size_t red = (size_t)nSub * (NT + 1) * 64 * nRGp * sizeof(float);
     size_t lds = stage > red ? stage : red;
+    {
+        const size_t f = expect_lds_floor();
+        lds = lds > f ? lds : f;
+    }
     // defocus search: one pass serves all nD factors when the accumulators fit (nT, nD <= 9); THX_EXPECT_ND=sweep keeps the
     // one-sweep-per-factor form for A/B runs
     {
@@ -808,6 +829,13 @@ int thx_device_count(int* count)
 int thx_set_device(int gpuIdx)
 {
     THX_CHECK(hipSetDevice(gpuIdx));
+    return 0;
+}
+
+int thx_expect_local_set_occupancy(int workgroupsPerCU)
+{
+    THX_REQUIRE(workgroupsPerCU >= 0 && workgroupsPerCU <= 8, "workgroupsPerCU must be 0 (unlimited) .. 8");
+    g_expectWgPerCU = workgroupsPerCU;
     return 0;
 }
 

@@ -201,6 +201,10 @@ class RefineShard:
         self.tranP0 = [t.clone() for t in self.tranP]
         # ---- particle filter state (Particle, src/Particle.cpp), used instead of the fixed support points ----
         self.use_pf = particle_filter
+        # clouds of a particle filter: 2 workgroups of the local-search kernel per CU; tightly clustered fixed support
+        # points: no cap (see thx_expect_local_set_occupancy)
+        from . import capi as _capi
+        _capi.call("thx_expect_local_set_occupancy", 2 if particle_filter else 0)
         self.pf_seed, self.pf_call = seed + 104729 * rank, 0
         self.transS, self.transQ = transS, 0.05                       # TRANS_Q, include/Optimiser.h:67
         self.pfL, self.pfS, self.peakFactorR = 2.0, 0.5, 1e-3         # script/demo_3D.json:71-73, PEAK_FACTOR_MIN
