@@ -104,3 +104,20 @@ def test_shard_indices_world1_and_odd_counts():
     assert got == list(range(101))
     sizes = [len(shard_indices(100000, r, 8)) for r in range(8)]
     assert sizes == [12500] * 8
+
+
+def test_pixel_visit_order_is_a_local_permutation(monkeypatch):
+    """the E-step visits the listed pixels along a Morton curve: a permutation of the list in which consecutive pixels
+    stay close (that is what keeps the gathered volume cells cached)"""
+    from thunder_amd.refine import pixel_list, pixel_visit_order
+    N = 64
+    pl = pixel_list(N, N // 2 - 2, 2)
+    for mode in ("morton", "tile"):
+        monkeypatch.setenv("THX_PIXEL_ORDER", mode)
+        o = pixel_visit_order(pl, N)
+        assert sorted(o.tolist()) == list(range(pl["nPxl"]))
+        ic, ir = pl["iCol"][o].astype(int), pl["iRow"][o].astype(int)
+        step = np.hypot(np.diff(ic), np.diff(ir))
+        assert np.median(step) <= 1.5 and np.mean(step) < 4.0
+    monkeypatch.setenv("THX_TILE_ORDER", "0")
+    assert pixel_visit_order(pl, N) is None

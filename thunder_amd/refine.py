@@ -100,19 +100,8 @@ class RefineShard:
         # neighbouring pixels and rotations while the lines are still cached): 158 ms per launch against 162 ms for
         # 16x16 tiles in row-major order (THX_PIXEL_ORDER=tile, THX_TILE_ORDER=T); the reference's row-major list
         # (THX_PIXEL_ORDER=tile THX_TILE_ORDER=0) is 6 % slower than the tiles.
-        tile = int(os.environ.get("THX_TILE_ORDER", "16"))
-        if os.environ.get("THX_PIXEL_ORDER", "morton") == "morton":
-            def _spread(v):
-                v = v.astype(np.uint32)
-                out = np.zeros_like(v)
-                for b in range(10):
-                    out |= ((v >> b) & 1) << (2 * b)
-                return out
-            order = np.argsort(_spread(pl["iCol"]) | (_spread(pl["iRow"] + N) << 1), kind="stable")
-            for k in ("iCol", "iRow", "iPxl", "iSig", "iColPad", "iRowPad"):
-                pl[k] = np.ascontiguousarray(pl[k][order])
-        elif tile > 0:
-            order = np.lexsort((pl["iCol"], pl["iRow"], pl["iCol"] // tile, (pl["iRow"] + N) // tile))
+        order = pixel_visit_order(pl, N)
+        if order is not None:
             for k in ("iCol", "iRow", "iPxl", "iSig", "iColPad", "iRowPad"):
                 pl[k] = np.ascontiguousarray(pl[k][order])
         self.pl, self.plM = pl, plM
@@ -551,6 +540,23 @@ class RefineShard:
             self.pf_call = 0
         for vi in range(len(self.halves)):
             self.refresh_rows(vi)
+
+
+def pixel_visit_order(pl, N):
+    """Permutation of the E-step pixel list: Morton (Z-order) curve over (iCol, iRow + N) by default,
+    THX_PIXEL_ORDER=tile -> TxT tiles in row-major order (THX_TILE_ORDER=T, 0 = the reference's row-major list: None)."""
+    if os.environ.get("THX_PIXEL_ORDER", "morton") == "morton":
+        def _spread(v):
+            v = v.astype(np.uint32)
+            out = np.zeros_like(v)
+            for b in range(10):
+                out |= ((v >> b) & 1) << (2 * b)
+            return out
+        return np.argsort(_spread(pl["iCol"]) | (_spread(pl["iRow"] + N) << 1), kind="stable")
+    tile = int(os.environ.get("THX_TILE_ORDER", "16"))
+    if tile > 0:
+        return np.lexsort((pl["iCol"], pl["iRow"], pl["iCol"] // tile, (pl["iRow"] + N) // tile))
+    return None
 
 
 def pixel_list(N, rU, rL, pf=2):
