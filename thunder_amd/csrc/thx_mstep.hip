@@ -742,6 +742,8 @@ __device__ __forceinline__ void insert_win_group(const InsertWinArgs& wa, const 
         const float tval = (pow2f_(cf) * 1.0f * wgt) * nmem;
         const float xd = x - fx, yd = y - fy, zd = z - fz;
         const float vx[2] = {1.0f - xd, xd}, vy[2] = {1.0f - yd, yd}, vz[2] = {1.0f - zd, zd};
+        // fixed-point scales folded into the pixel's value once (the brick's quantum is 2^-22 of the largest term)
+        const float vreS = vre * g.scaleF, vimS = vim * g.scaleF, tvalS = tval * g.scaleT;
 #pragma unroll
         for (int v = 0; v < 8; v++) {
             if (!((inMask >> v) & 1)) continue;
@@ -749,12 +751,12 @@ __device__ __forceinline__ void insert_win_group(const InsertWinArgs& wa, const 
             const int dp = comp3<pa>(ii, jj, kk), dq = comp3<qa>(ii, jj, kk), da = comp3<AX>(ii, jj, kk);
             const float wv = vx[ii] * vy[jj] * vz[kk];
             const int off = offA[dq][dp] + sg * da;
-            const float tq = (tval * wv) * g.scaleT;
+            const float tq = tvalS * wv;
             if (tq >= g.minQ) {
                 const int idx = AX == 0 ? ((qI[dq] * kWd + pI[dp]) * kWz + off) : ((qI[dq] * kWz + off) * kWd + pI[dp]);
                 if (wa.debug & 1) { if (idx < 0) sRe[0] = 1; continue; }
-                atomicAdd(&sRe[idx], __float2int_rn((vre * wv) * g.scaleF));
-                atomicAdd(&sIm[idx], __float2int_rn((vim * wv) * g.scaleF));
+                atomicAdd(&sRe[idx], __float2int_rn(vreS * wv));
+                atomicAdd(&sIm[idx], __float2int_rn(vimS * wv));
                 atomicAdd(reinterpret_cast<unsigned*>(&sT[idx]), __float2uint_rn(tq));
             } else {
                 // tiny term (see k_insert_tiles): F and T travel together as floats
