@@ -644,17 +644,74 @@ __device__ __forceinline__ void insert_tiny_term(float2* F, float* T, int P, int
 }
 
 // accumulate group gi_'s candidates of this window/slab (one wave), AX = dominant axis of the reference plane
+// Geometry of one (group, pixel) sample against the current window / slab: cell origin, brick coordinates of its
+// 8 voxels and the mask of those that lie inside.  Returns false when nothing of the cell belongs here.
+struct WinSample {
+    float x, y, z, fx, fy, fz;
+    int X0, Y0, Z0, sg;
+    int pI[2], qI[2], offA[2][2];
+    unsigned inMask;
+    bool conj;
+};
+
+template <int AX>
+__device__ __forceinline__ bool win_sample(const WinGeom& g, const double* R, int opf, int P, int pi, int pj, WinSample& w)
+{
+    constexpr int pa = AX == 0 ? 1 : 0;
+    constexpr int qa = AX == 2 ? 1 : 2;
+    const int icp = pi * opf, irp = pj * opf;
+    float x = (float)(R[0] * icp + R[3] * irp);
+    float y = (float)(R[1] * icp + R[4] * irp);
+    float z = (float)(R[2] * icp + R[5] * irp);
+    if (!coord_in_grid(x, y, z, P)) return false;
+    w.conj = false;
+    if (!(x >= 0.0f)) { x *= -1.0f; y *= -1.0f; z *= -1.0f; w.conj = true; }
+    w.x = x; w.y = y; w.z = z;
+    w.fx = floorf(x); w.fy = floorf(y); w.fz = floorf(z);
+    w.X0 = (int)w.fx; w.Y0 = (int)w.fy; w.Z0 = (int)w.fz;
+    w.sg = w.conj ? -1 : 1;
+    const int b0x = w.conj ? -1 - w.X0 : w.X0, b0y = w.conj ? -w.Y0 : w.Y0, b0z = w.conj ? -w.Z0 : w.Z0;
+    const int bp0 = comp3<pa>(b0x, b0y, b0z), bq0 = comp3<qa>(b0x, b0y, b0z), ba0 = comp3<AX>(b0x, b0y, b0z);
+    bool pin[2], qin[2];
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+        w.pI[d] = bp0 + w.sg * d - g.p0;
+        w.qI[d] = bq0 + w.sg * d - g.q0;
+        pin[d] = (unsigned)w.pI[d] < (unsigned)kWd;
+        qin[d] = (unsigned)w.qI[d] < (unsigned)kWd;
+    }
+    if (!((pin[0] || pin[1]) && (qin[0] || qin[1]))) return false;   // the cell misses this window's columns
+#pragma unroll
+    for (int dq = 0; dq < 2; dq++)
+#pragma unroll
+        for (int dp = 0; dp < 2; dp++)
+            w.offA[dq][dp] = ba0 - ((int)floorf(g.sp * (float)(bp0 + w.sg * dp) + g.sq * (float)(bq0 + w.sg * dq)) + g.w0);
+    unsigned inMask = 0;
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+        const int ii = v & 1, jj = (v >> 1) & 1, kk = v >> 2;
+        const int dp = comp3<pa>(ii, jj, kk), dq = comp3<qa>(ii, jj, kk), da = comp3<AX>(ii, jj, kk);
+        const int off = w.offA[dq][dp] + w.sg * da;
+        if (pin[dp] && qin[dq] && ((unsigned)off < (unsigned)kWz)) inMask |= 1u << v;
+    }
+    w.inMask = inMask;
+    return inMask != 0;
+}
+
+// accumulate group gi_'s candidates of this window/slab (one wave), AX = dominant axis of the reference plane.
+// Two phases: the wave walks the candidate box and keeps the pixels that really own voxels here (float pre-test, then the
+// exact geometry) in a per-wave LDS queue -- only ~22 of 64 lanes of a box trip are such hits -- and processes the queue
+// 64 entries at a time (value of the pixel for the group, 8 voxel terms), i.e. with full lanes.
 template <int AX>
 __device__ __forceinline__ void insert_win_group(const InsertWinArgs& wa, const WinGeom& g, int* sRe, int* sIm, int* sT,
                                                  const DrawTables& dt, int img, int gi_, int i0, int nI, int j0, int nJ,
-                                                 float wgt, float2* F, float* T)
+                                                 float wgt, float2* F, float* T, volatile int* queue)
 {
     const InsertArgs& a = wa.a;
     constexpr int pa = AX == 0 ? 1 : 0;
     constexpr int qa = AX == 2 ? 1 : 2;
     const int lane = threadIdx.x & 63;
     const int P = a.P, half = a.idim / 2;
-    const long nc = P / 2 + 1;
     const double* R = dt.R + 6 * gi_;
     const int m0 = dt.gStart[gi_], m1 = dt.gStart[gi_ + 1];
     const float nmem = (float)(m1 - m0);
@@ -664,64 +721,24 @@ __device__ __forceinline__ void insert_win_group(const InsertWinArgs& wa, const 
     const float A00 = (float)R[pa] * (float)a.opf, A01 = (float)R[3 + pa] * (float)a.opf, A10 = (float)R[qa] * (float)a.opf,
                 A11 = (float)R[3 + qa] * (float)a.opf;
     const float plo = (float)g.p0 - 2.5f, phi = (float)(g.p0 + kWd) + 1.5f, qlo = (float)g.q0 - 2.5f, qhi = (float)(g.q0 + kWd) + 1.5f;
-    for (int c = lane; c < nCand; c += 64) {
-        const int jr = (int)(((float)c + 0.5f) * rnI);
-        const int pi = i0 + (c - jr * nI), pj = j0 + jr;
-        const float pf_ = A00 * (float)pi + A01 * (float)pj, qf_ = A10 * (float)pi + A11 * (float)pj;
-        if (!(pf_ >= plo && pf_ < phi && qf_ >= qlo && qf_ < qhi)) continue;
+
+    // ---- phase 2: one queue entry per lane ----
+    auto process = [&](int pk) {
+        const int pi = pk & 0xFFFF, pj = (int)(short)(pk >> 16);
+        WinSample w;
+        if (!win_sample<AX>(g, R, a.opf, P, pi, pj, w)) return;   // cannot fail: the entry passed the same test in phase 1
         const int ti = pi - g.ui0, tj = pj - g.uj0;
         const bool tab = (unsigned)ti < (unsigned)kIPix && (unsigned)tj < (unsigned)kIPix;
-        int k = 0;
-        float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tab) {
-            px = g.pix[tj * kIPix + ti];
-            if (px.w == 0.f) continue;
-        } else {
-            k = wa.pixIndex[(pj + half) * (half + 1) + pi];
-            if (k < 0) continue;
-        }
-        const int icp = pi * a.opf, irp = pj * a.opf;
-        float x = (float)(R[0] * icp + R[3] * irp);
-        float y = (float)(R[1] * icp + R[4] * irp);
-        float z = (float)(R[2] * icp + R[5] * irp);
-        if (!coord_in_grid(x, y, z, P)) continue;
-        bool conj = false;
-        if (!(x >= 0.0f)) { x *= -1.0f; y *= -1.0f; z *= -1.0f; conj = true; }
-        const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
-        const int X0 = (int)fx, Y0 = (int)fy, Z0 = (int)fz;
-        const int sg = conj ? -1 : 1;
-        const int b0x = conj ? -1 - X0 : X0, b0y = conj ? -Y0 : Y0, b0z = conj ? -Z0 : Z0;
-        const int bp0 = comp3<pa>(b0x, b0y, b0z), bq0 = comp3<qa>(b0x, b0y, b0z), ba0 = comp3<AX>(b0x, b0y, b0z);
-        int pI[2], qI[2], offA[2][2];
-        bool pin[2], qin[2];
-#pragma unroll
-        for (int d = 0; d < 2; d++) {
-            pI[d] = bp0 + sg * d - g.p0;
-            qI[d] = bq0 + sg * d - g.q0;
-            pin[d] = (unsigned)pI[d] < (unsigned)kWd;
-            qin[d] = (unsigned)qI[d] < (unsigned)kWd;
-        }
-        if (!((pin[0] || pin[1]) && (qin[0] || qin[1]))) continue;   // the cell misses this window's columns
-#pragma unroll
-        for (int dq = 0; dq < 2; dq++)
-#pragma unroll
-            for (int dp = 0; dp < 2; dp++)
-                offA[dq][dp] = ba0 - ((int)floorf(g.sp * (float)(bp0 + sg * dp) + g.sq * (float)(bq0 + sg * dq)) + g.w0);
-        // which of the 8 voxels are in this window and slab?
-        unsigned inMask = 0;
-#pragma unroll
-        for (int v = 0; v < 8; v++) {
-            const int ii = v & 1, jj = (v >> 1) & 1, kk = v >> 2;
-            const int dp = comp3<pa>(ii, jj, kk), dq = comp3<qa>(ii, jj, kk), da = comp3<AX>(ii, jj, kk);
-            const int off = offA[dq][dp] + sg * da;
-            if (pin[dp] && qin[dq] && ((unsigned)off < (unsigned)kWz)) inMask |= 1u << v;
-        }
-        if (!inMask) continue;
-        // the value of this pixel for the group: (img * sum of the members' ramps) * ctf * w, T: n * ctf^2 * w
         float2 dv;
         float cf;
-        if (tab) { dv = make_float2(px.x, px.y); cf = px.z; }
-        else { dv = a.datP[(size_t)img * a.nPxl + k]; cf = a.ctfP[(size_t)img * a.nPxl + k]; }
+        if (tab) {
+            const float4 px = g.pix[tj * kIPix + ti];
+            dv = make_float2(px.x, px.y); cf = px.z;
+        } else {
+            const int k = wa.pixIndex[(pj + half) * (half + 1) + pi];
+            dv = a.datP[(size_t)img * a.nPxl + k]; cf = a.ctfP[(size_t)img * a.nPxl + k];
+        }
+        // the value of this pixel for the group: (img * sum of the members' ramps) * ctf * w, T: n * ctf^2 * w
         float2 S = make_float2(0.f, 0.f);
         if (tab && dt.U <= kMaxU) {
             for (int i = m0; i < m1; i++) {   // separable ramp exp(-i a_u i) exp(-i b_u j) from the window's tables
@@ -738,31 +755,74 @@ __device__ __forceinline__ void insert_win_group(const InsertWinArgs& wa, const 
         float vre = tv.x * cf, vim = tv.y * cf;
         vre = vre * 1.0f; vim = vim * 1.0f;
         vre = vre * wgt; vim = vim * wgt;
-        if (conj) vim = -vim;
+        if (w.conj) vim = -vim;
         const float tval = (pow2f_(cf) * 1.0f * wgt) * nmem;
-        const float xd = x - fx, yd = y - fy, zd = z - fz;
+        const float xd = w.x - w.fx, yd = w.y - w.fy, zd = w.z - w.fz;
         const float vx[2] = {1.0f - xd, xd}, vy[2] = {1.0f - yd, yd}, vz[2] = {1.0f - zd, zd};
         // fixed-point scales folded into the pixel's value once (the brick's quantum is 2^-22 of the largest term)
         const float vreS = vre * g.scaleF, vimS = vim * g.scaleF, tvalS = tval * g.scaleT;
 #pragma unroll
         for (int v = 0; v < 8; v++) {
-            if (!((inMask >> v) & 1)) continue;
+            if (!((w.inMask >> v) & 1)) continue;
             const int ii = v & 1, jj = (v >> 1) & 1, kk = v >> 2;
             const int dp = comp3<pa>(ii, jj, kk), dq = comp3<qa>(ii, jj, kk), da = comp3<AX>(ii, jj, kk);
             const float wv = vx[ii] * vy[jj] * vz[kk];
-            const int off = offA[dq][dp] + sg * da;
+            const int off = w.offA[dq][dp] + w.sg * da;
             const float tq = tvalS * wv;
             if (tq >= g.minQ) {
-                const int idx = AX == 0 ? ((qI[dq] * kWd + pI[dp]) * kWz + off) : ((qI[dq] * kWz + off) * kWd + pI[dp]);
+                const int idx = AX == 0 ? ((w.qI[dq] * kWd + w.pI[dp]) * kWz + off) : ((w.qI[dq] * kWz + off) * kWd + w.pI[dp]);
                 if (wa.debug & 1) { if (idx < 0) sRe[0] = 1; continue; }
                 atomicAdd(&sRe[idx], __float2int_rn(vreS * wv));
                 atomicAdd(&sIm[idx], __float2int_rn(vimS * wv));
                 atomicAdd(reinterpret_cast<unsigned*>(&sT[idx]), __float2uint_rn(tq));
             } else {
                 // tiny term (see k_insert_tiles): F and T travel together as floats
-                insert_tiny_term(F, T, P, X0 + ii, Y0 + jj, Z0 + kk, vre * wv, vim * wv, tval * wv);
+                insert_tiny_term(F, T, P, w.X0 + ii, w.Y0 + jj, w.Z0 + kk, vre * wv, vim * wv, tval * wv);
             }
         }
+    };
+
+    // ---- phase 1: walk the candidate box, queue the probable hits ----
+    // All in float: (p, q) inside the padded window, and the height of the sample above the sheared reference plane
+    // inside the padded slab (margins: cell extent, the floor of the shear, the Hermitian fold, float rounding).  The
+    // exact test is repeated per queue entry in phase 2, so a false positive only idles a lane there.
+    const float A20 = (float)R[AX] * (float)a.opf, A21 = (float)R[3 + AX] * (float)a.opf;
+    // |d(a - sp p - sq q)| <= 1 + |sp| + |sq| <= 3 between a sample and the voxels of its cell, + 1 for the floor of the shear
+    const float wlo = (float)g.w0 - 4.5f, whi = (float)(g.w0 + kWz) + 3.5f;
+    int qn = 0;   // wave-uniform
+    for (int c0 = 0; c0 < nCand; c0 += 64) {
+        const int c = c0 + lane;
+        bool hit = false;
+        int pk = 0;
+        if (c < nCand) {
+            const int jr = (int)(((float)c + 0.5f) * rnI);
+            const int pi = i0 + (c - jr * nI), pj = j0 + jr;
+            const float pf_ = A00 * (float)pi + A01 * (float)pj, qf_ = A10 * (float)pi + A11 * (float)pj;
+            const float wf_ = (A20 * (float)pi + A21 * (float)pj) - (g.sp * pf_ + g.sq * qf_);
+            if (pf_ >= plo && pf_ < phi && qf_ >= qlo && qf_ < qhi && wf_ >= wlo && wf_ < whi) {
+                const int ti = pi - g.ui0, tj = pj - g.uj0;
+                const bool tab = (unsigned)ti < (unsigned)kIPix && (unsigned)tj < (unsigned)kIPix;
+                hit = tab ? (g.pix[tj * kIPix + ti].w != 0.f) : (wa.pixIndex[(pj + half) * (half + 1) + pi] >= 0);
+                pk = (pi & 0xFFFF) | (pj << 16);
+            }
+        }
+        const unsigned long long bal = __ballot(hit);
+        if (hit) queue[qn + __popcll(bal & ((1ull << lane) - 1ull))] = pk;
+        qn += __popcll(bal);
+        if (qn >= 64) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int e0 = queue[lane];
+            const int e1 = (64 + lane < qn) ? queue[64 + lane] : 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (64 + lane < qn) queue[lane] = e1;   // the remainder moves to the front (each lane moves its own entry)
+            qn -= 64;
+            process(e0);
+        }
+    }
+    if (qn > 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int e0 = lane < qn ? queue[lane] : 0;
+        if (lane < qn) process(e0);
     }
 }
 
@@ -813,6 +873,7 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
     float4* sPix = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(sWr + 2 * a.mReco) + 15) & ~(uintptr_t)15);  // [kIPix][kIPix]
     float2* sEc = reinterpret_cast<float2*>(sPix + kIPix * kIPix);           // [kMaxU][kIPix]
     float2* sEr = sEc + kMaxU * kIPix;                                       // [kMaxU][kIPix]
+    int* sQueue = reinterpret_cast<int*>(sEr + kMaxU * kIPix);               // [waves][128] hit queues of insert_win_group
     __shared__ int sWlo, sWhi, sCls, sUi0, sUi1, sUj0, sUj1, sNext;
 
     const int img = blockIdx.y, wqI = blockIdx.x;
@@ -1004,9 +1065,9 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
                     const short* box = sBox + 4 * gi_;
                     if (box[1] == 0 || (wa.debug & 4)) continue;
                     if (sWr[2 * gi_ + 1] < (float)g.w0 || sWr[2 * gi_] > (float)(g.w0 + kWz)) continue;
-                    if (ax == 0) insert_win_group<0>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T);
-                    else if (ax == 1) insert_win_group<1>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T);
-                    else insert_win_group<2>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T);
+                    if (ax == 0) insert_win_group<0>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T, sQueue + 128 * grp);
+                    else if (ax == 1) insert_win_group<1>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T, sQueue + 128 * grp);
+                    else insert_win_group<2>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T, sQueue + 128 * grp);
                 }
                 lds_barrier();
                 if (tid == 0) sNext = 0;   // nobody draws between this barrier and the one after the flush
@@ -1180,7 +1241,8 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
         ldsWin = 3 * (size_t)kWinVox * sizeof(int) + (size_t)mReco * 6 * sizeof(double) +
                  ((size_t)(mReco + 1) + mReco + 2 * mReco) * sizeof(int) + 2 * (size_t)mReco * sizeof(float) +
                  4 * (size_t)mReco * sizeof(short) + 2 * (size_t)mReco * sizeof(float) + 32 +
-                 (size_t)kIPix * kIPix * sizeof(float4) + 2 * (size_t)kMaxU * kIPix * sizeof(float2);
+                 (size_t)kIPix * kIPix * sizeof(float4) + 2 * (size_t)kMaxU * kIPix * sizeof(float2) +
+                 (size_t)(kWinThreads / 64) * 128 * sizeof(int);
         THX_REQUIRE(ldsWin <= 160 * 1024, "mReco too large for the LDS draw table");
         THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_insert_win), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)ldsWin));
