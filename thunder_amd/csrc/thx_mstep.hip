@@ -698,98 +698,122 @@ __device__ __forceinline__ bool win_sample(const WinGeom& g, const double* R, in
     return inMask != 0;
 }
 
-// accumulate group gi_'s candidates of this window/slab (one wave), AX = dominant axis of the reference plane.
-// Two phases: the wave walks the candidate box and keeps the pixels that really own voxels here (float pre-test, then the
-// exact geometry) in a per-wave LDS queue -- only ~22 of 64 lanes of a box trip are such hits -- and processes the queue
-// 64 entries at a time (value of the pixel for the group, 8 voxel terms), i.e. with full lanes.
+// The group walk of k_insert_win, in two phases per wave.
+// win_enqueue: the wave walks the candidate box of one group and tests every pixel in float -- (p, q) inside the padded
+//   window, height above the sheared reference plane inside the padded slab, pixel listed -- and appends the probable hits
+//   (pixel + group, 32 bits) to its LDS queue; only ~22 of the 64 lanes of a box trip are real hits, so doing the exact
+//   work there would leave two thirds of the VALU idle (the kernel is VALU-bound: 65 % busy at 3.3 waves per SIMD).
+// win_process: one queue entry per lane -- exact geometry (fp64 position, cell, voxel mask), the pixel's value for the
+//   group, the 8 voxel terms -- run whenever 64 entries are waiting, and once more at the end of the slab for the rest.
+//   The queue outlives the groups of a slab, so practically every trip has full lanes.
+constexpr int kWinQueue = 128;   // entries per wave: at most 63 waiting + 64 appended per box trip
+
+__device__ __forceinline__ int win_pack(int pi, int pj, int gi) { return pi | ((pj + 1024) << 11) | (gi << 22); }
+
 template <int AX>
-__device__ __forceinline__ void insert_win_group(const InsertWinArgs& wa, const WinGeom& g, int* sRe, int* sIm, int* sT,
-                                                 const DrawTables& dt, int img, int gi_, int i0, int nI, int j0, int nJ,
-                                                 float wgt, float2* F, float* T, volatile int* queue)
+__device__ __forceinline__ void win_process(const InsertWinArgs& wa, const WinGeom& g, int* sRe, int* sIm, int* sT,
+                                            const DrawTables& dt, int img, float wgt, float2* F, float* T, int pk)
+{
+    const InsertArgs& a = wa.a;
+    constexpr int pa = AX == 0 ? 1 : 0;
+    constexpr int qa = AX == 2 ? 1 : 2;
+    const int P = a.P, half = a.idim / 2;
+    const int pi = pk & 0x7FF, pj = ((pk >> 11) & 0x7FF) - 1024, gi_ = (int)((unsigned)pk >> 22);
+    const double* R = dt.R + 6 * gi_;
+    WinSample w;
+    if (!win_sample<AX>(g, R, a.opf, P, pi, pj, w)) return;   // a false positive of the float test
+    const int m0 = dt.gStart[gi_], m1 = dt.gStart[gi_ + 1];
+    const float nmem = (float)(m1 - m0);
+    const int ti = pi - g.ui0, tj = pj - g.uj0;
+    const bool tab = (unsigned)ti < (unsigned)kIPix && (unsigned)tj < (unsigned)kIPix;
+    float2 dv;
+    float cf;
+    if (tab) {
+        const float4 px = g.pix[tj * kIPix + ti];
+        dv = make_float2(px.x, px.y); cf = px.z;
+    } else {
+        const int k = wa.pixIndex[(pj + half) * (half + 1) + pi];
+        dv = a.datP[(size_t)img * a.nPxl + k]; cf = a.ctfP[(size_t)img * a.nPxl + k];
+    }
+    // the value of this pixel for the group: (img * sum of the members' ramps) * ctf * w, T: n * ctf^2 * w
+    float2 S = make_float2(0.f, 0.f);
+    if (tab && dt.U <= kMaxU) {
+        for (int i = m0; i < m1; i++) {   // separable ramp exp(-i a_u i) exp(-i b_u j) from the window's tables
+            const int u = dt.mUid[i];
+            const float2 ec = g.ecol[u * kIPix + ti], er = g.erow[u * kIPix + tj];
+            S.x += ec.x * er.x - ec.y * er.y;
+            S.y += ec.x * er.y + ec.y * er.x;
+        }
+    } else {
+        S = insert_ramp_sum_slow(dt.slope, dt.mUid, m0, m1, pi, pj);
+    }
+    const float2 tv = cmul(dv, S);
+    if (a.cSearch) cf = insert_ctf_search(a.attr, a.dfac, img, a.mReco, dt.gInfo[2 * gi_ + 1], a.pixelSize, a.idim, pi, pj);
+    float vre = tv.x * cf, vim = tv.y * cf;
+    vre = vre * 1.0f; vim = vim * 1.0f;
+    vre = vre * wgt; vim = vim * wgt;
+    if (w.conj) vim = -vim;
+    const float tval = (pow2f_(cf) * 1.0f * wgt) * nmem;
+    const float xd = w.x - w.fx, yd = w.y - w.fy, zd = w.z - w.fz;
+    const float vx[2] = {1.0f - xd, xd}, vy[2] = {1.0f - yd, yd}, vz[2] = {1.0f - zd, zd};
+    // fixed-point scales folded into the pixel's value once (the brick's quantum is 2^-22 of the largest term)
+    const float vreS = vre * g.scaleF, vimS = vim * g.scaleF, tvalS = tval * g.scaleT;
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+        if (!((w.inMask >> v) & 1)) continue;
+        const int ii = v & 1, jj = (v >> 1) & 1, kk = v >> 2;
+        const int dp = comp3<pa>(ii, jj, kk), dq = comp3<qa>(ii, jj, kk), da = comp3<AX>(ii, jj, kk);
+        const float wv = vx[ii] * vy[jj] * vz[kk];
+        const int off = w.offA[dq][dp] + w.sg * da;
+        const float tq = tvalS * wv;
+        if (tq >= g.minQ) {
+            const int idx = AX == 0 ? ((w.qI[dq] * kWd + w.pI[dp]) * kWz + off) : ((w.qI[dq] * kWz + off) * kWd + w.pI[dp]);
+            if (wa.debug & 1) { if (idx < 0) sRe[0] = 1; continue; }
+            atomicAdd(&sRe[idx], __float2int_rn(vreS * wv));
+            atomicAdd(&sIm[idx], __float2int_rn(vimS * wv));
+            atomicAdd(reinterpret_cast<unsigned*>(&sT[idx]), __float2uint_rn(tq));
+        } else {
+            // tiny term (see k_insert_tiles): F and T travel together as floats
+            insert_tiny_term(F, T, P, w.X0 + ii, w.Y0 + jj, w.Z0 + kk, vre * wv, vim * wv, tval * wv);
+        }
+    }
+}
+
+// the entries still waiting at the end of a slab
+template <int AX>
+__device__ __forceinline__ void win_drain(const InsertWinArgs& wa, const WinGeom& g, int* sRe, int* sIm, int* sT,
+                                          const DrawTables& dt, int img, float wgt, float2* F, float* T, volatile int* queue,
+                                          int& qn)
+{
+    if (qn > 0) {
+        const int lane = threadIdx.x & 63;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int e0 = lane < qn ? queue[lane] : 0;
+        if (lane < qn) win_process<AX>(wa, g, sRe, sIm, sT, dt, img, wgt, F, T, e0);
+        qn = 0;
+    }
+}
+
+template <int AX>
+__device__ __forceinline__ void win_enqueue(const InsertWinArgs& wa, const WinGeom& g, int* sRe, int* sIm, int* sT,
+                                            const DrawTables& dt, int img, int gi_, int i0, int nI, int j0, int nJ, float wgt,
+                                            float2* F, float* T, volatile int* queue, int& qn)
 {
     const InsertArgs& a = wa.a;
     constexpr int pa = AX == 0 ? 1 : 0;
     constexpr int qa = AX == 2 ? 1 : 2;
     const int lane = threadIdx.x & 63;
-    const int P = a.P, half = a.idim / 2;
+    const int half = a.idim / 2;
     const double* R = dt.R + 6 * gi_;
-    const int m0 = dt.gStart[gi_], m1 = dt.gStart[gi_ + 1];
-    const float nmem = (float)(m1 - m0);
     const int nCand = nI * nJ;
     const float rnI = 1.0f / (float)nI;
-    // float pre-test on (p, q) of the sample (rows pa, qa of R; the margin covers float rounding and the cell extent)
+    // rows pa, qa, AX of the group's rotation: (p, q) of a pixel and its height above the sheared reference plane.  Margins:
+    // cell extent, Hermitian fold and float rounding in (p, q); |d(a - sp p - sq q)| <= 1 + |sp| + |sq| <= 3 between a
+    // sample and the voxels of its cell, + 1 for the floor of the shear, in the height.
     const float A00 = (float)R[pa] * (float)a.opf, A01 = (float)R[3 + pa] * (float)a.opf, A10 = (float)R[qa] * (float)a.opf,
-                A11 = (float)R[3 + qa] * (float)a.opf;
+                A11 = (float)R[3 + qa] * (float)a.opf, A20 = (float)R[AX] * (float)a.opf, A21 = (float)R[3 + AX] * (float)a.opf;
     const float plo = (float)g.p0 - 2.5f, phi = (float)(g.p0 + kWd) + 1.5f, qlo = (float)g.q0 - 2.5f, qhi = (float)(g.q0 + kWd) + 1.5f;
-
-    // ---- phase 2: one queue entry per lane ----
-    auto process = [&](int pk) {
-        const int pi = pk & 0xFFFF, pj = (int)(short)(pk >> 16);
-        WinSample w;
-        if (!win_sample<AX>(g, R, a.opf, P, pi, pj, w)) return;   // cannot fail: the entry passed the same test in phase 1
-        const int ti = pi - g.ui0, tj = pj - g.uj0;
-        const bool tab = (unsigned)ti < (unsigned)kIPix && (unsigned)tj < (unsigned)kIPix;
-        float2 dv;
-        float cf;
-        if (tab) {
-            const float4 px = g.pix[tj * kIPix + ti];
-            dv = make_float2(px.x, px.y); cf = px.z;
-        } else {
-            const int k = wa.pixIndex[(pj + half) * (half + 1) + pi];
-            dv = a.datP[(size_t)img * a.nPxl + k]; cf = a.ctfP[(size_t)img * a.nPxl + k];
-        }
-        // the value of this pixel for the group: (img * sum of the members' ramps) * ctf * w, T: n * ctf^2 * w
-        float2 S = make_float2(0.f, 0.f);
-        if (tab && dt.U <= kMaxU) {
-            for (int i = m0; i < m1; i++) {   // separable ramp exp(-i a_u i) exp(-i b_u j) from the window's tables
-                const int u = dt.mUid[i];
-                const float2 ec = g.ecol[u * kIPix + ti], er = g.erow[u * kIPix + tj];
-                S.x += ec.x * er.x - ec.y * er.y;
-                S.y += ec.x * er.y + ec.y * er.x;
-            }
-        } else {
-            S = insert_ramp_sum_slow(dt.slope, dt.mUid, m0, m1, pi, pj);
-        }
-        const float2 tv = cmul(dv, S);
-        if (a.cSearch) cf = insert_ctf_search(a.attr, a.dfac, img, a.mReco, dt.gInfo[2 * gi_ + 1], a.pixelSize, a.idim, pi, pj);
-        float vre = tv.x * cf, vim = tv.y * cf;
-        vre = vre * 1.0f; vim = vim * 1.0f;
-        vre = vre * wgt; vim = vim * wgt;
-        if (w.conj) vim = -vim;
-        const float tval = (pow2f_(cf) * 1.0f * wgt) * nmem;
-        const float xd = w.x - w.fx, yd = w.y - w.fy, zd = w.z - w.fz;
-        const float vx[2] = {1.0f - xd, xd}, vy[2] = {1.0f - yd, yd}, vz[2] = {1.0f - zd, zd};
-        // fixed-point scales folded into the pixel's value once (the brick's quantum is 2^-22 of the largest term)
-        const float vreS = vre * g.scaleF, vimS = vim * g.scaleF, tvalS = tval * g.scaleT;
-#pragma unroll
-        for (int v = 0; v < 8; v++) {
-            if (!((w.inMask >> v) & 1)) continue;
-            const int ii = v & 1, jj = (v >> 1) & 1, kk = v >> 2;
-            const int dp = comp3<pa>(ii, jj, kk), dq = comp3<qa>(ii, jj, kk), da = comp3<AX>(ii, jj, kk);
-            const float wv = vx[ii] * vy[jj] * vz[kk];
-            const int off = w.offA[dq][dp] + w.sg * da;
-            const float tq = tvalS * wv;
-            if (tq >= g.minQ) {
-                const int idx = AX == 0 ? ((w.qI[dq] * kWd + w.pI[dp]) * kWz + off) : ((w.qI[dq] * kWz + off) * kWd + w.pI[dp]);
-                if (wa.debug & 1) { if (idx < 0) sRe[0] = 1; continue; }
-                atomicAdd(&sRe[idx], __float2int_rn(vreS * wv));
-                atomicAdd(&sIm[idx], __float2int_rn(vimS * wv));
-                atomicAdd(reinterpret_cast<unsigned*>(&sT[idx]), __float2uint_rn(tq));
-            } else {
-                // tiny term (see k_insert_tiles): F and T travel together as floats
-                insert_tiny_term(F, T, P, w.X0 + ii, w.Y0 + jj, w.Z0 + kk, vre * wv, vim * wv, tval * wv);
-            }
-        }
-    };
-
-    // ---- phase 1: walk the candidate box, queue the probable hits ----
-    // All in float: (p, q) inside the padded window, and the height of the sample above the sheared reference plane
-    // inside the padded slab (margins: cell extent, the floor of the shear, the Hermitian fold, float rounding).  The
-    // exact test is repeated per queue entry in phase 2, so a false positive only idles a lane there.
-    const float A20 = (float)R[AX] * (float)a.opf, A21 = (float)R[3 + AX] * (float)a.opf;
-    // |d(a - sp p - sq q)| <= 1 + |sp| + |sq| <= 3 between a sample and the voxels of its cell, + 1 for the floor of the shear
     const float wlo = (float)g.w0 - 4.5f, whi = (float)(g.w0 + kWz) + 3.5f;
-    int qn = 0;   // wave-uniform
     for (int c0 = 0; c0 < nCand; c0 += 64) {
         const int c = c0 + lane;
         bool hit = false;
@@ -803,7 +827,7 @@ __device__ __forceinline__ void insert_win_group(const InsertWinArgs& wa, const 
                 const int ti = pi - g.ui0, tj = pj - g.uj0;
                 const bool tab = (unsigned)ti < (unsigned)kIPix && (unsigned)tj < (unsigned)kIPix;
                 hit = tab ? (g.pix[tj * kIPix + ti].w != 0.f) : (wa.pixIndex[(pj + half) * (half + 1) + pi] >= 0);
-                pk = (pi & 0xFFFF) | (pj << 16);
+                pk = win_pack(pi, pj, gi_);
             }
         }
         const unsigned long long bal = __ballot(hit);
@@ -816,13 +840,8 @@ __device__ __forceinline__ void insert_win_group(const InsertWinArgs& wa, const 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (64 + lane < qn) queue[lane] = e1;   // the remainder moves to the front (each lane moves its own entry)
             qn -= 64;
-            process(e0);
+            win_process<AX>(wa, g, sRe, sIm, sT, dt, img, wgt, F, T, e0);
         }
-    }
-    if (qn > 0) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int e0 = lane < qn ? queue[lane] : 0;
-        if (lane < qn) process(e0);
     }
 }
 
@@ -873,7 +892,7 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
     float4* sPix = reinterpret_cast<float4*>((reinterpret_cast<uintptr_t>(sWr + 2 * a.mReco) + 15) & ~(uintptr_t)15);  // [kIPix][kIPix]
     float2* sEc = reinterpret_cast<float2*>(sPix + kIPix * kIPix);           // [kMaxU][kIPix]
     float2* sEr = sEc + kMaxU * kIPix;                                       // [kMaxU][kIPix]
-    int* sQueue = reinterpret_cast<int*>(sEr + kMaxU * kIPix);               // [waves][128] hit queues of insert_win_group
+    int* sQueue = reinterpret_cast<int*>(sEr + kMaxU * kIPix);               // [waves][kWinQueue] probable-hit queues (win_enqueue)
     __shared__ int sWlo, sWhi, sCls, sUi0, sUi1, sUj0, sUj1, sNext;
 
     const int img = blockIdx.y, wqI = blockIdx.x;
@@ -1057,6 +1076,7 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
                 g.w0 = sl * kWz - kWz / 2;
                 // the waves draw groups from a shared counter: the work per group varies (candidate box, slab overlap) and
                 // every slab ends in a barrier, so a static split leaves waves idle at it
+                int qn = 0;   // entries waiting in this wave's queue (wave-uniform)
                 for (;;) {
                     int gi_ = 0;
                     if ((tid & 63) == 0) gi_ = atomicAdd(&sNext, 1);
@@ -1065,10 +1085,13 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
                     const short* box = sBox + 4 * gi_;
                     if (box[1] == 0 || (wa.debug & 4)) continue;
                     if (sWr[2 * gi_ + 1] < (float)g.w0 || sWr[2 * gi_] > (float)(g.w0 + kWz)) continue;
-                    if (ax == 0) insert_win_group<0>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T, sQueue + 128 * grp);
-                    else if (ax == 1) insert_win_group<1>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T, sQueue + 128 * grp);
-                    else insert_win_group<2>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T, sQueue + 128 * grp);
+                    if (ax == 0) win_enqueue<0>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T, sQueue + kWinQueue * grp, qn);
+                    else if (ax == 1) win_enqueue<1>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T, sQueue + kWinQueue * grp, qn);
+                    else win_enqueue<2>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T, sQueue + kWinQueue * grp, qn);
                 }
+                if (ax == 0) win_drain<0>(wa, g, sRe, sIm, sT, dt, img, wgt, F, T, sQueue + kWinQueue * grp, qn);
+                else if (ax == 1) win_drain<1>(wa, g, sRe, sIm, sT, dt, img, wgt, F, T, sQueue + kWinQueue * grp, qn);
+                else win_drain<2>(wa, g, sRe, sIm, sT, dt, img, wgt, F, T, sQueue + kWinQueue * grp, qn);
                 lds_barrier();
                 if (tid == 0) sNext = 0;   // nobody draws between this barrier and the one after the flush
                 if (wa.debug & 2) { lds_barrier(); continue; }
@@ -1242,8 +1265,9 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
                  ((size_t)(mReco + 1) + mReco + 2 * mReco) * sizeof(int) + 2 * (size_t)mReco * sizeof(float) +
                  4 * (size_t)mReco * sizeof(short) + 2 * (size_t)mReco * sizeof(float) + 32 +
                  (size_t)kIPix * kIPix * sizeof(float4) + 2 * (size_t)kMaxU * kIPix * sizeof(float2) +
-                 (size_t)(kWinThreads / 64) * 128 * sizeof(int);
+                 (size_t)(kWinThreads / 64) * kWinQueue * sizeof(int);
         THX_REQUIRE(ldsWin <= 160 * 1024, "mReco too large for the LDS draw table");
+        THX_REQUIRE(mReco <= 1024 && idim <= 2048, "window insertion packs (pixel, group) into 11 + 11 + 10 bits");
         THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_insert_win), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)ldsWin));
     }
