@@ -997,6 +997,9 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
             if (tid == 0) { sWlo = INT_MAX; sWhi = INT_MIN; sUi0 = INT_MAX; sUi1 = INT_MIN; sUj0 = INT_MAX; sUj1 = INT_MIN; sNext = 0; }
             __syncthreads();
             // ---- per group: candidate pixel box (inverse 2x2 map of the padded window corners) and sheared-w range ----
+            // (the six extrema are reduced inside the wave and reach LDS once per wave: 8 same-address LDS atomics from
+            // each of 62 lanes, with the other seven waves waiting at the barrier, were 14 % of the kernel)
+            int lUi0 = INT_MAX, lUi1 = INT_MIN, lUj0 = INT_MAX, lUj1 = INT_MIN, lWlo = INT_MAX, lWhi = INT_MIN;
             for (int gi_ = tid; gi_ < G; gi_ += kWinThreads) {
                 const double* R = sR + 6 * gi_;
                 short* box = sBox + 4 * gi_;
@@ -1021,7 +1024,7 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
                     j0 = j0 < -half ? -half : j0; j1 = j1 > half - 1 ? half - 1 : j1;
                     if (i1 < i0 || j1 < j0) continue;
                     box[0] = (short)i0; box[1] = (short)(i1 - i0 + 1); box[2] = (short)j0; box[3] = (short)(j1 - j0 + 1);
-                    atomicMin(&sUi0, i0); atomicMax(&sUi1, i1); atomicMin(&sUj0, j0); atomicMax(&sUj1, j1);
+                    lUi0 = min(lUi0, i0); lUi1 = max(lUi1, i1); lUj0 = min(lUj0, j0); lUj1 = max(lUj1, j1);
                 }
                 // height of the group's plane above the reference shear at the window corners
                 const float gn0 = (float)(R[1] * R[5] - R[2] * R[4]), gn1 = (float)(R[2] * R[3] - R[0] * R[5]),
@@ -1037,8 +1040,20 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
                 }
                 sWr[2 * gi_] = wmin - 3.0f;
                 sWr[2 * gi_ + 1] = wmax + 3.0f;
-                atomicMin(&sWlo, (int)floorf(wmin - 3.0f));
-                atomicMax(&sWhi, (int)ceilf(wmax + 3.0f));
+                lWlo = min(lWlo, (int)floorf(wmin - 3.0f));
+                lWhi = max(lWhi, (int)ceilf(wmax + 3.0f));
+            }
+            if (tid < ((G + 63) & ~63)) {   // the waves that held groups (wave-uniform condition)
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    lUi0 = min(lUi0, __shfl_xor(lUi0, o, 64)); lUi1 = max(lUi1, __shfl_xor(lUi1, o, 64));
+                    lUj0 = min(lUj0, __shfl_xor(lUj0, o, 64)); lUj1 = max(lUj1, __shfl_xor(lUj1, o, 64));
+                    lWlo = min(lWlo, __shfl_xor(lWlo, o, 64)); lWhi = max(lWhi, __shfl_xor(lWhi, o, 64));
+                }
+                if ((tid & 63) == 0) {
+                    atomicMin(&sUi0, lUi0); atomicMax(&sUi1, lUi1); atomicMin(&sUj0, lUj0); atomicMax(&sUj1, lUj1);
+                    atomicMin(&sWlo, lWlo); atomicMax(&sWhi, lWhi);
+                }
             }
             __syncthreads();
             if (sWlo > sWhi) continue;
