@@ -50,6 +50,10 @@ typedef struct thx_ctf_attr {
 
 const char* thx_last_error(void);
 int thx_version(void);
+/* The THX_* environment switches (A/B selection between tested code paths: THX_INSERT_PLAIN, THX_FFT, THX_EXPECT_ND,
+ * THX_EXPECT_KERNEL, ...) are read ONCE, when the library is loaded.  Test harnesses that change the environment
+ * afterwards call this to re-read them; it must not run concurrently with launches. */
+int thx_knobs_reload(void);
 
 /* getAviDevice(std::vector<int>&), Interface.h:16 -- number of visible gfx950 devices */
 int thx_device_count(int* count);
@@ -128,13 +132,18 @@ int thx_logdatavsprior_dev(float* out, const float* dat, const float* pri, const
  *   logW (optional, may be NULL) [nImg][nD][nT][nR] every log-likelihood.
  * Weights are relative to the per-image maximum exactly as the reference's running-baseline rescale leaves
  * them (mathematically identical; float rounding differs -- tolerance in tests/test_parity_gpu.py).
- * workspace: thx_expect_local_workspace() bytes of device scratch. */
+ * workspace: thx_expect_local_workspace() bytes of device scratch.
+ * wgPerCU: occupancy of the local-search kernel, workgroups (4 waves each) per CU; 0 = unlimited, negative = the
+ *   library default (2).  With the particle filter's clouds of support points (rotations ~1 degree apart, the
+ *   reference's production case) the kernel is bound by scattered 64-byte reads and is 17 % faster with 8 waves per CU
+ *   than with 20; callers that feed tightly clustered rotations (all within ~0.2 degree) should pass 0.  Results do
+ *   not depend on it. */
 size_t thx_expect_local_workspace(int nImg, int nR, int nT, int nD);
 int thx_expect_local_dev(const float* volumes, const int* volIdx, int vdim, int pf, int idim, const int* iCol,
                          const int* iRow, int nPxl, int nImg, const float* datP, const float* ctfP,
                          const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
                          const double* pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR,
-                         float* wT, float* wD, float* baseLine, float* logW, void* workspace, void* stream);
+                         float* wT, float* wD, float* baseLine, float* logW, void* workspace, int wgPerCU, void* stream);
 
 /* Cell-packed projector volume: for every cell origin of the half grid the 8 corner values of its trilinear cell stored
  * contiguously (64 bytes), so that one sample's gather is ONE contiguous read instead of four reads from four cache
@@ -144,19 +153,13 @@ int thx_expect_local_dev(const float* volumes, const int* volIdx, int vdim, int 
 size_t thx_projector_packed_bytes(int vdim);
 int thx_projector_pack_dev(float* cells, const float* volumes, int vdim, int nVol, void* stream);
 
-/* Occupancy of the local-search kernel: workgroups (4 waves each) per CU, 0 = unlimited.  Default 2: with the
- * particle filter's clouds of support points (rotations ~1 degree apart, the reference's production case) the
- * kernel is bound by scattered 64-byte reads and is 17 % faster with 8 waves per CU than with 20; callers that
- * feed tightly clustered rotations (all within ~0.2 degree) should set 0.  Results do not depend on it. */
-int thx_expect_local_set_occupancy(int workgroupsPerCU);
-
 /* thx_expect_local_dev gathering from cell-packed volumes (bit-identical results). */
 int thx_expect_local_packed_dev(const float* cells, const int* volIdx, int vdim, int pf, int idim, const int* iCol,
                                 const int* iRow, int nPxl, int nImg, const float* datP, const float* ctfP,
                                 const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
                                 const double* pC, const double* pR, const double* pT, const double* pD, float* wC,
                                 float* wR, float* wT, float* wD, float* baseLine, float* logW, void* workspace,
-                                void* stream);
+                                int wgPerCU, void* stream);
 
 /* Global scanning phase for class kIdx: src/Optimiser.cpp:756-894 (ExpectGlobal3D, Interface.h:221-237).
  *   rotP [nR][nPxl] slices (thx_project_dev), traP [nT][nPxl] ramps (thx_translate_dev)

@@ -287,7 +287,7 @@ def test_insert(oracle, dev, N, nK):
     np.testing.assert_allclose(Od.cpu().numpy(), Ow, rtol=1e-12, atol=1e-12)
 
 
-def test_insert_unrelated_draws_and_plain_kernel(oracle, dev, monkeypatch):
+def test_insert_unrelated_draws_and_plain_kernel(oracle, dev, knob_env):
     """draws that are NOT nearby orientations leave the LDS brick and take the direct-atomic path; the plain
     kernel (THX_INSERT_PLAIN=1) and the brick kernel must both match the oracle"""
     from thunder_amd import ops, synth
@@ -300,7 +300,7 @@ def test_insert_unrelated_draws_and_plain_kernel(oracle, dev, monkeypatch):
     Fw, Tw, _ = _oracle_insert(O, P, N, pl, im, quat, tran, offS, w, np.zeros_like(cls), 1)
     rot = ops.rotmat(T(quat.reshape(-1, 4), dev))
     for plain in ("0", "1"):
-        monkeypatch.setenv("THX_INSERT_PLAIN", plain)
+        knob_env("THX_INSERT_PLAIN", plain)
         F = torch.zeros((P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
         Tt = torch.zeros((P, P, P // 2 + 1), dtype=torch.float32, device=dev)
         ops.insert(F, Tt, P, T(im["dat"], dev), T(im["ctf"], dev), T(w, dev), rot, T(tran, dev), T(pl["iCol"], dev),
@@ -626,7 +626,7 @@ def test_full_size_properties_n256(oracle, dev):
     plan.close()
 
 
-def test_insert_then_reconstruct_matches_float_path(dev, monkeypatch):
+def test_insert_then_reconstruct_matches_float_path(dev, knob_env):
     """The gridding reconstruction is ill-conditioned where coverage is thin, so the bar on the inserted F/T (1e-5 max)
     does not by itself bound the map.  The LDS-brick kernel (fixed-point accumulation, tiny terms routed as floats) must
     give the same MAP-off, grid-corrected map as the plain float-atomic kernel (the reference's own arithmetic)."""
@@ -637,7 +637,7 @@ def test_insert_then_reconstruct_matches_float_path(dev, monkeypatch):
     rot, tran = sh.draw_reco(0, wR, wT)
     maps = {}
     for plain in ("1", "0"):
-        monkeypatch.setenv("THX_INSERT_PLAIN", plain)
+        knob_env("THX_INSERT_PLAIN", plain)
         sh.insertion(0, rot, tran)
         ops.normalise_TF(sh.F[0], sh.T[0], sh.P)
         maps[plain] = sh.plans[0].reconstruct(sh.F[0].clone(), sh.T[0].clone(), sh.maxRadius, MAP=False, gridCorr=True)
@@ -755,7 +755,7 @@ def test_full_size_properties_n512(oracle, dev):
 
 
 @pytest.mark.parametrize("N", [64, 128, 256, 512])
-def test_hand_fft_passes_match_rocfft(dev, monkeypatch, N):
+def test_hand_fft_passes_match_rocfft(dev, knob_env, N):
     """The gridding iteration on power-of-two grids (P = 128 ... 1024 here; the BASELINE grid is P = 512) runs on the
     hand-written FFT passes of thx_fft8.h (strided radix-8 passes with a radix-2 / 4 pre-stage where needed, x transform
     fused with the kernel multiply, z transform fused with the weight update); at P = 64 and 128 the same code is checked
@@ -776,10 +776,7 @@ def test_hand_fft_passes_match_rocfft(dev, monkeypatch, N):
     fscv = np.clip(np.linspace(1.0, 0.1, N // 2), 0, 1).astype(np.float32)
     out = {}
     for mode in ("rocfft", "hand"):
-        if mode == "rocfft":
-            monkeypatch.setenv("THX_FFT", "rocfft")
-        else:
-            monkeypatch.delenv("THX_FFT", raising=False)
+        knob_env("THX_FFT", "rocfft" if mode == "rocfft" else None)
         m = plan.reconstruct(F.clone(), Tt.clone(), N // 2 - 2, FSC=fscv, MAP=True, gridCorr=True)
         out[mode] = (m, plan.last_iters, plan.last_diffC)
     (ma, ia, da), (mb, ib, db) = out["rocfft"], out["hand"]
@@ -788,7 +785,7 @@ def test_hand_fft_passes_match_rocfft(dev, monkeypatch, N):
     plan.close()
 
 
-def test_expect_local_fused_defocus_search(oracle, dev, monkeypatch):
+def test_expect_local_fused_defocus_search(oracle, dev, knob_env):
     """CTF search at the reference's sizes (mLR 125, mLT 9, mLD 9): the fused kernel (one gather serves the 9 defocus
     factors) against one sweep per factor (THX_EXPECT_ND=sweep) and, for one image, against the oracle"""
     import time
@@ -810,10 +807,7 @@ def test_expect_local_fused_defocus_search(oracle, dev, monkeypatch):
             T(rot_h, dev), T(tran_h, dev))
     out = {}
     for mode in ("sweep", "fused"):
-        if mode == "sweep":
-            monkeypatch.setenv("THX_EXPECT_ND", "sweep")
-        else:
-            monkeypatch.delenv("THX_EXPECT_ND", raising=False)
+        knob_env("THX_EXPECT_ND", "sweep" if mode == "sweep" else None)
         ops.expect_local(*args, nD=nD, pD=T(pD, dev), pR=T(pR, dev), want_logW=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -40,6 +40,7 @@ SIGNATURES = {
     "thx_memcpy_d2h": (_i, [_vp, _vp, _sz]),
     "thx_memset_dev": (_i, [_vp, _i, _sz]),
     "thx_device_sync": (_i, []),
+    "thx_knobs_reload": (_i, []),
     "thx_rotmat_dev": (_i, [_vp, _vp, _i, _vp]),
     "thx_translate_dev": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "thx_ctf_dev": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp]),
@@ -51,10 +52,9 @@ SIGNATURES = {
     "thx_logdatavsprior_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "thx_expect_local_workspace": (_sz, [_i, _i, _i, _i]),
     "thx_expect_local_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i,
-                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "thx_expect_local_packed_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i,
-                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "thx_expect_local_set_occupancy": (_i, [_i]),
+                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "thx_projector_packed_bytes": (_sz, [_i]),
     "thx_projector_pack_dev": (_i, [_vp, _vp, _i, _i, _vp]),
     "thx_expect_global_workspace": (_sz, [_i, _i, _i]),

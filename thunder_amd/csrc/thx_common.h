@@ -42,6 +42,22 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 // them, which corrupted caller buffers in a torch-free process -- tests/cpp/mirror_roundtrip.cpp exercises that.)
 void* scratch(hipStream_t stream, int slot, size_t bytes);
 
+// Environment switches for A/B runs.  Read ONCE, when the library is first used -- never per launch -- and only
+// switches that select between tested code paths; the profiling-only switches (skipped work, shrunken sampling region)
+// exist solely in builds with -DTHX_PROFILING.
+struct Knobs {
+    int expectNSplit;     // THX_EXPECT_NSPLIT = 1..16: pixel splits of the local-search kernel (0 = automatic)
+    int expectWgPerCU;    // THX_EXPECT_WG_PER_CU: overrides the occupancy argument of thx_expect_local_dev (-1 = unset)
+    bool expectNdSweep;   // THX_EXPECT_ND=sweep: one launch per defocus factor instead of the fused kernel
+    int expectKernel;     // THX_EXPECT_KERNEL = gather | brick: forces one local-search kernel (0 = automatic, 1, 2)
+    bool insertPlain;     // THX_INSERT_PLAIN=1: plain float-atomic insertion (k_insert)
+    float minQuanta;      // THX_MIN_QUANTA: smallest T term accumulated in the fixed-point LDS brick
+    bool fftRocfft;       // THX_FFT=rocfft: library transforms in the gridding loop for every size
+    bool recoTrace;       // THX_RECO_TRACE: print diffC per balancing round
+    int insertDebug;      // THX_INSERT_DEBUG (honoured only with -DTHX_PROFILING)
+};
+const Knobs& knobs();
+
 constexpr double kM2xPi = 6.28318530717959;  // M_2X_PI, include/Macro.h:14
 
 // ---------------------------------------------------------------------------------------------

@@ -7,6 +7,7 @@
 
 #include <map>
 #include <mutex>
+#include <tuple>
 #include <utility>
 
 #include "thx_common.h"
@@ -22,13 +23,43 @@ void set_error(const char* fmt, ...)
     va_end(ap);
 }
 
+static Knobs read_knobs()
+{
+    Knobs v;
+    const char* e;
+    v.expectNSplit = 0;
+    if ((e = getenv("THX_EXPECT_NSPLIT"))) { const int n = atoi(e); if (n >= 1 && n <= 16) v.expectNSplit = n; }
+    v.expectWgPerCU = -1;
+    if ((e = getenv("THX_EXPECT_WG_PER_CU"))) v.expectWgPerCU = atoi(e);
+    e = getenv("THX_EXPECT_ND");
+    v.expectNdSweep = e && e[0] == 's';
+    e = getenv("THX_EXPECT_KERNEL");
+    v.expectKernel = !e ? 0 : (e[0] == 'g' ? 1 : (e[0] == 'b' ? 2 : 0));
+    e = getenv("THX_INSERT_PLAIN");
+    v.insertPlain = e && e[0] == '1';
+    e = getenv("THX_MIN_QUANTA");
+    v.minQuanta = e ? (float)atof(e) : -1.0f;
+    e = getenv("THX_FFT");
+    v.fftRocfft = e && e[0] == 'r';
+    v.recoTrace = getenv("THX_RECO_TRACE") != nullptr;
+    e = getenv("THX_INSERT_DEBUG");
+    v.insertDebug = e ? atoi(e) : 0;
+    return v;
+}
+
+static Knobs g_knobs = read_knobs();   // once, when the library is loaded
+const Knobs& knobs() { return g_knobs; }
+
+// keyed on (device, stream, slot): the Interface.h-shaped *_host entry points run on whichever device gpuIdx names
 void* scratch(hipStream_t stream, int slot, size_t bytes)
 {
     struct Buf { void* p = nullptr; size_t n = 0; };
     static std::mutex mtx;
-    static std::map<std::pair<hipStream_t, int>, Buf> bufs;
+    static std::map<std::tuple<int, hipStream_t, int>, Buf> bufs;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> g(mtx);
-    Buf& b = bufs[std::make_pair(stream, slot)];
+    Buf& b = bufs[std::make_tuple(dev, stream, slot)];
     if (b.n < bytes) {
         if (b.p) {
             (void)hipStreamSynchronize(stream);   // the old buffer may still be in use by queued work
@@ -234,7 +265,6 @@ struct ExpectLocalArgs {
     float* partV;  // [nImg][nD][nSplit][nT][nRpad]
     float* partC;  // [nImg][nD][nSplit]
     int nRpad;
-    float dbgScale;  // 1 in production; THX_EXPECT_DEBUG shrinks the sampled region (cache-resident) for profiling
 };
 
 template <int NT, bool PACKED>
@@ -311,9 +341,9 @@ __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
             if (rvalid) {
                 for (int e = sub; e < clen; e += nSub) {
                     const double nx = (double)sIc[e], ny = (double)sIr[e];
-                    const float x = (float)(m0 * nx + m3 * ny) * a.dbgScale;
-                    const float y = (float)(m1 * nx + m4 * ny) * a.dbgScale;
-                    const float z = (float)(m2 * nx + m5 * ny) * a.dbgScale;
+                    const float x = (float)(m0 * nx + m3 * ny);
+                    const float y = (float)(m1 * nx + m4 * ny);
+                    const float z = (float)(m2 * nx + m5 * ny);
                     float2 q = make_float2(0.f, 0.f);
                     if (coord_in_grid(x, y, z, P))
                         q = PACKED ? interp_ft_packed(reinterpret_cast<const float4*>(vol), P, x, y, z) : interp_ft(vol, P, x, y, z);
@@ -438,9 +468,9 @@ __global__ __launch_bounds__(256) void k_expect_local_nd(ExpectLocalArgs a)
             if (rvalid) {
                 for (int e = sub; e < clen; e += nSub) {
                     const double nx = (double)sIc[e], ny = (double)sIr[e];
-                    const float x = (float)(m0 * nx + m3 * ny) * a.dbgScale;
-                    const float y = (float)(m1 * nx + m4 * ny) * a.dbgScale;
-                    const float z = (float)(m2 * nx + m5 * ny) * a.dbgScale;
+                    const float x = (float)(m0 * nx + m3 * ny);
+                    const float y = (float)(m1 * nx + m4 * ny);
+                    const float z = (float)(m2 * nx + m5 * ny);
                     float2 q = make_float2(0.f, 0.f);
                     if (coord_in_grid(x, y, z, P))
                         q = PACKED ? interp_ft_packed(reinterpret_cast<const float4*>(vol), P, x, y, z) : interp_ft(vol, P, x, y, z);
@@ -753,7 +783,7 @@ static int expect_local_nsplit(int nImg)
     // enough blocks to fill 256 CUs x ~6 resident blocks when the batch is small
     int s = 1;
     while (s < 16 && (long)nImg * s < 2048) s *= 2;
-    if (const char* e = getenv("THX_EXPECT_NSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 16) s = v; }
+    if (knobs().expectNSplit) s = knobs().expectNSplit;
     return s;
 }
 
@@ -762,20 +792,21 @@ static int expect_local_nsplit(int nImg)
 // 12 waves 182 ms, 16-20 waves 194 ms, 4 waves 237 ms per 5 000-image launch on MI355X -- beyond ~2 waves per SIMD the
 // extra requests only thrash L2 / the memory queues.  With tightly clustered rotations the loads coalesce and the
 // kernel wants every wave it can get (82 ms unlimited, 113 ms at 2 workgroups).  The cap is applied by rounding the
-// dynamic LDS request up so that one more workgroup does not fit the CU's 160 KB.  0 = unlimited.
-static int g_expectWgPerCU = 2;
+// dynamic LDS request up so that one more workgroup does not fit the CU's 160 KB.  0 = unlimited; it is an argument of
+// thx_expect_local_dev (negative = this default).
+constexpr int kExpectWgPerCUDefault = 2;
 
-static size_t expect_lds_floor()
+static size_t expect_lds_floor(int wg)
 {
-    int wg = g_expectWgPerCU;
-    if (const char* e = getenv("THX_EXPECT_WG_PER_CU")) wg = atoi(e);
+    if (wg < 0) wg = kExpectWgPerCUDefault;
+    if (knobs().expectWgPerCU >= 0) wg = knobs().expectWgPerCU;
     if (wg <= 0 || wg > 8) return 0;
     const size_t f = (size_t)(160 * 1024) / (wg + 1) + 1024;
     return f > 64 * 1024 ? 64 * 1024 : f;   // one workgroup per CU would need > 80 KB: not offered (it is the slowest)
 }
 
 template <int NT>
-static int launch_expect_local(const ExpectLocalArgs& a, hipStream_t st, bool packed)
+static int launch_expect_local(const ExpectLocalArgs& a, hipStream_t st, bool packed, int wgPerCU)
 {
     const int nRG0 = (a.nR + 63) >> 6;
     const int nRGp = nRG0 >= 4 ? 4 : (nRG0 >= 2 ? 2 : 1);
@@ -784,14 +815,13 @@ static int launch_expect_local(const ExpectLocalArgs& a, hipStream_t st, bool pa
     size_t red = (size_t)nSub * (NT + 1) * 64 * nRGp * sizeof(float);
     size_t lds = stage > red ? stage : red;
     {
-        const size_t f = expect_lds_floor();
+        const size_t f = expect_lds_floor(wgPerCU);
         lds = lds > f ? lds : f;
     }
     // defocus search: one pass serves all nD factors when the accumulators fit (nT, nD <= 9); THX_EXPECT_ND=sweep keeps the
     // one-sweep-per-factor form for A/B runs
     {
-        const char* ev = getenv("THX_EXPECT_ND");
-        if (NT == 9 && a.nD > 1 && a.nD <= 9 && !(ev && ev[0] == 's')) {
+        if (NT == 9 && a.nD > 1 && a.nD <= 9 && !knobs().expectNdSweep) {
             constexpr int ND = 9;
             size_t stageN = (size_t)kChunk * (NT * sizeof(float2) + ND * sizeof(float) + sizeof(float) + 2 * sizeof(int)) + 4 * sizeof(float);
             size_t ldsN = stageN > red ? stageN : red;
@@ -802,6 +832,12 @@ static int launch_expect_local(const ExpectLocalArgs& a, hipStream_t st, bool pa
             THX_LAUNCH_CHECK();
             return 0;
         }
+    }
+    if (lds > 64 * 1024) {   // NT = 32: 68.6 KB of stage table, above the default dynamic-LDS limit
+        THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_expect_local<NT, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_expect_local<NT, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     if (packed)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expect_local<NT, true>), dim3(a.nSplit, a.nImg, a.nD), dim3(256), lds, st, a);
@@ -817,7 +853,15 @@ static int launch_expect_local(const ExpectLocalArgs& a, hipStream_t st, bool pa
 extern "C" {
 
 const char* thx_last_error(void) { return thx::g_err; }
-int thx_version(void) { return 100; }
+int thx_version(void) { return 200; }
+
+// Test-harness hook: re-reads the THX_* environment switches (they are otherwise read once, when the library is loaded).
+// Not for production use: must not run concurrently with launches.
+int thx_knobs_reload(void)
+{
+    thx::g_knobs = thx::read_knobs();
+    return 0;
+}
 
 int thx_device_count(int* count)
 {
@@ -829,13 +873,6 @@ int thx_device_count(int* count)
 int thx_set_device(int gpuIdx)
 {
     THX_CHECK(hipSetDevice(gpuIdx));
-    return 0;
-}
-
-int thx_expect_local_set_occupancy(int workgroupsPerCU)
-{
-    THX_REQUIRE(workgroupsPerCU >= 0 && workgroupsPerCU <= 8, "workgroupsPerCU must be 0 (unlimited) .. 8");
-    g_expectWgPerCU = workgroupsPerCU;
     return 0;
 }
 
@@ -967,7 +1004,7 @@ static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, 
                              const int* iRow, int nPxl, int nImg, const float* datP, const float* ctfP,
                              const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
                              const double* pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR,
-                             float* wT, float* wD, float* baseLine, float* logW, void* workspace, void* stream, bool packed)
+                             float* wT, float* wD, float* baseLine, float* logW, void* workspace, int wgPerCU, void* stream, bool packed)
 {
     if (nImg <= 0) return 0;
     THX_REQUIRE(volumes && iCol && iRow && datP && ctfP && sigRcpP && rotMat && trans, "NULL input pointer");
@@ -985,19 +1022,15 @@ static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, 
     a.datP = reinterpret_cast<const float2*>(datP);
     a.ctfP = ctfP; a.sigRcpP = sigRcpP; a.rotMat = rotMat; a.nR = nR; a.trans = trans; a.nT = nT; a.nD = nD;
     a.nSplit = expect_local_nsplit(nImg);
-    {
-        const char* dbg = getenv("THX_EXPECT_DEBUG");
-        a.dbgScale = (dbg && dbg[0] == '1') ? 0.0625f : 1.0f;   // x * 1.0f is exact: production results unchanged
-    }
     a.nRpad = ((nR + 63) / 64) * 64;
     a.partV = reinterpret_cast<float*>(workspace);
     a.partC = a.partV + (size_t)nImg * nD * a.nSplit * nT * a.nRpad;
     int rc;
     ExpectFinalArgs f;
     f.partV = a.partV; f.partC = a.partC; f.nSplit = a.nSplit;
-    if (nT <= 9) rc = launch_expect_local<9>(a, st, packed);
-    else if (nT <= 16) rc = launch_expect_local<16>(a, st, packed);
-    else rc = launch_expect_local<32>(a, st, packed);
+    if (nT <= 9) rc = launch_expect_local<9>(a, st, packed, wgPerCU);
+    else if (nT <= 16) rc = launch_expect_local<16>(a, st, packed, wgPerCU);
+    else rc = launch_expect_local<32>(a, st, packed, wgPerCU);
     if (rc) return rc;
     f.nR = nR; f.nRpad = a.nRpad; f.nT = nT; f.nD = nD;
     f.pC = pC; f.pR = pR; f.pT = pT; f.pD = pD; f.wC = wC; f.wR = wR; f.wT = wT; f.wD = wD; f.baseLine = baseLine;
@@ -1011,20 +1044,20 @@ int thx_expect_local_dev(const float* volumes, const int* volIdx, int vdim, int 
                          const int* iRow, int nPxl, int nImg, const float* datP, const float* ctfP,
                          const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
                          const double* pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR,
-                         float* wT, float* wD, float* baseLine, float* logW, void* workspace, void* stream)
+                         float* wT, float* wD, float* baseLine, float* logW, void* workspace, int wgPerCU, void* stream)
 {
     return expect_local_impl(volumes, volIdx, vdim, pf, idim, iCol, iRow, nPxl, nImg, datP, ctfP, sigRcpP, rotMat, nR, trans, nT,
-                             nD, pC, pR, pT, pD, wC, wR, wT, wD, baseLine, logW, workspace, stream, false);
+                             nD, pC, pR, pT, pD, wC, wR, wT, wD, baseLine, logW, workspace, wgPerCU, stream, false);
 }
 
 int thx_expect_local_packed_dev(const float* cells, const int* volIdx, int vdim, int pf, int idim, const int* iCol,
                                 const int* iRow, int nPxl, int nImg, const float* datP, const float* ctfP,
                                 const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
                                 const double* pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR,
-                                float* wT, float* wD, float* baseLine, float* logW, void* workspace, void* stream)
+                                float* wT, float* wD, float* baseLine, float* logW, void* workspace, int wgPerCU, void* stream)
 {
     return expect_local_impl(cells, volIdx, vdim, pf, idim, iCol, iRow, nPxl, nImg, datP, ctfP, sigRcpP, rotMat, nR, trans, nT,
-                             nD, pC, pR, pT, pD, wC, wR, wT, wD, baseLine, logW, workspace, stream, true);
+                             nD, pC, pR, pT, pD, wC, wR, wT, wD, baseLine, logW, workspace, wgPerCU, stream, true);
 }
 
 size_t thx_projector_packed_bytes(int vdim) { return (size_t)vdim * vdim * (vdim / 2 + 1) * 64; }

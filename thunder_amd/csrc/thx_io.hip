@@ -194,14 +194,15 @@ __global__ __launch_bounds__(256) void k_mask_scale(float* __restrict__ masked, 
     ori[e] = x * scale;
 }
 
-static int cached_plan_r2c(hipfftHandle* out, int idim, int batch)
+// one plan per (device, stream, shape): a hipFFT plan carries its stream and work area
+static int cached_plan_r2c(hipfftHandle* out, int idim, int batch, hipStream_t st)
 {
     static std::mutex mtx;
-    static std::map<std::tuple<int, int, int>, hipfftHandle> cache;
+    static std::map<std::tuple<int, hipStream_t, int, int>, hipfftHandle> cache;
     int dev = 0;
     THX_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> g(mtx);
-    auto key = std::make_tuple(dev, idim, batch);
+    auto key = std::make_tuple(dev, st, idim, batch);
     auto it = cache.find(key);
     if (it == cache.end()) {
         hipfftHandle p;
@@ -210,6 +211,7 @@ static int cached_plan_r2c(hipfftHandle* out, int idim, int batch)
             set_error("hipfftPlanMany(r2c %d x %d, batch %d) failed", idim, idim, batch);
             return 1001;
         }
+        if (hipfftSetStream(p, st) != HIPFFT_SUCCESS) { set_error("hipfftSetStream failed"); return 1002; }
         it = cache.emplace(key, p).first;
     }
     *out = it->second;
@@ -470,9 +472,8 @@ int thx_img_mask_normalise_fft_dev(float* imgFT, float* imgOriFT, float* imgRL, 
                            nPer, total, scale);
         THX_LAUNCH_CHECK();
         hipfftHandle plan;
-        int rc = cached_plan_r2c(&plan, idim, nb);
+        int rc = cached_plan_r2c(&plan, idim, nb, st);
         if (rc) return rc;
-        if (hipfftSetStream(plan, st) != HIPFFT_SUCCESS) { set_error("hipfftSetStream failed"); return 1002; }
         if (hipfftExecR2C(plan, scratchRL, reinterpret_cast<hipfftComplex*>(imgFT + (size_t)b * nFT)) != HIPFFT_SUCCESS ||
             hipfftExecR2C(plan, rl, reinterpret_cast<hipfftComplex*>(imgOriFT + (size_t)b * nFT)) != HIPFFT_SUCCESS) {
             set_error("hipfftExecR2C failed");

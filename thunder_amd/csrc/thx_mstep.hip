@@ -113,41 +113,28 @@ __global__ __launch_bounds__(256) void k_insert(InsertArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Insertion, LDS-brick form (the production path; k_insert above is the plain reference form kept for cSearch-free
-// A/B checks and as the fallback when a brick would not fit).
+// Insertion through an LDS brick (the production path, k_insert_win below; k_insert above is the plain reference form).
 //
-// Measured on MI355X (tools/atomic_bench.hip): fp32 global atomics retire ~19 G *transactions*/s chip-wide (one per
-// XCD per clock) and a transaction may carry up to 16 consecutive floats, so scattered 4-byte atomics (k_insert) reach
-// 2 % of the HBM roofline while runs of 16 consecutive floats are 16x faster.  All mReco draws of one image are
-// nearby orientations, so the samples of an 8x8-pixel tile land in a thin slab of the volume.  One workgroup
-// therefore owns (image, tile): it accumulates all draws into an LDS brick that follows the slab ("sheared brick":
-// columns along the plane's dominant axis, kTz voxels thick, based at the plane of the first draw) with ds_add_f32,
-// then flushes the brick to F/T walking the volume's contiguous x axis, so each global atomic transaction carries a
-// run of voxels.  Samples that fall outside the brick take the direct global-atomic path: correctness never depends on
-// the geometry estimate.
+// Measured on MI355X (tools/atomic_bench.hip, tools/lds_atomic_bench.hip): fp32 global atomics retire ~19 G
+// *transactions*/s chip-wide (one per XCD per clock) and a transaction may carry up to 16 consecutive floats, so
+// scattered 4-byte atomics (k_insert) reach 2 % of the HBM roofline while runs of 16 consecutive floats are 16x faster;
+// ds_add_f32 retires 0.33 lanes/clk/CU whatever the address pattern, ds_add_u32 6-8.  Hence: accumulate in an LDS brick
+// in 32-bit FIXED POINT (order-independent integer sums), flush the brick along the volume's contiguous x axis.
+//
+// Fixed point: T is unsigned with scale 2^(32 - ceil(log2(2 mReco))) / max(ctf^2 w), F signed with one bit less over
+// max|dat| |ctf| w (for one rotation the trilinear weights a voxel collects sum to <= 1).  A term enters the brick only if
+// its T part is >= kMinQuanta quanta (< 1 % rounding); smaller terms (trilinear weight ~1e-6, CTF zeros: ~1 % of terms)
+// go to the volume as float atomics, F and T together -- so T can never round to zero where F does not (which would let
+// the gridding weights W ~ 1 / (T*W conv K) explode).
 //
 // Hermitian fold in brick coordinates: a folded sample (x < 0 -> (X,Y,Z) = -(x,y,z), conjugated) addresses the brick
 // at (-1-X, -Y, -Z); non-folded samples at (X, Y, Z).  The two half-spaces stay disjoint (X = 0 of a folded sample is
 // brick x = -1, so F(0,j,k) and F(0,-j,-k) remain independent accumulators, SURVEY 8a note H) and adjacent.
-// grid (tile rows, nImg), block 512 = 64 pixels x 8 draw groups; a workgroup walks the tiles of its row.
+// (A pixel-tile form of this kernel -- workgroup = (image, 8x8-pixel tile), every draw's copy of the tile in one brick --
+// was 25 % faster for coincident draws and 5x slower for a particle filter's 1-degree clouds; removed, see DESIGN.md.)
 // ---------------------------------------------------------------------------------------------
-constexpr int kTB = 8;            // tile edge, image pixels
-constexpr int kTz = 8;            // brick thickness along the dominant axis, voxels
-constexpr int kBrickCap = 5376;   // brick voxels (x 12 B = 63 KB of LDS; with the draw tables 2 workgroups per CU)
 constexpr float kMinQuanta = 64.f;  // smallest T term (in fixed-point quanta) accumulated in the LDS brick
-constexpr int kMaxU = 16;         // unique shifts whose per-pixel ramps are tabulated in LDS (else computed per member)
-constexpr int kInsThreads = 512;  // 64 pixels x 8 draw groups: 16 waves per CU at 2 workgroups per CU
-constexpr int kInsWaves = kInsThreads / 64;
-
-struct InsertTileArgs {
-    InsertArgs a;
-    const int* pixIndex;  // [idim][idim/2+1] pixel-list position of (iRow + idim/2, iCol) or -1
-    int tilesI;           // tiles along iCol
-    const int* plan;      // k_insert_plan output, plan_stride(mReco) ints per image
-    float minQuanta;      // smallest T term (in fixed-point quanta) that is accumulated in the LDS brick
-    int debug;            // THX_INSERT_DEBUG bit mask (profiling only): 1 skip LDS adds, 2 skip flush, 4 skip fallback
-    unsigned long long* stats;  // optional [2]: in-brick voxel adds, fallback voxel adds
-};
+constexpr int kMaxU = 16;           // unique shifts whose ramps are tabulated in LDS (else computed per member)
 
 // ---------------------------------------------------------------------------------------------
 // Insert plan.  The mReco draws of one image come from a resampled particle filter (Particle::rand picks among
@@ -217,344 +204,20 @@ __global__ __launch_bounds__(128) void k_insert_plan(int* __restrict__ plan, con
 template <int W>
 __device__ __forceinline__ int comp3(int x, int y, int z) { return W == 0 ? x : (W == 1 ? y : z); }
 
-// Per-tile work of k_insert_tiles for a compile-time dominant axis AX (so the axis shuffles fold away):
-// accumulate this lane's pixel over the wave's share of the draws, then flush (and re-zero) the brick.
-struct TileGeom {
-    int pmin, qmin, Wp, Wq, total;
-    float sp, sq;          // column slopes: base(p, q) = floor(sp p + sq q) - M
-    float scaleF, scaleT, invF, invT, minQ;
-};
-
 struct DrawTables {      // LDS-resident per-image tables built from the insert plan
     const double* R;     // [G][6] rotation columns of each group's representative draw
     const int* gStart;   // [G+1]
     const int* mUid;     // [mReco] unique-shift id of the members, grouped
     const int* gInfo;    // [G][2]: class, representative draw
     const float* slope;  // [U][2] ramp slopes of the unique shifts
-    const float2* ramp;  // [U][64] per-pixel ramps of this tile (valid when U <= kMaxU)
     int G, U;
 };
-
-template <int AX, bool DBG>
-__device__ __forceinline__ void insert_tile_body(const InsertTileArgs& ta, const TileGeom& g, int* sRe, int* sIm, int* sT,
-                                                 const DrawTables& dt, int img, int pass, int k, int pi, int pj, float2 dv,
-                                                 float cf, float wgt, float2* F, float* T)
-{
-    const InsertArgs& a = ta.a;
-    constexpr int pa = AX == 0 ? 1 : 0;   // p = x unless the dominant axis is x
-    constexpr int qa = AX == 2 ? 1 : 2;
-    constexpr int M = (kTz - 2) / 2;
-    const int tid = threadIdx.x, grp = tid >> 6;
-    const int P = a.P;
-    const long nc = P / 2 + 1;
-    const int icp = pi * a.opf, irp = pj * a.opf;
-
-    const int lane = tid & 63;
-    if (k >= 0) {
-        for (int gi_ = grp; gi_ < dt.G; gi_ += kInsWaves) {
-            if (a.cls && dt.gInfo[2 * gi_] != pass) continue;
-            const double* R = dt.R + 6 * gi_;
-            // sum of the members' phase ramps; n = number of members
-            const int m0 = dt.gStart[gi_], m1 = dt.gStart[gi_ + 1];
-            float2 S = make_float2(0.f, 0.f);
-            for (int i = m0; i < m1; i++) {
-                const int u = dt.mUid[i];
-                const float2 r = dt.U <= kMaxU ? dt.ramp[u * 64 + lane] : ramp_value(dt.slope[2 * u], dt.slope[2 * u + 1], pi, pj);
-                S.x += r.x;
-                S.y += r.y;
-            }
-            const float nmem = (float)(m1 - m0);
-            const float2 tv = cmul(dv, S);
-            float c = cf;
-            if (a.cSearch) {
-                const CtfConst cc = ctf_const(a.attr[img], a.dfac[(size_t)img * a.mReco + dt.gInfo[2 * gi_ + 1]]);
-                c = ctf_value(cc, a.pixelSize, a.idim, a.idim, pi, pj);
-            }
-            // src[i] * ctf[i] * 1 * w, left to right (src/Reconstructor.cpp:830-833), summed over the group's members
-            float vre = tv.x * c, vim = tv.y * c;
-            vre = vre * 1.0f; vim = vim * 1.0f;
-            vre = vre * wgt; vim = vim * wgt;
-            const float tval = (pow2f_(c) * 1.0f * wgt) * nmem;
-            float x = (float)(R[0] * icp + R[3] * irp);
-            float y = (float)(R[1] * icp + R[4] * irp);
-            float z = (float)(R[2] * icp + R[5] * irp);
-            if (!coord_in_grid(x, y, z, P)) continue;
-            bool conj = false;
-            if (!(x >= 0.0f)) { x *= -1.0f; y *= -1.0f; z *= -1.0f; conj = true; vim = -vim; }
-            const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
-            const int X0 = (int)fx, Y0 = (int)fy, Z0 = (int)fz;
-            const float xd = x - fx, yd = y - fy, zd = z - fz;
-            const float vx[2] = {1.0f - xd, xd}, vy[2] = {1.0f - yd, yd}, vz[2] = {1.0f - zd, zd};
-            // brick coordinates of the cell origin; a folded cell runs backwards (sg = -1)
-            const int sg = conj ? -1 : 1;
-            const int b0x = conj ? -1 - X0 : X0, b0y = conj ? -Y0 : Y0, b0z = conj ? -Z0 : Z0;
-            const int bp0 = comp3<pa>(b0x, b0y, b0z), bq0 = comp3<qa>(b0x, b0y, b0z), ba0 = comp3<AX>(b0x, b0y, b0z);
-            int pI[2], qI[2], offA[2][2];
-            bool pin[2], qin[2];
-#pragma unroll
-            for (int d = 0; d < 2; d++) {
-                pI[d] = bp0 + sg * d - g.pmin;
-                qI[d] = bq0 + sg * d - g.qmin;
-                pin[d] = (unsigned)pI[d] < (unsigned)g.Wp;
-                qin[d] = (unsigned)qI[d] < (unsigned)g.Wq;
-            }
-#pragma unroll
-            for (int dq = 0; dq < 2; dq++)
-#pragma unroll
-                for (int dp = 0; dp < 2; dp++)
-                    offA[dq][dp] = ba0 - ((int)floorf(g.sp * (float)(bp0 + sg * dp) + g.sq * (float)(bq0 + sg * dq)) - M);
-            unsigned outside = 0;
-#pragma unroll
-            for (int kk = 0; kk < 2; kk++)
-#pragma unroll
-                for (int jj = 0; jj < 2; jj++)
-#pragma unroll
-                    for (int ii = 0; ii < 2; ii++) {
-                        const int dp = comp3<pa>(ii, jj, kk), dq = comp3<qa>(ii, jj, kk), da = comp3<AX>(ii, jj, kk);
-                        const float wv = vx[ii] * vy[jj] * vz[kk];
-                        const int off = offA[dq][dp] + sg * da;
-                        // A term enters the fixed-point brick only if its T part is at least kMinQuanta quanta, i.e. is
-                        // represented to better than 1 %; smaller terms (trilinear weight ~1e-6, or a CTF zero) go to
-                        // the volume as floats.  F and T of a term always travel together, so T can never round to zero
-                        // where F does not -- which would let the gridding weights W ~ 1 / (T*W conv K) explode.
-                        const float tq = (tval * wv) * g.scaleT;
-                        const bool in = pin[dp] && qin[dq] && ((unsigned)off < (unsigned)kTz) && (tq >= g.minQ);
-                        // outside voxels add 0 to a dummy slot: the hot path stays branch-free
-                        const int idx = in ? (AX == 0 ? ((qI[dq] * g.Wp + pI[dp]) * kTz + off)
-                                                      : ((qI[dq] * kTz + off) * g.Wp + pI[dp]))
-                                           : kBrickCap - 1;
-                        const float m1 = in ? g.scaleF : 0.f;
-                        if (!(DBG && (ta.debug & 1))) {
-                            atomicAdd(&sRe[idx], __float2int_rn((vre * wv) * m1));
-                            atomicAdd(&sIm[idx], __float2int_rn((vim * wv) * m1));
-                            atomicAdd(reinterpret_cast<unsigned*>(&sT[idx]), __float2uint_rn(in ? tq : 0.f));
-                        }
-                        if (!in) outside |= 1u << (kk * 4 + jj * 2 + ii);
-                    }
-            if (DBG && ta.stats) {
-                atomicAdd(&ta.stats[0], (unsigned long long)(8 - __popc(outside)));
-                atomicAdd(&ta.stats[1], (unsigned long long)__popc(outside));
-            }
-            if (outside && !(DBG && (ta.debug & 4))) {
-                // rare: samples that left the brick go straight to the volume
-#pragma unroll
-                for (int v = 0; v < 8; v++) {   // compile-time v: no runtime-indexed register arrays
-                    if (!((outside >> v) & 1)) continue;
-                    const float wv = vx[v & 1] * vy[(v >> 1) & 1] * vz[v >> 2];
-                    const int X = X0 + (v & 1), Y = Y0 + ((v >> 1) & 1), Z = Z0 + (v >> 2);
-                    const long gi = ((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X;
-                    unsafeAtomicAdd(&F[gi].x, vre * wv);
-                    unsafeAtomicAdd(&F[gi].y, vim * wv);
-                    unsafeAtomicAdd(&T[gi], tval * wv);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // ---- flush and re-zero: consecutive threads walk the brick's fastest axis = the volume's x axis ----
-    if (tid == 0) sRe[kBrickCap - 1] = sIm[kBrickCap - 1] = sT[kBrickCap - 1] = 0;
-    for (int e = tid; e < g.total; e += kInsThreads) {
-        const int ire = sRe[e], iim = sIm[e], itt = sT[e];
-        if ((ire | iim | itt) == 0) continue;
-        sRe[e] = 0; sIm[e] = 0; sT[e] = 0;
-        if (DBG && (ta.debug & 2)) continue;
-        const float re = (float)ire * g.invF, im = (float)iim * g.invF, tt = (float)(unsigned)itt * g.invT;
-        int p_i, q_i, off;
-        if (AX == 0) { off = e % kTz; const int r = e / kTz; q_i = r / g.Wp; p_i = r - q_i * g.Wp; }
-        else { const int r = e / g.Wp; p_i = e - r * g.Wp; off = r % kTz; q_i = r / kTz; }
-        const int bp = p_i + g.pmin, bq = q_i + g.qmin;
-        const int ba = off + ((int)floorf(g.sp * (float)bp + g.sq * (float)bq) - M);
-        int X = pa == 0 ? bp : ba;
-        int Y = pa == 1 ? bp : (qa == 1 ? bq : ba);
-        int Z = qa == 2 ? bq : ba;
-        if (X < 0) { X = -1 - X; Y = -Y; Z = -Z; }
-        const long gi = ((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X;
-        unsafeAtomicAdd(&F[gi].x, re);
-        unsafeAtomicAdd(&F[gi].y, im);
-        unsafeAtomicAdd(&T[gi], tt);
-    }
-}
-
-// grid (tilesJ, nImg): one workgroup owns a strip of tiles of one image (all tiles of one 8-row band), so the per-draw
-// table is staged once per strip; per tile: pixel loads + bounds (sync) -> accumulate (sync) -> flush.
-template <bool DBG>
-__global__ __launch_bounds__(kInsThreads, 4) void k_insert_tiles(InsertTileArgs ta)
-{
-    const InsertArgs& a = ta.a;
-    extern __shared__ __attribute__((aligned(16))) int brick[];  // sRe | sIm | sT, kBrickCap fixed-point words each
-    int* sRe = brick;
-    int* sIm = brick + kBrickCap;
-    int* sT = brick + 2 * kBrickCap;
-    // LDS tables after the brick: group rotations | gStart | member shift ids | group info | shift slopes | tile ramps
-    double* sR = reinterpret_cast<double*>(brick + 3 * kBrickCap);          // [mReco][6]
-    int* sGStart = reinterpret_cast<int*>(sR + 6 * a.mReco);                // [mReco+1]
-    int* sMUid = sGStart + a.mReco + 1;                                      // [mReco]
-    int* sGInfo = sMUid + a.mReco;                                           // [mReco][2]
-    float* sSlope = reinterpret_cast<float*>(sGInfo + 2 * a.mReco);          // [mReco][2]
-    float2* sRamp = reinterpret_cast<float2*>(sSlope + 2 * a.mReco + ((a.mReco & 1) ? 0 : 1));  // 8-byte aligned, [kMaxU][64]
-    __shared__ int sMin[3], sMax[3], sAny, sCls;
-    __shared__ float sAmax[kInsWaves], sCmax[kInsWaves];
-
-    const int img = blockIdx.y, tj = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
-    const int P = a.P, half = a.idim / 2;
-    const size_t volSize = (size_t)P * P * (P / 2 + 1);
-    const int j0 = tj * kTB - half;
-    const double offx = a.offS ? a.offS[2 * img] : 0.0, offy = a.offS ? a.offS[2 * img + 1] : 0.0;
-
-    // ---- stage the insert plan of this image; insertDir (src/Reconstructor.cpp:407-422) once per image ----
-    const int* plan = ta.plan + (size_t)img * plan_stride(a.mReco);
-    const int G = plan[0], U = plan[1];
-    const int* pGStart = plan + 2;
-    const int* pOrd = pGStart + a.mReco + 1;
-    const int* pUid = pOrd + a.mReco;
-    const int* pGRep = pUid + a.mReco;
-    const int* pTRep = pGRep + a.mReco;
-    for (int gi_ = tid; gi_ < G; gi_ += kInsThreads) {
-        const int rep = pGRep[gi_];
-        const double* R = a.rotMat + ((size_t)img * a.mReco + rep) * 9;
-        double* d = sR + 6 * gi_;
-        d[0] = R[0]; d[1] = R[1]; d[2] = R[2]; d[3] = R[3]; d[4] = R[4]; d[5] = R[5];
-        sGInfo[2 * gi_] = a.cls ? a.cls[(size_t)img * a.mReco + rep] : 0;
-        sGInfo[2 * gi_ + 1] = rep;
-    }
-    for (int i = tid; i <= G; i += kInsThreads) sGStart[i] = pGStart[i];
-    for (int i = tid; i < a.mReco; i += kInsThreads) sMUid[i] = pUid[pOrd[i]];
-    for (int u = tid; u < U; u += kInsThreads) {
-        const size_t dm = (size_t)img * a.mReco + pTRep[u];
-        // translate(transImgP, orignImgP, -(tran - offset)(0), -(tran - offset)(1), ...), src/Optimiser.cpp:7160-7169
-        const double tx = a.trans[2 * dm] - offx, ty = a.trans[2 * dm + 1] - offy;
-        sSlope[2 * u] = (float)(-tx) / a.idim;
-        sSlope[2 * u + 1] = (float)(-ty) / a.idim;
-    }
-    if (tj == 0 && tid == 0 && a.O) {
-        double ox = 0, oy = 0, oz = 0;
-        for (int m = 0; m < a.mReco; m++) {
-            const size_t dm = (size_t)img * a.mReco + m;
-            const double* R = a.rotMat + dm * 9;
-            const double tx = a.trans[2 * dm] - offx, ty = a.trans[2 * dm + 1] - offy;
-            ox += -(R[0] * tx + R[3] * ty);
-            oy += -(R[1] * tx + R[4] * ty);
-            oz += -(R[2] * tx + R[5] * ty);
-        }
-        unsafeAtomicAdd(&a.O[0], ox);
-        unsafeAtomicAdd(&a.O[1], oy);
-        unsafeAtomicAdd(&a.O[2], oz);
-        if (a.counter) atomicAdd(a.counter, a.mReco);
-    }
-    for (int e = tid; e < kBrickCap; e += kInsThreads) { sRe[e] = 0; sIm[e] = 0; sT[e] = 0; }
-    if (tid < 3) { sMin[tid] = INT_MAX; sMax[tid] = INT_MIN; }
-    if (tid == 0) sAny = 0;
-    __syncthreads();
-
-    // ---- slab geometry from the first draw: dominant axis of the plane normal, column slopes ----
-    // (only the first two columns of R are staged; the normal is their cross product)
-    const double* R0 = sR;
-    const float n0 = (float)(R0[1] * R0[5] - R0[2] * R0[4]);
-    const float n1 = (float)(R0[2] * R0[3] - R0[0] * R0[5]);
-    const float n2 = (float)(R0[0] * R0[4] - R0[1] * R0[3]);
-    const float an0 = fabsf(n0), an1 = fabsf(n1), an2 = fabsf(n2);
-    const int ax = (an0 >= an1 && an0 >= an2) ? 0 : (an1 >= an2 ? 1 : 2);
-    const int pa = ax == 0 ? 1 : 0, qa = ax == 2 ? 1 : 2;
-    const float na = ax == 0 ? n0 : (ax == 1 ? n1 : n2);
-    TileGeom g;
-    g.sp = -(pa == 0 ? n0 : n1) / na;
-    g.sq = -(qa == 1 ? n1 : n2) / na;
-    const float wgt = a.w[img];
-    DrawTables dt;
-    dt.R = sR; dt.gStart = sGStart; dt.mUid = sMUid; dt.gInfo = sGInfo; dt.slope = sSlope; dt.ramp = sRamp; dt.G = G; dt.U = U;
-    // Fixed-point scales.  For one rotation the trilinear weights a voxel collects from all pixels sum to <= 1 (pixels are
-    // 2 voxels apart, the hat functions 1 voxel wide), so a voxel's T total is <= mReco * boundT and |F| total <= mReco *
-    // boundF; with a safety factor 2:  T (unsigned) scale 2^(32 - ceil(log2(2 mReco))), F (signed) one bit less.
-    int lg = 32 - __clz(2 * a.mReco - 1);
-    lg = lg > 20 ? 20 : lg;
-    const float qT = ldexpf(1.0f, 32 - lg), qF = ldexpf(1.0f, 31 - lg);
-
-    const int nPass = a.cls ? a.nK : 1;
-    for (int pass = 0; pass < nPass; pass++) {
-        if (a.cls) {  // does any draw of this image go to class `pass`?
-            __syncthreads();
-            if (tid == 0) sCls = 0;
-            __syncthreads();
-            for (int gi_ = tid; gi_ < G; gi_ += kInsThreads)
-                if (sGInfo[2 * gi_] == pass) sCls = 1;
-            __syncthreads();
-            if (!sCls) continue;
-        }
-        float2* F = a.F + (size_t)pass * volSize;
-        float* T = a.T + (size_t)pass * volSize;
-        for (int ti = 0; ti < ta.tilesI; ti++) {
-            __syncthreads();   // the shared bounds / flags were reset by the previous tile (also on its `continue` paths)
-            const int i0 = ti * kTB;
-            // this lane's pixel of the tile
-            const int pi = i0 + (lane & (kTB - 1)), pj = j0 + (lane >> 3);
-            int k = -1;
-            if (pi <= half && pj < half) k = ta.pixIndex[(pj + half) * (half + 1) + pi];
-            float2 dv = make_float2(0.f, 0.f);
-            float cf = 0.f;
-            if (k >= 0) {
-                dv = a.datP[(size_t)img * a.nPxl + k];
-                cf = a.ctfP[(size_t)img * a.nPxl + k];
-            }
-            // bounds for the fixed-point scale (see the header comment) and the footprint box of the tile corners
-            {
-                float am = wave_max(fabsf(dv.x) + fabsf(dv.y)), cm = wave_max(fabsf(cf));
-                if (lane == 0) { sAmax[grp] = am; sCmax[grp] = cm; }
-                if (k >= 0 && grp == 0) sAny = 1;
-            }
-            if (U <= kMaxU)   // per-pixel ramps of the unique shifts, shared by all groups of this tile
-                for (int u = grp; u < U; u += kInsWaves) sRamp[u * 64 + lane] = ramp_value(sSlope[2 * u], sSlope[2 * u + 1], pi, pj);
-            for (int t = tid; t < 4 * G; t += kInsThreads) {
-                const int m = t >> 2, c = t & 3;
-                const double* R = sR + 6 * m;
-                const int ci = (i0 + ((c & 1) ? kTB - 1 : 0)) * a.opf, cj = (j0 + ((c & 2) ? kTB - 1 : 0)) * a.opf;
-                const float x = (float)(R[0] * ci + R[3] * cj), y = (float)(R[1] * ci + R[4] * cj),
-                            z = (float)(R[2] * ci + R[5] * cj);
-                const int fx = (int)floorf(x), fy = (int)floorf(y), fz = (int)floorf(z);
-                atomicMin(&sMin[0], fx); atomicMax(&sMax[0], fx);
-                atomicMin(&sMin[1], fy); atomicMax(&sMax[1], fy);
-                atomicMin(&sMin[2], fz); atomicMax(&sMax[2], fz);
-            }
-            __syncthreads();
-            const bool any = sAny != 0;
-            float amax = 0.f, cmaxT = 0.f;
-#pragma unroll
-            for (int w = 0; w < kInsWaves; w++) { amax = fmaxf(amax, sAmax[w]); cmaxT = fmaxf(cmaxT, sCmax[w]); }
-            g.pmin = sMin[pa] - 1;
-            g.qmin = sMin[qa] - 1;
-            g.Wp = sMax[pa] + 1 - g.pmin + 1;
-            g.Wq = sMax[qa] + 1 - g.qmin + 1;
-            __syncthreads();   // everyone has read the shared bounds: reset them for the next tile
-            if (tid < 3) { sMin[tid] = INT_MAX; sMax[tid] = INT_MIN; }
-            if (tid == 0) sAny = 0;
-            const float cmax = a.cSearch ? 1.0f : cmaxT;
-            const float boundF = amax * cmax * fabsf(wgt), boundT = cmax * cmax * fabsf(wgt);
-            if (!any || (!(boundF > 0.f) && !(boundT > 0.f))) continue;
-            if (g.Wp < 0) g.Wp = 0;
-            if (g.Wq < 0) g.Wq = 0;
-            if (g.Wp * kTz > kBrickCap - 1) g.Wp = (kBrickCap - 1) / kTz;
-            if (g.Wp * g.Wq * kTz > kBrickCap - 1) g.Wq = (kBrickCap - 1) / (g.Wp * kTz);
-            g.total = g.Wp * g.Wq * kTz;
-            g.scaleF = boundF > 0.f ? qF / boundF : 0.f;
-            g.scaleT = boundT > 0.f ? qT / boundT : 0.f;
-            g.invF = boundF / qF;
-            g.invT = boundT / qT;
-            g.minQ = ta.minQuanta;
-            if (ax == 0) insert_tile_body<0, DBG>(ta, g, sRe, sIm, sT, dt, img, pass, k, pi, pj, dv, cf, wgt, F, T);
-            else if (ax == 1) insert_tile_body<1, DBG>(ta, g, sRe, sIm, sT, dt, img, pass, k, pi, pj, dv, cf, wgt, F, T);
-            else insert_tile_body<2, DBG>(ta, g, sRe, sIm, sT, dt, img, pass, k, pi, pj, dv, cf, wgt, F, T);
-            __syncthreads();   // brick re-zeroed before the next tile accumulates
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Insertion, volume-window form (robust to the spread of the draws).
 //
-// k_insert_tiles owns (image, 8x8-pixel tile) and needs every draw's copy of the tile inside one 63 KB brick: fine when
-// the draws are within a voxel or two of each other, but a particle filter's draws are ~1 degree apart (4-16 voxels at
-// radius 250), most terms then leave the brick and take the 16x slower global-atomic path.  Here the brick is a fixed
-// WINDOW of the volume instead -- kWd x kWd voxels across, kWz thick along the sheared dominant axis of the image's
+// A particle filter's draws are ~1 degree apart (4-16 voxels at radius 250), so the brick cannot follow a tile of image
+// pixels: it is a fixed WINDOW of the volume -- kWd x kWd voxels across, kWz thick along the sheared dominant axis of the image's
 // reference plane -- and a workgroup owns (image, row of windows): for every window and slab it visits every group of
 // draws, enumerates the pixels whose trilinear cell can reach the window (inverse 2x2 map of the window corners: the
 // candidates), accumulates the terms that fall INSIDE into the LDS brick (fixed point, as above) and skips the rest --
@@ -573,6 +236,11 @@ constexpr int kIPix = THX_KIPIX;            // per-window tabulated pixel range 
 #ifndef THX_KWINTHREADS
 #define THX_KWINTHREADS 512
 #endif
+#ifdef THX_PROFILING   // THX_INSERT_DEBUG bits (skip LDS adds / flush / group loop) exist only in profiling builds
+constexpr bool kWinProfiling = true;
+#else
+constexpr bool kWinProfiling = false;
+#endif
 constexpr int kWinThreads = THX_KWINTHREADS; // 2 workgroups per CU (LDS): 512 threads = 4 waves per SIMD at <= 128 VGPRs
 
 struct InsertWinArgs {
@@ -584,7 +252,7 @@ struct InsertWinArgs {
     int nW;                 // windows per side; window w covers [pOrg + w kWd, pOrg + (w+1) kWd)
     int pOrg;
     float rMax2;            // (largest sample radius + 2)^2, voxels
-    int debug;              // THX_INSERT_DEBUG (profiling only): 1 skip LDS adds, 2 skip flush, 4 skip the group loop
+    int debug;              // builds with -DTHX_PROFILING only (THX_INSERT_DEBUG): 1 skip LDS adds, 2 skip flush, 4 skip the group loop
 };
 
 __global__ __launch_bounds__(256) void k_insert_bounds(float2* __restrict__ bounds, const float2* __restrict__ datP,
@@ -641,6 +309,58 @@ __device__ __forceinline__ void insert_tiny_term(float2* F, float* T, int P, int
     unsafeAtomicAdd(&F[gi].x, re);
     unsafeAtomicAdd(&F[gi].y, im);
     unsafeAtomicAdd(&T[gi], tt);
+}
+
+// A group whose plane is far from the image's reference plane (|normal component along the shear axis| < kFarGroup, i.e.
+// more than ~18 degrees away: a draw from another posterior mode): the sheared-window geometry degenerates for it (slopes
+// -n/gna unbounded), so the whole workgroup adds it with plain float atomics -- the arithmetic of k_insert for the group's
+// summed ramps.  Rare by construction; correctness never depends on how the draws are spread.
+constexpr float kFarGroup = 0.3f;
+
+struct DrawTables;
+struct InsertWinArgs;
+__device__ __attribute__((noinline)) void insert_far_group(const InsertWinArgs& wa, const DrawTables& dt, int img, int gi_, float wgt);
+
+__device__ __attribute__((noinline)) void insert_far_group(const InsertWinArgs& wa, const DrawTables& dt, int img, int gi_, float wgt)
+{
+    const InsertArgs& a = wa.a;
+    const int P = a.P;
+    const size_t volSize = (size_t)P * P * (P / 2 + 1);
+    const double* R = dt.R + 6 * gi_;
+    const int m0 = dt.gStart[gi_], m1 = dt.gStart[gi_ + 1];
+    const float nmem = (float)(m1 - m0);
+    float2* F = a.F + (size_t)dt.gInfo[2 * gi_] * volSize;
+    float* T = a.T + (size_t)dt.gInfo[2 * gi_] * volSize;
+    for (int p = threadIdx.x; p < a.nPxl; p += blockDim.x) {
+        const int pi = a.iCol[p], pj = a.iRow[p];
+        const float2 dv = a.datP[(size_t)img * a.nPxl + p];
+        float cf = a.ctfP[(size_t)img * a.nPxl + p];
+        const float2 S = insert_ramp_sum_slow(dt.slope, dt.mUid, m0, m1, pi, pj);
+        const float2 tv = cmul(dv, S);
+        if (a.cSearch) cf = insert_ctf_search(a.attr, a.dfac, img, a.mReco, dt.gInfo[2 * gi_ + 1], a.pixelSize, a.idim, pi, pj);
+        float vre = tv.x * cf, vim = tv.y * cf;
+        vre = vre * 1.0f; vim = vim * 1.0f;
+        vre = vre * wgt; vim = vim * wgt;
+        const float tval = (pow2f_(cf) * 1.0f * wgt) * nmem;
+        const int icp = pi * a.opf, irp = pj * a.opf;
+        const float x = (float)(R[0] * icp + R[3] * irp), y = (float)(R[1] * icp + R[4] * irp), z = (float)(R[2] * icp + R[5] * irp);
+        if (!coord_in_grid(x, y, z, P)) continue;
+        TriCell cell;
+        tri_cell(cell, x, y, z, P);
+        if (cell.conj) vim = -vim;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                for (int ii = 0; ii < 2; ii++) {
+                    const float wv = cell.w[kk * 4 + jj * 2 + ii];
+                    const long idx = cell.rowOff[kk][jj] + ii;
+                    unsafeAtomicAdd(&F[idx].x, vre * wv);
+                    unsafeAtomicAdd(&F[idx].y, vim * wv);
+                    unsafeAtomicAdd(&T[idx], tval * wv);
+                }
+    }
 }
 
 // accumulate group gi_'s candidates of this window/slab (one wave), AX = dominant axis of the reference plane
@@ -768,12 +488,12 @@ __device__ __forceinline__ void win_process(const InsertWinArgs& wa, const WinGe
         const float tq = tvalS * wv;
         if (tq >= g.minQ) {
             const int idx = AX == 0 ? ((w.qI[dq] * kWd + w.pI[dp]) * kWz + off) : ((w.qI[dq] * kWz + off) * kWd + w.pI[dp]);
-            if (wa.debug & 1) { if (idx < 0) sRe[0] = 1; continue; }
+            if (kWinProfiling && (wa.debug & 1)) { if (idx < 0) sRe[0] = 1; continue; }
             atomicAdd(&sRe[idx], __float2int_rn(vreS * wv));
             atomicAdd(&sIm[idx], __float2int_rn(vimS * wv));
             atomicAdd(reinterpret_cast<unsigned*>(&sT[idx]), __float2uint_rn(tq));
         } else {
-            // tiny term (see k_insert_tiles): F and T travel together as floats
+            // tiny term: F and T travel together as floats
             insert_tiny_term(F, T, P, w.X0 + ii, w.Y0 + jj, w.Z0 + kk, vre * wv, vim * wv, tval * wv);
         }
     }
@@ -956,7 +676,7 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
     g.sq = -(qa == 1 ? n1 : n2) / na;
     const float wgt = a.w[img];
     DrawTables dt;
-    dt.R = sR; dt.gStart = sGStart; dt.mUid = sMUid; dt.gInfo = sGInfo; dt.slope = sSlope; dt.ramp = nullptr; dt.G = G; dt.U = U;
+    dt.R = sR; dt.gStart = sGStart; dt.mUid = sMUid; dt.gInfo = sGInfo; dt.slope = sSlope; dt.G = G; dt.U = U;
     int lg = 32 - __clz(2 * a.mReco - 1);
     lg = lg > 20 ? 20 : lg;
     const float qT = ldexpf(1.0f, 32 - lg), qF = ldexpf(1.0f, 31 - lg);
@@ -971,6 +691,14 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
     g.minQ = wa.minQuanta;
     g.q0 = wa.pOrg + wqI * kWd;
     g.pix = sPix; g.ecol = sEc; g.erow = sEr;
+    const float wBound = sqrtf(wa.rMax2) * (1.0f + fabsf(g.sp) + fabsf(g.sq)) + 4.0f;
+    if (wqI == 0) {   // groups far from the reference plane (another posterior mode): plain atomics, once per image
+        for (int gi_ = 0; gi_ < G; gi_++) {
+            const double* R = sR + 6 * gi_;
+            const float gna = (float)(ax == 0 ? R[1] * R[5] - R[2] * R[4] : (ax == 1 ? R[2] * R[3] - R[0] * R[5] : R[0] * R[4] - R[1] * R[3]));
+            if (fabsf(gna) < kFarGroup) insert_far_group(wa, dt, img, gi_, wgt);
+        }
+    }
 
     const int nPass = a.cls ? a.nK : 1;
     for (int pass = 0; pass < nPass; pass++) {
@@ -1005,12 +733,12 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
                 short* box = sBox + 4 * gi_;
                 box[1] = 0;
                 if (a.cls && sGInfo[2 * gi_] != pass) continue;
-                // (p, q) = opf * A (i, j),  A = rows pa, qa of the first two columns of R
+                // (p, q) = opf * A (i, j),  A = rows pa, qa of the first two columns of R; det = +-(the normal's component
+                // along the shear axis): groups with |det| < kFarGroup are handled by insert_far_group
                 const float A00 = (float)R[pa], A01 = (float)R[3 + pa], A10 = (float)R[qa], A11 = (float)R[3 + qa];
                 const float det = A00 * A11 - A01 * A10;
-                if (fabsf(det) < 0.05f) {   // plane nearly parallel to the shear axis (cannot happen within a few degrees of R0)
-                    box[0] = 0; box[1] = (short)(half + 1); box[2] = (short)(-half); box[3] = (short)(2 * half);
-                } else {
+                if (fabsf(det) < 0.5f * kFarGroup) continue;
+                {
                     const float s = 1.0f / (det * (float)a.opf);
                     float imin = 1e30f, imax = -1e30f, jmin = 1e30f, jmax = -1e30f;
 #pragma unroll
@@ -1030,6 +758,10 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
                 const float gn0 = (float)(R[1] * R[5] - R[2] * R[4]), gn1 = (float)(R[2] * R[3] - R[0] * R[5]),
                             gn2 = (float)(R[0] * R[4] - R[1] * R[3]);
                 const float gna = ax == 0 ? gn0 : (ax == 1 ? gn1 : gn2);
+                // A draw from a far-away posterior mode can be (nearly) parallel to the shear axis: its slopes -n/gna blow up
+                // (gna -> 0; NaN at 0) and its candidate box is the whole image.  Such groups never enter the window walk:
+                // insert_far_group adds them with plain atomics, once per image.
+                if (fabsf(gna) < kFarGroup) { box[1] = 0; continue; }
                 const float gsp = -(pa == 0 ? gn0 : gn1) / gna, gsq = -(qa == 1 ? gn1 : gn2) / gna;
                 float wmin = 1e30f, wmax = -1e30f;
 #pragma unroll
@@ -1038,6 +770,9 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
                     const float wv = (gsp - g.sp) * pc + (gsq - g.sq) * qc;
                     wmin = fminf(wmin, wv); wmax = fmaxf(wmax, wv);
                 }
+                // every sample satisfies |a - sp p - sq q| <= rMax (1 + |sp| + |sq|): slabs beyond that hold nothing
+                wmin = fmaxf(wmin, -wBound); wmax = fminf(wmax, wBound);
+                if (wmin > wmax) { box[1] = 0; continue; }
                 sWr[2 * gi_] = wmin - 3.0f;
                 sWr[2 * gi_ + 1] = wmax + 3.0f;
                 lWlo = min(lWlo, (int)floorf(wmin - 3.0f));
@@ -1098,7 +833,7 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
                     gi_ = __builtin_amdgcn_readfirstlane(gi_);
                     if (gi_ >= G) break;
                     const short* box = sBox + 4 * gi_;
-                    if (box[1] == 0 || (wa.debug & 4)) continue;
+                    if (box[1] == 0 || (kWinProfiling && (wa.debug & 4))) continue;
                     if (sWr[2 * gi_ + 1] < (float)g.w0 || sWr[2 * gi_] > (float)(g.w0 + kWz)) continue;
                     if (ax == 0) win_enqueue<0>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T, sQueue + kWinQueue * grp, qn);
                     else if (ax == 1) win_enqueue<1>(wa, g, sRe, sIm, sT, dt, img, gi_, box[0], box[1], box[2], box[3], wgt, F, T, sQueue + kWinQueue * grp, qn);
@@ -1109,7 +844,7 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
                 else win_drain<2>(wa, g, sRe, sIm, sT, dt, img, wgt, F, T, sQueue + kWinQueue * grp, qn);
                 lds_barrier();
                 if (tid == 0) sNext = 0;   // nobody draws between this barrier and the one after the flush
-                if (wa.debug & 2) { lds_barrier(); continue; }
+                if (kWinProfiling && (wa.debug & 2)) { lds_barrier(); continue; }
                 if (ax == 0) insert_win_flush<0>(a, g, sRe, sIm, sT, F, T);
                 else if (ax == 1) insert_win_flush<1>(a, g, sRe, sIm, sT, F, T);
                 else insert_win_flush<2>(a, g, sRe, sIm, sT, F, T);
@@ -1215,17 +950,7 @@ __global__ __launch_bounds__(256) void k_symmetrize(float* __restrict__ dst, con
 
 using namespace thx;
 
-static unsigned long long* g_insert_stats = nullptr;  // profiling only (THX_INSERT_DEBUG & 8)
-
 extern "C" {
-
-// profiling aid, not part of the public ABI: in-brick / fallback voxel-add counts of the last tiled insert launch
-int thx_debug_insert_stats(unsigned long long* out2)
-{
-    if (!g_insert_stats) { out2[0] = out2[1] = 0; return 0; }
-    THX_CHECK(hipMemcpy(out2, g_insert_stats, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    return 0;
-}
 
 int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK, const float* datP,
                    const float* ctfP, const float* w, const double* rotMat, const double* trans, const double* offS,
@@ -1240,22 +965,15 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
     a.datP = reinterpret_cast<const float2*>(datP); a.ctfP = ctfP; a.w = w; a.rotMat = rotMat; a.trans = trans;
     a.offS = offS; a.cls = cls; a.attr = attr; a.dfac = dfac; a.cSearch = cSearch; a.pixelSize = pixelSize;
     a.iCol = iCol; a.iRow = iRow; a.opf = opf; a.nPxl = nPxl; a.mReco = mReco; a.idim = idim;
-    const char* plain = getenv("THX_INSERT_PLAIN");
-    // THX_INSERT_KERNEL: "win" (default) = volume-window kernel, robust to the spread of the draws; "tiles" = pixel-tile
-    // kernel, ~25 % faster when all draws of an image lie within ~0.3 degrees, 5x slower at 1 degree
-    const char* kern = getenv("THX_INSERT_KERNEL");
-    const bool win = !(kern && kern[0] == 't') && !(plain && plain[0] == '1');
-    const bool tiles = !(plain && plain[0] == '1');
+    // THX_INSERT_PLAIN=1 (read once at load, thx::knobs): the plain float-atomic form k_insert for A/B runs
+    const bool win = !knobs().insertPlain;
     hipStream_t st = as_stream(stream);
     int* pixIndex = nullptr;
     int* plan = nullptr;
     const int half = idim / 2;
-    const int tilesI = (half + 1 + kTB - 1) / kTB, tilesJ = (idim + kTB - 1) / kTB;
-    const size_t ldsBytes = 3 * (size_t)kBrickCap * sizeof(int) + (size_t)mReco * 6 * sizeof(double) +
-                            ((size_t)(mReco + 1) + mReco + 2 * mReco) * sizeof(int) + (2 * (size_t)mReco + 2) * sizeof(float) +
-                            (size_t)kMaxU * 64 * sizeof(float2) + 16;
-    THX_REQUIRE(!tiles || ldsBytes <= 160 * 1024, "mReco too large for the LDS draw table");
-    if (tiles) {
+    float2* bounds = nullptr;
+    size_t ldsWin = 0;
+    if (win) {
         const size_t tb = (size_t)idim * (half + 1) * sizeof(int);
         pixIndex = reinterpret_cast<int*>(scratch(st, 0, tb));
         THX_REQUIRE(pixIndex, "device scratch allocation failed");
@@ -1265,14 +983,6 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
         THX_REQUIRE(plan, "device scratch allocation failed");
         hipLaunchKernelGGL(k_insert_plan, dim3(nImg), dim3(128), 5 * (size_t)mReco * sizeof(int), st, plan, rotMat, trans, cls, dfac,
                            cSearch, mReco);
-        THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_insert_tiles<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
-        THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_insert_tiles<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
-    }
-    float2* bounds = nullptr;
-    size_t ldsWin = 0;
-    if (win) {
         bounds = reinterpret_cast<float2*>(scratch(st, 6, (size_t)nImg * sizeof(float2)));
         THX_REQUIRE(bounds, "device scratch allocation failed");
         hipLaunchKernelGGL(k_insert_bounds, dim3(nImg), dim3(256), 0, st, bounds, a.datP, a.ctfP, nPxl);
@@ -1298,34 +1008,14 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
         if (win) {
             InsertWinArgs wa;
             wa.a = b; wa.pixIndex = pixIndex; wa.plan = plan + (size_t)l0 * plan_stride(mReco); wa.bounds = bounds + l0;
-            const char* mq = getenv("THX_MIN_QUANTA");
-            wa.minQuanta = mq ? (float)atof(mq) : kMinQuanta;
+            wa.minQuanta = knobs().minQuanta >= 0.f ? knobs().minQuanta : kMinQuanta;
             const int rc = half * opf + 3;
             const int hw = (rc + kWd - 1) / kWd;
             wa.nW = 2 * hw;
             wa.pOrg = -hw * kWd;
             wa.rMax2 = (float)(half * opf + 2) * (float)(half * opf + 2);
-            const char* dbgw = getenv("THX_INSERT_DEBUG");
-            wa.debug = dbgw ? atoi(dbgw) : 0;
+            wa.debug = kWinProfiling ? knobs().insertDebug : 0;
             hipLaunchKernelGGL(k_insert_win, dim3(wa.nW, nl), dim3(kWinThreads), ldsWin, st, wa);
-        } else if (tiles) {
-            InsertTileArgs ta;
-            ta.a = b; ta.pixIndex = pixIndex; ta.tilesI = tilesI;
-            ta.plan = plan + (size_t)l0 * plan_stride(mReco);
-            const char* mq = getenv("THX_MIN_QUANTA");   // profiling knob
-            ta.minQuanta = mq ? (float)atof(mq) : kMinQuanta;
-            const char* dbg = getenv("THX_INSERT_DEBUG");
-            ta.debug = dbg ? atoi(dbg) : 0;
-            ta.stats = nullptr;
-            if (ta.debug & 8) {
-                if (!g_insert_stats) THX_CHECK(hipMalloc(reinterpret_cast<void**>(&g_insert_stats), 2 * sizeof(unsigned long long)));
-                THX_CHECK(hipMemsetAsync(g_insert_stats, 0, 2 * sizeof(unsigned long long), st));
-                ta.stats = g_insert_stats;
-            }
-            if (ta.debug)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_insert_tiles<true>), dim3(tilesJ, nl), dim3(kInsThreads), ldsBytes, st, ta);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_insert_tiles<false>), dim3(tilesJ, nl), dim3(kInsThreads), ldsBytes, st, ta);
         } else {
             hipLaunchKernelGGL(k_insert, dim3((nPxl + 255) / 256, nl), dim3(256), 0, st, b);
         }

@@ -59,14 +59,15 @@ static int cached_mask(const float** out, int idim, float r, float ew)
 }
 
 // batched in-place 2-D real plans on the padded layout: real rows of 2*(idim/2+1) floats overlay the complex rows
-static int cached_plan2d(hipfftHandle* out, int idim, int batch, hipfftType type)
+// (one plan per (device, stream, shape): a hipFFT plan carries its stream and work area)
+static int cached_plan2d(hipfftHandle* out, int idim, int batch, hipfftType type, hipStream_t st)
 {
     static std::mutex mtx;
-    static std::map<std::tuple<int, int, int, int>, hipfftHandle> cache;
+    static std::map<std::tuple<int, hipStream_t, int, int, int>, hipfftHandle> cache;
     int dev = 0;
     THX_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> g(mtx);
-    auto key = std::make_tuple(dev, idim, batch, (int)type);
+    auto key = std::make_tuple(dev, st, idim, batch, (int)type);
     auto it = cache.find(key);
     if (it == cache.end()) {
         hipfftHandle p;
@@ -77,6 +78,7 @@ static int cached_plan2d(hipfftHandle* out, int idim, int batch, hipfftType type
             THX_FFT_CHECK2(hipfftPlanMany(&p, 2, n, cEmbed, 1, idim * nc, rEmbed, 1, idim * 2 * nc, type, batch));
         else
             THX_FFT_CHECK2(hipfftPlanMany(&p, 2, n, rEmbed, 1, idim * 2 * nc, cEmbed, 1, idim * nc, type, batch));
+        THX_FFT_CHECK2(hipfftSetStream(p, st));
         it = cache.emplace(key, p).first;
     }
     *out = it->second;
@@ -324,14 +326,12 @@ int thx_remask_dev(float* imgFT, int nImg, int idim, float maskRadiusPx, float e
         const int nb = nImg - b < kBatch ? nImg - b : kBatch;
         float* p = imgFT + (size_t)b * imgSize;
         hipfftHandle c2r, r2c;
-        if ((rc = cached_plan2d(&c2r, idim, nb, HIPFFT_C2R))) return rc;
-        if ((rc = cached_plan2d(&r2c, idim, nb, HIPFFT_R2C))) return rc;
-        THX_FFT_CHECK2(hipfftSetStream(c2r, st));
+        if ((rc = cached_plan2d(&c2r, idim, nb, HIPFFT_C2R, st))) return rc;
+        if ((rc = cached_plan2d(&r2c, idim, nb, HIPFFT_R2C, st))) return rc;
         THX_FFT_CHECK2(hipfftExecC2R(c2r, reinterpret_cast<hipfftComplex*>(p), p));
         hipLaunchKernelGGL(k_scale_mask, dim3(idim, nb), dim3(128), 0, st, p, mask, idim, 2 * nc,
                            1.0 / ((double)idim * idim));
         THX_LAUNCH_CHECK();
-        THX_FFT_CHECK2(hipfftSetStream(r2c, st));
         THX_FFT_CHECK2(hipfftExecR2C(r2c, p, reinterpret_cast<hipfftComplex*>(p)));
     }
     return 0;

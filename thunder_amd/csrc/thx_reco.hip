@@ -6,6 +6,7 @@
 #include <math.h>
 
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -527,7 +528,7 @@ static int balance_W_hand(thx_reco* r, const float* T, int maxRadius, int maxIte
         diffCPrev = diffC;
         memcpy(&diffC, &bits, sizeof(float));
         iters = m + 1;
-        if (getenv("THX_RECO_TRACE")) fprintf(stderr, "hand round %d diffC %g\n", m, diffC);
+        if (knobs().recoTrace) fprintf(stderr, "hand round %d diffC %g\n", m, diffC);
         if ((double)diffC > (double)diffCPrev * 0.95) nNoDec += 1; else nNoDec = 0;   // as balance_W below
         if (((double)diffC < 1e-2) || ((m >= minIter) && (nNoDec == 2))) break;
     }
@@ -550,8 +551,8 @@ static int balance_W(thx_reco* r, const float* T, int maxRadius, int maxIter, in
     const long np = (long)r->N * pf;
     const bool pow2 = ((np & (np - 1)) == 0) && ((PF & (PF - 1)) == 0);
     {
-        const char* fv = getenv("THX_FFT");   // "rocfft": library transforms for every size (A/B and fallback)
-        if (r->handNS && pow2 && !(fv && fv[0] == 'r')) {
+        // THX_FFT=rocfft (read once at load): library transforms for every size (A/B and fallback)
+        if (r->handNS && pow2 && !knobs().fftRocfft) {
 #define THX_HAND(ns, rr) return balance_W_hand<ns, rr>(r, T, maxRadius, maxIter, minIter, itersOut, diffCOut, st)
             switch (PF) {
                 case 64: THX_HAND(2, 1);
@@ -584,7 +585,7 @@ static int balance_W(thx_reco* r, const float* T, int maxRadius, int maxIter, in
         diffCPrev = diffC;
         memcpy(&diffC, &bits, sizeof(float));
         iters = m + 1;
-        if (getenv("THX_RECO_TRACE")) fprintf(stderr, "rocfft round %d diffC %g\n", m, diffC);
+        if (knobs().recoTrace) fprintf(stderr, "rocfft round %d diffC %g\n", m, diffC);
         // src/Reconstructor.cpp:1542-1550 (DIFF_C_DECREASE_THRES 0.95, DIFF_C_THRES 1e-2, N_DIFF_C_NO_DECREASE 2); the
         // comparisons run in double against RFLOAT operands as in the reference
         if ((double)diffC > (double)diffCPrev * 0.95) nNoDec += 1; else nNoDec = 0;
@@ -646,18 +647,22 @@ int thx_reco_set_projectee_dev(thx_reco* r, const float* refRL, float* volume, v
     return 0;
 }
 
-// FFT plans of the small N^3 transforms are cached per (size, direction): plan creation costs far more than the
-// transform (the reference's FFT::fw re-plans every call with FFTW_ESTIMATE, src/FFT.cpp:176-199)
-static int cached_plan(hipfftHandle* out, int n, hipfftType type)
+// FFT plans of the small N^3 transforms are cached per (device, stream, size, direction): plan creation costs far more
+// than the transform (the reference's FFT::fw re-plans every call with FFTW_ESTIMATE, src/FFT.cpp:176-199).  One plan per
+// stream: a hipFFT plan carries its stream and work area, so two host threads on two streams must not share one.
+static int cached_plan(hipfftHandle* out, int n, hipfftType type, hipStream_t st)
 {
     static std::mutex mtx;
-    static std::map<std::pair<int, int>, hipfftHandle> cache;
+    static std::map<std::tuple<int, hipStream_t, int, int>, hipfftHandle> cache;
+    int dev = 0;
+    THX_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> g(mtx);
-    auto key = std::make_pair(n, (int)type);
+    auto key = std::make_tuple(dev, st, n, (int)type);
     auto it = cache.find(key);
     if (it == cache.end()) {
         hipfftHandle p;
         THX_FFT_CHECK(hipfftPlan3d(&p, n, n, n, type));
+        THX_FFT_CHECK(hipfftSetStream(p, st));
         it = cache.emplace(key, p).first;
     }
     *out = it->second;
@@ -668,9 +673,8 @@ int thx_fft3d_fw_dev(const float* rl, float* ft, int n, void* stream)
 {
     THX_REQUIRE(rl && ft, "NULL pointer");
     hipfftHandle p;
-    int rc = cached_plan(&p, n, HIPFFT_R2C);
+    int rc = cached_plan(&p, n, HIPFFT_R2C, as_stream(stream));
     if (rc) return rc;
-    THX_FFT_CHECK(hipfftSetStream(p, as_stream(stream)));
     THX_FFT_CHECK(hipfftExecR2C(p, const_cast<float*>(rl), reinterpret_cast<hipfftComplex*>(ft)));
     return 0;
 }
@@ -679,9 +683,8 @@ int thx_fft3d_bw_dev(float* ft, float* rl, int n, void* stream)
 {
     THX_REQUIRE(rl && ft, "NULL pointer");
     hipfftHandle p;
-    int rc = cached_plan(&p, n, HIPFFT_C2R);
+    int rc = cached_plan(&p, n, HIPFFT_C2R, as_stream(stream));
     if (rc) return rc;
-    THX_FFT_CHECK(hipfftSetStream(p, as_stream(stream)));
     THX_FFT_CHECK(hipfftExecC2R(p, reinterpret_cast<hipfftComplex*>(ft), rl));
     hipLaunchKernelGGL(k_scale_rl, dim3(nblk((size_t)n * n * n)), dim3(256), 0, as_stream(stream), rl, (size_t)n * n * n);
     THX_LAUNCH_CHECK();

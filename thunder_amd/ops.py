@@ -142,9 +142,10 @@ def pack_projector(volumes, vdim):
 
 
 def expect_local(volumes, vdim, pf, idim, iCol, iRow, datP, ctfP, sigRcpP, rotMat, trans, nD=1, volIdx=None, pC=None,
-                 pR=None, pT=None, pD=None, want_logW=False, workspace=None, packed=False):
+                 pR=None, pT=None, pD=None, want_logW=False, workspace=None, packed=False, wg_per_cu=-1):
     """One particle-filter phase for a batch of images (src/Optimiser.cpp:1225-1406); see thunder_amd.h.
-    packed=True: `volumes` is the output of pack_projector."""
+    packed=True: `volumes` is the output of pack_projector.  wg_per_cu: occupancy argument of the C ABI (0 = unlimited,
+    negative = library default)."""
     dev = datP.device
     _chk(volumes, _F32 if packed else _C64, "volumes"); _chk(datP, _C64, "datP"); _chk(ctfP, _F32, "ctfP"); _chk(sigRcpP, _F32, "sigRcpP")
     _chk(rotMat, _F64, "rotMat"); _chk(trans, _F64, "trans")
@@ -171,7 +172,7 @@ def expect_local(volumes, vdim, pf, idim, iCol, iRow, datP, ctfP, sigRcpP, rotMa
     capi.call("thx_expect_local_packed_dev" if packed else "thx_expect_local_dev", ptr(volumes), ptr(volIdx), vdim, pf, idim, ptr(iCol), ptr(iRow), nPxl, nImg,
               ptr(datP), ptr(ctfP), ptr(sigRcpP), ptr(rotMat), nR, ptr(trans), nT, nD, ptr(pC), ptr(pR), ptr(pT),
               ptr(pD), ptr(res.wC), ptr(res.wR), ptr(res.wT), ptr(res.wD), ptr(res.baseLine), ptr(res.logW),
-              ptr(workspace), stream_ptr())
+              ptr(workspace), int(wg_per_cu), stream_ptr())
     return res
 
 

@@ -204,8 +204,7 @@ class RefineShard:
         self.use_pf = particle_filter
         # clouds of a particle filter: 2 workgroups of the local-search kernel per CU; tightly clustered fixed support
         # points: no cap (see thx_expect_local_set_occupancy)
-        from . import capi as _capi
-        _capi.call("thx_expect_local_set_occupancy", 2 if particle_filter else 0)
+        self.wg_per_cu = 2 if particle_filter else 0
         self.pf_seed, self.pf_call = seed + 104729 * rank, 0
         self.transS, self.transQ = transS, 0.05                       # TRANS_Q, include/Optimiser.h:67
         self.pfL, self.pfS, self.peakFactorR = 2.0, 0.5, 1e-3         # script/demo_3D.json:71-73, PEAK_FACTOR_MIN
@@ -335,7 +334,7 @@ class RefineShard:
                     e0.record()
                 r = ops.expect_local(self.cells[vi:vi + 1] if self.use_packed else vol, self.P, self.pf, self.N, self.iCol,
                                      self.iRow, self.datP[b0:b1], self.ctfP[b0:b1], self.sigRcpP[b0:b1], rotB, tranB, nD=1,
-                                     pR=pR, pT=pT, workspace=self.ws[vi], packed=self.use_packed)
+                                     pR=pR, pT=pT, workspace=self.ws[vi], packed=self.use_packed, wg_per_cu=self.wg_per_cu)
                 if timed:
                     e1.record()
                     self.expect_ms.append((e0, e1, b1 - b0))

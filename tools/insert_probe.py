@@ -25,4 +25,4 @@ for dbg in [int(x) for x in os.environ.get("DBGS", "8,0,1,2,3,4").split(",")]:
         msg += "  in-brick adds %d fallback adds %d (%.2f%%)" % (out[0], out[1], 100.0 * out[1] / max(1, out[0] + out[1]))
     print(msg)
 os.environ["THX_INSERT_DEBUG"] = "0"
-os.environ["THX_INSERT_PLAIN"] = "1"
+os.environ["THX_INSERT_PLAIN"] = "1"  # set before the library is loaded (read once)
