@@ -1,11 +1,15 @@
 #!/usr/bin/env python
 """bench.py -- particles/sec of one refinement iteration of the E/M hot path on N MI355X GPUs.
 
-One "step" = one full iteration over the rank's HBM-resident shard of synthetic particles:
-  row gathers from the masked image stack, nPhase particle-filter phases (mLR rotations x mLT shifts each), sigma
-  update, mReco insertions per particle, half-set reduce (RCCL when N > 2), prepareTF, reconstruct (MAP off) -> FSC ->
-  reconstruct (MAP on), projector refresh, re-centring and re-masking (rocFFT 2-D) of the particle images.
-Workload = BASELINE.json configs[1] ("10k synthetic 256^3 particles, 3D refinement, 1xMI355X") per GPU, weak scaling.
+One "step" = one full iteration over the HBM-resident synthetic particles:
+  row gathers from the masked image stack, nPhase particle-filter phases (mLR rotations x mLT shifts each, perturb /
+  resample on the device), sigma update, mReco insertions per particle, half-set reduce (RCCL when a half spans more
+  than one rank), prepareTF, reconstruct (MAP off) -> FSC -> reconstruct (MAP on), projector refresh, re-centring and
+  re-masking (rocFFT 2-D) of the particle images.
+Workload = the configuration BASELINE.json's metric is quoted on: 100 000 synthetic 256^3 particles, 3-D refinement.
+It fits one GPU (about 125 GB of particle data + 15 GB of volumes in 288 GB), so N = 1 runs all of it; with N > 1 the same
+100 000 particles are sharded over the ranks (N = 8 is BASELINE configs[2]: 12 500 per GPU) -- total work fixed:
+"scaling": "strong".  `--particles 10000` gives configs[1].
 Launch: `python bench.py` (N=1) or
   `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`
 Prints ONE JSON line on rank 0.
@@ -24,17 +28,37 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 INSERT_BYTES_PER_PIXEL_SAMPLE = 204  # 12 B in + F 8x8 Bx(R+W) + T 8x4 Bx(R+W)
 EXPECT_BYTES_PER_PIXEL_SAMPLE = 64   # 8 neighbours x 8 B
+EXPECT_BYTES_PER_PIXEL = 16          # dat 8 + ctf 4 + sigRcp 4, read once per image-phase
 
 
-def cpu_baseline(args, shard):
-    """oracle (`kind: port`) on a bounded sample of the SAME workload, all host cores (OpenMP over images)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, shard, rounds_per_iteration):
+    """oracle (`kind: port`) on a bounded sample of the SAME workload, all host cores.
+    E-step + insertion: `n` particles of the shard through the oracle's OpenMP loop over images (one image per thread at
+    a time, F / T shared under `omp atomic` -- the reference's own structure, src/Optimiser.cpp:1162,7038).
+    Reconstruct leg: the oracle's gridding reconstruction at the full 512^3 grid is timed for 1 and for 3 balancing rounds
+    (scipy pocketfft on all cores + the oracle's C sweeps); fixed cost and cost per round follow by difference and are
+    scaled to the 4 reconstructions and the number of balancing rounds the GPU iteration actually ran."""
     from oracle import oracle as O
+    import scipy.fft as sfft
     import torch
     cores = os.cpu_count() or 1
     n = min(shard.nImg, max(4, int(args.cpu_particles) if args.cpu_particles else cores))
     pl = O.pixel_list(shard.N, shard.rU, 2, shard.pf)
     assert pl["nPxl"] == shard.nPxl
-    shard.reset_reference()
+    order = shard.e_order
+    if order is not None:   # the shard's E-step rows are in pixel-visit order
+        for k in ("iCol", "iRow", "iPxl", "iSig", "iColPad", "iRowPad"):
+            pl[k] = np.ascontiguousarray(pl[k][order])
     vol = shard.vols[0].cpu().numpy()
     dat = shard.datP[:n].cpu().numpy()
     ctf = shard.ctfP[:n].cpu().numpy()
@@ -52,16 +76,40 @@ def cpu_baseline(args, shard):
     iT = rng.integers(0, shard.mLT, size=(n, shard.mReco))
     recoRot = np.ascontiguousarray(np.take_along_axis(rot[:, -1], iR[:, :, None], axis=1))
     recoTran = np.ascontiguousarray(np.take_along_axis(tran[:, -1], iT[:, :, None], axis=1))
-    P = shard.P
+    P, N = shard.P, shard.N
     F = np.zeros((P, P, P // 2 + 1), np.complex64)
     T = np.zeros((P, P, P // 2 + 1), np.float32)
     t0 = time.perf_counter()
-    O.baseline_block(vol, P, shard.pf, shard.N, pl, dat, ctf, sig, rot, tran, recoRot, recoTran, F, T)
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "particles/s", "cores": cores, "kind": "port",
-            "sample": "%d particles x (%d phases x %d rot x %d shifts + %d inserts), oracle C port with OpenMP over "
-                      "images, E-step + insertion only (no reconstruct), %.1f s" % (n, shard.nPhase, shard.mLR,
-                                                                                   shard.mLT, shard.mReco, dt)}
+    O.baseline_block(vol, P, shard.pf, N, pl, dat, ctf, sig, rot, tran, recoRot, recoTran, F, T)
+    t_em = time.perf_counter() - t0
+    em_rate = n / t_em
+    # ---- reconstruct leg (per iteration, independent of the particle count): the GPU's own F / T of half 0 ----
+    reco = None
+    if not args.cpu_no_reconstruct:
+        Fh = shard.F[0].cpu().numpy()
+        Th = shard.T[0].cpu().numpy()
+        with sfft.set_workers(cores):
+            t0 = time.perf_counter()
+            O.reconstruct(Fh, Th, P, N, shard.pf, shard.maxRadius, MAP=False, gridCorr=True, max_rounds=1)
+            t1 = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            O.reconstruct(Fh, Th, P, N, shard.pf, shard.maxRadius, MAP=False, gridCorr=True, max_rounds=3)
+            t3 = time.perf_counter() - t0
+        per_round = max(0.0, (t3 - t1) / 2.0)
+        fixed = max(0.0, t1 - per_round)
+        reco = {"fixed_s": fixed, "per_round_s": per_round, "rounds_per_iteration": rounds_per_iteration,
+                "reconstructions_per_iteration": 4,
+                "seconds_per_iteration": 4 * fixed + rounds_per_iteration * per_round}
+    n_total = args.particles
+    t_iter = n_total / em_rate + (reco["seconds_per_iteration"] if reco else 0.0)
+    return {"value": n_total / t_iter, "unit": "particles/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "em_particles_per_s": em_rate, "reconstruct": reco,
+            "sample": "E-step + insertion: %d particles x (%d phases x %d rot x %d shifts + %d inserts) through the oracle C "
+                      "port, OpenMP over images on %d threads, %.1f s; reconstruct leg: oracle gridding reconstruction on "
+                      "the 512^3 grid timed for 1 and 3 balancing rounds (scipy pocketfft, %d workers), scaled to 4 "
+                      "reconstructions / %d rounds per iteration; value = %d particles / (particles / EM rate + "
+                      "reconstruct seconds)" % (n, shard.nPhase, shard.mLR, shard.mLT, shard.mReco, cores, t_em, cores,
+                                                rounds_per_iteration, n_total)}
 
 
 def main():
@@ -70,7 +118,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--box", type=int, default=256)
-    ap.add_argument("--particles", type=int, default=10000, help="particles per GPU (weak scaling)")
+    ap.add_argument("--particles", type=int, default=100000,
+                    help="TOTAL particles of the job, sharded over the GPUs (100000 = BASELINE metric / configs[2]; "
+                         "10000 = configs[1])")
     ap.add_argument("--mLR", type=int, default=125)
     ap.add_argument("--mLT", type=int, default=9)
     ap.add_argument("--phases", type=int, default=3)
@@ -79,7 +129,8 @@ def main():
     ap.add_argument("--fixed-support", action="store_true",
                     help="feed fixed, tightly clustered support points instead of running the particle filter")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-particles", type=int, default=0)
+    ap.add_argument("--cpu-particles", type=int, default=0, help="CPU baseline sample (default: one particle per core)")
+    ap.add_argument("--cpu-no-reconstruct", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -104,10 +155,11 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
 
     from thunder_amd import capi
-    from thunder_amd.refine import RefineShard
+    from thunder_amd.refine import RefineShard, shard_count
     capi.load()
 
-    shard = RefineShard(args.box, args.particles, dev, rank=rank, world=world, mLR=args.mLR, mLT=args.mLT,
+    n_local = shard_count(args.particles, rank, world)
+    shard = RefineShard(args.box, n_local, dev, rank=rank, world=world, mLR=args.mLR, mLT=args.mLT,
                         nPhase=args.phases, mReco=args.mReco, batch=args.batch, particle_filter=not args.fixed_support)
 
     def barrier():
@@ -123,6 +175,7 @@ def main():
     shard.insert_ms.clear()
     shard.expect_ms.clear()
     shard.stage_ms.clear()
+    shard.reco_rounds.clear()
     barrier()
     t0 = time.perf_counter()
     fsc = shard.run(args.steps, timed=True)
@@ -135,65 +188,72 @@ def main():
         dt = float(tt.item())
 
     if rank == 0:
-        total_particles = args.particles * world * args.steps
+        total_particles = args.particles * args.steps
         value = total_particles / dt
-        # dominant kernel: the insertion scatter; per-launch average from HIP events on the launch stream
+        # per-launch averages of the two gather / scatter kernels from HIP events on the launch stream
         ins = [(a.elapsed_time(b), n) for a, b, n in shard.insert_ms]
         exp = [(a.elapsed_time(b), n) for a, b, n in shard.expect_ms]
         ins_ms = float(np.mean([m for m, _ in ins]))
-        ins_bytes = float(np.mean([n for _, n in ins])) * shard.mReco * shard.nPxlM * INSERT_BYTES_PER_PIXEL_SAMPLE
+        ins_n = float(np.mean([n for _, n in ins]))
+        ins_bytes = ins_n * shard.mReco * shard.nPxlM * INSERT_BYTES_PER_PIXEL_SAMPLE
         exp_ms = float(np.mean([m for m, _ in exp]))
-        exp_bytes = float(np.mean([n for _, n in exp])) * shard.mLR * shard.nPxl * EXPECT_BYTES_PER_PIXEL_SAMPLE
+        exp_n = float(np.mean([n for _, n in exp]))
+        exp_bytes = exp_n * shard.nPxl * (EXPECT_BYTES_PER_PIXEL + EXPECT_BYTES_PER_PIXEL_SAMPLE * shard.mLR)
         t_ins, t_exp = sum(m for m, _ in ins), sum(m for m, _ in exp)
-        if t_ins >= t_exp:
-            kname, kms, kbytes = "k_insert_win", ins_ms, ins_bytes
-        else:
-            kname, kms, kbytes = "k_expect_local", exp_ms, exp_bytes
+        # dominant kernel by total time.  Only the E-step kernel has an HBM roofline that means something: the insertion
+        # kernel accumulates in LDS (PMC: 35 MB of HBM traffic per image against 505 MB "algorithmic") and is bound by
+        # its instruction stream / the LDS atomic rate, reported below as lds_add_frac.
+        kname, kms, kbytes = "k_expect_local", exp_ms, exp_bytes
         achieved = kbytes / (kms * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel from the committed PMC profile (FETCH_SIZE + WRITE_SIZE, separate rocprofv3
-        # passes, corrected as MI355X_MICROARCH.md prescribes), scaled to this run's images per launch; null if absent
-        traffic = None
+        # HBM traffic of that kernel from the committed PMC profile (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes,
+        # FETCH_SIZE calibrated on a known-byte-count 64-byte gather in the same passes -- tools/pmc_traffic.sh), scaled
+        # to this run's images per launch; null if absent
+        traffic, pmc_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        lds_rate = None
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
                 if j.get("box") == args.box:
-                    nper = float(np.mean([n for _, n in (exp if kname == "k_expect_local" else ins)]))
-                    if kname == "k_expect_local":
-                        traffic = j["hbm_bytes_per_image_phase"] * nper
-                    else:
-                        traffic = j["insert_hbm_bytes_per_image"] * nper
+                    traffic = j["hbm_bytes_per_image_phase"] * exp_n
+                    pmc_src = j.get("source")
+                    lds_rate = j.get("lds_add_u32_per_s")
             except Exception:
                 traffic = None
+        # insertion against its own bound: LDS integer adds per second vs the measured ds_add_u32 rate of the chip
+        # (tools/lds_atomic_bench.hip, recorded in profiles/pmc_traffic.json).  24 adds per pixel-sample (8 voxels x re,
+        # im, T); the insert plan merges draws with identical rotation, so the count below is an upper bound.
+        ins_terms_per_s = ins_n * shard.mReco * shard.nPxlM * 24 / (ins_ms * 1e-3)
         out = {
-            "metric": "particles/sec per refinement iteration (256^3 box); achieved HBM GB/s",
+            "metric": "particles/sec per refinement iteration (256^3 box, 100k particles); achieved HBM GB/s",
             "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d synthetic %d^3 particles per GPU, 3D refinement iteration "
-                                   "(local search %d phases x %d rot x %d shifts, %d inserts, 2 half-sets, "
-                                   "2x reconstruct per half, FSC, projector refresh)" % (
-                                       args.particles, args.box, args.phases, args.mLR, args.mLT, args.mReco),
-                       "box": args.box, "particles_per_gpu": args.particles, "nPxl": shard.nPxl, "pf": 2,
+            "config": {"workload": "%d synthetic %d^3 particles, 3D refinement iteration on %d GPU(s) (local search %d "
+                                   "phases x %d rot x %d shifts, %d inserts, 2 half-sets, 2x reconstruct per half, FSC, "
+                                   "projector refresh)" % (args.particles, args.box, world, args.phases, args.mLR,
+                                                           args.mLT, args.mReco),
+                       "box": args.box, "particles": args.particles, "particles_per_gpu": n_local, "nPxl": shard.nPxl,
+                       "pf": 2,
                        "search_state": "fixed seeded support points" if args.fixed_support else
                                        "device particle filter (perturb / resample every phase, Philox-seeded)",
                        "parallelism": "particles sharded over %d GPU(s); half-set F/T all-reduce" % world},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kms,
-                         "algorithmic_bytes_per_launch": kbytes,
-                         # tools/gather_probe.hip on MI355X: 64-byte gathers by the 64 lanes of a wave within +-R voxels of
-                         # a walking centre (the E-step's pattern without any cross-sample reuse), GB/s for R = 2 / 4 / 8
-                         "random_64B_gather_GBps": {"R2": 7000.0, "R4": 4190.0, "R8": 3530.0}},
-            "kernels": {"k_insert_win": {"avg_launch_ms": ins_ms, "GBps_algorithmic": ins_bytes / (ins_ms * 1e-3) / 1e9,
-                                     "total_ms": t_ins},
-                        "k_expect_local": {"avg_launch_ms": exp_ms,
+                         "images_per_launch": exp_n, "algorithmic_bytes_per_launch": kbytes, "traffic_source": pmc_src},
+            "kernels": {"k_insert_win": {"avg_launch_ms": ins_ms, "images_per_launch": ins_n, "total_ms": t_ins,
+                                         "lds_adds_per_s_upper": ins_terms_per_s,
+                                         "lds_add_frac": (ins_terms_per_s / lds_rate) if lds_rate else None,
+                                         "GBps_algorithmic_204B": ins_bytes / (ins_ms * 1e-3) / 1e9},
+                        "k_expect_local": {"avg_launch_ms": exp_ms, "images_per_launch": exp_n,
                                            "GBps_algorithmic": exp_bytes / (exp_ms * 1e-3) / 1e9, "total_ms": t_exp}},
             "stages_ms_per_step": {k: round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 2)
                                    for k, v in shard.stage_ms.items()},
+            "balancing_rounds_per_step": sum(shard.reco_rounds) / max(1, args.steps),
             "fsc_half_maps": [round(float(x), 4) for x in fsc[: 8]],
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, shard)
+            out["cpu_baseline"] = cpu_baseline(args, shard, out["balancing_rounds_per_step"])
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -245,7 +245,7 @@ def set_projectee(ref_rl, pf=2):
 
 
 def reconstruct(F, T, P, N, pf, maxRadius, FSC=None, joinHalf=False, MAP=True, gridCorr=True, a=1.9, alpha=15.0,
-                return_iters=False):
+                return_iters=False, max_rounds=30):
     """Reconstructor::reconstruct(Volume&) src/Reconstructor.cpp:1129-1831, MODE_3D, _size == _N.
     F complex64 [P][P][P/2+1], T float32 same grid (both AFTER prepareTF); returns float32 [N][N][N]
     (wrapped-index layout)."""
@@ -267,7 +267,7 @@ def reconstruct(F, T, P, N, pf, maxRadius, FSC=None, joinHalf=False, MAP=True, g
         Cv = np.zeros((P, P, P // 2 + 1), np.complex64)
         diffC = diffCPrev = np.float32(np.finfo(np.float32).max)
         nNoDec = 0
-        for m in range(30):  # MAX_N_ITER_BALANCE
+        for m in range(max_rounds):  # MAX_N_ITER_BALANCE = 30 (max_rounds < 30 only for bench.py's per-round timing)
             L.orc_calc_C(_p(Cv, c_f), _p(T, c_f), _p(W, c_f), C.c_int(P))
             crl = sfft.irfftn(Cv, s=(P, P, P)).astype(np.float32)  # bwExecutePlan incl. 1/size
             crl = np.ascontiguousarray(crl)

@@ -1,0 +1,252 @@
+"""GPU parity tests at the bench's own sizes and settings (BASELINE configs[1] / [4]): the HIP path exactly as `bench.py`
+drives it -- window insertion kernel with resampled particle-filter draws, cell-packed projector, Morton-ordered pixel
+list, particle-filter priors, 125 x 9 support points, occupancy cap 2 -- against the CPU oracle on the same inputs.
+
+These are the regimes the small-box tests do not reach: at P = 512 / 1024 a row of the insertion kernel has 34+ / 66+
+windows, the (pixel, group) packing uses all its bits and rMax clipping is active; the E-step runs the packed gather in
+pixel-visit order with non-uniform priors.  Oracle cost: a few seconds per case (C, single thread).
+"""
+import time
+
+import numpy as np
+import pytest
+
+from _util import quat_to_mat
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _filter_draws(rng, synth, quat0, shift0, nImg, mLR, mLT, mReco, spread):
+    """what Particle::resample + Particle::rand leave (src/Particle.cpp:2109-2300): a cloud of mLR rotations / mLT shifts
+    around the pose, resampled by (peaked) weights -- so support points repeat -- and mReco uniform picks among them"""
+    cloudR = synth.perturb_quats(quat0, mLR, spread, rng)                      # [nImg][mLR][4]
+    cloudT = shift0[:, None, :] + rng.normal(0, 0.6, size=(nImg, mLT, 2))
+    quat = np.empty((nImg, mReco, 4))
+    tran = np.empty((nImg, mReco, 2))
+    for l in range(nImg):
+        wR = rng.exponential(size=mLR) ** 3
+        wT = rng.exponential(size=mLT) ** 2
+        rsR = rng.choice(mLR, size=mLR, p=wR / wR.sum())                        # resample
+        rsT = rng.choice(mLT, size=mLT, p=wT / wT.sum())
+        quat[l] = cloudR[l][rsR[rng.integers(0, mLR, mReco)]]                   # rand
+        tran[l] = cloudT[l][rsT[rng.integers(0, mLT, mReco)]]
+    return quat, tran
+
+
+def _noisy_rows(O, vol_h, P, N, pl, quat0, shift0, attr, rng, pixelSize=1.32):
+    nImg = quat0.shape[0]
+    dat = np.zeros((nImg, pl["nPxl"]), np.complex64)
+    ctf = np.zeros((nImg, pl["nPxl"]), np.float32)
+    for l in range(nImg):
+        s = O.project(vol_h, P, 2, O.rotate3D(quat0[l]), pl["iCol"], pl["iRow"])
+        ctf[l] = O.ctf(pixelSize, *attr[l], N, pl["iCol"], pl["iRow"])
+        sig = s * ctf[l] * O.translate(shift0[l, 0], shift0[l, 1], N, pl["iCol"], pl["iRow"])
+        sd = np.sqrt(np.mean(np.abs(sig) ** 2)) * 3.0
+        dat[l] = (sig + (rng.normal(size=sig.shape) + 1j * rng.normal(size=sig.shape)) * sd / np.sqrt(2)).astype(np.complex64)
+    return dat, ctf
+
+
+def _oracle_insert(O, P, N, pl, dat, ctf, quat, tran, offS, w):
+    F = np.zeros((P, P, P // 2 + 1), np.complex64)
+    Tt = np.zeros((P, P, P // 2 + 1), np.float32)
+    for l in range(len(w)):
+        for m in range(quat.shape[1]):
+            t = tran[l, m] - offS[l]
+            src = O.translate(np.float32(-t[0]), np.float32(-t[1]), N, pl["iCol"], pl["iRow"], src=dat[l])
+            O.insertP(F, Tt, P, src, ctf[l], O.rotate3D(quat[l, m]), w[l], pl["iColPad"], pl["iRowPad"])
+    return F, Tt
+
+
+def _insert_vs_oracle(O, dev, N, nImg, mReco, seed, spread=0.01):
+    from thunder_amd import ops, synth
+    from thunder_amd.refine import pixel_list
+    rng = np.random.default_rng(seed)
+    P = 2 * N
+    pl = pixel_list(N, N // 2 - 2, 0)
+    plan = ops.RecoPlan(N, N, 2)
+    vol_h = plan.set_projectee(T(synth.blob_map(N, nblob=8), dev)).cpu().numpy()
+    plan.close()
+    quat0 = synth.random_quats(nImg, rng)
+    shift0 = rng.normal(0, 2.0, size=(nImg, 2))
+    attr = synth.ctf_params(nImg, rng)
+    dat, ctf = _noisy_rows(O, vol_h, P, N, pl, quat0, shift0, attr, rng)
+    del vol_h
+    quat, tran = _filter_draws(rng, synth, quat0, shift0, nImg, 125, 9, mReco, spread)
+    nGroups = [len({q.tobytes() for q in quat[l]}) for l in range(nImg)]
+    assert max(nGroups) < mReco, "the draws are meant to repeat support points"
+    offS = rng.normal(0, 0.8, size=(nImg, 2))
+    w = (rng.uniform(0.5, 1.0, size=nImg) / mReco).astype(np.float32)
+    t0 = time.perf_counter()
+    Fw, Tw = _oracle_insert(O, P, N, pl, dat, ctf, quat, tran, offS, w)
+    t_or = time.perf_counter() - t0
+    F = torch.zeros((P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
+    Tt = torch.zeros((P, P, P // 2 + 1), dtype=torch.float32, device=dev)
+    rot = ops.rotmat(T(quat.reshape(-1, 4), dev)).reshape(nImg, mReco, 9)
+    ops.insert(F, Tt, P, T(dat, dev), T(ctf, dev), T(w, dev), rot, T(tran, dev), T(pl["iCol"], dev), T(pl["iRow"], dev), 2, N,
+               offS=T(offS, dev))
+    Fg, Tg = F.cpu().numpy(), Tt.cpu().numpy()
+    del F, Tt
+    print("insert N=%d: %d images x %d draws (%s groups), oracle %.1f s" % (N, nImg, mReco, nGroups, t_or))
+    # bar of SURVEY 8c (7): 1e-5 of the largest accumulated magnitude (atomic order is arbitrary in the reference too)
+    eF, eT = np.abs(Fg - Fw).max() / np.abs(Fw).max(), np.abs(Tg - Tw).max() / np.abs(Tw).max()
+    assert eF <= 1e-5 and eT <= 1e-5, (eF, eT)
+    # no voxel outside the oracle's support is touched; voxels left at zero carry at most a sub-quantum contribution
+    assert not np.any((Fw == 0) & (Fg != 0)) and not np.any((Tw == 0) & (Tg != 0))
+    assert np.abs(Tw[Tg == 0]).max(initial=0) <= 1e-6 * np.abs(Tw).max()
+    # total mass: sum T = sum over in-grid samples of w ctf^2 (weights of a cell sum to 1)
+    np.testing.assert_allclose(Tg.sum(dtype=np.float64), Tw.sum(dtype=np.float64), rtol=1e-6)
+
+
+def test_insert_win_vs_oracle_n256(oracle, dev):
+    """configs[1] box: 3 images x 100 resampled draws (~1 degree spread, repeated support points, non-zero offS)"""
+    _insert_vs_oracle(oracle, dev, 256, 3, 100, seed=2560, spread=0.01)
+
+
+def test_insert_win_vs_oracle_n256_wide_cloud(oracle, dev):
+    """a cloud with a 4-degree spread: many slabs per window, draws leaving the reference plane by tens of voxels"""
+    _insert_vs_oracle(oracle, dev, 256, 2, 40, seed=2561, spread=0.04)
+
+
+def test_insert_win_vs_oracle_n512(oracle, dev):
+    """configs[4] box (P = 1024): one image x 20 draws"""
+    _insert_vs_oracle(oracle, dev, 512, 1, 20, seed=5120, spread=0.008)
+
+
+@pytest.mark.parametrize("N", [32, 64])
+def test_insert_far_posterior_modes(oracle, dev, N):
+    """draws of ONE image from far-apart posterior modes: exactly / nearly 90 degrees from the first draw (its plane
+    contains the shear axis of the reference plane: slopes -n/gna unbounded), 30-60 degrees away, and the reference
+    itself.  Must equal the oracle, in bounded time (the degenerate groups take the plain-atomic path)."""
+    from thunder_amd import ops, synth
+    from thunder_amd.refine import pixel_list
+    O = oracle
+    rng = np.random.default_rng(900 + N)
+    P = 2 * N
+    pl = pixel_list(N, N // 2 - 2, 0)
+    nImg = 3
+    q0 = synth.random_quats(nImg, rng)
+    q0[0] = [1.0, 0, 0, 0]                       # identity: normal = z exactly, shear axis z
+
+    def qmul(a, b):
+        return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                         a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+    def axis_angle(ax, deg):
+        h = np.deg2rad(deg) / 2
+        return np.concatenate([[np.cos(h)], np.sin(h) * np.asarray(ax, float) / np.linalg.norm(ax)])
+    turns = [axis_angle([1, 0, 0], 90.0), axis_angle([0, 1, 0], 90.0), axis_angle([1, 1, 0], 89.9), axis_angle([1, 0, 0], 75.0),
+             axis_angle([0, 1, 0], 45.0), axis_angle([1, 2, 3], 30.0), axis_angle([0, 0, 1], 90.0), axis_angle([1, 0, 0], 1.0)]
+    mReco = len(turns) + 2
+    quat = np.empty((nImg, mReco, 4))
+    for l in range(nImg):
+        quat[l, 0] = q0[l]
+        for m, t in enumerate(turns):
+            quat[l, 1 + m] = qmul(t, q0[l])
+        quat[l, -1] = quat[l, 1]               # a repeated far draw (grouped)
+    tran = rng.normal(0, 1.0, size=(nImg, mReco, 2))
+    tran[:, -1] = tran[:, 1]
+    dat = (rng.normal(size=(nImg, pl["nPxl"])) + 1j * rng.normal(size=(nImg, pl["nPxl"]))).astype(np.complex64)
+    ctf = rng.uniform(-1, 1, size=(nImg, pl["nPxl"])).astype(np.float32)
+    offS = rng.normal(0, 0.3, size=(nImg, 2))
+    w = (rng.uniform(0.5, 1.0, size=nImg) / mReco).astype(np.float32)
+    Fw, Tw = _oracle_insert(O, P, N, pl, dat, ctf, quat, tran, offS, w)
+    F = torch.zeros((P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
+    Tt = torch.zeros((P, P, P // 2 + 1), dtype=torch.float32, device=dev)
+    rot = ops.rotmat(T(quat.reshape(-1, 4), dev)).reshape(nImg, mReco, 9)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ops.insert(F, Tt, P, T(dat, dev), T(ctf, dev), T(w, dev), rot, T(tran, dev), T(pl["iCol"], dev), T(pl["iRow"], dev), 2, N,
+               offS=T(offS, dev))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert dt < 5.0, "insertion of far-apart draws took %.1f s" % dt
+    assert np.abs(F.cpu().numpy() - Fw).max() <= 1e-5 * np.abs(Fw).max()
+    assert np.abs(Tt.cpu().numpy() - Tw).max() <= 1e-5 * np.abs(Tw).max()
+
+
+def test_expect_local_bench_settings_n256(oracle, dev):
+    """configs[1] E-step exactly as bench.py launches it: cell-packed projector, Morton-ordered rL = 2 pixel list,
+    particle-filter priors (non-uniform pR / pT), 125 rotations x 9 shifts (~1 degree cloud), occupancy cap 2 -- two
+    images against the oracle's replay of src/Optimiser.cpp:1225-1406"""
+    from thunder_amd import ops, synth
+    from thunder_amd.refine import pixel_list, pixel_visit_order
+    O = oracle
+    rng = np.random.default_rng(2562)
+    N, P, nImg, nR, nT = 256, 512, 2, 125, 9
+    pl = pixel_list(N, N // 2 - 2, 2)
+    assert pl["nPxl"] == 24742
+    order = pixel_visit_order(pl, N)
+    assert order is not None
+    for k in ("iCol", "iRow", "iPxl", "iSig", "iColPad", "iRowPad"):
+        pl[k] = np.ascontiguousarray(pl[k][order])
+    plan = ops.RecoPlan(N, N, 2)
+    vol = plan.set_projectee(T(synth.blob_map(N, nblob=8), dev))
+    plan.close()
+    vol_h = vol.cpu().numpy()
+    quat0 = synth.random_quats(nImg, rng)
+    shift0 = rng.normal(0, 2.0, size=(nImg, 2))
+    attr = synth.ctf_params(nImg, rng)
+    dat, ctf = _noisy_rows(O, vol_h, P, N, pl, quat0, shift0, attr, rng)
+    sig = np.broadcast_to((-0.5 / np.mean(np.abs(dat) ** 2, axis=0, keepdims=True)).astype(np.float32), dat.shape).copy()
+    q = synth.perturb_quats(quat0, nR, 0.01, rng)
+    q[:, 0] = quat0
+    rot_h = np.stack([[O.rotate3D(x) for x in qs] for qs in q])
+    tran_h = shift0[:, None, :] + rng.normal(0, 0.5, size=(nImg, nT, 2))
+    pR = rng.exponential(size=(nImg, nR))
+    pR /= pR.sum(1, keepdims=True)
+    pT = rng.exponential(size=(nImg, nT))
+    pT /= pT.sum(1, keepdims=True)
+    cells = ops.pack_projector(vol[None].contiguous(), P)
+    res = ops.expect_local(cells, P, 2, N, T(pl["iCol"], dev), T(pl["iRow"], dev), T(dat, dev), T(ctf, dev), T(sig, dev),
+                           T(rot_h, dev), T(tran_h, dev), pR=T(pR, dev), pT=T(pT, dev), want_logW=True, packed=True,
+                           wg_per_cu=2)
+    del cells
+    for l in range(nImg):
+        t0 = time.perf_counter()
+        want = O.expect_local(vol_h, P, 2, N, pl["iCol"], pl["iRow"], dat[l], ctf[l], sig[l], rot_h[l], tran_h[l], pR=pR[l],
+                              pT=pT[l])
+        print("expect_local N=256 oracle: %.1f s" % (time.perf_counter() - t0))
+        wl = want["logW"][:, :, 0].T            # [nT][nR]
+        got = res.logW[l, 0].cpu().numpy()
+        # float sums of 24742 terms: error scale eps * |C|, C = sum sigRcp |dat|^2
+        Cabs = abs(float(np.sum(sig[l].astype(np.float64) * np.abs(dat[l].astype(np.complex128)) ** 2)))
+        assert np.abs(got - wl).max() <= 1e-6 * Cabs, (np.abs(got - wl).max(), Cabs)
+        dg, dw = got - got.max(), wl - wl.max()
+        assert np.abs(dg - dw).max() <= 1e-6 * Cabs
+        rtol = 3 * max(2e-6 * Cabs, 1e-4)
+        np.testing.assert_allclose(res.wR[l].cpu().numpy(), want["wR"].reshape(-1), rtol=rtol)
+        np.testing.assert_allclose(res.wT[l].cpu().numpy(), want["wT"].reshape(-1), rtol=rtol)
+        np.testing.assert_allclose(res.wC[l].item(), float(np.asarray(want["wC"]).reshape(-1)[0]), rtol=rtol)
+        assert int(res.wR[l].argmax()) == int(np.argmax(want["wR"]))
+
+
+@pytest.mark.parametrize("nT", [16, 32])
+def test_expect_local_many_shifts(oracle, dev, nT):
+    """the NT = 16 and NT = 32 instantiations of the local-search kernel (the 32-shift stage table needs 68.6 KB of
+    dynamic LDS): against the oracle at N = 32, standard and cell-packed layouts"""
+    from thunder_amd import ops, synth
+    from _util import make_case, make_images
+    O = oracle
+    rng = np.random.default_rng(40 + nT)
+    N, P, nImg, nR = 32, 64, 3, 70
+    ref, vol, pl = make_case(O, N, rL=2)
+    im = make_images(O, vol, pl, N, nImg, rng)
+    q = synth.perturb_quats(im["quat"], nR, 0.05, rng)
+    rot_h = np.stack([[O.rotate3D(x) for x in qs] for qs in q])
+    tran_h = im["shift"][:, None, :] + rng.normal(0, 0.7, size=(nImg, nT, 2))
+    args = (P, 2, N, T(pl["iCol"], dev), T(pl["iRow"], dev), T(im["dat"], dev), T(im["ctf"], dev), T(im["sigRcp"], dev),
+            T(rot_h, dev), T(tran_h, dev))
+    a = ops.expect_local(T(vol, dev), *args, want_logW=True)
+    b = ops.expect_local(ops.pack_projector(T(vol, dev)[None].contiguous(), P), *args, want_logW=True, packed=True)
+    assert torch.equal(a.logW, b.logW)
+    for l in range(nImg):
+        want = O.expect_local(vol, P, 2, N, pl["iCol"], pl["iRow"], im["dat"][l], im["ctf"][l], im["sigRcp"][l], rot_h[l], tran_h[l])
+        wl = want["logW"][:, :, 0].T
+        np.testing.assert_allclose(a.logW[l, 0].cpu().numpy(), wl, rtol=0, atol=1e-5 * np.abs(wl).max())
+        np.testing.assert_allclose(a.wT[l].cpu().numpy(), want["wT"].reshape(-1), rtol=2e-3)

@@ -406,13 +406,14 @@ def test_multirank_bench_control_flow_on_one_device(dev, world):
     env = dict(os.environ, THX_BENCH_ONE_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "1",
-           "--warmup", "1", "--box", "32", "--particles", "300", "--mReco", "20"]
+           "--warmup", "1", "--box", "32", "--particles", str(300 * world), "--mReco", "20"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # rank 0 prints ONE line
     j = json.loads(lines[0])
-    assert j["n_gpus"] == world and j["scaling"] == "weak" and j["value"] > 0 and j["cpu_baseline"] is None
+    assert j["n_gpus"] == world and j["scaling"] == "strong" and j["value"] > 0 and j["cpu_baseline"] is None
+    assert j["config"]["particles"] == 300 * world and j["config"]["particles_per_gpu"] == 300
     assert abs(j["value"] - 300 * world / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
     assert all(f > 0.5 for f in j["fsc_half_maps"][1:4]), j["fsc_half_maps"]
 

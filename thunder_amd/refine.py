@@ -101,6 +101,7 @@ class RefineShard:
         # 16x16 tiles in row-major order (THX_PIXEL_ORDER=tile, THX_TILE_ORDER=T); the reference's row-major list
         # (THX_PIXEL_ORDER=tile THX_TILE_ORDER=0) is 6 % slower than the tiles.
         order = pixel_visit_order(pl, N)
+        self.e_order = order
         if order is not None:
             for k in ("iCol", "iRow", "iPxl", "iSig", "iColPad", "iRowPad"):
                 pl[k] = np.ascontiguousarray(pl[k][order])
@@ -193,7 +194,7 @@ class RefineShard:
         # ---- fixed-work support points for every phase (seeded) ----
         stds = [0.02 / (2 ** p) for p in range(nPhase)]
         self.rotP, self.tranP = [], []
-        for p in range(nPhase):
+        for p in range(0 if particle_filter else nPhase):   # (the particle filter brings its own support points)
             q = synth.perturb_quats(self.quat, mLR, stds[p], rng)
             self.rotP.append(ops.rotmat(torch.from_numpy(q.reshape(-1, 4)).to(device)).reshape(nImg, mLR, 9))
             t = self.shift[:, None, :] + rng.normal(0, 0.5 / (2 ** p), size=(nImg, mLT, 2))
@@ -234,6 +235,7 @@ class RefineShard:
         self.insert_ms = []   # per-launch durations of the insertion kernel (HIP events on the launch stream)
         self.expect_ms = []
         self.stage_ms = {}    # name -> list of (event, event): coarse per-stage timing of the timed run
+        self.reco_rounds = []  # balancing rounds of every reconstruction (Reconstructor::reconstruct's gridding loop)
         self.last = {}
         self.sig = torch.empty((nV, nGroup, self.rSig), dtype=torch.float32, device=device)
         self.sigRcp = torch.empty_like(self.sig)
@@ -396,7 +398,9 @@ class RefineShard:
         g.allreduce_half(self.T[vi])
         g.allreduce_half(self.F[vi])
         ops.normalise_TF(self.F[vi], self.T[vi], self.P)
-        return self.plans[vi].reconstruct(self.F[vi], self.T[vi], self.maxRadius, MAP=False, gridCorr=True)
+        m = self.plans[vi].reconstruct(self.F[vi], self.T[vi], self.maxRadius, MAP=False, gridCorr=True)
+        self.reco_rounds.append(self.plans[vi].last_iters)
+        return m
 
     def fsc_of(self, a, b):
         ops = self.ops
@@ -405,6 +409,7 @@ class RefineShard:
     def final_map_and_refresh(self, vi, fsc):
         m = self.plans[vi].reconstruct(self.F[vi], self.T[vi], self.maxRadius, FSC=fsc, joinHalf=False, MAP=True,
                                        gridCorr=True)
+        self.reco_rounds.append(self.plans[vi].last_iters)
         self.vols[vi] = self.plans[vi].set_projectee(m)   # Model::refreshProj
         if self.use_packed and self.cells is not None:
             self.cells[vi] = self.ops.pack_projector(self.vols[vi:vi + 1], self.P)[0]
@@ -579,6 +584,11 @@ def pixel_list(N, rU, rL, pf=2):
     a = lambda x: np.asarray(x, np.int32)
     return dict(iCol=a(iCol), iRow=a(iRow), iPxl=a(iPxl), iSig=a(iSig), iColPad=a(iCol) * pf, iRowPad=a(iRow) * pf,
                 nPxl=len(iCol))
+
+
+def shard_count(nTotal, rank, world):
+    """number of particles `rank` owns when nTotal particles are sharded as shard_indices does"""
+    return int(len(shard_indices(nTotal, rank, world)))
 
 
 def shard_indices(nTotal, rank, world):

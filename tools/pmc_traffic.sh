@@ -1,11 +1,20 @@
 #!/bin/bash
 # HBM traffic of the hot kernels from the TCC counters, collected as MI355X_MICROARCH.md (HBM section) prescribes:
-# FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes with --kernel-trace only, plus a calibration dispatch of known
-# byte count (a 1 GiB float4 device copy) in the same passes to fix the unit / gfx950 factor for this access width.
+# FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes with --kernel-trace only.  The unit of FETCH_SIZE depends on the
+# access shape on gfx950, so every pass also profiles tools/pmc_calib: 1 GiB dispatches of known byte count in three
+# shapes (wide streaming copy, scattered 64-byte cells = the E-step's packed gathers, scattered 16-byte pairs).  A third
+# pass collects the L2's request / hit / miss counts for a cross-check (misses x 128-byte lines).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc_traffic
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
+[ -x tools/pmc_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/pmc_calib tools/pmc_calib.hip
+[ -x tools/lds_atomic_bench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/lds_atomic_bench tools/lds_atomic_bench.hip
+tools/lds_atomic_bench > $OUT/lds_atomic_bench.txt 2>&1
+tools/pmc_calib > $OUT/pmc_calib_unprofiled.txt 2>&1
 CMD="python tools/traffic_probe.py"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- $CMD > $OUT/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- $CMD > $OUT/write.log 2>&1
+for pass in fetch:FETCH_SIZE write:WRITE_SIZE l2:"TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum"; do
+    name=${pass%%:*}; ctr=${pass#*:}
+    rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/cal_$name -o p -- tools/pmc_calib > $OUT/cal_$name.log 2>&1
+    rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/$name -o p -- $CMD > $OUT/$name.log 2>&1
+done
 python tools/pmc_traffic_parse.py $OUT

@@ -1,57 +1,93 @@
-"""parse the two counter_collection.csv files of tools/pmc_traffic.sh into profiles-ready JSON"""
-import csv, glob, json, sys, collections
+"""parse the counter_collection.csv files of tools/pmc_traffic.sh into profiles-ready JSON.
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB.  Their bytes-per-unit are NOT assumed: each is calibrated on the 1 GiB
+dispatches of tools/pmc_calib profiled in the same pass -- the streaming copy for WRITE_SIZE (and as a reference point
+for FETCH_SIZE), the scattered 64-byte-cell gather for the E-step kernel's FETCH_SIZE (same request shape)."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
 out = sys.argv[1]
-res = {}
-for which in ("fetch", "write"):
-    fs = glob.glob("%s/%s/**/*counter_collection.csv" % (out, which), recursive=True)
-    rows = list(csv.DictReader(open(fs[0])))
-    per = collections.defaultdict(list)
-    for r in rows:
-        per[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    res[which] = {k: v for k, v in per.items()}
 GiB = 1024.0 ** 3
-def find(d, key):
-    return [(k, v) for k, v in d.items() if key in k]
-summary = {}
-# calibration: the 1 GiB device-to-device copy issued by tools/traffic_probe.py runs as __amd_rocclr_copyBuffer
-# (float4 streaming: 1 GiB read + 1 GiB written); it is the largest dispatch of that name.
-cal = {}
-for which in ("fetch", "write"):
-    best = None
-    for k, v in res[which].items():
-        if "copyBuffer" in k and max(v) > 0:
-            if best is None or max(v) > best[1]:
-                best = (k, max(v))
-    cal[which] = best
-summary["calibration"] = {w: {"kernel": cal[w][0][:80], "raw_for_1GiB": cal[w][1], "bytes_per_unit": GiB / cal[w][1]} for w in cal if cal[w]}
-summary["note"] = ("FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies a wide coalesced read stream at half its "
-                   "bytes (MI355X_MICROARCH.md, HBM section): the 1 GiB copy reads 524288 KiB by the counter. bytes_per_unit "
-                   "below therefore applies the same x2 to the kernels' fetch counts (an upper bound for their mixed-width "
-                   "gathers); WRITE_SIZE is exact (1 GiB -> 1048576 KiB).")
-for name in ("k_insert_win", "k_insert_tiles", "k_expect_local<"):
-    ent = {}
-    for which in ("fetch", "write"):
-        f = find(res[which], name)
-        if f:
-            vals = f[0][1]
-            ent[which + "_raw_per_launch"] = sum(vals) / len(vals)
-            ent[which + "_bytes_per_launch"] = ent[which + "_raw_per_launch"] * summary["calibration"][which]["bytes_per_unit"]
-            ent["launches"] = len(vals)
-    if ent:
-        ent["hbm_bytes_per_launch"] = ent.get("fetch_bytes_per_launch", 0) + ent.get("write_bytes_per_launch", 0)
+
+
+def load(dirname):
+    fs = glob.glob("%s/%s/**/*counter_collection.csv" % (out, dirname), recursive=True)
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not fs:
+        return per
+    for r in csv.DictReader(open(fs[0])):
+        per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return per
+
+
+def pick(per, key, counter, how=max):
+    vals = [v for k, d in per.items() if key in k for v in d.get(counter, [])]
+    return how(vals) if vals else None
+
+
+summary = {"calibration": {}, "note": "raw = counter value per dispatch (KiB for FETCH_SIZE / WRITE_SIZE); bytes_per_unit = "
+           "known bytes of the calibration dispatch / its raw value, measured in the same rocprofv3 pass"}
+cal_f, cal_w, cal_l2 = load("cal_fetch"), load("cal_write"), load("cal_l2")
+for kern, nbytes in (("k_cal_stream", GiB), ("k_cal_gather64", GiB), ("k_cal_gather16", GiB)):
+    raw = pick(cal_f, kern, "FETCH_SIZE")
+    ent = {"known_read_bytes": nbytes, "FETCH_SIZE_raw": raw, "fetch_bytes_per_unit": (nbytes / raw) if raw else None}
+    if kern == "k_cal_stream":
+        raww = pick(cal_w, kern, "WRITE_SIZE")
+        ent.update({"known_written_bytes": nbytes, "WRITE_SIZE_raw": raww, "write_bytes_per_unit": (nbytes / raww) if raww else None})
+    for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_HIT_sum", "TCC_MISS_sum"):
+        v = pick(cal_l2, kern, c)
+        if v is not None:
+            ent[c] = v
+    summary["calibration"][kern] = ent
+fetch, write, l2 = load("fetch"), load("write"), load("l2")
+u_gather = summary["calibration"]["k_cal_gather64"]["fetch_bytes_per_unit"]
+u_stream = summary["calibration"]["k_cal_stream"]["fetch_bytes_per_unit"]
+u_write = summary["calibration"]["k_cal_stream"].get("write_bytes_per_unit")
+n_per_launch = int(os.environ.get("THX_PROBE_PARTICLES", "2048")) // 2
+for name, unit_f, shape in (("k_expect_local", u_gather, "scattered 64-byte cells"), ("k_insert_win", u_stream, "streamed rows")):
+    ent = {"fetch_calibration": shape}
+    fr = pick(fetch, name, "FETCH_SIZE", how=lambda v: sum(v) / len(v))
+    wr = pick(write, name, "WRITE_SIZE", how=lambda v: sum(v) / len(v))
+    if fr is not None and unit_f:
+        ent["fetch_raw_per_launch"] = fr
+        ent["fetch_bytes_per_launch"] = fr * unit_f
+        ent["fetch_bytes_per_launch_if_stream_unit"] = fr * u_stream if u_stream else None
+    if wr is not None and u_write:
+        ent["write_raw_per_launch"] = wr
+        ent["write_bytes_per_launch"] = wr * u_write
+    for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_HIT_sum", "TCC_MISS_sum"):
+        v = pick(l2, name, c, how=lambda v: sum(v) / len(v))
+        if v is not None:
+            ent[c + "_per_launch"] = v
+    if "fetch_bytes_per_launch" in ent:
+        ent["hbm_bytes_per_launch"] = ent["fetch_bytes_per_launch"] + ent.get("write_bytes_per_launch", 0.0)
+        ent["images_per_launch"] = n_per_launch
         summary[name] = ent
+# measured LDS integer-add rate of the chip (tools/lds_atomic_bench): the insertion kernel's own bound
+lds_rate = None
+try:
+    for line in open(out + "/lds_atomic_bench.txt"):
+        m = re.match(r"ds_add_u32 random\s+[\d.]+ ms\s+([\d.]+) G lane-ops/s", line)
+        if m:
+            lds_rate = float(m.group(1)) * 1e9
+except OSError:
+    pass
+summary["lds_add_u32_random_per_s"] = lds_rate
 print(json.dumps(summary, indent=1))
 json.dump(summary, open(out + "/summary.json", "w"), indent=1)
-# per-image figures bench.py scales into roofline.traffic (tools/traffic_probe.py launches 1024 images per kernel)
-import os
-n_per_launch = int(os.environ.get("THX_PROBE_PARTICLES", "2048")) // 2
-pm = {"box": 256, "images_per_launch": n_per_launch,
+pm = {"box": 256, "images_per_launch": n_per_launch, "lds_add_u32_per_s": lds_rate,
       "source": "tools/pmc_traffic.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
-                "tools/traffic_probe.py (particle-filter support points, one phase); KiB units; FETCH_SIZE x2 (gfx950 "
-                "wide-read correction, calibrated on a 1 GiB device copy in the same passes); WRITE_SIZE exact"}
-if "k_expect_local<" in summary:
-    pm["hbm_bytes_per_image_phase"] = summary["k_expect_local<"]["hbm_bytes_per_launch"] / n_per_launch
-ins = summary.get("k_insert_win") or summary.get("k_insert_tiles")
-if ins:
-    pm["insert_hbm_bytes_per_image"] = ins["hbm_bytes_per_launch"] / n_per_launch
+                "tools/traffic_probe.py (particle-filter support points, one phase); KiB units; FETCH_SIZE of the E-step kernel "
+                "scaled by the bytes-per-unit measured on tools/pmc_calib's 1 GiB scattered 64-byte-cell gather in the same "
+                "pass (x%.3f; the wide streaming copy gives x%.3f), WRITE_SIZE by the 1 GiB streaming copy" % (
+                    (u_gather or 0) / 1024.0, (u_stream or 0) / 1024.0)}
+if "k_expect_local" in summary:
+    pm["hbm_bytes_per_image_phase"] = summary["k_expect_local"]["hbm_bytes_per_launch"] / n_per_launch
+if "k_insert_win" in summary:
+    pm["insert_hbm_bytes_per_image"] = summary["k_insert_win"]["hbm_bytes_per_launch"] / n_per_launch
 json.dump(pm, open(out + "/pmc_traffic.json", "w"), indent=1)
