@@ -41,42 +41,36 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(args, shard, rounds_per_iteration):
+def cpu_baseline(args, shard, nat, rounds_per_iteration):
     """oracle (`kind: port`) on a bounded sample of the SAME workload, all host cores.
-    E-step + insertion: `n` particles of the shard through the oracle's OpenMP loop over images (one image per thread at
-    a time, F / T shared under `omp atomic` -- the reference's own structure, src/Optimiser.cpp:1162,7038).
+    E-step + insertion: `n` particles of the shard -- their rows, noise model and the particle filter's current support
+    points copied out of the native driver's HBM state -- through the oracle's OpenMP loop over images (one image per
+    thread at a time, F / T shared under `omp atomic`: the reference's own structure, src/Optimiser.cpp:1162,7038).
     Reconstruct leg: the oracle's gridding reconstruction at the full 512^3 grid is timed for 1 and for 3 balancing rounds
     (scipy pocketfft on all cores + the oracle's C sweeps); fixed cost and cost per round follow by difference and are
     scaled to the 4 reconstructions and the number of balancing rounds the GPU iteration actually ran."""
     from oracle import oracle as O
     import scipy.fft as sfft
-    import torch
     cores = os.cpu_count() or 1
     n = min(shard.nImg, max(4, int(args.cpu_particles) if args.cpu_particles else cores))
-    pl = O.pixel_list(shard.N, shard.rU, 2, shard.pf)
-    assert pl["nPxl"] == shard.nPxl
-    order = shard.e_order
-    if order is not None:   # the shard's E-step rows are in pixel-visit order
-        for k in ("iCol", "iRow", "iPxl", "iSig", "iColPad", "iRowPad"):
-            pl[k] = np.ascontiguousarray(pl[k][order])
-    vol = shard.vols[0].cpu().numpy()
-    dat = shard.datP[:n].cpu().numpy()
-    ctf = shard.ctfP[:n].cpu().numpy()
-    sig = shard.sigRcpP[:n].cpu().numpy()
-    if shard.use_pf:   # the particle filter's current support points, the same work in every phase
-        st = shard.pf_state
-        r1 = shard.ops.rotmat(st["r"][:n].reshape(-1, 4)).reshape(n, shard.mLR, 9)
-        rot = torch.stack([r1] * shard.nPhase, dim=1).cpu().numpy()
-        tran = torch.stack([st["t"][:n]] * shard.nPhase, dim=1).cpu().numpy()
-    else:
-        rot = torch.stack([r[:n] for r in shard.rotP], dim=1).cpu().numpy()      # [n][nPhase][mLR][9]
-        tran = torch.stack([t[:n] for t in shard.tranP], dim=1).cpu().numpy()    # [n][nPhase][mLT][2]
+    v = nat.view()
+    nPxl, P, N = v.nPxl, shard.P, shard.N
+    iCol, iRow = nat.fetch(v.iCol, np.int32, (nPxl,)), nat.fetch(v.iRow, np.int32, (nPxl,))
+    pl = dict(iCol=iCol, iRow=iRow, iColPad=iCol * shard.pf, iRowPad=iRow * shard.pf, nPxl=nPxl)
+    vol = nat.fetch(v.vols, np.complex64, (P, P, P // 2 + 1))
+    dat = nat.fetch(v.datP, np.complex64, (n, nPxl))
+    ctf = nat.fetch(v.ctfP, np.float32, (n, nPxl))
+    sig = nat.fetch(v.sigRcpP, np.float32, (n, nPxl))
+    quat = nat.fetch(v.r, np.float64, (n, shard.mLR, 4))
+    t1 = nat.fetch(v.t, np.float64, (n, shard.mLT, 2))
+    r1 = np.stack([[O.rotate3D(q) for q in qs] for qs in quat])          # the filter's current support points,
+    rot = np.ascontiguousarray(np.stack([r1] * shard.nPhase, axis=1))    # the same work in every phase
+    tran = np.ascontiguousarray(np.stack([t1] * shard.nPhase, axis=1))
     rng = np.random.default_rng(1)
     iR = rng.integers(0, shard.mLR, size=(n, shard.mReco))
     iT = rng.integers(0, shard.mLT, size=(n, shard.mReco))
     recoRot = np.ascontiguousarray(np.take_along_axis(rot[:, -1], iR[:, :, None], axis=1))
     recoTran = np.ascontiguousarray(np.take_along_axis(tran[:, -1], iT[:, :, None], axis=1))
-    P, N = shard.P, shard.N
     F = np.zeros((P, P, P // 2 + 1), np.complex64)
     T = np.zeros((P, P, P // 2 + 1), np.float32)
     t0 = time.perf_counter()
@@ -86,17 +80,17 @@ def cpu_baseline(args, shard, rounds_per_iteration):
     # ---- reconstruct leg (per iteration, independent of the particle count): the GPU's own F / T of half 0 ----
     reco = None
     if not args.cpu_no_reconstruct:
-        Fh = shard.F[0].cpu().numpy()
-        Th = shard.T[0].cpu().numpy()
+        Fh = nat.fetch(v.F, np.complex64, (P, P, P // 2 + 1))
+        Th = np.maximum(nat.fetch(v.T, np.float32, (P, P, P // 2 + 1)), 0)
         with sfft.set_workers(cores):
             t0 = time.perf_counter()
             O.reconstruct(Fh, Th, P, N, shard.pf, shard.maxRadius, MAP=False, gridCorr=True, max_rounds=1)
-            t1 = time.perf_counter() - t0
+            t1_ = time.perf_counter() - t0
             t0 = time.perf_counter()
             O.reconstruct(Fh, Th, P, N, shard.pf, shard.maxRadius, MAP=False, gridCorr=True, max_rounds=3)
-            t3 = time.perf_counter() - t0
-        per_round = max(0.0, (t3 - t1) / 2.0)
-        fixed = max(0.0, t1 - per_round)
+            t3_ = time.perf_counter() - t0
+        per_round = max(0.0, (t3_ - t1_) / 2.0)
+        fixed = max(0.0, t1_ - per_round)
         reco = {"fixed_s": fixed, "per_round_s": per_round, "rounds_per_iteration": rounds_per_iteration,
                 "reconstructions_per_iteration": 4,
                 "seconds_per_iteration": 4 * fixed + rounds_per_iteration * per_round}
@@ -106,9 +100,9 @@ def cpu_baseline(args, shard, rounds_per_iteration):
             "em_particles_per_s": em_rate, "reconstruct": reco,
             "sample": "E-step + insertion: %d particles x (%d phases x %d rot x %d shifts + %d inserts) through the oracle C "
                       "port, OpenMP over images on %d threads, %.1f s; reconstruct leg: oracle gridding reconstruction on "
-                      "the 512^3 grid timed for 1 and 3 balancing rounds (scipy pocketfft, %d workers), scaled to 4 "
+                      "the %d^3 grid timed for 1 and 3 balancing rounds (scipy pocketfft, %d workers), scaled to 4 "
                       "reconstructions / %d rounds per iteration; value = %d particles / (particles / EM rate + "
-                      "reconstruct seconds)" % (n, shard.nPhase, shard.mLR, shard.mLT, shard.mReco, cores, t_em, cores,
+                      "reconstruct seconds)" % (n, shard.nPhase, shard.mLR, shard.mLT, shard.mReco, cores, t_em, P, cores,
                                                 rounds_per_iteration, n_total)}
 
 
@@ -126,8 +120,6 @@ def main():
     ap.add_argument("--phases", type=int, default=3)
     ap.add_argument("--mReco", type=int, default=100)
     ap.add_argument("--batch", type=int, default=10240, help="max images per kernel launch")
-    ap.add_argument("--fixed-support", action="store_true",
-                    help="feed fixed, tightly clustered support points instead of running the particle filter")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles", type=int, default=0, help="CPU baseline sample (default: one particle per core)")
     ap.add_argument("--cpu-no-reconstruct", action="store_true")
@@ -137,11 +129,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    # test hook: THX_BENCH_ONE_DEVICE=1 runs every rank on GPU 0 with the gloo backend, so the multi-rank control flow
-    # (half-set groups, F/T all-reduce, half-map exchange, max-over-ranks timing) can be exercised on a 1-GPU box
-    one_dev = os.environ.get("THX_BENCH_ONE_DEVICE", "0") == "1"
-    if one_dev:
-        local = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -149,18 +136,30 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_dev:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev)
+        dist.init_process_group(backend="nccl", device_id=dev)
 
     from thunder_amd import capi
+    from thunder_amd.native import NativeRefine, make_comms, STAGES
     from thunder_amd.refine import RefineShard, shard_count
     capi.load()
 
+    # ---- synthetic particles of this rank (generation only; every other buffer belongs to the native driver) ----
     n_local = shard_count(args.particles, rank, world)
     shard = RefineShard(args.box, n_local, dev, rank=rank, world=world, mLR=args.mLR, mLT=args.mLT,
-                        nPhase=args.phases, mReco=args.mReco, batch=args.batch, particle_filter=not args.fixed_support)
+                        nPhase=args.phases, mReco=args.mReco, batch=args.batch, particle_filter=True, allocate=False)
+    shard.release_generation_state()
+
+    # ---- RCCL communicators in native code (thx_comm_*): the unique ids travel through the launcher's process group,
+    #      as the reference broadcasts them over MPI (gpu/src/cuthunder.cu:4192-4206) ----
+    def share_from(root, uid):
+        import torch.distributed as dist
+        box = [uid]
+        dist.broadcast_object_list(box, src=root)
+        return box[0]
+    hemi = wcomm = None
+    if world > 1:
+        hemi, wcomm = make_comms(rank, world, share_from)
+    nat = NativeRefine(shard, hemi, wcomm)
 
     def barrier():
         if world > 1:
@@ -169,16 +168,13 @@ def main():
         torch.cuda.synchronize()
 
     if args.warmup:
-        shard.reset_reference()
-        shard.run(args.warmup)
-    shard.reset_reference()
-    shard.insert_ms.clear()
-    shard.expect_ms.clear()
-    shard.stage_ms.clear()
-    shard.reco_rounds.clear()
+        nat.reset()
+        nat.run(args.warmup)
+    nat.reset()
+    nat.stats(reset=True)
     barrier()
     t0 = time.perf_counter()
-    fsc = shard.run(args.steps, timed=True)
+    fsc = nat.run(args.steps, timed=True)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -190,16 +186,17 @@ def main():
     if rank == 0:
         total_particles = args.particles * args.steps
         value = total_particles / dt
-        # per-launch averages of the two gather / scatter kernels from HIP events on the launch stream
-        ins = [(a.elapsed_time(b), n) for a, b, n in shard.insert_ms]
-        exp = [(a.elapsed_time(b), n) for a, b, n in shard.expect_ms]
-        ins_ms = float(np.mean([m for m, _ in ins]))
-        ins_n = float(np.mean([n for _, n in ins]))
-        ins_bytes = ins_n * shard.mReco * shard.nPxlM * INSERT_BYTES_PER_PIXEL_SAMPLE
-        exp_ms = float(np.mean([m for m, _ in exp]))
-        exp_n = float(np.mean([n for _, n in exp]))
-        exp_bytes = exp_n * shard.nPxl * (EXPECT_BYTES_PER_PIXEL + EXPECT_BYTES_PER_PIXEL_SAMPLE * shard.mLR)
-        t_ins, t_exp = sum(m for m, _ in ins), sum(m for m, _ in exp)
+        # per-launch averages of the two gather / scatter kernels: HIP events recorded by the native driver on its launch
+        # stream around every thx_expect_local_dev / thx_insert_dev call of the timed iterations
+        st = nat.stats()
+        nPxl, nPxlM = st.nPxl, st.nPxlM
+        ins_ms = st.insertMs / max(1, st.insertLaunches)
+        ins_n = st.insertImages / max(1, st.insertLaunches)
+        ins_bytes = ins_n * shard.mReco * nPxlM * INSERT_BYTES_PER_PIXEL_SAMPLE
+        exp_ms = st.expectMs / max(1, st.expectLaunches)
+        exp_n = st.expectImages / max(1, st.expectLaunches)
+        exp_bytes = exp_n * nPxl * (EXPECT_BYTES_PER_PIXEL + EXPECT_BYTES_PER_PIXEL_SAMPLE * shard.mLR)
+        t_ins, t_exp = st.insertMs, st.expectMs
         # dominant kernel by total time.  Only the E-step kernel has an HBM roofline that means something: the insertion
         # kernel accumulates in LDS (PMC: 35 MB of HBM traffic per image against 505 MB "algorithmic") and is bound by
         # its instruction stream / the LDS atomic rate, reported below as lds_add_frac.
@@ -223,7 +220,7 @@ def main():
         # insertion against its own bound: LDS integer adds per second vs the measured ds_add_u32 rate of the chip
         # (tools/lds_atomic_bench.hip, recorded in profiles/pmc_traffic.json).  24 adds per pixel-sample (8 voxels x re,
         # im, T); the insert plan merges draws with identical rotation, so the count below is an upper bound.
-        ins_terms_per_s = ins_n * shard.mReco * shard.nPxlM * 24 / (ins_ms * 1e-3)
+        ins_terms_per_s = ins_n * shard.mReco * nPxlM * 24 / (ins_ms * 1e-3)
         out = {
             "metric": "particles/sec per refinement iteration (256^3 box, 100k particles); achieved HBM GB/s",
             "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -233,11 +230,12 @@ def main():
                                    "phases x %d rot x %d shifts, %d inserts, 2 half-sets, 2x reconstruct per half, FSC, "
                                    "projector refresh)" % (args.particles, args.box, world, args.phases, args.mLR,
                                                            args.mLT, args.mReco),
-                       "box": args.box, "particles": args.particles, "particles_per_gpu": n_local, "nPxl": shard.nPxl,
+                       "box": args.box, "particles": args.particles, "particles_per_gpu": n_local, "nPxl": nPxl,
                        "pf": 2,
-                       "search_state": "fixed seeded support points" if args.fixed_support else
-                                       "device particle filter (perturb / resample every phase, Philox-seeded)",
-                       "parallelism": "particles sharded over %d GPU(s); half-set F/T all-reduce" % world},
+                       "search_state": "device particle filter (perturb / resample every phase, Philox-seeded)",
+                       "driver": "native C++ iteration driver (thx_refine_iterate) through the C ABI",
+                       "parallelism": "particles sharded over %d GPU(s); half-set F/T all-reduce in native RCCL "
+                                      "(thx_reco_allreduce)" % world},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kms,
                          "images_per_launch": exp_n, "algorithmic_bytes_per_launch": kbytes, "traffic_source": pmc_src},
@@ -247,13 +245,12 @@ def main():
                                          "GBps_algorithmic_204B": ins_bytes / (ins_ms * 1e-3) / 1e9},
                         "k_expect_local": {"avg_launch_ms": exp_ms, "images_per_launch": exp_n,
                                            "GBps_algorithmic": exp_bytes / (exp_ms * 1e-3) / 1e9, "total_ms": t_exp}},
-            "stages_ms_per_step": {k: round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 2)
-                                   for k, v in shard.stage_ms.items()},
-            "balancing_rounds_per_step": sum(shard.reco_rounds) / max(1, args.steps),
+            "stages_ms_per_step": {k: round(st.stageMs[i] / args.steps, 2) for i, k in enumerate(STAGES)},
+            "balancing_rounds_per_step": st.balancingRounds / max(1, args.steps),
             "fsc_half_maps": [round(float(x), 4) for x in fsc[: 8]],
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, shard, out["balancing_rounds_per_step"])
+            out["cpu_baseline"] = cpu_baseline(args, shard, nat, out["balancing_rounds_per_step"])
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -360,6 +360,123 @@ int thx_pf_acg_stats_dev(double* A, double* mean, double* k123, double* wBal, in
                          int n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Half-set exchange in native code (RCCL over xGMI; one process per GPU)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Communicator bootstrap as gpu/src/cuthunder.cu:4192-4206 does it (ncclGetUniqueId on the hemisphere's root, the id
+ * shared by the caller's launcher -- MPI_Bcast in the reference --, ncclCommInitRank on every member).  id128: 128 bytes.
+ * thx_comm_init binds the communicator to the CURRENT device.  A NULL thx_comm* or a communicator of size 1 makes
+ * every collective below a no-op. */
+typedef struct thx_comm thx_comm;
+int thx_comm_unique_id(void* id128);
+int thx_comm_init(thx_comm** out, const void* id128, int rank, int size);
+int thx_comm_destroy(thx_comm* c);
+int thx_comm_rank(const thx_comm* c);
+int thx_comm_size(const thx_comm* c);
+/* in-place collectives on DEVICE buffers, enqueued on `stream` */
+int thx_comm_allreduce_f32(thx_comm* c, float* buf, size_t count, void* stream);
+int thx_comm_allreduce_f64(thx_comm* c, double* buf, size_t count, void* stream);
+int thx_comm_allreduce_i32(thx_comm* c, int* buf, size_t count, void* stream);
+int thx_comm_allreduce_max_f64(thx_comm* c, double* buf, size_t count, void* stream);
+int thx_comm_broadcast(thx_comm* c, void* buf, size_t bytes, int root, void* stream);
+
+/* Reconstructor::allReduceF / allReduceT (src/Reconstructor.cpp:2350-2484, MPI_Allreduce_Large over _hemi) and the
+ * reference GPU path's ncclAllReduce of F, T, O, counter (gpu/src/cuthunder.cu:4972-5067): sums the accumulators over
+ * the ranks of the half, in place.  Only the voxels inside the sample sphere (radius maxRadius * pf + 2: inserted samples
+ * lie inside maxRadius * pf, their trilinear cells reach one further) travel: F (re, im) and T of those voxels are packed
+ * into ONE contiguous buffer (half of the grid), reduced by ONE ring all-reduce, and unpacked; voxels outside keep their
+ * local values (zero after insertion).  O (3 doubles) and counter (1 int) may be NULL.
+ * workspace: thx_reco_allreduce_workspace() bytes of device memory. */
+size_t thx_reco_allreduce_workspace(int dim, int maxRadius, int pf);
+int thx_reco_allreduce(thx_comm* hemi, float* F, float* T, double* O, int* counter, int dim, int maxRadius, int pf,
+                       void* workspace, void* stream);
+/* the pack (unpack = 0) / unpack (unpack = 1) halves of thx_reco_allreduce on their own (parity probe of the sphere-row
+ * tables on one GPU); *nVoxOut (host, optional) = packed voxels */
+int thx_reco_sphere_pack_dev(float* F, float* T, int dim, int maxRadius, int pf, void* workspace, int unpack, long* nVoxOut,
+                             void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The iteration driver in native code: Optimiser::expectation (src/Optimiser.cpp:1141-1660, local phases) +
+ * Optimiser::maximization (src/Optimiser.cpp:3405-3480: allReduceSigma :6395-6710, reconstructRef :6711-7766) +
+ * Model::compareTwoHemispheres / refreshProj + reCentreImg / reMaskImg (:6065-6149), sequenced on the host side of this
+ * library over one rank's HBM-resident shard of particles.  What bench.py times and tests/cpp/iteration.cpp drives.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Optimiser::allocPreCalIdx (src/Optimiser.cpp:7991-8041) on the host: the half-plane pixel list rL <= |k| < rU.
+ * order: 0 = the reference's row-major order, 1 = Morton (Z-order) visit order (the E-step's default).  Output arrays
+ * (may be NULL) hold at least (rU + 2) * (2 rU + 2) ints; *nPxl receives the count. */
+int thx_pixel_list_host(int N, int rU, int rL, int order, int* iCol, int* iRow, int* iPxl, int* iSig, int* nPxl);
+
+/* The mReco draws of the insertion (src/Optimiser.cpp:7129-7150) from a RESAMPLED filter (thx_pf_update_dev): uniform
+ * picks among the support points r [nImg][nR][4], t [nImg][nT][2] (Particle::rand, src/Particle.cpp:2109-2178) ->
+ * recoRot [nImg][mReco][9], recoTran [nImg][mReco][2].  Philox stream (seed, img0 + image, call, 7, draw). */
+int thx_draw_reco_dev(double* recoRot, double* recoTran, const double* r, const double* t, int nImg, int nR, int nT, int mReco,
+                      unsigned long long seed, unsigned call, unsigned img0, void* stream);
+
+typedef struct thx_refine thx_refine;
+typedef struct thx_refine_config {
+    int N, pf;                 /* box size, padding factor */
+    int nImg;                  /* particles of this rank */
+    int halfOfRank;            /* -1: both half-sets live on this rank ([0, nHalfA) = half 0, the rest = half 1);
+                                  0 / 1: the whole shard belongs to that half (odd / even ranks, src/Parallel.cpp:26-36) */
+    int nHalfA;
+    int mLR, mLT, nPhase, mReco;  /* script/demo_3D.json: 125, 9, 3 (MIN_N_PHASE_PER_ITER_LOCAL), 100 */
+    int batch;                 /* images per kernel launch, at most */
+    int rL;                    /* lower cut-off of the E-step pixel list (Optimiser::_rL) */
+    int nGroup, groupSig;      /* micrograph groups, OPTIMISER_SIGMA_GROUP */
+    int pixelOrder;            /* E-step pixel list: 0 row-major, 1 Morton */
+    int wgPerCU;               /* occupancy argument of thx_expect_local_dev */
+    float pixelSize, maskRadiusPx, sigma2Init;
+    double transS, transQ;     /* Optimiser::_para.transS, TRANS_Q (include/Optimiser.h:67) */
+    double pfL, pfS;           /* perturbation factors of the first / later phases (script/demo_3D.json:71-73) */
+    double peakFactorR;        /* PEAK_FACTOR_MIN */
+    unsigned long long seed;
+} thx_refine_config;
+
+typedef struct thx_refine_stats {
+    double expectMs, insertMs;            /* HIP-event totals of the local-search / insertion launches (timed iterations) */
+    long expectLaunches, expectImages, insertLaunches, insertImages;
+    double stageMs[8];                    /* rows, expectation, sigma, insertion, reconstruct (+FSC, refresh), recentre+remask */
+    long balancingRounds, iterations;
+    int nPxl, nPxlM, batch;
+} thx_refine_stats;
+
+/* hemi: communicator of this rank's half (NULL = the half lives on this rank alone); world: all ranks (NULL = one rank) */
+int thx_refine_create(thx_refine** out, const thx_refine_config* cfg, thx_comm* hemi, thx_comm* world);
+int thx_refine_destroy(thx_refine* h);
+/* imgOri DEVICE complex64 [nImg][N][N/2+1] as Optimiser::initImg leaves _imgOri -- BORROWED until destroy;
+ * attr DEVICE [nImg]; groupID HOST [nImg] 1-based; quat0 DEVICE [nImg][mLR][4], tran0 DEVICE [nImg][mLT][2] initial
+ * support points of the particle filter (Particle::load). */
+int thx_refine_set_particles(thx_refine* h, const float* imgOri, const thx_ctf_attr* attr, const int* groupID_host,
+                             const double* quat0, const double* tran0, void* stream);
+int thx_refine_set_reference(thx_refine* h, const float* refRL, void* stream);   /* DEVICE [N]^3 initial map */
+int thx_refine_reset(thx_refine* h, void* stream);     /* the state before the first iteration */
+/* one EM iteration; fscHost (optional) [N/2] receives the half-map FSC; timed != 0 records HIP events for thx_refine_stats.
+ * Synchronises the stream (FSC to the host between the two reconstructions, and the gridding loop's stop rule). */
+int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream);
+int thx_refine_get_map(thx_refine* h, int half, float* dstRL, void* stream);       /* DEVICE [N]^3, the MAP-on map */
+/* DEVICE copies of the per-particle state (any pointer may be NULL): offset [nImg][2], topR [nImg][4], topT [nImg][2],
+ * sig [local halves][nGroup][N/2-1] */
+int thx_refine_get_state(thx_refine* h, double* offset, double* topR, double* topT, float* sig, void* stream);
+int thx_refine_get_stats(thx_refine* h, thx_refine_stats* out, int reset);
+/* read-only DEVICE views of the handle's resident state (valid until destroy; contents change with every iteration):
+ * what tests compare against the oracle and bench.py's cpu_baseline leg copies its sample from */
+typedef struct thx_refine_view {
+    int nImg, nPxl, nPxlM, nVol, vdim, rSig;
+    const int *iCol, *iRow, *iPxl, *iSig, *iColM, *iRowM; /* E-step list [nPxl] (in visit order), M-step list [nPxlM] */
+    const float *img;                       /* [nImg][N][N/2+1] complex64: re-centred, masked images (_img) */
+    const float *datP, *ctfP, *sigRcpP;     /* E-step rows [nImg][nPxl] (complex64 / f32 / f32) */
+    const float *datM, *ctfM;               /* M-step rows [nImg][nPxlM] */
+    const double *r, *t, *wR, *wT;          /* particle filter: [nImg][mLR][4], [nImg][mLT][2], priors */
+    const double *offset;                   /* [nImg][2] */
+    const float *vols, *cells;              /* [nVol] projector FTs / their cell-packed copies */
+    const float *F, *T;                     /* [nVol] accumulators of the last iteration (after prepareTF / Wiener term) */
+    const float *sig;                       /* [nVol][nGroup][rSig] */
+    const double *recoRot, *recoTran;       /* draws of the LAST inserted local half [n][mReco][9] / [n][mReco][2] */
+} thx_refine_view;
+int thx_refine_get_view(thx_refine* h, thx_refine_view* out);
+
+/* ---------------------------------------------------------------------------------------------
  * Interface.h-shaped HOST-pointer entry points (what -DGPU_VERSION call sites bind to)
  * ------------------------------------------------------------------------------------------- */
 

@@ -52,3 +52,26 @@ def test_no_oracle_in_product_path():
                 if re.search(r"from\s+oracle|import\s+oracle|thunder_oracle|libthunder_oracle", t):
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_native_pixel_list_matches_python():
+    """Optimiser::allocPreCalIdx on the host, three statements of it: the oracle's C, the harness's Python and the native
+    driver's C++ (thx_pixel_list_host), incl. the Morton visit order"""
+    import ctypes as C
+    import numpy as np
+    from oracle import oracle as O
+    from thunder_amd import capi
+    from thunder_amd.refine import pixel_list, pixel_visit_order
+    for N, rL in ((16, 0), (32, 1), (64, 2), (256, 2), (256, 0)):
+        rU = N // 2 - 2
+        pl, po = pixel_list(N, rU, rL), O.pixel_list(N, rU, rL, 2)
+        cap = (rU + 2) * (2 * rU + 2)
+        for order in (0, 1):
+            out = [np.zeros(cap, np.int32) for _ in range(4)]
+            n = C.c_int(0)
+            capi.call("thx_pixel_list_host", N, rU, rL, order, *[a.ctypes.data for a in out], C.byref(n))
+            assert n.value == pl["nPxl"] == po["nPxl"]
+            perm = np.arange(n.value) if order == 0 else pixel_visit_order(pl, N)
+            for a, k in zip(out, ("iCol", "iRow", "iPxl", "iSig")):
+                assert np.array_equal(a[:n.value], pl[k][perm]), (N, rL, order, k)
+                assert np.array_equal(pl[k], po[k])

@@ -214,16 +214,25 @@ def test_expect_local_bench_settings_n256(oracle, dev):
         print("expect_local N=256 oracle: %.1f s" % (time.perf_counter() - t0))
         wl = want["logW"][:, :, 0].T            # [nT][nR]
         got = res.logW[l, 0].cpu().numpy()
-        # float sums of 24742 terms: error scale eps * |C|, C = sum sigRcp |dat|^2
+        # The oracle's (= the reference's scalar) sequential float sum of 24742 terms of like sign carries ~5e-6 |L| of
+        # rounding drift; the stated bar between two summation orders is 1e-5 max|L| (src/Optimiser.cpp:25-79).  Against
+        # the fp64 value of the same sum the device must be within 5e-7 |C| (C = sum sigRcp |dat|^2).
+        scale = np.abs(wl).max()
+        assert np.abs(got - wl).max() <= 1e-5 * scale, (np.abs(got - wl).max(), scale)
         Cabs = abs(float(np.sum(sig[l].astype(np.float64) * np.abs(dat[l].astype(np.complex128)) ** 2)))
-        assert np.abs(got - wl).max() <= 1e-6 * Cabs, (np.abs(got - wl).max(), Cabs)
-        dg, dw = got - got.max(), wl - wl.max()
-        assert np.abs(dg - dw).max() <= 1e-6 * Cabs
-        rtol = 3 * max(2e-6 * Cabs, 1e-4)
-        np.testing.assert_allclose(res.wR[l].cpu().numpy(), want["wR"].reshape(-1), rtol=rtol)
-        np.testing.assert_allclose(res.wT[l].cpu().numpy(), want["wT"].reshape(-1), rtol=rtol)
-        np.testing.assert_allclose(res.wC[l].item(), float(np.asarray(want["wC"]).reshape(-1)[0]), rtol=rtol)
-        assert int(res.wR[l].argmax()) == int(np.argmax(want["wR"]))
+        for (ir, it) in [(0, 0), (7, 3), (64, 8), (124, 5), (33, 1)]:
+            sl = O.project(vol_h, P, 2, rot_h[l, ir], pl["iCol"], pl["iRow"])
+            ramp = O.translate(np.float32(tran_h[l, it, 0]), np.float32(tran_h[l, it, 1]), N, pl["iCol"], pl["iRow"])
+            exact = O.logDataVSPrior_f64(dat[l], ramp * sl, ctf[l], sig[l])
+            assert abs(got[it, ir] - exact) <= 5e-7 * Cabs, (got[it, ir], exact, Cabs)
+            assert abs(got[it, ir] - exact) <= abs(wl[it, ir] - exact) + 2e-7 * Cabs   # no worse than the reference's own sum
+        tolw = max(2e-5 * scale, 1e-4)
+        for name in ("wR", "wT", "wC"):
+            g = getattr(res, name)[l].cpu().numpy().reshape(-1)
+            np.testing.assert_allclose(g, np.asarray(want[name]).reshape(-1), rtol=3 * tolw, atol=1e-30, err_msg=name)
+        # the device's best rotation is (one of) the oracle's best
+        wRo = want["wR"].reshape(-1)
+        assert wRo[int(res.wR[l].argmax())] >= (1 - 3 * tolw) * wRo.max()
 
 
 @pytest.mark.parametrize("nT", [16, 32])

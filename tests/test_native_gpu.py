@@ -1,0 +1,128 @@
+"""The native iteration driver (thx_refine_*) and the native RCCL layer (thx_comm_*) on the GPU box.
+
+* the C++ driver reproduces the Python harness (thunder_amd.refine.RefineShard, the sequencing the other GPU tests use)
+  on the same particles: same kernels, same Philox streams -> identical particle-filter decisions in the first iteration,
+  half maps and FSC that agree to the accuracy the atomically inserted F / T allow;
+* RCCL itself: with one GPU a one-rank communicator is the only one RCCL will build; THX_COMM_FORCE=1 makes the library
+  issue the real ncclAllReduce / ncclBroadcast calls on it (sum over one rank = identity), which exercises the bootstrap,
+  the sphere-row packing and the collective calls of thx_reco_allreduce end to end;
+* tests/cpp/iteration.cpp: a torch-free C++ program driving rows -> phases -> sigma -> insert -> reduce -> reconstruct x 2
+  -> refresh through the C ABI only (two processes over RCCL when two GPUs are visible).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def test_native_driver_matches_python_harness(dev):
+    from thunder_amd import ops
+    from thunder_amd.native import NativeRefine
+    from thunder_amd.refine import RefineShard
+    N, n = 64, 700
+    sh = RefineShard(N, n, dev, mReco=20, batch=256)          # three batches per half: the batched paths are exercised
+    nat = NativeRefine(sh)
+    nat.reset()
+    v = nat.view()
+    assert (v.nPxl, v.nPxlM) == (sh.nPxl, sh.nPxlM)
+    # identical pixel lists (host integer work on both sides) and identical state after reset
+    assert np.array_equal(nat.fetch(v.iCol, np.int32, (sh.nPxl,)), sh.pl["iCol"])
+    assert np.array_equal(nat.fetch(v.iRow, np.int32, (sh.nPxl,)), sh.pl["iRow"])
+    assert np.array_equal(nat.fetch(v.datP, np.complex64, (n, sh.nPxl)), sh.datP.cpu().numpy())
+    assert np.array_equal(nat.fetch(v.ctfP, np.float32, (n, sh.nPxl)), sh.ctfP.cpu().numpy())
+    assert np.array_equal(nat.fetch(v.sigRcpP, np.float32, (n, sh.nPxl)), sh.sigRcpP.cpu().numpy())
+    assert np.array_equal(nat.fetch(v.vols, np.complex64, tuple(sh.vols.shape)), sh.vols.cpu().numpy())
+    fsc_py = sh.run(1)
+    fsc_na = nat.iterate(timed=True)
+    off, topR, topT = nat.state()
+    # first iteration: every particle-filter decision is a function of bit-identical likelihoods and the same Philox
+    # streams, so the top poses and the re-centring offsets agree exactly
+    assert torch.equal(topR, sh.pf_state["topR"]) and torch.equal(topT, sh.pf_state["topT"])
+    assert torch.equal(off, sh.offset)
+    # sigma tables: deterministic kernels on identical inputs
+    sig = nat.fetch(v.sig, np.float32, tuple(sh.sig.shape))
+    np.testing.assert_allclose(sig, sh.sig.cpu().numpy(), rtol=1e-6)
+    # maps: the inserted F / T differ in the last bits (atomic order), the gridding loop amplifies that a little
+    for h in (0, 1):
+        a, b = nat.map(h), sh.last["maps"][h]
+        fs = ops.fsc(ops.fft3d_fw(a), ops.fft3d_fw(b), N, N // 2).cpu().numpy()
+        assert np.all(fs[:N // 2 - 3] >= 0.999), fs
+        assert (a - b).abs().max().item() <= 2e-3 * b.abs().max().item()
+    np.testing.assert_allclose(fsc_na[:N // 2 - 3], fsc_py[:N // 2 - 3], atol=2e-3)
+    # second iteration keeps tracking
+    fsc_py2, fsc_na2 = sh.run(1), nat.iterate(timed=True)
+    np.testing.assert_allclose(fsc_na2[:N // 2 - 3], fsc_py2[:N // 2 - 3], atol=1e-2)
+    same = (nat.state()[1] == sh.pf_state["topR"]).all(dim=1).float().mean().item()
+    assert same >= 0.9, same
+    st = nat.stats()
+    assert st.iterations == 2 and st.expectLaunches == 2 * 2 * sh.nPhase * 2 and st.insertLaunches == 2 * 2 * 2
+    assert st.expectImages == 2 * sh.nPhase * n and st.insertImages == 2 * n and st.expectMs > 0 and st.insertMs > 0
+    assert st.balancingRounds >= 2 * 4 * 5
+    nat.close()
+
+
+def test_native_rccl_single_rank_forced(dev, knob_env):
+    from thunder_amd import capi
+    from thunder_amd.capi import ptr, stream_ptr
+    from thunder_amd.native import Comm
+    knob_env("THX_COMM_FORCE", "1")
+    comm = Comm(0, 1, lambda uid: uid)
+    assert capi.load().thx_comm_size(comm.handle) == 1 and capi.load().thx_comm_rank(comm.handle) == 0
+    g = torch.Generator(device=dev).manual_seed(5)
+    a = torch.randn(100003, device=dev, generator=g)
+    a0 = a.clone()
+    comm.allreduce(a)
+    d = torch.randn(77, device=dev, generator=g, dtype=torch.float64)
+    d0 = d.clone()
+    comm.allreduce(d)
+    b = torch.arange(1000, device=dev, dtype=torch.int32)
+    comm.broadcast(b, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(a, a0) and torch.equal(d, d0) and torch.equal(b, torch.arange(1000, device=dev, dtype=torch.int32))
+    # thx_reco_allreduce: pack the sphere rows -> ncclAllReduce over the one rank -> unpack: F, T, O, counter unchanged
+    P, rU, pf = 128, 30, 2
+    F = torch.randn((P, P, P // 2 + 1, 2), device=dev, generator=g)
+    T = torch.rand((P, P, P // 2 + 1), device=dev, generator=g)
+    O = torch.tensor([1.5, -2.0, 3.25], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([42], dtype=torch.int32, device=dev)
+    F0, T0 = F.clone(), T.clone()
+    need = capi.load().thx_reco_allreduce_workspace(P, rU, pf)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    capi.call("thx_reco_allreduce", comm.handle, ptr(F), ptr(T), ptr(O), ptr(cnt), P, rU, pf, ptr(ws), stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(F, F0) and torch.equal(T, T0) and cnt.item() == 42 and O.tolist() == [1.5, -2.0, 3.25]
+    # the packed buffer holds exactly the sphere voxels: pack, wipe the volumes, unpack -> inside restored, outside zero
+    nvox = C.c_long(0)
+    capi.call("thx_reco_sphere_pack_dev", ptr(F), ptr(T), P, rU, pf, ptr(ws), 0, C.byref(nvox), stream_ptr())
+    F.zero_(); T.zero_()
+    capi.call("thx_reco_sphere_pack_dev", ptr(F), ptr(T), P, rU, pf, ptr(ws), 1, None, stream_ptr())
+    ax = torch.fft.fftfreq(P, d=1.0 / P, device=dev)
+    r2 = ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :P // 2 + 1] ** 2
+    R = rU * pf + 2
+    row_len = torch.floor(torch.sqrt((R * R - ax[:, None] ** 2 - ax[None, :] ** 2).clamp_min(-1))) + 1
+    inside = (ax[None, None, :P // 2 + 1] < row_len[:, :, None]) & ((ax[:, None] ** 2 + ax[None, :] ** 2) <= R * R)[:, :, None]
+    assert int(inside.sum()) == nvox.value
+    assert bool((r2 <= (R - 1) ** 2)[inside.logical_not()].logical_not().all())      # every voxel within R - 1 travels
+    assert torch.equal(T[inside], T0[inside]) and torch.equal(F[inside], F0[inside])
+    assert T[~inside].abs().max().item() == 0 and F[~inside].abs().max().item() == 0
+    comm.close()
+
+
+def test_cpp_iteration_driver(dev, tmp_path):
+    """tests/cpp/iteration.cpp: torch-free C++ over the C ABI -- synthetic particles, thx_refine_create ... iterate x 2,
+    half-map FSC and agreement with the generating map; with >= 2 GPUs it forks two ranks that reduce over RCCL"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "iteration")
+    libdir = os.path.join(root, "thunder_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "iteration.cpp"), "-o", exe, "-L" + libdir,
+                           "-lthunder_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+    print(out.stdout)

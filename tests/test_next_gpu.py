@@ -393,21 +393,24 @@ def test_against_committed_golden_next(dev):
 
 
 @pytest.mark.parametrize("world", [2, 4])
-def test_multirank_bench_control_flow_on_one_device(dev, world):
-    """bench.py under torch.distributed.run with every rank on GPU 0 (gloo instead of RCCL: THX_BENCH_ONE_DEVICE=1):
-    half-set groups, the F/T all-reduce within a half (world 4), the half-map exchange and the max-over-ranks timing"""
+def test_multirank_bench_native_rccl(dev, world):
+    """bench.py under torch.distributed.run, one rank per GPU: native RCCL communicators (thx_comm_*), the F/T all-reduce
+    within a half (world 4), the half-map exchange and the max-over-ranks timing.  Needs `world` GPUs (RCCL refuses two
+    ranks on one device): skipped on the 1-GPU box, where tests/test_native_gpu.py drives the same RCCL calls through a
+    one-rank communicator and tests/test_dist_cpu.py the sharding / grouping logic over gloo."""
     import json
     import os
     import socket
     import subprocess
     import sys
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs" % world)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, THX_BENCH_ONE_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "1",
            "--warmup", "1", "--box", "32", "--particles", str(300 * world), "--mReco", "20"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # rank 0 prints ONE line

@@ -10,8 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libthunder_amd.so")
-SOURCES = ["thx_estep.hip", "thx_mstep.hip", "thx_reco.hip", "thx_next.hip", "thx_io.hip", "thx_pf.hip", "thx_iface.hip", "thx_host.hip"]
-HEADERS = ["thx_common.h", "thx_fft8.h", os.path.join("..", "..", "include", "thunder_amd.h")]
+SOURCES = ["thx_estep.hip", "thx_mstep.hip", "thx_reco.hip", "thx_next.hip", "thx_io.hip", "thx_pf.hip", "thx_iface.hip", "thx_host.hip", "thx_comm.hip", "thx_refine.hip"]
+HEADERS = ["thx_common.h", "thx_fft8.h", "thx_philox.h", os.path.join("..", "..", "include", "thunder_amd.h")]
 
 # -ffp-contract=off: see thx_common.h (bit-identical trilinear arithmetic); fused ops are written out as fmaf().
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -53,7 +53,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s" % s)
         if verbose and out:
             sys.stderr.write(out.decode(errors="replace"))
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lhipfft"]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lhipfft", "-lrccl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

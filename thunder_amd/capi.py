@@ -22,6 +22,32 @@ class CtfAttr(C.Structure):
                 ("phaseShift", C.c_float)]
 
 
+class RefineConfig(C.Structure):
+    """thx_refine_config (include/thunder_amd.h)"""
+    _fields_ = [("N", C.c_int), ("pf", C.c_int), ("nImg", C.c_int), ("halfOfRank", C.c_int), ("nHalfA", C.c_int),
+                ("mLR", C.c_int), ("mLT", C.c_int), ("nPhase", C.c_int), ("mReco", C.c_int), ("batch", C.c_int),
+                ("rL", C.c_int), ("nGroup", C.c_int), ("groupSig", C.c_int), ("pixelOrder", C.c_int), ("wgPerCU", C.c_int),
+                ("pixelSize", C.c_float), ("maskRadiusPx", C.c_float), ("sigma2Init", C.c_float),
+                ("transS", C.c_double), ("transQ", C.c_double), ("pfL", C.c_double), ("pfS", C.c_double),
+                ("peakFactorR", C.c_double), ("seed", C.c_ulonglong)]
+
+
+class RefineStats(C.Structure):
+    """thx_refine_stats (include/thunder_amd.h)"""
+    _fields_ = [("expectMs", C.c_double), ("insertMs", C.c_double), ("expectLaunches", C.c_long), ("expectImages", C.c_long),
+                ("insertLaunches", C.c_long), ("insertImages", C.c_long), ("stageMs", C.c_double * 8),
+                ("balancingRounds", C.c_long), ("iterations", C.c_long), ("nPxl", C.c_int), ("nPxlM", C.c_int),
+                ("batch", C.c_int)]
+
+
+class RefineView(C.Structure):
+    """thx_refine_view (include/thunder_amd.h): device pointers as integers"""
+    _fields_ = [(n, C.c_int) for n in ("nImg", "nPxl", "nPxlM", "nVol", "vdim", "rSig")] + \
+               [(n, C.c_void_p) for n in ("iCol", "iRow", "iPxl", "iSig", "iColM", "iRowM", "img", "datP", "ctfP", "sigRcpP",
+                                          "datM", "ctfM", "r", "t", "wR", "wT", "offset", "vols", "cells", "F", "T", "sig",
+                                          "recoRot", "recoTran")]
+
+
 _vp = C.c_void_p
 _i = C.c_int
 _f = C.c_float
@@ -41,6 +67,31 @@ SIGNATURES = {
     "thx_memset_dev": (_i, [_vp, _i, _sz]),
     "thx_device_sync": (_i, []),
     "thx_knobs_reload": (_i, []),
+    "thx_comm_unique_id": (_i, [_vp]),
+    "thx_comm_init": (_i, [C.POINTER(_vp), _vp, _i, _i]),
+    "thx_comm_destroy": (_i, [_vp]),
+    "thx_comm_rank": (_i, [_vp]),
+    "thx_comm_size": (_i, [_vp]),
+    "thx_comm_allreduce_f32": (_i, [_vp, _vp, _sz, _vp]),
+    "thx_comm_allreduce_f64": (_i, [_vp, _vp, _sz, _vp]),
+    "thx_comm_allreduce_i32": (_i, [_vp, _vp, _sz, _vp]),
+    "thx_comm_allreduce_max_f64": (_i, [_vp, _vp, _sz, _vp]),
+    "thx_comm_broadcast": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "thx_reco_allreduce_workspace": (_sz, [_i, _i, _i]),
+    "thx_reco_allreduce": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "thx_reco_sphere_pack_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, C.POINTER(C.c_long), _vp]),
+    "thx_pixel_list_host": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
+    "thx_draw_reco_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_ulonglong, C.c_uint, C.c_uint, _vp]),
+    "thx_refine_create": (_i, [C.POINTER(_vp), C.POINTER(RefineConfig), _vp, _vp]),
+    "thx_refine_destroy": (_i, [_vp]),
+    "thx_refine_set_particles": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "thx_refine_set_reference": (_i, [_vp, _vp, _vp]),
+    "thx_refine_reset": (_i, [_vp, _vp]),
+    "thx_refine_iterate": (_i, [_vp, _vp, _i, _vp]),
+    "thx_refine_get_map": (_i, [_vp, _i, _vp, _vp]),
+    "thx_refine_get_state": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "thx_refine_get_stats": (_i, [_vp, C.POINTER(RefineStats), _i]),
+    "thx_refine_get_view": (_i, [_vp, C.POINTER(RefineView)]),
     "thx_rotmat_dev": (_i, [_vp, _vp, _i, _vp]),
     "thx_translate_dev": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "thx_ctf_dev": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp]),

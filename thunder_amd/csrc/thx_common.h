@@ -55,6 +55,7 @@ struct Knobs {
     bool fftRocfft;       // THX_FFT=rocfft: library transforms in the gridding loop for every size
     bool recoTrace;       // THX_RECO_TRACE: print diffC per balancing round
     int insertDebug;      // THX_INSERT_DEBUG (honoured only with -DTHX_PROFILING)
+    bool commForce;       // THX_COMM_FORCE=1: issue the RCCL calls on one-rank communicators too (1-GPU test of the path)
 };
 const Knobs& knobs();
 

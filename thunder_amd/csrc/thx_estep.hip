@@ -44,6 +44,8 @@ static Knobs read_knobs()
     v.recoTrace = getenv("THX_RECO_TRACE") != nullptr;
     e = getenv("THX_INSERT_DEBUG");
     v.insertDebug = e ? atoi(e) : 0;
+    e = getenv("THX_COMM_FORCE");
+    v.commForce = e && e[0] == '1';
     return v;
 }
 

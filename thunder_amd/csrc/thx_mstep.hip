@@ -313,55 +313,11 @@ __device__ __forceinline__ void insert_tiny_term(float2* F, float* T, int P, int
 
 // A group whose plane is far from the image's reference plane (|normal component along the shear axis| < kFarGroup, i.e.
 // more than ~18 degrees away: a draw from another posterior mode): the sheared-window geometry degenerates for it (slopes
-// -n/gna unbounded), so the whole workgroup adds it with plain float atomics -- the arithmetic of k_insert for the group's
-// summed ramps.  Rare by construction; correctness never depends on how the draws are spread.
+// -n/gna unbounded), so k_insert_win skips it and k_insert_far (one workgroup per image, launched behind it) adds it with
+// plain float atomics -- the arithmetic of k_insert for the group's summed ramps.  A separate kernel on purpose: inlined
+// or called from k_insert_win its registers cost the hot kernel 48 spilled VGPRs (1.5x slower).  Rare by construction;
+// correctness never depends on how the draws are spread.
 constexpr float kFarGroup = 0.3f;
-
-struct DrawTables;
-struct InsertWinArgs;
-__device__ __attribute__((noinline)) void insert_far_group(const InsertWinArgs& wa, const DrawTables& dt, int img, int gi_, float wgt);
-
-__device__ __attribute__((noinline)) void insert_far_group(const InsertWinArgs& wa, const DrawTables& dt, int img, int gi_, float wgt)
-{
-    const InsertArgs& a = wa.a;
-    const int P = a.P;
-    const size_t volSize = (size_t)P * P * (P / 2 + 1);
-    const double* R = dt.R + 6 * gi_;
-    const int m0 = dt.gStart[gi_], m1 = dt.gStart[gi_ + 1];
-    const float nmem = (float)(m1 - m0);
-    float2* F = a.F + (size_t)dt.gInfo[2 * gi_] * volSize;
-    float* T = a.T + (size_t)dt.gInfo[2 * gi_] * volSize;
-    for (int p = threadIdx.x; p < a.nPxl; p += blockDim.x) {
-        const int pi = a.iCol[p], pj = a.iRow[p];
-        const float2 dv = a.datP[(size_t)img * a.nPxl + p];
-        float cf = a.ctfP[(size_t)img * a.nPxl + p];
-        const float2 S = insert_ramp_sum_slow(dt.slope, dt.mUid, m0, m1, pi, pj);
-        const float2 tv = cmul(dv, S);
-        if (a.cSearch) cf = insert_ctf_search(a.attr, a.dfac, img, a.mReco, dt.gInfo[2 * gi_ + 1], a.pixelSize, a.idim, pi, pj);
-        float vre = tv.x * cf, vim = tv.y * cf;
-        vre = vre * 1.0f; vim = vim * 1.0f;
-        vre = vre * wgt; vim = vim * wgt;
-        const float tval = (pow2f_(cf) * 1.0f * wgt) * nmem;
-        const int icp = pi * a.opf, irp = pj * a.opf;
-        const float x = (float)(R[0] * icp + R[3] * irp), y = (float)(R[1] * icp + R[4] * irp), z = (float)(R[2] * icp + R[5] * irp);
-        if (!coord_in_grid(x, y, z, P)) continue;
-        TriCell cell;
-        tri_cell(cell, x, y, z, P);
-        if (cell.conj) vim = -vim;
-#pragma unroll
-        for (int kk = 0; kk < 2; kk++)
-#pragma unroll
-            for (int jj = 0; jj < 2; jj++)
-#pragma unroll
-                for (int ii = 0; ii < 2; ii++) {
-                    const float wv = cell.w[kk * 4 + jj * 2 + ii];
-                    const long idx = cell.rowOff[kk][jj] + ii;
-                    unsafeAtomicAdd(&F[idx].x, vre * wv);
-                    unsafeAtomicAdd(&F[idx].y, vim * wv);
-                    unsafeAtomicAdd(&T[idx], tval * wv);
-                }
-    }
-}
 
 // accumulate group gi_'s candidates of this window/slab (one wave), AX = dominant axis of the reference plane
 // Geometry of one (group, pixel) sample against the current window / slab: cell origin, brick coordinates of its
@@ -528,12 +484,15 @@ __device__ __forceinline__ void win_enqueue(const InsertWinArgs& wa, const WinGe
     const int nCand = nI * nJ;
     const float rnI = 1.0f / (float)nI;
     // rows pa, qa, AX of the group's rotation: (p, q) of a pixel and its height above the sheared reference plane.  Margins:
-    // cell extent, Hermitian fold and float rounding in (p, q); |d(a - sp p - sq q)| <= 1 + |sp| + |sq| <= 3 between a
-    // sample and the voxels of its cell, + 1 for the floor of the shear, in the height.
+    // a voxel of a sample's cell sits at sample + d, d in (-1, 1] per axis, and d_x in [-2, 0) for a Hermitian-folded sample
+    // (its brick x is -1 - X).  Its slab offset is  off = (wf - w0) + d_a - sp d_p - sq d_q + frac,  frac in [0, 1) the
+    // floor of the shear, |sp|, |sq| <= 1: off - (wf - w0) lies in [-4, 5), so a voxel inside the slab (0 <= off < kWz) needs
+    // wf in (w0 - 5, w0 + kWz + 4].  (The first version used +-3.5 / 4.5: samples of planes with both slopes near 1 were
+    // dropped at slab boundaries -- 1e-5 of the mass, 5e-3 of max T at single voxels; tests/test_fullsize_gpu.py.)
     const float A00 = (float)R[pa] * (float)a.opf, A01 = (float)R[3 + pa] * (float)a.opf, A10 = (float)R[qa] * (float)a.opf,
                 A11 = (float)R[3 + qa] * (float)a.opf, A20 = (float)R[AX] * (float)a.opf, A21 = (float)R[3 + AX] * (float)a.opf;
     const float plo = (float)g.p0 - 2.5f, phi = (float)(g.p0 + kWd) + 1.5f, qlo = (float)g.q0 - 2.5f, qhi = (float)(g.q0 + kWd) + 1.5f;
-    const float wlo = (float)g.w0 - 4.5f, whi = (float)(g.w0 + kWz) + 3.5f;
+    const float wlo = (float)g.w0 - 5.25f, whi = (float)(g.w0 + kWz) + 4.25f;
     for (int c0 = 0; c0 < nCand; c0 += 64) {
         const int c = c0 + lane;
         bool hit = false;
@@ -692,13 +651,6 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
     g.q0 = wa.pOrg + wqI * kWd;
     g.pix = sPix; g.ecol = sEc; g.erow = sEr;
     const float wBound = sqrtf(wa.rMax2) * (1.0f + fabsf(g.sp) + fabsf(g.sq)) + 4.0f;
-    if (wqI == 0) {   // groups far from the reference plane (another posterior mode): plain atomics, once per image
-        for (int gi_ = 0; gi_ < G; gi_++) {
-            const double* R = sR + 6 * gi_;
-            const float gna = (float)(ax == 0 ? R[1] * R[5] - R[2] * R[4] : (ax == 1 ? R[2] * R[3] - R[0] * R[5] : R[0] * R[4] - R[1] * R[3]));
-            if (fabsf(gna) < kFarGroup) insert_far_group(wa, dt, img, gi_, wgt);
-        }
-    }
 
     const int nPass = a.cls ? a.nK : 1;
     for (int pass = 0; pass < nPass; pass++) {
@@ -734,7 +686,7 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
                 box[1] = 0;
                 if (a.cls && sGInfo[2 * gi_] != pass) continue;
                 // (p, q) = opf * A (i, j),  A = rows pa, qa of the first two columns of R; det = +-(the normal's component
-                // along the shear axis): groups with |det| < kFarGroup are handled by insert_far_group
+                // along the shear axis): groups with |det| < kFarGroup are handled by k_insert_far
                 const float A00 = (float)R[pa], A01 = (float)R[3 + pa], A10 = (float)R[qa], A11 = (float)R[3 + qa];
                 const float det = A00 * A11 - A01 * A10;
                 if (fabsf(det) < 0.5f * kFarGroup) continue;
@@ -760,7 +712,7 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
                 const float gna = ax == 0 ? gn0 : (ax == 1 ? gn1 : gn2);
                 // A draw from a far-away posterior mode can be (nearly) parallel to the shear axis: its slopes -n/gna blow up
                 // (gna -> 0; NaN at 0) and its candidate box is the whole image.  Such groups never enter the window walk:
-                // insert_far_group adds them with plain atomics, once per image.
+                // k_insert_far adds them with plain atomics, once per image.
                 if (fabsf(gna) < kFarGroup) { box[1] = 0; continue; }
                 const float gsp = -(pa == 0 ? gn0 : gn1) / gna, gsq = -(qa == 1 ? gn1 : gn2) / gna;
                 float wmin = 1e30f, wmax = -1e30f;
@@ -773,10 +725,11 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
                 // every sample satisfies |a - sp p - sq q| <= rMax (1 + |sp| + |sq|): slabs beyond that hold nothing
                 wmin = fmaxf(wmin, -wBound); wmax = fminf(wmax, wBound);
                 if (wmin > wmax) { box[1] = 0; continue; }
-                sWr[2 * gi_] = wmin - 3.0f;
-                sWr[2 * gi_ + 1] = wmax + 3.0f;
-                lWlo = min(lWlo, (int)floorf(wmin - 3.0f));
-                lWhi = max(lWhi, (int)ceilf(wmax + 3.0f));
+                // slabs this group can reach: a voxel offset in [0, kWz) needs w0 in (wf - kWz - 4, wf + 5), wf in [wmin, wmax]
+                sWr[2 * gi_] = wmin - 4.25f;
+                sWr[2 * gi_ + 1] = wmax + 5.25f;
+                lWlo = min(lWlo, (int)floorf(wmin - 4.25f));
+                lWhi = max(lWhi, (int)ceilf(wmax + 5.25f));
             }
             if (tid < ((G + 63) & ~63)) {   // the waves that held groups (wave-uniform condition)
 #pragma unroll
@@ -850,6 +803,78 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
                 else insert_win_flush<2>(a, g, sRe, sIm, sT, F, T);
                 lds_barrier();   // the flush's global atomics stay in flight
             }
+        }
+    }
+}
+
+// grid (nImg), block 256: the groups of an image that k_insert_win leaves out (see kFarGroup).  The reference plane and its
+// shear axis are derived exactly as k_insert_win derives them (first group's normal, same float expressions).
+__global__ __launch_bounds__(256) void k_insert_far(InsertWinArgs wa)
+{
+    const InsertArgs& a = wa.a;
+    const int img = blockIdx.x;
+    const int P = a.P;
+    const size_t volSize = (size_t)P * P * (P / 2 + 1);
+    const int* plan = wa.plan + (size_t)img * plan_stride(a.mReco);
+    const int G = plan[0];
+    const int* pGStart = plan + 2;
+    const int* pOrd = pGStart + a.mReco + 1;
+    const int* pGRep = pOrd + 2 * a.mReco;
+    const double* Rimg = a.rotMat + (size_t)img * a.mReco * 9;
+    const double* R0 = Rimg + (size_t)pGRep[0] * 9;
+    const float n0 = (float)(R0[1] * R0[5] - R0[2] * R0[4]);
+    const float n1 = (float)(R0[2] * R0[3] - R0[0] * R0[5]);
+    const float n2 = (float)(R0[0] * R0[4] - R0[1] * R0[3]);
+    const float an0 = fabsf(n0), an1 = fabsf(n1), an2 = fabsf(n2);
+    const int ax = (an0 >= an1 && an0 >= an2) ? 0 : (an1 >= an2 ? 1 : 2);
+    const float wgt = a.w[img];
+    const double offx = a.offS ? a.offS[2 * img] : 0.0, offy = a.offS ? a.offS[2 * img + 1] : 0.0;
+    for (int gi_ = 0; gi_ < G; gi_++) {
+        const int rep = pGRep[gi_];
+        const double* R = Rimg + (size_t)rep * 9;
+        const float gna = (float)(ax == 0 ? R[1] * R[5] - R[2] * R[4] : (ax == 1 ? R[2] * R[3] - R[0] * R[5] : R[0] * R[4] - R[1] * R[3]));
+        if (!(fabsf(gna) < kFarGroup)) continue;
+        const int m0 = pGStart[gi_], m1 = pGStart[gi_ + 1];
+        const float nmem = (float)(m1 - m0);
+        const int k = a.cls ? a.cls[(size_t)img * a.mReco + rep] : 0;
+        float2* F = a.F + (size_t)k * volSize;
+        float* T = a.T + (size_t)k * volSize;
+        for (int p = threadIdx.x; p < a.nPxl; p += blockDim.x) {
+            const int pi = a.iCol[p], pj = a.iRow[p];
+            const float2 dv = a.datP[(size_t)img * a.nPxl + p];
+            float cf = a.ctfP[(size_t)img * a.nPxl + p];
+            float2 S = make_float2(0.f, 0.f);
+            for (int i = m0; i < m1; i++) {   // sum of the members' phase ramps
+                const size_t dm = (size_t)img * a.mReco + pOrd[i];
+                const double tx = a.trans[2 * dm] - offx, ty = a.trans[2 * dm + 1] - offy;
+                const float2 r = ramp_value((float)(-tx) / a.idim, (float)(-ty) / a.idim, pi, pj);
+                S.x += r.x;
+                S.y += r.y;
+            }
+            const float2 tv = cmul(dv, S);
+            if (a.cSearch) cf = insert_ctf_search(a.attr, a.dfac, img, a.mReco, rep, a.pixelSize, a.idim, pi, pj);
+            float vre = tv.x * cf, vim = tv.y * cf;
+            vre = vre * 1.0f; vim = vim * 1.0f;
+            vre = vre * wgt; vim = vim * wgt;
+            const float tval = (pow2f_(cf) * 1.0f * wgt) * nmem;
+            const int icp = pi * a.opf, irp = pj * a.opf;
+            const float x = (float)(R[0] * icp + R[3] * irp), y = (float)(R[1] * icp + R[4] * irp), z = (float)(R[2] * icp + R[5] * irp);
+            if (!coord_in_grid(x, y, z, P)) continue;
+            TriCell cell;
+            tri_cell(cell, x, y, z, P);
+            if (cell.conj) vim = -vim;
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                    for (int ii = 0; ii < 2; ii++) {
+                        const float wv = cell.w[kk * 4 + jj * 2 + ii];
+                        const long idx = cell.rowOff[kk][jj] + ii;
+                        unsafeAtomicAdd(&F[idx].x, vre * wv);
+                        unsafeAtomicAdd(&F[idx].y, vim * wv);
+                        unsafeAtomicAdd(&T[idx], tval * wv);
+                    }
         }
     }
 }
@@ -1016,6 +1041,7 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
             wa.rMax2 = (float)(half * opf + 2) * (float)(half * opf + 2);
             wa.debug = kWinProfiling ? knobs().insertDebug : 0;
             hipLaunchKernelGGL(k_insert_win, dim3(wa.nW, nl), dim3(kWinThreads), ldsWin, st, wa);
+            hipLaunchKernelGGL(k_insert_far, dim3(nl), dim3(256), 0, st, wa);
         } else {
             hipLaunchKernelGGL(k_insert, dim3((nPxl + 255) / 256, nl), dim3(256), 0, st, b);
         }

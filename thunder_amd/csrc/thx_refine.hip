@@ -1,0 +1,706 @@
+// thx_refine.hip -- the per-iteration E/M loop sequenced in native code (host side C++, device work through the C ABI of
+// this library only).  Reference control flow, restricted to the path in scope:
+//   Optimiser::expectation   src/Optimiser.cpp:1141-1660 (HOT LOOP B: local particle-filter phases)
+//   Optimiser::maximization  src/Optimiser.cpp:3405-3480 -> allReduceSigma :6395-6710, reconstructRef :6711-7766
+//                            (HOT LOOP C :7038-7241, prepareTF, reconstruct x 2 per half)
+//   Model::compareTwoHemispheres FSC (src/Model.cpp:424-551, src/Functions/Spectrum.cpp:302-337), Model::refreshProj
+//   (src/Model.cpp:1013-1044), Optimiser::reCentreImg / reMaskImg (:6065-6149), allocPreCalIdx / allocPreCal (:7991-8171)
+// One thx_refine handle = one rank's HBM-resident shard of particles (one process per GPU).  The only exchange between
+// ranks is the half-set reduction of F / T (thx_reco_allreduce, RCCL over xGMI), three small sigma tables, and the two
+// N^3 half maps for the FSC -- all through thx_comm (thx_comm.hip).  The handle BORROWS the caller's image stack
+// (_imgOri) and owns everything else.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "thx_common.h"
+#include "thx_philox.h"
+
+struct thx_comm;
+extern "C" {
+int thx_comm_rank(const thx_comm* c);
+int thx_comm_size(const thx_comm* c);
+int thx_comm_allreduce_f32(thx_comm* c, float* buf, size_t count, void* stream);
+int thx_comm_broadcast(thx_comm* c, void* buf, size_t bytes, int root, void* stream);
+size_t thx_reco_allreduce_workspace(int dim, int maxRadius, int pf);
+int thx_reco_allreduce(thx_comm* hemi, float* F, float* T, double* O, int* counter, int dim, int maxRadius, int pf,
+                       void* workspace, void* stream);
+}
+
+namespace thx {
+
+// ---------------------------------------------------------------------------------------------
+// host integer work: Optimiser::allocPreCalIdx (src/Optimiser.cpp:7991-8041) and the pixel-visit order of the E-step
+// ---------------------------------------------------------------------------------------------
+struct PixelList {
+    std::vector<int> iCol, iRow, iPxl, iSig;
+    int nPxl = 0;
+};
+
+static PixelList pixel_list_host(int N, int rU, int rL)
+{
+    PixelList pl;
+    const float rU2 = pow2f_((float)rU), rL2 = pow2f_((float)rL);   // TSGSL_pow_2 on RFLOAT
+    const int lim = rU + 1;
+    for (int j = -lim; j < lim; j++)
+        for (int i = 0; i <= lim; i++) {   // IMAGE_FOR_PIXEL_R_FT(rU + 1)
+            if (i == 0 && j < 0) continue;
+            const float u = (float)((double)i * i + (double)j * j);   // QUAD(i, j) narrowed to RFLOAT
+            if (u < rU2 && u >= rL2) {
+                const int v = (int)rint(gsl_hypot_((double)i, (double)j));   // AROUND(NORM(i, j))
+                if (v < rU && v >= rL) {
+                    pl.iPxl.push_back((j >= 0 ? j : j + N) * (N / 2 + 1) + i);
+                    pl.iCol.push_back(i);
+                    pl.iRow.push_back(j);
+                    pl.iSig.push_back(v);
+                }
+            }
+        }
+    pl.nPxl = (int)pl.iCol.size();
+    return pl;
+}
+
+static unsigned spread_bits(unsigned v)
+{
+    unsigned o = 0;
+    for (int b = 0; b < 12; b++) o |= ((v >> b) & 1u) << (2 * b);
+    return o;
+}
+
+// Morton (Z-order) visit order over (iCol, iRow + N): neighbouring pixels -- and the volume cells their rotations touch --
+// stay close together in time (thunder_amd/refine.py:pixel_visit_order is the Python twin; tests compare the two)
+static void morton_order(PixelList& pl, int N)
+{
+    std::vector<int> idx(pl.nPxl);
+    for (int i = 0; i < pl.nPxl; i++) idx[i] = i;
+    std::vector<unsigned> key(pl.nPxl);
+    for (int i = 0; i < pl.nPxl; i++) key[i] = spread_bits((unsigned)pl.iCol[i]) | (spread_bits((unsigned)(pl.iRow[i] + N)) << 1);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key[a] < key[b]; });
+    PixelList o;
+    o.nPxl = pl.nPxl;
+    for (int i : idx) {
+        o.iCol.push_back(pl.iCol[i]); o.iRow.push_back(pl.iRow[i]); o.iPxl.push_back(pl.iPxl[i]); o.iSig.push_back(pl.iSig[i]);
+    }
+    pl = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small device kernels of the driver
+// ---------------------------------------------------------------------------------------------
+// allocPreCal, src/Optimiser.cpp:8077-8081: _sigRcpP[l][p] = _sigRcp(groupID[l] - 1, iSig[p]);  grid (ceil(nPxl/256), nImg)
+__global__ void k_sigrcp_rows(float* __restrict__ sigRcpP, const float* __restrict__ sigRcp, const int* __restrict__ gid0,
+                              const int* __restrict__ iSig, int nPxl, int rSig)
+{
+    const int l = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nPxl) return;
+    sigRcpP[(size_t)l * nPxl + p] = sigRcp[(size_t)gid0[l] * rSig + iSig[p]];
+}
+
+// The mReco draws of the insertion (src/Optimiser.cpp:7129-7150): the filter has been resampled (thx_pf_update_dev), so
+// Particle::rand(quat) / rand(tran) (src/Particle.cpp:2109-2178) is a uniform pick among the support points.
+// One thread per draw; rotation matrix as rotate3D (src/Geometry/Euler.cpp:181-189).
+__global__ void k_draw_reco(double* __restrict__ recoRot, double* __restrict__ recoTran, const double* __restrict__ r,
+                            const double* __restrict__ t, int nImg, int nR, int nT, int mReco, unsigned long long seed,
+                            unsigned call, unsigned img0)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)nImg * mReco) return;
+    const int l = (int)(e / mReco), m = (int)(e - (size_t)l * mReco);
+    double u[4];
+    draw_u4(u, seed, img0 + (unsigned)l, call, 7u, (unsigned)m);
+    int iR = (int)(u[0] * nR), iT = (int)(u[1] * nT);
+    iR = iR >= nR ? nR - 1 : iR;
+    iT = iT >= nT ? nT - 1 : iT;
+    const double* q = r + ((size_t)l * nR + iR) * 4;
+    const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const double A[3][3] = {{0, -q3, q2}, {q3, 0, -q1}, {-q2, q1, 0}};
+    double* mat = recoRot + e * 9;
+    for (int rr = 0; rr < 3; rr++)
+        for (int c = 0; c < 3; c++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += A[rr][k] * A[k][c];
+            mat[c * 3 + rr] = (rr == c ? 1.0 : 0.0) + 2 * q0 * A[rr][c] + 2 * s;
+        }
+    recoTran[2 * e] = t[((size_t)l * nT + iT) * 2];
+    recoTran[2 * e + 1] = t[((size_t)l * nT + iT) * 2 + 1];
+}
+
+// reCentreImg bookkeeping, src/Optimiser.cpp:6065-6090: _offset[l] -= tran; _par[l].setT(t - tran); setTopT(topT - tran)
+__global__ void k_recentre_state(double* __restrict__ offset, double* __restrict__ t, double* __restrict__ topT,
+                                 const double* __restrict__ tranTop, int nImg, int nT)
+{
+    const int l = blockIdx.x;
+    if (l >= nImg) return;
+    const double tx = tranTop[2 * l], ty = tranTop[2 * l + 1];
+    for (int i = threadIdx.x; i < nT; i += blockDim.x) {
+        t[((size_t)l * nT + i) * 2] -= tx;
+        t[((size_t)l * nT + i) * 2 + 1] -= ty;
+    }
+    if (threadIdx.x == 0) {
+        offset[2 * l] -= tx; offset[2 * l + 1] -= ty;
+        topT[2 * l] -= tx; topT[2 * l + 1] -= ty;
+    }
+}
+
+// Particle::load -> calVari for the shifts (src/Particle.cpp:1291-1330): per-column standard deviation (n - 1 form)
+__global__ void k_shift_sd(double* __restrict__ s01, const double* __restrict__ t, int nImg, int nT)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nImg) return;
+    for (int c = 0; c < 2; c++) {
+        double m = 0;
+        for (int i = 0; i < nT; i++) m += t[((size_t)l * nT + i) * 2 + c];
+        m /= nT;
+        double v = 0;
+        for (int i = 0; i < nT; i++) { const double d = t[((size_t)l * nT + i) * 2 + c] - m; v += d * d; }
+        s01[2 * l + c] = sqrt(v / (nT > 1 ? nT - 1 : 1));
+    }
+}
+
+template <typename T>
+__global__ void k_fill(T* __restrict__ p, T v, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// first support point of every image: topR [n][4] <- r [n][nR][4] (stride copy)
+__global__ void k_take_first(double* __restrict__ dst, const double* __restrict__ src, int n, int stride, int width)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)n * width) return;
+    const size_t l = e / width, c = e - l * width;
+    dst[e] = src[l * stride + c];
+}
+
+}  // namespace thx
+
+using namespace thx;
+
+// ---- the C ABI this driver sequences (declared in include/thunder_amd.h, which thx_common.h includes) ----
+
+struct thx_refine_stats_acc {
+    double ms = 0;
+    long launches = 0, images = 0;
+};
+
+struct thx_refine {
+    thx_refine_config cfg;
+    thx_comm* hemi = nullptr;
+    thx_comm* world = nullptr;
+    int N, pf, P, nc, rU, rSig, nPxl, nPxlM, nV, nImg, batch;
+    int halves[2];
+    int lo[2], hi[2];
+    std::vector<void*> owned;
+    std::vector<int> gidHost;
+    // pixel lists
+    int *iCol, *iRow, *iPxl, *iSig, *iColM, *iRowM, *iPxlM;
+    // particles
+    const float* imgOri = nullptr;
+    float* img = nullptr;
+    thx_ctf_attr* attr = nullptr;
+    int* gid0 = nullptr;
+    float *datM, *ctfM, *datP, *ctfP, *sigRcpP, *w;
+    double* offset;
+    // particle-filter state and its initial copy
+    double *r, *t, *wR, *wT, *k123, *s01, *topR, *topT, *r0, *t0, *pD;
+    // reference, accumulators
+    float* refRL = nullptr;
+    float *vols, *cells, *F, *T, *maps, *mapsX, *ftA, *ftB, *fscDev;
+    float *sig, *sigRcp, *acc;
+    thx_reco* plans[2] = {nullptr, nullptr};
+    // per-batch / per-half scratch
+    double *rotB, *recoRot, *recoTran, *rotTop, *tranTop;
+    float *uR, *uT, *wC, *wD, *baseL, *spec;
+    void *wsExpect, *wsReduce;
+    unsigned pfCall = 0;
+    bool haveCells = false;
+    // timing (HIP events on the launch stream, resolved in thx_refine_stats)
+    bool timed = false;
+    struct Ev { hipEvent_t a, b; int kind; int images; };
+    std::vector<Ev> events;
+    thx_refine_stats_acc accExpect, accInsert;
+    double stageMs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long recoRounds = 0, iterations = 0;
+};
+
+namespace {
+
+template <typename T>
+int dalloc(thx_refine* h, T** p, size_t n)
+{
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, (n ? n : 1) * sizeof(T));
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed in the refine driver: %s", n * sizeof(T), hipGetErrorString(e));
+        return (int)e;
+    }
+    h->owned.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return 0;
+}
+
+template <typename T>
+int upload(thx_refine* h, T** p, const std::vector<T>& v)
+{
+    THX_RC(dalloc(h, p, v.size()));
+    THX_CHECK(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+enum { EV_EXPECT = 0, EV_INSERT = 1, EV_STAGE0 = 8 };   // stages: rows, expectation, sigma, insertion, reconstruct, recentre
+enum { ST_ROWS = 0, ST_EXPECT, ST_SIGMA, ST_INSERT, ST_RECO, ST_RECENTRE, ST_COUNT };
+
+struct Scope {
+    thx_refine* h; hipStream_t st; int kind, images; hipEvent_t a{}, b{}; bool on;
+    Scope(thx_refine* h_, hipStream_t st_, int kind_, int images_ = 0) : h(h_), st(st_), kind(kind_), images(images_), on(h_->timed)
+    {
+        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
+    }
+    ~Scope()
+    {
+        if (on) { (void)hipEventRecord(b, st); h->events.push_back({a, b, kind, images}); }
+    }
+};
+
+int resolve_events(thx_refine* h)
+{
+    for (auto& e : h->events) {
+        THX_CHECK(hipEventSynchronize(e.b));
+        float ms = 0;
+        THX_CHECK(hipEventElapsedTime(&ms, e.a, e.b));
+        if (e.kind == EV_EXPECT) { h->accExpect.ms += ms; h->accExpect.launches++; h->accExpect.images += e.images; }
+        else if (e.kind == EV_INSERT) { h->accInsert.ms += ms; h->accInsert.launches++; h->accInsert.images += e.images; }
+        else h->stageMs[e.kind - EV_STAGE0] += ms;
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    h->events.clear();
+    return 0;
+}
+
+unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+
+// Optimiser::allocPreCal rows of local half vi: _datP from the masked stack, _sigRcpP from the group's sigma table
+int refresh_rows(thx_refine* h, int vi, hipStream_t st)
+{
+    const int lo = h->lo[vi], n = h->hi[vi] - lo;
+    if (n <= 0) return 0;
+    const size_t imgSize = (size_t)h->N * h->nc * 2;
+    THX_RC(thx_gather_pixels_dev(h->datP + (size_t)lo * h->nPxl * 2, h->img + (size_t)lo * imgSize, h->iPxl, h->nPxl, h->N, n, st));
+    for (int l0 = 0; l0 < n; l0 += 65535) {
+        const int nl = std::min(65535, n - l0);
+        hipLaunchKernelGGL(k_sigrcp_rows, dim3((h->nPxl + 255) / 256, nl), dim3(256), 0, st,
+                           h->sigRcpP + (size_t)(lo + l0) * h->nPxl, h->sigRcp + (size_t)vi * h->cfg.nGroup * h->rSig,
+                           h->gid0 + lo + l0, h->iSig, h->nPxl, h->rSig);
+    }
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+// HOT LOOP B: nPhase particle-filter phases over the images of local half vi
+int expectation(thx_refine* h, int vi, hipStream_t st)
+{
+    const thx_refine_config& c = h->cfg;
+    const size_t cellStride = thx_projector_packed_bytes(h->P) / sizeof(float);
+    for (int p = 0; p < c.nPhase; p++) {
+        for (int b0 = h->lo[vi]; b0 < h->hi[vi]; b0 += h->batch) {
+            const int nb = std::min(h->batch, h->hi[vi] - b0);
+            double* r = h->r + (size_t)b0 * c.mLR * 4;
+            double* t = h->t + (size_t)b0 * c.mLT * 2;
+            double* wR = h->wR + (size_t)b0 * c.mLR;
+            double* wT = h->wT + (size_t)b0 * c.mLT;
+            double* k = h->k123 + (size_t)b0 * 3;
+            double* s = h->s01 + (size_t)b0 * 2;
+            const double f = p == 0 ? c.pfL : c.pfS;
+            // Particle::perturb, then the phase's support points are the filter's own (src/Optimiser.cpp:1186-1208)
+            h->pfCall++;
+            THX_RC(thx_pf_perturb_dev(r, t, wR, wT, k, s, nb, c.mLR, c.mLT, f, f, c.transS, c.transQ, c.seed, h->pfCall, st));
+            THX_RC(thx_rotmat_dev(r, h->rotB, nb * c.mLR, st));
+            {
+                Scope ev(h, st, EV_EXPECT, nb);
+                THX_RC(thx_expect_local_packed_dev(h->cells + (size_t)vi * cellStride, nullptr, h->P, h->pf, h->N, h->iCol, h->iRow,
+                                                   h->nPxl, nb, h->datP + (size_t)b0 * h->nPxl * 2, h->ctfP + (size_t)b0 * h->nPxl,
+                                                   h->sigRcpP + (size_t)b0 * h->nPxl, h->rotB, c.mLR, t, c.mLT, 1, nullptr, wR, wT,
+                                                   h->pD, h->wC, h->uR, h->uT, h->wD, h->baseL, nullptr, h->wsExpect, c.wgPerCU, st));
+            }
+            h->pfCall++;
+            THX_RC(thx_pf_update_dev(r, t, wR, wT, h->uR, h->uT, k, s, h->topR + (size_t)b0 * 4, h->topT + (size_t)b0 * 2, nb, c.mLR,
+                                     c.mLT, c.peakFactorR, c.seed, h->pfCall, st));
+        }
+    }
+    return 0;
+}
+
+// Optimiser::allReduceSigma (src/Optimiser.cpp:6395-6710) for local half vi, from the top pose of the last phase
+int sigma_update(thx_refine* h, int vi, hipStream_t st)
+{
+    const thx_refine_config& c = h->cfg;
+    const int lo = h->lo[vi], n = h->hi[vi] - lo;
+    if (n <= 0) return 0;
+    const size_t imgSize = (size_t)h->N * h->nc * 2;
+    THX_RC(thx_rotmat_dev(h->topR + (size_t)lo * 4, h->rotTop, n, st));
+    THX_CHECK(hipMemcpyAsync(h->tranTop, h->topT + (size_t)lo * 2, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    const size_t volStride = (size_t)h->P * h->P * (h->P / 2 + 1) * 2;
+    THX_RC(thx_sigma_spectra_dev(h->spec, h->vols + (size_t)vi * volStride, nullptr, h->P, h->pf, h->N, h->rU, h->rSig,
+                                 h->img + (size_t)lo * imgSize, h->imgOri + (size_t)lo * imgSize, h->attr + lo, nullptr, c.pixelSize,
+                                 h->rotTop, h->tranTop, h->offset + (size_t)lo * 2, n, st));
+    const size_t tab = (size_t)c.nGroup * (h->rSig + 1);
+    THX_CHECK(hipMemsetAsync(h->acc, 0, 3 * tab * sizeof(float), st));
+    THX_RC(thx_sigma_accum_dev(h->acc, h->acc + tab, h->acc + 2 * tab, h->spec, h->gidHost.data() + lo, n, c.nGroup, h->rSig,
+                               c.groupSig, st));
+    THX_RC(thx_comm_allreduce_f32(h->hemi, h->acc, 3 * tab, st));   // :6608-6650, the three tables in one collective
+    THX_RC(thx_sigma_final_dev(h->sig + (size_t)vi * c.nGroup * h->rSig, h->sigRcp + (size_t)vi * c.nGroup * h->rSig, h->acc,
+                               h->acc + tab, h->acc + 2 * tab, c.nGroup, h->rSig, c.groupSig, c.maskRadiusPx * c.pixelSize, h->N,
+                               c.pixelSize, st));
+    return 0;
+}
+
+// HOT LOOP C: mReco draws per image, trilinear insertion into the half's F / T
+int insertion(thx_refine* h, int vi, hipStream_t st)
+{
+    const thx_refine_config& c = h->cfg;
+    const int lo = h->lo[vi], n = h->hi[vi] - lo;
+    const size_t volN = (size_t)h->P * h->P * (h->P / 2 + 1);
+    float* F = h->F + (size_t)vi * volN * 2;
+    float* T = h->T + (size_t)vi * volN;
+    THX_CHECK(hipMemsetAsync(F, 0, volN * 2 * sizeof(float), st));
+    THX_CHECK(hipMemsetAsync(T, 0, volN * sizeof(float), st));
+    if (n <= 0) return 0;
+    h->pfCall++;
+    hipLaunchKernelGGL(k_draw_reco, dim3(blocks_for((size_t)n * c.mReco)), dim3(256), 0, st, h->recoRot, h->recoTran,
+                       h->r + (size_t)lo * c.mLR * 4, h->t + (size_t)lo * c.mLT * 2, n, c.mLR, c.mLT, c.mReco, c.seed, h->pfCall,
+                       (unsigned)lo);
+    THX_LAUNCH_CHECK();
+    for (int b0 = lo; b0 < h->hi[vi]; b0 += h->batch) {
+        const int nb = std::min(h->batch, h->hi[vi] - b0);
+        Scope ev(h, st, EV_INSERT, nb);
+        THX_RC(thx_insert_dev(F, T, nullptr, nullptr, h->P, 1, h->datM + (size_t)b0 * h->nPxlM * 2, h->ctfM + (size_t)b0 * h->nPxlM,
+                              h->w + b0, h->recoRot + (size_t)(b0 - lo) * c.mReco * 9, h->recoTran + (size_t)(b0 - lo) * c.mReco * 2,
+                              h->offset + (size_t)b0 * 2, nullptr, nullptr, nullptr, 0, c.pixelSize, h->iColM, h->iRowM, h->pf,
+                              h->nPxlM, c.mReco, h->N, nb, st));
+    }
+    return 0;
+}
+
+int refresh_projector(thx_refine* h, int vi, const float* mapRL, hipStream_t st)
+{
+    const size_t volStride = (size_t)h->P * h->P * (h->P / 2 + 1) * 2;
+    const size_t cellStride = thx_projector_packed_bytes(h->P) / sizeof(float);
+    THX_RC(thx_reco_set_projectee_dev(h->plans[vi], mapRL, h->vols + (size_t)vi * volStride, st));   // Model::refreshProj
+    THX_RC(thx_projector_pack_dev(h->cells + (size_t)vi * cellStride, h->vols + (size_t)vi * volStride, h->P, 1, st));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int thx_pixel_list_host(int N, int rU, int rL, int order, int* iCol, int* iRow, int* iPxl, int* iSig, int* nPxl)
+{
+    THX_REQUIRE(nPxl && N > 0 && rU > 0 && rL >= 0, "bad arguments");
+    PixelList pl = pixel_list_host(N, rU, rL);
+    if (order == 1) morton_order(pl, N);
+    *nPxl = pl.nPxl;
+    if (iCol) memcpy(iCol, pl.iCol.data(), pl.nPxl * sizeof(int));
+    if (iRow) memcpy(iRow, pl.iRow.data(), pl.nPxl * sizeof(int));
+    if (iPxl) memcpy(iPxl, pl.iPxl.data(), pl.nPxl * sizeof(int));
+    if (iSig) memcpy(iSig, pl.iSig.data(), pl.nPxl * sizeof(int));
+    return 0;
+}
+
+int thx_draw_reco_dev(double* recoRot, double* recoTran, const double* r, const double* t, int nImg, int nR, int nT, int mReco,
+                      unsigned long long seed, unsigned call, unsigned img0, void* stream)
+{
+    if (nImg <= 0 || mReco <= 0) return 0;
+    THX_REQUIRE(recoRot && recoTran && r && t && nR > 0 && nT > 0, "bad arguments");
+    hipLaunchKernelGGL(k_draw_reco, dim3(blocks_for((size_t)nImg * mReco)), dim3(256), 0, as_stream(stream), recoRot, recoTran, r, t,
+                       nImg, nR, nT, mReco, seed, call, img0);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_refine_destroy(thx_refine* h)
+{
+    if (!h) return 0;
+    (void)hipDeviceSynchronize();
+    for (auto& e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (int v = 0; v < 2; v++)
+        if (h->plans[v]) (void)thx_reco_destroy(h->plans[v]);
+    for (void* p : h->owned) (void)hipFree(p);
+    delete h;
+    return 0;
+}
+
+int thx_refine_create(thx_refine** out, const thx_refine_config* cfg, thx_comm* hemi, thx_comm* world)
+{
+    THX_REQUIRE(out && cfg, "NULL argument");
+    const thx_refine_config& c = *cfg;
+    THX_REQUIRE(c.N > 0 && (c.N % 2) == 0 && c.pf >= 1 && c.nImg > 0, "bad box / particle count");
+    THX_REQUIRE(c.mLR > 0 && c.mLR <= 256 && c.mLT > 0 && c.mLT <= 9 && c.nPhase > 0 && c.mReco > 0, "bad search parameters");
+    THX_REQUIRE(c.nGroup > 0 && c.batch > 0, "bad nGroup / batch");
+    THX_REQUIRE(c.halfOfRank >= -1 && c.halfOfRank <= 1, "halfOfRank must be -1 (both halves here), 0 or 1");
+    thx_refine* h = new thx_refine;
+    h->cfg = c;
+    h->hemi = hemi;
+    h->world = world;
+    h->N = c.N; h->pf = c.pf; h->P = c.N * c.pf; h->nc = c.N / 2 + 1;
+    h->rU = c.N / 2 - 2;
+    h->rSig = c.N / 2 - 1;
+    h->nImg = c.nImg;
+    if (c.halfOfRank < 0) {   // both halves on this rank: [0, nHalfA) is half 0, the rest half 1
+        THX_REQUIRE(c.nHalfA >= 0 && c.nHalfA <= c.nImg, "nHalfA out of range");
+        h->nV = 2;
+        h->halves[0] = 0; h->halves[1] = 1;
+        h->lo[0] = 0; h->hi[0] = c.nHalfA; h->lo[1] = c.nHalfA; h->hi[1] = c.nImg;
+    } else {
+        h->nV = 1;
+        h->halves[0] = c.halfOfRank; h->halves[1] = -1;
+        h->lo[0] = 0; h->hi[0] = c.nImg; h->lo[1] = h->hi[1] = 0;
+    }
+    int nmax = 0;
+    for (int v = 0; v < h->nV; v++) nmax = std::max(nmax, h->hi[v] - h->lo[v]);
+    // balanced batches of at most cfg.batch images (a short last batch leaves the chip half empty)
+    const int nb = std::max(1, (nmax + c.batch - 1) / c.batch);
+    h->batch = std::min(65535, std::max(1, (nmax + nb - 1) / nb));
+#define RC_OR_FREE(expr) do { int _rc = (expr); if (_rc) { thx_refine_destroy(h); return _rc; } } while (0)
+    PixelList pl = pixel_list_host(c.N, h->rU, c.rL), plM = pixel_list_host(c.N, h->rU, 0);
+    if (c.pixelOrder == 1) morton_order(pl, c.N);
+    h->nPxl = pl.nPxl; h->nPxlM = plM.nPxl;
+    RC_OR_FREE(upload(h, &h->iCol, pl.iCol)); RC_OR_FREE(upload(h, &h->iRow, pl.iRow));
+    RC_OR_FREE(upload(h, &h->iPxl, pl.iPxl)); RC_OR_FREE(upload(h, &h->iSig, pl.iSig));
+    RC_OR_FREE(upload(h, &h->iColM, plM.iCol)); RC_OR_FREE(upload(h, &h->iRowM, plM.iRow)); RC_OR_FREE(upload(h, &h->iPxlM, plM.iPxl));
+    const size_t n = c.nImg, imgSize = (size_t)c.N * h->nc * 2, volN = (size_t)h->P * h->P * (h->P / 2 + 1);
+    RC_OR_FREE(dalloc(h, &h->img, n * imgSize));
+    RC_OR_FREE(dalloc(h, &h->attr, n));
+    RC_OR_FREE(dalloc(h, &h->gid0, n));
+    RC_OR_FREE(dalloc(h, &h->datM, n * h->nPxlM * 2)); RC_OR_FREE(dalloc(h, &h->ctfM, n * h->nPxlM));
+    RC_OR_FREE(dalloc(h, &h->datP, n * h->nPxl * 2)); RC_OR_FREE(dalloc(h, &h->ctfP, n * h->nPxl));
+    RC_OR_FREE(dalloc(h, &h->sigRcpP, n * h->nPxl)); RC_OR_FREE(dalloc(h, &h->w, n));
+    RC_OR_FREE(dalloc(h, &h->offset, n * 2));
+    RC_OR_FREE(dalloc(h, &h->r, n * c.mLR * 4)); RC_OR_FREE(dalloc(h, &h->t, n * c.mLT * 2));
+    RC_OR_FREE(dalloc(h, &h->r0, n * c.mLR * 4)); RC_OR_FREE(dalloc(h, &h->t0, n * c.mLT * 2));
+    RC_OR_FREE(dalloc(h, &h->wR, n * c.mLR)); RC_OR_FREE(dalloc(h, &h->wT, n * c.mLT));
+    RC_OR_FREE(dalloc(h, &h->k123, n * 3)); RC_OR_FREE(dalloc(h, &h->s01, n * 2));
+    RC_OR_FREE(dalloc(h, &h->topR, n * 4)); RC_OR_FREE(dalloc(h, &h->topT, n * 2));
+    RC_OR_FREE(dalloc(h, &h->refRL, (size_t)c.N * c.N * c.N));
+    RC_OR_FREE(dalloc(h, &h->vols, h->nV * volN * 2));
+    RC_OR_FREE(dalloc(h, &h->cells, h->nV * (thx_projector_packed_bytes(h->P) / sizeof(float))));
+    RC_OR_FREE(dalloc(h, &h->F, h->nV * volN * 2)); RC_OR_FREE(dalloc(h, &h->T, h->nV * volN));
+    RC_OR_FREE(dalloc(h, &h->maps, 2 * (size_t)c.N * c.N * c.N)); RC_OR_FREE(dalloc(h, &h->mapsX, 2 * (size_t)c.N * c.N * c.N));
+    RC_OR_FREE(dalloc(h, &h->ftA, imgSize * c.N)); RC_OR_FREE(dalloc(h, &h->ftB, imgSize * c.N));
+    RC_OR_FREE(dalloc(h, &h->fscDev, (size_t)c.N / 2));
+    RC_OR_FREE(dalloc(h, &h->sig, (size_t)h->nV * c.nGroup * h->rSig)); RC_OR_FREE(dalloc(h, &h->sigRcp, (size_t)h->nV * c.nGroup * h->rSig));
+    RC_OR_FREE(dalloc(h, &h->acc, 3 * (size_t)c.nGroup * (h->rSig + 1)));
+    const size_t B = h->batch;
+    RC_OR_FREE(dalloc(h, &h->rotB, B * c.mLR * 9)); RC_OR_FREE(dalloc(h, &h->pD, B));
+    RC_OR_FREE(dalloc(h, &h->uR, B * c.mLR)); RC_OR_FREE(dalloc(h, &h->uT, B * c.mLT));
+    RC_OR_FREE(dalloc(h, &h->wC, B)); RC_OR_FREE(dalloc(h, &h->wD, B)); RC_OR_FREE(dalloc(h, &h->baseL, B));
+    RC_OR_FREE(dalloc(h, &h->recoRot, (size_t)nmax * c.mReco * 9)); RC_OR_FREE(dalloc(h, &h->recoTran, (size_t)nmax * c.mReco * 2));
+    RC_OR_FREE(dalloc(h, &h->rotTop, (size_t)nmax * 9)); RC_OR_FREE(dalloc(h, &h->tranTop, (size_t)nmax * 2));
+    RC_OR_FREE(dalloc(h, &h->spec, (size_t)nmax * 4 * h->rSig));
+    {
+        char* ws = nullptr;
+        RC_OR_FREE(dalloc(h, &ws, thx_expect_local_workspace((int)B, c.mLR, c.mLT, 1)));
+        h->wsExpect = ws;
+        char* wr = nullptr;
+        RC_OR_FREE(dalloc(h, &wr, hemi ? thx_reco_allreduce_workspace(h->P, h->rU, c.pf) : 16));
+        h->wsReduce = wr;
+    }
+    for (int v = 0; v < h->nV; v++) RC_OR_FREE(thx_reco_create(&h->plans[v], c.N, c.N, c.pf, 1.9f, 15.0f));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill<double>), dim3(blocks_for(B)), dim3(256), 0, nullptr, h->pD, 1.0, B);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill<float>), dim3(blocks_for(n)), dim3(256), 0, nullptr, h->w, 1.0f / c.mReco, n);
+    if (hipDeviceSynchronize() != hipSuccess) { set_error("refine driver: device error during create"); thx_refine_destroy(h); return -1; }
+#undef RC_OR_FREE
+    *out = h;
+    return 0;
+}
+
+int thx_refine_set_particles(thx_refine* h, const float* imgOri, const thx_ctf_attr* attr, const int* groupID_host,
+                             const double* quat0, const double* tran0, void* stream)
+{
+    THX_REQUIRE(h && imgOri && attr && groupID_host && quat0 && tran0, "NULL argument");
+    hipStream_t st = as_stream(stream);
+    const thx_refine_config& c = h->cfg;
+    const size_t n = h->nImg;
+    h->imgOri = imgOri;
+    h->gidHost.assign(groupID_host, groupID_host + n);
+    std::vector<int> g0(n);
+    for (size_t l = 0; l < n; l++) {
+        THX_REQUIRE(groupID_host[l] >= 1 && groupID_host[l] <= c.nGroup, "groupID out of range (1-based)");
+        g0[l] = groupID_host[l] - 1;
+    }
+    THX_CHECK(hipMemcpyAsync(h->gid0, g0.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+    THX_CHECK(hipMemcpyAsync(h->attr, attr, n * sizeof(thx_ctf_attr), hipMemcpyDeviceToDevice, st));
+    THX_CHECK(hipMemcpyAsync(h->r0, quat0, n * c.mLR * 4 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    THX_CHECK(hipMemcpyAsync(h->t0, tran0, n * c.mLT * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    // M-step rows (the unmasked images on the rL = 0 list, src/Optimiser.cpp:6722) and the CTF rows never change
+    THX_RC(thx_gather_pixels_dev(h->datM, imgOri, h->iPxlM, h->nPxlM, h->N, (int)n, st));
+    THX_RC(thx_ctf_dev(h->ctfM, h->attr, nullptr, c.pixelSize, h->iColM, h->iRowM, h->nPxlM, h->N, (int)n, st));
+    THX_RC(thx_ctf_dev(h->ctfP, h->attr, nullptr, c.pixelSize, h->iCol, h->iRow, h->nPxl, h->N, (int)n, st));
+    THX_CHECK(hipStreamSynchronize(st));   // g0 is a host temporary
+    return 0;
+}
+
+int thx_refine_set_reference(thx_refine* h, const float* refRL, void* stream)
+{
+    THX_REQUIRE(h && refRL, "NULL argument");
+    THX_CHECK(hipMemcpyAsync(h->refRL, refRL, (size_t)h->N * h->N * h->N * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
+    return 0;
+}
+
+// the state before the first iteration: initial reference, no re-centring offset, masked copies of the images as read
+// (Optimiser::initImg masks them on load), flat initial noise model, initial support points (Particle::load)
+int thx_refine_reset(thx_refine* h, void* stream)
+{
+    THX_REQUIRE(h && h->imgOri, "thx_refine_set_particles has not been called");
+    hipStream_t st = as_stream(stream);
+    const thx_refine_config& c = h->cfg;
+    const size_t n = h->nImg, imgSize = (size_t)h->N * h->nc * 2;
+    for (int v = 0; v < h->nV; v++) THX_RC(refresh_projector(h, v, h->refRL, st));
+    THX_CHECK(hipMemsetAsync(h->offset, 0, n * 2 * sizeof(double), st));
+    THX_CHECK(hipMemcpyAsync(h->img, h->imgOri, n * imgSize * sizeof(float), hipMemcpyDeviceToDevice, st));
+    THX_RC(thx_remask_dev(h->img, (int)n, h->N, c.maskRadiusPx, 6.0f, st));
+    const size_t nsig = (size_t)h->nV * c.nGroup * h->rSig;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill<float>), dim3(blocks_for(nsig)), dim3(256), 0, st, h->sig, c.sigma2Init, nsig);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill<float>), dim3(blocks_for(nsig)), dim3(256), 0, st, h->sigRcp, -0.5f / c.sigma2Init, nsig);
+    THX_CHECK(hipMemcpyAsync(h->r, h->r0, n * c.mLR * 4 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    THX_CHECK(hipMemcpyAsync(h->t, h->t0, n * c.mLT * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill<double>), dim3(blocks_for(n * c.mLR)), dim3(256), 0, st, h->wR, 1.0 / c.mLR, n * c.mLR);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill<double>), dim3(blocks_for(n * c.mLT)), dim3(256), 0, st, h->wT, 1.0 / c.mLT, n * c.mLT);
+    // Particle::load -> calVari: ACG concentration of the rotations, per-column sd of the shifts
+    {
+        double* scratchA = reinterpret_cast<double*>(scratch(st, 7, n * (16 + 4 + (size_t)c.mLR) * sizeof(double)));
+        THX_REQUIRE(scratchA, "device scratch allocation failed");
+        THX_RC(thx_pf_acg_stats_dev(scratchA, scratchA + n * 16, h->k123, scratchA + n * 20, nullptr, h->r, (int)n, c.mLR, st));
+    }
+    hipLaunchKernelGGL(k_shift_sd, dim3(blocks_for(n)), dim3(256), 0, st, h->s01, h->t, (int)n, c.mLT);
+    hipLaunchKernelGGL(k_take_first, dim3(blocks_for(n * 4)), dim3(256), 0, st, h->topR, h->r, (int)n, c.mLR * 4, 4);
+    hipLaunchKernelGGL(k_take_first, dim3(blocks_for(n * 2)), dim3(256), 0, st, h->topT, h->t, (int)n, c.mLT * 2, 2);
+    THX_LAUNCH_CHECK();
+    h->pfCall = 0;
+    for (int v = 0; v < h->nV; v++) THX_RC(refresh_rows(h, v, st));
+    return 0;
+}
+
+int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
+{
+    THX_REQUIRE(h && h->imgOri, "thx_refine_set_particles has not been called");
+    hipStream_t st = as_stream(stream);
+    const thx_refine_config& c = h->cfg;
+    const size_t mapN = (size_t)h->N * h->N * h->N, volN = (size_t)h->P * h->P * (h->P / 2 + 1);
+    const size_t imgSize = (size_t)h->N * h->nc * 2;
+    h->timed = timed != 0;
+    // ---- E and M per local half: rows -> expectation -> sigma update -> draws + insertion ----
+    for (int vi = 0; vi < h->nV; vi++) {
+        { Scope s(h, st, EV_STAGE0 + ST_ROWS); THX_RC(refresh_rows(h, vi, st)); }
+        { Scope s(h, st, EV_STAGE0 + ST_EXPECT); THX_RC(expectation(h, vi, st)); }
+        { Scope s(h, st, EV_STAGE0 + ST_SIGMA); THX_RC(sigma_update(h, vi, st)); }
+        { Scope s(h, st, EV_STAGE0 + ST_INSERT); THX_RC(insertion(h, vi, st)); }
+    }
+    // ---- half-set reduce, prepareTF, reconstruct (MAP off) -> FSC -> reconstruct (MAP on) -> projector refresh ----
+    std::vector<float> fsc(h->N / 2);
+    {
+        Scope s(h, st, EV_STAGE0 + ST_RECO);
+        int iters = 0;
+        float diffC = 0;
+        for (int vi = 0; vi < h->nV; vi++) {
+            float* F = h->F + (size_t)vi * volN * 2;
+            float* T = h->T + (size_t)vi * volN;
+            THX_RC(thx_reco_allreduce(h->hemi, F, T, nullptr, nullptr, h->P, h->rU, h->pf, h->wsReduce, st));
+            THX_RC(thx_normalise_tf_dev(F, T, h->P, st));
+            THX_RC(thx_reco_reconstruct_dev(h->plans[vi], F, T, h->rU, nullptr, 0, 0, 0, 1, h->maps + (size_t)h->halves[vi] * mapN,
+                                            &iters, &diffC, st));
+            h->recoRounds += iters;
+        }
+        // every rank ends up with both half maps (the reference sends them to the master, src/Model.cpp:375-391): broadcast
+        // from world ranks 0 and 1, which lead halves 0 and 1
+        if (h->world && thx_comm_size(h->world) > 1) {
+            THX_RC(thx_comm_broadcast(h->world, h->maps, mapN * sizeof(float), 0, st));
+            THX_RC(thx_comm_broadcast(h->world, h->maps + mapN, mapN * sizeof(float), 1, st));
+        }
+        THX_RC(thx_fft3d_fw_dev(h->maps, h->ftA, h->N, st));
+        THX_RC(thx_fft3d_fw_dev(h->maps + mapN, h->ftB, h->N, st));
+        THX_RC(thx_fsc_dev(h->fscDev, h->N / 2, h->ftA, h->ftB, h->N, st));
+        THX_CHECK(hipMemcpyAsync(fsc.data(), h->fscDev, fsc.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+        THX_CHECK(hipStreamSynchronize(st));
+        for (int vi = 0; vi < h->nV; vi++) {
+            float* F = h->F + (size_t)vi * volN * 2;
+            float* T = h->T + (size_t)vi * volN;
+            float* m = h->mapsX + (size_t)h->halves[vi] * mapN;
+            THX_RC(thx_reco_reconstruct_dev(h->plans[vi], F, T, h->rU, fsc.data(), (int)fsc.size(), 0, 1, 1, m, &iters, &diffC, st));
+            h->recoRounds += iters;
+            THX_RC(refresh_projector(h, vi, m, st));
+        }
+    }
+    // ---- re-centre and re-mask the particle images with the top shift of the last phase ----
+    {
+        Scope s(h, st, EV_STAGE0 + ST_RECENTRE);
+        for (int vi = 0; vi < h->nV; vi++) {
+            const int lo = h->lo[vi], n = h->hi[vi] - lo;
+            if (n <= 0) continue;
+            THX_CHECK(hipMemcpyAsync(h->tranTop, h->topT + (size_t)lo * 2, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(k_recentre_state, dim3(n), dim3(64), 0, st, h->offset + (size_t)lo * 2, h->t + (size_t)lo * c.mLT * 2,
+                               h->topT + (size_t)lo * 2, h->tranTop, n, c.mLT);
+            THX_LAUNCH_CHECK();
+            THX_RC(thx_translate_image_dev(h->img + (size_t)lo * imgSize, h->imgOri + (size_t)lo * imgSize, h->offset + (size_t)lo * 2, n,
+                                           h->N, -1.0f, st));
+            THX_RC(thx_remask_dev(h->img + (size_t)lo * imgSize, n, h->N, c.maskRadiusPx, 6.0f, st));
+        }
+    }
+    h->iterations++;
+    if (fscHost) memcpy(fscHost, fsc.data(), fsc.size() * sizeof(float));
+    return 0;
+}
+
+int thx_refine_get_map(thx_refine* h, int half, float* dstRL, void* stream)
+{
+    THX_REQUIRE(h && dstRL && (half == 0 || half == 1), "bad arguments");
+    const size_t mapN = (size_t)h->N * h->N * h->N;
+    THX_CHECK(hipMemcpyAsync(dstRL, h->mapsX + (size_t)half * mapN, mapN * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
+    return 0;
+}
+
+int thx_refine_get_state(thx_refine* h, double* offset, double* topR, double* topT, float* sig, void* stream)
+{
+    THX_REQUIRE(h, "NULL handle");
+    hipStream_t st = as_stream(stream);
+    const size_t n = h->nImg;
+    if (offset) THX_CHECK(hipMemcpyAsync(offset, h->offset, n * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (topR) THX_CHECK(hipMemcpyAsync(topR, h->topR, n * 4 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (topT) THX_CHECK(hipMemcpyAsync(topT, h->topT, n * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (sig) THX_CHECK(hipMemcpyAsync(sig, h->sig, (size_t)h->nV * h->cfg.nGroup * h->rSig * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+int thx_refine_get_view(thx_refine* h, thx_refine_view* v)
+{
+    THX_REQUIRE(h && v, "NULL argument");
+    v->nImg = h->nImg; v->nPxl = h->nPxl; v->nPxlM = h->nPxlM; v->nVol = h->nV; v->vdim = h->P; v->rSig = h->rSig;
+    v->iCol = h->iCol; v->iRow = h->iRow; v->iPxl = h->iPxl; v->iSig = h->iSig; v->iColM = h->iColM; v->iRowM = h->iRowM;
+    v->img = h->img; v->datP = h->datP; v->ctfP = h->ctfP; v->sigRcpP = h->sigRcpP; v->datM = h->datM; v->ctfM = h->ctfM;
+    v->r = h->r; v->t = h->t; v->wR = h->wR; v->wT = h->wT; v->offset = h->offset;
+    v->vols = h->vols; v->cells = h->cells; v->F = h->F; v->T = h->T; v->sig = h->sig;
+    v->recoRot = h->recoRot; v->recoTran = h->recoTran;
+    return 0;
+}
+
+int thx_refine_get_stats(thx_refine* h, thx_refine_stats* out, int reset)
+{
+    THX_REQUIRE(h && out, "NULL argument");
+    THX_RC(resolve_events(h));
+    out->expectMs = h->accExpect.ms; out->expectLaunches = h->accExpect.launches; out->expectImages = h->accExpect.images;
+    out->insertMs = h->accInsert.ms; out->insertLaunches = h->accInsert.launches; out->insertImages = h->accInsert.images;
+    for (int i = 0; i < ST_COUNT; i++) out->stageMs[i] = h->stageMs[i];
+    out->balancingRounds = h->recoRounds;
+    out->iterations = h->iterations;
+    out->nPxl = h->nPxl; out->nPxlM = h->nPxlM; out->batch = h->batch;
+    if (reset) {
+        h->accExpect = thx_refine_stats_acc(); h->accInsert = thx_refine_stats_acc();
+        for (int i = 0; i < 8; i++) h->stageMs[i] = 0;
+        h->recoRounds = 0; h->iterations = 0;
+    }
+    return 0;
+}
+
+}  // extern "C"

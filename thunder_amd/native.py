@@ -1,0 +1,171 @@
+"""Front-end of the native iteration driver (thx_refine_*, thunder_amd/csrc/thx_refine.hip) and of the native RCCL
+communicators (thx_comm_*, thx_comm.hip).  No arithmetic and no sequencing happens here: the EM iteration -- rows,
+particle-filter phases, sigma update, draws, insertion, half-set reduce, reconstructions, FSC, projector refresh,
+re-centring / re-masking -- runs in C++ behind one call, thx_refine_iterate.  Python only generates the synthetic
+particles (RefineShard(allocate=False)), shares the RCCL unique id between the ranks and prints the result.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+from .capi import RefineConfig, RefineStats, RefineView, ptr, stream_ptr
+
+STAGES = ("rows", "expectation", "sigma", "insertion", "reconstruct", "recentre_remask")
+
+
+class Comm:
+    """thx_comm: an RCCL communicator created from a 128-byte unique id (gpu/src/cuthunder.cu:4192-4206).
+    `share(id_bytes or None)` is the launcher's broadcast of the id from the group's root (MPI_Bcast in the reference;
+    torch.distributed's object broadcast in bench.py; a pipe in tests/cpp/iteration.cpp)."""
+
+    def __init__(self, rank, size, share):
+        self.rank, self.size = rank, size
+        uid = None
+        if rank == 0:
+            buf = (C.c_ubyte * 128)()
+            capi.call("thx_comm_unique_id", C.cast(buf, C.c_void_p))
+            uid = bytes(buf)
+        uid = share(uid)
+        assert isinstance(uid, (bytes, bytearray)) and len(uid) == 128
+        h = C.c_void_p()
+        buf = (C.c_ubyte * 128).from_buffer_copy(uid)
+        capi.call("thx_comm_init", C.byref(h), C.cast(buf, C.c_void_p), rank, size)
+        self._h = h
+
+    @property
+    def handle(self):
+        return self._h
+
+    def allreduce(self, t):
+        n = t.numel() * (2 if t.is_complex() else 1)
+        name = {torch.float32: "thx_comm_allreduce_f32", torch.complex64: "thx_comm_allreduce_f32",
+                torch.float64: "thx_comm_allreduce_f64", torch.int32: "thx_comm_allreduce_i32"}[t.dtype]
+        capi.call(name, self._h, ptr(t), n, stream_ptr())
+        return t
+
+    def broadcast(self, t, root):
+        capi.call("thx_comm_broadcast", self._h, ptr(t), t.numel() * t.element_size(), root, stream_ptr())
+        return t
+
+    def close(self):
+        if self._h is not None:
+            capi.call("thx_comm_destroy", self._h)
+            self._h = None
+
+
+def make_comms(rank, world, share_from):
+    """(hemi, world) communicators of one rank: hemi spans the ranks r with r % 2 == rank % 2 (the reference's odd / even
+    hemispheres, src/Parallel.cpp:26-36); share_from(root_world_rank, id_or_None) -> id is the launcher's broadcast.
+    With world <= 2 a half is one rank: no hemisphere communicator."""
+    if world == 1:
+        return None, None
+    wcomm = Comm(rank, world, lambda uid: share_from(0, uid))
+    hemi = None
+    if world > 2:
+        h = rank % 2
+        peers = [r for r in range(world) if r % 2 == h]
+        # both hemispheres bootstrap (every rank takes part in both broadcasts, uses its own half's id)
+        ids = {}
+        for hh in (0, 1):
+            root = hh   # world rank hh leads half hh
+            uid = None
+            if rank == root:
+                buf = (C.c_ubyte * 128)()
+                capi.call("thx_comm_unique_id", C.cast(buf, C.c_void_p))
+                uid = bytes(buf)
+            ids[hh] = share_from(root, uid)
+        hemi = Comm.__new__(Comm)
+        hemi.rank, hemi.size = peers.index(rank), len(peers)
+        hh = C.c_void_p()
+        buf = (C.c_ubyte * 128).from_buffer_copy(ids[h])
+        capi.call("thx_comm_init", C.byref(hh), C.cast(buf, C.c_void_p), hemi.rank, hemi.size)
+        hemi._h = hh
+    return hemi, wcomm
+
+
+class NativeRefine:
+    """thx_refine handle over the particles of a RefineShard (which only has to have GENERATED them: allocate=False)."""
+
+    def __init__(self, shard, hemi=None, world=None, pixel_order=1):
+        self.shard = shard
+        s = shard
+        cfg = RefineConfig()
+        cfg.N, cfg.pf, cfg.nImg = s.N, s.pf, s.nImg
+        if s.world == 1:
+            cfg.halfOfRank, cfg.nHalfA = -1, s.ranges[0][1]
+        else:
+            cfg.halfOfRank, cfg.nHalfA = s.groups.half, 0
+        cfg.mLR, cfg.mLT, cfg.nPhase, cfg.mReco, cfg.batch = s.mLR, s.mLT, s.nPhase, s.mReco, s.batch
+        cfg.rL, cfg.nGroup, cfg.groupSig = s.rL, s.nGroup, 1 if s.groupSig else 0
+        cfg.pixelOrder, cfg.wgPerCU = pixel_order, s.wg_per_cu
+        cfg.pixelSize, cfg.maskRadiusPx, cfg.sigma2Init = s.pixelSize, s.maskRadiusPx, s.sigma2
+        cfg.transS, cfg.transQ, cfg.pfL, cfg.pfS, cfg.peakFactorR = s.transS, s.transQ, s.pfL, s.pfS, s.peakFactorR
+        cfg.seed = s.pf_seed
+        assert s.use_pf, "the native driver runs the device particle filter"
+        self.cfg = cfg
+        h = C.c_void_p()
+        capi.call("thx_refine_create", C.byref(h), C.byref(cfg), hemi.handle if hemi is not None else None,
+                  world.handle if world is not None else None)
+        self._h = h
+        gid = np.ascontiguousarray(s.gid.astype(np.int32))
+        capi.call("thx_refine_set_particles", self._h, ptr(s.imgOri), ptr(s.attr), gid.ctypes.data, ptr(s.pf0["r"]),
+                  ptr(s.pf0["t"]), stream_ptr())
+        capi.call("thx_refine_set_reference", self._h, ptr(s.ref), stream_ptr())
+        torch.cuda.synchronize()
+
+    def reset(self):
+        capi.call("thx_refine_reset", self._h, stream_ptr())
+
+    def iterate(self, timed=False):
+        fsc = np.zeros(self.shard.N // 2, np.float32)
+        capi.call("thx_refine_iterate", self._h, fsc.ctypes.data, 1 if timed else 0, stream_ptr())
+        return fsc
+
+    def run(self, steps, timed=False):
+        fsc = None
+        for _ in range(steps):
+            fsc = self.iterate(timed)
+        return fsc
+
+    def stats(self, reset=False):
+        st = RefineStats()
+        capi.call("thx_refine_get_stats", self._h, C.byref(st), 1 if reset else 0)
+        return st
+
+    def view(self):
+        v = RefineView()
+        capi.call("thx_refine_get_view", self._h, C.byref(v))
+        return v
+
+    def map(self, half):
+        N = self.shard.N
+        m = torch.empty((N, N, N), dtype=torch.float32, device=self.shard.dev)
+        capi.call("thx_refine_get_map", self._h, half, ptr(m), stream_ptr())
+        return m
+
+    def state(self):
+        n, dev = self.shard.nImg, self.shard.dev
+        off = torch.empty((n, 2), dtype=torch.float64, device=dev)
+        topR = torch.empty((n, 4), dtype=torch.float64, device=dev)
+        topT = torch.empty((n, 2), dtype=torch.float64, device=dev)
+        capi.call("thx_refine_get_state", self._h, ptr(off), ptr(topR), ptr(topT), None, stream_ptr())
+        return off, topR, topT
+
+    def fetch(self, dev_ptr, dtype, shape, offset_elems=0):
+        """host copy of a slice of one of view()'s device arrays"""
+        a = np.empty(shape, dtype)
+        capi.call("thx_memcpy_d2h", a.ctypes.data, int(dev_ptr) + offset_elems * a.itemsize, a.nbytes)
+        return a
+
+    def close(self):
+        if self._h is not None:
+            capi.call("thx_refine_destroy", self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -332,6 +332,18 @@ def pf_update(r, t, wR, wT, uR, uT, k123, s01, topR, topT, peakFactorR, seed, ca
               ptr(topT), r.shape[0], r.shape[1], t.shape[1], float(peakFactorR), int(seed), int(call), stream_ptr())
 
 
+def draw_reco(r, t, mReco, seed, call, img0=0):
+    """the mReco draws of the insertion from a resampled filter (thx_draw_reco_dev): r [n][nR][4], t [n][nT][2] f64 ->
+    rotation matrices [n][mReco][9], shifts [n][mReco][2]"""
+    _chk(r, _F64, "r"); _chk(t, _F64, "t")
+    n, nR, nT = r.shape[0], r.shape[1], t.shape[1]
+    rot = torch.empty((n, mReco, 9), dtype=_F64, device=r.device)
+    tran = torch.empty((n, mReco, 2), dtype=_F64, device=r.device)
+    capi.call("thx_draw_reco_dev", ptr(rot), ptr(tran), ptr(r), ptr(t), n, nR, nT, mReco, int(seed), int(call), int(img0),
+              stream_ptr())
+    return rot, tran
+
+
 def pf_acg_stats(quat):
     """inferACG / mean / k1..k3 / balance weights of [n][m][4] f64 clouds -> (A [n][16], mean [n][4], k [n][3], w [n][m])"""
     _chk(quat, _F64, "quat")

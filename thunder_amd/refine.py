@@ -72,10 +72,12 @@ class RefineShard:
 
     def __init__(self, N, nImg, device, rank=0, world=1, pf=2, mLR=125, mLT=9, nPhase=3, mReco=100, seed=1000,
                  batch=10240, pixelSize=1.32, snr=0.01, rL=2, ops=None, oracle_pixel_list=None, nGroup=8, groupSig=True,
-                 maskFrac=0.45, particle_filter=True, transS=2.0, data=None):
+                 maskFrac=0.45, particle_filter=True, transS=2.0, data=None, allocate=True):
         """data (optional): particles read from files instead of synthesised here -- dict(imgOri complex64 device stack
         [nImg][N][N/2+1] as Optimiser::initImg leaves _imgOri, attr float32 [nImg][7], quat [nImg][4], shift [nImg][2]
-        (initial poses, e.g. the .thu columns), gid int32 [nImg] 1-based group ids, ref float32 [N]^3 initial map)."""
+        (initial poses, e.g. the .thu columns), gid int32 [nImg] 1-based group ids, ref float32 [N]^3 initial map).
+        allocate=False: only the particles are generated (imgOri, attr, poses, initial support points, reference) and
+        handed to the native iteration driver (thunder_amd.native.NativeRefine), which owns every other buffer."""
         if ops is None:
             from . import ops as _ops
             ops = _ops
@@ -86,7 +88,7 @@ class RefineShard:
         nb = max(1, -(-nImg // max(1, batch)))
         batch = -(-nImg // nb)
         self.mLR, self.mLT, self.nPhase, self.mReco, self.batch = mLR, mLT, nPhase, mReco, batch
-        self.rU = N // 2 - 2
+        self.rU, self.rL = N // 2 - 2, rL
         self.maxRadius = self.rU
         self.groups = HalfGroups(rank, world)
         self.halves = self.groups.local_halves()
@@ -159,7 +161,6 @@ class RefineShard:
         self.iPxlM = torch.from_numpy(plM["iPxl"]).to(device)
         self.iSigE = torch.from_numpy(pl["iSig"].astype(np.int64)).to(device)
         self.imgOri = torch.zeros((nImg, N, nc), dtype=torch.complex64, device=device)
-        self.ctfM = ops.ctf(self.attr, pixelSize, self.iColM, self.iRowM, N)
         gen = torch.Generator(device=device)
         gen.manual_seed(seed + 31 * rank)
         if data is not None:
@@ -172,7 +173,7 @@ class RefineShard:
             rot = ops.rotmat(torch.from_numpy(self.quat[b0:b1]).to(device))
             sl = ops.project(v, rot, self.iColM, self.iRowM, pf)
             ramp = ops.translate(torch.from_numpy(self.shift[b0:b1]).to(device), self.iColM, self.iRowM, N)
-            sig = sl * ramp * self.ctfM[b0:b1]
+            sig = sl * ramp * ops.ctf(self.attr[b0:b1].contiguous(), pixelSize, self.iColM, self.iRowM, N)
             if b0 == 0:
                 p_sig = float((sig.abs() ** 2).mean().item())
                 self.sigma2 = p_sig / snr / 2.0  # per real component of an FT coefficient
@@ -184,7 +185,22 @@ class RefineShard:
                 rl = torch.randn((c1 - c0, N, N), generator=gen, device=device, dtype=torch.float32)
                 self.imgOri[c0:c1] += torch.fft.rfft2(rl) * float(np.sqrt(2.0 * self.sigma2) / N)
             del sig, sl, ramp, flat
+        self.transS, self.transQ = transS, 0.05                       # TRANS_Q, include/Optimiser.h:67
+        self.pfL, self.pfS, self.peakFactorR = 2.0, 0.5, 1e-3         # script/demo_3D.json:71-73, PEAK_FACTOR_MIN
+        self.use_pf = particle_filter
+        self.wg_per_cu = 2 if particle_filter else 0
+        self.pf_seed, self.pf_call = seed + 104729 * rank, 0
+        if self.use_pf:
+            q0 = synth.perturb_quats(self.quat, mLR, 0.02, rng)
+            t0 = self.shift[:, None, :] + rng.normal(0, 0.5, size=(nImg, mLT, 2))
+            self.pf0 = dict(r=torch.from_numpy(np.ascontiguousarray(q0)).to(device),
+                            t=torch.from_numpy(np.ascontiguousarray(t0)).to(device))
+            self.pf_state = {}
+        self.allocated = allocate
+        if not allocate:
+            return
         # M-step rows (_imgOri on the rL = 0 list) never change; E-step rows are re-gathered from _img every iteration
+        self.ctfM = ops.ctf(self.attr, pixelSize, self.iColM, self.iRowM, N)
         self.datM = ops.gather_pixels(self.imgOri, self.iPxlM, N)
         self.ctfP = self.ctfM[:, e2m].contiguous()
         self.img = torch.empty_like(self.imgOri)
@@ -201,20 +217,6 @@ class RefineShard:
             t[:, 0, :] = self.shift
             self.tranP.append(torch.from_numpy(np.ascontiguousarray(t)).to(device))
         self.tranP0 = [t.clone() for t in self.tranP]
-        # ---- particle filter state (Particle, src/Particle.cpp), used instead of the fixed support points ----
-        self.use_pf = particle_filter
-        # clouds of a particle filter: 2 workgroups of the local-search kernel per CU; tightly clustered fixed support
-        # points: no cap (see thx_expect_local_set_occupancy)
-        self.wg_per_cu = 2 if particle_filter else 0
-        self.pf_seed, self.pf_call = seed + 104729 * rank, 0
-        self.transS, self.transQ = transS, 0.05                       # TRANS_Q, include/Optimiser.h:67
-        self.pfL, self.pfS, self.peakFactorR = 2.0, 0.5, 1e-3         # script/demo_3D.json:71-73, PEAK_FACTOR_MIN
-        if self.use_pf:
-            q0 = synth.perturb_quats(self.quat, mLR, 0.02, rng)
-            t0 = self.shift[:, None, :] + rng.normal(0, 0.5, size=(nImg, mLT, 2))
-            self.pf0 = dict(r=torch.from_numpy(np.ascontiguousarray(q0)).to(device),
-                            t=torch.from_numpy(np.ascontiguousarray(t0)).to(device))
-            self.pf_state = {}
         self.w = torch.full((nImg,), 1.0 / mReco, dtype=torch.float32, device=device)
         nV = len(self.halves)
         self.F = torch.zeros((nV, self.P, self.P, self.P // 2 + 1), dtype=torch.complex64, device=device)
@@ -240,6 +242,16 @@ class RefineShard:
         self.sig = torch.empty((nV, nGroup, self.rSig), dtype=torch.float32, device=device)
         self.sigRcp = torch.empty_like(self.sig)
         self.reset_reference()
+
+    def release_generation_state(self):
+        """after the particles have been handed to the native driver: drop the projector volume and the reconstruction
+        plan that generated them (about 2.5 GB at N = 256)"""
+        self.vols = None
+        self.cells = None
+        if self.plan is not None:
+            self.plan.close()
+            self.plan = None
+        torch.cuda.empty_cache()
 
     # -----------------------------------------------------------------------------------------
     def _stage(self, name, timed):
@@ -358,12 +370,8 @@ class RefineShard:
         n, gen = hi - lo, self.gens[vi]
         if self.use_pf:   # the filter has been resampled by thx_pf_update_dev: Particle::rand = a uniform pick
             st = self.pf_state
-            uR = torch.randint(0, self.mLR, (n, self.mReco), device=self.dev, generator=gen)
-            uT = torch.randint(0, self.mLT, (n, self.mReco), device=self.dev, generator=gen)
-            q = torch.gather(st["r"][lo:hi], 1, uR[:, :, None].expand(-1, -1, 4)).contiguous()
-            rot = self.ops.rotmat(q.reshape(-1, 4)).reshape(n, self.mReco, 9)
-            tran = torch.gather(st["t"][lo:hi], 1, uT[:, :, None].expand(-1, -1, 2)).contiguous()
-            return rot, tran
+            self.pf_call += 1
+            return self.ops.draw_reco(st["r"][lo:hi], st["t"][lo:hi], self.mReco, self.pf_seed, self.pf_call, lo)
         rsR = torch.multinomial(wR.clamp_min(1e-30), self.mLR, replacement=True, generator=gen)   # resample
         rsT = torch.multinomial(wT.clamp_min(1e-30), self.mLT, replacement=True, generator=gen)
         uR = torch.randint(0, self.mLR, (n, self.mReco), device=self.dev, generator=gen)          # rand
