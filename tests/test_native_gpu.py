@@ -42,9 +42,11 @@ def test_native_driver_matches_python_harness(dev):
     fsc_na = nat.iterate(timed=True)
     off, topR, topT = nat.state()
     # first iteration: every particle-filter decision is a function of bit-identical likelihoods and the same Philox
-    # streams, so the top poses and the re-centring offsets agree exactly
-    assert torch.equal(topR, sh.pf_state["topR"]) and torch.equal(topT, sh.pf_state["topT"])
-    assert torch.equal(off, sh.offset)
+    # streams, so the same support points win; the shifts agree to rounding (the initial spread of the shifts, which
+    # scales their perturbation, is torch.std in the harness and k_shift_sd in the driver)
+    assert torch.equal(topR, sh.pf_state["topR"])
+    assert (topT - sh.pf_state["topT"]).abs().max().item() <= 1e-9
+    assert (off - sh.offset).abs().max().item() <= 1e-9 and off.abs().max().item() > 0.1
     # sigma tables: deterministic kernels on identical inputs
     sig = nat.fetch(v.sig, np.float32, tuple(sh.sig.shape))
     np.testing.assert_allclose(sig, sh.sig.cpu().numpy(), rtol=1e-6)
@@ -105,8 +107,10 @@ def test_native_rccl_single_rank_forced(dev, knob_env):
     ax = torch.fft.fftfreq(P, d=1.0 / P, device=dev)
     r2 = ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :P // 2 + 1] ** 2
     R = rU * pf + 2
-    row_len = torch.floor(torch.sqrt((R * R - ax[:, None] ** 2 - ax[None, :] ** 2).clamp_min(-1))) + 1
-    inside = (ax[None, None, :P // 2 + 1] < row_len[:, :, None]) & ((ax[:, None] ** 2 + ax[None, :] ** 2) <= R * R)[:, :, None]
+    ii = torch.arange(P // 2 + 1, device=dev, dtype=ax.dtype)
+    r2 = ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ii[None, None, :] ** 2
+    row_len = torch.floor(torch.sqrt((R * R - ax[:, None] ** 2 - ax[None, :] ** 2).clamp_min(0))) + 1
+    inside = (ii[None, None, :] < row_len[:, :, None]) & ((ax[:, None] ** 2 + ax[None, :] ** 2) <= R * R)[:, :, None]
     assert int(inside.sum()) == nvox.value
     assert bool((r2 <= (R - 1) ** 2)[inside.logical_not()].logical_not().all())      # every voxel within R - 1 travels
     assert torch.equal(T[inside], T0[inside]) and torch.equal(F[inside], F0[inside])
