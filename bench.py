@@ -106,6 +106,92 @@ def cpu_baseline(args, shard, nat, rounds_per_iteration):
                                                 rounds_per_iteration, n_total)}
 
 
+def bench_global_scan(args, dev):
+    """--classification: the global scanning stage of BASELINE configs[3] (3-D classification, K = 4) on one GPU's share of
+    images: every image against 4 classes x 10 000 rotations x 30 shifts at the scan radius r = 24 (866 pixels, rL = 2)
+    -- Optimiser::expectation's global loop (src/Optimiser.cpp:756-894), logDataVSPrior_m_n_huabin (:9931-9973).
+    Per class: slices of the class volume for all rotations (thx_project_dev), then thx_expect_global_dev streams every
+    image's rows against them.  This stage is a dense contraction over pixels (2 FMAs per pixel x rotation x shift), so
+    its bound is the fp32 FMA rate of the chip -- 157.3 TFLOP/s, vector or f32 MFMA alike (MI355X_MICROARCH.md) --, not HBM."""
+    import torch
+    from thunder_amd import ops, synth
+    from thunder_amd.refine import pixel_list
+    N, K, nR, nT, rScan = args.box, 4, 10000, 30, 24
+    nImg = args.scan_images
+    P = 2 * N
+    rng = np.random.default_rng(4)
+    pl = pixel_list(N, rScan, 2)
+    iCol, iRow = torch.from_numpy(pl["iCol"]).to(dev), torch.from_numpy(pl["iRow"]).to(dev)
+    nPxl = pl["nPxl"]
+    plan = ops.RecoPlan(N, N, 2)
+    vols = [plan.set_projectee(torch.from_numpy(synth.blob_map(N, seed=300 + k, nblob=20)).to(dev)) for k in range(K)]
+    mats = ops.rotmat(torch.from_numpy(synth.random_quats(nR, rng)).to(dev))
+    shifts = np.ascontiguousarray(rng.normal(0, 3.0, size=(nT, 2)))
+    traP = ops.translate(torch.from_numpy(shifts).to(dev), iCol, iRow, N)
+    attr = torch.from_numpy(synth.ctf_params(nImg, rng)).to(dev)
+    ctf = ops.ctf(attr, 1.32, iCol, iRow, N)
+    # images: a slice of a random class at a random scanned rotation / shift, plus noise
+    cls_true, r_true, t_true = rng.integers(0, K, nImg), rng.integers(0, nR, nImg), rng.integers(0, nT, nImg)
+    dat = torch.empty((nImg, nPxl), dtype=torch.complex64, device=dev)
+    for k in range(K):
+        sel = np.nonzero(cls_true == k)[0]
+        if len(sel) == 0:
+            continue
+        rot_k = mats[torch.from_numpy(r_true[sel]).to(dev)].contiguous()
+        sl = ops.project(vols[k], rot_k, iCol, iRow, 2)
+        s = torch.from_numpy(sel).to(dev)
+        dat[s] = sl * traP[torch.from_numpy(t_true[sel]).to(dev)] * ctf[s]
+    sd = 3.0 * float(dat.abs().pow(2).mean().sqrt())
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    dat = (dat + torch.view_as_complex(torch.randn((nImg, nPxl, 2), generator=g, device=dev)) * (sd / np.sqrt(2))).contiguous()
+    sigRcp = torch.full((nImg, nPxl), -0.5 / (sd * sd / 2), dtype=torch.float32, device=dev)
+    pR = torch.full((nImg, nR), 1.0 / nR, dtype=torch.float64, device=dev)
+    pT = torch.full((nImg, nT), 1.0 / nT, dtype=torch.float64, device=dev)
+    wC = torch.zeros((nImg, K), dtype=torch.float32, device=dev)
+    wR = torch.zeros((K, nImg, nR), dtype=torch.float32, device=dev)
+    wT = torch.zeros((K, nImg, nT), dtype=torch.float32, device=dev)
+    base = torch.empty((nImg,), dtype=torch.float32, device=dev)
+    from thunder_amd import capi
+    ws = torch.empty(capi.load().thx_expect_global_workspace(nImg, nR, nT), dtype=torch.uint8, device=dev)
+    rotP = torch.empty((nR, nPxl), dtype=torch.complex64, device=dev)
+    ev = []
+
+    def scan(timed):
+        wC.zero_(); wR.zero_(); wT.zero_(); base.fill_(float("nan"))
+        for k in range(K):
+            ops.project(vols[k], mats, iCol, iRow, 2, out=rotP)
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            ops.expect_global(rotP, traP, dat, ctf, sigRcp, pR, pT, wC, wR, wT, base, k, K, workspace=ws)
+            if timed:
+                e1.record()
+                ev.append((e0, e1))
+    for _ in range(args.warmup):
+        scan(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        scan(True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ok = float((wC.argmax(1).cpu().numpy() == cls_true).mean())
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    flops = 4.0 * nImg * nR * nT * nPxl          # 2 FMAs per (pixel, rotation, shift) in the expanded likelihood
+    out = {"metric": "images/sec through the global scanning stage (K = 4 classes x 10000 rotations x 30 shifts, r = 24)",
+           "value": nImg * args.steps / dt, "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": "configs[3] global scan: %d synthetic %d^3 images x %d classes x %d rotations x %d shifts at "
+                                  "r = %d (%d pixels)" % (nImg, N, K, nR, nT, rScan, nPxl), "classes_recovered": ok},
+           "roofline": {"bound": "mfma", "kernel": "k_expect_global (one class: %d images x %d rot x %d shifts)" % (nImg, nR, nT),
+                        "achieved": flops / (k_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                        "frac": flops / (k_ms * 1e-3) / 1e12 / 157.3, "traffic": None, "avg_launch_ms": k_ms,
+                        "note": "fp32 FMAs on the vector ALUs; the f32 MFMA rate of gfx950 equals the vector rate (157.3 TFLOP/s)"},
+           "cpu_baseline": None}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +209,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles", type=int, default=0, help="CPU baseline sample (default: one particle per core)")
     ap.add_argument("--cpu-no-reconstruct", action="store_true")
+    ap.add_argument("--classification", action="store_true",
+                    help="time the global scanning stage of configs[3] (K = 4 x 10000 rotations x 30 shifts at r = 24) instead")
+    ap.add_argument("--scan-images", type=int, default=1024)
     args = ap.parse_args()
 
     import torch
@@ -138,6 +227,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
+    if args.classification:
+        from thunder_amd import capi
+        capi.load()
+        bench_global_scan(args, dev)
+        return
     from thunder_amd import capi
     from thunder_amd.native import NativeRefine, make_comms, STAGES
     from thunder_amd.refine import RefineShard, shard_count

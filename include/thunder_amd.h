@@ -286,6 +286,26 @@ int thx_sigma_accum_dev(float* sigM, float* sigN, float* svd, const float* spec,
 int thx_sigma_final_dev(float* sig, float* sigRcp, const float* sigM, const float* sigN, const float* svd, int nGroup,
                         int rSig, int group, float maskRadius, int size, float pixelSize, void* stream);
 
+/* Model::compareTwoHemispheres, MODE_3D (src/Model.cpp:307-700) on the two half maps' FTs A, B (DEVICE complex64
+ * [N][N][N/2+1], modified only by the averaging):
+ *   fscHost (HOST [rU], may be NULL = fscFlag off): the gold-standard FSC (src/Functions/Spectrum.cpp:302-337); with a mask
+ *     (maskRL DEVICE [N]^3 = _maskFSC, or maskRL NULL and coreR > 0 = _coreFSC with softMask(mask, coreR, ew),
+ *     src/Functions/Mask.cpp:470-486) its mask-corrected form (:424-563): randomPhaseThres = resP(fscUnmask, 0.8, 1, 1),
+ *     FSC of the masked phase-randomised halves (randomPhase, src/Functions/Spectrum.cpp:365-386; phases from the Philox
+ *     stream (seed, element, call / call + 1, 9) instead of GSL's global generator), FSC of the masked halves,
+ *     (fscMask - fscRF) / (1 - fscRF) beyond randomPhaseThres + 2.  *randomPhaseThresOut (HOST, optional).
+ *   avgFlag: A = B = (A + B) / 2 inside QUAD_3 < avgR^2 (gold standard, one reference, :629-674; avgR =
+ *     min(AROUND(resA2P(1 / A_B_AVERAGE_THRES, size, pixelSize)), r) is the caller's), avgR < 0: everywhere (:688-696).
+ * Synchronises the stream (the FSC curves come back to the host). */
+int thx_compare_hemispheres_dev(float* A, float* B, int N, int rU, float* fscHost, const float* maskRL, float coreR, float ew,
+                                int avgFlag, int avgR, unsigned long long seed, unsigned call, int* randomPhaseThresOut,
+                                void* stream);
+/* its pieces, exposed for the parity tests: softMask(Volume& mask, r, ew) and randomPhase(dst, src, r) (phases: DEVICE
+ * [N][N][N/2+1] floats receiving the angles, may be NULL) */
+int thx_core_mask_dev(float* mask, int N, float r, float ew, void* stream);
+int thx_random_phase_dev(float* dst, const float* src, int N, int r, unsigned long long seed, unsigned call, float* phases,
+                         void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Data formats either side of the path
  * ------------------------------------------------------------------------------------------- */
@@ -315,6 +335,20 @@ int thx_mrc_write_stack(const char* path, const float* src, int size, int nSlc, 
 int thx_thu_count(const char* path, int* nParticle, int* nGroup);
 int thx_thu_load(const char* path, int nParticle, thx_ctf_attr* ctf, char* particlePath, int pathStride, int* groupID,
                  int* classID, double* quat, double* tran, double* stdT, double* defocusFactor, double* score);
+
+/* Optimiser::saveDatabase + writeDescInfo, src/Optimiser.cpp:8217-8416: writes (append = 0) or appends (the reference's
+ * ranks append in turn) the 27-column particle table: the '#' description block, then one line per particle in the
+ * reference's column order and formats (%18.9lf / %6d / %6lu).  HOST arrays; ctf and particlePath [n][pathStride] are
+ * required, the others may be NULL (written as the neutral values the loader assumes): micrographPath [n][micStride],
+ * coordXY [n][2], groupID / classID [n], quat [n][4] (Particle::rank1st), k123 [n][3], tran [n][2] (already minus the
+ * re-centring offset, OPTIMISER_RECENTRE_IMAGE_EACH_ITERATION), stdT [n][2], defocusFactor / stdDefocus / score [n]. */
+int thx_thu_write(const char* path, int append, int nParticle, const thx_ctf_attr* ctf, const char* particlePath, int pathStride,
+                  const char* micrographPath, int micStride, const double* coordXY, const int* groupID, const int* classID,
+                  const double* quat, const double* k123, const double* tran, const double* stdT, const double* defocusFactor,
+                  const double* stdDefocus, const double* score);
+/* the columns thx_thu_load leaves out (micrograph path, coordinates, K1..K3, sd of the defocus factor); any may be NULL */
+int thx_thu_load_extra(const char* path, int nParticle, char* micrographPath, int micStride, double* coordXY, double* k123,
+                       double* stdDefocus);
 
 /* Optimiser::substractBgImg, src/Optimiser.cpp:4928-4962 (OPTIMISER_INIT_IMG_NORMALISE_OUT_MASK_REGION): per image
  * (x - bgMean) / bgStddev over the pixels outside maskRadiusPx (bgMeanStddev, src/Image/ImageFunctions.cpp:607-621).

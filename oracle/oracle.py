@@ -230,6 +230,60 @@ def fsc(A, B, P, nShell):
     return out
 
 
+def res_p(fsc_, thres, pf=1, rL=1, inverse=False):
+    """resP(fsc, thres, pf, rL, inverse), src/Functions/Spectrum.cpp:339-363"""
+    n = len(fsc_)
+    if inverse:
+        result = n - 1
+        while result >= rL and not (fsc_[result] > thres):
+            result -= 1
+    else:
+        result = rL
+        while result < n and not (fsc_[result] < thres):
+            result += 1
+        result -= 1
+    return int(result / pf) if result >= 0 else -int(-result / pf)
+
+
+def compare_hemispheres(A, B, N, rU, phasesA=None, phasesB=None, mask=None, coreR=0.0, ew=6.0, avg_r=None):
+    """Model::compareTwoHemispheres, MODE_3D (src/Model.cpp:307-700): A, B complex64 half FTs [N][N][N/2+1] of the two
+    half maps.  With a mask (given, _maskFSC, or the core mask of radius coreR, _coreFSC) the mask-corrected FSC of
+    :424-563: fscUnmask -> randomPhaseThres = resP(fscUnmask, 0.8, 1, 1) -> FSC of the masked phase-randomised halves ->
+    FSC of the masked halves -> (fscMask - fscRF) / (1 - fscRF) beyond randomPhaseThres + 2.  phasesA/B: the random
+    phases per stored element (the reference draws them from GSL's global generator).  avg_r: None = no averaging,
+    >= 0: average inside that radius (:663-674), < 0: everywhere.  Returns dict(fsc, thres, A, B)."""
+    L = lib()
+    A, B = c64(A).copy(), c64(B).copy()
+    fsc_ = fsc(A, B, N, rU)
+    thres = None
+    if mask is not None or coreR > 0:
+        if mask is None:
+            mask = np.zeros((N, N, N), np.float32)
+            L.orc_core_mask(_p(mask, c_f), C.c_int(N), C.c_float(coreR), C.c_float(ew))
+        mask = f32(mask)
+        thres = res_p(fsc_, 0.8, 1, 1, False)
+
+        def masked_ft(ft):
+            rl = np.ascontiguousarray(sfft.irfftn(ft, s=(N, N, N)).astype(np.float32))   # FFT::bw incl. 1/size
+            out = np.empty_like(rl)
+            L.orc_alpha_mask(_p(out, c_f), _p(rl, c_f), _p(mask, c_f), C.c_float(0.0), C.c_size_t(rl.size))
+            return np.ascontiguousarray(sfft.rfftn(out).astype(np.complex64))
+        rp = []
+        for src, ph in ((A, phasesA), (B, phasesB)):
+            d = np.empty_like(src)
+            L.orc_random_phase(_p(d, c_f), _p(src, c_f), C.c_int(N), C.c_int(thres), _p(f32(ph), c_f))
+            rp.append(masked_ft(d))
+        fscRF = fsc(rp[0], rp[1], N, rU)
+        fscMask = fsc(masked_ft(A), masked_ft(B), N, rU)
+        out = np.empty(rU, np.float32)
+        for i in range(rU):
+            out[i] = fscMask[i] if i < thres + 2 else (fscMask[i] - fscRF[i]) / (np.float32(1) - fscRF[i])
+        fsc_ = out
+    if avg_r is not None:
+        L.orc_average_halves(_p(A, c_f), _p(B, c_f), C.c_int(N), C.c_int(int(avg_r)))
+    return dict(fsc=fsc_, thres=thres, A=A, B=B)
+
+
 # ---------------------------------------------------------------------------------------------
 def set_projectee(ref_rl, pf=2):
     """Projector::setProjectee(Volume) src/Projector.cpp:123-148 starting from the real-space map

@@ -1424,3 +1424,70 @@ void orc_resample(int* idx, double* wOut, const double* w, const double* u, int 
     for (int j = 0; j < nOut; j++) wOut[j] /= ws;
     free(cdf);
 }
+
+/* ========================================================================================== */
+/* Model::compareTwoHemispheres, 3-D mode (src/Model.cpp:307-700) -- element-wise pieces        */
+/* ========================================================================================== */
+
+/* softMask(Volume& mask, r, ew), src/Functions/Mask.cpp:470-486; in-memory layout [N][N][N] */
+void orc_core_mask(RFLOAT* mask, int N, RFLOAT r, RFLOAT ew)
+{
+    for (long k = -N / 2; k < N / 2; k++)
+        for (long j = -N / 2; j < N / 2; j++)
+            for (long i = -N / 2; i < N / 2; i++) {
+                RFLOAT u = (RFLOAT)gsl_hypot3_((double)i, (double)j, (double)k);
+                RFLOAT v;
+                if (u > r + ew) v = 0;
+                else if (u >= r) v = (RFLOAT)(0.5 + 0.5 * cos((u - r) / ew * M_PI));
+                else v = 1;
+                mask[((size_t)(k < 0 ? k + N : k) * N + (j < 0 ? j + N : j)) * N + (i < 0 ? i + N : i)] = v;
+            }
+}
+
+/* softMask(dst, src, alpha, bg), src/Functions/Mask.cpp:510-521 */
+void orc_alpha_mask(RFLOAT* dst, const RFLOAT* src, const RFLOAT* alpha, RFLOAT bg, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        RFLOAT w = 1 - alpha[i];
+        dst[i] = bg * w + src[i] * (1 - w);
+    }
+}
+
+/* randomPhase(dst, src, r), src/Functions/Spectrum.cpp:365-386, with the phases (the reference's TSGSL_ran_flat draws, one
+ * per stored element in loop order) supplied by the caller: phases[e] for the stored element e */
+void orc_random_phase(RFLOAT* dst, const RFLOAT* src, int N, int r, const RFLOAT* phases)
+{
+    const long nc = N / 2 + 1;
+    for (long k = -N / 2; k < N / 2; k++)
+        for (long j = -N / 2; j < N / 2; j++)
+            for (long i = 0; i <= N / 2; i++) {
+                size_t e = ((size_t)(k < 0 ? k + N : k) * N + (j < 0 ? j + N : j)) * nc + i;
+                int u = AROUND_(gsl_hypot3_((double)i, (double)j, (double)k));
+                RFLOAT re = src[2 * e], im = src[2 * e + 1];
+                if (u > r) {
+                    RFLOAT c = cosf(phases[e]), s = sinf(phases[e]);   /* COMPLEX_POLAR */
+                    RFLOAT nr = re * c - im * s, ni = re * s + im * c;
+                    re = nr; im = ni;
+                }
+                dst[2 * e] = re; dst[2 * e + 1] = im;
+            }
+}
+
+/* averaging of the two halves: src/Model.cpp:663-674 (inside QUAD_3 < r^2) or :620-627 / :688-696 (r < 0: everywhere) */
+void orc_average_halves(RFLOAT* A, RFLOAT* B, int N, int r)
+{
+    const long nc = N / 2 + 1;
+    for (long k = -N / 2; k < N / 2; k++)
+        for (long j = -N / 2; j < N / 2; j++)
+            for (long i = 0; i <= N / 2; i++) {
+                if (r >= 0) {
+                    RFLOAT q = (RFLOAT)((double)i * i + (double)j * j + (double)k * k);
+                    if (!(q < pow2f_((RFLOAT)r))) continue;
+                }
+                size_t e = ((size_t)(k < 0 ? k + N : k) * N + (j < 0 ? j + N : j)) * nc + i;
+                for (int c = 0; c < 2; c++) {
+                    RFLOAT avg = (A[2 * e + c] + B[2 * e + c]) / 2;
+                    A[2 * e + c] = avg; B[2 * e + c] = avg;
+                }
+            }
+}

@@ -120,6 +120,74 @@ def test_thu_table(tmp_path, lib):
         lib.call("thx_thu_load", p.encode(), n + 1, None, None, 0, gid.ctypes.data, None, None, None, None, None, None)
 
 
+def test_thu_write_roundtrip(tmp_path, lib):
+    """Optimiser::saveDatabase's table (src/Optimiser.cpp:8217-8416): written by thx_thu_write (two 'ranks': write then
+    append), read back by the library's own loaders and by a plain whitespace parser the way Database::reGenDatabase
+    (src/Database.cpp:40-100) sees it; the line layout equals the reference's fprintf format"""
+    from thunder_amd.capi import CtfAttr
+    rng = np.random.default_rng(11)
+    n = 9
+    ctf = (CtfAttr * n)()
+    for l in range(n):
+        ctf[l].voltage, ctf[l].defocusU, ctf[l].defocusV = 300000.0, 15000.5 + 10 * l, 15100.25 + 10 * l
+        ctf[l].defocusTheta, ctf[l].Cs, ctf[l].amplitudeContrast, ctf[l].phaseShift = 0.1 * l, 2.7e7, 0.1, 0.0
+    paths = C.create_string_buffer(n * 64)
+    mics = C.create_string_buffer(n * 32)
+    for l in range(n):
+        paths[l * 64:l * 64 + 64] = ("%06d@stack_%d.mrcs" % (l + 1, l % 2)).encode().ljust(64, b"\0")
+        mics[l * 32:l * 32 + 32] = ("mic_%03d.mrc" % (l % 4)).encode().ljust(32, b"\0")
+    coord = rng.uniform(0, 4000, (n, 2)); gid = (np.arange(n) % 3 + 1).astype(np.int32); cid = (np.arange(n) % 2).astype(np.int32)
+    quat = rng.normal(size=(n, 4)); quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    k123 = rng.uniform(1e-5, 1e-3, (n, 3)); tran = rng.normal(0, 2, (n, 2)); stdT = rng.uniform(0.1, 1, (n, 2))
+    dfac = rng.normal(1, 0.01, n); sdf = rng.uniform(0, 0.01, n); score = rng.uniform(0, 1, n)
+    p = str(tmp_path / "Meta_Round_001.thu")
+    cut = 5
+
+    def part(a, lo, hi):
+        return np.ascontiguousarray(a[lo:hi])
+    for lo, hi, app in ((0, cut, 0), (cut, n, 1)):
+        arrs = [part(x, lo, hi) for x in (coord, gid, cid, quat, k123, tran, stdT, dfac, sdf, score)]
+        lib.call("thx_thu_write", p.encode(), app, hi - lo, C.cast(C.byref(ctf, lo * C.sizeof(CtfAttr)), C.c_void_p),
+                 C.cast(C.byref(paths, lo * 64), C.c_void_p), 64, C.cast(C.byref(mics, lo * 32), C.c_void_p), 32,
+                 *[a.ctypes.data for a in arrs])
+    text = open(p).read().splitlines()
+    assert text[0] == "#0:VOLTAGE\tFLOAT\t18.9f" and text[13] == "#13QUATERNION_0\tFLOAT\t18.9f" and text[27] == ""
+    data = [t for t in text if t.strip() and not t.lstrip().startswith("#")]
+    assert len(data) == n and sum(t.startswith("#0:") for t in text) == 2      # every rank writes the description block
+    # the reference's line: its format string continues lines inside the literal (21 blanks before columns 7, 11, 13, 17, 20, 24, 26)
+    l = 3
+    want = ("%18.9f %18.9f %18.9f %18.9f %18.9f %18.9f %18.9f " + " " * 21 + "%s %s %18.9f %18.9f " + " " * 21 + "%6d %6d " + " " * 21
+            + "%18.9f %18.9f %18.9f %18.9f " + " " * 21 + "%18.9f %18.9f %18.9f " + " " * 21 + "%18.9f %18.9f %18.9f %18.9f " + " " * 21
+            + "%18.9f %18.9f " + " " * 21 + "%18.9f") % (
+        ctf[l].voltage, ctf[l].defocusU, ctf[l].defocusV, ctf[l].defocusTheta, ctf[l].Cs, ctf[l].amplitudeContrast, ctf[l].phaseShift,
+        "%06d@stack_%d.mrcs" % (l + 1, l % 2), "mic_%03d.mrc" % (l % 4), coord[l, 0], coord[l, 1], gid[l], cid[l], *quat[l], *k123[l],
+        *tran[l], *stdT[l], dfac[l], sdf[l], score[l])
+    assert data[l] == want
+    cols = [t.split() for t in data]
+    assert all(len(c) == 27 for c in cols)
+    # read back through the library
+    cnt, grp = C.c_int(), C.c_int()
+    lib.call("thx_thu_count", p.encode(), C.byref(cnt), C.byref(grp))
+    assert (cnt.value, grp.value) == (n, 3)
+    ctf2 = (CtfAttr * n)(); paths2 = C.create_string_buffer(n * 64); mics2 = C.create_string_buffer(n * 32)
+    gid2 = np.zeros(n, np.int32); cid2 = np.zeros(n, np.int32)
+    quat2 = np.zeros((n, 4)); tran2 = np.zeros((n, 2)); stdT2 = np.zeros((n, 2)); dfac2 = np.zeros(n); score2 = np.zeros(n)
+    coord2 = np.zeros((n, 2)); k2 = np.zeros((n, 3)); sdf2 = np.zeros(n)
+    lib.call("thx_thu_load", p.encode(), n, C.cast(ctf2, C.c_void_p), C.cast(paths2, C.c_void_p), 64, gid2.ctypes.data,
+             cid2.ctypes.data, quat2.ctypes.data, tran2.ctypes.data, stdT2.ctypes.data, dfac2.ctypes.data, score2.ctypes.data)
+    lib.call("thx_thu_load_extra", p.encode(), n, C.cast(mics2, C.c_void_p), 32, coord2.ctypes.data, k2.ctypes.data, sdf2.ctypes.data)
+    assert paths2.raw == paths.raw and mics2.raw == mics.raw
+    assert np.array_equal(gid2, gid) and np.array_equal(cid2, cid)
+    for a, b in ((quat2, quat), (tran2, tran), (stdT2, stdT), (dfac2, dfac), (score2, score), (coord2, coord), (k2, k123), (sdf2, sdf)):
+        assert np.allclose(a, b, atol=6e-10, rtol=0)
+    assert all(abs(ctf2[l].defocusU - ctf[l].defocusU) < 1e-2 and ctf2[l].Cs == ctf[l].Cs for l in range(n))
+    # only the required columns given: neutral values for the rest
+    lib.call("thx_thu_write", p.encode(), 0, 2, C.cast(ctf, C.c_void_p), C.cast(paths, C.c_void_p), 64, None, 0, None, None, None, None,
+             None, None, None, None, None, None)
+    c = [t.split() for t in open(p).read().splitlines() if t.strip() and not t.startswith("#")]
+    assert len(c) == 2 and c[0][8] == "mic.mrc" and [float(x) for x in c[0][13:17]] == [1, 0, 0, 0] and float(c[0][24]) == 1
+
+
 def test_ingestion_oracle_statistics(oracle):
     """the oracle's GSL-style running statistics against numpy on a noisy disc image"""
     O = oracle

@@ -252,3 +252,31 @@ def test_golden_regression(oracle):
     assert np.allclose(tab[:64], g["tab_head"], rtol=1e-6) and np.allclose(tab[-64:], g["tab_tail"], rtol=1e-6)
     assert abs(tab.sum(dtype=np.float64) - float(g["tab_sum"])) <= 1e-6 * float(g["tab_sum"])
     assert tab[0] == np.float32(g["nf"])  # MKB_RL_R2(0) == MKB_RL(0) == nf
+
+
+def test_compare_hemispheres_oracle_properties(oracle):
+    """mask-corrected FSC of Model::compareTwoHemispheres (oracle side): identical halves give FSC = 1 with or without the
+    correction; for independent noise the phase-randomised, masked FSC is ~0 beyond the substitution shell, so the
+    corrected curve stays close to the masked one; resP follows src/Functions/Spectrum.cpp:339-363"""
+    import scipy.fft as sfft
+    from thunder_amd import synth
+    O = oracle
+    N, rU = 32, 15
+    rng = np.random.default_rng(3)
+    ref = synth.blob_map(N, nblob=10)
+    ft = np.ascontiguousarray(sfft.rfftn(ref).astype(np.complex64))
+    ph = rng.uniform(0, 2 * np.pi, size=ft.shape).astype(np.float32)
+    same = O.compare_hemispheres(ft, ft, N, rU, ph, ph, coreR=9.0)
+    assert np.all(np.abs(same["fsc"] - 1) < 1e-4)
+    assert O.res_p(np.array([1, .9, .85, .7, .9]), 0.8) == 2 and O.res_p(np.array([1, .9, .9]), 0.8) == 2
+    assert O.res_p(np.array([1, .5, .9, .2]), 0.8, inverse=True) == 2
+    noise = [np.ascontiguousarray(sfft.rfftn(rng.normal(size=(N, N, N)).astype(np.float32) * np.abs(ref).max() * 0.3).astype(np.complex64))
+             for _ in range(2)]
+    ph2 = rng.uniform(0, 2 * np.pi, size=ft.shape).astype(np.float32)
+    out = O.compare_hemispheres(ft + noise[0], ft + noise[1], N, rU, ph, ph2, coreR=9.0, avg_r=4)
+    plain = O.fsc(ft + noise[0], ft + noise[1], N, rU)
+    assert out["thres"] is not None and out["fsc"][0] > 0.99
+    assert np.all(out["fsc"][:out["thres"] + 2] >= plain[:out["thres"] + 2] - 0.02)   # masking removes noise outside the core
+    k = np.fft.fftfreq(N) * N
+    r2 = k[:, None, None] ** 2 + k[None, :, None] ** 2 + k[None, None, :N // 2 + 1] ** 2
+    assert np.array_equal(out["A"][r2 < 16], out["B"][r2 < 16]) and not np.array_equal(out["A"][r2 >= 16], out["B"][r2 >= 16])

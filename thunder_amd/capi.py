@@ -80,6 +80,12 @@ SIGNATURES = {
     "thx_reco_allreduce_workspace": (_sz, [_i, _i, _i]),
     "thx_reco_allreduce": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "thx_reco_sphere_pack_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, C.POINTER(C.c_long), _vp]),
+    "thx_compare_hemispheres_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp, _f, _f, _i, _i, C.c_ulonglong, C.c_uint, C.POINTER(_i),
+                                         _vp]),
+    "thx_core_mask_dev": (_i, [_vp, _i, _f, _f, _vp]),
+    "thx_random_phase_dev": (_i, [_vp, _vp, _i, _i, C.c_ulonglong, C.c_uint, _vp, _vp]),
+    "thx_thu_write": (_i, [C.c_char_p, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "thx_thu_load_extra": (_i, [C.c_char_p, _i, _vp, _i, _vp, _vp, _vp]),
     "thx_pixel_list_host": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "thx_draw_reco_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_ulonglong, C.c_uint, C.c_uint, _vp]),
     "thx_refine_create": (_i, [C.POINTER(_vp), C.POINTER(RefineConfig), _vp, _vp]),

@@ -400,6 +400,83 @@ int thx_thu_load(const char* path, int nParticle, thx_ctf_attr* ctf, char* parti
     return 0;
 }
 
+// Optimiser::saveDatabase (src/Optimiser.cpp:8251-8416) + writeDescInfo (:8217-8249): the 27-column table the next run
+// (or the reference) reads back.  The reference's ranks append in turn (rank 1 opens "w", the others "a", every rank
+// writes the '#' description block); `append` selects the mode.  Column formats and order as the reference's fprintf.
+int thx_thu_write(const char* path, int append, int nParticle, const thx_ctf_attr* ctf, const char* particlePath, int pathStride,
+                  const char* micrographPath, int micStride, const double* coordXY, const int* groupID, const int* classID,
+                  const double* quat, const double* k123, const double* tran, const double* stdT, const double* defocusFactor,
+                  const double* stdDefocus, const double* score)
+{
+    THX_REQUIRE(path && nParticle >= 0 && ctf && particlePath && pathStride > 1, "bad arguments");
+    File fh;
+    fh.f = fopen(path, append ? "a" : "w");
+    if (!fh.f) { set_error("FAIL TO OPEN %s FOR WRITING", path); return -2; }
+    FILE* file = fh.f;
+    static const char* desc[27] = {"#0:VOLTAGE\tFLOAT\t18.9f", "#1:DEFOCUS_U\tFLOAT\t18.9f", "#2:DEFOCUS_V\tFLOAT\t18.9f",
+                                   "#3:DEFOCUS_THETA\tFLOAT\t18.9f", "#4:CS\tFLOAT\t18.9f", "#5:AMPLITUTDE_CONTRAST\tFLOAT\t18.9f",
+                                   "#6:PHASE_SHIFT\tFLOAT\t18.9f", "#7:PARTICLE_PATH\tSTRING", "#8:MICROGRAPH_PATH\tSTRING",
+                                   "#9:COORDINATE_X\tFLOAT\t18.9f", "#10:COORDINATE_Y\tFLOAT\t18.9f", "#11:GROUP_ID\tINT\t6d",
+                                   "#12:CLASS_ID\tINT\t6d", "#13QUATERNION_0\tFLOAT\t18.9f", "#14:QUATERNION_1\tFLOAT\t18.9f",
+                                   "#15:QUATERNION_2\tFLOAT\t18.9f", "#16:QUATERNION_3\tFLOAT\t18.9f", "#17:K1\tFLOAT\t18.9f",
+                                   "#18:K2\tFLOAT\t18.9f", "#19:K3\tFLOAT\t18.9f", "#20:TRANSLATION_X\tFLOAT\t18.9f",
+                                   "#21:TRANSLATION_Y\tFLOAT\t18.9f", "#22:STD_TRANSLATION_X\tFLOAT\t18.9f",
+                                   "#23:STD_TRANSLATION_Y\tFLOAT\t18.9f", "#24:DEFOCUS_FACTOR\tFLOAT\t18.9f",
+                                   "#25:STD_DEFOCUS_FACTOR\tFLOAT\t18.9f", "#26:SCORE\tFLOAT\t18.9f\n"};
+    for (int c = 0; c < 27; c++) fprintf(file, "%s\n", desc[c]);
+    const char* pad = "                     ";   // the reference's format string continues its lines inside the literal
+    for (int l = 0; l < nParticle; l++) {
+        const thx_ctf_attr& a = ctf[l];
+        const char* mic = micrographPath ? micrographPath + (size_t)l * micStride : "mic.mrc";
+        fprintf(file, "%18.9lf %18.9lf %18.9lf %18.9lf %18.9lf %18.9lf %18.9lf %s%s %s %18.9lf %18.9lf %s%6d %6lu %s"
+                      "%18.9lf %18.9lf %18.9lf %18.9lf %s%18.9lf %18.9lf %18.9lf %s%18.9lf %18.9lf %18.9lf %18.9lf %s%18.9lf %18.9lf %s"
+                      "%18.9lf\n",
+                (double)a.voltage, (double)a.defocusU, (double)a.defocusV, (double)a.defocusTheta, (double)a.Cs,
+                (double)a.amplitudeContrast, (double)a.phaseShift, pad, particlePath + (size_t)l * pathStride, mic,
+                coordXY ? coordXY[2 * (size_t)l] : 0.0, coordXY ? coordXY[2 * (size_t)l + 1] : 0.0, pad, groupID ? groupID[l] : 1,
+                (unsigned long)(classID ? classID[l] : 0), pad, quat ? quat[4 * (size_t)l] : 1.0, quat ? quat[4 * (size_t)l + 1] : 0.0,
+                quat ? quat[4 * (size_t)l + 2] : 0.0, quat ? quat[4 * (size_t)l + 3] : 0.0, pad, k123 ? k123[3 * (size_t)l] : 1.0,
+                k123 ? k123[3 * (size_t)l + 1] : 1.0, k123 ? k123[3 * (size_t)l + 2] : 1.0, pad, tran ? tran[2 * (size_t)l] : 0.0,
+                tran ? tran[2 * (size_t)l + 1] : 0.0, stdT ? stdT[2 * (size_t)l] : 0.0, stdT ? stdT[2 * (size_t)l + 1] : 0.0, pad,
+                defocusFactor ? defocusFactor[l] : 1.0, stdDefocus ? stdDefocus[l] : 0.0, pad, score ? score[l] : 0.0);
+    }
+    if (ferror(file)) { set_error("write error on %s", path); return -3; }
+    return 0;
+}
+
+// the columns thx_thu_load does not return: micrograph path, coordinates, K1..K3, sd of the defocus factor
+int thx_thu_load_extra(const char* path, int nParticle, char* micrographPath, int micStride, double* coordXY, double* k123,
+                       double* stdDefocus)
+{
+    THX_REQUIRE(path && nParticle >= 0, "bad arguments");
+    File fh;
+    fh.f = fopen(path, "r");
+    if (!fh.f) { set_error("FAIL TO OPEN DATABASE (%s)", path); return -2; }
+    std::vector<char> line(1 << 16);
+    int l = 0;
+    while (l < nParticle && fgets(line.data(), (int)line.size() - 1, fh.f)) {
+        if (!thu_data_line(line.data())) continue;
+        double v[27];
+        for (int c = 0; c < 27; c++) v[c] = 0;
+        std::string mic;
+        int col = 0;
+        for (char* w = strtok(line.data(), " \t\r\n"); w && col < 27; w = strtok(nullptr, " \t\r\n"), col++) {
+            if (col == 8) mic = w;
+            else if (col != 7) v[col] = atof(w);
+        }
+        if (micrographPath && micStride > 1) {
+            strncpy(micrographPath + (size_t)l * micStride, mic.c_str(), micStride - 1);
+            micrographPath[(size_t)l * micStride + micStride - 1] = 0;
+        }
+        if (coordXY) { coordXY[2 * (size_t)l] = v[9]; coordXY[2 * (size_t)l + 1] = v[10]; }
+        if (k123) for (int c = 0; c < 3; c++) k123[3 * (size_t)l + c] = v[17 + c];
+        if (stdDefocus) stdDefocus[l] = v[25];
+        l++;
+    }
+    if (l != nParticle) { set_error("%s holds %d particles, %d requested", path, l, nParticle); return -9; }
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // ingestion on the device
 // ---------------------------------------------------------------------------------------------
