@@ -259,3 +259,37 @@ def test_expect_local_many_shifts(oracle, dev, nT):
         wl = want["logW"][:, :, 0].T
         np.testing.assert_allclose(a.logW[l, 0].cpu().numpy(), wl, rtol=0, atol=1e-5 * np.abs(wl).max())
         np.testing.assert_allclose(a.wT[l].cpu().numpy(), want["wT"].reshape(-1), rtol=2e-3)
+
+
+def test_insert_bit_reproducible_n256(dev):
+    """the window kernel accumulates in fixed point end to end (LDS bricks AND the global volumes, thx_mstep.hip:acc_add), so
+    F and T are bit-identical from run to run whatever the scheduling -- 96 images x 100 filter draws at the bench's box"""
+    from thunder_amd import ops, synth
+    from thunder_amd.refine import pixel_list
+    rng = np.random.default_rng(77)
+    N, P, nImg, mReco = 256, 512, 96, 100
+    pl = pixel_list(N, N // 2 - 2, 0)
+    quat0 = synth.random_quats(nImg, rng)
+    quat, tran = _filter_draws(rng, synth, quat0, rng.normal(0, 2.0, size=(nImg, 2)), nImg, 125, 9, mReco, 0.03)
+    dat = T((rng.normal(size=(nImg, pl["nPxl"])) + 1j * rng.normal(size=(nImg, pl["nPxl"]))).astype(np.complex64), dev)
+    ctf = T(rng.uniform(-1, 1, size=(nImg, pl["nPxl"])).astype(np.float32), dev)
+    w = T((rng.uniform(0.2, 1.0, size=nImg) / mReco).astype(np.float32), dev)
+    rot = ops.rotmat(T(quat.reshape(-1, 4), dev)).reshape(nImg, mReco, 9)
+    trn, iCol, iRow = T(tran, dev), T(pl["iCol"], dev), T(pl["iRow"], dev)
+    outs = []
+    for rep in range(3):
+        F = torch.zeros((P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
+        Tt = torch.zeros((P, P, P // 2 + 1), dtype=torch.float32, device=dev)
+        ops.insert(F, Tt, P, dat, ctf, w, rot, trn, iCol, iRow, 2, N)
+        if rep == 1:   # perturb the scheduling: other work in flight on a second stream
+            s2 = torch.cuda.Stream()
+            with torch.cuda.stream(s2):
+                junk = torch.randn(1 << 26, device=dev).cumsum(0)
+            s2.synchronize()
+            del junk
+        outs.append((F, Tt))
+    for F, Tt in outs[1:]:
+        assert torch.equal(F, outs[0][0]) and torch.equal(Tt, outs[0][1])
+    mass = float(Tt.sum(dtype=torch.float64))
+    want = float((w.double()[:, None] * ctf.double() ** 2).sum()) * mReco
+    assert abs(mass - want) <= 2e-5 * want

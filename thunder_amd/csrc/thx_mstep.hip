@@ -248,6 +248,9 @@ struct InsertWinArgs {
     const int* pixIndex;
     const int* plan;
     const float2* bounds;   // [nImg]: max(|re| + |im|) of the image row, max |ctf|
+    long long* accF;        // [nK][vol][2] fixed-point accumulators of this launch (see acc_add)
+    long long* accT;        // [nK][vol]
+    const int* gexp;        // [2]: E_F, E_T (k_insert_scale)
     float minQuanta;
     int nW;                 // windows per side; window w covers [pOrg + w kWd, pOrg + (w+1) kWd)
     int pOrg;
@@ -273,6 +276,66 @@ __global__ __launch_bounds__(256) void k_insert_bounds(float2* __restrict__ boun
         bounds[img] = make_float2(fmaxf(fmaxf(sa[0], sa[1]), fmaxf(sa[2], sa[3])), fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
 }
 
+// exponents of an image's brick quanta: the largest powers of two with |F term| * 2^eF <= 2^(31 - lg), T * 2^eT <= 2^(32 - lg)
+__device__ __forceinline__ void image_exponents(float boundF, float boundT, int lg, int& eF, int& eT)
+{
+    int ebF = 0, ebT = 0;
+    (void)frexpf(boundF, &ebF);   // bound = m 2^eb, m in [0.5, 1)
+    (void)frexpf(boundT, &ebT);
+    eF = 31 - lg - ebF;
+    eT = 32 - lg - ebT;
+}
+
+// one launch-wide pair of exponents: the finest image quantum, at most 2^10 finer than that of the image with the largest
+// bound (coarser images shift left exactly; a rare image more than 2^10 below the largest shifts right, i.e. is rounded
+// to the launch's quantum -- 2^-41 of the largest term).  Headroom: 65535 images x 2^31 x 2^10 < 2^63.
+__global__ __launch_bounds__(256) void k_insert_scale(int* __restrict__ gexp, const float2* __restrict__ bounds,
+                                                      const float* __restrict__ w, int nImg, int mReco, int cSearch)
+{
+    __shared__ int sMaxF[4], sMinF[4], sMaxT[4], sMinT[4];
+    int lg = 32 - __clz(2 * mReco - 1);
+    lg = lg > 20 ? 20 : lg;
+    int maxF = INT_MIN, minF = INT_MAX, maxT = INT_MIN, minT = INT_MAX;
+    for (int l = threadIdx.x; l < nImg; l += blockDim.x) {
+        const float2 bnd = bounds[l];
+        const float cmax = cSearch ? 1.0f : bnd.y, wg = fabsf(w[l]);
+        const float bF = bnd.x * cmax * wg, bT = cmax * cmax * wg;
+        int eF, eT;
+        image_exponents(bF, bT, lg, eF, eT);
+        if (bF > 0.f) { maxF = max(maxF, eF); minF = min(minF, eF); }
+        if (bT > 0.f) { maxT = max(maxT, eT); minT = min(minT, eT); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        maxF = max(maxF, __shfl_xor(maxF, o, 64)); minF = min(minF, __shfl_xor(minF, o, 64));
+        maxT = max(maxT, __shfl_xor(maxT, o, 64)); minT = min(minT, __shfl_xor(minT, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { const int wv = threadIdx.x >> 6; sMaxF[wv] = maxF; sMinF[wv] = minF; sMaxT[wv] = maxT; sMinT[wv] = minT; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int wv = 1; wv < 4; wv++) { maxF = max(maxF, sMaxF[wv]); minF = min(minF, sMinF[wv]); maxT = max(maxT, sMaxT[wv]); minT = min(minT, sMinT[wv]); }
+        maxF = max(sMaxF[0], maxF); minF = min(sMinF[0], minF); maxT = max(sMaxT[0], maxT); minT = min(sMinT[0], minT);
+        gexp[0] = minF == INT_MAX ? 0 : min(maxF, minF + 10);
+        gexp[1] = minT == INT_MAX ? 0 : min(maxT, minT + 10);
+    }
+}
+
+// F += accF 2^-E_F, T += accT 2^-E_T for the voxels the launch touched; one thread per voxel (deterministic)
+__global__ __launch_bounds__(256) void k_insert_convert(float2* __restrict__ F, float* __restrict__ T, const long long* __restrict__ accF,
+                                                        const long long* __restrict__ accT, const int* __restrict__ gexp, size_t n)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const long long re = accF[2 * e], im = accF[2 * e + 1], tt = accT[e];
+    if ((re | im | tt) == 0) return;
+    const double iF = ldexp(1.0, -gexp[0]), iT = ldexp(1.0, -gexp[1]);
+    float2 f = F[e];
+    f.x = f.x + (float)((double)re * iF);
+    f.y = f.y + (float)((double)im * iF);
+    F[e] = f;
+    T[e] = T[e] + (float)((double)tt * iT);
+}
+
 struct WinGeom {
     int p0, q0, w0;        // window origin in brick coordinates (w0 = slab base relative to the sheared plane)
     int ui0, uj0;          // origin of the tabulated pixel range
@@ -280,7 +343,9 @@ struct WinGeom {
     const float2* ecol;    // LDS [kMaxU][kIPix] exp(-i 2 pi i tx_u / N) (valid when U <= kMaxU)
     const float2* erow;    // LDS [kMaxU][kIPix]
     float sp, sq;
-    float scaleF, scaleT, invF, invT, minQ;
+    float scaleF, scaleT, minQ;   // scaleF / scaleT: the image's brick quanta per unit, powers of two
+    int shF, shT;                 // left shifts taking brick quanta to the launch's global quanta (negative: right)
+    float gF, gT;                 // global quanta per unit, 2^E_F / 2^E_T
 };
 
 // Rarely taken branches of insert_win_group, kept out of line: inlined, their temporaries (sincos / atan2 sequences, 64-bit
@@ -302,13 +367,24 @@ __device__ __attribute__((noinline)) float insert_ctf_search(const thx_ctf_attr*
     const CtfConst cc = ctf_const(attr[img], dfac[(size_t)img * mReco + rep]);
     return ctf_value(cc, pixelSize, idim, idim, pi, pj);
 }
-__device__ __forceinline__ void insert_tiny_term(float2* F, float* T, int P, int X, int Y, int Z, float re, float im, float tt)
+// The volume accumulators of the window kernel are 64-bit FIXED POINT (quanta 2^-E_F / 2^-E_T of one unit, one pair of
+// exponents per launch, k_insert_scale): integer atomic adds commute, so F and T come out bit-identical run to run whatever
+// the order in which workgroups flush -- the float atomics of the first version made the gridding loop's round count move
+// by +-10 % from run to run.  k_insert_convert adds the accumulators to the caller's float volumes afterwards.
+__device__ __forceinline__ void acc_add(long long* F, long long* T, long gi, long long re, long long im, long long tt)
+{
+    atomicAdd(reinterpret_cast<unsigned long long*>(F + 2 * gi), (unsigned long long)re);
+    atomicAdd(reinterpret_cast<unsigned long long*>(F + 2 * gi + 1), (unsigned long long)im);
+    atomicAdd(reinterpret_cast<unsigned long long*>(T + gi), (unsigned long long)tt);
+}
+__device__ __forceinline__ long long shift_ll(long long v, int sh) { return sh >= 0 ? v << sh : v >> (-sh); }
+
+__device__ __forceinline__ void insert_tiny_term(long long* F, long long* T, int P, int X, int Y, int Z, float re, float im, float tt,
+                                                 float gF, float gT)
 {
     const long nc = P / 2 + 1;
     const long gi = ((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X;
-    unsafeAtomicAdd(&F[gi].x, re);
-    unsafeAtomicAdd(&F[gi].y, im);
-    unsafeAtomicAdd(&T[gi], tt);
+    acc_add(F, T, gi, __float2ll_rn(re * gF), __float2ll_rn(im * gF), __float2ll_rn(tt * gT));
 }
 
 // A group whose plane is far from the image's reference plane (|normal component along the shear axis| < kFarGroup, i.e.
@@ -388,7 +464,7 @@ __device__ __forceinline__ int win_pack(int pi, int pj, int gi) { return pi | ((
 
 template <int AX>
 __device__ __forceinline__ void win_process(const InsertWinArgs& wa, const WinGeom& g, int* sRe, int* sIm, int* sT,
-                                            const DrawTables& dt, int img, float wgt, float2* F, float* T, int pk)
+                                            const DrawTables& dt, int img, float wgt, long long* F, long long* T, int pk)
 {
     const InsertArgs& a = wa.a;
     constexpr int pa = AX == 0 ? 1 : 0;
@@ -450,7 +526,7 @@ __device__ __forceinline__ void win_process(const InsertWinArgs& wa, const WinGe
             atomicAdd(reinterpret_cast<unsigned*>(&sT[idx]), __float2uint_rn(tq));
         } else {
             // tiny term: F and T travel together as floats
-            insert_tiny_term(F, T, P, w.X0 + ii, w.Y0 + jj, w.Z0 + kk, vre * wv, vim * wv, tval * wv);
+            insert_tiny_term(F, T, P, w.X0 + ii, w.Y0 + jj, w.Z0 + kk, vre * wv, vim * wv, tval * wv, g.gF, g.gT);
         }
     }
 }
@@ -458,7 +534,7 @@ __device__ __forceinline__ void win_process(const InsertWinArgs& wa, const WinGe
 // the entries still waiting at the end of a slab
 template <int AX>
 __device__ __forceinline__ void win_drain(const InsertWinArgs& wa, const WinGeom& g, int* sRe, int* sIm, int* sT,
-                                          const DrawTables& dt, int img, float wgt, float2* F, float* T, volatile int* queue,
+                                          const DrawTables& dt, int img, float wgt, long long* F, long long* T, volatile int* queue,
                                           int& qn)
 {
     if (qn > 0) {
@@ -473,7 +549,7 @@ __device__ __forceinline__ void win_drain(const InsertWinArgs& wa, const WinGeom
 template <int AX>
 __device__ __forceinline__ void win_enqueue(const InsertWinArgs& wa, const WinGeom& g, int* sRe, int* sIm, int* sT,
                                             const DrawTables& dt, int img, int gi_, int i0, int nI, int j0, int nJ, float wgt,
-                                            float2* F, float* T, volatile int* queue, int& qn)
+                                            long long* F, long long* T, volatile int* queue, int& qn)
 {
     const InsertArgs& a = wa.a;
     constexpr int pa = AX == 0 ? 1 : 0;
@@ -525,8 +601,8 @@ __device__ __forceinline__ void win_enqueue(const InsertWinArgs& wa, const WinGe
 }
 
 template <int AX>
-__device__ __forceinline__ void insert_win_flush(const InsertArgs& a, const WinGeom& g, int* sRe, int* sIm, int* sT, float2* F,
-                                                 float* T)
+__device__ __forceinline__ void insert_win_flush(const InsertArgs& a, const WinGeom& g, int* sRe, int* sIm, int* sT, long long* F,
+                                                 long long* T)
 {
     constexpr int pa = AX == 0 ? 1 : 0;
     constexpr int qa = AX == 2 ? 1 : 2;
@@ -536,7 +612,6 @@ __device__ __forceinline__ void insert_win_flush(const InsertArgs& a, const WinG
         const int ire = sRe[e], iim = sIm[e], itt = sT[e];
         if ((ire | iim | itt) == 0) continue;
         sRe[e] = 0; sIm[e] = 0; sT[e] = 0;
-        const float re = (float)ire * g.invF, im = (float)iim * g.invF, tt = (float)(unsigned)itt * g.invT;
         int p_i, q_i, off;
         if (AX == 0) { off = e % kWz; const int r = e / kWz; q_i = r / kWd; p_i = r - q_i * kWd; }
         else { const int r = e / kWd; p_i = e - r * kWd; off = r % kWz; q_i = r / kWz; }
@@ -547,9 +622,7 @@ __device__ __forceinline__ void insert_win_flush(const InsertArgs& a, const WinG
         int Z = qa == 2 ? bq : ba;
         if (X < 0) { X = -1 - X; Y = -Y; Z = -Z; }
         const long gi = ((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X;
-        unsafeAtomicAdd(&F[gi].x, re);
-        unsafeAtomicAdd(&F[gi].y, im);
-        unsafeAtomicAdd(&T[gi], tt);
+        acc_add(F, T, gi, shift_ll((long long)ire, g.shF), shift_ll((long long)iim, g.shF), shift_ll((long long)(unsigned)itt, g.shT));
     }
 }
 
@@ -638,15 +711,18 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
     dt.R = sR; dt.gStart = sGStart; dt.mUid = sMUid; dt.gInfo = sGInfo; dt.slope = sSlope; dt.G = G; dt.U = U;
     int lg = 32 - __clz(2 * a.mReco - 1);
     lg = lg > 20 ? 20 : lg;
-    const float qT = ldexpf(1.0f, 32 - lg), qF = ldexpf(1.0f, 31 - lg);
     const float2 bnd = wa.bounds[img];
     const float cmax = a.cSearch ? 1.0f : bnd.y;
     const float boundF = bnd.x * cmax * fabsf(wgt), boundT = cmax * cmax * fabsf(wgt);
     if (!(boundF > 0.f) && !(boundT > 0.f)) return;
-    g.scaleF = boundF > 0.f ? qF / boundF : 0.f;
-    g.scaleT = boundT > 0.f ? qT / boundT : 0.f;
-    g.invF = boundF / qF;
-    g.invT = boundT / qT;
+    // brick quanta: the largest power of two with  bound * scale <= 2^(31 - lg) (F, signed) / 2^(32 - lg) (T, unsigned)
+    int eF, eT;
+    image_exponents(boundF, boundT, lg, eF, eT);
+    g.scaleF = boundF > 0.f ? ldexpf(1.0f, eF) : 0.f;
+    g.scaleT = boundT > 0.f ? ldexpf(1.0f, eT) : 0.f;
+    const int EF = wa.gexp[0], ET = wa.gexp[1];
+    g.shF = EF - eF; g.shT = ET - eT;
+    g.gF = ldexpf(1.0f, EF); g.gT = ldexpf(1.0f, ET);
     g.minQ = wa.minQuanta;
     g.q0 = wa.pOrg + wqI * kWd;
     g.pix = sPix; g.ecol = sEc; g.erow = sEr;
@@ -663,8 +739,8 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
             __syncthreads();
             if (!sCls) continue;
         }
-        float2* F = a.F + (size_t)pass * volSize;
-        float* T = a.T + (size_t)pass * volSize;
+        long long* F = wa.accF + (size_t)pass * volSize * 2;
+        long long* T = wa.accT + (size_t)pass * volSize;
         for (int wpI = 0; wpI < wa.nW; wpI++) {
             g.p0 = wa.pOrg + wpI * kWd;
             // nearest point of the (padded) window to the origin, in the (p, q) projection: beyond every sample?
@@ -828,6 +904,7 @@ __global__ __launch_bounds__(256) void k_insert_far(InsertWinArgs wa)
     const float an0 = fabsf(n0), an1 = fabsf(n1), an2 = fabsf(n2);
     const int ax = (an0 >= an1 && an0 >= an2) ? 0 : (an1 >= an2 ? 1 : 2);
     const float wgt = a.w[img];
+    const float gF = ldexpf(1.0f, wa.gexp[0]), gT = ldexpf(1.0f, wa.gexp[1]);
     const double offx = a.offS ? a.offS[2 * img] : 0.0, offy = a.offS ? a.offS[2 * img + 1] : 0.0;
     for (int gi_ = 0; gi_ < G; gi_++) {
         const int rep = pGRep[gi_];
@@ -837,8 +914,8 @@ __global__ __launch_bounds__(256) void k_insert_far(InsertWinArgs wa)
         const int m0 = pGStart[gi_], m1 = pGStart[gi_ + 1];
         const float nmem = (float)(m1 - m0);
         const int k = a.cls ? a.cls[(size_t)img * a.mReco + rep] : 0;
-        float2* F = a.F + (size_t)k * volSize;
-        float* T = a.T + (size_t)k * volSize;
+        long long* F = wa.accF + (size_t)k * volSize * 2;
+        long long* T = wa.accT + (size_t)k * volSize;
         for (int p = threadIdx.x; p < a.nPxl; p += blockDim.x) {
             const int pi = a.iCol[p], pj = a.iRow[p];
             const float2 dv = a.datP[(size_t)img * a.nPxl + p];
@@ -871,9 +948,7 @@ __global__ __launch_bounds__(256) void k_insert_far(InsertWinArgs wa)
                     for (int ii = 0; ii < 2; ii++) {
                         const float wv = cell.w[kk * 4 + jj * 2 + ii];
                         const long idx = cell.rowOff[kk][jj] + ii;
-                        unsafeAtomicAdd(&F[idx].x, vre * wv);
-                        unsafeAtomicAdd(&F[idx].y, vim * wv);
-                        unsafeAtomicAdd(&T[idx], tval * wv);
+                        acc_add(F, T, idx, __float2ll_rn((vre * wv) * gF), __float2ll_rn((vim * wv) * gF), __float2ll_rn((tval * wv) * gT));
                     }
         }
     }
@@ -997,6 +1072,8 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
     int* plan = nullptr;
     const int half = idim / 2;
     float2* bounds = nullptr;
+    int* gexp = nullptr;
+    long long *accF = nullptr, *accT = nullptr;
     size_t ldsWin = 0;
     if (win) {
         const size_t tb = (size_t)idim * (half + 1) * sizeof(int);
@@ -1008,9 +1085,17 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
         THX_REQUIRE(plan, "device scratch allocation failed");
         hipLaunchKernelGGL(k_insert_plan, dim3(nImg), dim3(128), 5 * (size_t)mReco * sizeof(int), st, plan, rotMat, trans, cls, dfac,
                            cSearch, mReco);
-        bounds = reinterpret_cast<float2*>(scratch(st, 6, (size_t)nImg * sizeof(float2)));
+        bounds = reinterpret_cast<float2*>(scratch(st, 6, (size_t)nImg * sizeof(float2) + 16));
         THX_REQUIRE(bounds, "device scratch allocation failed");
         hipLaunchKernelGGL(k_insert_bounds, dim3(nImg), dim3(256), 0, st, bounds, a.datP, a.ctfP, nPxl);
+        // launch-wide fixed-point exponents + the 64-bit accumulators (zeroed; converted into F / T at the end of the call)
+        gexp = reinterpret_cast<int*>(bounds + nImg);
+        hipLaunchKernelGGL(k_insert_scale, dim3(1), dim3(256), 0, st, gexp, bounds, w, nImg, mReco, cSearch);
+        const size_t volSize = (size_t)dim * dim * (dim / 2 + 1) * (size_t)(nK > 0 ? nK : 1);
+        accF = reinterpret_cast<long long*>(scratch(st, 10, volSize * 3 * sizeof(long long)));
+        THX_REQUIRE(accF, "device scratch allocation failed (fixed-point accumulators)");
+        accT = accF + 2 * volSize;
+        THX_CHECK(hipMemsetAsync(accF, 0, volSize * 3 * sizeof(long long), st));
         ldsWin = 3 * (size_t)kWinVox * sizeof(int) + (size_t)mReco * 6 * sizeof(double) +
                  ((size_t)(mReco + 1) + mReco + 2 * mReco) * sizeof(int) + 2 * (size_t)mReco * sizeof(float) +
                  4 * (size_t)mReco * sizeof(short) + 2 * (size_t)mReco * sizeof(float) + 32 +
@@ -1033,6 +1118,7 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
         if (win) {
             InsertWinArgs wa;
             wa.a = b; wa.pixIndex = pixIndex; wa.plan = plan + (size_t)l0 * plan_stride(mReco); wa.bounds = bounds + l0;
+            wa.accF = accF; wa.accT = accT; wa.gexp = gexp;
             wa.minQuanta = knobs().minQuanta >= 0.f ? knobs().minQuanta : kMinQuanta;
             const int rc = half * opf + 3;
             const int hw = (rc + kWd - 1) / kWd;
@@ -1045,6 +1131,10 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
         } else {
             hipLaunchKernelGGL(k_insert, dim3((nPxl + 255) / 256, nl), dim3(256), 0, st, b);
         }
+    }
+    if (win) {
+        const size_t nVox = (size_t)dim * dim * (dim / 2 + 1) * (size_t)(nK > 0 ? nK : 1);
+        hipLaunchKernelGGL(k_insert_convert, dim3((unsigned)((nVox + 255) / 256)), dim3(256), 0, st, a.F, a.T, accF, accT, gexp, nVox);
     }
     THX_LAUNCH_CHECK();
     return 0;
