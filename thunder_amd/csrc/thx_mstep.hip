@@ -286,9 +286,10 @@ __device__ __forceinline__ void image_exponents(float boundF, float boundT, int 
     eT = 32 - lg - ebT;
 }
 
-// one launch-wide pair of exponents: the finest image quantum, at most 2^10 finer than that of the image with the largest
-// bound (coarser images shift left exactly; a rare image more than 2^10 below the largest shifts right, i.e. is rounded
-// to the launch's quantum -- 2^-41 of the largest term).  Headroom: 65535 images x 2^31 x 2^10 < 2^63.
+// one launch-wide pair of exponents: 7 bits below the finest image quantum (room for the sub-quantum "tiny" terms), the
+// finest being taken at most 2^8 finer than that of the image with the largest bound (coarser images shift left exactly;
+// a rare image more than 2^8 below the largest shifts right, i.e. is rounded to the launch's quantum -- 2^-46 of the
+// largest term).  Headroom: 65535 images x 2^31 x 2^15 < 2^63.
 __global__ __launch_bounds__(256) void k_insert_scale(int* __restrict__ gexp, const float2* __restrict__ bounds,
                                                       const float* __restrict__ w, int nImg, int mReco, int cSearch)
 {
@@ -315,8 +316,8 @@ __global__ __launch_bounds__(256) void k_insert_scale(int* __restrict__ gexp, co
     if (threadIdx.x == 0) {
         for (int wv = 1; wv < 4; wv++) { maxF = max(maxF, sMaxF[wv]); minF = min(minF, sMinF[wv]); maxT = max(maxT, sMaxT[wv]); minT = min(minT, sMinT[wv]); }
         maxF = max(sMaxF[0], maxF); minF = min(sMinF[0], minF); maxT = max(sMaxT[0], maxT); minT = min(sMinT[0], minT);
-        gexp[0] = minF == INT_MAX ? 0 : min(maxF, minF + 10);
-        gexp[1] = minT == INT_MAX ? 0 : min(maxT, minT + 10);
+        gexp[0] = minF == INT_MAX ? 0 : min(maxF, minF + 8) + 7;
+        gexp[1] = minT == INT_MAX ? 0 : min(maxT, minT + 8) + 7;
     }
 }
 
@@ -384,7 +385,11 @@ __device__ __forceinline__ void insert_tiny_term(long long* F, long long* T, int
 {
     const long nc = P / 2 + 1;
     const long gi = ((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X;
-    acc_add(F, T, gi, __float2ll_rn(re * gF), __float2ll_rn(im * gF), __float2ll_rn(tt * gT));
+    // F and T of a term travel together: a T part below the launch's quantum (a CTF zero: T ~ ctf^2, F ~ ctf) drops the
+    // whole term -- T = 0 under F != 0 lets the gridding weights W ~ 1 / (T W conv K) explode (observed: maps x 70)
+    const long long t = __float2ll_rn(tt * gT);
+    if (t == 0) return;
+    acc_add(F, T, gi, __float2ll_rn(re * gF), __float2ll_rn(im * gF), t);
 }
 
 // A group whose plane is far from the image's reference plane (|normal component along the shear axis| < kFarGroup, i.e.
@@ -622,7 +627,9 @@ __device__ __forceinline__ void insert_win_flush(const InsertArgs& a, const WinG
         int Z = qa == 2 ? bq : ba;
         if (X < 0) { X = -1 - X; Y = -Y; Z = -Z; }
         const long gi = ((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X;
-        acc_add(F, T, gi, shift_ll((long long)ire, g.shF), shift_ll((long long)iim, g.shF), shift_ll((long long)(unsigned)itt, g.shT));
+        const long long t = shift_ll((long long)(unsigned)itt, g.shT);
+        if (t == 0) continue;   // (only with a right shift: an image far below the launch's scale) F and T travel together
+        acc_add(F, T, gi, shift_ll((long long)ire, g.shF), shift_ll((long long)iim, g.shF), t);
     }
 }
 
@@ -948,7 +955,8 @@ __global__ __launch_bounds__(256) void k_insert_far(InsertWinArgs wa)
                     for (int ii = 0; ii < 2; ii++) {
                         const float wv = cell.w[kk * 4 + jj * 2 + ii];
                         const long idx = cell.rowOff[kk][jj] + ii;
-                        acc_add(F, T, idx, __float2ll_rn((vre * wv) * gF), __float2ll_rn((vim * wv) * gF), __float2ll_rn((tval * wv) * gT));
+                        const long long t = __float2ll_rn((tval * wv) * gT);
+                        if (t != 0) acc_add(F, T, idx, __float2ll_rn((vre * wv) * gF), __float2ll_rn((vim * wv) * gF), t);
                     }
         }
     }
