@@ -344,6 +344,7 @@ struct WinGeom {
     const float2* ecol;    // LDS [kMaxU][kIPix] exp(-i 2 pi i tx_u / N) (valid when U <= kMaxU)
     const float2* erow;    // LDS [kMaxU][kIPix]
     float sp, sq;
+    float devLo, devHi;           // range of (slab offset of a cell's voxel) - (height of its sample): see win_enqueue
     float scaleF, scaleT, minQ;   // scaleF / scaleT: the image's brick quanta per unit, powers of two
     int shF, shT;                 // left shifts taking brick quanta to the launch's global quanta (negative: right)
     float gF, gT;                 // global quanta per unit, 2^E_F / 2^E_T
@@ -567,13 +568,14 @@ __device__ __forceinline__ void win_enqueue(const InsertWinArgs& wa, const WinGe
     // rows pa, qa, AX of the group's rotation: (p, q) of a pixel and its height above the sheared reference plane.  Margins:
     // a voxel of a sample's cell sits at sample + d, d in (-1, 1] per axis, and d_x in [-2, 0) for a Hermitian-folded sample
     // (its brick x is -1 - X).  Its slab offset is  off = (wf - w0) + d_a - sp d_p - sq d_q + frac,  frac in [0, 1) the
-    // floor of the shear, |sp|, |sq| <= 1: off - (wf - w0) lies in [-4, 5), so a voxel inside the slab (0 <= off < kWz) needs
-    // wf in (w0 - 5, w0 + kWz + 4].  (The first version used +-3.5 / 4.5: samples of planes with both slopes near 1 were
-    // dropped at slab boundaries -- 1e-5 of the mass, 5e-3 of max T at single voxels; tests/test_fullsize_gpu.py.)
+    // floor of the shear: off - (wf - w0) lies in [devLo, devHi) (per image, from the signs and sizes of its slopes; at most
+    // [-4, 5)), so a voxel inside the slab (0 <= off < kWz) needs wf in (w0 - devHi, w0 + kWz - devLo].  (The first version
+    // used fixed -4.5 / +3.5: samples of planes with both slopes near 1 were dropped at slab boundaries -- 1e-5 of the mass,
+    // 5e-3 of max T at single voxels; tests/test_fullsize_gpu.py.)
     const float A00 = (float)R[pa] * (float)a.opf, A01 = (float)R[3 + pa] * (float)a.opf, A10 = (float)R[qa] * (float)a.opf,
                 A11 = (float)R[3 + qa] * (float)a.opf, A20 = (float)R[AX] * (float)a.opf, A21 = (float)R[3 + AX] * (float)a.opf;
     const float plo = (float)g.p0 - 2.5f, phi = (float)(g.p0 + kWd) + 1.5f, qlo = (float)g.q0 - 2.5f, qhi = (float)(g.q0 + kWd) + 1.5f;
-    const float wlo = (float)g.w0 - 5.25f, whi = (float)(g.w0 + kWz) + 4.25f;
+    const float wlo = (float)g.w0 - g.devHi - 0.25f, whi = (float)(g.w0 + kWz) - g.devLo + 0.25f;
     for (int c0 = 0; c0 < nCand; c0 += 64) {
         const int c = c0 + lane;
         bool hit = false;
@@ -713,6 +715,11 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
     WinGeom g;
     g.sp = -(pa == 0 ? n0 : n1) / na;
     g.sq = -(qa == 1 ? n1 : n2) / na;
+    {   // d_x in [-2, 1] (Hermitian fold), d_y, d_z in (-1, 1]; q is never the x axis
+        const float Lp = pa == 0 ? 2.f : 1.f, La = ax == 0 ? 2.f : 1.f;
+        g.devHi = 1.f + fabsf(g.sp) * (g.sp > 0.f ? Lp : 1.f) + fabsf(g.sq) + 1.f;
+        g.devLo = -La - fabsf(g.sp) * (g.sp > 0.f ? 1.f : Lp) - fabsf(g.sq);
+    }
     const float wgt = a.w[img];
     DrawTables dt;
     dt.R = sR; dt.gStart = sGStart; dt.mUid = sMUid; dt.gInfo = sGInfo; dt.slope = sSlope; dt.G = G; dt.U = U;
@@ -808,11 +815,11 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
                 // every sample satisfies |a - sp p - sq q| <= rMax (1 + |sp| + |sq|): slabs beyond that hold nothing
                 wmin = fmaxf(wmin, -wBound); wmax = fminf(wmax, wBound);
                 if (wmin > wmax) { box[1] = 0; continue; }
-                // slabs this group can reach: a voxel offset in [0, kWz) needs w0 in (wf - kWz - 4, wf + 5), wf in [wmin, wmax]
-                sWr[2 * gi_] = wmin - 4.25f;
-                sWr[2 * gi_ + 1] = wmax + 5.25f;
-                lWlo = min(lWlo, (int)floorf(wmin - 4.25f));
-                lWhi = max(lWhi, (int)ceilf(wmax + 5.25f));
+                // slabs this group can reach: a voxel offset in [0, kWz) needs w0 in (wf + devLo - kWz, wf + devHi), wf in [wmin, wmax]
+                sWr[2 * gi_] = wmin + g.devLo - 0.25f;
+                sWr[2 * gi_ + 1] = wmax + g.devHi + 0.25f;
+                lWlo = min(lWlo, (int)floorf(wmin + g.devLo - 0.25f));
+                lWhi = max(lWhi, (int)ceilf(wmax + g.devHi + 0.25f));
             }
             if (tid < ((G + 63) & ~63)) {   // the waves that held groups (wave-uniform condition)
 #pragma unroll
