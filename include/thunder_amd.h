@@ -137,13 +137,16 @@ int thx_logdatavsprior_dev(float* out, const float* dat, const float* pri, const
  *   library default (2).  With the particle filter's clouds of support points (rotations ~1 degree apart, the
  *   reference's production case) the kernel is bound by scattered 64-byte reads and is 17 % faster with 8 waves per CU
  *   than with 20; callers that feed tightly clustered rotations (all within ~0.2 degree) should pass 0.  Results do
- *   not depend on it. */
+ *   not depend on it.
+ * active (DEVICE [nImg] ints, may be NULL): images with active[img] == 0 are skipped and their outputs left untouched --
+ *   the per-image stop rule of the local search (thx_pf_stop_rule_dev) ends an image's phases this way. */
 size_t thx_expect_local_workspace(int nImg, int nR, int nT, int nD);
 int thx_expect_local_dev(const float* volumes, const int* volIdx, int vdim, int pf, int idim, const int* iCol,
                          const int* iRow, int nPxl, int nImg, const float* datP, const float* ctfP,
                          const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
                          const double* pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR,
-                         float* wT, float* wD, float* baseLine, float* logW, void* workspace, int wgPerCU, void* stream);
+                         float* wT, float* wD, float* baseLine, float* logW, void* workspace, int wgPerCU, const int* active,
+                         void* stream);
 
 /* Cell-packed projector volume: for every cell origin of the half grid the 8 corner values of its trilinear cell stored
  * contiguously (64 bytes), so that one sample's gather is ONE contiguous read instead of four reads from four cache
@@ -159,7 +162,7 @@ int thx_expect_local_packed_dev(const float* cells, const int* volIdx, int vdim,
                                 const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
                                 const double* pC, const double* pR, const double* pT, const double* pD, float* wC,
                                 float* wR, float* wT, float* wD, float* baseLine, float* logW, void* workspace,
-                                int wgPerCU, void* stream);
+                                int wgPerCU, const int* active, void* stream);
 
 /* Global scanning phase for class kIdx: src/Optimiser.cpp:756-894 (ExpectGlobal3D, Interface.h:221-237).
  *   rotP [nR][nPxl] slices (thx_project_dev), traP [nT][nPxl] ramps (thx_translate_dev)
@@ -377,7 +380,7 @@ int thx_img_mask_normalise_fft_dev(float* imgFT, float* imgOriFT, float* imgRL, 
  *   the shifts, reCentre (:2473-2495, transM = transS chi2inv_Q(transQ, 2)), balanceWeight for both (:2309-2376). */
 int thx_pf_perturb_dev(double* r, double* t, double* wR, double* wT, const double* k123, const double* s01, int nImg,
                        int nR, int nT, double pfR, double pfT, double transS, double transQ, unsigned long long seed,
-                       unsigned call, void* stream);
+                       unsigned call, const int* active, void* stream);
 
 /* thx_pf_update_dev = what follows the likelihood of a phase, src/Optimiser.cpp:1410-1475: setUR/setUT from the E-step's
  *   wR / wT (uR, uT: DEVICE floats), keepHalfHeightPeak(PAR_R) (peakFactorR < 0 disables it), calRank1st, calVari (ACG
@@ -385,7 +388,19 @@ int thx_pf_perturb_dev(double* r, double* t, double* wR, double* wT, const doubl
  *   (src/Particle.cpp:990-1143,1291-1480,1964-1990,2202-2300). */
 int thx_pf_update_dev(double* r, double* t, double* wR, double* wT, const float* uR, const float* uT, double* k123,
                       double* s01, double* topR, double* topT, int nImg, int nR, int nT, double peakFactorR,
-                      unsigned long long seed, unsigned call, void* stream);
+                      unsigned long long seed, unsigned call, const int* active, void* stream);
+
+/* The per-image stop rule of the local search, src/Optimiser.cpp:1168-1183,1510-1615 (MODE_3D): all DEVICE arrays.
+ * thx_pf_stop_init_dev: active[l] = 1, nP[l] = 0, state[l] = {k1 = k2 = k3 = 1, tVariS0 = tVariS1 = 5 transS,
+ *   dVari = 5 ctfRefineS, nPhaseWithNoVariDecrease = 0} (state [nImg][8] doubles).
+ * thx_pf_stop_rule_dev, after the phase with index `phase` >= MIN_N_PHASE_PER_ITER_LOCAL (3): for every active image
+ *   compares k123 / s01 (and sD [nImg], the defocus sd under CTF search, NULL = 0) with the minima seen so far
+ *   (PARTICLE_FILTER_DECREASE_FACTOR 0.95, squared for k1..k3), updates them, and on N_PHASE_WITH_NO_VARI_DECREASE = 1
+ *   phase without a decrease sets active[l] = 0, nP[l] = phase.  *nActive (DEVICE int, zeroed by the caller) += the
+ *   images still active.  thx_pf_perturb / thx_expect_local / thx_pf_update skip images with active == 0. */
+int thx_pf_stop_init_dev(int* active, int* nP, double* state, double transS, double ctfRefineS, int nImg, void* stream);
+int thx_pf_stop_rule_dev(int* active, int* nP, double* state, const double* k123, const double* s01, const double* sD, int phase,
+                         int nImg, int* nActive, void* stream);
 
 /* The deterministic ACG statistics on their own (parity probe): for quat [nImg][n][4] -> A [nImg][16] (inferACG,
  * DirectionalStat.cpp:93-145), mean [nImg][4] (:224-262), k123 [nImg][3] (calVari's mean-frame ratios), wBal [nImg][n]
@@ -455,6 +470,9 @@ typedef struct thx_refine_config {
                                   0 / 1: the whole shard belongs to that half (odd / even ranks, src/Parallel.cpp:26-36) */
     int nHalfA;
     int mLR, mLT, nPhase, mReco;  /* script/demo_3D.json: 125, 9, 3 (MIN_N_PHASE_PER_ITER_LOCAL), 100 */
+    int maxPhase;              /* <= nPhase: exactly nPhase phases per image (the fixed-work iteration bench.py times);
+                                  > nPhase: the reference's per-image stop rule from phase index nPhase on, at most maxPhase
+                                  phases (MAX_N_PHASE_PER_ITER = 100, include/Optimiser.h:58) */
     int batch;                 /* images per kernel launch, at most */
     int rL;                    /* lower cut-off of the E-step pixel list (Optimiser::_rL) */
     int nGroup, groupSig;      /* micrograph groups, OPTIMISER_SIGMA_GROUP */
@@ -472,6 +490,7 @@ typedef struct thx_refine_stats {
     long expectLaunches, expectImages, insertLaunches, insertImages;
     double stageMs[8];                    /* rows, expectation, sigma, insertion, reconstruct (+FSC, refresh), recentre+remask */
     long balancingRounds, iterations;
+    long imagePhases;                     /* sum over images of the phases they ran (Optimiser::_nF) */
     int nPxl, nPxlM, batch;
 } thx_refine_stats;
 
@@ -507,6 +526,7 @@ typedef struct thx_refine_view {
     const float *F, *T;                     /* [nVol] accumulators of the last iteration (after prepareTF / Wiener term) */
     const float *sig;                       /* [nVol][nGroup][rSig] */
     const double *recoRot, *recoTran;       /* draws of the LAST inserted local half [n][mReco][9] / [n][mReco][2] */
+    const int *nP;                          /* [nImg] phase index at which the stop rule ended the image's search (maxPhase > nPhase) */
 } thx_refine_view;
 int thx_refine_get_view(thx_refine* h, thx_refine_view* out);
 
@@ -538,6 +558,17 @@ int thx_InsertFT_host(float* F3D, float* T3D_complex, double* O3D, int* counter,
                       const double* nT, const double* nD, const int* nC, const int* iCol, const int* iRow,
                       float pixelSize, int cSearch, int opf, int npxl, int mReco, int idim, int vdim, int nK,
                       int imgNum);
+
+/* InsertFT with the hemisphere reduction INSIDE, as the reference's GPU build has it (ncclAllReduce of F, T, O, counter
+ * over commF, gpu/src/cuthunder.cu:4972-5067): the MPI_Comm& hemi of the reference signature becomes the RCCL communicator
+ * of the hemisphere (thx_comm_init).  F3D / T3D must hold only THIS rank's contribution on entry (the reference resets
+ * them before insertion); on return every rank of the hemisphere holds the sums.  O3D / counter: this rank's running
+ * values += the hemisphere's sums of this call.  maxRadius: Reconstructor::_maxRadius (the reduced sphere). */
+int thx_InsertFT_hemi_host(thx_comm* hemi, int maxRadius, float* F3D, float* T3D_complex, double* O3D, int* counter,
+                           const float* datP, const float* ctfP, const thx_ctf_attr* ctfaData, const double* offS, const float* w,
+                           const double* nR, const double* nT, const double* nD, const int* nC, const int* iCol,
+                           const int* iRow, float pixelSize, int cSearch, int opf, int npxl, int mReco, int idim, int vdim,
+                           int nK, int imgNum);
 
 /* void PrepareTF(int gpuIdx, Volume& F3D, Volume& T3D, double* symMat, int nSymmetryElement, int maxRadius, int pf)
  *                                                                                Interface.h:320-326

@@ -230,6 +230,26 @@ def fsc(A, B, P, nShell):
     return out
 
 
+def stop_rule_init(transS, ctfRefineS=0.01):
+    """state of the per-image stop rule of the local search, src/Optimiser.cpp:1168-1183 (not OPTIMISER_COMPRESS_CRITERIA)"""
+    return dict(k1=1.0, k2=1.0, k3=1.0, s0=5.0 * transS, s1=5.0 * transS, d=5.0 * ctfRefineS, noDec=0)
+
+
+def stop_rule(st, k1, k2, k3, s0, s1, d=0.0):
+    """src/Optimiser.cpp:1510-1615, MODE_3D branch, evaluated after a phase with index >= MIN_N_PHASE_PER_ITER_LOCAL:
+    returns True when the image's search ends (nPhaseWithNoVariDecrease == N_PHASE_WITH_NO_VARI_DECREASE = 1)"""
+    f = 0.95   # PARTICLE_FILTER_DECREASE_FACTOR
+    if (k1 < st["k1"] * f * f) or (k2 < st["k2"] * f * f) or (k3 < st["k3"] * f * f) or (s0 < st["s0"] * f) or \
+       (s1 < st["s1"] * f) or (d < st["d"] * f):
+        st["noDec"] = 0
+    else:
+        st["noDec"] += 1
+    for key, v in (("k1", k1), ("k2", k2), ("k3", k3), ("s0", s0), ("s1", s1), ("d", d)):
+        if v < st[key]:
+            st[key] = v
+    return st["noDec"] == 1
+
+
 def res_p(fsc_, thres, pf=1, rL=1, inverse=False):
     """resP(fsc, thres, pf, rL, inverse), src/Functions/Spectrum.cpp:339-363"""
     n = len(fsc_)

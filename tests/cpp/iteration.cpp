@@ -170,7 +170,7 @@ static Result run_rank(int rank, int world, const unsigned char* uid /*128 bytes
     cfg.N = N; cfg.pf = pf; cfg.nImg = n;
     cfg.halfOfRank = world > 1 ? rank % 2 : -1;
     cfg.nHalfA = (n + 1) / 2;
-    cfg.mLR = mLR; cfg.mLT = mLT; cfg.nPhase = nPhase; cfg.mReco = mReco; cfg.batch = 100;
+    cfg.mLR = mLR; cfg.mLT = mLT; cfg.nPhase = nPhase; cfg.maxPhase = 0; cfg.mReco = mReco; cfg.batch = 100;
     cfg.rL = 1; cfg.nGroup = 1; cfg.groupSig = 1; cfg.pixelOrder = 1; cfg.wgPerCU = -1;
     cfg.pixelSize = pixelSize; cfg.maskRadiusPx = 0.45f * N; cfg.sigma2Init = (float)sigma2;
     cfg.transS = 2.0; cfg.transQ = 0.05; cfg.pfL = 2.0; cfg.pfS = 0.5; cfg.peakFactorR = 1e-3;

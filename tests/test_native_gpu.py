@@ -130,3 +130,28 @@ def test_cpp_iteration_driver(dev, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
     print(out.stdout)
+
+
+def test_native_driver_stop_rule(dev):
+    """maxPhase > nPhase: the reference's per-image stop rule inside the native driver (src/Optimiser.cpp:1510-1615): every
+    image runs at least 5 phases (indices 0-4: the first check, after phase 3, always finds room), stopped images skip the
+    later launches through the device mask, and the iteration still converges"""
+    from thunder_amd.native import NativeRefine
+    from thunder_amd.refine import RefineShard
+    N, n = 64, 500
+    sh = RefineShard(N, n, dev, mReco=20, batch=128, allocate=False)
+    nat = NativeRefine(sh, max_phase=12)
+    nat.reset()
+    fsc = nat.iterate(timed=True)
+    st = nat.stats()
+    nP = nat.fetch(nat.view().nP, np.int32, (n,))
+    ran = np.where(nP > 0, nP + 1, 12)              # images that never stopped ran all 12 phases
+    assert ran.min() >= 5 and ran.max() <= 12
+    assert st.imagePhases == int(ran.sum()), (st.imagePhases, int(ran.sum()))
+    assert 5 * n <= st.imagePhases < 12 * n and (nP > 0).mean() > 0.5
+    assert np.all(fsc[1:6] > 0.9), fsc[:10]
+    fixed = NativeRefine(sh)                         # the fixed-work iteration on the same particles
+    fixed.reset()
+    fixed.iterate()
+    assert fixed.stats().imagePhases == 3 * n
+    nat.close(); fixed.close()

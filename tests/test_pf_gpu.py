@@ -177,3 +177,47 @@ def test_update_resample(oracle, dev):
               duR.data_ptr(), duT.data_ptr(), dk2.data_ptr(), ds2.data_ptr(), topR.data_ptr(),
               topT.data_ptr(), nImg, nR, nT, peak, seed, call, capi.stream_ptr())
     assert np.array_equal(dq2.cpu().numpy(), gq) and np.array_equal(dwT2.cpu().numpy(), gwT)
+
+
+def test_stop_rule_matches_oracle(oracle, dev):
+    """the per-image stop rule (src/Optimiser.cpp:1510-1615) on the device against the oracle's restatement, over random
+    variance histories; the active mask makes perturb / expect_local / update leave stopped images untouched"""
+    import torch
+    from thunder_amd import ops
+    O = oracle
+    rng = np.random.default_rng(17)
+    n, transS = 300, 2.0
+    active, nP, state = ops.pf_stop_init(n, transS, dev)
+    st_h = [O.stop_rule_init(transS) for _ in range(n)]
+    alive_h = np.ones(n, bool)
+    nP_h = np.zeros(n, np.int64)
+    k = np.full((n, 3), 1e-3)
+    s = np.full((n, 2), 1.0)
+    for phase in range(3, 14):
+        # variances shrink by a random factor around the rule's threshold, some stall, some bounce back
+        k = k * rng.choice([0.7, 0.9, 0.93, 1.0, 1.1], size=(n, 3))
+        s = s * rng.choice([0.8, 0.94, 0.96, 1.0, 1.05], size=(n, 2))
+        cnt = ops.pf_stop_rule(active, nP, state, torch.from_numpy(k).to(dev), torch.from_numpy(s).to(dev), phase)
+        for l in range(n):
+            if alive_h[l] and O.stop_rule(st_h[l], k[l, 0], k[l, 1], k[l, 2], s[l, 0], s[l, 1]):
+                alive_h[l] = False
+                nP_h[l] = phase
+        assert cnt == int(alive_h.sum())
+        assert np.array_equal(active.cpu().numpy().astype(bool), alive_h)
+    assert np.array_equal(nP.cpu().numpy(), nP_h) and 0 < alive_h.sum() < n or alive_h.sum() == 0
+    assert nP_h[~alive_h].min() >= 4      # phase 3 always finds "room" (the initial minima are 1 and 5 transS)
+    # masked kernels: a stopped image's filter state is not touched
+    nR, nT, m = 20, 5, 8
+    from thunder_amd import synth
+    q = torch.from_numpy(synth.perturb_quats(synth.random_quats(m, rng), nR, 0.05, rng)).to(dev)
+    t = torch.from_numpy(rng.normal(0, 1, size=(m, nT, 2))).to(dev)
+    wR = torch.full((m, nR), 1.0 / nR, dtype=torch.float64, device=dev)
+    wT = torch.full((m, nT), 1.0 / nT, dtype=torch.float64, device=dev)
+    kk = ops.pf_acg_stats(q)[2]
+    ss = t.std(dim=1).contiguous()
+    act = torch.tensor([1, 0, 1, 0, 0, 1, 1, 0], dtype=torch.int32, device=dev)
+    q0, t0 = q.clone(), t.clone()
+    ops.pf_perturb(q, t, wR, wT, kk, ss, 2.0, 2.0, 2.0, 0.05, 5, 1, active=act)
+    off = (act == 0)
+    assert torch.equal(q[off], q0[off]) and torch.equal(t[off], t0[off])
+    assert not torch.equal(q[~off], q0[~off])

@@ -25,7 +25,8 @@ class CtfAttr(C.Structure):
 class RefineConfig(C.Structure):
     """thx_refine_config (include/thunder_amd.h)"""
     _fields_ = [("N", C.c_int), ("pf", C.c_int), ("nImg", C.c_int), ("halfOfRank", C.c_int), ("nHalfA", C.c_int),
-                ("mLR", C.c_int), ("mLT", C.c_int), ("nPhase", C.c_int), ("mReco", C.c_int), ("batch", C.c_int),
+                ("mLR", C.c_int), ("mLT", C.c_int), ("nPhase", C.c_int), ("mReco", C.c_int), ("maxPhase", C.c_int),
+                ("batch", C.c_int),
                 ("rL", C.c_int), ("nGroup", C.c_int), ("groupSig", C.c_int), ("pixelOrder", C.c_int), ("wgPerCU", C.c_int),
                 ("pixelSize", C.c_float), ("maskRadiusPx", C.c_float), ("sigma2Init", C.c_float),
                 ("transS", C.c_double), ("transQ", C.c_double), ("pfL", C.c_double), ("pfS", C.c_double),
@@ -36,7 +37,8 @@ class RefineStats(C.Structure):
     """thx_refine_stats (include/thunder_amd.h)"""
     _fields_ = [("expectMs", C.c_double), ("insertMs", C.c_double), ("expectLaunches", C.c_long), ("expectImages", C.c_long),
                 ("insertLaunches", C.c_long), ("insertImages", C.c_long), ("stageMs", C.c_double * 8),
-                ("balancingRounds", C.c_long), ("iterations", C.c_long), ("nPxl", C.c_int), ("nPxlM", C.c_int),
+                ("balancingRounds", C.c_long), ("iterations", C.c_long), ("imagePhases", C.c_long), ("nPxl", C.c_int),
+                ("nPxlM", C.c_int),
                 ("batch", C.c_int)]
 
 
@@ -45,7 +47,7 @@ class RefineView(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("nImg", "nPxl", "nPxlM", "nVol", "vdim", "rSig")] + \
                [(n, C.c_void_p) for n in ("iCol", "iRow", "iPxl", "iSig", "iColM", "iRowM", "img", "datP", "ctfP", "sigRcpP",
                                           "datM", "ctfM", "r", "t", "wR", "wT", "offset", "vols", "cells", "F", "T", "sig",
-                                          "recoRot", "recoTran")]
+                                          "recoRot", "recoTran", "nP")]
 
 
 _vp = C.c_void_p
@@ -109,9 +111,9 @@ SIGNATURES = {
     "thx_logdatavsprior_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "thx_expect_local_workspace": (_sz, [_i, _i, _i, _i]),
     "thx_expect_local_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i,
-                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "thx_expect_local_packed_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i,
-                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "thx_projector_packed_bytes": (_sz, [_i]),
     "thx_projector_pack_dev": (_i, [_vp, _vp, _i, _i, _vp]),
     "thx_expect_global_workspace": (_sz, [_i, _i, _i]),
@@ -146,13 +148,17 @@ SIGNATURES = {
     "thx_img_subtract_bg_dev": (_i, [_vp, _i, _i, _f, _vp]),
     "thx_img_stats_dev": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "thx_img_mask_normalise_fft_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _vp]),
-    "thx_pf_perturb_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _d, _d, C.c_ulonglong, C.c_uint, _vp]),
+    "thx_pf_perturb_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _d, _d, C.c_ulonglong, C.c_uint, _vp, _vp]),
     "thx_pf_update_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, C.c_ulonglong,
-                               C.c_uint, _vp]),
+                               C.c_uint, _vp, _vp]),
+    "thx_pf_stop_init_dev": (_i, [_vp, _vp, _vp, _d, _d, _i, _vp]),
+    "thx_pf_stop_rule_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "thx_pf_acg_stats_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "thx_ExpectProject_host": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "thx_ExpectRotran_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "thx_InsertFT_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i,
+                               _i, _i, _i, _i, _i, _i, _i]),
+    "thx_InsertFT_hemi_host": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i,
                                _i, _i, _i, _i, _i, _i, _i]),
     "thx_PrepareTF_host": (_i, [_i, _vp, _vp, _i, _vp, _i, _i, _i]),
     "thx_ReconstructG_host": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _i, _i, _i, _i, _vp]),

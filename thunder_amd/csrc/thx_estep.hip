@@ -267,6 +267,7 @@ struct ExpectLocalArgs {
     float* partV;  // [nImg][nD][nSplit][nT][nRpad]
     float* partC;  // [nImg][nD][nSplit]
     int nRpad;
+    const int* active;   // [nImg] or NULL: images with active[img] == 0 are skipped (outputs untouched)
 };
 
 template <int NT, bool PACKED>
@@ -280,6 +281,7 @@ __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
     float* sRed = reinterpret_cast<float*>(sIr + kChunk);             // [4 waves] block-reduce scratch
 
     const int split = blockIdx.x, img = blockIdx.y, d = blockIdx.z;
+    if (a.active && !a.active[img]) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.P;
     const float2* vol = a.volumes + (size_t)(a.volIdx ? a.volIdx[img] : 0) * ((size_t)P * P * (P / 2 + 1)) * (PACKED ? 8 : 1);
@@ -408,6 +410,7 @@ __global__ __launch_bounds__(256) void k_expect_local_nd(ExpectLocalArgs a)
     float* sRed = reinterpret_cast<float*>(sIr + kChunk);             // [4 waves]
 
     const int split = blockIdx.x, img = blockIdx.y;
+    if (a.active && !a.active[img]) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = a.P;
     const float2* vol = a.volumes + (size_t)(a.volIdx ? a.volIdx[img] : 0) * ((size_t)P * P * (P / 2 + 1)) * (PACKED ? 8 : 1);
@@ -548,6 +551,7 @@ struct ExpectFinalArgs {
     float* wD;
     float* baseLine;
     float* logW;
+    const int* active;
 };
 
 __device__ __forceinline__ double block_sum_256(double v, double* sred)
@@ -566,6 +570,7 @@ __global__ __launch_bounds__(256) void k_expect_final(ExpectFinalArgs a)
     __shared__ double sred[4];
     __shared__ float sfred[5];
     const int img = blockIdx.x, tid = threadIdx.x;
+    if (a.active && !a.active[img]) return;
     const int n = a.nD * a.nT * a.nR;
     float lmax = -INFINITY, cconst = 0.f;
     for (int e = tid; e < n; e += 256) {
@@ -1010,7 +1015,8 @@ static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, 
                              const int* iRow, int nPxl, int nImg, const float* datP, const float* ctfP,
                              const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
                              const double* pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR,
-                             float* wT, float* wD, float* baseLine, float* logW, void* workspace, int wgPerCU, void* stream, bool packed)
+                             float* wT, float* wD, float* baseLine, float* logW, void* workspace, int wgPerCU, const int* active, void* stream,
+                             bool packed)
 {
     if (nImg <= 0) return 0;
     THX_REQUIRE(volumes && iCol && iRow && datP && ctfP && sigRcpP && rotMat && trans, "NULL input pointer");
@@ -1028,6 +1034,7 @@ static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, 
     a.datP = reinterpret_cast<const float2*>(datP);
     a.ctfP = ctfP; a.sigRcpP = sigRcpP; a.rotMat = rotMat; a.nR = nR; a.trans = trans; a.nT = nT; a.nD = nD;
     a.nSplit = expect_local_nsplit(nImg);
+    a.active = active;
     a.nRpad = ((nR + 63) / 64) * 64;
     a.partV = reinterpret_cast<float*>(workspace);
     a.partC = a.partV + (size_t)nImg * nD * a.nSplit * nT * a.nRpad;
@@ -1041,6 +1048,7 @@ static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, 
     f.nR = nR; f.nRpad = a.nRpad; f.nT = nT; f.nD = nD;
     f.pC = pC; f.pR = pR; f.pT = pT; f.pD = pD; f.wC = wC; f.wR = wR; f.wT = wT; f.wD = wD; f.baseLine = baseLine;
     f.logW = logW;
+    f.active = active;
     hipLaunchKernelGGL(k_expect_final, dim3(nImg), dim3(256), (size_t)nD * nT * nR * sizeof(float), st, f);
     THX_LAUNCH_CHECK();
     return 0;
@@ -1050,20 +1058,22 @@ int thx_expect_local_dev(const float* volumes, const int* volIdx, int vdim, int 
                          const int* iRow, int nPxl, int nImg, const float* datP, const float* ctfP,
                          const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
                          const double* pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR,
-                         float* wT, float* wD, float* baseLine, float* logW, void* workspace, int wgPerCU, void* stream)
+                         float* wT, float* wD, float* baseLine, float* logW, void* workspace, int wgPerCU, const int* active,
+                         void* stream)
 {
     return expect_local_impl(volumes, volIdx, vdim, pf, idim, iCol, iRow, nPxl, nImg, datP, ctfP, sigRcpP, rotMat, nR, trans, nT,
-                             nD, pC, pR, pT, pD, wC, wR, wT, wD, baseLine, logW, workspace, wgPerCU, stream, false);
+                             nD, pC, pR, pT, pD, wC, wR, wT, wD, baseLine, logW, workspace, wgPerCU, active, stream, false);
 }
 
 int thx_expect_local_packed_dev(const float* cells, const int* volIdx, int vdim, int pf, int idim, const int* iCol,
                                 const int* iRow, int nPxl, int nImg, const float* datP, const float* ctfP,
                                 const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
                                 const double* pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR,
-                                float* wT, float* wD, float* baseLine, float* logW, void* workspace, int wgPerCU, void* stream)
+                                float* wT, float* wD, float* baseLine, float* logW, void* workspace, int wgPerCU, const int* active,
+                         void* stream)
 {
     return expect_local_impl(cells, volIdx, vdim, pf, idim, iCol, iRow, nPxl, nImg, datP, ctfP, sigRcpP, rotMat, nR, trans, nT,
-                             nD, pC, pR, pT, pD, wC, wR, wT, wD, baseLine, logW, workspace, wgPerCU, stream, true);
+                             nD, pC, pR, pT, pD, wC, wR, wT, wD, baseLine, logW, workspace, wgPerCU, active, stream, true);
 }
 
 size_t thx_projector_packed_bytes(int vdim) { return (size_t)vdim * vdim * (vdim / 2 + 1) * 64; }

@@ -76,11 +76,11 @@ int thx_ExpectRotran_host(float* traP, const double* trans, const double* rot, d
     return 0;
 }
 
-int thx_InsertFT_host(float* F3D, float* T3D_complex, double* O3D, int* counter, const float* datP, const float* ctfP,
-                      const thx_ctf_attr* ctfaData, const double* offS, const float* w, const double* nR,
-                      const double* nT, const double* nD, const int* nC, const int* iCol, const int* iRow,
-                      float pixelSize, int cSearch, int opf, int npxl, int mReco, int idim, int vdim, int nK,
-                      int imgNum)
+static int insert_ft_host(thx_comm* hemi, int maxRadius, float* F3D, float* T3D_complex, double* O3D, int* counter, const float* datP,
+                          const float* ctfP, const thx_ctf_attr* ctfaData, const double* offS, const float* w, const double* nR,
+                          const double* nT, const double* nD, const int* nC, const int* iCol, const int* iRow,
+                          float pixelSize, int cSearch, int opf, int npxl, int mReco, int idim, int vdim, int nK,
+                          int imgNum)
 {
     THX_REQUIRE(F3D && T3D_complex && datP && ctfP && w && nR && nT && iCol && iRow, "NULL pointer");
     const size_t nvol = (size_t)vdim * vdim * (vdim / 2 + 1);
@@ -117,6 +117,15 @@ int thx_InsertFT_host(float* F3D, float* T3D_complex, double* O3D, int* counter,
                           offS ? dOff.as<double>() : nullptr, nC ? dCls.as<int>() : nullptr,
                           cSearch ? dAttr.as<thx_ctf_attr>() : nullptr, cSearch ? dDf.as<double>() : nullptr, cSearch,
                           pixelSize, dCol.as<int>(), dRow.as<int>(), opf, npxl, mReco, idim, imgNum, nullptr));
+    if (hemi && thx_comm_size(hemi) > 1) {   // the reference's ncclAllReduce of F, T, O, counter (gpu/src/cuthunder.cu:4972-5067)
+        DevBuf ws;
+        THX_RC(ws.alloc(thx_reco_allreduce_workspace(vdim, maxRadius, opf)));
+        for (int k = 0; k < nK; k++)
+            THX_RC(thx_reco_allreduce(hemi, dF.as<float>() + (size_t)k * nvol * 2, dT.as<float>() + (size_t)k * nvol,
+                                      k == 0 ? dO.as<double>() : nullptr, k == 0 ? dCnt.as<int>() : nullptr, vdim, maxRadius, opf,
+                                      ws.p, nullptr));
+        THX_CHECK(hipDeviceSynchronize());
+    }
     THX_CHECK(hipMemcpy(F3D, dF.p, nvol * nK * 2 * sizeof(float), hipMemcpyDeviceToHost));
     {
         std::vector<float> t(nvol * nK);
@@ -134,6 +143,27 @@ int thx_InsertFT_host(float* F3D, float* T3D_complex, double* O3D, int* counter,
         counter[0] += c;
     }
     return 0;
+}
+
+int thx_InsertFT_host(float* F3D, float* T3D_complex, double* O3D, int* counter, const float* datP, const float* ctfP,
+                      const thx_ctf_attr* ctfaData, const double* offS, const float* w, const double* nR,
+                      const double* nT, const double* nD, const int* nC, const int* iCol, const int* iRow,
+                      float pixelSize, int cSearch, int opf, int npxl, int mReco, int idim, int vdim, int nK,
+                      int imgNum)
+{
+    return insert_ft_host(nullptr, 0, F3D, T3D_complex, O3D, counter, datP, ctfP, ctfaData, offS, w, nR, nT, nD, nC, iCol, iRow,
+                          pixelSize, cSearch, opf, npxl, mReco, idim, vdim, nK, imgNum);
+}
+
+int thx_InsertFT_hemi_host(thx_comm* hemi, int maxRadius, float* F3D, float* T3D_complex, double* O3D, int* counter,
+                           const float* datP, const float* ctfP, const thx_ctf_attr* ctfaData, const double* offS, const float* w,
+                           const double* nR, const double* nT, const double* nD, const int* nC, const int* iCol,
+                           const int* iRow, float pixelSize, int cSearch, int opf, int npxl, int mReco, int idim, int vdim,
+                           int nK, int imgNum)
+{
+    THX_REQUIRE(!hemi || maxRadius > 0, "maxRadius must be given with a communicator");
+    return insert_ft_host(hemi, maxRadius, F3D, T3D_complex, O3D, counter, datP, ctfP, ctfaData, offS, w, nR, nT, nD, nC, iCol, iRow,
+                          pixelSize, cSearch, opf, npxl, mReco, idim, vdim, nK, imgNum);
 }
 
 int thx_PrepareTF_host(int gpuIdx, float* F3D, float* T3D_complex, int vdim, const double* symMat,

@@ -305,7 +305,7 @@ int thx_ExpectLocalM_host(int gpuIdx, int datShift, thx_calpoint* mcp, const flo
     THX_RC(thx_expect_local_dev(mcp->vol, nullptr, mcp->vdim, mcp->pf, mcp->idim, mcp->iCol, mcp->iRow, npxl, 1,
                                 devdatP + 2 * slot, ctf, devsigP + slot, mcp->devRotm, mcp->nR, mcp->devnT, mcp->nT, nD,
                                 mcp->devC, mcp->devR, mcp->devT, mcp->devD, mcp->devwC, mcp->devwR, mcp->devwT, mcp->devwD,
-                                mcp->devBaseL, nullptr, mcp->ws, -1, st));
+                                mcp->devBaseL, nullptr, mcp->ws, -1, nullptr, st));
     THX_CHECK(hipMemcpyAsync(wC, mcp->devwC, sizeof(float), hipMemcpyDeviceToHost, st));
     THX_CHECK(hipMemcpyAsync(wR, mcp->devwR, mcp->nR * sizeof(float), hipMemcpyDeviceToHost, st));
     THX_CHECK(hipMemcpyAsync(wT, mcp->devwT, mcp->nT * sizeof(float), hipMemcpyDeviceToHost, st));

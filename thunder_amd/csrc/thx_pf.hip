@@ -256,6 +256,7 @@ struct PfArgs {
     double pfR, pfT, transS, transM, peakFactorR;
     unsigned long long seed;
     unsigned call;
+    const int* active;   // [nImg] or NULL: images with active[img] == 0 are left untouched (per-image stop rule)
 };
 
 // Particle::perturb(pf, PAR_R) + perturb(pf, PAR_T), src/Particle.cpp:1149-1272 (MODE_3D)
@@ -263,6 +264,7 @@ __global__ __launch_bounds__(64) void k_pf_perturb(PfArgs a)
 {
     __shared__ double sq[kPfMax * 4], st[kPfMax * 2], sw[kPfMax];
     const int img = blockIdx.x, lane = threadIdx.x;
+    if (a.active && !a.active[img]) return;
     const int nR = a.nR, nT = a.nT;
     if (nR > 0) {
         double* r = a.r + (size_t)img * nR * 4;
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(64) void k_pf_update(PfArgs a)
     __shared__ double sq[kPfMax * 4], sw[kPfMax], su[kPfMax], tq[kPfMax * 4], tw[kPfMax], tu[kPfMax], cdf[kPfMax];
     __shared__ unsigned keys[kPfMax];
     const int img = blockIdx.x, lane = threadIdx.x;
+    if (a.active && !a.active[img]) return;
     const int nR = a.nR, nT = a.nT;
     if (nR > 0) {
         double* r = a.r + (size_t)img * nR * 4;
@@ -421,6 +424,55 @@ __global__ __launch_bounds__(64) void k_pf_acg_stats(double* __restrict__ Aout, 
     if (lane == 0) { kOut[3 * (size_t)img] = A[5] / A[0]; kOut[3 * (size_t)img + 1] = A[10] / A[0]; kOut[3 * (size_t)img + 2] = A[15] / A[0]; }
 }
 
+// The per-image stop rule of the local search, src/Optimiser.cpp:1510-1615 (MODE_3D, not OPTIMISER_COMPRESS_CRITERIA): after
+// the phase with index `phase` >= MIN_N_PHASE_PER_ITER_LOCAL the variances of the filter (k1..k3, s0, s1; the defocus
+// variance `dVari` only under CTF search) are compared with the smallest ever seen; no decrease by PARTICLE_FILTER_DECREASE_
+// FACTOR (0.95; squared for k1..k3) in N_PHASE_WITH_NO_VARI_DECREASE = 1 phase ends the image's search.
+// state [nImg][8]: k1, k2, k3, s0, s1, dVari minima, nPhaseWithNoVariDecrease, (unused); nP [nImg]: phase at which it stopped.
+__global__ void k_pf_stop_rule(int* __restrict__ active, int* __restrict__ nP, double* __restrict__ state,
+                               const double* __restrict__ k123, const double* __restrict__ s01, const double* __restrict__ sD,
+                               int phase, int nImg, int* __restrict__ nActive)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nImg || !active[l]) return;
+    double* st = state + (size_t)l * 8;
+    const double k1 = k123[3 * l], k2 = k123[3 * l + 1], k3 = k123[3 * l + 2], s0 = s01[2 * l], s1 = s01[2 * l + 1];
+    const double d = sD ? sD[l] : 0.0;
+    const double f = 0.95, f2 = 0.95 * 0.95;   // PARTICLE_FILTER_DECREASE_FACTOR, gsl_pow_2 of it
+    int noDec = (int)st[6];
+    if ((k1 < st[0] * f2) || (k2 < st[1] * f2) || (k3 < st[2] * f2) || (s0 < st[3] * f) || (s1 < st[4] * f) || (d < st[5] * f))
+        noDec = 0;   // there is still room for searching
+    else
+        noDec += 1;
+    if (k1 < st[0]) st[0] = k1;
+    if (k2 < st[1]) st[1] = k2;
+    if (k3 < st[2]) st[2] = k3;
+    if (s0 < st[3]) st[3] = s0;
+    if (s1 < st[4]) st[4] = s1;
+    if (d < st[5]) st[5] = d;
+    st[6] = (double)noDec;
+    if (noDec == 1) {   // N_PHASE_WITH_NO_VARI_DECREASE
+        active[l] = 0;
+        nP[l] = phase;
+    } else {
+        atomicAdd(nActive, 1);
+    }
+}
+
+__global__ void k_pf_stop_init(int* __restrict__ active, int* __restrict__ nP, double* __restrict__ state, double transS,
+                               double ctfRefineS, int nImg)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nImg) return;
+    active[l] = 1;
+    nP[l] = 0;
+    double* st = state + (size_t)l * 8;
+    st[0] = st[1] = st[2] = 1.0;                // k1 = k2 = k3 = 1 (src/Optimiser.cpp:1178-1180)
+    st[3] = st[4] = 5 * transS;                 // tVariS0 = tVariS1 = 5 * transS
+    st[5] = 5 * ctfRefineS;                     // dVari
+    st[6] = 0.0; st[7] = 0.0;
+}
+
 }  // namespace thx
 
 using namespace thx;
@@ -429,7 +481,7 @@ extern "C" {
 
 int thx_pf_perturb_dev(double* r, double* t, double* wR, double* wT, const double* k123, const double* s01, int nImg,
                        int nR, int nT, double pfR, double pfT, double transS, double transQ, unsigned long long seed,
-                       unsigned call, void* stream)
+                       unsigned call, const int* active, void* stream)
 {
     if (nImg <= 0) return 0;
     THX_REQUIRE(nR >= 0 && nT >= 0 && nR <= kPfMax && nT <= kPfMax, "nR / nT must be <= 256");
@@ -442,7 +494,7 @@ int thx_pf_perturb_dev(double* r, double* t, double* wR, double* wT, const doubl
     a.nR = nR; a.nT = nT; a.pfR = pfR; a.pfT = pfT; a.transS = transS;
     // PARTICLE_RECENTRE_TRANSQ: transM = transS * gsl_cdf_chisq_Qinv(transQ, 2); for 2 degrees of freedom Q(x) = exp(-x/2)
     a.transM = transS * (-2.0 * log(transQ));
-    a.seed = seed; a.call = call;
+    a.seed = seed; a.call = call; a.active = active;
     hipLaunchKernelGGL(k_pf_perturb, dim3(nImg), dim3(64), 0, as_stream(stream), a);
     THX_LAUNCH_CHECK();
     return 0;
@@ -450,7 +502,7 @@ int thx_pf_perturb_dev(double* r, double* t, double* wR, double* wT, const doubl
 
 int thx_pf_update_dev(double* r, double* t, double* wR, double* wT, const float* uR, const float* uT, double* k123,
                       double* s01, double* topR, double* topT, int nImg, int nR, int nT, double peakFactorR,
-                      unsigned long long seed, unsigned call, void* stream)
+                      unsigned long long seed, unsigned call, const int* active, void* stream)
 {
     if (nImg <= 0) return 0;
     THX_REQUIRE(nR >= 0 && nT >= 0 && nR <= kPfMax && nT <= kPfMax, "nR / nT must be <= 256");
@@ -459,8 +511,29 @@ int thx_pf_update_dev(double* r, double* t, double* wR, double* wT, const float*
     PfArgs a;
     memset(&a, 0, sizeof(a));
     a.r = r; a.t = t; a.wR = wR; a.wT = wT; a.uR = uR; a.uT = uT; a.k123 = k123; a.s01 = s01; a.topR = topR; a.topT = topT;
-    a.nR = nR; a.nT = nT; a.peakFactorR = peakFactorR; a.seed = seed; a.call = call;
+    a.nR = nR; a.nT = nT; a.peakFactorR = peakFactorR; a.seed = seed; a.call = call; a.active = active;
     hipLaunchKernelGGL(k_pf_update, dim3(nImg), dim3(64), 0, as_stream(stream), a);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_pf_stop_init_dev(int* active, int* nP, double* state, double transS, double ctfRefineS, int nImg, void* stream)
+{
+    if (nImg <= 0) return 0;
+    THX_REQUIRE(active && nP && state, "NULL pointer");
+    hipLaunchKernelGGL(k_pf_stop_init, dim3((nImg + 255) / 256), dim3(256), 0, as_stream(stream), active, nP, state, transS, ctfRefineS,
+                       nImg);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_pf_stop_rule_dev(int* active, int* nP, double* state, const double* k123, const double* s01, const double* sD, int phase,
+                         int nImg, int* nActive, void* stream)
+{
+    if (nImg <= 0) return 0;
+    THX_REQUIRE(active && nP && state && k123 && s01 && nActive, "NULL pointer");
+    hipLaunchKernelGGL(k_pf_stop_rule, dim3((nImg + 255) / 256), dim3(256), 0, as_stream(stream), active, nP, state, k123, s01, sD,
+                       phase, nImg, nActive);
     THX_LAUNCH_CHECK();
     return 0;
 }

@@ -214,6 +214,9 @@ struct thx_refine {
     float *uR, *uT, *wC, *wD, *baseL, *spec;
     void *wsExpect, *wsReduce;
     unsigned pfCall = 0;
+    int *active = nullptr, *nP = nullptr, *nActiveDev = nullptr;   // per-image stop rule
+    double* stopState = nullptr;
+    long imagePhases = 0;
     bool haveCells = false;
     // timing (HIP events on the launch stream, resolved in thx_refine_stats)
     bool timed = false;
@@ -298,13 +301,23 @@ int refresh_rows(thx_refine* h, int vi, hipStream_t st)
     return 0;
 }
 
-// HOT LOOP B: nPhase particle-filter phases over the images of local half vi
+// HOT LOOP B: the particle-filter phases over the images of local half vi.  cfg.maxPhase <= nPhase: exactly nPhase phases
+// per image (the fixed-work iteration).  Otherwise the reference's per-image stop rule (src/Optimiser.cpp:1510-1615): from
+// phase index nPhase (= MIN_N_PHASE_PER_ITER_LOCAL) on every image's variances are checked after the phase, images without
+// a decrease drop out (device mask: their workgroups return at once), and the loop ends when no image of the half is left.
 int expectation(thx_refine* h, int vi, hipStream_t st)
 {
     const thx_refine_config& c = h->cfg;
     const size_t cellStride = thx_projector_packed_bytes(h->P) / sizeof(float);
-    for (int p = 0; p < c.nPhase; p++) {
-        for (int b0 = h->lo[vi]; b0 < h->hi[vi]; b0 += h->batch) {
+    const int lo = h->lo[vi], n = h->hi[vi] - lo;
+    if (n <= 0) return 0;
+    const bool rule = c.maxPhase > c.nPhase;
+    const int nPhaseMax = rule ? c.maxPhase : c.nPhase;
+    if (rule) THX_RC(thx_pf_stop_init_dev(h->active + lo, h->nP + lo, h->stopState + (size_t)lo * 8, c.transS, 0.01, n, st));
+    long imagePhases = 0;
+    int nActive = n;
+    for (int p = 0; p < nPhaseMax && nActive > 0; p++) {
+        for (int b0 = lo; b0 < h->hi[vi]; b0 += h->batch) {
             const int nb = std::min(h->batch, h->hi[vi] - b0);
             double* r = h->r + (size_t)b0 * c.mLR * 4;
             double* t = h->t + (size_t)b0 * c.mLT * 2;
@@ -312,23 +325,34 @@ int expectation(thx_refine* h, int vi, hipStream_t st)
             double* wT = h->wT + (size_t)b0 * c.mLT;
             double* k = h->k123 + (size_t)b0 * 3;
             double* s = h->s01 + (size_t)b0 * 2;
+            const int* act = rule ? h->active + b0 : nullptr;
             const double f = p == 0 ? c.pfL : c.pfS;
             // Particle::perturb, then the phase's support points are the filter's own (src/Optimiser.cpp:1186-1208)
             h->pfCall++;
-            THX_RC(thx_pf_perturb_dev(r, t, wR, wT, k, s, nb, c.mLR, c.mLT, f, f, c.transS, c.transQ, c.seed, h->pfCall, st));
+            THX_RC(thx_pf_perturb_dev(r, t, wR, wT, k, s, nb, c.mLR, c.mLT, f, f, c.transS, c.transQ, c.seed, h->pfCall, act, st));
             THX_RC(thx_rotmat_dev(r, h->rotB, nb * c.mLR, st));
             {
                 Scope ev(h, st, EV_EXPECT, nb);
                 THX_RC(thx_expect_local_packed_dev(h->cells + (size_t)vi * cellStride, nullptr, h->P, h->pf, h->N, h->iCol, h->iRow,
                                                    h->nPxl, nb, h->datP + (size_t)b0 * h->nPxl * 2, h->ctfP + (size_t)b0 * h->nPxl,
                                                    h->sigRcpP + (size_t)b0 * h->nPxl, h->rotB, c.mLR, t, c.mLT, 1, nullptr, wR, wT,
-                                                   h->pD, h->wC, h->uR, h->uT, h->wD, h->baseL, nullptr, h->wsExpect, c.wgPerCU, st));
+                                                   h->pD, h->wC, h->uR, h->uT, h->wD, h->baseL, nullptr, h->wsExpect, c.wgPerCU, act,
+                                                   st));
             }
             h->pfCall++;
             THX_RC(thx_pf_update_dev(r, t, wR, wT, h->uR, h->uT, k, s, h->topR + (size_t)b0 * 4, h->topT + (size_t)b0 * 2, nb, c.mLR,
-                                     c.mLT, c.peakFactorR, c.seed, h->pfCall, st));
+                                     c.mLT, c.peakFactorR, c.seed, h->pfCall, act, st));
+        }
+        imagePhases += nActive;
+        if (rule && p >= c.nPhase) {
+            THX_CHECK(hipMemsetAsync(h->nActiveDev, 0, sizeof(int), st));
+            THX_RC(thx_pf_stop_rule_dev(h->active + lo, h->nP + lo, h->stopState + (size_t)lo * 8, h->k123 + (size_t)lo * 3,
+                                        h->s01 + (size_t)lo * 2, nullptr, p, n, h->nActiveDev, st));
+            THX_CHECK(hipMemcpyAsync(&nActive, h->nActiveDev, sizeof(int), hipMemcpyDeviceToHost, st));
+            THX_CHECK(hipStreamSynchronize(st));
         }
     }
+    h->imagePhases += imagePhases;
     return 0;
 }
 
@@ -483,6 +507,8 @@ int thx_refine_create(thx_refine** out, const thx_refine_config* cfg, thx_comm* 
     RC_OR_FREE(dalloc(h, &h->wR, n * c.mLR)); RC_OR_FREE(dalloc(h, &h->wT, n * c.mLT));
     RC_OR_FREE(dalloc(h, &h->k123, n * 3)); RC_OR_FREE(dalloc(h, &h->s01, n * 2));
     RC_OR_FREE(dalloc(h, &h->topR, n * 4)); RC_OR_FREE(dalloc(h, &h->topT, n * 2));
+    RC_OR_FREE(dalloc(h, &h->active, n)); RC_OR_FREE(dalloc(h, &h->nP, n)); RC_OR_FREE(dalloc(h, &h->nActiveDev, (size_t)1));
+    RC_OR_FREE(dalloc(h, &h->stopState, n * 8));
     RC_OR_FREE(dalloc(h, &h->refRL, (size_t)c.N * c.N * c.N));
     RC_OR_FREE(dalloc(h, &h->vols, h->nV * volN * 2));
     RC_OR_FREE(dalloc(h, &h->cells, h->nV * (thx_projector_packed_bytes(h->P) / sizeof(float))));
@@ -682,6 +708,7 @@ int thx_refine_get_view(thx_refine* h, thx_refine_view* v)
     v->r = h->r; v->t = h->t; v->wR = h->wR; v->wT = h->wT; v->offset = h->offset;
     v->vols = h->vols; v->cells = h->cells; v->F = h->F; v->T = h->T; v->sig = h->sig;
     v->recoRot = h->recoRot; v->recoTran = h->recoTran;
+    v->nP = h->nP;
     return 0;
 }
 
@@ -694,11 +721,12 @@ int thx_refine_get_stats(thx_refine* h, thx_refine_stats* out, int reset)
     for (int i = 0; i < ST_COUNT; i++) out->stageMs[i] = h->stageMs[i];
     out->balancingRounds = h->recoRounds;
     out->iterations = h->iterations;
+    out->imagePhases = h->imagePhases;
     out->nPxl = h->nPxl; out->nPxlM = h->nPxlM; out->batch = h->batch;
     if (reset) {
         h->accExpect = thx_refine_stats_acc(); h->accInsert = thx_refine_stats_acc();
         for (int i = 0; i < 8; i++) h->stageMs[i] = 0;
-        h->recoRounds = 0; h->iterations = 0;
+        h->recoRounds = 0; h->iterations = 0; h->imagePhases = 0;
     }
     return 0;
 }

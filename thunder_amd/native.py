@@ -88,7 +88,7 @@ def make_comms(rank, world, share_from):
 class NativeRefine:
     """thx_refine handle over the particles of a RefineShard (which only has to have GENERATED them: allocate=False)."""
 
-    def __init__(self, shard, hemi=None, world=None, pixel_order=1):
+    def __init__(self, shard, hemi=None, world=None, pixel_order=1, max_phase=0):
         self.shard = shard
         s = shard
         cfg = RefineConfig()
@@ -98,6 +98,7 @@ class NativeRefine:
         else:
             cfg.halfOfRank, cfg.nHalfA = s.groups.half, 0
         cfg.mLR, cfg.mLT, cfg.nPhase, cfg.mReco, cfg.batch = s.mLR, s.mLT, s.nPhase, s.mReco, s.batch
+        cfg.maxPhase = max_phase
         cfg.rL, cfg.nGroup, cfg.groupSig = s.rL, s.nGroup, 1 if s.groupSig else 0
         cfg.pixelOrder, cfg.wgPerCU = pixel_order, s.wg_per_cu
         cfg.pixelSize, cfg.maskRadiusPx, cfg.sigma2Init = s.pixelSize, s.maskRadiusPx, s.sigma2

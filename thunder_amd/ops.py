@@ -142,7 +142,7 @@ def pack_projector(volumes, vdim):
 
 
 def expect_local(volumes, vdim, pf, idim, iCol, iRow, datP, ctfP, sigRcpP, rotMat, trans, nD=1, volIdx=None, pC=None,
-                 pR=None, pT=None, pD=None, want_logW=False, workspace=None, packed=False, wg_per_cu=-1):
+                 pR=None, pT=None, pD=None, want_logW=False, workspace=None, packed=False, wg_per_cu=-1, active=None):
     """One particle-filter phase for a batch of images (src/Optimiser.cpp:1225-1406); see thunder_amd.h.
     packed=True: `volumes` is the output of pack_projector.  wg_per_cu: occupancy argument of the C ABI (0 = unlimited,
     negative = library default)."""
@@ -172,7 +172,7 @@ def expect_local(volumes, vdim, pf, idim, iCol, iRow, datP, ctfP, sigRcpP, rotMa
     capi.call("thx_expect_local_packed_dev" if packed else "thx_expect_local_dev", ptr(volumes), ptr(volIdx), vdim, pf, idim, ptr(iCol), ptr(iRow), nPxl, nImg,
               ptr(datP), ptr(ctfP), ptr(sigRcpP), ptr(rotMat), nR, ptr(trans), nT, nD, ptr(pC), ptr(pR), ptr(pT),
               ptr(pD), ptr(res.wC), ptr(res.wR), ptr(res.wT), ptr(res.wD), ptr(res.baseLine), ptr(res.logW),
-              ptr(workspace), int(wg_per_cu), stream_ptr())
+              ptr(workspace), int(wg_per_cu), ptr(active), stream_ptr())
     return res
 
 
@@ -317,19 +317,19 @@ def init_images(imgRL, maskRadiusPx, ew=6.0, reduce_stats=None):
 
 # ---------------------------------------------------------------------------------------------
 # particle filter
-def pf_perturb(r, t, wR, wT, k123, s01, pfR, pfT, transS, transQ, seed, call):
+def pf_perturb(r, t, wR, wT, k123, s01, pfR, pfT, transS, transQ, seed, call, active=None):
     """Particle::perturb(pf, PAR_R) + perturb(pf, PAR_T) (src/Particle.cpp:1149-1272) for [n][nR][4] / [n][nT][2] f64"""
     for x, nm in ((r, "r"), (t, "t"), (wR, "wR"), (wT, "wT"), (k123, "k123"), (s01, "s01")):
         _chk(x, _F64, nm)
     capi.call("thx_pf_perturb_dev", ptr(r), ptr(t), ptr(wR), ptr(wT), ptr(k123), ptr(s01), r.shape[0], r.shape[1],
-              t.shape[1], float(pfR), float(pfT), float(transS), float(transQ), int(seed), int(call), stream_ptr())
+              t.shape[1], float(pfR), float(pfT), float(transS), float(transQ), int(seed), int(call), ptr(active), stream_ptr())
 
 
-def pf_update(r, t, wR, wT, uR, uT, k123, s01, topR, topT, peakFactorR, seed, call):
+def pf_update(r, t, wR, wT, uR, uT, k123, s01, topR, topT, peakFactorR, seed, call, active=None):
     """setUR/UT, keepHalfHeightPeak, calRank1st, calVari, resample (src/Optimiser.cpp:1410-1475)"""
     _chk(uR, _F32, "uR"); _chk(uT, _F32, "uT")
     capi.call("thx_pf_update_dev", ptr(r), ptr(t), ptr(wR), ptr(wT), ptr(uR), ptr(uT), ptr(k123), ptr(s01), ptr(topR),
-              ptr(topT), r.shape[0], r.shape[1], t.shape[1], float(peakFactorR), int(seed), int(call), stream_ptr())
+              ptr(topT), r.shape[0], r.shape[1], t.shape[1], float(peakFactorR), int(seed), int(call), ptr(active), stream_ptr())
 
 
 def draw_reco(r, t, mReco, seed, call, img0=0):
@@ -342,6 +342,23 @@ def draw_reco(r, t, mReco, seed, call, img0=0):
     capi.call("thx_draw_reco_dev", ptr(rot), ptr(tran), ptr(r), ptr(t), n, nR, nT, mReco, int(seed), int(call), int(img0),
               stream_ptr())
     return rot, tran
+
+
+def pf_stop_init(n, transS, device, ctfRefineS=0.01):
+    """state of the per-image stop rule (src/Optimiser.cpp:1168-1183): (active int32 [n], nP int32 [n], state f64 [n][8])"""
+    active = torch.empty(n, dtype=_I32, device=device)
+    nP = torch.empty(n, dtype=_I32, device=device)
+    state = torch.empty((n, 8), dtype=_F64, device=device)
+    capi.call("thx_pf_stop_init_dev", ptr(active), ptr(nP), ptr(state), float(transS), float(ctfRefineS), n, stream_ptr())
+    return active, nP, state
+
+
+def pf_stop_rule(active, nP, state, k123, s01, phase, sD=None):
+    """src/Optimiser.cpp:1510-1615 after phase `phase`; returns the number of images still active"""
+    cnt = torch.zeros(1, dtype=_I32, device=active.device)
+    capi.call("thx_pf_stop_rule_dev", ptr(active), ptr(nP), ptr(state), ptr(k123), ptr(s01), ptr(sD), int(phase), active.numel(),
+              ptr(cnt), stream_ptr())
+    return int(cnt.item())
 
 
 def pf_acg_stats(quat):
