@@ -93,7 +93,7 @@ def test_perturb(oracle, dev):
     pfR, pfT, transS, transQ = 2.0, 0.5, 2.0, 0.05
     dq, dt, dwR, dwT, dk, ds = T(q, dev), T(t, dev), T(wR, dev), T(wT, dev), T(k, dev), T(s, dev)
     capi.call("thx_pf_perturb_dev", dq.data_ptr(), dt.data_ptr(), dwR.data_ptr(), dwT.data_ptr(), dk.data_ptr(),
-              ds.data_ptr(), nImg, nR, nT, pfR, pfT, transS, transQ, seed, call, capi.stream_ptr())
+              ds.data_ptr(), nImg, nR, nT, pfR, pfT, transS, transQ, seed, call, None, capi.stream_ptr())
     gq, gt, gwR, gwT = [x.cpu().numpy() for x in (dq, dt, dwR, dwT)]
     img = np.arange(nImg)[:, None]
     g = PH.draw_n4(seed, img, call, 0, np.arange(nR)[None, :])
@@ -137,7 +137,7 @@ def test_update_resample(oracle, dev):
     duR, duT = T(uR, dev), T(uT, dev)
     capi.call("thx_pf_update_dev", dq.data_ptr(), dt.data_ptr(), dwR.data_ptr(), dwT.data_ptr(), duR.data_ptr(),
               duT.data_ptr(), dk.data_ptr(), ds.data_ptr(), topR.data_ptr(), topT.data_ptr(), nImg, nR, nT, peak,
-              seed, call, capi.stream_ptr())
+              seed, call, None, capi.stream_ptr())
     gq, gt, gwR, gwT, gk, gs, gtopR, gtopT = [x.cpu().numpy() for x in (dq, dt, dwR, dwT, dk, ds, topR, topT)]
     for l in range(nImg):
         # rank-1st, variances
@@ -175,7 +175,7 @@ def test_update_resample(oracle, dev):
     dq2, dt2, dwR2, dwT2, dk2, ds2 = [T(x, dev) for x in (q, t, wR, wT, k, s)]
     capi.call("thx_pf_update_dev", dq2.data_ptr(), dt2.data_ptr(), dwR2.data_ptr(), dwT2.data_ptr(),
               duR.data_ptr(), duT.data_ptr(), dk2.data_ptr(), ds2.data_ptr(), topR.data_ptr(),
-              topT.data_ptr(), nImg, nR, nT, peak, seed, call, capi.stream_ptr())
+              topT.data_ptr(), nImg, nR, nT, peak, seed, call, None, capi.stream_ptr())
     assert np.array_equal(dq2.cpu().numpy(), gq) and np.array_equal(dwT2.cpu().numpy(), gwT)
 
 
