@@ -415,6 +415,8 @@ struct thx_reco {
 
 extern "C" {
 
+static int reco_fill(thx_reco* r, int size, int N, int pf, float a, float alpha);
+
 int thx_reco_create(thx_reco** out, int size, int N, int pf, float a, float alpha)
 {
     THX_REQUIRE(out, "out is NULL");
@@ -423,6 +425,14 @@ int thx_reco_create(thx_reco** out, int size, int N, int pf, float a, float alph
     THX_REQUIRE(pf * size <= 2 * kMaxHalfP && pf * N <= 2 * kMaxHalfP, "grids above 2048 are not supported");
     thx_reco* r = new thx_reco();
     memset(r, 0, sizeof(*r));
+    const int rc = reco_fill(r, size, N, pf, a, alpha);
+    if (rc) { (void)thx_reco_destroy(r); return rc; }   // no leak of the partly built handle (buffers, plans)
+    *out = r;
+    return 0;
+}
+
+static int reco_fill(thx_reco* r, int size, int N, int pf, float a, float alpha)
+{
     r->size = size; r->N = N; r->pf = pf; r->PF = pf * size; r->PN = pf * N; r->a = a; r->alpha = alpha;
     r->nf = mkb_rl(0.f, a, alpha);  // nf = MKB_RL(0, _a, _alpha), src/Reconstructor.cpp:2600
     std::vector<float> tab(kTabN + 1);
@@ -465,17 +475,16 @@ int thx_reco_create(thx_reco** out, int size, int N, int pf, float a, float alph
     if (r->haveN) THX_FFT_CHECK(plan_padded(&r->c2rN, r->PN, HIPFFT_C2R));
     else r->c2rN = r->c2rF;
     THX_FFT_CHECK(hipfftPlan3d(&r->r2cStd, r->PN, r->PN, r->PN, HIPFFT_R2C));
-    *out = r;
     return 0;
 }
 
 int thx_reco_destroy(thx_reco* r)
 {
     if (!r) return 0;
-    (void)hipfftDestroy(r->r2cF);
-    (void)hipfftDestroy(r->c2rF);
-    (void)hipfftDestroy(r->r2cStd);
-    if (r->haveN) (void)hipfftDestroy(r->c2rN);
+    if (r->r2cF) (void)hipfftDestroy(r->r2cF);
+    if (r->c2rF) (void)hipfftDestroy(r->c2rF);
+    if (r->r2cStd) (void)hipfftDestroy(r->r2cStd);
+    if (r->haveN && r->c2rN) (void)hipfftDestroy(r->c2rN);
     (void)hipFree(r->tw); (void)hipFree(r->tab); (void)hipFree(r->W); (void)hipFree(r->C); (void)hipFree(r->rl); (void)hipFree(r->diff); (void)hipFree(r->fscDev);
     delete r;
     return 0;
