@@ -316,7 +316,7 @@ def main():
         # im, T); the insert plan merges draws with identical rotation, so the count below is an upper bound.
         ins_terms_per_s = ins_n * shard.mReco * nPxlM * 24 / (ins_ms * 1e-3)
         out = {
-            "metric": "particles/sec per refinement iteration (256^3 box, 100k particles); achieved HBM GB/s",
+            "metric": "particles/sec per refinement iteration (256\u00b3 box, 100k particles); achieved HBM GB/s",
             "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

@@ -15,7 +15,7 @@ HEADERS = ["thx_common.h", "thx_fft8.h", "thx_philox.h", os.path.join("..", ".."
 
 # -ffp-contract=off: see thx_common.h (bit-identical trilinear arithmetic); fused ops are written out as fmaf().
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result"] + os.environ.get("THX_EXTRA_FLAGS", "").split()
 
 
 def _hipcc():
