@@ -209,6 +209,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-particles", type=int, default=0, help="CPU baseline sample (default: one particle per core)")
     ap.add_argument("--cpu-no-reconstruct", action="store_true")
+    ap.add_argument("--unsorted", action="store_true",
+                    help="keep the particles in random order (default: stored by view direction, thx_view_order_host)")
     ap.add_argument("--classification", action="store_true",
                     help="time the global scanning stage of configs[3] (K = 4 x 10000 rotations x 30 shifts at r = 24) instead")
     ap.add_argument("--scan-images", type=int, default=1024)
@@ -240,7 +242,8 @@ def main():
     # ---- synthetic particles of this rank (generation only; every other buffer belongs to the native driver) ----
     n_local = shard_count(args.particles, rank, world)
     shard = RefineShard(args.box, n_local, dev, rank=rank, world=world, mLR=args.mLR, mLT=args.mLT,
-                        nPhase=args.phases, mReco=args.mReco, batch=args.batch, particle_filter=True, allocate=False)
+                        nPhase=args.phases, mReco=args.mReco, batch=args.batch, particle_filter=True, allocate=False,
+                        sort_view=not args.unsorted)
     shard.release_generation_state()
 
     # ---- RCCL communicators in native code (thx_comm_*): the unique ids travel through the launcher's process group,
@@ -327,6 +330,7 @@ def main():
                        "box": args.box, "particles": args.particles, "particles_per_gpu": n_local, "nPxl": nPxl,
                        "pf": 2,
                        "search_state": "device particle filter (perturb / resample every phase, Philox-seeded)",
+                       "particle_order": "random" if args.unsorted else "by view direction (thx_view_order_host)",
                        "driver": "native C++ iteration driver (thx_refine_iterate) through the C ABI",
                        "parallelism": "particles sharded over %d GPU(s); half-set F/T all-reduce in native RCCL "
                                       "(thx_reco_allreduce)" % world},

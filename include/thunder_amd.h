@@ -456,6 +456,13 @@ int thx_reco_sphere_pack_dev(float* F, float* T, int dim, int maxRadius, int pf,
  * (may be NULL) hold at least (rU + 2) * (2 rU + 2) ints; *nPxl receives the count. */
 int thx_pixel_list_host(int N, int rU, int rL, int order, int* iCol, int* iRow, int* iPxl, int* iSig, int* nPxl);
 
+/* Shard layout: perm [n] (HOST) orders n particles along a Morton curve over their view direction (the normal R e_z of the
+ * central slice of quat [n][4], folded to one hemisphere, equal-area map): a caller that stores its particles in this
+ * order -- by the previous iteration's top rotation -- puts images that cut the volume along nearly the same plane next to
+ * each other in every launch, and the local-search kernel's gathers hit L2 / Infinity Cache more often (-8 % at 100 k
+ * particles).  Results do not depend on the order. */
+int thx_view_order_host(const double* quat, int n, int* perm);
+
 /* The mReco draws of the insertion (src/Optimiser.cpp:7129-7150) from a RESAMPLED filter (thx_pf_update_dev): uniform
  * picks among the support points r [nImg][nR][4], t [nImg][nT][2] (Particle::rand, src/Particle.cpp:2109-2178) ->
  * recoRot [nImg][mReco][9], recoTran [nImg][mReco][2].  Philox stream (seed, img0 + image, call, 7, draw). */

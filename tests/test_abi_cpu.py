@@ -75,3 +75,25 @@ def test_native_pixel_list_matches_python():
             for a, k in zip(out, ("iCol", "iRow", "iPxl", "iSig")):
                 assert np.array_equal(a[:n.value], pl[k][perm]), (N, rL, order, k)
                 assert np.array_equal(pl[k], po[k])
+
+
+def test_view_order_matches_python():
+    """thx_view_order_host (shard layout by view direction) against its Python twin; a permutation; neighbours in the order
+    have nearby view directions"""
+    import numpy as np
+    from thunder_amd import capi, synth
+    from thunder_amd.refine import view_order
+    rng = np.random.default_rng(8)
+    q = synth.random_quats(5000, rng)
+    perm = np.zeros(len(q), np.int32)
+    capi.call("thx_view_order_host", q.ctypes.data, len(q), perm.ctypes.data)
+    assert np.array_equal(perm, view_order(q)) and np.array_equal(np.sort(perm), np.arange(len(q)))
+    def normal(x):
+        n = np.stack([2 * (x[:, 1] * x[:, 3] + x[:, 0] * x[:, 2]), 2 * (x[:, 2] * x[:, 3] - x[:, 0] * x[:, 1]),
+                      1 - 2 * (x[:, 1] ** 2 + x[:, 2] ** 2)], 1)
+        return n * np.where(n[:, 2:3] < 0, -1, 1)
+    n = normal(q[perm])
+    ang = np.degrees(np.arccos(np.clip(np.abs(np.sum(n[1:] * n[:-1], 1)), 0, 1)))
+    rnd = normal(q)
+    ang0 = np.degrees(np.arccos(np.clip(np.abs(np.sum(rnd[1:] * rnd[:-1], 1)), 0, 1)))
+    assert np.median(ang) < 3.0 < 30.0 < np.median(ang0)

@@ -89,6 +89,7 @@ SIGNATURES = {
     "thx_thu_write": (_i, [C.c_char_p, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "thx_thu_load_extra": (_i, [C.c_char_p, _i, _vp, _i, _vp, _vp, _vp]),
     "thx_pixel_list_host": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
+    "thx_view_order_host": (_i, [_vp, _i, _vp]),
     "thx_draw_reco_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_ulonglong, C.c_uint, C.c_uint, _vp]),
     "thx_refine_create": (_i, [C.POINTER(_vp), C.POINTER(RefineConfig), _vp, _vp]),
     "thx_refine_destroy": (_i, [_vp]),

@@ -33,8 +33,6 @@ static Knobs read_knobs()
     if ((e = getenv("THX_EXPECT_WG_PER_CU"))) v.expectWgPerCU = atoi(e);
     e = getenv("THX_EXPECT_ND");
     v.expectNdSweep = e && e[0] == 's';
-    e = getenv("THX_EXPECT_KERNEL");
-    v.expectKernel = !e ? 0 : (e[0] == 'g' ? 1 : (e[0] == 'b' ? 2 : 0));
     e = getenv("THX_INSERT_PLAIN");
     v.insertPlain = e && e[0] == '1';
     e = getenv("THX_MIN_QUANTA");
@@ -850,6 +848,8 @@ static int launch_expect_local(const ExpectLocalArgs& a, hipStream_t st, bool pa
         THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_expect_local<NT, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
+    // (dealing the images of a launch to the XCDs in contiguous runs, so that orientation-sorted neighbours share an L2,
+    // was measured with view-ordered particles: no gain -- the reuse between neighbouring images happens in the Infinity Cache)
     if (packed)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expect_local<NT, true>), dim3(a.nSplit, a.nImg, a.nD), dim3(256), lds, st, a);
     else

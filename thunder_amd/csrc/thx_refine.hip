@@ -433,6 +433,25 @@ int thx_pixel_list_host(int N, int rU, int rL, int order, int* iCol, int* iRow, 
     return 0;
 }
 
+int thx_view_order_host(const double* quat, int n, int* perm)
+{
+    THX_REQUIRE(quat && perm && n >= 0, "bad arguments");
+    std::vector<unsigned> key(n);
+    for (int l = 0; l < n; l++) {
+        const double q0 = quat[4 * (size_t)l], q1 = quat[4 * (size_t)l + 1], q2 = quat[4 * (size_t)l + 2], q3 = quat[4 * (size_t)l + 3];
+        double nx = 2 * (q1 * q3 + q0 * q2), ny = 2 * (q2 * q3 - q0 * q1), nz = 1 - 2 * (q1 * q1 + q2 * q2);   // R e_z
+        if (nz < 0) { nx = -nx; ny = -ny; nz = -nz; }
+        const double s = sqrt(1.0 / (1.0 + nz));   // Lambert azimuthal equal-area, scaled to the unit disc
+        double X = floor((nx * s + 1) * 0.5 * 1023), Y = floor((ny * s + 1) * 0.5 * 1023);
+        X = X < 0 ? 0 : (X > 1023 ? 1023 : X);
+        Y = Y < 0 ? 0 : (Y > 1023 ? 1023 : Y);
+        key[l] = spread_bits((unsigned)X) | (spread_bits((unsigned)Y) << 1);
+    }
+    for (int l = 0; l < n; l++) perm[l] = l;
+    std::stable_sort(perm, perm + n, [&](int a, int b) { return key[a] < key[b]; });
+    return 0;
+}
+
 int thx_draw_reco_dev(double* recoRot, double* recoTran, const double* r, const double* t, int nImg, int nR, int nT, int mReco,
                       unsigned long long seed, unsigned call, unsigned img0, void* stream)
 {

@@ -72,7 +72,7 @@ class RefineShard:
 
     def __init__(self, N, nImg, device, rank=0, world=1, pf=2, mLR=125, mLT=9, nPhase=3, mReco=100, seed=1000,
                  batch=10240, pixelSize=1.32, snr=0.01, rL=2, ops=None, oracle_pixel_list=None, nGroup=8, groupSig=True,
-                 maskFrac=0.45, particle_filter=True, transS=2.0, data=None, allocate=True):
+                 maskFrac=0.45, particle_filter=True, transS=2.0, data=None, allocate=True, sort_view=False):
         """data (optional): particles read from files instead of synthesised here -- dict(imgOri complex64 device stack
         [nImg][N][N/2+1] as Optimiser::initImg leaves _imgOri, attr float32 [nImg][7], quat [nImg][4], shift [nImg][2]
         (initial poses, e.g. the .thu columns), gid int32 [nImg] 1-based group ids, ref float32 [N]^3 initial map).
@@ -127,6 +127,11 @@ class RefineShard:
         # ---- particles: pose, shift, CTF, noisy image on the pixel list ----
         if data is None:
             self.quat = synth.random_quats(nImg, rng)
+            if sort_view:   # shard layout: particles ordered by view direction within each half (see view_order)
+                nA = (nImg + 1) // 2 if world == 1 else nImg
+                for lo, hi in ((0, nA), (nA, nImg)):
+                    if hi > lo:
+                        self.quat[lo:hi] = self.quat[lo:hi][view_order(self.quat[lo:hi])]
             self.shift = rng.normal(0, 2.0, size=(nImg, 2))
             self.attr = torch.from_numpy(synth.ctf_params(nImg, rng)).to(device)
         else:
@@ -552,6 +557,28 @@ class RefineShard:
             self.pf_call = 0
         for vi in range(len(self.halves)):
             self.refresh_rows(vi)
+
+
+def view_order(quat):
+    """Permutation that orders particles along a Morton curve over their view direction (the normal of the central slice,
+    R e_z, folded to one hemisphere; Lambert equal-area map to a 1024 x 1024 grid): images next to each other in a launch
+    cut the volume along nearly the same plane, so the cells one image's cloud of rotations fetches are still in L2 /
+    Infinity Cache when its neighbours ask for them (-8 % E-step time at 100 k particles).  Host-side layout work, like the
+    pixel-visit order; thx_view_order_host is the C twin (tests compare the two).  In a running refinement the key is the
+    previous iteration's top rotation."""
+    q0, q1, q2, q3 = quat[:, 0], quat[:, 1], quat[:, 2], quat[:, 3]
+    n = np.stack([2 * (q1 * q3 + q0 * q2), 2 * (q2 * q3 - q0 * q1), 1 - 2 * (q1 * q1 + q2 * q2)], axis=1)
+    n = n * np.where(n[:, 2:3] < 0, -1.0, 1.0)
+    s = np.sqrt(1.0 / (1.0 + n[:, 2]))
+    X = np.floor((n[:, 0] * s + 1) * 0.5 * 1023).clip(0, 1023).astype(np.uint32)
+    Y = np.floor((n[:, 1] * s + 1) * 0.5 * 1023).clip(0, 1023).astype(np.uint32)
+
+    def spread(v):
+        o = np.zeros_like(v)
+        for b in range(10):
+            o |= ((v >> b) & 1) << (2 * b)
+        return o
+    return np.argsort(spread(X) | (spread(Y) << 1), kind="stable")
 
 
 def pixel_visit_order(pl, N):
