@@ -184,10 +184,10 @@ def bench_global_scan(args, dev):
            "data": "synthetic",
            "config": {"workload": "configs[3] global scan: %d synthetic %d^3 images x %d classes x %d rotations x %d shifts at "
                                   "r = %d (%d pixels)" % (nImg, N, K, nR, nT, rScan, nPxl), "classes_recovered": ok},
-           "roofline": {"bound": "mfma", "kernel": "k_expect_global (one class: %d images x %d rot x %d shifts)" % (nImg, nR, nT),
+           "roofline": {"bound": "mfma", "kernel": "thx_expect_global_dev = k_scan_tables + k_scan_gemm (f32 MFMA) + fold (one class: %d images x %d rot x %d shifts)" % (nImg, nR, nT),
                         "achieved": flops / (k_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                         "frac": flops / (k_ms * 1e-3) / 1e12 / 157.3, "traffic": None, "avg_launch_ms": k_ms,
-                        "note": "fp32 FMAs on the vector ALUs; the f32 MFMA rate of gfx950 equals the vector rate (157.3 TFLOP/s)"},
+                        "note": "exact-f32 contraction on v_mfma_f32_32x32x2_f32 (bit-equal to the fmaf chain); peak = f32 MFMA = f32 vector rate"},
            "cpu_baseline": None}
     print(json.dumps(out))
 

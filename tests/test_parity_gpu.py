@@ -194,11 +194,17 @@ def test_expect_local_dsearch_and_volidx(oracle, dev):
                                        rtol=1e-3, err_msg=name)
 
 
-def test_expect_global(oracle, dev):
+@pytest.mark.parametrize("nR,nT,nImg,form", [(70, 11, 5, "small"), (301, 11, 37, "tiled"), (301, 11, 37, "simple")])
+def test_expect_global(oracle, dev, knob_env, nR, nT, nImg, form):
+    """the scanning stage against the oracle: the rotation-per-thread kernel (small problems), the LDS-tiled contraction
+    (nImg * nT >= 256 and nR >= 256; ragged tiles on purpose) and the former forced onto the latter's sizes -- the two forms
+    accumulate in the same order, so their outputs must be bit-identical"""
     from thunder_amd import ops, synth
     O = oracle
     rng = np.random.default_rng(17)
-    N, nR, nT, nImg, nK = 32, 70, 11, 5, 2
+    N, nK = 32, 2
+    if form == "simple":
+        knob_env("THX_SCAN", "simple")
     ref, vol, pl = make_case(O, N, rU=10)
     _, vol2, _ = make_case(O, N, seed=31, rU=10)
     P = 2 * N
@@ -231,6 +237,15 @@ def test_expect_global(oracle, dev):
     np.testing.assert_allclose(d_wC.cpu().numpy(), wC, rtol=tol)
     np.testing.assert_allclose(d_wR.cpu().numpy(), wR, rtol=tol, atol=1e-30)
     np.testing.assert_allclose(d_wT.cpu().numpy(), wT, rtol=tol, atol=1e-30)
+    got = {k: v.cpu().numpy().copy() for k, v in (("wC", d_wC), ("wR", d_wR), ("wT", d_wT), ("base", d_base))}
+    if form == "tiled":
+        _scan_forms["tiled"] = got
+    elif form == "simple" and "tiled" in _scan_forms:
+        for k, v in got.items():
+            assert np.array_equal(v, _scan_forms["tiled"][k]), k
+
+
+_scan_forms = {}
 
 
 # ---------------------------------------------------------------------------------------------

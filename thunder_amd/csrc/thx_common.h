@@ -49,6 +49,8 @@ struct Knobs {
     int expectNSplit;     // THX_EXPECT_NSPLIT = 1..16: pixel splits of the local-search kernel (0 = automatic)
     int expectWgPerCU;    // THX_EXPECT_WG_PER_CU: overrides the occupancy argument of thx_expect_local_dev (-1 = unset)
     bool expectNdSweep;   // THX_EXPECT_ND=sweep: one launch per defocus factor instead of the fused kernel
+    bool scanSimple;      // THX_SCAN=simple: the rotation-per-thread global-scan kernel for every size (A/B)
+    int scanTile;         // THX_SCAN=t42 / t24 / t44: wave tiles of the scan contraction (A/B; default 2 x 2)
     bool insertPlain;     // THX_INSERT_PLAIN=1: plain float-atomic insertion (k_insert)
     float minQuanta;      // THX_MIN_QUANTA: smallest T term accumulated in the fixed-point LDS brick
     bool fftRocfft;       // THX_FFT=rocfft: library transforms in the gridding loop for every size

@@ -33,6 +33,9 @@ static Knobs read_knobs()
     if ((e = getenv("THX_EXPECT_WG_PER_CU"))) v.expectWgPerCU = atoi(e);
     e = getenv("THX_EXPECT_ND");
     v.expectNdSweep = e && e[0] == 's';
+    e = getenv("THX_SCAN");
+    v.scanSimple = e && e[0] == 's';
+    v.scanTile = e && e[0] == 't' ? atoi(e + 1) : 0;
     e = getenv("THX_INSERT_PLAIN");
     v.insertPlain = e && e[0] == '1';
     e = getenv("THX_MIN_QUANTA");
@@ -713,7 +716,8 @@ __global__ __launch_bounds__(256) void k_expect_global(ExpectGlobalArgs a, int t
 }
 
 // [nR][nPxl] -> [nPxl][nR] through a padded 32x32 LDS tile (coalesced on both sides)
-__global__ __launch_bounds__(256) void k_transpose_c64(float2* __restrict__ dst, const float2* __restrict__ src, int nR, int nPxl)
+__global__ __launch_bounds__(256) void k_transpose_c64(float2* __restrict__ dst, const float2* __restrict__ src, int nR, int nPxl,
+                                                       long ldd)
 {
     __shared__ float2 tile[32][33];
     const int p0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -722,7 +726,219 @@ __global__ __launch_bounds__(256) void k_transpose_c64(float2* __restrict__ dst,
         if (r0 + k < nR && p0 + tx < nPxl) tile[k][tx] = src[(size_t)(r0 + k) * nPxl + p0 + tx];
     __syncthreads();
     for (int k = ty; k < 32; k += 8)
-        if (p0 + k < nPxl && r0 + tx < nR) dst[(size_t)(p0 + k) * nR + r0 + tx] = tile[tx][k];
+        if (p0 + k < nPxl && r0 + tx < nR) dst[(size_t)(p0 + k) * ldd + r0 + tx] = tile[tx][k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same stage as a two-operand LDS-tiled contraction (the form for production sizes: thousands of images x 10^4
+// rotations).  Per class
+//   acc[m][n]  = sum_k A[k][m] Bq[k][n],   m = (image, shift), n = rotation, k = (pixel, re | im): A[2p] = Re A_t, A[2p+1] = -Im A_t
+//   accB[i][n] = sum_p sB[p][i] |q(p, n)|^2
+//   dvp[m][n]  = C_image + (accB[image][n] - 2 acc[m][n])
+// with every sum running over k in ascending order inside one thread -- the SAME sequence of fmaf's as k_expect_global, so
+// the results are bit-identical to it (tests compare both with the oracle).
+// ---------------------------------------------------------------------------------------------
+constexpr int kGM = 128, kGN = 128, kGK = 16;
+
+// A operand, k-major: tabA[2p][m] = Re(s ctf conj(dat) ramp_t), tabA[2p+1][m] = -Im(...); tabS[p][i] = s ctf^2; tabC[i].
+// grid (ceil(nPxl/32), ceil(nImg/8)), block 256 = 32 pixels x 8 images
+__global__ __launch_bounds__(256) void k_scan_tables(float* __restrict__ tabA, float* __restrict__ tabS, ExpectGlobalArgs a, long Mpad,
+                                                     long Ipad)
+{
+    const int p = blockIdx.x * 32 + (threadIdx.x & 31), img = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (p >= a.nPxl || img >= a.nImg) return;
+    const float s = a.sigRcpP[(size_t)img * a.nPxl + p], cf = a.ctfP[(size_t)img * a.nPxl + p];
+    const float2 dv = a.datP[(size_t)img * a.nPxl + p];
+    const float g = s * cf;
+    tabS[(size_t)p * Ipad + img] = g * cf;
+    const float2 cd = make_float2(dv.x * g, -dv.y * g);
+    for (int t = 0; t < a.nT; t++) {
+        const float2 A = cmul(cd, a.traP[(size_t)t * a.nPxl + p]);
+        const size_t m = (size_t)img * a.nT + t;
+        tabA[(size_t)(2 * p) * Mpad + m] = A.x;
+        tabA[(size_t)(2 * p + 1) * Mpad + m] = -A.y;
+    }
+}
+
+// C_image = sum_p s |dat|^2 in the order k_expect_global sums it (per-thread strided partials, wave tree, 4 waves)
+__global__ __launch_bounds__(256) void k_scan_const(float* __restrict__ tabC, ExpectGlobalArgs a)
+{
+    __shared__ float sRed[4];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    float cpart = 0.f;
+    for (int p = tid; p < a.nPxl; p += 256) {
+        const float2 dv = a.datP[(size_t)img * a.nPxl + p];
+        cpart = fmaf(a.sigRcpP[(size_t)img * a.nPxl + p], fmaf(dv.x, dv.x, dv.y * dv.y), cpart);
+    }
+    cpart = wave_sum(cpart);
+    if ((tid & 63) == 0) sRed[tid >> 6] = cpart;
+    __syncthreads();
+    if (tid == 0) tabC[img] = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+}
+
+// |q|^2 of the transposed slices: q2[p][n] = fmaf(q.x, q.x, q.y q.y)
+__global__ __launch_bounds__(256) void k_scan_q2(float* __restrict__ q2, const float2* __restrict__ rotPT, size_t n)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const float2 q = rotPT[e];
+    q2[e] = fmaf(q.x, q.x, q.y * q.y);
+}
+
+// QPAIR = true : B operand is the float2 array rotPT [K/2][ldb] read as rows (2p: re, 2p+1: im); epilogue writes dvp
+// QPAIR = false: B operand is the float array q2 [K][ldb]; epilogue writes accB [M][N] (M = images)
+// K is a multiple of 16 (zero rows appended) with 16 spare rows allocated behind it, lda / ldb cover whole tiles.
+// The products run on v_mfma_f32_32x32x2_f32, whose result is bit-for-bit the k-ordered fmaf chain
+// D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) (one rounding per product, no wider accumulator) at the vector pipe's peak rate
+// without its operand traffic: one VGPR per operand per lane, 4 LDS dwords per 4 instructions.  Workgroup = 4 waves as
+// 2 x 2, each wave TM x TN tiles of 32 x 32; LDS tiles double-buffered (one barrier per 16-deep step), the next step's
+// global loads in flight during the multiply.  Workgroups are numbered so that the 64 that share an XCD's L2 at any
+// time form an 8 x 8 patch of the output (8 A panels + 8 B panels for 64 workgroups).
+template <bool QPAIR, int TM, int TN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN <= 4 ? 1 : (TM * TN <= 8 ? 2 : 1), TM * TN <= 4 ? 3 : (TM * TN <= 8 ? 2 : 1)))) void k_scan_gemm(float* __restrict__ out, const float* A, const void* Bv,
+                                                   const float* __restrict__ accB, const float* __restrict__ tabC, int M, int N, int K,
+                                                   long lda, long ldb, int nT, int tilesM, int tilesN)
+{
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    __shared__ __attribute__((aligned(16))) float As[2][kGK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][kGK][BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware numbering: workgroup b runs on XCD b % 8; its slot b / 8 walks 8 x 8 patches
+    int tm, tn;
+    {
+        const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+        const int patch = (slot >> 6) * 8 + xcd, within = slot & 63;
+        const int patchesN = (tilesN + 7) / 8;
+        tn = (patch % patchesN) * 8 + (within & 7);
+        tm = (patch / patchesN) * 8 + (within >> 3);
+        if (tn >= tilesN || tm >= tilesM) return;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    // global -> register staging.  The operands are padded by the launcher (rows to a multiple of 16 with zeros, columns to
+    // whole tiles), so a step's loads are unconditional 16-byte loads from pointers that advance by a constant: nothing
+    // but the loads themselves is issued per step, and all of them are in flight during the multiply.
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    f4v ra[TM], rb[TN];
+    size_t oa[TM], ob[TN];   // running offsets (floats) into A / B
+    const float* Bf = reinterpret_cast<const float*>(Bv);
+#pragma unroll
+    for (int u = 0; u < TM; u++) {
+        const int idx = tid + 256 * u;
+        oa[u] = (size_t)(idx / (BM / 4)) * lda + m0 + (idx % (BM / 4)) * 4;
+    }
+#pragma unroll
+    for (int u = 0; u < TN; u++) {
+        const int idx = tid + 256 * u;
+        if (QPAIR) ob[u] = 2 * ((size_t)(idx / (BN / 2)) * ldb + n0 + (idx % (BN / 2)) * 2);
+        else ob[u] = (size_t)(idx / (BN / 4)) * ldb + n0 + (idx % (BN / 4)) * 4;
+    }
+    const size_t stepA = (size_t)kGK * lda, stepB = (size_t)kGK * ldb;   // floats per step (QPAIR: 8 rows of float2)
+#define THX_SCAN_LOAD()                                                 \
+    {                                                                   \
+        _Pragma("unroll") for (int u = 0; u < TM; u++) {                \
+            ra[u] = *reinterpret_cast<const f4v*>(A + oa[u]);           \
+            oa[u] += stepA;                                             \
+        }                                                               \
+        _Pragma("unroll") for (int u = 0; u < TN; u++) {                \
+            rb[u] = *reinterpret_cast<const f4v*>(Bf + ob[u]);          \
+            ob[u] += stepB;                                             \
+        }                                                               \
+    }
+#define THX_SCAN_STORE(buf)                                                                                         \
+    {                                                                                                               \
+        _Pragma("unroll") for (int u = 0; u < TM; u++) {                                                            \
+            const int idx = tid + 256 * u;                                                                          \
+            *reinterpret_cast<f4v*>(&As[buf][idx / (BM / 4)][(idx % (BM / 4)) * 4]) = ra[u];                        \
+        }                                                                                                           \
+        _Pragma("unroll") for (int u = 0; u < TN; u++) {                                                            \
+            const int idx = tid + 256 * u;                                                                          \
+            if (QPAIR) { /* (re, im) of two rotations of pixel pr -> rows 2 pr (re) and 2 pr + 1 (im) */            \
+                const int pr = idx / (BN / 2), n = (idx % (BN / 2)) * 2;                                            \
+                *reinterpret_cast<f2v*>(&Bs[buf][2 * pr][n]) = f2v{rb[u].x, rb[u].z};                              \
+                *reinterpret_cast<f2v*>(&Bs[buf][2 * pr + 1][n]) = f2v{rb[u].y, rb[u].w};                          \
+            } else {                                                                                                \
+                *reinterpret_cast<f4v*>(&Bs[buf][idx / (BN / 4)][(idx % (BN / 4)) * 4]) = rb[u];                    \
+            }                                                                                                       \
+        }                                                                                                           \
+    }
+    f16v acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    // operand lanes: A[i = lane % 32][k = lane / 32], B[k = lane / 32][j = lane % 32]
+    const int kh = lane >> 5, l32 = lane & 31;
+    const int wm = (wave >> 1) * (32 * TM), wn = (wave & 1) * (32 * TN);
+    THX_SCAN_LOAD();
+    THX_SCAN_STORE(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += kGK) {
+        // the next step's operands, in flight during the multiply (the step after the last reads the 16 spare rows the
+        // launcher allocates behind each operand; they are staged and never multiplied)
+        THX_SCAN_LOAD();
+        asm volatile("" ::: "memory");   // the loads are issued here, not sunk to their use behind the multiplies
+        float av[2][TM], bv[2][TN];   // operands of step s + 1 are read while step s multiplies
+#pragma unroll
+        for (int i = 0; i < TM; i++) av[0][i] = As[buf][kh][wm + 32 * i + l32];
+#pragma unroll
+        for (int j = 0; j < TN; j++) bv[0][j] = Bs[buf][kh][wn + 32 * j + l32];
+#pragma unroll
+        for (int s = 0; s < kGK / 2; s++) {
+            if (s + 1 < kGK / 2) {
+#pragma unroll
+                for (int i = 0; i < TM; i++) av[(s + 1) & 1][i] = As[buf][2 * s + 2 + kh][wm + 32 * i + l32];
+#pragma unroll
+                for (int j = 0; j < TN; j++) bv[(s + 1) & 1][j] = Bs[buf][2 * s + 2 + kh][wn + 32 * j + l32];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the multiplies they overlap with
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the staging stores stay behind the multiplies (their loads need the time)
+        THX_SCAN_STORE(buf ^ 1);   // the other buffer's readers finished before the previous barrier
+        __syncthreads();
+        buf ^= 1;
+    }
+#undef THX_SCAN_LOAD
+#undef THX_SCAN_STORE
+    // epilogue: accumulator register r of lane l is D[8 (r / 4) + 4 (l / 32) + r % 4][l % 32].  Four rows at a time: the
+    // loads first (clamped addresses, no branch: 4 x TN in flight), then the predicated stores.
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int rc = 0; rc < 4; rc++) {
+            float ab[4][TN], cc[4];
+            const int mb = m0 + wm + 32 * i + 8 * rc + 4 * kh;
+            if (QPAIR) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int img = min(mb + r, M - 1) / nT;
+                    cc[r] = tabC[img];
+#pragma unroll
+                    for (int j = 0; j < TN; j++) ab[r][j] = accB[(size_t)img * N + min(n0 + wn + 32 * j + l32, N - 1)];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    const int n = n0 + wn + 32 * j + l32;
+                    const float v = acc[i][j][4 * rc + r];
+                    const float o = QPAIR ? cc[r] + (ab[r][j] - 2.0f * v) : v;
+                    if (mb + r < M && n < N) out[(size_t)(mb + r) * N + n] = o;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 }
 
 // stage 2: grid (nImg), block 256
@@ -776,6 +992,88 @@ __global__ __launch_bounds__(256) void k_expect_global_fold(const float* __restr
         s = block_sum_256(s, sred);
         if (tid == 0) b[t] = (float)((double)b[t] + s);
         sc += s * pt[t];
+    }
+    if (tid == 0) {
+        wC[(size_t)l * nK + kIdx] = (float)((double)wC[(size_t)l * nK + kIdx] + sc);
+        baseL[l] = base;
+    }
+}
+
+// stage 2 for nT <= 32 (every configuration of the reference's scan: 30 shifts at most): the weights of one (shift,
+// rotation) are exponentiated once; a thread owns rotations m = tid, tid + 256, ... and carries the nT partial sums of
+// wT in registers.  Same summation orders as k_expect_global_fold, so the same bits.
+__global__ __launch_bounds__(256) void k_expect_global_fold32(const float* __restrict__ dvp, const double* __restrict__ pR,
+                                                              const double* __restrict__ pT, float* __restrict__ wC,
+                                                              float* __restrict__ wR, float* __restrict__ wT,
+                                                              float* __restrict__ baseL, int kIdx, int nK, int nR, int nT,
+                                                              int nImg)
+{
+    __shared__ float sfred[4];
+    __shared__ double sred[4];
+    __shared__ double sPt[32];
+    const int l = blockIdx.x, tid = threadIdx.x;
+    const float* d = dvp + (size_t)l * nT * nR;
+    const int n = nT * nR;
+    float lmax = -INFINITY;
+    if ((((size_t)l * n) & 3) == 0) {   // 16-byte loads when the image's block is aligned
+        const float4* d4 = reinterpret_cast<const float4*>(d);
+        for (int e = tid; e < n / 4; e += 256) {
+            const float4 v = d4[e];
+            lmax = fmaxf(lmax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        }
+        for (int e = (n / 4) * 4 + tid; e < n; e += 256) lmax = fmaxf(lmax, d[e]);
+    } else {
+        for (int e = tid; e < n; e += 256) lmax = fmaxf(lmax, d[e]);
+    }
+    lmax = wave_max(lmax);
+    if ((tid & 63) == 0) sfred[tid >> 6] = lmax;
+    if (tid < 32) sPt[tid] = tid < nT ? pT[(size_t)l * nT + tid] : 0.0;
+    __syncthreads();
+    lmax = fmaxf(fmaxf(sfred[0], sfred[1]), fmaxf(sfred[2], sfred[3]));
+    const float old = baseL[l];
+    const bool unset = isnan(old);
+    const float base = unset ? lmax : fmaxf(old, lmax);
+    const float nf = unset ? 1.0f : expf(old - base);
+    if (!unset && base > old) {   // rescale what earlier classes / sweeps accumulated (src/Optimiser.cpp:843-871)
+        for (int q = tid; q < nK; q += 256) wC[(size_t)l * nK + q] *= nf;
+        for (int td = 0; td < nK; td++) {
+            float* a = wR + ((size_t)td * nImg + l) * nR;
+            float* b = wT + ((size_t)td * nImg + l) * nT;
+            for (int q = tid; q < nR; q += 256) a[q] *= nf;
+            for (int q = tid; q < nT; q += 256) b[q] *= nf;
+        }
+    }
+    __syncthreads();
+    const double* pr = pR + (size_t)l * nR;
+    float* a = wR + ((size_t)kIdx * nImg + l) * nR;
+    float* b = wT + ((size_t)kIdx * nImg + l) * nT;
+    double sT[32];
+#pragma unroll
+    for (int t = 0; t < 32; t++) sT[t] = 0;
+    for (int m = tid; m < nR; m += 256) {
+        const double prm = pr[m];
+        float dv[32];
+#pragma unroll
+        for (int t = 0; t < 32; t++) dv[t] = t < nT ? d[(size_t)t * nR + m] : 0.f;   // all of a rotation's loads in flight
+        double s = 0;
+#pragma unroll
+        for (int t = 0; t < 32; t++) {
+            if (t < nT) {
+                const double w = (double)expf(dv[t] - base);
+                s += w * sPt[t];
+                sT[t] += w * prm;
+            }
+        }
+        a[m] = (float)((double)a[m] + s);
+    }
+    double sc = 0;
+#pragma unroll
+    for (int t = 0; t < 32; t++) {
+        if (t < nT) {   // uniform
+            const double s = block_sum_256(sT[t], sred);
+            if (tid == 0) b[t] = (float)((double)b[t] + s);
+            sc += s * sPt[t];
+        }
     }
     if (tid == 0) {
         wC[(size_t)l * nK + kIdx] = (float)((double)wC[(size_t)l * nK + kIdx] + sc);
@@ -1105,22 +1403,68 @@ int thx_expect_global_dev(const float* rotP, const float* traP, const float* dat
     THX_REQUIRE(nImg <= 65535, "nImg must be <= 65535 per call");
     hipStream_t st = as_stream(stream);
     ExpectGlobalArgs a;
-    float2* rotPT = reinterpret_cast<float2*>(scratch(st, 4, (size_t)nR * nPxl * sizeof(float2)));
+    // production sizes: the LDS-tiled contraction (bit-identical sums); small problems: the rotation-per-thread kernel
+    const bool tiled = (size_t)nImg * nT >= 256 && nR >= 256 && !knobs().scanSimple;
+    const int tileSel = knobs().scanTile;
+    const int bm = (tileSel == 42 || tileSel == 44) ? 256 : 128, bn = (tileSel == 24 || tileSel == 44) ? 256 : 128;
+    // padded shapes of the tiled form: pixel rows to 16, rotation / (image, shift) / image columns to whole tiles
+    const long P16 = ((nPxl + 15) / 16) * 16, Npad = tiled ? (((long)nR + 255) / 256) * 256 : nR;
+    float2* rotPT = reinterpret_cast<float2*>(scratch(st, 4, (size_t)(tiled ? P16 + 16 : nPxl) * Npad * sizeof(float2)));
     THX_REQUIRE(rotPT, "device scratch allocation failed");
+    if (tiled && P16 > nPxl) THX_CHECK(hipMemsetAsync(rotPT + (size_t)nPxl * Npad, 0, (size_t)(P16 - nPxl) * Npad * sizeof(float2), st));
     hipLaunchKernelGGL(k_transpose_c64, dim3((nPxl + 31) / 32, (nR + 31) / 32), dim3(256), 0, st, rotPT,
-                       reinterpret_cast<const float2*>(rotP), nR, nPxl);
+                       reinterpret_cast<const float2*>(rotP), nR, nPxl, Npad);
     a.rotPT = rotPT;
     a.traP = reinterpret_cast<const float2*>(traP);
     a.datP = reinterpret_cast<const float2*>(datP);
     a.ctfP = ctfP; a.sigRcpP = sigRcpP; a.nR = nR; a.nT = nT; a.nPxl = nPxl; a.nImg = nImg;
     a.dvp = reinterpret_cast<float*>(workspace);
-    constexpr int NT = 8;
-    for (int t0 = 0; t0 < nT; t0 += NT) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expect_global<NT>), dim3((nR + 255) / 256, nImg), dim3(256), 0, st, a, t0);
+    if (tiled) {
+        const int Mrows = nImg * nT;
+        const long Mpad = (((long)Mrows + 255) / 256) * 256, Ipad = (((long)nImg + 127) / 128) * 128;
+        const int K = 2 * nPxl, Kpad = 2 * (((nPxl + 7) / 8) * 8);
+        const size_t nA = (size_t)(Kpad + 16) * Mpad, nS = (size_t)(P16 + 16) * Ipad, nQ = (size_t)(P16 + 16) * Npad, nB = (size_t)nImg * nR;
+        float* tabA = reinterpret_cast<float*>(scratch(st, 11, (nA + nS + nQ + nB + nImg + 64) * sizeof(float)));
+        THX_REQUIRE(tabA, "device scratch allocation failed");
+        float *tabS = tabA + nA, *q2 = tabS + nS, *accB = q2 + nQ, *tabC = accB + nB;
+        if (Kpad > K) THX_CHECK(hipMemsetAsync(tabA + (size_t)K * Mpad, 0, (size_t)(Kpad - K) * Mpad * sizeof(float), st));
+        if (P16 > nPxl) THX_CHECK(hipMemsetAsync(tabS + (size_t)nPxl * Ipad, 0, (size_t)(P16 - nPxl) * Ipad * sizeof(float), st));
+        hipLaunchKernelGGL(k_scan_tables, dim3((nPxl + 31) / 32, (nImg + 7) / 8), dim3(256), 0, st, tabA, tabS, a, Mpad, Ipad);
+        hipLaunchKernelGGL(k_scan_const, dim3(nImg), dim3(256), 0, st, tabC, a);
+        hipLaunchKernelGGL(k_scan_q2, dim3((unsigned)(((size_t)P16 * Npad + 255) / 256)), dim3(256), 0, st, q2, rotPT, (size_t)P16 * Npad);
+        {
+            const int tM = (nImg + 127) / 128, tN = (nR + 127) / 128;
+            const int nwg = ((((tM + 7) / 8) * ((tN + 7) / 8) + 7) / 8) * 8 * 64;   // patches rounded up to the 8 XCDs
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_gemm<false, 2, 2>), dim3(nwg), dim3(256), 0, st, accB, tabS, q2, nullptr, nullptr,
+                               nImg, nR, (int)P16, Ipad, Npad, 1, tM, tN);
+        }
+        {
+            auto launch = [&](auto kern) {
+                const int tM = (Mrows + bm - 1) / bm, tN = (nR + bn - 1) / bn;
+                const int nwg = ((((tM + 7) / 8) * ((tN + 7) / 8) + 7) / 8) * 8 * 64;
+                hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), 0, st, a.dvp, tabA, rotPT, accB, tabC, Mrows, nR, Kpad, Mpad, Npad, nT, tM,
+                                   tN);
+            };
+            switch (tileSel) {
+            case 42: launch(k_scan_gemm<true, 4, 2>); break;
+            case 24: launch(k_scan_gemm<true, 2, 4>); break;
+            case 44: launch(k_scan_gemm<true, 4, 4>); break;
+            default: launch(k_scan_gemm<true, 2, 2>); break;
+            }
+        }
+    } else {
+        constexpr int NT = 8;
+        for (int t0 = 0; t0 < nT; t0 += NT) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expect_global<NT>), dim3((nR + 255) / 256, nImg), dim3(256), 0, st, a, t0);
+        }
     }
     THX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_expect_global_fold, dim3(nImg), dim3(256), 0, st, a.dvp, pR, pT, wC, wR, wT, baseL, kIdx, nK, nR,
-                       nT, nImg);
+    if (nT <= 32)
+        hipLaunchKernelGGL(k_expect_global_fold32, dim3(nImg), dim3(256), 0, st, a.dvp, pR, pT, wC, wR, wT, baseL, kIdx, nK, nR,
+                           nT, nImg);
+    else
+        hipLaunchKernelGGL(k_expect_global_fold, dim3(nImg), dim3(256), 0, st, a.dvp, pR, pT, wC, wR, wT, baseL, kIdx, nK, nR,
+                           nT, nImg);
     THX_LAUNCH_CHECK();
     return 0;
 }
