@@ -255,7 +255,7 @@ struct InsertWinArgs {
     int nW;                 // windows per side; window w covers [pOrg + w kWd, pOrg + (w+1) kWd)
     int pOrg;
     float rMax2;            // (largest sample radius + 2)^2, voxels
-    int debug;              // builds with -DTHX_PROFILING only (THX_INSERT_DEBUG): 1 skip LDS adds, 2 skip flush, 4 skip the group loop
+    int debug;              // builds with -DTHX_PROFILING only (THX_INSERT_DEBUG): 1 skip LDS adds, 2 skip flush, 4 skip the group loop, 8 skip the exact stage, 16 exact geometry only
 };
 
 __global__ __launch_bounds__(256) void k_insert_bounds(float2* __restrict__ bounds, const float2* __restrict__ datP,
@@ -479,7 +479,9 @@ __device__ __forceinline__ void win_process(const InsertWinArgs& wa, const WinGe
     const int pi = pk & 0x7FF, pj = ((pk >> 11) & 0x7FF) - 1024, gi_ = (int)((unsigned)pk >> 22);
     const double* R = dt.R + 6 * gi_;
     WinSample w;
+    if (kWinProfiling && (wa.debug & 8)) { if (pk == 0x7fffffff) sRe[0] = 1; return; }
     if (!win_sample<AX>(g, R, a.opf, P, pi, pj, w)) return;   // a false positive of the float test
+    if (kWinProfiling && (wa.debug & 16)) { if (w.inMask == 0x12345) sRe[0] = 1; return; }
     const int m0 = dt.gStart[gi_], m1 = dt.gStart[gi_ + 1];
     const float nmem = (float)(m1 - m0);
     const int ti = pi - g.ui0, tj = pj - g.uj0;
@@ -838,7 +840,7 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
             // ---- pixel data and separable ramps of the unique shifts for the pixel range in play ----
             g.ui0 = sUi0 <= sUi1 ? sUi0 - ((kIPix - (sUi1 - sUi0 + 1)) > 0 ? (kIPix - (sUi1 - sUi0 + 1)) / 2 : 0) : 0;
             g.uj0 = sUj0 <= sUj1 ? sUj0 - ((kIPix - (sUj1 - sUj0 + 1)) > 0 ? (kIPix - (sUj1 - sUj0 + 1)) / 2 : 0) : -half;
-            for (int e = tid; e < kIPix * kIPix; e += kWinThreads) {
+            for (int e = tid; e < kIPix * kIPix && !(kWinProfiling && (wa.debug & 32)); e += kWinThreads) {
                 const int tj = e / kIPix, ti = e - tj * kIPix;
                 const int pi = g.ui0 + ti, pj = g.uj0 + tj;
                 float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -851,7 +853,7 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
                 }
                 sPix[e] = px;
             }
-            if (U <= kMaxU)
+            if (U <= kMaxU && !(kWinProfiling && (wa.debug & 64)))
                 for (int e = tid; e < 2 * U * kIPix; e += kWinThreads) {
                     const int which = e / (U * kIPix), rem = e - which * U * kIPix, u = rem / kIPix, o = rem - u * kIPix;
                     // exp(-2 pi i n slope): the whole turns are removed in double (n slope is exact to 1e-13), the
@@ -865,7 +867,7 @@ __global__ __launch_bounds__(kWinThreads, kWinThreads / 128) void k_insert_win(I
             __syncthreads();
             const int sLo = (sWlo + kWz / 2) >= 0 ? (sWlo + kWz / 2) / kWz : -((-(sWlo + kWz / 2) + kWz - 1) / kWz);
             const int sHi = (sWhi + kWz / 2) >= 0 ? (sWhi + kWz / 2) / kWz : -((-(sWhi + kWz / 2) + kWz - 1) / kWz);
-            for (int sl = sLo; sl <= sHi; sl++) {
+            for (int sl = sLo; sl <= sHi && !(kWinProfiling && (wa.debug & 128)); sl++) {
                 g.w0 = sl * kWz - kWz / 2;
                 // the waves draw groups from a shared counter: the work per group varies (candidate box, slab overlap) and
                 // every slab ends in a barrier, so a static split leaves waves idle at it
