@@ -9,6 +9,9 @@ cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_100k
 rm -rf $OUT/stats
 python bench.py --particles 10000 --no-cpu-baseline > $OUT/bench_10k.json 2>> $OUT/bench_100k.err
 python bench.py --classification --steps 2 --warmup 1 > $OUT/bench_global_scan.json 2>> $OUT/bench_100k.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scanstats -- python bench.py --classification --steps 2 --warmup 1 > /dev/null 2>> $OUT/stats.err
+cp $(find $OUT/scanstats -name "*kernel_stats.csv" | head -1) $OUT/global_scan_kernel_stats.csv
+rm -rf $OUT/scanstats
 bash tools/pmc_traffic.sh > $OUT/pmc.log 2>&1
 cp gpurun_out/pmc_traffic/summary.json $OUT/pmc_traffic_summary.json
 cp gpurun_out/pmc_traffic/pmc_traffic.json $OUT/pmc_traffic.json
