@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libthunder_amd.so")
+LIB_PATH = os.environ.get("THX_LIB") or os.path.join(_HERE, "lib", "libthunder_amd.so")   # THX_LIB: an alternative build, for A/B runs of compile-time parameters
 
 
 class ThxError(RuntimeError):
