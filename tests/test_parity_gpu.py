@@ -248,6 +248,43 @@ def test_expect_global(oracle, dev, knob_env, nR, nT, nImg, form):
 _scan_forms = {}
 
 
+def test_expect_global_forms_bit_identical_scan_size(dev, knob_env):
+    """the two forms of the scanning stage at the classification scan's pixel count (866) and shift count (30), ragged in
+    images and rotations, two classes swept twice (so the carried baseline is rescaled): the f32-MFMA contraction must
+    reproduce the rotation-per-thread kernel bit for bit -- its sums run over k in the same order with one rounding per
+    product"""
+    from thunder_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    nImg, nT, nR, nPxl, nK = 129, 30, 1001, 866, 2
+
+    def cplx(*shape, scale=1.0):
+        return (torch.randn(*shape, 2, generator=g) * scale).view(*shape, 2)
+
+    rot = [torch.view_as_complex(cplx(nR, nPxl).contiguous()).to(dev) for _ in range(nK)]
+    ang = torch.rand(nT, nPxl, generator=g, dtype=torch.float64) * 6.283185307179586
+    tra = torch.complex(torch.cos(ang), torch.sin(ang)).to(torch.complex64).to(dev)
+    dat = torch.view_as_complex(cplx(nImg, nPxl).contiguous()).to(dev)
+    ctf = (torch.rand(nImg, nPxl, generator=g) * 2 - 1).to(dev)
+    sig = (-0.5 / (0.5 + torch.rand(nImg, nPxl, generator=g))).to(dev) * 1e-2
+    pR = (0.5 + torch.rand(nImg, nR, generator=g, dtype=torch.float64)).to(dev)
+    pT = (0.5 + torch.rand(nImg, nT, generator=g, dtype=torch.float64)).to(dev)
+    out = {}
+    for form in ("simple", "tiled"):
+        knob_env("THX_SCAN", "simple" if form == "simple" else None)
+        wC = torch.zeros((nImg, nK), dtype=torch.float32, device=dev)
+        wR = torch.zeros((nK, nImg, nR), dtype=torch.float32, device=dev)
+        wT = torch.zeros((nK, nImg, nT), dtype=torch.float32, device=dev)
+        base = torch.full((nImg,), float("nan"), dtype=torch.float32, device=dev)
+        for sweep in range(2):
+            for k in range(nK):
+                ops.expect_global(rot[(k + sweep) % nK], tra, dat, ctf, sig, pR, pT, wC, wR, wT, base, k, nK)
+        out[form] = [t.cpu() for t in (wC, wR, wT, base)]
+        assert all(torch.isfinite(t).all() for t in out[form])
+    for a, b, name in zip(out["simple"], out["tiled"], ("wC", "wR", "wT", "base")):
+        assert torch.equal(a, b), name
+    assert out["tiled"][1].abs().max() > 0
+
+
 # ---------------------------------------------------------------------------------------------
 def _insert_case(O, N, nImg, mReco, rng, nK=1):
     from thunder_amd import synth

@@ -738,7 +738,10 @@ __global__ __launch_bounds__(256) void k_transpose_c64(float2* __restrict__ dst,
 // with every sum running over k in ascending order inside one thread -- the SAME sequence of fmaf's as k_expect_global, so
 // the results are bit-identical to it (tests compare both with the oracle).
 // ---------------------------------------------------------------------------------------------
-constexpr int kGM = 128, kGN = 128, kGK = 16;
+#ifndef THX_SCAN_BK
+#define THX_SCAN_BK 16
+#endif
+constexpr int kGM = 128, kGN = 128, kGK = THX_SCAN_BK;   // depth of one LDS step (a multiple of 16)
 
 // A operand, k-major: tabA[2p][m] = Re(s ctf conj(dat) ramp_t), tabA[2p+1][m] = -Im(...); tabS[p][i] = s ctf^2; tabC[i].
 // grid (ceil(nPxl/32), ceil(nImg/8)), block 256 = 32 pixels x 8 images
@@ -820,16 +823,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN <= 
     // but the loads themselves is issued per step, and all of them are in flight during the multiply.
     typedef float f4v __attribute__((ext_vector_type(4)));
     typedef float f2v __attribute__((ext_vector_type(2)));
-    f4v ra[TM], rb[TN];
-    size_t oa[TM], ob[TN];   // running offsets (floats) into A / B
+    constexpr int NA = TM * kGK / 16, NB = TN * kGK / 16;   // 16-byte loads per thread and step
+    f4v ra[NA], rb[NB];
+    size_t oa[NA], ob[NB];   // running offsets (floats) into A / B
     const float* Bf = reinterpret_cast<const float*>(Bv);
 #pragma unroll
-    for (int u = 0; u < TM; u++) {
+    for (int u = 0; u < NA; u++) {
         const int idx = tid + 256 * u;
         oa[u] = (size_t)(idx / (BM / 4)) * lda + m0 + (idx % (BM / 4)) * 4;
     }
 #pragma unroll
-    for (int u = 0; u < TN; u++) {
+    for (int u = 0; u < NB; u++) {
         const int idx = tid + 256 * u;
         if (QPAIR) ob[u] = 2 * ((size_t)(idx / (BN / 2)) * ldb + n0 + (idx % (BN / 2)) * 2);
         else ob[u] = (size_t)(idx / (BN / 4)) * ldb + n0 + (idx % (BN / 4)) * 4;
@@ -837,22 +841,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN <= 
     const size_t stepA = (size_t)kGK * lda, stepB = (size_t)kGK * ldb;   // floats per step (QPAIR: 8 rows of float2)
 #define THX_SCAN_LOAD()                                                 \
     {                                                                   \
-        _Pragma("unroll") for (int u = 0; u < TM; u++) {                \
+        _Pragma("unroll") for (int u = 0; u < NA; u++) {                \
             ra[u] = *reinterpret_cast<const f4v*>(A + oa[u]);           \
             oa[u] += stepA;                                             \
         }                                                               \
-        _Pragma("unroll") for (int u = 0; u < TN; u++) {                \
+        _Pragma("unroll") for (int u = 0; u < NB; u++) {                \
             rb[u] = *reinterpret_cast<const f4v*>(Bf + ob[u]);          \
             ob[u] += stepB;                                             \
         }                                                               \
     }
 #define THX_SCAN_STORE(buf)                                                                                         \
     {                                                                                                               \
-        _Pragma("unroll") for (int u = 0; u < TM; u++) {                                                            \
+        _Pragma("unroll") for (int u = 0; u < NA; u++) {                                                            \
             const int idx = tid + 256 * u;                                                                          \
             *reinterpret_cast<f4v*>(&As[buf][idx / (BM / 4)][(idx % (BM / 4)) * 4]) = ra[u];                        \
         }                                                                                                           \
-        _Pragma("unroll") for (int u = 0; u < TN; u++) {                                                            \
+        _Pragma("unroll") for (int u = 0; u < NB; u++) {                                                            \
             const int idx = tid + 256 * u;                                                                          \
             if (QPAIR) { /* (re, im) of two rotations of pixel pr -> rows 2 pr (re) and 2 pr + 1 (im) */            \
                 const int pr = idx / (BN / 2), n = (idx % (BN / 2)) * 2;                                            \
@@ -1408,8 +1412,8 @@ int thx_expect_global_dev(const float* rotP, const float* traP, const float* dat
     const int tileSel = knobs().scanTile;
     const int bm = (tileSel == 42 || tileSel == 44) ? 256 : 128, bn = (tileSel == 24 || tileSel == 44) ? 256 : 128;
     // padded shapes of the tiled form: pixel rows to 16, rotation / (image, shift) / image columns to whole tiles
-    const long P16 = ((nPxl + 15) / 16) * 16, Npad = tiled ? (((long)nR + 255) / 256) * 256 : nR;
-    float2* rotPT = reinterpret_cast<float2*>(scratch(st, 4, (size_t)(tiled ? P16 + 16 : nPxl) * Npad * sizeof(float2)));
+    const long P16 = ((nPxl + kGK - 1) / kGK) * kGK, Npad = tiled ? (((long)nR + 255) / 256) * 256 : nR;
+    float2* rotPT = reinterpret_cast<float2*>(scratch(st, 4, (size_t)(tiled ? P16 + kGK : nPxl) * Npad * sizeof(float2)));
     THX_REQUIRE(rotPT, "device scratch allocation failed");
     if (tiled && P16 > nPxl) THX_CHECK(hipMemsetAsync(rotPT + (size_t)nPxl * Npad, 0, (size_t)(P16 - nPxl) * Npad * sizeof(float2), st));
     hipLaunchKernelGGL(k_transpose_c64, dim3((nPxl + 31) / 32, (nR + 31) / 32), dim3(256), 0, st, rotPT,
@@ -1422,8 +1426,8 @@ int thx_expect_global_dev(const float* rotP, const float* traP, const float* dat
     if (tiled) {
         const int Mrows = nImg * nT;
         const long Mpad = (((long)Mrows + 255) / 256) * 256, Ipad = (((long)nImg + 127) / 128) * 128;
-        const int K = 2 * nPxl, Kpad = 2 * (((nPxl + 7) / 8) * 8);
-        const size_t nA = (size_t)(Kpad + 16) * Mpad, nS = (size_t)(P16 + 16) * Ipad, nQ = (size_t)(P16 + 16) * Npad, nB = (size_t)nImg * nR;
+        const int K = 2 * nPxl, Kpad = ((2 * nPxl + kGK - 1) / kGK) * kGK;
+        const size_t nA = (size_t)(Kpad + kGK) * Mpad, nS = (size_t)(P16 + kGK) * Ipad, nQ = (size_t)(P16 + kGK) * Npad, nB = (size_t)nImg * nR;
         float* tabA = reinterpret_cast<float*>(scratch(st, 11, (nA + nS + nQ + nB + nImg + 64) * sizeof(float)));
         THX_REQUIRE(tabA, "device scratch allocation failed");
         float *tabS = tabA + nA, *q2 = tabS + nS, *accB = q2 + nQ, *tabC = accB + nB;
