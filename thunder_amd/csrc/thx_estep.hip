@@ -744,12 +744,12 @@ __global__ __launch_bounds__(256) void k_transpose_c64(float2* __restrict__ dst,
 constexpr int kGM = 128, kGN = 128, kGK = THX_SCAN_BK;   // depth of one LDS step (a multiple of 16)
 
 // A operand, k-major: tabA[2p][m] = Re(s ctf conj(dat) ramp_t), tabA[2p+1][m] = -Im(...); tabS[p][i] = s ctf^2; tabC[i].
-// grid (ceil(nImg nT / 256), nPxl), block 256: lane <-> m = (image, shift), so the two rows of a pixel are written in
+// grid (nPxl, ceil(nImg nT / 256)), block 256: lane <-> m = (image, shift), so the two rows of a pixel are written in
 // 256-byte runs (the image's three inputs are the same address for the nT lanes of an image: broadcast loads)
 __global__ __launch_bounds__(256) void k_scan_tables(float* __restrict__ tabA, float* __restrict__ tabS, ExpectGlobalArgs a, long Mpad,
                                                      long Ipad)
 {
-    const int p = blockIdx.y, m = blockIdx.x * 256 + threadIdx.x;
+    const int p = blockIdx.x, m = blockIdx.y * 256 + threadIdx.x;
     if (m >= a.nImg * a.nT) return;
     const int img = m / a.nT, t = m - img * a.nT;
     const float s = a.sigRcpP[(size_t)img * a.nPxl + p], cf = a.ctfP[(size_t)img * a.nPxl + p];
@@ -1432,7 +1432,8 @@ int thx_expect_global_dev(const float* rotP, const float* traP, const float* dat
         float *tabS = tabA + nA, *q2 = tabS + nS, *accB = q2 + nQ, *tabC = accB + nB;
         if (Kpad > K) THX_CHECK(hipMemsetAsync(tabA + (size_t)K * Mpad, 0, (size_t)(Kpad - K) * Mpad * sizeof(float), st));
         if (P16 > nPxl) THX_CHECK(hipMemsetAsync(tabS + (size_t)nPxl * Ipad, 0, (size_t)(P16 - nPxl) * Ipad * sizeof(float), st));
-        hipLaunchKernelGGL(k_scan_tables, dim3((Mrows + 255) / 256, nPxl), dim3(256), 0, st, tabA, tabS, a, Mpad, Ipad);
+        THX_REQUIRE((Mrows + 255) / 256 <= 65535, "too many (image, shift) rows for one launch");
+        hipLaunchKernelGGL(k_scan_tables, dim3(nPxl, (Mrows + 255) / 256), dim3(256), 0, st, tabA, tabS, a, Mpad, Ipad);
         hipLaunchKernelGGL(k_scan_const, dim3(nImg), dim3(256), 0, st, tabC, a);
         hipLaunchKernelGGL(k_scan_q2, dim3((unsigned)(((size_t)P16 * Npad + 255) / 256)), dim3(256), 0, st, q2, rotPT, (size_t)P16 * Npad);
         {

@@ -518,8 +518,6 @@ __device__ __forceinline__ void win_process(const InsertWinArgs& wa, const WinGe
     const float vx[2] = {1.0f - xd, xd}, vy[2] = {1.0f - yd, yd}, vz[2] = {1.0f - zd, zd};
     // fixed-point scales folded into the pixel's value once (the brick's quantum is 2^-22 of the largest term)
     const float vreS = vre * g.scaleF, vimS = vim * g.scaleF, tvalS = tval * g.scaleT;
-    unsigned tiny = 0;   // voxels whose term is below the brick's quantum floor: handled after the loop (rare), so that the
-                         // loop keeps no volume pointers / global scales live (they were SGPR spills read back per voxel)
 #pragma unroll
     for (int v = 0; v < 8; v++) {
         if (!((w.inMask >> v) & 1)) continue;
@@ -535,16 +533,7 @@ __device__ __forceinline__ void win_process(const InsertWinArgs& wa, const WinGe
             atomicAdd(&sIm[idx], __float2int_rn(vimS * wv));
             atomicAdd(reinterpret_cast<unsigned*>(&sT[idx]), __float2uint_rn(tq));
         } else {
-            tiny |= 1u << v;
-        }
-    }
-    if (tiny) {
-        // tiny terms: F and T travel together as floats, rounded once to the launch's quanta
-#pragma nounroll
-        for (int v = 0; v < 8; v++) {
-            if (!((tiny >> v) & 1)) continue;
-            const int ii = v & 1, jj = (v >> 1) & 1, kk = v >> 2;
-            const float wv = (ii ? vx[1] : vx[0]) * (jj ? vy[1] : vy[0]) * (kk ? vz[1] : vz[0]);
+            // tiny term: F and T travel together as floats
             insert_tiny_term(F, T, P, w.X0 + ii, w.Y0 + jj, w.Z0 + kk, vre * wv, vim * wv, tval * wv, g.gF, g.gT);
         }
     }
