@@ -194,7 +194,8 @@ def test_expect_local_dsearch_and_volidx(oracle, dev):
                                        rtol=1e-3, err_msg=name)
 
 
-@pytest.mark.parametrize("nR,nT,nImg,form", [(70, 11, 5, "small"), (301, 11, 37, "tiled"), (301, 11, 37, "simple")])
+@pytest.mark.parametrize("nR,nT,nImg,form", [(70, 11, 5, "small"), (301, 11, 37, "tiled"), (301, 11, 37, "simple"),
+                                                (257, 35, 8, "tiled")])   # 35 shifts: the general fold behind the tiled contraction
 def test_expect_global(oracle, dev, knob_env, nR, nT, nImg, form):
     """the scanning stage against the oracle: the rotation-per-thread kernel (small problems), the LDS-tiled contraction
     (nImg * nT >= 256 and nR >= 256; ragged tiles on purpose) and the former forced onto the latter's sizes -- the two forms
@@ -239,10 +240,10 @@ def test_expect_global(oracle, dev, knob_env, nR, nT, nImg, form):
     np.testing.assert_allclose(d_wT.cpu().numpy(), wT, rtol=tol, atol=1e-30)
     got = {k: v.cpu().numpy().copy() for k, v in (("wC", d_wC), ("wR", d_wR), ("wT", d_wT), ("base", d_base))}
     if form == "tiled":
-        _scan_forms["tiled"] = got
-    elif form == "simple" and "tiled" in _scan_forms:
+        _scan_forms[(nR, nT, nImg)] = got
+    elif form == "simple" and (nR, nT, nImg) in _scan_forms:
         for k, v in got.items():
-            assert np.array_equal(v, _scan_forms["tiled"][k]), k
+            assert np.array_equal(v, _scan_forms[(nR, nT, nImg)][k]), k
 
 
 _scan_forms = {}
