@@ -306,6 +306,9 @@ int thx_compare_hemispheres_dev(float* A, float* B, int N, int rU, float* fscHos
 /* its pieces, exposed for the parity tests: softMask(Volume& mask, r, ew) and randomPhase(dst, src, r) (phases: DEVICE
  * [N][N][N/2+1] floats receiving the angles, may be NULL) */
 int thx_core_mask_dev(float* mask, int N, float r, float ew, void* stream);
+/* softMask(Volume& dst, const Volume& src, r, ew, bg), src/Functions/Mask.cpp:499-521, in place on a DEVICE [N]^3 map
+ * (Optimiser::solventFlatten's spherical mask, src/Optimiser.cpp:7958-7975) */
+int thx_soft_mask_volume_dev(float* vol, int N, float r, float ew, float bg, void* stream);
 int thx_random_phase_dev(float* dst, const float* src, int N, int r, unsigned long long seed, unsigned call, float* phases,
                          void* stream);
 
@@ -490,7 +493,24 @@ typedef struct thx_refine_config {
     double pfL, pfS;           /* perturbation factors of the first / later phases (script/demo_3D.json:71-73) */
     double peakFactorR;        /* PEAK_FACTOR_MIN */
     unsigned long long seed;
+    /* Model::compareTwoHemispheres / Optimiser::solventFlatten between the reconstructions and Model::refreshProj: */
+    int coreFSC;               /* "Calculate FSC Using Core Region" (script/demo_3D.json:23: true): mask-corrected FSC with the
+                                  core mask of radius AROUND(maskRadius / pixelSize) (src/Optimiser.cpp:188, src/Model.cpp:411-563) */
+    int goldenAverage;         /* != 0: the two references are averaged inside min(AROUND(resA2P(1 / A_B_AVERAGE_THRES)), r)
+                                  after the MAP reconstruction (_goldenStandard, k == 1: src/Model.cpp:616-674) */
+    int solventFlatten;        /* != 0: Optimiser::solventFlatten's spherical soft mask (maskRadius / pixelSize, EDGE_WIDTH_RL,
+                                  background 0; src/Optimiser.cpp:7768-7990, no provided mask) before the projector refresh */
 } thx_refine_config;
+
+/* optional per-phase trace of the local search (tests hold the chain against the oracle with it): DEVICE buffers, any may
+ * be NULL; index [phase][image of this rank].  uR / uT: the E-step's weights as handed to the filter (Particle::setUR /
+ * setUT); r / t: the support points after Particle::resample; k123 / s01: Particle::calVari of the phase. */
+typedef struct thx_refine_capture {
+    float *uR, *uT;            /* [nPhase][nImg][mLR], [nPhase][nImg][mLT] */
+    double *r, *t;             /* [nPhase][nImg][mLR][4], [nPhase][nImg][mLT][2] */
+    double *k123, *s01;        /* [nPhase][nImg][3], [nPhase][nImg][2] */
+    float *mapsFsc;            /* [2][N]^3: the two MAP-off half maps the FSC is computed from */
+} thx_refine_capture;
 
 typedef struct thx_refine_stats {
     double expectMs, insertMs;            /* HIP-event totals of the local-search / insertion launches (timed iterations) */
@@ -511,10 +531,18 @@ int thx_refine_set_particles(thx_refine* h, const float* imgOri, const thx_ctf_a
                              const double* quat0, const double* tran0, void* stream);
 int thx_refine_set_reference(thx_refine* h, const float* refRL, void* stream);   /* DEVICE [N]^3 initial map */
 int thx_refine_reset(thx_refine* h, void* stream);     /* the state before the first iteration */
-/* one EM iteration; fscHost (optional) [N/2] receives the half-map FSC; timed != 0 records HIP events for thx_refine_stats.
- * Synchronises the stream (FSC to the host between the two reconstructions, and the gridding loop's stop rule). */
+/* one EM iteration in the reference's order (src/Optimiser.cpp:3595-4073): expectation, allReduceSigma, insertion,
+ * prepareTF, reconstruct (MAP off) -> compareTwoHemispheres (FSC of THIS iteration, Model::_FSC), reconstruct (MAP on,
+ * joinHalf: OPTIMISER_RECONSTRUCT_JOIN_HALF) with the FSC Model::resetReco handed to the reconstructor at the end of the
+ * PREVIOUS iteration (all ones before the first: src/Model.cpp:1086,1122), gold-standard averaging, solvent flattening,
+ * Model::refreshProj, reCentreImg, reMaskImg.  fscHost (optional) [N/2] receives this iteration's FSC (rU = N/2 - 2 shells,
+ * the rest 0); timed != 0 records HIP events for thx_refine_stats.  Synchronises the stream (FSC to the host, the gridding
+ * loop's stop rule). */
 int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream);
-int thx_refine_get_map(thx_refine* h, int half, float* dstRL, void* stream);       /* DEVICE [N]^3, the MAP-on map */
+/* capture (copied; NULL = off): where the following iterations leave their per-phase trace */
+int thx_refine_set_capture(thx_refine* h, const thx_refine_capture* capture);
+/* DEVICE [N]^3: the reference of `half` as Model::refreshProj consumed it (MAP-on map, averaged / flattened) */
+int thx_refine_get_map(thx_refine* h, int half, float* dstRL, void* stream);
 /* DEVICE copies of the per-particle state (any pointer may be NULL): offset [nImg][2], topR [nImg][4], topT [nImg][2],
  * sig [local halves][nGroup][N/2-1] */
 int thx_refine_get_state(thx_refine* h, double* offset, double* topR, double* topT, float* sig, void* stream);

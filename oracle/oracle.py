@@ -319,13 +319,18 @@ def set_projectee(ref_rl, pf=2):
 
 
 def reconstruct(F, T, P, N, pf, maxRadius, FSC=None, joinHalf=False, MAP=True, gridCorr=True, a=1.9, alpha=15.0,
-                return_iters=False, max_rounds=30):
+                return_iters=False, max_rounds=30, T_inplace=False):
     """Reconstructor::reconstruct(Volume&) src/Reconstructor.cpp:1129-1831, MODE_3D, _size == _N.
     F complex64 [P][P][P/2+1], T float32 same grid (both AFTER prepareTF); returns float32 [N][N][N]
-    (wrapped-index layout)."""
+    (wrapped-index layout).  The reference changes _T3D in place (Wiener term :1242-1270, 1e-25 floor :1322-1324), so a
+    second reconstruct() of the same iteration starts from the first one's T: T_inplace=True does the same to the caller's
+    array (float32, contiguous); the default works on a copy."""
     L = lib()
     F = c64(F).copy()
-    T = f32(T).copy()
+    if T_inplace:
+        assert T.dtype == np.float32 and T.flags.c_contiguous
+    else:
+        T = f32(T).copy()
     n = T.size
     if MAP:
         FSC = f32(FSC)
@@ -570,3 +575,279 @@ def init_images(rl, r, ew=6.0):
     ori *= scale
     return (sfft.rfft2(msk).astype(np.complex64), sfft.rfft2(ori).astype(np.complex64),
             dict(mean=float(mean), stdN=float(stdN), stdD=float(stdD), stdS=float(stdS), stdStdN=float(stdStdN)))
+
+
+# ---------------------------------------------------------------------------------------------
+# The particle filter of the local search (src/Particle.cpp) with its random draws as inputs
+def _dp(a):
+    return a.ctypes.data_as(c_d)
+
+
+def pf_perturb(q, t, k, s, pfR, pfT, transS, transQ, gR, gT):
+    """Particle::perturb(pf, PAR_R) + perturb(pf, PAR_T) of one image (src/Optimiser.cpp:1186-1208, src/Particle.cpp:
+    1149-1272): q [nR][4], t [nT][2] support points, k (k1, k2, k3), s (s0, s1) of the last calVari; gR [nR][4], gT [nT][4]
+    standard normals (the draws).  Returns new q, t and the balanced priors wR, wT (balanceWeight + normW)."""
+    q, t, gR, gT = f64(q).copy(), f64(t).copy(), f64(gR), f64(gT)
+    nR, nT = len(q), len(t)
+    L = lib()
+    L.orc_perturb_R(_dp(q), C.c_int(nR), _dp(f64(k)), C.c_double(pfR), _dp(gR))
+    wR = np.zeros(nR)
+    L.orc_balance_weight_R(_dp(wR), _dp(q), C.c_int(nR))
+    L.orc_perturb_T(_dp(t), C.c_int(nT), C.c_double(s[0]), C.c_double(s[1]), C.c_double(pfT), C.c_double(transS),
+                    C.c_double(transQ), _dp(gT))
+    wT = np.zeros(nT)
+    L.orc_balance_weight_T(_dp(wT), _dp(t), C.c_int(nT))
+    return q, t, wR, wT
+
+
+def pf_resample(val, w, u, rank, u0):
+    """Particle::resample(n, pt) for one parameter (src/Particle.cpp:1291-1430, PARTICLE_PRIOR_ONE): shuffle (rank[i] = new
+    position of element i, the draw), _topX = element of the largest u, w *= u, systematic resampling with the draw u0 in
+    [0, 1 / n).  Returns (values [n], weights [n], source index of every output in the UNSHUFFLED order, index of the top)."""
+    n = len(w)
+    inv = np.empty(n, np.int64)
+    inv[np.asarray(rank)] = np.arange(n)          # shuffled[j] = original[inv[j]]
+    ws, us = np.ascontiguousarray(f64(w)[inv]), np.ascontiguousarray(f64(u)[inv])
+    top = int(inv[int(np.argmax(us))])            # d_value_max_index on the shuffled list: first maximum
+    idx = np.zeros(n, np.int32)
+    wo = np.zeros(n)
+    lib().orc_resample(_p(idx, c_i), _dp(wo), _dp(ws), _dp(us), C.c_int(n), C.c_int(n), C.c_double(float(u0)))
+    src = inv[idx]
+    return val[src].copy(), wo, src, top
+
+
+def pf_update(q, t, wR, wT, uR, uT, peakFactorR, rankR, u0R, rankT, u0T):
+    """The filter bookkeeping after the likelihoods of a phase, src/Optimiser.cpp:1408-1475: setUR, keepHalfHeightPeak(PAR_R)
+    (OPTIMISER_PEAK_FACTOR_R; _T off), setUT, calRank1st, calVari(PAR_R / PAR_T), resample(mLR, PAR_R), resample(mLT, PAR_T).
+    uR / uT are the E-step weights (RFLOAT).  Returns dict(q, t, wR, wT, k, s, topR, topT, srcR, srcT)."""
+    L = lib()
+    q, t = f64(q).copy(), f64(t).copy()
+    nR, nT = len(q), len(t)
+    u = f64(np.asarray(uR, np.float32).astype(np.float64)).copy()
+    L.orc_keep_half_height_peak(_dp(u), C.c_int(nR), C.c_double(peakFactorR))
+    ut = f64(np.asarray(uT, np.float32).astype(np.float64)).copy()
+    k, mean, s = np.zeros(3), np.zeros(4), np.zeros(2)
+    L.orc_cal_vari_R(_dp(k), _dp(mean), _dp(q), C.c_int(nR))      # rotates q to the mean frame and back, in place
+    L.orc_cal_vari_T(_dp(s), _dp(t), C.c_int(nT))
+    q2, wR2, srcR, topR = pf_resample(q, wR, u, rankR, u0R)
+    t2, wT2, srcT, topT = pf_resample(t, wT, ut, rankT, u0T)
+    return dict(q=q2, t=t2, wR=wR2, wT=wT2, k=k, s=s, topR=q[topR].copy(), topT=t[topT].copy(), srcR=srcR, srcT=srcT,
+                iTopR=topR, iTopT=topT, qPre=q, uRk=u, uTk=ut)
+
+
+def cal_vari(q, t):
+    """Particle::calVari(PAR_R) + (PAR_T) -> (k [3], s [2]) (q is rotated to the mean frame and back: a copy here)"""
+    q = f64(q).copy()
+    k, mean, s = np.zeros(3), np.zeros(4), np.zeros(2)
+    lib().orc_cal_vari_R(_dp(k), _dp(mean), _dp(q), C.c_int(len(q)))
+    lib().orc_cal_vari_T(_dp(s), _dp(f64(t)), C.c_int(len(t)))
+    return k, s
+
+
+def soft_mask_volume(vol, r, ew, bg=0.0):
+    """softMask(Volume& dst, const Volume& src, r, ew, bg) src/Functions/Mask.cpp:499-521 (returns a new array)"""
+    out = f32(vol).copy()
+    lib().orc_soft_mask_volume(_p(out, c_f), C.c_int(out.shape[0]), C.c_float(r), C.c_float(ew), C.c_float(bg))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+class Iteration:
+    """One EM iteration of the local search, chained exactly as the reference runs it (MODE_3D, k = 1, C1, no CTF search):
+
+      Optimiser::expectation   src/Optimiser.cpp:1141-1660   allocPreCal rows, then per image and phase: perturb -> slices x
+                                                             ramps -> logDataVSPrior -> weights -> setU / keepHalfHeightPeak /
+                                                             calRank1st / calVari / resample
+      Optimiser::maximization  :3405-3530                    allReduceSigma (:6395-6710), reconstructRef (:6711-7766): mReco
+                                                             Particle::rand draws -> translate -> insertP; prepareTF; reconstruct
+                                                             (MAP off) -> compareTwoHemispheres(fsc) -> reconstruct (MAP on,
+                                                             joinHalf, the FSC Model::resetReco set at the END OF THE PREVIOUS
+                                                             iteration) -> compareTwoHemispheres(avg)
+      Optimiser::run           :3800-4073                    reCentreImg, reMaskImg, solventFlatten, Model::refreshProj,
+                                                             Model::resetReco
+
+    Random draws are inputs: `ph` offers draw_n4 / draw_u4 / shuffle_ranks(seed, image, call, purpose, index) (tests hand in
+    their numpy replica of the device's Philox streams, tests/_philox.py; the numbering of `call` / `image` follows the
+    launches of thx_refine_iterate: two calls per batch and phase, one per half for the insertion draws).
+    normCorrection (OPTIMISER_NORM_CORRECTION) is outside the scope of this repo and not chained.
+
+    cfg: dict(N, pf, nHalfA, mLR, mLT, nPhase, mReco, batch, rL, nGroup, groupSig, pixelSize, maskRadiusPx, sigma2Init,
+    transS, transQ, pfL, pfS, peakFactorR, seed, coreFSC, goldenAverage, solventFlatten).
+    `resolve` (optional): callback(phase, image, own) -> own, lets a test adopt the device's choice where a discrete decision
+    (resampled indices, top support point) hinges on rounding -- after checking its tie rule."""
+
+    def __init__(self, cfg, imgOri, attr, gid, quat0, tran0, ref, ph):
+        self.c = dict(cfg)
+        c = self.c
+        self.ph = ph
+        N, pf = c["N"], c["pf"]
+        self.N, self.pf, self.P = N, pf, N * pf
+        self.rU, self.rSig = N // 2 - 2, N // 2 - 1
+        self.imgOri = c64(imgOri)
+        self.n = self.imgOri.shape[0]
+        self.attr = f32(attr).reshape(self.n, 7)
+        self.gid = i32(gid)
+        self.q0, self.t0 = f64(quat0), f64(tran0)
+        self.ref = f32(ref)
+        self.pl = pixel_list(N, self.rU, c["rL"], pf)          # expectation: allocPreCalIdx(_r, _rL), :631
+        self.plM = pixel_list(N, self.rU, 0, pf)               # reconstruction: allocPreCalIdx(rU, 0), :6722
+        nA = c["nHalfA"]
+        self.ranges = [(0, nA), (nA, self.n)]
+        nmax = max(hi - lo for lo, hi in self.ranges)
+        nb = max(1, -(-nmax // c["batch"]))
+        self.batch = min(65535, max(1, -(-nmax // nb)))        # thx_refine_create's balanced batches
+        self.mask2d = soft_mask(N, np.float32(c["maskRadiusPx"]), 6.0)
+        self.ctfM = np.stack([ctf(c["pixelSize"], *self.attr[l], N, self.plM["iCol"], self.plM["iRow"]) for l in range(self.n)])
+        self.ctfP = np.stack([ctf(c["pixelSize"], *self.attr[l], N, self.pl["iCol"], self.pl["iRow"]) for l in range(self.n)])
+        self.datM = np.ascontiguousarray(self.imgOri.reshape(self.n, -1)[:, self.plM["iPxl"]])
+        self.reset()
+
+    # -- helpers ------------------------------------------------------------------------------
+    def _remask(self, imgs):
+        out = np.empty_like(imgs)
+        N = self.N
+        for l in range(imgs.shape[0]):
+            rl = np.ascontiguousarray(sfft.irfft2(imgs[l], s=(N, N), norm="forward").astype(np.float32))
+            lib().orc_scale_mul_rl(_p(rl, c_f), _p(self.mask2d, c_f), C.c_size_t(rl.size))
+            out[l] = sfft.rfft2(rl).astype(np.complex64)
+        return out
+
+    def reset(self):
+        """the state before the first iteration (thx_refine_reset): Optimiser::initImg has masked the images, flat noise
+        model, support points as loaded, weights uniform, Particle::load -> calVari"""
+        c = self.c
+        self.vols = [set_projectee(self.ref, self.pf) for _ in range(2)]
+        self.offset = np.zeros((self.n, 2))
+        self.img = self._remask(self.imgOri)
+        self.sig = np.full((2, c["nGroup"], self.rSig), np.float32(c["sigma2Init"]), np.float32)
+        self.sigRcp = np.full((2, c["nGroup"], self.rSig), np.float32(-0.5) / np.float32(c["sigma2Init"]), np.float32)
+        self.q, self.t = self.q0.copy(), self.t0.copy()
+        self.k = np.zeros((self.n, 3))
+        self.s = np.zeros((self.n, 2))
+        for l in range(self.n):
+            self.k[l], self.s[l] = cal_vari(self.q[l], self.t[l])
+        self.topR, self.topT = self.q[:, 0].copy(), self.t[:, 0].copy()
+        self.pfCall = 0
+        self.iterCount = 0
+        self.fscReco = np.ones(self.rU, np.float32)            # Model::initProjReco, src/Model.cpp:1086
+
+    # -- one iteration --------------------------------------------------------------------------
+    def iterate(self, resolve=None):
+        c, ph, N, P, pf = self.c, self.ph, self.N, self.P, self.pf
+        pl, plM = self.pl, self.plM
+        seed, mLR, mLT = c["seed"], c["mLR"], c["mLT"]
+        out = dict(uR=np.zeros((c["nPhase"], self.n, mLR), np.float32), uT=np.zeros((c["nPhase"], self.n, mLT), np.float32),
+                   srcR=np.zeros((c["nPhase"], self.n, mLR), np.int64), srcT=np.zeros((c["nPhase"], self.n, mLT), np.int64),
+                   k=np.zeros((c["nPhase"], self.n, 3)), s=np.zeros((c["nPhase"], self.n, 2)))
+        F = [np.zeros((P, P, P // 2 + 1), np.complex64) for _ in range(2)]
+        T = [np.zeros((P, P, P // 2 + 1), np.float32) for _ in range(2)]
+        w = np.float32(np.float32(1.0) / np.float32(c["mReco"]))
+        for vi, (lo, hi) in enumerate(self.ranges):
+            # allocPreCal(mask = true, pixelMajor = false, ctf = false), :8043-8171
+            datP = np.ascontiguousarray(self.img[lo:hi].reshape(hi - lo, -1)[:, pl["iPxl"]])
+            sigRcpP = np.ascontiguousarray(self.sigRcp[vi][self.gid[lo:hi] - 1][:, pl["iSig"]])
+            # HOT LOOP B.  The driver runs it batch by batch: all images of a batch do phase p before any does p + 1;
+            # images are independent, so only the Philox numbering (call per batch, image index within the batch) matters.
+            for p in range(c["nPhase"]):
+                for b0 in range(lo, hi, self.batch):
+                    b1 = min(hi, b0 + self.batch)
+                    self.pfCall += 1
+                    callP = self.pfCall
+                    self.pfCall += 1
+                    callU = self.pfCall
+                    f = c["pfL"] if p == 0 else c["pfS"]
+                    for l in range(b0, b1):
+                        li = l - b0
+                        gR = np.stack(ph.draw_n4(seed, li, callP, 0, np.arange(mLR)), axis=1)
+                        gT = np.stack(ph.draw_n4(seed, li, callP, 1, np.arange(mLT)), axis=1)
+                        q, t, wR, wT = pf_perturb(self.q[l], self.t[l], self.k[l], self.s[l], f, f, c["transS"], c["transQ"], gR, gT)
+                        rot = np.stack([rotate3D(x) for x in q])
+                        e = expect_local(self.vols[vi], P, pf, N, pl["iCol"], pl["iRow"], datP[l - lo], self.ctfP[l],
+                                         sigRcpP[l - lo], rot, t, nD=1, pC=1.0, pR=wR, pT=wT)
+                        own = pf_update(q, t, wR, wT, e["wR"], e["wT"], c["peakFactorR"],
+                                        ph.shuffle_ranks(seed, li, callU, 2, mLR), ph.draw_u4(seed, li, callU, 3, 0)[0] / mLR,
+                                        ph.shuffle_ranks(seed, li, callU, 4, mLT), ph.draw_u4(seed, li, callU, 5, 0)[0] / mLT)
+                        own.update(uR=e["wR"], uT=e["wT"], tPre=t, qIn=q, wRIn=wR, wTIn=wT, li=li, callU=callU,
+                                   scaleL=float(np.abs(e["logW"]).max()))
+                        if resolve is not None:
+                            own = resolve(p, l, own)
+                        self.q[l], self.t[l], self.k[l], self.s[l] = own["q"], own["t"], own["k"], own["s"]
+                        self.topR[l], self.topT[l] = own["topR"], own["topT"]
+                        out["uR"][p, l], out["uT"][p, l] = e["wR"], e["wT"]
+                        out["srcR"][p, l], out["srcT"][p, l] = own["srcR"], own["srcT"]
+                        out["k"][p, l], out["s"][p, l] = own["k"], own["s"]
+            # allReduceSigma (OPTIMISER_SIGMA_RANK1ST, OPTIMISER_SIGMA_WHOLE_FREQUENCY), :6395-6710
+            spec = np.stack([sigma_image(self.vols[vi], P, pf, N, self.rU, self.rSig, rotate3D(self.topR[l]), self.topT[l],
+                                         self.offset[l], c["pixelSize"], self.attr[l], self.img[l], self.imgOri[l])
+                             for l in range(lo, hi)])
+            acc = sigma_accum(spec, self.gid[lo:hi], c["nGroup"], bool(c["groupSig"]))
+            sig, rcp = sigma_final(*acc, np.float32(c["maskRadiusPx"]) * np.float32(c["pixelSize"]), N, c["pixelSize"],
+                                   bool(c["groupSig"]))
+            # HOT LOOP C, :7038-7241: Particle::rand = uniform picks among the (resampled) support points
+            self.pfCall += 1
+            for l in range(lo, hi):
+                u = ph.draw_u4(seed, l, self.pfCall, 7, np.arange(c["mReco"]))
+                iR = np.minimum((u[0] * mLR).astype(np.int64), mLR - 1)
+                iT = np.minimum((u[1] * mLT).astype(np.int64), mLT - 1)
+                for m in range(c["mReco"]):
+                    tt = self.t[l, iT[m]] - self.offset[l]
+                    src = translate(np.float32(-tt[0]), np.float32(-tt[1]), N, plM["iCol"], plM["iRow"], src=self.datM[l])
+                    insertP(F[vi], T[vi], P, src, self.ctfM[l], rotate3D(self.q[l, iR[m]]), w, plM["iColPad"], plM["iRowPad"])
+            self.sig[vi], self.sigRcp[vi] = sig, rcp
+        out["F_raw"], out["T_raw"] = [x.copy() for x in F], [x.copy() for x in T]
+        # prepareTF (one rank per half: the all-reduce is the identity; C1: no symmetrisation), :7268 -> Reconstructor.cpp:1056-1091
+        maps, rounds = [], []
+        for vi in range(2):
+            normalise_TF(F[vi], T[vi], P)
+            m, it, diffs, _ = reconstruct(F[vi], T[vi], P, N, pf, self.rU, MAP=False, joinHalf=True, gridCorr=True, return_iters=True,
+                                          T_inplace=True)
+            maps.append(m)
+            rounds.append(it)
+        out["F"], out["T"] = F, T
+        out["mapsFsc"] = maps
+        # compareTwoHemispheres(true, false), :7547: Model::_FSC of THIS iteration
+        A, B = sfft.rfftn(maps[0]).astype(np.complex64), sfft.rfftn(maps[1]).astype(np.complex64)
+        coreR = float(int(np.rint(np.float32(c["maskRadiusPx"])))) if c["coreFSC"] else 0.0
+        phA = phB = None
+        if c["coreFSC"]:
+            ne = N * N * (N // 2 + 1)
+            call = 0x40000000 + 2 * self.iterCount
+            e = np.arange(ne, dtype=np.uint64)
+            lo32, hi32 = (e & np.uint64(0xFFFFFFFF)).astype(np.uint32), (e >> np.uint64(32)).astype(np.uint32)
+            pi = 3.14159265358979323846   # TSGSL_ran_flat(engine, 0, 2 * M_PI) narrowed to RFLOAT; device: (float)(u * 2 * pi)
+            phA = (ph.draw_u4(seed, lo32, call, 9, hi32)[0] * 2 * pi).astype(np.float32)
+            phB = (ph.draw_u4(seed, lo32, call + 1, 9, hi32)[0] * 2 * pi).astype(np.float32)
+        cmpd = compare_hemispheres(A, B, N, self.rU, phA, phB, coreR=coreR, ew=6.0)
+        fsc_ = cmpd["fsc"]
+        # reconstruct with MAP on: Reconstructor::_FSC is what resetReco set at the end of the previous iteration
+        mapsX = []
+        for vi in range(2):
+            m, it, diffs, _ = reconstruct(F[vi], T[vi], P, N, pf, self.rU, FSC=self.fscReco, joinHalf=True, MAP=True, gridCorr=True,
+                                          return_iters=True, T_inplace=True)
+            mapsX.append(m)
+            rounds.append(it)
+        out["mapsMAP"] = [m.copy() for m in mapsX]
+        if c["goldenAverage"]:   # compareTwoHemispheres(false, true), :7747 (k == 1, _goldenStandard)
+            resP = np.float32(np.float32(1.0 / 20.0) * np.float32(N) * np.float32(c["pixelSize"]))
+            avgR = min(int(np.rint(np.float64(resP))), self.rU)
+            A, B = sfft.rfftn(mapsX[0]).astype(np.complex64), sfft.rfftn(mapsX[1]).astype(np.complex64)
+            cm = compare_hemispheres(A, B, N, self.rU, avg_r=avgR)
+            mapsX = [np.ascontiguousarray(sfft.irfftn(x, s=(N, N, N)).astype(np.float32)) for x in (cm["A"], cm["B"])]
+            out["avgR"] = avgR
+        for vi in range(2):
+            if c["solventFlatten"]:   # Optimiser::solventFlatten(false), :7958-7975
+                mapsX[vi] = soft_mask_volume(mapsX[vi], np.float32(c["maskRadiusPx"]), 6.0, 0.0)
+            self.vols[vi] = set_projectee(mapsX[vi], pf)           # Model::refreshProj
+        self.fscReco = fsc_.astype(np.float32).copy()             # Model::resetReco, src/Model.cpp:1122
+        # reCentreImg + reMaskImg, :6065-6149
+        for l in range(self.n):
+            tr = self.topT[l].copy()
+            self.offset[l] -= tr
+            self.t[l] -= tr
+            self.topT[l] -= tr
+            self.img[l] = translate_image(self.imgOri[l], self.offset[l, 0], self.offset[l, 1])
+        self.img = self._remask(self.img)
+        self.iterCount += 1
+        out.update(fsc=fsc_, maps=mapsX, rounds=rounds, sig=self.sig.copy(), offset=self.offset.copy(), topR=self.topR.copy(),
+                   q=self.q.copy(), t=self.t.copy(), vols=[v for v in self.vols], img=self.img)
+        return out

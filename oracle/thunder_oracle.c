@@ -1334,17 +1334,66 @@ static void qmul_(double* d, const double* a, const double* b)
 }
 
 /* Particle::calVari(PAR_R), MODE_3D with PARTICLE_ROT_MEAN_USING_STAT_CAL_VARI, src/Particle.cpp:1020-1080:
- * k[3] = (k1, k2, k3); q [n][4] is rotated to the mean frame and back (in place, as the reference does) */
+ * mean = inferACG(mean, _r); every quaternion is LEFT-multiplied by conj(mean) (quaternion_mul(quat, quaternion_conj(mean),
+ * quat), :1052-1058; quaternion_mul(dst, a, b) is the Hamilton product a * b, src/Geometry/Euler.cpp:13-26), k1..k3 =
+ * inferACG(k1, k2, k3, _r), then left-multiplied by mean again (:1066-1074).  k[3] = (k1, k2, k3); q [n][4] is rotated to
+ * the mean frame and back in place, as the reference does.  (The random anchor of :1039-1043 only feeds symmetrise(),
+ * which returns at once for C1.) */
 void orc_cal_vari_R(double* k, double* mean, double* q, int n)
 {
     double A[16], cm[4];
     orc_infer_acg(A, q, n);
     orc_sym4_top_eigvec(mean, A);
     cm[0] = mean[0]; cm[1] = -mean[1]; cm[2] = -mean[2]; cm[3] = -mean[3];
-    for (int i = 0; i < n; i++) { double t[4]; qmul_(t, q + 4 * i, cm); memcpy(q + 4 * i, t, sizeof(t)); }
+    for (int i = 0; i < n; i++) { double t[4]; qmul_(t, cm, q + 4 * i); memcpy(q + 4 * i, t, sizeof(t)); }
     orc_infer_acg(A, q, n);
     k[0] = A[5] / A[0]; k[1] = A[10] / A[0]; k[2] = A[15] / A[0];
-    for (int i = 0; i < n; i++) { double t[4]; qmul_(t, q + 4 * i, mean); memcpy(q + 4 * i, t, sizeof(t)); }
+    for (int i = 0; i < n; i++) { double t[4]; qmul_(t, mean, q + 4 * i); memcpy(q + 4 * i, t, sizeof(t)); }
+}
+
+/* Particle::perturb(pf, PAR_R), MODE_3D, src/Particle.cpp:1185-1243 (PARTICLE_ROTATION_KAPPA off,
+ * PARTICLE_ROT_MEAN_USING_STAT_PERTURB on), WITHOUT the closing balanceWeight (orc_balance_weight_R):
+ *   d = sampleACG(pf^2 min(PERTURB_K_MAX = 1, k1), ..k2, ..k3, nR) (src/Geometry/DirectionalStat.cpp:40-88: L = chol(diag(1,
+ *   k1', k2', k3')) = the square roots of the diagonal, v = L g, v /= |v|; g [n][4] are the standard normals, an input here);
+ *   mean = inferACG(mean, _r);  quat = conj(mean) * quat;  quat = d_i * quat;  quat = mean * quat   (three passes). */
+void orc_perturb_R(double* q, int n, const double* k, double pf, const double* g)
+{
+    double A[16], mean[4], cm[4];
+    const double pf2 = pf * pf;   /* gsl_pow_2(pf) */
+    const double l1 = sqrt(pf2 * (k[0] < 1.0 ? k[0] : 1.0)), l2 = sqrt(pf2 * (k[1] < 1.0 ? k[1] : 1.0)),
+                 l3 = sqrt(pf2 * (k[2] < 1.0 ? k[2] : 1.0));
+    orc_infer_acg(A, q, n);
+    orc_sym4_top_eigvec(mean, A);
+    cm[0] = mean[0]; cm[1] = -mean[1]; cm[2] = -mean[2]; cm[3] = -mean[3];
+    for (int i = 0; i < n; i++) { double t[4]; qmul_(t, cm, q + 4 * i); memcpy(q + 4 * i, t, sizeof(t)); }
+    for (int i = 0; i < n; i++) {
+        double v[4] = {g[4 * i], l1 * g[4 * i + 1], l2 * g[4 * i + 2], l3 * g[4 * i + 3]}, t[4];
+        double nrm = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+        for (int c = 0; c < 4; c++) v[c] /= nrm;
+        qmul_(t, v, q + 4 * i);
+        memcpy(q + 4 * i, t, sizeof(t));
+    }
+    for (int i = 0; i < n; i++) { double t[4]; qmul_(t, mean, q + 4 * i); memcpy(q + 4 * i, t, sizeof(t)); }
+}
+
+/* Particle::perturb(pf, PAR_T), src/Particle.cpp:1244-1272, + reCentre (PARTICLE_RECENTRE_TRANSQ), :2473-2495, WITHOUT
+ * the closing balanceWeight.  gsl_ran_bivariate_gaussian(engine, s0, s1, rho = 0, &x, &y) (PARTICLE_RHO off: _rho = 0)
+ * returns (s0 n0, s1 n1) for two independent standard normals (randist/bigauss.c); g [n][4] = n0, n1 and the two normals
+ * of the re-draw.  transM = transS * gsl_cdf_chisq_Qinv(transQ, 2) = transS * (-2 ln transQ) (chi-square, 2 dof:
+ * Q(x) = exp(-x / 2)). */
+void orc_perturb_T(double* t, int n, double s0, double s1, double pf, double transS, double transQ, const double* g)
+{
+    const double transM = transS * (-2.0 * log(transQ));
+    for (int i = 0; i < n; i++) {
+        double x = s0 * g[4 * i], y = s1 * g[4 * i + 1];
+        t[2 * i] += x * pf;
+        t[2 * i + 1] += y * pf;
+    }
+    for (int i = 0; i < n; i++)
+        if (gsl_hypot_(t[2 * i], t[2 * i + 1]) > transM) {
+            t[2 * i] = transS * g[4 * i + 2];
+            t[2 * i + 1] = transS * g[4 * i + 3];
+        }
 }
 
 /* gsl_stats_mean / gsl_stats_sd_m on doubles (statistics/mean_source.c, variance_source.c) */
@@ -1441,6 +1490,23 @@ void orc_core_mask(RFLOAT* mask, int N, RFLOAT r, RFLOAT ew)
                 else if (u >= r) v = (RFLOAT)(0.5 + 0.5 * cos((u - r) / ew * M_PI));
                 else v = 1;
                 mask[((size_t)(k < 0 ? k + N : k) * N + (j < 0 ? j + N : j)) * N + (i < 0 ? i + N : i)] = v;
+            }
+}
+
+/* softMask(Volume& dst, const Volume& src, r, ew, bg), src/Functions/Mask.cpp:499-521, in place (the spherical mask of
+ * Optimiser::solventFlatten, src/Optimiser.cpp:7958-7975, OPTIMISER_SOLVENT_FLATTEN_MASK_ZERO: bg = 0) */
+void orc_soft_mask_volume(RFLOAT* vol, int N, RFLOAT r, RFLOAT ew, RFLOAT bg)
+{
+    for (long k = -N / 2; k < N / 2; k++)
+        for (long j = -N / 2; j < N / 2; j++)
+            for (long i = -N / 2; i < N / 2; i++) {
+                size_t e = ((size_t)(k < 0 ? k + N : k) * N + (j < 0 ? j + N : j)) * N + (i < 0 ? i + N : i);
+                RFLOAT u = (RFLOAT)gsl_hypot3_((double)i, (double)j, (double)k);
+                if (u > r + ew) vol[e] = bg;
+                else if (u >= r) {
+                    RFLOAT w = (RFLOAT)(0.5 - 0.5 * cos((u - r) / ew * M_PI));
+                    vol[e] = bg * w + vol[e] * (1 - w);
+                }
             }
 }
 

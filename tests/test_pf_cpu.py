@@ -64,7 +64,8 @@ def test_cal_vari_and_weights(oracle):
     d = rng.standard_normal((n, 4)) * np.array([1, 0.05, 0.03, 0.01])
     d[:, 0] = 1
     d /= np.linalg.norm(d, axis=1, keepdims=True)
-    q = np.ascontiguousarray(synth.quat_mul(d, mean[None, :]))
+    # calVari looks at conj(mean) * r (LEFT multiplication, src/Particle.cpp:1052-1058): a cloud mean * d shows d's axes
+    q = np.ascontiguousarray(synth.quat_mul(np.broadcast_to(mean, d.shape), d))
     q0 = q.copy()
     k, m = np.zeros(3), np.zeros(4)
     O.lib().orc_cal_vari_R(_dp(k), _dp(m), _dp(q), n)

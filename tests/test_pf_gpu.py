@@ -95,32 +95,23 @@ def test_perturb(oracle, dev):
     capi.call("thx_pf_perturb_dev", dq.data_ptr(), dt.data_ptr(), dwR.data_ptr(), dwT.data_ptr(), dk.data_ptr(),
               ds.data_ptr(), nImg, nR, nT, pfR, pfT, transS, transQ, seed, call, None, capi.stream_ptr())
     gq, gt, gwR, gwT = [x.cpu().numpy() for x in (dq, dt, dwR, dwT)]
-    img = np.arange(nImg)[:, None]
-    g = PH.draw_n4(seed, img, call, 0, np.arange(nR)[None, :])
-    L = np.sqrt(pfR ** 2 * np.minimum(1.0, k))            # [nImg][3]
-    v = np.stack([g[0], L[:, 0:1] * g[1], L[:, 1:2] * g[2], L[:, 2:3] * g[3]], axis=2)
-    v /= np.linalg.norm(v, axis=2, keepdims=True)
-    want_q = synth.quat_mul(v, q)                         # pert * r
-    assert np.abs(gq - want_q).max() <= 1e-12 and np.abs(np.linalg.norm(gq, axis=2) - 1).max() < 1e-12
-    g = PH.draw_n4(seed, img, call, 1, np.arange(nT)[None, :])
-    want_t = t + np.stack([s[:, 0:1] * g[0], s[:, 1:2] * g[1]], axis=2) * pfT
-    transM = transS * (-2.0 * np.log(transQ))
-    far = np.hypot(want_t[..., 0], want_t[..., 1]) > transM
-    want_t[far] = np.stack([transS * g[2], transS * g[3]], axis=2)[far]
-    assert np.abs(gt - want_t).max() <= 1e-12
     for l in range(nImg):
-        ww = np.zeros(nR)
-        O.lib().orc_balance_weight_R(_dp(ww), _dp(np.ascontiguousarray(gq[l])), nR)
-        assert np.allclose(gwR[l], ww, rtol=5e-2) and abs(gwR[l].sum() - 1) < 1e-12
-        wt = np.zeros(nT)
-        O.lib().orc_balance_weight_T(_dp(wt), _dp(np.ascontiguousarray(gt[l])), nT)
-        assert np.allclose(gwT[l], wt, rtol=1e-9)
-    # the angular size of the perturbation follows pf * sqrt(min(1, k)): the vector part is L g_c / |g_0| (a scaled Cauchy
-    # ratio for small L), whose median magnitude is L
-    rel = synth.quat_mul(gq, q * np.array([1, -1, -1, -1.0]))
-    for c in range(3):
-        got = np.median(np.abs(rel[1:, :, c + 1]), axis=1)
-        assert np.allclose(got, pfR * np.sqrt(k[1:, c]), rtol=0.4)
+        # Particle::perturb in the reference's own order: mean = inferACG(mean, r); r <- mean * (pert * (conj(mean) * r))
+        # (src/Particle.cpp:1185-1243), shifts + reCentre (:1244-1272, 2473-2495), then balanceWeight for both
+        gR = np.stack(PH.draw_n4(seed, l, call, 0, np.arange(nR)), axis=1)
+        gT = np.stack(PH.draw_n4(seed, l, call, 1, np.arange(nT)), axis=1)
+        wq, wt, wwR, wwT = O.pf_perturb(q[l], t[l], k[l], s[l], pfR, pfT, transS, transQ, gR, gT)
+        assert np.abs(gq[l] - wq).max() <= 1e-12 and np.abs(np.linalg.norm(gq[l], axis=1) - 1).max() < 1e-12
+        assert np.abs(gt[l] - wt).max() <= 1e-12
+        assert np.allclose(gwR[l], wwR, rtol=1e-7) and abs(gwR[l].sum() - 1) < 1e-12
+        assert np.allclose(gwT[l], wwT, rtol=1e-9)
+        # the perturbation is NOT pert * r: it acts in the frame of the cloud's mean (conjugated by it)
+        v = np.stack([gR[:, 0], gR[:, 1] * np.sqrt(pfR ** 2 * min(1.0, k[l, 0])), gR[:, 2] * np.sqrt(pfR ** 2 * min(1.0, k[l, 1])),
+                      gR[:, 3] * np.sqrt(pfR ** 2 * min(1.0, k[l, 2]))], axis=1)
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        assert np.abs(synth.quat_mul(v, q[l]) - wq).max() > 1e-6
+    transM = transS * (-2.0 * np.log(transQ))
+    assert np.all(np.hypot(gt[..., 0], gt[..., 1]) <= max(transM, 6 * transS))
 
 
 def test_update_resample(oracle, dev):

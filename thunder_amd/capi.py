@@ -30,7 +30,13 @@ class RefineConfig(C.Structure):
                 ("rL", C.c_int), ("nGroup", C.c_int), ("groupSig", C.c_int), ("pixelOrder", C.c_int), ("wgPerCU", C.c_int),
                 ("pixelSize", C.c_float), ("maskRadiusPx", C.c_float), ("sigma2Init", C.c_float),
                 ("transS", C.c_double), ("transQ", C.c_double), ("pfL", C.c_double), ("pfS", C.c_double),
-                ("peakFactorR", C.c_double), ("seed", C.c_ulonglong)]
+                ("peakFactorR", C.c_double), ("seed", C.c_ulonglong),
+                ("coreFSC", C.c_int), ("goldenAverage", C.c_int), ("solventFlatten", C.c_int)]
+
+
+class RefineCapture(C.Structure):
+    """thx_refine_capture (include/thunder_amd.h): device pointers as integers"""
+    _fields_ = [(n, C.c_void_p) for n in ("uR", "uT", "r", "t", "k123", "s01", "mapsFsc")]
 
 
 class RefineStats(C.Structure):
@@ -85,6 +91,7 @@ SIGNATURES = {
     "thx_compare_hemispheres_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp, _f, _f, _i, _i, C.c_ulonglong, C.c_uint, C.POINTER(_i),
                                          _vp]),
     "thx_core_mask_dev": (_i, [_vp, _i, _f, _f, _vp]),
+    "thx_soft_mask_volume_dev": (_i, [_vp, _i, _f, _f, _f, _vp]),
     "thx_random_phase_dev": (_i, [_vp, _vp, _i, _i, C.c_ulonglong, C.c_uint, _vp, _vp]),
     "thx_thu_write": (_i, [C.c_char_p, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "thx_thu_load_extra": (_i, [C.c_char_p, _i, _vp, _i, _vp, _vp, _vp]),
@@ -98,6 +105,7 @@ SIGNATURES = {
     "thx_refine_reset": (_i, [_vp, _vp]),
     "thx_refine_iterate": (_i, [_vp, _vp, _i, _vp]),
     "thx_refine_get_map": (_i, [_vp, _i, _vp, _vp]),
+    "thx_refine_set_capture": (_i, [_vp, _vp]),
     "thx_refine_get_state": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "thx_refine_get_stats": (_i, [_vp, C.POINTER(RefineStats), _i]),
     "thx_refine_get_view": (_i, [_vp, C.POINTER(RefineView)]),

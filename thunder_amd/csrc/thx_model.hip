@@ -25,6 +25,22 @@ __global__ __launch_bounds__(256) void k_core_mask(float* __restrict__ mask, int
     mask[e] = v;
 }
 
+// softMask(Volume& dst, const Volume& src, r, ew, bg), src/Functions/Mask.cpp:499-521, in place: beyond r + ew the
+// background, inside r untouched, in between bg * w + src * (1 - w) with w = 0.5 - 0.5 cos((u - r) / ew * pi) narrowed to RFLOAT
+__global__ __launch_bounds__(256) void k_soft_mask_volume(float* __restrict__ vol, int N, float r, float ew, float bg)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)N * N * N) return;
+    const int iw = (int)(e % N), jw = (int)((e / N) % N), kw = (int)(e / ((size_t)N * N));
+    const int i = iw >= N / 2 ? iw - N : iw, j = jw >= N / 2 ? jw - N : jw, k = kw >= N / 2 ? kw - N : kw;
+    const float u = (float)gsl_hypot3_((double)i, (double)j, (double)k);   // NORM_3 narrowed to RFLOAT
+    if (u > r + ew) vol[e] = bg;
+    else if (u >= r) {
+        const float w = (float)(0.5 - 0.5 * cos((u - r) / ew * 3.14159265358979323846));
+        vol[e] = bg * w + vol[e] * (1 - w);
+    }
+}
+
 // softMask(dst, src, alpha, bg): dst = bg * w + src * (1 - w), w = 1 - alpha  (src/Functions/Mask.cpp:510-521)
 __global__ __launch_bounds__(256) void k_alpha_mask(float* dst, const float* src, const float* __restrict__ alpha, float bg, size_t n)
 {
@@ -90,6 +106,14 @@ int thx_core_mask_dev(float* mask, int N, float r, float ew, void* stream)
 {
     THX_REQUIRE(mask && N > 0, "bad arguments");
     hipLaunchKernelGGL(k_core_mask, dim3(nblk((size_t)N * N * N)), dim3(256), 0, as_stream(stream), mask, N, r, ew);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_soft_mask_volume_dev(float* vol, int N, float r, float ew, float bg, void* stream)
+{
+    THX_REQUIRE(vol && N > 0 && ew > 0, "bad arguments");
+    hipLaunchKernelGGL(k_soft_mask_volume, dim3(nblk((size_t)N * N * N)), dim3(256), 0, as_stream(stream), vol, N, r, ew, bg);
     THX_LAUNCH_CHECK();
     return 0;
 }

@@ -272,6 +272,13 @@ __global__ __launch_bounds__(64) void k_pf_perturb(PfArgs a)
         // sampleACG(d, pf^2 min(1, k1), pf^2 min(1, k2), pf^2 min(1, k3), nR): L = chol(diag(1, ...)) = sqrt of the diagonal
         const double pf2 = a.pfR * a.pfR;
         const double l1 = sqrt(pf2 * fmin(1.0, k[0])), l2 = sqrt(pf2 * fmin(1.0, k[1])), l3 = sqrt(pf2 * fmin(1.0, k[2]));
+        // mean = inferACG(mean, _r) of the cloud BEFORE the perturbation (PARTICLE_ROT_MEAN_USING_STAT_PERTURB, :1203-1207)
+        for (int i = lane; i < nR * 4; i += 64) sq[i] = r[i];
+        __builtin_amdgcn_wave_barrier();
+        double A[16], mean[4], cm[4];
+        infer_acg(A, sq, nR, lane, nullptr);
+        sym4_top_eigvec(mean, A);
+        cm[0] = mean[0]; cm[1] = -mean[1]; cm[2] = -mean[2]; cm[3] = -mean[3];
         for (int i = lane; i < nR; i += 64) {
             double g[4];
             draw_n4(g, a.seed, img, a.call, 0, i);
@@ -279,9 +286,12 @@ __global__ __launch_bounds__(64) void k_pf_perturb(PfArgs a)
             const double nrm = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
 #pragma unroll
             for (int c = 0; c < 4; c++) v[c] /= nrm;
-            // ((r conj(mean)) -> pert * . -> . * mean) == pert * r: the mean frame cancels (:1196-1230)
-            double o[4];
-            qmul(o, v, r + 4 * i);
+            // quat = conj(mean) * quat; quat = pert * quat; quat = mean * quat (:1211-1239; quaternion_mul(dst, a, b) = a * b):
+            // the anisotropic perturbation acts in the frame calVari estimated k1..k3 in
+            double o[4], o2[4];
+            qmul(o, cm, sq + 4 * i);
+            qmul(o2, v, o);
+            qmul(o, mean, o2);
 #pragma unroll
             for (int c = 0; c < 4; c++) { r[4 * i + c] = o[c]; sq[4 * i + c] = o[c]; }
         }
@@ -341,14 +351,13 @@ __global__ __launch_bounds__(64) void k_pf_update(PfArgs a)
             const double hh = umax * a.peakFactorR;
             for (int i = lane; i < nR; i += 64) su[i] = (su[i] < hh) ? 0.0 : su[i] - hh;
         }
-        if (lane < 4) a.topR[4 * (size_t)img + lane] = sq[4 * imax + lane];  // calRank1st
         __builtin_amdgcn_wave_barrier();
-        // calVari(PAR_R), :1020-1080
+        // calVari(PAR_R), :1020-1080: LEFT multiplication by conj(mean), inferACG(k1, k2, k3), left multiplication by mean
         double A[16], mean[4], cm[4];
         infer_acg(A, sq, nR, lane, nullptr);
         sym4_top_eigvec(mean, A);
         cm[0] = mean[0]; cm[1] = -mean[1]; cm[2] = -mean[2]; cm[3] = -mean[3];
-        for (int i = lane; i < nR; i += 64) { double o[4]; qmul(o, sq + 4 * i, cm); for (int c = 0; c < 4; c++) sq[4 * i + c] = o[c]; }
+        for (int i = lane; i < nR; i += 64) { double o[4]; qmul(o, cm, sq + 4 * i); for (int c = 0; c < 4; c++) sq[4 * i + c] = o[c]; }
         __builtin_amdgcn_wave_barrier();
         infer_acg(A, sq, nR, lane, nullptr);
         if (lane == 0) {
@@ -356,7 +365,10 @@ __global__ __launch_bounds__(64) void k_pf_update(PfArgs a)
             a.k123[3 * (size_t)img + 1] = A[10] / A[0];
             a.k123[3 * (size_t)img + 2] = A[15] / A[0];
         }
-        for (int i = lane; i < nR; i += 64) { double o[4]; qmul(o, sq + 4 * i, mean); for (int c = 0; c < 4; c++) sq[4 * i + c] = o[c]; }
+        for (int i = lane; i < nR; i += 64) { double o[4]; qmul(o, mean, sq + 4 * i); for (int c = 0; c < 4; c++) sq[4 * i + c] = o[c]; }
+        __builtin_amdgcn_wave_barrier();
+        // calRank1st(PAR_R) (:990-1002), taken again by resample() after calVari's round trip (:1381-1383): _topR = _r.row(iMax)
+        if (lane < 4) a.topR[4 * (size_t)img + lane] = sq[4 * imax + lane];
         __builtin_amdgcn_wave_barrier();
         resample<4>(sq, sw, su, tq, tw, tu, cdf, keys, nR, lane, a.seed, img, a.call, 2);
         for (int i = lane; i < nR; i += 64) {
@@ -417,7 +429,7 @@ __global__ __launch_bounds__(64) void k_pf_acg_stats(double* __restrict__ Aout, 
     for (int i = lane; i < n; i += 64) wBal[(size_t)img * n + i] = sw[i];
     cm[0] = mean[0]; cm[1] = -mean[1]; cm[2] = -mean[2]; cm[3] = -mean[3];
     __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < n; i += 64) { double o[4]; qmul(o, sq + 4 * i, cm); for (int c = 0; c < 4; c++) sq[4 * i + c] = o[c]; }
+    for (int i = lane; i < n; i += 64) { double o[4]; qmul(o, cm, sq + 4 * i); for (int c = 0; c < 4; c++) sq[4 * i + c] = o[c]; }
     __builtin_amdgcn_wave_barrier();
     infer_acg(A, sq, n, lane, &rounds);
     if (lane == 0 && roundsOut) roundsOut[2 * (size_t)img + 1] = rounds;

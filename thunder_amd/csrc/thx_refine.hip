@@ -23,6 +23,10 @@ int thx_comm_size(const thx_comm* c);
 int thx_comm_allreduce_f32(thx_comm* c, float* buf, size_t count, void* stream);
 int thx_comm_broadcast(thx_comm* c, void* buf, size_t bytes, int root, void* stream);
 size_t thx_reco_allreduce_workspace(int dim, int maxRadius, int pf);
+int thx_compare_hemispheres_dev(float* A, float* B, int N, int rU, float* fscHost, const float* maskRL, float coreR, float ew,
+                                int avgFlag, int avgR, unsigned long long seed, unsigned call, int* randomPhaseThresOut,
+                                void* stream);
+int thx_soft_mask_volume_dev(float* vol, int N, float r, float ew, float bg, void* stream);
 int thx_reco_allreduce(thx_comm* hemi, float* F, float* T, double* O, int* counter, int dim, int maxRadius, int pf,
                        void* workspace, void* stream);
 }
@@ -213,11 +217,13 @@ struct thx_refine {
     double *rotB, *recoRot, *recoTran, *rotTop, *tranTop;
     float *uR, *uT, *wC, *wD, *baseL, *spec;
     void *wsExpect, *wsReduce;
-    unsigned pfCall = 0;
+    unsigned pfCall = 0, iterCount = 0;
     int *active = nullptr, *nP = nullptr, *nActiveDev = nullptr;   // per-image stop rule
     double* stopState = nullptr;
     long imagePhases = 0;
     bool haveCells = false;
+    std::vector<float> fscReco;          // Reconstructor::_FSC: what Model::resetReco handed over at the end of the last iteration
+    thx_refine_capture cap = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // timing (HIP events on the launch stream, resolved in thx_refine_stats)
     bool timed = false;
     struct Ev { hipEvent_t a, b; int kind; int images; };
@@ -342,6 +348,16 @@ int expectation(thx_refine* h, int vi, hipStream_t st)
             h->pfCall++;
             THX_RC(thx_pf_update_dev(r, t, wR, wT, h->uR, h->uT, k, s, h->topR + (size_t)b0 * 4, h->topT + (size_t)b0 * 2, nb, c.mLR,
                                      c.mLT, c.peakFactorR, c.seed, h->pfCall, act, st));
+            if (p < c.nPhase) {   // optional trace for the chain-level parity tests
+                const size_t at = (size_t)p * h->nImg + b0;
+                const thx_refine_capture& cp = h->cap;
+                if (cp.uR) THX_CHECK(hipMemcpyAsync(cp.uR + at * c.mLR, h->uR, (size_t)nb * c.mLR * sizeof(float), hipMemcpyDeviceToDevice, st));
+                if (cp.uT) THX_CHECK(hipMemcpyAsync(cp.uT + at * c.mLT, h->uT, (size_t)nb * c.mLT * sizeof(float), hipMemcpyDeviceToDevice, st));
+                if (cp.r) THX_CHECK(hipMemcpyAsync(cp.r + at * c.mLR * 4, r, (size_t)nb * c.mLR * 4 * sizeof(double), hipMemcpyDeviceToDevice, st));
+                if (cp.t) THX_CHECK(hipMemcpyAsync(cp.t + at * c.mLT * 2, t, (size_t)nb * c.mLT * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+                if (cp.k123) THX_CHECK(hipMemcpyAsync(cp.k123 + at * 3, k, (size_t)nb * 3 * sizeof(double), hipMemcpyDeviceToDevice, st));
+                if (cp.s01) THX_CHECK(hipMemcpyAsync(cp.s01 + at * 2, s, (size_t)nb * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+            }
         }
         imagePhases += nActive;
         if (rule && p >= c.nPhase) {
@@ -480,9 +496,15 @@ int thx_refine_create(thx_refine** out, const thx_refine_config* cfg, thx_comm* 
     THX_REQUIRE(out && cfg, "NULL argument");
     const thx_refine_config& c = *cfg;
     THX_REQUIRE(c.N > 0 && (c.N % 2) == 0 && c.pf >= 1 && c.nImg > 0, "bad box / particle count");
-    THX_REQUIRE(c.mLR > 0 && c.mLR <= 256 && c.mLT > 0 && c.mLT <= 9 && c.nPhase > 0 && c.mReco > 0, "bad search parameters");
+    THX_REQUIRE(c.mLR > 0 && c.mLR <= 256 && c.mLT > 0 && c.mLT <= 32 && c.nPhase > 0 && c.mReco > 0, "bad search parameters");
     THX_REQUIRE(c.nGroup > 0 && c.batch > 0, "bad nGroup / batch");
     THX_REQUIRE(c.halfOfRank >= -1 && c.halfOfRank <= 1, "halfOfRank must be -1 (both halves here), 0 or 1");
+    // thx_refine_iterate broadcasts half map h from world rank h: with several ranks the caller must follow the reference's
+    // odd / even convention (src/Parallel.cpp:26-36) -- rank r owns half r mod 2 -- and no rank may hold both halves
+    if (world && thx_comm_size(world) > 1) {
+        THX_REQUIRE(c.halfOfRank >= 0, "halfOfRank = -1 (both halves on one rank) needs a one-rank world");
+        THX_REQUIRE(c.halfOfRank == thx_comm_rank(world) % 2, "halfOfRank must equal the world rank mod 2 (rank r owns half r mod 2)");
+    }
     thx_refine* h = new thx_refine;
     h->cfg = c;
     h->hemi = hemi;
@@ -533,6 +555,10 @@ int thx_refine_create(thx_refine** out, const thx_refine_config* cfg, thx_comm* 
     RC_OR_FREE(dalloc(h, &h->cells, h->nV * (thx_projector_packed_bytes(h->P) / sizeof(float))));
     RC_OR_FREE(dalloc(h, &h->F, h->nV * volN * 2)); RC_OR_FREE(dalloc(h, &h->T, h->nV * volN));
     RC_OR_FREE(dalloc(h, &h->maps, 2 * (size_t)c.N * c.N * c.N)); RC_OR_FREE(dalloc(h, &h->mapsX, 2 * (size_t)c.N * c.N * c.N));
+    if (hipMemset(h->maps, 0, 2 * (size_t)c.N * c.N * c.N * sizeof(float)) != hipSuccess ||
+        hipMemset(h->mapsX, 0, 2 * (size_t)c.N * c.N * c.N * sizeof(float)) != hipSuccess) {
+        set_error("refine driver: hipMemset of the half maps failed"); thx_refine_destroy(h); return -1;
+    }
     RC_OR_FREE(dalloc(h, &h->ftA, imgSize * c.N)); RC_OR_FREE(dalloc(h, &h->ftB, imgSize * c.N));
     RC_OR_FREE(dalloc(h, &h->fscDev, (size_t)c.N / 2));
     RC_OR_FREE(dalloc(h, &h->sig, (size_t)h->nV * c.nGroup * h->rSig)); RC_OR_FREE(dalloc(h, &h->sigRcp, (size_t)h->nV * c.nGroup * h->rSig));
@@ -624,6 +650,8 @@ int thx_refine_reset(thx_refine* h, void* stream)
     hipLaunchKernelGGL(k_take_first, dim3(blocks_for(n * 2)), dim3(256), 0, st, h->topT, h->t, (int)n, c.mLT * 2, 2);
     THX_LAUNCH_CHECK();
     h->pfCall = 0;
+    h->iterCount = 0;
+    h->fscReco.assign(h->rU, 1.0f);   // Model::initProjReco: _reco[l]->setFSC(vec::Constant(_rU, 1)), src/Model.cpp:1086
     for (int v = 0; v < h->nV; v++) THX_RC(refresh_rows(h, v, st));
     return 0;
 }
@@ -643,40 +671,72 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
         { Scope s(h, st, EV_STAGE0 + ST_SIGMA); THX_RC(sigma_update(h, vi, st)); }
         { Scope s(h, st, EV_STAGE0 + ST_INSERT); THX_RC(insertion(h, vi, st)); }
     }
-    // ---- half-set reduce, prepareTF, reconstruct (MAP off) -> FSC -> reconstruct (MAP on) -> projector refresh ----
-    std::vector<float> fsc(h->N / 2);
+    // ---- Optimiser::reconstructRef after the insertion (src/Optimiser.cpp:7248-7760) and the run loop up to Model::resetReco
+    // (:3900-4073): prepareTF; reconstruct with MAP off -> compareTwoHemispheres(fsc) -> Model::_FSC; reconstruct with MAP on
+    // and the reconstructor's OWN FSC (set by resetReco at the end of the previous iteration); compareTwoHemispheres(avg);
+    // solventFlatten; refreshProj; resetReco ----
+    std::vector<float> fsc(h->N / 2, 0.f);
     {
         Scope s(h, st, EV_STAGE0 + ST_RECO);
         int iters = 0;
         float diffC = 0;
+        const bool multi = h->world && thx_comm_size(h->world) > 1;
         for (int vi = 0; vi < h->nV; vi++) {
             float* F = h->F + (size_t)vi * volN * 2;
             float* T = h->T + (size_t)vi * volN;
             THX_RC(thx_reco_allreduce(h->hemi, F, T, nullptr, nullptr, h->P, h->rU, h->pf, h->wsReduce, st));
             THX_RC(thx_normalise_tf_dev(F, T, h->P, st));
-            THX_RC(thx_reco_reconstruct_dev(h->plans[vi], F, T, h->rU, nullptr, 0, 0, 0, 1, h->maps + (size_t)h->halves[vi] * mapN,
+            // setMAP(false); setJoinHalf(true) (OPTIMISER_RECONSTRUCT_JOIN_HALF); setGridCorr(true) (OPTIMISER_3D_GRID_CORR), :7326-7352
+            THX_RC(thx_reco_reconstruct_dev(h->plans[vi], F, T, h->rU, nullptr, 0, 1, 0, 1, h->maps + (size_t)h->halves[vi] * mapN,
                                             &iters, &diffC, st));
             h->recoRounds += iters;
         }
         // every rank ends up with both half maps (the reference sends them to the master, src/Model.cpp:375-391): broadcast
-        // from world ranks 0 and 1, which lead halves 0 and 1
-        if (h->world && thx_comm_size(h->world) > 1) {
+        // from world ranks 0 and 1, which lead halves 0 and 1 (checked in thx_refine_create)
+        if (multi) {
             THX_RC(thx_comm_broadcast(h->world, h->maps, mapN * sizeof(float), 0, st));
             THX_RC(thx_comm_broadcast(h->world, h->maps + mapN, mapN * sizeof(float), 1, st));
         }
+        if (h->cap.mapsFsc) THX_CHECK(hipMemcpyAsync(h->cap.mapsFsc, h->maps, 2 * mapN * sizeof(float), hipMemcpyDeviceToDevice, st));
         THX_RC(thx_fft3d_fw_dev(h->maps, h->ftA, h->N, st));
         THX_RC(thx_fft3d_fw_dev(h->maps + mapN, h->ftB, h->N, st));
-        THX_RC(thx_fsc_dev(h->fscDev, h->N / 2, h->ftA, h->ftB, h->N, st));
-        THX_CHECK(hipMemcpyAsync(fsc.data(), h->fscDev, fsc.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-        THX_CHECK(hipStreamSynchronize(st));
+        // compareTwoHemispheres(true, false, ...), src/Optimiser.cpp:7547: FSC over _rU shells, core-mask corrected on request
+        const float coreR = c.coreFSC ? (float)(int)rint((double)(c.maskRadiusPx)) : 0.f;   // AROUND(maskRadius / pixelSize), :188
+        // random phases: Philox calls fscCall (half A) and fscCall + 1 (half B) -- a function of the iteration count only, so
+        // that every rank substitutes the same phases and arrives at the same curve
+        const unsigned fscCall = 0x40000000u + 2u * h->iterCount;
+        THX_RC(thx_compare_hemispheres_dev(h->ftA, h->ftB, h->N, h->rU, fsc.data(), nullptr, coreR, 6.0f /* EDGE_WIDTH_RL */, 0, 0,
+                                           c.seed, fscCall, nullptr, st));
         for (int vi = 0; vi < h->nV; vi++) {
             float* F = h->F + (size_t)vi * volN * 2;
             float* T = h->T + (size_t)vi * volN;
             float* m = h->mapsX + (size_t)h->halves[vi] * mapN;
-            THX_RC(thx_reco_reconstruct_dev(h->plans[vi], F, T, h->rU, fsc.data(), (int)fsc.size(), 0, 1, 1, m, &iters, &diffC, st));
+            // setMAP(true); setJoinHalf(true); setGridCorr(true), :7574-7600; Reconstructor::_FSC is last iteration's
+            THX_RC(thx_reco_reconstruct_dev(h->plans[vi], F, T, h->rU, h->fscReco.data(), (int)h->fscReco.size(), 1, 1, 1, m, &iters,
+                                            &diffC, st));
             h->recoRounds += iters;
+        }
+        if (c.goldenAverage) {
+            // compareTwoHemispheres(false, true, ...), :7747: A = B = (A + B) / 2 inside r (src/Model.cpp:629-674)
+            if (multi) {
+                THX_RC(thx_comm_broadcast(h->world, h->mapsX, mapN * sizeof(float), 0, st));
+                THX_RC(thx_comm_broadcast(h->world, h->mapsX + mapN, mapN * sizeof(float), 1, st));
+            }
+            const float resP = (float)(1.0 / 20.0) * (float)h->N * c.pixelSize;   // resA2P(1.0 / A_B_AVERAGE_THRES, _size, _pixelSize)
+            const int avgR = std::min((int)rint((double)resP), h->rU);               // GSL_MIN_INT(AROUND(...), _r)
+            THX_RC(thx_fft3d_fw_dev(h->mapsX, h->ftA, h->N, st));
+            THX_RC(thx_fft3d_fw_dev(h->mapsX + mapN, h->ftB, h->N, st));
+            THX_RC(thx_compare_hemispheres_dev(h->ftA, h->ftB, h->N, h->rU, nullptr, nullptr, 0.f, 6.0f, 1, avgR, c.seed, 0, nullptr, st));
+            THX_RC(thx_fft3d_bw_dev(h->ftA, h->mapsX, h->N, st));
+            THX_RC(thx_fft3d_bw_dev(h->ftB, h->mapsX + mapN, h->N, st));
+        }
+        for (int vi = 0; vi < h->nV; vi++) {
+            float* m = h->mapsX + (size_t)h->halves[vi] * mapN;
+            if (c.solventFlatten)   // softMask(ref, ref, maskRadius / pixelSize, EDGE_WIDTH_RL, 0), :7958-7975
+                THX_RC(thx_soft_mask_volume_dev(m, h->N, c.maskRadiusPx, 6.0f, 0.f, st));
             THX_RC(refresh_projector(h, vi, m, st));
         }
+        h->fscReco.assign(fsc.begin(), fsc.begin() + h->rU);   // Model::resetReco: _reco[l]->setFSC(_FSC.col(l)), src/Model.cpp:1122
     }
     // ---- re-centre and re-mask the particle images with the top shift of the last phase ----
     {
@@ -694,7 +754,16 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
         }
     }
     h->iterations++;
+    h->iterCount++;
     if (fscHost) memcpy(fscHost, fsc.data(), fsc.size() * sizeof(float));
+    return 0;
+}
+
+int thx_refine_set_capture(thx_refine* h, const thx_refine_capture* capture)
+{
+    THX_REQUIRE(h, "NULL handle");
+    if (capture) h->cap = *capture;
+    else h->cap = thx_refine_capture{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     return 0;
 }
 

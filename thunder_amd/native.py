@@ -104,6 +104,7 @@ class NativeRefine:
         cfg.pixelSize, cfg.maskRadiusPx, cfg.sigma2Init = s.pixelSize, s.maskRadiusPx, s.sigma2
         cfg.transS, cfg.transQ, cfg.pfL, cfg.pfS, cfg.peakFactorR = s.transS, s.transQ, s.pfL, s.pfS, s.peakFactorR
         cfg.seed = s.pf_seed
+        cfg.coreFSC, cfg.goldenAverage, cfg.solventFlatten = int(s.coreFSC), int(s.goldenAverage), int(s.solventFlatten)
         assert s.use_pf, "the native driver runs the device particle filter"
         self.cfg = cfg
         h = C.c_void_p()
@@ -118,6 +119,23 @@ class NativeRefine:
 
     def reset(self):
         capi.call("thx_refine_reset", self._h, stream_ptr())
+
+    def capture(self, maps=True):
+        """per-phase trace of the local search (thx_refine_set_capture): returns the dict of device tensors the following
+        iterations fill -- uR, uT, r, t, k123, s01 indexed [phase][image], mapsFsc [2][N]^3"""
+        s, c = self.shard, self.cfg
+        n, dev = s.nImg, s.dev
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        cap = dict(uR=z((c.nPhase, n, c.mLR), torch.float32), uT=z((c.nPhase, n, c.mLT), torch.float32),
+                   r=z((c.nPhase, n, c.mLR, 4), torch.float64), t=z((c.nPhase, n, c.mLT, 2), torch.float64),
+                   k123=z((c.nPhase, n, 3), torch.float64), s01=z((c.nPhase, n, 2), torch.float64),
+                   mapsFsc=z((2, s.N, s.N, s.N), torch.float32) if maps else None)
+        st = capi.RefineCapture()
+        for k, v in cap.items():
+            setattr(st, k, ptr(v) if v is not None else None)
+        capi.call("thx_refine_set_capture", self._h, C.byref(st))
+        self._cap = cap
+        return cap
 
     def iterate(self, timed=False):
         fsc = np.zeros(self.shard.N // 2, np.float32)

@@ -228,6 +228,27 @@ def fft3d_fw(rl):
 
 # ---------------------------------------------------------------------------------------------
 # callers either side of the E/M loop
+def fft3d_bw(ft, n):
+    """FFT::bw (c2r incl. 1/size) of a half-complex [n][n][n/2+1] FT; the input is destroyed"""
+    rl = torch.empty((n, n, n), dtype=torch.float32, device=ft.device)
+    call("thx_fft3d_bw_dev", ptr(ft), ptr(rl), n, stream_ptr())
+    return rl
+
+
+def compare_hemispheres(A, B, N, rU, fsc=True, coreR=0.0, ew=6.0, avg_r=None, seed=0, call_id=0):
+    """Model::compareTwoHemispheres on two half-map FTs (in place for the averaging) -> FSC [rU] (numpy) or None"""
+    import numpy as np
+    out = np.zeros(rU, np.float32) if fsc else None
+    call("thx_compare_hemispheres_dev", ptr(A), ptr(B), N, rU, out.ctypes.data if fsc else None, None, float(coreR), float(ew),
+         0 if avg_r is None else 1, 0 if avg_r is None else int(avg_r), int(seed), int(call_id), None, stream_ptr())
+    return out
+
+
+def soft_mask_volume(vol, r, ew=6.0, bg=0.0):
+    call("thx_soft_mask_volume_dev", ptr(vol), vol.shape[0], float(r), float(ew), float(bg), stream_ptr())
+    return vol
+
+
 def remask(imgFT, maskRadiusPx, ew=6.0):
     """Optimiser::reMaskImg src/Optimiser.cpp:6093-6149 (ReMask Interface.h:517) IN PLACE on [nImg][N][N/2+1] c64"""
     _chk(imgFT, _C64, "imgFT")

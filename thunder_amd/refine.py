@@ -72,7 +72,8 @@ class RefineShard:
 
     def __init__(self, N, nImg, device, rank=0, world=1, pf=2, mLR=125, mLT=9, nPhase=3, mReco=100, seed=1000,
                  batch=10240, pixelSize=1.32, snr=0.01, rL=2, ops=None, oracle_pixel_list=None, nGroup=8, groupSig=True,
-                 maskFrac=0.45, particle_filter=True, transS=2.0, data=None, allocate=True, sort_view=False):
+                 maskFrac=0.45, particle_filter=True, transS=2.0, data=None, allocate=True, sort_view=False, coreFSC=True,
+                 goldenAverage=True, solventFlatten=True):
         """data (optional): particles read from files instead of synthesised here -- dict(imgOri complex64 device stack
         [nImg][N][N/2+1] as Optimiser::initImg leaves _imgOri, attr float32 [nImg][7], quat [nImg][4], shift [nImg][2]
         (initial poses, e.g. the .thu columns), gid int32 [nImg] 1-based group ids, ref float32 [N]^3 initial map).
@@ -152,6 +153,8 @@ class RefineShard:
         self.pixelSize, self.rSig = pixelSize, N // 2 - 1
         self.maskRadiusPx = float(np.float32(maskFrac * N))
         self.nGroup, self.groupSig = nGroup, groupSig
+        # script/demo_3D.json:23 "Calculate FSC Using Core Region": true; :50 "Using Golden Standard FSC": true
+        self.coreFSC, self.goldenAverage, self.solventFlatten = coreFSC, goldenAverage, solventFlatten
         self.gid = rng.integers(1, nGroup + 1, nImg).astype(np.int32)          # Optimiser::_groupID (1-based, host)
         if data is not None:
             self.gid = np.ascontiguousarray(np.asarray(data["gid"], np.int32).reshape(nImg))
@@ -406,27 +409,53 @@ class RefineShard:
                 self.insert_ms.append((e0, e1, b1 - b0))
 
     def reduce_and_first_map(self, vi):
-        """half-set reduce, prepareTF (normalisation; C1: no symmetry sweep), reconstruct with MAP off"""
+        """half-set reduce, prepareTF (normalisation; C1: no symmetry sweep), reconstruct with MAP off
+        (setJoinHalf(true): OPTIMISER_RECONSTRUCT_JOIN_HALF, src/Optimiser.cpp:7326-7352)"""
         ops, g = self.ops, self.groups
         g.allreduce_half(self.T[vi])
         g.allreduce_half(self.F[vi])
         ops.normalise_TF(self.F[vi], self.T[vi], self.P)
-        m = self.plans[vi].reconstruct(self.F[vi], self.T[vi], self.maxRadius, MAP=False, gridCorr=True)
+        m = self.plans[vi].reconstruct(self.F[vi], self.T[vi], self.maxRadius, joinHalf=True, MAP=False, gridCorr=True)
         self.reco_rounds.append(self.plans[vi].last_iters)
         return m
 
     def fsc_of(self, a, b):
+        """compareTwoHemispheres(true, false) (src/Optimiser.cpp:7547): Model::_FSC over rU shells, core-mask corrected
+        when coreFSC; returned padded to N / 2 entries"""
         ops = self.ops
-        return ops.fsc(ops.fft3d_fw(a), ops.fft3d_fw(b), self.N, self.N // 2).cpu().numpy()
+        coreR = float(np.rint(np.float32(self.maskRadiusPx))) if self.coreFSC else 0.0
+        f = ops.compare_hemispheres(ops.fft3d_fw(a), ops.fft3d_fw(b), self.N, self.rU, coreR=coreR, seed=self.pf_seed,
+                                    call_id=0x40000000 + 2 * self.iter_count)
+        out = np.zeros(self.N // 2, np.float32)
+        out[:self.rU] = f
+        return out
 
-    def final_map_and_refresh(self, vi, fsc):
-        m = self.plans[vi].reconstruct(self.F[vi], self.T[vi], self.maxRadius, FSC=fsc, joinHalf=False, MAP=True,
+    def final_map(self, vi):
+        """reconstruct with MAP on and the FSC Model::resetReco handed to the reconstructor at the end of the PREVIOUS
+        iteration (src/Model.cpp:1086,1122), joinHalf on (src/Optimiser.cpp:7574-7600)"""
+        m = self.plans[vi].reconstruct(self.F[vi], self.T[vi], self.maxRadius, FSC=self.fsc_reco, joinHalf=True, MAP=True,
                                        gridCorr=True)
         self.reco_rounds.append(self.plans[vi].last_iters)
-        self.vols[vi] = self.plans[vi].set_projectee(m)   # Model::refreshProj
-        if self.use_packed and self.cells is not None:
-            self.cells[vi] = self.ops.pack_projector(self.vols[vi:vi + 1], self.P)[0]
         return m
+
+    def average_flatten_refresh(self, maps):
+        """compareTwoHemispheres(false, true) (gold-standard averaging inside A_B_AVERAGE_THRES), Optimiser::solventFlatten's
+        spherical mask, Model::refreshProj; maps = {half: MAP-on map} with BOTH halves present"""
+        ops, N = self.ops, self.N
+        if self.goldenAverage:
+            resP = np.float32(np.float32(1.0 / 20.0) * np.float32(N) * np.float32(self.pixelSize))
+            avgR = min(int(np.rint(np.float64(resP))), self.rU)
+            A, B = ops.fft3d_fw(maps[0]), ops.fft3d_fw(maps[1])
+            ops.compare_hemispheres(A, B, N, self.rU, fsc=False, avg_r=avgR)
+            maps = {0: ops.fft3d_bw(A, N), 1: ops.fft3d_bw(B, N)}
+        for vi, h in enumerate(self.halves):
+            m = maps[h]
+            if self.solventFlatten:
+                ops.soft_mask_volume(m, self.maskRadiusPx, 6.0, 0.0)
+            self.vols[vi] = self.plans[vi].set_projectee(m)   # Model::refreshProj
+            if self.use_packed and self.cells is not None:
+                self.cells[vi] = ops.pack_projector(self.vols[vi:vi + 1], self.P)[0]
+        return maps
 
     def em_stage(self, vi, timed=False):
         """rows -> expectation -> sigma update -> draws -> insertion for local half `vi`; returns the top shifts"""
@@ -453,7 +482,13 @@ class RefineShard:
             a, b = self.groups.exchange_half_maps(maps)
             fsc = self.fsc_of(a, b)
             for vi, h in enumerate(self.halves):
-                maps[h] = self.final_map_and_refresh(vi, fsc)
+                maps[h] = self.final_map(vi)
+            if self.goldenAverage:
+                a, b = self.groups.exchange_half_maps(maps)
+                maps = {0: a, 1: b}
+            maps = self.average_flatten_refresh(maps)
+            self.fsc_reco = fsc[:self.rU].copy()           # Model::resetReco
+            self.iter_count += 1
         with self._stage("recentre_remask", timed):
             for vi, h in enumerate(self.halves):
                 self.recentre_and_remask(vi, top[vi])
@@ -461,75 +496,12 @@ class RefineShard:
         return fsc
 
     def run(self, steps, timed=False):
-        """`steps` EM iterations.  With both halves on this GPU (world == 1) the two half-set chains are independent
-        except for the FSC exchange in the middle of each iteration, so they run as two host threads on two HIP streams,
-        half 1 one stage behind half 0: the FFT-bound reconstruction of one half then overlaps the gather/scatter-bound
-        E-step or insertion of the other.  Measured gain on MI355X: +1.7 % (every stage already keeps the chip busy), so
-        this path is opt-in (THX_OVERLAP=1); the default runs the halves back to back, which also keeps the per-kernel
-        event timings of bench.py undisturbed.  world > 1 has one half per rank and always runs back to back."""
-        if self.world > 1 or len(self.halves) < 2 or os.environ.get("THX_OVERLAP", "0") != "1":
-            fsc = None
-            for _ in range(steps):
-                fsc = self.iteration(timed)
-            return fsc
-        import threading
-        torch.cuda.synchronize()
-        streams = [torch.cuda.Stream(device=self.dev) for _ in self.halves]
-        meet = threading.Barrier(2)
-        e_done = [[threading.Event() for _ in range(steps)] for _ in self.halves]
-        e_evt = [[None] * steps for _ in self.halves]
-        r1_evt = [[None] * steps for _ in self.halves]
-        maps1 = [[None] * steps for _ in self.halves]
-        out, errs = {}, []
-
-        def chain(vi):
-            try:
-                torch.cuda.set_device(self.dev)
-                with torch.cuda.stream(streams[vi]):
-                    for it in range(steps):
-                        if vi == 1:   # stay one stage behind half 0
-                            e_done[0][it].wait()
-                            streams[vi].wait_event(e_evt[0][it])
-                        self.refresh_rows(vi)
-                        wR, wT = self.expectation(vi, timed)
-                        e_evt[vi][it] = torch.cuda.Event()
-                        e_evt[vi][it].record()
-                        e_done[vi][it].set()
-                        rotTop, tranTop = self.top_pose(vi, wR, wT)
-                        self.sigma_update(vi, rotTop, tranTop)
-                        rot, tran = self.draw_reco(vi, wR, wT)
-                        self.insertion(vi, rot, tran, timed)
-                        maps1[vi][it] = self.reduce_and_first_map(vi)
-                        r1_evt[vi][it] = torch.cuda.Event()
-                        r1_evt[vi][it].record()
-                        meet.wait()                                   # both first maps are enqueued
-                        streams[vi].wait_event(r1_evt[1 - vi][it])
-                        fsc = self.fsc_of(maps1[0][it], maps1[1][it])
-                        m = self.final_map_and_refresh(vi, fsc)
-                        self.recentre_and_remask(vi, tranTop)
-                        meet.wait()                                   # keep the two chains in the same iteration
-                        out[vi] = (fsc, m)
-                    streams[vi].synchronize()
-            except BaseException as e:   # surface worker failures in the caller
-                errs.append(e)
-                try:
-                    meet.abort()
-                except Exception:
-                    pass
-                for ev in e_done[vi]:
-                    ev.set()
-
-        th = [threading.Thread(target=chain, args=(vi,)) for vi in range(2)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        if errs:
-            raise errs[0]
-        torch.cuda.synchronize()
-        self.last["fsc"] = out[0][0]
-        self.last["maps"] = {self.halves[0]: out[0][1], self.halves[1]: out[1][1]}
-        return out[0][0]
+        """`steps` EM iterations, the local halves back to back.  (Running the two half-set chains on two streams was measured
+        in round 1: +1.7 %, every stage already keeps the chip busy; removed.)"""
+        fsc = None
+        for _ in range(steps):
+            fsc = self.iteration(timed)
+        return fsc
 
     def reset_reference(self):
         """back to the state before the first iteration: initial reference, no re-centring offset, masked copies of the
@@ -538,6 +510,8 @@ class RefineShard:
         for vi in range(self.vols.shape[0]):
             self.vols[vi] = v
         self.cells = None   # rebuilt on the next expectation
+        self.fsc_reco = np.ones(self.rU, np.float32)       # Model::initProjReco: setFSC(vec::Constant(_rU, 1))
+        self.iter_count = 0
         self.offset.zero_()
         for t, t0 in zip(self.tranP, self.tranP0):
             t.copy_(t0)
