@@ -504,12 +504,17 @@ typedef struct thx_refine_config {
 
 /* optional per-phase trace of the local search (tests hold the chain against the oracle with it): DEVICE buffers, any may
  * be NULL; index [phase][image of this rank].  uR / uT: the E-step's weights as handed to the filter (Particle::setUR /
- * setUT); r / t: the support points after Particle::resample; k123 / s01: Particle::calVari of the phase. */
+ * setUT); rP / tP: the support points after Particle::perturb, r / t: after Particle::resample; k123 / s01:
+ * Particle::calVari of the phase. */
 typedef struct thx_refine_capture {
     float *uR, *uT;            /* [nPhase][nImg][mLR], [nPhase][nImg][mLT] */
     double *r, *t;             /* [nPhase][nImg][mLR][4], [nPhase][nImg][mLT][2] */
     double *k123, *s01;        /* [nPhase][nImg][3], [nPhase][nImg][2] */
     float *mapsFsc;            /* [2][N]^3: the two MAP-off half maps the FSC is computed from */
+    double *rP, *tP;           /* [nPhase][nImg][mLR][4], [nPhase][nImg][mLT][2]: the support points after Particle::perturb */
+    double *wRP, *wTP;         /* [nPhase][nImg][mLR], [nPhase][nImg][mLT]: their priors (Particle::balanceWeight) */
+    float *Fraw, *Traw;        /* [local halves] complex / real (pf N)^3 half grids: the accumulators as the insertion left them,
+                                  before the half-set reduce and prepareTF's normalisation */
 } thx_refine_capture;
 
 typedef struct thx_refine_stats {
@@ -519,6 +524,8 @@ typedef struct thx_refine_stats {
     long balancingRounds, iterations;
     long imagePhases;                     /* sum over images of the phases they ran (Optimiser::_nF) */
     int nPxl, nPxlM, batch;
+    int lastRounds[4];                    /* balancing rounds of the last iteration's reconstructions: MAP off, local halves 0 / 1;
+                                             MAP on, local halves 0 / 1 (0 where this rank holds no such half) */
 } thx_refine_stats;
 
 /* hemi: communicator of this rank's half (NULL = the half lives on this rank alone); world: all ranks (NULL = one rank) */

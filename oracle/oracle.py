@@ -319,12 +319,14 @@ def set_projectee(ref_rl, pf=2):
 
 
 def reconstruct(F, T, P, N, pf, maxRadius, FSC=None, joinHalf=False, MAP=True, gridCorr=True, a=1.9, alpha=15.0,
-                return_iters=False, max_rounds=30, T_inplace=False):
+                return_iters=False, max_rounds=30, T_inplace=False, force_rounds=None):
     """Reconstructor::reconstruct(Volume&) src/Reconstructor.cpp:1129-1831, MODE_3D, _size == _N.
     F complex64 [P][P][P/2+1], T float32 same grid (both AFTER prepareTF); returns float32 [N][N][N]
     (wrapped-index layout).  The reference changes _T3D in place (Wiener term :1242-1270, 1e-25 floor :1322-1324), so a
     second reconstruct() of the same iteration starts from the first one's T: T_inplace=True does the same to the caller's
-    array (float32, contiguous); the default works on a copy."""
+    array (float32, contiguous); the default works on a copy.  force_rounds = k runs exactly k balancing rounds whatever the
+    stop rule of :1530-1551 says (tests use it to compare two implementations after the SAME round when the rule -- which
+    compares a max norm with 0.95 x its previous value on a loop that has not converged -- lets them stop in different ones)."""
     L = lib()
     F = c64(F).copy()
     if T_inplace:
@@ -346,7 +348,7 @@ def reconstruct(F, T, P, N, pf, maxRadius, FSC=None, joinHalf=False, MAP=True, g
         Cv = np.zeros((P, P, P // 2 + 1), np.complex64)
         diffC = diffCPrev = np.float32(np.finfo(np.float32).max)
         nNoDec = 0
-        for m in range(max_rounds):  # MAX_N_ITER_BALANCE = 30 (max_rounds < 30 only for bench.py's per-round timing)
+        for m in range(max_rounds if force_rounds is None else force_rounds):  # MAX_N_ITER_BALANCE = 30
             L.orc_calc_C(_p(Cv, c_f), _p(T, c_f), _p(W, c_f), C.c_int(P))
             crl = sfft.irfftn(Cv, s=(P, P, P)).astype(np.float32)  # bwExecutePlan incl. 1/size
             crl = np.ascontiguousarray(crl)
@@ -361,7 +363,7 @@ def reconstruct(F, T, P, N, pf, maxRadius, FSC=None, joinHalf=False, MAP=True, g
                 nNoDec += 1
             else:
                 nNoDec = 0
-            if (diffC < 1e-2) or ((m >= 10) and (nNoDec == 2)):
+            if force_rounds is None and ((diffC < 1e-2) or ((m >= 10) and (nNoDec == 2))):
                 break
     else:
         L.orc_W_nogridcorr(_p(W, c_f), _p(T, c_f), C.c_int(P), C.c_int(pf), C.c_int(maxRadius))
@@ -674,7 +676,9 @@ class Iteration:
     cfg: dict(N, pf, nHalfA, mLR, mLT, nPhase, mReco, batch, rL, nGroup, groupSig, pixelSize, maskRadiusPx, sigma2Init,
     transS, transQ, pfL, pfS, peakFactorR, seed, coreFSC, goldenAverage, solventFlatten).
     `resolve` (optional): callback(phase, image, own) -> own, lets a test adopt the device's choice where a discrete decision
-    (resampled indices, top support point) hinges on rounding -- after checking its tie rule."""
+    (resampled indices, top support point) hinges on rounding -- after checking its tie rule; if it has a method
+    after_perturb(phase, image, q_in, q, t, wR, wT) -> (q, t, wR, wT) it is also shown every perturbed cloud (the mean frame
+    of Particle::perturb is numerically undetermined when the resampled cloud has collapsed onto a few points)."""
 
     def __init__(self, cfg, imgOri, attr, gid, quat0, tran0, ref, ph):
         self.c = dict(cfg)
@@ -731,8 +735,57 @@ class Iteration:
         self.iterCount = 0
         self.fscReco = np.ones(self.rU, np.float32)            # Model::initProjReco, src/Model.cpp:1086
 
+    def fsc_of_maps(self, mapA, mapB, iterCount):
+        """Model::compareTwoHemispheres(true, false) on the two MAP-off half maps (src/Model.cpp:307-612): FSC over rU shells,
+        mask-corrected with the core mask when coreFSC (random phases: the Philox streams of iteration `iterCount`)"""
+        c, ph, N = self.c, self.ph, self.N
+        A, B = sfft.rfftn(f32(mapA)).astype(np.complex64), sfft.rfftn(f32(mapB)).astype(np.complex64)
+        coreR = float(int(np.rint(np.float32(c["maskRadiusPx"])))) if c["coreFSC"] else 0.0
+        phA = phB = None
+        if c["coreFSC"]:
+            ne = N * N * (N // 2 + 1)
+            call = 0x40000000 + 2 * iterCount
+            e = np.arange(ne, dtype=np.uint64)
+            lo32, hi32 = (e & np.uint64(0xFFFFFFFF)).astype(np.uint32), (e >> np.uint64(32)).astype(np.uint32)
+            pi = 3.14159265358979323846   # TSGSL_ran_flat(engine, 0, 2 * M_PI) narrowed to RFLOAT; device: (float)(u * 2 * pi)
+            phA = (ph.draw_u4(c["seed"], lo32, call, 9, hi32)[0] * 2 * pi).astype(np.float32)
+            phB = (ph.draw_u4(c["seed"], lo32, call + 1, 9, hi32)[0] * 2 * pi).astype(np.float32)
+        return compare_hemispheres(A, B, N, self.rU, phA, phB, coreR=coreR, ew=6.0)["fsc"]
+
     # -- one iteration --------------------------------------------------------------------------
-    def iterate(self, resolve=None):
+    def _reconstruct_all(self, F, T, force):
+        """reconstructRef after prepareTF (src/Optimiser.cpp:7326-7747): reconstruct with MAP off -> compareTwoHemispheres(fsc) ->
+        reconstruct with MAP on (Reconstructor::_FSC of the previous iteration, joinHalf) -> compareTwoHemispheres(avg) ->
+        solventFlatten.  T [2] is changed in place as the reference changes _T3D.  force: None = the reference's stop rule,
+        else the four round counts to run (MAP off half 0 / 1, MAP on half 0 / 1)."""
+        c, N, P, pf = self.c, self.N, self.P, self.pf
+        maps, rounds = [], []
+        for vi in range(2):
+            m, it, diffs, _ = reconstruct(F[vi], T[vi], P, N, pf, self.rU, MAP=False, joinHalf=True, gridCorr=True, return_iters=True,
+                                          T_inplace=True, force_rounds=None if force is None else force[vi])
+            maps.append(m)
+            rounds.append(it)
+        res = dict(mapsFsc=maps, fsc=self.fsc_of_maps(maps[0], maps[1], self.iterCount))
+        mapsX = []
+        for vi in range(2):
+            m, it, diffs, _ = reconstruct(F[vi], T[vi], P, N, pf, self.rU, FSC=self.fscReco, joinHalf=True, MAP=True, gridCorr=True,
+                                          return_iters=True, T_inplace=True, force_rounds=None if force is None else force[2 + vi])
+            mapsX.append(m)
+            rounds.append(it)
+        res["mapsMAP"] = [m.copy() for m in mapsX]
+        if c["goldenAverage"]:   # compareTwoHemispheres(false, true), :7747 (k == 1, _goldenStandard)
+            resP = np.float32(np.float32(1.0 / 20.0) * np.float32(N) * np.float32(c["pixelSize"]))
+            avgR = min(int(np.rint(np.float64(resP))), self.rU)
+            A, B = sfft.rfftn(mapsX[0]).astype(np.complex64), sfft.rfftn(mapsX[1]).astype(np.complex64)
+            cm = compare_hemispheres(A, B, N, self.rU, avg_r=avgR)
+            mapsX = [np.ascontiguousarray(sfft.irfftn(x, s=(N, N, N)).astype(np.float32)) for x in (cm["A"], cm["B"])]
+            res["avgR"] = avgR
+        if c["solventFlatten"]:   # Optimiser::solventFlatten(false), :7958-7975
+            mapsX = [soft_mask_volume(m, np.float32(c["maskRadiusPx"]), 6.0, 0.0) for m in mapsX]
+        res["maps"], res["rounds"] = mapsX, rounds
+        return res
+
+    def iterate(self, resolve=None, force_rounds=None):
         c, ph, N, P, pf = self.c, self.ph, self.N, self.P, self.pf
         pl, plM = self.pl, self.plM
         seed, mLR, mLT = c["seed"], c["mLR"], c["mLT"]
@@ -761,6 +814,10 @@ class Iteration:
                         gR = np.stack(ph.draw_n4(seed, li, callP, 0, np.arange(mLR)), axis=1)
                         gT = np.stack(ph.draw_n4(seed, li, callP, 1, np.arange(mLT)), axis=1)
                         q, t, wR, wT = pf_perturb(self.q[l], self.t[l], self.k[l], self.s[l], f, f, c["transS"], c["transQ"], gR, gT)
+                        if resolve is not None and hasattr(resolve, "after_perturb"):
+                            if hasattr(resolve, "k_in"):
+                                resolve.k_in[l] = (self.k[l].copy(), self.s[l].copy())
+                            q, t, wR, wT = resolve.after_perturb(p, l, self.q[l], q, t, wR, wT)
                         rot = np.stack([rotate3D(x) for x in q])
                         e = expect_local(self.vols[vi], P, pf, N, pl["iCol"], pl["iRow"], datP[l - lo], self.ctfP[l],
                                          sigRcpP[l - lo], rot, t, nD=1, pC=1.0, pR=wR, pT=wT)
@@ -796,47 +853,17 @@ class Iteration:
             self.sig[vi], self.sigRcp[vi] = sig, rcp
         out["F_raw"], out["T_raw"] = [x.copy() for x in F], [x.copy() for x in T]
         # prepareTF (one rank per half: the all-reduce is the identity; C1: no symmetrisation), :7268 -> Reconstructor.cpp:1056-1091
-        maps, rounds = [], []
         for vi in range(2):
             normalise_TF(F[vi], T[vi], P)
-            m, it, diffs, _ = reconstruct(F[vi], T[vi], P, N, pf, self.rU, MAP=False, joinHalf=True, gridCorr=True, return_iters=True,
-                                          T_inplace=True)
-            maps.append(m)
-            rounds.append(it)
+        Tn = [t.copy() for t in T]
+        rec = self._reconstruct_all(F, T, None)
         out["F"], out["T"] = F, T
-        out["mapsFsc"] = maps
-        # compareTwoHemispheres(true, false), :7547: Model::_FSC of THIS iteration
-        A, B = sfft.rfftn(maps[0]).astype(np.complex64), sfft.rfftn(maps[1]).astype(np.complex64)
-        coreR = float(int(np.rint(np.float32(c["maskRadiusPx"])))) if c["coreFSC"] else 0.0
-        phA = phB = None
-        if c["coreFSC"]:
-            ne = N * N * (N // 2 + 1)
-            call = 0x40000000 + 2 * self.iterCount
-            e = np.arange(ne, dtype=np.uint64)
-            lo32, hi32 = (e & np.uint64(0xFFFFFFFF)).astype(np.uint32), (e >> np.uint64(32)).astype(np.uint32)
-            pi = 3.14159265358979323846   # TSGSL_ran_flat(engine, 0, 2 * M_PI) narrowed to RFLOAT; device: (float)(u * 2 * pi)
-            phA = (ph.draw_u4(seed, lo32, call, 9, hi32)[0] * 2 * pi).astype(np.float32)
-            phB = (ph.draw_u4(seed, lo32, call + 1, 9, hi32)[0] * 2 * pi).astype(np.float32)
-        cmpd = compare_hemispheres(A, B, N, self.rU, phA, phB, coreR=coreR, ew=6.0)
-        fsc_ = cmpd["fsc"]
-        # reconstruct with MAP on: Reconstructor::_FSC is what resetReco set at the end of the previous iteration
-        mapsX = []
+        if force_rounds is not None and list(force_rounds) != rec["rounds"]:
+            out["forced"] = self._reconstruct_all(F, Tn, list(force_rounds))
+        out["mapsFsc"], out["mapsMAP"], fsc_, mapsX, rounds = rec["mapsFsc"], rec["mapsMAP"], rec["fsc"], rec["maps"], rec["rounds"]
+        if "avgR" in rec:
+            out["avgR"] = rec["avgR"]
         for vi in range(2):
-            m, it, diffs, _ = reconstruct(F[vi], T[vi], P, N, pf, self.rU, FSC=self.fscReco, joinHalf=True, MAP=True, gridCorr=True,
-                                          return_iters=True, T_inplace=True)
-            mapsX.append(m)
-            rounds.append(it)
-        out["mapsMAP"] = [m.copy() for m in mapsX]
-        if c["goldenAverage"]:   # compareTwoHemispheres(false, true), :7747 (k == 1, _goldenStandard)
-            resP = np.float32(np.float32(1.0 / 20.0) * np.float32(N) * np.float32(c["pixelSize"]))
-            avgR = min(int(np.rint(np.float64(resP))), self.rU)
-            A, B = sfft.rfftn(mapsX[0]).astype(np.complex64), sfft.rfftn(mapsX[1]).astype(np.complex64)
-            cm = compare_hemispheres(A, B, N, self.rU, avg_r=avgR)
-            mapsX = [np.ascontiguousarray(sfft.irfftn(x, s=(N, N, N)).astype(np.float32)) for x in (cm["A"], cm["B"])]
-            out["avgR"] = avgR
-        for vi in range(2):
-            if c["solventFlatten"]:   # Optimiser::solventFlatten(false), :7958-7975
-                mapsX[vi] = soft_mask_volume(mapsX[vi], np.float32(c["maskRadiusPx"]), 6.0, 0.0)
             self.vols[vi] = set_projectee(mapsX[vi], pf)           # Model::refreshProj
         self.fscReco = fsc_.astype(np.float32).copy()             # Model::resetReco, src/Model.cpp:1122
         # reCentreImg + reMaskImg, :6065-6149

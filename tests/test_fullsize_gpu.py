@@ -293,3 +293,54 @@ def test_insert_bit_reproducible_n256(dev):
     mass = float(Tt.sum(dtype=torch.float64))
     want = float((w.double()[:, None] * ctf.double() ** 2).sum()) * mReco
     assert abs(mass - want) <= 2e-5 * want
+
+
+def test_reconstruct_vs_oracle_p512(oracle, dev):
+    """Reconstructor::reconstruct at the bench's grid (N = 256, P = 512; src/Reconstructor.cpp:1129-1831, convoluteC :2595-2674,
+    checkC :2563-2592): thx_reco_reconstruct_dev -- the hand-written radix-8 passes -- against the oracle on the F / T of a
+    bench-like insertion (96 images x 100 resampled filter draws), MAP off and MAP on (joinHalf, a decaying FSC).
+    The balancing loop's stop rule fires on a max norm that jitters (tests/test_iteration_cpu.py::test_stop_rule_is_noise_
+    sensitive); on IDENTICAL inputs both sides are expected to stop after the same round, and that is asserted.
+    Bars of SURVEY 8c (9): 1e-4 of max, FSC >= 0.9999 per shell, checkC's distance to 3 digits."""
+    import os
+    import scipy.fft as sfft
+    from thunder_amd import ops, synth
+    from thunder_amd.refine import pixel_list
+    O = oracle
+    rng = np.random.default_rng(78)
+    N, P, nImg, mReco = 256, 512, 96, 100
+    rU = N // 2 - 2
+    pl = pixel_list(N, rU, 0)
+    plan = ops.RecoPlan(N, N, 2)
+    vol_h = plan.set_projectee(T(synth.blob_map(N, nblob=8), dev)).cpu().numpy()
+    quat0 = synth.random_quats(nImg, rng)
+    shift0 = rng.normal(0, 2.0, size=(nImg, 2))
+    attr = synth.ctf_params(nImg, rng)
+    dat, ctf = _noisy_rows(O, vol_h, P, N, pl, quat0, shift0, attr, rng)
+    del vol_h
+    quat, tran = _filter_draws(rng, synth, quat0, shift0, nImg, 125, 9, mReco, 0.03)
+    w = T(np.full(nImg, 1.0 / mReco, np.float32), dev)
+    F = torch.zeros((P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
+    Tt = torch.zeros((P, P, P // 2 + 1), dtype=torch.float32, device=dev)
+    rot = ops.rotmat(T(quat.reshape(-1, 4), dev)).reshape(nImg, mReco, 9)
+    ops.insert(F, Tt, P, T(dat, dev), T(ctf, dev), w, rot, T(tran, dev), T(pl["iCol"], dev), T(pl["iRow"], dev), 2, N)
+    ops.normalise_TF(F, Tt, P)
+    Fh, Th = F.cpu().numpy(), Tt.cpu().numpy()
+    fsc = np.clip(1.2 - np.arange(rU) / (0.6 * rU), 0.02, 1.0).astype(np.float32)
+    t0 = time.perf_counter()
+    with sfft.set_workers(os.cpu_count() or 1):
+        for MAP in (False, True):
+            m_dev = plan.reconstruct(F, Tt, rU, FSC=fsc, joinHalf=True, MAP=MAP, gridCorr=True).cpu().numpy()   # T in place, as the reference
+            k_dev, d_dev = plan.last_iters, plan.last_diffC
+            m_or, k_or, diffs, _ = O.reconstruct(Fh, Th, P, N, 2, rU, FSC=fsc, joinHalf=True, MAP=MAP, gridCorr=True, return_iters=True,
+                                                 T_inplace=True)
+            note = ""
+            assert k_or == k_dev, "round counts differ on identical inputs: device %d oracle %d, diffC %s" % (k_dev, k_or, diffs[-4:])
+            e = np.abs(m_dev - m_or).max() / np.abs(m_or).max()
+            fs = O.fsc(sfft.rfftn(m_dev).astype(np.complex64), sfft.rfftn(m_or).astype(np.complex64), N, rU)
+            print("P = 512, MAP %s: rounds device %d oracle %d%s, diffC device %.5f oracle %.5f, map %.2e of max, min FSC %.6f"
+                  % ("on" if MAP else "off", k_dev, k_or, note, d_dev, diffs[-1], e, fs.min()))
+            assert abs(d_dev - diffs[-1]) <= 1e-3 * diffs[-1]
+            assert e <= 1e-4 and fs.min() >= 0.9999
+    print("oracle + device reconstructions at P = 512: %.0f s" % (time.perf_counter() - t0))
+    plan.close()

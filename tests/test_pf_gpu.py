@@ -23,7 +23,8 @@ def _cloud(rng, nImg, n, spread):
     d = rng.standard_normal((nImg, n, 4)) * np.array([1.0, spread, 0.6 * spread, 0.3 * spread])
     d[..., 0] = 1.0
     d /= np.linalg.norm(d, axis=2, keepdims=True)
-    q = synth.quat_mul(d, mean[:, None, :])
+    # mean * d: calVari estimates k1..k3 on conj(mean) * r (LEFT multiplication, src/Particle.cpp:1052-1058)
+    q = synth.quat_mul(np.broadcast_to(mean[:, None, :], d.shape), d)
     return q / np.linalg.norm(q, axis=2, keepdims=True)
 
 
@@ -101,7 +102,8 @@ def test_perturb(oracle, dev):
         gR = np.stack(PH.draw_n4(seed, l, call, 0, np.arange(nR)), axis=1)
         gT = np.stack(PH.draw_n4(seed, l, call, 1, np.arange(nT)), axis=1)
         wq, wt, wwR, wwT = O.pf_perturb(q[l], t[l], k[l], s[l], pfR, pfT, transS, transQ, gR, gT)
-        assert np.abs(gq[l] - wq).max() <= 1e-12 and np.abs(np.linalg.norm(gq[l], axis=1) - 1).max() < 1e-12
+        # (the conjugation by the cloud's mean inherits the 1e-9 accuracy of the ACG estimate, see test_acg_statistics)
+        assert np.abs(gq[l] - wq).max() <= 2e-9 and np.abs(np.linalg.norm(gq[l], axis=1) - 1).max() < 1e-12
         assert np.abs(gt[l] - wt).max() <= 1e-12
         assert np.allclose(gwR[l], wwR, rtol=1e-7) and abs(gwR[l].sum() - 1) < 1e-12
         assert np.allclose(gwT[l], wwT, rtol=1e-9)
@@ -132,7 +134,8 @@ def test_update_resample(oracle, dev):
     gq, gt, gwR, gwT, gk, gs, gtopR, gtopT = [x.cpu().numpy() for x in (dq, dt, dwR, dwT, dk, ds, topR, topT)]
     for l in range(nImg):
         # rank-1st, variances
-        assert np.array_equal(gtopR[l], q[l, uR[l].argmax()]) and np.array_equal(gtopT[l], t[l, uT[l].argmax()])
+        # (_topR is taken after calVari's round trip through the mean frame, as resample() does: 1e-16 of noise)
+        assert np.abs(gtopR[l] - q[l, uR[l].argmax()]).max() <= 1e-14 and np.array_equal(gtopT[l], t[l, uT[l].argmax()])
         kw, mw, qq = np.zeros(3), np.zeros(4), np.ascontiguousarray(q[l].copy())
         O.lib().orc_cal_vari_R(_dp(kw), _dp(mw), _dp(qq), nR)
         assert np.allclose(gk[l], kw, rtol=5e-2)

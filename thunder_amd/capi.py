@@ -36,7 +36,7 @@ class RefineConfig(C.Structure):
 
 class RefineCapture(C.Structure):
     """thx_refine_capture (include/thunder_amd.h): device pointers as integers"""
-    _fields_ = [(n, C.c_void_p) for n in ("uR", "uT", "r", "t", "k123", "s01", "mapsFsc")]
+    _fields_ = [(n, C.c_void_p) for n in ("uR", "uT", "r", "t", "k123", "s01", "mapsFsc", "rP", "tP", "wRP", "wTP", "Fraw", "Traw")]
 
 
 class RefineStats(C.Structure):
@@ -45,7 +45,7 @@ class RefineStats(C.Structure):
                 ("insertLaunches", C.c_long), ("insertImages", C.c_long), ("stageMs", C.c_double * 8),
                 ("balancingRounds", C.c_long), ("iterations", C.c_long), ("imagePhases", C.c_long), ("nPxl", C.c_int),
                 ("nPxlM", C.c_int),
-                ("batch", C.c_int)]
+                ("batch", C.c_int), ("lastRounds", C.c_int * 4)]
 
 
 class RefineView(C.Structure):

@@ -379,7 +379,14 @@ __device__ __forceinline__ void acc_add(long long* F, long long* T, long gi, lon
     atomicAdd(reinterpret_cast<unsigned long long*>(F + 2 * gi + 1), (unsigned long long)im);
     atomicAdd(reinterpret_cast<unsigned long long*>(T + gi), (unsigned long long)tt);
 }
-__device__ __forceinline__ long long shift_ll(long long v, int sh) { return sh >= 0 ? v << sh : v >> (-sh); }
+// left shifts are exact; a right shift (an image more than 2^8 below the launch's largest) rounds to nearest, ties away from
+// zero -- an arithmetic shift alone would floor, i.e. bias every negative F term of such an image towards -inf
+__device__ __forceinline__ long long shift_ll(long long v, int sh)
+{
+    if (sh >= 0) return v << sh;
+    const long long half = 1LL << (-sh - 1);
+    return v >= 0 ? (v + half) >> (-sh) : -((-v + half) >> (-sh));
+}
 
 __device__ __forceinline__ void insert_tiny_term(long long* F, long long* T, int P, int X, int Y, int Z, float re, float im, float tt,
                                                  float gF, float gT)

@@ -223,7 +223,7 @@ struct thx_refine {
     long imagePhases = 0;
     bool haveCells = false;
     std::vector<float> fscReco;          // Reconstructor::_FSC: what Model::resetReco handed over at the end of the last iteration
-    thx_refine_capture cap = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    thx_refine_capture cap = {};
     // timing (HIP events on the launch stream, resolved in thx_refine_stats)
     bool timed = false;
     struct Ev { hipEvent_t a, b; int kind; int images; };
@@ -231,6 +231,7 @@ struct thx_refine {
     thx_refine_stats_acc accExpect, accInsert;
     double stageMs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long recoRounds = 0, iterations = 0;
+    int lastRounds[4] = {0, 0, 0, 0};
 };
 
 namespace {
@@ -337,6 +338,13 @@ int expectation(thx_refine* h, int vi, hipStream_t st)
             h->pfCall++;
             THX_RC(thx_pf_perturb_dev(r, t, wR, wT, k, s, nb, c.mLR, c.mLT, f, f, c.transS, c.transQ, c.seed, h->pfCall, act, st));
             THX_RC(thx_rotmat_dev(r, h->rotB, nb * c.mLR, st));
+            if (p < c.nPhase && (h->cap.rP || h->cap.tP || h->cap.wRP || h->cap.wTP)) {
+                const size_t at = (size_t)p * h->nImg + b0;
+                if (h->cap.rP) THX_CHECK(hipMemcpyAsync(h->cap.rP + at * c.mLR * 4, r, (size_t)nb * c.mLR * 4 * sizeof(double), hipMemcpyDeviceToDevice, st));
+                if (h->cap.tP) THX_CHECK(hipMemcpyAsync(h->cap.tP + at * c.mLT * 2, t, (size_t)nb * c.mLT * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+                if (h->cap.wRP) THX_CHECK(hipMemcpyAsync(h->cap.wRP + at * c.mLR, wR, (size_t)nb * c.mLR * sizeof(double), hipMemcpyDeviceToDevice, st));
+                if (h->cap.wTP) THX_CHECK(hipMemcpyAsync(h->cap.wTP + at * c.mLT, wT, (size_t)nb * c.mLT * sizeof(double), hipMemcpyDeviceToDevice, st));
+            }
             {
                 Scope ev(h, st, EV_EXPECT, nb);
                 THX_RC(thx_expect_local_packed_dev(h->cells + (size_t)vi * cellStride, nullptr, h->P, h->pf, h->N, h->iCol, h->iRow,
@@ -670,6 +678,8 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
         { Scope s(h, st, EV_STAGE0 + ST_EXPECT); THX_RC(expectation(h, vi, st)); }
         { Scope s(h, st, EV_STAGE0 + ST_SIGMA); THX_RC(sigma_update(h, vi, st)); }
         { Scope s(h, st, EV_STAGE0 + ST_INSERT); THX_RC(insertion(h, vi, st)); }
+        if (h->cap.Fraw) THX_CHECK(hipMemcpyAsync(h->cap.Fraw + (size_t)vi * volN * 2, h->F + (size_t)vi * volN * 2, volN * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (h->cap.Traw) THX_CHECK(hipMemcpyAsync(h->cap.Traw + (size_t)vi * volN, h->T + (size_t)vi * volN, volN * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     // ---- Optimiser::reconstructRef after the insertion (src/Optimiser.cpp:7248-7760) and the run loop up to Model::resetReco
     // (:3900-4073): prepareTF; reconstruct with MAP off -> compareTwoHemispheres(fsc) -> Model::_FSC; reconstruct with MAP on
@@ -690,6 +700,7 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
             THX_RC(thx_reco_reconstruct_dev(h->plans[vi], F, T, h->rU, nullptr, 0, 1, 0, 1, h->maps + (size_t)h->halves[vi] * mapN,
                                             &iters, &diffC, st));
             h->recoRounds += iters;
+            h->lastRounds[vi] = iters;
         }
         // every rank ends up with both half maps (the reference sends them to the master, src/Model.cpp:375-391): broadcast
         // from world ranks 0 and 1, which lead halves 0 and 1 (checked in thx_refine_create)
@@ -715,6 +726,7 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
             THX_RC(thx_reco_reconstruct_dev(h->plans[vi], F, T, h->rU, h->fscReco.data(), (int)h->fscReco.size(), 1, 1, 1, m, &iters,
                                             &diffC, st));
             h->recoRounds += iters;
+            h->lastRounds[2 + vi] = iters;
         }
         if (c.goldenAverage) {
             // compareTwoHemispheres(false, true, ...), :7747: A = B = (A + B) / 2 inside r (src/Model.cpp:629-674)
@@ -763,7 +775,7 @@ int thx_refine_set_capture(thx_refine* h, const thx_refine_capture* capture)
 {
     THX_REQUIRE(h, "NULL handle");
     if (capture) h->cap = *capture;
-    else h->cap = thx_refine_capture{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    else h->cap = thx_refine_capture{};
     return 0;
 }
 
@@ -811,6 +823,7 @@ int thx_refine_get_stats(thx_refine* h, thx_refine_stats* out, int reset)
     out->iterations = h->iterations;
     out->imagePhases = h->imagePhases;
     out->nPxl = h->nPxl; out->nPxlM = h->nPxlM; out->batch = h->batch;
+    for (int i = 0; i < 4; i++) out->lastRounds[i] = h->lastRounds[i];
     if (reset) {
         h->accExpect = thx_refine_stats_acc(); h->accInsert = thx_refine_stats_acc();
         for (int i = 0; i < 8; i++) h->stageMs[i] = 0;

@@ -129,7 +129,13 @@ class NativeRefine:
         cap = dict(uR=z((c.nPhase, n, c.mLR), torch.float32), uT=z((c.nPhase, n, c.mLT), torch.float32),
                    r=z((c.nPhase, n, c.mLR, 4), torch.float64), t=z((c.nPhase, n, c.mLT, 2), torch.float64),
                    k123=z((c.nPhase, n, 3), torch.float64), s01=z((c.nPhase, n, 2), torch.float64),
-                   mapsFsc=z((2, s.N, s.N, s.N), torch.float32) if maps else None)
+                   mapsFsc=z((2, s.N, s.N, s.N), torch.float32) if maps else None,
+                   rP=z((c.nPhase, n, c.mLR, 4), torch.float64), tP=z((c.nPhase, n, c.mLT, 2), torch.float64),
+                   wRP=z((c.nPhase, n, c.mLR), torch.float64), wTP=z((c.nPhase, n, c.mLT), torch.float64))
+        if maps:
+            P, nV = s.N * s.pf, 2 if s.world == 1 else 1
+            cap["Fraw"] = z((nV, P, P, P // 2 + 1), torch.complex64)
+            cap["Traw"] = z((nV, P, P, P // 2 + 1), torch.float32)
         st = capi.RefineCapture()
         for k, v in cap.items():
             setattr(st, k, ptr(v) if v is not None else None)
