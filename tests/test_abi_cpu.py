@@ -97,3 +97,21 @@ def test_view_order_matches_python():
     rnd = normal(q)
     ang0 = np.degrees(np.arccos(np.clip(np.abs(np.sum(rnd[1:] * rnd[:-1], 1)), 0, 1)))
     assert np.median(ang) < 3.0 < 30.0 < np.median(ang0)
+
+
+def test_integration_stub_matches_interface_h():
+    """integration/Interface_thx.cpp (the reference-side replacement of gpu/interface/Interface.cpp) defines every 3-D entry
+    of gpu/interface/Interface.h:16-528 with the reference's own parameter lists (tools/iface_check.py; textual, build
+    container only -- on the GPU box the reference is absent and the script has nothing to compare)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "iface_check.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 problems" in r.stdout or "not present" in r.stdout
+    # every thx_* the stub forwards to is declared in the C ABI header
+    import re
+    stub = open(os.path.join(root, "integration", "Interface_thx.cpp")).read()
+    header = open(os.path.join(root, "include", "thunder_amd.h")).read()
+    for name in sorted(set(re.findall(r"\b(thx_\w+)\s*\(", stub))):
+        assert re.search(r"\b%s\s*\(" % name, header), name
