@@ -52,7 +52,7 @@ def cpu_baseline(args, shard, nat, rounds_per_iteration):
     from oracle import oracle as O
     import scipy.fft as sfft
     cores = os.cpu_count() or 1
-    n = min(shard.nImg, max(4, int(args.cpu_particles) if args.cpu_particles else cores))
+    n = min(shard.nImg, max(4, int(args.cpu_particles) if args.cpu_particles else 2 * cores))
     v = nat.view()
     nPxl, P, N = v.nPxl, shard.P, shard.N
     iCol, iRow = nat.fetch(v.iCol, np.int32, (nPxl,)), nat.fetch(v.iRow, np.int32, (nPxl,))
@@ -71,12 +71,29 @@ def cpu_baseline(args, shard, nat, rounds_per_iteration):
     iT = rng.integers(0, shard.mLT, size=(n, shard.mReco))
     recoRot = np.ascontiguousarray(np.take_along_axis(rot[:, -1], iR[:, :, None], axis=1))
     recoTran = np.ascontiguousarray(np.take_along_axis(tran[:, -1], iT[:, :, None], axis=1))
-    F = np.zeros((P, P, P // 2 + 1), np.complex64)
-    T = np.zeros((P, P, P // 2 + 1), np.float32)
+    # thread layout: the reference is deployed as several MPI ranks per node, each an OpenMP team with PRIVATE F / T that
+    # MPI_Allreduce_Large sums afterwards (src/Parallel.cpp:26-36, src/Reconstructor.cpp:2383,2436) -- `groups` teams of
+    # cores / groups threads here, their accumulators added up inside the timed region.  --cpu-shared also times the
+    # single-team form (every thread on ONE F / T under `omp atomic`) that round 2 reported.
+    groups = max(1, min(int(args.cpu_groups), cores))
+    F = np.zeros((groups, P, P, P // 2 + 1), np.complex64)
+    T = np.zeros((groups, P, P, P // 2 + 1), np.float32)
     t0 = time.perf_counter()
-    O.baseline_block(vol, P, shard.pf, N, pl, dat, ctf, sig, rot, tran, recoRot, recoTran, F, T)
+    O.baseline_block(vol, P, shard.pf, N, pl, dat, ctf, sig, rot, tran, recoRot, recoTran, F, T, groups=groups)
+    Fsum, Tsum = F.sum(axis=0), T.sum(axis=0)      # the hemisphere all-reduce of the groups' volumes
     t_em = time.perf_counter() - t0
     em_rate = n / t_em
+    shared = None
+    if args.cpu_shared:
+        n_sh = min(n, cores)
+        F1 = np.zeros((P, P, P // 2 + 1), np.complex64)
+        T1 = np.zeros((P, P, P // 2 + 1), np.float32)
+        t0 = time.perf_counter()
+        O.baseline_block(vol, P, shard.pf, N, pl, dat[:n_sh], ctf[:n_sh], sig[:n_sh], rot[:n_sh], tran[:n_sh], recoRot[:n_sh],
+                         recoTran[:n_sh], F1, T1, groups=1)
+        shared = {"particles": n_sh, "em_particles_per_s": n_sh / (time.perf_counter() - t0)}
+        del F1, T1
+    del F, T, Fsum, Tsum
     # ---- reconstruct leg (per iteration, independent of the particle count): the GPU's own F / T of half 0 ----
     reco = None
     if not args.cpu_no_reconstruct:
@@ -98,11 +115,14 @@ def cpu_baseline(args, shard, nat, rounds_per_iteration):
     t_iter = n_total / em_rate + (reco["seconds_per_iteration"] if reco else 0.0)
     return {"value": n_total / t_iter, "unit": "particles/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "em_particles_per_s": em_rate, "reconstruct": reco,
+            "thread_layout": "%d groups x %d threads, private F / T per group, summed at the end" % (groups, max(1, cores // groups)),
+            "single_team_shared_FT": shared,
+            "note": "a reported baseline, not the target: GPU / CPU says nothing about kernel quality, roofline.frac does",
             "sample": "E-step + insertion: %d particles x (%d phases x %d rot x %d shifts + %d inserts) through the oracle C "
-                      "port, OpenMP over images on %d threads, %.1f s; reconstruct leg: oracle gridding reconstruction on "
+                      "port, OpenMP over images on %d threads in %d groups with private F / T, %.1f s; reconstruct leg: oracle gridding reconstruction on "
                       "the %d^3 grid timed for 1 and 3 balancing rounds (scipy pocketfft, %d workers), scaled to 4 "
                       "reconstructions / %d rounds per iteration; value = %d particles / (particles / EM rate + "
-                      "reconstruct seconds)" % (n, shard.nPhase, shard.mLR, shard.mLT, shard.mReco, cores, t_em, P, cores,
+                      "reconstruct seconds)" % (n, shard.nPhase, shard.mLR, shard.mLT, shard.mReco, cores, groups, t_em, P, cores,
                                                 rounds_per_iteration, n_total)}
 
 
@@ -207,8 +227,10 @@ def main():
     ap.add_argument("--mReco", type=int, default=100)
     ap.add_argument("--batch", type=int, default=10240, help="max images per kernel launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-particles", type=int, default=0, help="CPU baseline sample (default: one particle per core)")
+    ap.add_argument("--cpu-particles", type=int, default=0, help="CPU baseline sample (default: two particles per core)")
     ap.add_argument("--cpu-no-reconstruct", action="store_true")
+    ap.add_argument("--cpu-groups", type=int, default=16, help="CPU baseline: thread groups with private F / T (MPI ranks of the reference)")
+    ap.add_argument("--cpu-shared", action="store_true", help="CPU baseline: also time the single-team form (one shared F / T)")
     ap.add_argument("--unsorted", action="store_true",
                     help="keep the particles in random order (default: stored by view direction, thx_view_order_host)")
     ap.add_argument("--classification", action="store_true",

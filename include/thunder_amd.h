@@ -193,6 +193,31 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
                    const int* cls, const thx_ctf_attr* attr, const double* dfac, int cSearch, float pixelSize,
                    const int* iCol, const int* iRow, int opf, int nPxl, int mReco, int idim, int nImg, void* stream);
 
+/* The same insertion as a SESSION over several calls (batches of images, and -- through the hemisphere communicator --
+ * several ranks) that accumulate into ONE pair of 64-bit fixed-point volumes before anything becomes a float:
+ *   bounds  DEVICE [nImg][2]: per image max(|re| + |im|) of its row and max |ctf| (they fix the image's brick quanta);
+ *   thx_insert_scale_dev: gexp DEVICE [2] = the exponents of the session's quanta from the extrema over `nImg` images of this
+ *     rank and, with hemi != NULL, over every rank of the half (one ncclMax of four numbers); nImgHemi = images of the
+ *     whole half (head-room of the 64-bit sums);
+ *   acc  DEVICE, thx_insert_acc_bytes(dim, nK) bytes, zeroed by the caller before the first accumulate call:
+ *     [nK][vol][2] F | [nK][vol] T, long long;
+ *   thx_insert_accumulate_dev: thx_insert_dev's arguments without F / T, any number of calls (bounds / w / rows of THAT call's
+ *     images);
+ *   thx_reco_allreduce_acc (thx_comm.hip): the half-set reduce on the integers -- N ranks give bit for bit the one-rank sums;
+ *   thx_insert_finish_dev: F += accF 2^-gexp[0], T += accT 2^-gexp[1].
+ * thx_insert_dev is bounds + scale + a zeroed scratch acc + accumulate + finish in one call. */
+typedef struct thx_comm thx_comm;   /* RCCL communicator handle, declared with the thx_comm_* calls below */
+size_t thx_insert_acc_bytes(int dim, int nK);
+int thx_insert_bounds_dev(float* bounds, const float* datP, const float* ctfP, int nPxl, int nImg, void* stream);
+int thx_insert_scale_dev(int* gexp, const float* bounds, const float* w, int nImg, int mReco, int cSearch, long nImgHemi,
+                         thx_comm* hemi, void* stream);
+int thx_insert_accumulate_dev(void* acc, const int* gexp, const float* bounds, double* O, int* counter, int dim, int nK,
+                              const float* datP, const float* ctfP, const float* w, const double* rotMat, const double* trans,
+                              const double* offS, const int* cls, const thx_ctf_attr* attr, const double* dfac, int cSearch,
+                              float pixelSize, const int* iCol, const int* iRow, int opf, int nPxl, int mReco, int idim, int nImg,
+                              void* stream);
+int thx_insert_finish_dev(float* F, float* T, const void* acc, const int* gexp, int dim, int nK, void* stream);
+
 /* Reconstructor::allReduceT tail (RECONSTRUCTOR_NORMALISE_T_F), src/Reconstructor.cpp:2455-2476:
  * sf = 1/T[0]; T *= sf; F *= sf.  (The sum over ranks itself is RCCL, done by the caller on F/T.) */
 int thx_normalise_tf_dev(float* F, float* T, int dim, void* stream);
@@ -442,6 +467,12 @@ int thx_comm_broadcast(thx_comm* c, void* buf, size_t bytes, int root, void* str
 size_t thx_reco_allreduce_workspace(int dim, int maxRadius, int pf);
 int thx_reco_allreduce(thx_comm* hemi, float* F, float* T, double* O, int* counter, int dim, int maxRadius, int pf,
                        void* workspace, void* stream);
+/* the same reduce on the 64-bit fixed-point accumulators of an insertion session (thx_insert_accumulate_dev), BEFORE
+ * thx_insert_finish_dev: integer sums are associative, so N ranks end with bit for bit the volumes one rank would have
+ * accumulated (gpu/src/cuthunder.cu:4972-5067 reduces floats).  workspace: thx_reco_allreduce_acc_workspace() bytes. */
+size_t thx_reco_allreduce_acc_workspace(int dim, int maxRadius, int pf);
+int thx_reco_allreduce_acc(thx_comm* hemi, void* acc, double* O, int* counter, int dim, int maxRadius, int pf, void* workspace,
+                           void* stream);
 /* the pack (unpack = 0) / unpack (unpack = 1) halves of thx_reco_allreduce on their own (parity probe of the sphere-row
  * tables on one GPU); *nVoxOut (host, optional) = packed voxels */
 int thx_reco_sphere_pack_dev(float* F, float* T, int dim, int maxRadius, int pf, void* workspace, int unpack, long* nVoxOut,

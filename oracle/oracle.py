@@ -377,19 +377,22 @@ def reconstruct(F, T, P, N, pf, maxRadius, FSC=None, joinHalf=False, MAP=True, g
     return dst
 
 
-def baseline_block(vol, P, pf, N, pl, dat, ctf_, sigRcp, rot, tran, recoRot, recoTran, F, T):
-    """bench.py cpu_baseline: fixed-work E (nPhase x nR x nT) + M (mReco inserts) for a block."""
+def baseline_block(vol, P, pf, N, pl, dat, ctf_, sigRcp, rot, tran, recoRot, recoTran, F, T, groups=1):
+    """bench.py cpu_baseline: fixed-work E (nPhase x nR x nT) + M (mReco inserts) for a block.  groups > 1: F / T are
+    [groups][P][P][P/2+1] -- one private pair per group of threads (the reference's MPI ranks); the caller sums them."""
+    if groups > 1:
+        assert F.shape[0] == groups and T.shape[0] == groups and F.flags.c_contiguous and T.flags.c_contiguous
     vol, dat, ctf_, sigRcp = c64(vol), c64(dat), f32(ctf_), f32(sigRcp)
     rot, tran, recoRot, recoTran = f64(rot), f64(tran), f64(recoRot), f64(recoTran)
     nImg, nPhase, nR = rot.shape[0], rot.shape[1], rot.shape[2]
     nT = tran.shape[2]
     mReco = recoRot.shape[1]
     wR = np.zeros((nImg, nR), np.float32)
-    lib().orc_baseline_block(_p(vol, c_f), C.c_int(P), C.c_int(pf), C.c_int(N), _p(i32(pl["iCol"]), c_i),
+    lib().orc_baseline_block_groups(_p(vol, c_f), C.c_int(P), C.c_int(pf), C.c_int(N), _p(i32(pl["iCol"]), c_i),
                              _p(i32(pl["iRow"]), c_i), _p(i32(pl["iColPad"]), c_i), _p(i32(pl["iRowPad"]), c_i),
                              C.c_int(pl["nPxl"]), C.c_int(nImg), _p(dat, c_f), _p(ctf_, c_f), _p(sigRcp, c_f),
                              _p(rot, c_d), _p(tran, c_d), C.c_int(nPhase), C.c_int(nR), C.c_int(nT), _p(recoRot, c_d),
-                             _p(recoTran, c_d), C.c_int(mReco), _p(F, c_f), _p(T, c_f), _p(wR, c_f))
+                             _p(recoTran, c_d), C.c_int(mReco), _p(F, c_f), _p(T, c_f), _p(wR, c_f), C.c_int(groups))
     return wR
 
 

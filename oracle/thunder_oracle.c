@@ -758,13 +758,25 @@ void orc_fsc(RFLOAT* dst, int nShell, const RFLOAT* A, const RFLOAT* B, int P)
 /* a block of particles, OpenMP over images exactly as HOT LOOP B / HOT LOOP C                   */
 /* (src/Optimiser.cpp:1162, :7038).  Returns nothing; the caller times it.                       */
 /* ------------------------------------------------------------------------------------------ */
-void orc_baseline_block(const RFLOAT* vol, int P, int pf, int N, const int* iCol, const int* iRow, const int* iColPad,
-                        const int* iRowPad, int nPxl, int nImg, const RFLOAT* dat, const RFLOAT* ctf,
-                        const RFLOAT* sigRcp, const double* rot /*[nImg][nPhase][nR][9]*/, const double* tran
-                        /*[nImg][nPhase][nT][2]*/, int nPhase, int nR, int nT, const double* recoRot /*[nImg][mReco][9]*/,
-                        const double* recoTran /*[nImg][mReco][2]*/, int mReco, RFLOAT* F, RFLOAT* T, RFLOAT* wRout)
+/* nGroups > 1: the threads are dealt to nGroups groups, each with its OWN pair of accumulators F [g][vol][2], T [g][vol]
+ * (threads of a group share theirs under `omp atomic`) -- the reference's deployment: several MPI ranks per node, each an
+ * OpenMP team with private _F3D / _T3D, summed by MPI_Allreduce_Large afterwards (src/Parallel.cpp:26-36,
+ * src/Reconstructor.cpp:2383,2436; the caller adds the groups up).  nGroups = 1: one team, one pair. */
+#include <omp.h>
+void orc_baseline_block_groups(const RFLOAT* vol, int P, int pf, int N, const int* iCol, const int* iRow, const int* iColPad,
+                               const int* iRowPad, int nPxl, int nImg, const RFLOAT* dat, const RFLOAT* ctf,
+                               const RFLOAT* sigRcp, const double* rot /*[nImg][nPhase][nR][9]*/, const double* tran
+                               /*[nImg][nPhase][nT][2]*/, int nPhase, int nR, int nT, const double* recoRot /*[nImg][mReco][9]*/,
+                               const double* recoTran /*[nImg][mReco][2]*/, int mReco, RFLOAT* Fall, RFLOAT* Tall, RFLOAT* wRout,
+                               int nGroups)
 {
-#pragma omp parallel for schedule(dynamic)
+    const size_t volN = (size_t)P * P * (P / 2 + 1);
+    if (nGroups < 1) nGroups = 1;
+#pragma omp parallel
+  {
+    RFLOAT* F = Fall + (size_t)(omp_get_thread_num() % nGroups) * volN * 2;
+    RFLOAT* T = Tall + (size_t)(omp_get_thread_num() % nGroups) * volN;
+#pragma omp for schedule(dynamic)
     for (int l = 0; l < nImg; l++) {
         double* pR = (double*)malloc(nR * sizeof(double));
         double* pT = (double*)malloc(nT * sizeof(double));
@@ -816,6 +828,16 @@ void orc_baseline_block(const RFLOAT* vol, int P, int pf, int N, const int* iCol
         }
         free(transImg); free(pR); free(pT); free(wR); free(wT);
     }
+  }
+}
+
+void orc_baseline_block(const RFLOAT* vol, int P, int pf, int N, const int* iCol, const int* iRow, const int* iColPad,
+                        const int* iRowPad, int nPxl, int nImg, const RFLOAT* dat, const RFLOAT* ctf,
+                        const RFLOAT* sigRcp, const double* rot, const double* tran, int nPhase, int nR, int nT,
+                        const double* recoRot, const double* recoTran, int mReco, RFLOAT* F, RFLOAT* T, RFLOAT* wRout)
+{
+    orc_baseline_block_groups(vol, P, pf, N, iCol, iRow, iColPad, iRowPad, nPxl, nImg, dat, ctf, sigRcp, rot, tran, nPhase, nR, nT,
+                              recoRot, recoTran, mReco, F, T, wRout, 1);
 }
 
 /* ========================================================================================== */

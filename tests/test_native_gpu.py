@@ -149,7 +149,7 @@ def test_native_driver_stop_rule(dev):
     assert ran.min() >= 5 and ran.max() <= 12
     assert st.imagePhases == int(ran.sum()), (st.imagePhases, int(ran.sum()))
     assert 5 * n <= st.imagePhases < 12 * n and (nP > 0).mean() > 0.5
-    assert np.all(fsc[1:5] > 0.9), fsc[:10]
+    assert np.all(fsc[1:4] > 0.9), fsc[:10]     # (the core-mask corrected curve, compareTwoHemispheres with _coreFSC)
     fixed = NativeRefine(sh)                         # the fixed-work iteration on the same particles
     fixed.reset()
     fixed.iterate()

@@ -130,6 +130,14 @@ SIGNATURES = {
                                    _vp, _vp]),
     "thx_insert_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp,
                             _vp, _i, _i, _i, _i, _i, _vp]),
+    "thx_insert_acc_bytes": (_sz, [_i, _i]),
+    "thx_insert_bounds_dev": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "thx_insert_scale_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, C.c_long, _vp, _vp]),
+    "thx_insert_accumulate_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f,
+                                       _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "thx_insert_finish_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "thx_reco_allreduce_acc_workspace": (_sz, [_i, _i, _i]),
+    "thx_reco_allreduce_acc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "thx_normalise_tf_dev": (_i, [_vp, _vp, _i, _vp]),
     "thx_symmetrize_dev": (_i, [_vp, _vp, _i, _i, _vp, _i, _d, _vp]),
     "thx_reco_create": (_i, [C.POINTER(_vp), _i, _i, _i, _f, _f]),

@@ -94,6 +94,27 @@ __global__ __launch_bounds__(256) void k_sphere_pack(float2* __restrict__ F, flo
     }
 }
 
+// the same for the 64-bit fixed-point accumulators of the insertion (acc = [F re, im per voxel | T per voxel], thx_mstep.hip):
+// buf = [2 total | total] long long
+template <int DIR>
+__global__ __launch_bounds__(256) void k_sphere_pack_acc(long long* __restrict__ accF, long long* __restrict__ accT,
+                                                         long long* __restrict__ buf, const long* __restrict__ rowOff, int P, long total)
+{
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)P * P) return;
+    const int lane = threadIdx.x & 63;
+    const long o = rowOff[row];
+    const int len = (int)(rowOff[row + 1] - o);
+    longlong2* bF = reinterpret_cast<longlong2*>(buf) + o;
+    long long* bT = buf + 2 * total + o;
+    longlong2* f = reinterpret_cast<longlong2*>(accF) + row * (P / 2 + 1);
+    long long* t = accT + row * (P / 2 + 1);
+    for (int i = lane; i < len; i += 64) {
+        if (DIR == 0) { bF[i] = f[i]; bT[i] = t[i]; }
+        else { f[i] = bF[i]; t[i] = bT[i]; }
+    }
+}
+
 }  // namespace thx
 
 using namespace thx;
@@ -203,6 +224,41 @@ int thx_reco_allreduce(thx_comm* hemi, float* F, float* T, double* O, int* count
     THX_NCCL_CHECK(ncclAllReduce(buf, buf, (size_t)sr.total * 3, ncclFloat, ncclSum, hemi->c, st));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sphere_pack<1>), dim3(blocks), dim3(256), 0, st, reinterpret_cast<float2*>(F), T, buf,
                        sr.rowOff, dim, sr.total);
+    THX_LAUNCH_CHECK();
+    if (O) THX_NCCL_CHECK(ncclAllReduce(O, O, 3, ncclDouble, ncclSum, hemi->c, st));
+    if (counter) THX_NCCL_CHECK(ncclAllReduce(counter, counter, 1, ncclInt32, ncclSum, hemi->c, st));
+    return 0;
+}
+
+size_t thx_reco_allreduce_acc_workspace(int dim, int maxRadius, int pf)
+{
+    return 2 * thx_reco_allreduce_workspace(dim, maxRadius, pf);   // 3 x 8 bytes per sphere voxel
+}
+
+// The half-set reduce BEFORE the accumulators become floats: every rank of the half has accumulated in the same quanta
+// (thx_insert_scale_dev takes the extrema over the hemisphere), integer addition is associative, so the sums of N ranks are
+// bit for bit what one rank would have accumulated over all the particles -- summing the converted floats
+// (thx_reco_allreduce) depends on how the particles were dealt to the ranks.  One ring all-reduce of the sphere rows
+// (ncclInt64: 24 bytes per voxel instead of 12).
+int thx_reco_allreduce_acc(thx_comm* hemi, void* acc, double* O, int* counter, int dim, int maxRadius, int pf, void* workspace,
+                           void* stream)
+{
+    if (!hemi || (hemi->size == 1 && !knobs().commForce)) return 0;
+    THX_REQUIRE(acc && workspace && dim > 0 && maxRadius > 0 && pf > 0, "bad arguments");
+    hipStream_t st = as_stream(stream);
+    SphereRows sr;
+    const int R = maxRadius * pf + 2;
+    THX_RC(sphere_rows(&sr, dim, R));
+    THX_REQUIRE((size_t)sr.total * 3 * sizeof(long long) <= thx_reco_allreduce_acc_workspace(dim, maxRadius, pf), "workspace too small");
+    const size_t volN = (size_t)dim * dim * (dim / 2 + 1);
+    long long* accF = reinterpret_cast<long long*>(acc);
+    long long* accT = accF + 2 * volN;
+    long long* buf = reinterpret_cast<long long*>(workspace);
+    const unsigned blocks = (unsigned)(((long)dim * dim + 3) / 4);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sphere_pack_acc<0>), dim3(blocks), dim3(256), 0, st, accF, accT, buf, sr.rowOff, dim, sr.total);
+    THX_LAUNCH_CHECK();
+    THX_NCCL_CHECK(ncclAllReduce(buf, buf, (size_t)sr.total * 3, ncclInt64, ncclSum, hemi->c, st));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sphere_pack_acc<1>), dim3(blocks), dim3(256), 0, st, accF, accT, buf, sr.rowOff, dim, sr.total);
     THX_LAUNCH_CHECK();
     if (O) THX_NCCL_CHECK(ncclAllReduce(O, O, 3, ncclDouble, ncclSum, hemi->c, st));
     if (counter) THX_NCCL_CHECK(ncclAllReduce(counter, counter, 1, ncclInt32, ncclSum, hemi->c, st));

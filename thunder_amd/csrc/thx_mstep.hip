@@ -290,9 +290,12 @@ __device__ __forceinline__ void image_exponents(float boundF, float boundT, int 
 // finest being taken at most 2^8 finer than that of the image with the largest bound (coarser images shift left exactly;
 // a rare image more than 2^8 below the largest shifts right, i.e. is rounded to the launch's quantum -- 2^-46 of the
 // largest term).  Headroom: 65535 images x 2^31 x 2^15 < 2^63.
-__global__ __launch_bounds__(256) void k_insert_scale(int* __restrict__ gexp, const float2* __restrict__ bounds,
+__global__ __launch_bounds__(256) void k_insert_scale(double* __restrict__ ext, const float2* __restrict__ bounds,
                                                       const float* __restrict__ w, int nImg, int mReco, int cSearch)
 {
+    // ext [4] = max E_F, -min E_F, max E_T, -min E_T over the images (as doubles: the hemisphere takes their maximum with
+    // one ncclMax all-reduce, so that every rank of a half works in the SAME quanta and the integer sums of the ranks add
+    // up to exactly what one rank would have accumulated)
     __shared__ int sMaxF[4], sMinF[4], sMaxT[4], sMinT[4];
     int lg = 32 - __clz(2 * mReco - 1);
     lg = lg > 20 ? 20 : lg;
@@ -314,11 +317,21 @@ __global__ __launch_bounds__(256) void k_insert_scale(int* __restrict__ gexp, co
     if ((threadIdx.x & 63) == 0) { const int wv = threadIdx.x >> 6; sMaxF[wv] = maxF; sMinF[wv] = minF; sMaxT[wv] = maxT; sMinT[wv] = minT; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int wv = 1; wv < 4; wv++) { maxF = max(maxF, sMaxF[wv]); minF = min(minF, sMinF[wv]); maxT = max(maxT, sMaxT[wv]); minT = min(minT, sMinT[wv]); }
-        maxF = max(sMaxF[0], maxF); minF = min(sMinF[0], minF); maxT = max(sMaxT[0], maxT); minT = min(sMinT[0], minT);
-        gexp[0] = minF == INT_MAX ? 0 : min(maxF, minF + 8) + 7;
-        gexp[1] = minT == INT_MAX ? 0 : min(maxT, minT + 8) + 7;
+        for (int wv = 0; wv < 4; wv++) { maxF = max(maxF, sMaxF[wv]); minF = min(minF, sMinF[wv]); maxT = max(maxT, sMaxT[wv]); minT = min(minT, sMinT[wv]); }
+        // "no image" is encoded as -1e9 on all four so that the maximum over ranks ignores it
+        ext[0] = maxF == INT_MIN ? -1e9 : (double)maxF; ext[1] = minF == INT_MAX ? -1e9 : -(double)minF;
+        ext[2] = maxT == INT_MIN ? -1e9 : (double)maxT; ext[3] = minT == INT_MAX ? -1e9 : -(double)minT;
     }
+}
+
+// gexp = 7 bits below the finest image quantum, the finest taken at most 2^8 finer than the coarsest's; `spare` bits are
+// given back when more than 2^16 images (all ranks of the half) accumulate into one volume: 2^16 x 2^31 x 2^15 < 2^63
+__global__ void k_insert_scale_final(int* __restrict__ gexp, const double* __restrict__ ext, int spare)
+{
+    const bool haveF = ext[0] > -1e8, haveT = ext[2] > -1e8;
+    const int maxF = (int)ext[0], minF = -(int)ext[1], maxT = (int)ext[2], minT = -(int)ext[3];
+    gexp[0] = haveF ? min(maxF, minF + 8) + 7 - spare : 0;
+    gexp[1] = haveT ? min(maxT, minT + 8) + 7 - spare : 0;
 }
 
 // F += accF 2^-E_F, T += accT 2^-E_T for the voxels the launch touched; one thread per voxel (deterministic)
@@ -1074,62 +1087,80 @@ __global__ __launch_bounds__(256) void k_symmetrize(float* __restrict__ dst, con
 
 using namespace thx;
 
+struct thx_comm;
+extern "C" int thx_comm_allreduce_max_f64(thx_comm* c, double* buf, size_t count, void* stream);
+
 extern "C" {
 
-int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK, const float* datP,
-                   const float* ctfP, const float* w, const double* rotMat, const double* trans, const double* offS,
-                   const int* cls, const thx_ctf_attr* attr, const double* dfac, int cSearch, float pixelSize,
-                   const int* iCol, const int* iRow, int opf, int nPxl, int mReco, int idim, int nImg, void* stream)
+size_t thx_insert_acc_bytes(int dim, int nK)
+{
+    return (size_t)dim * dim * (dim / 2 + 1) * (size_t)(nK > 0 ? nK : 1) * 3 * sizeof(long long);
+}
+
+int thx_insert_bounds_dev(float* bounds, const float* datP, const float* ctfP, int nPxl, int nImg, void* stream)
+{
+    if (nImg <= 0) return 0;
+    THX_REQUIRE(bounds && datP && ctfP && nPxl > 0, "bad arguments");
+    hipLaunchKernelGGL(k_insert_bounds, dim3(nImg), dim3(256), 0, as_stream(stream), reinterpret_cast<float2*>(bounds),
+                       reinterpret_cast<const float2*>(datP), ctfP, nPxl);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_insert_scale_dev(int* gexp, const float* bounds, const float* w, int nImg, int mReco, int cSearch, long nImgHemi,
+                         thx_comm* hemi, void* stream)
+{
+    THX_REQUIRE(gexp && (nImg <= 0 || (bounds && w)) && mReco > 0, "bad arguments");
+    hipStream_t st = as_stream(stream);
+    double* ext = reinterpret_cast<double*>(scratch(st, 11, 4 * sizeof(double)));
+    THX_REQUIRE(ext, "device scratch allocation failed");
+    hipLaunchKernelGGL(k_insert_scale, dim3(1), dim3(256), 0, st, ext, reinterpret_cast<const float2*>(bounds), w, nImg > 0 ? nImg : 0,
+                       mReco, cSearch);
+    THX_RC(thx_comm_allreduce_max_f64(hemi, ext, 4, st));
+    int spare = 0;
+    for (long n = (nImgHemi > nImg ? nImgHemi : nImg); n > 65536; n = (n + 1) / 2) spare++;
+    hipLaunchKernelGGL(k_insert_scale_final, dim3(1), dim3(1), 0, st, gexp, ext, spare);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_insert_accumulate_dev(void* acc, const int* gexp, const float* bounds, double* O, int* counter, int dim, int nK,
+                              const float* datP, const float* ctfP, const float* w, const double* rotMat, const double* trans,
+                              const double* offS, const int* cls, const thx_ctf_attr* attr, const double* dfac, int cSearch,
+                              float pixelSize, const int* iCol, const int* iRow, int opf, int nPxl, int mReco, int idim, int nImg,
+                              void* stream)
 {
     if (nImg <= 0 || mReco <= 0 || nPxl <= 0) return 0;
-    THX_REQUIRE(F && T && datP && ctfP && w && rotMat && trans && iCol && iRow, "NULL pointer");
+    THX_REQUIRE(acc && gexp && bounds && datP && ctfP && w && rotMat && trans && iCol && iRow, "NULL pointer");
     THX_REQUIRE(!cSearch || (attr && dfac), "cSearch needs attr and dfac");
     InsertArgs a;
-    a.F = reinterpret_cast<float2*>(F); a.T = T; a.O = O; a.counter = counter; a.P = dim; a.nK = nK;
+    a.F = nullptr; a.T = nullptr; a.O = O; a.counter = counter; a.P = dim; a.nK = nK;
     a.datP = reinterpret_cast<const float2*>(datP); a.ctfP = ctfP; a.w = w; a.rotMat = rotMat; a.trans = trans;
     a.offS = offS; a.cls = cls; a.attr = attr; a.dfac = dfac; a.cSearch = cSearch; a.pixelSize = pixelSize;
     a.iCol = iCol; a.iRow = iRow; a.opf = opf; a.nPxl = nPxl; a.mReco = mReco; a.idim = idim;
-    // THX_INSERT_PLAIN=1 (read once at load, thx::knobs): the plain float-atomic form k_insert for A/B runs
-    const bool win = !knobs().insertPlain;
     hipStream_t st = as_stream(stream);
-    int* pixIndex = nullptr;
-    int* plan = nullptr;
     const int half = idim / 2;
-    float2* bounds = nullptr;
-    int* gexp = nullptr;
-    long long *accF = nullptr, *accT = nullptr;
-    size_t ldsWin = 0;
-    if (win) {
-        const size_t tb = (size_t)idim * (half + 1) * sizeof(int);
-        pixIndex = reinterpret_cast<int*>(scratch(st, 0, tb));
-        THX_REQUIRE(pixIndex, "device scratch allocation failed");
-        THX_CHECK(hipMemsetAsync(pixIndex, 0xFF, tb, st));
-        hipLaunchKernelGGL(k_pix_index, dim3((nPxl + 255) / 256), dim3(256), 0, st, pixIndex, iCol, iRow, nPxl, idim);
-        plan = reinterpret_cast<int*>(scratch(st, 3, (size_t)nImg * plan_stride(mReco) * sizeof(int)));
-        THX_REQUIRE(plan, "device scratch allocation failed");
-        hipLaunchKernelGGL(k_insert_plan, dim3(nImg), dim3(128), 5 * (size_t)mReco * sizeof(int), st, plan, rotMat, trans, cls, dfac,
-                           cSearch, mReco);
-        bounds = reinterpret_cast<float2*>(scratch(st, 6, (size_t)nImg * sizeof(float2) + 16));
-        THX_REQUIRE(bounds, "device scratch allocation failed");
-        hipLaunchKernelGGL(k_insert_bounds, dim3(nImg), dim3(256), 0, st, bounds, a.datP, a.ctfP, nPxl);
-        // launch-wide fixed-point exponents + the 64-bit accumulators (zeroed; converted into F / T at the end of the call)
-        gexp = reinterpret_cast<int*>(bounds + nImg);
-        hipLaunchKernelGGL(k_insert_scale, dim3(1), dim3(256), 0, st, gexp, bounds, w, nImg, mReco, cSearch);
-        const size_t volSize = (size_t)dim * dim * (dim / 2 + 1) * (size_t)(nK > 0 ? nK : 1);
-        accF = reinterpret_cast<long long*>(scratch(st, 10, volSize * 3 * sizeof(long long)));
-        THX_REQUIRE(accF, "device scratch allocation failed (fixed-point accumulators)");
-        accT = accF + 2 * volSize;
-        THX_CHECK(hipMemsetAsync(accF, 0, volSize * 3 * sizeof(long long), st));
-        ldsWin = 3 * (size_t)kWinVox * sizeof(int) + (size_t)mReco * 6 * sizeof(double) +
-                 ((size_t)(mReco + 1) + mReco + 2 * mReco) * sizeof(int) + 2 * (size_t)mReco * sizeof(float) +
-                 4 * (size_t)mReco * sizeof(short) + 2 * (size_t)mReco * sizeof(float) + 32 +
-                 (size_t)kIPix * kIPix * sizeof(float4) + 2 * (size_t)kMaxU * kIPix * sizeof(float2) +
-                 (size_t)(kWinThreads / 64) * kWinQueue * sizeof(int);
-        THX_REQUIRE(ldsWin <= 160 * 1024, "mReco too large for the LDS draw table");
-        THX_REQUIRE(mReco <= 1024 && idim <= 2048, "window insertion packs (pixel, group) into 11 + 11 + 10 bits");
-        THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_insert_win), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)ldsWin));
-    }
+    const size_t tb = (size_t)idim * (half + 1) * sizeof(int);
+    int* pixIndex = reinterpret_cast<int*>(scratch(st, 0, tb));
+    THX_REQUIRE(pixIndex, "device scratch allocation failed");
+    THX_CHECK(hipMemsetAsync(pixIndex, 0xFF, tb, st));
+    hipLaunchKernelGGL(k_pix_index, dim3((nPxl + 255) / 256), dim3(256), 0, st, pixIndex, iCol, iRow, nPxl, idim);
+    int* plan = reinterpret_cast<int*>(scratch(st, 3, (size_t)nImg * plan_stride(mReco) * sizeof(int)));
+    THX_REQUIRE(plan, "device scratch allocation failed");
+    hipLaunchKernelGGL(k_insert_plan, dim3(nImg), dim3(128), 5 * (size_t)mReco * sizeof(int), st, plan, rotMat, trans, cls, dfac,
+                       cSearch, mReco);
+    const size_t volSize = (size_t)dim * dim * (dim / 2 + 1) * (size_t)(nK > 0 ? nK : 1);
+    long long* accF = reinterpret_cast<long long*>(acc);
+    long long* accT = accF + 2 * volSize;
+    const size_t ldsWin = 3 * (size_t)kWinVox * sizeof(int) + (size_t)mReco * 6 * sizeof(double) +
+                          ((size_t)(mReco + 1) + mReco + 2 * mReco) * sizeof(int) + 2 * (size_t)mReco * sizeof(float) +
+                          4 * (size_t)mReco * sizeof(short) + 2 * (size_t)mReco * sizeof(float) + 32 +
+                          (size_t)kIPix * kIPix * sizeof(float4) + 2 * (size_t)kMaxU * kIPix * sizeof(float2) +
+                          (size_t)(kWinThreads / 64) * kWinQueue * sizeof(int);
+    THX_REQUIRE(ldsWin <= 160 * 1024, "mReco too large for the LDS draw table");
+    THX_REQUIRE(mReco <= 1024 && idim <= 2048, "window insertion packs (pixel, group) into 11 + 11 + 10 bits");
+    THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_insert_win), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)ldsWin));
     for (int l0 = 0; l0 < nImg; l0 += 65535) {
         const int nl = nImg - l0 < 65535 ? nImg - l0 : 65535;
         InsertArgs b = a;
@@ -1139,28 +1170,76 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
         if (b.cls) b.cls += (size_t)l0 * mReco;
         if (b.attr) b.attr += l0;
         if (b.dfac) b.dfac += (size_t)l0 * mReco;
-        if (win) {
-            InsertWinArgs wa;
-            wa.a = b; wa.pixIndex = pixIndex; wa.plan = plan + (size_t)l0 * plan_stride(mReco); wa.bounds = bounds + l0;
-            wa.accF = accF; wa.accT = accT; wa.gexp = gexp;
-            wa.minQuanta = knobs().minQuanta >= 0.f ? knobs().minQuanta : kMinQuanta;
-            const int rc = half * opf + 3;
-            const int hw = (rc + kWd - 1) / kWd;
-            wa.nW = 2 * hw;
-            wa.pOrg = -hw * kWd;
-            wa.rMax2 = (float)(half * opf + 2) * (float)(half * opf + 2);
-            wa.debug = kWinProfiling ? knobs().insertDebug : 0;
-            hipLaunchKernelGGL(k_insert_win, dim3(wa.nW, nl), dim3(kWinThreads), ldsWin, st, wa);
-            hipLaunchKernelGGL(k_insert_far, dim3(nl), dim3(256), 0, st, wa);
-        } else {
-            hipLaunchKernelGGL(k_insert, dim3((nPxl + 255) / 256, nl), dim3(256), 0, st, b);
-        }
-    }
-    if (win) {
-        const size_t nVox = (size_t)dim * dim * (dim / 2 + 1) * (size_t)(nK > 0 ? nK : 1);
-        hipLaunchKernelGGL(k_insert_convert, dim3((unsigned)((nVox + 255) / 256)), dim3(256), 0, st, a.F, a.T, accF, accT, gexp, nVox);
+        InsertWinArgs wa;
+        wa.a = b; wa.pixIndex = pixIndex; wa.plan = plan + (size_t)l0 * plan_stride(mReco);
+        wa.bounds = reinterpret_cast<const float2*>(bounds) + l0;
+        wa.accF = accF; wa.accT = accT; wa.gexp = gexp;
+        wa.minQuanta = knobs().minQuanta >= 0.f ? knobs().minQuanta : kMinQuanta;
+        const int rc = half * opf + 3;
+        const int hw = (rc + kWd - 1) / kWd;
+        wa.nW = 2 * hw;
+        wa.pOrg = -hw * kWd;
+        wa.rMax2 = (float)(half * opf + 2) * (float)(half * opf + 2);
+        wa.debug = kWinProfiling ? knobs().insertDebug : 0;
+        hipLaunchKernelGGL(k_insert_win, dim3(wa.nW, nl), dim3(kWinThreads), ldsWin, st, wa);
+        hipLaunchKernelGGL(k_insert_far, dim3(nl), dim3(256), 0, st, wa);
     }
     THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_insert_finish_dev(float* F, float* T, const void* acc, const int* gexp, int dim, int nK, void* stream)
+{
+    THX_REQUIRE(F && T && acc && gexp && dim > 0, "bad arguments");
+    const size_t nVox = (size_t)dim * dim * (dim / 2 + 1) * (size_t)(nK > 0 ? nK : 1);
+    const long long* accF = reinterpret_cast<const long long*>(acc);
+    hipLaunchKernelGGL(k_insert_convert, dim3((unsigned)((nVox + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<float2*>(F), T, accF, accF + 2 * nVox, gexp, nVox);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK, const float* datP,
+                   const float* ctfP, const float* w, const double* rotMat, const double* trans, const double* offS,
+                   const int* cls, const thx_ctf_attr* attr, const double* dfac, int cSearch, float pixelSize,
+                   const int* iCol, const int* iRow, int opf, int nPxl, int mReco, int idim, int nImg, void* stream)
+{
+    if (nImg <= 0 || mReco <= 0 || nPxl <= 0) return 0;
+    THX_REQUIRE(F && T && datP && ctfP && w && rotMat && trans && iCol && iRow, "NULL pointer");
+    THX_REQUIRE(!cSearch || (attr && dfac), "cSearch needs attr and dfac");
+    hipStream_t st = as_stream(stream);
+    if (knobs().insertPlain) {   // THX_INSERT_PLAIN=1 (read once at load, thx::knobs): the plain float-atomic form k_insert for A/B runs
+        InsertArgs a;
+        a.F = reinterpret_cast<float2*>(F); a.T = T; a.O = O; a.counter = counter; a.P = dim; a.nK = nK;
+        a.datP = reinterpret_cast<const float2*>(datP); a.ctfP = ctfP; a.w = w; a.rotMat = rotMat; a.trans = trans;
+        a.offS = offS; a.cls = cls; a.attr = attr; a.dfac = dfac; a.cSearch = cSearch; a.pixelSize = pixelSize;
+        a.iCol = iCol; a.iRow = iRow; a.opf = opf; a.nPxl = nPxl; a.mReco = mReco; a.idim = idim;
+        for (int l0 = 0; l0 < nImg; l0 += 65535) {
+            const int nl = nImg - l0 < 65535 ? nImg - l0 : 65535;
+            InsertArgs b = a;
+            b.datP += (size_t)l0 * nPxl; b.ctfP += (size_t)l0 * nPxl; b.w += l0;
+            b.rotMat += (size_t)l0 * mReco * 9; b.trans += (size_t)l0 * mReco * 2;
+            if (b.offS) b.offS += (size_t)l0 * 2;
+            if (b.cls) b.cls += (size_t)l0 * mReco;
+            if (b.attr) b.attr += l0;
+            if (b.dfac) b.dfac += (size_t)l0 * mReco;
+            hipLaunchKernelGGL(k_insert, dim3((nPxl + 255) / 256, nl), dim3(256), 0, st, b);
+        }
+        THX_LAUNCH_CHECK();
+        return 0;
+    }
+    // one-call form of the session below: bounds -> quanta -> zeroed 64-bit accumulators -> accumulate -> F / T += them
+    float* bounds = reinterpret_cast<float*>(scratch(st, 6, (size_t)nImg * 2 * sizeof(float) + 16));
+    THX_REQUIRE(bounds, "device scratch allocation failed");
+    int* gexp = reinterpret_cast<int*>(bounds + 2 * (size_t)nImg);
+    void* acc = scratch(st, 10, thx_insert_acc_bytes(dim, nK));
+    THX_REQUIRE(acc, "device scratch allocation failed (fixed-point accumulators)");
+    THX_RC(thx_insert_bounds_dev(bounds, datP, ctfP, nPxl, nImg, stream));
+    THX_RC(thx_insert_scale_dev(gexp, bounds, w, nImg, mReco, cSearch, nImg, nullptr, stream));
+    THX_CHECK(hipMemsetAsync(acc, 0, thx_insert_acc_bytes(dim, nK), st));
+    THX_RC(thx_insert_accumulate_dev(acc, gexp, bounds, O, counter, dim, nK, datP, ctfP, w, rotMat, trans, offS, cls, attr, dfac, cSearch,
+                                     pixelSize, iCol, iRow, opf, nPxl, mReco, idim, nImg, stream));
+    THX_RC(thx_insert_finish_dev(F, T, acc, gexp, dim, nK, stream));
     return 0;
 }
 

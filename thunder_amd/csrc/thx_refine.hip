@@ -21,6 +21,7 @@ extern "C" {
 int thx_comm_rank(const thx_comm* c);
 int thx_comm_size(const thx_comm* c);
 int thx_comm_allreduce_f32(thx_comm* c, float* buf, size_t count, void* stream);
+int thx_comm_allreduce_f64(thx_comm* c, double* buf, size_t count, void* stream);
 int thx_comm_broadcast(thx_comm* c, void* buf, size_t bytes, int root, void* stream);
 size_t thx_reco_allreduce_workspace(int dim, int maxRadius, int pf);
 int thx_compare_hemispheres_dev(float* A, float* B, int N, int rU, float* fscHost, const float* maskRL, float coreR, float ew,
@@ -29,6 +30,9 @@ int thx_compare_hemispheres_dev(float* A, float* B, int N, int rU, float* fscHos
 int thx_soft_mask_volume_dev(float* vol, int N, float r, float ew, float bg, void* stream);
 int thx_reco_allreduce(thx_comm* hemi, float* F, float* T, double* O, int* counter, int dim, int maxRadius, int pf,
                        void* workspace, void* stream);
+size_t thx_reco_allreduce_acc_workspace(int dim, int maxRadius, int pf);
+int thx_reco_allreduce_acc(thx_comm* hemi, void* acc, double* O, int* counter, int dim, int maxRadius, int pf, void* workspace,
+                           void* stream);
 }
 
 namespace thx {
@@ -217,6 +221,10 @@ struct thx_refine {
     double *rotB, *recoRot, *recoTran, *rotTop, *tranTop;
     float *uR, *uT, *wC, *wD, *baseL, *spec;
     void *wsExpect, *wsReduce;
+    void* accInt = nullptr;      // 64-bit fixed-point accumulators of the insertion session (one half at a time)
+    float* bounds = nullptr;     // [nImg][2] per-image bounds of the M-step rows (they never change)
+    int* gexp = nullptr;         // [2] the session's quanta
+    long nImgHemi = 0;           // images of this rank's half over all its ranks (head-room of the sums)
     unsigned pfCall = 0, iterCount = 0;
     int *active = nullptr, *nP = nullptr, *nActiveDev = nullptr;   // per-image stop rule
     double* stopState = nullptr;
@@ -414,20 +422,29 @@ int insertion(thx_refine* h, int vi, hipStream_t st)
     float* T = h->T + (size_t)vi * volN;
     THX_CHECK(hipMemsetAsync(F, 0, volN * 2 * sizeof(float), st));
     THX_CHECK(hipMemsetAsync(T, 0, volN * sizeof(float), st));
-    if (n <= 0) return 0;
-    h->pfCall++;
-    hipLaunchKernelGGL(k_draw_reco, dim3(blocks_for((size_t)n * c.mReco)), dim3(256), 0, st, h->recoRot, h->recoTran,
-                       h->r + (size_t)lo * c.mLR * 4, h->t + (size_t)lo * c.mLT * 2, n, c.mLR, c.mLT, c.mReco, c.seed, h->pfCall,
-                       (unsigned)lo);
-    THX_LAUNCH_CHECK();
+    // one insertion SESSION per half: common quanta over every image of the half (all ranks), 64-bit accumulators zeroed once,
+    // all batches accumulate into them, the half-set reduce runs on the integers (N ranks == 1 rank, bit for bit), and only
+    // then do they become the float F / T that prepareTF normalises
+    THX_RC(thx_insert_scale_dev(h->gexp, h->bounds + (size_t)lo * 2, h->w + lo, n > 0 ? n : 0, c.mReco, 0, h->nImgHemi, h->hemi, st));
+    THX_CHECK(hipMemsetAsync(h->accInt, 0, thx_insert_acc_bytes(h->P, 1), st));
+    if (n > 0) {
+        h->pfCall++;
+        hipLaunchKernelGGL(k_draw_reco, dim3(blocks_for((size_t)n * c.mReco)), dim3(256), 0, st, h->recoRot, h->recoTran,
+                           h->r + (size_t)lo * c.mLR * 4, h->t + (size_t)lo * c.mLT * 2, n, c.mLR, c.mLT, c.mReco, c.seed, h->pfCall,
+                           (unsigned)lo);
+        THX_LAUNCH_CHECK();
+    }
     for (int b0 = lo; b0 < h->hi[vi]; b0 += h->batch) {
         const int nb = std::min(h->batch, h->hi[vi] - b0);
         Scope ev(h, st, EV_INSERT, nb);
-        THX_RC(thx_insert_dev(F, T, nullptr, nullptr, h->P, 1, h->datM + (size_t)b0 * h->nPxlM * 2, h->ctfM + (size_t)b0 * h->nPxlM,
-                              h->w + b0, h->recoRot + (size_t)(b0 - lo) * c.mReco * 9, h->recoTran + (size_t)(b0 - lo) * c.mReco * 2,
-                              h->offset + (size_t)b0 * 2, nullptr, nullptr, nullptr, 0, c.pixelSize, h->iColM, h->iRowM, h->pf,
-                              h->nPxlM, c.mReco, h->N, nb, st));
+        THX_RC(thx_insert_accumulate_dev(h->accInt, h->gexp, h->bounds + (size_t)b0 * 2, nullptr, nullptr, h->P, 1,
+                                         h->datM + (size_t)b0 * h->nPxlM * 2, h->ctfM + (size_t)b0 * h->nPxlM, h->w + b0,
+                                         h->recoRot + (size_t)(b0 - lo) * c.mReco * 9, h->recoTran + (size_t)(b0 - lo) * c.mReco * 2,
+                                         h->offset + (size_t)b0 * 2, nullptr, nullptr, nullptr, 0, c.pixelSize, h->iColM, h->iRowM, h->pf,
+                                         h->nPxlM, c.mReco, h->N, nb, st));
     }
+    THX_RC(thx_reco_allreduce_acc(h->hemi, h->accInt, nullptr, nullptr, h->P, h->rU, h->pf, h->wsReduce, st));
+    THX_RC(thx_insert_finish_dev(F, T, h->accInt, h->gexp, h->P, 1, st));
     return 0;
 }
 
@@ -583,8 +600,13 @@ int thx_refine_create(thx_refine** out, const thx_refine_config* cfg, thx_comm* 
         RC_OR_FREE(dalloc(h, &ws, thx_expect_local_workspace((int)B, c.mLR, c.mLT, 1)));
         h->wsExpect = ws;
         char* wr = nullptr;
-        RC_OR_FREE(dalloc(h, &wr, hemi ? thx_reco_allreduce_workspace(h->P, h->rU, c.pf) : 16));
+        RC_OR_FREE(dalloc(h, &wr, hemi ? thx_reco_allreduce_acc_workspace(h->P, h->rU, c.pf) : 16));
         h->wsReduce = wr;
+        char* ac = nullptr;
+        RC_OR_FREE(dalloc(h, &ac, thx_insert_acc_bytes(h->P, 1)));
+        h->accInt = ac;
+        RC_OR_FREE(dalloc(h, &h->bounds, n * 2));
+        RC_OR_FREE(dalloc(h, &h->gexp, (size_t)2));
     }
     for (int v = 0; v < h->nV; v++) RC_OR_FREE(thx_reco_create(&h->plans[v], c.N, c.N, c.pf, 1.9f, 15.0f));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill<double>), dim3(blocks_for(B)), dim3(256), 0, nullptr, h->pD, 1.0, B);
@@ -617,6 +639,19 @@ int thx_refine_set_particles(thx_refine* h, const float* imgOri, const thx_ctf_a
     THX_RC(thx_gather_pixels_dev(h->datM, imgOri, h->iPxlM, h->nPxlM, h->N, (int)n, st));
     THX_RC(thx_ctf_dev(h->ctfM, h->attr, nullptr, c.pixelSize, h->iColM, h->iRowM, h->nPxlM, h->N, (int)n, st));
     THX_RC(thx_ctf_dev(h->ctfP, h->attr, nullptr, c.pixelSize, h->iCol, h->iRow, h->nPxl, h->N, (int)n, st));
+    THX_RC(thx_insert_bounds_dev(h->bounds, h->datM, h->ctfM, h->nPxlM, (int)n, st));
+    {   // images of this rank's half over all of its ranks (the 64-bit sums' head-room, thx_insert_scale_dev)
+        double* cnt = reinterpret_cast<double*>(scratch(st, 7, sizeof(double)));
+        THX_REQUIRE(cnt, "device scratch allocation failed");
+        const double mine = (double)(h->nV == 2 ? std::max(h->hi[0] - h->lo[0], h->hi[1] - h->lo[1]) : h->nImg);
+        THX_CHECK(hipMemcpyAsync(cnt, &mine, sizeof(double), hipMemcpyHostToDevice, st));
+        THX_CHECK(hipStreamSynchronize(st));
+        THX_RC(thx_comm_allreduce_f64(h->hemi, cnt, 1, st));
+        double tot = mine;
+        THX_CHECK(hipMemcpyAsync(&tot, cnt, sizeof(double), hipMemcpyDeviceToHost, st));
+        THX_CHECK(hipStreamSynchronize(st));
+        h->nImgHemi = (long)tot;
+    }
     THX_CHECK(hipStreamSynchronize(st));   // g0 is a host temporary
     return 0;
 }
@@ -694,8 +729,7 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
         for (int vi = 0; vi < h->nV; vi++) {
             float* F = h->F + (size_t)vi * volN * 2;
             float* T = h->T + (size_t)vi * volN;
-            THX_RC(thx_reco_allreduce(h->hemi, F, T, nullptr, nullptr, h->P, h->rU, h->pf, h->wsReduce, st));
-            THX_RC(thx_normalise_tf_dev(F, T, h->P, st));
+            THX_RC(thx_normalise_tf_dev(F, T, h->P, st));   // (the half-set reduce ran on the fixed-point accumulators, insertion())
             // setMAP(false); setJoinHalf(true) (OPTIMISER_RECONSTRUCT_JOIN_HALF); setGridCorr(true) (OPTIMISER_3D_GRID_CORR), :7326-7352
             THX_RC(thx_reco_reconstruct_dev(h->plans[vi], F, T, h->rU, nullptr, 0, 1, 0, 1, h->maps + (size_t)h->halves[vi] * mapN,
                                             &iters, &diffC, st));

@@ -231,7 +231,7 @@ def fft3d_fw(rl):
 def fft3d_bw(ft, n):
     """FFT::bw (c2r incl. 1/size) of a half-complex [n][n][n/2+1] FT; the input is destroyed"""
     rl = torch.empty((n, n, n), dtype=torch.float32, device=ft.device)
-    call("thx_fft3d_bw_dev", ptr(ft), ptr(rl), n, stream_ptr())
+    capi.call("thx_fft3d_bw_dev", ptr(ft), ptr(rl), n, stream_ptr())
     return rl
 
 
@@ -239,13 +239,13 @@ def compare_hemispheres(A, B, N, rU, fsc=True, coreR=0.0, ew=6.0, avg_r=None, se
     """Model::compareTwoHemispheres on two half-map FTs (in place for the averaging) -> FSC [rU] (numpy) or None"""
     import numpy as np
     out = np.zeros(rU, np.float32) if fsc else None
-    call("thx_compare_hemispheres_dev", ptr(A), ptr(B), N, rU, out.ctypes.data if fsc else None, None, float(coreR), float(ew),
+    capi.call("thx_compare_hemispheres_dev", ptr(A), ptr(B), N, rU, out.ctypes.data if fsc else None, None, float(coreR), float(ew),
          0 if avg_r is None else 1, 0 if avg_r is None else int(avg_r), int(seed), int(call_id), None, stream_ptr())
     return out
 
 
 def soft_mask_volume(vol, r, ew=6.0, bg=0.0):
-    call("thx_soft_mask_volume_dev", ptr(vol), vol.shape[0], float(r), float(ew), float(bg), stream_ptr())
+    capi.call("thx_soft_mask_volume_dev", ptr(vol), vol.shape[0], float(r), float(ew), float(bg), stream_ptr())
     return vol
 
 
