@@ -217,6 +217,10 @@ int thx_insert_accumulate_dev(void* acc, const int* gexp, const float* bounds, d
                               float pixelSize, const int* iCol, const int* iRow, int opf, int nPxl, int mReco, int idim, int nImg,
                               void* stream);
 int thx_insert_finish_dev(float* F, float* T, const void* acc, const int* gexp, int dim, int nK, void* stream);
+/* measurement: (image, group) pairs inserted on the current device since the last reset -- a group = the draws of an image
+ * that share a rotation [, class, defocus factor] and are inserted as one; the window kernel issues 24 LDS adds per listed
+ * pixel and GROUP (8 voxels x re, im, T), which is what its roofline counts (bench.py).  Synchronises the stream. */
+int thx_insert_groups_total(unsigned long long* out, int reset, void* stream);
 
 /* Reconstructor::allReduceT tail (RECONSTRUCTOR_NORMALISE_T_F), src/Reconstructor.cpp:2455-2476:
  * sf = 1/T[0]; T *= sf; F *= sf.  (The sum over ranks itself is RCCL, done by the caller on F/T.) */
@@ -430,6 +434,13 @@ int thx_pf_stop_init_dev(int* active, int* nP, double* state, double transS, dou
 int thx_pf_stop_rule_dev(int* active, int* nP, double* state, const double* k123, const double* s01, const double* sD, int phase,
                          int nImg, int* nActive, void* stream);
 
+/* The class of every image after the global scan, src/Optimiser.cpp:925-952: uC [nImg][nK] = the scan's class weights (wC of
+ * thx_expect_global_dev), wC [nImg][nK] the filter's class priors (NULL = 1 / nK) -> keepHalfHeightPeak(PAR_C) with
+ * peakFactorC (PEAK_FACTOR_C = 1 - 1e-2), resample(k, PAR_C), Particle::rand(cls).  cls [nImg] out.  Philox streams
+ * (seed, image, call, 6 = shuffle keys / 7 = u0 / 8 = the pick). */
+int thx_pf_class_select_dev(int* cls, const float* uC, const double* wC, int nImg, int nK, double peakFactorC,
+                            unsigned long long seed, unsigned call, void* stream);
+
 /* The deterministic ACG statistics on their own (parity probe): for quat [nImg][n][4] -> A [nImg][16] (inferACG,
  * DirectionalStat.cpp:93-145), mean [nImg][4] (:224-262), k123 [nImg][3] (calVari's mean-frame ratios), wBal [nImg][n]
  * (balanceWeight(PAR_R)), rounds [nImg][2] fixed-point rounds of the two inferACG calls (may be NULL). */
@@ -555,6 +566,7 @@ typedef struct thx_refine_stats {
     long balancingRounds, iterations;
     long imagePhases;                     /* sum over images of the phases they ran (Optimiser::_nF) */
     int nPxl, nPxlM, batch;
+    unsigned long long insertGroups;      /* (image, group) pairs the insertion launches of the timed iterations processed */
     int lastRounds[4];                    /* balancing rounds of the last iteration's reconstructions: MAP off, local halves 0 / 1;
                                              MAP on, local halves 0 / 1 (0 where this rank holds no such half) */
 } thx_refine_stats;

@@ -640,6 +640,17 @@ def pf_update(q, t, wR, wT, uR, uT, peakFactorR, rankR, u0R, rankT, u0T):
                 iTopR=topR, iTopT=topT, qPre=q, uRk=u, uTk=ut)
 
 
+def pf_class_select(uC, wC, peakFactorC, rank, u0, pick):
+    """the class an image continues with after the global scan, src/Optimiser.cpp:925-952: setUC, setPeakFactor(PAR_C)
+    (PARTICLE_PEAK_FACTOR_C: 1 - 1e-2), keepHalfHeightPeak(PAR_C), resample(k, PAR_C) (src/Particle.cpp:1296-1338), rand(cls)
+    (:2109-2120).  Draws as inputs: rank (shuffle), u0 in [0, 1 / k), pick in [0, k)."""
+    k = len(uC)
+    u = f64(np.asarray(uC, np.float32).astype(np.float64)).copy()
+    lib().orc_keep_half_height_peak(_dp(u), C.c_int(k), C.c_double(peakFactorC))
+    cls, _, src, _ = pf_resample(np.arange(k), f64(wC), u, rank, u0)
+    return int(cls[int(pick)])
+
+
 def cal_vari(q, t):
     """Particle::calVari(PAR_R) + (PAR_T) -> (k [3], s [2]) (q is rotated to the mean frame and back: a copy here)"""
     q = f64(q).copy()

@@ -155,3 +155,70 @@ def test_native_driver_stop_rule(dev):
     fixed.iterate()
     assert fixed.stats().imagePhases == 3 * n
     nat.close(); fixed.close()
+
+
+def test_insertion_session_ranks_add_up_bitwise(dev, knob_env):
+    """the half-set reduce on the 64-bit fixed-point accumulators (thx_insert_scale_dev -> thx_insert_accumulate_dev ->
+    thx_reco_allreduce_acc -> thx_insert_finish_dev): two 'ranks' holding different particles of a half, working in the common
+    quanta, sum to bit for bit the F / T one rank accumulates over all of them, in any batching -- checked on one GPU by
+    adding the two ranks' accumulators as integers (what ncclSum over ncclInt64 does); the real collective runs on a forced
+    one-rank communicator (identity) through the same pack / unpack of the sphere rows."""
+    from thunder_amd import capi, ops, synth
+    from thunder_amd.capi import ptr, stream_ptr
+    from thunder_amd.native import Comm
+    from thunder_amd.refine import pixel_list
+    rng = np.random.default_rng(31)
+    N, P, nImg, mReco = 64, 128, 90, 24
+    rU = N // 2 - 2
+    pl = pixel_list(N, rU, 0)
+    nPxl = pl["nPxl"]
+    T_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dat = T_((rng.normal(size=(nImg, nPxl)) + 1j * rng.normal(size=(nImg, nPxl))).astype(np.complex64) * rng.uniform(0.01, 30, size=(nImg, 1)).astype(np.float32))
+    ctf = T_(rng.uniform(-1, 1, size=(nImg, nPxl)).astype(np.float32))
+    w = T_((rng.uniform(0.2, 1.0, size=nImg) / mReco).astype(np.float32))
+    q0 = synth.random_quats(nImg, rng)
+    quat = synth.perturb_quats(q0, mReco, 0.03, rng)
+    quat[:, 1::2] = quat[:, 0:-1:2]                       # repeated support points, as a resampled filter gives
+    rot = ops.rotmat(T_(quat.reshape(-1, 4))).reshape(nImg, mReco, 9)
+    trn = T_(rng.normal(0, 1.5, size=(nImg, mReco, 2)))
+    iCol, iRow = T_(pl["iCol"]), T_(pl["iRow"])
+    L = capi.load()
+    nacc = L.thx_insert_acc_bytes(P, 1) // 8
+    bounds = torch.empty((nImg, 2), dtype=torch.float32, device=dev)
+    gexp = torch.zeros(2, dtype=torch.int32, device=dev)
+    capi.call("thx_insert_bounds_dev", ptr(bounds), ptr(dat), ptr(ctf), nPxl, nImg, stream_ptr())
+    capi.call("thx_insert_scale_dev", ptr(gexp), ptr(bounds), ptr(w), nImg, mReco, 0, nImg, None, stream_ptr())
+
+    def accumulate(acc, lo, hi):
+        capi.call("thx_insert_accumulate_dev", ptr(acc), ptr(gexp), ptr(bounds[lo:hi]), None, None, P, 1, ptr(dat[lo:hi]), ptr(ctf[lo:hi]),
+                  ptr(w[lo:hi]), ptr(rot[lo:hi]), ptr(trn[lo:hi]), None, None, None, None, 0, 1.32, ptr(iCol), ptr(iRow), 2, nPxl, mReco, N,
+                  hi - lo, stream_ptr())
+
+    def finish(acc):
+        F = torch.zeros((P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
+        Tt = torch.zeros((P, P, P // 2 + 1), dtype=torch.float32, device=dev)
+        capi.call("thx_insert_finish_dev", ptr(F), ptr(Tt), ptr(acc), ptr(gexp), P, 1, stream_ptr())
+        return F, Tt
+    one = torch.zeros(nacc, dtype=torch.int64, device=dev)
+    accumulate(one, 0, nImg)
+    F1, T1 = finish(one)
+    # two ranks (uneven shares), each in two batches, summed as integers
+    a, b = torch.zeros(nacc, dtype=torch.int64, device=dev), torch.zeros(nacc, dtype=torch.int64, device=dev)
+    accumulate(a, 0, 20); accumulate(a, 20, 37)
+    accumulate(b, 37, 80); accumulate(b, 80, nImg)
+    F2, T2 = finish(a + b)
+    assert torch.equal(F1, F2) and torch.equal(T1, T2)
+    # the one-call form uses the same session
+    F3 = torch.zeros_like(F1); T3 = torch.zeros_like(T1)
+    ops.insert(F3, T3, P, dat, ctf, w, rot, trn, iCol, iRow, 2, N)
+    assert torch.equal(F1, F3) and torch.equal(T1, T3)
+    # thx_reco_allreduce_acc on a forced one-rank communicator: pack sphere rows -> ncclAllReduce(ncclInt64) -> unpack = identity
+    # inside the sphere; nothing the insertion wrote lies outside it
+    knob_env("THX_COMM_FORCE", "1")
+    comm = Comm(0, 1, lambda uid: uid)
+    ws = torch.empty(L.thx_reco_allreduce_acc_workspace(P, rU, 2), dtype=torch.uint8, device=dev)
+    red = one.clone()
+    capi.call("thx_reco_allreduce_acc", comm.handle, ptr(red), None, None, P, rU, 2, ptr(ws), stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(red, one)
+    comm.close()

@@ -215,3 +215,33 @@ def test_stop_rule_matches_oracle(oracle, dev):
     off = (act == 0)
     assert torch.equal(q[off], q0[off]) and torch.equal(t[off], t0[off])
     assert not torch.equal(q[~off], q0[~off])
+
+
+def test_class_select_after_scan(oracle, dev):
+    """PAR_C after the global scan (src/Optimiser.cpp:925-952): keepHalfHeightPeak(PAR_C) at PEAK_FACTOR_C = 0.99, resample(k, PAR_C),
+    rand(cls) -- the device kernel against the oracle with replayed draws; clear winners give the arg-max, weights within
+    1 % of the largest share the image between the classes"""
+    from thunder_amd import ops
+    O = oracle
+    rng = np.random.default_rng(41)
+    nImg, K, seed, call = 400, 4, 99991, 3
+    uC = rng.uniform(0.0, 1.0, size=(nImg, K)).astype(np.float32) ** 6
+    close = rng.choice(nImg, 120, replace=False)              # near-ties: a second class within 1 % of the best
+    for l in close:
+        a, b = rng.choice(K, 2, replace=False)
+        uC[l, a] = uC[l].max() * 1.2
+        uC[l, b] = uC[l, a] * np.float32(rng.uniform(0.991, 0.9999))
+    wC = rng.uniform(0.5, 1.5, size=(nImg, K))
+    wC /= wC.sum(1, keepdims=True)
+    got = ops.pf_class_select(T(uC, dev), seed, call, wC=T(wC, dev)).cpu().numpy()
+    want = np.empty(nImg, np.int64)
+    for l in range(nImg):
+        rank = PH.shuffle_ranks(seed, l, call, 6, K)
+        u0 = PH.draw_u4(seed, l, call, 7, 0)[0] / K
+        pick = min(int(PH.draw_u4(seed, l, call, 8, 0)[0] * K), K - 1)
+        want[l] = O.pf_class_select(uC[l], wC[l], 1.0 - 1e-2, rank, u0, pick)
+    assert np.array_equal(got, want)
+    clear = np.setdiff1d(np.arange(nImg), close)
+    assert np.array_equal(got[clear], uC[clear].argmax(1))
+    second = np.mean(got[close] != uC[close].argmax(1))
+    assert 0.02 < second < 0.6, second                         # the runner-up within 1 % keeps a share (u - 0.99 max)

@@ -45,7 +45,7 @@ class RefineStats(C.Structure):
                 ("insertLaunches", C.c_long), ("insertImages", C.c_long), ("stageMs", C.c_double * 8),
                 ("balancingRounds", C.c_long), ("iterations", C.c_long), ("imagePhases", C.c_long), ("nPxl", C.c_int),
                 ("nPxlM", C.c_int),
-                ("batch", C.c_int), ("lastRounds", C.c_int * 4)]
+                ("batch", C.c_int), ("insertGroups", C.c_ulonglong), ("lastRounds", C.c_int * 4)]
 
 
 class RefineView(C.Structure):
@@ -136,6 +136,7 @@ SIGNATURES = {
     "thx_insert_accumulate_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f,
                                        _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "thx_insert_finish_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "thx_insert_groups_total": (_i, [_vp, _i, _vp]),
     "thx_reco_allreduce_acc_workspace": (_sz, [_i, _i, _i]),
     "thx_reco_allreduce_acc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "thx_normalise_tf_dev": (_i, [_vp, _vp, _i, _vp]),
@@ -171,6 +172,7 @@ SIGNATURES = {
     "thx_pf_stop_init_dev": (_i, [_vp, _vp, _vp, _d, _d, _i, _vp]),
     "thx_pf_stop_rule_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "thx_pf_acg_stats_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "thx_pf_class_select_dev": (_i, [_vp, _vp, _vp, _i, _i, _d, C.c_ulonglong, C.c_uint, _vp]),
     "thx_ExpectProject_host": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "thx_ExpectRotran_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "thx_InsertFT_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i,

@@ -201,6 +201,17 @@ __global__ __launch_bounds__(128) void k_insert_plan(int* __restrict__ plan, con
     for (int m = tid; m < mReco; m += blockDim.x) ouid[m] = uid[m];
 }
 
+// sum of the group counts of a launch's images (plan[0] of each) into a running device counter: the adds the window kernel
+// actually issues are 24 per (listed pixel, GROUP), not per draw
+__global__ void k_plan_groups(unsigned long long* __restrict__ total, const int* __restrict__ plan, int nImg, int stride)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long g = l < nImg ? (unsigned long long)plan[(size_t)l * stride] : 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o, 64);
+    if ((threadIdx.x & 63) == 0 && g) atomicAdd(total, g);
+}
+
 template <int W>
 __device__ __forceinline__ int comp3(int x, int y, int z) { return W == 0 ? x : (W == 1 ? y : z); }
 
@@ -1087,6 +1098,20 @@ __global__ __launch_bounds__(256) void k_symmetrize(float* __restrict__ dst, con
 
 using namespace thx;
 
+// running count of (image, group) pairs inserted on this device since the last thx_insert_groups_total(reset): one 8-byte
+// device word per device, allocated on first use
+static unsigned long long* group_counter()
+{
+    static unsigned long long* ctr[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!ctr[dev]) {
+        if (hipMalloc(reinterpret_cast<void**>(&ctr[dev]), sizeof(unsigned long long)) != hipSuccess) return nullptr;
+        (void)hipMemset(ctr[dev], 0, sizeof(unsigned long long));
+    }
+    return ctr[dev];
+}
+
 struct thx_comm;
 extern "C" int thx_comm_allreduce_max_f64(thx_comm* c, double* buf, size_t count, void* stream);
 
@@ -1149,6 +1174,8 @@ int thx_insert_accumulate_dev(void* acc, const int* gexp, const float* bounds, d
     THX_REQUIRE(plan, "device scratch allocation failed");
     hipLaunchKernelGGL(k_insert_plan, dim3(nImg), dim3(128), 5 * (size_t)mReco * sizeof(int), st, plan, rotMat, trans, cls, dfac,
                        cSearch, mReco);
+    if (unsigned long long* gc = group_counter())
+        hipLaunchKernelGGL(k_plan_groups, dim3((nImg + 255) / 256), dim3(256), 0, st, gc, plan, nImg, plan_stride(mReco));
     const size_t volSize = (size_t)dim * dim * (dim / 2 + 1) * (size_t)(nK > 0 ? nK : 1);
     long long* accF = reinterpret_cast<long long*>(acc);
     long long* accT = accF + 2 * volSize;
@@ -1185,6 +1212,18 @@ int thx_insert_accumulate_dev(void* acc, const int* gexp, const float* bounds, d
         hipLaunchKernelGGL(k_insert_far, dim3(nl), dim3(256), 0, st, wa);
     }
     THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_insert_groups_total(unsigned long long* out, int reset, void* stream)
+{
+    THX_REQUIRE(out, "NULL pointer");
+    unsigned long long* gc = group_counter();
+    THX_REQUIRE(gc, "no device counter");
+    hipStream_t st = as_stream(stream);
+    THX_CHECK(hipMemcpyAsync(out, gc, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    if (reset) THX_CHECK(hipMemsetAsync(gc, 0, sizeof(unsigned long long), st));
+    THX_CHECK(hipStreamSynchronize(st));
     return 0;
 }
 

@@ -485,6 +485,59 @@ __global__ void k_pf_stop_init(int* __restrict__ active, int* __restrict__ nP, d
     st[6] = 0.0; st[7] = 0.0;
 }
 
+// Class selection after the global scan, src/Optimiser.cpp:925-952: setUC(wC) -> setPeakFactor(PAR_C) (PARTICLE_PEAK_FACTOR_C:
+// _peakFactorC = PEAK_FACTOR_C = 1 - 1e-2) -> keepHalfHeightPeak(PAR_C) -> resample(k, PAR_C) (shuffle, w *= u, systematic
+// resampling, src/Particle.cpp:1296-1338) -> Particle::rand(cls) (uniform pick among the k resampled classes, :2109-2120).
+// One thread per image (k <= 64 classes): Philox streams (seed, image, call, 6 / 7 / 8, .).
+constexpr int kMaxClasses = 64;
+__global__ void k_pf_class_select(int* __restrict__ cls, const float* __restrict__ uC, const double* __restrict__ wC, int nImg, int nK,
+                                  double peakFactorC, unsigned long long seed, unsigned call)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nImg) return;
+    double u[kMaxClasses], w[kMaxClasses], su[kMaxClasses], sw[kMaxClasses];
+    int sc[kMaxClasses];
+    unsigned key[kMaxClasses];
+    double umax = -1.0;
+    for (int i = 0; i < nK; i++) {
+        u[i] = (double)uC[(size_t)l * nK + i];
+        w[i] = wC ? wC[(size_t)l * nK + i] : 1.0 / nK;
+        if (u[i] > umax) umax = u[i];
+    }
+    const double hh = umax * peakFactorC;
+    for (int i = 0; i < nK; i++) u[i] = (u[i] < hh) ? 0.0 : u[i] - hh;
+    for (int i = 0; i < nK; i++) {
+        Philox g{(unsigned)seed, (unsigned)(seed >> 32)};
+        unsigned c[4] = {(unsigned)l, call, 6u, (unsigned)i};
+        g(c);
+        key[i] = c[0];
+    }
+    for (int i = 0; i < nK; i++) {
+        int rank = 0;
+        for (int j = 0; j < nK; j++) rank += (key[j] < key[i]) || (key[j] == key[i] && j < i);
+        sc[rank] = i; sw[rank] = w[i]; su[rank] = u[i];
+    }
+    double sum = 0;
+    for (int i = 0; i < nK; i++) sum += sw[i] * su[i];
+    double cdf[kMaxClasses], acc = 0;
+    for (int i = 0; i < nK; i++) { acc += (sw[i] * su[i]) / sum; cdf[i] = acc; }
+    const double last = cdf[nK - 1];
+    for (int i = 0; i < nK; i++) cdf[i] /= last;
+    double d4[4];
+    draw_u4(d4, seed, (unsigned)l, call, 7u, 0);
+    const double u0 = d4[0] * (1.0 / nK);
+    draw_u4(d4, seed, (unsigned)l, call, 8u, 0);
+    int pick = (int)(d4[0] * nK);          // gsl_rng_uniform_int(engine, _nC) among the resampled classes
+    pick = pick >= nK ? nK - 1 : pick;
+    int i = 0, chosen = sc[0];
+    for (int j = 0; j < nK; j++) {
+        const double uj = u0 + j * 1.0 / nK;
+        while (uj > cdf[i]) i++;
+        if (j == pick) chosen = sc[i];
+    }
+    cls[l] = chosen;
+}
+
 }  // namespace thx
 
 using namespace thx;
@@ -546,6 +599,17 @@ int thx_pf_stop_rule_dev(int* active, int* nP, double* state, const double* k123
     THX_REQUIRE(active && nP && state && k123 && s01 && nActive, "NULL pointer");
     hipLaunchKernelGGL(k_pf_stop_rule, dim3((nImg + 255) / 256), dim3(256), 0, as_stream(stream), active, nP, state, k123, s01, sD,
                        phase, nImg, nActive);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_pf_class_select_dev(int* cls, const float* uC, const double* wC, int nImg, int nK, double peakFactorC,
+                            unsigned long long seed, unsigned call, void* stream)
+{
+    if (nImg <= 0) return 0;
+    THX_REQUIRE(cls && uC && nK >= 1 && nK <= kMaxClasses, "bad arguments (at most 64 classes)");
+    hipLaunchKernelGGL(k_pf_class_select, dim3((nImg + 63) / 64), dim3(64), 0, as_stream(stream), cls, uC, wC, nImg, nK, peakFactorC,
+                       seed, call);
     THX_LAUNCH_CHECK();
     return 0;
 }

@@ -30,6 +30,7 @@ int thx_compare_hemispheres_dev(float* A, float* B, int N, int rU, float* fscHos
 int thx_soft_mask_volume_dev(float* vol, int N, float r, float ew, float bg, void* stream);
 int thx_reco_allreduce(thx_comm* hemi, float* F, float* T, double* O, int* counter, int dim, int maxRadius, int pf,
                        void* workspace, void* stream);
+int thx_insert_groups_total(unsigned long long* out, int reset, void* stream);
 size_t thx_reco_allreduce_acc_workspace(int dim, int maxRadius, int pf);
 int thx_reco_allreduce_acc(thx_comm* hemi, void* acc, double* O, int* counter, int dim, int maxRadius, int pf, void* workspace,
                            void* stream);
@@ -858,6 +859,11 @@ int thx_refine_get_stats(thx_refine* h, thx_refine_stats* out, int reset)
     out->imagePhases = h->imagePhases;
     out->nPxl = h->nPxl; out->nPxlM = h->nPxlM; out->batch = h->batch;
     for (int i = 0; i < 4; i++) out->lastRounds[i] = h->lastRounds[i];
+    {
+        unsigned long long g = 0;
+        THX_RC(thx_insert_groups_total(&g, reset, nullptr));   // cumulative on the device since the last reset
+        out->insertGroups = g;
+    }
     if (reset) {
         h->accExpect = thx_refine_stats_acc(); h->accInsert = thx_refine_stats_acc();
         for (int i = 0; i < 8; i++) h->stageMs[i] = 0;

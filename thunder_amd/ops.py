@@ -382,6 +382,17 @@ def pf_stop_rule(active, nP, state, k123, s01, phase, sD=None):
     return int(cnt.item())
 
 
+def pf_class_select(uC, seed, call_id, wC=None, peakFactorC=1.0 - 1e-2):
+    """class of every image after the global scan (src/Optimiser.cpp:925-952): keepHalfHeightPeak(PAR_C), resample(k, PAR_C),
+    Particle::rand(cls); uC [nImg][nK] f32 scan weights -> int32 [nImg]"""
+    _chk(uC, _F32, "uC")
+    nImg, nK = uC.shape
+    cls = torch.empty((nImg,), dtype=_I32, device=uC.device)
+    capi.call("thx_pf_class_select_dev", ptr(cls), ptr(uC), ptr(wC), nImg, nK, float(peakFactorC), int(seed), int(call_id),
+              stream_ptr())
+    return cls
+
+
 def pf_acg_stats(quat):
     """inferACG / mean / k1..k3 / balance weights of [n][m][4] f64 clouds -> (A [n][16], mean [n][4], k [n][3], w [n][m])"""
     _chk(quat, _F64, "quat")
