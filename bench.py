@@ -345,7 +345,8 @@ def main():
         ins_terms_per_s_upper = ins_n * shard.mReco * nPxlM * 24 / (ins_ms * 1e-3)
         ins_terms_per_s = ins_n * groups_per_image * nPxlM * 24 / (ins_ms * 1e-3)
         out = {
-            "metric": "particles/sec per refinement iteration (256\u00b3 box, 100k particles); achieved HBM GB/s",
+            "metric": "particles/sec per refinement iteration (256\u00b3 box, 100k particles); achieved HBM GB/s" if (args.box, args.particles) == (256, 100000)
+                      else "particles/sec per refinement iteration (%d\u00b3 box, %d particles); achieved HBM GB/s" % (args.box, args.particles),
             "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -354,6 +355,7 @@ def main():
                                    "projector refresh)" % (args.particles, args.box, world, args.phases, args.mLR,
                                                            args.mLT, args.mReco),
                        "box": args.box, "particles": args.particles, "particles_per_gpu": n_local, "nPxl": nPxl,
+                       "hbm_in_use_GB": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9, 1),
                        "pf": 2,
                        "search_state": "device particle filter (perturb / resample every phase, Philox-seeded)",
                        "particle_order": "random" if args.unsorted else "by view direction (thx_view_order_host)",
