@@ -82,7 +82,8 @@ print(json.dumps(summary, indent=1))
 json.dump(summary, open(out + "/summary.json", "w"), indent=1)
 pm = {"box": 256, "images_per_launch": n_per_launch, "lds_add_u32_per_s": lds_rate,
       "source": "tools/pmc_traffic.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
-                "tools/traffic_probe.py (particle-filter support points, one phase); KiB units; FETCH_SIZE of the E-step kernel "
+                + (("`%s` (average over every launch of the run)" % os.environ["PMC_CMD"]) if os.environ.get("PMC_CMD") else
+                   "tools/traffic_probe.py (particle-filter support points, one phase)") + "; KiB units; FETCH_SIZE of the E-step kernel "
                 "scaled by the bytes-per-unit measured on tools/pmc_calib's 1 GiB scattered 64-byte-cell gather in the same "
                 "pass (x%.3f; the wide streaming copy gives x%.3f), WRITE_SIZE by the 1 GiB streaming copy" % (
                     (u_gather or 0) / 1024.0, (u_stream or 0) / 1024.0)}
