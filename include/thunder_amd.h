@@ -434,6 +434,17 @@ int thx_pf_stop_init_dev(int* active, int* nP, double* state, double transS, dou
 int thx_pf_stop_rule_dev(int* active, int* nP, double* state, const double* k123, const double* s01, const double* sD, int phase,
                          int nImg, int* nActive, void* stream);
 
+/* The defocus factor of the CTF search (PAR_D), d / wD [nImg][nD] support points and priors, sD [nImg] their spread:
+ *   thx_pf_perturb_d_dev  init != 0: Particle::initD(nD, scale = ctfRefineS) (src/Particle.cpp:281-311, phase 0 of a CTF search,
+ *                         src/Optimiser.cpp:1196-1197); init == 0: Particle::perturb(scale = perturbFactorSCTF, PAR_D) (:1273-1287,
+ *                         src/Optimiser.cpp:1209); both followed by balanceWeight(PAR_D).  Philox (seed, image, call, 10, i).
+ *   thx_pf_update_d_dev   after the likelihoods (uD = wD of thx_expect_local_dev): calRank1st(PAR_D) -> topD [nImg],
+ *                         calVari(PAR_D) -> sD, resample(mLD, PAR_D) (src/Optimiser.cpp:1465-1470).  Philox purposes 11 / 12. */
+int thx_pf_perturb_d_dev(double* d, double* wD, const double* sD, int nImg, int nD, double scale, int init, unsigned long long seed,
+                         unsigned call, const int* active, void* stream);
+int thx_pf_update_d_dev(double* d, double* wD, const float* uD, double* sD, double* topD, int nImg, int nD, unsigned long long seed,
+                        unsigned call, const int* active, void* stream);
+
 /* The class of every image after the global scan, src/Optimiser.cpp:925-952: uC [nImg][nK] = the scan's class weights (wC of
  * thx_expect_global_dev), wC [nImg][nK] the filter's class priors (NULL = 1 / nK) -> keepHalfHeightPeak(PAR_C) with
  * peakFactorC (PEAK_FACTOR_C = 1 - 1e-2), resample(k, PAR_C), Particle::rand(cls).  cls [nImg] out.  Philox streams

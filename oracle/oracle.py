@@ -651,6 +651,32 @@ def pf_class_select(uC, wC, peakFactorC, rank, u0, pick):
     return int(cls[int(pick)])
 
 
+def pf_perturb_d(d, s, scale, init, g):
+    """Particle::initD (init: d = 1 + N(0, scale^2), src/Particle.cpp:281-311) or perturb(scale, PAR_D) (d += N(0, s^2) scale,
+    :1273-1287), then balanceWeight(PAR_D) + normW (:2405-2440).  g [nD] standard normals.  Returns d, wD."""
+    g = f64(g)
+    d = (1.0 + scale * g) if init else (f64(d) + (s * g) * scale)
+    n = len(d)
+    m = float(np.mean(d))
+    sd = float(np.std(d, ddof=1)) if n > 1 else 0.0
+    if sd == 0:
+        w = np.ones(n)
+    else:
+        u = (d - m) / abs(sd)
+        w = 1.0 / ((1.0 / (np.sqrt(2 * np.pi) * abs(sd))) * np.exp(-u * u / 2))      # gsl_ran_gaussian_pdf
+    return d, w / w.sum()
+
+
+def pf_update_d(d, wD, uD, rank, u0):
+    """setUD, calRank1st(PAR_D), calVari(PAR_D), resample(mLD, PAR_D) (src/Optimiser.cpp:1424-1470; OPTIMISER_PEAK_FACTOR_D off)"""
+    d = f64(d)
+    u = np.asarray(uD, np.float32).astype(np.float64)
+    top = float(d[int(np.argmax(u))])
+    s = float(np.std(d, ddof=1)) if len(d) > 1 else 0.0
+    d2, w2, src, _ = pf_resample(d, wD, u, rank, u0)
+    return d2, w2, s, top, src
+
+
 def cal_vari(q, t):
     """Particle::calVari(PAR_R) + (PAR_T) -> (k [3], s [2]) (q is rotated to the mean frame and back: a copy here)"""
     q = f64(q).copy()

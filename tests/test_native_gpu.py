@@ -222,3 +222,90 @@ def test_insertion_session_ranks_add_up_bitwise(dev, knob_env):
     torch.cuda.synchronize()
     assert torch.equal(red, one)
     comm.close()
+
+
+def test_iteration_is_bit_reproducible(dev):
+    """two runs of the native driver on the same particles give the same bits: support points, sigma tables, inserted F / T
+    (fixed-point sums), FSC, half maps, the refreshed projector -- whatever the scheduling.  (The gridding loop's stop rule
+    amplifies a last-bit difference into another round count, tests/test_iteration_cpu.py, so nothing before it may jitter.)"""
+    from thunder_amd.native import NativeRefine
+    from thunder_amd.refine import RefineShard
+    N, n = 64, 300
+    sh = RefineShard(N, n, dev, mReco=20, batch=64, allocate=False, snr=0.2)
+    P = 2 * N
+    runs = []
+    for rep in range(2):
+        nat = NativeRefine(sh)
+        nat.reset()
+        snap = []
+        for it in range(2):
+            fsc = nat.iterate()
+            v = nat.view()
+            off, topR, topT = nat.state()
+            snap.append(dict(fsc=fsc.copy(), r=nat.fetch(v.r, np.float64, (n, sh.mLR, 4)), t=nat.fetch(v.t, np.float64, (n, sh.mLT, 2)),
+                             sig=nat.fetch(v.sig, np.float32, (2, sh.nGroup, N // 2 - 1)),
+                             F=nat.fetch(v.F, np.complex64, (2, P, P, P // 2 + 1)), T=nat.fetch(v.T, np.float32, (2, P, P, P // 2 + 1)),
+                             maps=np.stack([nat.map(h).cpu().numpy() for h in (0, 1)]),
+                             vols=nat.fetch(v.vols, np.complex64, (2, P, P, P // 2 + 1)), off=off.cpu().numpy(),
+                             rounds=list(nat.stats().lastRounds)))
+            if rep == 0 and it == 0:   # perturb the scheduling of the second run: other work in flight
+                s2 = torch.cuda.Stream()
+                with torch.cuda.stream(s2):
+                    junk = torch.randn(1 << 26, device=dev).cumsum(0)
+                s2.synchronize()
+                del junk
+        runs.append(snap)
+        nat.close()
+    for it in range(2):
+        a, b = runs[0][it], runs[1][it]
+        for k in ("r", "t", "sig", "F", "T", "fsc", "maps", "vols", "off"):
+            assert np.array_equal(a[k], b[k]), "iteration %d: %s differs between two runs (%g)" % (it + 1, k, np.abs(a[k] - b[k]).max())
+        assert a["rounds"] == b["rounds"]
+
+
+def test_refine_driver_error_paths(dev):
+    """the driver's int-status error convention: bad configurations and out-of-order calls return a status and a
+    message, leak nothing and leave the handle destroyable; a failed call does not poison the next one"""
+    import ctypes as C
+    from thunder_amd import capi
+    from thunder_amd.capi import RefineConfig, ThxError, ptr, stream_ptr
+    from thunder_amd.native import NativeRefine
+    from thunder_amd.refine import RefineShard
+    sh = RefineShard(32, 40, dev, mReco=8, batch=16, allocate=False)
+    nat = NativeRefine(sh)
+
+    def bad(**kw):
+        cfg = RefineConfig.from_buffer_copy(bytes(nat.cfg))
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        h = C.c_void_p()
+        with pytest.raises(ThxError) as e:
+            capi.call("thx_refine_create", C.byref(h), C.byref(cfg), None, None)
+        assert not h.value
+        return str(e.value)
+    assert "search parameters" in bad(mLT=40) and "search parameters" in bad(mReco=0)
+    assert "box" in bad(N=33) and "halfOfRank" in bad(halfOfRank=2) and "nHalfA" in bad(nHalfA=1000)
+    # a handle without particles refuses to run, and says why
+    h = C.c_void_p()
+    capi.call("thx_refine_create", C.byref(h), C.byref(nat.cfg), None, None)
+    with pytest.raises(ThxError) as e:
+        capi.call("thx_refine_iterate", h, None, 0, stream_ptr())
+    assert "set_particles" in str(e.value)
+    with pytest.raises(ThxError) as e:
+        capi.call("thx_refine_reset", h, stream_ptr())
+    assert "set_particles" in str(e.value)
+    # group ids out of range are rejected before anything is launched; the handle is still usable afterwards
+    gid = np.full(40, 99, np.int32)
+    with pytest.raises(ThxError) as e:
+        capi.call("thx_refine_set_particles", h, ptr(sh.imgOri), ptr(sh.attr), gid.ctypes.data, ptr(sh.pf0["r"]), ptr(sh.pf0["t"]), stream_ptr())
+    assert "groupID" in str(e.value)
+    gid = np.ascontiguousarray(sh.gid.astype(np.int32))
+    capi.call("thx_refine_set_particles", h, ptr(sh.imgOri), ptr(sh.attr), gid.ctypes.data, ptr(sh.pf0["r"]), ptr(sh.pf0["t"]), stream_ptr())
+    capi.call("thx_refine_set_reference", h, ptr(sh.ref), stream_ptr())
+    capi.call("thx_refine_reset", h, stream_ptr())
+    fsc = np.zeros(16, np.float32)
+    capi.call("thx_refine_iterate", h, fsc.ctypes.data, 0, stream_ptr())
+    assert fsc[0] > 0.99
+    capi.call("thx_refine_destroy", h)
+    capi.call("thx_refine_destroy", None)      # NULL is a no-op
+    nat.close()

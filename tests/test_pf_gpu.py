@@ -245,3 +245,42 @@ def test_class_select_after_scan(oracle, dev):
     assert np.array_equal(got[clear], uC[clear].argmax(1))
     second = np.mean(got[close] != uC[close].argmax(1))
     assert 0.02 < second < 0.6, second                         # the runner-up within 1 % keeps a share (u - 0.99 max)
+
+
+def test_defocus_filter(oracle, dev):
+    """PAR_D of the CTF search: Particle::initD / perturb(PAR_D) + balanceWeight(PAR_D), then calRank1st / calVari / resample(PAR_D)
+    -- device kernels against the oracle with replayed draws"""
+    from thunder_amd import capi
+    O = oracle
+    rng = np.random.default_rng(51)
+    nImg, nD, seed = 50, 9, 424242
+    d = torch.zeros((nImg, nD), dtype=torch.float64, device=dev)
+    wD = torch.zeros((nImg, nD), dtype=torch.float64, device=dev)
+    capi.call("thx_pf_perturb_d_dev", d.data_ptr(), wD.data_ptr(), None, nImg, nD, 0.01, 1, seed, 1, None, capi.stream_ptr())
+    d0, w0 = d.cpu().numpy(), wD.cpu().numpy()
+    for l in range(nImg):
+        g = PH.draw_n4(seed, l, 1, 10, np.arange(nD))[0]
+        wd, ww = O.pf_perturb_d(None, 0.0, 0.01, True, g)
+        assert np.abs(d0[l] - wd).max() <= 1e-15 and np.allclose(w0[l], ww, rtol=1e-10)
+    assert abs(d0.mean() - 1) < 5e-3 and 0.007 < d0.std() < 0.013
+    # a phase: likelihood weights -> top point, spread, resampling; then the next perturbation uses that spread
+    uD = (rng.uniform(0, 1, (nImg, nD)) ** 3).astype(np.float32)
+    sD = torch.zeros(nImg, dtype=torch.float64, device=dev)
+    topD = torch.zeros(nImg, dtype=torch.float64, device=dev)
+    duD = T(uD, dev)
+    capi.call("thx_pf_update_d_dev", d.data_ptr(), wD.data_ptr(), duD.data_ptr(), sD.data_ptr(), topD.data_ptr(), nImg, nD, seed, 2,
+              None, capi.stream_ptr())
+    d1, w1, s1, t1 = d.cpu().numpy(), wD.cpu().numpy(), sD.cpu().numpy(), topD.cpu().numpy()
+    for l in range(nImg):
+        rank = PH.shuffle_ranks(seed, l, 2, 11, nD)
+        u0 = PH.draw_u4(seed, l, 2, 12, 0)[0] / nD
+        wd, ww, ws, wt, _ = O.pf_update_d(d0[l], w0[l], uD[l], rank, u0)
+        assert np.array_equal(d1[l], wd) and np.allclose(w1[l], ww, rtol=1e-10) and abs(s1[l] - ws) <= 1e-15 and t1[l] == wt
+    capi.call("thx_pf_perturb_d_dev", d.data_ptr(), wD.data_ptr(), sD.data_ptr(), nImg, nD, 0.5, 0, seed, 3, None, capi.stream_ptr())
+    d2, w2 = d.cpu().numpy(), wD.cpu().numpy()
+    for l in range(nImg):
+        g = PH.draw_n4(seed, l, 3, 10, np.arange(nD))[0]
+        wd, ww = O.pf_perturb_d(d1[l], s1[l], 0.5, False, g)
+        assert np.abs(d2[l] - wd).max() <= 1e-15
+        if np.std(wd) > 0:
+            assert np.allclose(w2[l], ww, rtol=1e-9)

@@ -172,6 +172,8 @@ SIGNATURES = {
     "thx_pf_stop_init_dev": (_i, [_vp, _vp, _vp, _d, _d, _i, _vp]),
     "thx_pf_stop_rule_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "thx_pf_acg_stats_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "thx_pf_perturb_d_dev": (_i, [_vp, _vp, _vp, _i, _i, _d, _i, C.c_ulonglong, C.c_uint, _vp, _vp]),
+    "thx_pf_update_d_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, C.c_ulonglong, C.c_uint, _vp, _vp]),
     "thx_pf_class_select_dev": (_i, [_vp, _vp, _vp, _i, _i, _d, C.c_ulonglong, C.c_uint, _vp]),
     "thx_ExpectProject_host": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "thx_ExpectRotran_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),

@@ -485,6 +485,100 @@ __global__ void k_pf_stop_init(int* __restrict__ active, int* __restrict__ nP, d
     st[6] = 0.0; st[7] = 0.0;
 }
 
+// The defocus factor of the CTF search (PAR_D), one thread per image (mLD <= 64 support points):
+//   mode 0  Particle::initD(nD, sD), src/Particle.cpp:281-311 (PARTICLE_DEFOCUS_INIT_GAUSSIAN): d_i = 1 + N(0, sD^2)
+//   mode 1  Particle::perturb(pf, PAR_D), :1273-1287: d_i += N(0, s^2) pf   (s = the last calVari(PAR_D))
+// followed by balanceWeight(PAR_D) + normW (:2405-2440): w_i = 1 / N(d_i - mean; sd), 1 when sd == 0.
+// Philox stream (seed, image, call, 10, i).
+__global__ void k_pf_perturb_d(double* __restrict__ d, double* __restrict__ wD, const double* __restrict__ sD, int nImg, int nD,
+                               double scale, int init, unsigned long long seed, unsigned call, const int* __restrict__ active)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nImg || (active && !active[l])) return;
+    double* dd = d + (size_t)l * nD;
+    double* w = wD + (size_t)l * nD;
+    const double s = init ? scale : sD[l];
+    for (int i = 0; i < nD; i++) {
+        double g[4];
+        draw_n4(g, seed, (unsigned)l, call, 10u, (unsigned)i);
+        dd[i] = init ? 1.0 + s * g[0] : dd[i] + (s * g[0]) * scale;      // gsl_ran_gaussian(engine, sigma) = sigma * n
+    }
+    // gsl_stats_mean / gsl_stats_sd_m (recurrences in long double in GSL; two-pass in double here: 1e-16)
+    double m = 0;
+    for (int i = 0; i < nD; i++) m += dd[i];
+    m /= nD;
+    double sd = 0;
+    if (nD > 1) {
+        double v = 0;
+        for (int i = 0; i < nD; i++) v += (dd[i] - m) * (dd[i] - m);
+        sd = sqrt(v / nD * ((double)nD / (double)(nD - 1)));
+    }
+    double sum = 0;
+    for (int i = 0; i < nD; i++) {
+        if (sd == 0) w[i] = 1.0;
+        else {
+            const double u = (dd[i] - m) / fabs(sd);
+            w[i] = 1.0 / ((1.0 / (sqrt(2 * 3.14159265358979323846) * fabs(sd))) * exp(-u * u / 2));   // gsl_ran_gaussian_pdf
+        }
+        sum += w[i];
+    }
+    for (int i = 0; i < nD; i++) w[i] /= sum;
+}
+
+// after the likelihoods of a CTF-search phase (src/Optimiser.cpp:1424-1436,1465-1470): setUD, [keepHalfHeightPeak(PAR_D) --
+// OPTIMISER_PEAK_FACTOR_D is off], calRank1st(PAR_D), calVari(PAR_D) (gsl_stats_sd, 0 for one point), resample(mLD, PAR_D).
+// Philox streams (seed, image, call, 11 = shuffle keys / 12 = u0).
+__global__ void k_pf_update_d(double* __restrict__ d, double* __restrict__ wD, const float* __restrict__ uD, double* __restrict__ sD,
+                              double* __restrict__ topD, int nImg, int nD, unsigned long long seed, unsigned call,
+                              const int* __restrict__ active)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nImg || (active && !active[l])) return;
+    double dd[64], w[64], u[64], sv[64], sw[64], su[64], cdf[64];
+    unsigned key[64];
+    int imax = 0;
+    for (int i = 0; i < nD; i++) {
+        dd[i] = d[(size_t)l * nD + i]; w[i] = wD[(size_t)l * nD + i]; u[i] = (double)uD[(size_t)l * nD + i];
+        if (u[i] > u[imax]) imax = i;
+    }
+    topD[l] = dd[imax];
+    double m = 0;
+    for (int i = 0; i < nD; i++) m += dd[i];
+    m /= nD;
+    double v = 0;
+    for (int i = 0; i < nD; i++) v += (dd[i] - m) * (dd[i] - m);
+    sD[l] = nD > 1 ? sqrt(v / nD * ((double)nD / (double)(nD - 1))) : 0.0;
+    for (int i = 0; i < nD; i++) {
+        Philox g{(unsigned)seed, (unsigned)(seed >> 32)};
+        unsigned c[4] = {(unsigned)l, call, 11u, (unsigned)i};
+        g(c);
+        key[i] = c[0];
+    }
+    for (int i = 0; i < nD; i++) {
+        int rank = 0;
+        for (int j = 0; j < nD; j++) rank += (key[j] < key[i]) || (key[j] == key[i] && j < i);
+        sv[rank] = dd[i]; sw[rank] = w[i]; su[rank] = u[i];
+    }
+    double sum = 0, acc = 0;
+    for (int i = 0; i < nD; i++) sum += sw[i] * su[i];
+    for (int i = 0; i < nD; i++) { acc += (sw[i] * su[i]) / sum; cdf[i] = acc; }
+    const double last = cdf[nD - 1];
+    for (int i = 0; i < nD; i++) cdf[i] /= last;
+    double d4[4];
+    draw_u4(d4, seed, (unsigned)l, call, 12u, 0);
+    const double u0 = d4[0] * (1.0 / nD);
+    int i = 0;
+    double ws = 0;
+    for (int j = 0; j < nD; j++) {
+        const double uj = u0 + j * 1.0 / nD;
+        while (uj > cdf[i]) i++;
+        d[(size_t)l * nD + j] = sv[i];
+        w[j] = 1.0 / su[i];
+        ws += w[j];
+    }
+    for (int j = 0; j < nD; j++) wD[(size_t)l * nD + j] = w[j] / ws;
+}
+
 // Class selection after the global scan, src/Optimiser.cpp:925-952: setUC(wC) -> setPeakFactor(PAR_C) (PARTICLE_PEAK_FACTOR_C:
 // _peakFactorC = PEAK_FACTOR_C = 1 - 1e-2) -> keepHalfHeightPeak(PAR_C) -> resample(k, PAR_C) (shuffle, w *= u, systematic
 // resampling, src/Particle.cpp:1296-1338) -> Particle::rand(cls) (uniform pick among the k resampled classes, :2109-2120).
@@ -599,6 +693,28 @@ int thx_pf_stop_rule_dev(int* active, int* nP, double* state, const double* k123
     THX_REQUIRE(active && nP && state && k123 && s01 && nActive, "NULL pointer");
     hipLaunchKernelGGL(k_pf_stop_rule, dim3((nImg + 255) / 256), dim3(256), 0, as_stream(stream), active, nP, state, k123, s01, sD,
                        phase, nImg, nActive);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_pf_perturb_d_dev(double* d, double* wD, const double* sD, int nImg, int nD, double scale, int init, unsigned long long seed,
+                         unsigned call, const int* active, void* stream)
+{
+    if (nImg <= 0) return 0;
+    THX_REQUIRE(d && wD && (init || sD) && nD >= 1 && nD <= 64, "bad arguments (at most 64 defocus support points)");
+    hipLaunchKernelGGL(k_pf_perturb_d, dim3((nImg + 63) / 64), dim3(64), 0, as_stream(stream), d, wD, sD, nImg, nD, scale, init, seed, call,
+                       active);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_pf_update_d_dev(double* d, double* wD, const float* uD, double* sD, double* topD, int nImg, int nD, unsigned long long seed,
+                        unsigned call, const int* active, void* stream)
+{
+    if (nImg <= 0) return 0;
+    THX_REQUIRE(d && wD && uD && sD && topD && nD >= 1 && nD <= 64, "bad arguments (at most 64 defocus support points)");
+    hipLaunchKernelGGL(k_pf_update_d, dim3((nImg + 63) / 64), dim3(64), 0, as_stream(stream), d, wD, uD, sD, topD, nImg, nD, seed, call,
+                       active);
     THX_LAUNCH_CHECK();
     return 0;
 }
