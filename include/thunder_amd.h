@@ -507,6 +507,11 @@ int thx_reco_sphere_pack_dev(float* F, float* T, int dim, int maxRadius, int pf,
  * library over one rank's HBM-resident shard of particles.  What bench.py times and tests/cpp/iteration.cpp drives.
  * ------------------------------------------------------------------------------------------- */
 
+/* The library caches, per (device, stream), grow-only scratch buffers and hipFFT plans (a plan carries its stream).  A caller
+ * that destroys a stream calls this first: it synchronises the stream, frees that stream's scratch and destroys its plans,
+ * so that a recycled handle value can never meet a plan bound to a dead stream. */
+int thx_release_stream(void* stream);
+
 /* Optimiser::allocPreCalIdx (src/Optimiser.cpp:7991-8041) on the host: the half-plane pixel list rL <= |k| < rU.
  * order: 0 = the reference's row-major order, 1 = Morton (Z-order) visit order (the E-step's default).  Output arrays
  * (may be NULL) hold at least (rU + 2) * (2 rU + 2) ints; *nPxl receives the count. */

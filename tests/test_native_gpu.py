@@ -309,3 +309,29 @@ def test_refine_driver_error_paths(dev):
     capi.call("thx_refine_destroy", h)
     capi.call("thx_refine_destroy", None)      # NULL is a no-op
     nat.close()
+
+
+def test_release_stream_evicts_scratch_and_plans(dev):
+    """thx_release_stream: work on a side stream (scratch buffers, 2-D and 3-D hipFFT plans are cached per stream), release it,
+    destroy it; a new stream -- possibly with the recycled handle value -- works and gives the same results"""
+    from thunder_amd import capi, ops
+    N = 32
+    g = torch.Generator(device=dev).manual_seed(3)
+    rl = torch.randn((N, N, N), device=dev, generator=g)
+    img = torch.view_as_complex(torch.randn((6, N, N // 2 + 1, 2), device=dev, generator=g)).contiguous()
+    want_ft = ops.fft3d_fw(rl).clone()
+    want_img = img.clone()
+    ops.remask(want_img, 12.0)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            ft = ops.fft3d_fw(rl)
+            im = img.clone()
+            ops.remask(im, 12.0)
+        s.synchronize()
+        assert torch.equal(ft, want_ft) and torch.equal(im, want_img)
+        capi.call("thx_release_stream", s.cuda_stream)
+        del s
+    capi.call("thx_release_stream", capi.stream_ptr())     # releasing the default stream's caches is harmless: they are rebuilt
+    assert torch.equal(ops.fft3d_fw(rl), want_ft)

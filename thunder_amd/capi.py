@@ -137,6 +137,7 @@ SIGNATURES = {
                                        _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "thx_insert_finish_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "thx_insert_groups_total": (_i, [_vp, _i, _vp]),
+    "thx_release_stream": (_i, [_vp]),
     "thx_reco_allreduce_acc_workspace": (_sz, [_i, _i, _i]),
     "thx_reco_allreduce_acc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "thx_normalise_tf_dev": (_i, [_vp, _vp, _i, _vp]),

@@ -54,11 +54,34 @@ static Knobs g_knobs = read_knobs();   // once, when the library is loaded
 const Knobs& knobs() { return g_knobs; }
 
 // keyed on (device, stream, slot): the Interface.h-shaped *_host entry points run on whichever device gpuIdx names
+struct ScratchBuf { void* p = nullptr; size_t n = 0; };
+static std::mutex g_scratchMtx;
+static std::map<std::tuple<int, hipStream_t, int>, ScratchBuf> g_scratch;
+void release_io_plans(int dev, hipStream_t st);
+void release_next_plans(int dev, hipStream_t st);
+extern "C" void thx_release_reco_plans_(int dev, hipStream_t st);
+// everything the library caches per (device, stream): scratch buffers and hipFFT plans (which carry their stream).  A caller
+// that destroys a stream calls this first -- a recycled handle value must not find a plan bound to the destroyed stream.
+int release_stream(hipStream_t stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    (void)hipStreamSynchronize(stream);
+    {
+        std::lock_guard<std::mutex> g(g_scratchMtx);
+        for (auto it = g_scratch.begin(); it != g_scratch.end();)
+            if (std::get<0>(it->first) == dev && std::get<1>(it->first) == stream) { if (it->second.p) (void)hipFree(it->second.p); it = g_scratch.erase(it); } else ++it;
+    }
+    release_io_plans(dev, stream);
+    release_next_plans(dev, stream);
+    thx_release_reco_plans_(dev, stream);
+    return 0;
+}
 void* scratch(hipStream_t stream, int slot, size_t bytes)
 {
-    struct Buf { void* p = nullptr; size_t n = 0; };
-    static std::mutex mtx;
-    static std::map<std::tuple<int, hipStream_t, int>, Buf> bufs;
+    using Buf = ScratchBuf;
+    std::mutex& mtx = g_scratchMtx;
+    auto& bufs = g_scratch;
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> g(mtx);
@@ -1163,6 +1186,12 @@ static int launch_expect_local(const ExpectLocalArgs& a, hipStream_t st, bool pa
 // C ABI
 // =============================================================================================
 extern "C" {
+
+int thx_release_stream(void* stream)
+{
+    return release_stream(as_stream(stream));
+}
+
 
 const char* thx_last_error(void) { return thx::g_err; }
 int thx_version(void) { return 200; }

@@ -195,10 +195,18 @@ __global__ __launch_bounds__(256) void k_mask_scale(float* __restrict__ masked, 
 }
 
 // one plan per (device, stream, shape): a hipFFT plan carries its stream and work area
+static std::mutex g_planIoMtx;
+static std::map<std::tuple<int, hipStream_t, int, int>, hipfftHandle> g_planIo;
+void release_io_plans(int dev, hipStream_t st)
+{
+    std::lock_guard<std::mutex> g(g_planIoMtx);
+    for (auto it = g_planIo.begin(); it != g_planIo.end();)
+        if (std::get<0>(it->first) == dev && std::get<1>(it->first) == st) { (void)hipfftDestroy(it->second); it = g_planIo.erase(it); } else ++it;
+}
 static int cached_plan_r2c(hipfftHandle* out, int idim, int batch, hipStream_t st)
 {
-    static std::mutex mtx;
-    static std::map<std::tuple<int, hipStream_t, int, int>, hipfftHandle> cache;
+    std::mutex& mtx = g_planIoMtx;
+    auto& cache = g_planIo;
     int dev = 0;
     THX_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> g(mtx);

@@ -60,10 +60,18 @@ static int cached_mask(const float** out, int idim, float r, float ew)
 
 // batched in-place 2-D real plans on the padded layout: real rows of 2*(idim/2+1) floats overlay the complex rows
 // (one plan per (device, stream, shape): a hipFFT plan carries its stream and work area)
+static std::mutex g_plan2dMtx;
+static std::map<std::tuple<int, hipStream_t, int, int, int>, hipfftHandle> g_plan2d;
+void release_next_plans(int dev, hipStream_t st)
+{
+    std::lock_guard<std::mutex> g(g_plan2dMtx);
+    for (auto it = g_plan2d.begin(); it != g_plan2d.end();)
+        if (std::get<0>(it->first) == dev && std::get<1>(it->first) == st) { (void)hipfftDestroy(it->second); it = g_plan2d.erase(it); } else ++it;
+}
 static int cached_plan2d(hipfftHandle* out, int idim, int batch, hipfftType type, hipStream_t st)
 {
-    static std::mutex mtx;
-    static std::map<std::tuple<int, hipStream_t, int, int, int>, hipfftHandle> cache;
+    std::mutex& mtx = g_plan2dMtx;
+    auto& cache = g_plan2d;
     int dev = 0;
     THX_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> g(mtx);

@@ -659,10 +659,18 @@ int thx_reco_set_projectee_dev(thx_reco* r, const float* refRL, float* volume, v
 // FFT plans of the small N^3 transforms are cached per (device, stream, size, direction): plan creation costs far more
 // than the transform (the reference's FFT::fw re-plans every call with FFTW_ESTIMATE, src/FFT.cpp:176-199).  One plan per
 // stream: a hipFFT plan carries its stream and work area, so two host threads on two streams must not share one.
+static std::mutex g_plan3dMtx;
+static std::map<std::tuple<int, hipStream_t, int, int>, hipfftHandle> g_plan3d;
+void thx_release_reco_plans_(int dev, hipStream_t st)   /* internal (called by thx_release_stream) */
+{
+    std::lock_guard<std::mutex> g(g_plan3dMtx);
+    for (auto it = g_plan3d.begin(); it != g_plan3d.end();)
+        if (std::get<0>(it->first) == dev && std::get<1>(it->first) == st) { (void)hipfftDestroy(it->second); it = g_plan3d.erase(it); } else ++it;
+}
 static int cached_plan(hipfftHandle* out, int n, hipfftType type, hipStream_t st)
 {
-    static std::mutex mtx;
-    static std::map<std::tuple<int, hipStream_t, int, int>, hipfftHandle> cache;
+    std::mutex& mtx = g_plan3dMtx;
+    auto& cache = g_plan3d;
     int dev = 0;
     THX_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> g(mtx);
