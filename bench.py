@@ -210,6 +210,36 @@ def bench_global_scan(args, dev):
                         "frac": flops / (k_ms * 1e-3) / 1e12 / 157.3, "traffic": None, "avg_launch_ms": k_ms,
                         "note": "exact-f32 contraction on v_mfma_f32_32x32x2_f32 (bit-equal to the fmaf chain); peak = f32 MFMA = f32 vector rate"},
            "cpu_baseline": None}
+    if not args.no_cpu_baseline:
+        # the oracle's restatement of the scanning loop (src/Optimiser.cpp:756-894, logDataVSPrior_m_n_huabin) on a bounded
+        # sample: every host core takes a block of images through ONE class (all 10 000 rotations x 30 shifts), the figure is
+        # scaled to the K classes.  (The reference splits the rotations over OpenMP threads and locks per image; blocks of
+        # images are the same arithmetic without the locks.)
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import oracle as O
+        cores = os.cpu_count() or 1
+        per = max(1, int(args.scan_cpu_images_per_core))
+        n_cpu = min(nImg, per * cores)
+        ops.project(vols[0], mats, iCol, iRow, 2, out=rotP)
+        rotP_h, traP_h = rotP.cpu().numpy(), traP.cpu().numpy()
+        dat_h, ctf_h, sig_h = dat[:n_cpu].cpu().numpy(), ctf[:n_cpu].cpu().numpy(), sigRcp[:n_cpu].cpu().numpy()
+
+        def block(b):
+            lo, hi = b * per, min(n_cpu, (b + 1) * per)
+            m = hi - lo
+            wC_ = np.zeros((m, K), np.float32); wR_ = np.zeros((K, m, nR), np.float32); wT_ = np.zeros((K, m, nT), np.float32)
+            base_ = np.full(m, np.nan, np.float32)
+            O.expect_global(rotP_h, traP_h, np.ascontiguousarray(dat_h[lo:hi].T), np.ascontiguousarray(ctf_h[lo:hi].T),
+                            np.ascontiguousarray(sig_h[lo:hi].T), K, 0, np.full((m, nR), 1.0 / nR), np.full((m, nT), 1.0 / nT), wC_, wR_, wT_,
+                            base_)
+            return int(wR_[0].argmax(1)[0])
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(block, range((n_cpu + per - 1) // per)))
+        t_cpu = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n_cpu / (t_cpu * K), "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+                               "sample": "%d images x 1 class x %d rotations x %d shifts through the oracle's scanning loop, %d host "
+                                         "threads x %d images each, %.1f s; scaled to %d classes" % (n_cpu, nR, nT, cores, per, t_cpu, K)}
     print(json.dumps(out))
 
 
@@ -237,6 +267,7 @@ def main():
     ap.add_argument("--classification", action="store_true",
                     help="time the global scanning stage of configs[3] (K = 4 x 10000 rotations x 30 shifts at r = 24) instead")
     ap.add_argument("--scan-images", type=int, default=1024)
+    ap.add_argument("--scan-cpu-images-per-core", type=int, default=2)
     args = ap.parse_args()
 
     import torch
