@@ -313,30 +313,66 @@ __global__ __launch_bounds__(256) void k_scale_rl(float* __restrict__ rl, size_t
     if (e < n) rl[e] = (float)((double)rl[e] * (1.0 / (double)n));
 }
 
-// FSC shell sums (src/Functions/Spectrum.cpp:302-337): LDS-privatised per block, fp64 global atomics
-__global__ __launch_bounds__(256) void k_fsc_accum(double* __restrict__ acc, int nShell, const float2* __restrict__ A,
-                                                   const float2* __restrict__ B, int P)
+// FSC shell sums (src/Functions/Spectrum.cpp:302-337), DETERMINISTIC: no atomics anywhere.  A wave owns a fixed set of rows
+// (j, k) of the half grid; along a row the shell index u = AROUND(NORM_3(i, j, k)) never decreases, so the lanes of a 64-element
+// chunk that share a shell are contiguous and a segmented wave scan (fixed tree order) leaves each shell's chunk total in the
+// last lane of its segment, which adds it to the wave's PRIVATE table in LDS (distinct shells: no conflict; chunks and rows
+// in program order).  Every wave writes its table; k_fsc_reduce adds the tables in wave order.  (The first version summed
+// floats with LDS atomics: the curve moved by an ulp from run to run, and the MAP reconstruction's stop rule -- DESIGN 3a --
+// turned that ulp into another round count.)
+constexpr int kFscBlocks = 256;
+__global__ __launch_bounds__(256) void k_fsc_rows(double* __restrict__ part, int nShell, const float2* __restrict__ A,
+                                                  const float2* __restrict__ B, int P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* s = reinterpret_cast<float*>(smem_raw);  // [3][nShell]
-    for (int q = threadIdx.x; q < 3 * nShell; q += blockDim.x) s[q] = 0.f;
-    __syncthreads();
-    const size_t n = (size_t)P * P * (P / 2 + 1);
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
-        int i, j, k;
-        unpack_half(e, P, i, j, k);
-        const int u = (int)rint(gsl_hypot3_((double)i, (double)j, (double)k));
-        if (u < nShell) {
-            const float2 a = A[e], b = B[e];
-            atomicAdd(&s[u], a.x * b.x + a.y * b.y);
-            atomicAdd(&s[nShell + u], a.x * a.x + a.y * a.y);
-            atomicAdd(&s[2 * nShell + u], b.x * b.x + b.y * b.y);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* my = reinterpret_cast<double*>(smem_raw) + (size_t)wave * 3 * nShell;
+    for (int q = lane; q < 3 * nShell; q += 64) my[q] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    const int nc = P / 2 + 1;
+    const long rows = (long)P * P;
+    const int gw = blockIdx.x * 4 + wave, nW = gridDim.x * 4;
+    for (long row = gw; row < rows; row += nW) {
+        const int jw = (int)(row % P), kw = (int)(row / P);
+        const int j = jw >= P / 2 ? jw - P : jw, k = kw >= P / 2 ? kw - P : kw;
+        for (int i0 = 0; i0 < nc; i0 += 64) {
+            const int i = i0 + lane;
+            int u = INT_MAX;
+            double s0 = 0, s1 = 0, s2 = 0;
+            if (i < nc) {
+                const int uu = (int)rint(gsl_hypot3_((double)i, (double)j, (double)k));
+                if (uu < nShell) {
+                    u = uu;
+                    const float2 a = A[(size_t)row * nc + i], b = B[(size_t)row * nc + i];
+                    s0 = (double)(a.x * b.x + a.y * b.y);
+                    s1 = (double)(a.x * a.x + a.y * a.y);
+                    s2 = (double)(b.x * b.x + b.y * b.y);
+                }
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int uo = __shfl_up(u, o, 64);
+                const double t0 = __shfl_up(s0, o, 64), t1 = __shfl_up(s1, o, 64), t2 = __shfl_up(s2, o, 64);
+                if (lane >= o && uo == u) { s0 += t0; s1 += t1; s2 += t2; }
+            }
+            const int un = __shfl_down(u, 1, 64);
+            if (u != INT_MAX && (lane == 63 || un != u)) {
+                my[u] += s0; my[nShell + u] += s1; my[2 * nShell + u] += s2;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
-    __syncthreads();
-    for (int q = threadIdx.x; q < 3 * nShell; q += blockDim.x)
-        if (s[q] != 0.f) unsafeAtomicAdd(&acc[q], (double)s[q]);
+    __builtin_amdgcn_wave_barrier();
+    for (int q = lane; q < 3 * nShell; q += 64) part[(size_t)gw * 3 * nShell + q] = my[q];
+}
+
+__global__ void k_fsc_reduce(double* __restrict__ acc, const double* __restrict__ part, int n3, int nW)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n3) return;
+    double s = 0;
+    for (int w = 0; w < nW; w++) s += part[(size_t)w * n3 + q];
+    acc[q] = s;
 }
 
 __global__ void k_fsc_final(float* __restrict__ fsc, const double* __restrict__ acc, int nShell)
@@ -713,11 +749,14 @@ int thx_fsc_dev(float* fsc, int nShell, const float* A, const float* B, int dim,
     THX_REQUIRE(fsc && A && B && nShell > 0 && nShell <= 4096, "bad arguments");
     hipStream_t st = as_stream(stream);
     double* acc = nullptr;
-    acc = reinterpret_cast<double*>(scratch(st, 2, 3 * nShell * sizeof(double)));
+    const int nW = kFscBlocks * 4;
+    acc = reinterpret_cast<double*>(scratch(st, 2, (size_t)(nW + 1) * 3 * nShell * sizeof(double)));
     THX_REQUIRE(acc, "device scratch allocation failed");
-    THX_CHECK(hipMemsetAsync(acc, 0, 3 * nShell * sizeof(double), st));
-    hipLaunchKernelGGL(k_fsc_accum, dim3(1024), dim3(256), 3 * nShell * sizeof(float), st, acc, nShell,
+    double* part = acc + 3 * nShell;
+    THX_REQUIRE(4 * 3 * (size_t)nShell * sizeof(double) <= 64 * 1024, "too many shells for the per-wave tables");
+    hipLaunchKernelGGL(k_fsc_rows, dim3(kFscBlocks), dim3(256), 4 * 3 * (size_t)nShell * sizeof(double), st, part, nShell,
                        reinterpret_cast<const float2*>(A), reinterpret_cast<const float2*>(B), dim);
+    hipLaunchKernelGGL(k_fsc_reduce, dim3((3 * nShell + 255) / 256), dim3(256), 0, st, acc, part, 3 * nShell, nW);
     hipLaunchKernelGGL(k_fsc_final, dim3((nShell + 255) / 256), dim3(256), 0, st, fsc, acc, nShell);
     THX_LAUNCH_CHECK();
     return 0;
