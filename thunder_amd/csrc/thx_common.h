@@ -52,6 +52,7 @@ struct Knobs {
     bool scanSimple;      // THX_SCAN=simple: the rotation-per-thread global-scan kernel for every size (A/B)
     int scanTile;         // THX_SCAN=t42 / t24 / t44: wave tiles of the scan contraction (A/B; default 2 x 2)
     bool insertPlain;     // THX_INSERT_PLAIN=1: plain float-atomic insertion (k_insert)
+    bool insertWin;       // THX_INSERT=win: the per-image window kernel (k_insert_win) instead of the brick-sorted form (A/B)
     float minQuanta;      // THX_MIN_QUANTA: smallest T term accumulated in the fixed-point LDS brick
     bool fftRocfft;       // THX_FFT=rocfft: library transforms in the gridding loop for every size
     bool recoTrace;       // THX_RECO_TRACE: print diffC per balancing round

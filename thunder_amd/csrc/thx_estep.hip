@@ -38,6 +38,8 @@ static Knobs read_knobs()
     v.scanTile = e && e[0] == 't' ? atoi(e + 1) : 0;
     e = getenv("THX_INSERT_PLAIN");
     v.insertPlain = e && e[0] == '1';
+    e = getenv("THX_INSERT");
+    v.insertWin = e && e[0] == 'w';
     e = getenv("THX_MIN_QUANTA");
     v.minQuanta = e ? (float)atof(e) : -1.0f;
     e = getenv("THX_FFT");

@@ -1,0 +1,605 @@
+// thx_insert_sort.hip -- brick-sorted Fourier insertion (back-projection), the production form of HOT LOOP C.
+// Reference behaviour: src/Optimiser.cpp:7038-7241 (the loop over images and draws), src/Reconstructor.cpp:782-863
+// (insertP: value * ctf * w into F, ctf^2 * w into T), src/Image/Volume.cpp:565-712 (addFTHalf: trilinear scatter on the
+// half-Hermitian grid), include/Functions/Interpolation.h:152-200 (the eight weights).  gfx950 only.
+//
+// Why this shape.  The per-image window kernel (k_insert_win, thx_mstep.hip) keeps the IMAGE side coalesced and pays on the
+// VOLUME side: one (window, slab) step of one image holds ~900 samples between two barriers and one flush of a 48 KB brick,
+// and finding the samples of a window costs 2.5 float tests per hit -- 0.12 of the LDS-add rate, instruction-bound.  Here the
+// two sides are decoupled by a sort through HBM, 28 bytes per sample each way:
+//   k_bin  (image-major): one thread per listed pixel, all groups of the image's draws; every sample is computed ONCE at full
+//          lane occupancy -- exact position, cell, fractional offsets, value -- and written as a record into the segment of its
+//          brick.  A segment = the records one (256-pixel region, 8 groups) pass sends to one 16 x 16 x 8 brick of cell origins;
+//          the pass counts per brick in an LDS hash table (wave-aggregated), reserves its records with ONE global atomic,
+//          recomputes and scatters.
+//   sort   the segment descriptors (not the records) by brick: rocPRIM radix sort of ~1/140 of the record count.
+//   k_acc  (brick-major): a workgroup takes ~16 k records of consecutive bricks, accumulates each brick's 17 x 17 x 9 voxels in
+//          LDS as 64-bit integers over ALL the images of the chunk, and flushes a brick once.
+// No window geometry, no shear, no candidate tests, no far-group special case: a sample's brick is a shift of its cell origin.
+//
+// Arithmetic.  Every voxel term is rounded ONCE, to the session's 64-bit quanta (k_insert_scale: 2^-E_F, 2^-E_T):
+// re = rint((vre 2^E_F) wv), t = rint((tval 2^E_T) wv); a term whose T part rounds to zero is dropped whole (F and T travel
+// together: T = 0 under F != 0 lets the gridding weights explode).  That is the rule the window kernel applies to its
+// sub-quantum terms, here applied to all of them, so a term carries 7 more bits than a brick term of the window kernel did.
+// Integer sums commute: F and T are bit-identical from run to run, for any chunking, and across ranks.
+#include "thx_insert.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <vector>
+
+namespace thx {
+
+constexpr int kBLx = 4, kBLy = 4, kBLz = 3;                       // log2 of the brick edges in cell origins
+constexpr int kBx = 1 << kBLx, kBy = 1 << kBLy, kBz = 1 << kBLz;  // 16 x 16 x 8
+constexpr int kVx = kBx + 1, kVy = kBy + 1, kVz = kBz + 1;        // voxels a brick's cells reach
+constexpr int kBrickVox = kVx * kVy * kVz;                        // 2601 x 24 B = 62.4 KB of LDS: two workgroups per CU
+constexpr int kBinThreads = 256;                                  // pixels per region
+constexpr int kPassGroups = 8;                                    // groups per pass of k_bin
+constexpr int kHash = kBinThreads * kPassGroups;                  // >= the distinct bricks of a pass, whatever the input
+constexpr int kRampU = 16;                                        // unique shifts whose ramps a thread keeps in registers
+constexpr int kAccThreads = 512;
+constexpr unsigned kAccSpan = 16384;                              // records per workgroup of k_acc
+
+struct BinArgs {
+    InsertArgs a;               // image-indexed pointers at the chunk's first image
+    const int* plan;            // k_insert_plan, at the chunk's first image
+    const int* gexp;            // [2]: E_F, E_T
+    long long* accF;            // [nK][vol][2]
+    long long* accT;            // [nK][vol]
+    uint4* recA;                // [capR]: xd, yd, zd (float bits), cell
+    float* recB;                // [capR][3]: vre 2^E_F, vim 2^E_F (conjugated where folded), tval 2^E_T
+    unsigned* segKey;           // [capS] brick id of the segment
+    unsigned long long* segVal; // [capS] first record | count << 32
+    unsigned long long* counter;// records | segments << 40 reserved so far
+    unsigned capR, capS;
+    int nBx, nBy, nBz;
+};
+
+// float -> int64, round to nearest even, |q| < 2^51: the sum with 1.5 x 2^52 holds the integer in its low mantissa bits
+__device__ __forceinline__ long long f2ll_magic(float q)
+{
+    const double d = (double)q + 6755399441055744.0;
+    return __double_as_longlong(d) - 0x4338000000000000LL;
+}
+
+struct SampleGeom {
+    float xd, yd, zd;
+    int X0, Y0, Z0;
+    int key;
+    unsigned cell;
+    bool conj;
+};
+
+// position of pixel (icp, irp) (padded units) under the rotation whose first two columns are R[0..5]: the reference's
+// arithmetic (double products and sum, narrowed once; src/Reconstructor.cpp:805-811), the Hermitian fold and the cell
+__device__ __forceinline__ bool sample_geom(const double* R, int icp, int irp, int P, int cls, int nBx, int nBy, int nBz, SampleGeom& s)
+{
+    float x = (float)(R[0] * icp + R[3] * irp);
+    float y = (float)(R[1] * icp + R[4] * irp);
+    float z = (float)(R[2] * icp + R[5] * irp);
+    if (!coord_in_grid(x, y, z, P)) return false;
+    s.conj = false;
+    if (!(x >= 0.0f)) { x *= -1.0f; y *= -1.0f; z *= -1.0f; s.conj = true; }
+    const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+    s.X0 = (int)fx; s.Y0 = (int)fy; s.Z0 = (int)fz;
+    s.xd = x - fx; s.yd = y - fy; s.zd = z - fz;
+    const int yb = s.Y0 + P / 2, zb = s.Z0 + P / 2;
+    s.key = ((cls * nBz + (zb >> kBLz)) * nBy + (yb >> kBLy)) * nBx + (s.X0 >> kBLx);
+    s.cell = (unsigned)(s.X0 & (kBx - 1)) | ((unsigned)(yb & (kBy - 1)) << 4) | ((unsigned)(zb & (kBz - 1)) << 8);
+    return true;
+}
+
+// lanes of a wave with equal keys: the lowest is their leader, n their number, rank the lane's position among them
+struct WaveGroup {
+    int lead, n, rank;
+};
+__device__ __forceinline__ WaveGroup wave_group_by_key(bool valid, int key)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    WaveGroup g;
+    g.lead = lane; g.n = 0; g.rank = 0;
+    unsigned long long rem = __ballot(valid);
+    while (rem) {
+        const int l = __ffsll((long long)rem) - 1;
+        const int k = __builtin_amdgcn_readlane(key, l);
+        const bool mine = valid && key == k;
+        const unsigned long long eq = __ballot(mine);
+        if (mine) { g.lead = l; g.n = __popcll(eq); g.rank = __popcll(eq & lt); }
+        rem &= ~eq;
+    }
+    return g;
+}
+
+__device__ __forceinline__ unsigned hash_of(int key) { return ((unsigned)key * 2654435761u) >> (32 - 11); }
+static_assert(kHash == 2048, "hash_of keeps 11 bits");
+
+__device__ __forceinline__ int hash_insert(int* hKey, int key)
+{
+    unsigned h = hash_of(key);
+    for (;;) {
+        const int prev = atomicCAS(&hKey[h], -1, key);
+        if (prev == -1 || prev == key) return (int)h;
+        h = (h + 1) & (kHash - 1);
+    }
+}
+__device__ __forceinline__ int hash_find(const int* hKey, int key)
+{
+    unsigned h = hash_of(key);
+    while (hKey[h] != key) h = (h + 1) & (kHash - 1);
+    return (int)h;
+}
+
+// more unique shifts than a thread keeps ramps for: the members' ramps one by one (translate(), src/Image/ImageFunctions.cpp:243-251)
+__device__ __attribute__((noinline)) float2 ramp_sum_members(const double* trans, const int* pOrd, size_t dm0, int m0, int m1, double offx,
+                                                             double offy, int idim, int pi, int pj)
+{
+    float2 S = make_float2(0.f, 0.f);
+    for (int i = m0; i < m1; i++) {
+        const size_t dm = dm0 + pOrd[i];
+        const double tx = trans[2 * dm] - offx, ty = trans[2 * dm + 1] - offy;
+        const float2 r = ramp_value((float)(-tx) / idim, (float)(-ty) / idim, pi, pj);
+        S.x += r.x;
+        S.y += r.y;
+    }
+    return S;
+}
+
+// the eight voxel terms of one sample straight into the 64-bit volume accumulators: what k_acc does through LDS, term for term
+// (taken only by a pass whose records do not fit the chunk's buffers)
+__device__ __attribute__((noinline)) void terms_direct(long long* F, long long* T, int P, const SampleGeom& s, float vreS, float vimS, float tvalS)
+{
+    const float vx[2] = {1.0f - s.xd, s.xd}, vy[2] = {1.0f - s.yd, s.yd}, vz[2] = {1.0f - s.zd, s.zd};
+    const long nc = P / 2 + 1;
+    for (int v = 0; v < 8; v++) {
+        const int ii = v & 1, jj = (v >> 1) & 1, kk = v >> 2;
+        const float wv = vx[ii] * vy[jj] * vz[kk];
+        const long long t = f2ll_magic(tvalS * wv);
+        if (t == 0) continue;
+        const int X = s.X0 + ii, Y = s.Y0 + jj, Z = s.Z0 + kk;
+        const long gi = ((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X;
+        acc_add(F, T, gi, f2ll_magic(vreS * wv), f2ll_magic(vimS * wv), t);
+    }
+}
+
+// grid (ceil(nPxl / 256), images of the chunk)
+__global__ __launch_bounds__(kBinThreads) void k_bin(BinArgs b)
+{
+    const InsertArgs& a = b.a;
+    __shared__ int hKey[kHash];
+    __shared__ int hCnt[kHash];
+    __shared__ unsigned hBase[kHash];
+    __shared__ double sR[kPassGroups][6];
+    __shared__ int sCntI[kPassGroups][kRampU];
+    __shared__ int sCls[kPassGroups], sRep[kPassGroups], sM0[kPassGroups + 1];
+    __shared__ int sWS[kBinThreads / 64], sWN[kBinThreads / 64];
+    __shared__ unsigned long long sRecBase;
+    __shared__ unsigned sSegBase;
+    __shared__ int sDirect;
+
+    const int img = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = blockIdx.x * kBinThreads + tid;
+    const bool listed = p < a.nPxl;
+    const int P = a.P;
+    const size_t volSize = (size_t)P * P * (P / 2 + 1);
+    const size_t dm0 = (size_t)img * a.mReco;
+    const double offx = a.offS ? a.offS[2 * img] : 0.0, offy = a.offS ? a.offS[2 * img + 1] : 0.0;
+
+    const int* plan = b.plan + (size_t)img * plan_stride(a.mReco);
+    const int G = plan[0], U = plan[1];
+    const int* pGStart = plan + 2;
+    const int* pOrd = pGStart + a.mReco + 1;
+    const int* pUid = pOrd + a.mReco;
+    const int* pGRep = pUid + a.mReco;
+    const int* pTRep = pGRep + a.mReco;
+
+    if (blockIdx.x == 0 && tid == 0 && a.O) {   // insertDir (src/Reconstructor.cpp:407-422) once per image
+        double ox = 0, oy = 0, oz = 0;
+        for (int m = 0; m < a.mReco; m++) {
+            const double* R = a.rotMat + (dm0 + m) * 9;
+            const double tx = a.trans[2 * (dm0 + m)] - offx, ty = a.trans[2 * (dm0 + m) + 1] - offy;
+            ox += -(R[0] * tx + R[3] * ty);
+            oy += -(R[1] * tx + R[4] * ty);
+            oz += -(R[2] * tx + R[5] * ty);
+        }
+        unsafeAtomicAdd(&a.O[0], ox);
+        unsafeAtomicAdd(&a.O[1], oy);
+        unsafeAtomicAdd(&a.O[2], oz);
+        if (a.counter) atomicAdd(a.counter, a.mReco);
+    }
+
+    // this thread's pixel: coordinates, value, CTF, and the phase ramps of the image's unique shifts
+    int pi = 0, pj = 0;
+    float2 dv = make_float2(0.f, 0.f);
+    float cf = 0.f;
+    if (listed) {
+        pi = a.iCol[p]; pj = a.iRow[p];
+        dv = a.datP[(size_t)img * a.nPxl + p];
+        cf = a.ctfP[(size_t)img * a.nPxl + p];
+    }
+    const int icp = pi * a.opf, irp = pj * a.opf;   // _iColPad / _iRowPad, src/Optimiser.cpp:8031-8033
+    float2 ramp[kRampU];
+#pragma unroll
+    for (int u = 0; u < kRampU; u++) {
+        ramp[u] = make_float2(0.f, 0.f);
+        if (u < U && U <= kRampU) {
+            // translate(transImgP, orignImgP, -(tran - offset)(0), -(tran - offset)(1), ...), src/Optimiser.cpp:7160-7169
+            const size_t dm = dm0 + pTRep[u];
+            const double tx = a.trans[2 * dm] - offx, ty = a.trans[2 * dm + 1] - offy;
+            ramp[u] = ramp_value((float)(-tx) / a.idim, (float)(-ty) / a.idim, pi, pj);
+        }
+    }
+    const float wgt = a.w[img];
+    const float gF = ldexpf(1.0f, b.gexp[0]), gT = ldexpf(1.0f, b.gexp[1]);
+
+    for (int g0 = 0; g0 < G; g0 += kPassGroups) {
+        const int ng = G - g0 < kPassGroups ? G - g0 : kPassGroups;
+        __syncthreads();   // the previous pass is done with the tables
+        for (int i = tid; i < kHash; i += kBinThreads) { hKey[i] = -1; hCnt[i] = 0; }
+        if (tid < ng) {
+            const int rep = pGRep[g0 + tid];
+            const double* R = a.rotMat + (dm0 + rep) * 9;
+#pragma unroll
+            for (int e = 0; e < 6; e++) sR[tid][e] = R[e];
+            sCls[tid] = a.cls ? a.cls[dm0 + rep] : 0;
+            sRep[tid] = rep;
+        }
+        if (tid <= ng) sM0[tid] = pGStart[g0 + tid];
+        if (tid < kPassGroups * kRampU) (&sCntI[0][0])[tid] = 0;
+        __syncthreads();
+        if (U <= kRampU)   // how many members of each group carry each unique shift
+            for (int m = sM0[0] + tid; m < sM0[ng]; m += kBinThreads) {
+                int gl = 0;
+                while (gl + 1 < ng && m >= sM0[gl + 1]) gl++;
+                atomicAdd(&sCntI[gl][pUid[pOrd[m]]], 1);
+            }
+
+        // ---- count: samples of this pass per brick ----
+        for (int gl = 0; gl < ng; gl++) {
+            SampleGeom s;
+            const bool v = listed && sample_geom(sR[gl], icp, irp, P, sCls[gl], b.nBx, b.nBy, b.nBz, s);
+            const WaveGroup wg = wave_group_by_key(v, v ? s.key : -1);
+            if (v && lane == wg.lead) atomicAdd(&hCnt[hash_insert(hKey, s.key)], wg.n);
+        }
+        __syncthreads();
+
+        // ---- one reservation for the pass: records and segment descriptors ----
+        constexpr int kPer = kHash / kBinThreads;
+        int c[kPer], sum = 0, nz = 0;
+#pragma unroll
+        for (int i = 0; i < kPer; i++) { c[i] = hCnt[tid * kPer + i]; sum += c[i]; nz += c[i] > 0; }
+        int isum = sum, inz = nz;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int ts = __shfl_up(isum, o, 64), tn = __shfl_up(inz, o, 64);
+            if (lane >= o) { isum += ts; inz += tn; }
+        }
+        if (lane == 63) { sWS[wave] = isum; sWN[wave] = inz; }
+        __syncthreads();
+        int total = 0, totalSeg = 0, preS = 0, preN = 0;
+#pragma unroll
+        for (int wv = 0; wv < kBinThreads / 64; wv++) {
+            if (wv < wave) { preS += sWS[wv]; preN += sWN[wv]; }
+            total += sWS[wv]; totalSeg += sWN[wv];
+        }
+        if (total == 0) continue;   // (uniform)
+        if (tid == 0) {
+            const unsigned long long old = atomicAdd(b.counter, (unsigned long long)total | ((unsigned long long)totalSeg << 40));
+            const unsigned long long rb = old & ((1ull << 40) - 1ull), sb = old >> 40;
+            sRecBase = rb;
+            sSegBase = (unsigned)(sb < 0xFFFFFFFFull ? sb : 0xFFFFFFFFull);
+            sDirect = (rb + (unsigned long long)total > (unsigned long long)b.capR) || (sb + (unsigned long long)totalSeg > (unsigned long long)b.capS);
+        }
+        __syncthreads();
+        const bool direct = sDirect != 0;
+        {
+            unsigned rOff = (unsigned)sRecBase + (unsigned)(preS + isum - sum);
+            unsigned long long sIdx = (unsigned long long)sSegBase + (unsigned long long)(preN + inz - nz);
+#pragma unroll
+            for (int i = 0; i < kPer; i++) {
+                if (c[i] <= 0) continue;
+                if (!direct) {
+                    b.segKey[sIdx] = (unsigned)hKey[tid * kPer + i];
+                    b.segVal[sIdx] = (unsigned long long)rOff | ((unsigned long long)c[i] << 32);
+                    hBase[tid * kPer + i] = rOff;
+                } else if (sIdx < (unsigned long long)b.capS) {   // a hole: sorts behind every brick, holds nothing
+                    b.segKey[sIdx] = 0xFFFFFFFFu;
+                    b.segVal[sIdx] = 0ull;
+                }
+                rOff += (unsigned)c[i];
+                sIdx++;
+            }
+        }
+        __syncthreads();
+
+        // ---- scatter: the samples again, now with their values, each into its brick's segment ----
+        for (int gl = 0; gl < ng; gl++) {
+            SampleGeom s;
+            const bool v = listed && sample_geom(sR[gl], icp, irp, P, sCls[gl], b.nBx, b.nBy, b.nBz, s);
+            unsigned idx = 0;
+            if (!direct) {
+                const WaveGroup wg = wave_group_by_key(v, v ? s.key : -1);
+                unsigned base = 0;
+                if (v && lane == wg.lead) base = atomicAdd(&hBase[hash_find(hKey, s.key)], (unsigned)wg.n);
+                base = (unsigned)__shfl((int)base, wg.lead, 64);
+                idx = base + (unsigned)wg.rank;
+            }
+            if (!v) continue;
+            // the value of this pixel for the group: (img * sum of the members' ramps) * ctf * w, T: n * ctf^2 * w
+            const int m0 = sM0[gl], m1 = sM0[gl + 1];
+            float2 S = make_float2(0.f, 0.f);
+            if (U <= kRampU) {
+#pragma unroll
+                for (int u = 0; u < kRampU; u++)
+                    if (u < U) {
+                        const float n = (float)sCntI[gl][u];
+                        S.x = fmaf(n, ramp[u].x, S.x);
+                        S.y = fmaf(n, ramp[u].y, S.y);
+                    }
+            } else {
+                S = ramp_sum_members(a.trans, pOrd, dm0, m0, m1, offx, offy, a.idim, pi, pj);
+            }
+            const float2 tv = cmul(dv, S);
+            float cfv = cf;
+            if (a.cSearch) cfv = insert_ctf_search(a.attr, a.dfac, img, a.mReco, sRep[gl], a.pixelSize, a.idim, pi, pj);
+            // src[i] * ctf[i] * 1 * w, left to right (src/Reconstructor.cpp:830-833)
+            float vre = tv.x * cfv, vim = tv.y * cfv;
+            vre = vre * 1.0f; vim = vim * 1.0f;
+            vre = vre * wgt; vim = vim * wgt;
+            if (s.conj) vim = -vim;
+            const float tval = (pow2f_(cfv) * 1.0f * wgt) * (float)(m1 - m0);
+            const float vreS = vre * gF, vimS = vim * gF, tvalS = tval * gT;
+            if (direct) {
+                terms_direct(b.accF + (size_t)sCls[gl] * volSize * 2, b.accT + (size_t)sCls[gl] * volSize, P, s, vreS, vimS, tvalS);
+            } else {
+                b.recA[idx] = make_uint4(__float_as_uint(s.xd), __float_as_uint(s.yd), __float_as_uint(s.zd), s.cell);
+                float* rb = b.recB + 3 * (size_t)idx;
+                rb[0] = vreS; rb[1] = vimS; rb[2] = tvalS;
+            }
+        }
+    }
+}
+
+__global__ void k_plan_counts(int* __restrict__ out, const int* __restrict__ plan, int nImg, int stride)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l < nImg) out[l] = plan[(size_t)l * stride];
+}
+
+__global__ void k_seg_unpack(unsigned* __restrict__ segOff, unsigned* __restrict__ segCnt, unsigned* __restrict__ cum0,
+                             const unsigned long long* __restrict__ val, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) cum0[0] = 0u;
+    if (i >= n) return;
+    const unsigned long long v = val[i];
+    segOff[i] = (unsigned)v;
+    segCnt[i] = (unsigned)(v >> 32);
+}
+
+struct AccArgs {
+    const uint4* recA;
+    const float* recB;
+    const unsigned* segKey;   // sorted
+    const unsigned* segOff;
+    const unsigned* segCnt;
+    const unsigned* cum;      // [nSeg + 1] records before segment i
+    int nSeg;
+    long long* accF;
+    long long* accT;
+    int P, nBx, nBy, nBz;
+};
+
+// first index in [0, n] whose cum is >= v
+__device__ __forceinline__ int lower_bound_u32(const unsigned* __restrict__ cum, int n, unsigned long long v)
+{
+    int lo = 0, hi = n + 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((unsigned long long)cum[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// workgroup w owns the segments that START in records [w kAccSpan, (w + 1) kAccSpan) of the sorted order
+__global__ __launch_bounds__(kAccThreads, 2) void k_acc(AccArgs q)
+{
+    __shared__ long long sRe[kBrickVox], sIm[kBrickVox], sT[kBrickVox];
+    __shared__ int sRunEnd, sNext;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned long long lo = (unsigned long long)blockIdx.x * kAccSpan, hi = lo + kAccSpan;
+    if (lo >= (unsigned long long)q.cum[q.nSeg]) return;
+    int s0 = lower_bound_u32(q.cum, q.nSeg, lo), s1 = lower_bound_u32(q.cum, q.nSeg, hi);
+    s1 = s1 > q.nSeg ? q.nSeg : s1;
+    for (int e = tid; e < kBrickVox; e += kAccThreads) { sRe[e] = 0; sIm[e] = 0; sT[e] = 0; }
+    const int P = q.P;
+    const long nc = P / 2 + 1;
+    const size_t volSize = (size_t)P * P * (P / 2 + 1);
+    for (int s = s0; s < s1;) {
+        const unsigned key = q.segKey[s];
+        lds_barrier();   // (LDS only: the previous brick's global atomics stay in flight)
+        if (tid == 0) { sRunEnd = s1; sNext = s; }
+        lds_barrier();
+        for (int i = s + 1 + tid; i < s1; i += kAccThreads)
+            if (q.segKey[i] != key) { atomicMin(&sRunEnd, i); break; }
+        lds_barrier();
+        const int e = sRunEnd;
+        // ---- accumulate the run's segments, a wave at a time ----
+        for (;;) {
+            int i = 0;
+            if (lane == 0) i = atomicAdd(&sNext, 1);
+            i = __builtin_amdgcn_readfirstlane(i);
+            if (i >= e) break;
+            const unsigned off = q.segOff[i], cnt = q.segCnt[i];
+            for (unsigned r = lane; r < cnt; r += 64) {
+                const uint4 ra = q.recA[off + r];
+                const float* rb = q.recB + 3 * (size_t)(off + r);
+                const float vreS = rb[0], vimS = rb[1], tvalS = rb[2];
+                const float xd = __uint_as_float(ra.x), yd = __uint_as_float(ra.y), zd = __uint_as_float(ra.z);
+                const float vx[2] = {1.0f - xd, xd}, vy[2] = {1.0f - yd, yd}, vz[2] = {1.0f - zd, zd};
+                const int cx = ra.w & (kBx - 1), cy = (ra.w >> 4) & (kBy - 1), cz = (ra.w >> 8) & (kBz - 1);
+                const int base = (cz * kVy + cy) * kVx + cx;
+#pragma unroll
+                for (int v = 0; v < 8; v++) {
+                    const int ii = v & 1, jj = (v >> 1) & 1, kk = v >> 2;
+                    const float wv = vx[ii] * vy[jj] * vz[kk];
+                    const long long t = f2ll_magic(tvalS * wv);
+                    if (t == 0) continue;   // F and T travel together
+                    const int idx = base + (kk * kVy + jj) * kVx + ii;
+                    atomicAdd(reinterpret_cast<unsigned long long*>(&sRe[idx]), (unsigned long long)f2ll_magic(vreS * wv));
+                    atomicAdd(reinterpret_cast<unsigned long long*>(&sIm[idx]), (unsigned long long)f2ll_magic(vimS * wv));
+                    atomicAdd(reinterpret_cast<unsigned long long*>(&sT[idx]), (unsigned long long)t);
+                }
+            }
+        }
+        lds_barrier();
+        // ---- flush the brick: x fastest, i.e. along the volume's contiguous axis ----
+        {
+            const int bx = (int)(key % (unsigned)q.nBx), by = (int)((key / (unsigned)q.nBx) % (unsigned)q.nBy);
+            const int bzk = (int)(key / ((unsigned)q.nBx * (unsigned)q.nBy));
+            const int bz = bzk % q.nBz, cls = bzk / q.nBz;
+            long long* F = q.accF + (size_t)cls * volSize * 2;
+            long long* T = q.accT + (size_t)cls * volSize;
+            for (int v = tid; v < kBrickVox; v += kAccThreads) {
+                const long long re = sRe[v], im = sIm[v], tt = sT[v];
+                if ((re | im | tt) == 0) continue;
+                sRe[v] = 0; sIm[v] = 0; sT[v] = 0;
+                const int vxI = v % kVx, r = v / kVx, vyI = r % kVy, vzI = r / kVy;
+                const int X = bx * kBx + vxI, Y = by * kBy + vyI - P / 2, Z = bz * kBz + vzI - P / 2;
+                const long gi = ((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X;
+                acc_add(F, T, gi, re, im, tt);
+            }
+        }
+        lds_barrier();   // the flush's global atomics stay in flight
+        s = e;
+    }
+}
+
+// scratch the sorted form keeps per device: chosen on first use (THX_INSERT_SCRATCH_MB, else min(8 GiB, 40 % of the free memory))
+static size_t sort_budget_bytes(size_t oneImageWorst)
+{
+    static size_t budget[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!budget[dev]) {
+        size_t b = 0;
+        if (const char* e = getenv("THX_INSERT_SCRATCH_MB")) b = (size_t)atoll(e) << 20;
+        if (!b) {
+            size_t freeB = 0, totalB = 0;
+            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = (size_t)4 << 30;
+            b = std::min((size_t)8 << 30, (size_t)(0.4 * (double)freeB));
+        }
+        budget[dev] = std::max(b, (size_t)64 << 20);
+    }
+    if (budget[dev] < oneImageWorst) budget[dev] = oneImageWorst;
+    return budget[dev];
+}
+
+static inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const int* gexp, long long* accF, long long* accT, int nImg)
+{
+    const int nPxl = a.nPxl, mReco = a.mReco, P = a.P, nK = a.nK > 0 ? a.nK : 1;
+    const int nBx = (P / 2 + kBx - 1) / kBx + 1, nBy = (P + kBy - 1) / kBy, nBz = (P + kBz - 1) / kBz;
+    const unsigned long long nBrick = (unsigned long long)nBx * nBy * nBz * nK;
+    THX_REQUIRE(nBrick < 0x7FFFFFFFull, "volume has too many bricks for 31-bit brick ids");
+    // the images' group counts decide how many fit a chunk
+    int* gDev = reinterpret_cast<int*>(scratch(st, 13, (size_t)nImg * sizeof(int)));
+    THX_REQUIRE(gDev, "device scratch allocation failed");
+    hipLaunchKernelGGL(k_plan_counts, dim3((nImg + 255) / 256), dim3(256), 0, st, gDev, plan, nImg, plan_stride(mReco));
+    std::vector<int> gHost(nImg);
+    THX_CHECK(hipMemcpyAsync(gHost.data(), gDev, (size_t)nImg * sizeof(int), hipMemcpyDeviceToHost, st));
+    THX_CHECK(hipStreamSynchronize(st));
+
+    constexpr size_t kRecBytes = sizeof(uint4) + 3 * sizeof(float);
+    constexpr size_t kSegBytes = 2 * sizeof(unsigned) + 2 * sizeof(unsigned long long) + 3 * sizeof(unsigned);
+    const size_t perRec = kRecBytes + kSegBytes / 32 + 1;
+    const size_t budget = sort_budget_bytes((size_t)mReco * nPxl * perRec + ((size_t)1 << 20));
+    size_t capR64 = (budget - ((size_t)1 << 20)) / perRec;
+    capR64 = std::min(capR64, (size_t)0xFFFF0000u);
+    const unsigned capR = (unsigned)capR64;
+    const unsigned capS = capR / 32 + 4096;
+    size_t o = 0;
+    const size_t oRecA = o; o += align256((size_t)capR * sizeof(uint4));
+    const size_t oRecB = o; o += align256((size_t)capR * 3 * sizeof(float));
+    const size_t oKeyIn = o; o += align256((size_t)capS * sizeof(unsigned));
+    const size_t oKeyOut = o; o += align256((size_t)capS * sizeof(unsigned));
+    const size_t oValIn = o; o += align256((size_t)capS * sizeof(unsigned long long));
+    const size_t oValOut = o; o += align256((size_t)capS * sizeof(unsigned long long));
+    const size_t oOff = o; o += align256((size_t)capS * sizeof(unsigned));
+    const size_t oCnt = o; o += align256((size_t)capS * sizeof(unsigned));
+    const size_t oCum = o; o += align256(((size_t)capS + 1) * sizeof(unsigned));
+    const size_t oCtr = o; o += 256;
+    char* buf = reinterpret_cast<char*>(scratch(st, 12, o));
+    THX_REQUIRE(buf, "device scratch allocation failed (brick-sorted insertion records)");
+    unsigned* keyIn = reinterpret_cast<unsigned*>(buf + oKeyIn);
+    unsigned* keyOut = reinterpret_cast<unsigned*>(buf + oKeyOut);
+    unsigned long long* valIn = reinterpret_cast<unsigned long long*>(buf + oValIn);
+    unsigned long long* valOut = reinterpret_cast<unsigned long long*>(buf + oValOut);
+    unsigned* segOff = reinterpret_cast<unsigned*>(buf + oOff);
+    unsigned* segCnt = reinterpret_cast<unsigned*>(buf + oCnt);
+    unsigned* cum = reinterpret_cast<unsigned*>(buf + oCum);
+    unsigned long long* ctr = reinterpret_cast<unsigned long long*>(buf + oCtr);
+
+    int keyBits = 1;
+    while ((1ull << keyBits) <= nBrick) keyBits++;   // 2^keyBits - 1 > every brick id: holes (all ones) sort last
+    size_t tmpSort = 0, tmpScan = 0;
+    THX_CHECK(rocprim::radix_sort_pairs(nullptr, tmpSort, keyIn, keyOut, valIn, valOut, (size_t)capS, 0u, (unsigned)keyBits, st));
+    THX_CHECK(rocprim::inclusive_scan(nullptr, tmpScan, segCnt, cum + 1, (size_t)capS, rocprim::plus<unsigned>(), st));
+    const size_t tmpBytes = std::max(tmpSort, tmpScan);
+    void* tmp = scratch(st, 14, tmpBytes);
+    THX_REQUIRE(tmp, "device scratch allocation failed (sort workspace)");
+
+    const int nRegion = (nPxl + kBinThreads - 1) / kBinThreads;
+    for (int l0 = 0; l0 < nImg;) {
+        unsigned long long need = 0;
+        int l1 = l0;
+        while (l1 < nImg && l1 - l0 < 65535) {
+            const unsigned long long add = (unsigned long long)gHost[l1] * (unsigned long long)nPxl;
+            if (l1 > l0 && need + add > (unsigned long long)capR) break;
+            need += add;
+            l1++;
+        }
+        const int nl = l1 - l0;
+        BinArgs b;
+        b.a = a;
+        b.a.datP += (size_t)l0 * nPxl; b.a.ctfP += (size_t)l0 * nPxl; b.a.w += l0;
+        b.a.rotMat += (size_t)l0 * mReco * 9; b.a.trans += (size_t)l0 * mReco * 2;
+        if (b.a.offS) b.a.offS += (size_t)l0 * 2;
+        if (b.a.cls) b.a.cls += (size_t)l0 * mReco;
+        if (b.a.attr) b.a.attr += l0;
+        if (b.a.dfac) b.a.dfac += (size_t)l0 * mReco;
+        b.plan = plan + (size_t)l0 * plan_stride(mReco);
+        b.gexp = gexp; b.accF = accF; b.accT = accT;
+        b.recA = reinterpret_cast<uint4*>(buf + oRecA); b.recB = reinterpret_cast<float*>(buf + oRecB);
+        b.segKey = keyIn; b.segVal = valIn; b.counter = ctr; b.capR = capR; b.capS = capS;
+        b.nBx = nBx; b.nBy = nBy; b.nBz = nBz;
+        THX_CHECK(hipMemsetAsync(ctr, 0, sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_bin, dim3(nRegion, nl), dim3(kBinThreads), 0, st, b);
+        unsigned long long used = 0;
+        THX_CHECK(hipMemcpyAsync(&used, ctr, sizeof(used), hipMemcpyDeviceToHost, st));
+        THX_CHECK(hipStreamSynchronize(st));
+        const unsigned long long usedRec = used & ((1ull << 40) - 1ull), usedSeg = used >> 40;
+        const int nSeg = (int)std::min<unsigned long long>(usedSeg, capS);
+        const unsigned long long nRec = std::min<unsigned long long>(usedRec, capR);
+        if (nSeg > 0 && nRec > 0) {
+            size_t tb = tmpBytes;
+            THX_CHECK(rocprim::radix_sort_pairs(tmp, tb, keyIn, keyOut, valIn, valOut, (size_t)nSeg, 0u, (unsigned)keyBits, st));
+            hipLaunchKernelGGL(k_seg_unpack, dim3((nSeg + 255) / 256), dim3(256), 0, st, segOff, segCnt, cum, valOut, nSeg);
+            tb = tmpBytes;
+            THX_CHECK(rocprim::inclusive_scan(tmp, tb, segCnt, cum + 1, (size_t)nSeg, rocprim::plus<unsigned>(), st));
+            AccArgs q;
+            q.recA = b.recA; q.recB = b.recB; q.segKey = keyOut; q.segOff = segOff; q.segCnt = segCnt; q.cum = cum; q.nSeg = nSeg;
+            q.accF = accF; q.accT = accT; q.P = P; q.nBx = nBx; q.nBy = nBy; q.nBz = nBz;
+            const unsigned nWg = (unsigned)((nRec + kAccSpan - 1) / kAccSpan);
+            hipLaunchKernelGGL(k_acc, dim3(nWg), dim3(kAccThreads), 0, st, q);
+        }
+        l0 = l1;
+    }
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace thx

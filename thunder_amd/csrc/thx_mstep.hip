@@ -3,6 +3,7 @@
 // src/Reconstructor.cpp:407-422,782-863,2455-2476,2676-2690, src/Image/Volume.cpp:340-375,565-712,
 // include/Geometry/Transformation.h:105-131,170-194.  gfx950 only.
 #include "thx_common.h"
+#include "thx_insert.h"
 
 namespace thx {
 
@@ -14,27 +15,6 @@ namespace thx {
 // (global_atomic_add_f32): the MI355X counterpart of the reference's `#pragma omp atomic`
 // (src/Image/Volume.cpp:584-587,676-677).  grid (ceil(nPxl/256), nImg).
 // ---------------------------------------------------------------------------------------------
-struct InsertArgs {
-    float2* F;
-    float* T;
-    double* O;
-    int* counter;
-    int P, nK;
-    const float2* datP;
-    const float* ctfP;
-    const float* w;
-    const double* rotMat;
-    const double* trans;
-    const double* offS;
-    const int* cls;
-    const thx_ctf_attr* attr;
-    const double* dfac;
-    int cSearch;
-    float pixelSize;
-    const int* iCol;
-    const int* iRow;
-    int opf, nPxl, mReco, idim;
-};
 
 __global__ __launch_bounds__(256) void k_insert(InsertArgs a)
 {
@@ -145,7 +125,6 @@ constexpr int kMaxU = 16;           // unique shifts whose ramps are tabulated i
 // Per image: [0] G, [1] U, gStart[mReco+1], ord[mReco] (draws sorted by group), uid[mReco] (unique-shift id per draw),
 // gRep[mReco] (representative draw of group g), tRep[mReco] (representative draw of unique shift u).
 // ---------------------------------------------------------------------------------------------
-__host__ __device__ inline int plan_stride(int mReco) { return 5 * mReco + 3; }
 
 __global__ __launch_bounds__(128) void k_insert_plan(int* __restrict__ plan, const double* __restrict__ rotMat,
                                                      const double* __restrict__ trans, const int* __restrict__ cls,
@@ -387,22 +366,10 @@ __device__ __attribute__((noinline)) float2 insert_ramp_sum_slow(const float* sl
     }
     return S;
 }
-__device__ __attribute__((noinline)) float insert_ctf_search(const thx_ctf_attr* attr, const double* dfac, int img, int mReco, int rep,
-                                                             float pixelSize, int idim, int pi, int pj)
-{
-    const CtfConst cc = ctf_const(attr[img], dfac[(size_t)img * mReco + rep]);
-    return ctf_value(cc, pixelSize, idim, idim, pi, pj);
-}
 // The volume accumulators of the window kernel are 64-bit FIXED POINT (quanta 2^-E_F / 2^-E_T of one unit, one pair of
 // exponents per launch, k_insert_scale): integer atomic adds commute, so F and T come out bit-identical run to run whatever
 // the order in which workgroups flush -- the float atomics of the first version made the gridding loop's round count move
 // by +-10 % from run to run.  k_insert_convert adds the accumulators to the caller's float volumes afterwards.
-__device__ __forceinline__ void acc_add(long long* F, long long* T, long gi, long long re, long long im, long long tt)
-{
-    atomicAdd(reinterpret_cast<unsigned long long*>(F + 2 * gi), (unsigned long long)re);
-    atomicAdd(reinterpret_cast<unsigned long long*>(F + 2 * gi + 1), (unsigned long long)im);
-    atomicAdd(reinterpret_cast<unsigned long long*>(T + gi), (unsigned long long)tt);
-}
 // left shifts are exact; a right shift (an image more than 2^8 below the launch's largest) rounds to nearest, ties away from
 // zero -- an arithmetic shift alone would floor, i.e. bias every negative F term of such an image towards -inf
 __device__ __forceinline__ long long shift_ll(long long v, int sh)
@@ -1165,11 +1132,6 @@ int thx_insert_accumulate_dev(void* acc, const int* gexp, const float* bounds, d
     a.iCol = iCol; a.iRow = iRow; a.opf = opf; a.nPxl = nPxl; a.mReco = mReco; a.idim = idim;
     hipStream_t st = as_stream(stream);
     const int half = idim / 2;
-    const size_t tb = (size_t)idim * (half + 1) * sizeof(int);
-    int* pixIndex = reinterpret_cast<int*>(scratch(st, 0, tb));
-    THX_REQUIRE(pixIndex, "device scratch allocation failed");
-    THX_CHECK(hipMemsetAsync(pixIndex, 0xFF, tb, st));
-    hipLaunchKernelGGL(k_pix_index, dim3((nPxl + 255) / 256), dim3(256), 0, st, pixIndex, iCol, iRow, nPxl, idim);
     int* plan = reinterpret_cast<int*>(scratch(st, 3, (size_t)nImg * plan_stride(mReco) * sizeof(int)));
     THX_REQUIRE(plan, "device scratch allocation failed");
     hipLaunchKernelGGL(k_insert_plan, dim3(nImg), dim3(128), 5 * (size_t)mReco * sizeof(int), st, plan, rotMat, trans, cls, dfac,
@@ -1179,6 +1141,14 @@ int thx_insert_accumulate_dev(void* acc, const int* gexp, const float* bounds, d
     const size_t volSize = (size_t)dim * dim * (dim / 2 + 1) * (size_t)(nK > 0 ? nK : 1);
     long long* accF = reinterpret_cast<long long*>(acc);
     long long* accT = accF + 2 * volSize;
+    // the production form: samples binned by brick of the volume, bricks accumulated over all the images of a chunk
+    // (thx_insert_sort.hip); THX_INSERT=win keeps the per-image window kernel below for A/B runs
+    if (!knobs().insertWin) return insert_sorted(st, a, plan, gexp, accF, accT, nImg);
+    const size_t tb = (size_t)idim * (half + 1) * sizeof(int);
+    int* pixIndex = reinterpret_cast<int*>(scratch(st, 0, tb));
+    THX_REQUIRE(pixIndex, "device scratch allocation failed");
+    THX_CHECK(hipMemsetAsync(pixIndex, 0xFF, tb, st));
+    hipLaunchKernelGGL(k_pix_index, dim3((nPxl + 255) / 256), dim3(256), 0, st, pixIndex, iCol, iRow, nPxl, idim);
     const size_t ldsWin = 3 * (size_t)kWinVox * sizeof(int) + (size_t)mReco * 6 * sizeof(double) +
                           ((size_t)(mReco + 1) + mReco + 2 * mReco) * sizeof(int) + 2 * (size_t)mReco * sizeof(float) +
                           4 * (size_t)mReco * sizeof(short) + 2 * (size_t)mReco * sizeof(float) + 32 +
