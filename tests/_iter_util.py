@@ -201,6 +201,22 @@ class Follower:
             self.adopted.append((p, l, "resample" if exact else "resample (threshold within 1e-5)"))
             for k in ("q", "t", "wR", "wT", "srcR", "srcT", "topR", "topT", "iTopR", "iTopT"):
                 own[k] = alt[k]
+        elif "iTopR" in own:
+            # same resampled indices, but _topR / _topT = the FIRST LARGEST weight (src/Particle.cpp:1291-1430) is a discrete
+            # decision too: two support points whose weights agree to within the weight bar can swap under the device's rounding
+            seed, mLR, mLT = c["seed"], c["mLR"], c["mLT"]
+            li, call = own["li"], own["callU"]
+            alt = O.pf_update(own["qIn"], own["tPre"], own["wRIn"], own["wTIn"], uR, uT, c["peakFactorR"],
+                              PH.shuffle_ranks(seed, li, call, 2, mLR), PH.draw_u4(seed, li, call, 3, 0)[0] / mLR,
+                              PH.shuffle_ranks(seed, li, call, 4, mLT), PH.draw_u4(seed, li, call, 5, 0)[0] / mLT)
+            if alt["iTopR"] != own["iTopR"] or alt["iTopT"] != own["iTopT"]:
+                for mine, ia, io, name in ((np.asarray(own["uR"], np.float64), alt["iTopR"], own["iTopR"], "uR"),
+                                           (np.asarray(own["uT"], np.float64), alt["iTopT"], own["iTopT"], "uT")):
+                    assert abs(mine[ia] - mine[io]) <= 2 * bar * abs(mine[io]) + 2e-6 * mine.max(), \
+                        "phase %d image %d: the device's top %s is not a tie in the oracle's weights" % (p, l, name)
+                self.adopted.append((p, l, "top"))
+                for k in ("topR", "topT", "iTopR", "iTopT"):
+                    own[k] = alt[k]
         return own
 
 

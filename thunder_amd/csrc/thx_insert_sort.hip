@@ -46,14 +46,15 @@ struct BinArgs {
     InsertArgs a;               // image-indexed pointers at the chunk's first image
     const int* plan;            // k_insert_plan, at the chunk's first image
     const int* gexp;            // [2]: E_F, E_T
+    const unsigned* groupsBefore; // [images of the chunk]: groups of the chunk's earlier images (the records' static layout)
     long long* accF;            // [nK][vol][2]
     long long* accT;            // [nK][vol]
     uint4* recA;                // [capR]: xd, yd, zd (float bits), cell
     float* recB;                // [capR][3]: vre 2^E_F, vim 2^E_F (conjugated where folded), tval 2^E_T
     unsigned* segKey;           // [capS] brick id of the segment
     unsigned long long* segVal; // [capS] first record | count << 32
-    unsigned long long* counter;// records | segments << 40 reserved so far
-    unsigned capR, capS;
+    unsigned* counter;          // segment descriptors reserved so far
+    unsigned capS;
     int nBx, nBy, nBz;
 };
 
@@ -66,7 +67,6 @@ __device__ __forceinline__ long long f2ll_magic(float q)
 
 struct SampleGeom {
     float xd, yd, zd;
-    int X0, Y0, Z0;
     int key;
     unsigned cell;
     bool conj;
@@ -83,34 +83,11 @@ __device__ __forceinline__ bool sample_geom(const double* R, int icp, int irp, i
     s.conj = false;
     if (!(x >= 0.0f)) { x *= -1.0f; y *= -1.0f; z *= -1.0f; s.conj = true; }
     const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
-    s.X0 = (int)fx; s.Y0 = (int)fy; s.Z0 = (int)fz;
+    const int X0 = (int)fx, yb = (int)fy + P / 2, zb = (int)fz + P / 2;
     s.xd = x - fx; s.yd = y - fy; s.zd = z - fz;
-    const int yb = s.Y0 + P / 2, zb = s.Z0 + P / 2;
-    s.key = ((cls * nBz + (zb >> kBLz)) * nBy + (yb >> kBLy)) * nBx + (s.X0 >> kBLx);
-    s.cell = (unsigned)(s.X0 & (kBx - 1)) | ((unsigned)(yb & (kBy - 1)) << 4) | ((unsigned)(zb & (kBz - 1)) << 8);
+    s.key = ((cls * nBz + (zb >> kBLz)) * nBy + (yb >> kBLy)) * nBx + (X0 >> kBLx);
+    s.cell = (unsigned)(X0 & (kBx - 1)) | ((unsigned)(yb & (kBy - 1)) << 4) | ((unsigned)(zb & (kBz - 1)) << 8);
     return true;
-}
-
-// lanes of a wave with equal keys: the lowest is their leader, n their number, rank the lane's position among them
-struct WaveGroup {
-    int lead, n, rank;
-};
-__device__ __forceinline__ WaveGroup wave_group_by_key(bool valid, int key)
-{
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    WaveGroup g;
-    g.lead = lane; g.n = 0; g.rank = 0;
-    unsigned long long rem = __ballot(valid);
-    while (rem) {
-        const int l = __ffsll((long long)rem) - 1;
-        const int k = __builtin_amdgcn_readlane(key, l);
-        const bool mine = valid && key == k;
-        const unsigned long long eq = __ballot(mine);
-        if (mine) { g.lead = l; g.n = __popcll(eq); g.rank = __popcll(eq & lt); }
-        rem &= ~eq;
-    }
-    return g;
 }
 
 __device__ __forceinline__ unsigned hash_of(int key) { return ((unsigned)key * 2654435761u) >> (32 - 11); }
@@ -147,43 +124,87 @@ __device__ __attribute__((noinline)) float2 ramp_sum_members(const double* trans
     return S;
 }
 
-// the eight voxel terms of one sample straight into the 64-bit volume accumulators: what k_acc does through LDS, term for term
-// (taken only by a pass whose records do not fit the chunk's buffers)
-__device__ __attribute__((noinline)) void terms_direct(long long* F, long long* T, int P, const SampleGeom& s, float vreS, float vimS, float tvalS)
+// the records of one segment straight into the 64-bit volume accumulators: what k_acc does through LDS, term for term.  Taken
+// only by a workgroup of k_bin whose segment descriptors no longer fit the chunk's table (capS), for the segments it holds.
+__device__ __forceinline__ void segment_direct(long long* accF, long long* accT, int P, int nBx, int nBy, int nBz, unsigned key,
+                                                         const uint4* recA, const float* recB, unsigned off, unsigned cnt)
 {
-    const float vx[2] = {1.0f - s.xd, s.xd}, vy[2] = {1.0f - s.yd, s.yd}, vz[2] = {1.0f - s.zd, s.zd};
     const long nc = P / 2 + 1;
-    for (int v = 0; v < 8; v++) {
-        const int ii = v & 1, jj = (v >> 1) & 1, kk = v >> 2;
-        const float wv = vx[ii] * vy[jj] * vz[kk];
-        const long long t = f2ll_magic(tvalS * wv);
-        if (t == 0) continue;
-        const int X = s.X0 + ii, Y = s.Y0 + jj, Z = s.Z0 + kk;
-        const long gi = ((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X;
-        acc_add(F, T, gi, f2ll_magic(vreS * wv), f2ll_magic(vimS * wv), t);
+    const size_t volSize = (size_t)P * P * (P / 2 + 1);
+    const int bx = (int)(key % (unsigned)nBx), by = (int)((key / (unsigned)nBx) % (unsigned)nBy);
+    const int bzk = (int)(key / ((unsigned)nBx * (unsigned)nBy));
+    const int bz = bzk % nBz, cls = bzk / nBz;
+    long long* F = accF + (size_t)cls * volSize * 2;
+    long long* T = accT + (size_t)cls * volSize;
+    for (unsigned r = threadIdx.x; r < cnt; r += blockDim.x) {
+        const uint4 ra = recA[off + r];
+        const float* rb = recB + 3 * (size_t)(off + r);
+        const float vreS = rb[0], vimS = rb[1], tvalS = rb[2];
+        const float xd = __uint_as_float(ra.x), yd = __uint_as_float(ra.y), zd = __uint_as_float(ra.z);
+        const float vx[2] = {1.0f - xd, xd}, vy[2] = {1.0f - yd, yd}, vz[2] = {1.0f - zd, zd};
+        const int X0 = bx * kBx + (int)(ra.w & (kBx - 1)), Y0 = by * kBy + (int)((ra.w >> 4) & (kBy - 1)) - P / 2,
+                  Z0 = bz * kBz + (int)((ra.w >> 8) & (kBz - 1)) - P / 2;
+        for (int v = 0; v < 8; v++) {
+            const int ii = v & 1, jj = (v >> 1) & 1, kk = v >> 2;
+            const float wv = vx[ii] * vy[jj] * vz[kk];
+            const long long t = f2ll_magic(tvalS * wv);
+            if (t == 0) continue;
+            const int X = X0 + ii, Y = Y0 + jj, Z = Z0 + kk;
+            const long gi = ((long)(Z >= 0 ? Z : Z + P) * P + (Y >= 0 ? Y : Y + P)) * nc + X;
+            acc_add(F, T, gi, f2ll_magic(vreS * wv), f2ll_magic(vimS * wv), t);
+        }
     }
 }
 
-// grid (ceil(nPxl / 256), images of the chunk)
+// descriptors a workgroup of k_bin collects in LDS before it reserves table space for them with one global atomic
+constexpr int kSegList = kHash;   // a pass may touch up to 8 x 256 bricks
+
+// the workgroup's collected descriptors -> the chunk's table (or, when the table is full, their records straight into the volume)
+__device__ __forceinline__ void bin_flush_list(const BinArgs& b, const unsigned* lKey, const unsigned* lVal, unsigned regionBase, int n,
+                                               unsigned* sBase)
+{
+    __syncthreads();   // the list is complete, and the workgroup's record stores are visible to all of it
+    if (n == 0) return;
+    if (threadIdx.x == 0) *sBase = atomicAdd(b.counter, (unsigned)n);
+    __syncthreads();
+    const unsigned base = *sBase;
+    if ((unsigned long long)base + (unsigned long long)n <= (unsigned long long)b.capS) {
+        for (int i = threadIdx.x; i < n; i += kBinThreads) {
+            b.segKey[base + i] = lKey[i];
+            b.segVal[base + i] = (unsigned long long)(regionBase + (lVal[i] & 0xFFFFFu)) | ((unsigned long long)(lVal[i] >> 20) << 32);
+        }
+    } else {
+        // (what it did reserve inside the table becomes holes: they sort behind every brick and hold nothing)
+        for (unsigned i = base + threadIdx.x; i < b.capS; i += kBinThreads) { b.segKey[i] = 0xFFFFFFFFu; b.segVal[i] = 0ull; }
+        for (int i = 0; i < n; i++)
+            segment_direct(b.accF, b.accT, b.a.P, b.nBx, b.nBy, b.nBz, lKey[i], b.recA, b.recB, regionBase + (lVal[i] & 0xFFFFFu), lVal[i] >> 20);
+    }
+    __syncthreads();
+}
+
+// grid (ceil(nPxl / 256), images of the chunk).  Records have a STATIC place: image l of the chunk owns
+// [groupsBefore[l], groupsBefore[l] + G_l) x nRegion x 256 records, region r the G_l x 256 of them from r G_l 256 on, the pass
+// that starts with group g0 the 8 x 256 from g0 256 on, and the pass's segments are packed at the front of that span.
+// CS: CTF search (a CTF value per sample instead of the image's row); SLOWU: some image of the launch has more unique shifts
+// than a thread keeps ramps for -- both compile-time, so that the common instance carries neither path's registers.
+template <bool CS, bool SLOWU>
 __global__ __launch_bounds__(kBinThreads) void k_bin(BinArgs b)
 {
     const InsertArgs& a = b.a;
     __shared__ int hKey[kHash];
-    __shared__ int hCnt[kHash];
-    __shared__ unsigned hBase[kHash];
+    __shared__ int hCnt[kHash];          // samples per slot (count), then the slot's next record (scatter)
+    __shared__ unsigned lKey[kSegList];
+    __shared__ unsigned lVal[kSegList];   // record offset from the region's base (20 bits) | count << 20
     __shared__ double sR[kPassGroups][6];
     __shared__ int sCntI[kPassGroups][kRampU];
     __shared__ int sCls[kPassGroups], sRep[kPassGroups], sM0[kPassGroups + 1];
     __shared__ int sWS[kBinThreads / 64], sWN[kBinThreads / 64];
-    __shared__ unsigned long long sRecBase;
-    __shared__ unsigned sSegBase;
-    __shared__ int sDirect;
+    __shared__ unsigned sFlushBase;
 
     const int img = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = blockIdx.x * kBinThreads + tid;
     const bool listed = p < a.nPxl;
     const int P = a.P;
-    const size_t volSize = (size_t)P * P * (P / 2 + 1);
     const size_t dm0 = (size_t)img * a.mReco;
     const double offx = a.offS ? a.offS[2 * img] : 0.0, offy = a.offS ? a.offS[2 * img + 1] : 0.0;
 
@@ -224,7 +245,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin(BinArgs b)
 #pragma unroll
     for (int u = 0; u < kRampU; u++) {
         ramp[u] = make_float2(0.f, 0.f);
-        if (u < U && U <= kRampU) {
+        if (u < U && (!SLOWU || U <= kRampU)) {
             // translate(transImgP, orignImgP, -(tran - offset)(0), -(tran - offset)(1), ...), src/Optimiser.cpp:7160-7169
             const size_t dm = dm0 + pTRep[u];
             const double tx = a.trans[2 * dm] - offx, ty = a.trans[2 * dm + 1] - offy;
@@ -233,6 +254,8 @@ __global__ __launch_bounds__(kBinThreads) void k_bin(BinArgs b)
     }
     const float wgt = a.w[img];
     const float gF = ldexpf(1.0f, b.gexp[0]), gT = ldexpf(1.0f, b.gexp[1]);
+    const unsigned regionBase = (b.groupsBefore[img] * gridDim.x + blockIdx.x * (unsigned)G) * (unsigned)kBinThreads;
+    int lN = 0;   // descriptors waiting in the LDS list (uniform)
 
     for (int g0 = 0; g0 < G; g0 += kPassGroups) {
         const int ng = G - g0 < kPassGroups ? G - g0 : kPassGroups;
@@ -249,7 +272,7 @@ __global__ __launch_bounds__(kBinThreads) void k_bin(BinArgs b)
         if (tid <= ng) sM0[tid] = pGStart[g0 + tid];
         if (tid < kPassGroups * kRampU) (&sCntI[0][0])[tid] = 0;
         __syncthreads();
-        if (U <= kRampU)   // how many members of each group carry each unique shift
+        if (!SLOWU || U <= kRampU)   // how many members of each group carry each unique shift
             for (int m = sM0[0] + tid; m < sM0[ng]; m += kBinThreads) {
                 int gl = 0;
                 while (gl + 1 < ng && m >= sM0[gl + 1]) gl++;
@@ -259,13 +282,12 @@ __global__ __launch_bounds__(kBinThreads) void k_bin(BinArgs b)
         // ---- count: samples of this pass per brick ----
         for (int gl = 0; gl < ng; gl++) {
             SampleGeom s;
-            const bool v = listed && sample_geom(sR[gl], icp, irp, P, sCls[gl], b.nBx, b.nBy, b.nBz, s);
-            const WaveGroup wg = wave_group_by_key(v, v ? s.key : -1);
-            if (v && lane == wg.lead) atomicAdd(&hCnt[hash_insert(hKey, s.key)], wg.n);
+            // (LDS atomics of one wave on a few addresses: the hardware's own serialisation is cheaper than sorting the lanes by key)
+            if (listed && sample_geom(sR[gl], icp, irp, P, sCls[gl], b.nBx, b.nBy, b.nBz, s)) atomicAdd(&hCnt[hash_insert(hKey, s.key)], 1);
         }
         __syncthreads();
 
-        // ---- one reservation for the pass: records and segment descriptors ----
+        // ---- the pass's segments: one per brick it touched, packed from the pass's static record base on ----
         constexpr int kPer = kHash / kBinThreads;
         int c[kPer], sum = 0, nz = 0;
 #pragma unroll
@@ -278,59 +300,42 @@ __global__ __launch_bounds__(kBinThreads) void k_bin(BinArgs b)
         }
         if (lane == 63) { sWS[wave] = isum; sWN[wave] = inz; }
         __syncthreads();
-        int total = 0, totalSeg = 0, preS = 0, preN = 0;
+        int totalSeg = 0, preS = 0, preN = 0;
 #pragma unroll
         for (int wv = 0; wv < kBinThreads / 64; wv++) {
             if (wv < wave) { preS += sWS[wv]; preN += sWN[wv]; }
-            total += sWS[wv]; totalSeg += sWN[wv];
+            totalSeg += sWN[wv];
         }
-        if (total == 0) continue;   // (uniform)
-        if (tid == 0) {
-            const unsigned long long old = atomicAdd(b.counter, (unsigned long long)total | ((unsigned long long)totalSeg << 40));
-            const unsigned long long rb = old & ((1ull << 40) - 1ull), sb = old >> 40;
-            sRecBase = rb;
-            sSegBase = (unsigned)(sb < 0xFFFFFFFFull ? sb : 0xFFFFFFFFull);
-            sDirect = (rb + (unsigned long long)total > (unsigned long long)b.capR) || (sb + (unsigned long long)totalSeg > (unsigned long long)b.capS);
+        if (totalSeg == 0) continue;   // (uniform)
+        if (lN + totalSeg > kSegList) {   // (uniform; totalSeg <= kSegList by the static_assert below)
+            bin_flush_list(b, lKey, lVal, regionBase, lN, &sFlushBase);
+            lN = 0;
         }
-        __syncthreads();
-        const bool direct = sDirect != 0;
         {
-            unsigned rOff = (unsigned)sRecBase + (unsigned)(preS + isum - sum);
-            unsigned long long sIdx = (unsigned long long)sSegBase + (unsigned long long)(preN + inz - nz);
+            unsigned rOff = (unsigned)g0 * (unsigned)kBinThreads + (unsigned)(preS + isum - sum);   // from the region's base
+            int li = lN + preN + inz - nz;
 #pragma unroll
             for (int i = 0; i < kPer; i++) {
                 if (c[i] <= 0) continue;
-                if (!direct) {
-                    b.segKey[sIdx] = (unsigned)hKey[tid * kPer + i];
-                    b.segVal[sIdx] = (unsigned long long)rOff | ((unsigned long long)c[i] << 32);
-                    hBase[tid * kPer + i] = rOff;
-                } else if (sIdx < (unsigned long long)b.capS) {   // a hole: sorts behind every brick, holds nothing
-                    b.segKey[sIdx] = 0xFFFFFFFFu;
-                    b.segVal[sIdx] = 0ull;
-                }
+                lKey[li] = (unsigned)hKey[tid * kPer + i];
+                lVal[li] = rOff | ((unsigned)c[i] << 20);
+                hCnt[tid * kPer + i] = (int)(regionBase + rOff);
                 rOff += (unsigned)c[i];
-                sIdx++;
+                li++;
             }
         }
+        lN += totalSeg;
         __syncthreads();
 
         // ---- scatter: the samples again, now with their values, each into its brick's segment ----
         for (int gl = 0; gl < ng; gl++) {
             SampleGeom s;
-            const bool v = listed && sample_geom(sR[gl], icp, irp, P, sCls[gl], b.nBx, b.nBy, b.nBz, s);
-            unsigned idx = 0;
-            if (!direct) {
-                const WaveGroup wg = wave_group_by_key(v, v ? s.key : -1);
-                unsigned base = 0;
-                if (v && lane == wg.lead) base = atomicAdd(&hBase[hash_find(hKey, s.key)], (unsigned)wg.n);
-                base = (unsigned)__shfl((int)base, wg.lead, 64);
-                idx = base + (unsigned)wg.rank;
-            }
-            if (!v) continue;
+            if (!(listed && sample_geom(sR[gl], icp, irp, P, sCls[gl], b.nBx, b.nBy, b.nBz, s))) continue;
+            const unsigned idx = (unsigned)atomicAdd(&hCnt[hash_find(hKey, s.key)], 1);
             // the value of this pixel for the group: (img * sum of the members' ramps) * ctf * w, T: n * ctf^2 * w
             const int m0 = sM0[gl], m1 = sM0[gl + 1];
             float2 S = make_float2(0.f, 0.f);
-            if (U <= kRampU) {
+            if (!SLOWU || U <= kRampU) {
 #pragma unroll
                 for (int u = 0; u < kRampU; u++)
                     if (u < U) {
@@ -338,34 +343,33 @@ __global__ __launch_bounds__(kBinThreads) void k_bin(BinArgs b)
                         S.x = fmaf(n, ramp[u].x, S.x);
                         S.y = fmaf(n, ramp[u].y, S.y);
                     }
-            } else {
+            } else if (SLOWU) {
                 S = ramp_sum_members(a.trans, pOrd, dm0, m0, m1, offx, offy, a.idim, pi, pj);
             }
             const float2 tv = cmul(dv, S);
             float cfv = cf;
-            if (a.cSearch) cfv = insert_ctf_search(a.attr, a.dfac, img, a.mReco, sRep[gl], a.pixelSize, a.idim, pi, pj);
+            if (CS) cfv = insert_ctf_search(a.attr, a.dfac, img, a.mReco, sRep[gl], a.pixelSize, a.idim, pi, pj);
             // src[i] * ctf[i] * 1 * w, left to right (src/Reconstructor.cpp:830-833)
             float vre = tv.x * cfv, vim = tv.y * cfv;
             vre = vre * 1.0f; vim = vim * 1.0f;
             vre = vre * wgt; vim = vim * wgt;
             if (s.conj) vim = -vim;
             const float tval = (pow2f_(cfv) * 1.0f * wgt) * (float)(m1 - m0);
-            const float vreS = vre * gF, vimS = vim * gF, tvalS = tval * gT;
-            if (direct) {
-                terms_direct(b.accF + (size_t)sCls[gl] * volSize * 2, b.accT + (size_t)sCls[gl] * volSize, P, s, vreS, vimS, tvalS);
-            } else {
-                b.recA[idx] = make_uint4(__float_as_uint(s.xd), __float_as_uint(s.yd), __float_as_uint(s.zd), s.cell);
-                float* rb = b.recB + 3 * (size_t)idx;
-                rb[0] = vreS; rb[1] = vimS; rb[2] = tvalS;
-            }
+            b.recA[idx] = make_uint4(__float_as_uint(s.xd), __float_as_uint(s.yd), __float_as_uint(s.zd), s.cell);
+            float* rb = b.recB + 3 * (size_t)idx;
+            rb[0] = vre * gF; rb[1] = vim * gF; rb[2] = tval * gT;
         }
     }
+    bin_flush_list(b, lKey, lVal, regionBase, lN, &sFlushBase);
 }
 
+// out[l] = groups of image l; out[nImg] = the largest number of unique shifts of any image (zeroed by the caller)
 __global__ void k_plan_counts(int* __restrict__ out, const int* __restrict__ plan, int nImg, int stride)
 {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l < nImg) out[l] = plan[(size_t)l * stride];
+    if (l >= nImg) return;
+    out[l] = plan[(size_t)l * stride];
+    atomicMax(&out[nImg], plan[(size_t)l * stride + 1]);
 }
 
 __global__ void k_seg_unpack(unsigned* __restrict__ segOff, unsigned* __restrict__ segCnt, unsigned* __restrict__ cum0,
@@ -426,17 +430,44 @@ __global__ __launch_bounds__(kAccThreads, 2) void k_acc(AccArgs q)
             if (q.segKey[i] != key) { atomicMin(&sRunEnd, i); break; }
         lds_barrier();
         const int e = sRunEnd;
-        // ---- accumulate the run's segments, a wave at a time ----
-        for (;;) {
-            int i = 0;
-            if (lane == 0) i = atomicAdd(&sNext, 1);
-            i = __builtin_amdgcn_readfirstlane(i);
-            if (i >= e) break;
-            const unsigned off = q.segOff[i], cnt = q.segCnt[i];
-            for (unsigned r = lane; r < cnt; r += 64) {
-                const uint4 ra = q.recA[off + r];
-                const float* rb = q.recB + 3 * (size_t)(off + r);
-                const float vreS = rb[0], vimS = rb[1], tvalS = rb[2];
+        // ---- accumulate the run's segments, a wave at a time; the records of the NEXT batch of 64 are in flight while the
+        // current one is added (a wave's loads would otherwise be exposed once per batch: 16 waves per CU do not cover them) ----
+        unsigned segPos = 0, segLeft = 0;   // (wave-uniform) the wave's current segment
+        auto next_batch = [&](unsigned& bOff, unsigned& bN) -> bool {
+            if (segLeft == 0) {
+                int i = 0;
+                if (lane == 0) i = atomicAdd(&sNext, 1);
+                i = __builtin_amdgcn_readfirstlane(i);
+                if (i >= e) return false;
+                segPos = q.segOff[i];
+                segLeft = q.segCnt[i];
+            }
+            bOff = segPos;
+            bN = segLeft < 64u ? segLeft : 64u;
+            segPos += bN;
+            segLeft -= bN;
+            return true;
+        };
+        unsigned bOff = 0, bN = 0;
+        bool more = next_batch(bOff, bN);
+        uint4 raN = make_uint4(0u, 0u, 0u, 0u);
+        float v0N = 0.f, v1N = 0.f, v2N = 0.f;
+        if (more && lane < bN) {
+            raN = q.recA[bOff + lane];
+            const float* rb = q.recB + 3 * (size_t)(bOff + lane);
+            v0N = rb[0]; v1N = rb[1]; v2N = rb[2];
+        }
+        while (more) {
+            const uint4 ra = raN;
+            const float vreS = v0N, vimS = v1N, tvalS = v2N;
+            const bool act = lane < bN;
+            more = next_batch(bOff, bN);
+            if (more && lane < bN) {
+                raN = q.recA[bOff + lane];
+                const float* rb = q.recB + 3 * (size_t)(bOff + lane);
+                v0N = rb[0]; v1N = rb[1]; v2N = rb[2];
+            }
+            if (act) {
                 const float xd = __uint_as_float(ra.x), yd = __uint_as_float(ra.y), zd = __uint_as_float(ra.z);
                 const float vx[2] = {1.0f - xd, xd}, vy[2] = {1.0f - yd, yd}, vz[2] = {1.0f - zd, zd};
                 const int cx = ra.w & (kBx - 1), cy = (ra.w >> 4) & (kBy - 1), cz = (ra.w >> 8) & (kBz - 1);
@@ -505,22 +536,28 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
     const int nBx = (P / 2 + kBx - 1) / kBx + 1, nBy = (P + kBy - 1) / kBy, nBz = (P + kBz - 1) / kBz;
     const unsigned long long nBrick = (unsigned long long)nBx * nBy * nBz * nK;
     THX_REQUIRE(nBrick < 0x7FFFFFFFull, "volume has too many bricks for 31-bit brick ids");
+    THX_REQUIRE(mReco < 4096, "brick-sorted insertion packs a region's record offsets into 20 bits (mReco < 4096)");
     // the images' group counts decide how many fit a chunk
-    int* gDev = reinterpret_cast<int*>(scratch(st, 13, (size_t)nImg * sizeof(int)));
+    int* gDev = reinterpret_cast<int*>(scratch(st, 13, ((size_t)nImg + 1) * sizeof(int)));
     THX_REQUIRE(gDev, "device scratch allocation failed");
+    THX_CHECK(hipMemsetAsync(gDev + nImg, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_plan_counts, dim3((nImg + 255) / 256), dim3(256), 0, st, gDev, plan, nImg, plan_stride(mReco));
-    std::vector<int> gHost(nImg);
-    THX_CHECK(hipMemcpyAsync(gHost.data(), gDev, (size_t)nImg * sizeof(int), hipMemcpyDeviceToHost, st));
+    std::vector<int> gHost(nImg + 1);
+    THX_CHECK(hipMemcpyAsync(gHost.data(), gDev, ((size_t)nImg + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
     THX_CHECK(hipStreamSynchronize(st));
+    const bool slowU = gHost[nImg] > kRampU;
 
     constexpr size_t kRecBytes = sizeof(uint4) + 3 * sizeof(float);
     constexpr size_t kSegBytes = 2 * sizeof(unsigned) + 2 * sizeof(unsigned long long) + 3 * sizeof(unsigned);
-    const size_t perRec = kRecBytes + kSegBytes / 32 + 1;
-    const size_t budget = sort_budget_bytes((size_t)mReco * nPxl * perRec + ((size_t)1 << 20));
+    constexpr int kSegShare = 8;   // descriptor slots per 8 records; a pass that finds the table full inserts its segments itself
+    const int nRegion = (nPxl + kBinThreads - 1) / kBinThreads;
+    const size_t recPerGroup = (size_t)nRegion * kBinThreads;   // static record span of one group of one image
+    const size_t perRec = kRecBytes + kSegBytes / kSegShare + 1;
+    const size_t budget = sort_budget_bytes((size_t)mReco * recPerGroup * perRec + ((size_t)1 << 20));
     size_t capR64 = (budget - ((size_t)1 << 20)) / perRec;
     capR64 = std::min(capR64, (size_t)0xFFFF0000u);
     const unsigned capR = (unsigned)capR64;
-    const unsigned capS = capR / 32 + 4096;
+    const unsigned capS = capR / kSegShare + 4096;
     size_t o = 0;
     const size_t oRecA = o; o += align256((size_t)capR * sizeof(uint4));
     const size_t oRecB = o; o += align256((size_t)capR * 3 * sizeof(float));
@@ -532,6 +569,7 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
     const size_t oCnt = o; o += align256((size_t)capS * sizeof(unsigned));
     const size_t oCum = o; o += align256(((size_t)capS + 1) * sizeof(unsigned));
     const size_t oCtr = o; o += 256;
+    const size_t oPre = o; o += align256((size_t)nImg * sizeof(unsigned));
     char* buf = reinterpret_cast<char*>(scratch(st, 12, o));
     THX_REQUIRE(buf, "device scratch allocation failed (brick-sorted insertion records)");
     unsigned* keyIn = reinterpret_cast<unsigned*>(buf + oKeyIn);
@@ -541,7 +579,8 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
     unsigned* segOff = reinterpret_cast<unsigned*>(buf + oOff);
     unsigned* segCnt = reinterpret_cast<unsigned*>(buf + oCnt);
     unsigned* cum = reinterpret_cast<unsigned*>(buf + oCum);
-    unsigned long long* ctr = reinterpret_cast<unsigned long long*>(buf + oCtr);
+    unsigned* ctr = reinterpret_cast<unsigned*>(buf + oCtr);
+    unsigned* preDev = reinterpret_cast<unsigned*>(buf + oPre);
 
     int keyBits = 1;
     while ((1ull << keyBits) <= nBrick) keyBits++;   // 2^keyBits - 1 > every brick id: holes (all ones) sort last
@@ -552,16 +591,27 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
     void* tmp = scratch(st, 14, tmpBytes);
     THX_REQUIRE(tmp, "device scratch allocation failed (sort workspace)");
 
-    const int nRegion = (nPxl + kBinThreads - 1) / kBinThreads;
+    // chunks: as many images as the record buffer holds; every image knows the groups of the chunk's images before it
+    std::vector<unsigned> pre(nImg);
+    std::vector<int> chunkEnd;
     for (int l0 = 0; l0 < nImg;) {
-        unsigned long long need = 0;
+        unsigned long long groups = 0;
         int l1 = l0;
         while (l1 < nImg && l1 - l0 < 65535) {
-            const unsigned long long add = (unsigned long long)gHost[l1] * (unsigned long long)nPxl;
-            if (l1 > l0 && need + add > (unsigned long long)capR) break;
-            need += add;
+            const unsigned long long g = (unsigned long long)gHost[l1];
+            if (l1 > l0 && (groups + g) * recPerGroup > (unsigned long long)capR) break;
+            pre[l1] = (unsigned)groups;
+            groups += g;
             l1++;
         }
+        chunkEnd.push_back(l1);
+        l0 = l1;
+    }
+    THX_CHECK(hipMemcpyAsync(preDev, pre.data(), (size_t)nImg * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    THX_CHECK(hipStreamSynchronize(st));   // (pre is pageable host memory)
+
+    int l0 = 0;
+    for (int l1 : chunkEnd) {
         const int nl = l1 - l0;
         BinArgs b;
         b.a = a;
@@ -572,19 +622,24 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
         if (b.a.attr) b.a.attr += l0;
         if (b.a.dfac) b.a.dfac += (size_t)l0 * mReco;
         b.plan = plan + (size_t)l0 * plan_stride(mReco);
-        b.gexp = gexp; b.accF = accF; b.accT = accT;
+        b.gexp = gexp; b.groupsBefore = preDev + l0; b.accF = accF; b.accT = accT;
         b.recA = reinterpret_cast<uint4*>(buf + oRecA); b.recB = reinterpret_cast<float*>(buf + oRecB);
-        b.segKey = keyIn; b.segVal = valIn; b.counter = ctr; b.capR = capR; b.capS = capS;
+        b.segKey = keyIn; b.segVal = valIn; b.counter = ctr; b.capS = capS;
         b.nBx = nBx; b.nBy = nBy; b.nBz = nBz;
-        THX_CHECK(hipMemsetAsync(ctr, 0, sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_bin, dim3(nRegion, nl), dim3(kBinThreads), 0, st, b);
-        unsigned long long used = 0;
+        THX_CHECK(hipMemsetAsync(ctr, 0, sizeof(unsigned), st));
+        if (a.cSearch) {
+            if (slowU) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin<true, true>), dim3(nRegion, nl), dim3(kBinThreads), 0, st, b);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin<true, false>), dim3(nRegion, nl), dim3(kBinThreads), 0, st, b);
+        } else {
+            if (slowU) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin<false, true>), dim3(nRegion, nl), dim3(kBinThreads), 0, st, b);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin<false, false>), dim3(nRegion, nl), dim3(kBinThreads), 0, st, b);
+        }
+        unsigned used = 0;
         THX_CHECK(hipMemcpyAsync(&used, ctr, sizeof(used), hipMemcpyDeviceToHost, st));
         THX_CHECK(hipStreamSynchronize(st));
-        const unsigned long long usedRec = used & ((1ull << 40) - 1ull), usedSeg = used >> 40;
-        const int nSeg = (int)std::min<unsigned long long>(usedSeg, capS);
-        const unsigned long long nRec = std::min<unsigned long long>(usedRec, capR);
-        if (nSeg > 0 && nRec > 0) {
+        const int nSeg = (int)std::min(used, capS);
+        const unsigned long long nRecMax = ((unsigned long long)pre[l1 - 1] + (unsigned long long)gHost[l1 - 1]) * recPerGroup;
+        if (nSeg > 0) {
             size_t tb = tmpBytes;
             THX_CHECK(rocprim::radix_sort_pairs(tmp, tb, keyIn, keyOut, valIn, valOut, (size_t)nSeg, 0u, (unsigned)keyBits, st));
             hipLaunchKernelGGL(k_seg_unpack, dim3((nSeg + 255) / 256), dim3(256), 0, st, segOff, segCnt, cum, valOut, nSeg);
@@ -593,7 +648,7 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
             AccArgs q;
             q.recA = b.recA; q.recB = b.recB; q.segKey = keyOut; q.segOff = segOff; q.segCnt = segCnt; q.cum = cum; q.nSeg = nSeg;
             q.accF = accF; q.accT = accT; q.P = P; q.nBx = nBx; q.nBy = nBy; q.nBz = nBz;
-            const unsigned nWg = (unsigned)((nRec + kAccSpan - 1) / kAccSpan);
+            const unsigned nWg = (unsigned)((nRecMax + kAccSpan - 1) / kAccSpan);   // (those beyond the records that exist return at once)
             hipLaunchKernelGGL(k_acc, dim3(nWg), dim3(kAccThreads), 0, st, q);
         }
         l0 = l1;
