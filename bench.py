@@ -349,8 +349,8 @@ def main():
         exp_bytes = exp_n * nPxl * (EXPECT_BYTES_PER_PIXEL + EXPECT_BYTES_PER_PIXEL_SAMPLE * shard.mLR)
         t_ins, t_exp = st.insertMs, st.expectMs
         # dominant kernel by total time.  Only the E-step kernel has an HBM roofline that means something: the insertion
-        # kernel accumulates in LDS (PMC: 35 MB of HBM traffic per image against 505 MB "algorithmic") and is bound by
-        # its instruction stream / the LDS atomic rate, reported below as lds_add_frac.
+        # accumulates in LDS (its HBM traffic is the 56 bytes per record of the sort, a tenth of the 505 MB "algorithmic"
+        # bytes per image) and is bound by the LDS atomic rate, reported below as lds_add_frac.
         kname, kms, kbytes = "k_expect_local", exp_ms, exp_bytes
         achieved = kbytes / (kms * 1e-3) / 1e9
         # HBM traffic of that kernel from the committed PMC profile (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes,
@@ -368,14 +368,20 @@ def main():
                     lds_rate = j.get("lds_add_u32_per_s")
             except Exception:
                 traffic = None
-        # insertion against its own bound: LDS integer adds per second vs the measured ds_add_u32 rate of the chip
-        # (tools/lds_atomic_bench.hip, recorded in profiles/pmc_traffic.json).  The window kernel issues 24 adds (8 voxels x
-        # re, im, T) per listed pixel and GROUP -- the insert plan merges the draws of an image that share a rotation -- and
-        # the driver counts the groups its launches processed (thx_insert_groups_total); the per-draw figure is kept as
-        # the upper bound round 2 reported.
+        # insertion against its own bound.  The brick-sorted form (k_bin + segment sort + k_acc, thx_insert_sort.hip) issues
+        # 24 ds_add_u64 (8 voxels x re, im, T) per RECORD = per (listed pixel, GROUP of draws) -- the insert plan merges the
+        # draws of an image that share a rotation; the driver counts the groups its launches processed
+        # (thx_insert_groups_total) -- and moves each record through HBM once each way (28 bytes written by k_bin, read by
+        # k_acc).  lds_add_frac prices the whole insertion call (plan, k_bin, sort, k_acc) against the chip's measured
+        # ds_add_u64 rate (tools/lds_atomic_bench.hip, recorded in profiles/pmc_traffic.json).
         groups_per_image = st.insertGroups / max(1, st.insertImages)
-        ins_terms_per_s_upper = ins_n * shard.mReco * nPxlM * 24 / (ins_ms * 1e-3)
-        ins_terms_per_s = ins_n * groups_per_image * nPxlM * 24 / (ins_ms * 1e-3)
+        lds_rate64 = None
+        try:
+            lds_rate64 = json.load(open(pmc)).get("lds_add_u64_per_s")
+        except Exception:
+            pass
+        ins_records_per_s = ins_n * groups_per_image * nPxlM / (ins_ms * 1e-3)
+        ins_terms_per_s = ins_records_per_s * 24
         out = {
             "metric": "particles/sec per refinement iteration (256\u00b3 box, 100k particles); achieved HBM GB/s" if (args.box, args.particles) == (256, 100000)
                       else "particles/sec per refinement iteration (%d\u00b3 box, %d particles); achieved HBM GB/s" % (args.box, args.particles),
@@ -397,12 +403,13 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kms,
                          "images_per_launch": exp_n, "algorithmic_bytes_per_launch": kbytes, "traffic_source": pmc_src},
-            "kernels": {"k_insert_win": {"avg_launch_ms": ins_ms, "images_per_launch": ins_n, "total_ms": t_ins,
-                                         "groups_per_image": groups_per_image, "us_per_image": ins_ms * 1e3 / max(1.0, ins_n),
-                                         "lds_adds_per_s": ins_terms_per_s,
-                                         "lds_add_frac": (ins_terms_per_s / lds_rate) if lds_rate else None,
-                                         "lds_adds_per_s_per_draw_upper": ins_terms_per_s_upper,
-                                         "GBps_algorithmic_204B": ins_bytes / (ins_ms * 1e-3) / 1e9},
+            "kernels": {"insertion (k_bin + segment sort + k_acc)": {
+                            "avg_call_ms": ins_ms, "images_per_call": ins_n, "total_ms": t_ins,
+                            "groups_per_image": groups_per_image, "us_per_image": ins_ms * 1e3 / max(1.0, ins_n),
+                            "records_per_s": ins_records_per_s, "lds_adds_u64_per_s": ins_terms_per_s,
+                            "lds_add_frac": (ins_terms_per_s / lds_rate64) if lds_rate64 else None,
+                            "record_GBps_written_plus_read": ins_records_per_s * 56 / 1e9,
+                            "GBps_algorithmic_204B_per_draw": ins_bytes / (ins_ms * 1e-3) / 1e9},
                         "k_expect_local": {"avg_launch_ms": exp_ms, "images_per_launch": exp_n,
                                            "GBps_algorithmic": exp_bytes / (exp_ms * 1e-3) / 1e9, "total_ms": t_exp}},
             "stages_ms_per_step": {k: round(st.stageMs[i] / args.steps, 2) for i, k in enumerate(STAGES)},

@@ -68,19 +68,34 @@ for name, unit_f, shape in (("k_expect_local", u_gather, "scattered 64-byte cell
         ent["hbm_bytes_per_launch"] = ent["fetch_bytes_per_launch"] + ent.get("write_bytes_per_launch", 0.0)
         ent["images_per_launch"] = n_per_launch
         summary[name] = ent
-# measured LDS integer-add rate of the chip (tools/lds_atomic_bench): the insertion kernel's own bound
-lds_rate = None
+# the brick-sorted insertion runs k_bin and k_acc once per CHUNK of images: totals over every launch of the run, per image
+# (images of the run = images per E-step launch x its launches / 3 phases)
+n_exp = pick(fetch, "k_expect_local", "FETCH_SIZE", how=len)
+n_img_total = n_per_launch * (n_exp or 0) / 3.0
+for name in ("k_bin", "k_acc"):
+    fr = pick(fetch, name, "FETCH_SIZE", how=sum)
+    wr = pick(write, name, "WRITE_SIZE", how=sum)
+    if fr is not None and wr is not None and u_stream and u_write and n_img_total:
+        summary[name] = {"fetch_calibration": "streamed rows", "launches": pick(fetch, name, "FETCH_SIZE", how=len),
+                         "fetch_bytes_per_image": fr * u_stream / n_img_total, "write_bytes_per_image": wr * u_write / n_img_total,
+                         "images_total": n_img_total}
+# measured LDS integer-add rates of the chip (tools/lds_atomic_bench): the insertion kernels' own bound
+lds_rate, lds_rate64 = None, None
 try:
     for line in open(out + "/lds_atomic_bench.txt"):
         m = re.match(r"ds_add_u32 random\s+[\d.]+ ms\s+([\d.]+) G lane-ops/s", line)
         if m:
             lds_rate = float(m.group(1)) * 1e9
+        m = re.match(r"ds_add_u64 random\s+[\d.]+ ms\s+([\d.]+) G lane-ops/s", line)
+        if m:
+            lds_rate64 = float(m.group(1)) * 1e9
 except OSError:
     pass
 summary["lds_add_u32_random_per_s"] = lds_rate
+summary["lds_add_u64_random_per_s"] = lds_rate64
 print(json.dumps(summary, indent=1))
 json.dump(summary, open(out + "/summary.json", "w"), indent=1)
-pm = {"box": 256, "images_per_launch": n_per_launch, "lds_add_u32_per_s": lds_rate,
+pm = {"box": int(os.environ.get("THX_PROBE_BOX", "256")), "images_per_launch": n_per_launch, "lds_add_u32_per_s": lds_rate, "lds_add_u64_per_s": lds_rate64,
       "source": "tools/pmc_traffic.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
                 + (("`%s` (average over every launch of the run)" % os.environ["PMC_CMD"]) if os.environ.get("PMC_CMD") else
                    "tools/traffic_probe.py (particle-filter support points, one phase)") + "; KiB units; FETCH_SIZE of the E-step kernel "
@@ -91,4 +106,6 @@ if "k_expect_local" in summary:
     pm["hbm_bytes_per_image_phase"] = summary["k_expect_local"]["hbm_bytes_per_launch"] / n_per_launch
 if "k_insert_win" in summary:
     pm["insert_hbm_bytes_per_image"] = summary["k_insert_win"]["hbm_bytes_per_launch"] / n_per_launch
+if "k_bin" in summary and "k_acc" in summary:
+    pm["insert_hbm_bytes_per_image"] = sum(summary[k]["fetch_bytes_per_image"] + summary[k]["write_bytes_per_image"] for k in ("k_bin", "k_acc"))
 json.dump(pm, open(out + "/pmc_traffic.json", "w"), indent=1)
