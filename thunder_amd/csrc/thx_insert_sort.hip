@@ -41,7 +41,7 @@ constexpr int kHash = kBinThreads * kPassGroups;                  // >= the dist
 constexpr int kRampU = 16;                                        // unique shifts whose ramps a thread keeps in registers
 constexpr int kAccThreads = 512;
 constexpr unsigned kAccSpan = 16384;                              // records per workgroup of k_acc
-constexpr int kAccStage = 512;                                    // segment descriptors staged in LDS at a time
+constexpr int kAccStage = kAccThreads;                                    // segment descriptors staged in LDS at a time
 
 struct BinArgs {
     InsertArgs a;               // image-indexed pointers at the chunk's first image
@@ -412,7 +412,7 @@ __device__ __forceinline__ int lower_bound_u32(const unsigned* __restrict__ cum,
 __global__ __launch_bounds__(kAccThreads, 2) void k_acc(AccArgs q)
 {
     __shared__ long long sRe[kBrickVox], sIm[kBrickVox], sT[kBrickVox];
-    __shared__ unsigned sOff[kAccStage], sCnt[kAccStage];
+    __shared__ unsigned sOff[kAccStage], sExc[kAccStage + 1], sWaveTot[kAccThreads / 64];
     __shared__ int sRunEnd, sNext;
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned long long lo = (unsigned long long)blockIdx.x * kAccSpan, hi = lo + kAccSpan;
@@ -437,28 +437,46 @@ __global__ __launch_bounds__(kAccThreads, 2) void k_acc(AccArgs q)
         for (int blk = s; blk < e; blk += kAccStage) {   // the run's descriptors, kAccStage at a time, through LDS
         const int nb = e - blk < kAccStage ? e - blk : kAccStage;
         if (blk > s) lds_barrier();   // the previous block's descriptors are no longer read
-        for (int i = tid; i < nb; i += kAccThreads) { sOff[i] = q.segOff[blk + i]; sCnt[i] = q.segCnt[blk + i]; }
-        if (tid == 0) sNext = 0;
-        lds_barrier();
-        // (wave-uniform) the wave's current segment: first record, records, batches of 64, batches done
-        unsigned segBase = 0, segN = 0, segNb = 0, segB = 0;
-        auto next_batch = [&](size_t& rec, bool& ok) -> bool {
-            if (segB == segNb) {
-                int i = 0;
-                if (lane == 0) i = atomicAdd(&sNext, 1);
-                i = __builtin_amdgcn_readfirstlane(i);
-                if (i >= nb) return false;
-                segBase = sOff[i];
-                segN = sCnt[i];
-                segNb = (segN + 63u) >> 6;
-                segB = 0;
+        // the block's records form ONE logical stream (sExc = records before each segment): a wave takes 64 consecutive
+        // records of the stream whatever segments they lie in -- taken segment by segment, a third of the lanes of the LDS
+        // atomics would be idle (a segment holds ~130 records: two full batches and a remainder)
+        {
+            const unsigned c = tid < nb ? q.segCnt[blk + tid] : 0u;
+            unsigned inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = (unsigned)__shfl_up((int)inc, o, 64);
+                if (lane >= o) inc += t;
             }
-            // (64 consecutive records; a strided assignment -- lane k takes record k nb + b, so that the same pixel under
-            // several nearly equal rotations does not meet itself in one LDS instruction -- measured 3 % slower)
-            const unsigned r = segB * 64u + (unsigned)lane;
-            ok = r < segN;
-            rec = ok ? (size_t)(segBase + r) : 0;
-            segB++;
+            if (lane == 63) sWaveTot[tid >> 6] = inc;
+            if (tid < nb) sOff[tid] = q.segOff[blk + tid];
+            lds_barrier();
+            unsigned pre = 0, tot = 0;
+#pragma unroll
+            for (int wv = 0; wv < kAccThreads / 64; wv++) {
+                if (wv < (tid >> 6)) pre += sWaveTot[wv];
+                tot += sWaveTot[wv];
+            }
+            if (tid < nb) sExc[tid] = pre + inc - c;
+            if (tid == 0) { sExc[nb] = tot; sNext = 0; }
+        }
+        lds_barrier();
+        const unsigned nRecBlk = sExc[nb];
+        auto next_batch = [&](size_t& rec, bool& ok) -> bool {
+            int j = 0;
+            if (lane == 0) j = atomicAdd(&sNext, 1);
+            const unsigned r0 = (unsigned)__builtin_amdgcn_readfirstlane(j) * 64u;
+            if (r0 >= nRecBlk) return false;
+            int lo_ = 0, hi_ = nb - 1;   // (uniform) last segment that starts at or before r0
+            while (lo_ < hi_) {
+                const int mid = (lo_ + hi_ + 1) >> 1;
+                if ((unsigned)__builtin_amdgcn_readfirstlane((int)sExc[mid]) <= r0) lo_ = mid; else hi_ = mid - 1;
+            }
+            const unsigned r = r0 + (unsigned)lane;
+            ok = r < nRecBlk;
+            int i = lo_;
+            while (ok && sExc[i + 1] <= r) i++;   // (a batch spans a segment or two)
+            rec = ok ? (size_t)(sOff[i] + (r - sExc[i])) : 0;
             return true;
         };
         // (the loads are unconditional -- lanes without a record read record 0 -- so that the loaded registers have ONE
