@@ -1,9 +1,9 @@
 """GPU parity tests at the bench's own sizes and settings (BASELINE configs[1] / [4]): the HIP path exactly as `bench.py`
-drives it -- window insertion kernel with resampled particle-filter draws, cell-packed projector, Morton-ordered pixel
+drives it -- brick-sorted insertion with resampled particle-filter draws, cell-packed projector, Morton-ordered pixel
 list, particle-filter priors, 125 x 9 support points, occupancy cap 2 -- against the CPU oracle on the same inputs.
 
-These are the regimes the small-box tests do not reach: at P = 512 / 1024 a row of the insertion kernel has 34+ / 66+
-windows, the (pixel, group) packing uses all its bits and rMax clipping is active; the E-step runs the packed gather in
+These are the regimes the small-box tests do not reach: at P = 512 / 1024 the volume has 35 k / 280 k bricks, a region of
+the pixel list touches tens of them per pass and the grid's rim clips samples; the E-step runs the packed gather in
 pixel-visit order with non-uniform priors.  Oracle cost: a few seconds per case (C, single thread).
 """
 import time
@@ -103,26 +103,26 @@ def _insert_vs_oracle(O, dev, N, nImg, mReco, seed, spread=0.01):
     np.testing.assert_allclose(Tg.sum(dtype=np.float64), Tw.sum(dtype=np.float64), rtol=1e-6)
 
 
-def test_insert_win_vs_oracle_n256(oracle, dev):
+def test_insert_vs_oracle_n256(oracle, dev):
     """configs[1] box: 3 images x 100 resampled draws (~1 degree spread, repeated support points, non-zero offS)"""
     _insert_vs_oracle(oracle, dev, 256, 3, 100, seed=2560, spread=0.01)
 
 
-def test_insert_win_vs_oracle_n256_wide_cloud(oracle, dev):
-    """a cloud with a 4-degree spread: many slabs per window, draws leaving the reference plane by tens of voxels"""
+def test_insert_vs_oracle_n256_wide_cloud(oracle, dev):
+    """a cloud with a 4-degree spread: draws leaving the first draw's plane by tens of voxels"""
     _insert_vs_oracle(oracle, dev, 256, 2, 40, seed=2561, spread=0.04)
 
 
-def test_insert_win_vs_oracle_n512(oracle, dev):
+def test_insert_vs_oracle_n512(oracle, dev):
     """configs[4] box (P = 1024): one image x 20 draws"""
     _insert_vs_oracle(oracle, dev, 512, 1, 20, seed=5120, spread=0.008)
 
 
 @pytest.mark.parametrize("N", [32, 64])
 def test_insert_far_posterior_modes(oracle, dev, N):
-    """draws of ONE image from far-apart posterior modes: exactly / nearly 90 degrees from the first draw (its plane
-    contains the shear axis of the reference plane: slopes -n/gna unbounded), 30-60 degrees away, and the reference
-    itself.  Must equal the oracle, in bounded time (the degenerate groups take the plain-atomic path)."""
+    """draws of ONE image from far-apart posterior modes: exactly / nearly 90 degrees from the first draw, 30-60 degrees away,
+    and the first draw itself (the case that broke the per-image window kernel of rounds 1-2: unbounded shear slopes).  Must
+    equal the oracle, in bounded time -- the brick-sorted form has no reference plane, every draw is binned the same way."""
     from thunder_amd import ops, synth
     from thunder_amd.refine import pixel_list
     O = oracle
@@ -262,7 +262,7 @@ def test_expect_local_many_shifts(oracle, dev, nT):
 
 
 def test_insert_bit_reproducible_n256(dev):
-    """the window kernel accumulates in fixed point end to end (LDS bricks AND the global volumes, thx_mstep.hip:acc_add), so
+    """the insertion accumulates in 64-bit fixed point end to end (LDS bricks AND the global volumes, thx_insert.h:acc_add), so
     F and T are bit-identical from run to run whatever the scheduling -- 96 images x 100 filter draws at the bench's box"""
     from thunder_amd import ops, synth
     from thunder_amd.refine import pixel_list

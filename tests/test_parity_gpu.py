@@ -336,7 +336,7 @@ def test_insert(oracle, dev, N, nK):
     assert np.abs(Fg - Fw).max() <= 1e-5 * np.abs(Fw).max()
     assert np.abs(Tg - Tw).max() <= 1e-5 * np.abs(Tw).max()
     # untouched voxels stay exactly zero; voxels the device left at zero carry at most a sub-quantum contribution
-    # (the LDS brick accumulates in fixed point with a quantum of 2^-22 of the tile's largest term)
+    # (every term is rounded to the session's 64-bit quantum, 2^-30 or less of the largest possible term)
     assert not np.any((Fw == 0) & (Fg != 0)) and not np.any((Tw == 0) & (Tg != 0))
     assert np.abs(Fw[Fg == 0]).max(initial=0) <= 1e-6 * np.abs(Fw).max()
     assert np.abs(Tw[Tg == 0]).max(initial=0) <= 1e-6 * np.abs(Tw).max()
@@ -345,8 +345,8 @@ def test_insert(oracle, dev, N, nK):
 
 
 def test_insert_unrelated_draws_and_plain_kernel(oracle, dev, knob_env):
-    """draws that are NOT nearby orientations leave the LDS brick and take the direct-atomic path; the plain
-    kernel (THX_INSERT_PLAIN=1) and the brick kernel must both match the oracle"""
+    """draws that are NOT nearby orientations (every draw its own plane through the volume: many bricks per pass of k_bin);
+    the plain kernel (THX_INSERT_PLAIN=1) and the brick-sorted form must both match the oracle"""
     from thunder_amd import ops, synth
     O = oracle
     rng = np.random.default_rng(77)
@@ -364,6 +364,38 @@ def test_insert_unrelated_draws_and_plain_kernel(oracle, dev, knob_env):
                    T(pl["iRow"], dev), 2, N, offS=T(offS, dev))
         assert np.abs(F.cpu().numpy() - Fw[0]).max() <= 1e-5 * np.abs(Fw).max(), plain
         assert np.abs(Tt.cpu().numpy() - Tw[0]).max() <= 1e-5 * np.abs(Tw).max(), plain
+
+
+def test_insert_sorted_special_paths(oracle, dev, knob_env):
+    """the brick-sorted insertion (thx_insert_sort.hip) off its common path: more unique shifts per image than a thread keeps
+    ramps for (every draw its own shift: k_bin's member-by-member ramp sum), images spread over many chunks of the record
+    buffer (THX_INSERT_SCRATCH_MB=1: one image's worst case per chunk) and a descriptor table that is full at once
+    (THX_INSERT_SEG_CAP=8: workgroups insert their segments themselves).  All against the oracle, and the three runs bit for
+    bit equal to each other -- every term is rounded once, to the session's quanta, whichever way it travels."""
+    from thunder_amd import ops
+    O = oracle
+    rng = np.random.default_rng(4242)
+    N, nImg, mReco, nK = 32, 7, 24, 2
+    P = 2 * N
+    ref, vol, pl, im, quat, tran, offS, w, cls = _insert_case(O, N, nImg, mReco, rng, nK)
+    assert len({t.tobytes() for t in tran[0]}) == mReco > 16
+    Fw, Tw, _ = _oracle_insert(O, P, N, pl, im, quat, tran, offS, w, cls, nK)
+    rot = ops.rotmat(T(quat.reshape(-1, 4), dev))
+    outs = []
+    for knob, val in ((None, None), ("THX_INSERT_SCRATCH_MB", "1"), ("THX_INSERT_SEG_CAP", "8")):
+        if knob:
+            knob_env(knob, val)
+        F = torch.zeros((nK, P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
+        Tt = torch.zeros((nK, P, P, P // 2 + 1), dtype=torch.float32, device=dev)
+        ops.insert(F, Tt, P, T(im["dat"], dev), T(im["ctf"], dev), T(w, dev), rot, T(tran, dev), T(pl["iCol"], dev),
+                   T(pl["iRow"], dev), 2, N, offS=T(offS, dev), cls=T(cls, dev), nK=nK)
+        if knob:
+            knob_env(knob, None)
+        assert np.abs(F.cpu().numpy() - Fw).max() <= 1e-5 * np.abs(Fw).max(), knob
+        assert np.abs(Tt.cpu().numpy() - Tw).max() <= 1e-5 * np.abs(Tw).max(), knob
+        outs.append((F, Tt))
+    for F, Tt in outs[1:]:
+        assert torch.equal(F, outs[0][0]) and torch.equal(Tt, outs[0][1])
 
 
 def test_insert_linearity_and_csearch(oracle, dev):

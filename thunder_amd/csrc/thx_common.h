@@ -43,8 +43,7 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 void* scratch(hipStream_t stream, int slot, size_t bytes);
 
 // Environment switches for A/B runs.  Read ONCE, when the library is first used -- never per launch -- and only
-// switches that select between tested code paths; the profiling-only switches (skipped work, shrunken sampling region)
-// exist solely in builds with -DTHX_PROFILING.
+// switches that select between tested code paths.
 struct Knobs {
     int expectNSplit;     // THX_EXPECT_NSPLIT = 1..16: pixel splits of the local-search kernel (0 = automatic)
     int expectWgPerCU;    // THX_EXPECT_WG_PER_CU: overrides the occupancy argument of thx_expect_local_dev (-1 = unset)
@@ -52,11 +51,10 @@ struct Knobs {
     bool scanSimple;      // THX_SCAN=simple: the rotation-per-thread global-scan kernel for every size (A/B)
     int scanTile;         // THX_SCAN=t42 / t24 / t44: wave tiles of the scan contraction (A/B; default 2 x 2)
     bool insertPlain;     // THX_INSERT_PLAIN=1: plain float-atomic insertion (k_insert)
-    bool insertWin;       // THX_INSERT=win: the per-image window kernel (k_insert_win) instead of the brick-sorted form (A/B)
-    float minQuanta;      // THX_MIN_QUANTA: smallest T term accumulated in the fixed-point LDS brick
+    long insertScratchMB; // THX_INSERT_SCRATCH_MB: record / descriptor scratch of the brick-sorted insertion (0 = min(8 GiB, 40 % of free))
+    long insertSegCap;    // THX_INSERT_SEG_CAP: descriptor table size, to exercise the table-full path in tests (0 = records / 8)
     bool fftRocfft;       // THX_FFT=rocfft: library transforms in the gridding loop for every size
     bool recoTrace;       // THX_RECO_TRACE: print diffC per balancing round
-    int insertDebug;      // THX_INSERT_DEBUG (honoured only with -DTHX_PROFILING)
     bool commForce;       // THX_COMM_FORCE=1: issue the RCCL calls on one-rank communicators too (1-GPU test of the path)
 };
 const Knobs& knobs();

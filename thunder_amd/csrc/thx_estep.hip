@@ -38,15 +38,13 @@ static Knobs read_knobs()
     v.scanTile = e && e[0] == 't' ? atoi(e + 1) : 0;
     e = getenv("THX_INSERT_PLAIN");
     v.insertPlain = e && e[0] == '1';
-    e = getenv("THX_INSERT");
-    v.insertWin = e && e[0] == 'w';
-    e = getenv("THX_MIN_QUANTA");
-    v.minQuanta = e ? (float)atof(e) : -1.0f;
+    e = getenv("THX_INSERT_SCRATCH_MB");
+    v.insertScratchMB = e ? atol(e) : 0;
+    e = getenv("THX_INSERT_SEG_CAP");
+    v.insertSegCap = e ? atol(e) : 0;
     e = getenv("THX_FFT");
     v.fftRocfft = e && e[0] == 'r';
     v.recoTrace = getenv("THX_RECO_TRACE") != nullptr;
-    e = getenv("THX_INSERT_DEBUG");
-    v.insertDebug = e ? atoi(e) : 0;
     e = getenv("THX_COMM_FORCE");
     v.commForce = e && e[0] == '1';
     return v;

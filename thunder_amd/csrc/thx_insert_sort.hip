@@ -536,24 +536,23 @@ __global__ __launch_bounds__(kAccThreads, 2) void k_acc(AccArgs q)
     }
 }
 
-// scratch the sorted form keeps per device: chosen on first use (THX_INSERT_SCRATCH_MB, else min(8 GiB, 40 % of the free memory))
+// scratch the sorted form keeps per device: THX_INSERT_SCRATCH_MB, else chosen on first use as min(8 GiB, 40 % of the free
+// memory); never less than one image's worst case
 static size_t sort_budget_bytes(size_t oneImageWorst)
 {
-    static size_t budget[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!budget[dev]) {
-        size_t b = 0;
-        if (const char* e = getenv("THX_INSERT_SCRATCH_MB")) b = (size_t)atoll(e) << 20;
-        if (!b) {
+    static size_t chosen[64] = {0};
+    size_t b = knobs().insertScratchMB > 0 ? (size_t)knobs().insertScratchMB << 20 : 0;
+    if (!b) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!chosen[dev]) {
             size_t freeB = 0, totalB = 0;
             if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = (size_t)4 << 30;
-            b = std::min((size_t)8 << 30, (size_t)(0.4 * (double)freeB));
+            chosen[dev] = std::max(std::min((size_t)8 << 30, (size_t)(0.4 * (double)freeB)), (size_t)64 << 20);
         }
-        budget[dev] = std::max(b, (size_t)64 << 20);
+        b = chosen[dev];
     }
-    if (budget[dev] < oneImageWorst) budget[dev] = oneImageWorst;
-    return budget[dev];
+    return std::max(b, oneImageWorst);
 }
 
 static inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
@@ -585,7 +584,7 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
     size_t capR64 = (budget - ((size_t)1 << 20)) / perRec;
     capR64 = std::min(capR64, (size_t)0xFFFF0000u);
     const unsigned capR = (unsigned)capR64;
-    const unsigned capS = capR / kSegShare + 4096;
+    const unsigned capS = knobs().insertSegCap > 0 ? (unsigned)knobs().insertSegCap : capR / kSegShare + 4096;
     size_t o = 0;
     const size_t oRecA = o; o += align256((size_t)capR * sizeof(uint4));
     const size_t oRecB = o; o += align256((size_t)capR * 3 * sizeof(float));
