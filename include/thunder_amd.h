@@ -187,7 +187,10 @@ int thx_expect_global_dev(const float* rotP, const float* traP, const float* dat
  *   cls [nImg][mReco] (NULL = class 0); iCol/iRow UNPADDED pixel indices, opf = padding factor
  *   cSearch != 0: CTF recomputed per draw from attr [nImg] with defocus * dfac [nImg][mReco] (:7183-7202)
  *   O (3 doubles) += -R*(tran-offS) and counter += 1 per draw (insertDir).
- * fp32 hardware atomics: summation order differs run to run exactly as the reference's `omp atomic`. */
+ * Accumulation is 64-bit fixed point (every voxel term rounded once to the call's quanta, integer atomics): F / T come out
+ * bit-identical from run to run -- the reference's `omp atomic` float sums do not.  The brick-sorted form behind it
+ * (thx_insert_sort.hip) keeps its sample records in library scratch: THX_INSERT_SCRATCH_MB megabytes per (device, stream),
+ * default min(8 GiB, 40 % of the free memory), never less than one image's worst case; requires mReco < 4096. */
 int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK, const float* datP,
                    const float* ctfP, const float* w, const double* rotMat, const double* trans, const double* offS,
                    const int* cls, const thx_ctf_attr* attr, const double* dfac, int cSearch, float pixelSize,
@@ -195,7 +198,7 @@ int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK,
 
 /* The same insertion as a SESSION over several calls (batches of images, and -- through the hemisphere communicator --
  * several ranks) that accumulate into ONE pair of 64-bit fixed-point volumes before anything becomes a float:
- *   bounds  DEVICE [nImg][2]: per image max(|re| + |im|) of its row and max |ctf| (they fix the image's brick quanta);
+ *   bounds  DEVICE [nImg][2]: per image max(|re| + |im|) of its row and max |ctf| (they bound the image's largest term);
  *   thx_insert_scale_dev: gexp DEVICE [2] = the exponents of the session's quanta from the extrema over `nImg` images of this
  *     rank and, with hemi != NULL, over every rank of the half (one ncclMax of four numbers); nImgHemi = images of the
  *     whole half (head-room of the 64-bit sums);
