@@ -243,6 +243,275 @@ def bench_global_scan(args, dev):
     print(json.dumps(out))
 
 
+def bench_classification_iteration(args, dev):
+    """--classification: one whole iteration of BASELINE configs[3] (3-D classification, K = 4 references) on ONE GPU's share
+    of the images, sequenced over the batched `*_dev` entry points the way Optimiser::expectation does for a classification
+    (src/Optimiser.cpp:631-1660): global scan of every image against K classes x 10 000 rotations x 30 shifts at r = 24
+    (:756-894) -> class of every image (keepHalfHeightPeak(PAR_C) / resample / rand, :925-952: k_pf_class_select) -> support
+    points from the selected class's scan posterior (Particle::resample(mLR, PAR_R) / (mLT, PAR_T): a multinomial draw in
+    torch here -- the one step of this sequence without a device kernel of its own) -> 3 local particle-filter phases
+    against the assigned reference (volIdx; k_pf_perturb / k_expect_local<9, packed> / k_pf_update) -> mReco draws per image ->
+    multi-reference insertion (cls per draw, K pairs of F / T in one session: k_bin / sort / k_acc) -> normalise + 2
+    reconstructions per class (MAP off / on, Reconstructor::reconstruct).  Left out of the timed region: the sigma update and
+    the re-centring of the images (timed in the refinement bench), half-set splitting (one GPU's share is one half here).
+    `value` = images per second through the whole iteration; the per-stage times and the roofline of each stage's dominant
+    kernel ride along."""
+    import torch
+    from thunder_amd import capi, ops, synth
+    from thunder_amd.refine import pixel_list
+    N, K, nR, nT, rScan = args.box, 4, 10000, 30, 24
+    mLR, mLT, mReco, nPhase = args.mLR, args.mLT, args.mReco, args.phases
+    nImg = args.scan_images
+    P, pf, rU = 2 * N, 2, N // 2 - 2
+    rng = np.random.default_rng(4)
+    T_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    plS, plE, plM = pixel_list(N, rScan, 2), pixel_list(N, rU, 2), pixel_list(N, rU, 0)
+    posM = {(int(i), int(j)): k for k, (i, j) in enumerate(zip(plM["iCol"], plM["iRow"]))}
+    e2m = T_(np.asarray([posM[(int(i), int(j))] for i, j in zip(plE["iCol"], plE["iRow"])], np.int64))
+    s2m = T_(np.asarray([posM[(int(i), int(j))] for i, j in zip(plS["iCol"], plS["iRow"])], np.int64))
+    iColS, iRowS, iColE, iRowE, iColM, iRowM = (T_(plS["iCol"]), T_(plS["iRow"]), T_(plE["iCol"]), T_(plE["iRow"]),
+                                                T_(plM["iCol"]), T_(plM["iRow"]))
+    nPxlS, nPxlE, nPxlM = plS["nPxl"], plE["nPxl"], plM["nPxl"]
+    plan = ops.RecoPlan(N, N, pf)
+    vols = torch.stack([plan.set_projectee(T_(synth.blob_map(N, seed=300 + k, nblob=20))) for k in range(K)]).contiguous()
+    cells = ops.pack_projector(vols, P)
+    quat = synth.random_quats(nR, rng)
+    mats = ops.rotmat(T_(quat))
+    quatD = T_(quat)
+    shifts = np.ascontiguousarray(rng.normal(0, 3.0, size=(nT, 2)))
+    shiftsD = T_(shifts)
+    traS = ops.translate(shiftsD, iColS, iRowS, N)
+    traM = ops.translate(shiftsD, iColM, iRowM, N)
+    attr = T_(synth.ctf_params(nImg, rng))
+    ctfM = ops.ctf(attr, 1.32, iColM, iRowM, N)
+    # images: a slice of a random class at a random scanned rotation / shift, plus noise (rL = 0 list; the E-step and scan rows
+    # are its sub-lists)
+    cls_true, r_true, t_true = rng.integers(0, K, nImg), rng.integers(0, nR, nImg), rng.integers(0, nT, nImg)
+    if not args.unsorted:
+        # stored by class and view direction of the previous iteration's poses (here: the generating ones), as the refinement
+        # bench stores its particles by view (thx_view_order_host): images next to each other in a launch gather from the
+        # same reference along nearly the same plane
+        from thunder_amd.refine import view_order
+        perm = view_order(quat[r_true])
+        perm = perm[np.argsort(cls_true[perm], kind="stable")]
+        cls_true, r_true, t_true = cls_true[perm], r_true[perm], t_true[perm]
+    datM = torch.empty((nImg, nPxlM), dtype=torch.complex64, device=dev)
+    for k in range(K):
+        sel = np.nonzero(cls_true == k)[0]
+        for c0 in range(0, len(sel), 1024):
+            ss = sel[c0:c0 + 1024]
+            sl = ops.project(vols[k], mats[T_(r_true[ss])].contiguous(), iColM, iRowM, pf)
+            st_ = T_(ss)
+            datM[st_] = sl * traM[T_(t_true[ss])] * ctfM[st_]
+    sd = 3.0 * float(datM.abs().pow(2).mean().sqrt())
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    for c0 in range(0, nImg, 2048):
+        c1 = min(nImg, c0 + 2048)
+        datM[c0:c1] += torch.view_as_complex(torch.randn((c1 - c0, nPxlM, 2), generator=g, device=dev)) * (sd / np.sqrt(2))
+    datE, ctfE = datM[:, e2m].contiguous(), ctfM[:, e2m].contiguous()
+    datS, ctfS = datM[:, s2m].contiguous(), ctfM[:, s2m].contiguous()
+    sig = -0.5 / (sd * sd / 2)
+    sigE = torch.full((nImg, nPxlE), sig, dtype=torch.float32, device=dev)
+    sigS = torch.full((nImg, nPxlS), sig, dtype=torch.float32, device=dev)
+    pR = torch.full((nImg, nR), 1.0 / nR, dtype=torch.float64, device=dev)
+    pT = torch.full((nImg, nT), 1.0 / nT, dtype=torch.float64, device=dev)
+    wC = torch.zeros((nImg, K), dtype=torch.float32, device=dev)
+    wR = torch.zeros((K, nImg, nR), dtype=torch.float32, device=dev)
+    wT = torch.zeros((K, nImg, nT), dtype=torch.float32, device=dev)
+    base = torch.empty((nImg,), dtype=torch.float32, device=dev)
+    wsG = torch.empty(capi.load().thx_expect_global_workspace(nImg, nR, nT), dtype=torch.uint8, device=dev)
+    batch = min(nImg, args.batch)
+    wsL = torch.empty(capi.load().thx_expect_local_workspace(batch, mLR, mLT, 1), dtype=torch.uint8, device=dev)
+    rotP = torch.empty((nR, nPxlS), dtype=torch.complex64, device=dev)
+    F = torch.zeros((K, P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
+    Tt = torch.zeros((K, P, P, P // 2 + 1), dtype=torch.float32, device=dev)
+    w = torch.full((nImg,), 1.0 / mReco, dtype=torch.float32, device=dev)
+    ar = torch.arange(nImg, device=dev)
+    seed, state = 20240607, {"call": 0}
+    ev = {"scan": [], "local": [], "insert": []}
+    stage_ms = {}
+    maps = {}
+
+    class Stage:
+        def __init__(self, name, timed): self.name, self.timed = name, timed
+        def __enter__(self):
+            if self.timed:
+                torch.cuda.synchronize(); self.t0 = time.perf_counter()
+        def __exit__(self, *a):
+            if self.timed:
+                torch.cuda.synchronize(); stage_ms[self.name] = stage_ms.get(self.name, 0.0) + (time.perf_counter() - self.t0) * 1e3
+
+    def timed_call(key, timed, fn, n):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        r = fn()
+        if timed:
+            e1.record(); ev[key].append((e0, e1, n))
+        return r
+
+    def iteration(timed):
+        with Stage("scan", timed):
+            wC.zero_(); wR.zero_(); wT.zero_(); base.fill_(float("nan"))
+            for k in range(K):
+                ops.project(vols[k], mats, iColS, iRowS, pf, out=rotP)
+                timed_call("scan", timed, lambda: ops.expect_global(rotP, traS, datS, ctfS, sigS, pR, pT, wC, wR, wT, base, k, K, workspace=wsG), nImg)
+        with Stage("class_select_and_support_points", timed):
+            state["call"] += 1
+            cls = ops.pf_class_select(wC, seed, state["call"])
+            cl = cls.to(torch.int64)
+            iR = torch.multinomial(wR[cl, ar].clamp_min(1e-30), mLR, replacement=True, generator=g)
+            iT = torch.multinomial(wT[cl, ar].clamp_min(1e-30), mLT, replacement=True, generator=g)
+            q = quatD[iR]                                                   # [nImg][mLR][4]
+            q = q + 0.02 * torch.randn(q.shape, generator=g, device=dev, dtype=torch.float64)   # a collapsed cloud has no ACG statistics
+            q = (q / q.norm(dim=2, keepdim=True)).contiguous()
+            t = (shiftsD[iT] + 0.3 * torch.randn((nImg, mLT, 2), generator=g, device=dev, dtype=torch.float64)).contiguous()
+            st = dict(r=q, t=t,
+                      wR=torch.full((nImg, mLR), 1.0 / mLR, dtype=torch.float64, device=dev),
+                      wT=torch.full((nImg, mLT), 1.0 / mLT, dtype=torch.float64, device=dev),
+                      k=ops.pf_acg_stats(q)[2], s=t.std(dim=1, unbiased=True).contiguous(),
+                      topR=q[:, 0].contiguous(), topT=t[:, 0].contiguous())
+        with Stage("local_phases", timed):
+            for p_ in range(nPhase):
+                for b0 in range(0, nImg, batch):
+                    b1 = min(nImg, b0 + batch); sl = slice(b0, b1)
+                    state["call"] += 1
+                    f = 2.0 if p_ == 0 else 0.5
+                    ops.pf_perturb(st["r"][sl], st["t"][sl], st["wR"][sl], st["wT"][sl], st["k"][sl], st["s"][sl], f, f, 2.0, 0.05, seed, state["call"])
+                    rotB = ops.rotmat(st["r"][sl].reshape(-1, 4)).reshape(b1 - b0, mLR, 9)
+                    r = timed_call("local", timed, lambda: ops.expect_local(cells, P, pf, N, iColE, iRowE, datE[sl], ctfE[sl], sigE[sl], rotB, st["t"][sl],
+                                                                            volIdx=cls[sl], pR=st["wR"][sl], pT=st["wT"][sl], workspace=wsL, packed=True, wg_per_cu=2), b1 - b0)
+                    state["call"] += 1
+                    ops.pf_update(st["r"][sl], st["t"][sl], st["wR"][sl], st["wT"][sl], r.wR, r.wT, st["k"][sl], st["s"][sl], st["topR"][sl], st["topT"][sl],
+                                  1e-3, seed, state["call"])
+        with Stage("insertion", timed):
+            F.zero_(); Tt.zero_()
+            for b0 in range(0, nImg, batch):
+                b1 = min(nImg, b0 + batch); sl = slice(b0, b1)
+                state["call"] += 1
+                rot, tran = ops.draw_reco(st["r"][sl], st["t"][sl], mReco, seed, state["call"], b0)
+                clsD = cls[sl][:, None].expand(-1, mReco).contiguous()
+                timed_call("insert", timed, lambda: ops.insert(F, Tt, P, datM[sl], ctfM[sl], w[sl], rot, tran, iColM, iRowM, pf, N, cls=clsD, nK=K), b1 - b0)
+        with Stage("reconstruct", timed):
+            rounds = 0
+            for k in range(K):
+                if float(Tt[k, 0, 0, 0]) <= 0:
+                    continue
+                ops.normalise_TF(F[k], Tt[k], P)
+                for MAP in (False, True):
+                    Tk = Tt[k].clone()   # (reconstruct works on T in place, as the reference does)
+                    maps[k] = plan.reconstruct(F[k], Tk, rU, FSC=np.ones(rU, np.float32) if MAP else None, joinHalf=False, MAP=MAP, gridCorr=True)
+                    rounds += int(plan.last_iters)
+        return cls, st, rounds
+
+    for _ in range(args.warmup):
+        iteration(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cls, st, rounds = iteration(True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ok = float((cls.cpu().numpy() == cls_true).mean())
+    # poses after the local phases against the generating ones
+    d = np.abs((st["topR"].cpu().numpy() * quat[r_true]).sum(1)).clip(0, 1)
+    ang = np.degrees(2 * np.arccos(d))
+    ms = lambda key: float(np.mean([a.elapsed_time(b) for a, b, _ in ev[key]]))
+    n_of = lambda key: float(np.mean([n for _, _, n in ev[key]]))
+    scan_ms, loc_ms, ins_ms = ms("scan"), ms("local"), ms("insert")
+    flops = 4.0 * nImg * nR * nT * nPxlS
+    loc_bytes = n_of("local") * nPxlE * (EXPECT_BYTES_PER_PIXEL + EXPECT_BYTES_PER_PIXEL_SAMPLE * mLR)
+    stages = {k: round(v / args.steps, 2) for k, v in stage_ms.items()}
+    dominant = max(("scan", "local_phases"), key=lambda k: stages.get(k, 0.0))
+    roof_scan = {"bound": "mfma", "kernel": "thx_expect_global_dev = k_scan_tables + k_scan_gemm (f32 MFMA) + fold (one class: %d images x %d rot x %d shifts)" % (nImg, nR, nT),
+                 "achieved": flops / (scan_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / (scan_ms * 1e-3) / 1e12 / 157.3,
+                 "traffic": None, "avg_launch_ms": scan_ms,
+                 "note": "exact-f32 contraction on v_mfma_f32_32x32x2_f32 (bit-equal to the fmaf chain); peak = f32 MFMA = f32 vector rate"}
+    roof_local = {"bound": "hbm", "kernel": "k_expect_local<9, packed> with volIdx (K cell-packed references)", "achieved": loc_bytes / (loc_ms * 1e-3) / 1e9,
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": loc_bytes / (loc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                  "avg_launch_ms": loc_ms, "images_per_launch": n_of("local")}
+    out = {"metric": "images/sec through one 3-D classification iteration (K = 4, %d^3 box): global scan + class selection + %d local phases + "
+                     "multi-reference insertion + 2 reconstructions per class" % (N, nPhase),
+           "value": nImg * args.steps / dt, "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "configs[3] on one GPU's share: %d synthetic %d^3 images, K = %d classes; scan %d rotations x %d shifts at r = %d "
+                                  "(%d pixels); local search %d phases x %d rot x %d shifts on %d pixels; %d inserts per image into %d F / T pairs; "
+                                  "%d reconstructions" % (nImg, N, K, nR, nT, rScan, nPxlS, nPhase, mLR, mLT, nPxlE, mReco, K, 2 * K),
+                      "classes_recovered": ok, "median_pose_error_deg": float(np.median(ang)), "particle_order": "random" if args.unsorted else "by class, then view direction",
+                      "sequenced_by": "Python over the *_dev entry points (the native driver runs one class)"},
+           "roofline": roof_scan if dominant == "scan" else roof_local,
+           "rooflines": {"scan": roof_scan, "local_phases": roof_local},
+           "kernels": {"insertion (k_bin + segment sort + k_acc), %d classes in one session" % K: {"avg_call_ms": ins_ms, "images_per_call": n_of("insert"),
+                                                                                             "us_per_image": ins_ms * 1e3 / max(1.0, n_of("insert"))}},
+           "stages_ms_per_step": stages, "balancing_rounds_per_step": rounds, "cpu_baseline": None}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_classification(args, dev, dict(K=K, nR=nR, nT=nT, N=N, P=P, pf=pf, nImg=nImg, mLR=mLR, mLT=mLT, mReco=mReco, nPhase=nPhase,
+                                                                      vols=vols, mats=mats, iColS=iColS, iRowS=iRowS, rotP=rotP, traS=traS, datS=datS, ctfS=ctfS, sigS=sigS,
+                                                                      plE=plE, datE=datE, ctfE=ctfE, sigE=sigE, st=st, cls=cls))
+    print(json.dumps(out))
+    plan.close()
+
+
+def cpu_baseline_classification(args, dev, c):
+    """oracle (`kind: port`) on bounded samples of the classification iteration, all host cores: the scanning loop (every core a block
+    of images through ONE class, scaled to K) and the local phases + insertion (oracle.baseline_block on the filter's support points
+    of the sample, one class volume: the arithmetic does not depend on which class an image is in).  The reconstructions are left
+    out (the refinement bench times that leg); value = images / (scan seconds + local-and-insertion seconds) for the job's images."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    from thunder_amd import ops
+    K, nR, nT, nImg = c["K"], c["nR"], c["nT"], c["nImg"]
+    cores = os.cpu_count() or 1
+    per = max(1, int(args.scan_cpu_images_per_core))
+    n_cpu = min(nImg, per * cores)
+    ops.project(c["vols"][0], c["mats"], c["iColS"], c["iRowS"], c["pf"], out=c["rotP"])
+    rotP_h, traP_h = c["rotP"].cpu().numpy(), c["traS"].cpu().numpy()
+    dat_h, ctf_h, sig_h = c["datS"][:n_cpu].cpu().numpy(), c["ctfS"][:n_cpu].cpu().numpy(), c["sigS"][:n_cpu].cpu().numpy()
+
+    def block(b):
+        lo, hi = b * per, min(n_cpu, (b + 1) * per)
+        m = hi - lo
+        wC_ = np.zeros((m, K), np.float32); wR_ = np.zeros((K, m, nR), np.float32); wT_ = np.zeros((K, m, nT), np.float32)
+        base_ = np.full(m, np.nan, np.float32)
+        O.expect_global(rotP_h, traP_h, np.ascontiguousarray(dat_h[lo:hi].T), np.ascontiguousarray(ctf_h[lo:hi].T),
+                        np.ascontiguousarray(sig_h[lo:hi].T), K, 0, np.full((m, nR), 1.0 / nR), np.full((m, nT), 1.0 / nT), wC_, wR_, wT_, base_)
+        return int(wR_[0].argmax(1)[0])
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(block, range((n_cpu + per - 1) // per)))
+    t_scan = time.perf_counter() - t0
+    scan_rate = n_cpu / (t_scan * K)
+    # local phases + insertion
+    n = min(nImg, max(4, int(args.cpu_particles) if args.cpu_particles else cores))
+    P, N, pf, plE = c["P"], c["N"], c["pf"], c["plE"]
+    pl = dict(iCol=plE["iCol"], iRow=plE["iRow"], iColPad=plE["iColPad"], iRowPad=plE["iRowPad"], nPxl=plE["nPxl"])
+    vol = c["vols"][0].cpu().numpy()
+    dat, ctf, sig = c["datE"][:n].cpu().numpy(), c["ctfE"][:n].cpu().numpy(), c["sigE"][:n].cpu().numpy()
+    quat, t1 = c["st"]["r"][:n].cpu().numpy(), c["st"]["t"][:n].cpu().numpy()
+    r1 = np.stack([[O.rotate3D(q) for q in qs] for qs in quat])
+    rot = np.ascontiguousarray(np.stack([r1] * c["nPhase"], axis=1))
+    tran = np.ascontiguousarray(np.stack([t1] * c["nPhase"], axis=1))
+    rng = np.random.default_rng(1)
+    iR, iT = rng.integers(0, c["mLR"], size=(n, c["mReco"])), rng.integers(0, c["mLT"], size=(n, c["mReco"]))
+    recoRot = np.ascontiguousarray(np.take_along_axis(rot[:, -1], iR[:, :, None], axis=1))
+    recoTran = np.ascontiguousarray(np.take_along_axis(tran[:, -1], iT[:, :, None], axis=1))
+    groups = max(1, min(int(args.cpu_groups), cores))
+    F = np.zeros((groups, P, P, P // 2 + 1), np.complex64)
+    T = np.zeros((groups, P, P, P // 2 + 1), np.float32)
+    t0 = time.perf_counter()
+    O.baseline_block(vol, P, pf, N, pl, dat, ctf, sig, rot, tran, recoRot, recoTran, F, T, groups=groups)
+    F.sum(axis=0); T.sum(axis=0)
+    t_em = time.perf_counter() - t0
+    em_rate = n / t_em
+    value = 1.0 / (1.0 / scan_rate + 1.0 / em_rate)
+    return {"value": value, "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "scan_images_per_s": scan_rate, "local_and_insertion_images_per_s": em_rate,
+            "sample": "scan: %d images x 1 class x %d rotations x %d shifts through the oracle's scanning loop (%d threads x %d images, %.1f s), scaled "
+                      "to %d classes; local phases + insertion: %d images x (%d phases x %d rot x %d shifts + %d inserts) through the oracle C port, %d "
+                      "threads in %d groups with private F / T, %.1f s; reconstructions not included" % (
+                          n_cpu, nR, nT, cores, per, t_scan, K, n, c["nPhase"], c["mLR"], c["mLT"], c["mReco"], cores, groups, t_em)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,8 +534,10 @@ def main():
     ap.add_argument("--unsorted", action="store_true",
                     help="keep the particles in random order (default: stored by view direction, thx_view_order_host)")
     ap.add_argument("--classification", action="store_true",
-                    help="time the global scanning stage of configs[3] (K = 4 x 10000 rotations x 30 shifts at r = 24) instead")
-    ap.add_argument("--scan-images", type=int, default=1024)
+                    help="one whole K = 4 classification iteration of configs[3] on one GPU's share of the images instead "
+                         "(scan, class selection, local phases, multi-reference insertion, reconstructions)")
+    ap.add_argument("--scan-only", action="store_true", help="with --classification: the global scanning stage on its own")
+    ap.add_argument("--scan-images", type=int, default=0, help="images of the classification bench (default 6250 = 50 000 / 8 GPUs; 1024 with --scan-only)")
     ap.add_argument("--scan-cpu-images-per-core", type=int, default=2)
     args = ap.parse_args()
 
@@ -286,7 +557,13 @@ def main():
     if args.classification:
         from thunder_amd import capi
         capi.load()
-        bench_global_scan(args, dev)
+        if not args.scan_images:
+            args.scan_images = 1024 if args.scan_only else 6250
+        if args.scan_only:
+            bench_global_scan(args, dev)
+        else:
+            args.batch = min(args.batch, 3125)
+            bench_classification_iteration(args, dev)
         return
     from thunder_amd import capi
     from thunder_amd.native import NativeRefine, make_comms, STAGES
