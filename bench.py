@@ -25,6 +25,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+INIT_OUTSIDE_CONFIDENCE_AREA = 0.5   # include/Particle.h:59
+TRANS_SEARCH_FACTOR = 0.25           # script/demo_3D.json "Translation Search Factor"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 INSERT_BYTES_PER_PIXEL_SAMPLE = 204  # 12 B in + F 8x8 Bx(R+W) + T 8x4 Bx(R+W)
 EXPECT_BYTES_PER_PIXEL_SAMPLE = 64   # 8 neighbours x 8 B
@@ -248,8 +250,8 @@ def bench_classification_iteration(args, dev):
     of the images, sequenced over the batched `*_dev` entry points the way Optimiser::expectation does for a classification
     (src/Optimiser.cpp:631-1660): global scan of every image against K classes x 10 000 rotations x 30 shifts at r = 24
     (:756-894) -> class of every image (keepHalfHeightPeak(PAR_C) / resample / rand, :925-952: k_pf_class_select) -> support
-    points from the selected class's scan posterior (Particle::resample(mLR, PAR_R) / (mLT, PAR_T): a multinomial draw in
-    torch here -- the one step of this sequence without a device kernel of its own) -> 3 local particle-filter phases
+    points from the selected class's scan posterior (keepHalfHeightPeak / resample(mLR, PAR_R) / resample(mLT, PAR_T) / calVari,
+    :953-1008: k_pf_scan_support) -> 3 local particle-filter phases
     against the assigned reference (volIdx; k_pf_perturb / k_expect_local<9, packed> / k_pf_update) -> mReco draws per image ->
     multi-reference insertion (cls per draw, K pairs of F / T in one session: k_bin / sort / k_acc) -> normalise + 2
     reconstructions per class (MAP off / on, Reconstructor::reconstruct).  Left out of the timed region: the sigma update and
@@ -359,18 +361,14 @@ def bench_classification_iteration(args, dev):
         with Stage("class_select_and_support_points", timed):
             state["call"] += 1
             cls = ops.pf_class_select(wC, seed, state["call"])
-            cl = cls.to(torch.int64)
-            iR = torch.multinomial(wR[cl, ar].clamp_min(1e-30), mLR, replacement=True, generator=g)
-            iT = torch.multinomial(wT[cl, ar].clamp_min(1e-30), mLT, replacement=True, generator=g)
-            q = quatD[iR]                                                   # [nImg][mLR][4]
-            q = q + 0.02 * torch.randn(q.shape, generator=g, device=dev, dtype=torch.float64)   # a collapsed cloud has no ACG statistics
-            q = (q / q.norm(dim=2, keepdim=True)).contiguous()
-            t = (shiftsD[iT] + 0.3 * torch.randn((nImg, mLT, 2), generator=g, device=dev, dtype=torch.float64)).contiguous()
-            st = dict(r=q, t=t,
-                      wR=torch.full((nImg, mLR), 1.0 / mLR, dtype=torch.float64, device=dev),
-                      wT=torch.full((nImg, mLT), 1.0 / mLT, dtype=torch.float64, device=dev),
-                      k=ops.pf_acg_stats(q)[2], s=t.std(dim=1, unbiased=True).contiguous(),
-                      topR=q[:, 0].contiguous(), topT=t[:, 0].contiguous())
+            state["call"] += 1
+            # Particle::keepHalfHeightPeak(PAR_R) / resample(mLR, PAR_R) / resample(mLT, PAR_T) / calVari on the scan posterior of the
+            # image's class (src/Optimiser.cpp:953-1008)
+            # with the scanning phase's minimum spread (OPTIMISER_SCAN_SET_MIN_STD_WITH_PERTURB, :1032-1079): scanMinStdR = nR^(-1/3),
+            # scanMinStdT = 1 / Qinv(INIT_OUTSIDE_CONFIDENCE_AREA, 2) / sqrt(transSearchFactor pi), over perturbFactorSGlobal = 0.5
+            minK = (nR ** (-1.0 / 3) / 0.5) ** 2
+            minS = 1.0 / (-2.0 * np.log(INIT_OUTSIDE_CONFIDENCE_AREA)) / np.sqrt(TRANS_SEARCH_FACTOR * np.pi) / 0.5
+            st = ops.pf_scan_support(quatD, shiftsD, wR, wT, cls, mLR, mLT, 1e-3, seed, state["call"], minK, minS)
         with Stage("local_phases", timed):
             for p_ in range(nPhase):
                 for b0 in range(0, nImg, batch):

@@ -455,6 +455,21 @@ int thx_pf_update_d_dev(double* d, double* wD, const float* uD, double* sD, doub
 int thx_pf_class_select_dev(int* cls, const float* uC, const double* wC, int nImg, int nK, double peakFactorC,
                             unsigned long long seed, unsigned call, void* stream);
 
+/* Support points of the local search after a global scan, src/Optimiser.cpp:953-1008: for every image the scanned grid
+ * (gridR [nRin][4] quaternions, gridT [nTin][2] shifts, shared by all images; uniform priors) with the scan weights of its
+ * class -- uR [nK][nImg][nRin], uT [nK][nImg][nTin] as thx_expect_global_dev leaves them, cls [nImg] from
+ * thx_pf_class_select_dev (NULL = class 0) -- goes through keepHalfHeightPeak(PAR_R) (peakFactorR; < 0 = off),
+ * resample(mLR, PAR_R), resample(mLT, PAR_T) (src/Particle.cpp:1291-1430: shuffle, top = first largest weight, systematic draw
+ * of mLR / mLT of the nRin / nTin points), calVari(PAR_R), calVari(PAR_T), and the minimum spread of the scanning phase:
+ * k1..k3 = max(minK, k), s0, s1 = max(minS, s) (:1032-1079; OPTIMISER_SCAN_SET_MIN_STD_WITH_PERTURB: minK = (scanMinStdR /
+ * perturbFactorSGlobal)^2 with scanMinStdR = nRin^(-1/3), minS = scanMinStdT / perturbFactorSGlobal; 0 = none).  Out: r [nImg][mLR][4], t [nImg][mLT][2], their priors
+ * wR / wT, k123 [nImg][3], s01 [nImg][2], topR [nImg][4], topT [nImg][2] -- the state thx_pf_perturb_dev continues from.
+ * Philox streams (seed, image, call, 2 / 3 = rotation shuffle keys / u0, 4 / 5 = shift shuffle keys / u0).  nRin, nTin <= 16384. */
+int thx_pf_scan_support_dev(double* r, double* t, double* wR, double* wT, double* k123, double* s01, double* topR, double* topT,
+                            const double* gridR, const double* gridT, const float* uR, const float* uT, const int* cls, int nImg,
+                            int nRin, int nTin, int mLR, int mLT, double peakFactorR, double minK, double minS, unsigned long long seed,
+                            unsigned call, void* stream);
+
 /* The deterministic ACG statistics on their own (parity probe): for quat [nImg][n][4] -> A [nImg][16] (inferACG,
  * DirectionalStat.cpp:93-145), mean [nImg][4] (:224-262), k123 [nImg][3] (calVari's mean-frame ratios), wBal [nImg][n]
  * (balanceWeight(PAR_R)), rounds [nImg][2] fixed-point rounds of the two inferACG calls (may be NULL). */

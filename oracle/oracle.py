@@ -605,20 +605,42 @@ def pf_perturb(q, t, k, s, pfR, pfT, transS, transQ, gR, gT):
     return q, t, wR, wT
 
 
-def pf_resample(val, w, u, rank, u0):
+def pf_resample(val, w, u, rank, u0, nOut=None):
     """Particle::resample(n, pt) for one parameter (src/Particle.cpp:1291-1430, PARTICLE_PRIOR_ONE): shuffle (rank[i] = new
     position of element i, the draw), _topX = element of the largest u, w *= u, systematic resampling with the draw u0 in
     [0, 1 / n).  Returns (values [n], weights [n], source index of every output in the UNSHUFFLED order, index of the top)."""
     n = len(w)
+    nOut = n if nOut is None else int(nOut)       # resample(n', pt) with n' < n: the support points after a global scan
     inv = np.empty(n, np.int64)
     inv[np.asarray(rank)] = np.arange(n)          # shuffled[j] = original[inv[j]]
     ws, us = np.ascontiguousarray(f64(w)[inv]), np.ascontiguousarray(f64(u)[inv])
     top = int(inv[int(np.argmax(us))])            # d_value_max_index on the shuffled list: first maximum
-    idx = np.zeros(n, np.int32)
-    wo = np.zeros(n)
-    lib().orc_resample(_p(idx, c_i), _dp(wo), _dp(ws), _dp(us), C.c_int(n), C.c_int(n), C.c_double(float(u0)))
+    idx = np.zeros(nOut, np.int32)
+    wo = np.zeros(nOut)
+    lib().orc_resample(_p(idx, c_i), _dp(wo), _dp(ws), _dp(us), C.c_int(n), C.c_int(nOut), C.c_double(float(u0)))
     src = inv[idx]
     return val[src].copy(), wo, src, top
+
+
+def pf_scan_support(gridR, gridT, uR, uT, peakFactorR, mLR, mLT, rankR, u0R, rankT, u0T, minK=0.0, minS=0.0):
+    """The filter of one image after a global scan, src/Optimiser.cpp:953-1008: the scanned grid with uniform priors and the scan
+    weights uR [nRin] / uT [nTin] (RFLOAT) -> keepHalfHeightPeak(PAR_R) (OPTIMISER_PEAK_FACTOR_R; _T off), resample(mLR, PAR_R),
+    resample(mLT, PAR_T), calVari(PAR_R), calVari(PAR_T), k = max(minK, k), s = max(minS, s).  u0R in [0, 1 / mLR), u0T in [0, 1 / mLT).  Returns dict(q, t, wR, wT, k, s,
+    topR, topT, srcR, srcT, uRk)."""
+    L = lib()
+    gridR, gridT = f64(gridR), f64(gridT)
+    nR, nT = len(gridR), len(gridT)
+    u = f64(np.asarray(uR, np.float32).astype(np.float64)).copy()
+    L.orc_keep_half_height_peak(_dp(u), C.c_int(nR), C.c_double(peakFactorR))
+    ut = f64(np.asarray(uT, np.float32).astype(np.float64)).copy()
+    q2, wR2, srcR, topR = pf_resample(gridR, np.full(nR, 1.0 / nR), u, rankR, u0R, nOut=mLR)
+    t2, wT2, srcT, topT = pf_resample(gridT, np.full(nT, 1.0 / nT), ut, rankT, u0T, nOut=mLT)
+    q2, t2 = np.ascontiguousarray(q2), np.ascontiguousarray(t2)
+    k, mean, s = np.zeros(3), np.zeros(4), np.zeros(2)
+    L.orc_cal_vari_R(_dp(k), _dp(mean), _dp(q2), C.c_int(mLR))      # rotates q to the mean frame and back, in place
+    L.orc_cal_vari_T(_dp(s), _dp(t2), C.c_int(mLT))
+    k, s = np.maximum(k, minK), np.maximum(s, minS)                 # setK1..3 / setS0, S1 with the scan's minimum spread, :1032-1079
+    return dict(q=q2, t=t2, wR=wR2, wT=wT2, k=k, s=s, topR=gridR[topR].copy(), topT=gridT[topT].copy(), srcR=srcR, srcT=srcT, uRk=u)
 
 
 def pf_update(q, t, wR, wT, uR, uT, peakFactorR, rankR, u0R, rankT, u0T):

@@ -247,6 +247,52 @@ def test_class_select_after_scan(oracle, dev):
     assert 0.02 < second < 0.6, second                         # the runner-up within 1 % keeps a share (u - 0.99 max)
 
 
+def test_scan_support_points(oracle, dev):
+    """thx_pf_scan_support_dev against the oracle's restatement of src/Optimiser.cpp:953-1008: the scanned grid (10 000 rotations /
+    30 shifts in one case: the bitonic shuffle at its full size) with peaked scan weights of K classes -> keepHalfHeightPeak,
+    resample(mLR) / resample(mLT) with the replayed shuffle and u0, calVari.  The cumulative sums are formed in the reference's
+    order (serial), the normalising sum in a wave tree: a resampled index may sit on its threshold -- such a draw must then be an
+    immediate neighbour in the shuffled order, and there are at most a handful of them."""
+    from thunder_amd import ops, synth
+    O = oracle
+    for nImg, nK, nRin, nTin, mLR, mLT, seed_np in ((5, 2, 700, 30, 125, 9, 31), (2, 1, 10000, 30, 125, 9, 32)):
+        rng = np.random.default_rng(seed_np)
+        seed, call, peak = 13579, 7, 1e-3
+        gridR = synth.random_quats(nRin, rng)
+        gridT = np.ascontiguousarray(rng.normal(0, 3.0, size=(nTin, 2)))
+        # scan posterior: a few strong modes on a weak background
+        uR = (rng.uniform(0, 1, (nK, nImg, nRin)) ** 40).astype(np.float32)
+        uT = (rng.uniform(0.01, 1, (nK, nImg, nTin)) ** 3).astype(np.float32)
+        cls = rng.integers(0, nK, nImg).astype(np.int32)
+        minK, minS = (2.0 * nRin ** (-1.0 / 3)) ** 2, 0.35          # the scanning phase's minimum spread (one of the k below it in case 2)
+        st = ops.pf_scan_support(T(gridR, dev), T(gridT, dev), T(uR, dev), T(uT, dev), T(cls, dev), mLR, mLT, peak, seed, call, minK, minS)
+        g = {k: v.cpu().numpy() for k, v in st.items()}
+        near = 0
+        for l in range(nImg):
+            rankR, rankT = PH.shuffle_ranks(seed, l, call, 2, nRin), PH.shuffle_ranks(seed, l, call, 4, nTin)
+            w = O.pf_scan_support(gridR, gridT, uR[cls[l], l], uT[cls[l], l], peak, mLR, mLT, rankR, PH.draw_u4(seed, l, call, 3, 0)[0] / mLR,
+                                  rankT, PH.draw_u4(seed, l, call, 5, 0)[0] / mLT, minK, minS)
+            assert np.array_equal(g["topR"][l], w["topR"]) and np.array_equal(g["topT"][l], w["topT"])
+            # which grid point every device support point is (before calVari's round trip: 1e-16 of noise on the quaternion)
+            dR = np.abs(g["r"][l][:, None, :] - gridR[None, w["srcR"], :]).max(axis=2)      # [mLR device][mLR oracle]
+            same = dR.diagonal() <= 1e-13
+            for j in np.nonzero(~same)[0]:     # a draw on its threshold: the neighbour in the shuffled order
+                srcD = int(np.argmin(np.abs(gridR - g["r"][l][j]).max(axis=1)))
+                assert abs(int(rankR[srcD]) - int(rankR[w["srcR"][j]])) <= 1, (l, j)
+                near += 1
+            if same.all():
+                assert np.allclose(g["wR"][l], w["wR"], rtol=1e-9) and np.allclose(g["k"][l], w["k"], rtol=5e-2)
+            assert np.all(w["uRk"][w["srcR"]] > 0) and abs(g["wR"][l].sum() - 1) < 1e-12
+            assert np.array_equal(g["t"][l], w["t"]) and np.allclose(g["wT"][l], w["wT"], rtol=1e-9)
+            assert np.allclose(g["s"][l], w["s"], rtol=1e-12)
+        assert near <= 2
+        # reproducible; another call id -> another shuffle
+        st2 = ops.pf_scan_support(T(gridR, dev), T(gridT, dev), T(uR, dev), T(uT, dev), T(cls, dev), mLR, mLT, peak, seed, call, minK, minS)
+        assert all(torch.equal(st[k], st2[k]) for k in st)
+        st3 = ops.pf_scan_support(T(gridR, dev), T(gridT, dev), T(uR, dev), T(uT, dev), T(cls, dev), mLR, mLT, peak, seed, call + 1, minK, minS)
+        assert not torch.equal(st["r"], st3["r"])
+
+
 def test_defocus_filter(oracle, dev):
     """PAR_D of the CTF search: Particle::initD / perturb(PAR_D) + balanceWeight(PAR_D), then calRank1st / calVari / resample(PAR_D)
     -- device kernels against the oracle with replayed draws"""

@@ -409,6 +409,180 @@ __global__ __launch_bounds__(64) void k_pf_update(PfArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Support points of the local search after a GLOBAL scan, src/Optimiser.cpp:953-1008: the particle holds the nIn scanned grid
+// points with their scan weights u (uniform priors 1 / nIn); keepHalfHeightPeak(PAR_R) (peak factor; not for PAR_T), then
+// resample(mLR, PAR_R) / resample(mLT, PAR_T) -- shuffle, _top = first largest u of the shuffled list, w *= u, systematic draw of
+// nOut < nIn points (src/Particle.cpp:1291-1430) -- then calVari(PAR_R) / calVari(PAR_T) on the new points.
+// One wave per image.  The shuffle of 10 000 points is a bitonic sort of (Philox key << 32 | index) in LDS (ties by index, as
+// the n^2 rank of resample<> above); the sorted pairs are then compacted in place to the indices, and the second half of the
+// same LDS holds the shuffled u for the one sequential pass the cumulative sum needs.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__device__ void resample_from_grid(double* outVal /*LDS [nOut][W]*/, double* outW /*LDS [nOut]*/, double* top /*global [W]*/,
+                                   const double* __restrict__ grid /*global [nIn][W]*/, const float* __restrict__ u /*global [nIn]*/,
+                                   double peakFactor, int nIn, int nOut, unsigned long long* pairs /*LDS [NP]*/, int NP, int lane,
+                                   unsigned long long seed, unsigned img, unsigned call, unsigned purpose)
+{
+    // keepHalfHeightPeak: hh = max(u) * peakFactor; u < hh -> 0, else u - hh   (:1964-2011)
+    double umax = -1.0;
+    for (int i = lane; i < nIn; i += 64) umax = fmax(umax, (double)u[i]);
+    for (int o = 32; o > 0; o >>= 1) umax = fmax(umax, __shfl_xor(umax, o, 64));
+    const double hh = peakFactor >= 0 ? umax * peakFactor : 0.0;
+    const bool peak = peakFactor >= 0;
+    // shuffle: sort by (random key, index)
+    for (int i = lane; i < NP; i += 64) {
+        unsigned long long pr = ~0ull;
+        if (i < nIn) {
+            Philox g{(unsigned)seed, (unsigned)(seed >> 32)};
+            unsigned c[4] = {img, call, purpose, (unsigned)i};
+            g(c);
+            pr = ((unsigned long long)c[0] << 32) | (unsigned)i;
+        }
+        pairs[i] = pr;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 2; k <= NP; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < NP; t += 64) {
+                const int x = t ^ j;
+                if (x > t) {
+                    const unsigned long long a = pairs[t], b = pairs[x];
+                    if ((a > b) == ((t & k) == 0)) { pairs[t] = b; pairs[x] = a; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    // pairs -> indices (first half of the buffer), then the shuffled u behind them
+    unsigned* idx = reinterpret_cast<unsigned*>(pairs);
+    float* uv = reinterpret_cast<float*>(pairs) + NP;
+    for (int c0 = 0; c0 < NP; c0 += 64) {
+        const unsigned e = (unsigned)pairs[c0 + lane];
+        __builtin_amdgcn_wave_barrier();
+        idx[c0 + lane] = e;
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int p = lane; p < nIn; p += 64) uv[p] = u[idx[p]];
+    __builtin_amdgcn_wave_barrier();
+    auto ud = [&](int p) -> double {   // the shuffled list's weight after keepHalfHeightPeak, in double as Particle holds it
+        const double v = (double)uv[p];
+        return peak ? (v < hh ? 0.0 : v - hh) : v;
+    };
+    // _top: first largest u of the shuffled list
+    int pTop = INT_MAX;
+    for (int p = lane; p < nIn; p += 64)
+        if ((double)uv[p] == umax) { pTop = p; break; }
+    for (int o = 32; o > 0; o >>= 1) pTop = min(pTop, __shfl_xor(pTop, o, 64));
+    if (lane < W) top[lane] = grid[(size_t)idx[pTop] * W + lane];
+    // w *= u; w /= sum; cdf = cumsum(w); cdf /= cdf[n - 1]; systematic draw
+    const double w0 = 1.0 / nIn;
+    double sum = 0;
+    for (int p = lane; p < nIn; p += 64) sum += w0 * ud(p);
+    sum = wave_sum(sum);
+    double u4[4];
+    draw_u4(u4, seed, img, call, purpose + 1, 0);
+    const double u0 = u4[0] * (1.0 / nOut);   // gsl_ran_flat(engine, 0, 1.0 / n)
+    int* src = reinterpret_cast<int*>(outW);  // (the source positions, for the wave)
+    // The cumulative sum runs in the reference's order (serial over the shuffled list), 64 points at a time: the divisions of a
+    // chunk are done by the 64 lanes, the 64 additions by every lane alike (shuffles), lane i keeping the running sum after point i.
+    double last = 0;
+    for (int c0 = 0; c0 < nIn; c0 += 64) {
+        const int p = c0 + lane;
+        const double term = p < nIn ? (w0 * ud(p)) / sum : 0.0;
+        const int m = nIn - c0 < 64 ? nIn - c0 : 64;
+        for (int i = 0; i < m; i++) last += __shfl(term, i, 64);
+    }
+    {
+        double acc = 0;
+        int j = 0;
+        for (int c0 = 0; c0 < nIn && j < nOut; c0 += 64) {
+            const int p = c0 + lane;
+            const double term = p < nIn ? (w0 * ud(p)) / sum : 0.0;
+            const int m = nIn - c0 < 64 ? nIn - c0 : 64;
+            double mine = 0;
+            for (int i = 0; i < m; i++) { acc += __shfl(term, i, 64); if (lane == i) mine = acc; }
+            const double cdf = mine / last;
+            while (j < nOut) {   // smallest p with !(uj > cdf[p])
+                const double uj = u0 + j * 1.0 / nOut;
+                const unsigned long long hit = __ballot(lane < m && !(uj > cdf));
+                if (!hit) break;
+                if (lane == 0) src[2 * j] = c0 + __ffsll((long long)hit) - 1;
+                j++;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    double ws = 0;
+    int mySrc[4];
+    for (int j = lane, q = 0; j < nOut; j += 64, q++) mySrc[q] = src[2 * j];
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane, q = 0; j < nOut; j += 64, q++) {
+#pragma unroll
+        for (int c = 0; c < W; c++) outVal[W * j + c] = grid[(size_t)idx[mySrc[q]] * W + c];
+        outW[j] = 1.0 / ud(mySrc[q]);
+        ws += outW[j];
+    }
+    ws = wave_sum(ws);
+    for (int j = lane; j < nOut; j += 64) outW[j] /= ws;
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct ScanSupportArgs {
+    double *r, *t, *wR, *wT, *k123, *s01, *topR, *topT;
+    const double *gridR, *gridT;
+    const float *uR, *uT;   // [nK][nImg][nRin], [nK][nImg][nTin]
+    const int* cls;         // [nImg] or NULL (class 0)
+    int nImg, nRin, nTin, mLR, mLT, NPR, NPT;
+    double peakFactorR, minK, minS;
+    unsigned long long seed;
+    unsigned call;
+};
+
+__global__ __launch_bounds__(64) void k_pf_scan_support(ScanSupportArgs a)
+{
+    extern __shared__ unsigned long long pairs[];
+    __shared__ double sq[kPfMax * 4], sw[kPfMax];
+    const int img = blockIdx.x, lane = threadIdx.x;
+    const size_t row = (size_t)(a.cls ? a.cls[img] : 0) * a.nImg + img;
+    // ---- rotations ----
+    resample_from_grid<4>(sq, sw, a.topR + 4 * (size_t)img, a.gridR, a.uR + row * a.nRin, a.peakFactorR, a.nRin, a.mLR, pairs, a.NPR, lane,
+                          a.seed, (unsigned)img, a.call, 2);
+    {   // calVari(PAR_R) on the new points, as in k_pf_update
+        double A[16], mean[4], cm[4];
+        infer_acg(A, sq, a.mLR, lane, nullptr);
+        sym4_top_eigvec(mean, A);
+        cm[0] = mean[0]; cm[1] = -mean[1]; cm[2] = -mean[2]; cm[3] = -mean[3];
+        for (int i = lane; i < a.mLR; i += 64) { double o[4]; qmul(o, cm, sq + 4 * i); for (int c = 0; c < 4; c++) sq[4 * i + c] = o[c]; }
+        __builtin_amdgcn_wave_barrier();
+        infer_acg(A, sq, a.mLR, lane, nullptr);
+        if (lane == 0) {   // setK1..3(max(minimum of the scanning phase, k)), src/Optimiser.cpp:1032-1050
+            a.k123[3 * (size_t)img] = fmax(a.minK, A[5] / A[0]);
+            a.k123[3 * (size_t)img + 1] = fmax(a.minK, A[10] / A[0]);
+            a.k123[3 * (size_t)img + 2] = fmax(a.minK, A[15] / A[0]);
+        }
+        for (int i = lane; i < a.mLR; i += 64) { double o[4]; qmul(o, mean, sq + 4 * i); for (int c = 0; c < 4; c++) sq[4 * i + c] = o[c]; }
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int i = lane; i < a.mLR; i += 64) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) a.r[((size_t)img * a.mLR + i) * 4 + c] = sq[4 * i + c];
+        a.wR[(size_t)img * a.mLR + i] = sw[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- shifts ----
+    resample_from_grid<2>(sq, sw, a.topT + 2 * (size_t)img, a.gridT, a.uT + row * a.nTin, -1.0, a.nTin, a.mLT, pairs, a.NPT, lane, a.seed,
+                          (unsigned)img, a.call, 4);
+    double m, s0, s1;
+    col_mean_sd(m, s0, sq, 0, a.mLT, lane);
+    col_mean_sd(m, s1, sq, 1, a.mLT, lane);
+    if (lane == 0) { a.s01[2 * (size_t)img] = fmax(a.minS, s0); a.s01[2 * (size_t)img + 1] = fmax(a.minS, s1); }   // setS0 / setS1, :1067-1079
+    for (int i = lane; i < a.mLT; i += 64) {
+        a.t[((size_t)img * a.mLT + i) * 2] = sq[2 * i];
+        a.t[((size_t)img * a.mLT + i) * 2 + 1] = sq[2 * i + 1];
+        a.wT[(size_t)img * a.mLT + i] = sw[i];
+    }
+}
+
 // inferACG / statistics probe for the parity tests: A [nImg][16], mean [nImg][4], k123 [nImg][3], wBal [nImg][n]
 __global__ __launch_bounds__(64) void k_pf_acg_stats(double* __restrict__ Aout, double* __restrict__ meanOut,
                                                      double* __restrict__ kOut, double* __restrict__ wBal,
@@ -726,6 +900,29 @@ int thx_pf_class_select_dev(int* cls, const float* uC, const double* wC, int nIm
     THX_REQUIRE(cls && uC && nK >= 1 && nK <= kMaxClasses, "bad arguments (at most 64 classes)");
     hipLaunchKernelGGL(k_pf_class_select, dim3((nImg + 63) / 64), dim3(64), 0, as_stream(stream), cls, uC, wC, nImg, nK, peakFactorC,
                        seed, call);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_pf_scan_support_dev(double* r, double* t, double* wR, double* wT, double* k123, double* s01, double* topR, double* topT,
+                            const double* gridR, const double* gridT, const float* uR, const float* uT, const int* cls, int nImg,
+                            int nRin, int nTin, int mLR, int mLT, double peakFactorR, double minK, double minS, unsigned long long seed,
+                            unsigned call, void* stream)
+{
+    if (nImg <= 0) return 0;
+    THX_REQUIRE(r && t && wR && wT && k123 && s01 && topR && topT && gridR && gridT && uR && uT, "NULL pointer");
+    THX_REQUIRE(mLR >= 5 && mLR <= kPfMax && mLT >= 2 && mLT <= kPfMax && mLR <= nRin && mLT <= nTin, "bad support sizes");
+    THX_REQUIRE(nRin <= 16384 && nTin <= 16384, "at most 16384 scanned points per parameter (the shuffle sorts them in LDS)");
+    ScanSupportArgs a;
+    a.r = r; a.t = t; a.wR = wR; a.wT = wT; a.k123 = k123; a.s01 = s01; a.topR = topR; a.topT = topT;
+    a.gridR = gridR; a.gridT = gridT; a.uR = uR; a.uT = uT; a.cls = cls;
+    a.nImg = nImg; a.nRin = nRin; a.nTin = nTin; a.mLR = mLR; a.mLT = mLT;
+    a.NPR = 64; while (a.NPR < nRin) a.NPR <<= 1;
+    a.NPT = 64; while (a.NPT < nTin) a.NPT <<= 1;
+    a.peakFactorR = peakFactorR; a.minK = minK; a.minS = minS; a.seed = seed; a.call = call;
+    const size_t lds = (size_t)(a.NPR > a.NPT ? a.NPR : a.NPT) * sizeof(unsigned long long);
+    THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pf_scan_support), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_pf_scan_support, dim3(nImg), dim3(64), lds, as_stream(stream), a);
     THX_LAUNCH_CHECK();
     return 0;
 }

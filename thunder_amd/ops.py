@@ -393,6 +393,23 @@ def pf_class_select(uC, seed, call_id, wC=None, peakFactorC=1.0 - 1e-2):
     return cls
 
 
+def pf_scan_support(gridR, gridT, uR, uT, cls, mLR, mLT, peakFactorR, seed, call, minK=0.0, minS=0.0):
+    """support points of the local search after a global scan (src/Optimiser.cpp:953-1008, thx_pf_scan_support_dev): gridR
+    [nRin][4], gridT [nTin][2] f64; uR [nK][nImg][nRin], uT [nK][nImg][nTin] f32 scan weights; cls [nImg] int32 or None ->
+    dict(r, t, wR, wT, k, s, topR, topT) = the filter state thx_pf_perturb_dev continues from"""
+    _chk(gridR, _F64, "gridR"); _chk(gridT, _F64, "gridT"); _chk(uR, _F32, "uR"); _chk(uT, _F32, "uT")
+    nImg, nRin, nTin, dev = uR.shape[1], uR.shape[2], uT.shape[2], uR.device
+    if cls is not None:
+        _chk(cls, _I32, "cls")
+    e = lambda *sh: torch.empty(sh, dtype=_F64, device=dev)
+    st = dict(r=e(nImg, mLR, 4), t=e(nImg, mLT, 2), wR=e(nImg, mLR), wT=e(nImg, mLT), k=e(nImg, 3), s=e(nImg, 2), topR=e(nImg, 4),
+              topT=e(nImg, 2))
+    capi.call("thx_pf_scan_support_dev", ptr(st["r"]), ptr(st["t"]), ptr(st["wR"]), ptr(st["wT"]), ptr(st["k"]), ptr(st["s"]),
+              ptr(st["topR"]), ptr(st["topT"]), ptr(gridR), ptr(gridT), ptr(uR), ptr(uT), ptr(cls), nImg, nRin, nTin, int(mLR), int(mLT),
+              float(peakFactorR), float(minK), float(minS), int(seed), int(call), stream_ptr())
+    return st
+
+
 def pf_acg_stats(quat):
     """inferACG / mean / k1..k3 / balance weights of [n][m][4] f64 clouds -> (A [n][16], mean [n][4], k [n][3], w [n][m])"""
     _chk(quat, _F64, "quat")
