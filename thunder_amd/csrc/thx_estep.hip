@@ -298,11 +298,14 @@ template <int NT, bool PACKED>
 __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float2* sA = reinterpret_cast<float2*>(smem_raw);                 // [kChunk][NT]
-    float* sB = reinterpret_cast<float*>(sA + kChunk * NT);           // [kChunk]
-    int* sIc = reinterpret_cast<int*>(sB + kChunk);                   // [kChunk]
-    int* sIr = sIc + kChunk;                                          // [kChunk]
-    float* sRed = reinterpret_cast<float*>(sIr + kChunk);             // [4 waves] block-reduce scratch
+    // per pixel the NT values A_t = s ctf conj(dat) ramp_t, laid out for two-lane FMAs: shifts in pairs (re_t, re_t+1, -im_t,
+    // -im_t+1), an odd last one as (re, -im) -- so that acc_t += re_t q.x; acc_t += -im_t q.y is one v_pk_fma_f32 per product
+    // for two shifts, with no register shuffling and no sign flips in the loop
+    float* sA = reinterpret_cast<float*>(smem_raw);                   // [kChunk][2 NT]
+    double* sIc = reinterpret_cast<double*>(sA + kChunk * 2 * NT);    // [kChunk] padded pixel coordinates, as the doubles the
+    double* sIr = sIc + kChunk;                                       // [kChunk] rotation multiplies
+    float* sB = reinterpret_cast<float*>(sIr + kChunk);               // [kChunk]
+    float* sRed = sB + kChunk;                                        // [4 waves] block-reduce scratch
 
     const int split = blockIdx.x, img = blockIdx.y, d = blockIdx.z;
     if (a.active && !a.active[img]) return;
@@ -335,10 +338,10 @@ __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
             const double* m = a.rotMat + ((size_t)img * a.nR + r) * 9;
             m0 = m[0]; m1 = m[1]; m2 = m[2]; m3 = m[3]; m4 = m[4]; m5 = m[5];
         }
-        float acc[NT];
+        thx_v2f accP[(NT + 1) / 2];   // (acc_t, acc_t+1); the odd last shift in lane 0 of the last pair
         float accB = 0.f;
 #pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = 0.f;
+        for (int i = 0; i < (NT + 1) / 2; i++) accP[i] = thx_v2f{0.f, 0.f};
 
         for (int c = c0; c < c1; c++) {
             const int pbase = c * kChunk;
@@ -348,8 +351,8 @@ __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
             for (int e = tid; e < clen; e += 256) {
                 const int p = pbase + e;
                 const int ic = a.iCol[p], ir = a.iRow[p];
-                sIc[e] = ic * a.pf;
-                sIr[e] = ir * a.pf;
+                sIc[e] = (double)(ic * a.pf);
+                sIr[e] = (double)(ir * a.pf);
                 const float s = sig[p], cf = ctf[p];
                 const float2 dv = dat[p];
                 const float g = s * cf;
@@ -360,7 +363,10 @@ __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
                 for (int t = 0; t < NT; t++) {
                     if (t < a.nT) {
                         const float rCol = (float)tr[2 * t] / a.idim, rRow = (float)tr[2 * t + 1] / a.idim;
-                        sA[e * NT + t] = cmul(cd, ramp_value(rCol, rRow, ic, ir));
+                        const float2 A = cmul(cd, ramp_value(rCol, rRow, ic, ir));
+                        float* dst = sA + e * 2 * NT + ((NT & 1) && t == NT - 1 ? 2 * t : 4 * (t >> 1) + (t & 1));
+                        dst[0] = A.x;
+                        dst[(NT & 1) && t == NT - 1 ? 1 : 2] = -A.y;
                     }
                 }
             }
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
             // ---- hot loop: lane = rotation, walk this wave's pixel sub-stream ----
             if (rvalid) {
                 for (int e = sub; e < clen; e += nSub) {
-                    const double nx = (double)sIc[e], ny = (double)sIr[e];
+                    const double nx = sIc[e], ny = sIr[e];
                     const float x = (float)(m0 * nx + m3 * ny);
                     const float y = (float)(m1 * nx + m4 * ny);
                     const float z = (float)(m2 * nx + m5 * ny);
@@ -376,12 +382,18 @@ __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
                     if (coord_in_grid(x, y, z, P))
                         q = PACKED ? interp_ft_packed(reinterpret_cast<const float4*>(vol), P, x, y, z) : interp_ft(vol, P, x, y, z);
                     accB = fmaf(sB[e], fmaf(q.x, q.x, q.y * q.y), accB);
-                    const float2* Ap = sA + e * NT;
+                    const float* Ap = sA + e * 2 * NT;
+                    const thx_v2f qx = {q.x, q.x}, qy = {q.y, q.y};
 #pragma unroll
-                    for (int t = 0; t < NT; t++) {
-                        const float2 A = Ap[t];
-                        acc[t] = fmaf(A.x, q.x, acc[t]);
-                        acc[t] = fmaf(-A.y, q.y, acc[t]);
+                    for (int i = 0; i < NT / 2; i++) {
+                        const float2 re = *reinterpret_cast<const float2*>(Ap + 4 * i), ni = *reinterpret_cast<const float2*>(Ap + 4 * i + 2);
+                        accP[i] = __builtin_elementwise_fma(thx_v2f{re.x, re.y}, qx, accP[i]);
+                        accP[i] = __builtin_elementwise_fma(thx_v2f{ni.x, ni.y}, qy, accP[i]);
+                    }
+                    if (NT & 1) {
+                        const float2 A = *reinterpret_cast<const float2*>(Ap + 2 * (NT - 1));
+                        accP[NT / 2].x = fmaf(A.x, q.x, accP[NT / 2].x);
+                        accP[NT / 2].x = fmaf(A.y, q.y, accP[NT / 2].x);
                     }
                 }
             }
@@ -392,7 +404,7 @@ __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
         const int slots = 64 * nRGp;
         const int slot = rg * 64 + lane;
 #pragma unroll
-        for (int t = 0; t < NT; t++) sAcc[(sub * (NT + 1) + t) * slots + slot] = acc[t];
+        for (int t = 0; t < NT; t++) sAcc[(sub * (NT + 1) + t) * slots + slot] = (t & 1) ? accP[t >> 1].y : accP[t >> 1].x;
         sAcc[(sub * (NT + 1) + NT) * slots + slot] = accB;
         __syncthreads();
         if (sub == 0 && rvalid) {
@@ -1144,7 +1156,7 @@ static int launch_expect_local(const ExpectLocalArgs& a, hipStream_t st, bool pa
     const int nRG0 = (a.nR + 63) >> 6;
     const int nRGp = nRG0 >= 4 ? 4 : (nRG0 >= 2 ? 2 : 1);
     const int nSub = 4 / nRGp;
-    size_t stage = (size_t)kChunk * NT * sizeof(float2) + kChunk * (sizeof(float) + 2 * sizeof(int)) + 4 * sizeof(float);
+    size_t stage = (size_t)kChunk * NT * sizeof(float2) + kChunk * (sizeof(float) + 2 * sizeof(double)) + 4 * sizeof(float);
     size_t red = (size_t)nSub * (NT + 1) * 64 * nRGp * sizeof(float);
     size_t lds = stage > red ? stage : red;
     {
