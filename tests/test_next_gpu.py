@@ -521,6 +521,23 @@ def test_classification_k4_multi_reference(oracle, dev):
     plan.close()
 
 
+def test_classification_iteration_bench_small(dev):
+    """`bench.py --classification` end to end on a small box (BASELINE config (3) in small, every step on its device kernel: scan
+    -> k_pf_class_select -> k_pf_scan_support -> local phases with volIdx -> multi-reference insertion session -> 2 reconstructions
+    per class): one JSON line with the per-stage times and both rooflines, all classes recovered, poses within a few degrees."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--classification", "--box", "64", "--scan-images", "96",
+                          "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["unit"] == "images/s" and d["value"] > 0 and d["n_gpus"] == 1 and d["dtype"] == "f32"
+    assert set(d["stages_ms_per_step"]) == {"scan", "class_select_and_support_points", "local_phases", "insertion", "reconstruct"}
+    assert d["rooflines"]["scan"]["bound"] == "mfma" and d["rooflines"]["local_phases"]["bound"] == "hbm"
+    assert d["config"]["classes_recovered"] >= 0.95 and d["config"]["median_pose_error_deg"] <= 8.0
+    assert d["balancing_rounds_per_step"] > 8 * 10
+
+
 def test_config0_demo3d_128_box_iterations(dev):
     """BASELINE config (0) on the GPU path: script/demo_3D.json's search sizes (mLR 125, mLT 9, mReco 100) on 1 000
     synthetic 128^3 particles, both half sets, two full EM iterations (rows, 3 particle-filter phases, sigma update,
