@@ -31,18 +31,29 @@ def qmul(a, b):
                         w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], -1)
 
 
-def run(name, r):
+def run(name, r, perm=None):
     rot = ops.rotmat(r.reshape(-1, 4).contiguous()).reshape(m, sh.mLR, 9)
+    dat, ctf, sig, tt, pR_, pT_ = sh.datP[lo:hi], sh.ctfP[lo:hi], sh.sigRcpP[lo:hi], t0, wR, wT
+    if perm is not None:
+        rot, dat, ctf, sig, tt, pR_, pT_ = [x[perm].contiguous() for x in (rot, dat, ctf, sig, tt, pR_, pT_)]
     best = 1e9
     for rep in range(3):
         torch.cuda.synchronize(); t_ = time.perf_counter()
-        ops.expect_local(sh.cells[0:1], sh.P, sh.pf, sh.N, sh.iCol, sh.iRow, sh.datP[lo:hi], sh.ctfP[lo:hi], sh.sigRcpP[lo:hi], rot, t0,
-                         pR=wR, pT=wT, workspace=sh.ws[0], packed=True, wg_per_cu=2)
+        ops.expect_local(sh.cells[0:1], sh.P, sh.pf, sh.N, sh.iCol, sh.iRow, dat, ctf, sig, rot, tt,
+                         pR=pR_, pT=pT_, workspace=sh.ws[0], packed=True, wg_per_cu=2)
         torch.cuda.synchronize(); best = min(best, time.perf_counter() - t_)
     print("%-58s %7.1f ms for %d images = %6.2f us per image-phase" % (name, best * 1e3, m, best / m * 1e6), flush=True)
 
 
 run("A  the filter's own clouds (view-ordered images)", r0)
+# E: the same images and clouds as A, stored so that the workgroups of ONE XCD (workgroup i -> XCD i mod 8, 64 resident per XCD at 2
+# per CU) are 64 view-neighbours: position 8 (64 q + r) + x holds image (8 q + x) 64 + r
+for blk in (64, 16):
+    if m % (8 * blk) == 0:
+        pos = torch.arange(m, device=dev)
+        x, j = pos % 8, pos // 8
+        src = ((j // blk) * 8 + x) * blk + (j % blk)
+        run("E  A's images, %d view-neighbours per XCD at a time" % blk, r0, perm=src)
 run("B  every image on image 0's cloud", r0[:1].expand(m, -1, -1).contiguous())
 run("C  groups of 8 consecutive images share a cloud", r0[::8].repeat_interleave(8, dim=0)[:m].contiguous())
 g = torch.Generator(device=dev); g.manual_seed(3)
