@@ -418,20 +418,14 @@ __global__ __launch_bounds__(64) void k_pf_update(PfArgs a)
 // the n^2 rank of resample<> above); the sorted pairs are then compacted in place to the indices, and the second half of the
 // same LDS holds the shuffled u for the one sequential pass the cumulative sum needs.
 // ---------------------------------------------------------------------------------------------
-template <int W>
-__device__ void resample_from_grid(double* outVal /*LDS [nOut][W]*/, double* outW /*LDS [nOut]*/, double* top /*global [W]*/,
-                                   const double* __restrict__ grid /*global [nIn][W]*/, const float* __restrict__ u /*global [nIn]*/,
-                                   double peakFactor, int nIn, int nOut, unsigned long long* pairs /*LDS [NP]*/, int NP, int lane,
-                                   unsigned long long seed, unsigned img, unsigned call, unsigned purpose)
+// gsl_ran_shuffle as a sort: pairs[i] = (Philox key of element i) << 32 | i, sorted ascending (ties by index); NT threads of
+// one workgroup (64: one wave, no workgroup barrier)
+template <int NT>
+__device__ void shuffle_sort(unsigned long long* pairs /*LDS [NP]*/, int NP, int nIn, int tid, unsigned long long seed, unsigned img,
+                             unsigned call, unsigned purpose)
 {
-    // keepHalfHeightPeak: hh = max(u) * peakFactor; u < hh -> 0, else u - hh   (:1964-2011)
-    double umax = -1.0;
-    for (int i = lane; i < nIn; i += 64) umax = fmax(umax, (double)u[i]);
-    for (int o = 32; o > 0; o >>= 1) umax = fmax(umax, __shfl_xor(umax, o, 64));
-    const double hh = peakFactor >= 0 ? umax * peakFactor : 0.0;
-    const bool peak = peakFactor >= 0;
-    // shuffle: sort by (random key, index)
-    for (int i = lane; i < NP; i += 64) {
+    auto bar = [] { if (NT > 64) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
+    for (int i = tid; i < NP; i += NT) {
         unsigned long long pr = ~0ull;
         if (i < nIn) {
             Philox g{(unsigned)seed, (unsigned)(seed >> 32)};
@@ -441,18 +435,31 @@ __device__ void resample_from_grid(double* outVal /*LDS [nOut][W]*/, double* out
         }
         pairs[i] = pr;
     }
-    __builtin_amdgcn_wave_barrier();
+    bar();
     for (int k = 2; k <= NP; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = lane; t < NP; t += 64) {
-                const int x = t ^ j;
-                if (x > t) {
-                    const unsigned long long a = pairs[t], b = pairs[x];
-                    if ((a > b) == ((t & k) == 0)) { pairs[t] = b; pairs[x] = a; }
-                }
+            for (int q = tid; q < NP / 2; q += NT) {   // the q-th compare-exchange of this pass: (t, t + j)
+                const int t = ((q & ~(j - 1)) << 1) | (q & (j - 1)), x = t + j;
+                const unsigned long long a = pairs[t], b = pairs[x];
+                if ((a > b) == ((t & k) == 0)) { pairs[t] = b; pairs[x] = a; }
             }
-            __builtin_amdgcn_wave_barrier();
+            bar();
         }
+}
+
+template <int W>
+__device__ void resample_from_grid(double* outVal /*LDS [nOut][W]*/, double* outW /*LDS [nOut]*/, double* top /*global [W]*/,
+                                   const double* __restrict__ grid /*global [nIn][W]*/, const float* __restrict__ u /*global [nIn]*/,
+                                   double peakFactor, int nIn, int nOut, unsigned long long* pairs /*LDS [NP]*/, int NP, int lane,
+                                   unsigned long long seed, unsigned img, unsigned call, unsigned purpose, bool presorted)
+{
+    // keepHalfHeightPeak: hh = max(u) * peakFactor; u < hh -> 0, else u - hh   (:1964-2011)
+    double umax = -1.0;
+    for (int i = lane; i < nIn; i += 64) umax = fmax(umax, (double)u[i]);
+    for (int o = 32; o > 0; o >>= 1) umax = fmax(umax, __shfl_xor(umax, o, 64));
+    const double hh = peakFactor >= 0 ? umax * peakFactor : 0.0;
+    const bool peak = peakFactor >= 0;
+    if (!presorted) shuffle_sort<64>(pairs, NP, nIn, lane, seed, img, call, purpose);
     // pairs -> indices (first half of the buffer), then the shuffled u behind them
     unsigned* idx = reinterpret_cast<unsigned*>(pairs);
     float* uv = reinterpret_cast<float*>(pairs) + NP;
@@ -538,15 +545,18 @@ struct ScanSupportArgs {
     unsigned call;
 };
 
-__global__ __launch_bounds__(64) void k_pf_scan_support(ScanSupportArgs a)
+constexpr int kScanSupThreads = 256;   // the 10 000-point shuffle is sorted by four waves; one wave does the rest
+__global__ __launch_bounds__(kScanSupThreads) void k_pf_scan_support(ScanSupportArgs a)
 {
     extern __shared__ unsigned long long pairs[];
     __shared__ double sq[kPfMax * 4], sw[kPfMax];
     const int img = blockIdx.x, lane = threadIdx.x;
     const size_t row = (size_t)(a.cls ? a.cls[img] : 0) * a.nImg + img;
     // ---- rotations ----
+    shuffle_sort<kScanSupThreads>(pairs, a.NPR, a.nRin, threadIdx.x, a.seed, (unsigned)img, a.call, 2);
+    if (threadIdx.x >= 64) return;   // (no workgroup barrier below this line)
     resample_from_grid<4>(sq, sw, a.topR + 4 * (size_t)img, a.gridR, a.uR + row * a.nRin, a.peakFactorR, a.nRin, a.mLR, pairs, a.NPR, lane,
-                          a.seed, (unsigned)img, a.call, 2);
+                          a.seed, (unsigned)img, a.call, 2, true);
     {   // calVari(PAR_R) on the new points, as in k_pf_update
         double A[16], mean[4], cm[4];
         infer_acg(A, sq, a.mLR, lane, nullptr);
@@ -571,7 +581,7 @@ __global__ __launch_bounds__(64) void k_pf_scan_support(ScanSupportArgs a)
     __builtin_amdgcn_wave_barrier();
     // ---- shifts ----
     resample_from_grid<2>(sq, sw, a.topT + 2 * (size_t)img, a.gridT, a.uT + row * a.nTin, -1.0, a.nTin, a.mLT, pairs, a.NPT, lane, a.seed,
-                          (unsigned)img, a.call, 4);
+                          (unsigned)img, a.call, 4, false);
     double m, s0, s1;
     col_mean_sd(m, s0, sq, 0, a.mLT, lane);
     col_mean_sd(m, s1, sq, 1, a.mLT, lane);
@@ -922,7 +932,7 @@ int thx_pf_scan_support_dev(double* r, double* t, double* wR, double* wT, double
     a.peakFactorR = peakFactorR; a.minK = minK; a.minS = minS; a.seed = seed; a.call = call;
     const size_t lds = (size_t)(a.NPR > a.NPT ? a.NPR : a.NPT) * sizeof(unsigned long long);
     THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pf_scan_support), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_pf_scan_support, dim3(nImg), dim3(64), lds, as_stream(stream), a);
+    hipLaunchKernelGGL(k_pf_scan_support, dim3(nImg), dim3(kScanSupThreads), lds, as_stream(stream), a);
     THX_LAUNCH_CHECK();
     return 0;
 }
