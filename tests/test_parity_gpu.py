@@ -398,6 +398,28 @@ def test_insert_sorted_special_paths(oracle, dev, knob_env):
         assert torch.equal(F, outs[0][0]) and torch.equal(Tt, outs[0][1])
 
 
+def test_insert_sorted_many_unrelated_groups(oracle, dev):
+    """160 draws per image, every one its own rotation anywhere on the sphere: 20 passes of k_bin per region, each touching tens of
+    bricks all over the volume -- the workgroup's descriptor list (2 048 entries) fills up and is flushed in the middle of its
+    passes.  Against the oracle."""
+    from thunder_amd import ops, synth
+    O = oracle
+    rng = np.random.default_rng(515)
+    N, nImg, mReco = 64, 2, 160
+    P = 2 * N
+    ref, vol, pl, im, quat, tran, offS, w, cls = _insert_case(O, N, nImg, mReco, rng)
+    quat = synth.random_quats(nImg * mReco, rng).reshape(nImg, mReco, 4)
+    tran = np.repeat(tran[:, :4], mReco // 4, axis=1)                  # 4 unique shifts per image: the register-ramp path
+    Fw, Tw, _ = _oracle_insert(O, P, N, pl, im, quat, tran, offS, w, np.zeros_like(cls), 1)
+    F = torch.zeros((P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
+    Tt = torch.zeros((P, P, P // 2 + 1), dtype=torch.float32, device=dev)
+    ops.insert(F, Tt, P, T(im["dat"], dev), T(im["ctf"], dev), T(w, dev), ops.rotmat(T(quat.reshape(-1, 4), dev)), T(tran, dev),
+               T(pl["iCol"], dev), T(pl["iRow"], dev), 2, N, offS=T(offS, dev))
+    assert np.abs(F.cpu().numpy() - Fw[0]).max() <= 1e-5 * np.abs(Fw).max()
+    assert np.abs(Tt.cpu().numpy() - Tw[0]).max() <= 1e-5 * np.abs(Tw).max()
+    np.testing.assert_allclose(Tt.sum(dtype=torch.float64).item(), Tw.sum(dtype=np.float64), rtol=1e-6)
+
+
 def test_insert_linearity_and_csearch(oracle, dev):
     """size-independent properties: insert(a)+insert(b) == insert(a and b); cSearch with dfac == 1 equals the
     precomputed-CTF path to rounding of the on-device CTF"""
