@@ -3,23 +3,25 @@
 // (insertP: value * ctf * w into F, ctf^2 * w into T), src/Image/Volume.cpp:565-712 (addFTHalf: trilinear scatter on the
 // half-Hermitian grid), include/Functions/Interpolation.h:152-200 (the eight weights).  gfx950 only.
 //
-// Why this shape.  The per-image window kernel (k_insert_win, thx_mstep.hip) keeps the IMAGE side coalesced and pays on the
-// VOLUME side: one (window, slab) step of one image holds ~900 samples between two barriers and one flush of a 48 KB brick,
-// and finding the samples of a window costs 2.5 float tests per hit -- 0.12 of the LDS-add rate, instruction-bound.  Here the
-// two sides are decoupled by a sort through HBM, 28 bytes per sample each way:
+// Why this shape.  The per-image window kernel of rounds 1 - 2 (k_insert_win, in this repository's history) kept the IMAGE side
+// coalesced and paid on the VOLUME side: one (window, slab) step of one image held ~900 samples between two barriers and one
+// flush of a 48 KB brick, and finding the samples of a window cost 2.5 float tests per hit -- 0.12 of the LDS-add rate,
+// instruction-bound.  Here the two sides are decoupled by a sort through HBM, 28 bytes per sample each way:
 //   k_bin  (image-major): one thread per listed pixel, all groups of the image's draws; every sample is computed ONCE at full
 //          lane occupancy -- exact position, cell, fractional offsets, value -- and written as a record into the segment of its
 //          brick.  A segment = the records one (256-pixel region, 8 groups) pass sends to one 16 x 16 x 8 brick of cell origins;
-//          the pass counts per brick in an LDS hash table (wave-aggregated), reserves its records with ONE global atomic,
-//          recomputes and scatters.
-//   sort   the segment descriptors (not the records) by brick: rocPRIM radix sort of ~1/140 of the record count.
+//          the pass counts per brick in an LDS hash table, lays its segments out from its STATIC place in the record buffer (no
+//          global atomic per pass: one returning atomic on one address per pass serialised the chip), recomputes and scatters;
+//          the descriptors collect in LDS and take table space with one atomic per workgroup.
+//   sort   the segment descriptors (not the records) by brick: rocPRIM radix sort of ~1/130 of the record count.
 //   k_acc  (brick-major): a workgroup takes ~16 k records of consecutive bricks, accumulates each brick's 17 x 17 x 9 voxels in
 //          LDS as 64-bit integers over ALL the images of the chunk, and flushes a brick once.
 // No window geometry, no shear, no candidate tests, no far-group special case: a sample's brick is a shift of its cell origin.
+// Bounds: k_acc the LDS atomic unit (24 ds_add_u64 per record), k_bin the HBM writes of the records.
 //
 // Arithmetic.  Every voxel term is rounded ONCE, to the session's 64-bit quanta (k_insert_scale: 2^-E_F, 2^-E_T):
 // re = rint((vre 2^E_F) wv), t = rint((tval 2^E_T) wv); a term whose T part rounds to zero is dropped whole (F and T travel
-// together: T = 0 under F != 0 lets the gridding weights explode).  That is the rule the window kernel applies to its
+// together: T = 0 under F != 0 lets the gridding weights explode).  That is the rule the window kernel applied to its
 // sub-quantum terms, here applied to all of them, so a term carries 7 more bits than a brick term of the window kernel did.
 // Integer sums commute: F and T are bit-identical from run to run, for any chunking, and across ranks.
 #include "thx_insert.h"
@@ -41,7 +43,7 @@ constexpr int kHash = kBinThreads * kPassGroups;                  // >= the dist
 constexpr int kRampU = 16;                                        // unique shifts whose ramps a thread keeps in registers
 constexpr int kAccThreads = 512;
 constexpr unsigned kAccSpan = 16384;                              // records per workgroup of k_acc
-constexpr int kAccStage = kAccThreads;                                    // segment descriptors staged in LDS at a time
+constexpr int kAccStage = kAccThreads;                             // segment descriptors staged in LDS at a time (one per thread)
 
 struct BinArgs {
     InsertArgs a;               // image-indexed pointers at the chunk's first image
