@@ -261,6 +261,34 @@ def test_expect_local_many_shifts(oracle, dev, nT):
         np.testing.assert_allclose(a.wT[l].cpu().numpy(), want["wT"].reshape(-1), rtol=2e-3)
 
 
+def test_insert_chunking_bit_identical_n256(dev, knob_env):
+    """the bench's box with the record buffer of the brick-sorted insertion cut to ~1 / 12 of what the 48 images need
+    (THX_INSERT_SCRATCH_MB=128: a dozen chunks, bricks flushed a dozen times) against the default (one chunk): F and T must be
+    bit for bit the same -- every term is rounded once to the session's quanta, whatever chunk it travels in"""
+    from thunder_amd import ops, synth
+    from thunder_amd.refine import pixel_list
+    rng = np.random.default_rng(78)
+    N, P, nImg, mReco = 256, 512, 48, 100
+    pl = pixel_list(N, N // 2 - 2, 0)
+    quat0 = synth.random_quats(nImg, rng)
+    quat, tran = _filter_draws(rng, synth, quat0, rng.normal(0, 2.0, size=(nImg, 2)), nImg, 125, 9, mReco, 0.03)
+    dat = T((rng.normal(size=(nImg, pl["nPxl"])) + 1j * rng.normal(size=(nImg, pl["nPxl"]))).astype(np.complex64), dev)
+    ctf = T(rng.uniform(-1, 1, size=(nImg, pl["nPxl"])).astype(np.float32), dev)
+    w = T((rng.uniform(0.2, 1.0, size=nImg) / mReco).astype(np.float32), dev)
+    rot = ops.rotmat(T(quat.reshape(-1, 4), dev)).reshape(nImg, mReco, 9)
+    trn, iCol, iRow = T(tran, dev), T(pl["iCol"], dev), T(pl["iRow"], dev)
+    outs = []
+    for mb in (None, "128"):
+        knob_env("THX_INSERT_SCRATCH_MB", mb)
+        F = torch.zeros((P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
+        Tt = torch.zeros((P, P, P // 2 + 1), dtype=torch.float32, device=dev)
+        ops.insert(F, Tt, P, dat, ctf, w, rot, trn, iCol, iRow, 2, N)
+        outs.append((F, Tt))
+    knob_env("THX_INSERT_SCRATCH_MB", None)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][1].sum(dtype=torch.float64)) > 0
+
+
 def test_insert_bit_reproducible_n256(dev):
     """the insertion accumulates in 64-bit fixed point end to end (LDS bricks AND the global volumes, thx_insert.h:acc_add), so
     F and T are bit-identical from run to run whatever the scheduling -- 96 images x 100 filter draws at the bench's box"""
