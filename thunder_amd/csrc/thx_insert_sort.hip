@@ -17,7 +17,8 @@
 //   k_acc  (brick-major): a workgroup takes ~16 k records of consecutive bricks, accumulates each brick's 17 x 17 x 9 voxels in
 //          LDS as 64-bit integers over ALL the images of the chunk, and flushes a brick once.
 // No window geometry, no shear, no candidate tests, no far-group special case: a sample's brick is a shift of its cell origin.
-// Bounds: k_acc the LDS atomic unit (24 ds_add_u64 per record), k_bin the HBM writes of the records.
+// Bounds: k_acc the LDS atomic unit (24 ds_add_u64 per record: 0.73 of its rate); k_bin writes its records at about
+// the write rate of HBM but is within 12 % of its time without the stores (instruction issue and LDS latency).
 //
 // Arithmetic.  Every voxel term is rounded ONCE, to the session's 64-bit quanta (k_insert_scale: 2^-E_F, 2^-E_T):
 // re = rint((vre 2^E_F) wv), t = rint((tval 2^E_T) wv); a term whose T part rounds to zero is dropped whole (F and T travel
