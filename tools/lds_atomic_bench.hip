@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256) void k_lds(float* out, int iters)
         int idx;
         if (PATTERN == 0) idx = (int)((h >> 8) % LDSN);                       // random
         else if (PATTERN == 1) idx = (int)(((it * 256 + tid) * 1) % LDSN);   // conflict-free, distinct
-        else idx = (int)(((h >> 8) % 64) * 192 + (tid & 63));                // random rows, lane = bank (conflict-free)
+        else if (PATTERN == 2) idx = (int)(((h >> 8) % 64) * 192 + (tid & 63));   // random rows, lane = bank (conflict-free)
+        else idx = (int)(2 * ((it * 256 + tid) % (LDSN / 2)));                // distinct consecutive 8-byte slots (for MODE 4)
         const float v = (float)(it & 7) * 0.125f + 1.0f;
         if (MODE == 0) atomicAdd(&s[idx], v);                                        // ds_add_f32
         else if (MODE == 1) atomicAdd(reinterpret_cast<unsigned*>(s) + idx, (unsigned)(it + 1));  // ds_add_u32
@@ -70,6 +71,7 @@ int main()
     run<1, 0>("ds_add_u32 random", out);
     run<1, 1>("ds_add_u32 linear", out);
     run<4, 0>("ds_add_u64 random", out);
+    run<4, 3>("ds_add_u64 linear (conflict-free)", out);
     run<2, 0>("read-add-write random (non-atomic)", out);
     run<2, 1>("read-add-write linear (non-atomic)", out);
     run<3, 0>("ds_write_b32 random", out);
