@@ -379,7 +379,7 @@ def bench_classification_iteration(args, dev):
                     ops.pf_perturb(st["r"][sl], st["t"][sl], st["wR"][sl], st["wT"][sl], st["k"][sl], st["s"][sl], f, f, 2.0, 0.05, seed, state["call"])
                     rotB = ops.rotmat(st["r"][sl].reshape(-1, 4)).reshape(b1 - b0, mLR, 9)
                     r = timed_call("local", timed, lambda: ops.expect_local(cells, P, pf, N, iColE, iRowE, datE[sl], ctfE[sl], sigE[sl], rotB, st["t"][sl],
-                                                                            volIdx=cls[sl], pR=st["wR"][sl], pT=st["wT"][sl], workspace=wsL, packed=True, wg_per_cu=2), b1 - b0)
+                                                                            volIdx=cls[sl], pR=st["wR"][sl], pT=st["wT"][sl], workspace=wsL, packed=True, wg_per_cu=args.wg_per_cu), b1 - b0)
                     state["call"] += 1
                     ops.pf_update(st["r"][sl], st["t"][sl], st["wR"][sl], st["wT"][sl], r.wR, r.wT, st["k"][sl], st["s"][sl], st["topR"][sl], st["topT"][sl],
                                   1e-3, seed, state["call"])
@@ -535,6 +535,7 @@ def main():
     ap.add_argument("--classification", action="store_true",
                     help="one whole K = 4 classification iteration of configs[3] on one GPU's share of the images instead "
                          "(scan, class selection, local phases, multi-reference insertion, reconstructions)")
+    ap.add_argument("--wg-per-cu", type=int, default=2, help="with --classification: occupancy argument of thx_expect_local_dev (workgroups per CU; 0 = unlimited)")
     ap.add_argument("--scan-only", action="store_true", help="with --classification: the global scanning stage on its own")
     ap.add_argument("--scan-images", type=int, default=0, help="images of the classification bench (default 6250 = 50 000 / 8 GPUs; 1024 with --scan-only)")
     ap.add_argument("--scan-cpu-images-per-core", type=int, default=2)
