@@ -299,6 +299,21 @@ int thx_translate_image_dev(float* dst, const float* src, const double* trans, i
 int thx_translate_volume_dev(float* dst, const float* src, int dim, float r, double ox, double oy, double oz,
                              void* stream);
 
+/* Optimiser::normCorrection, src/Optimiser.cpp:6201-6394 (called at the head of Optimiser::maximization from the second
+ * iteration on, :3405-3413), as include/Config.h configures it (OPTIMISER_NORM_MASK, _CTF_ON_THE_FLY):
+ *   thx_norm_residual_dev: norm [nImg] = sum over rL^2 <= i^2 + j^2 < rNorm^2 of |img - ctf . P . ramp(t)|^2 with P the top pose's
+ *     slice inside projR = Projector::_maxRadius (img = the MASKED stack _img; rotMat [nImg][9], trans [nImg][2]);
+ *     rNorm = min(_r, Model::resolutionP(0.75)) is the caller's (src/Functions/Spectrum.cpp:339-363 on the previous FSC);
+ *   thx_median_f32_dev: out (device, 1 float) = median(values, n) as gsl_stats_quantile_from_sorted_data(.., 0.5) -- over the norms
+ *     of ALL particles of the job (the reference all-reduces the vector over MPI_COMM_WORLD first);
+ *   thx_norm_scale_dev: img[l] *= sqrt(median / norm[l]), imgOri[l] *= the same, in place ([nImg][idim][idim/2+1] complex64).
+ * All device pointers. */
+int thx_norm_residual_dev(float* norm, const float* volumes, const int* volIdx, int vdim, int pf, int idim, int projR, float rL,
+                          float rNorm, const float* img, const thx_ctf_attr* attr, const double* dfac, float pixelSize,
+                          const double* rotMat, const double* trans, int nImg, void* stream);
+int thx_median_f32_dev(float* out, const float* values, int n, void* stream);
+int thx_norm_scale_dev(float* img, float* imgOri, const float* norm, const float* median, int idim, int nImg, void* stream);
+
 /* Per-image part of Optimiser::allReduceSigma, src/Optimiser.cpp:6443-6565, as include/Config.h configures it
  * (OPTIMISER_SIGMA_RANK1ST, _SIGMA_WHOLE_FREQUENCY, _RECENTRE_IMAGE_EACH_ITERATION, _CTF_ON_THE_FLY; w = 1):
  * with P = the top pose's slice (radius projR = Projector::_maxRadius), spec [nImg][4][rSig] receives the shell

@@ -472,6 +472,29 @@ def sigma_image(vol, P, pf, N, projR, rSig, rot, tran, offset, pixelSize, attr, 
     return out
 
 
+def norm_residual(vol, P, pf, N, projR, rL, rNorm, rot, tran, pixelSize, attr, img):
+    """Per-image part of Optimiser::normCorrection (src/Optimiser.cpp:6201-6358): norm(_ID[l]) of the masked image `img` against
+    the top pose's CTF-modulated slice, summed over rL^2 <= i^2 + j^2 < rNorm^2."""
+    vol, img = c64(vol), c64(img)
+    rot, tran = f64(rot), f64(tran)
+    lib().orc_norm_residual.restype = C.c_float
+    return float(lib().orc_norm_residual(_p(vol, c_f), C.c_int(P), C.c_int(pf), C.c_int(N), C.c_int(projR), C.c_float(rL), C.c_float(rNorm),
+                                         _p(rot, c_d), _p(tran, c_d), C.c_float(pixelSize), *[C.c_float(a) for a in attr], _p(img, c_f)))
+
+
+def median(values):
+    """median(vec, n), src/Functions/Functions.cpp:246-252"""
+    v = f32(values)
+    lib().orc_median.restype = C.c_float
+    return float(lib().orc_median(_p(v, c_f), C.c_int(len(v))))
+
+
+def norm_scale(img, imgOri, norm, m):
+    """the closing loop of normCorrection (:6380-6392): both stacks of image l times sqrt(m / norm(l)) (RFLOAT)"""
+    f = np.sqrt(np.float32(m) / f32(norm)).astype(np.float32)
+    return (c64(img) * f[:, None, None]).astype(np.complex64), (c64(imgOri) * f[:, None, None]).astype(np.complex64)
+
+
 def sigma_accum(spec, groupID, nGroup, group=True):
     """Group accumulation of allReduceSigma (src/Optimiser.cpp:6567-6597); groupID 1-based.
     Returns sigM, sigN, svd as float32 [nGroup][rSig+1]."""

