@@ -3,7 +3,8 @@
 
 One "step" = one full iteration over the HBM-resident synthetic particles:
   row gathers from the masked image stack, nPhase particle-filter phases (mLR rotations x mLT shifts each, perturb /
-  resample on the device), sigma update, mReco insertions per particle, half-set reduce (RCCL when a half spans more
+  resample on the device), noise normalisation of the image stacks (Optimiser::normCorrection, from the second iteration on), sigma
+  update, mReco insertions per particle, half-set reduce (RCCL when a half spans more
   than one rank), prepareTF, reconstruct (MAP off) -> FSC -> reconstruct (MAP on), projector refresh, re-centring and
   re-masking (rocFFT 2-D) of the particle images.
 Workload = the configuration BASELINE.json's metric is quoted on: 100 000 synthetic 256^3 particles, 3-D refinement.
@@ -530,6 +531,8 @@ def main():
     ap.add_argument("--cpu-no-reconstruct", action="store_true")
     ap.add_argument("--cpu-groups", type=int, default=16, help="CPU baseline: thread groups with private F / T (MPI ranks of the reference)")
     ap.add_argument("--cpu-shared", action="store_true", help="CPU baseline: also time the single-team form (one shared F / T)")
+    ap.add_argument("--no-norm-correction", action="store_true",
+                    help="leave Optimiser::normCorrection (OPTIMISER_NORM_CORRECTION, on in the reference's Config.h) out of the iteration")
     ap.add_argument("--unsorted", action="store_true",
                     help="keep the particles in random order (default: stored by view direction, thx_view_order_host)")
     ap.add_argument("--classification", action="store_true",
@@ -587,7 +590,7 @@ def main():
     hemi = wcomm = None
     if world > 1:
         hemi, wcomm = make_comms(rank, world, share_from)
-    nat = NativeRefine(shard, hemi, wcomm)
+    nat = NativeRefine(shard, hemi, wcomm, norm_correction=not args.no_norm_correction)
 
     def barrier():
         if world > 1:
@@ -666,9 +669,9 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%d synthetic %d^3 particles, 3D refinement iteration on %d GPU(s) (local search %d "
-                                   "phases x %d rot x %d shifts, %d inserts, 2 half-sets, 2x reconstruct per half, FSC, "
+                                   "phases x %d rot x %d shifts, normCorrection%s, %d inserts, 2 half-sets, 2x reconstruct per half, FSC, "
                                    "projector refresh)" % (args.particles, args.box, world, args.phases, args.mLR,
-                                                           args.mLT, args.mReco),
+                                                           args.mLT, " off" if args.no_norm_correction else "", args.mReco),
                        "box": args.box, "particles": args.particles, "particles_per_gpu": n_local, "nPxl": nPxl,
                        "hbm_in_use_GB": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9, 1),
                        "pf": 2,

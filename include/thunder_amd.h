@@ -594,6 +594,11 @@ typedef struct thx_refine_config {
                                   after the MAP reconstruction (_goldenStandard, k == 1: src/Model.cpp:616-674) */
     int solventFlatten;        /* != 0: Optimiser::solventFlatten's spherical soft mask (maskRadius / pixelSize, EDGE_WIDTH_RL,
                                   background 0; src/Optimiser.cpp:7768-7990, no provided mask) before the projector refresh */
+    int normCorrection;        /* != 0: Optimiser::normCorrection (OPTIMISER_NORM_CORRECTION, src/Optimiser.cpp:3405-3413,6201-6394) at
+                                  the head of the M-step of every iteration but the first: both image stacks -- the driver's _img and
+                                  the caller's _imgOri, IN PLACE -- are rescaled image by image to the median residual power over
+                                  ALL particles (one all-reduce of the norm vector over `world`); the expectations of all local halves
+                                  then run before the first M-step (the Philox call sequence differs from normCorrection == 0) */
 } thx_refine_config;
 
 /* optional per-phase trace of the local search (tests hold the chain against the oracle with it): DEVICE buffers, any may
@@ -614,13 +619,15 @@ typedef struct thx_refine_capture {
 typedef struct thx_refine_stats {
     double expectMs, insertMs;            /* HIP-event totals of the local-search / insertion launches (timed iterations) */
     long expectLaunches, expectImages, insertLaunches, insertImages;
-    double stageMs[8];                    /* rows, expectation, sigma, insertion, reconstruct (+FSC, refresh), recentre+remask */
+    double stageMs[8];                    /* rows, expectation, sigma, insertion, reconstruct (+FSC, refresh), recentre+remask,
+                                             normCorrection */
     long balancingRounds, iterations;
     long imagePhases;                     /* sum over images of the phases they ran (Optimiser::_nF) */
     int nPxl, nPxlM, batch;
     unsigned long long insertGroups;      /* (image, group) pairs the insertion launches of the timed iterations processed */
     int lastRounds[4];                    /* balancing rounds of the last iteration's reconstructions: MAP off, local halves 0 / 1;
                                              MAP on, local halves 0 / 1 (0 where this rank holds no such half) */
+    float normMedian, normRadius;         /* normCorrection of the last iteration: the median of the norms and rNorm (0 when it did not run) */
 } thx_refine_stats;
 
 /* hemi: communicator of this rank's half (NULL = the half lives on this rank alone); world: all ranks (NULL = one rank) */
@@ -664,6 +671,7 @@ typedef struct thx_refine_view {
     const float *sig;                       /* [nVol][nGroup][rSig] */
     const double *recoRot, *recoTran;       /* draws of the LAST inserted local half [n][mReco][9] / [n][mReco][2] */
     const int *nP;                          /* [nImg] phase index at which the stop rule ended the image's search (maxPhase > nPhase) */
+    const float *norm;                      /* [nImg] normCorrection's norms of the last iteration that ran it */
 } thx_refine_view;
 int thx_refine_get_view(thx_refine* h, thx_refine_view* out);
 

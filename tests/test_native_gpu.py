@@ -335,3 +335,40 @@ def test_release_stream_evicts_scratch_and_plans(dev):
         del s
     capi.call("thx_release_stream", capi.stream_ptr())     # releasing the default stream's caches is harmless: they are rebuilt
     assert torch.equal(ops.fft3d_fw(rl), want_ft)
+
+def test_native_norm_correction(dev):
+    """Optimiser::normCorrection inside the native iteration (thx_refine_config.normCorrection): nothing in the first iteration; in
+    the second the caller's _imgOri stack and the driver's _img are multiplied image by image by sqrt(median / norm_l) -- checked
+    bit for bit from the norms the driver exposes -- with rNorm = min(rU, resP(previous FSC, 0.75)), and the refinement still
+    converges.  (The kernels have their own oracle parity test, tests/test_next_gpu.py::test_norm_correction.)"""
+    from thunder_amd.native import NativeRefine
+    from thunder_amd.refine import RefineShard
+    N, n = 64, 96
+    sh = RefineShard(N, n, dev, mLR=40, mLT=5, nPhase=2, mReco=16, batch=64, particle_filter=True, allocate=False, snr=0.5)
+    nat = NativeRefine(sh, norm_correction=True)
+    nat.reset()
+    ori0 = sh.imgOri.clone()
+    fsc1 = nat.iterate()
+    st = nat.stats()
+    assert st.normMedian == 0.0 and torch.equal(sh.imgOri, ori0)            # (_iter != 0)
+    fsc2 = nat.iterate()
+    st = nat.stats()
+    v = nat.view()
+    norm = nat.fetch(v.norm, np.float32, (n,))
+    assert norm.min() > 0 and st.normMedian > 0
+    # resP(fsc, 0.75, 1, 1, false) on the FSC of the first iteration, capped at rU = N / 2 - 2
+    res = 1
+    while res < N // 2 - 2 and fsc1[res] >= 0.75:
+        res += 1
+    assert st.normRadius == min(N // 2 - 2, res - 1)
+    srt = np.sort(norm)
+    idx = 0.5 * (n - 1)
+    lhs = int(idx)
+    med = np.float32((1 - (idx - lhs)) * np.float64(srt[lhs]) + (idx - lhs) * np.float64(srt[lhs + 1]))
+    assert np.float32(st.normMedian) == med
+    f = np.sqrt(med / norm).astype(np.float32)
+    want = (ori0.cpu().numpy() * f[:, None, None]).astype(np.complex64)
+    assert np.array_equal(sh.imgOri.cpu().numpy(), want)
+    assert 0.2 < f.min() and f.max() < 5.0
+    assert np.all(np.isfinite(fsc2)) and fsc2[1] >= 0.95 and fsc2[2] >= 0.9      # (96 noisy particles: the half maps agree to shell 3)
+    nat.close()

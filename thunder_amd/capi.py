@@ -31,7 +31,7 @@ class RefineConfig(C.Structure):
                 ("pixelSize", C.c_float), ("maskRadiusPx", C.c_float), ("sigma2Init", C.c_float),
                 ("transS", C.c_double), ("transQ", C.c_double), ("pfL", C.c_double), ("pfS", C.c_double),
                 ("peakFactorR", C.c_double), ("seed", C.c_ulonglong),
-                ("coreFSC", C.c_int), ("goldenAverage", C.c_int), ("solventFlatten", C.c_int)]
+                ("coreFSC", C.c_int), ("goldenAverage", C.c_int), ("solventFlatten", C.c_int), ("normCorrection", C.c_int)]
 
 
 class RefineCapture(C.Structure):
@@ -45,7 +45,8 @@ class RefineStats(C.Structure):
                 ("insertLaunches", C.c_long), ("insertImages", C.c_long), ("stageMs", C.c_double * 8),
                 ("balancingRounds", C.c_long), ("iterations", C.c_long), ("imagePhases", C.c_long), ("nPxl", C.c_int),
                 ("nPxlM", C.c_int),
-                ("batch", C.c_int), ("insertGroups", C.c_ulonglong), ("lastRounds", C.c_int * 4)]
+                ("batch", C.c_int), ("insertGroups", C.c_ulonglong), ("lastRounds", C.c_int * 4), ("normMedian", C.c_float),
+                ("normRadius", C.c_float)]
 
 
 class RefineView(C.Structure):
@@ -53,7 +54,7 @@ class RefineView(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("nImg", "nPxl", "nPxlM", "nVol", "vdim", "rSig")] + \
                [(n, C.c_void_p) for n in ("iCol", "iRow", "iPxl", "iSig", "iColM", "iRowM", "img", "datP", "ctfP", "sigRcpP",
                                           "datM", "ctfM", "r", "t", "wR", "wT", "offset", "vols", "cells", "F", "T", "sig",
-                                          "recoRot", "recoTran", "nP")]
+                                          "recoRot", "recoTran", "nP", "norm")]
 
 
 _vp = C.c_void_p

@@ -241,6 +241,10 @@ struct thx_refine {
     double stageMs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long recoRounds = 0, iterations = 0;
     int lastRounds[4] = {0, 0, 0, 0};
+    float* norm = nullptr;       // [nImg] normCorrection: the local norms; normAll [world total] + the median behind it
+    float* normAll = nullptr;
+    long nImgWorld = 0, worldOffset = 0;   // particles of the whole job; of the ranks before this one
+    float lastNormMedian = 0.f, lastNormRadius = 0.f;
 };
 
 namespace {
@@ -268,7 +272,7 @@ int upload(thx_refine* h, T** p, const std::vector<T>& v)
 }
 
 enum { EV_EXPECT = 0, EV_INSERT = 1, EV_STAGE0 = 8 };   // stages: rows, expectation, sigma, insertion, reconstruct, recentre
-enum { ST_ROWS = 0, ST_EXPECT, ST_SIGMA, ST_INSERT, ST_RECO, ST_RECENTRE, ST_COUNT };
+enum { ST_ROWS = 0, ST_EXPECT, ST_SIGMA, ST_INSERT, ST_RECO, ST_RECENTRE, ST_NORM, ST_COUNT };
 
 struct Scope {
     thx_refine* h; hipStream_t st; int kind, images; hipEvent_t a{}, b{}; bool on;
@@ -410,6 +414,51 @@ int sigma_update(thx_refine* h, int vi, hipStream_t st)
     THX_RC(thx_sigma_final_dev(h->sig + (size_t)vi * c.nGroup * h->rSig, h->sigRcp + (size_t)vi * c.nGroup * h->rSig, h->acc,
                                h->acc + tab, h->acc + 2 * tab, c.nGroup, h->rSig, c.groupSig, c.maskRadiusPx * c.pixelSize, h->N,
                                c.pixelSize, st));
+    return 0;
+}
+
+// Optimiser::normCorrection (src/Optimiser.cpp:6201-6394) at the head of Optimiser::maximization (:3405-3413): the residual power
+// of every image against its top pose's slice over rL <= r < rNorm, the median over ALL particles of the job, both stacks
+// rescaled in place; then the rows and bounds that were cut from _imgOri are cut again.
+int norm_correction(thx_refine* h, hipStream_t st)
+{
+    const thx_refine_config& c = h->cfg;
+    const size_t imgSize = (size_t)h->N * h->nc * 2;
+    const size_t volStride = (size_t)h->P * h->P * (h->P / 2 + 1) * 2;
+    // rNorm = min(_r, _model.resolutionP(0.75, false)): resP(_FSC, 0.75, 1, 1, false), src/Functions/Spectrum.cpp:339-363, on the
+    // FSC the previous iteration left in the model
+    int res = 1;
+    for (; res < (int)h->fscReco.size(); res++)
+        if (h->fscReco[res] < 0.75f) break;
+    res--;
+    const float rNorm = std::min((float)h->rU, (float)res);
+    for (int vi = 0; vi < h->nV; vi++) {
+        const int lo = h->lo[vi], n = h->hi[vi] - lo;
+        if (n <= 0) continue;
+        THX_RC(thx_rotmat_dev(h->topR + (size_t)lo * 4, h->rotTop, n, st));
+        THX_RC(thx_norm_residual_dev(h->norm + lo, h->vols + (size_t)vi * volStride, nullptr, h->P, h->pf, h->N, h->rU, (float)c.rL, rNorm,
+                                     h->img + (size_t)lo * imgSize, h->attr + lo, nullptr, c.pixelSize, h->rotTop, h->topT + (size_t)lo * 2,
+                                     n, st));
+    }
+    // norm of every particle of the job on every rank: each rank's norms at its offset of a zeroed vector, summed over world
+    // (MPI_Allreduce(MPI_IN_PLACE, norm.data(), norm.size(), .., MPI_SUM, MPI_COMM_WORLD), :6362-6367)
+    const float* all = h->norm;
+    long nAll = h->nImg;
+    if (h->world && thx_comm_size(h->world) > 1) {
+        THX_CHECK(hipMemsetAsync(h->normAll, 0, (size_t)h->nImgWorld * sizeof(float), st));
+        THX_CHECK(hipMemcpyAsync(h->normAll + h->worldOffset, h->norm, (size_t)h->nImg * sizeof(float), hipMemcpyDeviceToDevice, st));
+        THX_RC(thx_comm_allreduce_f32(h->world, h->normAll, (size_t)h->nImgWorld, st));
+        all = h->normAll;
+        nAll = h->nImgWorld;
+    }
+    float* med = h->normAll + h->nImgWorld;
+    THX_RC(thx_median_f32_dev(med, all, (int)nAll, st));
+    THX_RC(thx_norm_scale_dev(h->img, const_cast<float*>(h->imgOri), h->norm, med, h->N, h->nImg, st));
+    THX_RC(thx_gather_pixels_dev(h->datM, h->imgOri, h->iPxlM, h->nPxlM, h->N, h->nImg, st));
+    THX_RC(thx_insert_bounds_dev(h->bounds, h->datM, h->ctfM, h->nPxlM, h->nImg, st));
+    THX_CHECK(hipMemcpyAsync(&h->lastNormMedian, med, sizeof(float), hipMemcpyDeviceToHost, st));
+    THX_CHECK(hipStreamSynchronize(st));
+    h->lastNormRadius = rNorm;
     return 0;
 }
 
@@ -653,6 +702,24 @@ int thx_refine_set_particles(thx_refine* h, const float* imgOri, const thx_ctf_a
         THX_CHECK(hipStreamSynchronize(st));
         h->nImgHemi = (long)tot;
     }
+    if (c.normCorrection && !h->norm) {   // normCorrection's median runs over the norms of every rank's particles
+        const int ws = h->world ? thx_comm_size(h->world) : 1, wr = h->world ? thx_comm_rank(h->world) : 0;
+        std::vector<int> cnt(ws, 0);
+        cnt[wr] = h->nImg;
+        if (ws > 1) {
+            int* d = reinterpret_cast<int*>(scratch(st, 7, (size_t)ws * sizeof(int)));
+            THX_REQUIRE(d, "device scratch allocation failed");
+            THX_CHECK(hipMemcpyAsync(d, cnt.data(), (size_t)ws * sizeof(int), hipMemcpyHostToDevice, st));
+            THX_CHECK(hipStreamSynchronize(st));
+            THX_RC(thx_comm_allreduce_i32(h->world, d, (size_t)ws, st));
+            THX_CHECK(hipMemcpyAsync(cnt.data(), d, (size_t)ws * sizeof(int), hipMemcpyDeviceToHost, st));
+            THX_CHECK(hipStreamSynchronize(st));
+        }
+        h->nImgWorld = 0; h->worldOffset = 0;
+        for (int r = 0; r < ws; r++) { if (r < wr) h->worldOffset += cnt[r]; h->nImgWorld += cnt[r]; }
+        THX_RC(dalloc(h, &h->norm, (size_t)h->nImg));
+        THX_RC(dalloc(h, &h->normAll, (size_t)h->nImgWorld + 1));
+    }
     THX_CHECK(hipStreamSynchronize(st));   // g0 is a host temporary
     return 0;
 }
@@ -709,9 +776,22 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
     const size_t imgSize = (size_t)h->N * h->nc * 2;
     h->timed = timed != 0;
     // ---- E and M per local half: rows -> expectation -> sigma update -> draws + insertion ----
+    // With normCorrection the M-step starts with a statistic over ALL particles (src/Optimiser.cpp:3405-3413), so every local
+    // half's expectation runs first; without it each half goes through E and M in turn (the order the chain tests replay).
+    const bool normOn = c.normCorrection != 0;
+    h->lastNormMedian = 0.f; h->lastNormRadius = 0.f;
+    if (normOn) {
+        for (int vi = 0; vi < h->nV; vi++) {
+            { Scope s(h, st, EV_STAGE0 + ST_ROWS); THX_RC(refresh_rows(h, vi, st)); }
+            { Scope s(h, st, EV_STAGE0 + ST_EXPECT); THX_RC(expectation(h, vi, st)); }
+        }
+        if (h->iterCount != 0) { Scope s(h, st, EV_STAGE0 + ST_NORM); THX_RC(norm_correction(h, st)); }   // (_iter != 0)
+    }
     for (int vi = 0; vi < h->nV; vi++) {
-        { Scope s(h, st, EV_STAGE0 + ST_ROWS); THX_RC(refresh_rows(h, vi, st)); }
-        { Scope s(h, st, EV_STAGE0 + ST_EXPECT); THX_RC(expectation(h, vi, st)); }
+        if (!normOn) {
+            { Scope s(h, st, EV_STAGE0 + ST_ROWS); THX_RC(refresh_rows(h, vi, st)); }
+            { Scope s(h, st, EV_STAGE0 + ST_EXPECT); THX_RC(expectation(h, vi, st)); }
+        }
         { Scope s(h, st, EV_STAGE0 + ST_SIGMA); THX_RC(sigma_update(h, vi, st)); }
         { Scope s(h, st, EV_STAGE0 + ST_INSERT); THX_RC(insertion(h, vi, st)); }
         if (h->cap.Fraw) THX_CHECK(hipMemcpyAsync(h->cap.Fraw + (size_t)vi * volN * 2, h->F + (size_t)vi * volN * 2, volN * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -844,6 +924,7 @@ int thx_refine_get_view(thx_refine* h, thx_refine_view* v)
     v->vols = h->vols; v->cells = h->cells; v->F = h->F; v->T = h->T; v->sig = h->sig;
     v->recoRot = h->recoRot; v->recoTran = h->recoTran;
     v->nP = h->nP;
+    v->norm = h->norm;
     return 0;
 }
 
@@ -859,6 +940,7 @@ int thx_refine_get_stats(thx_refine* h, thx_refine_stats* out, int reset)
     out->imagePhases = h->imagePhases;
     out->nPxl = h->nPxl; out->nPxlM = h->nPxlM; out->batch = h->batch;
     for (int i = 0; i < 4; i++) out->lastRounds[i] = h->lastRounds[i];
+    out->normMedian = h->lastNormMedian; out->normRadius = h->lastNormRadius;
     {
         unsigned long long g = 0;
         THX_RC(thx_insert_groups_total(&g, reset, nullptr));   // cumulative on the device since the last reset

@@ -12,7 +12,7 @@ import torch
 from . import capi
 from .capi import RefineConfig, RefineStats, RefineView, ptr, stream_ptr
 
-STAGES = ("rows", "expectation", "sigma", "insertion", "reconstruct", "recentre_remask")
+STAGES = ("rows", "expectation", "sigma", "insertion", "reconstruct", "recentre_remask", "norm_correction")
 
 
 class Comm:
@@ -88,7 +88,7 @@ def make_comms(rank, world, share_from):
 class NativeRefine:
     """thx_refine handle over the particles of a RefineShard (which only has to have GENERATED them: allocate=False)."""
 
-    def __init__(self, shard, hemi=None, world=None, pixel_order=1, max_phase=0):
+    def __init__(self, shard, hemi=None, world=None, pixel_order=1, max_phase=0, norm_correction=False):
         self.shard = shard
         s = shard
         cfg = RefineConfig()
@@ -105,6 +105,7 @@ class NativeRefine:
         cfg.transS, cfg.transQ, cfg.pfL, cfg.pfS, cfg.peakFactorR = s.transS, s.transQ, s.pfL, s.pfS, s.peakFactorR
         cfg.seed = s.pf_seed
         cfg.coreFSC, cfg.goldenAverage, cfg.solventFlatten = int(s.coreFSC), int(s.goldenAverage), int(s.solventFlatten)
+        cfg.normCorrection = 1 if norm_correction else 0   # Optimiser::normCorrection: rescales shard.imgOri IN PLACE from iteration 2 on
         assert s.use_pf, "the native driver runs the device particle filter"
         self.cfg = cfg
         h = C.c_void_p()
