@@ -110,6 +110,43 @@ def test_sigma_image_invariants(oracle):
     assert np.allclose(spec[3][2:projR - 1], 1.21 * spec[2][2:projR - 1], rtol=1e-3)
 
 
+def test_norm_correction_oracle(oracle):
+    """the oracle's restatement of Optimiser::normCorrection (src/Optimiser.cpp:6201-6394): a noise-free image has no residual;
+    the norm over the ring is the sum of the residual shell spectra times their pixel counts; the median is GSL's; after the
+    rescaling every image's norm is the median (to rounding)"""
+    O = oracle
+    rng = np.random.default_rng(8)
+    N, P, projR, rL, rNorm = 32, 64, 13, 2.0, 10.0
+    _, vol, _ = make_case(O, N)
+    im = full_images(O, vol, N, 6, rng, projR)
+    dl = O.disc_list(N, projR)
+    clean = np.zeros((N, N // 2 + 1), np.complex64)
+    s = O.project(vol, P, 2, im["rot"][0], dl["iCol"], dl["iRow"])
+    clean.reshape(-1)[dl["iPxl"]] = (s * O.translate(im["tran"][0, 0], im["tran"][0, 1], N, dl["iCol"], dl["iRow"])) * \
+        O.ctf(im["pixelSize"], *im["attr"][0], N, dl["iCol"], dl["iRow"])
+    ref_power = O.norm_residual(vol, P, 2, N, projR, rL, rNorm, im["rot"][0], im["tran"][0], im["pixelSize"], im["attr"][0], 0 * clean)
+    assert O.norm_residual(vol, P, 2, N, projR, rL, rNorm, im["rot"][0], im["tran"][0], im["pixelSize"], im["attr"][0], clean) <= 1e-9 * ref_power
+    norm = np.array([O.norm_residual(vol, P, 2, N, projR, rL, rNorm, im["rot"][l], im["tran"][l], im["pixelSize"], im["attr"][l],
+                                     im["img"][l]) for l in range(6)], np.float32)
+    # direct numpy restatement on image 1: |img - model|^2 over rL^2 <= i^2 + j^2 < rNorm^2
+    l = 1
+    model = np.zeros((N, N // 2 + 1), np.complex64)
+    sl = O.project(vol, P, 2, im["rot"][l], dl["iCol"], dl["iRow"])
+    model.reshape(-1)[dl["iPxl"]] = (sl * O.translate(im["tran"][l, 0], im["tran"][l, 1], N, dl["iCol"], dl["iRow"])) * \
+        O.ctf(im["pixelSize"], *im["attr"][l], N, dl["iCol"], dl["iRow"])
+    jj = np.fft.fftfreq(N, 1.0 / N)[:, None]
+    ii = np.arange(N // 2 + 1)[None, :]
+    ring = (ii * ii + jj * jj >= rL * rL) & (ii * ii + jj * jj < rNorm * rNorm)
+    assert np.isclose(norm[l], (np.abs(im["img"][l] - model) ** 2)[ring].sum(dtype=np.float64), rtol=1e-5)
+    # the median: even and odd counts against numpy (linear interpolation at 0.5 (n - 1))
+    for n in (6, 5, 1):
+        assert np.isclose(O.median(norm[:n]), np.quantile(norm[:n].astype(np.float64), 0.5), rtol=1e-7)
+    m = O.median(norm)
+    img2, ori2 = O.norm_scale(im["img"], im["imgOri"], norm, m)
+    assert np.allclose(np.abs(img2[3]) ** 2, np.abs(im["img"][3]) ** 2 * (m / norm[3]), rtol=1e-5)
+    assert np.array_equal(img2[2] == 0, im["img"][2] == 0) and ori2.dtype == np.complex64
+
+
 def test_sigma_accum_final(oracle):
     O = oracle
     rng = np.random.default_rng(8)
