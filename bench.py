@@ -277,7 +277,8 @@ def bench_classification_iteration(args, dev):
                                                 T_(plM["iCol"]), T_(plM["iRow"]))
     nPxlS, nPxlE, nPxlM = plS["nPxl"], plE["nPxl"], plM["nPxl"]
     plan = ops.RecoPlan(N, N, pf)
-    vols = torch.stack([plan.set_projectee(T_(synth.blob_map(N, seed=300 + k, nblob=20))) for k in range(K)]).contiguous()
+    refs = torch.stack([T_(synth.blob_map(N, seed=300 + k, nblob=20)) for k in range(K)]).contiguous()
+    vols = torch.stack([plan.set_projectee(refs[k]) for k in range(K)]).contiguous()
     cells = ops.pack_projector(vols, P)
     quat = synth.random_quats(nR, rng)
     mats = ops.rotmat(T_(quat))
@@ -315,20 +316,23 @@ def bench_classification_iteration(args, dev):
     datE, ctfE = datM[:, e2m].contiguous(), ctfM[:, e2m].contiguous()
     datS, ctfS = datM[:, s2m].contiguous(), ctfM[:, s2m].contiguous()
     sig = -0.5 / (sd * sd / 2)
+    sigM = torch.full((nImg, nPxlM), sig, dtype=torch.float32, device=dev)
     sigE = torch.full((nImg, nPxlE), sig, dtype=torch.float32, device=dev)
     sigS = torch.full((nImg, nPxlS), sig, dtype=torch.float32, device=dev)
     pR = torch.full((nImg, nR), 1.0 / nR, dtype=torch.float64, device=dev)
     pT = torch.full((nImg, nT), 1.0 / nT, dtype=torch.float64, device=dev)
+    native = not args.python_sequencing
+    py = (not native) or args.check_native
     wC = torch.zeros((nImg, K), dtype=torch.float32, device=dev)
-    wR = torch.zeros((K, nImg, nR), dtype=torch.float32, device=dev)
-    wT = torch.zeros((K, nImg, nT), dtype=torch.float32, device=dev)
+    wR = torch.zeros((K, nImg, nR) if py else (1,), dtype=torch.float32, device=dev)
+    wT = torch.zeros((K, nImg, nT) if py else (1,), dtype=torch.float32, device=dev)
     base = torch.empty((nImg,), dtype=torch.float32, device=dev)
     wsG = torch.empty(capi.load().thx_expect_global_workspace(nImg, nR, nT), dtype=torch.uint8, device=dev)
     batch = min(nImg, args.batch)
     wsL = torch.empty(capi.load().thx_expect_local_workspace(batch, mLR, mLT, 1), dtype=torch.uint8, device=dev)
     rotP = torch.empty((nR, nPxlS), dtype=torch.complex64, device=dev)
-    F = torch.zeros((K, P, P, P // 2 + 1), dtype=torch.complex64, device=dev)
-    Tt = torch.zeros((K, P, P, P // 2 + 1), dtype=torch.float32, device=dev)
+    F = torch.zeros((K, P, P, P // 2 + 1) if py else (1,), dtype=torch.complex64, device=dev)
+    Tt = torch.zeros((K, P, P, P // 2 + 1) if py else (1,), dtype=torch.float32, device=dev)
     w = torch.full((nImg,), 1.0 / mReco, dtype=torch.float32, device=dev)
     ar = torch.arange(nImg, device=dev)
     seed, state = 20240607, {"call": 0}
@@ -398,27 +402,79 @@ def bench_classification_iteration(args, dev):
                 if float(Tt[k, 0, 0, 0]) <= 0:
                     continue
                 ops.normalise_TF(F[k], Tt[k], P)
-                for MAP in (False, True):
-                    Tk = Tt[k].clone()   # (reconstruct works on T in place, as the reference does)
-                    maps[k] = plan.reconstruct(F[k], Tk, rU, FSC=np.ones(rU, np.float32) if MAP else None, joinHalf=False, MAP=MAP, gridCorr=True)
+                for MAP in (False, True):   # (reconstruct works on the class's ONE T in place, as the reference does)
+                    maps[(k, MAP)] = plan.reconstruct(F[k], Tt[k], rU, FSC=np.ones(rU, np.float32) if MAP else None, joinHalf=False, MAP=MAP, gridCorr=True)
                     rounds += int(plan.last_iters)
         return cls, st, rounds
 
-    for _ in range(args.warmup):
-        iteration(False)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        cls, st, rounds = iteration(True)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    ref_run = None
+    if native and args.check_native:
+        # A/B: the same iteration sequenced in Python first (Philox call counter from 0, as the fresh native handle's)
+        cls_p, st_p, rounds_p = iteration(False)
+        torch.cuda.synchronize()
+        ref_run = dict(cls=cls_p.cpu().numpy(), r=st_p["r"].cpu().numpy(), t=st_p["t"].cpu().numpy(), topR=st_p["topR"].cpu().numpy(),
+                       F=F.cpu().numpy(), T=Tt.cpu().numpy(), maps={k: m.cpu().numpy() for k, m in maps.items()}, rounds=rounds_p)
+    if native:
+        # the iteration in native code (thx_classify_iterate, thunder_amd/csrc/thx_classify.hip): Python hands over the rows, the
+        # scanned grid and the references once and calls the driver once per iteration
+        from thunder_amd.native import CLASSIFY_STAGES, NativeClassify
+        F = Tt = wR = wT = None
+        nat = NativeClassify(N, K, nImg, nR, nT, rScan, rL=2, pf=pf, mLR=mLR, mLT=mLT, nPhase=nPhase, mReco=mReco, batch=batch, pixel_order=0,
+                             wg_per_cu=args.wg_per_cu, seed=seed)
+        nat.set_grid(quatD, shiftsD); nat.set_particles(datM, ctfM, sigM, w); nat.set_references(refs)
+        for _ in range(args.warmup):
+            nat.iterate(False)
+        torch.cuda.synchronize()
+        nat.stats(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            nat.iterate(True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ns, v = nat.stats(), nat.view()
+        cls = T_(nat.fetch(v.cls, np.int32, (nImg,)))
+        st = dict(r=T_(nat.fetch(v.r, np.float64, (nImg, mLR, 4))), t=T_(nat.fetch(v.t, np.float64, (nImg, mLT, 2))),
+                  topR=T_(nat.fetch(v.topR, np.float64, (nImg, 4))))
+        rounds = int(ns.balancingRounds) // max(1, args.steps)
+        for i, name in enumerate(CLASSIFY_STAGES):
+            stage_ms[name] = float(ns.stageMs[i])
+        rotP = torch.empty((nR, nPxlS), dtype=torch.complex64, device=dev)   # (the CPU baseline's sample of slices)
+        check = None
+        if ref_run is not None:
+            volN, mapN = P * P * (P // 2 + 1), N * N * N
+            Fn = nat.fetch(v.F, np.complex64, (K, P, P, P // 2 + 1)); Tn = nat.fetch(v.T, np.float32, (K, P, P, P // 2 + 1))
+            m0 = nat.fetch(v.maps, np.float32, (K, N, N, N)); m1 = nat.fetch(v.mapsMAP, np.float32, (K, N, N, N))
+            dm = 0.0
+            for (k, MAP), m in ref_run["maps"].items():
+                dm = max(dm, float(np.abs((m1 if MAP else m0)[k] - m).max()))
+            check = {"cls_equal": bool((cls.cpu().numpy() == ref_run["cls"]).all()),
+                     "r_max_abs_diff": float(np.abs(st["r"].cpu().numpy() - ref_run["r"]).max()),
+                     "t_max_abs_diff": float(np.abs(st["t"].cpu().numpy() - ref_run["t"]).max()),
+                     "topR_max_abs_diff": float(np.abs(st["topR"].cpu().numpy() - ref_run["topR"]).max()),
+                     "F_max_abs_diff": float(np.abs(Fn - ref_run["F"]).max()), "T_max_abs_diff": float(np.abs(Tn - ref_run["T"]).max()),
+                     "F_max_abs": float(np.abs(ref_run["F"]).max()), "maps_max_abs_diff": dm,
+                     "rounds_native": int(ns.balancingRounds), "rounds_python": int(ref_run["rounds"]),
+                     "single_batch": bool(nImg <= batch)}
+    else:
+        for _ in range(args.warmup):
+            iteration(False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            cls, st, rounds = iteration(True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     ok = float((cls.cpu().numpy() == cls_true).mean())
     # poses after the local phases against the generating ones
     d = np.abs((st["topR"].cpu().numpy() * quat[r_true]).sum(1)).clip(0, 1)
     ang = np.degrees(2 * np.arccos(d))
     ms = lambda key: float(np.mean([a.elapsed_time(b) for a, b, _ in ev[key]]))
     n_of = lambda key: float(np.mean([n for _, _, n in ev[key]]))
-    scan_ms, loc_ms, ins_ms = ms("scan"), ms("local"), ms("insert")
+    if native:
+        scan_ms, loc_ms, ins_ms = ns.scanMs / max(1, ns.scanLaunches), ns.localMs / max(1, ns.localLaunches), ns.insertMs / max(1, ns.insertLaunches)
+        n_of = lambda key: {"local": ns.localImages / max(1, ns.localLaunches), "insert": ns.insertImages / max(1, ns.insertLaunches), "scan": float(nImg)}[key]
+    else:
+        scan_ms, loc_ms, ins_ms = ms("scan"), ms("local"), ms("insert")
     flops = 4.0 * nImg * nR * nT * nPxlS
     loc_bytes = n_of("local") * nPxlE * (EXPECT_BYTES_PER_PIXEL + EXPECT_BYTES_PER_PIXEL_SAMPLE * mLR)
     stages = {k: round(v / args.steps, 2) for k, v in stage_ms.items()}
@@ -438,7 +494,7 @@ def bench_classification_iteration(args, dev):
                                   "(%d pixels); local search %d phases x %d rot x %d shifts on %d pixels; %d inserts per image into %d F / T pairs; "
                                   "%d reconstructions" % (nImg, N, K, nR, nT, rScan, nPxlS, nPhase, mLR, mLT, nPxlE, mReco, K, 2 * K),
                       "classes_recovered": ok, "median_pose_error_deg": float(np.median(ang)), "particle_order": "random" if args.unsorted else "by class, then view direction",
-                      "sequenced_by": "Python over the *_dev entry points (the native driver runs one class)"},
+                      "sequenced_by": "thx_classify_iterate (native C++ driver, thx_classify.hip)" if native else "Python over the *_dev entry points (--python-sequencing)"},
            "roofline": roof_scan if dominant == "scan" else roof_local,
            "rooflines": {"scan": roof_scan, "local_phases": roof_local},
            "kernels": {"insertion (k_bin + segment sort + k_acc), %d classes in one session" % K: {"avg_call_ms": ins_ms, "images_per_call": n_of("insert"),
@@ -448,6 +504,8 @@ def bench_classification_iteration(args, dev):
         out["cpu_baseline"] = cpu_baseline_classification(args, dev, dict(K=K, nR=nR, nT=nT, N=N, P=P, pf=pf, nImg=nImg, mLR=mLR, mLT=mLT, mReco=mReco, nPhase=nPhase,
                                                                       vols=vols, mats=mats, iColS=iColS, iRowS=iRowS, rotP=rotP, traS=traS, datS=datS, ctfS=ctfS, sigS=sigS,
                                                                       plE=plE, datE=datE, ctfE=ctfE, sigE=sigE, st=st, cls=cls))
+    if native and check is not None:
+        out["native_vs_python"] = check
     print(json.dumps(out))
     plan.close()
 
@@ -539,6 +597,10 @@ def main():
                     help="one whole K = 4 classification iteration of configs[3] on one GPU's share of the images instead "
                          "(scan, class selection, local phases, multi-reference insertion, reconstructions)")
     ap.add_argument("--wg-per-cu", type=int, default=2, help="with --classification: occupancy argument of thx_expect_local_dev (workgroups per CU; 0 = unlimited)")
+    ap.add_argument("--python-sequencing", action="store_true", help="with --classification: sequence the iteration in Python over the *_dev calls "
+                                                                         "instead of the native driver thx_classify_iterate (A/B)")
+    ap.add_argument("--check-native", action="store_true", help="with --classification --warmup 0 --steps 1: run the Python sequencing once first and "
+                                                                    "report the native driver's differences from it (bit-identical when one batch holds every image)")
     ap.add_argument("--scan-only", action="store_true", help="with --classification: the global scanning stage on its own")
     ap.add_argument("--scan-images", type=int, default=0, help="images of the classification bench (default 6250 = 50 000 / 8 GPUs; 1024 with --scan-only)")
     ap.add_argument("--scan-cpu-images-per-core", type=int, default=2)

@@ -531,6 +531,9 @@ int thx_reco_allreduce(thx_comm* hemi, float* F, float* T, double* O, int* count
 size_t thx_reco_allreduce_acc_workspace(int dim, int maxRadius, int pf);
 int thx_reco_allreduce_acc(thx_comm* hemi, void* acc, double* O, int* counter, int dim, int maxRadius, int pf, void* workspace,
                            void* stream);
+/* class k of a session over nK classes (acc as thx_insert_acc_bytes(dim, nK) lays it out); thx_reco_allreduce_acc is nK = 1, k = 0 */
+int thx_reco_allreduce_acc_class(thx_comm* hemi, void* acc, int nK, int k, double* O, int* counter, int dim, int maxRadius, int pf,
+                                 void* workspace, void* stream);
 /* the pack (unpack = 0) / unpack (unpack = 1) halves of thx_reco_allreduce on their own (parity probe of the sphere-row
  * tables on one GPU); *nVoxOut (host, optional) = packed voxels */
 int thx_reco_sphere_pack_dev(float* F, float* T, int dim, int maxRadius, int pf, void* workspace, int unpack, long* nVoxOut,
@@ -674,6 +677,66 @@ typedef struct thx_refine_view {
     const float *norm;                      /* [nImg] normCorrection's norms of the last iteration that ran it */
 } thx_refine_view;
 int thx_refine_get_view(thx_refine* h, thx_refine_view* out);
+
+/* ---------------------------------------------------------------------------------------------
+ * One 3-D classification iteration over K references in native code (thx_classify.hip; BASELINE configs[3]):
+ * Optimiser::expectation's global search -- scan of every image against nK classes x nR rotations x nT shifts at r = rScan
+ * (src/Optimiser.cpp:756-894), class of the image (:925-952), support points from the scan posterior of that class with the
+ * scanning phase's minimum spread (:953-1079) -- the local particle-filter phases against the assigned reference (:1141-1660),
+ * the mReco draws of every image inserted into the F / T of its class (:7038-7241; ONE fixed-point session over all batches,
+ * reduced over the ranks of the half on the integers), prepareTF's normalisation and the MAP-off / MAP-on reconstructions of
+ * every class (:7248-7760), Model::refreshProj per class (src/Model.cpp:1013-1044).  One handle = one rank's shard of ONE
+ * half-set.  Left to the caller, as in bench.py --classification: the sigma update, re-centring and the comparison of the two
+ * half maps of a class (thx_compare_hemispheres_dev), whose FSC comes back through thx_classify_set_fsc.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct thx_classify thx_classify;
+typedef struct thx_classify_config {
+    int N, pf, nK;             /* box, padding factor, classes (<= 16) */
+    int nImg;                  /* images of this rank */
+    long nImgHemi;             /* images of the whole half over all its ranks (head-room of the 64-bit sums); 0 = nImg */
+    int nR, nT;                /* scanned rotations / shifts (script/demo_3D.json: mS = 10 000 -> nR, nT >= 30) */
+    int rScan, rL;             /* frequency limit of the scan (Optimiser::_r in the global search), lower cut-off */
+    int mLR, mLT, nPhase, mReco;
+    int batch;                 /* images per launch of the local search / insertion, at most */
+    int pixelOrder, wgPerCU;   /* as thx_refine_config */
+    int refresh;               /* != 0: the MAP-on map of every class becomes its reference for the next iteration */
+    float pixelSize;
+    double transS, transQ, pfL, pfS;    /* as thx_refine_config */
+    double peakFactorR, peakFactorC;    /* PEAK_FACTOR_MIN, PEAK_FACTOR_C */
+    double scanMinK, scanMinS;          /* minimum spread after the scan (thx_pf_scan_support_dev's minK / minS) */
+    unsigned long long seed;
+} thx_classify_config;
+typedef struct thx_classify_stats {
+    double stageMs[5];                  /* scan, class + support points, local phases, insertion, reconstruct (+ refresh) */
+    double scanMs, localMs, insertMs;   /* HIP-event totals of the thx_expect_global_dev / local-search / insertion launches */
+    long scanLaunches, localLaunches, localImages, insertLaunches, insertImages;
+    long balancingRounds, iterations;
+    int nPxlS, nPxlE, nPxlM, batch;
+    int lastRounds[32];                 /* [class][MAP off, MAP on] balancing rounds of the last iteration */
+    int classCount[16];                 /* images per class in the last iteration (this rank) */
+} thx_classify_stats;
+/* read-only DEVICE views (valid until destroy) */
+typedef struct thx_classify_view {
+    int nImg, nK, nPxlS, nPxlE, nPxlM, vdim;
+    const int* cls;                         /* [nImg] */
+    const float *uC, *uR, *uT;              /* scan weights [nImg][nK], [nK][nImg][nR], [nK][nImg][nT] */
+    const double *r, *t, *wR, *wT, *topR, *topT;   /* filter state after the local phases */
+    const float *vols, *cells, *F, *T;      /* [nK] projector FTs, cell-packed copies, accumulators after reconstruct */
+    const float *maps, *mapsMAP;            /* [nK][N]^3 MAP-off / MAP-on maps of the last iteration */
+} thx_classify_view;
+int thx_classify_create(thx_classify** out, const thx_classify_config* cfg, thx_comm* hemi);
+int thx_classify_destroy(thx_classify* h);
+/* quat [nR][4], shifts [nT][2] doubles (host or device): the scanned grid, shared by all images */
+int thx_classify_set_grid(thx_classify* h, const double* quat, const double* shifts, void* stream);
+/* DEVICE rows on the rL = 0 pixel list (thx_pixel_list_host(N, N / 2 - 2, 0, 0)), BORROWED until destroy: datM [nImg][nPxlM]
+ * complex64 (unmasked images), ctfM, sigRcpM [nImg][nPxlM], w [nImg] (already / mReco).  The rows of the scan and of the
+ * local search are cut from them. */
+int thx_classify_set_particles(thx_classify* h, const float* datM, const float* ctfM, const float* sigRcpM, const float* w, void* stream);
+int thx_classify_set_references(thx_classify* h, const float* refRL, void* stream);   /* DEVICE [nK][N]^3 */
+int thx_classify_set_fsc(thx_classify* h, const float* fscHost, int n);   /* [nK][N / 2 - 2]: Reconstructor::_FSC of the MAP pass (ones at first) */
+int thx_classify_iterate(thx_classify* h, int timed, void* stream);
+int thx_classify_get_view(thx_classify* h, thx_classify_view* out);
+int thx_classify_get_stats(thx_classify* h, thx_classify_stats* out, int reset);
 
 /* ---------------------------------------------------------------------------------------------
  * Interface.h-shaped HOST-pointer entry points (what -DGPU_VERSION call sites bind to)

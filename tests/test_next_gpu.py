@@ -569,6 +569,34 @@ def test_classification_iteration_bench_small(dev):
     assert d["rooflines"]["scan"]["bound"] == "mfma" and d["rooflines"]["local_phases"]["bound"] == "hbm"
     assert d["config"]["classes_recovered"] >= 0.95 and d["config"]["median_pose_error_deg"] <= 8.0
     assert d["balancing_rounds_per_step"] > 8 * 10
+    assert "thx_classify_iterate" in d["config"]["sequenced_by"]
+
+
+def test_native_classification_driver_matches_python_sequencing(dev):
+    """thx_classify_iterate (thx_classify.hip: the K-class iteration sequenced in C++) against the same iteration sequenced in
+    Python over the `*_dev` entry points, from the same rows, grid, references and Philox counters: same class for every image,
+    the same support points and top poses bit for bit, F / T bit for bit (one batch holds every image, so the one-call insertion
+    and the session share their quanta), the same balancing rounds and maps.  Every stage behind both sequencings is held
+    against the oracle by its own test (test_expect_global*, test_pf_class_select*, test_pf_scan_support*, test_expect_local*,
+    test_insert*, test_reconstruct*); this test pins the ORDER: which weights reach which filter call, which class the draws
+    go to, one T per class through both reconstructions."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--classification", "--box", "64", "--scan-images", "96",
+                          "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--check-native"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    c = json.loads(out.stdout.strip().splitlines()[-1])["native_vs_python"]
+    assert c["single_batch"] and c["cls_equal"], c
+    assert c["r_max_abs_diff"] == 0.0 and c["t_max_abs_diff"] == 0.0 and c["topR_max_abs_diff"] == 0.0, c
+    assert c["F_max_abs"] > 0 and c["F_max_abs_diff"] == 0.0 and c["T_max_abs_diff"] == 0.0, c
+    assert c["rounds_native"] == c["rounds_python"] and c["maps_max_abs_diff"] == 0.0, c
+    # several batches: the session's common quanta differ from the per-batch quanta of the one-call form by rounding only
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--classification", "--box", "64", "--scan-images", "96", "--batch", "40",
+                          "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--check-native"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    c = json.loads(out.stdout.strip().splitlines()[-1])["native_vs_python"]
+    assert not c["single_batch"] and c["cls_equal"] and c["r_max_abs_diff"] == 0.0 and c["topR_max_abs_diff"] == 0.0, c
+    assert c["F_max_abs_diff"] <= 1e-6 * c["F_max_abs"], c
 
 
 def test_config0_demo3d_128_box_iterations(dev):

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libthunder_amd.so")
-SOURCES = ["thx_estep.hip", "thx_mstep.hip", "thx_insert_sort.hip", "thx_reco.hip", "thx_next.hip", "thx_io.hip", "thx_pf.hip", "thx_iface.hip", "thx_host.hip", "thx_comm.hip", "thx_refine.hip", "thx_model.hip"]
+SOURCES = ["thx_estep.hip", "thx_mstep.hip", "thx_insert_sort.hip", "thx_reco.hip", "thx_next.hip", "thx_io.hip", "thx_pf.hip", "thx_iface.hip", "thx_host.hip", "thx_comm.hip", "thx_refine.hip", "thx_model.hip", "thx_classify.hip"]
 HEADERS = ["thx_common.h", "thx_insert.h", "thx_fft8.h", "thx_philox.h", os.path.join("..", "..", "include", "thunder_amd.h")]
 
 # -ffp-contract=off: see thx_common.h (bit-identical trilinear arithmetic); fused ops are written out as fmaf().

@@ -57,6 +57,33 @@ class RefineView(C.Structure):
                                           "recoRot", "recoTran", "nP", "norm")]
 
 
+class ClassifyConfig(C.Structure):
+    """thx_classify_config (include/thunder_amd.h)"""
+    _fields_ = [("N", C.c_int), ("pf", C.c_int), ("nK", C.c_int), ("nImg", C.c_int), ("nImgHemi", C.c_long),
+                ("nR", C.c_int), ("nT", C.c_int), ("rScan", C.c_int), ("rL", C.c_int),
+                ("mLR", C.c_int), ("mLT", C.c_int), ("nPhase", C.c_int), ("mReco", C.c_int), ("batch", C.c_int),
+                ("pixelOrder", C.c_int), ("wgPerCU", C.c_int), ("refresh", C.c_int), ("pixelSize", C.c_float),
+                ("transS", C.c_double), ("transQ", C.c_double), ("pfL", C.c_double), ("pfS", C.c_double),
+                ("peakFactorR", C.c_double), ("peakFactorC", C.c_double), ("scanMinK", C.c_double), ("scanMinS", C.c_double),
+                ("seed", C.c_ulonglong)]
+
+
+class ClassifyStats(C.Structure):
+    """thx_classify_stats (include/thunder_amd.h)"""
+    _fields_ = [("stageMs", C.c_double * 5), ("scanMs", C.c_double), ("localMs", C.c_double), ("insertMs", C.c_double),
+                ("scanLaunches", C.c_long), ("localLaunches", C.c_long), ("localImages", C.c_long), ("insertLaunches", C.c_long),
+                ("insertImages", C.c_long), ("balancingRounds", C.c_long), ("iterations", C.c_long),
+                ("nPxlS", C.c_int), ("nPxlE", C.c_int), ("nPxlM", C.c_int), ("batch", C.c_int),
+                ("lastRounds", C.c_int * 32), ("classCount", C.c_int * 16)]
+
+
+class ClassifyView(C.Structure):
+    """thx_classify_view (include/thunder_amd.h): device pointers as integers"""
+    _fields_ = [(n, C.c_int) for n in ("nImg", "nK", "nPxlS", "nPxlE", "nPxlM", "vdim")] + \
+               [(n, C.c_void_p) for n in ("cls", "uC", "uR", "uT", "r", "t", "wR", "wT", "topR", "topT", "vols", "cells", "F", "T",
+                                          "maps", "mapsMAP")]
+
+
 _vp = C.c_void_p
 _i = C.c_int
 _f = C.c_float
@@ -110,6 +137,16 @@ SIGNATURES = {
     "thx_refine_get_state": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "thx_refine_get_stats": (_i, [_vp, C.POINTER(RefineStats), _i]),
     "thx_refine_get_view": (_i, [_vp, C.POINTER(RefineView)]),
+    "thx_classify_create": (_i, [C.POINTER(_vp), C.POINTER(ClassifyConfig), _vp]),
+    "thx_classify_destroy": (_i, [_vp]),
+    "thx_classify_set_grid": (_i, [_vp, _vp, _vp, _vp]),
+    "thx_classify_set_particles": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "thx_classify_set_references": (_i, [_vp, _vp, _vp]),
+    "thx_classify_set_fsc": (_i, [_vp, _vp, _i]),
+    "thx_classify_iterate": (_i, [_vp, _i, _vp]),
+    "thx_classify_get_view": (_i, [_vp, C.POINTER(ClassifyView)]),
+    "thx_classify_get_stats": (_i, [_vp, C.POINTER(ClassifyStats), _i]),
+    "thx_reco_allreduce_acc_class": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "thx_rotmat_dev": (_i, [_vp, _vp, _i, _vp]),
     "thx_translate_dev": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "thx_ctf_dev": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp]),

@@ -240,19 +240,30 @@ size_t thx_reco_allreduce_acc_workspace(int dim, int maxRadius, int pf)
 // bit for bit what one rank would have accumulated over all the particles -- summing the converted floats
 // (thx_reco_allreduce) depends on how the particles were dealt to the ranks.  One ring all-reduce of the sphere rows
 // (ncclInt64: 24 bytes per voxel instead of 12).
+int thx_reco_allreduce_acc_class(thx_comm* hemi, void* acc, int nK, int k, double* O, int* counter, int dim, int maxRadius, int pf,
+                                 void* workspace, void* stream);
+
 int thx_reco_allreduce_acc(thx_comm* hemi, void* acc, double* O, int* counter, int dim, int maxRadius, int pf, void* workspace,
                            void* stream)
 {
+    return thx_reco_allreduce_acc_class(hemi, acc, 1, 0, O, counter, dim, maxRadius, pf, workspace, stream);
+}
+
+// class k of a session over nK classes (acc = [nK][vol][2] F | [nK][vol] T, thx_insert_acc_bytes(dim, nK)): the classification
+// driver reduces its K pairs one after the other through the same workspace
+int thx_reco_allreduce_acc_class(thx_comm* hemi, void* acc, int nK, int k, double* O, int* counter, int dim, int maxRadius, int pf,
+                                 void* workspace, void* stream)
+{
     if (!hemi || (hemi->size == 1 && !knobs().commForce)) return 0;
-    THX_REQUIRE(acc && workspace && dim > 0 && maxRadius > 0 && pf > 0, "bad arguments");
+    THX_REQUIRE(acc && workspace && dim > 0 && maxRadius > 0 && pf > 0 && nK >= 1 && k >= 0 && k < nK, "bad arguments");
     hipStream_t st = as_stream(stream);
     SphereRows sr;
     const int R = maxRadius * pf + 2;
     THX_RC(sphere_rows(&sr, dim, R));
     THX_REQUIRE((size_t)sr.total * 3 * sizeof(long long) <= thx_reco_allreduce_acc_workspace(dim, maxRadius, pf), "workspace too small");
     const size_t volN = (size_t)dim * dim * (dim / 2 + 1);
-    long long* accF = reinterpret_cast<long long*>(acc);
-    long long* accT = accF + 2 * volN;
+    long long* accF = reinterpret_cast<long long*>(acc) + (size_t)k * 2 * volN;
+    long long* accT = reinterpret_cast<long long*>(acc) + (size_t)nK * 2 * volN + (size_t)k * volN;
     long long* buf = reinterpret_cast<long long*>(workspace);
     const unsigned blocks = (unsigned)(((long)dim * dim + 3) / 4);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sphere_pack_acc<0>), dim3(blocks), dim3(256), 0, st, accF, accT, buf, sr.rowOff, dim, sr.total);

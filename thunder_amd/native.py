@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import capi
-from .capi import RefineConfig, RefineStats, RefineView, ptr, stream_ptr
+from .capi import ClassifyConfig, ClassifyStats, ClassifyView, RefineConfig, RefineStats, RefineView, ptr, stream_ptr
 
 STAGES = ("rows", "expectation", "sigma", "insertion", "reconstruct", "recentre_remask", "norm_correction")
 
@@ -188,6 +188,91 @@ class NativeRefine:
     def close(self):
         if self._h is not None:
             capi.call("thx_refine_destroy", self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+CLASSIFY_STAGES = ("scan", "class_select_and_support_points", "local_phases", "insertion", "reconstruct")
+INIT_OUTSIDE_CONFIDENCE_AREA = 0.5   # include/Particle.h:59
+TRANS_SEARCH_FACTOR = 0.25           # script/demo_3D.json "Translation Search Factor"
+
+
+def scan_min_spread(nR, perturbFactorSGlobal=0.5):
+    """the scanning phase's minimum spread (OPTIMISER_SCAN_SET_MIN_STD_WITH_PERTURB, src/Optimiser.cpp:1032-1079): scanMinStdR =
+    nR^(-1/3), scanMinStdT = 1 / Qinv(INIT_OUTSIDE_CONFIDENCE_AREA, 2) / sqrt(transSearchFactor pi), over perturbFactorSGlobal
+    -> (minK, minS) of thx_pf_scan_support_dev"""
+    minK = (nR ** (-1.0 / 3) / perturbFactorSGlobal) ** 2
+    minS = 1.0 / (-2.0 * np.log(INIT_OUTSIDE_CONFIDENCE_AREA)) / np.sqrt(TRANS_SEARCH_FACTOR * np.pi) / perturbFactorSGlobal
+    return float(minK), float(minS)
+
+
+class NativeClassify:
+    """thx_classify handle (thunder_amd/csrc/thx_classify.hip): one K-class classification iteration -- global scan, class of
+    every image, support points, local phases against the assigned reference, multi-reference insertion session, 2
+    reconstructions per class -- behind one call.  The tensors handed to set_particles are borrowed: keep them alive."""
+
+    def __init__(self, N, K, nImg, nR, nT, rScan, rL=2, pf=2, mLR=125, mLT=9, nPhase=3, mReco=100, batch=10240, pixel_order=0,
+                 wg_per_cu=2, refresh=False, pixelSize=1.32, transS=2.0, transQ=0.05, pfL=2.0, pfS=0.5, peakFactorR=1e-3,
+                 peakFactorC=1.0 - 1e-2, seed=20240607, hemi=None, nImgHemi=0):
+        cfg = ClassifyConfig()
+        cfg.N, cfg.pf, cfg.nK, cfg.nImg, cfg.nImgHemi = N, pf, K, nImg, nImgHemi
+        cfg.nR, cfg.nT, cfg.rScan, cfg.rL = nR, nT, rScan, rL
+        cfg.mLR, cfg.mLT, cfg.nPhase, cfg.mReco, cfg.batch = mLR, mLT, nPhase, mReco, batch
+        cfg.pixelOrder, cfg.wgPerCU, cfg.refresh, cfg.pixelSize = pixel_order, wg_per_cu, 1 if refresh else 0, pixelSize
+        cfg.transS, cfg.transQ, cfg.pfL, cfg.pfS = transS, transQ, pfL, pfS
+        cfg.peakFactorR, cfg.peakFactorC = peakFactorR, peakFactorC
+        cfg.scanMinK, cfg.scanMinS = scan_min_spread(nR)
+        cfg.seed = seed
+        self.cfg = cfg
+        h = C.c_void_p()
+        capi.call("thx_classify_create", C.byref(h), C.byref(cfg), hemi.handle if hemi is not None else None)
+        self._h = h
+        self._keep = []
+
+    def set_grid(self, quat, shifts):
+        capi.call("thx_classify_set_grid", self._h, ptr(quat), ptr(shifts), stream_ptr())
+
+    def set_particles(self, datM, ctfM, sigRcpM, w):
+        assert datM.dtype == torch.complex64 and ctfM.dtype == torch.float32 and sigRcpM.dtype == torch.float32 and w.dtype == torch.float32
+        self._keep = [datM, ctfM, sigRcpM, w]
+        capi.call("thx_classify_set_particles", self._h, ptr(datM), ptr(ctfM), ptr(sigRcpM), ptr(w), stream_ptr())
+
+    def set_references(self, refRL):
+        assert refRL.dtype == torch.float32 and refRL.shape[0] == self.cfg.nK
+        capi.call("thx_classify_set_references", self._h, ptr(refRL), stream_ptr())
+
+    def set_fsc(self, fsc):
+        f = np.ascontiguousarray(np.asarray(fsc, np.float32))
+        capi.call("thx_classify_set_fsc", self._h, f.ctypes.data, f.size)
+
+    def iterate(self, timed=False):
+        capi.call("thx_classify_iterate", self._h, 1 if timed else 0, stream_ptr())
+
+    def stats(self, reset=False):
+        st = ClassifyStats()
+        capi.call("thx_classify_get_stats", self._h, C.byref(st), 1 if reset else 0)
+        return st
+
+    def view(self):
+        v = ClassifyView()
+        capi.call("thx_classify_get_view", self._h, C.byref(v))
+        return v
+
+    def fetch(self, dev_ptr, dtype, shape):
+        """host copy of one of view()'s device arrays"""
+        a = np.empty(shape, dtype)
+        torch.cuda.synchronize()
+        capi.call("thx_memcpy_d2h", a.ctypes.data, int(dev_ptr), a.nbytes)
+        return a
+
+    def close(self):
+        if self._h is not None:
+            capi.call("thx_classify_destroy", self._h)
             self._h = None
 
     def __del__(self):
