@@ -724,7 +724,15 @@ typedef struct thx_classify_view {
     const float *vols, *cells, *F, *T;      /* [nK] projector FTs, cell-packed copies, accumulators after reconstruct */
     const float *maps, *mapsMAP;            /* [nK][N]^3 MAP-off / MAP-on maps of the last iteration */
 } thx_classify_view;
+/* optional trace of the following iterations (DEVICE buffers, any may be NULL; copied; NULL struct = off): what the stage-level
+ * parity test holds against the oracle */
+typedef struct thx_classify_capture {
+    double *r0, *t0;           /* [nImg][mLR][4], [nImg][mLT][2]: the support points as thx_pf_scan_support_dev left them */
+    float *Fraw, *Traw;        /* [nK] complex / real (pf N)^3 half grids: the accumulators as the insertion session left them,
+                                  before prepareTF's normalisation */
+} thx_classify_capture;
 int thx_classify_create(thx_classify** out, const thx_classify_config* cfg, thx_comm* hemi);
+int thx_classify_set_capture(thx_classify* h, const thx_classify_capture* capture);
 int thx_classify_destroy(thx_classify* h);
 /* quat [nR][4], shifts [nT][2] doubles (host or device): the scanned grid, shared by all images */
 int thx_classify_set_grid(thx_classify* h, const double* quat, const double* shifts, void* stream);

@@ -1,0 +1,212 @@
+"""thx_classify_iterate (thunder_amd/csrc/thx_classify.hip: one K-class classification iteration in native code) against the
+oracle, stage boundary by stage boundary, on seeded inputs built with numpy + the oracle only:
+
+  scan weights of every class (carried baseline)      oracle.expect_global over the K classes            relative weight bar
+  class of every image                                oracle.pf_class_select on the device's uC, replayed Philox draws   equal
+  support points after the scan                       oracle.pf_scan_support on the device's uR / uT of that class       tie rule of test_pf_gpu.py
+  [local phases: the launches of thx_refine_iterate's chain (tests/test_iteration_gpu.py) with volIdx; the order of the calls is
+   pinned bit for bit against the Python sequencing in tests/test_next_gpu.py]
+  F / T of every class as the insertion left them     oracle.insertP of the replayed draws from the device's final support points  1e-5 max
+  MAP-off / MAP-on maps of every class                oracle.reconstruct from the device's raw F / T (one T through both)          the chain test's bars
+
+The Philox numbering follows the driver's launches: call 1 = class selection, 2 = support points, two calls per batch and
+phase, one per batch for the insertion draws (image index = global index)."""
+import numpy as np
+import pytest
+
+import _philox as PH
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def _case(O, N, K, nImg, nR, nT, seed):
+    """K blob references, images = CTF x slice of a random class at a scanned rotation x ramp of a scanned shift + noise, as rows
+    on the rL = 0 list"""
+    from thunder_amd import synth
+    rng = np.random.default_rng(seed)
+    pf, P, rU = 2, 2 * N, N // 2 - 2
+    refs = np.stack([synth.blob_map(N, seed=seed + 10 + k, nblob=10) for k in range(K)])
+    vols = [O.set_projectee(refs[k], pf) for k in range(K)]
+    plM = O.pixel_list(N, rU, 0, pf)
+    quat = synth.random_quats(nR, rng)
+    shifts = np.ascontiguousarray(rng.normal(0, 1.5, size=(nT, 2)))
+    cls_true, r_true, t_true = rng.integers(0, K, nImg), rng.integers(0, nR, nImg), rng.integers(0, nT, nImg)
+    attr = synth.ctf_params(nImg, rng)
+    ctfM = np.stack([O.ctf(1.32, *attr[l], N, plM["iCol"], plM["iRow"]) for l in range(nImg)])
+    datM = np.stack([O.project(vols[cls_true[l]], P, pf, O.rotate3D(quat[r_true[l]]), plM["iCol"], plM["iRow"]) * ctfM[l]
+                     * O.translate(np.float32(shifts[t_true[l], 0]), np.float32(shifts[t_true[l], 1]), N, plM["iCol"], plM["iRow"])
+                     for l in range(nImg)]).astype(np.complex64)
+    sd = 0.5 * float(np.sqrt(np.mean(np.abs(datM) ** 2)))
+    datM = (datM + (rng.standard_normal(datM.shape) + 1j * rng.standard_normal(datM.shape)) * (sd / np.sqrt(2))).astype(np.complex64)
+    sigM = np.full(datM.shape, np.float32(-0.5 / (sd * sd / 2)), np.float32)
+    return dict(refs=refs, vols=vols, plM=plM, quat=quat, shifts=shifts, cls_true=cls_true, r_true=r_true, datM=datM, ctfM=ctfM, sigM=sigM)
+
+
+@pytest.mark.parametrize("N,K,nImg,nR,nT,rScan,mLR,mLT,nPhase,mReco", [(32, 2, 128, 150, 6, 9, 40, 5, 2, 20), (32, 3, 150, 300, 4, 8, 24, 4, 1, 16)])
+def test_native_classification_stages_against_oracle(oracle, dev, N, K, nImg, nR, nT, rScan, mLR, mLT, nPhase, mReco):
+    from thunder_amd.native import NativeClassify
+    O = oracle
+    pf, P, rU, rL, seed = 2, 2 * N, N // 2 - 2, 2, 777001
+    cs = _case(O, N, K, nImg, nR, nT, 50 + K)
+    plM, plS = cs["plM"], O.pixel_list(N, rScan, rL, pf)
+    posM = {(int(i), int(j)): k for k, (i, j) in enumerate(zip(plM["iCol"], plM["iRow"]))}
+    s2m = np.asarray([posM[(int(i), int(j))] for i, j in zip(plS["iCol"], plS["iRow"])])
+    w = np.full(nImg, np.float32(1.0) / np.float32(mReco), np.float32)
+    d = dict(datM=T(cs["datM"], dev), ctfM=T(cs["ctfM"], dev), sigM=T(cs["sigM"], dev), w=T(w, dev))
+    nat = NativeClassify(N, K, nImg, nR, nT, rScan, rL=rL, pf=pf, mLR=mLR, mLT=mLT, nPhase=nPhase, mReco=mReco, batch=nImg, seed=seed)
+    nat.set_grid(T(cs["quat"], dev), T(cs["shifts"], dev))
+    nat.set_particles(d["datM"], d["ctfM"], d["sigM"], d["w"])
+    nat.set_references(T(cs["refs"], dev))
+    cap = nat.capture()
+    nat.iterate()
+    torch.cuda.synchronize()
+    v, c = nat.view(), nat.cfg
+    assert (v.nPxlS, v.nPxlM) == (plS["nPxl"], plM["nPxl"])
+    # ---- the projectors of the K references (Projector::setProjectee) ----
+    volN = P * P * (P // 2 + 1)
+    vd = nat.fetch(v.vols, np.complex64, (K, P, P, P // 2 + 1))
+    for k in range(K):
+        assert _rel(vd[k], cs["vols"][k]) <= 2e-6
+    # ---- scan: class after class, the baseline and the weights carried along (src/Optimiser.cpp:756-894) ----
+    mats = np.stack([O.rotate3D(q) for q in cs["quat"]])
+    traP = np.stack([O.translate(np.float32(s[0]), np.float32(s[1]), N, plS["iCol"], plS["iRow"]) for s in cs["shifts"]])
+    dat_pm, ctf_pm, sig_pm = (np.ascontiguousarray(cs[k_][:, s2m].T) for k_ in ("datM", "ctfM", "sigM"))
+    wC, wR, wT = np.zeros((nImg, K), np.float32), np.zeros((K, nImg, nR), np.float32), np.zeros((K, nImg, nT), np.float32)
+    base = np.full(nImg, np.nan, np.float32)
+    pR, pT = np.full((nImg, nR), 1.0 / nR), np.full((nImg, nT), 1.0 / nT)
+    for k in range(K):
+        rotP = np.stack([O.project(cs["vols"][k], P, pf, m, plS["iCol"], plS["iRow"]) for m in mats])
+        O.expect_global(rotP, traP, dat_pm, ctf_pm, sig_pm, K, k, pR, pT, wC, wR, wT, base)
+    uC, uR, uT = nat.fetch(v.uC, np.float32, (nImg, K)), nat.fetch(v.uR, np.float32, (K, nImg, nR)), nat.fetch(v.uT, np.float32, (K, nImg, nT))
+    tol = max(6e-5 * float(np.abs(base).max()), 3e-4)      # the bar of test_expect_global
+    np.testing.assert_allclose(uC, wC, rtol=tol)
+    np.testing.assert_allclose(uR, wR, rtol=tol, atol=1e-30)
+    np.testing.assert_allclose(uT, wT, rtol=tol, atol=1e-30)
+    # ---- class of every image (:925-952), from the device's class weights with replayed draws: call 1 ----
+    cls = nat.fetch(v.cls, np.int32, (nImg,))
+    want = np.asarray([O.pf_class_select(uC[l], np.full(K, 1.0 / K), c.peakFactorC, PH.shuffle_ranks(seed, l, 1, 6, K),
+                                         PH.draw_u4(seed, l, 1, 7, 0)[0] / K, min(int(PH.draw_u4(seed, l, 1, 8, 0)[0] * K), K - 1))
+                       for l in range(nImg)])
+    assert np.array_equal(cls, want)
+    assert (cls == cs["cls_true"]).mean() >= 0.9
+    # ---- support points from the scan posterior of that class (:953-1079): call 2 ----
+    r0, t0 = cap["r0"].cpu().numpy(), cap["t0"].cpu().numpy()
+    near = 0
+    for l in range(nImg):
+        rankR, rankT = PH.shuffle_ranks(seed, l, 2, 2, nR), PH.shuffle_ranks(seed, l, 2, 4, nT)
+        ws = O.pf_scan_support(cs["quat"], cs["shifts"], uR[cls[l], l], uT[cls[l], l], c.peakFactorR, mLR, mLT, rankR,
+                               PH.draw_u4(seed, l, 2, 3, 0)[0] / mLR, rankT, PH.draw_u4(seed, l, 2, 5, 0)[0] / mLT, c.scanMinK, c.scanMinS)
+        dR = np.abs(r0[l][:, None, :] - cs["quat"][None, ws["srcR"], :]).max(axis=2)
+        same = dR.diagonal() <= 1e-13
+        for j in np.nonzero(~same)[0]:     # a draw on its threshold: the neighbour in the shuffled order (test_scan_support_points)
+            srcD = int(np.argmin(np.abs(cs["quat"] - r0[l][j]).max(axis=1)))
+            assert abs(int(rankR[srcD]) - int(rankR[ws["srcR"][j]])) <= 1, (l, j)
+            near += 1
+        assert np.array_equal(t0[l], ws["t"])
+    assert near <= 2
+    # ---- insertion (:7038-7241): the draws of every image from its FINAL support points into the F / T of its class ----
+    q, t = nat.fetch(v.r, np.float64, (nImg, mLR, 4)), nat.fetch(v.t, np.float64, (nImg, mLT, 2))
+    call = 2 + 2 * nPhase + 1
+    F = np.zeros((K, P, P, P // 2 + 1), np.complex64)
+    Tt = np.zeros((K, P, P, P // 2 + 1), np.float32)
+    for l in range(nImg):
+        u = PH.draw_u4(seed, l, call, 7, np.arange(mReco))
+        iR = np.minimum((u[0] * mLR).astype(np.int64), mLR - 1)
+        iT = np.minimum((u[1] * mLT).astype(np.int64), mLT - 1)
+        for m in range(mReco):
+            tt = t[l, iT[m]]
+            src = O.translate(np.float32(-tt[0]), np.float32(-tt[1]), N, plM["iCol"], plM["iRow"], src=cs["datM"][l])
+            O.insertP(F[cls[l]], Tt[cls[l]], P, src, cs["ctfM"][l], O.rotate3D(q[l, iR[m]]), w[l], plM["iColPad"], plM["iRowPad"])
+    Fd, Td = cap["Fraw"].cpu().numpy(), cap["Traw"].cpu().numpy()
+    for k in range(K):
+        assert (cls == k).any()
+        eF, eT = _rel(Fd[k], F[k]), _rel(Td[k], Tt[k])
+        print("class %d: inserted F %.2e T %.2e of max" % (k, eF, eT))
+        assert eF <= 1e-5 and eT <= 1e-5
+    # ---- prepareTF's normalisation, reconstruct with MAP off, then MAP on with the all-ones FSC, ONE T through both ----
+    st = nat.stats()
+    m0, m1 = nat.fetch(v.maps, np.float32, (K, N, N, N)), nat.fetch(v.mapsMAP, np.float32, (K, N, N, N))
+    ones = np.ones(rU, np.float32)
+    for k in range(K):
+        Fk, Tk = Fd[k].copy(), Td[k].copy()
+        O.normalise_TF(Fk, Tk, P)
+        dev_rounds = [int(st.lastRounds[2 * k]), int(st.lastRounds[2 * k + 1])]
+        assert all(10 < r_ <= 30 for r_ in dev_rounds)
+        a, ita, _, _ = O.reconstruct(Fk, Tk, P, N, pf, rU, MAP=False, joinHalf=False, gridCorr=True, return_iters=True, T_inplace=True)
+        if ita != dev_rounds[0]:    # the stop rule is noise-sensitive (tests/test_iteration_gpu.py): compare after the SAME round
+            Fk, Tk = Fd[k].copy(), Td[k].copy()
+            O.normalise_TF(Fk, Tk, P)
+            a, _, _, _ = O.reconstruct(Fk, Tk, P, N, pf, rU, MAP=False, joinHalf=False, gridCorr=True, return_iters=True, T_inplace=True,
+                                       force_rounds=dev_rounds[0])
+        Tsave = Tk.copy()
+        b, itb, _, _ = O.reconstruct(Fk, Tk, P, N, pf, rU, FSC=ones, MAP=True, joinHalf=False, gridCorr=True, return_iters=True, T_inplace=True)
+        if itb != dev_rounds[1]:
+            Tk = Tsave
+            b, _, _, _ = O.reconstruct(Fk, Tk, P, N, pf, rU, FSC=ones, MAP=True, joinHalf=False, gridCorr=True, return_iters=True,
+                                       T_inplace=True, force_rounds=dev_rounds[1])
+        e0, e1 = _rel(m0[k], a), _rel(m1[k], b)
+        f0 = O.fsc(np.fft.rfftn(m0[k]).astype(np.complex64), np.fft.rfftn(a).astype(np.complex64), N, rU)
+        f1 = O.fsc(np.fft.rfftn(m1[k]).astype(np.complex64), np.fft.rfftn(b).astype(np.complex64), N, rU)
+        print("class %d: rounds device %s oracle %s; maps %.2e / %.2e of max, min FSC %.5f / %.5f" % (k, dev_rounds, [ita, itb], e0, e1, f0.min(), f1.min()))
+        # the bars of the refinement chain (tests/test_iteration_gpu.py): with some tens of images per class the gridding loop is
+        # far from converged when its stop rule fires and amplifies rounding noise of the FFTs on rim voxels where T is 1e-6 of
+        # its largest value; identical-input reconstruction on well-covered volumes is held to 1e-4 in test_parity_gpu.py
+        # (measured here with equal round counts: 5e-4 ... 1e-2 of max, FSC >= 0.9989 -- the MAP pass with the all-ones FSC adds no
+        # regularisation and stops after ~12 rounds, the least converged of the four)
+        for e, f, same in ((e0, f0, ita == dev_rounds[0]), (e1, f1, itb == dev_rounds[1])):
+            assert e <= (2e-2 if same else 1e-1) and f.min() >= (0.998 if same else 0.95), (k, e, f.min(), same)
+        # the class map resembles its own reference, not the next class's
+        own = O.fsc(np.fft.rfftn(m0[k]).astype(np.complex64), np.fft.rfftn(cs["refs"][k]).astype(np.complex64), N, 6)
+        other = O.fsc(np.fft.rfftn(m0[k]).astype(np.complex64), np.fft.rfftn(cs["refs"][(k + 1) % K]).astype(np.complex64), N, 6)
+        assert own[1:6].mean() > other[1:6].mean() + 0.05, (k, own, other)
+    assert st.balancingRounds == sum(int(x) for x in st.lastRounds)
+    assert [int(x) for x in st.classCount[:K]] == [int((cls == k).sum()) for k in range(K)]
+    nat.close()
+
+
+def test_native_classification_refresh_and_errors(dev):
+    """cfg.refresh: the MAP-on maps become the next iteration's references (Model::refreshProj) -- the second iteration's scan sees
+    them; argument errors come back as status + message, not as crashes"""
+    from thunder_amd import capi, synth
+    from thunder_amd.native import NativeClassify
+    N, K, nImg, nR, nT = 32, 2, 16, 64, 4
+    rng = np.random.default_rng(3)
+    with pytest.raises(capi.ThxError):
+        NativeClassify(N, 17, nImg, nR, nT, 8)
+    with pytest.raises(capi.ThxError):
+        NativeClassify(N, K, nImg, nR, nT, N // 2)          # rScan beyond N / 2 - 2
+    nat = NativeClassify(N, K, nImg, nR, nT, 8, mLR=16, mLT=4, nPhase=1, mReco=4, refresh=True)
+    with pytest.raises(capi.ThxError):
+        nat.iterate()                                       # nothing set yet
+    nM = nat.stats().nPxlM
+    datM = torch.view_as_complex(torch.randn((nImg, nM, 2), device=dev)).contiguous()
+    ctfM = torch.rand((nImg, nM), device=dev) * 2 - 1
+    sigM = torch.full((nImg, nM), -0.5, device=dev)
+    w = torch.full((nImg,), 0.25, device=dev)
+    nat.set_grid(T(synth.random_quats(nR, rng), dev), T(rng.normal(0, 1, (nT, 2)), dev))
+    nat.set_particles(datM, ctfM, sigM, w)
+    refs = T(np.stack([synth.blob_map(N, seed=5 + k, nblob=6) for k in range(K)]), dev)
+    nat.set_references(refs)
+    v = nat.view()
+    P = 2 * N
+    before = nat.fetch(v.vols, np.complex64, (K, P, P, P // 2 + 1))
+    nat.iterate()
+    after = nat.fetch(v.vols, np.complex64, (K, P, P, P // 2 + 1))
+    cnt = [int(x) for x in nat.stats().classCount[:K]]
+    assert sum(cnt) == nImg
+    for k in range(K):
+        assert np.all(np.isfinite(after[k]))
+        assert (not np.array_equal(after[k], before[k])) == (cnt[k] > 0)      # an empty class keeps its reference
+    nat.iterate()
+    assert nat.stats().iterations == 2
+    nat.close()

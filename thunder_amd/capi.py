@@ -77,6 +77,11 @@ class ClassifyStats(C.Structure):
                 ("lastRounds", C.c_int * 32), ("classCount", C.c_int * 16)]
 
 
+class ClassifyCapture(C.Structure):
+    """thx_classify_capture (include/thunder_amd.h): device pointers as integers"""
+    _fields_ = [(n, C.c_void_p) for n in ("r0", "t0", "Fraw", "Traw")]
+
+
 class ClassifyView(C.Structure):
     """thx_classify_view (include/thunder_amd.h): device pointers as integers"""
     _fields_ = [(n, C.c_int) for n in ("nImg", "nK", "nPxlS", "nPxlE", "nPxlM", "vdim")] + \
@@ -139,6 +144,7 @@ SIGNATURES = {
     "thx_refine_get_view": (_i, [_vp, C.POINTER(RefineView)]),
     "thx_classify_create": (_i, [C.POINTER(_vp), C.POINTER(ClassifyConfig), _vp]),
     "thx_classify_destroy": (_i, [_vp]),
+    "thx_classify_set_capture": (_i, [_vp, _vp]),
     "thx_classify_set_grid": (_i, [_vp, _vp, _vp, _vp]),
     "thx_classify_set_particles": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "thx_classify_set_references": (_i, [_vp, _vp, _vp]),

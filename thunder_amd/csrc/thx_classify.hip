@@ -100,6 +100,7 @@ struct thx_classify {
     unsigned pfCall = 0;
     long nImgHemi = 0;
     std::vector<float> fscMAP;
+    thx_classify_capture cap = {};
     // timing
     bool timed = false;
     struct Ev { hipEvent_t a, b; int kind; int images; };
@@ -234,6 +235,9 @@ int scan_and_select(thx_classify* h, hipStream_t st)
         THX_RC(thx_pf_scan_support_dev(h->r, h->t, h->wR, h->wT, h->k123, h->s01, h->topR, h->topT, h->gridR, h->gridT, h->uR, h->uT,
                                        h->cls, h->nImg, c.nR, c.nT, c.mLR, c.mLT, c.peakFactorR, c.scanMinK, c.scanMinS, c.seed,
                                        h->pfCall, st));
+        // optional trace for the stage-level parity test: the support points as the scan left them
+        if (h->cap.r0) THX_CHECK(hipMemcpyAsync(h->cap.r0, h->r, (size_t)h->nImg * c.mLR * 4 * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (h->cap.t0) THX_CHECK(hipMemcpyAsync(h->cap.t0, h->t, (size_t)h->nImg * c.mLT * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
     return 0;
 }
@@ -297,6 +301,8 @@ int insertion(thx_classify* h, hipStream_t st)
     for (int k = 0; k < h->nK && h->hemi; k++)
         THX_RC(thx_reco_allreduce_acc_class(h->hemi, h->accInt, h->nK, k, nullptr, nullptr, h->P, h->rU, h->pf, h->wsReduce, st));
     THX_RC(thx_insert_finish_dev(h->F, h->T, h->accInt, h->gexp, h->P, h->nK, st));
+    if (h->cap.Fraw) THX_CHECK(hipMemcpyAsync(h->cap.Fraw, h->F, (size_t)h->nK * volN * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (h->cap.Traw) THX_CHECK(hipMemcpyAsync(h->cap.Traw, h->T, (size_t)h->nK * volN * sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
@@ -487,6 +493,13 @@ int thx_classify_set_fsc(thx_classify* h, const float* fscHost, int n)
 {
     THX_REQUIRE(h && fscHost && n == h->nK * h->rU, "fsc: [nK][N / 2 - 2] floats");
     h->fscMAP.assign(fscHost, fscHost + n);
+    return 0;
+}
+
+int thx_classify_set_capture(thx_classify* h, const thx_classify_capture* capture)
+{
+    THX_REQUIRE(h, "null handle");
+    if (capture) h->cap = *capture; else memset(&h->cap, 0, sizeof(h->cap));
     return 0;
 }
 

@@ -250,6 +250,22 @@ class NativeClassify:
         f = np.ascontiguousarray(np.asarray(fsc, np.float32))
         capi.call("thx_classify_set_fsc", self._h, f.ctypes.data, f.size)
 
+    def capture(self):
+        """stage trace (thx_classify_set_capture): dict of device tensors the following iterations fill -- r0, t0 (support points
+        after the scan), Fraw, Traw (accumulators before prepareTF)"""
+        c = self.cfg
+        P, dev = c.N * c.pf, torch.device("cuda", torch.cuda.current_device())
+        cap = dict(r0=torch.zeros((c.nImg, c.mLR, 4), dtype=torch.float64, device=dev),
+                   t0=torch.zeros((c.nImg, c.mLT, 2), dtype=torch.float64, device=dev),
+                   Fraw=torch.zeros((c.nK, P, P, P // 2 + 1), dtype=torch.complex64, device=dev),
+                   Traw=torch.zeros((c.nK, P, P, P // 2 + 1), dtype=torch.float32, device=dev))
+        st = capi.ClassifyCapture()
+        for k, v in cap.items():
+            setattr(st, k, ptr(v))
+        capi.call("thx_classify_set_capture", self._h, C.byref(st))
+        self._cap = cap
+        return cap
+
     def iterate(self, timed=False):
         capi.call("thx_classify_iterate", self._h, 1 if timed else 0, stream_ptr())
 
