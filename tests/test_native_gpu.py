@@ -132,6 +132,21 @@ def test_cpp_iteration_driver(dev, tmp_path):
     print(out.stdout)
 
 
+def test_cpp_classification_driver(dev, tmp_path):
+    """tests/cpp/classify.cpp: torch-free C++ over the C ABI -- K = 2 synthetic references, images on the scanned grid,
+    thx_classify_create ... thx_classify_iterate (scan, class, support points, local phases, multi-reference insertion, two
+    reconstructions per class, refresh): classes recovered, every class map agrees with its own generating map"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "classify")
+    libdir = os.path.join(root, "thunder_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "classify.cpp"), "-o", exe, "-L" + libdir,
+                           "-lthunder_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+    print(out.stdout)
+
+
 def test_native_driver_stop_rule(dev):
     """maxPhase > nPhase: the reference's per-image stop rule inside the native driver (src/Optimiser.cpp:1510-1615): every
     image runs at least 5 phases (indices 0-4: the first check, after phase 3, always finds room), stopped images skip the
