@@ -34,6 +34,10 @@
 
 namespace thx {
 
+#ifndef THX_BIN_KEEP
+#define THX_BIN_KEEP 1   // 1: k_bin keeps a pass's sample geometry and hash slots in registers between its count and scatter phases
+                         // (168 VGPRs, 3 waves per SIMD instead of 119 / 4, and still 3.2 % faster over the insertion call; 0: recompute)
+#endif
 constexpr int kBLx = 4, kBLy = 4, kBLz = 3;                       // log2 of the brick edges in cell origins
 constexpr int kBx = 1 << kBLx, kBy = 1 << kBLy, kBz = 1 << kBLz;  // 16 x 16 x 8
 constexpr int kVx = kBx + 1, kVy = kBy + 1, kVz = kBz + 1;        // voxels a brick's cells reach
@@ -284,11 +288,33 @@ __global__ __launch_bounds__(kBinThreads) void k_bin(BinArgs b)
             }
 
         // ---- count: samples of this pass per brick ----
+#if THX_BIN_KEEP
+        // a thread's samples stay in registers for the scatter below (geometry and hash slot once per sample; the loops are
+        // unrolled over the pass's 8 groups so that the arrays are registers)
+        float gXd[kPassGroups], gYd[kPassGroups], gZd[kPassGroups];
+        unsigned gInfo[kPassGroups];   // cell in brick (11 bits) | conj << 11 | hash slot << 12 | valid << 31; 0: no sample
+#pragma unroll
+        for (int gl = 0; gl < kPassGroups; gl++) {
+            gInfo[gl] = 0u;
+            gXd[gl] = gYd[gl] = gZd[gl] = 0.f;
+            if (gl < ng) {
+                SampleGeom s;
+                if (listed && sample_geom(sR[gl], icp, irp, P, sCls[gl], b.nBx, b.nBy, b.nBz, s)) {
+                    const int h = hash_insert(hKey, s.key);
+                    atomicAdd(&hCnt[h], 1);
+                    gXd[gl] = s.xd; gYd[gl] = s.yd; gZd[gl] = s.zd;
+                    gInfo[gl] = s.cell | (s.conj ? 0x800u : 0u) | ((unsigned)h << 12) | 0x80000000u;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
         for (int gl = 0; gl < ng; gl++) {
             SampleGeom s;
             // (LDS atomics of one wave on a few addresses: the hardware's own serialisation is cheaper than sorting the lanes by key)
             if (listed && sample_geom(sR[gl], icp, irp, P, sCls[gl], b.nBx, b.nBy, b.nBz, s)) atomicAdd(&hCnt[hash_insert(hKey, s.key)], 1);
         }
+#endif
         __syncthreads();
 
         // ---- the pass's segments: one per brick it touched, packed from the pass's static record base on ----
@@ -332,10 +358,19 @@ __global__ __launch_bounds__(kBinThreads) void k_bin(BinArgs b)
         __syncthreads();
 
         // ---- scatter: the samples again, now with their values, each into its brick's segment ----
+#if THX_BIN_KEEP
+#pragma unroll
+        for (int gl = 0; gl < kPassGroups; gl++) {
+            if (!(gInfo[gl] & 0x80000000u)) continue;
+            const unsigned idx = (unsigned)atomicAdd(&hCnt[(gInfo[gl] >> 12) & (kHash - 1)], 1);
+            SampleGeom s;
+            s.xd = gXd[gl]; s.yd = gYd[gl]; s.zd = gZd[gl]; s.cell = gInfo[gl] & 0x7FFu; s.conj = (gInfo[gl] & 0x800u) != 0;
+#else
         for (int gl = 0; gl < ng; gl++) {
             SampleGeom s;
             if (!(listed && sample_geom(sR[gl], icp, irp, P, sCls[gl], b.nBx, b.nBy, b.nBz, s))) continue;
             const unsigned idx = (unsigned)atomicAdd(&hCnt[hash_find(hKey, s.key)], 1);
+#endif
             // the value of this pixel for the group: (img * sum of the members' ramps) * ctf * w, T: n * ctf^2 * w
             const int m0 = sM0[gl], m1 = sM0[gl + 1];
             float2 S = make_float2(0.f, 0.f);
@@ -362,6 +397,9 @@ __global__ __launch_bounds__(kBinThreads) void k_bin(BinArgs b)
             b.recA[idx] = make_uint4(__float_as_uint(s.xd), __float_as_uint(s.yd), __float_as_uint(s.zd), s.cell);
             float* rb = b.recB + 3 * (size_t)idx;
             rb[0] = vre * gF; rb[1] = vim * gF; rb[2] = tval * gT;
+#if THX_BIN_KEEP
+            __builtin_amdgcn_sched_barrier(0);   // one group's record at a time: the unrolled bodies must not pile their loads up in registers
+#endif
         }
     }
     bin_flush_list(b, lKey, lVal, regionBase, lN, &sFlushBase);
