@@ -722,7 +722,8 @@ typedef struct thx_classify_view {
     const float *uC, *uR, *uT;              /* scan weights [nImg][nK], [nK][nImg][nR], [nK][nImg][nT] */
     const double *r, *t, *wR, *wT, *topR, *topT;   /* filter state after the local phases */
     const float *vols, *cells, *F, *T;      /* [nK] projector FTs, cell-packed copies, accumulators after reconstruct */
-    const float *maps, *mapsMAP;            /* [nK][N]^3 MAP-off / MAP-on maps of the last iteration */
+    const float *maps, *mapsMAP;            /* [nK][N]^3 MAP-off / MAP-on maps of the last iteration (a class no image of the half has
+                                               gone to keeps its reference and its previous -- initially zero -- maps) */
 } thx_classify_view;
 /* optional trace of the following iterations (DEVICE buffers, any may be NULL; copied; NULL struct = off): what the stage-level
  * parity test holds against the oracle */

@@ -210,3 +210,51 @@ def test_native_classification_refresh_and_errors(dev):
     nat.iterate()
     assert nat.stats().iterations == 2
     nat.close()
+
+
+def test_native_classification_forced_one_rank_reduce(dev, knob_env):
+    """the per-class integer half-set reduce of the classification driver (thx_reco_allreduce_acc_class: sphere rows of ONE class of
+    the [nK][vol][2] F | [nK][vol] T session buffer packed, ncclAllReduce(int64), unpacked) on a forced one-rank communicator:
+    the iteration with the communicator must equal the iteration without it bit for bit -- which also shows that class k's
+    pack / unpack addresses class k's rows and nothing else; and the reduce called directly leaves the other classes untouched"""
+    from thunder_amd import capi, synth
+    from thunder_amd.capi import ptr, stream_ptr
+    from thunder_amd.native import Comm, NativeClassify
+    knob_env("THX_COMM_FORCE", "1")
+    comm = Comm(0, 1, lambda uid: uid)
+    N, K, nImg, nR, nT = 32, 3, 48, 96, 4
+    P = 2 * N
+    rng = np.random.default_rng(8)
+    quat, shifts = T(synth.random_quats(nR, rng), dev), T(rng.normal(0, 1, (nT, 2)), dev)
+    refs = T(np.stack([synth.blob_map(N, seed=15 + k, nblob=6) for k in range(K)]), dev)
+    out = []
+    for hemi in (None, comm):
+        nat = NativeClassify(N, K, nImg, nR, nT, 8, mLR=16, mLT=4, nPhase=1, mReco=5, hemi=hemi, seed=99)
+        nM = nat.stats().nPxlM
+        g = torch.Generator(device=dev).manual_seed(4)
+        datM = torch.view_as_complex(torch.randn((nImg, nM, 2), device=dev, generator=g)).contiguous()
+        ctfM = torch.rand((nImg, nM), device=dev, generator=g) * 2 - 1
+        sigM = torch.full((nImg, nM), -0.5, device=dev)
+        w = torch.full((nImg,), 0.2, device=dev)
+        nat.set_grid(quat, shifts); nat.set_particles(datM, ctfM, sigM, w); nat.set_references(refs)
+        cap = nat.capture()
+        nat.iterate()
+        torch.cuda.synchronize()
+        v = nat.view()
+        out.append((cap["Fraw"].clone(), cap["Traw"].clone(), nat.fetch(v.maps, np.float32, (K, N, N, N)), nat.fetch(v.cls, np.int32, (nImg,))))
+        nat.close()
+    assert out[0][0].abs().max().item() > 0
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
+    # the reduce of class 1 on its own: a buffer of distinct integers comes back unchanged, classes 0 and 2 included
+    volN = P * P * (P // 2 + 1)
+    nbytes = capi.load().thx_insert_acc_bytes(P, K)
+    assert nbytes == K * volN * 3 * 8
+    acc = torch.arange(K * volN * 3, dtype=torch.int64, device=dev) * 7 - 12345
+    acc0 = acc.clone()
+    ws = torch.empty(capi.load().thx_reco_allreduce_acc_workspace(P, N // 2 - 2, 2), dtype=torch.uint8, device=dev)
+    for k in range(K):
+        capi.call("thx_reco_allreduce_acc_class", comm.handle, ptr(acc), K, k, None, None, P, N // 2 - 2, 2, ptr(ws), stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(acc, acc0)
+    comm.close()

@@ -317,10 +317,13 @@ int reconstruct_classes(thx_classify* h, hipStream_t st)
     hipLaunchKernelGGL(k_count_cls, dim3(blocks_for(h->nImg)), dim3(256), 0, st, h->clsCount, h->cls, h->nImg, h->nK);
     THX_LAUNCH_CHECK();
     THX_CHECK(hipMemcpyAsync(h->clsCountHost, h->clsCount, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
+    // T(0,0,0) of every class after the half-set reduce: the sum of w ctf(0)^2 over every draw any rank of the half sent there
+    float t0[16];
+    THX_CHECK(hipMemcpy2DAsync(t0, sizeof(float), h->T, volN * sizeof(float), sizeof(float), (size_t)h->nK, hipMemcpyDeviceToHost, st));
     THX_CHECK(hipStreamSynchronize(st));
     for (int k = 0; k < h->nK; k++) {
         h->lastRounds[2 * k] = h->lastRounds[2 * k + 1] = 0;
-        if (h->clsCountHost[k] == 0 && !h->hemi) continue;   // an empty class keeps its reference (T(0,0,0) = 0: nothing to normalise)
+        if (!(t0[k] > 0.f)) continue;   // a class no image of the half went to keeps its reference (sf = 1 / T(0,0,0) has nothing to normalise)
         float* F = h->F + (size_t)k * volN * 2;
         float* T = h->T + (size_t)k * volN;
         THX_RC(thx_normalise_tf_dev(F, T, h->P, st));
@@ -406,6 +409,8 @@ int thx_classify_create(thx_classify** out, const thx_classify_config* cfg, thx_
         }
         THX_RC(dalloc(h, &h->F, (size_t)c.nK * volN * 2)); THX_RC(dalloc(h, &h->T, (size_t)c.nK * volN));
         THX_RC(dalloc(h, &h->maps, (size_t)c.nK * mapN)); THX_RC(dalloc(h, &h->mapsX, (size_t)c.nK * mapN));
+        THX_CHECK(hipMemset(h->maps, 0, (size_t)c.nK * mapN * sizeof(float)));    // (the maps of a class no image went to stay zero)
+        THX_CHECK(hipMemset(h->mapsX, 0, (size_t)c.nK * mapN * sizeof(float)));
         {
             void* q = nullptr;
             hipError_t e = hipMalloc(&q, thx_insert_acc_bytes(h->P, c.nK));
