@@ -9,12 +9,12 @@
 // instruction-bound.  Here the two sides are decoupled by a sort through HBM, 28 bytes per sample each way:
 //   k_bin  (image-major): one thread per listed pixel, all groups of the image's draws; every sample is computed ONCE at full
 //          lane occupancy -- exact position, cell, fractional offsets, value -- and written as a record into the segment of its
-//          brick.  A segment = the records one (256-pixel region, 8 groups) pass sends to one 16 x 16 x 8 brick of cell origins;
+//          brick.  A segment = the records one (256-pixel region, 8 groups) pass sends to one 16 x 8 x 8 brick of cell origins;
 //          the pass counts per brick in an LDS hash table, lays its segments out from its STATIC place in the record buffer (no
 //          global atomic per pass: one returning atomic on one address per pass serialised the chip), recomputes and scatters;
 //          the descriptors collect in LDS and take table space with one atomic per workgroup.
 //   sort   the segment descriptors (not the records) by brick: rocPRIM radix sort of ~1/130 of the record count.
-//   k_acc  (brick-major): a workgroup takes ~16 k records of consecutive bricks, accumulates each brick's 17 x 17 x 9 voxels in
+//   k_acc  (brick-major): a workgroup takes ~16 k records of consecutive bricks, accumulates each brick's 17 x 9 x 9 voxels in
 //          LDS as 64-bit integers over ALL the images of the chunk, and flushes a brick once.
 // No window geometry, no shear, no candidate tests, no far-group special case: a sample's brick is a shift of its cell origin.
 // Bounds: k_acc the LDS atomic unit (24 ds_add_u64 per record: 0.73 of its rate); k_bin writes its records at about
@@ -38,10 +38,24 @@ namespace thx {
 #define THX_BIN_KEEP 1   // 1: k_bin keeps a pass's sample geometry and hash slots in registers between its count and scatter phases
                          // (168 VGPRs, 3 waves per SIMD instead of 119 / 4, and still 3.2 % faster over the insertion call; 0: recompute)
 #endif
-constexpr int kBLx = 4, kBLy = 4, kBLz = 3;                       // log2 of the brick edges in cell origins
-constexpr int kBx = 1 << kBLx, kBy = 1 << kBLy, kBz = 1 << kBLz;  // 16 x 16 x 8
+#ifndef THX_BRICK_LX
+#define THX_BRICK_LX 4
+#endif
+#ifndef THX_BRICK_LY
+#define THX_BRICK_LY 3    // 16 x 8 x 8 cell origins: 33 KB of LDS per brick, FOUR workgroups of k_acc per CU -- measured against 16 x 16 x 8 /
+                          // two per CU (-3 .. -5 % on the insertion), 16 x 16 x 4, 8 x 16 x 8 (equal), 16 x 4 x 8, 8 x 8 x 8, 16 x 8 x 4 (all slower)
+#endif
+#ifndef THX_BRICK_LZ
+#define THX_BRICK_LZ 3
+#endif
+#ifndef THX_ACC_WGS
+#define THX_ACC_WGS 4    // workgroups of k_acc per CU the launch bounds ask for (their LDS bricks must fit 160 KB together)
+#endif
+static_assert(THX_BRICK_LX <= 4 && THX_BRICK_LY <= 4 && THX_BRICK_LZ <= 3, "a record's cell field holds 4 + 4 + 3 bits");
+constexpr int kBLx = THX_BRICK_LX, kBLy = THX_BRICK_LY, kBLz = THX_BRICK_LZ;   // log2 of the brick edges in cell origins
+constexpr int kBx = 1 << kBLx, kBy = 1 << kBLy, kBz = 1 << kBLz;  // 16 x 8 x 8
 constexpr int kVx = kBx + 1, kVy = kBy + 1, kVz = kBz + 1;        // voxels a brick's cells reach
-constexpr int kBrickVox = kVx * kVy * kVz;                        // 2601 x 24 B = 62.4 KB of LDS: two workgroups per CU
+constexpr int kBrickVox = kVx * kVy * kVz;                        // 1377 x 24 B = 33 KB of LDS: four workgroups per CU
 constexpr int kBinThreads = 256;                                  // pixels per region
 constexpr int kPassGroups = 8;                                    // groups per pass of k_bin
 constexpr int kHash = kBinThreads * kPassGroups;                  // >= the distinct bricks of a pass, whatever the input
@@ -450,7 +464,7 @@ __device__ __forceinline__ int lower_bound_u32(const unsigned* __restrict__ cum,
 }
 
 // workgroup w owns the segments that START in records [w kAccSpan, (w + 1) kAccSpan) of the sorted order
-__global__ __launch_bounds__(kAccThreads, 2) void k_acc(AccArgs q)
+__global__ __launch_bounds__(kAccThreads, THX_ACC_WGS) void k_acc(AccArgs q)
 {
     __shared__ long long sRe[kBrickVox], sIm[kBrickVox], sT[kBrickVox];
     __shared__ unsigned sOff[kAccStage], sExc[kAccStage + 1], sWaveTot[kAccThreads / 64];
