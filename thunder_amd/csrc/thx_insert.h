@@ -49,7 +49,7 @@ __device__ __forceinline__ void acc_add(long long* F, long long* T, long gi, lon
 }
 
 // Brick-sorted insertion of nImg images (thx_insert_sort.hip): every (listed pixel, group of draws) sample is computed once,
-// binned by the 16 x 16 x 8 brick of the volume its trilinear cell starts in, and the bricks are accumulated in LDS over ALL the
+// binned by the 16 x 8 x 8 brick of the volume its trilinear cell starts in, and the bricks are accumulated in LDS over ALL the
 // images of a chunk before they are flushed.  `a` carries the chunk-independent arguments (image-indexed pointers at image 0).
 int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const int* gexp, long long* accF, long long* accT, int nImg);
 
