@@ -61,7 +61,10 @@ constexpr int kPassGroups = 8;                                    // groups per 
 constexpr int kHash = kBinThreads * kPassGroups;                  // >= the distinct bricks of a pass, whatever the input
 constexpr int kRampU = 16;                                        // unique shifts whose ramps a thread keeps in registers
 constexpr int kAccThreads = 512;
-constexpr unsigned kAccSpan = 16384;                              // records per workgroup of k_acc
+#ifndef THX_ACC_SPAN
+#define THX_ACC_SPAN 16384
+#endif
+constexpr unsigned kAccSpan = THX_ACC_SPAN;                              // records per workgroup of k_acc
 constexpr int kAccStage = kAccThreads;                             // segment descriptors staged in LDS at a time (one per thread)
 
 struct BinArgs {
