@@ -59,7 +59,10 @@ constexpr int kBrickVox = kVx * kVy * kVz;                        // 1377 x 24 B
 constexpr int kBinThreads = 256;                                  // pixels per region
 constexpr int kPassGroups = 8;                                    // groups per pass of k_bin
 constexpr int kHash = kBinThreads * kPassGroups;                  // >= the distinct bricks of a pass, whatever the input
-constexpr int kRampU = 16;                                        // unique shifts whose ramps a thread keeps in registers
+#ifndef THX_RAMP_U
+#define THX_RAMP_U 16
+#endif
+constexpr int kRampU = THX_RAMP_U;                                        // unique shifts whose ramps a thread keeps in registers
 constexpr int kAccThreads = 512;
 #ifndef THX_ACC_SPAN
 #define THX_ACC_SPAN 16384
@@ -308,18 +311,24 @@ __global__ __launch_bounds__(kBinThreads) void k_bin(BinArgs b)
 #if THX_BIN_KEEP
         // a thread's samples stay in registers for the scatter below (geometry and hash slot once per sample; the loops are
         // unrolled over the pass's 8 groups so that the arrays are registers)
+#if THX_BIN_KEEP == 1
         float gXd[kPassGroups], gYd[kPassGroups], gZd[kPassGroups];
+#endif
         unsigned gInfo[kPassGroups];   // cell in brick (11 bits) | conj << 11 | hash slot << 12 | valid << 31; 0: no sample
 #pragma unroll
         for (int gl = 0; gl < kPassGroups; gl++) {
             gInfo[gl] = 0u;
+#if THX_BIN_KEEP == 1
             gXd[gl] = gYd[gl] = gZd[gl] = 0.f;
+#endif
             if (gl < ng) {
                 SampleGeom s;
                 if (listed && sample_geom(sR[gl], icp, irp, P, sCls[gl], b.nBx, b.nBy, b.nBz, s)) {
                     const int h = hash_insert(hKey, s.key);
                     atomicAdd(&hCnt[h], 1);
+#if THX_BIN_KEEP == 1
                     gXd[gl] = s.xd; gYd[gl] = s.yd; gZd[gl] = s.zd;
+#endif
                     gInfo[gl] = s.cell | (s.conj ? 0x800u : 0u) | ((unsigned)h << 12) | 0x80000000u;
                 }
             }
@@ -381,7 +390,11 @@ __global__ __launch_bounds__(kBinThreads) void k_bin(BinArgs b)
             if (!(gInfo[gl] & 0x80000000u)) continue;
             const unsigned idx = (unsigned)atomicAdd(&hCnt[(gInfo[gl] >> 12) & (kHash - 1)], 1);
             SampleGeom s;
+#if THX_BIN_KEEP == 1
             s.xd = gXd[gl]; s.yd = gYd[gl]; s.zd = gZd[gl]; s.cell = gInfo[gl] & 0x7FFu; s.conj = (gInfo[gl] & 0x800u) != 0;
+#else   // 2: only the hash slot is kept, the geometry is computed again
+            (void)sample_geom(sR[gl], icp, irp, P, sCls[gl], b.nBx, b.nBy, b.nBz, s);
+#endif
 #else
         for (int gl = 0; gl < ng; gl++) {
             SampleGeom s;
