@@ -35,8 +35,10 @@
 namespace thx {
 
 #ifndef THX_BIN_KEEP
-#define THX_BIN_KEEP 1   // 1: k_bin keeps a pass's sample geometry and hash slots in registers between its count and scatter phases
-                         // (168 VGPRs, 3 waves per SIMD instead of 119 / 4, and still 3.2 % faster over the insertion call; 0: recompute)
+#define THX_BIN_KEEP 2   // k_bin between its count and scatter phases keeps, per sample, in registers -- 2: the hash slot of its brick (no
+                         // hash_find; 125 VGPRs with 12 ramp slots: 4 waves per SIMD); 1: slot and geometry (no second sample_geom either,
+                         // 160 - 168 VGPRs: 3 waves per SIMD); 0: nothing (recompute, look up).  Insertion stage of a 20 000-particle
+                         // iteration, same box: 312 / 307 / 303 ms for 0 / 1 / 2 at 12 ramp slots
 #endif
 #ifndef THX_BRICK_LX
 #define THX_BRICK_LX 4
@@ -60,7 +62,7 @@ constexpr int kBinThreads = 256;                                  // pixels per 
 constexpr int kPassGroups = 8;                                    // groups per pass of k_bin
 constexpr int kHash = kBinThreads * kPassGroups;                  // >= the distinct bricks of a pass, whatever the input
 #ifndef THX_RAMP_U
-#define THX_RAMP_U 16
+#define THX_RAMP_U 12   // (mLT = 9 in the reference's configuration; images with more unique shifts take the member-by-member path)
 #endif
 constexpr int kRampU = THX_RAMP_U;                                        // unique shifts whose ramps a thread keeps in registers
 constexpr int kAccThreads = 512;
