@@ -115,3 +115,35 @@ def test_integration_stub_matches_interface_h():
     header = open(os.path.join(root, "include", "thunder_amd.h")).read()
     for name in sorted(set(re.findall(r"\b(thx_\w+)\s*\(", stub))):
         assert re.search(r"\b%s\s*\(" % name, header), name
+
+
+def test_ctypes_struct_mirrors_match_the_header(tmp_path):
+    """thunder_amd/capi.py restates the C structs of include/thunder_amd.h field by field (ctypes): a C probe compiled against the
+    header prints sizeof and every offsetof, which must equal the ctypes layout -- a field added on one side only would otherwise
+    shift every later argument silently"""
+    import ctypes as C
+    import os
+    import subprocess
+    from thunder_amd import capi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pairs = [("thx_refine_config", capi.RefineConfig), ("thx_refine_stats", capi.RefineStats), ("thx_refine_view", capi.RefineView),
+             ("thx_refine_capture", capi.RefineCapture), ("thx_classify_config", capi.ClassifyConfig), ("thx_classify_stats", capi.ClassifyStats),
+             ("thx_classify_view", capi.ClassifyView), ("thx_classify_capture", capi.ClassifyCapture), ("thx_ctf_attr", capi.CtfAttr)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "thunder_amd.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (cname, fname))
+        lines.append('printf("\\n");')
+    lines += ['return 0;', '}']
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "probe")
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(root, "include"), str(src), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    assert len(out) == len(pairs)
+    for line, (cname, cls) in zip(out, pairs):
+        tok = line.split()
+        assert tok[0] == cname
+        want = [C.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
+        assert [int(x) for x in tok[1:]] == want, (cname, tok[1:], want)
