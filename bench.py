@@ -11,7 +11,8 @@ Workload = the configuration BASELINE.json's metric is quoted on: 100 000 synthe
 It fits one GPU (about 125 GB of particle data + 15 GB of volumes in 288 GB), so N = 1 runs all of it; with N > 1 the same
 100 000 particles are sharded over the ranks (N = 8 is BASELINE configs[2]: 12 500 per GPU) -- total work fixed:
 "scaling": "strong".  `--particles 10000` gives configs[1].
-`--classification` times BASELINE configs[3] instead: one whole K = 4 classification iteration on one GPU's share of the images.
+`--classification` times BASELINE configs[3] instead: one whole K = 4 classification iteration on one GPU's share of the images,
+sequenced by the native driver thx_classify_iterate (thunder_amd/csrc/thx_classify.hip; `--python-sequencing` for the A/B form).
 Launch: `python bench.py` (N=1) or
   `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`
 Prints ONE JSON line on rank 0.
