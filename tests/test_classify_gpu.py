@@ -30,26 +30,8 @@ def _rel(a, b):
 
 
 def _case(O, N, K, nImg, nR, nT, seed):
-    """K blob references, images = CTF x slice of a random class at a scanned rotation x ramp of a scanned shift + noise, as rows
-    on the rL = 0 list"""
-    from thunder_amd import synth
-    rng = np.random.default_rng(seed)
-    pf, P, rU = 2, 2 * N, N // 2 - 2
-    refs = np.stack([synth.blob_map(N, seed=seed + 10 + k, nblob=10) for k in range(K)])
-    vols = [O.set_projectee(refs[k], pf) for k in range(K)]
-    plM = O.pixel_list(N, rU, 0, pf)
-    quat = synth.random_quats(nR, rng)
-    shifts = np.ascontiguousarray(rng.normal(0, 1.5, size=(nT, 2)))
-    cls_true, r_true, t_true = rng.integers(0, K, nImg), rng.integers(0, nR, nImg), rng.integers(0, nT, nImg)
-    attr = synth.ctf_params(nImg, rng)
-    ctfM = np.stack([O.ctf(1.32, *attr[l], N, plM["iCol"], plM["iRow"]) for l in range(nImg)])
-    datM = np.stack([O.project(vols[cls_true[l]], P, pf, O.rotate3D(quat[r_true[l]]), plM["iCol"], plM["iRow"]) * ctfM[l]
-                     * O.translate(np.float32(shifts[t_true[l], 0]), np.float32(shifts[t_true[l], 1]), N, plM["iCol"], plM["iRow"])
-                     for l in range(nImg)]).astype(np.complex64)
-    sd = 0.5 * float(np.sqrt(np.mean(np.abs(datM) ** 2)))
-    datM = (datM + (rng.standard_normal(datM.shape) + 1j * rng.standard_normal(datM.shape)) * (sd / np.sqrt(2))).astype(np.complex64)
-    sigM = np.full(datM.shape, np.float32(-0.5 / (sd * sd / 2)), np.float32)
-    return dict(refs=refs, vols=vols, plM=plM, quat=quat, shifts=shifts, cls_true=cls_true, r_true=r_true, datM=datM, ctfM=ctfM, sigM=sigM)
+    import _classify_util as U
+    return U.make_case(O, N, K, nImg, nR, nT, seed)
 
 
 @pytest.mark.parametrize("N,K,nImg,nR,nT,rScan,mLR,mLT,nPhase,mReco", [(32, 2, 128, 150, 6, 9, 40, 5, 2, 20), (32, 3, 150, 300, 4, 8, 24, 4, 1, 16)])
@@ -258,3 +240,38 @@ def test_native_classification_forced_one_rank_reduce(dev, knob_env):
     torch.cuda.synchronize()
     assert torch.equal(acc, acc0)
     comm.close()
+
+
+def test_native_classification_against_committed_fixture(dev):
+    """fixture-only variant: tests/golden/classify_n16.npz holds the inputs and the oracle's scan weights, classes and support
+    points of a K = 2 iteration at N = 16 (generator: tests/golden/make_golden_classify.py); thx_classify_iterate on the same inputs
+    must reproduce them -- weights at the scan's bar, classes and resampled grid points exactly (no weight of this case sits
+    within rounding of a threshold)"""
+    import os
+    import sys
+    from thunder_amd.native import NativeClassify
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden_classify as G
+    g = np.load(os.path.join(here, "golden", "classify_n16.npz"))
+    c = G.CFG
+    nImg, K, nR, nT, mLR, mLT = c["nImg"], c["K"], c["nR"], c["nT"], c["mLR"], c["mLT"]
+    nat = NativeClassify(c["N"], K, nImg, nR, nT, c["rScan"], rL=c["rL"], mLR=mLR, mLT=mLT, nPhase=1, mReco=4, batch=nImg, seed=c["seed"],
+                         peakFactorR=c["peakFactorR"], peakFactorC=c["peakFactorC"], scan_min=(c["minK"], c["minS"]))
+    d = [T(g[k], dev) for k in ("datM", "ctfM", "sigM")]
+    w = torch.full((nImg,), 0.25, device=dev)
+    nat.set_grid(T(g["quat"], dev), T(g["shifts"], dev))
+    nat.set_particles(d[0], d[1], d[2], w)
+    nat.set_references(T(g["refs"], dev))
+    cap = nat.capture()
+    nat.iterate()
+    torch.cuda.synchronize()
+    v = nat.view()
+    tol = max(6e-5 * float(np.abs(g["base"]).max()), 3e-4)
+    np.testing.assert_allclose(nat.fetch(v.uC, np.float32, (nImg, K)), g["wC"], rtol=tol)
+    np.testing.assert_allclose(nat.fetch(v.uR, np.float32, (K, nImg, nR)), g["wR"], rtol=tol, atol=1e-30)
+    np.testing.assert_allclose(nat.fetch(v.uT, np.float32, (K, nImg, nT)), g["wT"], rtol=tol, atol=1e-30)
+    assert np.array_equal(nat.fetch(v.cls, np.int32, (nImg,)), g["cls"])
+    r0, t0 = cap["r0"].cpu().numpy(), cap["t0"].cpu().numpy()
+    assert np.abs(r0 - g["quat"][g["srcR"]]).max() <= 1e-13 and np.array_equal(t0, g["t0"])
+    nat.close()

@@ -109,3 +109,23 @@ def test_resample_and_peak(oracle):
     expect = n * u2 / u2.sum()
     assert np.all(np.abs(cnt - expect) <= 1.0 + 1e-9)          # systematic resampling: counts within 1 of n * p
     assert np.allclose(wo, (1 / u2[idx]) / (1 / u2[idx]).sum())
+
+
+def test_classification_stages_match_committed_fixture():
+    """tests/golden/classify_n16.npz against a fresh run of its generator: the oracle's scan weights over K classes, the class of
+    every image and the support points of the local search (replayed Philox draws) have not moved"""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden_classify as G
+    from oracle import oracle as O
+    g = np.load(os.path.join(here, "golden", "classify_n16.npz"))
+    out = G.compute(O)
+    assert set(out) == set(g.files)
+    for k in g.files:
+        if k in ("wC", "wR", "wT", "base", "k123"):
+            np.testing.assert_allclose(out[k], g[k], rtol=1e-6, atol=1e-30, err_msg=k)   # (expf / the compiler's reassociation-free sums: same binary, same bits here)
+        else:
+            assert np.array_equal(out[k], g[k]), k
+    assert (g["cls"] == g["cls_true"]).all()

@@ -218,7 +218,7 @@ class NativeClassify:
 
     def __init__(self, N, K, nImg, nR, nT, rScan, rL=2, pf=2, mLR=125, mLT=9, nPhase=3, mReco=100, batch=10240, pixel_order=0,
                  wg_per_cu=2, refresh=False, pixelSize=1.32, transS=2.0, transQ=0.05, pfL=2.0, pfS=0.5, peakFactorR=1e-3,
-                 peakFactorC=1.0 - 1e-2, seed=20240607, hemi=None, nImgHemi=0):
+                 peakFactorC=1.0 - 1e-2, seed=20240607, hemi=None, nImgHemi=0, scan_min=None):
         cfg = ClassifyConfig()
         cfg.N, cfg.pf, cfg.nK, cfg.nImg, cfg.nImgHemi = N, pf, K, nImg, nImgHemi
         cfg.nR, cfg.nT, cfg.rScan, cfg.rL = nR, nT, rScan, rL
@@ -226,7 +226,7 @@ class NativeClassify:
         cfg.pixelOrder, cfg.wgPerCU, cfg.refresh, cfg.pixelSize = pixel_order, wg_per_cu, 1 if refresh else 0, pixelSize
         cfg.transS, cfg.transQ, cfg.pfL, cfg.pfS = transS, transQ, pfL, pfS
         cfg.peakFactorR, cfg.peakFactorC = peakFactorR, peakFactorC
-        cfg.scanMinK, cfg.scanMinS = scan_min_spread(nR)
+        cfg.scanMinK, cfg.scanMinS = scan_min_spread(nR) if scan_min is None else scan_min   # (minK, minS) of thx_pf_scan_support_dev
         cfg.seed = seed
         self.cfg = cfg
         h = C.c_void_p()
