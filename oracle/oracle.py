@@ -963,3 +963,54 @@ class Iteration:
         out.update(fsc=fsc_, maps=mapsX, rounds=rounds, sig=self.sig.copy(), offset=self.offset.copy(), topR=self.topR.copy(),
                    q=self.q.copy(), t=self.t.copy(), vols=[v for v in self.vols], img=self.img)
         return out
+
+
+class ClassifyStages:
+    """The first three stages of one K-class classification iteration with a global search, chained as the reference runs them
+    (MODE_3D, C1, no CTF search), stage boundaries of thx_classify_iterate (thunder_amd/csrc/thx_classify.hip):
+
+      scan      src/Optimiser.cpp:756-894    for every class k: slices of reference k at the nR scanned rotations (Projector::project at
+                                             r = rScan), likelihood of every image at every (rotation, shift), weights and the running
+                                             baseline carried from class to class (expect_global above)
+      classes   :925-952                     setUC / keepHalfHeightPeak(PAR_C) / resample(k, PAR_C) / rand(cls)  (pf_class_select)
+      support   :953-1079                    keepHalfHeightPeak(PAR_R), resample(mLR, PAR_R), resample(mLT, PAR_T), calVari, minimum
+                                             spread of the scanning phase  (pf_scan_support), with the weights of the image's class
+
+    Random draws are inputs: `ph` offers draw_u4 / shuffle_ranks(seed, image, call, purpose, index) (tests hand in their numpy replica
+    of the device's Philox streams, tests/_philox.py); the driver's numbering: call 1 = class selection (purposes 6 / 7 / 8), call 2 =
+    support points (2 / 3 rotations, 4 / 5 shifts), image = index in the rank's shard."""
+
+    def __init__(self, N, K, vols, quat, shifts, rScan, rL, ph, pf=2):
+        self.N, self.K, self.pf, self.P = N, K, pf, N * pf
+        self.vols, self.quat, self.shifts, self.ph = vols, f64(quat), f64(shifts), ph
+        self.plS = pixel_list(N, rScan, rL, pf)
+
+    def scan(self, datS, ctfS, sigS):
+        """datS / ctfS / sigS: image-major rows [nImg][nPxlS] on the scan's pixel list -> wC [nImg][K], wR [K][nImg][nR],
+        wT [K][nImg][nT], base [nImg] (uniform priors: Particle::reset(nR, nT))"""
+        N, K, P, pf, plS = self.N, self.K, self.P, self.pf, self.plS
+        nImg, nR, nT = datS.shape[0], len(self.quat), len(self.shifts)
+        mats = np.stack([rotate3D(q) for q in self.quat])
+        traP = np.stack([translate(np.float32(s[0]), np.float32(s[1]), N, plS["iCol"], plS["iRow"]) for s in self.shifts])
+        dat_pm, ctf_pm, sig_pm = (np.ascontiguousarray(a.T) for a in (datS, ctfS, sigS))
+        wC, wR, wT = np.zeros((nImg, K), np.float32), np.zeros((K, nImg, nR), np.float32), np.zeros((K, nImg, nT), np.float32)
+        base = np.full(nImg, np.nan, np.float32)           # "unset", :737-745
+        pR, pT = np.full((nImg, nR), 1.0 / nR), np.full((nImg, nT), 1.0 / nT)
+        for k in range(K):
+            rotP = np.stack([project(self.vols[k], P, pf, m, plS["iCol"], plS["iRow"]) for m in mats])
+            expect_global(rotP, traP, dat_pm, ctf_pm, sig_pm, K, k, pR, pT, wC, wR, wT, base)
+        return wC, wR, wT, base
+
+    def classes(self, uC, seed, peakFactorC, call=1):
+        ph, (nImg, K) = self.ph, uC.shape
+        return np.asarray([pf_class_select(uC[l], np.full(K, 1.0 / K), peakFactorC, ph.shuffle_ranks(seed, l, call, 6, K),
+                                           ph.draw_u4(seed, l, call, 7, 0)[0] / K, min(int(ph.draw_u4(seed, l, call, 8, 0)[0] * K), K - 1))
+                           for l in range(nImg)], np.int32)
+
+    def support(self, uR, uT, cls, l, seed, peakFactorR, mLR, mLT, minK, minS, call=2):
+        """support points of image l from the scan weights of its class -> (pf_scan_support's dict, the rotation shuffle's ranks)"""
+        ph, nR, nT = self.ph, len(self.quat), len(self.shifts)
+        rankR, rankT = ph.shuffle_ranks(seed, l, call, 2, nR), ph.shuffle_ranks(seed, l, call, 4, nT)
+        ws = pf_scan_support(self.quat, self.shifts, uR[cls[l], l], uT[cls[l], l], peakFactorR, mLR, mLT, rankR,
+                             ph.draw_u4(seed, l, call, 3, 0)[0] / mLR, rankT, ph.draw_u4(seed, l, call, 5, 0)[0] / mLT, minK, minS)
+        return ws, rankR

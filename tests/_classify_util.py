@@ -35,32 +35,6 @@ def sub_rows(plM, plS):
     return np.asarray([posM[(int(i), int(j))] for i, j in zip(plS["iCol"], plS["iRow"])])
 
 
-def oracle_scan(O, N, K, vols, quat, shifts, plS, datS, ctfS, sigS):
-    """the scanning phase over the K classes with uniform priors: wC [nImg][K], wR [K][nImg][nR], wT [K][nImg][nT], base [nImg]"""
-    pf, P = 2, 2 * N
-    nImg, nR, nT = datS.shape[0], len(quat), len(shifts)
-    mats = np.stack([O.rotate3D(q) for q in quat])
-    traP = np.stack([O.translate(np.float32(s[0]), np.float32(s[1]), N, plS["iCol"], plS["iRow"]) for s in shifts])
-    dat_pm, ctf_pm, sig_pm = (np.ascontiguousarray(a.T) for a in (datS, ctfS, sigS))
-    wC, wR, wT = np.zeros((nImg, K), np.float32), np.zeros((K, nImg, nR), np.float32), np.zeros((K, nImg, nT), np.float32)
-    base = np.full(nImg, np.nan, np.float32)
-    pR, pT = np.full((nImg, nR), 1.0 / nR), np.full((nImg, nT), 1.0 / nT)
-    for k in range(K):
-        rotP = np.stack([O.project(vols[k], P, pf, m, plS["iCol"], plS["iRow"]) for m in mats])
-        O.expect_global(rotP, traP, dat_pm, ctf_pm, sig_pm, K, k, pR, pT, wC, wR, wT, base)
-    return wC, wR, wT, base
-
-
-def oracle_class_select(O, uC, seed, peakFactorC, call=1):
-    nImg, K = uC.shape
-    return np.asarray([O.pf_class_select(uC[l], np.full(K, 1.0 / K), peakFactorC, PH.shuffle_ranks(seed, l, call, 6, K),
-                                         PH.draw_u4(seed, l, call, 7, 0)[0] / K, min(int(PH.draw_u4(seed, l, call, 8, 0)[0] * K), K - 1))
-                       for l in range(nImg)], np.int32)
-
-
-def oracle_scan_support(O, quat, shifts, uR, uT, cls, l, seed, peakFactorR, mLR, mLT, minK, minS, call=2):
-    nR, nT = len(quat), len(shifts)
-    rankR, rankT = PH.shuffle_ranks(seed, l, call, 2, nR), PH.shuffle_ranks(seed, l, call, 4, nT)
-    ws = O.pf_scan_support(quat, shifts, uR[cls[l], l], uT[cls[l], l], peakFactorR, mLR, mLT, rankR, PH.draw_u4(seed, l, call, 3, 0)[0] / mLR,
-                           rankT, PH.draw_u4(seed, l, call, 5, 0)[0] / mLT, minK, minS)
-    return ws, rankR
+def stages(O, N, K, vols, quat, shifts, rScan, rL):
+    """oracle.ClassifyStages (scan -> classes -> support points) fed with the numpy replica of the device's Philox streams"""
+    return O.ClassifyStages(N, K, vols, quat, shifts, rScan, rL, PH)

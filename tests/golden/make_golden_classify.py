@@ -22,16 +22,14 @@ def compute(O):
     import _classify_util as U
     c = CFG
     cs = U.make_case(O, c["N"], c["K"], c["nImg"], c["nR"], c["nT"], c["case_seed"], noise=0.3)
-    plS = O.pixel_list(c["N"], c["rScan"], c["rL"], 2)
-    s2m = U.sub_rows(cs["plM"], plS)
-    wC, wR, wT, base = U.oracle_scan(O, c["N"], c["K"], cs["vols"], cs["quat"], cs["shifts"], plS, cs["datM"][:, s2m], cs["ctfM"][:, s2m],
-                                     cs["sigM"][:, s2m])
-    cls = U.oracle_class_select(O, wC, c["seed"], c["peakFactorC"])
+    st = U.stages(O, c["N"], c["K"], cs["vols"], cs["quat"], cs["shifts"], c["rScan"], c["rL"])
+    s2m = U.sub_rows(cs["plM"], st.plS)
+    wC, wR, wT, base = st.scan(cs["datM"][:, s2m], cs["ctfM"][:, s2m], cs["sigM"][:, s2m])
+    cls = st.classes(wC, c["seed"], c["peakFactorC"])
     r0 = np.zeros((c["nImg"], c["mLR"], 4)); t0 = np.zeros((c["nImg"], c["mLT"], 2))
     srcR = np.zeros((c["nImg"], c["mLR"]), np.int64); k123 = np.zeros((c["nImg"], 3)); s01 = np.zeros((c["nImg"], 2))
     for l in range(c["nImg"]):
-        ws, _ = U.oracle_scan_support(O, cs["quat"], cs["shifts"], wR, wT, cls, l, c["seed"], c["peakFactorR"], c["mLR"], c["mLT"], c["minK"],
-                                      c["minS"])
+        ws, _ = st.support(wR, wT, cls, l, c["seed"], c["peakFactorR"], c["mLR"], c["mLT"], c["minK"], c["minS"])
         r0[l], t0[l], srcR[l], k123[l], s01[l] = ws["q"], ws["t"], ws["srcR"], ws["k"], ws["s"]
     return dict(refs=cs["refs"], quat=cs["quat"], shifts=cs["shifts"], datM=cs["datM"], ctfM=cs["ctfM"], sigM=cs["sigM"], cls_true=cs["cls_true"],
                 wC=wC, wR=wR, wT=wT, base=base, cls=cls, r0=r0, t0=t0, srcR=srcR, k123=k123, s01=s01)

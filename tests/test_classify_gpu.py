@@ -40,9 +40,10 @@ def test_native_classification_stages_against_oracle(oracle, dev, N, K, nImg, nR
     O = oracle
     pf, P, rU, rL, seed = 2, 2 * N, N // 2 - 2, 2, 777001
     cs = _case(O, N, K, nImg, nR, nT, 50 + K)
-    plM, plS = cs["plM"], O.pixel_list(N, rScan, rL, pf)
-    posM = {(int(i), int(j)): k for k, (i, j) in enumerate(zip(plM["iCol"], plM["iRow"]))}
-    s2m = np.asarray([posM[(int(i), int(j))] for i, j in zip(plS["iCol"], plS["iRow"])])
+    import _classify_util as U
+    st_o = U.stages(O, N, K, cs["vols"], cs["quat"], cs["shifts"], rScan, rL)
+    plM, plS = cs["plM"], st_o.plS
+    s2m = U.sub_rows(plM, plS)
     w = np.full(nImg, np.float32(1.0) / np.float32(mReco), np.float32)
     d = dict(datM=T(cs["datM"], dev), ctfM=T(cs["ctfM"], dev), sigM=T(cs["sigM"], dev), w=T(w, dev))
     nat = NativeClassify(N, K, nImg, nR, nT, rScan, rL=rL, pf=pf, mLR=mLR, mLT=mLT, nPhase=nPhase, mReco=mReco, batch=nImg, seed=seed)
@@ -60,15 +61,7 @@ def test_native_classification_stages_against_oracle(oracle, dev, N, K, nImg, nR
     for k in range(K):
         assert _rel(vd[k], cs["vols"][k]) <= 2e-6
     # ---- scan: class after class, the baseline and the weights carried along (src/Optimiser.cpp:756-894) ----
-    mats = np.stack([O.rotate3D(q) for q in cs["quat"]])
-    traP = np.stack([O.translate(np.float32(s[0]), np.float32(s[1]), N, plS["iCol"], plS["iRow"]) for s in cs["shifts"]])
-    dat_pm, ctf_pm, sig_pm = (np.ascontiguousarray(cs[k_][:, s2m].T) for k_ in ("datM", "ctfM", "sigM"))
-    wC, wR, wT = np.zeros((nImg, K), np.float32), np.zeros((K, nImg, nR), np.float32), np.zeros((K, nImg, nT), np.float32)
-    base = np.full(nImg, np.nan, np.float32)
-    pR, pT = np.full((nImg, nR), 1.0 / nR), np.full((nImg, nT), 1.0 / nT)
-    for k in range(K):
-        rotP = np.stack([O.project(cs["vols"][k], P, pf, m, plS["iCol"], plS["iRow"]) for m in mats])
-        O.expect_global(rotP, traP, dat_pm, ctf_pm, sig_pm, K, k, pR, pT, wC, wR, wT, base)
+    wC, wR, wT, base = st_o.scan(cs["datM"][:, s2m], cs["ctfM"][:, s2m], cs["sigM"][:, s2m])
     uC, uR, uT = nat.fetch(v.uC, np.float32, (nImg, K)), nat.fetch(v.uR, np.float32, (K, nImg, nR)), nat.fetch(v.uT, np.float32, (K, nImg, nT))
     tol = max(6e-5 * float(np.abs(base).max()), 3e-4)      # the bar of test_expect_global
     np.testing.assert_allclose(uC, wC, rtol=tol)
@@ -76,18 +69,14 @@ def test_native_classification_stages_against_oracle(oracle, dev, N, K, nImg, nR
     np.testing.assert_allclose(uT, wT, rtol=tol, atol=1e-30)
     # ---- class of every image (:925-952), from the device's class weights with replayed draws: call 1 ----
     cls = nat.fetch(v.cls, np.int32, (nImg,))
-    want = np.asarray([O.pf_class_select(uC[l], np.full(K, 1.0 / K), c.peakFactorC, PH.shuffle_ranks(seed, l, 1, 6, K),
-                                         PH.draw_u4(seed, l, 1, 7, 0)[0] / K, min(int(PH.draw_u4(seed, l, 1, 8, 0)[0] * K), K - 1))
-                       for l in range(nImg)])
+    want = st_o.classes(uC, seed, c.peakFactorC)
     assert np.array_equal(cls, want)
     assert (cls == cs["cls_true"]).mean() >= 0.9
     # ---- support points from the scan posterior of that class (:953-1079): call 2 ----
     r0, t0 = cap["r0"].cpu().numpy(), cap["t0"].cpu().numpy()
     near = 0
     for l in range(nImg):
-        rankR, rankT = PH.shuffle_ranks(seed, l, 2, 2, nR), PH.shuffle_ranks(seed, l, 2, 4, nT)
-        ws = O.pf_scan_support(cs["quat"], cs["shifts"], uR[cls[l], l], uT[cls[l], l], c.peakFactorR, mLR, mLT, rankR,
-                               PH.draw_u4(seed, l, 2, 3, 0)[0] / mLR, rankT, PH.draw_u4(seed, l, 2, 5, 0)[0] / mLT, c.scanMinK, c.scanMinS)
+        ws, rankR = st_o.support(uR, uT, cls, l, seed, c.peakFactorR, mLR, mLT, c.scanMinK, c.scanMinS)
         dR = np.abs(r0[l][:, None, :] - cs["quat"][None, ws["srcR"], :]).max(axis=2)
         same = dR.diagonal() <= 1e-13
         for j in np.nonzero(~same)[0]:     # a draw on its threshold: the neighbour in the shuffled order (test_scan_support_points)
