@@ -513,6 +513,7 @@ int thx_classify_iterate(thx_classify* h, int timed, void* stream)
     THX_REQUIRE(h && h->datM && h->haveGrid && h->haveRefs, "thx_classify_set_grid / set_particles / set_references first");
     hipStream_t st = as_stream(stream);
     h->timed = timed != 0;
+    if (h->events.size() > 4096) THX_RC(resolve_events(h));   // (a caller that never asks for the statistics must not pile events up)
     THX_RC(scan_and_select(h, st));
     THX_RC(local_phases(h, st));
     THX_RC(insertion(h, st));
