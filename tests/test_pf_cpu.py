@@ -129,3 +129,33 @@ def test_classification_stages_match_committed_fixture():
         else:
             assert np.array_equal(out[k], g[k]), k
     assert (g["cls"] == g["cls_true"]).all()
+
+
+def test_classify_stages_properties():
+    """oracle.ClassifyStages on a small seeded case (numpy + oracle only): the scan recovers class, rotation and shift of images that
+    sit on the scanned grid; the class weights are the per-class maxima relative to the best class (one of them is 1); the support
+    points are grid points carrying scan weight, their priors sum to 1, the top point is the scan's best; the minimum spread of the
+    scanning phase bounds k1..k3 and s0, s1 from below; another call id draws other support points from the same weights"""
+    import _classify_util as U
+    from oracle import oracle as O
+    N, K, nImg, nR, nT, rScan, rL, mLR, mLT, seed = 16, 2, 10, 30, 3, 5, 1, 6, 3, 4711
+    cs = U.make_case(O, N, K, nImg, nR, nT, 123, noise=0.2)
+    st = U.stages(O, N, K, cs["vols"], cs["quat"], cs["shifts"], rScan, rL)
+    s2m = U.sub_rows(cs["plM"], st.plS)
+    wC, wR, wT, base = st.scan(cs["datM"][:, s2m], cs["ctfM"][:, s2m], cs["sigM"][:, s2m])
+    assert np.all(np.isfinite(base)) and np.all(wC >= 0) and np.all(wR >= 0) and np.all(wT >= 0)
+    cls = st.classes(wC, seed, 1.0 - 1e-2)
+    assert np.array_equal(cls, cs["cls_true"]) and np.array_equal(cls, wC.argmax(1))
+    assert np.array_equal(wR[cls, np.arange(nImg)].argmax(1), cs["r_true"])
+    minK, minS = 0.4, 0.3
+    for l in range(nImg):
+        ws, rankR = st.support(wR, wT, cls, l, seed, 1e-3, mLR, mLT, minK, minS)
+        assert sorted(rankR) == list(range(nR))
+        assert np.all(wR[cls[l], l][ws["srcR"]] > 0) and np.all(wT[cls[l], l][ws["srcT"]] > 0)
+        assert abs(ws["wR"].sum() - 1) < 1e-12 and abs(ws["wT"].sum() - 1) < 1e-12
+        assert np.array_equal(ws["topR"], cs["quat"][cs["r_true"][l]])
+        assert np.all(ws["k"] >= minK) and np.all(ws["s"] >= minS)
+        assert np.array_equal(ws["t"], cs["shifts"][ws["srcT"]])
+    a, _ = st.support(wR, wT, cls, 0, seed, 1e-3, mLR, mLT, 0.0, 0.0, call=2)
+    b, _ = st.support(wR, wT, cls, 0, seed, 1e-3, mLR, mLT, 0.0, 0.0, call=3)
+    assert np.array_equal(a["topR"], b["topR"])       # the top point does not depend on the draws
