@@ -597,7 +597,7 @@ def main():
     ap.add_argument("--classification", action="store_true",
                     help="one whole K = 4 classification iteration of configs[3] on one GPU's share of the images instead "
                          "(scan, class selection, local phases, multi-reference insertion, reconstructions)")
-    ap.add_argument("--wg-per-cu", type=int, default=2, help="with --classification: occupancy argument of thx_expect_local_dev (workgroups per CU; 0 = unlimited)")
+    ap.add_argument("--wg-per-cu", type=int, default=2, help="occupancy argument of the local-search kernel (workgroups of 4 waves per CU; 0 = unlimited; default 2, DESIGN 4.1)")
     ap.add_argument("--python-sequencing", action="store_true", help="with --classification: sequence the iteration in Python over the *_dev calls "
                                                                          "instead of the native driver thx_classify_iterate (A/B)")
     ap.add_argument("--check-native", action="store_true", help="with --classification --warmup 0 --steps 1: run the Python sequencing once first and "
@@ -642,6 +642,7 @@ def main():
                         nPhase=args.phases, mReco=args.mReco, batch=args.batch, particle_filter=True, allocate=False,
                         sort_view=not args.unsorted)
     shard.release_generation_state()
+    shard.wg_per_cu = args.wg_per_cu   # occupancy argument of the local-search kernel (thx_refine_config.wgPerCU; 2 = the library default)
 
     # ---- RCCL communicators in native code (thx_comm_*): the unique ids travel through the launcher's process group,
     #      as the reference broadcasts them over MPI (gpu/src/cuthunder.cu:4192-4206) ----
