@@ -135,7 +135,7 @@ def test_native_classification_stages_against_oracle(oracle, dev, N, K, nImg, nR
         # (measured here with equal round counts: 5e-4 ... 1e-2 of max, FSC >= 0.9989 -- the MAP pass with the all-ones FSC adds no
         # regularisation and stops after ~12 rounds, the least converged of the four)
         for e, f, same in ((e0, f0, ita == dev_rounds[0]), (e1, f1, itb == dev_rounds[1])):
-            assert e <= (2e-2 if same else 1e-1) and f.min() >= (0.998 if same else 0.95), (k, e, f.min(), same)
+            assert e <= (3e-2 if same else 1e-1) and f.min() >= (0.997 if same else 0.95), (k, e, f.min(), same)   # (3 x the measured worst)
         # the class map resembles its own reference, not the next class's
         own = O.fsc(np.fft.rfftn(m0[k]).astype(np.complex64), np.fft.rfftn(cs["refs"][k]).astype(np.complex64), N, 6)
         other = O.fsc(np.fft.rfftn(m0[k]).astype(np.complex64), np.fft.rfftn(cs["refs"][(k + 1) % K]).astype(np.complex64), N, 6)
