@@ -480,7 +480,7 @@ int thx_pf_class_select_dev(int* cls, const float* uC, const double* wC, int nIm
  * resample(mLR, PAR_R), resample(mLT, PAR_T) (src/Particle.cpp:1291-1430: shuffle, top = first largest weight, systematic draw
  * of mLR / mLT of the nRin / nTin points), calVari(PAR_R), calVari(PAR_T), and the minimum spread of the scanning phase:
  * k1..k3 = max(minK, k), s0, s1 = max(minS, s) (:1032-1079; OPTIMISER_SCAN_SET_MIN_STD_WITH_PERTURB: minK = (scanMinStdR /
- * perturbFactorSGlobal)^2 with scanMinStdR = nRin^(-1/3), minS = scanMinStdT / perturbFactorSGlobal; 0 = none).  Out: r [nImg][mLR][4], t [nImg][mLT][2], their priors
+ * perturbFactorSGlobal)^2 with scanMinStdR = mS^(-1/3) -- nRin^(-1/3) for C1 --, minS = scanMinStdT / perturbFactorSGlobal; 0 = none).  Out: r [nImg][mLR][4], t [nImg][mLT][2], their priors
  * wR / wT, k123 [nImg][3], s01 [nImg][2], topR [nImg][4], topT [nImg][2] -- the state thx_pf_perturb_dev continues from.
  * Philox streams (seed, image, call, 2 / 3 = rotation shuffle keys / u0, 4 / 5 = shift shuffle keys / u0).  nRin, nTin <= 16384. */
 int thx_pf_scan_support_dev(double* r, double* t, double* wR, double* wT, double* k123, double* s01, double* topR, double* topT,

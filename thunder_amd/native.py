@@ -203,8 +203,8 @@ TRANS_SEARCH_FACTOR = 0.25           # script/demo_3D.json "Translation Search F
 
 
 def scan_min_spread(nR, perturbFactorSGlobal=0.5):
-    """the scanning phase's minimum spread (OPTIMISER_SCAN_SET_MIN_STD_WITH_PERTURB, src/Optimiser.cpp:1032-1079): scanMinStdR =
-    nR^(-1/3), scanMinStdT = 1 / Qinv(INIT_OUTSIDE_CONFIDENCE_AREA, 2) / sqrt(transSearchFactor pi), over perturbFactorSGlobal
+    """the scanning phase's minimum spread (OPTIMISER_SCAN_SET_MIN_STD_WITH_PERTURB, src/Optimiser.cpp:667-690,1032-1079): scanMinStdR =
+    mS^(-1/3) in MODE_3D (mS = the scanned rotations before symmetry reduction: nR for C1, which is what this takes), scanMinStdT = 1 / Qinv(INIT_OUTSIDE_CONFIDENCE_AREA, 2) / sqrt(transSearchFactor pi), over perturbFactorSGlobal
     -> (minK, minS) of thx_pf_scan_support_dev"""
     minK = (nR ** (-1.0 / 3) / perturbFactorSGlobal) ** 2
     minS = 1.0 / (-2.0 * np.log(INIT_OUTSIDE_CONFIDENCE_AREA)) / np.sqrt(TRANS_SEARCH_FACTOR * np.pi) / perturbFactorSGlobal
