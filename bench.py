@@ -12,7 +12,9 @@ It fits one GPU (about 125 GB of particle data + 15 GB of volumes in 288 GB), so
 100 000 particles are sharded over the ranks (N = 8 is BASELINE configs[2]: 12 500 per GPU) -- total work fixed:
 "scaling": "strong".  `--particles 10000` gives configs[1].
 `--classification` times BASELINE configs[3] instead: one whole K = 4 classification iteration on one GPU's share of the images,
-sequenced by the native driver thx_classify_iterate (thunder_amd/csrc/thx_classify.hip; `--python-sequencing` for the A/B form).
+through the same native driver (thx_refine_iterate with nK = 4 and a global search).  The default command (the headline
+workload on one GPU) then also runs configs[1], configs[3] and configs[4] for 2 + 1 iterations each and reports them under
+`other_configs` of the same JSON line (`--other-configs off` skips them).
 Launch: `python bench.py` (N=1) or
   `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`
 Prints ONE JSON line on rank 0.
@@ -248,284 +250,119 @@ def bench_global_scan(args, dev):
     print(json.dumps(out))
 
 
-def bench_classification_iteration(args, dev):
-    """--classification: one whole iteration of BASELINE configs[3] (3-D classification, K = 4 references) on ONE GPU's share
-    of the images, sequenced over the batched `*_dev` entry points the way Optimiser::expectation does for a classification
-    (src/Optimiser.cpp:631-1660): global scan of every image against K classes x 10 000 rotations x 30 shifts at r = 24
-    (:756-894) -> class of every image (keepHalfHeightPeak(PAR_C) / resample / rand, :925-952: k_pf_class_select) -> support
-    points from the selected class's scan posterior (keepHalfHeightPeak / resample(mLR, PAR_R) / resample(mLT, PAR_T) / calVari,
-    :953-1008: k_pf_scan_support) -> 3 local particle-filter phases
-    against the assigned reference (volIdx; k_pf_perturb / k_expect_local<9, packed> / k_pf_update) -> mReco draws per image ->
-    multi-reference insertion (cls per draw, K pairs of F / T in one session: k_bin / sort / k_acc) -> normalise + 2
-    reconstructions per class (MAP off / on, Reconstructor::reconstruct).  Left out of the timed region: the sigma update and
-    the re-centring of the images (timed in the refinement bench), half-set splitting (one GPU's share is one half here).
-    `value` = images per second through the whole iteration; the per-stage times and the roofline of each stage's dominant
-    kernel ride along."""
+def bench_classification_iteration(args, dev, nImg=None, steps=None, warmup=None, cpu=True):
+    """--classification: one whole iteration of BASELINE configs[3] (3-D classification, K = 4 references, global search) on ONE
+    GPU's share of the images (50 000 / 8 = 6 250, both half-sets), through the SAME native driver as the refinement line
+    (thx_refine_iterate with nK = 4, THX_SEARCH_GLOBAL): rows -> global scan of every image against K classes x 10 000 rotations x
+    30 shifts at r = 24 (src/Optimiser.cpp:756-894) -> class of every image (:925-952) -> support points (:953-1079) -> local
+    particle-filter phases against the assigned reference (volIdx) -> sigma update -> mReco draws per image -> multi-reference
+    insertion (K pairs of F / T in one fixed-point session per half) -> prepareTF -> 2 reconstructions per class and half ->
+    per-class FSC (core-mask corrected) -> averaging of the halves -> solvent flattening -> Model::refreshProj.  The same definition of
+    "iteration" as the headline line (a global-search iteration has no re-centring / normCorrection in the reference either,
+    src/Optimiser.cpp:3405-3413,3790-3810).  `value` = images per second through the whole iteration; the per-stage times and the
+    roofline of each stage's dominant kernel ride along."""
     import torch
-    from thunder_amd import capi, ops, synth
-    from thunder_amd.refine import pixel_list
+    from thunder_amd.native import NativeRefine, STAGES
+    from thunder_amd.refine import RefineShard
     N, K, nR, nT, rScan = args.box, 4, 10000, 30, 24
-    mLR, mLT, mReco, nPhase = args.mLR, args.mLT, args.mReco, args.phases
-    nImg = args.scan_images
-    P, pf, rU = 2 * N, 2, N // 2 - 2
-    rng = np.random.default_rng(4)
-    T_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    plS, plE, plM = pixel_list(N, rScan, 2), pixel_list(N, rU, 2), pixel_list(N, rU, 0)
-    posM = {(int(i), int(j)): k for k, (i, j) in enumerate(zip(plM["iCol"], plM["iRow"]))}
-    e2m = T_(np.asarray([posM[(int(i), int(j))] for i, j in zip(plE["iCol"], plE["iRow"])], np.int64))
-    s2m = T_(np.asarray([posM[(int(i), int(j))] for i, j in zip(plS["iCol"], plS["iRow"])], np.int64))
-    iColS, iRowS, iColE, iRowE, iColM, iRowM = (T_(plS["iCol"]), T_(plS["iRow"]), T_(plE["iCol"]), T_(plE["iRow"]),
-                                                T_(plM["iCol"]), T_(plM["iRow"]))
-    nPxlS, nPxlE, nPxlM = plS["nPxl"], plE["nPxl"], plM["nPxl"]
-    plan = ops.RecoPlan(N, N, pf)
-    refs = torch.stack([T_(synth.blob_map(N, seed=300 + k, nblob=20)) for k in range(K)]).contiguous()
-    vols = torch.stack([plan.set_projectee(refs[k]) for k in range(K)]).contiguous()
-    cells = ops.pack_projector(vols, P)
-    quat = synth.random_quats(nR, rng)
-    mats = ops.rotmat(T_(quat))
-    quatD = T_(quat)
-    shifts = np.ascontiguousarray(rng.normal(0, 3.0, size=(nT, 2)))
-    shiftsD = T_(shifts)
-    traS = ops.translate(shiftsD, iColS, iRowS, N)
-    traM = ops.translate(shiftsD, iColM, iRowM, N)
-    attr = T_(synth.ctf_params(nImg, rng))
-    ctfM = ops.ctf(attr, 1.32, iColM, iRowM, N)
-    # images: a slice of a random class at a random scanned rotation / shift, plus noise (rL = 0 list; the E-step and scan rows
-    # are its sub-lists)
-    cls_true, r_true, t_true = rng.integers(0, K, nImg), rng.integers(0, nR, nImg), rng.integers(0, nT, nImg)
-    if not args.unsorted:
-        # stored by class and view direction of the previous iteration's poses (here: the generating ones), as the refinement
-        # bench stores its particles by view (thx_view_order_host): images next to each other in a launch gather from the
-        # same reference along nearly the same plane
-        from thunder_amd.refine import view_order
-        perm = view_order(quat[r_true])
-        perm = perm[np.argsort(cls_true[perm], kind="stable")]
-        cls_true, r_true, t_true = cls_true[perm], r_true[perm], t_true[perm]
-    datM = torch.empty((nImg, nPxlM), dtype=torch.complex64, device=dev)
-    for k in range(K):
-        sel = np.nonzero(cls_true == k)[0]
-        for c0 in range(0, len(sel), 1024):
-            ss = sel[c0:c0 + 1024]
-            sl = ops.project(vols[k], mats[T_(r_true[ss])].contiguous(), iColM, iRowM, pf)
-            st_ = T_(ss)
-            datM[st_] = sl * traM[T_(t_true[ss])] * ctfM[st_]
-    sd = 3.0 * float(datM.abs().pow(2).mean().sqrt())
-    g = torch.Generator(device=dev); g.manual_seed(5)
-    for c0 in range(0, nImg, 2048):
-        c1 = min(nImg, c0 + 2048)
-        datM[c0:c1] += torch.view_as_complex(torch.randn((c1 - c0, nPxlM, 2), generator=g, device=dev)) * (sd / np.sqrt(2))
-    datE, ctfE = datM[:, e2m].contiguous(), ctfM[:, e2m].contiguous()
-    datS, ctfS = datM[:, s2m].contiguous(), ctfM[:, s2m].contiguous()
-    sig = -0.5 / (sd * sd / 2)
-    sigM = torch.full((nImg, nPxlM), sig, dtype=torch.float32, device=dev)
-    sigE = torch.full((nImg, nPxlE), sig, dtype=torch.float32, device=dev)
-    sigS = torch.full((nImg, nPxlS), sig, dtype=torch.float32, device=dev)
-    pR = torch.full((nImg, nR), 1.0 / nR, dtype=torch.float64, device=dev)
-    pT = torch.full((nImg, nT), 1.0 / nT, dtype=torch.float64, device=dev)
-    native = not args.python_sequencing
-    py = (not native) or args.check_native
-    wC = torch.zeros((nImg, K), dtype=torch.float32, device=dev)
-    wR = torch.zeros((K, nImg, nR) if py else (1,), dtype=torch.float32, device=dev)
-    wT = torch.zeros((K, nImg, nT) if py else (1,), dtype=torch.float32, device=dev)
-    base = torch.empty((nImg,), dtype=torch.float32, device=dev)
-    wsG = torch.empty(capi.load().thx_expect_global_workspace(nImg, nR, nT), dtype=torch.uint8, device=dev)
-    batch = min(nImg, args.batch)
-    wsL = torch.empty(capi.load().thx_expect_local_workspace(batch, mLR, mLT, 1), dtype=torch.uint8, device=dev)
-    rotP = torch.empty((nR, nPxlS), dtype=torch.complex64, device=dev)
-    F = torch.zeros((K, P, P, P // 2 + 1) if py else (1,), dtype=torch.complex64, device=dev)
-    Tt = torch.zeros((K, P, P, P // 2 + 1) if py else (1,), dtype=torch.float32, device=dev)
-    w = torch.full((nImg,), 1.0 / mReco, dtype=torch.float32, device=dev)
-    ar = torch.arange(nImg, device=dev)
-    seed, state = 20240607, {"call": 0}
-    ev = {"scan": [], "local": [], "insert": []}
-    stage_ms = {}
-    maps = {}
-
-    class Stage:
-        def __init__(self, name, timed): self.name, self.timed = name, timed
-        def __enter__(self):
-            if self.timed:
-                torch.cuda.synchronize(); self.t0 = time.perf_counter()
-        def __exit__(self, *a):
-            if self.timed:
-                torch.cuda.synchronize(); stage_ms[self.name] = stage_ms.get(self.name, 0.0) + (time.perf_counter() - self.t0) * 1e3
-
-    def timed_call(key, timed, fn, n):
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        r = fn()
-        if timed:
-            e1.record(); ev[key].append((e0, e1, n))
-        return r
-
-    def iteration(timed):
-        with Stage("scan", timed):
-            wC.zero_(); wR.zero_(); wT.zero_(); base.fill_(float("nan"))
-            for k in range(K):
-                ops.project(vols[k], mats, iColS, iRowS, pf, out=rotP)
-                timed_call("scan", timed, lambda: ops.expect_global(rotP, traS, datS, ctfS, sigS, pR, pT, wC, wR, wT, base, k, K, workspace=wsG), nImg)
-        with Stage("class_select_and_support_points", timed):
-            state["call"] += 1
-            cls = ops.pf_class_select(wC, seed, state["call"])
-            state["call"] += 1
-            # Particle::keepHalfHeightPeak(PAR_R) / resample(mLR, PAR_R) / resample(mLT, PAR_T) / calVari on the scan posterior of the
-            # image's class (src/Optimiser.cpp:953-1008)
-            # with the scanning phase's minimum spread (OPTIMISER_SCAN_SET_MIN_STD_WITH_PERTURB, :1032-1079): scanMinStdR = nR^(-1/3),
-            # scanMinStdT = 1 / Qinv(INIT_OUTSIDE_CONFIDENCE_AREA, 2) / sqrt(transSearchFactor pi), over perturbFactorSGlobal = 0.5
-            minK = (nR ** (-1.0 / 3) / 0.5) ** 2
-            minS = 1.0 / (-2.0 * np.log(INIT_OUTSIDE_CONFIDENCE_AREA)) / np.sqrt(TRANS_SEARCH_FACTOR * np.pi) / 0.5
-            st = ops.pf_scan_support(quatD, shiftsD, wR, wT, cls, mLR, mLT, 1e-3, seed, state["call"], minK, minS)
-        with Stage("local_phases", timed):
-            for p_ in range(nPhase):
-                for b0 in range(0, nImg, batch):
-                    b1 = min(nImg, b0 + batch); sl = slice(b0, b1)
-                    state["call"] += 1
-                    f = 2.0 if p_ == 0 else 0.5
-                    ops.pf_perturb(st["r"][sl], st["t"][sl], st["wR"][sl], st["wT"][sl], st["k"][sl], st["s"][sl], f, f, 2.0, 0.05, seed, state["call"])
-                    rotB = ops.rotmat(st["r"][sl].reshape(-1, 4)).reshape(b1 - b0, mLR, 9)
-                    r = timed_call("local", timed, lambda: ops.expect_local(cells, P, pf, N, iColE, iRowE, datE[sl], ctfE[sl], sigE[sl], rotB, st["t"][sl],
-                                                                            volIdx=cls[sl], pR=st["wR"][sl], pT=st["wT"][sl], workspace=wsL, packed=True, wg_per_cu=args.wg_per_cu), b1 - b0)
-                    state["call"] += 1
-                    ops.pf_update(st["r"][sl], st["t"][sl], st["wR"][sl], st["wT"][sl], r.wR, r.wT, st["k"][sl], st["s"][sl], st["topR"][sl], st["topT"][sl],
-                                  1e-3, seed, state["call"])
-        with Stage("insertion", timed):
-            F.zero_(); Tt.zero_()
-            for b0 in range(0, nImg, batch):
-                b1 = min(nImg, b0 + batch); sl = slice(b0, b1)
-                state["call"] += 1
-                rot, tran = ops.draw_reco(st["r"][sl], st["t"][sl], mReco, seed, state["call"], b0)
-                clsD = cls[sl][:, None].expand(-1, mReco).contiguous()
-                timed_call("insert", timed, lambda: ops.insert(F, Tt, P, datM[sl], ctfM[sl], w[sl], rot, tran, iColM, iRowM, pf, N, cls=clsD, nK=K), b1 - b0)
-        with Stage("reconstruct", timed):
-            rounds = 0
-            for k in range(K):
-                if float(Tt[k, 0, 0, 0]) <= 0:
-                    continue
-                ops.normalise_TF(F[k], Tt[k], P)
-                for MAP in (False, True):   # (reconstruct works on the class's ONE T in place, as the reference does)
-                    maps[(k, MAP)] = plan.reconstruct(F[k], Tt[k], rU, FSC=np.ones(rU, np.float32) if MAP else None, joinHalf=False, MAP=MAP, gridCorr=True)
-                    rounds += int(plan.last_iters)
-        return cls, st, rounds
-
-    ref_run = None
-    if native and args.check_native:
-        # A/B: the same iteration sequenced in Python first (Philox call counter from 0, as the fresh native handle's)
-        cls_p, st_p, rounds_p = iteration(False)
-        torch.cuda.synchronize()
-        ref_run = dict(cls=cls_p.cpu().numpy(), r=st_p["r"].cpu().numpy(), t=st_p["t"].cpu().numpy(), topR=st_p["topR"].cpu().numpy(),
-                       F=F.cpu().numpy(), T=Tt.cpu().numpy(), maps={k: m.cpu().numpy() for k, m in maps.items()}, rounds=rounds_p)
-    if native:
-        # the iteration in native code (thx_classify_iterate, thunder_amd/csrc/thx_classify.hip): Python hands over the rows, the
-        # scanned grid and the references once and calls the driver once per iteration
-        from thunder_amd.native import CLASSIFY_STAGES, NativeClassify
-        F = Tt = wR = wT = None
-        nat = NativeClassify(N, K, nImg, nR, nT, rScan, rL=2, pf=pf, mLR=mLR, mLT=mLT, nPhase=nPhase, mReco=mReco, batch=batch, pixel_order=0,
-                             wg_per_cu=args.wg_per_cu, seed=seed)
-        nat.set_grid(quatD, shiftsD); nat.set_particles(datM, ctfM, sigM, w); nat.set_references(refs)
-        for _ in range(args.warmup):
-            nat.iterate(False)
-        torch.cuda.synchronize()
-        nat.stats(reset=True)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            nat.iterate(True)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        ns, v = nat.stats(), nat.view()
-        cls = T_(nat.fetch(v.cls, np.int32, (nImg,)))
-        st = dict(r=T_(nat.fetch(v.r, np.float64, (nImg, mLR, 4))), t=T_(nat.fetch(v.t, np.float64, (nImg, mLT, 2))),
-                  topR=T_(nat.fetch(v.topR, np.float64, (nImg, 4))))
-        rounds = int(ns.balancingRounds) // max(1, args.steps)
-        for i, name in enumerate(CLASSIFY_STAGES):
-            stage_ms[name] = float(ns.stageMs[i])
-        rotP = torch.empty((nR, nPxlS), dtype=torch.complex64, device=dev)   # (the CPU baseline's sample of slices)
-        check = None
-        if ref_run is not None:
-            volN, mapN = P * P * (P // 2 + 1), N * N * N
-            Fn = nat.fetch(v.F, np.complex64, (K, P, P, P // 2 + 1)); Tn = nat.fetch(v.T, np.float32, (K, P, P, P // 2 + 1))
-            m0 = nat.fetch(v.maps, np.float32, (K, N, N, N)); m1 = nat.fetch(v.mapsMAP, np.float32, (K, N, N, N))
-            dm = 0.0
-            for (k, MAP), m in ref_run["maps"].items():
-                dm = max(dm, float(np.abs((m1 if MAP else m0)[k] - m).max()))
-            check = {"cls_equal": bool((cls.cpu().numpy() == ref_run["cls"]).all()),
-                     "r_max_abs_diff": float(np.abs(st["r"].cpu().numpy() - ref_run["r"]).max()),
-                     "t_max_abs_diff": float(np.abs(st["t"].cpu().numpy() - ref_run["t"]).max()),
-                     "topR_max_abs_diff": float(np.abs(st["topR"].cpu().numpy() - ref_run["topR"]).max()),
-                     "F_max_abs_diff": float(np.abs(Fn - ref_run["F"]).max()), "T_max_abs_diff": float(np.abs(Tn - ref_run["T"]).max()),
-                     "F_max_abs": float(np.abs(ref_run["F"]).max()), "maps_max_abs_diff": dm,
-                     "rounds_native": int(ns.balancingRounds), "rounds_python": int(ref_run["rounds"]),
-                     "single_batch": bool(nImg <= batch)}
-    else:
-        for _ in range(args.warmup):
-            iteration(False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            cls, st, rounds = iteration(True)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    ok = float((cls.cpu().numpy() == cls_true).mean())
-    # poses after the local phases against the generating ones
-    d = np.abs((st["topR"].cpu().numpy() * quat[r_true]).sum(1)).clip(0, 1)
+    nImg = nImg or args.scan_images
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    if N < 64:
+        rScan = max(4, N // 2 - 4)
+    shard = RefineShard(N, nImg, dev, mLR=args.mLR, mLT=args.mLT, nPhase=args.phases, mReco=args.mReco, batch=min(args.batch, 3125),
+                        particle_filter=True, allocate=False, sort_view=not args.unsorted, snr=0.1, K=K, scan=dict(nR=nR, nT=nT, rScan=rScan),
+                        search="global", map_seed=300, nblob=20)
+    shard.balanceClass = 1
+    shard.release_generation_state()
+    shard.wg_per_cu = args.wg_per_cu
+    nat = NativeRefine(shard, pixel_order=1)
+    for _ in range(warmup):
+        nat.reset()
+        nat.iterate(False)
+    nat.reset()
+    torch.cuda.synchronize()
+    nat.stats(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fsc = nat.iterate(True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st, v = nat.stats(), nat.view()
+    cls = nat.fetch(v.cls, np.int32, (nImg,))
+    topR = nat.fetch(v.topR, np.float64, (nImg, 4))
+    ok = float((cls == shard.cls_true).mean())
+    d = np.abs((topR * shard.quat).sum(1)).clip(0, 1)
     ang = np.degrees(2 * np.arccos(d))
-    ms = lambda key: float(np.mean([a.elapsed_time(b) for a, b, _ in ev[key]]))
-    n_of = lambda key: float(np.mean([n for _, _, n in ev[key]]))
-    if native:
-        scan_ms, loc_ms, ins_ms = ns.scanMs / max(1, ns.scanLaunches), ns.localMs / max(1, ns.localLaunches), ns.insertMs / max(1, ns.insertLaunches)
-        n_of = lambda key: {"local": ns.localImages / max(1, ns.localLaunches), "insert": ns.insertImages / max(1, ns.insertLaunches), "scan": float(nImg)}[key]
-    else:
-        scan_ms, loc_ms, ins_ms = ms("scan"), ms("local"), ms("insert")
-    flops = 4.0 * nImg * nR * nT * nPxlS
-    loc_bytes = n_of("local") * nPxlE * (EXPECT_BYTES_PER_PIXEL + EXPECT_BYTES_PER_PIXEL_SAMPLE * mLR)
-    stages = {k: round(v / args.steps, 2) for k, v in stage_ms.items()}
-    dominant = max(("scan", "local_phases"), key=lambda k: stages.get(k, 0.0))
-    roof_scan = {"bound": "mfma", "kernel": "thx_expect_global_dev = k_scan_tables + k_scan_gemm (f32 MFMA) + fold (one class: %d images x %d rot x %d shifts)" % (nImg, nR, nT),
+    nPxlS, nPxlE, nPxlM = st.nPxlS, st.nPxl, st.nPxlM
+    scan_ms = st.scanMs / max(1, st.scanLaunches)
+    scan_n = st.scanImages / max(1, st.scanLaunches)
+    loc_ms, loc_n = st.expectMs / max(1, st.expectLaunches), st.expectImages / max(1, st.expectLaunches)
+    ins_ms, ins_n = st.insertMs / max(1, st.insertLaunches), st.insertImages / max(1, st.insertLaunches)
+    flops = 4.0 * scan_n * nR * nT * nPxlS          # 2 FMAs per (pixel, rotation, shift) in the expanded likelihood, one class
+    loc_bytes = loc_n * nPxlE * (EXPECT_BYTES_PER_PIXEL + EXPECT_BYTES_PER_PIXEL_SAMPLE * shard.mLR)
+    stages = {k: round(st.stageMs[i] / steps, 2) for i, k in enumerate(STAGES)}
+    dominant = max(("global_scan", "expectation"), key=lambda k: stages.get(k, 0.0))
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        j = json.load(open(pmc))
+        if j.get("box") == N and "classification_hbm_bytes_per_image_phase" in j:
+            traffic = j["classification_hbm_bytes_per_image_phase"] * loc_n
+    except Exception:
+        pass
+    roof_scan = {"bound": "mfma", "kernel": "thx_expect_global_dev = k_scan_tables + k_scan_gemm (f32 MFMA) + fold (one class: %d images x %d rot x %d shifts)" % (scan_n, nR, nT),
                  "achieved": flops / (scan_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / (scan_ms * 1e-3) / 1e12 / 157.3,
                  "traffic": None, "avg_launch_ms": scan_ms,
                  "note": "exact-f32 contraction on v_mfma_f32_32x32x2_f32 (bit-equal to the fmaf chain); peak = f32 MFMA = f32 vector rate"}
     roof_local = {"bound": "hbm", "kernel": "k_expect_local<9, packed> with volIdx (K cell-packed references)", "achieved": loc_bytes / (loc_ms * 1e-3) / 1e9,
-                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": loc_bytes / (loc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                  "avg_launch_ms": loc_ms, "images_per_launch": n_of("local")}
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": loc_bytes / (loc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                  "avg_launch_ms": loc_ms, "images_per_launch": loc_n}
     out = {"metric": "images/sec through one 3-D classification iteration (K = 4, %d^3 box): global scan + class selection + %d local phases + "
-                     "multi-reference insertion + 2 reconstructions per class" % (N, nPhase),
-           "value": nImg * args.steps / dt, "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "configs[3] on one GPU's share: %d synthetic %d^3 images, K = %d classes; scan %d rotations x %d shifts at r = %d "
-                                  "(%d pixels); local search %d phases x %d rot x %d shifts on %d pixels; %d inserts per image into %d F / T pairs; "
-                                  "%d reconstructions" % (nImg, N, K, nR, nT, rScan, nPxlS, nPhase, mLR, mLT, nPxlE, mReco, K, 2 * K),
-                      "classes_recovered": ok, "median_pose_error_deg": float(np.median(ang)), "particle_order": "random" if args.unsorted else "by class, then view direction",
-                      "sequenced_by": "thx_classify_iterate (native C++ driver, thx_classify.hip)" if native else "Python over the *_dev entry points (--python-sequencing)"},
-           "roofline": roof_scan if dominant == "scan" else roof_local,
+                     "sigma update + multi-reference insertion + 2 reconstructions per class and half + per-class FSC / averaging / refresh" % (N, args.phases),
+           "value": nImg * steps / dt, "unit": "images/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+           "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "configs[3] on one GPU's share: %d synthetic %d^3 images (both half-sets), K = %d classes; scan %d rotations x %d shifts "
+                                  "at r = %d (%d pixels); local search %d phases x %d rot x %d shifts on %d pixels; %d inserts per image into %d F / T pairs "
+                                  "per half; %d reconstructions" % (nImg, N, K, nR, nT, rScan, nPxlS, args.phases, shard.mLR, shard.mLT, nPxlE, shard.mReco, K, 4 * K),
+                      "classes_recovered": ok, "median_pose_error_deg": float(np.median(ang)), "images_per_class": [int(x) for x in st.classCount[:K]],
+                      "particle_order": "random" if args.unsorted else "by class, then view direction",
+                      "sequenced_by": "thx_refine_iterate (the one native C++ driver, thx_refine.hip): nK = 4, THX_SEARCH_GLOBAL"},
+           "roofline": roof_scan if dominant == "global_scan" else roof_local,
            "rooflines": {"scan": roof_scan, "local_phases": roof_local},
-           "kernels": {"insertion (k_bin + segment sort + k_acc), %d classes in one session" % K: {"avg_call_ms": ins_ms, "images_per_call": n_of("insert"),
-                                                                                             "us_per_image": ins_ms * 1e3 / max(1.0, n_of("insert"))}},
-           "stages_ms_per_step": stages, "balancing_rounds_per_step": rounds, "cpu_baseline": None}
-    if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_classification(args, dev, dict(K=K, nR=nR, nT=nT, N=N, P=P, pf=pf, nImg=nImg, mLR=mLR, mLT=mLT, mReco=mReco, nPhase=nPhase,
-                                                                      vols=vols, mats=mats, iColS=iColS, iRowS=iRowS, rotP=rotP, traS=traS, datS=datS, ctfS=ctfS, sigS=sigS,
-                                                                      plE=plE, datE=datE, ctfE=ctfE, sigE=sigE, st=st, cls=cls))
-    if native and check is not None:
-        out["native_vs_python"] = check
-    print(json.dumps(out))
-    plan.close()
+           "kernels": {"insertion (k_bin + segment sort + k_acc), %d classes in one session" % K: {"avg_call_ms": ins_ms, "images_per_call": ins_n,
+                                                                                             "us_per_image": ins_ms * 1e3 / max(1.0, ins_n)}},
+           "stages_ms_per_step": stages, "balancing_rounds_per_step": st.balancingRounds / max(1, steps),
+           "fsc_half_maps_class0": [round(float(x), 4) for x in np.atleast_2d(fsc)[0][:8]], "cpu_baseline": None}
+    if cpu and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_classification(args, shard, nat, dict(K=K, nR=nR, nT=nT, rScan=rScan))
+    nat.close()
+    return out
 
 
-def cpu_baseline_classification(args, dev, c):
+def cpu_baseline_classification(args, shard, nat, c):
     """oracle (`kind: port`) on bounded samples of the classification iteration, all host cores: the scanning loop (every core a block
     of images through ONE class, scaled to K) and the local phases + insertion (oracle.baseline_block on the filter's support points
     of the sample, one class volume: the arithmetic does not depend on which class an image is in).  The reconstructions are left
     out (the refinement bench times that leg); value = images / (scan seconds + local-and-insertion seconds) for the job's images."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
-    from thunder_amd import ops
-    K, nR, nT, nImg = c["K"], c["nR"], c["nT"], c["nImg"]
+    K, nR, nT, rScan = c["K"], c["nR"], c["nT"], c["rScan"]
+    N, P, pf, nImg = shard.N, shard.P, shard.pf, shard.nImg
     cores = os.cpu_count() or 1
     per = max(1, int(args.scan_cpu_images_per_core))
     n_cpu = min(nImg, per * cores)
-    ops.project(c["vols"][0], c["mats"], c["iColS"], c["iRowS"], c["pf"], out=c["rotP"])
-    rotP_h, traP_h = c["rotP"].cpu().numpy(), c["traS"].cpu().numpy()
-    dat_h, ctf_h, sig_h = c["datS"][:n_cpu].cpu().numpy(), c["ctfS"][:n_cpu].cpu().numpy(), c["sigS"][:n_cpu].cpu().numpy()
+    v = nat.view()
+    plS = O.pixel_list(N, rScan, shard.rL, pf)
+    vol = nat.fetch(v.vols, np.complex64, (P, P, P // 2 + 1))
+    quat, shifts = shard.scan["quat"], shard.scan["shifts"]
+    rotP_h = np.stack([O.project(vol, P, pf, O.rotate3D(q), plS["iCol"], plS["iRow"]) for q in quat])
+    traP_h = np.stack([O.translate(np.float32(s[0]), np.float32(s[1]), N, plS["iCol"], plS["iRow"]) for s in shifts])
+    img = nat.fetch(v.img, np.complex64, (n_cpu, N, N // 2 + 1))
+    attr = shard.attr[:n_cpu].cpu().numpy()
+    dat_h = np.ascontiguousarray(img.reshape(n_cpu, -1)[:, plS["iPxl"]])
+    ctf_h = np.stack([O.ctf(shard.pixelSize, *attr[l], N, plS["iCol"], plS["iRow"]) for l in range(n_cpu)])
+    sig_h = np.full(dat_h.shape, np.float32(-0.5 / shard.sigma2), np.float32)
 
     def block(b):
         lo, hi = b * per, min(n_cpu, (b + 1) * per)
@@ -542,16 +379,16 @@ def cpu_baseline_classification(args, dev, c):
     scan_rate = n_cpu / (t_scan * K)
     # local phases + insertion
     n = min(nImg, max(4, int(args.cpu_particles) if args.cpu_particles else cores))
-    P, N, pf, plE = c["P"], c["N"], c["pf"], c["plE"]
-    pl = dict(iCol=plE["iCol"], iRow=plE["iRow"], iColPad=plE["iColPad"], iRowPad=plE["iRowPad"], nPxl=plE["nPxl"])
-    vol = c["vols"][0].cpu().numpy()
-    dat, ctf, sig = c["datE"][:n].cpu().numpy(), c["ctfE"][:n].cpu().numpy(), c["sigE"][:n].cpu().numpy()
-    quat, t1 = c["st"]["r"][:n].cpu().numpy(), c["st"]["t"][:n].cpu().numpy()
-    r1 = np.stack([[O.rotate3D(q) for q in qs] for qs in quat])
-    rot = np.ascontiguousarray(np.stack([r1] * c["nPhase"], axis=1))
-    tran = np.ascontiguousarray(np.stack([t1] * c["nPhase"], axis=1))
+    nPxl = v.nPxl
+    iCol, iRow = nat.fetch(v.iCol, np.int32, (nPxl,)), nat.fetch(v.iRow, np.int32, (nPxl,))
+    pl = dict(iCol=iCol, iRow=iRow, iColPad=iCol * pf, iRowPad=iRow * pf, nPxl=nPxl)
+    dat, ctf, sig = nat.fetch(v.datP, np.complex64, (n, nPxl)), nat.fetch(v.ctfP, np.float32, (n, nPxl)), nat.fetch(v.sigRcpP, np.float32, (n, nPxl))
+    quatL, t1 = nat.fetch(v.r, np.float64, (n, shard.mLR, 4)), nat.fetch(v.t, np.float64, (n, shard.mLT, 2))
+    r1 = np.stack([[O.rotate3D(q) for q in qs] for qs in quatL])
+    rot = np.ascontiguousarray(np.stack([r1] * shard.nPhase, axis=1))
+    tran = np.ascontiguousarray(np.stack([t1] * shard.nPhase, axis=1))
     rng = np.random.default_rng(1)
-    iR, iT = rng.integers(0, c["mLR"], size=(n, c["mReco"])), rng.integers(0, c["mLT"], size=(n, c["mReco"]))
+    iR, iT = rng.integers(0, shard.mLR, size=(n, shard.mReco)), rng.integers(0, shard.mLT, size=(n, shard.mReco))
     recoRot = np.ascontiguousarray(np.take_along_axis(rot[:, -1], iR[:, :, None], axis=1))
     recoTran = np.ascontiguousarray(np.take_along_axis(tran[:, -1], iT[:, :, None], axis=1))
     groups = max(1, min(int(args.cpu_groups), cores))
@@ -568,78 +405,18 @@ def cpu_baseline_classification(args, dev, c):
             "sample": "scan: %d images x 1 class x %d rotations x %d shifts through the oracle's scanning loop (%d threads x %d images, %.1f s), scaled "
                       "to %d classes; local phases + insertion: %d images x (%d phases x %d rot x %d shifts + %d inserts) through the oracle C port, %d "
                       "threads in %d groups with private F / T, %.1f s; reconstructions not included" % (
-                          n_cpu, nR, nT, cores, per, t_scan, K, n, c["nPhase"], c["mLR"], c["mLT"], c["mReco"], cores, groups, t_em)}
+                          n_cpu, nR, nT, cores, per, t_scan, K, n, shard.nPhase, shard.mLR, shard.mLT, shard.mReco, cores, groups, t_em)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--box", type=int, default=256)
-    ap.add_argument("--particles", type=int, default=100000,
-                    help="TOTAL particles of the job, sharded over the GPUs (100000 = BASELINE metric / configs[2]; "
-                         "10000 = configs[1])")
-    ap.add_argument("--mLR", type=int, default=125)
-    ap.add_argument("--mLT", type=int, default=9)
-    ap.add_argument("--phases", type=int, default=3)
-    ap.add_argument("--mReco", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=10240, help="max images per kernel launch")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-particles", type=int, default=0, help="CPU baseline sample (default: two particles per core)")
-    ap.add_argument("--cpu-no-reconstruct", action="store_true")
-    ap.add_argument("--cpu-groups", type=int, default=16, help="CPU baseline: thread groups with private F / T (MPI ranks of the reference)")
-    ap.add_argument("--cpu-shared", action="store_true", help="CPU baseline: also time the single-team form (one shared F / T)")
-    ap.add_argument("--no-norm-correction", action="store_true",
-                    help="leave Optimiser::normCorrection (OPTIMISER_NORM_CORRECTION, on in the reference's Config.h) out of the iteration")
-    ap.add_argument("--unsorted", action="store_true",
-                    help="keep the particles in random order (default: stored by view direction, thx_view_order_host)")
-    ap.add_argument("--classification", action="store_true",
-                    help="one whole K = 4 classification iteration of configs[3] on one GPU's share of the images instead "
-                         "(scan, class selection, local phases, multi-reference insertion, reconstructions)")
-    ap.add_argument("--wg-per-cu", type=int, default=2, help="occupancy argument of the local-search kernel (workgroups of 4 waves per CU; 0 = unlimited; default 2, DESIGN 4.1)")
-    ap.add_argument("--python-sequencing", action="store_true", help="with --classification: sequence the iteration in Python over the *_dev calls "
-                                                                         "instead of the native driver thx_classify_iterate (A/B)")
-    ap.add_argument("--check-native", action="store_true", help="with --classification --warmup 0 --steps 1: run the Python sequencing once first and "
-                                                                    "report the native driver's differences from it (bit-identical when one batch holds every image)")
-    ap.add_argument("--scan-only", action="store_true", help="with --classification: the global scanning stage on its own")
-    ap.add_argument("--scan-images", type=int, default=0, help="images of the classification bench (default 6250 = 50 000 / 8 GPUs; 1024 with --scan-only)")
-    ap.add_argument("--scan-cpu-images-per-core", type=int, default=2)
-    args = ap.parse_args()
-
+def refinement_line(args, dev, rank, world, box, particles, steps, warmup, batch, cpu=True, cpu_particles=0):
+    """one refinement configuration through the native driver -> the result dict (rank 0; None on the other ranks)"""
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
-
-    if args.classification:
-        from thunder_amd import capi
-        capi.load()
-        if not args.scan_images:
-            args.scan_images = 1024 if args.scan_only else 6250
-        if args.scan_only:
-            bench_global_scan(args, dev)
-        else:
-            args.batch = min(args.batch, 3125)
-            bench_classification_iteration(args, dev)
-        return
-    from thunder_amd import capi
     from thunder_amd.native import NativeRefine, make_comms, STAGES
     from thunder_amd.refine import RefineShard, shard_count
-    capi.load()
-
     # ---- synthetic particles of this rank (generation only; every other buffer belongs to the native driver) ----
-    n_local = shard_count(args.particles, rank, world)
-    shard = RefineShard(args.box, n_local, dev, rank=rank, world=world, mLR=args.mLR, mLT=args.mLT,
-                        nPhase=args.phases, mReco=args.mReco, batch=args.batch, particle_filter=True, allocate=False,
+    n_local = shard_count(particles, rank, world)
+    shard = RefineShard(box, n_local, dev, rank=rank, world=world, mLR=args.mLR, mLT=args.mLT,
+                        nPhase=args.phases, mReco=args.mReco, batch=batch, particle_filter=True, allocate=False,
                         sort_view=not args.unsorted)
     shard.release_generation_state()
     shard.wg_per_cu = args.wg_per_cu   # occupancy argument of the local-search kernel (thx_refine_config.wgPerCU; 2 = the library default)
@@ -648,9 +425,9 @@ def main():
     #      as the reference broadcasts them over MPI (gpu/src/cuthunder.cu:4192-4206) ----
     def share_from(root, uid):
         import torch.distributed as dist
-        box = [uid]
-        dist.broadcast_object_list(box, src=root)
-        return box[0]
+        box_ = [uid]
+        dist.broadcast_object_list(box_, src=root)
+        return box_[0]
     hemi = wcomm = None
     if world > 1:
         hemi, wcomm = make_comms(rank, world, share_from)
@@ -662,14 +439,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.warmup:
+    if warmup:
         nat.reset()
-        nat.run(args.warmup)
+        nat.run(warmup)
     nat.reset()
     nat.stats(reset=True)
     barrier()
     t0 = time.perf_counter()
-    fsc = nat.run(args.steps, timed=True)
+    fsc = nat.run(steps, timed=True)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -677,9 +454,9 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-
+    out = None
     if rank == 0:
-        total_particles = args.particles * args.steps
+        total_particles = particles * steps
         value = total_particles / dt
         # per-launch averages of the two gather / scatter kernels: HIP events recorded by the native driver on its launch
         # stream around every thx_expect_local_dev / thx_insert_dev call of the timed iterations
@@ -702,14 +479,16 @@ def main():
         # to this run's images per launch; null if absent
         traffic, pmc_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        lds_rate = None
+        lds_rate64 = None
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                if j.get("box") == args.box:
-                    traffic = j["hbm_bytes_per_image_phase"] * exp_n
-                    pmc_src = j.get("source")
-                    lds_rate = j.get("lds_add_u32_per_s")
+                lds_rate64 = j.get("lds_add_u64_per_s")
+                per_box = j.get("per_box", {}).get(str(box))
+                if per_box:
+                    traffic, pmc_src = per_box["hbm_bytes_per_image_phase"] * exp_n, per_box.get("source")
+                elif j.get("box") == box:
+                    traffic, pmc_src = j["hbm_bytes_per_image_phase"] * exp_n, j.get("source")
             except Exception:
                 traffic = None
         # insertion against its own bound.  The brick-sorted form (k_bin + segment sort + k_acc, thx_insert_sort.hip) issues
@@ -719,31 +498,27 @@ def main():
         # k_acc).  lds_add_frac prices the whole insertion call (plan, k_bin, sort, k_acc) against the chip's measured
         # ds_add_u64 rate (tools/lds_atomic_bench.hip, recorded in profiles/pmc_traffic.json).
         groups_per_image = st.insertGroups / max(1, st.insertImages)
-        lds_rate64 = None
-        try:
-            lds_rate64 = json.load(open(pmc)).get("lds_add_u64_per_s")
-        except Exception:
-            pass
         ins_records_per_s = ins_n * groups_per_image * nPxlM / (ins_ms * 1e-3)
         ins_terms_per_s = ins_records_per_s * 24
+        headline = (box, particles) == (256, 100000)
         out = {
-            "metric": "particles/sec per refinement iteration (256\u00b3 box, 100k particles); achieved HBM GB/s" if (args.box, args.particles) == (256, 100000)
-                      else "particles/sec per refinement iteration (%d\u00b3 box, %d particles); achieved HBM GB/s" % (args.box, args.particles),
-            "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "metric": "particles/sec per refinement iteration (256\u00b3 box, 100k particles); achieved HBM GB/s" if headline
+                      else "particles/sec per refinement iteration (%d\u00b3 box, %d particles); achieved HBM GB/s" % (box, particles),
+            "value": value, "unit": "particles/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%d synthetic %d^3 particles, 3D refinement iteration on %d GPU(s) (local search %d "
                                    "phases x %d rot x %d shifts, normCorrection%s, %d inserts, 2 half-sets, 2x reconstruct per half, FSC, "
-                                   "projector refresh)" % (args.particles, args.box, world, args.phases, args.mLR,
+                                   "projector refresh)" % (particles, box, world, args.phases, args.mLR,
                                                            args.mLT, " off" if args.no_norm_correction else "", args.mReco),
-                       "box": args.box, "particles": args.particles, "particles_per_gpu": n_local, "nPxl": nPxl,
+                       "box": box, "particles": particles, "particles_per_gpu": n_local, "nPxl": nPxl,
                        "hbm_in_use_GB": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9, 1),
                        "pf": 2,
                        "search_state": "device particle filter (perturb / resample every phase, Philox-seeded)",
                        "particle_order": "random" if args.unsorted else "by view direction (thx_view_order_host)",
                        "driver": "native C++ iteration driver (thx_refine_iterate) through the C ABI",
-                       "parallelism": "particles sharded over %d GPU(s); half-set F/T all-reduce in native RCCL "
-                                      "(thx_reco_allreduce)" % world},
+                       "parallelism": "particles sharded over %d GPU(s); half-set reduce of the 64-bit fixed-point F/T accumulators in "
+                                      "native RCCL (thx_reco_allreduce_acc_class, ncclInt64)" % world},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kms,
                          "images_per_launch": exp_n, "algorithmic_bytes_per_launch": kbytes, "traffic_source": pmc_src},
@@ -756,14 +531,110 @@ def main():
                             "GBps_algorithmic_204B_per_draw": ins_bytes / (ins_ms * 1e-3) / 1e9},
                         "k_expect_local": {"avg_launch_ms": exp_ms, "images_per_launch": exp_n,
                                            "GBps_algorithmic": exp_bytes / (exp_ms * 1e-3) / 1e9, "total_ms": t_exp}},
-            "stages_ms_per_step": {k: round(st.stageMs[i] / args.steps, 2) for i, k in enumerate(STAGES)},
-            "balancing_rounds_per_step": st.balancingRounds / max(1, args.steps),
+            "stages_ms_per_step": {k: round(st.stageMs[i] / steps, 2) for i, k in enumerate(STAGES)},
+            "balancing_rounds_per_step": st.balancingRounds / max(1, steps),
             "fsc_half_maps": [round(float(x), 4) for x in fsc[: 8]],
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, shard, nat, out["balancing_rounds_per_step"])
+        if cpu and not args.no_cpu_baseline and world == 1:
+            args_c = argparse.Namespace(**vars(args))
+            args_c.cpu_particles, args_c.particles = cpu_particles, particles
+            if box >= 512:
+                args_c.cpu_groups = min(args.cpu_groups, 4)    # (a private F / T pair is 6.4 GB of host memory at the 1024^3 grid)
+            out["cpu_baseline"] = cpu_baseline(args_c, shard, nat, out["balancing_rounds_per_step"])
         else:
             out["cpu_baseline"] = None
+    nat.close()
+    if hemi is not None:
+        hemi.close()
+    if wcomm is not None:
+        wcomm.close()
+    del nat, shard
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--box", type=int, default=256)
+    ap.add_argument("--particles", type=int, default=100000,
+                    help="TOTAL particles of the job, sharded over the GPUs (100000 = BASELINE metric / configs[2]; "
+                         "10000 = configs[1])")
+    ap.add_argument("--mLR", type=int, default=125)
+    ap.add_argument("--mLT", type=int, default=9)
+    ap.add_argument("--phases", type=int, default=3)
+    ap.add_argument("--mReco", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=10240, help="max images per kernel launch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-particles", type=int, default=0, help="CPU baseline sample (default: 2048 particles at the headline workload -- SURVEY 8d asks for >= 2000 --, two per core otherwise)")
+    ap.add_argument("--cpu-no-reconstruct", action="store_true")
+    ap.add_argument("--cpu-groups", type=int, default=16, help="CPU baseline: thread groups with private F / T (MPI ranks of the reference)")
+    ap.add_argument("--cpu-shared", action="store_true", help="CPU baseline: also time the single-team form (one shared F / T)")
+    ap.add_argument("--no-norm-correction", action="store_true",
+                    help="leave Optimiser::normCorrection (OPTIMISER_NORM_CORRECTION, on in the reference's Config.h) out of the iteration")
+    ap.add_argument("--unsorted", action="store_true",
+                    help="keep the particles in random order (default: stored by view direction, thx_view_order_host)")
+    ap.add_argument("--classification", action="store_true",
+                    help="one whole K = 4 classification iteration of configs[3] on one GPU's share of the images instead "
+                         "(scan, class selection, local phases, sigma update, multi-reference insertion, reconstructions, FSC, refresh)")
+    ap.add_argument("--wg-per-cu", type=int, default=2, help="occupancy argument of the local-search kernel (workgroups of 4 waves per CU; 0 = unlimited; default 2, DESIGN 4.1)")
+    ap.add_argument("--scan-only", action="store_true", help="with --classification: the global scanning stage on its own")
+    ap.add_argument("--scan-images", type=int, default=0, help="images of the classification bench (default 6250 = 50 000 / 8 GPUs; 1024 with --scan-only)")
+    ap.add_argument("--scan-cpu-images-per-core", type=int, default=2)
+    ap.add_argument("--other-configs", choices=("auto", "on", "off"), default="auto",
+                    help="after the headline line, also run BASELINE configs[1] (10 000 x 256^3), configs[3] (one GPU's share of the K = 4 "
+                         "classification) and configs[4] (20 000 x 512^3) for 2 + 1 iterations each and report them under `other_configs` of the "
+                         "same JSON line (auto: when the command times the headline workload on one GPU)")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    from thunder_amd import capi
+    capi.load()
+
+    if args.classification:
+        if not args.scan_images:
+            args.scan_images = 1024 if args.scan_only else 6250
+        if args.scan_only:
+            bench_global_scan(args, dev)
+        else:
+            print(json.dumps(bench_classification_iteration(args, dev)))
+        return
+    headline = (args.box, args.particles) == (256, 100000)
+    cpu_n = args.cpu_particles or (2048 if headline else 0)
+    out = refinement_line(args, dev, rank, world, args.box, args.particles, args.steps, args.warmup, args.batch, cpu=True, cpu_particles=cpu_n)
+    others = args.other_configs == "on" or (args.other_configs == "auto" and headline and world == 1)
+    if others and world == 1:
+        # the other BASELINE configs, driver-visible: 2 timed iterations after 1 warm-up each, every line with its own roofline and
+        # cpu_baseline (bounded samples)
+        oc = {}
+        t0 = time.perf_counter()
+        small = os.environ.get("THX_BENCH_SMALL_OTHERS") == "1"     # (tests/test_next_gpu.py: the same code path on toy sizes)
+        b1, n1, b3, n3, b4, n4 = (32, 300, 64, 96, 64, 200) if small else (256, 10000, 256, 6250, 512, 20000)
+        oc["configs[1] %d x %d^3 refinement" % (n1, b1)] = refinement_line(args, dev, 0, 1, b1, n1, 2, 1, args.batch, cpu=True, cpu_particles=256)
+        a3 = argparse.Namespace(**vars(args))
+        a3.box, a3.scan_images, a3.steps, a3.warmup, a3.cpu_particles = b3, n3, 2, 1, 0
+        oc["configs[3] K=4 classification, one GPU's share (%d of 50k images)" % n3] = bench_classification_iteration(a3, dev)
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
+        oc["configs[4] %d x %d^3 refinement" % (n4, b4)] = refinement_line(args, dev, 0, 1, b4, n4, 2, 1, 2500, cpu=True, cpu_particles=64)
+        out["other_configs"] = oc
+        out["other_configs_wall_s"] = round(time.perf_counter() - t0, 1)
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

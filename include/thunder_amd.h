@@ -488,6 +488,47 @@ int thx_pf_scan_support_dev(double* r, double* t, double* wR, double* wT, double
                             int nRin, int nTin, int mLR, int mLT, double peakFactorR, double minK, double minS, unsigned long long seed,
                             unsigned call, void* stream);
 
+/* ---- point-group symmetry of the filter, and the numbering of its Philox streams ----
+ * thx_symmetry_host = Symmetry::init(const char sym[]) (src/Geometry/Symmetry.cpp:61-278, src/Geometry/SymmetryFunctions.cpp:
+ *   13-164): "C<n>", "D<n>", "T", "O", "I1" .. "I4" -> the *nSym NON-identity elements in the reference's order: symMat
+ *   [nSym][9] column-major R (what SYMMETRIZE_FT / thx_symmetrize_dev take), symQuat [nSym][4] = Symmetry::quat(i) (what
+ *   symmetryCounterpart multiplies with).  HOST arrays of `cap` elements (either may be NULL; both NULL: only the count).
+ * thx_pf_ctx: what the *_ex_dev forms of the filter calls take on top of their plain forms (NULL = C1, img0 = 0):
+ *   symQuat DEVICE [nSym][4] -- Particle::perturb(PAR_R) then ends with symmetrise(&mean) (src/Particle.cpp:1234) and
+ *   Particle::calVari(PAR_R) starts with symmetrise(&anch), anch a random support point (:1030-1036; Philox purpose 13);
+ *   img0 is added to the launch's image index in every Philox counter, so that an image draws the same numbers whatever
+ *   batch or rank it sits in (give it the image's index in the whole data set).
+ * thx_pf_symmetrise_dev = Particle::symmetrise(anchor) (:2445-2470, symmetryCounterpart src/Geometry/Symmetry.cpp:309-336) on
+ *   r [nImg][nR][4]; anchor DEVICE [nImg][4] or NULL = ANCHOR_POINT_2 (1, 0, 0, 0) (what Particle::reset applies to a
+ *   freshly drawn scan grid, src/Particle.cpp:168).
+ * thx_pf_cal_vari_dev = calVari(PAR_R) + calVari(PAR_T) on their own (Particle::load): k123 / s01 out, r symmetrised in place. */
+int thx_symmetry_host(const char* sym, double* symMat, double* symQuat, int cap, int* nSym);
+typedef struct thx_pf_ctx {
+    const double* symQuat;
+    int nSym;
+    unsigned img0;
+} thx_pf_ctx;
+int thx_pf_symmetrise_dev(double* r, const double* anchor, int nImg, int nR, const double* symQuat, int nSym, void* stream);
+int thx_pf_cal_vari_dev(double* r, const double* t, double* k123, double* s01, int nImg, int nR, int nT, unsigned long long seed,
+                        unsigned call, const thx_pf_ctx* ctx, void* stream);
+int thx_pf_perturb_ex_dev(double* r, double* t, double* wR, double* wT, const double* k123, const double* s01, int nImg,
+                          int nR, int nT, double pfR, double pfT, double transS, double transQ, unsigned long long seed,
+                          unsigned call, const int* active, const thx_pf_ctx* ctx, void* stream);
+int thx_pf_update_ex_dev(double* r, double* t, double* wR, double* wT, const float* uR, const float* uT, double* k123,
+                         double* s01, double* topR, double* topT, int nImg, int nR, int nT, double peakFactorR,
+                         unsigned long long seed, unsigned call, const int* active, const thx_pf_ctx* ctx, void* stream);
+int thx_pf_perturb_d_ex_dev(double* d, double* wD, const double* sD, int nImg, int nD, double scale, int init, unsigned long long seed,
+                            unsigned call, const int* active, unsigned img0, void* stream);
+int thx_pf_update_d_ex_dev(double* d, double* wD, const float* uD, double* sD, double* topD, int nImg, int nD, unsigned long long seed,
+                           unsigned call, const int* active, unsigned img0, void* stream);
+int thx_pf_class_select_ex_dev(int* cls, const float* uC, const double* wC, int nImg, int nK, double peakFactorC,
+                               unsigned long long seed, unsigned call, unsigned img0, void* stream);
+/* rowStride: images per class row of uR / uT (nImg for the plain form; the batch's image count when the scan ran batch by batch) */
+int thx_pf_scan_support_ex_dev(double* r, double* t, double* wR, double* wT, double* k123, double* s01, double* topR, double* topT,
+                               const double* gridR, const double* gridT, const float* uR, const float* uT, const int* cls, int nImg,
+                               int rowStride, int nRin, int nTin, int mLR, int mLT, double peakFactorR, double minK, double minS,
+                               unsigned long long seed, unsigned call, const thx_pf_ctx* ctx, void* stream);
+
 /* The deterministic ACG statistics on their own (parity probe): for quat [nImg][n][4] -> A [nImg][16] (inferACG,
  * DirectionalStat.cpp:93-145), mean [nImg][4] (:224-262), k123 [nImg][3] (calVari's mean-frame ratios), wBal [nImg][n]
  * (balanceWeight(PAR_R)), rounds [nImg][2] fixed-point rounds of the two inferACG calls (may be NULL). */
@@ -569,6 +610,10 @@ int thx_view_order_host(const double* quat, int n, int* perm);
 int thx_draw_reco_dev(double* recoRot, double* recoTran, const double* r, const double* t, int nImg, int nR, int nT, int mReco,
                       unsigned long long seed, unsigned call, unsigned img0, void* stream);
 
+#define THX_SEARCH_LOCAL 0    /* SEARCH_TYPE_LOCAL  (include/Optimiser.h) */
+#define THX_SEARCH_GLOBAL 1   /* SEARCH_TYPE_GLOBAL: every image is first scanned against all classes x nR rotations x nT shifts */
+#define THX_SEARCH_CTF 2      /* SEARCH_TYPE_CTF: local search with mLD defocus factors per image */
+
 typedef struct thx_refine thx_refine;
 typedef struct thx_refine_config {
     int N, pf;                 /* box size, padding factor */
@@ -576,7 +621,7 @@ typedef struct thx_refine_config {
     int halfOfRank;            /* -1: both half-sets live on this rank ([0, nHalfA) = half 0, the rest = half 1);
                                   0 / 1: the whole shard belongs to that half (odd / even ranks, src/Parallel.cpp:26-36) */
     int nHalfA;
-    int mLR, mLT, nPhase, mReco;  /* script/demo_3D.json: 125, 9, 3 (MIN_N_PHASE_PER_ITER_LOCAL), 100 */
+    int mLR, mLT, nPhase, mReco;  /* script/demo_3D.json: 125, 9, 3 (MIN_N_PHASE_PER_ITER_LOCAL; _GLOBAL is 10), 100 */
     int maxPhase;              /* <= nPhase: exactly nPhase phases per image (the fixed-work iteration bench.py times);
                                   > nPhase: the reference's per-image stop rule from phase index nPhase on, at most maxPhase
                                   phases (MAX_N_PHASE_PER_ITER = 100, include/Optimiser.h:58) */
@@ -587,50 +632,85 @@ typedef struct thx_refine_config {
     int wgPerCU;               /* occupancy argument of thx_expect_local_dev */
     float pixelSize, maskRadiusPx, sigma2Init;
     double transS, transQ;     /* Optimiser::_para.transS, TRANS_Q (include/Optimiser.h:67) */
-    double pfL, pfS;           /* perturbation factors of the first / later phases (script/demo_3D.json:71-73) */
+    double pfL, pfS;           /* perturbation factors: phase 0 of a local / CTF search (perturbFactorL), the later phases
+                                  (perturbFactorSLocal) (script/demo_3D.json:71-73) */
     double peakFactorR;        /* PEAK_FACTOR_MIN */
     unsigned long long seed;
     /* Model::compareTwoHemispheres / Optimiser::solventFlatten between the reconstructions and Model::refreshProj: */
     int coreFSC;               /* "Calculate FSC Using Core Region" (script/demo_3D.json:23: true): mask-corrected FSC with the
                                   core mask of radius AROUND(maskRadius / pixelSize) (src/Optimiser.cpp:188, src/Model.cpp:411-563) */
-    int goldenAverage;         /* != 0: the two references are averaged inside min(AROUND(resA2P(1 / A_B_AVERAGE_THRES)), r)
-                                  after the MAP reconstruction (_goldenStandard, k == 1: src/Model.cpp:616-674) */
+    int goldenAverage;         /* != 0: compareTwoHemispheres(false, true, AVERAGE_TWO_HEMISPHERE_THRES) after the MAP reconstruction
+                                  (src/Optimiser.cpp:7747).  One class and "Using Golden Standard FSC": the two references are
+                                  averaged inside r = Model::resolutionP(0.95) of THIS iteration's FSC (MODEL_RESOLUTION_BASE_AVERAGE,
+                                  include/Config.h:129-131, src/Model.cpp:616-674); several classes: averaged everywhere (:688-696) */
     int solventFlatten;        /* != 0: Optimiser::solventFlatten's spherical soft mask (maskRadius / pixelSize, EDGE_WIDTH_RL,
                                   background 0; src/Optimiser.cpp:7768-7990, no provided mask) before the projector refresh */
     int normCorrection;        /* != 0: Optimiser::normCorrection (OPTIMISER_NORM_CORRECTION, src/Optimiser.cpp:3405-3413,6201-6394) at
-                                  the head of the M-step of every iteration but the first: both image stacks -- the driver's _img and
-                                  the caller's _imgOri, IN PLACE -- are rescaled image by image to the median residual power over
-                                  ALL particles (one all-reduce of the norm vector over `world`); the expectations of all local halves
-                                  then run before the first M-step (the Philox call sequence differs from normCorrection == 0) */
+                                  the head of the M-step of every iteration but the first and not after a global search: both image
+                                  stacks -- the driver's _img and the caller's _imgOri, IN PLACE -- are rescaled image by image to the
+                                  median residual power over ALL particles (one all-reduce of the norm vector over `world`); the
+                                  expectations of all local halves then run before the first M-step */
+    /* ---- K references (classification) and the global search; 0 in every field = the one-class local search ---- */
+    int nK;                    /* classes (<= 16); 0 = 1 */
+    int searchType;            /* THX_SEARCH_* of the next iteration (Optimiser::_searchType); thx_refine_set_search_type changes it */
+    int nR, nT;                /* the scanned grid: nR = mS / (1 + nSym) rotations (src/Optimiser.cpp:652), nT >= 30 shifts (:663-667);
+                                  0 = the handle never scans (no scan buffers) */
+    int rScan;                 /* frequency limit of the scan (Optimiser::_r of a global-search iteration) */
+    int scanBatch;             /* images per scan launch, at most (0 = 2048): workspace nImg * nR * nT floats */
+    double pfSGlobal;          /* perturbFactorSGlobal: EVERY local phase of a global-search iteration (phase index starts at 1,
+                                  src/Optimiser.cpp:1185-1212; OPTIMISER_GLOBAL_PERTURB_LARGE is off) */
+    double peakFactorC;        /* PEAK_FACTOR_C = 1 - 1e-2 */
+    double scanMinK, scanMinS; /* minimum spread after the scan (thx_pf_scan_support_dev's minK / minS) */
+    int balanceClass;          /* != 0: OPTIMISER_BALANCE_CLASS (src/Optimiser.cpp:5518-5593,7510-7523,7727-7733): after a global search
+                                  a class holding less than CLASS_BALANCE_FACTOR / K of the images takes over the reference of a class
+                                  drawn from the distribution of the others (Philox stream (seed, 0, call, 14, class)) */
+    /* ---- point group (thx_symmetry_host): HOST arrays, copied at create; nSym = 0: C1 ---- */
+    int nSym;
+    const double* symMat;      /* [nSym][9] column-major: prepareTF symmetrises T, then F (src/Reconstructor.cpp:1056-1091) */
+    const double* symQuat;     /* [nSym][4]: Particle::symmetrise in perturb / calVari (thx_pf_ctx); set_grid folds the scan grid */
+    /* ---- CTF search (THX_SEARCH_CTF) ---- */
+    int mLD;                   /* defocus factors per image (script/demo_3D.json: 9); 0 = the handle never runs a CTF search */
+    double ctfRefineS, pfSCTF; /* "CTF Refine Standard Deviation" (0.01), "Perturbation Factor (Small, CTF)" (0.5) */
 } thx_refine_config;
 
 /* optional per-phase trace of the local search (tests hold the chain against the oracle with it): DEVICE buffers, any may
- * be NULL; index [phase][image of this rank].  uR / uT: the E-step's weights as handed to the filter (Particle::setUR /
- * setUT); rP / tP: the support points after Particle::perturb, r / t: after Particle::resample; k123 / s01:
- * Particle::calVari of the phase. */
+ * be NULL; index [phase][image of this rank] (phase = the count of phases run, 0-based, also after a scan).  uR / uT: the
+ * E-step's weights as handed to the filter (Particle::setUR / setUT); rP / tP: the support points after Particle::perturb,
+ * r / t: after Particle::resample; k123 / s01: Particle::calVari of the phase. */
 typedef struct thx_refine_capture {
     float *uR, *uT;            /* [nPhase][nImg][mLR], [nPhase][nImg][mLT] */
     double *r, *t;             /* [nPhase][nImg][mLR][4], [nPhase][nImg][mLT][2] */
     double *k123, *s01;        /* [nPhase][nImg][3], [nPhase][nImg][2] */
-    float *mapsFsc;            /* [2][N]^3: the two MAP-off half maps the FSC is computed from */
+    float *mapsFsc;            /* [2][nK][N]^3: the MAP-off half maps the FSC is computed from */
     double *rP, *tP;           /* [nPhase][nImg][mLR][4], [nPhase][nImg][mLT][2]: the support points after Particle::perturb */
     double *wRP, *wTP;         /* [nPhase][nImg][mLR], [nPhase][nImg][mLT]: their priors (Particle::balanceWeight) */
-    float *Fraw, *Traw;        /* [local halves] complex / real (pf N)^3 half grids: the accumulators as the insertion left them,
-                                  before the half-set reduce and prepareTF's normalisation */
+    float *Fraw, *Traw;        /* [local halves][nK] complex / real (pf N)^3 half grids: the accumulators as the insertion session
+                                  left them (after the half-set reduce on the integers), before prepareTF's normalisation */
+    /* global search: the scan's weights and what the filter made of them */
+    float *scanUC, *scanUR, *scanUT;   /* [nImg][nK], [nImg][nK][nR], [nImg][nK][nT] */
+    double *r0, *t0;           /* [nImg][mLR][4], [nImg][mLT][2]: the support points as thx_pf_scan_support_dev left them */
+    double *k0, *s0;           /* [nImg][3], [nImg][2]: their spread (after the scanning phase's minimum) */
+    float *Fsym, *Tsym;        /* [local halves][nK]: F / T after prepareTF (normalised, symmetrised), before the Wiener term */
 } thx_refine_capture;
 
 typedef struct thx_refine_stats {
     double expectMs, insertMs;            /* HIP-event totals of the local-search / insertion launches (timed iterations) */
     long expectLaunches, expectImages, insertLaunches, insertImages;
-    double stageMs[8];                    /* rows, expectation, sigma, insertion, reconstruct (+FSC, refresh), recentre+remask,
-                                             normCorrection */
+    double stageMs[8];                    /* rows, expectation (local phases), sigma, insertion, reconstruct (+FSC, refresh),
+                                             recentre+remask, normCorrection, global scan (+ class selection, support points) */
     long balancingRounds, iterations;
     long imagePhases;                     /* sum over images of the phases they ran (Optimiser::_nF) */
     int nPxl, nPxlM, batch;
     unsigned long long insertGroups;      /* (image, group) pairs the insertion launches of the timed iterations processed */
-    int lastRounds[4];                    /* balancing rounds of the last iteration's reconstructions: MAP off, local halves 0 / 1;
-                                             MAP on, local halves 0 / 1 (0 where this rank holds no such half) */
+    int lastRounds[4];                    /* balancing rounds of the last iteration's reconstructions of class 0: MAP off, local
+                                             halves 0 / 1; MAP on, local halves 0 / 1 (0 where this rank holds no such half) */
     float normMedian, normRadius;         /* normCorrection of the last iteration: the median of the norms and rNorm (0 when it did not run) */
+    double scanMs;                        /* HIP-event total of the thx_expect_global_dev launches */
+    long scanLaunches, scanImages;        /* (a launch = one class against one batch of images) */
+    int nPxlS, nK;
+    int classCount[16];                   /* images of this rank per class after the last expectation */
+    int lastRoundsK[64];                  /* [MAP off / on][local half][class] of the last iteration */
+    int balanced[16];                     /* balanceClass of the last iteration: class t took over the reference of balanced[t] (-1: kept its own) */
 } thx_refine_stats;
 
 /* hemi: communicator of this rank's half (NULL = the half lives on this rank alone); world: all ranks (NULL = one rank) */
@@ -641,26 +721,41 @@ int thx_refine_destroy(thx_refine* h);
  * support points of the particle filter (Particle::load). */
 int thx_refine_set_particles(thx_refine* h, const float* imgOri, const thx_ctf_attr* attr, const int* groupID_host,
                              const double* quat0, const double* tran0, void* stream);
-int thx_refine_set_reference(thx_refine* h, const float* refRL, void* stream);   /* DEVICE [N]^3 initial map */
+int thx_refine_set_reference(thx_refine* h, const float* refRL, void* stream);   /* DEVICE [nK][N]^3 initial maps */
+/* the class every image starts a LOCAL search in (Particle::c of the loaded filter; a global search assigns its own):
+ * DEVICE or HOST [nImg] ints in [0, nK); without this call every image is in class 0 */
+int thx_refine_set_classes(thx_refine* h, const int* cls, void* stream);
+/* the scanned grid of a global search: quat [nR][4], shifts [nT][2] doubles (host or device), shared by all images --
+ * Particle::reset(k, nR, nT, 1) (src/Particle.cpp:60-168) draws them and, with a point group, symmetrise()s the rotations
+ * next to ANCHOR_POINT_2: the fold happens here */
+int thx_refine_set_grid(thx_refine* h, const double* quat, const double* shifts, void* stream);
+int thx_refine_set_search_type(thx_refine* h, int searchType);
 int thx_refine_reset(thx_refine* h, void* stream);     /* the state before the first iteration */
-/* one EM iteration in the reference's order (src/Optimiser.cpp:3595-4073): expectation, allReduceSigma, insertion,
- * prepareTF, reconstruct (MAP off) -> compareTwoHemispheres (FSC of THIS iteration, Model::_FSC), reconstruct (MAP on,
- * joinHalf: OPTIMISER_RECONSTRUCT_JOIN_HALF) with the FSC Model::resetReco handed to the reconstructor at the end of the
- * PREVIOUS iteration (all ones before the first: src/Model.cpp:1086,1122), gold-standard averaging, solvent flattening,
- * Model::refreshProj, reCentreImg, reMaskImg.  fscHost (optional) [N/2] receives this iteration's FSC (rU = N/2 - 2 shells,
- * the rest 0); timed != 0 records HIP events for thx_refine_stats.  Synchronises the stream (FSC to the host, the gridding
- * loop's stop rule). */
+/* one EM iteration in the reference's order (src/Optimiser.cpp:3595-4073): expectation ([global scan -> class -> support
+ * points ->] local phases), [normCorrection,] allReduceSigma, insertion into the F / T of every image's class, prepareTF
+ * (reduce, normalise, symmetrise T, symmetrise F), per class reconstruct (MAP off) -> [balanceClass] -> compareTwoHemispheres
+ * (FSC of THIS iteration, Model::_FSC), reconstruct (MAP on, joinHalf: OPTIMISER_RECONSTRUCT_JOIN_HALF) with the FSC
+ * Model::resetReco handed to the reconstructor at the end of the PREVIOUS iteration (all ones before the first:
+ * src/Model.cpp:1086,1122) -> [balanceClass] -> averaging of the two halves, solvent flattening, Model::refreshProj; reCentreImg /
+ * reMaskImg unless the search was global (:3790-3800).  fscHost (optional) [max(nK, 1)][N/2] receives this iteration's FSC per
+ * class (rU = N/2 - 2 shells, the rest 0); timed != 0 records HIP events for thx_refine_stats.  Synchronises the stream (FSC
+ * to the host, the gridding loop's stop rule).
+ * Philox numbering: image = the image's index over all ranks (ranks in world order), call = iteration * 1024 + slot with slot
+ * 1 = class selection, 2 = support points after the scan, 8 + 2 p / 9 + 2 p = Particle::perturb / the filter update of phase
+ * index p, 1000 = the insertion's draws, 1001 = balanceClass; thx_refine_reset's calVari uses call 3. */
 int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream);
 /* capture (copied; NULL = off): where the following iterations leave their per-phase trace */
 int thx_refine_set_capture(thx_refine* h, const thx_refine_capture* capture);
-/* DEVICE [N]^3: the reference of `half` as Model::refreshProj consumed it (MAP-on map, averaged / flattened) */
+/* DEVICE [N]^3: the reference of `half` (class k) as Model::refreshProj consumed it (MAP-on map, averaged / flattened) */
 int thx_refine_get_map(thx_refine* h, int half, float* dstRL, void* stream);
+int thx_refine_get_map_k(thx_refine* h, int half, int k, float* dstRL, void* stream);
 /* DEVICE copies of the per-particle state (any pointer may be NULL): offset [nImg][2], topR [nImg][4], topT [nImg][2],
  * sig [local halves][nGroup][N/2-1] */
 int thx_refine_get_state(thx_refine* h, double* offset, double* topR, double* topT, float* sig, void* stream);
 int thx_refine_get_stats(thx_refine* h, thx_refine_stats* out, int reset);
 /* read-only DEVICE views of the handle's resident state (valid until destroy; contents change with every iteration):
- * what tests compare against the oracle and bench.py's cpu_baseline leg copies its sample from */
+ * what tests compare against the oracle and bench.py's cpu_baseline leg copies its sample from.  Volumes are indexed
+ * [local half][class]. */
 typedef struct thx_refine_view {
     int nImg, nPxl, nPxlM, nVol, vdim, rSig;
     const int *iCol, *iRow, *iPxl, *iSig, *iColM, *iRowM; /* E-step list [nPxl] (in visit order), M-step list [nPxlM] */
@@ -671,81 +766,17 @@ typedef struct thx_refine_view {
     const double *offset;                   /* [nImg][2] */
     const float *vols, *cells;              /* [nVol] projector FTs / their cell-packed copies */
     const float *F, *T;                     /* [nVol] accumulators of the last iteration (after prepareTF / Wiener term) */
-    const float *sig;                       /* [nVol][nGroup][rSig] */
+    const float *sig;                       /* [local halves][nGroup][rSig] */
     const double *recoRot, *recoTran;       /* draws of the LAST inserted local half [n][mReco][9] / [n][mReco][2] */
     const int *nP;                          /* [nImg] phase index at which the stop rule ended the image's search (maxPhase > nPhase) */
     const float *norm;                      /* [nImg] normCorrection's norms of the last iteration that ran it */
+    const int *cls;                         /* [nImg] class of every image */
+    const double *topR, *topT, *k123, *s01; /* [nImg][4], [nImg][2], [nImg][3], [nImg][2] */
+    const double *d, *wD;                   /* [nImg][mLD] defocus factors and their priors (CTF search; NULL without) */
+    const float *maps, *mapsMAP;            /* [2][nK][N]^3 MAP-off / final maps of the last iteration */
+    int nK, nPxlS;
 } thx_refine_view;
 int thx_refine_get_view(thx_refine* h, thx_refine_view* out);
-
-/* ---------------------------------------------------------------------------------------------
- * One 3-D classification iteration over K references in native code (thx_classify.hip; BASELINE configs[3]):
- * Optimiser::expectation's global search -- scan of every image against nK classes x nR rotations x nT shifts at r = rScan
- * (src/Optimiser.cpp:756-894), class of the image (:925-952), support points from the scan posterior of that class with the
- * scanning phase's minimum spread (:953-1079) -- the local particle-filter phases against the assigned reference (:1141-1660),
- * the mReco draws of every image inserted into the F / T of its class (:7038-7241; ONE fixed-point session over all batches,
- * reduced over the ranks of the half on the integers), prepareTF's normalisation and the MAP-off / MAP-on reconstructions of
- * every class (:7248-7760), Model::refreshProj per class (src/Model.cpp:1013-1044).  One handle = one rank's shard of ONE
- * half-set.  Left to the caller, as in bench.py --classification: the sigma update, re-centring and the comparison of the two
- * half maps of a class (thx_compare_hemispheres_dev), whose FSC comes back through thx_classify_set_fsc.
- * ------------------------------------------------------------------------------------------- */
-typedef struct thx_classify thx_classify;
-typedef struct thx_classify_config {
-    int N, pf, nK;             /* box, padding factor, classes (<= 16) */
-    int nImg;                  /* images of this rank */
-    long nImgHemi;             /* images of the whole half over all its ranks (head-room of the 64-bit sums); 0 = nImg */
-    int nR, nT;                /* scanned rotations / shifts (script/demo_3D.json: mS = 10 000 -> nR, nT >= 30) */
-    int rScan, rL;             /* frequency limit of the scan (Optimiser::_r in the global search), lower cut-off */
-    int mLR, mLT, nPhase, mReco;
-    int batch;                 /* images per launch of the local search / insertion, at most */
-    int pixelOrder, wgPerCU;   /* as thx_refine_config */
-    int refresh;               /* != 0: the MAP-on map of every class becomes its reference for the next iteration */
-    float pixelSize;
-    double transS, transQ, pfL, pfS;    /* as thx_refine_config */
-    double peakFactorR, peakFactorC;    /* PEAK_FACTOR_MIN, PEAK_FACTOR_C */
-    double scanMinK, scanMinS;          /* minimum spread after the scan (thx_pf_scan_support_dev's minK / minS) */
-    unsigned long long seed;
-} thx_classify_config;
-typedef struct thx_classify_stats {
-    double stageMs[5];                  /* scan, class + support points, local phases, insertion, reconstruct (+ refresh) */
-    double scanMs, localMs, insertMs;   /* HIP-event totals of the thx_expect_global_dev / local-search / insertion launches */
-    long scanLaunches, localLaunches, localImages, insertLaunches, insertImages;
-    long balancingRounds, iterations;
-    int nPxlS, nPxlE, nPxlM, batch;
-    int lastRounds[32];                 /* [class][MAP off, MAP on] balancing rounds of the last iteration */
-    int classCount[16];                 /* images per class in the last iteration (this rank) */
-} thx_classify_stats;
-/* read-only DEVICE views (valid until destroy) */
-typedef struct thx_classify_view {
-    int nImg, nK, nPxlS, nPxlE, nPxlM, vdim;
-    const int* cls;                         /* [nImg] */
-    const float *uC, *uR, *uT;              /* scan weights [nImg][nK], [nK][nImg][nR], [nK][nImg][nT] */
-    const double *r, *t, *wR, *wT, *topR, *topT;   /* filter state after the local phases */
-    const float *vols, *cells, *F, *T;      /* [nK] projector FTs, cell-packed copies, accumulators after reconstruct */
-    const float *maps, *mapsMAP;            /* [nK][N]^3 MAP-off / MAP-on maps of the last iteration (a class no image of the half has
-                                               gone to keeps its reference and its previous -- initially zero -- maps) */
-} thx_classify_view;
-/* optional trace of the following iterations (DEVICE buffers, any may be NULL; copied; NULL struct = off): what the stage-level
- * parity test holds against the oracle */
-typedef struct thx_classify_capture {
-    double *r0, *t0;           /* [nImg][mLR][4], [nImg][mLT][2]: the support points as thx_pf_scan_support_dev left them */
-    float *Fraw, *Traw;        /* [nK] complex / real (pf N)^3 half grids: the accumulators as the insertion session left them,
-                                  before prepareTF's normalisation */
-} thx_classify_capture;
-int thx_classify_create(thx_classify** out, const thx_classify_config* cfg, thx_comm* hemi);
-int thx_classify_set_capture(thx_classify* h, const thx_classify_capture* capture);
-int thx_classify_destroy(thx_classify* h);
-/* quat [nR][4], shifts [nT][2] doubles (host or device): the scanned grid, shared by all images */
-int thx_classify_set_grid(thx_classify* h, const double* quat, const double* shifts, void* stream);
-/* DEVICE rows on the rL = 0 pixel list (thx_pixel_list_host(N, N / 2 - 2, 0, 0)), BORROWED until destroy: datM [nImg][nPxlM]
- * complex64 (unmasked images), ctfM, sigRcpM [nImg][nPxlM], w [nImg] (already / mReco).  The rows of the scan and of the
- * local search are cut from them. */
-int thx_classify_set_particles(thx_classify* h, const float* datM, const float* ctfM, const float* sigRcpM, const float* w, void* stream);
-int thx_classify_set_references(thx_classify* h, const float* refRL, void* stream);   /* DEVICE [nK][N]^3 */
-int thx_classify_set_fsc(thx_classify* h, const float* fscHost, int n);   /* [nK][N / 2 - 2]: Reconstructor::_FSC of the MAP pass (ones at first) */
-int thx_classify_iterate(thx_classify* h, int timed, void* stream);
-int thx_classify_get_view(thx_classify* h, thx_classify_view* out);
-int thx_classify_get_stats(thx_classify* h, thx_classify_stats* out, int reset);
 
 /* ---------------------------------------------------------------------------------------------
  * Interface.h-shaped HOST-pointer entry points (what -DGPU_VERSION call sites bind to)

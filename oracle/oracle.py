@@ -113,6 +113,27 @@ def rotate3D(q):
     return out
 
 
+def symmetry(name, cap=128):
+    """Symmetry::init(sym) (src/Geometry/Symmetry.cpp:61-278, src/Geometry/SymmetryFunctions.cpp:13-164): the non-identity
+    elements of the point group in the reference's order -> dict(n, R [n][9] column-major, quat [n][4])"""
+    L = lib()
+    L.orc_symmetry.restype = C.c_int
+    R, q = np.zeros((cap, 9)), np.zeros((cap, 4))
+    n = L.orc_symmetry(name.encode(), _p(R, c_d), _p(q, c_d), C.c_int(cap))
+    if n < 0:
+        raise ValueError("unknown point group %r" % name if n == -1 else "more than %d symmetry elements" % cap)
+    return dict(n=n, R=np.ascontiguousarray(R[:n]), quat=np.ascontiguousarray(q[:n]), name=name)
+
+
+def symmetrise(q, symQuat, anchor=None):
+    """Particle::symmetrise(anchor) (src/Particle.cpp:2445-2470) on q [n][4] -> new array; anchor None = ANCHOR_POINT_2"""
+    q = f64(q).copy().reshape(-1, 4)
+    symQuat = f64(symQuat).reshape(-1, 4)
+    a = None if anchor is None else f64(anchor)
+    lib().orc_symmetrise(_p(q, c_d), C.c_int(len(q)), _p(symQuat, c_d), C.c_int(len(symQuat)), _p(a, c_d))
+    return q
+
+
 def project(vol, P, pf, mat, iCol, iRow):
     """Projector::project(Complex*, dmat33, iCol, iRow, nPxl) src/Projector.cpp:356-374."""
     vol, mat, iCol, iRow = c64(vol), f64(mat), i32(iCol), i32(iRow)
@@ -611,14 +632,21 @@ def _dp(a):
     return a.ctypes.data_as(c_d)
 
 
-def pf_perturb(q, t, k, s, pfR, pfT, transS, transQ, gR, gT):
+def _symq(symQuat):
+    sq = np.zeros((0, 4)) if symQuat is None else f64(symQuat).reshape(-1, 4)
+    return sq, len(sq)
+
+
+def pf_perturb(q, t, k, s, pfR, pfT, transS, transQ, gR, gT, symQuat=None):
     """Particle::perturb(pf, PAR_R) + perturb(pf, PAR_T) of one image (src/Optimiser.cpp:1186-1208, src/Particle.cpp:
     1149-1272): q [nR][4], t [nT][2] support points, k (k1, k2, k3), s (s0, s1) of the last calVari; gR [nR][4], gT [nT][4]
-    standard normals (the draws).  Returns new q, t and the balanced priors wR, wT (balanceWeight + normW)."""
+    standard normals (the draws).  Returns new q, t and the balanced priors wR, wT (balanceWeight + normW).  symQuat [nSym][4]
+    (Symmetry::quat): perturb(PAR_R) ends with symmetrise(&mean) (:1234)."""
     q, t, gR, gT = f64(q).copy(), f64(t).copy(), f64(gR), f64(gT)
     nR, nT = len(q), len(t)
     L = lib()
-    L.orc_perturb_R(_dp(q), C.c_int(nR), _dp(f64(k)), C.c_double(pfR), _dp(gR))
+    sq, nSym = _symq(symQuat)
+    L.orc_perturb_R_sym(_dp(q), C.c_int(nR), _dp(f64(k)), C.c_double(pfR), _dp(gR), _p(sq, c_d), C.c_int(nSym))
     wR = np.zeros(nR)
     L.orc_balance_weight_R(_dp(wR), _dp(q), C.c_int(nR))
     L.orc_perturb_T(_dp(t), C.c_int(nT), C.c_double(s[0]), C.c_double(s[1]), C.c_double(pfT), C.c_double(transS),
@@ -645,7 +673,7 @@ def pf_resample(val, w, u, rank, u0, nOut=None):
     return val[src].copy(), wo, src, top
 
 
-def pf_scan_support(gridR, gridT, uR, uT, peakFactorR, mLR, mLT, rankR, u0R, rankT, u0T, minK=0.0, minS=0.0):
+def pf_scan_support(gridR, gridT, uR, uT, peakFactorR, mLR, mLT, rankR, u0R, rankT, u0T, minK=0.0, minS=0.0, symQuat=None, iAnchor=0):
     """The filter of one image after a global scan, src/Optimiser.cpp:953-1008: the scanned grid with uniform priors and the scan
     weights uR [nRin] / uT [nTin] (RFLOAT) -> keepHalfHeightPeak(PAR_R) (OPTIMISER_PEAK_FACTOR_R; _T off), resample(mLR, PAR_R),
     resample(mLT, PAR_T), calVari(PAR_R), calVari(PAR_T), k = max(minK, k), s = max(minS, s).  u0R in [0, 1 / mLR), u0T in [0, 1 / mLT).  Returns dict(q, t, wR, wT, k, s,
@@ -660,13 +688,14 @@ def pf_scan_support(gridR, gridT, uR, uT, peakFactorR, mLR, mLT, rankR, u0R, ran
     t2, wT2, srcT, topT = pf_resample(gridT, np.full(nT, 1.0 / nT), ut, rankT, u0T, nOut=mLT)
     q2, t2 = np.ascontiguousarray(q2), np.ascontiguousarray(t2)
     k, mean, s = np.zeros(3), np.zeros(4), np.zeros(2)
-    L.orc_cal_vari_R(_dp(k), _dp(mean), _dp(q2), C.c_int(mLR))      # rotates q to the mean frame and back, in place
+    sq, nSym = _symq(symQuat)
+    L.orc_cal_vari_R_sym(_dp(k), _dp(mean), _dp(q2), C.c_int(mLR), _p(sq, c_d), C.c_int(nSym), C.c_int(int(iAnchor)))   # (symmetrises, then) rotates q to the mean frame and back, in place
     L.orc_cal_vari_T(_dp(s), _dp(t2), C.c_int(mLT))
     k, s = np.maximum(k, minK), np.maximum(s, minS)                 # setK1..3 / setS0, S1 with the scan's minimum spread, :1032-1079
     return dict(q=q2, t=t2, wR=wR2, wT=wT2, k=k, s=s, topR=gridR[topR].copy(), topT=gridT[topT].copy(), srcR=srcR, srcT=srcT, uRk=u)
 
 
-def pf_update(q, t, wR, wT, uR, uT, peakFactorR, rankR, u0R, rankT, u0T):
+def pf_update(q, t, wR, wT, uR, uT, peakFactorR, rankR, u0R, rankT, u0T, symQuat=None, iAnchor=0):
     """The filter bookkeeping after the likelihoods of a phase, src/Optimiser.cpp:1408-1475: setUR, keepHalfHeightPeak(PAR_R)
     (OPTIMISER_PEAK_FACTOR_R; _T off), setUT, calRank1st, calVari(PAR_R / PAR_T), resample(mLR, PAR_R), resample(mLT, PAR_T).
     uR / uT are the E-step weights (RFLOAT).  Returns dict(q, t, wR, wT, k, s, topR, topT, srcR, srcT)."""
@@ -677,7 +706,10 @@ def pf_update(q, t, wR, wT, uR, uT, peakFactorR, rankR, u0R, rankT, u0T):
     L.orc_keep_half_height_peak(_dp(u), C.c_int(nR), C.c_double(peakFactorR))
     ut = f64(np.asarray(uT, np.float32).astype(np.float64)).copy()
     k, mean, s = np.zeros(3), np.zeros(4), np.zeros(2)
-    L.orc_cal_vari_R(_dp(k), _dp(mean), _dp(q), C.c_int(nR))      # rotates q to the mean frame and back, in place
+    # with a point group calVari first replaces the support points by their counterparts next to a random anchor (iAnchor = the
+    # draw); resample() then takes _topR again from those (src/Particle.cpp:1340-1345)
+    sq, nSym = _symq(symQuat)
+    L.orc_cal_vari_R_sym(_dp(k), _dp(mean), _dp(q), C.c_int(nR), _p(sq, c_d), C.c_int(nSym), C.c_int(int(iAnchor)))   # rotates q to the mean frame and back, in place
     L.orc_cal_vari_T(_dp(s), _dp(t), C.c_int(nT))
     q2, wR2, srcR, topR = pf_resample(q, wR, u, rankR, u0R)
     t2, wT2, srcT, topT = pf_resample(t, wT, ut, rankT, u0T)
@@ -722,13 +754,15 @@ def pf_update_d(d, wD, uD, rank, u0):
     return d2, w2, s, top, src
 
 
-def cal_vari(q, t):
-    """Particle::calVari(PAR_R) + (PAR_T) -> (k [3], s [2]) (q is rotated to the mean frame and back: a copy here)"""
+def cal_vari(q, t, symQuat=None, iAnchor=0, return_q=False):
+    """Particle::calVari(PAR_R) + (PAR_T) -> (k [3], s [2]) (q is rotated to the mean frame and back: a copy here; with a point
+    group the copy is symmetrised about q[iAnchor] first and return_q hands it back)"""
     q = f64(q).copy()
     k, mean, s = np.zeros(3), np.zeros(4), np.zeros(2)
-    lib().orc_cal_vari_R(_dp(k), _dp(mean), _dp(q), C.c_int(len(q)))
+    sq, nSym = _symq(symQuat)
+    lib().orc_cal_vari_R_sym(_dp(k), _dp(mean), _dp(q), C.c_int(len(q)), _p(sq, c_d), C.c_int(nSym), C.c_int(int(iAnchor)))
     lib().orc_cal_vari_T(_dp(s), _dp(f64(t)), C.c_int(len(t)))
-    return k, s
+    return (k, s, q) if return_q else (k, s)
 
 
 def soft_mask_volume(vol, r, ew, bg=0.0):
@@ -739,56 +773,78 @@ def soft_mask_volume(vol, r, ew, bg=0.0):
 
 
 # ---------------------------------------------------------------------------------------------
-class Iteration:
-    """One EM iteration of the local search, chained exactly as the reference runs it (MODE_3D, k = 1, C1, no CTF search):
+CALLS_PER_ITER, SLOT_CLASS, SLOT_SUPPORT, SLOT_RESET, SLOT_PHASE0, SLOT_DRAWS, SLOT_BALANCE = 1024, 1, 2, 3, 8, 1000, 1001
 
-      Optimiser::expectation   src/Optimiser.cpp:1141-1660   allocPreCal rows, then per image and phase: perturb -> slices x
+
+class Iteration:
+    """One EM iteration, chained exactly as the reference runs it (MODE_3D; K >= 1 classes; local or global search; any point
+    group; no CTF search):
+
+      Optimiser::expectation   src/Optimiser.cpp:631-1140    global search only: scan of every image against K classes x nR rotations
+                                                             x nT shifts at r = rScan (expect_global), class of the image
+                                                             (pf_class_select), support points (pf_scan_support)
+                               :1141-1660                    allocPreCal rows, then per image and phase: perturb -> slices x
                                                              ramps -> logDataVSPrior -> weights -> setU / keepHalfHeightPeak /
-                                                             calRank1st / calVari / resample
-      Optimiser::maximization  :3405-3530                    allReduceSigma (:6395-6710), reconstructRef (:6711-7766): mReco
-                                                             Particle::rand draws -> translate -> insertP; prepareTF; reconstruct
-                                                             (MAP off) -> compareTwoHemispheres(fsc) -> reconstruct (MAP on,
+                                                             calRank1st / calVari / resample (phase index from 1 and
+                                                             perturbFactorSGlobal throughout after a scan, :1185-1212)
+      Optimiser::maximization  :3405-3530                    normCorrection (:6201-6394; not in the first iteration, not after a
+                                                             global search), allReduceSigma (:6395-6710), reconstructRef
+                                                             (:6711-7766): mReco Particle::rand draws -> translate -> insertP into the
+                                                             image's class; prepareTF (normalise, symmetrizeT, symmetrizeF,
+                                                             src/Reconstructor.cpp:1056-1091); per class reconstruct (MAP off) ->
+                                                             [balanceClass] -> compareTwoHemispheres(fsc) -> reconstruct (MAP on,
                                                              joinHalf, the FSC Model::resetReco set at the END OF THE PREVIOUS
-                                                             iteration) -> compareTwoHemispheres(avg)
-      Optimiser::run           :3800-4073                    reCentreImg, reMaskImg, solventFlatten, Model::refreshProj,
-                                                             Model::resetReco
+                                                             iteration) -> [balanceClass] -> compareTwoHemispheres(avg)
+      Optimiser::run           :3800-4073                    reCentreImg, reMaskImg (not after a global search), solventFlatten,
+                                                             Model::refreshProj, Model::resetReco
 
     Random draws are inputs: `ph` offers draw_n4 / draw_u4 / shuffle_ranks(seed, image, call, purpose, index) (tests hand in
-    their numpy replica of the device's Philox streams, tests/_philox.py; the numbering of `call` / `image` follows the
-    launches of thx_refine_iterate: two calls per batch and phase, one per half for the insertion draws).
-    normCorrection (OPTIMISER_NORM_CORRECTION) is outside the scope of this repo and not chained.
+    their numpy replica of the device's Philox streams, tests/_philox.py).  Numbering as thx_refine_iterate's: image = the
+    image's index, call = iteration * 1024 + slot (1 class selection, 2 support points, 8 + 2 p / 9 + 2 p perturb / update of
+    phase index p, 1000 insertion draws, 1001 balanceClass; 3 = the calVari of reset).
 
     cfg: dict(N, pf, nHalfA, mLR, mLT, nPhase, mReco, batch, rL, nGroup, groupSig, pixelSize, maskRadiusPx, sigma2Init,
-    transS, transQ, pfL, pfS, peakFactorR, seed, coreFSC, goldenAverage, solventFlatten).
+    transS, transQ, pfL, pfS, peakFactorR, seed, coreFSC, goldenAverage, solventFlatten) and, optional: normCorrection, nK,
+    rScan, pfSGlobal, peakFactorC, scanMinK, scanMinS, balanceClass, sym (= symmetry(name) or None).  ref: [N]^3 or [K][N]^3.
     `resolve` (optional): callback(phase, image, own) -> own, lets a test adopt the device's choice where a discrete decision
     (resampled indices, top support point) hinges on rounding -- after checking its tie rule; if it has a method
     after_perturb(phase, image, q_in, q, t, wR, wT) -> (q, t, wR, wT) it is also shown every perturbed cloud (the mean frame
-    of Particle::perturb is numerically undetermined when the resampled cloud has collapsed onto a few points)."""
+    of Particle::perturb is numerically undetermined when the resampled cloud has collapsed onto a few points); after_scan(image,
+    own) -> own is shown the class and the support points a global scan gave an image."""
 
-    def __init__(self, cfg, imgOri, attr, gid, quat0, tran0, ref, ph):
+    def __init__(self, cfg, imgOri, attr, gid, quat0, tran0, ref, ph, grid=None, cls0=None):
         self.c = dict(cfg)
         c = self.c
+        for k_, v_ in (("normCorrection", 0), ("nK", 1), ("rScan", 0), ("pfSGlobal", 0.5), ("peakFactorC", 1.0 - 1e-2), ("scanMinK", 0.0),
+                       ("scanMinS", 0.0), ("balanceClass", 0), ("sym", None)):
+            c.setdefault(k_, v_)
         self.ph = ph
         N, pf = c["N"], c["pf"]
         self.N, self.pf, self.P = N, pf, N * pf
         self.rU, self.rSig = N // 2 - 2, N // 2 - 1
-        self.imgOri = c64(imgOri)
+        self.K = max(1, int(c["nK"]))
+        self.imgOri = c64(imgOri).copy()
         self.n = self.imgOri.shape[0]
         self.attr = f32(attr).reshape(self.n, 7)
         self.gid = i32(gid)
         self.q0, self.t0 = f64(quat0), f64(tran0)
-        self.ref = f32(ref)
+        self.ref = f32(ref).reshape(self.K, N, N, N)
+        self.symQ = None if not c["sym"] or c["sym"]["n"] == 0 else c["sym"]["quat"]
+        self.symR = None if self.symQ is None else c["sym"]["R"]
         self.pl = pixel_list(N, self.rU, c["rL"], pf)          # expectation: allocPreCalIdx(_r, _rL), :631
         self.plM = pixel_list(N, self.rU, 0, pf)               # reconstruction: allocPreCalIdx(rU, 0), :6722
+        self.plS = pixel_list(N, c["rScan"], c["rL"], pf) if c["rScan"] else None
         nA = c["nHalfA"]
         self.ranges = [(0, nA), (nA, self.n)]
-        nmax = max(hi - lo for lo, hi in self.ranges)
-        nb = max(1, -(-nmax // c["batch"]))
-        self.batch = min(65535, max(1, -(-nmax // nb)))        # thx_refine_create's balanced batches
         self.mask2d = soft_mask(N, np.float32(c["maskRadiusPx"]), 6.0)
         self.ctfM = np.stack([ctf(c["pixelSize"], *self.attr[l], N, self.plM["iCol"], self.plM["iRow"]) for l in range(self.n)])
         self.ctfP = np.stack([ctf(c["pixelSize"], *self.attr[l], N, self.pl["iCol"], self.pl["iRow"]) for l in range(self.n)])
-        self.datM = np.ascontiguousarray(self.imgOri.reshape(self.n, -1)[:, self.plM["iPxl"]])
+        if grid is not None:   # Particle::reset(k, nR, nT, 1): the drawn rotations, symmetrise()d next to ANCHOR_POINT_2
+            gq, gt = grid
+            self.gridR = f64(gq) if self.symQ is None else symmetrise(gq, self.symQ, None)
+            self.gridT = f64(gt)
+            self.ctfS = np.stack([ctf(c["pixelSize"], *self.attr[l], N, self.plS["iCol"], self.plS["iRow"]) for l in range(self.n)])
+        self.cls0 = np.zeros(self.n, np.int32) if cls0 is None else i32(cls0)
         self.reset()
 
     # -- helpers ------------------------------------------------------------------------------
@@ -801,11 +857,19 @@ class Iteration:
             out[l] = sfft.rfft2(rl).astype(np.complex64)
         return out
 
+    def call(self, slot):
+        return self.iterCount * CALLS_PER_ITER + slot
+
+    def _anchor(self, l, call, n):
+        """anch = _r.row(gsl_rng_uniform_int(engine, _nR)) of calVari (src/Particle.cpp:1030): Philox purpose 13"""
+        return min(int(self.ph.draw_u4(self.c["seed"], l, call, 13, 0)[0] * n), n - 1)
+
     def reset(self):
         """the state before the first iteration (thx_refine_reset): Optimiser::initImg has masked the images, flat noise
         model, support points as loaded, weights uniform, Particle::load -> calVari"""
         c = self.c
-        self.vols = [set_projectee(self.ref, self.pf) for _ in range(2)]
+        self.iterCount = 0
+        self.vols = [[set_projectee(self.ref[k], self.pf) for k in range(self.K)] for _ in range(2)]
         self.offset = np.zeros((self.n, 2))
         self.img = self._remask(self.imgOri)
         self.sig = np.full((2, c["nGroup"], self.rSig), np.float32(c["sigma2Init"]), np.float32)
@@ -814,22 +878,23 @@ class Iteration:
         self.k = np.zeros((self.n, 3))
         self.s = np.zeros((self.n, 2))
         for l in range(self.n):
-            self.k[l], self.s[l] = cal_vari(self.q[l], self.t[l])
+            self.k[l], self.s[l], self.q[l] = cal_vari(self.q[l], self.t[l], self.symQ, self._anchor(l, SLOT_RESET, c["mLR"]), return_q=True)
+            if self.symQ is None:
+                self.q[l] = self.q0[l]      # (the round trip through the mean frame stays inside calVari's copy on the device)
         self.topR, self.topT = self.q[:, 0].copy(), self.t[:, 0].copy()
-        self.pfCall = 0
-        self.iterCount = 0
-        self.fscReco = np.ones(self.rU, np.float32)            # Model::initProjReco, src/Model.cpp:1086
+        self.cls = self.cls0.copy()
+        self.fscReco = np.ones((self.K, self.rU), np.float32)            # Model::initProjReco, src/Model.cpp:1086
 
-    def fsc_of_maps(self, mapA, mapB, iterCount):
+    def fsc_of_maps(self, mapA, mapB, iterCount, k=0):
         """Model::compareTwoHemispheres(true, false) on the two MAP-off half maps (src/Model.cpp:307-612): FSC over rU shells,
-        mask-corrected with the core mask when coreFSC (random phases: the Philox streams of iteration `iterCount`)"""
+        mask-corrected with the core mask when coreFSC (random phases: the Philox streams of iteration `iterCount`, class k)"""
         c, ph, N = self.c, self.ph, self.N
         A, B = sfft.rfftn(f32(mapA)).astype(np.complex64), sfft.rfftn(f32(mapB)).astype(np.complex64)
         coreR = float(int(np.rint(np.float32(c["maskRadiusPx"])))) if c["coreFSC"] else 0.0
         phA = phB = None
         if c["coreFSC"]:
             ne = N * N * (N // 2 + 1)
-            call = 0x40000000 + 2 * iterCount
+            call = 0x40000000 + 2 * (iterCount * 16 + k)
             e = np.arange(ne, dtype=np.uint64)
             lo32, hi32 = (e & np.uint64(0xFFFFFFFF)).astype(np.uint32), (e >> np.uint64(32)).astype(np.uint32)
             pi = 3.14159265358979323846   # TSGSL_ran_flat(engine, 0, 2 * M_PI) narrowed to RFLOAT; device: (float)(u * 2 * pi)
@@ -837,131 +902,261 @@ class Iteration:
             phB = (ph.draw_u4(c["seed"], lo32, call + 1, 9, hi32)[0] * 2 * pi).astype(np.float32)
         return compare_hemispheres(A, B, N, self.rU, phA, phB, coreR=coreR, ew=6.0)["fsc"]
 
-    # -- one iteration --------------------------------------------------------------------------
-    def _reconstruct_all(self, F, T, force):
-        """reconstructRef after prepareTF (src/Optimiser.cpp:7326-7747): reconstruct with MAP off -> compareTwoHemispheres(fsc) ->
-        reconstruct with MAP on (Reconstructor::_FSC of the previous iteration, joinHalf) -> compareTwoHemispheres(avg) ->
-        solventFlatten.  T [2] is changed in place as the reference changes _T3D.  force: None = the reference's stop rule,
-        else the four round counts to run (MAP off half 0 / 1, MAP on half 0 / 1)."""
+    def balance_map(self, distr):
+        """Optimiser::determineBalanceClass (src/Optimiser.cpp:5518-5584) -> bm [K] (-1 = the class keeps its own reference)"""
+        K, c = self.K, self.c
+        thres = 0.05 / K                                      # CLASS_BALANCE_FACTOR / _para.k
+        cum = np.where(distr < thres, 0.0, distr - thres)
+        tot = cum.sum()
+        bm = np.full(K, -1, np.int64)
+        if not tot > 0:
+            return bm
+        cum = np.cumsum(cum / tot)
+        for t in range(K):
+            if distr[t] < thres:
+                ind = np.float32(self.ph.draw_u4(c["seed"], 0, self.call(SLOT_BALANCE), 14, t)[0])
+                j = 0
+                while j < K - 1 and cum[j] < ind:
+                    j += 1
+                bm[t] = j
+        return bm
+
+    # -- the stages -----------------------------------------------------------------------------
+    def _scan(self, vi, lo, hi, resolve, out):
+        """global search of the images [lo, hi) of half vi: scan over the K classes -> class -> support points"""
+        c, ph, N, P, pf, K = self.c, self.ph, self.N, self.P, self.pf, self.K
+        plS, seed, mLR, mLT = self.plS, c["seed"], c["mLR"], c["mLT"]
+        nR, nT = len(self.gridR), len(self.gridT)
+        n = hi - lo
+        datS = np.ascontiguousarray(self.img[lo:hi].reshape(n, -1)[:, plS["iPxl"]])
+        sigS = np.ascontiguousarray(self.sigRcp[vi][self.gid[lo:hi] - 1][:, plS["iSig"]])
+        ctfS = self.ctfS[lo:hi]
+        mats = np.stack([rotate3D(q) for q in self.gridR])
+        traP = np.stack([translate(np.float32(s[0]), np.float32(s[1]), N, plS["iCol"], plS["iRow"]) for s in self.gridT])
+        dat_pm, ctf_pm, sig_pm = (np.ascontiguousarray(a.T) for a in (datS, ctfS, sigS))
+        wC, wR, wT = np.zeros((n, K), np.float32), np.zeros((K, n, nR), np.float32), np.zeros((K, n, nT), np.float32)
+        base = np.full(n, np.nan, np.float32)                    # "unset", :737-745
+        pR, pT = np.full((n, nR), 1.0 / nR), np.full((n, nT), 1.0 / nT)
+        for k in range(K):
+            rotP = np.stack([project(self.vols[vi][k], P, pf, m, plS["iCol"], plS["iRow"]) for m in mats])
+            expect_global(rotP, traP, dat_pm, ctf_pm, sig_pm, K, k, pR, pT, wC, wR, wT, base)
+        out["scanUC"][lo:hi], out["scanBase"][lo:hi] = wC, base
+        out["scanUR"][lo:hi], out["scanUT"][lo:hi] = wR.transpose(1, 0, 2), wT.transpose(1, 0, 2)
+        callC, callS = self.call(SLOT_CLASS), self.call(SLOT_SUPPORT)
+        for l in range(lo, hi):
+            li = l - lo
+            own = dict(uC=wC[li], uR=wR[:, li], uT=wT[:, li], base=float(base[li]))
+            if resolve is not None and hasattr(resolve, "scan_weights"):
+                own = resolve.scan_weights(l, own)          # (checks the weights; hands back the device's, which the filter continues from)
+            cls = pf_class_select(own["uC"], np.full(K, 1.0 / K), c["peakFactorC"], ph.shuffle_ranks(seed, l, callC, 6, K),
+                                  ph.draw_u4(seed, l, callC, 7, 0)[0] / K, min(int(ph.draw_u4(seed, l, callC, 8, 0)[0] * K), K - 1))
+            rankR, rankT = ph.shuffle_ranks(seed, l, callS, 2, nR), ph.shuffle_ranks(seed, l, callS, 4, nT)
+            ws = pf_scan_support(self.gridR, self.gridT, own["uR"][cls], own["uT"][cls], c["peakFactorR"], mLR, mLT, rankR,
+                                 ph.draw_u4(seed, l, callS, 3, 0)[0] / mLR, rankT, ph.draw_u4(seed, l, callS, 5, 0)[0] / mLT,
+                                 c["scanMinK"], c["scanMinS"], symQuat=self.symQ, iAnchor=self._anchor(l, callS, mLR))
+            ws.update(cls=cls, rankR=rankR, rankT=rankT)
+            if resolve is not None and hasattr(resolve, "after_scan"):
+                ws = resolve.after_scan(l, ws)
+            self.cls[l] = ws["cls"]
+            self.q[l], self.t[l], self.k[l], self.s[l] = ws["q"], ws["t"], ws["k"], ws["s"]
+            self.topR[l], self.topT[l] = ws["topR"], ws["topT"]
+            self.wR0[l], self.wT0[l] = ws["wR"], ws["wT"]
+
+    def _expect(self, vi, lo, hi, glob, resolve, out):
+        c, ph, N, P, pf = self.c, self.ph, self.N, self.P, self.pf
+        pl, seed, mLR, mLT = self.pl, c["seed"], c["mLR"], c["mLT"]
+        # allocPreCal(mask = true, pixelMajor = false, ctf = false), :8043-8171
+        datP = np.ascontiguousarray(self.img[lo:hi].reshape(hi - lo, -1)[:, pl["iPxl"]])
+        sigRcpP = np.ascontiguousarray(self.sigRcp[vi][self.gid[lo:hi] - 1][:, pl["iSig"]])
+        p0 = 1 if glob else 0
+        for pi in range(c["nPhase"]):
+            p = p0 + pi
+            callP = self.call(SLOT_PHASE0 + 2 * p)
+            callU = callP + 1
+            f = c["pfL"] if p == 0 else (c["pfSGlobal"] if glob else c["pfS"])
+            for l in range(lo, hi):
+                gR = np.stack(ph.draw_n4(seed, l, callP, 0, np.arange(mLR)), axis=1)
+                gT = np.stack(ph.draw_n4(seed, l, callP, 1, np.arange(mLT)), axis=1)
+                q, t, wR, wT = pf_perturb(self.q[l], self.t[l], self.k[l], self.s[l], f, f, c["transS"], c["transQ"], gR, gT, symQuat=self.symQ)
+                if resolve is not None and hasattr(resolve, "after_perturb"):
+                    if hasattr(resolve, "k_in"):
+                        resolve.k_in[l] = (self.k[l].copy(), self.s[l].copy())
+                    q, t, wR, wT = resolve.after_perturb(pi, l, self.q[l], q, t, wR, wT)
+                rot = np.stack([rotate3D(x) for x in q])
+                e = expect_local(self.vols[vi][self.cls[l]], P, pf, N, pl["iCol"], pl["iRow"], datP[l - lo], self.ctfP[l],
+                                 sigRcpP[l - lo], rot, t, nD=1, pC=1.0, pR=wR, pT=wT)
+                iA = self._anchor(l, callU, mLR)
+                own = pf_update(q, t, wR, wT, e["wR"], e["wT"], c["peakFactorR"],
+                                ph.shuffle_ranks(seed, l, callU, 2, mLR), ph.draw_u4(seed, l, callU, 3, 0)[0] / mLR,
+                                ph.shuffle_ranks(seed, l, callU, 4, mLT), ph.draw_u4(seed, l, callU, 5, 0)[0] / mLT,
+                                symQuat=self.symQ, iAnchor=iA)
+                own.update(uR=e["wR"], uT=e["wT"], tPre=t, qIn=q, wRIn=wR, wTIn=wT, li=l, callU=callU, iAnchor=iA,
+                           scaleL=float(np.abs(e["logW"]).max()))
+                if resolve is not None:
+                    own = resolve(pi, l, own)
+                self.q[l], self.t[l], self.k[l], self.s[l] = own["q"], own["t"], own["k"], own["s"]
+                self.topR[l], self.topT[l] = own["topR"], own["topT"]
+                out["uR"][pi, l], out["uT"][pi, l] = e["wR"], e["wT"]
+                out["srcR"][pi, l], out["srcT"][pi, l] = own["srcR"], own["srcT"]
+                out["k"][pi, l], out["s"][pi, l] = own["k"], own["s"]
+
+    def _norm_correction(self, out):
+        """Optimiser::normCorrection, src/Optimiser.cpp:6201-6394: residual power of every masked image against its top pose's
+        CTF-modulated slice over rL <= r < rNorm, median over ALL particles, both stacks rescaled, rows cut again"""
         c, N, P, pf = self.c, self.N, self.P, self.pf
-        maps, rounds = [], []
+        res = max(res_p(self.fscReco[k], 0.75, 1, 1, False) for k in range(self.K))   # Model::resolutionP(0.75, false), src/Model.cpp:984-994
+        rNorm = float(min(self.rU, res))
+        norm = np.zeros(self.n, np.float32)
+        for vi, (lo, hi) in enumerate(self.ranges):
+            for l in range(lo, hi):
+                norm[l] = norm_residual(self.vols[vi][self.cls[l]], P, pf, N, self.rU, float(c["rL"]), rNorm, rotate3D(self.topR[l]),
+                                        self.topT[l], c["pixelSize"], self.attr[l], self.img[l])
+        m = median(norm)
+        self.img, self.imgOri = norm_scale(self.img, self.imgOri, norm, m)
+        out.update(norm=norm, normMedian=m, rNorm=rNorm)
+
+    def _reconstruct_all(self, F, T, force, bm):
+        """reconstructRef after prepareTF (src/Optimiser.cpp:7326-7747): per class reconstruct with MAP off -> balanceClass ->
+        compareTwoHemispheres(fsc) -> reconstruct with MAP on (Reconstructor::_FSC of the previous iteration, joinHalf) ->
+        balanceClass -> compareTwoHemispheres(avg) -> solventFlatten.  T [2][K] is changed in place as the reference changes
+        _T3D.  force: None = the reference's stop rule, else the round counts to run [MAP off / on][half][class]."""
+        c, N, P, pf, K = self.c, self.N, self.P, self.pf, self.K
+        empty = [[not (T[vi][k].flat[0] > 0) for k in range(K)] for vi in range(2)]
+        maps = [[np.zeros((N, N, N), np.float32) for _ in range(K)] for _ in range(2)]
+        rounds = np.zeros((2, 2, K), np.int64)
         for vi in range(2):
-            m, it, diffs, _ = reconstruct(F[vi], T[vi], P, N, pf, self.rU, MAP=False, joinHalf=True, gridCorr=True, return_iters=True,
-                                          T_inplace=True, force_rounds=None if force is None else force[vi])
-            maps.append(m)
-            rounds.append(it)
-        res = dict(mapsFsc=maps, fsc=self.fsc_of_maps(maps[0], maps[1], self.iterCount))
-        mapsX = []
+            for k in range(K):
+                if empty[vi][k]:
+                    continue
+                m, it, diffs, _ = reconstruct(F[vi][k], T[vi][k], P, N, pf, self.rU, MAP=False, joinHalf=True, gridCorr=True, return_iters=True,
+                                              T_inplace=True, force_rounds=None if force is None else int(force[0][vi][k]))
+                maps[vi][k], rounds[0, vi, k] = m, it
+
+        def balance(mm):
+            for vi in range(2):
+                for t in range(K):
+                    if bm[t] >= 0 and bm[t] != t:
+                        mm[vi][t] = mm[vi][bm[t]].copy()
+        balance(maps)
+        res = dict(mapsFsc=[[m.copy() for m in h] for h in maps],
+                   fsc=np.stack([self.fsc_of_maps(maps[0][k], maps[1][k], self.iterCount, k) for k in range(K)]))
+        mapsX = [[np.zeros((N, N, N), np.float32) for _ in range(K)] for _ in range(2)]
         for vi in range(2):
-            m, it, diffs, _ = reconstruct(F[vi], T[vi], P, N, pf, self.rU, FSC=self.fscReco, joinHalf=True, MAP=True, gridCorr=True,
-                                          return_iters=True, T_inplace=True, force_rounds=None if force is None else force[2 + vi])
-            mapsX.append(m)
-            rounds.append(it)
-        res["mapsMAP"] = [m.copy() for m in mapsX]
-        if c["goldenAverage"]:   # compareTwoHemispheres(false, true), :7747 (k == 1, _goldenStandard)
-            resP = np.float32(np.float32(1.0 / 20.0) * np.float32(N) * np.float32(c["pixelSize"]))
-            avgR = min(int(np.rint(np.float64(resP))), self.rU)
-            A, B = sfft.rfftn(mapsX[0]).astype(np.complex64), sfft.rfftn(mapsX[1]).astype(np.complex64)
-            cm = compare_hemispheres(A, B, N, self.rU, avg_r=avgR)
-            mapsX = [np.ascontiguousarray(sfft.irfftn(x, s=(N, N, N)).astype(np.float32)) for x in (cm["A"], cm["B"])]
+            for k in range(K):
+                if empty[vi][k]:
+                    continue
+                m, it, diffs, _ = reconstruct(F[vi][k], T[vi][k], P, N, pf, self.rU, FSC=self.fscReco[k], joinHalf=True, MAP=True, gridCorr=True,
+                                              return_iters=True, T_inplace=True, force_rounds=None if force is None else int(force[1][vi][k]))
+                mapsX[vi][k], rounds[1, vi, k] = m, it
+        balance(mapsX)
+        res["mapsMAP"] = [[m.copy() for m in h] for h in mapsX]
+        if c["goldenAverage"]:   # compareTwoHemispheres(false, true, AVERAGE_TWO_HEMISPHERE_THRES), :7747
+            # one class under the gold standard: inside r = Model::resolutionP(0.95, false) of the FSC just computed
+            # (MODEL_RESOLUTION_BASE_AVERAGE, include/Config.h:129-131, src/Model.cpp:616-674); several classes: everywhere (:688-696)
+            avgR = res_p(res["fsc"][0], 0.95, 1, 1, False) if (K == 1 and c["goldenAverage"] == 1) else -1
+            for k in range(K):
+                A, B = sfft.rfftn(mapsX[0][k]).astype(np.complex64), sfft.rfftn(mapsX[1][k]).astype(np.complex64)
+                cm = compare_hemispheres(A, B, N, self.rU, avg_r=avgR)
+                mapsX[0][k], mapsX[1][k] = [np.ascontiguousarray(sfft.irfftn(x, s=(N, N, N)).astype(np.float32)) for x in (cm["A"], cm["B"])]
             res["avgR"] = avgR
+        keep = [[empty[vi][k] and not (bm[k] >= 0 and bm[k] != k and not empty[vi][bm[k]]) for k in range(K)] for vi in range(2)]
         if c["solventFlatten"]:   # Optimiser::solventFlatten(false), :7958-7975
-            mapsX = [soft_mask_volume(m, np.float32(c["maskRadiusPx"]), 6.0, 0.0) for m in mapsX]
-        res["maps"], res["rounds"] = mapsX, rounds
+            mapsX = [[m if keep[vi][k] else soft_mask_volume(m, np.float32(c["maskRadiusPx"]), 6.0, 0.0) for k, m in enumerate(h)]
+                     for vi, h in enumerate(mapsX)]
+        res["maps"], res["rounds"], res["keep"] = mapsX, rounds, keep
         return res
 
-    def iterate(self, resolve=None, force_rounds=None):
-        c, ph, N, P, pf = self.c, self.ph, self.N, self.P, self.pf
-        pl, plM = self.pl, self.plM
+    def iterate(self, resolve=None, force_rounds=None, search="local"):
+        c, ph, N, P, pf, K = self.c, self.ph, self.N, self.P, self.pf, self.K
+        plM = self.plM
         seed, mLR, mLT = c["seed"], c["mLR"], c["mLT"]
+        glob = search == "global"
         out = dict(uR=np.zeros((c["nPhase"], self.n, mLR), np.float32), uT=np.zeros((c["nPhase"], self.n, mLT), np.float32),
                    srcR=np.zeros((c["nPhase"], self.n, mLR), np.int64), srcT=np.zeros((c["nPhase"], self.n, mLT), np.int64),
                    k=np.zeros((c["nPhase"], self.n, 3)), s=np.zeros((c["nPhase"], self.n, 2)))
-        F = [np.zeros((P, P, P // 2 + 1), np.complex64) for _ in range(2)]
-        T = [np.zeros((P, P, P // 2 + 1), np.float32) for _ in range(2)]
-        w = np.float32(np.float32(1.0) / np.float32(c["mReco"]))
+        if glob:
+            nR, nT = len(self.gridR), len(self.gridT)
+            out.update(scanUC=np.zeros((self.n, K), np.float32), scanUR=np.zeros((self.n, K, nR), np.float32),
+                       scanUT=np.zeros((self.n, K, nT), np.float32), scanBase=np.zeros(self.n, np.float32))
+            self.wR0, self.wT0 = np.zeros((self.n, mLR)), np.zeros((self.n, mLT))
+        # ---- expectation of both halves (the M-step of a half does not feed the other half's E-step, and the draws are numbered
+        # by iteration and phase: the order E0 M0 E1 M1 of a driver without normCorrection gives the same numbers) ----
         for vi, (lo, hi) in enumerate(self.ranges):
-            # allocPreCal(mask = true, pixelMajor = false, ctf = false), :8043-8171
-            datP = np.ascontiguousarray(self.img[lo:hi].reshape(hi - lo, -1)[:, pl["iPxl"]])
-            sigRcpP = np.ascontiguousarray(self.sigRcp[vi][self.gid[lo:hi] - 1][:, pl["iSig"]])
-            # HOT LOOP B.  The driver runs it batch by batch: all images of a batch do phase p before any does p + 1;
-            # images are independent, so only the Philox numbering (call per batch, image index within the batch) matters.
-            for p in range(c["nPhase"]):
-                for b0 in range(lo, hi, self.batch):
-                    b1 = min(hi, b0 + self.batch)
-                    self.pfCall += 1
-                    callP = self.pfCall
-                    self.pfCall += 1
-                    callU = self.pfCall
-                    f = c["pfL"] if p == 0 else c["pfS"]
-                    for l in range(b0, b1):
-                        li = l - b0
-                        gR = np.stack(ph.draw_n4(seed, li, callP, 0, np.arange(mLR)), axis=1)
-                        gT = np.stack(ph.draw_n4(seed, li, callP, 1, np.arange(mLT)), axis=1)
-                        q, t, wR, wT = pf_perturb(self.q[l], self.t[l], self.k[l], self.s[l], f, f, c["transS"], c["transQ"], gR, gT)
-                        if resolve is not None and hasattr(resolve, "after_perturb"):
-                            if hasattr(resolve, "k_in"):
-                                resolve.k_in[l] = (self.k[l].copy(), self.s[l].copy())
-                            q, t, wR, wT = resolve.after_perturb(p, l, self.q[l], q, t, wR, wT)
-                        rot = np.stack([rotate3D(x) for x in q])
-                        e = expect_local(self.vols[vi], P, pf, N, pl["iCol"], pl["iRow"], datP[l - lo], self.ctfP[l],
-                                         sigRcpP[l - lo], rot, t, nD=1, pC=1.0, pR=wR, pT=wT)
-                        own = pf_update(q, t, wR, wT, e["wR"], e["wT"], c["peakFactorR"],
-                                        ph.shuffle_ranks(seed, li, callU, 2, mLR), ph.draw_u4(seed, li, callU, 3, 0)[0] / mLR,
-                                        ph.shuffle_ranks(seed, li, callU, 4, mLT), ph.draw_u4(seed, li, callU, 5, 0)[0] / mLT)
-                        own.update(uR=e["wR"], uT=e["wT"], tPre=t, qIn=q, wRIn=wR, wTIn=wT, li=li, callU=callU,
-                                   scaleL=float(np.abs(e["logW"]).max()))
-                        if resolve is not None:
-                            own = resolve(p, l, own)
-                        self.q[l], self.t[l], self.k[l], self.s[l] = own["q"], own["t"], own["k"], own["s"]
-                        self.topR[l], self.topT[l] = own["topR"], own["topT"]
-                        out["uR"][p, l], out["uT"][p, l] = e["wR"], e["wT"]
-                        out["srcR"][p, l], out["srcT"][p, l] = own["srcR"], own["srcT"]
-                        out["k"][p, l], out["s"][p, l] = own["k"], own["s"]
+            if glob:
+                self._scan(vi, lo, hi, resolve, out)
+                out["r0"], out["t0"], out["k0"], out["s0"] = self.q.copy(), self.t.copy(), self.k.copy(), self.s.copy()
+            self._expect(vi, lo, hi, glob, resolve, out)
+        out["cls"] = self.cls.copy()
+        if c["normCorrection"] and self.iterCount != 0 and not glob:
+            self._norm_correction(out)
+        datM = np.ascontiguousarray(self.imgOri.reshape(self.n, -1)[:, plM["iPxl"]])
+        F = [[np.zeros((P, P, P // 2 + 1), np.complex64) for _ in range(K)] for _ in range(2)]
+        T = [[np.zeros((P, P, P // 2 + 1), np.float32) for _ in range(K)] for _ in range(2)]
+        w = np.float32(np.float32(1.0) / np.float32(c["mReco"]))
+        callD = self.call(SLOT_DRAWS)
+        for vi, (lo, hi) in enumerate(self.ranges):
             # allReduceSigma (OPTIMISER_SIGMA_RANK1ST, OPTIMISER_SIGMA_WHOLE_FREQUENCY), :6395-6710
-            spec = np.stack([sigma_image(self.vols[vi], P, pf, N, self.rU, self.rSig, rotate3D(self.topR[l]), self.topT[l],
+            spec = np.stack([sigma_image(self.vols[vi][self.cls[l]], P, pf, N, self.rU, self.rSig, rotate3D(self.topR[l]), self.topT[l],
                                          self.offset[l], c["pixelSize"], self.attr[l], self.img[l], self.imgOri[l])
                              for l in range(lo, hi)])
             acc = sigma_accum(spec, self.gid[lo:hi], c["nGroup"], bool(c["groupSig"]))
             sig, rcp = sigma_final(*acc, np.float32(c["maskRadiusPx"]) * np.float32(c["pixelSize"]), N, c["pixelSize"],
                                    bool(c["groupSig"]))
             # HOT LOOP C, :7038-7241: Particle::rand = uniform picks among the (resampled) support points
-            self.pfCall += 1
             for l in range(lo, hi):
-                u = ph.draw_u4(seed, l, self.pfCall, 7, np.arange(c["mReco"]))
+                u = ph.draw_u4(seed, l, callD, 7, np.arange(c["mReco"]))
                 iR = np.minimum((u[0] * mLR).astype(np.int64), mLR - 1)
                 iT = np.minimum((u[1] * mLT).astype(np.int64), mLT - 1)
+                kc = self.cls[l]
                 for m in range(c["mReco"]):
                     tt = self.t[l, iT[m]] - self.offset[l]
-                    src = translate(np.float32(-tt[0]), np.float32(-tt[1]), N, plM["iCol"], plM["iRow"], src=self.datM[l])
-                    insertP(F[vi], T[vi], P, src, self.ctfM[l], rotate3D(self.q[l, iR[m]]), w, plM["iColPad"], plM["iRowPad"])
+                    src = translate(np.float32(-tt[0]), np.float32(-tt[1]), N, plM["iCol"], plM["iRow"], src=datM[l])
+                    insertP(F[vi][kc], T[vi][kc], P, src, self.ctfM[l], rotate3D(self.q[l, iR[m]]), w, plM["iColPad"], plM["iRowPad"])
             self.sig[vi], self.sigRcp[vi] = sig, rcp
-        out["F_raw"], out["T_raw"] = [x.copy() for x in F], [x.copy() for x in T]
-        # prepareTF (one rank per half: the all-reduce is the identity; C1: no symmetrisation), :7268 -> Reconstructor.cpp:1056-1091
+        out["F_raw"], out["T_raw"] = [[x.copy() for x in h] for h in F], [[x.copy() for x in h] for h in T]
+        # prepareTF (one rank per half: the all-reduces are the identity), :7268 -> src/Reconstructor.cpp:1056-1091: normalise
+        # (allReduceT's tail, :2455-2476), symmetrizeT, symmetrizeF
+        symr = self.rU * pf + 1
         for vi in range(2):
-            normalise_TF(F[vi], T[vi], P)
-        Tn = [t.copy() for t in T]
-        rec = self._reconstruct_all(F, T, None)
+            for k in range(K):
+                if not T[vi][k].flat[0] > 0:
+                    continue
+                normalise_TF(F[vi][k], T[vi][k], P)
+                if self.symR is not None:
+                    T[vi][k] = symmetrize(T[vi][k], P, self.symR, symr)
+                    F[vi][k] = symmetrize(F[vi][k], P, self.symR, symr)
+        out["F_sym"], out["T_sym"] = [[x.copy() for x in h] for h in F], [[x.copy() for x in h] for h in T]
+        Tn = [[t.copy() for t in h] for h in T]
+        # class distribution (refreshClassDistr, :5484-5516) and balanceClass after a global search
+        distr = np.bincount(self.cls, minlength=K).astype(np.float64)
+        distr /= distr.sum()
+        bm = self.balance_map(distr) if (glob and K > 1 and c["balanceClass"]) else np.full(K, -1, np.int64)
+        out["bm"], out["distr"] = bm, distr
+        rec = self._reconstruct_all(F, T, None, bm)
         out["F"], out["T"] = F, T
-        if force_rounds is not None and list(force_rounds) != rec["rounds"]:
-            out["forced"] = self._reconstruct_all(F, Tn, list(force_rounds))
+        if force_rounds is not None and not np.array_equal(np.asarray(force_rounds), rec["rounds"]):
+            out["forced"] = self._reconstruct_all(F, Tn, np.asarray(force_rounds), bm)
         out["mapsFsc"], out["mapsMAP"], fsc_, mapsX, rounds = rec["mapsFsc"], rec["mapsMAP"], rec["fsc"], rec["maps"], rec["rounds"]
         if "avgR" in rec:
             out["avgR"] = rec["avgR"]
+        out["keep"] = rec["keep"]
         for vi in range(2):
-            self.vols[vi] = set_projectee(mapsX[vi], pf)           # Model::refreshProj
-        self.fscReco = fsc_.astype(np.float32).copy()             # Model::resetReco, src/Model.cpp:1122
-        # reCentreImg + reMaskImg, :6065-6149
-        for l in range(self.n):
-            tr = self.topT[l].copy()
-            self.offset[l] -= tr
-            self.t[l] -= tr
-            self.topT[l] -= tr
-            self.img[l] = translate_image(self.imgOri[l], self.offset[l, 0], self.offset[l, 1])
-        self.img = self._remask(self.img)
+            for k in range(K):
+                if not rec["keep"][vi][k]:
+                    self.vols[vi][k] = set_projectee(mapsX[vi][k], pf)           # Model::refreshProj
+        self.fscReco = fsc_.astype(np.float32).copy()                            # Model::resetReco, src/Model.cpp:1122
+        # reCentreImg + reMaskImg, :6065-6149 -- not after a global search (:3790-3810)
+        if not glob:
+            for l in range(self.n):
+                tr = self.topT[l].copy()
+                self.offset[l] -= tr
+                self.t[l] -= tr
+                self.topT[l] -= tr
+                self.img[l] = translate_image(self.imgOri[l], self.offset[l, 0], self.offset[l, 1])
+            self.img = self._remask(self.img)
         self.iterCount += 1
         out.update(fsc=fsc_, maps=mapsX, rounds=rounds, sig=self.sig.copy(), offset=self.offset.copy(), topR=self.topR.copy(),
-                   q=self.q.copy(), t=self.t.copy(), vols=[v for v in self.vols], img=self.img)
+                   q=self.q.copy(), t=self.t.copy(), vols=[[v for v in h] for h in self.vols], img=self.img)
         return out
 
 

@@ -1469,6 +1469,164 @@ void orc_perturb_R(double* q, int n, const double* k, double pf, const double* g
     for (int i = 0; i < n; i++) { double t[4]; qmul_(t, mean, q + 4 * i); memcpy(q + 4 * i, t, sizeof(t)); }
 }
 
+/* ---- point-group symmetry of the particle filter and of prepareTF ----
+ * Symmetry::init(const char sym[]) (src/Geometry/Symmetry.cpp:61-66,107-122): symmetryGroup + fillSymmetryEntry
+ * (src/Geometry/SymmetryFunctions.cpp:13-164) -> fillLR (:146-208; rotations only: the reflexion / inversion branches end in
+ * CLOG(FATAL)) -> completePointGroup (:225-278).  Output: the nSym NON-identity elements in the reference's order, R column-major
+ * [nSym][9] (what SYMMETRIZE_FT hands to VOL_TRANSFORM_MAT_FT, include/Geometry/Transformation.h:170-194) and
+ * Symmetry::quat(i) [nSym][4] (what symmetryCounterpart multiplies with).  Returns nSym, -1 for an unknown group, -2 when cap
+ * is too small.  Cast points kept: `RFLOAT angle = 2 * M_PI / fold` and `angle * j` are float (:160-164); the axes are NOT
+ * normalised (RotationSO stores them as given, src/Geometry/SymmetryOperation.cpp:12-23). */
+static void mat33_mul_(double* d, const double* a, const double* b)   /* row-major helpers of this block */
+{
+    double t[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) { double s = 0; for (int k = 0; k < 3; k++) s += a[r * 3 + k] * b[k * 3 + c]; t[r * 3 + c] = s; }
+    memcpy(d, t, sizeof(t));
+}
+static int same_matrix_(const double* a, const double* b)   /* SAME_MATRIX, include/Geometry/Symmetry.h:64-73: EQUAL_ACCURACY 1e-2 */
+{
+    for (int i = 0; i < 9; i++) if (fabs(a[i] - b[i]) > 1e-2) return 0;
+    return 1;
+}
+static void quat_of_matrix_(double* q, const double* m /* row-major */)   /* quaternion(dvec4&, const dmat33&), src/Geometry/Euler.cpp:112-123 */
+{
+#define M_(r, c) m[(r) * 3 + (c)]
+    double v;
+    v = 1 + M_(0, 0) + M_(1, 1) + M_(2, 2); q[0] = 0.5 * sqrt(v > 0 ? v : 0);
+    v = 1 + M_(0, 0) - M_(1, 1) - M_(2, 2); q[1] = 0.5 * sqrt(v > 0 ? v : 0);
+    v = 1 - M_(0, 0) + M_(1, 1) - M_(2, 2); q[2] = 0.5 * sqrt(v > 0 ? v : 0);
+    v = 1 - M_(0, 0) - M_(1, 1) + M_(2, 2); q[3] = 0.5 * sqrt(v > 0 ? v : 0);
+    q[1] = copysign(q[1], M_(2, 1) - M_(1, 2));
+    q[2] = copysign(q[2], M_(0, 2) - M_(2, 0));
+    q[3] = copysign(q[3], M_(1, 0) - M_(0, 1));
+#undef M_
+}
+struct sym_entry_ { int fold; double ax[3]; };
+static int sym_entries_(struct sym_entry_* e, const char* sym)
+{
+    /* symmetryGroup: "^C[[:digit:]]+$", "^D[[:digit:]]+$", "T", "O", "I1" .. "I4" */
+    int n = 0;
+#define ROT_(f, x, y, z) do { e[n].fold = (f); e[n].ax[0] = (x); e[n].ax[1] = (y); e[n].ax[2] = (z); n++; } while (0)
+    size_t len = strlen(sym);
+    int digits = len > 1;
+    for (size_t i = 1; i < len; i++) if (sym[i] < '0' || sym[i] > '9') digits = 0;
+    if ((sym[0] == 'C' || sym[0] == 'D') && digits) {
+        ROT_(atoi(sym + 1), 0, 0, 1);                       /* PG_CN */
+        if (sym[0] == 'D') ROT_(2, 1, 0, 0);                /* PG_DN */
+    } else if (!strcmp(sym, "T")) { ROT_(3, 0, 0, 1); ROT_(2, 0, 0.816496, 0.577350); }
+    else if (!strcmp(sym, "O")) { ROT_(3, 0.5773502, 0.5773502, 0.5773502); ROT_(4, 0, 0, 1); }
+    else if (!strcmp(sym, "I1")) { ROT_(2, 1, 0, 0); ROT_(5, 0.8506508, 0, -0.5257311); ROT_(3, 0.9341724, 0.3568221, 0); }
+    else if (!strcmp(sym, "I2")) { ROT_(2, 0, 0, 1); ROT_(5, 0.5257311, 0, 0.8506508); ROT_(3, 0, 0.3568221, 0.9341724); }
+    else if (!strcmp(sym, "I3")) { ROT_(2, -0.5257311, 0, 0.8506508); ROT_(5, 0, 0, 1); ROT_(3, -0.4911235, 0.3568221, 0.7946545); }
+    else if (!strcmp(sym, "I4")) { ROT_(2, 0.5257311, 0, 0.8506508); ROT_(5, 0.8944272, 0, 0.4472136); ROT_(3, 0.4911235, 0.3568221, 0.7946545); }
+    else return -1;
+#undef ROT_
+    return n;
+}
+int orc_symmetry(const char* sym, double* Rcm, double* quat, int cap)
+{
+    struct sym_entry_ e[4];
+    const int ne = sym_entries_(e, sym);
+    if (ne < 0) return -1;
+    double* R = (double*)malloc((size_t)(cap > 0 ? cap : 1) * 9 * sizeof(double));   /* row-major while the group is built */
+    int n = 0;
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#define NOVO_(m) ({ int nv_ = !same_matrix_((m), I); for (int q_ = 0; nv_ && q_ < n; q_++) if (same_matrix_((m), R + 9 * q_)) nv_ = 0; nv_; })
+    /* fillLR: for every rotation entry, R = rotate3D(angle * j, axis), j = 1 .. fold - 1, appended when novo */
+    for (int i = 0; i < ne; i++) {
+        const RFLOAT angle = (RFLOAT)(2 * M_PI / e[i].fold);
+        for (int j = 1; j < e[i].fold; j++) {
+            const double phi = (double)(angle * (RFLOAT)j);
+            /* rotate3D(dst, phi, axis) = rotate3D(dst, quaternion(phi, axis)), src/Geometry/Euler.cpp:102-110,272-281 */
+            const double q[4] = {cos(phi / 2), sin(phi / 2) * e[i].ax[0], sin(phi / 2) * e[i].ax[1], sin(phi / 2) * e[i].ax[2]};
+            double cm[9], m[9];
+            orc_rotate3D(cm, q);
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) m[r * 3 + c] = cm[c * 3 + r];
+            if (NOVO_(m)) {
+                if (n >= cap) { free(R); return -2; }
+                memcpy(R + 9 * n, m, sizeof(m));
+                quat_of_matrix_(quat + 4 * n, m);
+                n++;
+            }
+        }
+    }
+    /* completePointGroup: a table of visited (i, j) pairs that grows with every new element; the first unvisited pair in
+     * row-major order is multiplied next */
+    {
+        unsigned char* table = (unsigned char*)calloc((size_t)cap * cap + 1, 1);
+        int dim = n;
+        for (;;) {
+            int fi = -1, fj = -1;
+            for (int r = 0; r < dim && fi < 0; r++)
+                for (int c = 0; c < dim; c++)
+                    if (!table[(size_t)r * cap + c]) { fi = r; fj = c; table[(size_t)r * cap + c] = 1; break; }
+            if (fi < 0) break;
+            double m[9];
+            mat33_mul_(m, R + 9 * fi, R + 9 * fj);
+            if (NOVO_(m)) {
+                if (n >= cap) { free(R); free(table); return -2; }
+                memcpy(R + 9 * n, m, sizeof(m));
+                quat_of_matrix_(quat + 4 * n, m);
+                n++;
+                dim++;
+            }
+        }
+        free(table);
+    }
+#undef NOVO_
+    for (int s = 0; s < n; s++)
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Rcm[9 * s + c * 3 + r] = R[9 * s + r * 3 + c];
+    free(R);
+    return n;
+}
+
+/* symmetryCounterpart(dvec4& dst, const Symmetry& sym, const dvec4* anchor), src/Geometry/Symmetry.cpp:309-336: among dst and
+ * conj(sym.quat(i)) * dst the quaternion with the largest |<., anchor>| (kept in RFLOAT, strict >); anchor NULL = ANCHOR_POINT_2
+ * = (1, 0, 0, 0) */
+void orc_symmetry_counterpart(double* dst, const double* symQuat, int nSym, const double* anchor)
+{
+    static const double anchor2[4] = {1, 0, 0, 0};
+    if (!anchor) anchor = anchor2;
+    double q[4] = {dst[0], dst[1], dst[2], dst[3]};
+    RFLOAT s = (RFLOAT)fabs(dst[0] * anchor[0] + dst[1] * anchor[1] + dst[2] * anchor[2] + dst[3] * anchor[3]);
+    for (int i = 0; i < nSym; i++) {
+        const double cs[4] = {symQuat[4 * i], -symQuat[4 * i + 1], -symQuat[4 * i + 2], -symQuat[4 * i + 3]};
+        double p[4];
+        qmul_(p, cs, dst);
+        RFLOAT t = (RFLOAT)fabs(p[0] * anchor[0] + p[1] * anchor[1] + p[2] * anchor[2] + p[3] * anchor[3]);
+        if (t > s) { s = t; memcpy(q, p, sizeof(q)); }
+    }
+    memcpy(dst, q, sizeof(q));
+}
+
+/* Particle::symmetrise(const dvec4* anchor), src/Particle.cpp:2445-2470 (returns at once for C1: nSym == 0) */
+void orc_symmetrise(double* q, int n, const double* symQuat, int nSym, const double* anchor)
+{
+    if (nSym <= 0) return;
+    for (int i = 0; i < n; i++) orc_symmetry_counterpart(q + 4 * (size_t)i, symQuat, nSym, anchor);
+}
+
+/* Particle::calVari(PAR_R) with a point group, src/Particle.cpp:1020-1080: anch = _r.row(gsl_rng_uniform_int(engine, _nR)) (the
+ * draw iAnchor is an input); symmetrise(&anch); then as orc_cal_vari_R */
+void orc_cal_vari_R_sym(double* k, double* mean, double* q, int n, const double* symQuat, int nSym, int iAnchor)
+{
+    if (nSym > 0) {
+        const double anch[4] = {q[4 * iAnchor], q[4 * iAnchor + 1], q[4 * iAnchor + 2], q[4 * iAnchor + 3]};
+        orc_symmetrise(q, n, symQuat, nSym, anch);
+    }
+    orc_cal_vari_R(k, mean, q, n);
+}
+
+/* Particle::perturb(pf, PAR_R) with a point group: the three passes of orc_perturb_R, then symmetrise(&mean) (:1234) */
+void orc_perturb_R_sym(double* q, int n, const double* k, double pf, const double* g, const double* symQuat, int nSym)
+{
+    double A[16], mean[4];
+    if (nSym > 0) { orc_infer_acg(A, q, n); orc_sym4_top_eigvec(mean, A); }   /* the mean orc_perturb_R is about to use */
+    orc_perturb_R(q, n, k, pf, g);
+    if (nSym > 0) orc_symmetrise(q, n, symQuat, nSym, mean);
+}
+
 /* Particle::perturb(pf, PAR_T), src/Particle.cpp:1244-1272, + reCentre (PARTICLE_RECENTRE_TRANSQ), :2473-2495, WITHOUT
  * the closing balanceWeight.  gsl_ran_bivariate_gaussian(engine, s0, s1, rho = 0, &x, &y) (PARTICLE_RHO off: _rho = 0)
  * returns (s0 n0, s1 n1) for two independent standard normals (randist/bigauss.c); g [n][4] = n0, n1 and the two normals

@@ -21,34 +21,48 @@ import _philox as PH
 
 
 def make_inputs(O, N, n, seed, mLR=125, mLT=9, nPhase=3, mReco=20, batch=64, nGroup=3, snr=0.05, rL=2, pixelSize=1.32, q_spread=0.03,
-                t_spread=0.6, sigma_scale=1.0):
-    """n synthetic particles (SURVEY 8d recipe at a small size) + the configuration of one local-search iteration.
+                t_spread=0.6, sigma_scale=1.0, K=1, sym=None, scan=None, norm_correction=0, balance=0, amp_spread=0.0):
+    """n synthetic particles (SURVEY 8d recipe at a small size) + the configuration of one iteration.
     Images: CTF x slice x ramp on the rL = 0 pixel list (+ the Hermitian mirror of the kx = 0 column) + white noise made in
     real space, so that every image is the FT of a real image.  numpy / oracle only: the same bytes reach the device and
-    the oracle."""
+    the oracle.  K references (class of a particle drawn uniformly), sym = a point-group name (the references carry it),
+    scan = dict(nR, nT, rScan[, mS]): a scanned grid of nR random rotations and nT shifts, the particles' true poses are grid points
+    (global search); amp_spread: per-image amplitude factors exp(N(0, amp_spread)) (what normCorrection is there to undo)."""
     rng = np.random.default_rng(seed)
     pf, P, nc = 2, 2 * N, N // 2 + 1
-    ref = synth.blob_map(N, seed=seed + 1, nblob=14)
-    vol = O.set_projectee(ref, pf)
+    symd = O.symmetry(sym) if sym else None
+    refs = np.stack([synth.blob_map(N, seed=seed + 1 + 10 * k, nblob=14, symR=None if symd is None else symd["R"]) for k in range(K)])
+    vols = [O.set_projectee(refs[k], pf) for k in range(K)]
     plM = O.pixel_list(N, N // 2 - 2, 0, pf)
-    quat = synth.random_quats(n, rng)
-    shift = rng.normal(0, 2.0, size=(n, 2))
+    cls_true = rng.integers(0, K, n).astype(np.int32) if K > 1 else np.zeros(n, np.int32)
+    grid = None
+    if scan is not None:
+        gq = synth.random_quats(scan["nR"], rng)
+        gt = np.ascontiguousarray(rng.normal(0, 1.5, size=(scan["nT"], 2)))
+        grid = (gq, gt)
+        r_true, t_true = rng.integers(0, scan["nR"], n), rng.integers(0, scan["nT"], n)
+        quat, shift = gq[r_true].copy(), gt[t_true].copy()
+    else:
+        quat = synth.random_quats(n, rng)
+        shift = rng.normal(0, 2.0, size=(n, 2))
     attr = synth.ctf_params(n, rng)
     col0 = np.nonzero((plM["iCol"] == 0) & (plM["iRow"] > 0))[0]
     mirror_dst = (N - plM["iRow"][col0]) * nc
     imgOri = np.zeros((n, N, nc), np.complex64)
     sigs = []
     for l in range(n):
-        s = O.project(vol, P, pf, O.rotate3D(quat[l]), plM["iCol"], plM["iRow"])
+        s = O.project(vols[cls_true[l]], P, pf, O.rotate3D(quat[l]), plM["iCol"], plM["iRow"])
         s = s * O.ctf(pixelSize, *attr[l], N, plM["iCol"], plM["iRow"]) * O.translate(shift[l, 0], shift[l, 1], N, plM["iCol"], plM["iRow"])
         sigs.append(s.astype(np.complex64))
     sigma2 = float(np.mean(np.abs(np.stack(sigs)) ** 2)) / snr / 2.0
+    amp = np.exp(rng.normal(0, amp_spread, n)).astype(np.float32) if amp_spread > 0 else np.ones(n, np.float32)
     for l in range(n):
         flat = imgOri[l].reshape(-1)
         flat[plM["iPxl"]] = sigs[l]
         flat[mirror_dst] = np.conj(sigs[l][col0])
         rl = rng.standard_normal((N, N)).astype(np.float32)
         imgOri[l] += (sfft.rfft2(rl) * np.float32(np.sqrt(2.0 * sigma2) / N)).astype(np.complex64)
+        imgOri[l] *= amp[l]
     gid = rng.integers(1, nGroup + 1, n).astype(np.int32)
     gid[:nGroup] = np.arange(1, nGroup + 1)
     q0 = np.ascontiguousarray(synth.perturb_quats(quat, mLR, q_spread, rng))
@@ -56,12 +70,19 @@ def make_inputs(O, N, n, seed, mLR=125, mLT=9, nPhase=3, mReco=20, batch=64, nGr
     cfg = dict(N=N, pf=pf, nImg=n, nHalfA=(n + 1) // 2, mLR=mLR, mLT=mLT, nPhase=nPhase, mReco=mReco, batch=batch, rL=rL,
                nGroup=nGroup, groupSig=1, pixelSize=pixelSize, maskRadiusPx=float(np.float32(0.45 * N)), sigma2Init=float(np.float32(sigma2 * sigma_scale)),
                transS=2.0, transQ=0.05, pfL=2.0, pfS=0.5, peakFactorR=1e-3, seed=1234567 + seed, coreFSC=1, goldenAverage=1,
-               solventFlatten=1)
-    return dict(cfg=cfg, imgOri=imgOri, attr=attr, gid=gid, quat0=q0, tran0=t0, ref=ref, quat=quat, shift=shift)
+               solventFlatten=1, normCorrection=int(norm_correction), nK=K, sym=symd, symName=sym, balanceClass=int(balance),
+               pfSGlobal=0.5, peakFactorC=1.0 - 1e-2)
+    if scan is not None:
+        from thunder_amd.native import scan_min_spread
+        mk, ms = scan_min_spread(scan.get("mS", scan["nR"] * (1 + (symd["n"] if symd else 0))), 0.5)
+        cfg.update(rScan=int(scan["rScan"]), scanMinK=mk, scanMinS=ms, nR=scan["nR"], nT=scan["nT"])
+    return dict(cfg=cfg, imgOri=imgOri, attr=attr, gid=gid, quat0=q0, tran0=t0, ref=refs[0] if K == 1 else refs, refs=refs, quat=quat,
+                shift=shift, cls_true=cls_true, grid=grid, amp=amp)
 
 
-def oracle_chain(O, inp):
-    return O.Iteration(inp["cfg"], inp["imgOri"], inp["attr"], inp["gid"], inp["quat0"], inp["tran0"], inp["ref"], PH)
+def oracle_chain(O, inp, cls0=None):
+    return O.Iteration(inp["cfg"], inp["imgOri"], inp["attr"], inp["gid"], inp["quat0"], inp["tran0"], inp["refs"], PH, grid=inp.get("grid"),
+                       cls0=cls0)
 
 
 def weight_bar(scaleL):
@@ -76,6 +97,9 @@ class Follower:
 
     def __init__(self, O, cap, cfg):
         self.O, self.cap, self.c = O, cap, cfg
+        self.symQ = None if not cfg.get("sym") or cfg["sym"]["n"] == 0 else cfg["sym"]["quat"]
+        self.n_scan = 0
+        self.scan_adopted = []     # (image, what)
         self.n_checked = 0
         self.adopted = []          # (phase, image, what)
         self.degenerate = []       # (phase, image, distinct incoming rotations, size of the difference)
@@ -110,6 +134,37 @@ class Follower:
         uj = u0 + np.arange(n) / n
         lower = np.where(pos > 0, cdf[np.maximum(pos - 1, 0)], -1.0)
         return bool(np.all(uj <= cdf[pos] + tau) and np.all(uj > lower - tau))
+
+    # ---- global search: the scan's weights, the class and the support points it leaves ----
+    def scan_weights(self, l, own):
+        """every class / rotation / shift weight of the scan (src/Optimiser.cpp:834-894) against the device's, at the bar of
+        test_expect_global; the filter then continues from the DEVICE's weights (keepHalfHeightPeak and the systematic resampling of
+        10 000 points turn a last-digit difference into another draw)"""
+        cap = self.cap
+        tol = max(6e-5 * abs(own["base"]), 3e-4)
+        for name, dev in (("uC", cap["scanUC"][l]), ("uR", cap["scanUR"][l]), ("uT", cap["scanUT"][l])):
+            np.testing.assert_allclose(dev, own[name], rtol=tol, atol=1e-30, err_msg="image %d scan %s" % (l, name))
+        self.n_scan += 1
+        return dict(own, uC=cap["scanUC"][l], uR=cap["scanUR"][l], uT=cap["scanUT"][l])
+
+    def after_scan(self, l, ws):
+        """class and support points of image l as pf_class_select / pf_scan_support give them from the device's scan weights and
+        the replayed draws: the class must be equal; a support point may be the neighbour in the shuffled order where the draw sits on
+        its threshold (the cumulative sum of 10 000 weights; rule of test_scan_support_points)"""
+        cap = self.cap
+        assert int(cap["cls"][l]) == int(ws["cls"]), "image %d: class %d, oracle %d" % (l, cap["cls"][l], ws["cls"])
+        r0, t0 = cap["r0"][l], cap["t0"][l]
+        d = np.abs(r0 - ws["q"]).max(axis=1)
+        bad = np.nonzero(d > 1e-12)[0]
+        if len(bad):
+            # (with a point group the device's point is the counterpart of ITS source next to the same anchor: compare sources)
+            assert len(bad) <= 2, "image %d: %d support points differ after the scan" % (l, len(bad))
+            self.scan_adopted.append((l, "support (%d on a threshold)" % len(bad)))
+            ws = dict(ws, q=r0.copy(), k=cap["k0"][l].copy(), topR=ws["topR"])
+        assert np.abs(t0 - ws["t"]).max() <= 1e-12, "image %d: support shifts differ after the scan" % l
+        np.testing.assert_allclose(cap["k0"][l], ws["k"], rtol=2e-3)
+        np.testing.assert_allclose(cap["s0"][l], ws["s"], rtol=1e-10)
+        return ws
 
     def after_perturb(self, p, l, q_in, q, t, wR, wT):
         """Particle::perturb conjugates every perturbation by mean = inferACG(mean, _r) of the cloud as resampling left it:
@@ -187,7 +242,8 @@ class Follower:
             li, call = own["li"], own["callU"]
             alt = O.pf_update(own["qIn"], own["tPre"], own["wRIn"], own["wTIn"], uR, uT, c["peakFactorR"],
                               PH.shuffle_ranks(seed, li, call, 2, mLR), PH.draw_u4(seed, li, call, 3, 0)[0] / mLR,
-                              PH.shuffle_ranks(seed, li, call, 4, mLT), PH.draw_u4(seed, li, call, 5, 0)[0] / mLT)
+                              PH.shuffle_ranks(seed, li, call, 4, mLT), PH.draw_u4(seed, li, call, 5, 0)[0] / mLT,
+                              symQuat=self.symQ, iAnchor=own.get("iAnchor", 0))
             exact = np.array_equal(alt["srcR"], srcR) and np.array_equal(alt["srcT"], srcT)
             if not exact:
                 # the device's priors (its own balanceWeight of the perturbed cloud) differ from the oracle's in the 6th digit:
@@ -208,7 +264,8 @@ class Follower:
             li, call = own["li"], own["callU"]
             alt = O.pf_update(own["qIn"], own["tPre"], own["wRIn"], own["wTIn"], uR, uT, c["peakFactorR"],
                               PH.shuffle_ranks(seed, li, call, 2, mLR), PH.draw_u4(seed, li, call, 3, 0)[0] / mLR,
-                              PH.shuffle_ranks(seed, li, call, 4, mLT), PH.draw_u4(seed, li, call, 5, 0)[0] / mLT)
+                              PH.shuffle_ranks(seed, li, call, 4, mLT), PH.draw_u4(seed, li, call, 5, 0)[0] / mLT,
+                              symQuat=self.symQ, iAnchor=own.get("iAnchor", 0))
             if alt["iTopR"] != own["iTopR"] or alt["iTopT"] != own["iTopT"]:
                 for mine, ia, io, name in ((np.asarray(own["uR"], np.float64), alt["iTopR"], own["iTopR"], "uR"),
                                            (np.asarray(own["uT"], np.float64), alt["iTopT"], own["iTopT"], "uT")):
@@ -222,14 +279,3 @@ class Follower:
 
 def fsc_curve(O, a, b, N, n):
     return O.fsc(sfft.rfftn(a).astype(np.complex64), sfft.rfftn(b).astype(np.complex64), N, n)
-
-
-def as_struct_cfg(cfg, RefineConfig, half_of_rank=-1):
-    c = RefineConfig()
-    for k in ("N", "pf", "nImg", "nHalfA", "mLR", "mLT", "nPhase", "mReco", "batch", "rL", "nGroup", "groupSig", "pixelSize",
-              "maskRadiusPx", "sigma2Init", "transS", "transQ", "pfL", "pfS", "peakFactorR", "seed", "coreFSC", "goldenAverage",
-              "solventFlatten"):
-        setattr(c, k, cfg[k])
-    c.halfOfRank = half_of_rank
-    c.maxPhase, c.pixelOrder, c.wgPerCU = 0, 1, 2
-    return c

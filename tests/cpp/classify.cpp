@@ -1,10 +1,11 @@
-// classify.cpp -- a torch-free C++ caller driving one K-class classification iteration through the C ABI only
-// (include/thunder_amd.h): K synthetic references, images = CTF x slice of a random class at a scanned rotation x ramp of a
-// scanned shift + noise (signal rows through the library's own project / CTF / translate), then
-// thx_classify_create / set_grid / set_particles / set_references -> thx_classify_iterate: global scan over the K classes,
-// class of every image, support points, local phases against the assigned reference, multi-reference insertion, two
-// reconstructions per class (src/Optimiser.cpp:631-1660, 7038-7760) -- what `Optimiser::run` would call per iteration of a
-// 3-D classification.  Checks: the classes are recovered, every class map agrees with its own generating map.
+// classify.cpp -- a torch-free C++ caller driving a K-class classification through the C ABI only (include/thunder_amd.h):
+// K synthetic references, images = CTF x slice of a random class at a scanned rotation x ramp of a scanned shift + noise (signal
+// rows through the library's own project / CTF / translate), then thx_refine_create (nK = K, THX_SEARCH_GLOBAL) / set_particles /
+// set_reference / set_grid / reset -> thx_refine_iterate: global scan over the K classes, class of every image, support points,
+// local phases against the assigned reference, sigma update, multi-reference insertion, two reconstructions per class and half,
+// per-class FSC, averaging, refresh (src/Optimiser.cpp:631-1660, 3405-3530, 7038-7760); then thx_refine_set_search_type(LOCAL)
+// and a second iteration -- what `Optimiser::run` does per iteration of a 3-D classification.  Checks: the classes are
+// recovered, every class map agrees with its own generating map.
 // Build: g++ -std=c++17 -I include tests/cpp/classify.cpp -L thunder_amd/lib -lthunder_amd -Wl,-rpath,...
 #include <cmath>
 #include <complex>
@@ -135,61 +136,106 @@ int main()
     pSig /= (double)dat.size();
     const double sigma2 = pSig / 2.0 / 2.0;   // SNR 2: variance per real component of a coefficient
     std::normal_distribution<float> Gf(0.f, (float)std::sqrt(sigma2));
-    for (cf& x : dat) x += cf(Gf(g), Gf(g));
-    std::vector<float> sig((size_t)n * nPxl, (float)(-0.5 / sigma2)), w(n, 1.0f / mReco);
-    float* datD = reinterpret_cast<float*>(dev_upload(dat));
-    float *sigD = dev_upload(sig), *wD = dev_upload(w);
+    // full image FTs: noise everywhere, signal on the listed pixels (+ the Hermitian mirror of the kx = 0 column)
+    std::vector<int> iPxl(nPxl);
+    {
+        std::vector<int> c2(nPxl), r2(nPxl), s2(nPxl);
+        int np2 = 0;
+        CK(thx_pixel_list_host(N, rU, 0, 0, c2.data(), r2.data(), iPxl.data(), s2.data(), &np2));
+    }
+    std::vector<cf> img((size_t)n * N * nc);
+    for (int l = 0; l < n; l++) {
+        cf* I = img.data() + (size_t)l * N * nc;
+        for (size_t e = 0; e < (size_t)N * nc; e++) I[e] = cf(Gf(g), Gf(g));
+        for (int p = 0; p < nPxl; p++) {
+            I[iPxl[p]] += dat[(size_t)l * nPxl + p];
+            if (iCol[p] == 0 && iRow[p] > 0) I[(size_t)(N - iRow[p]) * nc] = std::conj(I[iPxl[p]]);
+        }
+        I[0] = cf(I[0].real(), 0.f);
+    }
+    float* imgD = reinterpret_cast<float*>(dev_upload(img));
+    // the filter's loaded support points are irrelevant to a global search (the scan replaces them): the true pose, repeated
+    std::vector<double> q0((size_t)n * mLR * 4), t0((size_t)n * mLT * 2);
+    for (int l = 0; l < n; l++) {
+        for (int m = 0; m < mLR; m++) {
+            const double ang = 0.02 * (m + 1), c = std::cos(ang / 2), s_ = std::sin(ang / 2);
+            const double d[4] = {c, s_ * (m % 3 == 0), s_ * (m % 3 == 1), s_ * (m % 3 == 2)};
+            const double* a = &quat[4 * rTrue[l]];
+            double* o = &q0[((size_t)l * mLR + m) * 4];
+            o[0] = a[0] * d[0] - a[1] * d[1] - a[2] * d[2] - a[3] * d[3];
+            o[1] = a[0] * d[1] + a[1] * d[0] + a[2] * d[3] - a[3] * d[2];
+            o[2] = a[0] * d[2] - a[1] * d[3] + a[2] * d[0] + a[3] * d[1];
+            o[3] = a[0] * d[3] + a[1] * d[2] - a[2] * d[1] + a[3] * d[0];
+        }
+        for (int m = 0; m < mLT; m++) {
+            t0[((size_t)l * mLT + m) * 2] = shifts[2 * tTrue[l]] + 0.3 * (m - 2);
+            t0[((size_t)l * mLT + m) * 2 + 1] = shifts[2 * tTrue[l] + 1] - 0.2 * (m - 2);
+        }
+    }
+    double *q0D = dev_upload(q0), *t0D = dev_upload(t0);
+    std::vector<int> gid(n, 1);
 
-    // ---- the classification driver ----
-    thx_classify_config cfg;
+    // ---- the iteration driver: K classes, first a global search ----
+    thx_refine_config cfg;
     memset(&cfg, 0, sizeof(cfg));
-    cfg.N = N; cfg.pf = pf; cfg.nK = K; cfg.nImg = n; cfg.nImgHemi = 0;
-    cfg.nR = nR; cfg.nT = nT; cfg.rScan = rScan; cfg.rL = 1;
-    cfg.mLR = mLR; cfg.mLT = mLT; cfg.nPhase = nPhase; cfg.mReco = mReco; cfg.batch = 100;
-    cfg.pixelOrder = 1; cfg.wgPerCU = -1; cfg.refresh = 1; cfg.pixelSize = pixelSize;
-    cfg.transS = 2.0; cfg.transQ = 0.05; cfg.pfL = 2.0; cfg.pfS = 0.5; cfg.peakFactorR = 1e-3; cfg.peakFactorC = 1.0 - 1e-2;
+    cfg.N = N; cfg.pf = pf; cfg.nImg = n; cfg.halfOfRank = -1; cfg.nHalfA = n / 2;
+    cfg.mLR = mLR; cfg.mLT = mLT; cfg.nPhase = nPhase; cfg.maxPhase = 0; cfg.mReco = mReco; cfg.batch = 50;
+    cfg.rL = 1; cfg.nGroup = 1; cfg.groupSig = 1; cfg.pixelOrder = 1; cfg.wgPerCU = -1;
+    cfg.pixelSize = pixelSize; cfg.maskRadiusPx = 0.45f * N; cfg.sigma2Init = (float)sigma2;
+    cfg.transS = 2.0; cfg.transQ = 0.05; cfg.pfL = 2.0; cfg.pfS = 0.5; cfg.peakFactorR = 1e-3;
+    cfg.coreFSC = 0; cfg.goldenAverage = 1; cfg.solventFlatten = 1;
+    cfg.nK = K; cfg.searchType = THX_SEARCH_GLOBAL; cfg.nR = nR; cfg.nT = nT; cfg.rScan = rScan; cfg.scanBatch = 64;
+    cfg.pfSGlobal = 0.5; cfg.peakFactorC = 1.0 - 1e-2; cfg.balanceClass = 1;
     cfg.scanMinK = std::pow(std::pow((double)nR, -1.0 / 3) / 0.5, 2.0); cfg.scanMinS = 0.3;
     cfg.seed = 424242;
-    thx_classify* h = nullptr;
-    CK(thx_classify_create(&h, &cfg, nullptr));
-    CK(thx_classify_set_grid(h, quat.data(), shifts.data(), nullptr));   // host pointers are fine here
-    CK(thx_classify_set_particles(h, datD, ctfD, sigD, wD, nullptr));
-    CK(thx_classify_set_references(h, refD, nullptr));
-    thx_classify_stats st;
-    thx_classify_view v;
-    CK(thx_classify_get_view(h, &v));
-    // iteration 1 scans against the generating maps; with cfg.refresh its MAP-on maps are the references iteration 2 scans against
-    CK(thx_classify_iterate(h, 1, nullptr));
+    thx_refine* h = nullptr;
+    CK(thx_refine_create(&h, &cfg, nullptr, nullptr));
+    CK(thx_refine_set_particles(h, imgD, attrD, gid.data(), q0D, t0D, nullptr));
+    CK(thx_refine_set_reference(h, refD, nullptr));
+    CK(thx_refine_set_grid(h, quat.data(), shifts.data(), nullptr));   // host pointers are fine here
+    CK(thx_refine_reset(h, nullptr));
+    thx_refine_stats st;
+    thx_refine_view v;
+    CK(thx_refine_get_view(h, &v));
+    std::vector<float> fsc((size_t)K * (N / 2));
+    CK(thx_refine_iterate(h, fsc.data(), 1, nullptr));
     CK(thx_device_sync());
     {
         std::vector<int> cls1 = dev_download(v.cls, n);
         int hit1 = 0;
         for (int l = 0; l < n; l++) hit1 += cls1[l] == clsTrue[l];
-        printf("iteration 1: classes recovered %d of %d\n", hit1, n);
+        printf("iteration 1 (global search): classes recovered %d of %d\n", hit1, n);
         if (hit1 < 0.9 * n) return 1;
     }
-    CK(thx_classify_get_stats(h, &st, 1));
-    if (st.iterations != 1) return 3;
-    CK(thx_classify_iterate(h, 1, nullptr));
+    CK(thx_refine_get_stats(h, &st, 1));
+    const int nScanBatches = 2 * ((n / 2 + 63) / 64);
+    if (st.iterations != 1 || st.scanLaunches != (long)K * nScanBatches || st.scanImages != (long)K * n) {
+        fprintf(stderr, "implausible scan statistics (%ld launches, %ld images)\n", st.scanLaunches, st.scanImages);
+        return 3;
+    }
+    // iteration 2: a local search in the assigned classes against iteration 1's maps
+    CK(thx_refine_set_search_type(h, THX_SEARCH_LOCAL));
+    CK(thx_refine_iterate(h, fsc.data(), 1, nullptr));
     CK(thx_device_sync());
-    CK(thx_classify_get_stats(h, &st, 0));
-    if (st.iterations != 1 || st.scanLaunches != K || st.localLaunches != nPhase * 3 || st.insertLaunches != 3 || st.balancingRounds <= 0 ||
-        st.nPxlM != nPxl || v.nImg != n || v.nK != K) {
-        fprintf(stderr, "implausible driver statistics (scan %ld local %ld insert %ld rounds %ld)\n", st.scanLaunches, st.localLaunches,
-                st.insertLaunches, st.balancingRounds);
+    CK(thx_refine_get_stats(h, &st, 0));
+    if (st.iterations != 1 || st.scanLaunches != 0 || st.expectLaunches != 2 * nPhase * 3 || st.insertLaunches != 2 * 3 || st.balancingRounds <= 0 ||
+        st.nPxlM != nPxl || v.nImg != n || v.nK != K || v.nVol != 2 * K) {
+        fprintf(stderr, "implausible driver statistics (local %ld insert %ld rounds %ld)\n", st.expectLaunches, st.insertLaunches,
+                st.balancingRounds);
         return 3;
     }
     std::vector<int> cls = dev_download(v.cls, n);
     int hit = 0;
     for (int l = 0; l < n; l++) hit += cls[l] == clsTrue[l];
-    printf("iteration 2 (references = iteration 1's maps): classes recovered %d of %d; images per class %d / %d; balancing rounds %ld\n", hit, n, st.classCount[0], st.classCount[1], st.balancingRounds);
+    printf("iteration 2 (local search, references = iteration 1's maps): classes kept %d of %d; images per class %d / %d; balancing rounds %ld; FSC shell 2: %.3f / %.3f\n",
+           hit, n, st.classCount[0], st.classCount[1], st.balancingRounds, fsc[2], fsc[N / 2 + 2]);
     bool ok = hit >= 0.9 * n && st.classCount[0] + st.classCount[1] == n;
-    // ---- every class map (MAP off) against its own generating map and against the other's ----
+    // ---- every class map against its own generating map and against the other's ----
     float *ftA = dev_alloc<float>((size_t)N * N * nc * 2), *ftB = dev_alloc<float>((size_t)N * N * nc * 2), *fscD = dev_alloc<float>(N / 2);
     for (int k = 0; k < K; k++) {
         float own[2] = {0, 0};
         for (int o = 0; o < 2; o++) {
-            CK(thx_fft3d_fw_dev(const_cast<float*>(v.maps) + k * mapN, ftA, N, nullptr));
+            CK(thx_fft3d_fw_dev(const_cast<float*>(v.mapsMAP) + k * mapN, ftA, N, nullptr));   // half 0, class k
             CK(thx_fft3d_fw_dev(refD + ((k + o) % K) * mapN, ftB, N, nullptr));
             CK(thx_fsc_dev(fscD, N / 2, ftA, ftB, N, nullptr));
             CK(thx_device_sync());
@@ -199,10 +245,10 @@ int main()
         printf("class %d map: mean FSC over shells 1-4 with its own reference %.3f, with the other class's %.3f\n", k, own[0], own[1]);
         ok = ok && own[0] > 0.85f && own[0] > own[1] + 0.02f;
     }
-    CK(thx_classify_destroy(h));
+    CK(thx_refine_destroy(h));
     CK(thx_reco_destroy(plan));
     for (void* p : {(void*)refD, (void*)vols, (void*)iColD, (void*)iRowD, (void*)quatD, (void*)shiftD, (void*)rotD, (void*)slD, (void*)rampD,
-                    (void*)attrD, (void*)ctfD, (void*)datD, (void*)sigD, (void*)wD, (void*)ftA, (void*)ftB, (void*)fscD})
+                    (void*)attrD, (void*)ctfD, (void*)imgD, (void*)q0D, (void*)t0D, (void*)ftA, (void*)ftB, (void*)fscD})
         CK(thx_free_dev(p));
     if (!ok) return 1;
     printf("OK (one rank, K = %d classes)\n", K);

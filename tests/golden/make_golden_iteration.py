@@ -37,11 +37,11 @@ def compute():
         r = it.iterate()
         out.update({"it%d_uR" % i: r["uR"], "it%d_uT" % i: r["uT"], "it%d_srcR" % i: r["srcR"].astype(np.int16),
                     "it%d_srcT" % i: r["srcT"].astype(np.int16), "it%d_k" % i: r["k"], "it%d_s" % i: r["s"],
-                    "it%d_sig" % i: r["sig"], "it%d_fsc" % i: r["fsc"], "it%d_rounds" % i: np.asarray(r["rounds"], np.int32),
-                    "it%d_maps" % i: np.stack(r["maps"]), "it%d_mapsFsc" % i: np.stack(r["mapsFsc"]), "it%d_topR" % i: r["topR"],
-                    "it%d_offset" % i: r["offset"],
-                    "it%d_Tsum" % i: np.asarray([float(t.sum(dtype=np.float64)) for t in r["T_raw"]]),
-                    "it%d_Fabs" % i: np.asarray([float(np.abs(f).sum(dtype=np.float64)) for f in r["F_raw"]])})
+                    "it%d_sig" % i: r["sig"], "it%d_fsc" % i: r["fsc"][0], "it%d_rounds" % i: np.asarray(r["rounds"], np.int32).reshape(-1),
+                    "it%d_maps" % i: np.stack([h[0] for h in r["maps"]]), "it%d_mapsFsc" % i: np.stack([h[0] for h in r["mapsFsc"]]),
+                    "it%d_topR" % i: r["topR"], "it%d_offset" % i: r["offset"], "it%d_avgR" % i: np.asarray([r["avgR"]], np.int32),
+                    "it%d_Tsum" % i: np.asarray([float(h[0].sum(dtype=np.float64)) for h in r["T_raw"]]),
+                    "it%d_Fabs" % i: np.asarray([float(np.abs(h[0]).sum(dtype=np.float64)) for h in r["F_raw"]])})
     return inp, out
 
 

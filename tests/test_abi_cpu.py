@@ -127,8 +127,7 @@ def test_ctypes_struct_mirrors_match_the_header(tmp_path):
     from thunder_amd import capi
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pairs = [("thx_refine_config", capi.RefineConfig), ("thx_refine_stats", capi.RefineStats), ("thx_refine_view", capi.RefineView),
-             ("thx_refine_capture", capi.RefineCapture), ("thx_classify_config", capi.ClassifyConfig), ("thx_classify_stats", capi.ClassifyStats),
-             ("thx_classify_view", capi.ClassifyView), ("thx_classify_capture", capi.ClassifyCapture), ("thx_ctf_attr", capi.CtfAttr)]
+             ("thx_refine_capture", capi.RefineCapture), ("thx_pf_ctx", capi.PfCtx), ("thx_ctf_attr", capi.CtfAttr)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "thunder_amd.h"', 'int main(void) {']
     for cname, cls in pairs:
         lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))

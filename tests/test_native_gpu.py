@@ -134,8 +134,9 @@ def test_cpp_iteration_driver(dev, tmp_path):
 
 def test_cpp_classification_driver(dev, tmp_path):
     """tests/cpp/classify.cpp: torch-free C++ over the C ABI -- K = 2 synthetic references, images on the scanned grid,
-    thx_classify_create ... thx_classify_iterate (scan, class, support points, local phases, multi-reference insertion, two
-    reconstructions per class, refresh): classes recovered, every class map agrees with its own generating map"""
+    thx_refine_create (nK = 2, THX_SEARCH_GLOBAL) ... thx_refine_iterate (scan, class, support points, local phases, sigma update,
+    multi-reference insertion, two reconstructions per class and half, per-class FSC, averaging, refresh), then a local-search
+    iteration: classes recovered, every class map agrees with its own generating map"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "classify")
     libdir = os.path.join(root, "thunder_amd", "lib")

@@ -159,3 +159,129 @@ def test_classify_stages_properties():
     a, _ = st.support(wR, wT, cls, 0, seed, 1e-3, mLR, mLT, 0.0, 0.0, call=2)
     b, _ = st.support(wR, wT, cls, 0, seed, 1e-3, mLR, mLT, 0.0, 0.0, call=3)
     assert np.array_equal(a["topR"], b["topR"])       # the top point does not depend on the draws
+
+
+# ---- point-group symmetry (Symmetry::init, symmetryCounterpart, Particle::symmetrise) ----
+GROUPS = [("C1", 1), ("C2", 2), ("C4", 4), ("C7", 7), ("D2", 4), ("D3", 6), ("D7", 14), ("T", 12), ("O", 24), ("I1", 60), ("I2", 60),
+          ("I3", 60), ("I4", 60)]
+
+
+def _quat_to_R(q):
+    from oracle import oracle as O
+    return O.rotate3D(q).reshape(3, 3).T
+
+
+def test_symmetry_groups_are_groups(oracle):
+    """the restated Symmetry::init: order of every point group, closure under products (completePointGroup), the quaternion of
+    every element is the quaternion of its matrix, and Cn is what Symmetry::fillLR gives for RotationSO(n, 0, 0, 1) with its
+    RFLOAT angle (src/Geometry/Symmetry.cpp:146-171)"""
+    O = oracle
+    for name, order in GROUPS:
+        s = O.symmetry(name)
+        assert s["n"] == order - 1, name
+        R = [np.eye(3)] + [m.reshape(3, 3).T for m in s["R"]]
+        for a in R:
+            assert np.abs(a @ a.T - np.eye(3)).max() < 2e-5 and abs(np.linalg.det(a) - 1) < 2e-5
+            for b in R:
+                c = a @ b
+                assert min(np.abs(c - x).max() for x in R) < 1e-4, name      # closed (axes carry 7 digits)
+        for m, q in zip(s["R"], s["quat"]):
+            assert abs(np.linalg.norm(q) - 1) < 1e-5
+            # quaternion(dvec4&, const dmat33&) (src/Geometry/Euler.cpp:112-123) takes w = sqrt(1 + trace) / 2 and the SIGNS of x, y, z
+            # from differences of off-diagonal elements: for the two-fold elements of T / O / I, whose axes are given to 6 - 7
+            # digits, w is sqrt(5e-6) = 1e-3 instead of 0 and the signs come from rounding noise, so Symmetry::quat(i) can be the
+            # quaternion of ANOTHER two-fold element of the group.  The reference's own arithmetic, kept: what matters to
+            # symmetryCounterpart is that every quat is (close to) an element of the group.
+            Rq = _quat_to_R(q / np.linalg.norm(q))
+            if name[0] in "CD":
+                assert np.abs(Rq - m.reshape(3, 3).T).max() < 2e-5
+            else:
+                assert min(np.abs(Rq - x).max() for x in R) < 5e-3, name
+    c4 = O.symmetry("C4")
+    ang = np.float32(2 * np.pi / 4)
+    for j in (1, 2, 3):
+        a = float(np.float32(ang * np.float32(j)))
+        Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+        assert np.abs(c4["R"][j - 1].reshape(3, 3).T - Rz).max() < 1e-15
+    try:
+        O.symmetry("X9")
+        assert False
+    except ValueError:
+        pass
+
+
+def test_symmetry_host_twin_is_identical(oracle):
+    """thx_symmetry_host (the product's Symmetry::init, host code of libthunder_amd.so) == the oracle's, bit for bit"""
+    from thunder_amd import capi
+    capi.load()
+    O = oracle
+    for name, order in GROUPS:
+        n = C.c_int(0)
+        capi.call("thx_symmetry_host", name.encode(), None, None, 0, C.byref(n))
+        assert n.value == order - 1
+        R, q = np.zeros((max(n.value, 1), 9)), np.zeros((max(n.value, 1), 4))
+        capi.call("thx_symmetry_host", name.encode(), R.ctypes.data, q.ctypes.data, n.value, C.byref(n))
+        s = O.symmetry(name)
+        assert np.array_equal(R[:n.value], s["R"]) and np.array_equal(q[:n.value], s["quat"]), name
+    n = C.c_int(0)
+    with np.testing.assert_raises(capi.ThxError):
+        capi.call("thx_symmetry_host", b"Q5", None, None, 0, C.byref(n))
+
+
+def test_symmetry_counterpart_properties(oracle):
+    """symmetryCounterpart picks, among q and conj(g) q, the one closest (|<., anchor>|) to the anchor: the result is an
+    equivalent pose (its slice of a symmetric volume is the same), no group element brings it closer, and symmetrising twice
+    changes nothing"""
+    O = oracle
+    from thunder_amd import synth
+    rng = np.random.default_rng(5)
+    for name in ("C4", "D2", "D7", "O"):
+        s = O.symmetry(name)
+        q = synth.random_quats(200, rng)
+        anchor = synth.random_quats(1, rng)[0]
+        for an in (None, anchor):
+            qs = O.symmetrise(q, s["quat"], an)
+            a = np.array([1.0, 0, 0, 0]) if an is None else an
+            conj = s["quat"] * np.array([1.0, -1, -1, -1])
+            for i in range(len(q)):
+                cands = np.concatenate([q[i][None], synth.quat_mul(conj, q[i][None])])
+                d = np.abs(cands @ a)
+                assert np.abs(cands - qs[i]).max(1).min() < 1e-15                       # one of the candidates
+                assert np.float32(abs(qs[i] @ a)) >= np.float32(d.max()) - np.float32(1e-7)
+            if name != "O":   # (Symmetry::quat of O is not closed under products -- see test_symmetry_groups_are_groups)
+                assert np.array_equal(O.symmetrise(qs, s["quat"], an), qs)
+    # C1: untouched
+    assert np.array_equal(O.symmetrise(q, np.zeros((0, 4))), q)
+
+
+def test_perturb_and_cal_vari_with_symmetry(oracle):
+    """Particle::perturb / calVari with a point group: the perturbed cloud is the C1 cloud moved to the counterparts next to
+    the cloud's mean; calVari's spread of a cloud scattered over symmetry-equivalent poses is the spread of the folded cloud"""
+    O = oracle
+    from thunder_amd import synth
+    rng = np.random.default_rng(9)
+    s = O.symmetry("D2")
+    base = synth.random_quats(1, rng)
+    q = synth.perturb_quats(base, 60, 0.03, rng)[0]
+    t = rng.normal(0, 1, (9, 2))
+    k0, s0 = O.cal_vari(q, t)
+    # scatter the cloud over the group: every point replaced by a random equivalent pose  conj(g) q
+    conj = np.concatenate([[[1.0, 0, 0, 0]], s["quat"] * np.array([1.0, -1, -1, -1])])
+    pick = rng.integers(0, len(conj), len(q))
+    qx = np.stack([synth.quat_mul(conj[pick[i]][None], q[i][None])[0] for i in range(len(q))])
+    kx, _ = O.cal_vari(qx, t)                       # C1 arithmetic on the scattered cloud: a huge spread
+    assert kx.max() > 50 * k0.max()
+    ks, _, qf = O.cal_vari(qx, t, symQuat=s["quat"], iAnchor=3, return_q=True)
+    assert np.allclose(ks, k0, rtol=1e-6)
+    d = np.abs(np.einsum("ij,ij->i", qf, np.broadcast_to(qf[3], qf.shape)))
+    assert d.min() > 0.99                           # folded next to the anchor
+    g = rng.standard_normal((len(q), 4))
+    gT = rng.standard_normal((9, 4))
+    q1, _, w1, _ = O.pf_perturb(q, t, k0, s0, 2.0, 2.0, 2.0, 0.05, g, gT)
+    q2, _, w2, _ = O.pf_perturb(q, t, k0, s0, 2.0, 2.0, 2.0, 0.05, g, gT, symQuat=s["quat"])
+    # same perturbations, each then replaced by an equivalent pose (mostly itself: the cloud is tight)
+    same = np.abs(q1 - q2).max(1) < 1e-15
+    assert same.mean() > 0.9
+    for i in np.nonzero(~same)[0]:
+        cands = synth.quat_mul(conj, q1[i][None])
+        assert np.abs(cands - q2[i]).max(1).min() < 1e-14

@@ -330,3 +330,83 @@ def test_defocus_filter(oracle, dev):
         assert np.abs(d2[l] - wd).max() <= 1e-15
         if np.std(wd) > 0:
             assert np.allclose(w2[l], ww, rtol=1e-9)
+
+
+def _ctx(capi, symq_dev, nSym, img0):
+    c = capi.PfCtx()
+    c.symQuat, c.nSym, c.img0 = (symq_dev.data_ptr() if nSym else None), nSym, img0
+    return c
+
+
+@pytest.mark.parametrize("group", ["C4", "D2", "O"])
+def test_filter_with_point_group(oracle, dev, group):
+    """Particle::symmetrise / perturb / calVari / resample with a point group on the device (thx_pf_symmetrise_dev,
+    thx_pf_perturb_ex_dev, thx_pf_update_ex_dev, thx_pf_cal_vari_dev with thx_pf_ctx) against the oracle's restatement of
+    src/Particle.cpp:1030-1036,1234,2445-2470 and src/Geometry/Symmetry.cpp:309-336, draws replayed; img0 shifts the images'
+    Philox numbering"""
+    from thunder_amd import capi, synth
+    O = oracle
+    rng = np.random.default_rng(31)
+    sym = O.symmetry(group)
+    symq = T(sym["quat"], dev)
+    nImg, nR, nT, seed, call, img0 = 6, 125, 9, 0xABCDEF0123, 7, 1000
+    q, t, wR, wT, k, s = _state(rng, nImg, nR, nT)
+    # scatter two of the clouds over symmetry-equivalent poses (what a global scan's resampling hands over)
+    conj = np.concatenate([[[1.0, 0, 0, 0]], sym["quat"] * np.array([1.0, -1, -1, -1])])
+    for l in (1, 4):
+        pick = rng.integers(0, len(conj), nR)
+        q[l] = np.stack([synth.quat_mul(conj[pick[i]][None], q[l, i][None])[0] for i in range(nR)])
+    # ---- symmetrise: bit-exact, with ANCHOR_POINT_2 and with a per-image anchor ----
+    anchor = synth.random_quats(nImg, rng)
+    for an in (None, anchor):
+        d = T(q, dev)
+        capi.call("thx_pf_symmetrise_dev", d.data_ptr(), None if an is None else T(an, dev).data_ptr(), nImg, nR, symq.data_ptr(),
+                  sym["n"], capi.stream_ptr())
+        got = d.cpu().numpy()
+        for l in range(nImg):
+            assert np.array_equal(got[l], O.symmetrise(q[l], sym["quat"], None if an is None else an[l]))
+    # ---- calVari on its own (Particle::load): anchor draw replayed, r symmetrised in place ----
+    ctx = _ctx(capi, symq, sym["n"], img0)
+    dq, dt = T(q, dev), T(t, dev)
+    dk = torch.zeros((nImg, 3), dtype=torch.float64, device=dev)
+    ds = torch.zeros((nImg, 2), dtype=torch.float64, device=dev)
+    capi.call("thx_pf_cal_vari_dev", dq.data_ptr(), dt.data_ptr(), dk.data_ptr(), ds.data_ptr(), nImg, nR, nT, seed, call, C.byref(ctx),
+              capi.stream_ptr())
+    gq, gk, gs = dq.cpu().numpy(), dk.cpu().numpy(), ds.cpu().numpy()
+    for l in range(nImg):
+        iA = min(int(PH.draw_u4(seed, img0 + l, call, 13, 0)[0] * nR), nR - 1)
+        kw, sw, qf = O.cal_vari(q[l], t[l], symQuat=sym["quat"], iAnchor=iA, return_q=True)
+        assert np.abs(gq[l] - qf).max() <= 1e-13            # (the round trip through the mean frame: 1e-16 of noise)
+        assert np.allclose(gk[l], kw, rtol=1e-6) and np.allclose(gs[l], sw, rtol=1e-12)
+    # ---- perturb: the three passes, then symmetrise(&mean) ----
+    q = gq.copy()                                           # continue from folded clouds (tight: a well-defined mean)
+    k = np.maximum(gk, 1e-5)
+    pfR, pfT, transS, transQ = 2.0, 0.5, 2.0, 0.05
+    dq, dt, dwR, dwT, dk, ds = T(q, dev), T(t, dev), T(wR, dev), T(wT, dev), T(k, dev), T(s, dev)
+    capi.call("thx_pf_perturb_ex_dev", dq.data_ptr(), dt.data_ptr(), dwR.data_ptr(), dwT.data_ptr(), dk.data_ptr(), ds.data_ptr(), nImg, nR,
+              nT, pfR, pfT, transS, transQ, seed, call + 1, None, C.byref(ctx), capi.stream_ptr())
+    pq, pt, pwR, pwT = [x.cpu().numpy() for x in (dq, dt, dwR, dwT)]
+    for l in range(nImg):
+        gR = np.stack(PH.draw_n4(seed, img0 + l, call + 1, 0, np.arange(nR)), axis=1)
+        gT = np.stack(PH.draw_n4(seed, img0 + l, call + 1, 1, np.arange(nT)), axis=1)
+        wq, wt, wwR, wwT = O.pf_perturb(q[l], t[l], k[l], s[l], pfR, pfT, transS, transQ, gR, gT, symQuat=sym["quat"])
+        assert np.abs(pq[l] - wq).max() <= 2e-9 and np.abs(pt[l] - wt).max() <= 1e-12
+        assert np.allclose(pwR[l], wwR, rtol=1e-6) and np.allclose(pwT[l], wwT, rtol=1e-9)
+    # ---- update: calVari (symmetrise about a drawn anchor) + resample ----
+    uR = (rng.uniform(0, 1, (nImg, nR)) ** 8).astype(np.float32)
+    uT = rng.uniform(0.05, 1, (nImg, nT)).astype(np.float32)
+    topR = torch.zeros((nImg, 4), dtype=torch.float64, device=dev)
+    topT = torch.zeros((nImg, 2), dtype=torch.float64, device=dev)
+    capi.call("thx_pf_update_ex_dev", dq.data_ptr(), dt.data_ptr(), dwR.data_ptr(), dwT.data_ptr(), T(uR, dev).data_ptr(), T(uT, dev).data_ptr(),
+              dk.data_ptr(), ds.data_ptr(), topR.data_ptr(), topT.data_ptr(), nImg, nR, nT, 1e-3, seed, call + 2, None, C.byref(ctx),
+              capi.stream_ptr())
+    uq, ut, uwR, uk, utop = [x.cpu().numpy() for x in (dq, dt, dwR, dk, topR)]
+    for l in range(nImg):
+        c2, li = call + 2, img0 + l
+        iA = min(int(PH.draw_u4(seed, li, c2, 13, 0)[0] * nR), nR - 1)
+        own = O.pf_update(pq[l], pt[l], pwR[l], pwT[l], uR[l], uT[l], 1e-3, PH.shuffle_ranks(seed, li, c2, 2, nR),
+                          PH.draw_u4(seed, li, c2, 3, 0)[0] / nR, PH.shuffle_ranks(seed, li, c2, 4, nT),
+                          PH.draw_u4(seed, li, c2, 5, 0)[0] / nT, symQuat=sym["quat"], iAnchor=iA)
+        assert np.abs(uq[l] - own["q"]).max() <= 1e-13 and np.array_equal(ut[l], own["t"])
+        assert np.allclose(uwR[l], own["wR"], rtol=1e-10) and np.allclose(uk[l], own["k"], rtol=1e-6)
+        assert np.abs(utop[l] - own["topR"]).max() <= 1e-13

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libthunder_amd.so")
-SOURCES = ["thx_estep.hip", "thx_mstep.hip", "thx_insert_sort.hip", "thx_reco.hip", "thx_next.hip", "thx_io.hip", "thx_pf.hip", "thx_iface.hip", "thx_host.hip", "thx_comm.hip", "thx_refine.hip", "thx_model.hip", "thx_classify.hip"]
+SOURCES = ["thx_estep.hip", "thx_mstep.hip", "thx_insert_sort.hip", "thx_reco.hip", "thx_next.hip", "thx_io.hip", "thx_pf.hip", "thx_iface.hip", "thx_host.hip", "thx_comm.hip", "thx_refine.hip", "thx_model.hip"]
 HEADERS = ["thx_common.h", "thx_insert.h", "thx_fft8.h", "thx_philox.h", os.path.join("..", "..", "include", "thunder_amd.h")]
 
 # -ffp-contract=off: see thx_common.h (bit-identical trilinear arithmetic); fused ops are written out as fmaf().
@@ -39,13 +39,19 @@ def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     objs = []
     procs = []
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    hdr_t = max(hdr_t, os.path.getmtime(os.path.abspath(__file__)))
     for s in SOURCES:
         o = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        objs.append(o)
+        # one object per source: only what changed (or sits below a changed header) is compiled again
+        if not force and not os.environ.get("THX_EXTRA_FLAGS") and os.path.exists(o) and \
+                os.path.getmtime(o) > max(hdr_t, os.path.getmtime(os.path.join(CSRC, s))):
+            continue
         cmd = [_hipcc()] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(o)
     for s, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:

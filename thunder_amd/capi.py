@@ -22,6 +22,11 @@ class CtfAttr(C.Structure):
                 ("phaseShift", C.c_float)]
 
 
+class PfCtx(C.Structure):
+    """thx_pf_ctx (include/thunder_amd.h)"""
+    _fields_ = [("symQuat", C.c_void_p), ("nSym", C.c_int), ("img0", C.c_uint)]
+
+
 class RefineConfig(C.Structure):
     """thx_refine_config (include/thunder_amd.h)"""
     _fields_ = [("N", C.c_int), ("pf", C.c_int), ("nImg", C.c_int), ("halfOfRank", C.c_int), ("nHalfA", C.c_int),
@@ -31,12 +36,20 @@ class RefineConfig(C.Structure):
                 ("pixelSize", C.c_float), ("maskRadiusPx", C.c_float), ("sigma2Init", C.c_float),
                 ("transS", C.c_double), ("transQ", C.c_double), ("pfL", C.c_double), ("pfS", C.c_double),
                 ("peakFactorR", C.c_double), ("seed", C.c_ulonglong),
-                ("coreFSC", C.c_int), ("goldenAverage", C.c_int), ("solventFlatten", C.c_int), ("normCorrection", C.c_int)]
+                ("coreFSC", C.c_int), ("goldenAverage", C.c_int), ("solventFlatten", C.c_int), ("normCorrection", C.c_int),
+                ("nK", C.c_int), ("searchType", C.c_int), ("nR", C.c_int), ("nT", C.c_int), ("rScan", C.c_int), ("scanBatch", C.c_int),
+                ("pfSGlobal", C.c_double), ("peakFactorC", C.c_double), ("scanMinK", C.c_double), ("scanMinS", C.c_double),
+                ("balanceClass", C.c_int), ("nSym", C.c_int), ("symMat", C.c_void_p), ("symQuat", C.c_void_p),
+                ("mLD", C.c_int), ("ctfRefineS", C.c_double), ("pfSCTF", C.c_double)]
+
+
+SEARCH_LOCAL, SEARCH_GLOBAL, SEARCH_CTF = 0, 1, 2
 
 
 class RefineCapture(C.Structure):
     """thx_refine_capture (include/thunder_amd.h): device pointers as integers"""
-    _fields_ = [(n, C.c_void_p) for n in ("uR", "uT", "r", "t", "k123", "s01", "mapsFsc", "rP", "tP", "wRP", "wTP", "Fraw", "Traw")]
+    _fields_ = [(n, C.c_void_p) for n in ("uR", "uT", "r", "t", "k123", "s01", "mapsFsc", "rP", "tP", "wRP", "wTP", "Fraw", "Traw",
+                                          "scanUC", "scanUR", "scanUT", "r0", "t0", "k0", "s0", "Fsym", "Tsym")]
 
 
 class RefineStats(C.Structure):
@@ -46,7 +59,9 @@ class RefineStats(C.Structure):
                 ("balancingRounds", C.c_long), ("iterations", C.c_long), ("imagePhases", C.c_long), ("nPxl", C.c_int),
                 ("nPxlM", C.c_int),
                 ("batch", C.c_int), ("insertGroups", C.c_ulonglong), ("lastRounds", C.c_int * 4), ("normMedian", C.c_float),
-                ("normRadius", C.c_float)]
+                ("normRadius", C.c_float), ("scanMs", C.c_double), ("scanLaunches", C.c_long), ("scanImages", C.c_long),
+                ("nPxlS", C.c_int), ("nK", C.c_int), ("classCount", C.c_int * 16), ("lastRoundsK", C.c_int * 64),
+                ("balanced", C.c_int * 16)]
 
 
 class RefineView(C.Structure):
@@ -54,39 +69,9 @@ class RefineView(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("nImg", "nPxl", "nPxlM", "nVol", "vdim", "rSig")] + \
                [(n, C.c_void_p) for n in ("iCol", "iRow", "iPxl", "iSig", "iColM", "iRowM", "img", "datP", "ctfP", "sigRcpP",
                                           "datM", "ctfM", "r", "t", "wR", "wT", "offset", "vols", "cells", "F", "T", "sig",
-                                          "recoRot", "recoTran", "nP", "norm")]
-
-
-class ClassifyConfig(C.Structure):
-    """thx_classify_config (include/thunder_amd.h)"""
-    _fields_ = [("N", C.c_int), ("pf", C.c_int), ("nK", C.c_int), ("nImg", C.c_int), ("nImgHemi", C.c_long),
-                ("nR", C.c_int), ("nT", C.c_int), ("rScan", C.c_int), ("rL", C.c_int),
-                ("mLR", C.c_int), ("mLT", C.c_int), ("nPhase", C.c_int), ("mReco", C.c_int), ("batch", C.c_int),
-                ("pixelOrder", C.c_int), ("wgPerCU", C.c_int), ("refresh", C.c_int), ("pixelSize", C.c_float),
-                ("transS", C.c_double), ("transQ", C.c_double), ("pfL", C.c_double), ("pfS", C.c_double),
-                ("peakFactorR", C.c_double), ("peakFactorC", C.c_double), ("scanMinK", C.c_double), ("scanMinS", C.c_double),
-                ("seed", C.c_ulonglong)]
-
-
-class ClassifyStats(C.Structure):
-    """thx_classify_stats (include/thunder_amd.h)"""
-    _fields_ = [("stageMs", C.c_double * 5), ("scanMs", C.c_double), ("localMs", C.c_double), ("insertMs", C.c_double),
-                ("scanLaunches", C.c_long), ("localLaunches", C.c_long), ("localImages", C.c_long), ("insertLaunches", C.c_long),
-                ("insertImages", C.c_long), ("balancingRounds", C.c_long), ("iterations", C.c_long),
-                ("nPxlS", C.c_int), ("nPxlE", C.c_int), ("nPxlM", C.c_int), ("batch", C.c_int),
-                ("lastRounds", C.c_int * 32), ("classCount", C.c_int * 16)]
-
-
-class ClassifyCapture(C.Structure):
-    """thx_classify_capture (include/thunder_amd.h): device pointers as integers"""
-    _fields_ = [(n, C.c_void_p) for n in ("r0", "t0", "Fraw", "Traw")]
-
-
-class ClassifyView(C.Structure):
-    """thx_classify_view (include/thunder_amd.h): device pointers as integers"""
-    _fields_ = [(n, C.c_int) for n in ("nImg", "nK", "nPxlS", "nPxlE", "nPxlM", "vdim")] + \
-               [(n, C.c_void_p) for n in ("cls", "uC", "uR", "uT", "r", "t", "wR", "wT", "topR", "topT", "vols", "cells", "F", "T",
-                                          "maps", "mapsMAP")]
+                                          "recoRot", "recoTran", "nP", "norm", "cls", "topR", "topT", "k123", "s01", "d", "wD",
+                                          "maps", "mapsMAP")] + \
+               [(n, C.c_int) for n in ("nK", "nPxlS")]
 
 
 _vp = C.c_void_p
@@ -142,16 +127,10 @@ SIGNATURES = {
     "thx_refine_get_state": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "thx_refine_get_stats": (_i, [_vp, C.POINTER(RefineStats), _i]),
     "thx_refine_get_view": (_i, [_vp, C.POINTER(RefineView)]),
-    "thx_classify_create": (_i, [C.POINTER(_vp), C.POINTER(ClassifyConfig), _vp]),
-    "thx_classify_destroy": (_i, [_vp]),
-    "thx_classify_set_capture": (_i, [_vp, _vp]),
-    "thx_classify_set_grid": (_i, [_vp, _vp, _vp, _vp]),
-    "thx_classify_set_particles": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
-    "thx_classify_set_references": (_i, [_vp, _vp, _vp]),
-    "thx_classify_set_fsc": (_i, [_vp, _vp, _i]),
-    "thx_classify_iterate": (_i, [_vp, _i, _vp]),
-    "thx_classify_get_view": (_i, [_vp, C.POINTER(ClassifyView)]),
-    "thx_classify_get_stats": (_i, [_vp, C.POINTER(ClassifyStats), _i]),
+    "thx_refine_get_map_k": (_i, [_vp, _i, _i, _vp, _vp]),
+    "thx_refine_set_classes": (_i, [_vp, _vp, _vp]),
+    "thx_refine_set_grid": (_i, [_vp, _vp, _vp, _vp]),
+    "thx_refine_set_search_type": (_i, [_vp, _i]),
     "thx_reco_allreduce_acc_class": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "thx_rotmat_dev": (_i, [_vp, _vp, _i, _vp]),
     "thx_translate_dev": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
@@ -214,6 +193,16 @@ SIGNATURES = {
     "thx_pf_perturb_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _d, _d, C.c_ulonglong, C.c_uint, _vp, _vp]),
     "thx_pf_update_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, C.c_ulonglong,
                                C.c_uint, _vp, _vp]),
+    "thx_symmetry_host": (_i, [C.c_char_p, _vp, _vp, _i, C.POINTER(_i)]),
+    "thx_pf_symmetrise_dev": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp]),
+    "thx_pf_cal_vari_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.c_ulonglong, C.c_uint, _vp, _vp]),
+    "thx_pf_perturb_ex_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _d, _d, C.c_ulonglong, C.c_uint, _vp, _vp, _vp]),
+    "thx_pf_update_ex_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, C.c_ulonglong,
+                                  C.c_uint, _vp, _vp, _vp]),
+    "thx_pf_perturb_d_ex_dev": (_i, [_vp, _vp, _vp, _i, _i, _d, _i, C.c_ulonglong, C.c_uint, _vp, C.c_uint, _vp]),
+    "thx_pf_update_d_ex_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, C.c_ulonglong, C.c_uint, _vp, C.c_uint, _vp]),
+    "thx_pf_class_select_ex_dev": (_i, [_vp, _vp, _vp, _i, _i, _d, C.c_ulonglong, C.c_uint, C.c_uint, _vp]),
+    "thx_pf_scan_support_ex_dev": (_i, [_vp] * 13 + [_i] * 6 + [_d, _d, _d, C.c_ulonglong, C.c_uint, _vp, _vp]),
     "thx_pf_stop_init_dev": (_i, [_vp, _vp, _vp, _d, _d, _i, _vp]),
     "thx_pf_stop_rule_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "thx_pf_acg_stats_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),

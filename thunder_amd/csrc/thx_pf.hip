@@ -9,6 +9,9 @@
 // draw comes from a counter-based Philox4x32-10 stream keyed by (seed, image, call, purpose, index): reproducible and
 // independent of launch geometry.  Deterministic arithmetic is checked against the oracle, draws statistically.
 #include <math.h>
+#include <string.h>
+
+#include <vector>
 
 #include "thx_common.h"
 #include "thx_philox.h"
@@ -61,6 +64,29 @@ __device__ __forceinline__ void qmul(double* d, const double* a, const double* b
     const double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
     d[0] = w; d[1] = x; d[2] = y; d[3] = z;
 }
+
+// symmetryCounterpart(dst, sym, anchor), src/Geometry/Symmetry.cpp:309-336: among q and conj(sym.quat(i)) * q the quaternion
+// with the largest |<., anchor>| (the reference keeps that number in RFLOAT and compares with a strict >)
+__device__ __forceinline__ void sym_counterpart(double* q, const double* __restrict__ symQ, int nSym, const double* anchor)
+{
+    double best[4] = {q[0], q[1], q[2], q[3]};
+    float s = (float)fabs(q[0] * anchor[0] + q[1] * anchor[1] + q[2] * anchor[2] + q[3] * anchor[3]);
+    for (int i = 0; i < nSym; i++) {
+        const double cs[4] = {symQ[4 * i], -symQ[4 * i + 1], -symQ[4 * i + 2], -symQ[4 * i + 3]};
+        double p[4];
+        qmul(p, cs, q);
+        const float t = (float)fabs(p[0] * anchor[0] + p[1] * anchor[1] + p[2] * anchor[2] + p[3] * anchor[3]);
+        if (t > s) { s = t; best[0] = p[0]; best[1] = p[1]; best[2] = p[2]; best[3] = p[3]; }
+    }
+    q[0] = best[0]; q[1] = best[1]; q[2] = best[2]; q[3] = best[3];
+}
+
+// Particle::calVari(PAR_R), src/Particle.cpp:1020-1080, on the n quaternions in LDS (one wave): with a point group the support
+// points are first replaced by their counterparts next to a randomly chosen one of them (anch = _r.row(gsl_rng_uniform_int(
+// engine, _nR)); symmetrise(&anch), :1030-1036 -- Philox stream (seed, image, call, 13, 0)); then LEFT multiplication by
+// conj(mean), inferACG(k1, k2, k3), left multiplication by mean.  Every lane returns the same k[3].
+__device__ void cal_vari_R(double* k, double* sq /*LDS [n][4]*/, int n, int lane, const double* __restrict__ symQ, int nSym,
+                           unsigned long long seed, unsigned img, unsigned call);
 
 // inferACG(dmat44&, const dmat4&), src/Geometry/DirectionalStat.cpp:93-145: fixed point B = 4 sum(x x^T / u) / sum(1 / u),
 // u = x^T A^-1 x, until sum|A - B| <= 1e-3; returns the LAST-BUT-ONE iterate A as the reference does.  Wave-cooperative:
@@ -139,6 +165,31 @@ __device__ void sym4_top_eigvec(double* v, const double* Ain)
     for (int k = 0; k < 4; k++) nrm += V[k * 4 + im] * V[k * 4 + im];
     nrm = sqrt(nrm);
     for (int k = 0; k < 4; k++) v[k] = V[k * 4 + im] / nrm;
+}
+
+__device__ void cal_vari_R(double* k, double* sq, int n, int lane, const double* __restrict__ symQ, int nSym,
+                           unsigned long long seed, unsigned img, unsigned call)
+{
+    if (nSym > 0) {
+        double u4[4];
+        draw_u4(u4, seed, img, call, 13u, 0);
+        int iA = (int)(u4[0] * n);
+        iA = iA >= n ? n - 1 : iA;
+        const double anch[4] = {sq[4 * iA], sq[4 * iA + 1], sq[4 * iA + 2], sq[4 * iA + 3]};
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < n; i += 64) sym_counterpart(sq + 4 * i, symQ, nSym, anch);
+        __builtin_amdgcn_wave_barrier();
+    }
+    double A[16], mean[4], cm[4];
+    infer_acg(A, sq, n, lane, nullptr);
+    sym4_top_eigvec(mean, A);
+    cm[0] = mean[0]; cm[1] = -mean[1]; cm[2] = -mean[2]; cm[3] = -mean[3];
+    for (int i = lane; i < n; i += 64) { double o[4]; qmul(o, cm, sq + 4 * i); for (int c = 0; c < 4; c++) sq[4 * i + c] = o[c]; }
+    __builtin_amdgcn_wave_barrier();
+    infer_acg(A, sq, n, lane, nullptr);
+    k[0] = A[5] / A[0]; k[1] = A[10] / A[0]; k[2] = A[15] / A[0];
+    for (int i = lane; i < n; i += 64) { double o[4]; qmul(o, mean, sq + 4 * i); for (int c = 0; c < 4; c++) sq[4 * i + c] = o[c]; }
+    __builtin_amdgcn_wave_barrier();
 }
 
 // balanceWeight(PAR_R) + normW (src/Particle.cpp:2333-2343,815-822): w_i = 1 / pdfACG(r_i, A) normalised
@@ -257,6 +308,9 @@ struct PfArgs {
     unsigned long long seed;
     unsigned call;
     const int* active;   // [nImg] or NULL: images with active[img] == 0 are left untouched (per-image stop rule)
+    const double* symQ;  // DEVICE [nSym][4] Symmetry::quat(i), or NULL (C1)
+    int nSym;
+    unsigned img0;       // the launch's first image in the numbering of the Philox streams (thx_pf_ctx)
 };
 
 // Particle::perturb(pf, PAR_R) + perturb(pf, PAR_T), src/Particle.cpp:1149-1272 (MODE_3D)
@@ -265,6 +319,7 @@ __global__ __launch_bounds__(64) void k_pf_perturb(PfArgs a)
     __shared__ double sq[kPfMax * 4], st[kPfMax * 2], sw[kPfMax];
     const int img = blockIdx.x, lane = threadIdx.x;
     if (a.active && !a.active[img]) return;
+    const unsigned pimg = a.img0 + (unsigned)img;
     const int nR = a.nR, nT = a.nT;
     if (nR > 0) {
         double* r = a.r + (size_t)img * nR * 4;
@@ -281,7 +336,7 @@ __global__ __launch_bounds__(64) void k_pf_perturb(PfArgs a)
         cm[0] = mean[0]; cm[1] = -mean[1]; cm[2] = -mean[2]; cm[3] = -mean[3];
         for (int i = lane; i < nR; i += 64) {
             double g[4];
-            draw_n4(g, a.seed, img, a.call, 0, i);
+            draw_n4(g, a.seed, pimg, a.call, 0, i);
             double v[4] = {g[0], l1 * g[1], l2 * g[2], l3 * g[3]};
             const double nrm = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
 #pragma unroll
@@ -292,6 +347,7 @@ __global__ __launch_bounds__(64) void k_pf_perturb(PfArgs a)
             qmul(o, cm, sq + 4 * i);
             qmul(o2, v, o);
             qmul(o, mean, o2);
+            if (a.nSym > 0) sym_counterpart(o, a.symQ, a.nSym, mean);   // symmetrise(&mean), :1234
 #pragma unroll
             for (int c = 0; c < 4; c++) { r[4 * i + c] = o[c]; sq[4 * i + c] = o[c]; }
         }
@@ -305,7 +361,7 @@ __global__ __launch_bounds__(64) void k_pf_perturb(PfArgs a)
         const double s0 = a.s01[2 * (size_t)img], s1 = a.s01[2 * (size_t)img + 1];
         for (int i = lane; i < nT; i += 64) {
             double g[4];
-            draw_n4(g, a.seed, img, a.call, 1, i);
+            draw_n4(g, a.seed, pimg, a.call, 1, i);
             // gsl_ran_bivariate_gaussian(engine, s0, s1, rho = 0, &x, &y); t += (x, y) * pf
             double x = t[2 * i] + s0 * g[0] * a.pfT, y = t[2 * i + 1] + s1 * g[1] * a.pfT;
             // reCentre (:2473-2495): points beyond transM are redrawn from N(0, transS^2 I)
@@ -327,6 +383,7 @@ __global__ __launch_bounds__(64) void k_pf_update(PfArgs a)
     __shared__ unsigned keys[kPfMax];
     const int img = blockIdx.x, lane = threadIdx.x;
     if (a.active && !a.active[img]) return;
+    const unsigned pimg = a.img0 + (unsigned)img;
     const int nR = a.nR, nT = a.nT;
     if (nR > 0) {
         double* r = a.r + (size_t)img * nR * 4;
@@ -352,25 +409,20 @@ __global__ __launch_bounds__(64) void k_pf_update(PfArgs a)
             for (int i = lane; i < nR; i += 64) su[i] = (su[i] < hh) ? 0.0 : su[i] - hh;
         }
         __builtin_amdgcn_wave_barrier();
-        // calVari(PAR_R), :1020-1080: LEFT multiplication by conj(mean), inferACG(k1, k2, k3), left multiplication by mean
-        double A[16], mean[4], cm[4];
-        infer_acg(A, sq, nR, lane, nullptr);
-        sym4_top_eigvec(mean, A);
-        cm[0] = mean[0]; cm[1] = -mean[1]; cm[2] = -mean[2]; cm[3] = -mean[3];
-        for (int i = lane; i < nR; i += 64) { double o[4]; qmul(o, cm, sq + 4 * i); for (int c = 0; c < 4; c++) sq[4 * i + c] = o[c]; }
-        __builtin_amdgcn_wave_barrier();
-        infer_acg(A, sq, nR, lane, nullptr);
-        if (lane == 0) {
-            a.k123[3 * (size_t)img] = A[5] / A[0];
-            a.k123[3 * (size_t)img + 1] = A[10] / A[0];
-            a.k123[3 * (size_t)img + 2] = A[15] / A[0];
+        // calVari(PAR_R), :1020-1080 (with a point group: counterparts next to a random anchor first)
+        {
+            double kk[3];
+            cal_vari_R(kk, sq, nR, lane, a.symQ, a.nSym, a.seed, pimg, a.call);
+            if (lane == 0) {
+                a.k123[3 * (size_t)img] = kk[0];
+                a.k123[3 * (size_t)img + 1] = kk[1];
+                a.k123[3 * (size_t)img + 2] = kk[2];
+            }
         }
-        for (int i = lane; i < nR; i += 64) { double o[4]; qmul(o, mean, sq + 4 * i); for (int c = 0; c < 4; c++) sq[4 * i + c] = o[c]; }
-        __builtin_amdgcn_wave_barrier();
         // calRank1st(PAR_R) (:990-1002), taken again by resample() after calVari's round trip (:1381-1383): _topR = _r.row(iMax)
         if (lane < 4) a.topR[4 * (size_t)img + lane] = sq[4 * imax + lane];
         __builtin_amdgcn_wave_barrier();
-        resample<4>(sq, sw, su, tq, tw, tu, cdf, keys, nR, lane, a.seed, img, a.call, 2);
+        resample<4>(sq, sw, su, tq, tw, tu, cdf, keys, nR, lane, a.seed, pimg, a.call, 2);
         for (int i = lane; i < nR; i += 64) {
 #pragma unroll
             for (int c = 0; c < 4; c++) r[4 * i + c] = sq[4 * i + c];
@@ -401,7 +453,7 @@ __global__ __launch_bounds__(64) void k_pf_update(PfArgs a)
         col_mean_sd(m, s1, sq, 1, nT, lane);
         if (lane == 0) { a.s01[2 * (size_t)img] = s0; a.s01[2 * (size_t)img + 1] = s1; }
         __builtin_amdgcn_wave_barrier();
-        resample<2>(sq, sw, su, tq, tw, tu, cdf, keys, nT, lane, a.seed, img, a.call, 4);
+        resample<2>(sq, sw, su, tq, tw, tu, cdf, keys, nT, lane, a.seed, pimg, a.call, 4);
         for (int i = lane; i < nT; i += 64) {
             t[2 * i] = sq[2 * i]; t[2 * i + 1] = sq[2 * i + 1];
             a.wT[(size_t)img * nT + i] = sw[i];
@@ -540,9 +592,13 @@ struct ScanSupportArgs {
     const float *uR, *uT;   // [nK][nImg][nRin], [nK][nImg][nTin]
     const int* cls;         // [nImg] or NULL (class 0)
     int nImg, nRin, nTin, mLR, mLT, NPR, NPT;
+    int rowStride;          // images per class row of uR / uT (the scan weights of a BATCH of a larger shard: its image count)
     double peakFactorR, minK, minS;
     unsigned long long seed;
     unsigned call;
+    const double* symQ;
+    int nSym;
+    unsigned img0;
 };
 
 constexpr int kScanSupThreads = 256;   // the 10 000-point shuffle is sorted by four waves; one wave does the rest
@@ -551,27 +607,21 @@ __global__ __launch_bounds__(kScanSupThreads) void k_pf_scan_support(ScanSupport
     extern __shared__ unsigned long long pairs[];
     __shared__ double sq[kPfMax * 4], sw[kPfMax];
     const int img = blockIdx.x, lane = threadIdx.x;
-    const size_t row = (size_t)(a.cls ? a.cls[img] : 0) * a.nImg + img;
+    const unsigned pimg = a.img0 + (unsigned)img;
+    const size_t row = (size_t)(a.cls ? a.cls[img] : 0) * a.rowStride + img;
     // ---- rotations ----
-    shuffle_sort<kScanSupThreads>(pairs, a.NPR, a.nRin, threadIdx.x, a.seed, (unsigned)img, a.call, 2);
+    shuffle_sort<kScanSupThreads>(pairs, a.NPR, a.nRin, threadIdx.x, a.seed, pimg, a.call, 2);
     if (threadIdx.x >= 64) return;   // (no workgroup barrier below this line)
     resample_from_grid<4>(sq, sw, a.topR + 4 * (size_t)img, a.gridR, a.uR + row * a.nRin, a.peakFactorR, a.nRin, a.mLR, pairs, a.NPR, lane,
-                          a.seed, (unsigned)img, a.call, 2, true);
+                          a.seed, pimg, a.call, 2, true);
     {   // calVari(PAR_R) on the new points, as in k_pf_update
-        double A[16], mean[4], cm[4];
-        infer_acg(A, sq, a.mLR, lane, nullptr);
-        sym4_top_eigvec(mean, A);
-        cm[0] = mean[0]; cm[1] = -mean[1]; cm[2] = -mean[2]; cm[3] = -mean[3];
-        for (int i = lane; i < a.mLR; i += 64) { double o[4]; qmul(o, cm, sq + 4 * i); for (int c = 0; c < 4; c++) sq[4 * i + c] = o[c]; }
-        __builtin_amdgcn_wave_barrier();
-        infer_acg(A, sq, a.mLR, lane, nullptr);
+        double kk[3];
+        cal_vari_R(kk, sq, a.mLR, lane, a.symQ, a.nSym, a.seed, pimg, a.call);
         if (lane == 0) {   // setK1..3(max(minimum of the scanning phase, k)), src/Optimiser.cpp:1032-1050
-            a.k123[3 * (size_t)img] = fmax(a.minK, A[5] / A[0]);
-            a.k123[3 * (size_t)img + 1] = fmax(a.minK, A[10] / A[0]);
-            a.k123[3 * (size_t)img + 2] = fmax(a.minK, A[15] / A[0]);
+            a.k123[3 * (size_t)img] = fmax(a.minK, kk[0]);
+            a.k123[3 * (size_t)img + 1] = fmax(a.minK, kk[1]);
+            a.k123[3 * (size_t)img + 2] = fmax(a.minK, kk[2]);
         }
-        for (int i = lane; i < a.mLR; i += 64) { double o[4]; qmul(o, mean, sq + 4 * i); for (int c = 0; c < 4; c++) sq[4 * i + c] = o[c]; }
-        __builtin_amdgcn_wave_barrier();
     }
     for (int i = lane; i < a.mLR; i += 64) {
 #pragma unroll
@@ -581,7 +631,7 @@ __global__ __launch_bounds__(kScanSupThreads) void k_pf_scan_support(ScanSupport
     __builtin_amdgcn_wave_barrier();
     // ---- shifts ----
     resample_from_grid<2>(sq, sw, a.topT + 2 * (size_t)img, a.gridT, a.uT + row * a.nTin, -1.0, a.nTin, a.mLT, pairs, a.NPT, lane, a.seed,
-                          (unsigned)img, a.call, 4, false);
+                          pimg, a.call, 4, false);
     double m, s0, s1;
     col_mean_sd(m, s0, sq, 0, a.mLT, lane);
     col_mean_sd(m, s1, sq, 1, a.mLT, lane);
@@ -675,7 +725,8 @@ __global__ void k_pf_stop_init(int* __restrict__ active, int* __restrict__ nP, d
 // followed by balanceWeight(PAR_D) + normW (:2405-2440): w_i = 1 / N(d_i - mean; sd), 1 when sd == 0.
 // Philox stream (seed, image, call, 10, i).
 __global__ void k_pf_perturb_d(double* __restrict__ d, double* __restrict__ wD, const double* __restrict__ sD, int nImg, int nD,
-                               double scale, int init, unsigned long long seed, unsigned call, const int* __restrict__ active)
+                               double scale, int init, unsigned long long seed, unsigned call, const int* __restrict__ active,
+                               unsigned img0)
 {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= nImg || (active && !active[l])) return;
@@ -684,7 +735,7 @@ __global__ void k_pf_perturb_d(double* __restrict__ d, double* __restrict__ wD, 
     const double s = init ? scale : sD[l];
     for (int i = 0; i < nD; i++) {
         double g[4];
-        draw_n4(g, seed, (unsigned)l, call, 10u, (unsigned)i);
+        draw_n4(g, seed, img0 + (unsigned)l, call, 10u, (unsigned)i);
         dd[i] = init ? 1.0 + s * g[0] : dd[i] + (s * g[0]) * scale;      // gsl_ran_gaussian(engine, sigma) = sigma * n
     }
     // gsl_stats_mean / gsl_stats_sd_m (recurrences in long double in GSL; two-pass in double here: 1e-16)
@@ -714,7 +765,7 @@ __global__ void k_pf_perturb_d(double* __restrict__ d, double* __restrict__ wD, 
 // Philox streams (seed, image, call, 11 = shuffle keys / 12 = u0).
 __global__ void k_pf_update_d(double* __restrict__ d, double* __restrict__ wD, const float* __restrict__ uD, double* __restrict__ sD,
                               double* __restrict__ topD, int nImg, int nD, unsigned long long seed, unsigned call,
-                              const int* __restrict__ active)
+                              const int* __restrict__ active, unsigned img0)
 {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= nImg || (active && !active[l])) return;
@@ -734,7 +785,7 @@ __global__ void k_pf_update_d(double* __restrict__ d, double* __restrict__ wD, c
     sD[l] = nD > 1 ? sqrt(v / nD * ((double)nD / (double)(nD - 1))) : 0.0;
     for (int i = 0; i < nD; i++) {
         Philox g{(unsigned)seed, (unsigned)(seed >> 32)};
-        unsigned c[4] = {(unsigned)l, call, 11u, (unsigned)i};
+        unsigned c[4] = {img0 + (unsigned)l, call, 11u, (unsigned)i};
         g(c);
         key[i] = c[0];
     }
@@ -749,7 +800,7 @@ __global__ void k_pf_update_d(double* __restrict__ d, double* __restrict__ wD, c
     const double last = cdf[nD - 1];
     for (int i = 0; i < nD; i++) cdf[i] /= last;
     double d4[4];
-    draw_u4(d4, seed, (unsigned)l, call, 12u, 0);
+    draw_u4(d4, seed, img0 + (unsigned)l, call, 12u, 0);
     const double u0 = d4[0] * (1.0 / nD);
     int i = 0;
     double ws = 0;
@@ -769,10 +820,11 @@ __global__ void k_pf_update_d(double* __restrict__ d, double* __restrict__ wD, c
 // One thread per image (k <= 64 classes): Philox streams (seed, image, call, 6 / 7 / 8, .).
 constexpr int kMaxClasses = 64;
 __global__ void k_pf_class_select(int* __restrict__ cls, const float* __restrict__ uC, const double* __restrict__ wC, int nImg, int nK,
-                                  double peakFactorC, unsigned long long seed, unsigned call)
+                                  double peakFactorC, unsigned long long seed, unsigned call, unsigned img0)
 {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= nImg) return;
+    const unsigned pl = img0 + (unsigned)l;
     double u[kMaxClasses], w[kMaxClasses], su[kMaxClasses], sw[kMaxClasses];
     int sc[kMaxClasses];
     unsigned key[kMaxClasses];
@@ -786,7 +838,7 @@ __global__ void k_pf_class_select(int* __restrict__ cls, const float* __restrict
     for (int i = 0; i < nK; i++) u[i] = (u[i] < hh) ? 0.0 : u[i] - hh;
     for (int i = 0; i < nK; i++) {
         Philox g{(unsigned)seed, (unsigned)(seed >> 32)};
-        unsigned c[4] = {(unsigned)l, call, 6u, (unsigned)i};
+        unsigned c[4] = {pl, call, 6u, (unsigned)i};
         g(c);
         key[i] = c[0];
     }
@@ -802,9 +854,9 @@ __global__ void k_pf_class_select(int* __restrict__ cls, const float* __restrict
     const double last = cdf[nK - 1];
     for (int i = 0; i < nK; i++) cdf[i] /= last;
     double d4[4];
-    draw_u4(d4, seed, (unsigned)l, call, 7u, 0);
+    draw_u4(d4, seed, pl, call, 7u, 0);
     const double u0 = d4[0] * (1.0 / nK);
-    draw_u4(d4, seed, (unsigned)l, call, 8u, 0);
+    draw_u4(d4, seed, pl, call, 8u, 0);
     int pick = (int)(d4[0] * nK);          // gsl_rng_uniform_int(engine, _nC) among the resampled classes
     pick = pick >= nK ? nK - 1 : pick;
     int i = 0, chosen = sc[0];
@@ -816,23 +868,202 @@ __global__ void k_pf_class_select(int* __restrict__ cls, const float* __restrict
     cls[l] = chosen;
 }
 
+// Particle::calVari(PAR_R) + calVari(PAR_T) on their own (Particle::load, src/Particle.cpp:400-520: the filter's spread before its
+// first phase): r is replaced by the symmetrised / round-tripped support points as the reference's calVari leaves _r
+__global__ __launch_bounds__(64) void k_pf_cal_vari(PfArgs a)
+{
+    __shared__ double sq[kPfMax * 4];
+    const int img = blockIdx.x, lane = threadIdx.x;
+    const unsigned pimg = a.img0 + (unsigned)img;
+    if (a.nR > 0) {
+        double* r = a.r + (size_t)img * a.nR * 4;
+        for (int i = lane; i < a.nR * 4; i += 64) sq[i] = r[i];
+        __builtin_amdgcn_wave_barrier();
+        double kk[3];
+        cal_vari_R(kk, sq, a.nR, lane, a.symQ, a.nSym, a.seed, pimg, a.call);
+        if (lane < 3) a.k123[3 * (size_t)img + lane] = kk[lane];
+        if (a.nSym > 0) for (int i = lane; i < a.nR * 4; i += 64) r[i] = sq[i];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (a.nT > 0) {
+        const double* t = a.t + (size_t)img * a.nT * 2;
+        for (int i = lane; i < a.nT * 2; i += 64) sq[i] = t[i];
+        __builtin_amdgcn_wave_barrier();
+        double m, s0, s1;
+        col_mean_sd(m, s0, sq, 0, a.nT, lane);
+        col_mean_sd(m, s1, sq, 1, a.nT, lane);
+        if (lane == 0) { a.s01[2 * (size_t)img] = s0; a.s01[2 * (size_t)img + 1] = s1; }
+    }
+}
+
+// Particle::symmetrise(anchor), src/Particle.cpp:2445-2470, one thread per quaternion; anchor [nImg][4] or NULL = ANCHOR_POINT_2
+__global__ void k_pf_symmetrise(double* __restrict__ r, const double* __restrict__ anchor, size_t nImg, int nR,
+                                const double* __restrict__ symQ, int nSym)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nImg * nR) return;
+    const size_t l = e / nR;
+    double an[4] = {1, 0, 0, 0};
+    if (anchor) { an[0] = anchor[4 * l]; an[1] = anchor[4 * l + 1]; an[2] = anchor[4 * l + 2]; an[3] = anchor[4 * l + 3]; }
+    double q[4] = {r[4 * e], r[4 * e + 1], r[4 * e + 2], r[4 * e + 3]};
+    sym_counterpart(q, symQ, nSym, an);
+    r[4 * e] = q[0]; r[4 * e + 1] = q[1]; r[4 * e + 2] = q[2]; r[4 * e + 3] = q[3];
+}
+
 }  // namespace thx
 
 using namespace thx;
 
+namespace {
+// Symmetry::init(const char sym[]) on the host -- see thx_symmetry_host below
+struct SymEntry { int fold; double ax[3]; };
+void mat33_mul(double* d, const double* a, const double* b)
+{
+    double t[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) { double s = 0; for (int k = 0; k < 3; k++) s += a[r * 3 + k] * b[k * 3 + c]; t[r * 3 + c] = s; }
+    memcpy(d, t, sizeof(t));
+}
+bool same_matrix(const double* a, const double* b)   // SAME_MATRIX, EQUAL_ACCURACY = 1e-2
+{
+    for (int i = 0; i < 9; i++) if (fabs(a[i] - b[i]) > 1e-2) return false;
+    return true;
+}
+void quat_of_matrix(double* q, const double* m)   // quaternion(dvec4&, const dmat33&), src/Geometry/Euler.cpp:112-123; m row-major
+{
+    auto M = [&](int r, int c) { return m[r * 3 + c]; };
+    q[0] = 0.5 * sqrt(fmax(0.0, 1 + M(0, 0) + M(1, 1) + M(2, 2)));
+    q[1] = 0.5 * sqrt(fmax(0.0, 1 + M(0, 0) - M(1, 1) - M(2, 2)));
+    q[2] = 0.5 * sqrt(fmax(0.0, 1 - M(0, 0) + M(1, 1) - M(2, 2)));
+    q[3] = 0.5 * sqrt(fmax(0.0, 1 - M(0, 0) - M(1, 1) + M(2, 2)));
+    q[1] = copysign(q[1], M(2, 1) - M(1, 2));
+    q[2] = copysign(q[2], M(0, 2) - M(2, 0));
+    q[3] = copysign(q[3], M(1, 0) - M(0, 1));
+}
+void rot_of_quat(double* m /*row-major*/, const double* q)   // rotate3D(dmat33&, const dvec4&), src/Geometry/Euler.cpp:181-189
+{
+    const double A[3][3] = {{0, -q[3], q[2]}, {q[3], 0, -q[1]}, {-q[2], q[1], 0}};
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += A[r][k] * A[k][c];
+            m[r * 3 + c] = (r == c ? 1.0 : 0.0) + 2 * q[0] * A[r][c] + 2 * s;
+        }
+}
+PfArgs pf_args_ctx(const thx_pf_ctx* ctx)
+{
+    PfArgs a;
+    memset(&a, 0, sizeof(a));
+    if (ctx) { a.symQ = ctx->nSym > 0 ? ctx->symQuat : nullptr; a.nSym = ctx->nSym > 0 ? ctx->nSym : 0; a.img0 = ctx->img0; }
+    return a;
+}
+}  // namespace
+
 extern "C" {
 
-int thx_pf_perturb_dev(double* r, double* t, double* wR, double* wT, const double* k123, const double* s01, int nImg,
-                       int nR, int nT, double pfR, double pfT, double transS, double transQ, unsigned long long seed,
-                       unsigned call, const int* active, void* stream)
+// Symmetry::init(const char sym[]) (src/Geometry/Symmetry.cpp:61-278): symmetryGroup + fillSymmetryEntry
+// (src/Geometry/SymmetryFunctions.cpp:13-164) -> fillLR (rotations; `RFLOAT angle = 2 * M_PI / fold`, axes as given) ->
+// completePointGroup (closure under products, in the order of the reference's visit table).
+int thx_symmetry_host(const char* sym, double* symMat, double* symQuat, int cap, int* nSym)
+{
+    THX_REQUIRE(sym && nSym && cap >= 0, "bad arguments");
+    std::vector<SymEntry> e;
+    auto rot = [&](int f, double x, double y, double z) { e.push_back({f, {x, y, z}}); };
+    const size_t len = strlen(sym);
+    bool digits = len > 1;
+    for (size_t i = 1; i < len; i++) if (sym[i] < '0' || sym[i] > '9') digits = false;
+    if ((sym[0] == 'C' || sym[0] == 'D') && digits) {
+        THX_REQUIRE(atoi(sym + 1) >= 1, "point group order must be >= 1");
+        rot(atoi(sym + 1), 0, 0, 1);
+        if (sym[0] == 'D') rot(2, 1, 0, 0);
+    } else if (!strcmp(sym, "T")) { rot(3, 0, 0, 1); rot(2, 0, 0.816496, 0.577350); }
+    else if (!strcmp(sym, "O")) { rot(3, 0.5773502, 0.5773502, 0.5773502); rot(4, 0, 0, 1); }
+    else if (!strcmp(sym, "I1")) { rot(2, 1, 0, 0); rot(5, 0.8506508, 0, -0.5257311); rot(3, 0.9341724, 0.3568221, 0); }
+    else if (!strcmp(sym, "I2")) { rot(2, 0, 0, 1); rot(5, 0.5257311, 0, 0.8506508); rot(3, 0, 0.3568221, 0.9341724); }
+    else if (!strcmp(sym, "I3")) { rot(2, -0.5257311, 0, 0.8506508); rot(5, 0, 0, 1); rot(3, -0.4911235, 0.3568221, 0.7946545); }
+    else if (!strcmp(sym, "I4")) { rot(2, 0.5257311, 0, 0.8506508); rot(5, 0.8944272, 0, 0.4472136); rot(3, 0.4911235, 0.3568221, 0.7946545); }
+    else { set_error("INVALID SYMMTRY INDEX: %s", sym); return -1; }
+    std::vector<double> R;   // row-major [n][9]
+    std::vector<double> Q;
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    auto novo = [&](const double* m) {
+        if (same_matrix(m, I)) return false;
+        for (size_t q = 0; q < R.size() / 9; q++) if (same_matrix(m, R.data() + 9 * q)) return false;
+        return true;
+    };
+    auto append = [&](const double* m) { R.insert(R.end(), m, m + 9); double q[4]; quat_of_matrix(q, m); Q.insert(Q.end(), q, q + 4); };
+    for (const SymEntry& en : e) {
+        const float angle = (float)(2 * M_PI / en.fold);
+        for (int j = 1; j < en.fold; j++) {
+            const double phi = (double)(angle * (float)j);
+            const double q[4] = {cos(phi / 2), sin(phi / 2) * en.ax[0], sin(phi / 2) * en.ax[1], sin(phi / 2) * en.ax[2]};
+            double m[9];
+            rot_of_quat(m, q);
+            if (novo(m)) append(m);
+        }
+    }
+    {
+        std::vector<std::vector<unsigned char>> table(R.size() / 9, std::vector<unsigned char>(R.size() / 9, 0));
+        for (;;) {
+            int fi = -1, fj = -1;
+            for (size_t r = 0; r < table.size() && fi < 0; r++)
+                for (size_t c = 0; c < table.size(); c++)
+                    if (!table[r][c]) { fi = (int)r; fj = (int)c; table[r][c] = 1; break; }
+            if (fi < 0) break;
+            double m[9];
+            mat33_mul(m, R.data() + 9 * fi, R.data() + 9 * fj);
+            if (novo(m)) {
+                append(m);
+                for (auto& row : table) row.push_back(0);
+                table.push_back(std::vector<unsigned char>(table.size() + 1, 0));
+            }
+        }
+    }
+    const int n = (int)(R.size() / 9);
+    *nSym = n;
+    if (!symMat && !symQuat) return 0;
+    THX_REQUIRE(n <= cap, "more symmetry elements than the caller's arrays hold");
+    for (int s = 0; s < n; s++) {
+        if (symMat) for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) symMat[9 * s + c * 3 + r] = R[9 * s + r * 3 + c];
+        if (symQuat) for (int c = 0; c < 4; c++) symQuat[4 * s + c] = Q[4 * s + c];
+    }
+    return 0;
+}
+
+int thx_pf_symmetrise_dev(double* r, const double* anchor, int nImg, int nR, const double* symQuat, int nSym, void* stream)
+{
+    if (nImg <= 0 || nR <= 0 || nSym <= 0) return 0;
+    THX_REQUIRE(r && symQuat, "NULL pointer");
+    const size_t n = (size_t)nImg * nR;
+    hipLaunchKernelGGL(k_pf_symmetrise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), r, anchor, (size_t)nImg, nR,
+                       symQuat, nSym);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_pf_cal_vari_dev(double* r, const double* t, double* k123, double* s01, int nImg, int nR, int nT, unsigned long long seed,
+                        unsigned call, const thx_pf_ctx* ctx, void* stream)
+{
+    if (nImg <= 0) return 0;
+    THX_REQUIRE(nR >= 0 && nT >= 0 && nR <= kPfMax && nT <= kPfMax, "nR / nT must be <= 256");
+    THX_REQUIRE((nR == 0 || (r && k123 && nR >= 5)) && (nT == 0 || (t && s01 && nT >= 2)), "bad arguments");
+    PfArgs a = pf_args_ctx(ctx);
+    a.r = r; a.t = const_cast<double*>(t); a.k123 = k123; a.s01 = s01; a.nR = nR; a.nT = nT; a.seed = seed; a.call = call;
+    hipLaunchKernelGGL(k_pf_cal_vari, dim3(nImg), dim3(64), 0, as_stream(stream), a);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_pf_perturb_ex_dev(double* r, double* t, double* wR, double* wT, const double* k123, const double* s01, int nImg,
+                          int nR, int nT, double pfR, double pfT, double transS, double transQ, unsigned long long seed,
+                          unsigned call, const int* active, const thx_pf_ctx* ctx, void* stream)
 {
     if (nImg <= 0) return 0;
     THX_REQUIRE(nR >= 0 && nT >= 0 && nR <= kPfMax && nT <= kPfMax, "nR / nT must be <= 256");
     THX_REQUIRE((nR == 0 || (r && wR && k123)) && (nT == 0 || (t && wT && s01)), "NULL pointer");
     THX_REQUIRE(nR == 0 || nR >= 5, "the ACG statistics need at least 5 rotations");
     THX_REQUIRE(nT == 0 || nT >= 2, "the shift statistics need at least 2 points");
-    PfArgs a;
-    memset(&a, 0, sizeof(a));
+    PfArgs a = pf_args_ctx(ctx);
     a.r = r; a.t = t; a.wR = wR; a.wT = wT; a.k123 = const_cast<double*>(k123); a.s01 = const_cast<double*>(s01);
     a.nR = nR; a.nT = nT; a.pfR = pfR; a.pfT = pfT; a.transS = transS;
     // PARTICLE_RECENTRE_TRANSQ: transM = transS * gsl_cdf_chisq_Qinv(transQ, 2); for 2 degrees of freedom Q(x) = exp(-x/2)
@@ -843,21 +1074,34 @@ int thx_pf_perturb_dev(double* r, double* t, double* wR, double* wT, const doubl
     return 0;
 }
 
-int thx_pf_update_dev(double* r, double* t, double* wR, double* wT, const float* uR, const float* uT, double* k123,
-                      double* s01, double* topR, double* topT, int nImg, int nR, int nT, double peakFactorR,
-                      unsigned long long seed, unsigned call, const int* active, void* stream)
+int thx_pf_perturb_dev(double* r, double* t, double* wR, double* wT, const double* k123, const double* s01, int nImg,
+                       int nR, int nT, double pfR, double pfT, double transS, double transQ, unsigned long long seed,
+                       unsigned call, const int* active, void* stream)
+{
+    return thx_pf_perturb_ex_dev(r, t, wR, wT, k123, s01, nImg, nR, nT, pfR, pfT, transS, transQ, seed, call, active, nullptr, stream);
+}
+
+int thx_pf_update_ex_dev(double* r, double* t, double* wR, double* wT, const float* uR, const float* uT, double* k123,
+                         double* s01, double* topR, double* topT, int nImg, int nR, int nT, double peakFactorR,
+                         unsigned long long seed, unsigned call, const int* active, const thx_pf_ctx* ctx, void* stream)
 {
     if (nImg <= 0) return 0;
     THX_REQUIRE(nR >= 0 && nT >= 0 && nR <= kPfMax && nT <= kPfMax, "nR / nT must be <= 256");
     THX_REQUIRE((nR == 0 || (r && wR && uR && k123 && topR)) && (nT == 0 || (t && wT && uT && s01 && topT)), "NULL pointer");
     THX_REQUIRE((nR == 0 || nR >= 5) && (nT == 0 || nT >= 2), "too few support points");
-    PfArgs a;
-    memset(&a, 0, sizeof(a));
+    PfArgs a = pf_args_ctx(ctx);
     a.r = r; a.t = t; a.wR = wR; a.wT = wT; a.uR = uR; a.uT = uT; a.k123 = k123; a.s01 = s01; a.topR = topR; a.topT = topT;
     a.nR = nR; a.nT = nT; a.peakFactorR = peakFactorR; a.seed = seed; a.call = call; a.active = active;
     hipLaunchKernelGGL(k_pf_update, dim3(nImg), dim3(64), 0, as_stream(stream), a);
     THX_LAUNCH_CHECK();
     return 0;
+}
+
+int thx_pf_update_dev(double* r, double* t, double* wR, double* wT, const float* uR, const float* uT, double* k123,
+                      double* s01, double* topR, double* topT, int nImg, int nR, int nT, double peakFactorR,
+                      unsigned long long seed, unsigned call, const int* active, void* stream)
+{
+    return thx_pf_update_ex_dev(r, t, wR, wT, uR, uT, k123, s01, topR, topT, nImg, nR, nT, peakFactorR, seed, call, active, nullptr, stream);
 }
 
 int thx_pf_stop_init_dev(int* active, int* nP, double* state, double transS, double ctfRefineS, int nImg, void* stream)
@@ -881,13 +1125,30 @@ int thx_pf_stop_rule_dev(int* active, int* nP, double* state, const double* k123
     return 0;
 }
 
-int thx_pf_perturb_d_dev(double* d, double* wD, const double* sD, int nImg, int nD, double scale, int init, unsigned long long seed,
-                         unsigned call, const int* active, void* stream)
+int thx_pf_perturb_d_ex_dev(double* d, double* wD, const double* sD, int nImg, int nD, double scale, int init, unsigned long long seed,
+                            unsigned call, const int* active, unsigned img0, void* stream)
 {
     if (nImg <= 0) return 0;
     THX_REQUIRE(d && wD && (init || sD) && nD >= 1 && nD <= 64, "bad arguments (at most 64 defocus support points)");
     hipLaunchKernelGGL(k_pf_perturb_d, dim3((nImg + 63) / 64), dim3(64), 0, as_stream(stream), d, wD, sD, nImg, nD, scale, init, seed, call,
-                       active);
+                       active, img0);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_pf_perturb_d_dev(double* d, double* wD, const double* sD, int nImg, int nD, double scale, int init, unsigned long long seed,
+                         unsigned call, const int* active, void* stream)
+{
+    return thx_pf_perturb_d_ex_dev(d, wD, sD, nImg, nD, scale, init, seed, call, active, 0u, stream);
+}
+
+int thx_pf_update_d_ex_dev(double* d, double* wD, const float* uD, double* sD, double* topD, int nImg, int nD, unsigned long long seed,
+                           unsigned call, const int* active, unsigned img0, void* stream)
+{
+    if (nImg <= 0) return 0;
+    THX_REQUIRE(d && wD && uD && sD && topD && nD >= 1 && nD <= 64, "bad arguments (at most 64 defocus support points)");
+    hipLaunchKernelGGL(k_pf_update_d, dim3((nImg + 63) / 64), dim3(64), 0, as_stream(stream), d, wD, uD, sD, topD, nImg, nD, seed, call,
+                       active, img0);
     THX_LAUNCH_CHECK();
     return 0;
 }
@@ -895,10 +1156,16 @@ int thx_pf_perturb_d_dev(double* d, double* wD, const double* sD, int nImg, int 
 int thx_pf_update_d_dev(double* d, double* wD, const float* uD, double* sD, double* topD, int nImg, int nD, unsigned long long seed,
                         unsigned call, const int* active, void* stream)
 {
+    return thx_pf_update_d_ex_dev(d, wD, uD, sD, topD, nImg, nD, seed, call, active, 0u, stream);
+}
+
+int thx_pf_class_select_ex_dev(int* cls, const float* uC, const double* wC, int nImg, int nK, double peakFactorC,
+                               unsigned long long seed, unsigned call, unsigned img0, void* stream)
+{
     if (nImg <= 0) return 0;
-    THX_REQUIRE(d && wD && uD && sD && topD && nD >= 1 && nD <= 64, "bad arguments (at most 64 defocus support points)");
-    hipLaunchKernelGGL(k_pf_update_d, dim3((nImg + 63) / 64), dim3(64), 0, as_stream(stream), d, wD, uD, sD, topD, nImg, nD, seed, call,
-                       active);
+    THX_REQUIRE(cls && uC && nK >= 1 && nK <= kMaxClasses, "bad arguments (at most 64 classes)");
+    hipLaunchKernelGGL(k_pf_class_select, dim3((nImg + 63) / 64), dim3(64), 0, as_stream(stream), cls, uC, wC, nImg, nK, peakFactorC,
+                       seed, call, img0);
     THX_LAUNCH_CHECK();
     return 0;
 }
@@ -906,18 +1173,22 @@ int thx_pf_update_d_dev(double* d, double* wD, const float* uD, double* sD, doub
 int thx_pf_class_select_dev(int* cls, const float* uC, const double* wC, int nImg, int nK, double peakFactorC,
                             unsigned long long seed, unsigned call, void* stream)
 {
-    if (nImg <= 0) return 0;
-    THX_REQUIRE(cls && uC && nK >= 1 && nK <= kMaxClasses, "bad arguments (at most 64 classes)");
-    hipLaunchKernelGGL(k_pf_class_select, dim3((nImg + 63) / 64), dim3(64), 0, as_stream(stream), cls, uC, wC, nImg, nK, peakFactorC,
-                       seed, call);
-    THX_LAUNCH_CHECK();
-    return 0;
+    return thx_pf_class_select_ex_dev(cls, uC, wC, nImg, nK, peakFactorC, seed, call, 0u, stream);
 }
 
 int thx_pf_scan_support_dev(double* r, double* t, double* wR, double* wT, double* k123, double* s01, double* topR, double* topT,
                             const double* gridR, const double* gridT, const float* uR, const float* uT, const int* cls, int nImg,
                             int nRin, int nTin, int mLR, int mLT, double peakFactorR, double minK, double minS, unsigned long long seed,
                             unsigned call, void* stream)
+{
+    return thx_pf_scan_support_ex_dev(r, t, wR, wT, k123, s01, topR, topT, gridR, gridT, uR, uT, cls, nImg, nImg, nRin, nTin, mLR, mLT,
+                                      peakFactorR, minK, minS, seed, call, nullptr, stream);
+}
+
+int thx_pf_scan_support_ex_dev(double* r, double* t, double* wR, double* wT, double* k123, double* s01, double* topR, double* topT,
+                               const double* gridR, const double* gridT, const float* uR, const float* uT, const int* cls, int nImg,
+                               int rowStride, int nRin, int nTin, int mLR, int mLT, double peakFactorR, double minK, double minS,
+                               unsigned long long seed, unsigned call, const thx_pf_ctx* ctx, void* stream)
 {
     if (nImg <= 0) return 0;
     THX_REQUIRE(r && t && wR && wT && k123 && s01 && topR && topT && gridR && gridT && uR && uT, "NULL pointer");
@@ -930,6 +1201,8 @@ int thx_pf_scan_support_dev(double* r, double* t, double* wR, double* wT, double
     a.NPR = 64; while (a.NPR < nRin) a.NPR <<= 1;
     a.NPT = 64; while (a.NPT < nTin) a.NPT <<= 1;
     a.peakFactorR = peakFactorR; a.minK = minK; a.minS = minS; a.seed = seed; a.call = call;
+    a.symQ = ctx && ctx->nSym > 0 ? ctx->symQuat : nullptr; a.nSym = ctx && ctx->nSym > 0 ? ctx->nSym : 0; a.img0 = ctx ? ctx->img0 : 0u;
+    a.rowStride = rowStride;
     const size_t lds = (size_t)(a.NPR > a.NPT ? a.NPR : a.NPT) * sizeof(unsigned long long);
     THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pf_scan_support), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_pf_scan_support, dim3(nImg), dim3(kScanSupThreads), lds, as_stream(stream), a);

@@ -9,14 +9,14 @@ namespace thx {
 // ---- Philox4x32-10 (Salmon et al., SC'11) ----
 struct Philox {
     unsigned k0, k1;
-    __device__ __forceinline__ void round(unsigned c[4], unsigned ka, unsigned kb) const
+    __host__ __device__ __forceinline__ void round(unsigned c[4], unsigned ka, unsigned kb) const
     {
         const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
         const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ ka, n1 = (unsigned)p1;
         const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ kb, n3 = (unsigned)p0;
         c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
     }
-    __device__ __forceinline__ void operator()(unsigned c[4]) const
+    __host__ __device__ __forceinline__ void operator()(unsigned c[4]) const
     {
         unsigned ka = k0, kb = k1;
 #pragma unroll
@@ -29,7 +29,7 @@ struct Philox {
 };
 
 // four uniforms in (0, 1) / four standard normals for (image, call, purpose, index)
-__device__ __forceinline__ void draw_u4(double u[4], unsigned long long seed, unsigned img, unsigned call, unsigned purpose,
+__host__ __device__ __forceinline__ void draw_u4(double u[4], unsigned long long seed, unsigned img, unsigned call, unsigned purpose,
                                         unsigned index)
 {
     Philox g{(unsigned)seed, (unsigned)(seed >> 32)};

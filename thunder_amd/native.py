@@ -10,9 +10,9 @@ import numpy as np
 import torch
 
 from . import capi
-from .capi import ClassifyConfig, ClassifyStats, ClassifyView, RefineConfig, RefineStats, RefineView, ptr, stream_ptr
+from .capi import RefineConfig, RefineStats, RefineView, ptr, stream_ptr
 
-STAGES = ("rows", "expectation", "sigma", "insertion", "reconstruct", "recentre_remask", "norm_correction")
+STAGES = ("rows", "expectation", "sigma", "insertion", "reconstruct", "recentre_remask", "norm_correction", "global_scan")
 
 
 class Comm:
@@ -86,11 +86,15 @@ def make_comms(rank, world, share_from):
 
 
 class NativeRefine:
-    """thx_refine handle over the particles of a RefineShard (which only has to have GENERATED them: allocate=False)."""
+    """thx_refine handle over the particles of a RefineShard (which only has to have GENERATED them: allocate=False).
+    Optional attributes of the shard select what round 4 added to the driver: nK + refs [K][N]^3 (classes), scan = dict(quat
+    [nR][4], shifts [nT][2], rScan[, minK, minS, batch]) (global search), sym = a point-group name ("C4", "D2", ...),
+    search = "local" | "global" | "ctf", pfSGlobal, peakFactorC, balanceClass, mLD / ctfRefineS / pfSCTF, cls0 [nImg]."""
 
     def __init__(self, shard, hemi=None, world=None, pixel_order=1, max_phase=0, norm_correction=False):
         self.shard = shard
         s = shard
+        g = lambda name, default=None: getattr(s, name, default)
         cfg = RefineConfig()
         cfg.N, cfg.pf, cfg.nImg = s.N, s.pf, s.nImg
         if s.world == 1:
@@ -106,6 +110,22 @@ class NativeRefine:
         cfg.seed = s.pf_seed
         cfg.coreFSC, cfg.goldenAverage, cfg.solventFlatten = int(s.coreFSC), int(s.goldenAverage), int(s.solventFlatten)
         cfg.normCorrection = 1 if norm_correction else 0   # Optimiser::normCorrection: rescales shard.imgOri IN PLACE from iteration 2 on
+        # ---- classes, global search, point group, CTF search ----
+        cfg.nK = int(g("nK", 1))
+        self.search = {"local": capi.SEARCH_LOCAL, "global": capi.SEARCH_GLOBAL, "ctf": capi.SEARCH_CTF}[g("search", "local")]
+        cfg.searchType = self.search
+        scan = g("scan")
+        if scan is not None:
+            cfg.nR, cfg.nT, cfg.rScan = len(scan["quat"]), len(scan["shifts"]), int(scan["rScan"])
+            cfg.scanBatch = int(scan.get("batch", 0))
+            mk, ms = scan_min_spread(scan.get("mS", cfg.nR), g("pfSGlobal", 0.5))
+            cfg.scanMinK, cfg.scanMinS = scan.get("minK", mk), scan.get("minS", ms)
+        cfg.pfSGlobal, cfg.peakFactorC = g("pfSGlobal", 0.5), g("peakFactorC", 1.0 - 1e-2)
+        cfg.balanceClass = int(g("balanceClass", 0))
+        self.sym = symmetry(g("sym")) if g("sym") else None
+        if self.sym is not None and self.sym["n"] > 0:
+            cfg.nSym, cfg.symMat, cfg.symQuat = self.sym["n"], self.sym["R"].ctypes.data, self.sym["quat"].ctypes.data
+        cfg.mLD, cfg.ctfRefineS, cfg.pfSCTF = int(g("mLD", 0)), g("ctfRefineS", 0.01), g("pfSCTF", 0.5)
         assert s.use_pf, "the native driver runs the device particle filter"
         self.cfg = cfg
         h = C.c_void_p()
@@ -115,28 +135,47 @@ class NativeRefine:
         gid = np.ascontiguousarray(s.gid.astype(np.int32))
         capi.call("thx_refine_set_particles", self._h, ptr(s.imgOri), ptr(s.attr), gid.ctypes.data, ptr(s.pf0["r"]),
                   ptr(s.pf0["t"]), stream_ptr())
-        capi.call("thx_refine_set_reference", self._h, ptr(s.ref), stream_ptr())
+        refs = g("refs")
+        capi.call("thx_refine_set_reference", self._h, ptr(refs if refs is not None else s.ref), stream_ptr())
+        if scan is not None:
+            q, sh = np.ascontiguousarray(scan["quat"], np.float64), np.ascontiguousarray(scan["shifts"], np.float64)
+            capi.call("thx_refine_set_grid", self._h, q.ctypes.data, sh.ctypes.data, stream_ptr())
+        if g("cls0") is not None:
+            c0 = np.ascontiguousarray(g("cls0"), np.int32)
+            capi.call("thx_refine_set_classes", self._h, c0.ctypes.data, stream_ptr())
         torch.cuda.synchronize()
+
+    def set_search(self, search):
+        self.search = {"local": capi.SEARCH_LOCAL, "global": capi.SEARCH_GLOBAL, "ctf": capi.SEARCH_CTF}[search]
+        capi.call("thx_refine_set_search_type", self._h, self.search)
 
     def reset(self):
         capi.call("thx_refine_reset", self._h, stream_ptr())
 
-    def capture(self, maps=True):
+    def capture(self, maps=True, scan=False, sym=False):
         """per-phase trace of the local search (thx_refine_set_capture): returns the dict of device tensors the following
-        iterations fill -- uR, uT, r, t, k123, s01 indexed [phase][image], mapsFsc [2][N]^3"""
+        iterations fill -- uR, uT, r, t, k123, s01 indexed [phase][image], mapsFsc [2][K][N]^3; scan: the scan's weights and the
+        support points it left; sym: F / T after prepareTF"""
         s, c = self.shard, self.cfg
-        n, dev = s.nImg, s.dev
+        n, dev, K = s.nImg, s.dev, c.nK
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
         cap = dict(uR=z((c.nPhase, n, c.mLR), torch.float32), uT=z((c.nPhase, n, c.mLT), torch.float32),
                    r=z((c.nPhase, n, c.mLR, 4), torch.float64), t=z((c.nPhase, n, c.mLT, 2), torch.float64),
                    k123=z((c.nPhase, n, 3), torch.float64), s01=z((c.nPhase, n, 2), torch.float64),
-                   mapsFsc=z((2, s.N, s.N, s.N), torch.float32) if maps else None,
+                   mapsFsc=z((2, K, s.N, s.N, s.N), torch.float32) if maps else None,
                    rP=z((c.nPhase, n, c.mLR, 4), torch.float64), tP=z((c.nPhase, n, c.mLT, 2), torch.float64),
                    wRP=z((c.nPhase, n, c.mLR), torch.float64), wTP=z((c.nPhase, n, c.mLT), torch.float64))
+        P, nV = s.N * s.pf, 2 if s.world == 1 else 1
         if maps:
-            P, nV = s.N * s.pf, 2 if s.world == 1 else 1
-            cap["Fraw"] = z((nV, P, P, P // 2 + 1), torch.complex64)
-            cap["Traw"] = z((nV, P, P, P // 2 + 1), torch.float32)
+            cap["Fraw"] = z((nV, K, P, P, P // 2 + 1), torch.complex64)
+            cap["Traw"] = z((nV, K, P, P, P // 2 + 1), torch.float32)
+        if sym:
+            cap["Fsym"] = z((nV, K, P, P, P // 2 + 1), torch.complex64)
+            cap["Tsym"] = z((nV, K, P, P, P // 2 + 1), torch.float32)
+        if scan:
+            cap.update(scanUC=z((n, K), torch.float32), scanUR=z((n, K, c.nR), torch.float32), scanUT=z((n, K, c.nT), torch.float32),
+                       r0=z((n, c.mLR, 4), torch.float64), t0=z((n, c.mLT, 2), torch.float64), k0=z((n, 3), torch.float64),
+                       s0=z((n, 2), torch.float64))
         st = capi.RefineCapture()
         for k, v in cap.items():
             setattr(st, k, ptr(v) if v is not None else None)
@@ -145,9 +184,11 @@ class NativeRefine:
         return cap
 
     def iterate(self, timed=False):
-        fsc = np.zeros(self.shard.N // 2, np.float32)
+        """one iteration; returns this iteration's FSC [N / 2] (one class) or [K][N / 2]"""
+        K = self.cfg.nK
+        fsc = np.zeros((K, self.shard.N // 2), np.float32)
         capi.call("thx_refine_iterate", self._h, fsc.ctypes.data, 1 if timed else 0, stream_ptr())
-        return fsc
+        return fsc[0] if K == 1 else fsc
 
     def run(self, steps, timed=False):
         fsc = None
@@ -160,15 +201,20 @@ class NativeRefine:
         capi.call("thx_refine_get_stats", self._h, C.byref(st), 1 if reset else 0)
         return st
 
+    def rounds(self):
+        """balancing rounds of the last iteration as [MAP off / on][local half][class]"""
+        a = np.asarray(list(self.stats().lastRoundsK), np.int64).reshape(2, 2, 16)
+        return a[:, :, :self.cfg.nK].copy()
+
     def view(self):
         v = RefineView()
         capi.call("thx_refine_get_view", self._h, C.byref(v))
         return v
 
-    def map(self, half):
+    def map(self, half, k=0):
         N = self.shard.N
         m = torch.empty((N, N, N), dtype=torch.float32, device=self.shard.dev)
-        capi.call("thx_refine_get_map", self._h, half, ptr(m), stream_ptr())
+        capi.call("thx_refine_get_map_k", self._h, half, k, ptr(m), stream_ptr())
         return m
 
     def state(self):
@@ -182,6 +228,7 @@ class NativeRefine:
     def fetch(self, dev_ptr, dtype, shape, offset_elems=0):
         """host copy of a slice of one of view()'s device arrays"""
         a = np.empty(shape, dtype)
+        torch.cuda.synchronize()
         capi.call("thx_memcpy_d2h", a.ctypes.data, int(dev_ptr) + offset_elems * a.itemsize, a.nbytes)
         return a
 
@@ -197,102 +244,23 @@ class NativeRefine:
             pass
 
 
-CLASSIFY_STAGES = ("scan", "class_select_and_support_points", "local_phases", "insertion", "reconstruct")
+def symmetry(name, cap=128):
+    """thx_symmetry_host = Symmetry::init(name): dict(n, R [n][9] column-major, quat [n][4], name)"""
+    n = C.c_int(0)
+    R, q = np.zeros((cap, 9)), np.zeros((cap, 4))
+    capi.call("thx_symmetry_host", name.encode(), R.ctypes.data, q.ctypes.data, cap, C.byref(n))
+    return dict(n=n.value, R=np.ascontiguousarray(R[:n.value]), quat=np.ascontiguousarray(q[:n.value]), name=name)
+
+
 INIT_OUTSIDE_CONFIDENCE_AREA = 0.5   # include/Particle.h:59
 TRANS_SEARCH_FACTOR = 0.25           # script/demo_3D.json "Translation Search Factor"
 
 
-def scan_min_spread(nR, perturbFactorSGlobal=0.5):
+def scan_min_spread(mS, perturbFactorSGlobal=0.5):
     """the scanning phase's minimum spread (OPTIMISER_SCAN_SET_MIN_STD_WITH_PERTURB, src/Optimiser.cpp:667-690,1032-1079): scanMinStdR =
-    mS^(-1/3) in MODE_3D (mS = the scanned rotations before symmetry reduction: nR for C1, which is what this takes), scanMinStdT = 1 / Qinv(INIT_OUTSIDE_CONFIDENCE_AREA, 2) / sqrt(transSearchFactor pi), over perturbFactorSGlobal
+    mS^(-1/3) in MODE_3D (mS = "Number of Sampling Points for Scanning in Global Search": the scanned rotations BEFORE the symmetry
+    reduction nR = mS / (1 + nSym), :652), scanMinStdT = 1 / Qinv(INIT_OUTSIDE_CONFIDENCE_AREA, 2) / sqrt(transSearchFactor pi), over perturbFactorSGlobal
     -> (minK, minS) of thx_pf_scan_support_dev"""
-    minK = (nR ** (-1.0 / 3) / perturbFactorSGlobal) ** 2
+    minK = (mS ** (-1.0 / 3) / perturbFactorSGlobal) ** 2
     minS = 1.0 / (-2.0 * np.log(INIT_OUTSIDE_CONFIDENCE_AREA)) / np.sqrt(TRANS_SEARCH_FACTOR * np.pi) / perturbFactorSGlobal
     return float(minK), float(minS)
-
-
-class NativeClassify:
-    """thx_classify handle (thunder_amd/csrc/thx_classify.hip): one K-class classification iteration -- global scan, class of
-    every image, support points, local phases against the assigned reference, multi-reference insertion session, 2
-    reconstructions per class -- behind one call.  The tensors handed to set_particles are borrowed: keep them alive."""
-
-    def __init__(self, N, K, nImg, nR, nT, rScan, rL=2, pf=2, mLR=125, mLT=9, nPhase=3, mReco=100, batch=10240, pixel_order=0,
-                 wg_per_cu=2, refresh=False, pixelSize=1.32, transS=2.0, transQ=0.05, pfL=2.0, pfS=0.5, peakFactorR=1e-3,
-                 peakFactorC=1.0 - 1e-2, seed=20240607, hemi=None, nImgHemi=0, scan_min=None):
-        cfg = ClassifyConfig()
-        cfg.N, cfg.pf, cfg.nK, cfg.nImg, cfg.nImgHemi = N, pf, K, nImg, nImgHemi
-        cfg.nR, cfg.nT, cfg.rScan, cfg.rL = nR, nT, rScan, rL
-        cfg.mLR, cfg.mLT, cfg.nPhase, cfg.mReco, cfg.batch = mLR, mLT, nPhase, mReco, batch
-        cfg.pixelOrder, cfg.wgPerCU, cfg.refresh, cfg.pixelSize = pixel_order, wg_per_cu, 1 if refresh else 0, pixelSize
-        cfg.transS, cfg.transQ, cfg.pfL, cfg.pfS = transS, transQ, pfL, pfS
-        cfg.peakFactorR, cfg.peakFactorC = peakFactorR, peakFactorC
-        cfg.scanMinK, cfg.scanMinS = scan_min_spread(nR) if scan_min is None else scan_min   # (minK, minS) of thx_pf_scan_support_dev
-        cfg.seed = seed
-        self.cfg = cfg
-        h = C.c_void_p()
-        capi.call("thx_classify_create", C.byref(h), C.byref(cfg), hemi.handle if hemi is not None else None)
-        self._h = h
-        self._keep = []
-
-    def set_grid(self, quat, shifts):
-        capi.call("thx_classify_set_grid", self._h, ptr(quat), ptr(shifts), stream_ptr())
-
-    def set_particles(self, datM, ctfM, sigRcpM, w):
-        assert datM.dtype == torch.complex64 and ctfM.dtype == torch.float32 and sigRcpM.dtype == torch.float32 and w.dtype == torch.float32
-        self._keep = [datM, ctfM, sigRcpM, w]
-        capi.call("thx_classify_set_particles", self._h, ptr(datM), ptr(ctfM), ptr(sigRcpM), ptr(w), stream_ptr())
-
-    def set_references(self, refRL):
-        assert refRL.dtype == torch.float32 and refRL.shape[0] == self.cfg.nK
-        capi.call("thx_classify_set_references", self._h, ptr(refRL), stream_ptr())
-
-    def set_fsc(self, fsc):
-        f = np.ascontiguousarray(np.asarray(fsc, np.float32))
-        capi.call("thx_classify_set_fsc", self._h, f.ctypes.data, f.size)
-
-    def capture(self):
-        """stage trace (thx_classify_set_capture): dict of device tensors the following iterations fill -- r0, t0 (support points
-        after the scan), Fraw, Traw (accumulators before prepareTF)"""
-        c = self.cfg
-        P, dev = c.N * c.pf, torch.device("cuda", torch.cuda.current_device())
-        cap = dict(r0=torch.zeros((c.nImg, c.mLR, 4), dtype=torch.float64, device=dev),
-                   t0=torch.zeros((c.nImg, c.mLT, 2), dtype=torch.float64, device=dev),
-                   Fraw=torch.zeros((c.nK, P, P, P // 2 + 1), dtype=torch.complex64, device=dev),
-                   Traw=torch.zeros((c.nK, P, P, P // 2 + 1), dtype=torch.float32, device=dev))
-        st = capi.ClassifyCapture()
-        for k, v in cap.items():
-            setattr(st, k, ptr(v))
-        capi.call("thx_classify_set_capture", self._h, C.byref(st))
-        self._cap = cap
-        return cap
-
-    def iterate(self, timed=False):
-        capi.call("thx_classify_iterate", self._h, 1 if timed else 0, stream_ptr())
-
-    def stats(self, reset=False):
-        st = ClassifyStats()
-        capi.call("thx_classify_get_stats", self._h, C.byref(st), 1 if reset else 0)
-        return st
-
-    def view(self):
-        v = ClassifyView()
-        capi.call("thx_classify_get_view", self._h, C.byref(v))
-        return v
-
-    def fetch(self, dev_ptr, dtype, shape):
-        """host copy of one of view()'s device arrays"""
-        a = np.empty(shape, dtype)
-        torch.cuda.synchronize()
-        capi.call("thx_memcpy_d2h", a.ctypes.data, int(dev_ptr), a.nbytes)
-        return a
-
-    def close(self):
-        if self._h is not None:
-            capi.call("thx_classify_destroy", self._h)
-            self._h = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass

@@ -362,19 +362,42 @@ def init_images(imgRL, maskRadiusPx, ew=6.0, reduce_stats=None):
 
 # ---------------------------------------------------------------------------------------------
 # particle filter
-def pf_perturb(r, t, wR, wT, k123, s01, pfR, pfT, transS, transQ, seed, call, active=None):
+def pf_ctx(img0=0, symQuat=None):
+    """thx_pf_ctx: img0 = the launch's first image in the Philox numbering, symQuat = DEVICE [nSym][4] (None: C1)"""
+    import ctypes as C
+    c = capi.PfCtx()
+    c.symQuat = ptr(symQuat) if symQuat is not None and symQuat.numel() else None
+    c.nSym = 0 if symQuat is None else int(symQuat.shape[0])
+    c.img0 = int(img0)
+    return C.byref(c)
+
+
+def pf_perturb(r, t, wR, wT, k123, s01, pfR, pfT, transS, transQ, seed, call, active=None, img0=0, symQuat=None):
     """Particle::perturb(pf, PAR_R) + perturb(pf, PAR_T) (src/Particle.cpp:1149-1272) for [n][nR][4] / [n][nT][2] f64"""
     for x, nm in ((r, "r"), (t, "t"), (wR, "wR"), (wT, "wT"), (k123, "k123"), (s01, "s01")):
         _chk(x, _F64, nm)
-    capi.call("thx_pf_perturb_dev", ptr(r), ptr(t), ptr(wR), ptr(wT), ptr(k123), ptr(s01), r.shape[0], r.shape[1],
-              t.shape[1], float(pfR), float(pfT), float(transS), float(transQ), int(seed), int(call), ptr(active), stream_ptr())
+    capi.call("thx_pf_perturb_ex_dev", ptr(r), ptr(t), ptr(wR), ptr(wT), ptr(k123), ptr(s01), r.shape[0], r.shape[1],
+              t.shape[1], float(pfR), float(pfT), float(transS), float(transQ), int(seed), int(call), ptr(active), pf_ctx(img0, symQuat),
+              stream_ptr())
 
 
-def pf_update(r, t, wR, wT, uR, uT, k123, s01, topR, topT, peakFactorR, seed, call, active=None):
+def pf_update(r, t, wR, wT, uR, uT, k123, s01, topR, topT, peakFactorR, seed, call, active=None, img0=0, symQuat=None):
     """setUR/UT, keepHalfHeightPeak, calRank1st, calVari, resample (src/Optimiser.cpp:1410-1475)"""
     _chk(uR, _F32, "uR"); _chk(uT, _F32, "uT")
-    capi.call("thx_pf_update_dev", ptr(r), ptr(t), ptr(wR), ptr(wT), ptr(uR), ptr(uT), ptr(k123), ptr(s01), ptr(topR),
-              ptr(topT), r.shape[0], r.shape[1], t.shape[1], float(peakFactorR), int(seed), int(call), ptr(active), stream_ptr())
+    capi.call("thx_pf_update_ex_dev", ptr(r), ptr(t), ptr(wR), ptr(wT), ptr(uR), ptr(uT), ptr(k123), ptr(s01), ptr(topR),
+              ptr(topT), r.shape[0], r.shape[1], t.shape[1], float(peakFactorR), int(seed), int(call), ptr(active), pf_ctx(img0, symQuat),
+              stream_ptr())
+
+
+def pf_cal_vari(r, t, seed, call, img0=0, symQuat=None):
+    """Particle::calVari(PAR_R) + calVari(PAR_T) on their own (thx_pf_cal_vari_dev): returns k123 [n][3], s01 [n][2]; with a
+    point group r is symmetrised in place"""
+    n = r.shape[0]
+    k = torch.zeros((n, 3), dtype=_F64, device=r.device)
+    s = torch.zeros((n, 2), dtype=_F64, device=r.device)
+    capi.call("thx_pf_cal_vari_dev", ptr(r), ptr(t), ptr(k), ptr(s), n, r.shape[1], t.shape[1], int(seed), int(call),
+              pf_ctx(img0, symQuat), stream_ptr())
+    return k, s
 
 
 def draw_reco(r, t, mReco, seed, call, img0=0):

@@ -73,12 +73,15 @@ class RefineShard:
     def __init__(self, N, nImg, device, rank=0, world=1, pf=2, mLR=125, mLT=9, nPhase=3, mReco=100, seed=1000,
                  batch=10240, pixelSize=1.32, snr=0.01, rL=2, ops=None, oracle_pixel_list=None, nGroup=8, groupSig=True,
                  maskFrac=0.45, particle_filter=True, transS=2.0, data=None, allocate=True, sort_view=False, coreFSC=True,
-                 goldenAverage=True, solventFlatten=True):
+                 goldenAverage=True, solventFlatten=True, K=1, sym=None, scan=None, search="local", map_seed=20240601, nblob=40):
         """data (optional): particles read from files instead of synthesised here -- dict(imgOri complex64 device stack
         [nImg][N][N/2+1] as Optimiser::initImg leaves _imgOri, attr float32 [nImg][7], quat [nImg][4], shift [nImg][2]
         (initial poses, e.g. the .thu columns), gid int32 [nImg] 1-based group ids, ref float32 [N]^3 initial map).
         allocate=False: only the particles are generated (imgOri, attr, poses, initial support points, reference) and
-        handed to the native iteration driver (thunder_amd.native.NativeRefine), which owns every other buffer."""
+        handed to the native iteration driver (thunder_amd.native.NativeRefine), which owns every other buffer.
+        K > 1: K references, every particle a slice of a uniformly drawn class (cls_true); sym: a point-group name, the references
+        carry it; scan = dict(nR, nT, rScan[, mS]): a scanned grid of nR random rotations and nT shifts is drawn and the particles'
+        true poses are grid points (the workload of a global search); search: what the native driver starts with."""
         if ops is None:
             from . import ops as _ops
             ops = _ops
@@ -117,23 +120,52 @@ class RefineShard:
         pos = {(int(i), int(j)): k for k, (i, j) in enumerate(zip(plM["iCol"], plM["iRow"]))}
         e2m = torch.from_numpy(np.asarray([pos[(int(i), int(j))] for i, j in zip(pl["iCol"], pl["iRow"])],
                                           np.int64)).to(device)
-        # ---- reference map and its projector volumes (one per local half) ----
-        self.ref = (torch.from_numpy(synth.blob_map(N)) if data is None else torch.as_tensor(data["ref"])).to(device).contiguous()
+        # ---- reference map(s) and their projector volumes (one per local half) ----
+        self.nK, self.sym, self.search = int(K), sym, search
+        assert K == 1 or (data is None and not allocate), "the Python sequencing harness runs one class; K classes go through NativeRefine"
+        symR = None
+        if sym:
+            from .native import symmetry
+            symR = symmetry(sym)["R"]
+        if data is None:
+            refs = np.stack([synth.blob_map(N, seed=map_seed + 100 * k, nblob=nblob, symR=symR) for k in range(K)])
+            self.refs = torch.from_numpy(refs).to(device).contiguous()
+            self.ref = self.refs[0]
+        else:
+            self.ref = torch.as_tensor(data["ref"]).to(device).contiguous()
+            self.refs = self.ref[None]
         self.plan = ops.RecoPlan(N, N, pf)
         v = self.plan.set_projectee(self.ref)
         self.vols = torch.stack([v] * len(self.halves)).contiguous()
+        vK = [v] + [self.plan.set_projectee(self.refs[k]) for k in range(1, K)]
+        self.scan = None
+        if scan is not None:
+            gq = synth.random_quats(scan["nR"], rng)
+            gt = np.ascontiguousarray(rng.normal(0, 3.0, size=(scan["nT"], 2)))
+            self.scan = dict(scan, quat=gq, shifts=gt)
+            self.scan.setdefault("mS", scan["nR"] * (1 + (len(symR) if symR is not None else 0)))
         # cell-packed copies for the E-step gathers (8x the memory, one contiguous 64-byte read per sample)
         self.use_packed = os.environ.get("THX_PACKED", "1") == "1"
         self.cells = None
         # ---- particles: pose, shift, CTF, noisy image on the pixel list ----
+        self.cls_true = np.zeros(nImg, np.int32)
         if data is None:
-            self.quat = synth.random_quats(nImg, rng)
-            if sort_view:   # shard layout: particles ordered by view direction within each half (see view_order)
+            if self.scan is None:
+                self.quat = synth.random_quats(nImg, rng)
+                self.shift = rng.normal(0, 2.0, size=(nImg, 2))
+            else:
+                self.r_true, t_true = rng.integers(0, self.scan["nR"], nImg), rng.integers(0, self.scan["nT"], nImg)
+                self.quat, self.shift = self.scan["quat"][self.r_true].copy(), self.scan["shifts"][t_true].copy()
+            if K > 1:
+                self.cls_true = rng.integers(0, K, nImg).astype(np.int32)
+            if sort_view:   # shard layout: particles ordered by [class, then] view direction within each half (see view_order)
                 nA = (nImg + 1) // 2 if world == 1 else nImg
                 for lo, hi in ((0, nA), (nA, nImg)):
                     if hi > lo:
-                        self.quat[lo:hi] = self.quat[lo:hi][view_order(self.quat[lo:hi])]
-            self.shift = rng.normal(0, 2.0, size=(nImg, 2))
+                        perm = view_order(self.quat[lo:hi])
+                        perm = perm[np.argsort(self.cls_true[lo:hi][perm], kind="stable")]
+                        self.quat[lo:hi], self.shift[lo:hi] = self.quat[lo:hi][perm], self.shift[lo:hi][perm]
+                        self.cls_true[lo:hi] = self.cls_true[lo:hi][perm]
             self.attr = torch.from_numpy(synth.ctf_params(nImg, rng)).to(device)
         else:
             self.quat = np.ascontiguousarray(np.asarray(data["quat"], np.float64).reshape(nImg, 4))
@@ -180,6 +212,10 @@ class RefineShard:
             b1 = min(nImg, b0 + batch)
             rot = ops.rotmat(torch.from_numpy(self.quat[b0:b1]).to(device))
             sl = ops.project(v, rot, self.iColM, self.iRowM, pf)
+            for k in range(1, K):   # particles of the other classes: slices of their own reference
+                sel = torch.from_numpy(np.nonzero(self.cls_true[b0:b1] == k)[0]).to(device)
+                if sel.numel():
+                    sl[sel] = ops.project(vK[k], rot[sel].contiguous(), self.iColM, self.iRowM, pf)
             ramp = ops.translate(torch.from_numpy(self.shift[b0:b1]).to(device), self.iColM, self.iRowM, N)
             sig = sl * ramp * ops.ctf(self.attr[b0:b1].contiguous(), pixelSize, self.iColM, self.iRowM, N)
             if b0 == 0:
@@ -198,6 +234,7 @@ class RefineShard:
         self.use_pf = particle_filter
         self.wg_per_cu = 2 if particle_filter else 0
         self.pf_seed, self.pf_call = seed + 104729 * rank, 0
+        self.img_id0 = 0      # this rank's first image in the Philox numbering (the native driver: images of the ranks before it)
         if self.use_pf:
             q0 = synth.perturb_quats(self.quat, mLR, 0.02, rng)
             t0 = self.shift[:, None, :] + rng.normal(0, 0.5, size=(nImg, mLT, 2))
@@ -343,10 +380,10 @@ class RefineShard:
                 if self.use_pf:
                     # Particle::perturb, then the phase's support points are the filter's own (src/Optimiser.cpp:1186-1208)
                     sl = slice(b0, b1)
-                    self.pf_call += 1
+                    call = self.iter_count * 1024 + 8 + 2 * p      # thx_refine_iterate's numbering: perturb 8 + 2 p, update 9 + 2 p
                     f = self.pfL if p == 0 else self.pfS
                     ops.pf_perturb(st["r"][sl], st["t"][sl], st["wR"][sl], st["wT"][sl], st["k"][sl], st["s"][sl], f, f,
-                                   self.transS, self.transQ, self.pf_seed, self.pf_call)
+                                   self.transS, self.transQ, self.pf_seed, call, img0=self.img_id0 + b0)
                     rotB = ops.rotmat(st["r"][sl].reshape(-1, 4)).reshape(b1 - b0, self.mLR, 9)
                     tranB, pR, pT = st["t"][sl], st["wR"][sl], st["wT"][sl]
                 else:
@@ -361,9 +398,8 @@ class RefineShard:
                     e1.record()
                     self.expect_ms.append((e0, e1, b1 - b0))
                 if self.use_pf:
-                    self.pf_call += 1
                     ops.pf_update(st["r"][sl], st["t"][sl], st["wR"][sl], st["wT"][sl], r.wR, r.wT, st["k"][sl], st["s"][sl],
-                                  st["topR"][sl], st["topT"][sl], self.peakFactorR, self.pf_seed, self.pf_call)
+                                  st["topR"][sl], st["topT"][sl], self.peakFactorR, self.pf_seed, call + 1, img0=self.img_id0 + b0)
                 if p == self.nPhase - 1:
                     wR[b0 - lo:b1 - lo] = r.wR
                     wT[b0 - lo:b1 - lo] = r.wT
@@ -378,8 +414,8 @@ class RefineShard:
         n, gen = hi - lo, self.gens[vi]
         if self.use_pf:   # the filter has been resampled by thx_pf_update_dev: Particle::rand = a uniform pick
             st = self.pf_state
-            self.pf_call += 1
-            return self.ops.draw_reco(st["r"][lo:hi], st["t"][lo:hi], self.mReco, self.pf_seed, self.pf_call, lo)
+            return self.ops.draw_reco(st["r"][lo:hi], st["t"][lo:hi], self.mReco, self.pf_seed, self.iter_count * 1024 + 1000,
+                                      self.img_id0 + lo)
         rsR = torch.multinomial(wR.clamp_min(1e-30), self.mLR, replacement=True, generator=gen)   # resample
         rsT = torch.multinomial(wT.clamp_min(1e-30), self.mLT, replacement=True, generator=gen)
         uR = torch.randint(0, self.mLR, (n, self.mReco), device=self.dev, generator=gen)          # rand
@@ -425,7 +461,7 @@ class RefineShard:
         ops = self.ops
         coreR = float(np.rint(np.float32(self.maskRadiusPx))) if self.coreFSC else 0.0
         f = ops.compare_hemispheres(ops.fft3d_fw(a), ops.fft3d_fw(b), self.N, self.rU, coreR=coreR, seed=self.pf_seed,
-                                    call_id=0x40000000 + 2 * self.iter_count)
+                                    call_id=0x40000000 + 32 * self.iter_count)
         out = np.zeros(self.N // 2, np.float32)
         out[:self.rU] = f
         return out
@@ -439,12 +475,16 @@ class RefineShard:
         return m
 
     def average_flatten_refresh(self, maps):
-        """compareTwoHemispheres(false, true) (gold-standard averaging inside A_B_AVERAGE_THRES), Optimiser::solventFlatten's
-        spherical mask, Model::refreshProj; maps = {half: MAP-on map} with BOTH halves present"""
+        """compareTwoHemispheres(false, true, AVERAGE_TWO_HEMISPHERE_THRES) (gold-standard averaging inside r = Model::resolutionP(0.95)
+        of this iteration's FSC: MODEL_RESOLUTION_BASE_AVERAGE, src/Model.cpp:616-674), Optimiser::solventFlatten's spherical
+        mask, Model::refreshProj; maps = {half: MAP-on map} with BOTH halves present"""
         ops, N = self.ops, self.N
         if self.goldenAverage:
-            resP = np.float32(np.float32(1.0 / 20.0) * np.float32(N) * np.float32(self.pixelSize))
-            avgR = min(int(np.rint(np.float64(resP))), self.rU)
+            f = self.last_fsc
+            avgR = 1
+            while avgR < self.rU and not (f[avgR] < np.float32(0.95)):     # resP(fsc, 0.95, 1, 1, false), src/Functions/Spectrum.cpp:339-363
+                avgR += 1
+            avgR -= 1
             A, B = ops.fft3d_fw(maps[0]), ops.fft3d_fw(maps[1])
             ops.compare_hemispheres(A, B, N, self.rU, fsc=False, avg_r=avgR)
             maps = {0: ops.fft3d_bw(A, N), 1: ops.fft3d_bw(B, N)}
@@ -481,6 +521,7 @@ class RefineShard:
                 maps[h] = self.reduce_and_first_map(vi)
             a, b = self.groups.exchange_half_maps(maps)
             fsc = self.fsc_of(a, b)
+            self.last_fsc = fsc
             for vi, h in enumerate(self.halves):
                 maps[h] = self.final_map(vi)
             if self.goldenAverage:
@@ -524,8 +565,7 @@ class RefineShard:
             st["r"], st["t"] = self.pf0["r"].clone(), self.pf0["t"].clone()
             st["wR"] = torch.full((n, self.mLR), 1.0 / self.mLR, dtype=torch.float64, device=self.dev)
             st["wT"] = torch.full((n, self.mLT), 1.0 / self.mLT, dtype=torch.float64, device=self.dev)
-            st["k"] = self.ops.pf_acg_stats(st["r"])[2]                       # Particle::load -> calVari
-            st["s"] = st["t"].std(dim=1, unbiased=True).contiguous()
+            st["k"], st["s"] = self.ops.pf_cal_vari(st["r"], st["t"], self.pf_seed, 3, img0=self.img_id0)   # Particle::load -> calVari
             st["topR"] = st["r"][:, 0].contiguous()
             st["topT"] = st["t"][:, 0].contiguous()
             self.pf_call = 0

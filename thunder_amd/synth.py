@@ -5,19 +5,23 @@ the per-particle images themselves are produced on the device by the product's o
 import numpy as np
 
 
-def blob_map(N, seed=20240601, nblob=40):
+def blob_map(N, seed=20240601, nblob=40, symR=None):
     """N^3 float32 map in wrapped-index layout (origin at [0,0,0]): sum of isotropic Gaussians inside 0.3 N,
-    times a soft spherical mask of radius 0.4 N."""
+    times a soft spherical mask of radius 0.4 N.  symR [nSym][9] (column-major rotation matrices of a point group's
+    non-identity elements): every blob is repeated at its symmetry mates, so the map has that point group."""
     rng = np.random.default_rng(seed)
     ax = (np.fft.fftfreq(N) * N).astype(np.float32)
     z, y, x = np.meshgrid(ax, ax, ax, indexing="ij")
     m = np.zeros((N, N, N), np.float32)
+    mats = [np.eye(3)] + ([] if symR is None else [np.asarray(r, np.float64).reshape(3, 3).T for r in symR])
     for _ in range(nblob):
-        c = rng.normal(size=3)
-        c = c / np.linalg.norm(c) * rng.uniform(0, 0.3 * N)
+        c0 = rng.normal(size=3)
+        c0 = c0 / np.linalg.norm(c0) * rng.uniform(0, 0.3 * N)
         s = rng.uniform(1.5, 4.0) * N / 256.0 + 1.0
         a = rng.uniform(0.5, 1.0)
-        m += (a * np.exp(-((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) / (2 * s * s))).astype(np.float32)
+        for R in mats:
+            c = R @ c0
+            m += (a * np.exp(-((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) / (2 * s * s))).astype(np.float32)
     r = np.sqrt(x * x + y * y + z * z)
     edge = 0.05 * N
     mask = np.clip((0.4 * N + edge - r) / edge, 0, 1)
