@@ -496,7 +496,7 @@ def refinement_line(args, dev, rank, world, box, particles, steps, warmup, batch
         # draws of an image that share a rotation; the driver counts the groups its launches processed
         # (thx_insert_groups_total) -- and moves each record through HBM once each way (28 bytes written by k_bin, read by
         # k_acc).  lds_add_frac prices the whole insertion call (plan, k_bin, sort, k_acc) against the chip's measured
-        # ds_add_u64 rate (tools/lds_atomic_bench.hip, recorded in profiles/pmc_traffic.json).
+        # ds_add_u64 rate (tools/probes/lds_atomic_bench.hip, recorded in profiles/pmc_traffic.json).
         groups_per_image = st.insertGroups / max(1, st.insertImages)
         ins_records_per_s = ins_n * groups_per_image * nPxlM / (ins_ms * 1e-3)
         ins_terms_per_s = ins_records_per_s * 24

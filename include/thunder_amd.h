@@ -691,6 +691,9 @@ typedef struct thx_refine_capture {
     double *r0, *t0;           /* [nImg][mLR][4], [nImg][mLT][2]: the support points as thx_pf_scan_support_dev left them */
     double *k0, *s0;           /* [nImg][3], [nImg][2]: their spread (after the scanning phase's minimum) */
     float *Fsym, *Tsym;        /* [local halves][nK]: F / T after prepareTF (normalised, symmetrised), before the Wiener term */
+    /* CTF search: the defocus factors of every phase */
+    float *uD;                 /* [nPhase][nImg][mLD]: the E-step's weights of the defocus factors (Particle::setUD) */
+    double *dP, *dR;           /* [nPhase][nImg][mLD]: the factors after initD / perturb(PAR_D), and after resample(mLD, PAR_D) */
 } thx_refine_capture;
 
 typedef struct thx_refine_stats {

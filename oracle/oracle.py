@@ -845,6 +845,9 @@ class Iteration:
             self.gridT = f64(gt)
             self.ctfS = np.stack([ctf(c["pixelSize"], *self.attr[l], N, self.plS["iCol"], self.plS["iRow"]) for l in range(self.n)])
         self.cls0 = np.zeros(self.n, np.int32) if cls0 is None else i32(cls0)
+        self.mLD = int(c.get("mLD", 0))
+        if self.mLD:   # allocPreCal(.., ctf = true): the pre-calculated rows of the defocus search, :8124-8169
+            self.freqD, self.defD, self.K1, self.K2 = expect_precal(self.attr, N, c["pixelSize"], self.pl["iCol"], self.pl["iRow"])
         self.reset()
 
     # -- helpers ------------------------------------------------------------------------------
@@ -859,6 +862,13 @@ class Iteration:
 
     def call(self, slot):
         return self.iterCount * CALLS_PER_ITER + slot
+
+    def attr_d(self, l, d):
+        """_ctfAttr[l] with defocusU * d, defocusV * d (double products narrowed to RFLOAT, src/Optimiser.cpp:6534-6545,7183-7197)"""
+        a = self.attr[l].copy()
+        a[1] = np.float32(np.float64(a[1]) * d)
+        a[2] = np.float32(np.float64(a[2]) * d)
+        return a
 
     def _anchor(self, l, call, n):
         """anch = _r.row(gsl_rng_uniform_int(engine, _nR)) of calVari (src/Particle.cpp:1030): Philox purpose 13"""
@@ -883,6 +893,9 @@ class Iteration:
                 self.q[l] = self.q0[l]      # (the round trip through the mean frame stays inside calVari's copy on the device)
         self.topR, self.topT = self.q[:, 0].copy(), self.t[:, 0].copy()
         self.cls = self.cls0.copy()
+        self.d = np.ones((self.n, max(1, self.mLD)))
+        self.wD = np.full((self.n, max(1, self.mLD)), 1.0 / max(1, self.mLD))
+        self.sD, self.topD = np.zeros(self.n), np.ones(self.n)
         self.fscReco = np.ones((self.K, self.rU), np.float32)            # Model::initProjReco, src/Model.cpp:1086
 
     def fsc_of_maps(self, mapA, mapB, iterCount, k=0):
@@ -962,8 +975,9 @@ class Iteration:
             self.topR[l], self.topT[l] = ws["topR"], ws["topT"]
             self.wR0[l], self.wT0[l] = ws["wR"], ws["wT"]
 
-    def _expect(self, vi, lo, hi, glob, resolve, out):
+    def _expect(self, vi, lo, hi, glob, resolve, out, ctfs=False):
         c, ph, N, P, pf = self.c, self.ph, self.N, self.P, self.pf
+        mLD = self.mLD
         pl, seed, mLR, mLT = self.pl, c["seed"], c["mLR"], c["mLT"]
         # allocPreCal(mask = true, pixelMajor = false, ctf = false), :8043-8171
         datP = np.ascontiguousarray(self.img[lo:hi].reshape(hi - lo, -1)[:, pl["iPxl"]])
@@ -983,8 +997,17 @@ class Iteration:
                         resolve.k_in[l] = (self.k[l].copy(), self.s[l].copy())
                     q, t, wR, wT = resolve.after_perturb(pi, l, self.q[l], q, t, wR, wT)
                 rot = np.stack([rotate3D(x) for x in q])
-                e = expect_local(self.vols[vi][self.cls[l]], P, pf, N, pl["iCol"], pl["iRow"], datP[l - lo], self.ctfP[l],
-                                 sigRcpP[l - lo], rot, t, nD=1, pC=1.0, pR=wR, pT=wT)
+                if ctfs:
+                    # phase 0: Particle::initD(mLD, ctfRefineS); later: perturb(perturbFactorSCTF, PAR_D) (:1196-1209); then the CTF rows
+                    # of every defocus factor (:1246-1272)
+                    gD = ph.draw_n4(seed, l, callP, 10, np.arange(mLD))[0]
+                    dD, wDD = pf_perturb_d(self.d[l], self.sD[l], c["ctfRefineS"] if p == 0 else c["pfSCTF"], p == 0, gD)
+                    ctfRows = ctf_dsearch(self.freqD, self.defD[l], self.K1[l], self.K2[l], self.attr[l][6], self.attr[l][5], dD)
+                    e = expect_local(self.vols[vi][self.cls[l]], P, pf, N, pl["iCol"], pl["iRow"], datP[l - lo], ctfRows,
+                                     sigRcpP[l - lo], rot, t, nD=mLD, pC=1.0, pR=wR, pT=wT, pD=wDD, cSearch=True)
+                else:
+                    e = expect_local(self.vols[vi][self.cls[l]], P, pf, N, pl["iCol"], pl["iRow"], datP[l - lo], self.ctfP[l],
+                                     sigRcpP[l - lo], rot, t, nD=1, pC=1.0, pR=wR, pT=wT)
                 iA = self._anchor(l, callU, mLR)
                 own = pf_update(q, t, wR, wT, e["wR"], e["wT"], c["peakFactorR"],
                                 ph.shuffle_ranks(seed, l, callU, 2, mLR), ph.draw_u4(seed, l, callU, 3, 0)[0] / mLR,
@@ -992,8 +1015,15 @@ class Iteration:
                                 symQuat=self.symQ, iAnchor=iA)
                 own.update(uR=e["wR"], uT=e["wT"], tPre=t, qIn=q, wRIn=wR, wTIn=wT, li=l, callU=callU, iAnchor=iA,
                            scaleL=float(np.abs(e["logW"]).max()))
+                if ctfs:   # setUD, calRank1st(PAR_D), calVari(PAR_D), resample(mLD, PAR_D), :1424-1470
+                    d2, wD2, sD, topD, srcD = pf_update_d(dD, wDD, e["wD"], ph.shuffle_ranks(seed, l, callU, 11, mLD),
+                                                          ph.draw_u4(seed, l, callU, 12, 0)[0] / mLD)
+                    own.update(uD=e["wD"], dIn=dD, wDIn=wDD, d=d2, wD=wD2, sD=sD, topD=topD, srcD=srcD)
                 if resolve is not None:
                     own = resolve(pi, l, own)
+                if ctfs:
+                    self.d[l], self.wD[l], self.sD[l], self.topD[l] = own["d"], own["wD"], own["sD"], own["topD"]
+                    out["uD"][pi, l], out["dP"][pi, l] = e["wD"], dD
                 self.q[l], self.t[l], self.k[l], self.s[l] = own["q"], own["t"], own["k"], own["s"]
                 self.topR[l], self.topT[l] = own["topR"], own["topT"]
                 out["uR"][pi, l], out["uT"][pi, l] = e["wR"], e["wT"]
@@ -1070,8 +1100,9 @@ class Iteration:
         c, ph, N, P, pf, K = self.c, self.ph, self.N, self.P, self.pf, self.K
         plM = self.plM
         seed, mLR, mLT = c["seed"], c["mLR"], c["mLT"]
-        glob = search == "global"
+        glob, ctfs = search == "global", search == "ctf"
         out = dict(uR=np.zeros((c["nPhase"], self.n, mLR), np.float32), uT=np.zeros((c["nPhase"], self.n, mLT), np.float32),
+                   uD=np.zeros((c["nPhase"], self.n, max(1, self.mLD)), np.float32), dP=np.zeros((c["nPhase"], self.n, max(1, self.mLD))),
                    srcR=np.zeros((c["nPhase"], self.n, mLR), np.int64), srcT=np.zeros((c["nPhase"], self.n, mLT), np.int64),
                    k=np.zeros((c["nPhase"], self.n, 3)), s=np.zeros((c["nPhase"], self.n, 2)))
         if glob:
@@ -1085,7 +1116,7 @@ class Iteration:
             if glob:
                 self._scan(vi, lo, hi, resolve, out)
                 out["r0"], out["t0"], out["k0"], out["s0"] = self.q.copy(), self.t.copy(), self.k.copy(), self.s.copy()
-            self._expect(vi, lo, hi, glob, resolve, out)
+            self._expect(vi, lo, hi, glob, resolve, out, ctfs)
         out["cls"] = self.cls.copy()
         if c["normCorrection"] and self.iterCount != 0 and not glob:
             self._norm_correction(out)
@@ -1097,7 +1128,8 @@ class Iteration:
         for vi, (lo, hi) in enumerate(self.ranges):
             # allReduceSigma (OPTIMISER_SIGMA_RANK1ST, OPTIMISER_SIGMA_WHOLE_FREQUENCY), :6395-6710
             spec = np.stack([sigma_image(self.vols[vi][self.cls[l]], P, pf, N, self.rU, self.rSig, rotate3D(self.topR[l]), self.topT[l],
-                                         self.offset[l], c["pixelSize"], self.attr[l], self.img[l], self.imgOri[l])
+                                         self.offset[l], c["pixelSize"], self.attr_d(l, self.topD[l]) if ctfs else self.attr[l], self.img[l],
+                                         self.imgOri[l])
                              for l in range(lo, hi)])
             acc = sigma_accum(spec, self.gid[lo:hi], c["nGroup"], bool(c["groupSig"]))
             sig, rcp = sigma_final(*acc, np.float32(c["maskRadiusPx"]) * np.float32(c["pixelSize"]), N, c["pixelSize"],
@@ -1107,11 +1139,15 @@ class Iteration:
                 u = ph.draw_u4(seed, l, callD, 7, np.arange(c["mReco"]))
                 iR = np.minimum((u[0] * mLR).astype(np.int64), mLR - 1)
                 iT = np.minimum((u[1] * mLT).astype(np.int64), mLT - 1)
+                iD = np.minimum((u[2] * max(1, self.mLD)).astype(np.int64), max(1, self.mLD) - 1)
                 kc = self.cls[l]
                 for m in range(c["mReco"]):
                     tt = self.t[l, iT[m]] - self.offset[l]
                     src = translate(np.float32(-tt[0]), np.float32(-tt[1]), N, plM["iCol"], plM["iRow"], src=datM[l])
-                    insertP(F[vi][kc], T[vi][kc], P, src, self.ctfM[l], rotate3D(self.q[l, iR[m]]), w, plM["iColPad"], plM["iRowPad"])
+                    cm = self.ctfM[l]
+                    if ctfs:   # CTF(ctf, .., defocusU * d, defocusV * d, ..) of the draw's defocus factor, :7183-7202
+                        cm = ctf(c["pixelSize"], *self.attr_d(l, self.d[l, iD[m]]), N, plM["iCol"], plM["iRow"])
+                    insertP(F[vi][kc], T[vi][kc], P, src, cm, rotate3D(self.q[l, iR[m]]), w, plM["iColPad"], plM["iRowPad"])
             self.sig[vi], self.sigRcp[vi] = sig, rcp
         out["F_raw"], out["T_raw"] = [[x.copy() for x in h] for h in F], [[x.copy() for x in h] for h in T]
         # prepareTF (one rank per half: the all-reduces are the identity), :7268 -> src/Reconstructor.cpp:1056-1091: normalise
@@ -1156,7 +1192,7 @@ class Iteration:
             self.img = self._remask(self.img)
         self.iterCount += 1
         out.update(fsc=fsc_, maps=mapsX, rounds=rounds, sig=self.sig.copy(), offset=self.offset.copy(), topR=self.topR.copy(),
-                   q=self.q.copy(), t=self.t.copy(), vols=[[v for v in h] for h in self.vols], img=self.img)
+                   q=self.q.copy(), t=self.t.copy(), vols=[[v for v in h] for h in self.vols], img=self.img, d=self.d.copy(), topD=self.topD.copy())
         return out
 
 

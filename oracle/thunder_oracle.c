@@ -757,6 +757,37 @@ void orc_fsc(RFLOAT* dst, int nShell, const RFLOAT* A, const RFLOAT* B, int P)
 /* CPU-baseline driver (bench.py cpu_baseline leg): the fixed-work iteration of SURVEY 8(d) for  */
 /* a block of particles, OpenMP over images exactly as HOT LOOP B / HOT LOOP C                   */
 /* (src/Optimiser.cpp:1162, :7038).  Returns nothing; the caller times it.                       */
+/* Reconstructor::insertP (src/Reconstructor.cpp:782-863) with the reference's `omp atomic` adds (src/Image/Volume.cpp:565-712):
+ * what several threads sharing one F / T run (the CPU baseline and its per-op rate) */
+static void insertP_atomic_(RFLOAT* F, RFLOAT* T, int P, const RFLOAT* src, const RFLOAT* ctf, const double* R, RFLOAT w,
+                            const int* iColPad, const int* iRowPad, int nPxl)
+{
+    for (int i = 0; i < nPxl; i++) {
+        int ic = iColPad[i], ir = iRowPad[i];
+        double ox = R[0] * ic + R[3] * ir, oy = R[1] * ic + R[4] * ir, oz = R[2] * ic + R[5] * ir;
+        RFLOAT c = ctf[i];
+        RFLOAT vre = src[2 * i] * c * 1.0f * w, vim = src[2 * i + 1] * c * 1.0f * w;
+        RFLOAT tv = pow2f_(c) * 1.0f * w;
+        RFLOAT x = (RFLOAT)ox, y = (RFLOAT)oy, z = (RFLOAT)oz;
+        if (!(x >= 0)) { x = -x; y = -y; z = -z; vim = -vim; }
+        RFLOAT wt[2][2][2];
+        long x0[3];
+        tri_weights_(wt, x0, x, y, z);
+        for (int kk = 0; kk < 2; kk++)
+            for (int jj = 0; jj < 2; jj++)
+                for (int ii = 0; ii < 2; ii++) {
+                    size_t idx = iFTHalf3_(x0[0] + ii, x0[1] + jj, x0[2] + kk, P);
+                    RFLOAT a = vre * wt[kk][jj][ii], b = vim * wt[kk][jj][ii], t = tv * wt[kk][jj][ii];
+#pragma omp atomic
+                    F[2 * idx] += a;
+#pragma omp atomic
+                    F[2 * idx + 1] += b;
+#pragma omp atomic
+                    T[idx] += t;
+                }
+    }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* nGroups > 1: the threads are dealt to nGroups groups, each with its OWN pair of accumulators F [g][vol][2], T [g][vol]
  * (threads of a group share theirs under `omp atomic`) -- the reference's deployment: several MPI ranks per node, each an
@@ -800,31 +831,7 @@ void orc_baseline_block_groups(const RFLOAT* vol, int P, int pf, int N, const in
             orc_translate_src(transImg, dat + (size_t)l * nPxl * 2, (RFLOAT)(-tr[0]), (RFLOAT)(-tr[1]), N, N, iCol, iRow,
                               nPxl);
             /* insertP with atomic adds (the reference's `omp atomic`) */
-            const double* R = recoRot + ((size_t)l * mReco + m) * 9;
-            for (int i = 0; i < nPxl; i++) {
-                int ic = iColPad[i], ir = iRowPad[i];
-                double ox = R[0] * ic + R[3] * ir, oy = R[1] * ic + R[4] * ir, oz = R[2] * ic + R[5] * ir;
-                RFLOAT c = ctf[(size_t)l * nPxl + i];
-                RFLOAT vre = transImg[2 * i] * c * 1.0f * w, vim = transImg[2 * i + 1] * c * 1.0f * w;
-                RFLOAT tv = pow2f_(c) * 1.0f * w;
-                RFLOAT x = (RFLOAT)ox, y = (RFLOAT)oy, z = (RFLOAT)oz;
-                if (!(x >= 0)) { x = -x; y = -y; z = -z; vim = -vim; }
-                RFLOAT wt[2][2][2];
-                long x0[3];
-                tri_weights_(wt, x0, x, y, z);
-                for (int kk = 0; kk < 2; kk++)
-                    for (int jj = 0; jj < 2; jj++)
-                        for (int ii = 0; ii < 2; ii++) {
-                            size_t idx = iFTHalf3_(x0[0] + ii, x0[1] + jj, x0[2] + kk, P);
-                            RFLOAT a = vre * wt[kk][jj][ii], b = vim * wt[kk][jj][ii], t = tv * wt[kk][jj][ii];
-#pragma omp atomic
-                            F[2 * idx] += a;
-#pragma omp atomic
-                            F[2 * idx + 1] += b;
-#pragma omp atomic
-                            T[idx] += t;
-                        }
-            }
+            insertP_atomic_(F, T, P, transImg, ctf + (size_t)l * nPxl, recoRot + ((size_t)l * mReco + m) * 9, w, iColPad, iRowPad, nPxl);
         }
         free(transImg); free(pR); free(pT); free(wR); free(wT);
     }
@@ -1807,4 +1814,42 @@ void orc_average_halves(RFLOAT* A, RFLOAT* B, int N, int r)
                     A[2 * e + c] = avg; B[2 * e + c] = avg;
                 }
             }
+}
+
+
+/* ========================================================================================== */
+/* Per-op rates of this port on T threads (tools/cpu_port_vs_survey.py: SURVEY 8(d)'s 15 % check */
+/* against SURVEY 3.5's compiled-reference rates).  OpenMP over rotations, one call per rotation */
+/* and thread as the reference's loops make them (src/Optimiser.cpp:758-781, 7038-7232).         */
+/* ========================================================================================== */
+#include <omp.h>
+double orc_bench_project(const RFLOAT* vol, int P, int pf, const double* mats, int nRot, const int* iCol, const int* iRow, int nPxl,
+                         int threads)
+{
+    RFLOAT* buf = (RFLOAT*)malloc((size_t)threads * nPxl * 2 * sizeof(RFLOAT));
+    const double t0 = omp_get_wtime();
+#pragma omp parallel for num_threads(threads) schedule(dynamic)
+    for (int r = 0; r < nRot; r++)
+        orc_project(buf + (size_t)omp_get_thread_num() * nPxl * 2, vol, P, pf, mats + 9 * (size_t)r, iCol, iRow, nPxl);
+    const double dt = omp_get_wtime() - t0;
+    free(buf);
+    return dt;
+}
+double orc_bench_insertP(RFLOAT* F, RFLOAT* T, int P, const RFLOAT* src, const RFLOAT* ctf, const double* mats, int nRot, RFLOAT w,
+                         const int* iColPad, const int* iRowPad, int nPxl, int threads)
+{
+    const double t0 = omp_get_wtime();
+#pragma omp parallel for num_threads(threads) schedule(dynamic)
+    for (int r = 0; r < nRot; r++) insertP_atomic_(F, T, P, src, ctf, mats + 9 * (size_t)r, w, iColPad, iRowPad, nPxl);
+    return omp_get_wtime() - t0;
+}
+double orc_bench_logDataVSPrior(const RFLOAT* dat, const RFLOAT* pri, const RFLOAT* ctf, const RFLOAT* sigRcp, int m, int nCall,
+                                int threads, double* sink)
+{
+    double acc = 0;
+    const double t0 = omp_get_wtime();
+#pragma omp parallel for num_threads(threads) reduction(+ : acc)
+    for (int c = 0; c < nCall; c++) acc += orc_logDataVSPrior(dat, pri, ctf, sigRcp, m);
+    *sink = acc;
+    return omp_get_wtime() - t0;
 }

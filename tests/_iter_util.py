@@ -162,9 +162,12 @@ class Follower:
             self.scan_adopted.append((l, "support (%d on a threshold)" % len(bad)))
             ws = dict(ws, q=r0.copy(), k=cap["k0"][l].copy(), topR=ws["topR"])
         assert np.abs(t0 - ws["t"]).max() <= 1e-12, "image %d: support shifts differ after the scan" % l
-        np.testing.assert_allclose(cap["k0"][l], ws["k"], rtol=2e-3)
+        # calVari of the new support set: mLR draws from a few of the scanned rotations -- many copies of few points, the regime in
+        # which the ACG fixed point is ill-conditioned (tests/test_pf_gpu.py holds it to 5e-2 where the two sides stop in different
+        # rounds); the filter continues from the device's spread
+        np.testing.assert_allclose(cap["k0"][l], ws["k"], rtol=5e-2)
         np.testing.assert_allclose(cap["s0"][l], ws["s"], rtol=1e-10)
-        return ws
+        return dict(ws, k=cap["k0"][l].copy())
 
     def after_perturb(self, p, l, q_in, q, t, wR, wT):
         """Particle::perturb conjugates every perturbation by mean = inferACG(mean, _r) of the cloud as resampling left it:
@@ -182,6 +185,19 @@ class Follower:
         qd, td = self.cap["rP"][p, l], self.cap["tP"][p, l]
         assert np.abs(td - t).max() <= 1e-9, "phase %d image %d: perturbed shifts differ" % (p, l)
         conj = q_in * np.array([1.0, -1, -1, -1])
+        qd_dev = qd
+        if self.symQ is not None:
+            # Particle::perturb ends with symmetrise(&mean) (src/Particle.cpp:1234): every point is replaced by its symmetry mate
+            # nearest the cloud's mean -- and where the mean itself is numerically undetermined (collapsed clouds, below) the device and
+            # the oracle can settle on different mates of the same pose.  COUNTERPART RULE: every device point must be, to 1e-9, one of
+            # the mates of the oracle's point (checked through the perturbation it implies); the comparison below runs on the mate
+            # next to the oracle's point, the oracle continues from the device's own cloud.
+            cands = np.stack([qd] + [synth.quat_mul((g * np.array([1.0, -1, -1, -1]))[None], qd) for g in self.symQ])   # [1 + nSym][n][4]
+            dots = np.einsum("cni,ni->cn", cands, q)
+            best = np.abs(dots).argmax(axis=0)
+            ar = np.arange(len(q))
+            qd = cands[best, ar] * np.sign(dots[best, ar])[:, None]
+            self.n_counterpart = getattr(self, "n_counterpart", 0) + int(np.count_nonzero(best))
         po, pd = synth.quat_mul(q, conj), synth.quat_mul(qd, conj)          # mean * pert * conj(mean), both ways
         # (k1..k3 themselves carry the 2e-6 relative accuracy of the ACG estimate, so the perturbations agree to ~1e-6 |pert|)
         # k1..k3 carry the accuracy of the ACG estimate they come from (cofactor inverse at condition ~1e5: 1e-6 ... 1e-3
@@ -206,7 +222,7 @@ class Follower:
         # priors of the perturbed cloud: Particle::balanceWeight, w_i = 1 / pdfACG(r_i, A) -- A from the same kind of fixed point
         w = np.zeros(len(qd))
         self.O.lib().orc_balance_weight_R(w.ctypes.data_as(C.POINTER(C.c_double)),
-                                          np.ascontiguousarray(qd).ctypes.data_as(C.POINTER(C.c_double)), C.c_int(len(qd)))
+                                          np.ascontiguousarray(qd_dev).ctypes.data_as(C.POINTER(C.c_double)), C.c_int(len(qd)))
         wd, wtd = self.cap["wRP"][p, l], self.cap["wTP"][p, l]
         eR, eT = float(np.abs(wd / w - 1).max()), float(np.abs(wtd / wT - 1).max())
         self.prior_err.append(eR)
@@ -216,7 +232,7 @@ class Follower:
                 "phase %d image %d: rotation priors differ by %.2g with %d distinct incoming points" % (p, l, eR, nd)
             if not (self.degenerate and self.degenerate[-1][:2] == (p, l)):
                 self.degenerate.append((p, l, nd, ang))
-        return qd.copy(), td.copy(), wd.copy(), wtd.copy()
+        return qd_dev.copy(), td.copy(), wd.copy(), wtd.copy()
 
     def __call__(self, p, l, own):
         O, cap, c = self.O, self.cap, self.c
@@ -233,6 +249,21 @@ class Follower:
             assert np.all(err <= bar * np.abs(mine) + 1e-6 * mine.max()), \
                 "phase %d image %d %s: %.3g of the largest weight" % (p, l, name, err.max() / mine.max())
         self.n_checked += 1
+        if "uD" in own:
+            # CTF search: the weights of the defocus factors (Particle::setUD), the factors after initD / perturb(PAR_D) and after
+            # resample(mLD, PAR_D) -- the same tie rule: a resampling that differs must be what the oracle's resampler gives for the
+            # device's weights
+            uD, dP, dR = cap["uD"][p, l], cap["dP"][p, l], cap["dR"][p, l]
+            assert np.abs(dP - own["dIn"]).max() <= 1e-12, "phase %d image %d: perturbed defocus factors differ" % (p, l)
+            err = np.abs(uD.astype(np.float64) - own["uD"])
+            assert np.all(err <= bar * np.abs(own["uD"]) + 1e-6 * own["uD"].max()), "phase %d image %d uD: %.3g of the largest weight" % (p, l, err.max() / own["uD"].max())
+            if np.abs(dR - own["d"]).max() > 1e-12:
+                mLD = len(dR)
+                d2, wD2, sD, topD, srcD = O.pf_update_d(own["dIn"], own["wDIn"], uD, PH.shuffle_ranks(c["seed"], own["li"], own["callU"], 11, mLD),
+                                                        PH.draw_u4(c["seed"], own["li"], own["callU"], 12, 0)[0] / mLD)
+                assert np.abs(dR - d2).max() <= 1e-12, "phase %d image %d: the device's defocus resampling is not what its own weights give" % (p, l)
+                own.update(d=d2, wD=wD2, sD=sD, topD=topD, srcD=srcD)
+                self.adopted.append((p, l, "resample D"))
         # discrete decisions: resampled indices
         srcR = self._match(cap["r"][p, l], own["qPre"])
         srcT = self._match(cap["t"][p, l], own["tPre"])

@@ -778,6 +778,32 @@ def test_expect_local_packed_projector_is_bit_identical(oracle, dev):
         assert torch.equal(getattr(a, k), getattr(b, k)), k
 
 
+def test_expect_local_split_form_is_bit_identical(oracle, dev, knob_env):
+    """THX_EXPECT_SPLIT = m: the near-slab / tail form of the local-search kernel (samples within m voxels of the wave's mean slab
+    are requested one pixel ahead, the rest one at a time) reads the same cells and accumulates in the same order: every weight,
+    the base line and every log-likelihood are bit-identical to the default form -- for clouds that sit inside the slab, straddle
+    it, and lie outside it altogether"""
+    from thunder_amd import ops, synth
+    O = oracle
+    rng = np.random.default_rng(78)
+    N, P, nImg, nR, nT = 64, 128, 6, 125, 9
+    ref, vol, pl = make_case(O, N, rL=2)
+    im = make_images(O, vol, pl, N, nImg, rng)
+    spread = np.array([0.005, 0.02, 0.05, 0.2, 1.0, 0.03])
+    q = np.stack([synth.perturb_quats(im["quat"][l:l + 1], nR, spread[l], rng)[0] for l in range(nImg)])
+    rot = ops.rotmat(T(q.reshape(-1, 4), dev)).reshape(nImg, nR, 9)
+    tr = T(im["shift"][:, None, :] + rng.normal(0, 0.7, size=(nImg, nT, 2)), dev)
+    cells = ops.pack_projector(T(vol, dev)[None].contiguous(), P)
+    args = (P, 2, N, T(pl["iCol"], dev), T(pl["iRow"], dev), T(im["dat"], dev), T(im["ctf"], dev), T(im["sigRcp"], dev), rot, tr)
+    a = ops.expect_local(cells, *args, want_logW=True, packed=True)
+    for m in ("1.5", "6", "1000"):
+        knob_env("THX_EXPECT_SPLIT", m)
+        b = ops.expect_local(cells, *args, want_logW=True, packed=True)
+        for k in ("wR", "wT", "wC", "baseLine", "logW"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), (m, k)
+    knob_env("THX_EXPECT_SPLIT", None)
+
+
 def test_full_size_properties_n512(oracle, dev):
     """BASELINE config (4): 512^3 box (P = 1024, nPxl = 100941; 4.3 GB projector, 34 GB cell-packed, element offsets
     above 2^32).  Slices bit-exact against the oracle, packed == unpacked E-step, insertion mass / linearity, and a

@@ -48,6 +48,9 @@ struct Knobs {
     int expectNSplit;     // THX_EXPECT_NSPLIT = 1..16: pixel splits of the local-search kernel (0 = automatic)
     int expectWgPerCU;    // THX_EXPECT_WG_PER_CU: overrides the occupancy argument of thx_expect_local_dev (-1 = unset)
     bool expectNdSweep;   // THX_EXPECT_ND=sweep: one launch per defocus factor instead of the fused kernel
+    float expectSplit;    // THX_EXPECT_SPLIT=m: the near-slab / tail form of the local-search kernel (samples within m voxels of the cloud's
+                          // mean slab are fetched one pixel ahead); 0 = the one-at-a-time form (default)
+    int expectWgLater;    // THX_EXPECT_WG_LATER: occupancy argument of the local-search kernel for phase indices >= 1 (-1 = as phase 0)
     bool scanSimple;      // THX_SCAN=simple: the rotation-per-thread global-scan kernel for every size (A/B)
     int scanTile;         // THX_SCAN=t42 / t24 / t44: wave tiles of the scan contraction (A/B; default 2 x 2)
     bool insertPlain;     // THX_INSERT_PLAIN=1: plain float-atomic insertion (k_insert)
@@ -154,6 +157,36 @@ __device__ __forceinline__ float2 interp_ft_packed(const float4* __restrict__ ce
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const float4 ab = c[k * 2 + j];   // (i = 0: .x .y), (i = 1: .z .w)
+            const float w0 = vx[0] * vy[j] * vz[k], w1 = vx[1] * vy[j] * vz[k];
+            const thx_v2f a0 = {ab.x, ab.y}, a1 = {ab.z, ab.w}, ww0 = {w0, w0}, ww1 = {w1, w1};
+            acc = acc + a0 * ww0;
+            acc = acc + a1 * ww1;
+        }
+    return make_float2(acc.x, conj ? -acc.y : acc.y);
+}
+
+// interp_ft_packed in two halves for a software-pipelined caller: the cell of a sample (fold included), and the combination of its
+// four 16-byte rows -- the same products and sums in the same order (bit-identical)
+__device__ __forceinline__ const float4* packed_cell(const float4* __restrict__ cells, int P, float x, float y, float z)
+{
+    if (!(x >= 0.0f)) { x *= -1.0f; y *= -1.0f; z *= -1.0f; }
+    const int x0 = (int)floorf(x), y0 = (int)floorf(y), z0 = (int)floorf(z);
+    const long nc = P / 2 + 1;
+    return cells + (((long)(z0 >= 0 ? z0 : z0 + P) * P + (y0 >= 0 ? y0 : y0 + P)) * nc + x0) * 4;
+}
+__device__ __forceinline__ float2 packed_combine(const float4 c[4], float x, float y, float z)
+{
+    bool conj = false;
+    if (!(x >= 0.0f)) { x *= -1.0f; y *= -1.0f; z *= -1.0f; conj = true; }
+    const float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+    const float xd = x - fx, yd = y - fy, zd = z - fz;
+    const float vx[2] = {1.0f - xd, xd}, vy[2] = {1.0f - yd, yd}, vz[2] = {1.0f - zd, zd};
+    thx_v2f acc = {0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const float4 ab = c[k * 2 + j];
             const float w0 = vx[0] * vy[j] * vz[k], w1 = vx[1] * vy[j] * vz[k];
             const thx_v2f a0 = {ab.x, ab.y}, a1 = {ab.z, ab.w}, ww0 = {w0, w0}, ww1 = {w1, w1};
             acc = acc + a0 * ww0;

@@ -33,6 +33,10 @@ static Knobs read_knobs()
     if ((e = getenv("THX_EXPECT_WG_PER_CU"))) v.expectWgPerCU = atoi(e);
     e = getenv("THX_EXPECT_ND");
     v.expectNdSweep = e && e[0] == 's';
+    v.expectSplit = 0.f;
+    if ((e = getenv("THX_EXPECT_SPLIT"))) v.expectSplit = (float)atof(e);
+    v.expectWgLater = -1;
+    if ((e = getenv("THX_EXPECT_WG_LATER"))) v.expectWgLater = atoi(e);
     e = getenv("THX_SCAN");
     v.scanSimple = e && e[0] == 's';
     v.scanTile = e && e[0] == 't' ? atoi(e + 1) : 0;
@@ -292,9 +296,10 @@ struct ExpectLocalArgs {
     float* partC;  // [nImg][nD][nSplit]
     int nRpad;
     const int* active;   // [nImg] or NULL: images with active[img] == 0 are skipped (outputs untouched)
+    float splitM;        // SPLIT form: half-thickness (voxels) of the slab around the wave's mean slice whose samples are fetched ahead
 };
 
-template <int NT, bool PACKED>
+template <int NT, bool PACKED, bool SPLIT = false>
 __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -372,7 +377,76 @@ __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
             }
             __syncthreads();
             // ---- hot loop: lane = rotation, walk this wave's pixel sub-stream ----
-            if (rvalid) {
+            if (SPLIT && PACKED) {
+                // near-slab / tail form: a sample within splitM voxels of the slab around the wave's MEAN slice (the cells the other
+                // rotations of the cloud are touching too: L2 hits once one lane has fetched them) is requested one pixel AHEAD of its
+                // use; a sample of the tail keeps the one-at-a-time path -- it is requested first, so that waiting for it leaves the
+                // look-ahead requests in flight.  Same cells, same arithmetic, same order of accumulation: bit-identical.
+                const float4* cells = reinterpret_cast<const float4*>(vol);
+                float nbx = 0.f, nby = 0.f, nbz = 0.f;
+                {   // the wave's mean slice normal: sum over its rotations of col0 x col1 (R e_z)
+                    float nx = rvalid ? (float)(m1 * m5 - m2 * m4) : 0.f, ny = rvalid ? (float)(m2 * m3 - m0 * m5) : 0.f,
+                          nz = rvalid ? (float)(m0 * m4 - m1 * m3) : 0.f;
+                    nx = wave_sum(nx); ny = wave_sum(ny); nz = wave_sum(nz);
+                    const float nn = sqrtf(nx * nx + ny * ny + nz * nz);
+                    if (nn > 0.f) { nbx = nx / nn; nby = ny / nn; nbz = nz / nn; }
+                }
+                // every iteration issues exactly four "now" loads and four "ahead" loads, unconditionally -- a lane that has nothing to
+                // ask for reads the volume's first cell (one broadcast line per instruction) -- so that the compiler can count them:
+                // waiting for the tail's data is s_waitcnt vmcnt(4), which leaves the look-ahead in flight
+                const float4* dummy = cells;
+                float4 pre[4];
+                float px = 0.f, py = 0.f, pz = 0.f;
+                bool pin = false, pnear = false;
+                auto locate = [&](int e, float& x, float& y, float& z, bool& in, bool& near) {
+                    const double nx = sIc[e], ny = sIr[e];
+                    x = (float)(m0 * nx + m3 * ny);
+                    y = (float)(m1 * nx + m4 * ny);
+                    z = (float)(m2 * nx + m5 * ny);
+                    in = rvalid && coord_in_grid(x, y, z, P);
+                    near = in && fabsf(nbx * x + nby * y + nbz * z) <= a.splitM;
+                };
+                {
+                    if (sub < clen) locate(sub, px, py, pz, pin, pnear);
+                    const float4* c = pnear ? packed_cell(cells, P, px, py, pz) : dummy;
+                    pre[0] = c[0]; pre[1] = c[1]; pre[2] = c[2]; pre[3] = c[3];
+                }
+                for (int e = sub; e < clen; e += nSub) {
+                    const float x = px, y = py, z = pz;
+                    const bool in = pin, near = pnear;
+                    float4 cur[4] = {pre[0], pre[1], pre[2], pre[3]};
+                    float4 far[4];
+                    {   // tail: requested now, BEFORE the look-ahead of the next pixel
+                        const float4* c = (in && !near) ? packed_cell(cells, P, x, y, z) : dummy;
+                        far[0] = c[0]; far[1] = c[1]; far[2] = c[2]; far[3] = c[3];
+                    }
+                    {
+                        pin = false; pnear = false;
+                        if (e + nSub < clen) locate(e + nSub, px, py, pz, pin, pnear);
+                        const float4* c = pnear ? packed_cell(cells, P, px, py, pz) : dummy;
+                        pre[0] = c[0]; pre[1] = c[1]; pre[2] = c[2]; pre[3] = c[3];
+                    }
+                    if (!near) { cur[0] = far[0]; cur[1] = far[1]; cur[2] = far[2]; cur[3] = far[3]; }
+                    float2 q = make_float2(0.f, 0.f);
+                    if (in) q = packed_combine(cur, x, y, z);
+                    if (rvalid) {
+                        accB = fmaf(sB[e], fmaf(q.x, q.x, q.y * q.y), accB);
+                        const float* Ap = sA + e * 2 * NT;
+                        const thx_v2f qx = {q.x, q.x}, qy = {q.y, q.y};
+#pragma unroll
+                        for (int i = 0; i < NT / 2; i++) {
+                            const float2 re = *reinterpret_cast<const float2*>(Ap + 4 * i), ni = *reinterpret_cast<const float2*>(Ap + 4 * i + 2);
+                            accP[i] = __builtin_elementwise_fma(thx_v2f{re.x, re.y}, qx, accP[i]);
+                            accP[i] = __builtin_elementwise_fma(thx_v2f{ni.x, ni.y}, qy, accP[i]);
+                        }
+                        if (NT & 1) {
+                            const float2 A = *reinterpret_cast<const float2*>(Ap + 2 * (NT - 1));
+                            accP[NT / 2].x = fmaf(A.x, q.x, accP[NT / 2].x);
+                            accP[NT / 2].x = fmaf(A.y, q.y, accP[NT / 2].x);
+                        }
+                    }
+                }
+            } else if (rvalid) {
                 for (int e = sub; e < clen; e += nSub) {
                     const double nx = sIc[e], ny = sIr[e];
                     const float x = (float)(m0 * nx + m3 * ny);
@@ -1186,7 +1260,11 @@ static int launch_expect_local(const ExpectLocalArgs& a, hipStream_t st, bool pa
     }
     // (dealing the images of a launch to the XCDs in contiguous runs, so that orientation-sorted neighbours share an L2,
     // was measured with view-ordered particles: no gain -- the reuse between neighbouring images happens in the Infinity Cache)
-    if (packed)
+    if (packed && NT == 9 && knobs().expectSplit > 0.f) {   // A/B: the near-slab / tail form (THX_EXPECT_SPLIT = margin in voxels)
+        ExpectLocalArgs b = a;
+        b.splitM = knobs().expectSplit;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expect_local<NT, true, true>), dim3(a.nSplit, a.nImg, a.nD), dim3(256), lds, st, b);
+    } else if (packed)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expect_local<NT, true>), dim3(a.nSplit, a.nImg, a.nD), dim3(256), lds, st, a);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expect_local<NT, false>), dim3(a.nSplit, a.nImg, a.nD), dim3(256), lds, st, a);
@@ -1377,6 +1455,7 @@ static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, 
     a.ctfP = ctfP; a.sigRcpP = sigRcpP; a.rotMat = rotMat; a.nR = nR; a.trans = trans; a.nT = nT; a.nD = nD;
     a.nSplit = expect_local_nsplit(nImg);
     a.active = active;
+    a.splitM = 0.f;
     a.nRpad = ((nR + 63) / 64) * 64;
     a.partV = reinterpret_cast<float*>(workspace);
     a.partC = a.partV + (size_t)nImg * nD * a.nSplit * nT * a.nRpad;

@@ -30,6 +30,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 namespace thx {
@@ -482,7 +483,9 @@ __device__ __forceinline__ int lower_bound_u32(const unsigned* __restrict__ cum,
 }
 
 // workgroup w owns the segments that START in records [w kAccSpan, (w + 1) kAccSpan) of the sorted order
-__global__ __launch_bounds__(kAccThreads, THX_ACC_WGS) void k_acc(AccArgs q)
+// (HIP's second launch-bound argument is the minimum number of WAVES PER SIMD, not workgroups per CU: THX_ACC_WGS workgroups of
+// kAccThreads threads on a CU's four SIMDs)
+__global__ __launch_bounds__(kAccThreads, THX_ACC_WGS * kAccThreads / 64 / 4) void k_acc(AccArgs q)
 {
     __shared__ long long sRe[kBrickVox], sIm[kBrickVox], sT[kBrickVox];
     __shared__ unsigned sOff[kAccStage], sExc[kAccStage + 1], sWaveTot[kAccThreads / 64];
@@ -614,10 +617,12 @@ __global__ __launch_bounds__(kAccThreads, THX_ACC_WGS) void k_acc(AccArgs q)
 static size_t sort_budget_bytes(size_t oneImageWorst)
 {
     static size_t chosen[64] = {0};
+    static std::mutex mtx;
     size_t b = knobs().insertScratchMB > 0 ? (size_t)knobs().insertScratchMB << 20 : 0;
     if (!b) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        std::lock_guard<std::mutex> lock(mtx);
         if (!chosen[dev]) {
             size_t freeB = 0, totalB = 0;
             if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = (size_t)4 << 30;

@@ -2,6 +2,8 @@
 // symmetrisation.  Reference behaviour: src/Optimiser.cpp:7038-7241 (HOT LOOP C),
 // src/Reconstructor.cpp:407-422,782-863,2455-2476,2676-2690, src/Image/Volume.cpp:340-375,565-712,
 // include/Geometry/Transformation.h:105-131,170-194.  gfx950 only.
+#include <mutex>
+
 #include "thx_common.h"
 #include "thx_insert.h"
 
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void k_insert(InsertArgs a)
 // plain reference form with float atomics.  What this file keeps of it: the insert plan, the session's fixed-point scale
 // (k_insert_bounds / k_insert_scale) and the conversion of the 64-bit accumulators.
 //
-// Measured on MI355X (tools/atomic_bench.hip, tools/lds_atomic_bench.hip): fp32 global atomics retire ~19 G
+// Measured on MI355X (tools/probes/atomic_bench.hip, tools/probes/lds_atomic_bench.hip): fp32 global atomics retire ~19 G
 // *transactions*/s chip-wide (one per XCD per clock), so scattered 4-byte atomics (k_insert) reach 2 % of the HBM roofline;
 // ds_add_f32 retires 0.33 lanes/clk/CU whatever the address pattern, ds_add_u32 6.2, ds_add_u64 4.3.  Hence: accumulate in
 // LDS bricks in FIXED POINT (order-independent integer sums), flush a brick along the volume's contiguous x axis.
@@ -363,8 +365,10 @@ using namespace thx;
 static unsigned long long* group_counter()
 {
     static unsigned long long* ctr[64] = {nullptr};
+    static std::mutex mtx;   // (the insertion entry points are called from several host threads, as the library's other caches are)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mtx);
     if (!ctr[dev]) {
         if (hipMalloc(reinterpret_cast<void**>(&ctr[dev]), sizeof(unsigned long long)) != hipSuccess) return nullptr;
         (void)hipMemset(ctr[dev], 0, sizeof(unsigned long long));
@@ -426,8 +430,13 @@ int thx_insert_accumulate_dev(void* acc, const int* gexp, const float* bounds, d
     hipStream_t st = as_stream(stream);
     int* plan = reinterpret_cast<int*>(scratch(st, 3, (size_t)nImg * plan_stride(mReco) * sizeof(int)));
     THX_REQUIRE(plan, "device scratch allocation failed");
-    hipLaunchKernelGGL(k_insert_plan, dim3(nImg), dim3(128), 5 * (size_t)mReco * sizeof(int), st, plan, rotMat, trans, cls, dfac,
-                       cSearch, mReco);
+    // (5 ints of dynamic LDS per draw: above 64 KB -- mReco > 3 276 -- the launch needs the opt-in limit raised)
+    THX_REQUIRE(mReco <= 8000, "at most 8 000 draws per image (the insertion plan sorts them in 160 KB of LDS)");
+    const size_t planLds = 5 * (size_t)mReco * sizeof(int);
+    if (planLds > 48 * 1024)
+        THX_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_insert_plan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)planLds));
+    hipLaunchKernelGGL(k_insert_plan, dim3(nImg), dim3(128), planLds, st, plan, rotMat, trans, cls, dfac, cSearch, mReco);
+    THX_LAUNCH_CHECK();   // (a plan that did not launch must not reach k_plan_counts / k_bin)
     if (unsigned long long* gc = group_counter())
         hipLaunchKernelGGL(k_plan_groups, dim3((nImg + 255) / 256), dim3(256), 0, st, gc, plan, nImg, plan_stride(mReco));
     const size_t volSize = (size_t)dim * dim * (dim / 2 + 1) * (size_t)(nK > 0 ? nK : 1);

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_initW_floorT(float* __restrict__ W, flo
 
 // Row length of the library-internal complex work grid C: rocFFT's strided passes over a [P][P][P/2+1] grid run at
 // 1.8 TB/s because rows of 257 complex values start on odd 8-byte boundaries; with the rows padded to a multiple of 8
-// elements (64 B) the same transforms take 1.05 ms instead of 1.44 ms at P = 512 (tools/fft_layout_probe.hip).
+// elements (64 B) the same transforms take 1.05 ms instead of 1.44 ms at P = 512 (tools/probes/fft_layout_probe.hip).
 __host__ __device__ __forceinline__ int padded_nc(int P) { return ((P / 2 + 1) + 7) & ~7; }
 
 // correctly rounded a / b from the correctly rounded reciprocal rb = RN(1 / b) (Markstein): q0 = a rb, r = a - q0 b

@@ -499,6 +499,8 @@ int expectation(thx_refine* h, int vi, hipStream_t st)
                                            h->nPxl, nb, st));
                 pDb = h->wDD + (size_t)b0 * nD;
                 ctfRows = h->ctfD;
+                if (pi < c.nPhase && h->cap.dP)
+                    THX_CHECK(hipMemcpyAsync(h->cap.dP + ((size_t)pi * h->nImg + b0) * nD, d, (size_t)nb * nD * sizeof(double), hipMemcpyDeviceToDevice, st));
             }
             THX_RC(thx_rotmat_dev(r, h->rotB, nb * c.mLR, st));
             if (pi < c.nPhase && (h->cap.rP || h->cap.tP || h->cap.wRP || h->cap.wTP)) {
@@ -510,11 +512,12 @@ int expectation(thx_refine* h, int vi, hipStream_t st)
             }
             {
                 Scope ev(h, st, EV_EXPECT, nb);
+                const int wg = (p > 0 && knobs().expectWgLater >= 0) ? knobs().expectWgLater : c.wgPerCU;   // (A/B knob: the clouds of later phases are tighter)
                 if (!ctf)
                     THX_RC(thx_expect_local_packed_dev(cells_of(h, vi, 0), vol_idx(h, b0), h->P, h->pf, h->N, h->iCol, h->iRow, h->nPxl, nb,
                                                        h->datP + (size_t)b0 * h->nPxl * 2, ctfRows, h->sigRcpP + (size_t)b0 * h->nPxl, h->rotB,
                                                        c.mLR, t, c.mLT, 1, nullptr, wR, wT, pDb, h->wC, h->uR, h->uT, h->wD, h->baseL, nullptr,
-                                                       h->wsExpect, c.wgPerCU, act, st));
+                                                       h->wsExpect, wg, act, st));
                 else
                     THX_RC(thx_expect_local_dev(vol_of(h, vi, 0), vol_idx(h, b0), h->P, h->pf, h->N, h->iCol, h->iRow, h->nPxl, nb,
                                                 h->datP + (size_t)b0 * h->nPxl * 2, ctfRows, h->sigRcpP + (size_t)b0 * h->nPxl, h->rotB, c.mLR, t,
@@ -523,9 +526,14 @@ int expectation(thx_refine* h, int vi, hipStream_t st)
             }
             THX_RC(thx_pf_update_ex_dev(r, t, wR, wT, h->uR, h->uT, k, s, h->topR + (size_t)b0 * 4, h->topT + (size_t)b0 * 2, nb, c.mLR,
                                         c.mLT, c.peakFactorR, c.seed, callU, act, &ctx, st));
-            if (ctf)
+            if (ctf) {
+                if (pi < c.nPhase && h->cap.uD)
+                    THX_CHECK(hipMemcpyAsync(h->cap.uD + ((size_t)pi * h->nImg + b0) * nD, h->uD, (size_t)nb * nD * sizeof(float), hipMemcpyDeviceToDevice, st));
                 THX_RC(thx_pf_update_d_ex_dev(h->dD + (size_t)b0 * nD, h->wDD + (size_t)b0 * nD, h->uD, h->sD + b0, h->topD + b0, nb, nD, c.seed,
                                               callU, act, ctx.img0, st));
+                if (pi < c.nPhase && h->cap.dR)
+                    THX_CHECK(hipMemcpyAsync(h->cap.dR + ((size_t)pi * h->nImg + b0) * nD, h->dD + (size_t)b0 * nD, (size_t)nb * nD * sizeof(double), hipMemcpyDeviceToDevice, st));
+            }
             if (pi < c.nPhase) {   // optional trace for the chain-level parity tests
                 const size_t at = (size_t)pi * h->nImg + b0;
                 const thx_refine_capture& cp = h->cap;

@@ -172,6 +172,8 @@ class NativeRefine:
         if sym:
             cap["Fsym"] = z((nV, K, P, P, P // 2 + 1), torch.complex64)
             cap["Tsym"] = z((nV, K, P, P, P // 2 + 1), torch.float32)
+        if c.mLD > 0:
+            cap.update(uD=z((c.nPhase, n, c.mLD), torch.float32), dP=z((c.nPhase, n, c.mLD), torch.float64), dR=z((c.nPhase, n, c.mLD), torch.float64))
         if scan:
             cap.update(scanUC=z((n, K), torch.float32), scanUR=z((n, K, c.nR), torch.float32), scanUT=z((n, K, c.nT), torch.float32),
                        r0=z((n, c.mLR, 4), torch.float64), t0=z((n, c.mLT, 2), torch.float64), k0=z((n, 3), torch.float64),

@@ -8,13 +8,13 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc_traffic
 rm -rf $OUT; mkdir -p $OUT
 [ -x tools/pmc_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/pmc_calib tools/pmc_calib.hip
-[ -x tools/lds_atomic_bench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/lds_atomic_bench tools/lds_atomic_bench.hip
+[ -x tools/lds_atomic_bench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/lds_atomic_bench tools/probes/lds_atomic_bench.hip
 tools/lds_atomic_bench > $OUT/lds_atomic_bench.txt 2>&1
 tools/pmc_calib > $OUT/pmc_calib_unprofiled.txt 2>&1
 # PMC_CMD (optional): the command whose kernels are counted -- default the 1 024-image probe; round 3 counts the bench's own
 # view-ordered 100 k-particle iteration: PMC_CMD="python bench.py --steps 1 --warmup 0 --no-cpu-baseline" THX_PROBE_PARTICLES=20000
 # (THX_PROBE_PARTICLES / 2 = images per launch of the counted kernels, for the per-image figures)
-CMD="${PMC_CMD:-python tools/traffic_probe.py}"
+CMD="${PMC_CMD:-python tools/probes/traffic_probe.py}"
 for pass in fetch:FETCH_SIZE write:WRITE_SIZE l2:"TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum"; do
     name=${pass%%:*}; ctr=${pass#*:}
     rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/cal_$name -o p -- tools/pmc_calib > $OUT/cal_$name.log 2>&1
