@@ -995,6 +995,9 @@ class Iteration:
                 if resolve is not None and hasattr(resolve, "after_perturb"):
                     if hasattr(resolve, "k_in"):
                         resolve.k_in[l] = (self.k[l].copy(), self.s[l].copy())
+                    if self.symQ is not None and hasattr(resolve, "q_pure"):
+                        # (for the checker: the same perturbation before symmetrise(&mean) replaced the points by their mates)
+                        resolve.q_pure = pf_perturb(self.q[l], self.t[l], self.k[l], self.s[l], f, f, c["transS"], c["transQ"], gR, gT)[0]
                     q, t, wR, wT = resolve.after_perturb(pi, l, self.q[l], q, t, wR, wT)
                 rot = np.stack([rotate3D(x) for x in q])
                 if ctfs:
@@ -1096,7 +1099,7 @@ class Iteration:
         res["maps"], res["rounds"], res["keep"] = mapsX, rounds, keep
         return res
 
-    def iterate(self, resolve=None, force_rounds=None, search="local"):
+    def iterate(self, resolve=None, force_rounds=None, search="local", device_FT=None):
         c, ph, N, P, pf, K = self.c, self.ph, self.N, self.P, self.pf, self.K
         plM = self.plM
         seed, mLR, mLT = c["seed"], c["mLR"], c["mLT"]
@@ -1172,6 +1175,27 @@ class Iteration:
         out["F"], out["T"] = F, T
         if force_rounds is not None and not np.array_equal(np.asarray(force_rounds), rec["rounds"]):
             out["forced"] = self._reconstruct_all(F, Tn, np.asarray(force_rounds), bm)
+        if device_FT is not None:
+            # for the checker: the reconstruction stage on the DEVICE's F / T after prepareTF (every stage compared on identical
+            # inputs), for the device's round counts -- and once more with 1e-6 relative noise on those inputs: how far this
+            # volume's balancing loop carries the rounding level of the insertion (thin coverage makes it amplify by 1e4 and more)
+            fr = None if force_rounds is None else np.asarray(force_rounds)
+            rng = np.random.default_rng(20240)
+            Fd = [[np.where(Tn[vi][k].flat[0] > 0, device_FT[0][vi][k], 0).astype(np.complex64) for k in range(K)] for vi in range(2)]
+            Td = [[np.where(Tn[vi][k].flat[0] > 0, device_FT[1][vi][k], 0).astype(np.float32) for k in range(K)] for vi in range(2)]
+            noisy = lambda X, dt: [[(x * (1 + 1e-6 * rng.standard_normal(x.shape))).astype(dt) for x in h] for h in X]
+            Fn_, Tn_ = noisy(Fd, np.complex64), noisy(Td, np.float32)
+            out["onDevice"] = self._reconstruct_all(Fd, Td, fr, bm)
+            state = (self.fscReco.copy(), self.iterCount)
+
+            def with_noise():   # (on demand: the checker asks only where a comparison needs the volume's conditioning)
+                keep = (self.fscReco, self.iterCount)
+                self.fscReco, self.iterCount = state
+                try:
+                    return self._reconstruct_all(Fn_, Tn_, fr, bm)
+                finally:
+                    self.fscReco, self.iterCount = keep
+            out["onDeviceNoise"] = with_noise
         out["mapsFsc"], out["mapsMAP"], fsc_, mapsX, rounds = rec["mapsFsc"], rec["mapsMAP"], rec["fsc"], rec["maps"], rec["rounds"]
         if "avgR" in rec:
             out["avgR"] = rec["avgR"]

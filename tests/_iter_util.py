@@ -100,6 +100,8 @@ class Follower:
         self.symQ = None if not cfg.get("sym") or cfg["sym"]["n"] == 0 else cfg["sym"]["quat"]
         self.n_scan = 0
         self.scan_adopted = []     # (image, what)
+        self.q_pure, self.n_counterpart = None, 0
+        self.scan_collapsed = []   # (image, distinct support points): spread of a collapsed support set taken from the device
         self.n_checked = 0
         self.adopted = []          # (phase, image, what)
         self.degenerate = []       # (phase, image, distinct incoming rotations, size of the difference)
@@ -165,7 +167,17 @@ class Follower:
         # calVari of the new support set: mLR draws from a few of the scanned rotations -- many copies of few points, the regime in
         # which the ACG fixed point is ill-conditioned (tests/test_pf_gpu.py holds it to 5e-2 where the two sides stop in different
         # rounds); the filter continues from the device's spread
-        np.testing.assert_allclose(cap["k0"][l], ws["k"], rtol=5e-2)
+        # rounds); with fewer than `min_distinct` distinct points (or one point holding > 15 % of the copies: the collapsed-cloud
+        # condition of the mean-frame rule below) the 4 x 4 scatter matrix is near singular, its cofactor inverse is rounding noise on
+        # both sides and only the floor max(k, scanMinStdR) is common -- there the spread is required to be finite and at or above
+        # the floor, and is counted.  The filter continues from the device's spread either way.
+        _, mult = np.unique(np.round(ws["q"], 9), axis=0, return_counts=True)
+        if len(mult) < self.min_distinct or mult.max() > 0.15 * len(ws["q"]):
+            assert np.all(np.isfinite(cap["k0"][l])) and np.all(cap["k0"][l] >= self.c["scanMinK"] * (1 - 1e-12)), "image %d: spread after the scan" % l
+            if not np.allclose(cap["k0"][l], ws["k"], rtol=5e-2):
+                self.scan_collapsed.append((l, len(mult)))
+        else:
+            np.testing.assert_allclose(cap["k0"][l], ws["k"], rtol=5e-2, err_msg="image %d, %d distinct support points, largest multiplicity %d" % (l, len(mult), mult.max()))
         np.testing.assert_allclose(cap["s0"][l], ws["s"], rtol=1e-10)
         return dict(ws, k=cap["k0"][l].copy())
 
@@ -187,17 +199,25 @@ class Follower:
         conj = q_in * np.array([1.0, -1, -1, -1])
         qd_dev = qd
         if self.symQ is not None:
-            # Particle::perturb ends with symmetrise(&mean) (src/Particle.cpp:1234): every point is replaced by its symmetry mate
-            # nearest the cloud's mean -- and where the mean itself is numerically undetermined (collapsed clouds, below) the device and
-            # the oracle can settle on different mates of the same pose.  COUNTERPART RULE: every device point must be, to 1e-9, one of
-            # the mates of the oracle's point (checked through the perturbation it implies); the comparison below runs on the mate
-            # next to the oracle's point, the oracle continues from the device's own cloud.
-            cands = np.stack([qd] + [synth.quat_mul((g * np.array([1.0, -1, -1, -1]))[None], qd) for g in self.symQ])   # [1 + nSym][n][4]
-            dots = np.einsum("cni,ni->cn", cands, q)
-            best = np.abs(dots).argmax(axis=0)
-            ar = np.arange(len(q))
-            qd = cands[best, ar] * np.sign(dots[best, ar])[:, None]
-            self.n_counterpart = getattr(self, "n_counterpart", 0) + int(np.count_nonzero(best))
+            # Particle::perturb ends with symmetrise(&mean) (src/Particle.cpp:1234): every perturbed point is replaced by its symmetry
+            # mate nearest the cloud's mean -- and where the mean itself is numerically undetermined (collapsed clouds, below) the device
+            # and the oracle can settle on different mates of the same pose.  COUNTERPART RULE: the comparison is made on the
+            # perturbations BEFORE that step: the oracle's are known (q_pure: the same call without the point group); of the
+            # device's stored point the mate is taken whose rotation from the incoming point has the oracle's angle (a large
+            # heavy-tail perturbation can lie nearer another mate's, so "nearest to the incoming point" would not do) -- the Kabsch fit
+            # below then holds all of them to ONE frame rotation -- and the stored point must be that mate's counterpart next to
+            # the device's mean.  The oracle continues from the device's own cloud.
+            q_sym, q = q, self.q_pure
+            conjs = np.concatenate([[[1.0, 0, 0, 0]], self.symQ * np.array([1.0, -1, -1, -1])])
+            mates = lambda x: np.stack([synth.quat_mul(g[None], x) for g in conjs])                    # [1 + nSym][n][4]
+            assert np.abs(np.abs(np.einsum("cni,ni->cn", mates(q), q_sym)).max(axis=0) - 1).max() <= 1e-9   # (the oracle's own step)
+            cands = mates(qd)
+            po0 = np.abs(synth.quat_mul(q, conj)[:, 0])
+            pd0 = np.abs(np.stack([synth.quat_mul(cd, conj)[:, 0] for cd in cands]))
+            best = np.abs(pd0 - po0[None]).argmin(axis=0)
+            qd = cands[best, np.arange(len(qd))]
+            sg = np.sign(synth.quat_mul(qd, conj)[:, 0] * synth.quat_mul(q, conj)[:, 0])
+            qd = qd * np.where(sg == 0, 1.0, sg)[:, None]
         po, pd = synth.quat_mul(q, conj), synth.quat_mul(qd, conj)          # mean * pert * conj(mean), both ways
         # (k1..k3 themselves carry the 2e-6 relative accuracy of the ACG estimate, so the perturbations agree to ~1e-6 |pert|)
         # k1..k3 carry the accuracy of the ACG estimate they come from (cofactor inverse at condition ~1e5: 1e-6 ... 1e-3
@@ -211,6 +231,25 @@ class Follower:
         ang = float(np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1))) / 2   # angle between the two means (quaternion half-angle)
         nd = len(np.unique(np.round(q_in, 12), axis=0))
         assert resid <= 2e-4, "phase %d image %d: not the same perturbations in another frame (residual %.2g)" % (p, l, resid)
+        if self.symQ is not None:
+            # the device's mean = the frame rotation applied to the oracle's mean; its stored point must have the largest |<., mean>|
+            # among the mates (the reference compares in RFLOAT with a strict >: ties within 1e-6 go either way)
+            A, m = np.zeros(16), np.zeros(4)
+            L = self.O.lib()
+            L.orc_infer_acg(A.ctypes.data_as(C.POINTER(C.c_double)), np.ascontiguousarray(q_in).ctypes.data_as(C.POINTER(C.c_double)), C.c_int(len(q_in)))
+            L.orc_sym4_top_eigvec(m.ctypes.data_as(C.POINTER(C.c_double)), A.ctypes.data_as(C.POINTER(C.c_double)))
+            w_, V_ = np.linalg.eig(R)
+            ax = np.real(V_[:, np.argmin(np.abs(w_ - 1))])
+            sn = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) @ ax
+            th = np.arctan2(sn / 2, (np.trace(R) - 1) / 2)
+            rq = np.concatenate([[np.cos(th / 2)], np.sin(th / 2) * ax])
+            md = synth.quat_mul(rq[None], m[None])[0]
+            dots = np.abs(np.einsum("cni,i->cn", mates(qd_dev), md))
+            short = dots.max(axis=0) - dots[0]
+            self.n_counterpart += int(np.count_nonzero(short > 1e-6))
+            if ang <= self.max_mean_angle:
+                # (md carries the accuracy of the fit: 2e-4)
+                assert short.max() <= 2e-3, "phase %d image %d: a stored point is not the counterpart next to the mean (%.2g)" % (p, l, short.max())
         _, mult = np.unique(np.round(q_in, 12), axis=0, return_counts=True)
         self.mean_angles.append((ang, nd, int(mult.max())))
         if ang > self.max_mean_angle:

@@ -41,6 +41,8 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 // dropped: after a hipDeviceSynchronize the ROCm 7 pool hands released blocks to plain hipMalloc while still reusing
 // them, which corrupted caller buffers in a torch-free process -- tests/cpp/mirror_roundtrip.cpp exercises that.)
 void* scratch(hipStream_t stream, int slot, size_t bytes);
+// page-locked HOST memory with the same lifetime rules (for the few words a call reads back from its stream)
+void* pinned_host(hipStream_t stream, int slot, size_t bytes);
 
 // Environment switches for A/B runs.  Read ONCE, when the library is first used -- never per launch -- and only
 // switches that select between tested code paths.

@@ -61,6 +61,7 @@ const Knobs& knobs() { return g_knobs; }
 struct ScratchBuf { void* p = nullptr; size_t n = 0; };
 static std::mutex g_scratchMtx;
 static std::map<std::tuple<int, hipStream_t, int>, ScratchBuf> g_scratch;
+static std::map<std::tuple<int, hipStream_t, int>, ScratchBuf> g_pinned;
 void release_io_plans(int dev, hipStream_t st);
 void release_next_plans(int dev, hipStream_t st);
 extern "C" void thx_release_reco_plans_(int dev, hipStream_t st);
@@ -75,11 +76,34 @@ int release_stream(hipStream_t stream)
         std::lock_guard<std::mutex> g(g_scratchMtx);
         for (auto it = g_scratch.begin(); it != g_scratch.end();)
             if (std::get<0>(it->first) == dev && std::get<1>(it->first) == stream) { if (it->second.p) (void)hipFree(it->second.p); it = g_scratch.erase(it); } else ++it;
+        for (auto it = g_pinned.begin(); it != g_pinned.end();)
+            if (std::get<0>(it->first) == dev && std::get<1>(it->first) == stream) { if (it->second.p) (void)hipHostFree(it->second.p); it = g_pinned.erase(it); } else ++it;
     }
     release_io_plans(dev, stream);
     release_next_plans(dev, stream);
     thx_release_reco_plans_(dev, stream);
     return 0;
+}
+// page-locked host memory for the few words the host reads back inside a call (grow-only, per (device, stream, slot) like
+// scratch(): a read-back into pageable memory makes hipMemcpyAsync stage and block)
+void* pinned_host(hipStream_t stream, int slot, size_t bytes)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(g_scratchMtx);
+    ScratchBuf& b = g_pinned[std::make_tuple(dev, stream, slot)];
+    if (b.n < bytes) {
+        if (b.p) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipHostFree(b.p);
+        }
+        b.p = nullptr;
+        b.n = 0;
+        const size_t want = bytes < 4096 ? 4096 : bytes;
+        if (hipHostMalloc(&b.p, want) != hipSuccess) { b.p = nullptr; return nullptr; }
+        b.n = want;
+    }
+    return b.p;
 }
 void* scratch(hipStream_t stream, int slot, size_t bytes)
 {

@@ -635,6 +635,12 @@ static size_t sort_budget_bytes(size_t oneImageWorst)
 
 static inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
+// two events for the pipelined chunk loop, destroyed on every way out
+struct EventPair {
+    hipEvent_t e[2] = {nullptr, nullptr};
+    ~EventPair() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+};
+
 int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const int* gexp, long long* accF, long long* accT, int nImg)
 {
     const int nPxl = a.nPxl, mReco = a.mReco, P = a.P, nK = a.nK > 0 ? a.nK : 1;
@@ -642,13 +648,18 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
     const unsigned long long nBrick = (unsigned long long)nBx * nBy * nBz * nK;
     THX_REQUIRE(nBrick < 0x7FFFFFFFull, "volume has too many bricks for 31-bit brick ids");
     THX_REQUIRE(mReco < 4096, "brick-sorted insertion packs a region's record offsets into 20 bits (mReco < 4096)");
-    // the images' group counts decide how many fit a chunk
+    // the images' group counts decide how many fit a chunk: the call's one blocking read-back (page-locked)
     int* gDev = reinterpret_cast<int*>(scratch(st, 13, ((size_t)nImg + 1) * sizeof(int)));
     THX_REQUIRE(gDev, "device scratch allocation failed");
+    // host words of the call: [nImg + 1] group counts, [nImg] groups-before, [2] descriptor counts of the two chunks in flight
+    int* hostWords = reinterpret_cast<int*>(pinned_host(st, 0, ((size_t)2 * nImg + 4) * sizeof(int)));
+    THX_REQUIRE(hostWords, "page-locked host allocation failed");
+    int* gHost = hostWords;
+    unsigned* pre = reinterpret_cast<unsigned*>(hostWords + nImg + 1);
+    unsigned* usedHost = reinterpret_cast<unsigned*>(hostWords + 2 * nImg + 1);
     THX_CHECK(hipMemsetAsync(gDev + nImg, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_plan_counts, dim3((nImg + 255) / 256), dim3(256), 0, st, gDev, plan, nImg, plan_stride(mReco));
-    std::vector<int> gHost(nImg + 1);
-    THX_CHECK(hipMemcpyAsync(gHost.data(), gDev, ((size_t)nImg + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+    THX_CHECK(hipMemcpyAsync(gHost, gDev, ((size_t)nImg + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
     THX_CHECK(hipStreamSynchronize(st));
     const bool slowU = gHost[nImg] > kRampU;
 
@@ -658,17 +669,46 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
     const int nRegion = (nPxl + kBinThreads - 1) / kBinThreads;
     const size_t recPerGroup = (size_t)nRegion * kBinThreads;   // static record span of one group of one image
     const size_t perRec = kRecBytes + kSegBytes / kSegShare + 1;
-    const size_t budget = sort_budget_bytes((size_t)mReco * recPerGroup * perRec + ((size_t)1 << 20));
-    size_t capR64 = (budget - ((size_t)1 << 20)) / perRec;
-    capR64 = std::min(capR64, (size_t)0xFFFF0000u);
+    const size_t budget = sort_budget_bytes(2 * ((size_t)mReco * recPerGroup * perRec + ((size_t)1 << 20)));
+
+    // chunks: as many images as a record buffer holds; every image knows the groups of the chunk's images before it.  All of
+    // them in ONE buffer if they fit; otherwise the scratch is TWO record buffers and chunk c + 1 is binned while the host
+    // waits for the descriptor count of chunk c (the GPU has no idle gap in the loop; measured before: ~100 us per chunk)
+    std::vector<int> chunkEnd;
+    auto make_chunks = [&](unsigned long long cap) {
+        chunkEnd.clear();
+        for (int l0 = 0; l0 < nImg;) {
+            unsigned long long groups = 0;
+            int l1 = l0;
+            while (l1 < nImg && l1 - l0 < 65535) {
+                const unsigned long long g = (unsigned long long)gHost[l1];
+                if (l1 > l0 && (groups + g) * recPerGroup > cap) break;
+                pre[l1] = (unsigned)groups;
+                groups += g;
+                l1++;
+            }
+            chunkEnd.push_back(l1);
+            l0 = l1;
+        }
+    };
+    size_t capR64 = std::min((budget - ((size_t)1 << 20)) / perRec, (size_t)0xFFFF0000u);
+    make_chunks(capR64);
+    const int nSets = chunkEnd.size() > 1 ? 2 : 1;
+    if (nSets == 2) {
+        capR64 /= 2;
+        make_chunks(capR64);
+    }
     const unsigned capR = (unsigned)capR64;
     const unsigned capS = knobs().insertSegCap > 0 ? (unsigned)knobs().insertSegCap : capR / kSegShare + 4096;
     size_t o = 0;
-    const size_t oRecA = o; o += align256((size_t)capR * sizeof(uint4));
-    const size_t oRecB = o; o += align256((size_t)capR * 3 * sizeof(float));
-    const size_t oKeyIn = o; o += align256((size_t)capS * sizeof(unsigned));
+    size_t oRecA[2], oRecB[2], oKeyIn[2], oValIn[2];
+    for (int s = 0; s < nSets; s++) {
+        oRecA[s] = o; o += align256((size_t)capR * sizeof(uint4));
+        oRecB[s] = o; o += align256((size_t)capR * 3 * sizeof(float));
+        oKeyIn[s] = o; o += align256((size_t)capS * sizeof(unsigned));
+        oValIn[s] = o; o += align256((size_t)capS * sizeof(unsigned long long));
+    }
     const size_t oKeyOut = o; o += align256((size_t)capS * sizeof(unsigned));
-    const size_t oValIn = o; o += align256((size_t)capS * sizeof(unsigned long long));
     const size_t oValOut = o; o += align256((size_t)capS * sizeof(unsigned long long));
     const size_t oOff = o; o += align256((size_t)capS * sizeof(unsigned));
     const size_t oCnt = o; o += align256((size_t)capS * sizeof(unsigned));
@@ -677,47 +717,31 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
     const size_t oPre = o; o += align256((size_t)nImg * sizeof(unsigned));
     char* buf = reinterpret_cast<char*>(scratch(st, 12, o));
     THX_REQUIRE(buf, "device scratch allocation failed (brick-sorted insertion records)");
-    unsigned* keyIn = reinterpret_cast<unsigned*>(buf + oKeyIn);
     unsigned* keyOut = reinterpret_cast<unsigned*>(buf + oKeyOut);
-    unsigned long long* valIn = reinterpret_cast<unsigned long long*>(buf + oValIn);
     unsigned long long* valOut = reinterpret_cast<unsigned long long*>(buf + oValOut);
     unsigned* segOff = reinterpret_cast<unsigned*>(buf + oOff);
     unsigned* segCnt = reinterpret_cast<unsigned*>(buf + oCnt);
     unsigned* cum = reinterpret_cast<unsigned*>(buf + oCum);
-    unsigned* ctr = reinterpret_cast<unsigned*>(buf + oCtr);
+    unsigned* ctr = reinterpret_cast<unsigned*>(buf + oCtr);   // [2]
     unsigned* preDev = reinterpret_cast<unsigned*>(buf + oPre);
 
     int keyBits = 1;
     while ((1ull << keyBits) <= nBrick) keyBits++;   // 2^keyBits - 1 > every brick id: holes (all ones) sort last
     size_t tmpSort = 0, tmpScan = 0;
-    THX_CHECK(rocprim::radix_sort_pairs(nullptr, tmpSort, keyIn, keyOut, valIn, valOut, (size_t)capS, 0u, (unsigned)keyBits, st));
+    THX_CHECK(rocprim::radix_sort_pairs(nullptr, tmpSort, reinterpret_cast<unsigned*>(buf + oKeyIn[0]), keyOut,
+                                        reinterpret_cast<unsigned long long*>(buf + oValIn[0]), valOut, (size_t)capS, 0u, (unsigned)keyBits, st));
     THX_CHECK(rocprim::inclusive_scan(nullptr, tmpScan, segCnt, cum + 1, (size_t)capS, rocprim::plus<unsigned>(), st));
     const size_t tmpBytes = std::max(tmpSort, tmpScan);
     void* tmp = scratch(st, 14, tmpBytes);
     THX_REQUIRE(tmp, "device scratch allocation failed (sort workspace)");
+    THX_CHECK(hipMemcpyAsync(preDev, pre, (size_t)nImg * sizeof(unsigned), hipMemcpyHostToDevice, st));   // (page-locked: no wait)
 
-    // chunks: as many images as the record buffer holds; every image knows the groups of the chunk's images before it
-    std::vector<unsigned> pre(nImg);
-    std::vector<int> chunkEnd;
-    for (int l0 = 0; l0 < nImg;) {
-        unsigned long long groups = 0;
-        int l1 = l0;
-        while (l1 < nImg && l1 - l0 < 65535) {
-            const unsigned long long g = (unsigned long long)gHost[l1];
-            if (l1 > l0 && (groups + g) * recPerGroup > (unsigned long long)capR) break;
-            pre[l1] = (unsigned)groups;
-            groups += g;
-            l1++;
-        }
-        chunkEnd.push_back(l1);
-        l0 = l1;
-    }
-    THX_CHECK(hipMemcpyAsync(preDev, pre.data(), (size_t)nImg * sizeof(unsigned), hipMemcpyHostToDevice, st));
-    THX_CHECK(hipStreamSynchronize(st));   // (pre is pageable host memory)
-
-    int l0 = 0;
-    for (int l1 : chunkEnd) {
-        const int nl = l1 - l0;
+    EventPair ev;
+    for (int s = 0; s < nSets; s++) THX_CHECK(hipEventCreateWithFlags(&ev.e[s], hipEventDisableTiming));
+    const int nChunk = (int)chunkEnd.size();
+    // k_bin of chunk ci into record buffer `set`, its descriptor count on the way to the host
+    auto launch_bin = [&](int ci, int set) -> int {
+        const int l0 = ci ? chunkEnd[ci - 1] : 0, nl = chunkEnd[ci] - l0;
         BinArgs b;
         b.a = a;
         b.a.datP += (size_t)l0 * nPxl; b.a.ctfP += (size_t)l0 * nPxl; b.a.w += l0;
@@ -728,10 +752,11 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
         if (b.a.dfac) b.a.dfac += (size_t)l0 * mReco;
         b.plan = plan + (size_t)l0 * plan_stride(mReco);
         b.gexp = gexp; b.groupsBefore = preDev + l0; b.accF = accF; b.accT = accT;
-        b.recA = reinterpret_cast<uint4*>(buf + oRecA); b.recB = reinterpret_cast<float*>(buf + oRecB);
-        b.segKey = keyIn; b.segVal = valIn; b.counter = ctr; b.capS = capS;
+        b.recA = reinterpret_cast<uint4*>(buf + oRecA[set]); b.recB = reinterpret_cast<float*>(buf + oRecB[set]);
+        b.segKey = reinterpret_cast<unsigned*>(buf + oKeyIn[set]); b.segVal = reinterpret_cast<unsigned long long*>(buf + oValIn[set]);
+        b.counter = ctr + set; b.capS = capS;
         b.nBx = nBx; b.nBy = nBy; b.nBz = nBz;
-        THX_CHECK(hipMemsetAsync(ctr, 0, sizeof(unsigned), st));
+        THX_CHECK(hipMemsetAsync(ctr + set, 0, sizeof(unsigned), st));
         if (a.cSearch) {
             if (slowU) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin<true, true>), dim3(nRegion, nl), dim3(kBinThreads), 0, st, b);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin<true, false>), dim3(nRegion, nl), dim3(kBinThreads), 0, st, b);
@@ -739,24 +764,38 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
             if (slowU) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin<false, true>), dim3(nRegion, nl), dim3(kBinThreads), 0, st, b);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bin<false, false>), dim3(nRegion, nl), dim3(kBinThreads), 0, st, b);
         }
-        unsigned used = 0;
-        THX_CHECK(hipMemcpyAsync(&used, ctr, sizeof(used), hipMemcpyDeviceToHost, st));
-        THX_CHECK(hipStreamSynchronize(st));
-        const int nSeg = (int)std::min(used, capS);
+        THX_CHECK(hipMemcpyAsync(usedHost + set, ctr + set, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        THX_CHECK(hipEventRecord(ev.e[set], st));
+        return 0;
+    };
+    // descriptor sort and k_acc of chunk ci (the host needs the descriptor count: rocPRIM takes its sizes from the host)
+    auto launch_acc = [&](int ci, int set) -> int {
+        const int l1 = chunkEnd[ci];
+        THX_CHECK(hipEventSynchronize(ev.e[set]));
+        const int nSeg = (int)std::min(usedHost[set], capS);
         const unsigned long long nRecMax = ((unsigned long long)pre[l1 - 1] + (unsigned long long)gHost[l1 - 1]) * recPerGroup;
-        if (nSeg > 0) {
-            size_t tb = tmpBytes;
-            THX_CHECK(rocprim::radix_sort_pairs(tmp, tb, keyIn, keyOut, valIn, valOut, (size_t)nSeg, 0u, (unsigned)keyBits, st));
-            hipLaunchKernelGGL(k_seg_unpack, dim3((nSeg + 255) / 256), dim3(256), 0, st, segOff, segCnt, cum, valOut, nSeg);
-            tb = tmpBytes;
-            THX_CHECK(rocprim::inclusive_scan(tmp, tb, segCnt, cum + 1, (size_t)nSeg, rocprim::plus<unsigned>(), st));
-            AccArgs q;
-            q.recA = b.recA; q.recB = b.recB; q.segKey = keyOut; q.segOff = segOff; q.segCnt = segCnt; q.cum = cum; q.nSeg = nSeg;
-            q.accF = accF; q.accT = accT; q.P = P; q.nBx = nBx; q.nBy = nBy; q.nBz = nBz;
-            const unsigned nWg = (unsigned)((nRecMax + kAccSpan - 1) / kAccSpan);   // (those beyond the records that exist return at once)
-            hipLaunchKernelGGL(k_acc, dim3(nWg), dim3(kAccThreads), 0, st, q);
-        }
-        l0 = l1;
+        if (nSeg <= 0) return 0;
+        unsigned* keyIn = reinterpret_cast<unsigned*>(buf + oKeyIn[set]);
+        unsigned long long* valIn = reinterpret_cast<unsigned long long*>(buf + oValIn[set]);
+        size_t tb = tmpBytes;
+        THX_CHECK(rocprim::radix_sort_pairs(tmp, tb, keyIn, keyOut, valIn, valOut, (size_t)nSeg, 0u, (unsigned)keyBits, st));
+        hipLaunchKernelGGL(k_seg_unpack, dim3((nSeg + 255) / 256), dim3(256), 0, st, segOff, segCnt, cum, valOut, nSeg);
+        tb = tmpBytes;
+        THX_CHECK(rocprim::inclusive_scan(tmp, tb, segCnt, cum + 1, (size_t)nSeg, rocprim::plus<unsigned>(), st));
+        AccArgs q;
+        q.recA = reinterpret_cast<const uint4*>(buf + oRecA[set]); q.recB = reinterpret_cast<const float*>(buf + oRecB[set]);
+        q.segKey = keyOut; q.segOff = segOff; q.segCnt = segCnt; q.cum = cum; q.nSeg = nSeg;
+        q.accF = accF; q.accT = accT; q.P = P; q.nBx = nBx; q.nBy = nBy; q.nBz = nBz;
+        const unsigned nWg = (unsigned)((nRecMax + kAccSpan - 1) / kAccSpan);   // (those beyond the records that exist return at once)
+        hipLaunchKernelGGL(k_acc, dim3(nWg), dim3(kAccThreads), 0, st, q);
+        return 0;
+    };
+    // stream order: bin(0) bin(1) | sort+acc(0) bin(2) | sort+acc(1) bin(3) ...: buffer c & 1 is binned into again only after
+    // k_acc of chunk c - 2 (same stream), and the host's wait for chunk c's count falls under k_bin of chunk c + 1
+    if (launch_bin(0, 0)) return -1;
+    for (int ci = 0; ci < nChunk; ci++) {
+        if (ci + 1 < nChunk && launch_bin(ci + 1, (ci + 1) & 1)) return -1;
+        if (launch_acc(ci, ci & 1)) return -1;
     }
     THX_LAUNCH_CHECK();
     return 0;

@@ -88,6 +88,36 @@ __device__ __forceinline__ void sym_counterpart(double* q, const double* __restr
 __device__ void cal_vari_R(double* k, double* sq /*LDS [n][4]*/, int n, int lane, const double* __restrict__ symQ, int nSym,
                            unsigned long long seed, unsigned img, unsigned call);
 
+// inverse of a SYMMETRIC 4x4 for inferACG's rounds: the ten distinct cofactors (the other six are the same products summed in
+// another order) times 1 / det -- against inv4's sixteen cofactors and sixteen divisions; differs from it by <= 1 ulp per entry,
+// the level of the wave-ordered sums around it.  A round of the fixed point is a dependent chain of f64 latencies (an
+// image whose cloud has collapsed runs thousands of them while its launch waits): THX_ACG_FAST=0 restores the plain form.
+#ifndef THX_ACG_FAST
+#define THX_ACG_FAST 1
+#endif
+__device__ __forceinline__ void inv4_sym(double* o, const double* m)
+{
+    const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[5], f = m[6], g = m[7], h = m[10], i = m[11], j = m[15];
+    // 2x2 minors of the lower two rows / columns
+    const double hj = h * j - i * i, fj = f * j - g * i, fi = f * i - g * h, ej = e * j - g * g, ei = e * i - g * f, eh = e * h - f * f;
+    const double cj = c * j - d * i, ci = c * i - d * h, cg = c * g - d * f, bj = b * j - d * g, bi = b * i - d * f, bh = b * h - c * f;
+    const double bg = b * g - d * e, bf = b * f - c * e;
+    const double c00 = e * hj - f * fj + g * fi;
+    const double c01 = -(b * hj - f * cj + g * ci);
+    const double c02 = b * fj - e * cj + g * cg;
+    const double c03 = -(b * fi - e * ci + f * cg);
+    const double c11 = a * hj - c * cj + d * ci;
+    const double c12 = -(a * fj - b * cj + d * (c * g - d * f));
+    const double c13 = a * fi - b * ci + c * cg;
+    const double c22 = a * ej - b * bj + d * bg;
+    const double c23 = -(a * ei - b * bi + c * bg);
+    const double c33 = a * eh - b * bh + c * bf;
+    const double rdet = 1.0 / (a * c00 + b * c01 + c * c02 + d * c03);
+    o[0] = c00 * rdet; o[1] = o[4] = c01 * rdet; o[2] = o[8] = c02 * rdet; o[3] = o[12] = c03 * rdet;
+    o[5] = c11 * rdet; o[6] = o[9] = c12 * rdet; o[7] = o[13] = c13 * rdet;
+    o[10] = c22 * rdet; o[11] = o[14] = c23 * rdet; o[15] = c33 * rdet;
+}
+
 // inferACG(dmat44&, const dmat4&), src/Geometry/DirectionalStat.cpp:93-145: fixed point B = 4 sum(x x^T / u) / sum(1 / u),
 // u = x^T A^-1 x, until sum|A - B| <= 1e-3; returns the LAST-BUT-ONE iterate A as the reference does.  Wave-cooperative:
 // lanes stride over the quaternions in LDS, 11 wave sums per round, every lane ends with the same A.
@@ -102,7 +132,11 @@ __device__ void infer_acg(double* A, const double* q /*LDS [n][4]*/, int n, int 
 #pragma unroll
         for (int i = 0; i < 16; i++) A[i] = B[i];
         double Ainv[16];
+#if THX_ACG_FAST
+        inv4_sym(Ainv, A);
+#else
         inv4(Ainv, A, nullptr);
+#endif
         double s[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, nf = 0;
         for (int i = lane; i < n; i += 64) {
             const double* x = q + 4 * i;
@@ -111,7 +145,12 @@ __device__ void infer_acg(double* A, const double* q /*LDS [n][4]*/, int n, int 
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
-                for (int k = j; k < 4; k++) s[e++] += (x[j] * x[k]) / u;
+                for (int k = j; k < 4; k++)
+#if THX_ACG_FAST
+                    s[e++] += (x[j] * x[k]) * ru;
+#else
+                    s[e++] += (x[j] * x[k]) / u;
+#endif
             nf += ru;
         }
 #pragma unroll
