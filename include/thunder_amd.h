@@ -190,10 +190,10 @@ int thx_expect_global_dev(const float* rotP, const float* traP, const float* dat
  * Accumulation is 64-bit fixed point (every voxel term rounded once to the call's quanta, integer atomics): F / T come out
  * bit-identical from run to run -- the reference's `omp atomic` float sums do not.  The brick-sorted form behind it
  * (thx_insert_sort.hip) keeps its sample records in library scratch: THX_INSERT_SCRATCH_MB megabytes per (device, stream),
- * default min(8 GiB, 40 % of the free memory), never less than one image's worst case; requires mReco < 4096.  The call (and
- * thx_insert_accumulate_dev) WAITS on `stream` a few times -- once for the images' group counts, once per chunk of images for
- * the number of segment descriptors to sort -- so it cannot be captured into a graph; work queued on other streams is not
- * affected. */
+ * default min(32 GiB, 40 % of the free memory), never less than one image's worst case; requires mReco < 4096.  The call (and
+ * thx_insert_accumulate_dev) WAITS on the host a few times -- once on `stream` for the images' group counts, once per chunk of
+ * images on an event for the number of segment descriptors to sort (the next chunk is already queued behind it: the GPU does
+ * not idle) -- so it cannot be captured into a graph; work queued on other streams is not affected. */
 int thx_insert_dev(float* F, float* T, double* O, int* counter, int dim, int nK, const float* datP,
                    const float* ctfP, const float* w, const double* rotMat, const double* trans, const double* offS,
                    const int* cls, const thx_ctf_attr* attr, const double* dfac, int cSearch, float pixelSize,

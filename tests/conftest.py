@@ -1,6 +1,12 @@
 import os
 import sys
 
+# The oracle's C loops carry `omp parallel for` and numpy's BLAS keeps a thread pool: on the GPU box (256 hardware threads) every
+# one of the chain tests' ~1e5 small calls would wake a 256-thread team (measured: a chain test 100 s there against 14 s on 8
+# cores).  Capped before anything loads a threading runtime; an explicit setting in the environment wins.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "8")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

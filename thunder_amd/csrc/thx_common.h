@@ -56,7 +56,7 @@ struct Knobs {
     bool scanSimple;      // THX_SCAN=simple: the rotation-per-thread global-scan kernel for every size (A/B)
     int scanTile;         // THX_SCAN=t42 / t24 / t44: wave tiles of the scan contraction (A/B; default 2 x 2)
     bool insertPlain;     // THX_INSERT_PLAIN=1: plain float-atomic insertion (k_insert)
-    long insertScratchMB; // THX_INSERT_SCRATCH_MB: record / descriptor scratch of the brick-sorted insertion (0 = min(8 GiB, 40 % of free))
+    long insertScratchMB; // THX_INSERT_SCRATCH_MB: record / descriptor scratch of the brick-sorted insertion (0 = min(32 GiB, 40 % of free))
     long insertSegCap;    // THX_INSERT_SEG_CAP: descriptor table size, to exercise the table-full path in tests (0 = records / 8)
     bool fftRocfft;       // THX_FFT=rocfft: library transforms in the gridding loop for every size
     bool recoTrace;       // THX_RECO_TRACE: print diffC per balancing round

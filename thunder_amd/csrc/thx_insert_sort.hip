@@ -612,8 +612,10 @@ __global__ __launch_bounds__(kAccThreads, THX_ACC_WGS * kAccThreads / 64 / 4) vo
     }
 }
 
-// scratch the sorted form keeps per device: THX_INSERT_SCRATCH_MB, else chosen on first use as min(8 GiB, 40 % of the free
-// memory); never less than one image's worst case
+// scratch the sorted form keeps per device: THX_INSERT_SCRATCH_MB, else chosen on first use as min(32 GiB, 40 % of the free
+// memory); never less than one image's worst case.  (Every chunk flushes each brick it touched once -- 8 MB of 64-bit atomics per
+// image at 250-image chunks -- so larger chunks are cheaper: insertion stage of 20 000 particles 374 / 335 / 309 / 302 / 297 ms at
+// 4 / 8 / 16 / 32 / 64 GiB, two record buffers each)
 static size_t sort_budget_bytes(size_t oneImageWorst)
 {
     static size_t chosen[64] = {0};
@@ -626,7 +628,7 @@ static size_t sort_budget_bytes(size_t oneImageWorst)
         if (!chosen[dev]) {
             size_t freeB = 0, totalB = 0;
             if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = (size_t)4 << 30;
-            chosen[dev] = std::max(std::min((size_t)8 << 30, (size_t)(0.4 * (double)freeB)), (size_t)64 << 20);
+            chosen[dev] = std::max(std::min((size_t)32 << 30, (size_t)(0.4 * (double)freeB)), (size_t)64 << 20);
         }
         b = chosen[dev];
     }
@@ -669,7 +671,8 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
     const int nRegion = (nPxl + kBinThreads - 1) / kBinThreads;
     const size_t recPerGroup = (size_t)nRegion * kBinThreads;   // static record span of one group of one image
     const size_t perRec = kRecBytes + kSegBytes / kSegShare + 1;
-    const size_t budget = sort_budget_bytes(2 * ((size_t)mReco * recPerGroup * perRec + ((size_t)1 << 20)));
+    const size_t oneImageWorst = (size_t)mReco * recPerGroup * perRec + ((size_t)1 << 20);
+    const size_t budget = sort_budget_bytes(oneImageWorst);
 
     // chunks: as many images as a record buffer holds; every image knows the groups of the chunk's images before it.  All of
     // them in ONE buffer if they fit; otherwise the scratch is TWO record buffers and chunk c + 1 is binned while the host
@@ -693,7 +696,8 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
     };
     size_t capR64 = std::min((budget - ((size_t)1 << 20)) / perRec, (size_t)0xFFFF0000u);
     make_chunks(capR64);
-    const int nSets = chunkEnd.size() > 1 ? 2 : 1;
+    // (two buffers only if each still holds any one image: a job that fills the GPU -- 20 000 x 512^2 -- keeps the one-buffer loop)
+    const int nSets = (chunkEnd.size() > 1 && budget >= 2 * oneImageWorst) ? 2 : 1;
     if (nSets == 2) {
         capR64 /= 2;
         make_chunks(capR64);
@@ -794,8 +798,9 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
     // k_acc of chunk c - 2 (same stream), and the host's wait for chunk c's count falls under k_bin of chunk c + 1
     if (launch_bin(0, 0)) return -1;
     for (int ci = 0; ci < nChunk; ci++) {
-        if (ci + 1 < nChunk && launch_bin(ci + 1, (ci + 1) & 1)) return -1;
-        if (launch_acc(ci, ci & 1)) return -1;
+        if (nSets == 2 && ci + 1 < nChunk && launch_bin(ci + 1, (ci + 1) & 1)) return -1;
+        if (launch_acc(ci, nSets == 2 ? (ci & 1) : 0)) return -1;
+        if (nSets == 1 && ci + 1 < nChunk && launch_bin(ci + 1, 0)) return -1;
     }
     THX_LAUNCH_CHECK();
     return 0;
