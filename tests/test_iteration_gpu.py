@@ -251,7 +251,8 @@ def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, s
             vd = nat.fetch(v.vols, np.complex64, (P, P, P // 2 + 1), offset_elems=(h * K + k) * nv)
             want = O.set_projectee(nat.map(h, k).cpu().numpy(), 2)
             assert _rel(vd, want) <= 2e-6
-            assert _rel(vd, O.set_projectee(ref_["maps"][h][k], 2)) <= max(1e-1 if loose else 5e-3, 10 * sens[h, k])
+            if not loose:    # (the oracle chain's own projector: only where its map was held to the tight bar above)
+                assert _rel(vd, O.set_projectee(ref_["maps"][h][k], 2)) <= max(5e-3, 10 * sens[h, k])
             it.vols[h][k] = want                               # the chain continues from the device's reference ...
     it.fscReco = fsc_dev[:, :rU].astype(np.float32).copy()     # ... and the device's FSC (Model::resetReco)
     # ---- reCentreImg + reMaskImg (not after a global search) ----
