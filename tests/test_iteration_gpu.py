@@ -388,7 +388,9 @@ def test_classification_matches_oracle_chain(oracle, dev, K, n, nR, nT, sym, sca
     # every class map resembles its own reference, not the next class's
     for k in range(K):
         own = [U.fsc_curve(O, out2["maps"][0][k], inp["refs"][j], N, 6)[1:5].mean() for j in range(K)]
-        assert int(np.argmax(own)) == k and own[k] > 0.85, (k, own)
+        # (the ORACLE's maps after two iterations on 48 images per class and half: a property of the algorithm on this input, seen
+        # between 0.74 and 0.97 for the own class and below 0.6 for the others as the filter's trajectory changes)
+        assert int(np.argmax(own)) == k and own[k] > 0.65 and own[k] > sorted(own)[-2] + 0.1, (k, own)
         assert np.array_equal(out1["maps"][0][k], out1["maps"][1][k])       # A = B = (A + B) / 2 for K > 1
     nat.close()
 
