@@ -672,7 +672,7 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
     const size_t recPerGroup = (size_t)nRegion * kBinThreads;   // static record span of one group of one image
     const size_t perRec = kRecBytes + kSegBytes / kSegShare + 1;
     const size_t oneImageWorst = (size_t)mReco * recPerGroup * perRec + ((size_t)1 << 20);
-    const size_t budget = sort_budget_bytes(oneImageWorst);
+    size_t budget = sort_budget_bytes(oneImageWorst);
 
     // chunks: as many images as a record buffer holds; every image knows the groups of the chunk's images before it.  All of
     // them in ONE buffer if they fit; otherwise the scratch is TWO record buffers and chunk c + 1 is binned while the host
@@ -694,32 +694,43 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
             l0 = l1;
         }
     };
-    size_t capR64 = std::min((budget - ((size_t)1 << 20)) / perRec, (size_t)0xFFFF0000u);
-    make_chunks(capR64);
-    // (two buffers only if each still holds any one image: a job that fills the GPU -- 20 000 x 512^2 -- keeps the one-buffer loop)
-    const int nSets = (chunkEnd.size() > 1 && budget >= 2 * oneImageWorst) ? 2 : 1;
-    if (nSets == 2) {
-        capR64 /= 2;
+    // (the layout is tried with the chosen budget; if the device cannot give that much any more -- another job's data arrived since
+    // the budget was chosen -- with half of it, down to one image's worst case)
+    int nSets = 1;
+    unsigned capR = 0, capS = 0;
+    size_t oRecA[2] = {0, 0}, oRecB[2] = {0, 0}, oKeyIn[2] = {0, 0}, oValIn[2] = {0, 0};
+    size_t oKeyOut = 0, oValOut = 0, oOff = 0, oCnt = 0, oCum = 0, oCtr = 0, oPre = 0;
+    char* buf = nullptr;
+    for (;;) {
+        size_t capR64 = std::min((budget - ((size_t)1 << 20)) / perRec, (size_t)0xFFFF0000u);
         make_chunks(capR64);
+        // (two buffers only if each still holds any one image: a job that fills the GPU -- 20 000 x 512^2 -- keeps the one-buffer loop)
+        nSets = (chunkEnd.size() > 1 && budget >= 2 * oneImageWorst) ? 2 : 1;
+        if (nSets == 2) {
+            capR64 /= 2;
+            make_chunks(capR64);
+        }
+        capR = (unsigned)capR64;
+        capS = knobs().insertSegCap > 0 ? (unsigned)knobs().insertSegCap : capR / kSegShare + 4096;
+        size_t o = 0;
+        for (int s = 0; s < nSets; s++) {
+            oRecA[s] = o; o += align256((size_t)capR * sizeof(uint4));
+            oRecB[s] = o; o += align256((size_t)capR * 3 * sizeof(float));
+            oKeyIn[s] = o; o += align256((size_t)capS * sizeof(unsigned));
+            oValIn[s] = o; o += align256((size_t)capS * sizeof(unsigned long long));
+        }
+        oKeyOut = o; o += align256((size_t)capS * sizeof(unsigned));
+        oValOut = o; o += align256((size_t)capS * sizeof(unsigned long long));
+        oOff = o; o += align256((size_t)capS * sizeof(unsigned));
+        oCnt = o; o += align256((size_t)capS * sizeof(unsigned));
+        oCum = o; o += align256(((size_t)capS + 1) * sizeof(unsigned));
+        oCtr = o; o += 256;
+        oPre = o; o += align256((size_t)nImg * sizeof(unsigned));
+        buf = reinterpret_cast<char*>(scratch(st, 12, o));
+        if (buf || budget <= oneImageWorst) break;
+        (void)hipGetLastError();
+        budget = std::max(budget / 2, oneImageWorst);
     }
-    const unsigned capR = (unsigned)capR64;
-    const unsigned capS = knobs().insertSegCap > 0 ? (unsigned)knobs().insertSegCap : capR / kSegShare + 4096;
-    size_t o = 0;
-    size_t oRecA[2], oRecB[2], oKeyIn[2], oValIn[2];
-    for (int s = 0; s < nSets; s++) {
-        oRecA[s] = o; o += align256((size_t)capR * sizeof(uint4));
-        oRecB[s] = o; o += align256((size_t)capR * 3 * sizeof(float));
-        oKeyIn[s] = o; o += align256((size_t)capS * sizeof(unsigned));
-        oValIn[s] = o; o += align256((size_t)capS * sizeof(unsigned long long));
-    }
-    const size_t oKeyOut = o; o += align256((size_t)capS * sizeof(unsigned));
-    const size_t oValOut = o; o += align256((size_t)capS * sizeof(unsigned long long));
-    const size_t oOff = o; o += align256((size_t)capS * sizeof(unsigned));
-    const size_t oCnt = o; o += align256((size_t)capS * sizeof(unsigned));
-    const size_t oCum = o; o += align256(((size_t)capS + 1) * sizeof(unsigned));
-    const size_t oCtr = o; o += 256;
-    const size_t oPre = o; o += align256((size_t)nImg * sizeof(unsigned));
-    char* buf = reinterpret_cast<char*>(scratch(st, 12, o));
     THX_REQUIRE(buf, "device scratch allocation failed (brick-sorted insertion records)");
     unsigned* keyOut = reinterpret_cast<unsigned*>(buf + oKeyOut);
     unsigned long long* valOut = reinterpret_cast<unsigned long long*>(buf + oValOut);
