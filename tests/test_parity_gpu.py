@@ -912,13 +912,17 @@ def test_hand_fft_passes_match_rocfft(dev, knob_env, N):
     F = (vol * Tt).contiguous()
     fscv = np.clip(np.linspace(1.0, 0.1, N // 2), 0, 1).astype(np.float32)
     out = {}
-    for mode in ("rocfft", "hand"):
+    for mode in ("rocfft", "hand", "hand_natural"):
         knob_env("THX_FFT", "rocfft" if mode == "rocfft" else None)
+        knob_env("THX_RECO_WT", "natural" if mode == "hand_natural" else None)
         m = plan.reconstruct(F.clone(), Tt.clone(), N // 2 - 2, FSC=fscv, MAP=True, gridCorr=True)
         out[mode] = (m, plan.last_iters, plan.last_diffC)
     (ma, ia, da), (mb, ib, db) = out["rocfft"], out["hand"]
     assert ia == ib and abs(da - db) <= 1e-3 * max(1.0, da), (ia, ib, da, db)
     assert (ma - mb).abs().max().item() <= 1e-4 * ma.abs().max().item()
+    # W / T tiled by z column for the loop (the default) or in the volume's layout: the same arithmetic, bit for bit
+    mc, ic, dc = out["hand_natural"]
+    assert ic == ib and dc == db and torch.equal(mc, mb)
     plan.close()
 
 

@@ -43,6 +43,10 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 void* scratch(hipStream_t stream, int slot, size_t bytes);
 // page-locked HOST memory with the same lifetime rules (for the few words a call reads back from its stream)
 void* pinned_host(hipStream_t stream, int slot, size_t bytes);
+// bytes the (stream, slot) scratch buffer currently holds (0: none)
+size_t scratch_size(hipStream_t stream, int slot);
+// gives the (stream, slot) buffer back to the device (after the stream's queued work)
+void scratch_release(hipStream_t stream, int slot);
 
 // Environment switches for A/B runs.  Read ONCE, when the library is first used -- never per launch -- and only
 // switches that select between tested code paths.
@@ -60,6 +64,7 @@ struct Knobs {
     long insertSegCap;    // THX_INSERT_SEG_CAP: descriptor table size, to exercise the table-full path in tests (0 = records / 8)
     bool fftRocfft;       // THX_FFT=rocfft: library transforms in the gridding loop for every size
     bool recoTrace;       // THX_RECO_TRACE: print diffC per balancing round
+    bool recoNatural;     // THX_RECO_WT=natural: W / T of the hand-written gridding loop in the volume's own layout (A/B; default: tiled by z column)
     bool commForce;       // THX_COMM_FORCE=1: issue the RCCL calls on one-rank communicators too (1-GPU test of the path)
 };
 const Knobs& knobs();

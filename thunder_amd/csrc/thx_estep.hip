@@ -49,6 +49,7 @@ static Knobs read_knobs()
     e = getenv("THX_FFT");
     v.fftRocfft = e && e[0] == 'r';
     v.recoTrace = getenv("THX_RECO_TRACE") != nullptr;
+    { const char* w = getenv("THX_RECO_WT"); v.recoNatural = w && w[0] == 'n'; }
     e = getenv("THX_COMM_FORCE");
     v.commForce = e && e[0] == '1';
     return v;
@@ -104,6 +105,25 @@ void* pinned_host(hipStream_t stream, int slot, size_t bytes)
         b.n = want;
     }
     return b.p;
+}
+void scratch_release(hipStream_t stream, int slot)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(g_scratchMtx);
+    auto it = g_scratch.find(std::make_tuple(dev, stream, slot));
+    if (it == g_scratch.end()) return;
+    (void)hipStreamSynchronize(stream);
+    if (it->second.p) (void)hipFree(it->second.p);
+    g_scratch.erase(it);
+}
+size_t scratch_size(hipStream_t stream, int slot)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(g_scratchMtx);
+    auto it = g_scratch.find(std::make_tuple(dev, stream, slot));
+    return it == g_scratch.end() ? 0 : it->second.n;
 }
 void* scratch(hipStream_t stream, int slot, size_t bytes)
 {

@@ -673,6 +673,16 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
     const size_t perRec = kRecBytes + kSegBytes / kSegShare + 1;
     const size_t oneImageWorst = (size_t)mReco * recPerGroup * perRec + ((size_t)1 << 20);
     size_t budget = sort_budget_bytes(oneImageWorst);
+    {
+        // the budget was chosen at the first call; what the device can give NOW may be less (another job's data has arrived):
+        // never more than what this stream already holds or 40 % of what a new allocation could get
+        size_t freeB = 0, totalB = 0;
+        const size_t held = scratch_size(st, 12);
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+            const size_t can = std::max(held, (size_t)(0.4 * (double)(freeB + held)));
+            budget = std::max(std::min(budget, can), oneImageWorst);
+        }
+    }
 
     // chunks: as many images as a record buffer holds; every image knows the groups of the chunk's images before it.  All of
     // them in ONE buffer if they fit; otherwise the scratch is TWO record buffers and chunk c + 1 is binned while the host
@@ -696,6 +706,10 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
     };
     // (the layout is tried with the chosen budget; if the device cannot give that much any more -- another job's data arrived since
     // the budget was chosen -- with half of it, down to one image's worst case)
+    int keyBits = 1;
+    while ((1ull << keyBits) <= nBrick) keyBits++;   // 2^keyBits - 1 > every brick id: holes (all ones) sort last
+    size_t tmpSort = 0, tmpScan = 0;
+    void* tmp = nullptr;
     int nSets = 1;
     unsigned capR = 0, capS = 0;
     size_t oRecA[2] = {0, 0}, oRecB[2] = {0, 0}, oKeyIn[2] = {0, 0}, oValIn[2] = {0, 0};
@@ -727,7 +741,20 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
         oCtr = o; o += 256;
         oPre = o; o += align256((size_t)nImg * sizeof(unsigned));
         buf = reinterpret_cast<char*>(scratch(st, 12, o));
-        if (buf || budget <= oneImageWorst) break;
+        if (buf) {
+            // the sort's workspace belongs to the same layout: if it does not fit next to the records, the whole layout shrinks
+            tmpSort = 0; tmpScan = 0;
+            THX_CHECK(rocprim::radix_sort_pairs(nullptr, tmpSort, reinterpret_cast<unsigned*>(buf + oKeyIn[0]), reinterpret_cast<unsigned*>(buf + oKeyOut),
+                                                reinterpret_cast<unsigned long long*>(buf + oValIn[0]), reinterpret_cast<unsigned long long*>(buf + oValOut),
+                                                (size_t)capS, 0u, (unsigned)keyBits, st));
+            THX_CHECK(rocprim::inclusive_scan(nullptr, tmpScan, reinterpret_cast<unsigned*>(buf + oCnt), reinterpret_cast<unsigned*>(buf + oCum) + 1, (size_t)capS,
+                                              rocprim::plus<unsigned>(), st));
+            tmp = scratch(st, 14, std::max(tmpSort, tmpScan));
+            if (tmp) break;
+            buf = nullptr;
+            scratch_release(st, 12);   // (grow-only otherwise: the smaller layout must not sit in the buffer that was too large)
+        }
+        if (budget <= oneImageWorst) break;
         (void)hipGetLastError();
         budget = std::max(budget / 2, oneImageWorst);
     }
@@ -740,15 +767,8 @@ int insert_sorted(hipStream_t st, const InsertArgs& a, const int* plan, const in
     unsigned* ctr = reinterpret_cast<unsigned*>(buf + oCtr);   // [2]
     unsigned* preDev = reinterpret_cast<unsigned*>(buf + oPre);
 
-    int keyBits = 1;
-    while ((1ull << keyBits) <= nBrick) keyBits++;   // 2^keyBits - 1 > every brick id: holes (all ones) sort last
-    size_t tmpSort = 0, tmpScan = 0;
-    THX_CHECK(rocprim::radix_sort_pairs(nullptr, tmpSort, reinterpret_cast<unsigned*>(buf + oKeyIn[0]), keyOut,
-                                        reinterpret_cast<unsigned long long*>(buf + oValIn[0]), valOut, (size_t)capS, 0u, (unsigned)keyBits, st));
-    THX_CHECK(rocprim::inclusive_scan(nullptr, tmpScan, segCnt, cum + 1, (size_t)capS, rocprim::plus<unsigned>(), st));
-    const size_t tmpBytes = std::max(tmpSort, tmpScan);
-    void* tmp = scratch(st, 14, tmpBytes);
     THX_REQUIRE(tmp, "device scratch allocation failed (sort workspace)");
+    const size_t tmpBytes = std::max(tmpSort, tmpScan);
     THX_CHECK(hipMemcpyAsync(preDev, pre, (size_t)nImg * sizeof(unsigned), hipMemcpyHostToDevice, st));   // (page-locked: no wait)
 
     EventPair ev;

@@ -484,7 +484,14 @@ static int reco_fill(thx_reco* r, int size, int N, int pf, float a, float alpha)
     r->rs = (float)(1.0 / (double)(1.0f / kTabN));
     THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->tab), (kTabN + 1) * sizeof(float)));
     THX_CHECK(hipMemcpy(r->tab, tab.data(), (kTabN + 1) * sizeof(float), hipMemcpyHostToDevice));
-    THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->W), nHalfF * sizeof(float)));
+    // (the hand-written loop keeps W tiled by z column while it runs: rows padded to a whole number of x tiles)
+    size_t nW = nHalfF;
+    {
+        const int pfP = r->PF, nt8 = pfP / 8, txz = nt8 * 16 <= 1024 ? 16 : (nt8 * 8 <= 1024 ? 8 : 4);
+        const size_t tiled = (size_t)pfP * pfP * (size_t)(((pfP / 2 + 1) + txz - 1) / txz) * txz;
+        if (tiled > nW) nW = tiled;
+    }
+    THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->W), nW * sizeof(float)));
     THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->C), nHalfM * sizeof(float2)));
     THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->rl), (size_t)PM * PM * PM * sizeof(float)));
     THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->diff), sizeof(unsigned)));
@@ -531,9 +538,9 @@ int thx_reco_destroy(thx_reco* r)
 // The same iteration with the hand-written passes of thx_fft8.h (PF = R 8^NS: 64 ... 1024, power-of-two N pf; 2048 stays on rocFFT: untested): per round
 // y inverse -> fused x (inverse, kernel multiply, forward) -> y forward -> fused z (forward, W update + checkC, C = T W,
 // inverse of the next round).  C stays in its padded half-complex grid; the real grid is never materialised.
-template <int NS, int R>
-static int balance_W_hand(thx_reco* r, const float* T, int maxRadius, int maxIter, int minIter, int* itersOut,
-                          float* diffCOut, hipStream_t st)
+template <int NS, int R, bool TILED>
+static int balance_W_hand_t(thx_reco* r, const float* T, int maxRadius, int maxIter, int minIter, int* itersOut,
+                            float* diffCOut, hipStream_t st)
 {
     constexpr int P = f8_n<NS, R>(), NT8 = P / 8, nc = P / 2 + 1;
     constexpr int TXZ = NT8 * 16 <= 1024 ? 16 : (NT8 * 8 <= 1024 ? 8 : 4), TXY = NT8 * 8 <= 1024 ? 8 : 4;
@@ -541,31 +548,46 @@ static int balance_W_hand(thx_reco* r, const float* T, int maxRadius, int maxIte
     const size_t ldsZ = (size_t)(f8_rows<NS, R>() * TXZ + P) * sizeof(float2);
     const size_t ldsY = (size_t)(f8_rows<NS, R>() * TXY + P) * sizeof(float2);
     const size_t ldsX = (size_t)(f8_rows<NS, R>() * 5 + P) * sizeof(float2) + (P / 2 + 1) * sizeof(float);
+    constexpr int nTx = (nc + TXZ - 1) / TXZ;
+    const size_t ldsT = (size_t)16 * nTx * TXZ * sizeof(float);
     static std::once_flag once;
     static hipError_t attrErr = hipSuccess;
     std::call_once(once, [&]() {
-        const void* fn[5] = {reinterpret_cast<const void*>(k_fft_z_update<NS, R, TXZ, true>),
-                             reinterpret_cast<const void*>(k_fft_z_update<NS, R, TXZ, false>),
+        const void* fn[6] = {reinterpret_cast<const void*>(k_fft_z_update<NS, R, TXZ, true, TILED>),
+                             reinterpret_cast<const void*>(k_fft_z_update<NS, R, TXZ, false, TILED>),
                              reinterpret_cast<const void*>(k_fft_strided<NS, R, TXY, 1>),
                              reinterpret_cast<const void*>(k_fft_strided<NS, R, TXY, -1>),
-                             reinterpret_cast<const void*>(k_fft_x_conv<NS, R>)};
-        const size_t sz[5] = {ldsZ, ldsZ, ldsY, ldsY, ldsX};
-        for (int i = 0; i < 5 && attrErr == hipSuccess; i++)
+                             reinterpret_cast<const void*>(k_fft_x_conv<NS, R>),
+                             reinterpret_cast<const void*>(k_tile_real<TXZ>)};
+        const size_t sz[6] = {ldsZ, ldsZ, ldsY, ldsY, ldsX, ldsT};
+        for (int i = 0; i < 6 && attrErr == hipSuccess; i++)
             attrErr = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)sz[i]);
     });
     THX_CHECK(attrErr);
-    const dim3 gZ((nc + TXZ - 1) / TXZ, P), bZ(NT8 * TXZ), gY((nc + TXY - 1) / TXY, P), bY(NT8 * TXY);
+    const dim3 gZ(nTx, P), bZ(NT8 * TXZ), gY((nc + TXY - 1) / TXY, P), bY(NT8 * TXY);
     const int r2i = maxRadius * pf;
     int iters = 0, nNoDec = 0;
     float diffC = 3.402823466e+38f, diffCPrev = 3.402823466e+38f;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, R, TXZ, true>), gZ, bZ, ldsZ, st, r->C, r->W, T, ncp, r2i, r->diff, r->tw);
+    // TILED: W moves into the z pass's layout for the duration of the loop (through the real-space scratch, which the
+    // hand-written loop does not use), T's tiled copy stays in that scratch; W comes back in the volume's layout at the end
+    const size_t nTiled = (size_t)P * P * nTx * TXZ, nNat = (size_t)P * P * nc;
+    float* Wz = r->W;
+    const float* Tz = T;
+    if (TILED) {
+        const dim3 gT(P / 16, P);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_real<TXZ>), gT, dim3(256), ldsT, st, r->rl, r->W, P, nc, nTx, 1);
+        THX_CHECK(hipMemcpyAsync(r->W, r->rl, nTiled * sizeof(float), hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_real<TXZ>), gT, dim3(256), ldsT, st, r->rl, T, P, nc, nTx, 1);
+        Tz = r->rl;
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, R, TXZ, true, TILED>), gZ, bZ, ldsZ, st, r->C, Wz, Tz, ncp, r2i, r->diff, r->tw);
     for (int m = 0; m < maxIter; m++) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_strided<NS, R, TXY, 1>), gY, bY, ldsY, st, r->C, (long)ncp, (long)P * ncp, nc, r->tw);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_x_conv<NS, R>), dim3(P / 2 + 1, P / 2 + 1), dim3(NT8 * 4), ldsX, st, r->C, ncp,
                            r->N * pf, r->tab, kTabN, r->nf, r->rnf, r->rs, r->tw);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_strided<NS, R, TXY, -1>), gY, bY, ldsY, st, r->C, (long)ncp, (long)P * ncp, nc, r->tw);
         THX_CHECK(hipMemsetAsync(r->diff, 0, sizeof(unsigned), st));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, R, TXZ, false>), gZ, bZ, ldsZ, st, r->C, r->W, T, ncp, r2i, r->diff,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, R, TXZ, false, TILED>), gZ, bZ, ldsZ, st, r->C, Wz, Tz, ncp, r2i, r->diff,
                            r->tw);
         unsigned bits = 0;
         THX_CHECK(hipMemcpyAsync(&bits, r->diff, sizeof(unsigned), hipMemcpyDeviceToHost, st));
@@ -577,10 +599,22 @@ static int balance_W_hand(thx_reco* r, const float* T, int maxRadius, int maxIte
         if ((double)diffC > (double)diffCPrev * 0.95) nNoDec += 1; else nNoDec = 0;   // as balance_W below
         if (((double)diffC < 1e-2) || ((m >= minIter) && (nNoDec == 2))) break;
     }
+    if (TILED) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_real<TXZ>), dim3(P / 16, P), dim3(256), ldsT, st, r->rl, r->W, P, nc, nTx, 0);
+        THX_CHECK(hipMemcpyAsync(r->W, r->rl, nNat * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
     THX_LAUNCH_CHECK();
     *itersOut = iters;
     *diffCOut = diffC;
     return 0;
+}
+
+template <int NS, int R>
+static int balance_W_hand(thx_reco* r, const float* T, int maxRadius, int maxIter, int minIter, int* itersOut, float* diffCOut,
+                          hipStream_t st)
+{
+    if (knobs().recoNatural) return balance_W_hand_t<NS, R, false>(r, T, maxRadius, maxIter, minIter, itersOut, diffCOut, st);
+    return balance_W_hand_t<NS, R, true>(r, T, maxRadius, maxIter, minIter, itersOut, diffCOut, st);
 }
 
 extern "C" {

@@ -1,7 +1,7 @@
 """timing aid: one grid-corrected reconstruction (gridding-weight iteration + final transform) on analytic inputs,
 hand-written FFT passes vs THX_FFT=rocfft, for a given box size"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from thunder_amd import ops, synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
@@ -15,11 +15,14 @@ Tt = (1.0 / (1.0 + r / 8.0)).to(torch.float32).contiguous()
 Tt[r >= (N // 2 - 2) * 2 + 1] = 0
 F = (vol * Tt).contiguous()
 del r
-for mode in ("rocfft", "hand"):
-    if mode == "rocfft":
-        os.environ["THX_FFT"] = "rocfft"
-    else:
-        os.environ.pop("THX_FFT", None)
+from thunder_amd import capi
+for mode in ("rocfft", "hand_natural", "hand"):
+    for k, v in (("THX_FFT", "rocfft" if mode == "rocfft" else None), ("THX_RECO_WT", "natural" if mode == "hand_natural" else None)):
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    capi.call("thx_knobs_reload")
     plan.reconstruct(F.clone(), Tt.clone(), N // 2 - 2, MAP=False, gridCorr=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
