@@ -64,6 +64,7 @@ struct Knobs {
     long insertSegCap;    // THX_INSERT_SEG_CAP: descriptor table size, to exercise the table-full path in tests (0 = records / 8)
     bool fftRocfft;       // THX_FFT=rocfft: library transforms in the gridding loop for every size
     bool recoTrace;       // THX_RECO_TRACE: print diffC per balancing round
+    int fftzWaves;        // THX_FFTZ_WAVES = 4 / 8: register budget of the fused z pass of the gridding loop (0 = per size)
     bool recoNatural;     // THX_RECO_WT=natural: W / T of the hand-written gridding loop in the volume's own layout (A/B; default: tiled by z column)
     bool commForce;       // THX_COMM_FORCE=1: issue the RCCL calls on one-rank communicators too (1-GPU test of the path)
 };

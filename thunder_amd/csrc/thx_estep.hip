@@ -49,6 +49,7 @@ static Knobs read_knobs()
     e = getenv("THX_FFT");
     v.fftRocfft = e && e[0] == 'r';
     v.recoTrace = getenv("THX_RECO_TRACE") != nullptr;
+    { const char* w = getenv("THX_FFTZ_WAVES"); v.fftzWaves = w ? atoi(w) : 0; }
     { const char* w = getenv("THX_RECO_WT"); v.recoNatural = w && w[0] == 'n'; }
     e = getenv("THX_COMM_FORCE");
     v.commForce = e && e[0] == '1';

@@ -299,8 +299,11 @@ __global__ __launch_bounds__((f8_n<NS, R>() / 8) * 4) void k_fft_x_conv(float2* 
 // values one workgroup touches are one contiguous run of P TX floats; in the volume's layout they are P segments of TX floats
 // (32 bytes at P = 1024) a whole z plane apart, and such a pass runs at the fabric's REQUEST rate, not at its bandwidth
 // (P = 1024: 335 M requests, 60 % of them for W and T, in 7.9 ms = 43 G/s).
-template <int NS, int R, int TX, bool FIRST, bool TILED>
-__global__ __launch_bounds__((f8_n<NS, R>() / 8) * TX, 8) void k_fft_z_update(float2* __restrict__ C, float* __restrict__ W,
+// WPS: waves per SIMD the register allocation aims at (HIP's second launch-bound argument).  A 1024-thread workgroup is 4 waves per
+// SIMD: 8 lets two of them share a CU but caps the kernel at 64 VGPRs -- the P = 1024 instance then spills 46 dwords per thread
+// to scratch -- 4 gives it 128 VGPRs and one workgroup per CU.
+template <int NS, int R, int TX, bool FIRST, bool TILED, int WPS>
+__global__ __launch_bounds__((f8_n<NS, R>() / 8) * TX, WPS) void k_fft_z_update(float2* __restrict__ C, float* __restrict__ W,
                                                                          const float* __restrict__ T, int ncp, int r2i,
                                                                          unsigned* __restrict__ diffBits,
                                                                          const float2* __restrict__ tw)

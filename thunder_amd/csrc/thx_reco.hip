@@ -538,7 +538,7 @@ int thx_reco_destroy(thx_reco* r)
 // The same iteration with the hand-written passes of thx_fft8.h (PF = R 8^NS: 64 ... 1024, power-of-two N pf; 2048 stays on rocFFT: untested): per round
 // y inverse -> fused x (inverse, kernel multiply, forward) -> y forward -> fused z (forward, W update + checkC, C = T W,
 // inverse of the next round).  C stays in its padded half-complex grid; the real grid is never materialised.
-template <int NS, int R, bool TILED>
+template <int NS, int R, bool TILED, int WPS>
 static int balance_W_hand_t(thx_reco* r, const float* T, int maxRadius, int maxIter, int minIter, int* itersOut,
                             float* diffCOut, hipStream_t st)
 {
@@ -553,8 +553,8 @@ static int balance_W_hand_t(thx_reco* r, const float* T, int maxRadius, int maxI
     static std::once_flag once;
     static hipError_t attrErr = hipSuccess;
     std::call_once(once, [&]() {
-        const void* fn[6] = {reinterpret_cast<const void*>(k_fft_z_update<NS, R, TXZ, true, TILED>),
-                             reinterpret_cast<const void*>(k_fft_z_update<NS, R, TXZ, false, TILED>),
+        const void* fn[6] = {reinterpret_cast<const void*>(k_fft_z_update<NS, R, TXZ, true, TILED, WPS>),
+                             reinterpret_cast<const void*>(k_fft_z_update<NS, R, TXZ, false, TILED, WPS>),
                              reinterpret_cast<const void*>(k_fft_strided<NS, R, TXY, 1>),
                              reinterpret_cast<const void*>(k_fft_strided<NS, R, TXY, -1>),
                              reinterpret_cast<const void*>(k_fft_x_conv<NS, R>),
@@ -580,14 +580,14 @@ static int balance_W_hand_t(thx_reco* r, const float* T, int maxRadius, int maxI
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_real<TXZ>), gT, dim3(256), ldsT, st, r->rl, T, P, nc, nTx, 1);
         Tz = r->rl;
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, R, TXZ, true, TILED>), gZ, bZ, ldsZ, st, r->C, Wz, Tz, ncp, r2i, r->diff, r->tw);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, R, TXZ, true, TILED, WPS>), gZ, bZ, ldsZ, st, r->C, Wz, Tz, ncp, r2i, r->diff, r->tw);
     for (int m = 0; m < maxIter; m++) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_strided<NS, R, TXY, 1>), gY, bY, ldsY, st, r->C, (long)ncp, (long)P * ncp, nc, r->tw);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_x_conv<NS, R>), dim3(P / 2 + 1, P / 2 + 1), dim3(NT8 * 4), ldsX, st, r->C, ncp,
                            r->N * pf, r->tab, kTabN, r->nf, r->rnf, r->rs, r->tw);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_strided<NS, R, TXY, -1>), gY, bY, ldsY, st, r->C, (long)ncp, (long)P * ncp, nc, r->tw);
         THX_CHECK(hipMemsetAsync(r->diff, 0, sizeof(unsigned), st));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, R, TXZ, false, TILED>), gZ, bZ, ldsZ, st, r->C, Wz, Tz, ncp, r2i, r->diff,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, R, TXZ, false, TILED, WPS>), gZ, bZ, ldsZ, st, r->C, Wz, Tz, ncp, r2i, r->diff,
                            r->tw);
         unsigned bits = 0;
         THX_CHECK(hipMemcpyAsync(&bits, r->diff, sizeof(unsigned), hipMemcpyDeviceToHost, st));
@@ -613,8 +613,14 @@ template <int NS, int R>
 static int balance_W_hand(thx_reco* r, const float* T, int maxRadius, int maxIter, int minIter, int* itersOut, float* diffCOut,
                           hipStream_t st)
 {
-    if (knobs().recoNatural) return balance_W_hand_t<NS, R, false>(r, T, maxRadius, maxIter, minIter, itersOut, diffCOut, st);
-    return balance_W_hand_t<NS, R, true>(r, T, maxRadius, maxIter, minIter, itersOut, diffCOut, st);
+    // THX_FFTZ_WAVES = 4 / 8 (A/B); default: 4 for the 1024-point instance (no spills), 8 otherwise
+    const int wps = knobs().fftzWaves > 0 ? knobs().fftzWaves : ((NS == 3 && R == 2) ? 4 : 8);
+    const bool nat = knobs().recoNatural;
+#define THX_BW(tiled, w) return balance_W_hand_t<NS, R, tiled, w>(r, T, maxRadius, maxIter, minIter, itersOut, diffCOut, st)
+    if (wps <= 4) { if (nat) THX_BW(false, 4); THX_BW(true, 4); }
+    if (nat) THX_BW(false, 8);
+    THX_BW(true, 8);
+#undef THX_BW
 }
 
 extern "C" {

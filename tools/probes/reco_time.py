@@ -16,8 +16,9 @@ Tt[r >= (N // 2 - 2) * 2 + 1] = 0
 F = (vol * Tt).contiguous()
 del r
 from thunder_amd import capi
-for mode in ("rocfft", "hand_natural", "hand"):
-    for k, v in (("THX_FFT", "rocfft" if mode == "rocfft" else None), ("THX_RECO_WT", "natural" if mode == "hand_natural" else None)):
+for mode in ("rocfft", "hand_natural", "hand", "hand_waves8", "hand_waves4"):
+    for k, v in (("THX_FFT", "rocfft" if mode == "rocfft" else None), ("THX_RECO_WT", "natural" if mode == "hand_natural" else None),
+                 ("THX_FFTZ_WAVES", {"hand_waves8": "8", "hand_waves4": "4"}.get(mode))):
         if v is None:
             os.environ.pop(k, None)
         else:
