@@ -408,6 +408,56 @@ def cpu_baseline_classification(args, shard, nat, c):
                           n_cpu, nR, nT, cores, per, t_scan, K, n, shard.nPhase, shard.mLR, shard.mLT, shard.mReco, cores, groups, t_em)}
 
 
+def bench_config0(args, dev, small=False):
+    """BASELINE configs[0] as script/demo_3D.json defines the run (K = 4, C4, mS = 10 000 -> nR = 2 500 scanned rotations, nT = 30,
+    mLR 125, mLT 9, mReco 100; a global-search iteration, then a local-search iteration) on 1 000 synthetic 128^3 particles through
+    the native driver: what tests/test_next_gpu.py::test_config0_demo3d_as_specified checks for correctness, timed"""
+    import torch
+    from thunder_amd.native import NativeRefine, STAGES
+    from thunder_amd.refine import RefineShard
+    N, n, K = (32, 200, 4) if small else (128, 1000, 4)
+    scan = dict(nR=200, nT=4, rScan=8, mS=800) if small else dict(nR=2500, nT=30, rScan=12, mS=10000)
+    sh = RefineShard(N, n, dev, snr=0.1, K=K, sym="C4", scan=scan, search="global", allocate=False, nblob=24,
+                     **(dict(mLR=40, mLT=4, mReco=16) if small else {}))
+    sh.balanceClass = 1
+    sh.release_generation_state()
+    nat = NativeRefine(sh)
+    out = {}
+    for timed in (False, True):     # one untimed pass of the two iterations (plans, scratch), then the timed one
+        nat.reset()
+        nat.set_search("global")
+        torch.cuda.synchronize()
+        nat.stats(reset=True)
+        t0 = time.perf_counter()
+        nat.iterate(timed)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        st1 = nat.stats()
+        stages1 = {k: round(st1.stageMs[i], 2) for i, k in enumerate(STAGES)}
+        cls = nat.fetch(nat.view().cls, np.int32, (n,))
+        nat.set_search("local")
+        nat.stats(reset=True)
+        nat.iterate(timed)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        st2 = nat.stats()
+        stages2 = {k: round(st2.stageMs[i], 2) for i, k in enumerate(STAGES)}
+        out = {"metric": "particles/sec per iteration (script/demo_3D.json: K = 4, C4, global then local search; %d x %d^3 particles)" % (n, N),
+               "value": 2.0 * n / (t2 - t0), "unit": "particles/s", "n_gpus": 1, "steps": 2, "warmup": 2,
+               "ms_per_step": 1e3 * (t2 - t0) / 2.0, "ms_global_search_iteration": 1e3 * (t1 - t0), "ms_local_search_iteration": 1e3 * (t2 - t1),
+               "higher_is_better": True, "dtype": "f32", "data": "synthetic", "vs_baseline": None,
+               "config": {"workload": "%d synthetic %d^3 particles, K = %d classes, point group C4, nR = %d scanned rotations x nT = %d shifts, "
+                                      "mLR 125 / mLT 9 / mReco 100; iteration 1 global search, iteration 2 local search" % (n, N, K, scan["nR"], scan["nT"]),
+                          "driver": "thx_refine_iterate"},
+               "classes_recovered": float((cls == sh.cls_true).mean()),
+               "stages_ms_global_iteration": stages1, "stages_ms_local_iteration": stages2,
+               "roofline": None, "cpu_baseline": None,
+               "note": "the plumbing case: launch-bound at this size (every stage is milliseconds); correctness of this exact run is "
+                       "tests/test_next_gpu.py::test_config0_demo3d_as_specified"}
+    nat.close()
+    return out
+
+
 def refinement_line(args, dev, rank, world, box, particles, steps, warmup, batch, cpu=True, cpu_particles=0):
     """one refinement configuration through the native driver -> the result dict (rank 0; None on the other ranks)"""
     import torch
@@ -585,6 +635,7 @@ def main():
     ap.add_argument("--scan-only", action="store_true", help="with --classification: the global scanning stage on its own")
     ap.add_argument("--scan-images", type=int, default=0, help="images of the classification bench (default 6250 = 50 000 / 8 GPUs; 1024 with --scan-only)")
     ap.add_argument("--scan-cpu-images-per-core", type=int, default=2)
+    ap.add_argument("--config0", action="store_true", help="BASELINE configs[0] on its own: script/demo_3D.json's run (K = 4, C4, global then local search) on 1 000 x 128^3 particles")
     ap.add_argument("--other-configs", choices=("auto", "on", "off"), default="auto",
                     help="after the headline line, also run BASELINE configs[1] (10 000 x 256^3), configs[3] (one GPU's share of the K = 4 "
                          "classification) and configs[4] (20 000 x 512^3) for 2 + 1 iterations each and report them under `other_configs` of the "
@@ -606,6 +657,9 @@ def main():
     from thunder_amd import capi
     capi.load()
 
+    if args.config0:
+        print(json.dumps(bench_config0(args, dev)))
+        return
     if args.classification:
         if not args.scan_images:
             args.scan_images = 1024 if args.scan_only else 6250
@@ -637,7 +691,8 @@ def main():
             torch.cuda.synchronize()
             capi.call("thx_release_stream", stream_ptr())
             torch.cuda.empty_cache()
-        for name, run in (("configs[1] %d x %d^3 refinement" % (n1, b1),
+        for name, run in (("configs[0] script/demo_3D.json as specified", lambda: bench_config0(args, dev, small)),
+                          ("configs[1] %d x %d^3 refinement" % (n1, b1),
                            lambda: refinement_line(args, dev, 0, 1, b1, n1, 2, 1, args.batch, cpu=True, cpu_particles=256)),
                           ("configs[3] K=4 classification, one GPU's share (%d of 50k images)" % n3, lambda: bench_classification_iteration(a3, dev)),
                           ("configs[4] %d x %d^3 refinement" % (n4, b4),

@@ -587,8 +587,11 @@ def test_bench_other_configs_small(dev):
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
     oc = d["other_configs"]
-    assert len(oc) == 3 and all(v["value"] > 0 and v["roofline"]["frac"] > 0 for v in oc.values())
+    assert len(oc) == 4 and all("error" not in v and v["value"] > 0 for v in oc.values()), oc
+    assert all(v["roofline"]["frac"] > 0 for k, v in oc.items() if not k.startswith("configs[0]"))
     assert any(v["unit"] == "images/s" for v in oc.values())
+    c0 = [v for k, v in oc.items() if k.startswith("configs[0]")][0]     # demo_3D.json's run shape (K = 4, C4, global then local search)
+    assert c0["ms_global_search_iteration"] > 0 and c0["ms_local_search_iteration"] > 0 and 0 <= c0["classes_recovered"] <= 1
 
 
 def test_config0_demo3d_128_box_iterations(dev):
