@@ -694,6 +694,9 @@ typedef struct thx_refine_capture {
     /* CTF search: the defocus factors of every phase */
     float *uD;                 /* [nPhase][nImg][mLD]: the E-step's weights of the defocus factors (Particle::setUD) */
     double *dP, *dR;           /* [nPhase][nImg][mLD]: the factors after initD / perturb(PAR_D), and after resample(mLD, PAR_D) */
+    int phases;                /* leading dimension of the per-phase arrays above (0: cfg.nPhase); with the per-image stop rule
+                                  (maxPhase > nPhase) a trace of maxPhase phases follows every image to the phase it stops in --
+                                  rows of images that have stopped are left untouched */
 } thx_refine_capture;
 
 typedef struct thx_refine_stats {

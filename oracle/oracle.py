@@ -260,7 +260,8 @@ def stop_rule(st, k1, k2, k3, s0, s1, d=0.0):
     """src/Optimiser.cpp:1510-1615, MODE_3D branch, evaluated after a phase with index >= MIN_N_PHASE_PER_ITER_LOCAL:
     returns True when the image's search ends (nPhaseWithNoVariDecrease == N_PHASE_WITH_NO_VARI_DECREASE = 1)"""
     f = 0.95   # PARTICLE_FILTER_DECREASE_FACTOR
-    if (k1 < st["k1"] * f * f) or (k2 < st["k2"] * f * f) or (k3 < st["k3"] * f * f) or (s0 < st["s0"] * f) or \
+    f2 = f * f   # gsl_pow_2(PARTICLE_FILTER_DECREASE_FACTOR): the product is formed first, as there
+    if (k1 < st["k1"] * f2) or (k2 < st["k2"] * f2) or (k3 < st["k3"] * f2) or (s0 < st["s0"] * f) or \
        (s1 < st["s1"] * f) or (d < st["d"] * f):
         st["noDec"] = 0
     else:
@@ -983,12 +984,23 @@ class Iteration:
         datP = np.ascontiguousarray(self.img[lo:hi].reshape(hi - lo, -1)[:, pl["iPxl"]])
         sigRcpP = np.ascontiguousarray(self.sigRcp[vi][self.gid[lo:hi] - 1][:, pl["iSig"]])
         p0 = 1 if glob else 0
-        for pi in range(c["nPhase"]):
-            p = p0 + pi
+        # the per-image stop rule (:1510-1615) when maxPhase > nPhase: from phase index nPhase (MIN_N_PHASE_PER_ITER_LOCAL / _GLOBAL) on
+        # the image's variances are compared with the smallest seen so far after every phase; the driver's form of the reference's
+        # `for phase < MAX_N_PHASE_PER_ITER ... break` (phases outermost, a mask over the images)
+        rule = c.get("maxPhase", 0) > c["nPhase"]
+        pEnd = c["maxPhase"] if rule else p0 + c["nPhase"]
+        stop = {l: stop_rule_init(c["transS"], c.get("ctfRefineS", 0.01) if ctfs else 0.01) for l in range(lo, hi)}
+        active = {l: True for l in range(lo, hi)}
+        for p in range(p0, pEnd):
+            pi = p - p0
+            if not any(active.values()):
+                break
             callP = self.call(SLOT_PHASE0 + 2 * p)
             callU = callP + 1
             f = c["pfL"] if p == 0 else (c["pfSGlobal"] if glob else c["pfS"])
             for l in range(lo, hi):
+                if not active[l]:
+                    continue
                 gR = np.stack(ph.draw_n4(seed, l, callP, 0, np.arange(mLR)), axis=1)
                 gT = np.stack(ph.draw_n4(seed, l, callP, 1, np.arange(mLT)), axis=1)
                 q, t, wR, wT = pf_perturb(self.q[l], self.t[l], self.k[l], self.s[l], f, f, c["transS"], c["transQ"], gR, gT, symQuat=self.symQ)
@@ -1032,6 +1044,11 @@ class Iteration:
                 out["uR"][pi, l], out["uT"][pi, l] = e["wR"], e["wT"]
                 out["srcR"][pi, l], out["srcT"][pi, l] = own["srcR"], own["srcT"]
                 out["k"][pi, l], out["s"][pi, l] = own["k"], own["s"]
+                out["phases"][l] = pi + 1
+                kS, sS = own.get("k_stop", own["k"]), own.get("s_stop", own["s"])      # (a checker may hand in the variances to decide on)
+                if rule and p >= c["nPhase"] and stop_rule(stop[l], kS[0], kS[1], kS[2], sS[0], sS[1], float(self.sD[l]) if ctfs else 0.0):
+                    active[l] = False
+                    out["nP"][l] = p
 
     def _norm_correction(self, out):
         """Optimiser::normCorrection, src/Optimiser.cpp:6201-6394: residual power of every masked image against its top pose's
@@ -1104,10 +1121,12 @@ class Iteration:
         plM = self.plM
         seed, mLR, mLT = c["seed"], c["mLR"], c["mLT"]
         glob, ctfs = search == "global", search == "ctf"
-        out = dict(uR=np.zeros((c["nPhase"], self.n, mLR), np.float32), uT=np.zeros((c["nPhase"], self.n, mLT), np.float32),
-                   uD=np.zeros((c["nPhase"], self.n, max(1, self.mLD)), np.float32), dP=np.zeros((c["nPhase"], self.n, max(1, self.mLD))),
-                   srcR=np.zeros((c["nPhase"], self.n, mLR), np.int64), srcT=np.zeros((c["nPhase"], self.n, mLT), np.int64),
-                   k=np.zeros((c["nPhase"], self.n, 3)), s=np.zeros((c["nPhase"], self.n, 2)))
+        nPh = max(c["nPhase"], c.get("maxPhase", 0))
+        out = dict(uR=np.zeros((nPh, self.n, mLR), np.float32), uT=np.zeros((nPh, self.n, mLT), np.float32),
+                   uD=np.zeros((nPh, self.n, max(1, self.mLD)), np.float32), dP=np.zeros((nPh, self.n, max(1, self.mLD))),
+                   srcR=np.zeros((nPh, self.n, mLR), np.int64), srcT=np.zeros((nPh, self.n, mLT), np.int64),
+                   k=np.zeros((nPh, self.n, 3)), s=np.zeros((nPh, self.n, 2)),
+                   phases=np.zeros(self.n, np.int64), nP=np.zeros(self.n, np.int64))   # phases an image ran; phase index it stopped in
         if glob:
             nR, nT = len(self.gridR), len(self.gridT)
             out.update(scanUC=np.zeros((self.n, K), np.float32), scanUR=np.zeros((self.n, K, nR), np.float32),

@@ -21,7 +21,7 @@ import _philox as PH
 
 
 def make_inputs(O, N, n, seed, mLR=125, mLT=9, nPhase=3, mReco=20, batch=64, nGroup=3, snr=0.05, rL=2, pixelSize=1.32, q_spread=0.03,
-                t_spread=0.6, sigma_scale=1.0, K=1, sym=None, scan=None, norm_correction=0, balance=0, amp_spread=0.0):
+                t_spread=0.6, sigma_scale=1.0, K=1, sym=None, scan=None, norm_correction=0, balance=0, amp_spread=0.0, max_phase=0):
     """n synthetic particles (SURVEY 8d recipe at a small size) + the configuration of one iteration.
     Images: CTF x slice x ramp on the rL = 0 pixel list (+ the Hermitian mirror of the kx = 0 column) + white noise made in
     real space, so that every image is the FT of a real image.  numpy / oracle only: the same bytes reach the device and
@@ -71,7 +71,7 @@ def make_inputs(O, N, n, seed, mLR=125, mLT=9, nPhase=3, mReco=20, batch=64, nGr
                nGroup=nGroup, groupSig=1, pixelSize=pixelSize, maskRadiusPx=float(np.float32(0.45 * N)), sigma2Init=float(np.float32(sigma2 * sigma_scale)),
                transS=2.0, transQ=0.05, pfL=2.0, pfS=0.5, peakFactorR=1e-3, seed=1234567 + seed, coreFSC=1, goldenAverage=1,
                solventFlatten=1, normCorrection=int(norm_correction), nK=K, sym=symd, symName=sym, balanceClass=int(balance),
-               pfSGlobal=0.5, peakFactorC=1.0 - 1e-2)
+               pfSGlobal=0.5, peakFactorC=1.0 - 1e-2, maxPhase=int(max_phase))
     if scan is not None:
         from thunder_amd.native import scan_min_spread
         mk, ms = scan_min_spread(scan.get("mS", scan["nR"] * (1 + (symd["n"] if symd else 0))), 0.5)
@@ -344,6 +344,10 @@ class Follower:
                 self.adopted.append((p, l, "top"))
                 for k in ("topR", "topT", "iTopR", "iTopT"):
                     own[k] = alt[k]
+        # the per-image stop rule (maxPhase > nPhase) compares the phase's variances with 0.95 x the smallest seen: a discrete decision
+        # on numbers that carry the ACG estimate's accuracy -- the oracle's rule is fed the DEVICE's variances of this phase (held to
+        # the oracle's own by the caller), so that the two sides must take the same decision in the same phase
+        own["k_stop"], own["s_stop"] = cap["k123"][p, l].copy(), cap["s01"][p, l].copy()
         return own
 
 

@@ -10,8 +10,8 @@ import types
 import numpy as np
 
 DUMP_DIR = os.environ.get("THX_CHAIN_DUMP")
-VIEW_ARRAYS = ("cls", "r", "t", "norm", "sig", "vols", "img", "k123", "F", "T", "d")
-STAT_FIELDS = ("balancingRounds", "normRadius", "normMedian")
+VIEW_ARRAYS = ("cls", "r", "t", "norm", "sig", "vols", "img", "k123", "F", "T", "d", "nP")
+STAT_FIELDS = ("balancingRounds", "normRadius", "normMedian", "imagePhases")
 
 
 def _shapes(c, K):
@@ -19,7 +19,7 @@ def _shapes(c, K):
     return dict(cls=(np.int32, (n,)), r=(np.float64, (n, c["mLR"], 4)), t=(np.float64, (n, c["mLT"], 2)), norm=(np.float32, (n,)),
                 sig=(np.float32, (2, c["nGroup"], N // 2 - 1)), vols=(np.complex64, (2 * K, P, P, P // 2 + 1)),
                 img=(np.complex64, (n, N, N // 2 + 1)), k123=(np.float64, (n, 3)), F=(np.complex64, (2 * K, P, P, P // 2 + 1)),
-                T=(np.float32, (2 * K, P, P, P // 2 + 1)), d=(np.float64, (n, max(c.get("mLD", 0), 1))))
+                T=(np.float32, (2 * K, P, P, P // 2 + 1)), d=(np.float64, (n, max(c.get("mLD", 0), 1))), nP=(np.int32, (n,)))
 
 
 class Recorder:

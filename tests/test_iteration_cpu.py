@@ -206,3 +206,29 @@ def test_chain_norm_correction(oracle):
     assert r2["normMedian"] == O.median(r2["norm"]) and scale[7] < 1
     # the insertion saw the rescaled rows: T is unchanged by the scale (CTF^2 weights), F scales with the images
     assert np.all(np.isfinite(r2["F_raw"][0][0])) and np.all(np.isfinite(r2["maps"][0][0]))
+
+
+def test_chain_per_image_stop_rule(oracle):
+    """the per-image stop rule in the chain (src/Optimiser.cpp:1183,1510-1615; maxPhase > nPhase): every image runs phases 0 ..
+    nPhase unconditionally -- the rule is first asked AFTER the phase with index nPhase = MIN_N_PHASE_PER_ITER_LOCAL, so an image
+    runs at least nPhase + 1 phases --, ends in the first phase in which none of its variances fell by 5 % (squared for k1..k3)
+    below the smallest seen so far, and at maxPhase at the latest; images stop in different phases"""
+    O = oracle
+    N, n, nPhase, maxPhase = 16, 60, 2, 7
+    inp = U.make_inputs(O, N, n, seed=11, mLR=16, mLT=4, nPhase=nPhase, mReco=6, batch=32, snr=1.0, rL=1, max_phase=maxPhase)
+    it = U.oracle_chain(O, inp)
+    r = it.iterate()
+    ran, nP = r["phases"], r["nP"]
+    assert ran.min() >= nPhase + 1 and ran.max() <= maxPhase and len(np.unique(ran)) > 1
+    stopped = nP > 0                                      # (phase INDEX in which the rule ended the search; 0: it never did)
+    assert np.all(nP[stopped] == ran[stopped] - 1) and np.all(ran[~stopped] == maxPhase) and stopped.any() and (~stopped).any()
+    # the decision, restated: k / s of the phases an image ran, against the running minima from (1, 1, 1, 5 transS, 5 transS)
+    for l in range(n):
+        st = O.stop_rule_init(inp["cfg"]["transS"])
+        for p in range(int(ran[l])):
+            if p >= nPhase:
+                end = O.stop_rule(st, *r["k"][p, l], *r["s"][p, l])
+                assert end == (p == ran[l] - 1 and stopped[l])
+    # rows of phases an image did not run stay empty
+    for l in range(n):
+        assert not np.any(r["uR"][ran[l]:, l]) and np.all(r["uR"][:ran[l], l].sum(axis=1) > 0)

@@ -49,7 +49,8 @@ SEARCH_LOCAL, SEARCH_GLOBAL, SEARCH_CTF = 0, 1, 2
 class RefineCapture(C.Structure):
     """thx_refine_capture (include/thunder_amd.h): device pointers as integers"""
     _fields_ = [(n, C.c_void_p) for n in ("uR", "uT", "r", "t", "k123", "s01", "mapsFsc", "rP", "tP", "wRP", "wTP", "Fraw", "Traw",
-                                          "scanUC", "scanUR", "scanUT", "r0", "t0", "k0", "s0", "Fsym", "Tsym", "uD", "dP", "dR")]
+                                          "scanUC", "scanUR", "scanUT", "r0", "t0", "k0", "s0", "Fsym", "Tsym", "uD", "dP", "dR")] + \
+               [("phases", C.c_int)]
 
 
 class RefineStats(C.Structure):

@@ -471,6 +471,7 @@ int expectation(thx_refine* h, int vi, hipStream_t st)
     const int p0 = global ? 1 : 0;
     const int pEnd = rule ? c.maxPhase : p0 + c.nPhase;   // phase indices [p0, pEnd)
     if (rule) THX_RC(thx_pf_stop_init_dev(h->active + lo, h->nP + lo, h->stopState + (size_t)lo * 8, c.transS, ctf ? c.ctfRefineS : 0.01, n, st));
+    const int capP = h->cap.phases > 0 ? h->cap.phases : c.nPhase;   // depth of the optional per-phase trace
     long imagePhases = 0;
     int nActive = n;
     for (int p = p0; p < pEnd && nActive > 0; p++) {
@@ -499,11 +500,11 @@ int expectation(thx_refine* h, int vi, hipStream_t st)
                                            h->nPxl, nb, st));
                 pDb = h->wDD + (size_t)b0 * nD;
                 ctfRows = h->ctfD;
-                if (pi < c.nPhase && h->cap.dP)
+                if (pi < capP && h->cap.dP)
                     THX_CHECK(hipMemcpyAsync(h->cap.dP + ((size_t)pi * h->nImg + b0) * nD, d, (size_t)nb * nD * sizeof(double), hipMemcpyDeviceToDevice, st));
             }
             THX_RC(thx_rotmat_dev(r, h->rotB, nb * c.mLR, st));
-            if (pi < c.nPhase && (h->cap.rP || h->cap.tP || h->cap.wRP || h->cap.wTP)) {
+            if (pi < capP && (h->cap.rP || h->cap.tP || h->cap.wRP || h->cap.wTP)) {
                 const size_t at = (size_t)pi * h->nImg + b0;
                 if (h->cap.rP) THX_CHECK(hipMemcpyAsync(h->cap.rP + at * c.mLR * 4, r, (size_t)nb * c.mLR * 4 * sizeof(double), hipMemcpyDeviceToDevice, st));
                 if (h->cap.tP) THX_CHECK(hipMemcpyAsync(h->cap.tP + at * c.mLT * 2, t, (size_t)nb * c.mLT * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -527,14 +528,14 @@ int expectation(thx_refine* h, int vi, hipStream_t st)
             THX_RC(thx_pf_update_ex_dev(r, t, wR, wT, h->uR, h->uT, k, s, h->topR + (size_t)b0 * 4, h->topT + (size_t)b0 * 2, nb, c.mLR,
                                         c.mLT, c.peakFactorR, c.seed, callU, act, &ctx, st));
             if (ctf) {
-                if (pi < c.nPhase && h->cap.uD)
+                if (pi < capP && h->cap.uD)
                     THX_CHECK(hipMemcpyAsync(h->cap.uD + ((size_t)pi * h->nImg + b0) * nD, h->uD, (size_t)nb * nD * sizeof(float), hipMemcpyDeviceToDevice, st));
                 THX_RC(thx_pf_update_d_ex_dev(h->dD + (size_t)b0 * nD, h->wDD + (size_t)b0 * nD, h->uD, h->sD + b0, h->topD + b0, nb, nD, c.seed,
                                               callU, act, ctx.img0, st));
-                if (pi < c.nPhase && h->cap.dR)
+                if (pi < capP && h->cap.dR)
                     THX_CHECK(hipMemcpyAsync(h->cap.dR + ((size_t)pi * h->nImg + b0) * nD, h->dD + (size_t)b0 * nD, (size_t)nb * nD * sizeof(double), hipMemcpyDeviceToDevice, st));
             }
-            if (pi < c.nPhase) {   // optional trace for the chain-level parity tests
+            if (pi < capP) {   // optional trace for the chain-level parity tests
                 const size_t at = (size_t)pi * h->nImg + b0;
                 const thx_refine_capture& cp = h->cap;
                 if (cp.uR) THX_CHECK(hipMemcpyAsync(cp.uR + at * c.mLR, h->uR, (size_t)nb * c.mLR * sizeof(float), hipMemcpyDeviceToDevice, st));

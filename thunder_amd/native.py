@@ -158,13 +158,14 @@ class NativeRefine:
         support points it left; sym: F / T after prepareTF"""
         s, c = self.shard, self.cfg
         n, dev, K = s.nImg, s.dev, c.nK
+        nP = max(c.nPhase, c.maxPhase)     # (with the per-image stop rule the trace follows every image to its last phase)
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
-        cap = dict(uR=z((c.nPhase, n, c.mLR), torch.float32), uT=z((c.nPhase, n, c.mLT), torch.float32),
-                   r=z((c.nPhase, n, c.mLR, 4), torch.float64), t=z((c.nPhase, n, c.mLT, 2), torch.float64),
-                   k123=z((c.nPhase, n, 3), torch.float64), s01=z((c.nPhase, n, 2), torch.float64),
+        cap = dict(uR=z((nP, n, c.mLR), torch.float32), uT=z((nP, n, c.mLT), torch.float32),
+                   r=z((nP, n, c.mLR, 4), torch.float64), t=z((nP, n, c.mLT, 2), torch.float64),
+                   k123=z((nP, n, 3), torch.float64), s01=z((nP, n, 2), torch.float64),
                    mapsFsc=z((2, K, s.N, s.N, s.N), torch.float32) if maps else None,
-                   rP=z((c.nPhase, n, c.mLR, 4), torch.float64), tP=z((c.nPhase, n, c.mLT, 2), torch.float64),
-                   wRP=z((c.nPhase, n, c.mLR), torch.float64), wTP=z((c.nPhase, n, c.mLT), torch.float64))
+                   rP=z((nP, n, c.mLR, 4), torch.float64), tP=z((nP, n, c.mLT, 2), torch.float64),
+                   wRP=z((nP, n, c.mLR), torch.float64), wTP=z((nP, n, c.mLT), torch.float64))
         P, nV = s.N * s.pf, 2 if s.world == 1 else 1
         if maps:
             cap["Fraw"] = z((nV, K, P, P, P // 2 + 1), torch.complex64)
@@ -173,7 +174,7 @@ class NativeRefine:
             cap["Fsym"] = z((nV, K, P, P, P // 2 + 1), torch.complex64)
             cap["Tsym"] = z((nV, K, P, P, P // 2 + 1), torch.float32)
         if c.mLD > 0:
-            cap.update(uD=z((c.nPhase, n, c.mLD), torch.float32), dP=z((c.nPhase, n, c.mLD), torch.float64), dR=z((c.nPhase, n, c.mLD), torch.float64))
+            cap.update(uD=z((nP, n, c.mLD), torch.float32), dP=z((nP, n, c.mLD), torch.float64), dR=z((nP, n, c.mLD), torch.float64))
         if scan:
             cap.update(scanUC=z((n, K), torch.float32), scanUR=z((n, K, c.nR), torch.float32), scanUT=z((n, K, c.nT), torch.float32),
                        r0=z((n, c.mLR, 4), torch.float64), t0=z((n, c.mLT, 2), torch.float64), k0=z((n, 3), torch.float64),
@@ -181,6 +182,7 @@ class NativeRefine:
         st = capi.RefineCapture()
         for k, v in cap.items():
             setattr(st, k, ptr(v) if v is not None else None)
+        st.phases = nP
         capi.call("thx_refine_set_capture", self._h, C.byref(st))
         self._cap = cap
         return cap
