@@ -74,6 +74,59 @@ def test_acg_statistics(oracle, dev):
     assert np.all(k[:, 0] > k[:, 1]) and np.all(k[:, 1] > k[:, 2]) and np.all(k > 0) and np.all(k < 0.05)
 
 
+def test_acg_collapsed_clouds(oracle, dev):
+    """inferACG on clouds as resampling leaves them when a few support points take most of the weight: 125 copies of 4 - 12 distinct
+    rotations, one of them holding up to a third.  Tyler's fixed point then converges linearly towards a near-singular matrix --
+    hundreds to tens of thousands of rounds, in the reference as here (no round limit there; 100 000 here) -- and one such image
+    holds its whole k_pf_perturb launch.  Held: where the device runs the oracle's number of rounds it lands on its matrix (1e-5);
+    where the stop falls in another round the matrices still agree to 5e-2; every result is finite and the launch is bounded."""
+    import time
+    from thunder_amd import capi
+    O = oracle
+    O.lib().orc_infer_acg.restype = C.c_int
+    rng = np.random.default_rng(77)
+    n = 125
+    clouds = []
+    for m, top in ((4, 0.34), (5, 0.3), (6, 0.25), (8, 0.3), (12, 0.2), (12, 0.1)):
+        base = _cloud(rng, 1, m, 0.03)[0]
+        w = rng.uniform(0.2, 1.0, m)
+        w[0] = top / (1 - top) * w[1:].sum()
+        idx = rng.choice(m, size=n, p=w / w.sum())
+        idx[:m] = np.arange(m)                      # (every point at least once)
+        clouds.append(base[idx])
+    q = np.ascontiguousarray(np.stack(clouds))
+    nImg = len(q)
+    A = torch.empty((nImg, 16), dtype=torch.float64, device=dev)
+    mean = torch.empty((nImg, 4), dtype=torch.float64, device=dev)
+    k = torch.empty((nImg, 3), dtype=torch.float64, device=dev)
+    wb = torch.empty((nImg, n), dtype=torch.float64, device=dev)
+    rounds = torch.zeros((nImg, 2), dtype=torch.int32, device=dev)
+    dq = T(q, dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    capi.call("thx_pf_acg_stats_dev", A.data_ptr(), mean.data_ptr(), k.data_ptr(), wb.data_ptr(), rounds.data_ptr(),
+              dq.data_ptr(), nImg, n, capi.stream_ptr())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    A, rounds = A.cpu().numpy(), rounds.cpu().numpy()
+    want, dA = [], []
+    for l in range(nImg):
+        Aw = np.zeros(16)
+        rw = O.lib().orc_infer_acg(_dp(Aw), _dp(np.ascontiguousarray(q[l])), n)
+        want.append(rw)
+        dA.append(float(np.abs(A[l] - Aw).sum() / max(1.0, np.abs(Aw).sum())))
+    print("collapsed clouds: rounds device %s oracle %s, |A - A_oracle| / |A_oracle| %s, %.1f ms for the launch (%.2f us per round of the slowest)"
+          % (rounds[:, 0].tolist(), want, ["%.1e" % x for x in dA], dt * 1e3, dt * 1e6 / max(1, rounds[:, 0].max())))
+    # measured: rounds device [3454, 28, 53, 10, 9, 8] oracle [189, 28, 112, 10, 9, 8]; |A - A_oracle| / |A_oracle| 9e-3, 1e-7, 3e-3, 2e-6,
+    # 2e-8, 8e-12.  With 4 - 6 distinct points the iterates crawl along a nearly flat direction of the fixed-point map and WHEN
+    # sum|A - B| first drops under 1e-3 is decided by rounding (the device forms the inverse from ten cofactors and a reciprocal,
+    # the oracle from sixteen and divisions), yet the matrices returned agree to a per cent -- the regime of the chain tests'
+    # collapsed-cloud rule
+    for l in range(nImg):
+        assert dA[l] <= (1e-5 if want[l] == rounds[l, 0] else 5e-2), (l, dA[l], want[l], rounds[l, 0])
+    assert np.all(np.isfinite(A)) and max(want) > 100 and rounds.max() < 100000 and dt < 1.0
+
+
 def _state(rng, nImg, nR, nT):
     q = _cloud(rng, nImg, nR, 0.03)
     t = rng.normal(0, 1.2, size=(nImg, nT, 2))
