@@ -260,6 +260,15 @@ int thx_reco_destroy(thx_reco* r);
 int thx_reco_reconstruct_dev(thx_reco* r, const float* F, float* T, int maxRadius, const float* FSC_host, int nFSC,
                              int joinHalf, int MAP, int gridCorr, float* dstRL, int* nIterOut, float* diffCOut,
                              void* stream);
+/* the same without a host synchronisation on the hand-written gridding loop (power-of-two grids 64 .. 1024: the stop rule is
+ * evaluated on the device and the queued rounds after it fall through): `result` -- 8 ints of DEVICE or page-locked HOST memory --
+ * receives {done, balancing rounds, -, diffC as float bits, -} when the stream gets there */
+int thx_reco_reconstruct_async_dev(thx_reco* r, const float* F, float* T, int maxRadius, const float* FSC_host, int nFSC,
+                                   int joinHalf, int MAP, int gridCorr, float* dstRL, void* result, void* stream);
+/* bounds of the gridding loop of the following reconstructions on this plan (default MAX_N_ITER_BALANCE = 30, MIN_N_ITER_BALANCE
+ * = 10, include/Reconstructor.h): two implementations are compared after the SAME number of rounds this way where the stop rule
+ * -- a max norm against 0.95 x its previous value -- would let rounding decide (tests at P = 1024) */
+int thx_reco_set_balance_rounds(thx_reco* r, int maxIter, int minIter);
 
 /* Projector::setProjectee(Volume src, nThread), src/Projector.cpp:123-148 + gridCorrection :524-606, starting from
  * the real-space map (the reference first fft.bw's the FT it is handed): zero-pad x pf, divide by TIK_RL,
@@ -542,18 +551,28 @@ int thx_pf_acg_stats_dev(double* A, double* mean, double* k123, double* wBal, in
 /* Communicator bootstrap as gpu/src/cuthunder.cu:4192-4206 does it (ncclGetUniqueId on the hemisphere's root, the id
  * shared by the caller's launcher -- MPI_Bcast in the reference --, ncclCommInitRank on every member).  id128: 128 bytes.
  * thx_comm_init binds the communicator to the CURRENT device.  A NULL thx_comm* or a communicator of size 1 makes
- * every collective below a no-op. */
+ * every collective below a no-op.
+ * Transports.  The id decides what the communicator runs over: an RCCL id (the default and the only product path), or --
+ * when the environment of the process that DRAWS the id holds THX_COMM_TRANSPORT=shm -- the name of a POSIX shared-memory
+ * segment.  The shm transport is TEST-ONLY: every collective becomes device -> host copy, barrier, rank-ordered host sum,
+ * host -> device copy; it exists because RCCL refuses two ranks on one device, so that 2 or 4 processes sharing one GPU can
+ * run the unchanged multi-rank branches of thx_refine_iterate and be held to the one-rank result
+ * (tests/test_multirank_gpu.py).  thx_comm_transport names the transport of a communicator ("rccl", "shm", "none"). */
 typedef struct thx_comm thx_comm;
 int thx_comm_unique_id(void* id128);
 int thx_comm_init(thx_comm** out, const void* id128, int rank, int size);
 int thx_comm_destroy(thx_comm* c);
 int thx_comm_rank(const thx_comm* c);
 int thx_comm_size(const thx_comm* c);
+const char* thx_comm_transport(const thx_comm* c);
 /* in-place collectives on DEVICE buffers, enqueued on `stream` */
 int thx_comm_allreduce_f32(thx_comm* c, float* buf, size_t count, void* stream);
 int thx_comm_allreduce_f64(thx_comm* c, double* buf, size_t count, void* stream);
 int thx_comm_allreduce_i32(thx_comm* c, int* buf, size_t count, void* stream);
+int thx_comm_allreduce_i64(thx_comm* c, long long* buf, size_t count, void* stream);
 int thx_comm_allreduce_max_f64(thx_comm* c, double* buf, size_t count, void* stream);
+/* ncclReduce: only `root` receives the sums; the other ranks' buffers are left as they were */
+int thx_comm_reduce_i64(thx_comm* c, long long* buf, size_t count, int root, void* stream);
 int thx_comm_broadcast(thx_comm* c, void* buf, size_t bytes, int root, void* stream);
 
 /* Reconstructor::allReduceF / allReduceT (src/Reconstructor.cpp:2350-2484, MPI_Allreduce_Large over _hemi) and the
@@ -575,6 +594,11 @@ int thx_reco_allreduce_acc(thx_comm* hemi, void* acc, double* O, int* counter, i
 /* class k of a session over nK classes (acc as thx_insert_acc_bytes(dim, nK) lays it out); thx_reco_allreduce_acc is nK = 1, k = 0 */
 int thx_reco_allreduce_acc_class(thx_comm* hemi, void* acc, int nK, int k, double* O, int* counter, int dim, int maxRadius, int pf,
                                  void* workspace, void* stream);
+/* the same towards ONE rank of the half (root >= 0: ncclReduce; root < 0: all-reduce): the rank that reconstructs class k is
+ * the only one that needs the sums (thx_refine_iterate with owners, src/Reconstructor.cpp:2383,2436 reduce to everybody); the
+ * other ranks' accumulators of the class keep their partial sums */
+int thx_reco_reduce_acc_class(thx_comm* hemi, void* acc, int nK, int k, int root, int dim, int maxRadius, int pf, void* workspace,
+                              void* stream);
 /* the pack (unpack = 0) / unpack (unpack = 1) halves of thx_reco_allreduce on their own (parity probe of the sphere-row
  * tables on one GPU); *nVoxOut (host, optional) = packed voxels */
 int thx_reco_sphere_pack_dev(float* F, float* T, int dim, int maxRadius, int pf, void* workspace, int unpack, long* nVoxOut,
@@ -663,7 +687,9 @@ typedef struct thx_refine_config {
     double scanMinK, scanMinS; /* minimum spread after the scan (thx_pf_scan_support_dev's minK / minS) */
     int balanceClass;          /* != 0: OPTIMISER_BALANCE_CLASS (src/Optimiser.cpp:5518-5593,7510-7523,7727-7733): after a global search
                                   a class holding less than CLASS_BALANCE_FACTOR / K of the images takes over the reference of a class
-                                  drawn from the distribution of the others (Philox stream (seed, 0, call, 14, class)) */
+                                  drawn from the distribution of the others (Philox stream (seed, 0, call, 14, class)).  Every rank
+                                  evaluates that stream itself: `seed` must be the same number on all ranks
+                                  (thx_refine_set_particles checks it over `world`) */
     /* ---- point group (thx_symmetry_host): HOST arrays, copied at create; nSym = 0: C1 ---- */
     int nSym;
     const double* symMat;      /* [nSym][9] column-major: prepareTF symmetrises T, then F (src/Reconstructor.cpp:1056-1091) */
@@ -696,7 +722,8 @@ typedef struct thx_refine_capture {
     double *dP, *dR;           /* [nPhase][nImg][mLD]: the factors after initD / perturb(PAR_D), and after resample(mLD, PAR_D) */
     int phases;                /* leading dimension of the per-phase arrays above (0: cfg.nPhase); with the per-image stop rule
                                   (maxPhase > nPhase) a trace of maxPhase phases follows every image to the phase it stops in --
-                                  rows of images that have stopped are left untouched */
+                                  the rows of an image at phases after the one it stopped in are UNDEFINED (whole batches of the
+                                  per-batch scratch are copied; view.nP tells where every image stopped) */
 } thx_refine_capture;
 
 typedef struct thx_refine_stats {
@@ -727,6 +754,11 @@ int thx_refine_destroy(thx_refine* h);
  * support points of the particle filter (Particle::load). */
 int thx_refine_set_particles(thx_refine* h, const float* imgOri, const thx_ctf_attr* attr, const int* groupID_host,
                              const double* quat0, const double* tran0, void* stream);
+/* The Philox number of this rank's first image (default, -1: the particles of the world ranks before it).  A caller that
+ * deals the particles of a job to the ranks in any other way -- e.g. each half's particles in contiguous parts, so that an
+ * N-rank run draws for every image exactly what a one-rank run of the same job draws -- says where its shard starts.  Call
+ * before thx_refine_reset. */
+int thx_refine_set_image_base(thx_refine* h, long long base);
 int thx_refine_set_reference(thx_refine* h, const float* refRL, void* stream);   /* DEVICE [nK][N]^3 initial maps */
 /* the class every image starts a LOCAL search in (Particle::c of the loaded filter; a global search assigns its own):
  * DEVICE or HOST [nImg] ints in [0, nK); without this call every image is in class 0 */

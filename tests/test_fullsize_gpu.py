@@ -378,3 +378,121 @@ def test_reconstruct_vs_oracle_p512(oracle, dev):
             assert e <= 1e-4 and fs.min() >= 0.9999
     print("oracle + device reconstructions at P = 512: %.0f s" % (time.perf_counter() - t0))
     plan.close()
+
+
+def _expect_local_vs_oracle(O, dev, N, nImg, nR, nT, K, seed, spread):
+    """k_expect_local (cell-packed, Morton list, filter priors, occupancy cap 2, volIdx when K > 1) against the oracle's replay of
+    src/Optimiser.cpp:1225-1406 for every image: logW of every (rotation, shift) at 1e-5 max|L|, the weights, the best rotation"""
+    from thunder_amd import ops, synth
+    from thunder_amd.refine import pixel_list, pixel_visit_order
+    rng = np.random.default_rng(seed)
+    P = 2 * N
+    pl = pixel_list(N, N // 2 - 2, 2)
+    order = pixel_visit_order(pl, N)
+    for k in ("iCol", "iRow", "iPxl", "iSig", "iColPad", "iRowPad"):
+        pl[k] = np.ascontiguousarray(pl[k][order])
+    plan = ops.RecoPlan(N, N, 2)
+    vols = torch.stack([plan.set_projectee(T(synth.blob_map(N, seed=seed + 10 * k, nblob=8), dev)) for k in range(K)]).contiguous()
+    plan.close()
+    vol_h = [vols[k].cpu().numpy() for k in range(K)]
+    cls = (np.arange(nImg) % K).astype(np.int32)[::-1].copy()           # every class is used; not in storage order
+    quat0 = synth.random_quats(nImg, rng)
+    shift0 = rng.normal(0, 2.0, size=(nImg, 2))
+    attr = synth.ctf_params(nImg, rng)
+    dat = np.zeros((nImg, pl["nPxl"]), np.complex64)
+    ctf = np.zeros((nImg, pl["nPxl"]), np.float32)
+    for l in range(nImg):
+        d, c = _noisy_rows(O, vol_h[cls[l]], P, N, pl, quat0[l:l + 1], shift0[l:l + 1], attr[l:l + 1], rng)
+        dat[l], ctf[l] = d[0], c[0]
+    sig = np.broadcast_to((-0.5 / np.mean(np.abs(dat) ** 2, axis=0, keepdims=True)).astype(np.float32), dat.shape).copy()
+    q = synth.perturb_quats(quat0, nR, spread, rng)
+    q[:, 0] = quat0
+    rot_h = np.stack([[O.rotate3D(x) for x in qs] for qs in q])
+    tran_h = shift0[:, None, :] + rng.normal(0, 0.5, size=(nImg, nT, 2))
+    pR = rng.exponential(size=(nImg, nR)); pR /= pR.sum(1, keepdims=True)
+    pT = rng.exponential(size=(nImg, nT)); pT /= pT.sum(1, keepdims=True)
+    cells = ops.pack_projector(vols, P)
+    del vols
+    torch.cuda.empty_cache()
+    res = ops.expect_local(cells, P, 2, N, T(pl["iCol"], dev), T(pl["iRow"], dev), T(dat, dev), T(ctf, dev), T(sig, dev),
+                           T(rot_h, dev), T(tran_h, dev), pR=T(pR, dev), pT=T(pT, dev), want_logW=True, packed=True, wg_per_cu=2,
+                           volIdx=T(cls, dev) if K > 1 else None)
+    torch.cuda.synchronize()
+    del cells
+    torch.cuda.empty_cache()
+    for l in range(nImg):
+        t0 = time.perf_counter()
+        want = O.expect_local(vol_h[cls[l]], P, 2, N, pl["iCol"], pl["iRow"], dat[l], ctf[l], sig[l], rot_h[l], tran_h[l], pR=pR[l], pT=pT[l])
+        wl = want["logW"][:, :, 0].T            # [nT][nR]
+        got = res.logW[l, 0].cpu().numpy()
+        scale = np.abs(wl).max()
+        e = np.abs(got - wl).max()
+        print("expect_local N=%d K=%d image %d (class %d): |logW - oracle| %.2e of max|L|, oracle %.1f s" % (N, K, l, cls[l], e / scale, time.perf_counter() - t0))
+        assert e <= 1e-5 * scale, (e, scale)
+        Cabs = abs(float(np.sum(sig[l].astype(np.float64) * np.abs(dat[l].astype(np.complex128)) ** 2)))
+        for (ir, it) in [(0, 0), (nR - 1, nT - 1), (nR // 2, 1)]:
+            sl = O.project(vol_h[cls[l]], P, 2, rot_h[l, ir], pl["iCol"], pl["iRow"])
+            ramp = O.translate(np.float32(tran_h[l, it, 0]), np.float32(tran_h[l, it, 1]), N, pl["iCol"], pl["iRow"])
+            exact = O.logDataVSPrior_f64(dat[l], ramp * sl, ctf[l], sig[l])
+            assert abs(got[it, ir] - exact) <= 5e-7 * Cabs, (got[it, ir], exact, Cabs)
+        tolw = max(2e-5 * scale, 1e-4)
+        for name in ("wR", "wT", "wC"):
+            g = getattr(res, name)[l].cpu().numpy().reshape(-1)
+            np.testing.assert_allclose(g, np.asarray(want[name]).reshape(-1), rtol=3 * tolw, atol=1e-30, err_msg=name)
+        wRo = want["wR"].reshape(-1)
+        assert wRo[int(res.wR[l].argmax())] >= (1 - 3 * tolw) * wRo.max()
+        if K > 1:      # against ANOTHER class's volume the likelihoods are different numbers: volIdx really selects
+            other = O.expect_local(vol_h[(cls[l] + 1) % K], P, 2, N, pl["iCol"], pl["iRow"], dat[l], ctf[l], sig[l], rot_h[l][:2], tran_h[l][:2])
+            assert np.abs(other["logW"][:, :, 0].T - got[:2, :2]).max() > 1e-3 * scale
+
+
+def test_expect_local_vs_oracle_n512(oracle, dev):
+    """configs[4] box: the cell-packed E-step at N = 512 (P = 1024: 34 GB of cells, element offsets beyond 2^32) against the
+    oracle -- 2 images x 12 rotations x 3 shifts, logW and weights (until round 5 this size was held packed == unpacked only)"""
+    _expect_local_vs_oracle(oracle, dev, 512, 2, 12, 3, 1, seed=5121, spread=0.006)
+
+
+def test_expect_local_vs_oracle_k4_n256(oracle, dev):
+    """configs[3] at full size: the local phase with volIdx over FOUR 4.3 GB cell-packed references at 256^3 -- 4 images (one per
+    class), 125 x 9 support points with a 3-degree cloud (after a scan), against the oracle on each image's own reference"""
+    _expect_local_vs_oracle(oracle, dev, 256, 4, 125, 9, 4, seed=2563, spread=0.03)
+
+
+def test_reconstruct_vs_oracle_p1024(oracle, dev):
+    """configs[4] grid: thx_reco_reconstruct_dev at P = 1024 -- the <3, 2> instances of the hand-written passes, incl. the z pass that
+    runs one workgroup per CU -- against the oracle (src/Reconstructor.cpp:1129-1831) with the number of balancing rounds pinned
+    to 3 on both sides (thx_reco_set_balance_rounds / force_rounds), MAP on with joinHalf.  Inputs analytic (a smooth sampling
+    density; F = reference x T).  Bars of SURVEY 8c (9): 1e-4 of max, FSC >= 0.9999 per shell."""
+    import os
+    import scipy.fft as sfft
+    from thunder_amd import ops, synth
+    O = oracle
+    N, P = 512, 1024
+    rU = N // 2 - 2
+    plan = ops.RecoPlan(N, N, 2)
+    vol = plan.set_projectee(T(synth.blob_map(N, nblob=8), dev))
+    ax = torch.fft.fftfreq(P, d=1.0 / P, device=dev)
+    r = torch.sqrt(ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :P // 2 + 1] ** 2)
+    Tt = (1.0 / (1.0 + r / 8.0)).to(torch.float32).contiguous()
+    Tt[r >= rU * 2 + 1] = 0
+    del r
+    F = (vol * Tt).contiguous()
+    del vol
+    fsc = np.clip(1.2 - np.arange(rU) / (0.6 * rU), 0.02, 1.0).astype(np.float32)
+    Fh, Th = F.cpu().numpy(), Tt.cpu().numpy()
+    plan.set_balance_rounds(3, 3)
+    m_dev = plan.reconstruct(F, Tt, rU, FSC=fsc, joinHalf=True, MAP=True, gridCorr=True).cpu().numpy()
+    assert plan.last_iters == 3
+    d_dev = plan.last_diffC
+    plan.close()
+    del F, Tt
+    torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    with sfft.set_workers(os.cpu_count() or 1):
+        m_or, k_or, diffs, _ = O.reconstruct(Fh, Th, P, N, 2, rU, FSC=fsc, joinHalf=True, MAP=True, gridCorr=True, return_iters=True,
+                                             force_rounds=3)
+        e = np.abs(m_dev - m_or).max() / np.abs(m_or).max()
+        fs = O.fsc(sfft.rfftn(m_dev).astype(np.complex64), sfft.rfftn(m_or).astype(np.complex64), N, rU)
+    print("P = 1024, 3 rounds: diffC device %.5f oracle %.5f, map %.2e of max, min FSC %.6f, oracle %.0f s" % (d_dev, diffs[-1], e, fs.min(), time.perf_counter() - t0))
+    assert k_or == 3 and abs(d_dev - diffs[-1]) <= 1e-3 * diffs[-1]
+    assert e <= 1e-4 and fs.min() >= 0.9999

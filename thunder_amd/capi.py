@@ -103,6 +103,9 @@ SIGNATURES = {
     "thx_comm_allreduce_f64": (_i, [_vp, _vp, _sz, _vp]),
     "thx_comm_allreduce_i32": (_i, [_vp, _vp, _sz, _vp]),
     "thx_comm_allreduce_max_f64": (_i, [_vp, _vp, _sz, _vp]),
+    "thx_comm_allreduce_i64": (_i, [_vp, _vp, _sz, _vp]),
+    "thx_comm_reduce_i64": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "thx_comm_transport": (C.c_char_p, [_vp]),
     "thx_comm_broadcast": (_i, [_vp, _vp, _sz, _i, _vp]),
     "thx_reco_allreduce_workspace": (_sz, [_i, _i, _i]),
     "thx_reco_allreduce": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -121,6 +124,7 @@ SIGNATURES = {
     "thx_refine_destroy": (_i, [_vp]),
     "thx_refine_set_particles": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "thx_refine_set_reference": (_i, [_vp, _vp, _vp]),
+    "thx_refine_set_image_base": (_i, [_vp, C.c_longlong]),
     "thx_refine_reset": (_i, [_vp, _vp]),
     "thx_refine_iterate": (_i, [_vp, _vp, _i, _vp]),
     "thx_refine_get_map": (_i, [_vp, _i, _vp, _vp]),
@@ -133,6 +137,7 @@ SIGNATURES = {
     "thx_refine_set_grid": (_i, [_vp, _vp, _vp, _vp]),
     "thx_refine_set_search_type": (_i, [_vp, _i]),
     "thx_reco_allreduce_acc_class": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "thx_reco_reduce_acc_class": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "thx_rotmat_dev": (_i, [_vp, _vp, _i, _vp]),
     "thx_translate_dev": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "thx_ctf_dev": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp]),
@@ -168,6 +173,7 @@ SIGNATURES = {
     "thx_symmetrize_dev": (_i, [_vp, _vp, _i, _i, _vp, _i, _d, _vp]),
     "thx_reco_create": (_i, [C.POINTER(_vp), _i, _i, _i, _f, _f]),
     "thx_reco_destroy": (_i, [_vp]),
+    "thx_reco_set_balance_rounds": (_i, [_vp, _i, _i]),
     "thx_reco_reconstruct_dev": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, C.POINTER(_i), C.POINTER(_f),
                                       _vp]),
     "thx_reco_set_projectee_dev": (_i, [_vp, _vp, _vp, _vp]),
@@ -182,6 +188,7 @@ SIGNATURES = {
     "thx_sigma_accum_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "thx_sigma_final_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp]),
     "thx_mrc_info": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "thx_reco_reconstruct_async_dev": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "thx_mrc_read_images": (_i, [C.c_char_p, _i, _i, _vp]),
     "thx_mrc_read_volume": (_i, [C.c_char_p, _vp]),
     "thx_mrc_write_volume": (_i, [C.c_char_p, _vp, _i, _i, _i, _f]),

@@ -56,6 +56,8 @@ struct Knobs {
     bool expectNdSweep;   // THX_EXPECT_ND=sweep: one launch per defocus factor instead of the fused kernel
     float expectSplit;    // THX_EXPECT_SPLIT=m: the near-slab / tail form of the local-search kernel (samples within m voxels of the cloud's
                           // mean slab are fetched one pixel ahead); 0 = the one-at-a-time form (default)
+    int expectOrder;      // THX_EXPECT_ORDER = 1 / 2 / 3: lane <-> rotation of the local-search kernel follows a ranking of the image's cloud by the
+                          // in-plane angle / the two tilt components relative to its first rotation (A/B; 0 = storage order; bit-identical results)
     int expectWgLater;    // THX_EXPECT_WG_LATER: occupancy argument of the local-search kernel for phase indices >= 1 (-1 = as phase 0)
     bool scanSimple;      // THX_SCAN=simple: the rotation-per-thread global-scan kernel for every size (A/B)
     int scanTile;         // THX_SCAN=t42 / t24 / t44: wave tiles of the scan contraction (A/B; default 2 x 2)
@@ -66,6 +68,9 @@ struct Knobs {
     bool recoTrace;       // THX_RECO_TRACE: print diffC per balancing round
     int fftzWaves;        // THX_FFTZ_WAVES = 4 / 8: register budget of the fused z pass of the gridding loop (0 = per size)
     bool recoNatural;     // THX_RECO_WT=natural: W / T of the hand-written gridding loop in the volume's own layout (A/B; default: tiled by z column)
+    bool recoHostStop;    // THX_RECO_STOP=host: the gridding loop's stop rule on the host, one 4-byte read-back per round (A/B; default: on the device)
+    bool recoReplicate;   // THX_RECO_OWNERS=0: every rank of a half reconstructs every class after an all-reduce, as the reference's ranks do
+                          // (A/B; default: class k is reduced to, and reconstructed by, rank k mod (ranks of the half))
     bool commForce;       // THX_COMM_FORCE=1: issue the RCCL calls on one-rank communicators too (1-GPU test of the path)
 };
 const Knobs& knobs();

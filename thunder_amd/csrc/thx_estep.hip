@@ -35,6 +35,8 @@ static Knobs read_knobs()
     v.expectNdSweep = e && e[0] == 's';
     v.expectSplit = 0.f;
     if ((e = getenv("THX_EXPECT_SPLIT"))) v.expectSplit = (float)atof(e);
+    v.expectOrder = 0;
+    if ((e = getenv("THX_EXPECT_ORDER"))) v.expectOrder = atoi(e);
     v.expectWgLater = -1;
     if ((e = getenv("THX_EXPECT_WG_LATER"))) v.expectWgLater = atoi(e);
     e = getenv("THX_SCAN");
@@ -51,6 +53,8 @@ static Knobs read_knobs()
     v.recoTrace = getenv("THX_RECO_TRACE") != nullptr;
     { const char* w = getenv("THX_FFTZ_WAVES"); v.fftzWaves = w ? atoi(w) : 0; }
     { const char* w = getenv("THX_RECO_WT"); v.recoNatural = w && w[0] == 'n'; }
+    { const char* w = getenv("THX_RECO_STOP"); v.recoHostStop = w && w[0] == 'h'; }
+    { const char* w = getenv("THX_RECO_OWNERS"); v.recoReplicate = w && w[0] == '0'; }
     e = getenv("THX_COMM_FORCE");
     v.commForce = e && e[0] == '1';
     return v;
@@ -320,6 +324,37 @@ __global__ __launch_bounds__(256) void k_pack_cells(float4* __restrict__ cells, 
     cells[e] = make_float4(a.x, a.y, b.x, b.y);
 }
 
+// Ordering of an image's cloud of rotations for the lane <-> rotation mapping of k_expect_local (A/B, THX_EXPECT_ORDER).
+// A listed pixel p = (x, y, 0) under R_i = R_0 d_i, d_i ~ 1 + [w_i]x, lands at R_0 (p + w_i x p): in the slice's own frame the
+// cloud of one pixel is spread by w_z (-y, x) IN the plane and by (w_x y - w_y x) off it.  Ranking the rotations by one of
+// the three components of w puts each of the kernel's 64-rotation waves on one half of the cloud along that direction.
+// key: 1 = w_z (in-plane angle), 2 = w_x, 3 = w_y, all relative to the image's first rotation.  One workgroup of 256 threads
+// per image; order[img][rank] = rotation.
+__global__ __launch_bounds__(256) void k_cloud_order(unsigned char* __restrict__ order, const double* __restrict__ rotMat, int nR,
+                                                     int key)
+{
+    __shared__ float sk[256];
+    const int img = blockIdx.x, i = threadIdx.x;
+    const double* m0 = rotMat + (size_t)img * nR * 9;
+    if (i < nR) {
+        const double* m = m0 + (size_t)i * 9;
+        // d = R_0^T R_i, d[a][b] = col_a(R_0) . col_b(R_i); w = (d[2][1] - d[1][2], d[0][2] - d[2][0], d[1][0] - d[0][1]) / 2
+        auto dot = [&](int a, int b) { return m0[3 * a] * m[3 * b] + m0[3 * a + 1] * m[3 * b + 1] + m0[3 * a + 2] * m[3 * b + 2]; };
+        double w;
+        if (key == 2) w = dot(2, 1) - dot(1, 2);
+        else if (key == 3) w = dot(0, 2) - dot(2, 0);
+        else w = dot(1, 0) - dot(0, 1);
+        sk[i] = (float)w;
+    }
+    __syncthreads();
+    if (i < nR) {
+        const float k = sk[i];
+        int rank = 0;
+        for (int j = 0; j < nR; j++) rank += (sk[j] < k || (sk[j] == k && j < i)) ? 1 : 0;
+        order[(size_t)img * nR + rank] = (unsigned char)i;
+    }
+}
+
 constexpr int kChunk = 256;  // pixels staged per LDS table
 
 struct ExpectLocalArgs {
@@ -341,6 +376,7 @@ struct ExpectLocalArgs {
     float* partC;  // [nImg][nD][nSplit]
     int nRpad;
     const int* active;   // [nImg] or NULL: images with active[img] == 0 are skipped (outputs untouched)
+    const unsigned char* order;   // [nImg][nR] or NULL: lane slot s of an image works on rotation order[s] (k_cloud_order)
     float splitM;        // SPLIT form: half-thickness (voxels) of the slab around the wave's mean slice whose samples are fetched ahead
 };
 
@@ -381,8 +417,11 @@ __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
     float cpart = 0.f;
 
     for (int pass = 0; pass < nPass; pass++) {
-        const int r = (pass * nRGp + rg) * 64 + lane;
-        const bool rvalid = r < a.nR;
+        const int rslot = (pass * nRGp + rg) * 64 + lane;
+        const bool rvalid = rslot < a.nR;
+        // which rotation this lane carries: its slot, or -- with an ordering of the cloud -- the rotation ranked there (the
+        // results go back to the rotation's own place: bit-identical outputs whatever the order)
+        const int r = (rvalid && a.order) ? (int)a.order[(size_t)img * a.nR + rslot] : rslot;
         double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
         if (rvalid) {
             const double* m = a.rotMat + ((size_t)img * a.nR + r) * 9;
@@ -1501,6 +1540,14 @@ static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, 
     a.nSplit = expect_local_nsplit(nImg);
     a.active = active;
     a.splitM = 0.f;
+    a.order = nullptr;
+    if (knobs().expectOrder > 0 && nR > 64 && nR <= 256 && nD == 1) {   // (one wave holds a cloud of <= 64 rotations whatever the order)
+        unsigned char* ord = reinterpret_cast<unsigned char*>(scratch(st, 18, (size_t)nImg * nR));
+        THX_REQUIRE(ord, "device scratch allocation failed");
+        hipLaunchKernelGGL(k_cloud_order, dim3(nImg), dim3(256), 0, st, ord, rotMat, nR, knobs().expectOrder);
+        THX_LAUNCH_CHECK();
+        a.order = ord;
+    }
     a.nRpad = ((nR + 63) / 64) * 64;
     a.partV = reinterpret_cast<float*>(workspace);
     a.partC = a.partV + (size_t)nImg * nD * a.nSplit * nT * a.nRpad;

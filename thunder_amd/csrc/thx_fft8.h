@@ -178,9 +178,11 @@ __device__ __forceinline__ void f8_xcd_tile(int& bx, int& by)
 // ---------------------------------------------------------------------------------------------
 template <int NS, int R, int TX, int DIR>
 __global__ __launch_bounds__((f8_n<NS, R>() / 8) * TX) void k_fft_strided(float2* __restrict__ data, long strideE, long strideB,
-                                                                        int nx, const float2* __restrict__ tw)
+                                                                        int nx, const float2* __restrict__ tw,
+                                                                        const int* __restrict__ stop)
 {
     constexpr int N = f8_n<NS, R>(), NT8 = N / 8;
+    if (stop && *stop) return;   // the gridding loop's stop rule has fired (k_reco_stop_rule): the queued rounds fall through
     extern __shared__ float2 f8_lds[];
     float2* sTw = f8_lds + f8_rows<NS, R>() * TX;
     const int c = threadIdx.x % TX, t = threadIdx.x / TX;
@@ -213,9 +215,11 @@ __global__ __launch_bounds__((f8_n<NS, R>() / 8) * TX) void k_fft_strided(float2
 template <int NS, int R>
 __global__ __launch_bounds__((f8_n<NS, R>() / 8) * 4) void k_fft_x_conv(float2* __restrict__ C, int ncp, int NP,
                                                                       const float* __restrict__ tab, int tabN, float nf,
-                                                                      float rnf, float rs, const float2* __restrict__ tw)
+                                                                      float rnf, float rs, const float2* __restrict__ tw,
+                                                                      const int* __restrict__ stop)
 {
     constexpr int P = f8_n<NS, R>(), NT8 = P / 8, h = P / 2, NCOL = 4, PITCH = NCOL + 1, NTHR = NT8 * NCOL;
+    if (stop && *stop) return;
     extern __shared__ float2 f8_lds[];
     float2* sTw = f8_lds + f8_rows<NS, R>() * PITCH;
     float* sval = reinterpret_cast<float*>(sTw + P);   // [h + 1]
@@ -306,9 +310,10 @@ template <int NS, int R, int TX, bool FIRST, bool TILED, int WPS>
 __global__ __launch_bounds__((f8_n<NS, R>() / 8) * TX, WPS) void k_fft_z_update(float2* __restrict__ C, float* __restrict__ W,
                                                                          const float* __restrict__ T, int ncp, int r2i,
                                                                          unsigned* __restrict__ diffBits,
-                                                                         const float2* __restrict__ tw)
+                                                                         const float2* __restrict__ tw, const int* __restrict__ stop)
 {
     constexpr int P = f8_n<NS, R>(), NT8 = P / 8, nc = P / 2 + 1, NTHR = NT8 * TX;
+    if (stop && *stop) return;
     extern __shared__ float2 f8_lds[];
     float2* sTw = f8_lds + f8_rows<NS, R>() * TX;
     __shared__ float sred[16];

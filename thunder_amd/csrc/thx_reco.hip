@@ -427,6 +427,32 @@ __global__ __launch_bounds__(256) void k_correctF(float* __restrict__ dst, const
 
 static inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
+// The stop rule of the gridding loop (src/Reconstructor.cpp:1530-1551: DIFF_C_THRES 1e-2, DIFF_C_DECREASE_THRES 0.95,
+// N_DIFF_C_NO_DECREASE 2, comparisons in double against RFLOAT operands) evaluated ON THE DEVICE after every round: the host
+// queues all MAX_N_ITER_BALANCE rounds without reading anything back; once `done` is set the kernels of the remaining rounds
+// return at entry, so W is exactly what the host-driven loop leaves.
+struct RecoStop {
+    int done, iters, nNoDec;
+    float diffC, diffCPrev;
+};
+
+__global__ void k_reco_stop_init(RecoStop* s)
+{
+    s->done = 0; s->iters = 0; s->nNoDec = 0;
+    s->diffC = 3.402823466e+38f; s->diffCPrev = 3.402823466e+38f;
+}
+
+__global__ void k_reco_stop_rule(RecoStop* s, const unsigned* diffBits, int m, int minIter)
+{
+    if (s->done) return;
+    const float d = __uint_as_float(*diffBits);
+    s->diffCPrev = s->diffC;
+    s->diffC = d;
+    s->iters = m + 1;
+    if ((double)d > (double)s->diffCPrev * 0.95) s->nNoDec += 1; else s->nNoDec = 0;
+    if (((double)d < 1e-2) || ((m >= minIter) && (s->nNoDec == 2))) s->done = 1;
+}
+
 }  // namespace thx
 
 using namespace thx;
@@ -439,6 +465,8 @@ struct thx_reco {
     float2* C;        // device, max(PF, PN) half grid
     float* rl;        // device, max(PF, PN)^3
     unsigned* diff;   // device scalar
+    int* stop;        // device RecoStop: the gridding loop's stop rule evaluated on the device (k_reco_stop_rule)
+    int maxIter, minIter;   // MAX_N_ITER_BALANCE 30 / MIN_N_ITER_BALANCE 10 (include/Reconstructor.h); thx_reco_set_balance_rounds
     float* fscDev;    // device, up to 4096 shells
     float rnf, rs;    // RN(1 / nf), RN(1 / table step): launch constants of k_convolute_rl
     // r2cF / c2rF / c2rN work on the padded C grid (rows of padded_nc); r2cStd writes the standard [P][P][P/2+1] layout
@@ -470,6 +498,7 @@ int thx_reco_create(thx_reco** out, int size, int N, int pf, float a, float alph
 static int reco_fill(thx_reco* r, int size, int N, int pf, float a, float alpha)
 {
     r->size = size; r->N = N; r->pf = pf; r->PF = pf * size; r->PN = pf * N; r->a = a; r->alpha = alpha;
+    r->maxIter = 30; r->minIter = 10;
     r->nf = mkb_rl(0.f, a, alpha);  // nf = MKB_RL(0, _a, _alpha), src/Reconstructor.cpp:2600
     std::vector<float> tab(kTabN + 1);
     {
@@ -495,6 +524,7 @@ static int reco_fill(thx_reco* r, int size, int N, int pf, float a, float alpha)
     THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->C), nHalfM * sizeof(float2)));
     THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->rl), (size_t)PM * PM * PM * sizeof(float)));
     THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->diff), sizeof(unsigned)));
+    THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->stop), sizeof(RecoStop)));
     THX_CHECK(hipMalloc(reinterpret_cast<void**>(&r->fscDev), 4096 * sizeof(float)));
     auto plan_padded = [](hipfftHandle* h, int P, hipfftType type) -> hipfftResult {
         int n[3] = {P, P, P};
@@ -521,6 +551,13 @@ static int reco_fill(thx_reco* r, int size, int N, int pf, float a, float alpha)
     return 0;
 }
 
+int thx_reco_set_balance_rounds(thx_reco* r, int maxIter, int minIter)
+{
+    THX_REQUIRE(r && maxIter >= 0 && maxIter <= 1000 && minIter >= 0, "bad arguments");
+    r->maxIter = maxIter; r->minIter = minIter;
+    return 0;
+}
+
 int thx_reco_destroy(thx_reco* r)
 {
     if (!r) return 0;
@@ -528,7 +565,7 @@ int thx_reco_destroy(thx_reco* r)
     if (r->c2rF) (void)hipfftDestroy(r->c2rF);
     if (r->r2cStd) (void)hipfftDestroy(r->r2cStd);
     if (r->haveN && r->c2rN) (void)hipfftDestroy(r->c2rN);
-    (void)hipFree(r->tw); (void)hipFree(r->tab); (void)hipFree(r->W); (void)hipFree(r->C); (void)hipFree(r->rl); (void)hipFree(r->diff); (void)hipFree(r->fscDev);
+    (void)hipFree(r->tw); (void)hipFree(r->tab); (void)hipFree(r->W); (void)hipFree(r->C); (void)hipFree(r->rl); (void)hipFree(r->diff); (void)hipFree(r->stop); (void)hipFree(r->fscDev);
     delete r;
     return 0;
 }
@@ -540,7 +577,7 @@ int thx_reco_destroy(thx_reco* r)
 // inverse of the next round).  C stays in its padded half-complex grid; the real grid is never materialised.
 template <int NS, int R, bool TILED, int WPS>
 static int balance_W_hand_t(thx_reco* r, const float* T, int maxRadius, int maxIter, int minIter, int* itersOut,
-                            float* diffCOut, hipStream_t st)
+                            float* diffCOut, void* resultDev, hipStream_t st)
 {
     constexpr int P = f8_n<NS, R>(), NT8 = P / 8, nc = P / 2 + 1;
     constexpr int TXZ = NT8 * 16 <= 1024 ? 16 : (NT8 * 8 <= 1024 ? 8 : 4), TXY = NT8 * 8 <= 1024 ? 8 : 4;
@@ -580,15 +617,26 @@ static int balance_W_hand_t(thx_reco* r, const float* T, int maxRadius, int maxI
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tile_real<TXZ>), gT, dim3(256), ldsT, st, r->rl, T, P, nc, nTx, 1);
         Tz = r->rl;
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, R, TXZ, true, TILED, WPS>), gZ, bZ, ldsZ, st, r->C, Wz, Tz, ncp, r2i, r->diff, r->tw);
+    // stop rule: on the device (default; the host queues every round and reads nothing back) or, THX_RECO_STOP=host, one
+    // 4-byte read-back per round as in rounds 1-4 (A/B; the two give the same W bit for bit)
+    const bool devStop = !knobs().recoHostStop;
+    RecoStop* stop = reinterpret_cast<RecoStop*>(r->stop);
+    const int* flag = devStop ? &stop->done : nullptr;
+    if (devStop) hipLaunchKernelGGL(k_reco_stop_init, dim3(1), dim3(1), 0, st, stop);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, R, TXZ, true, TILED, WPS>), gZ, bZ, ldsZ, st, r->C, Wz, Tz, ncp, r2i, r->diff, r->tw,
+                       (const int*)nullptr);
     for (int m = 0; m < maxIter; m++) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_strided<NS, R, TXY, 1>), gY, bY, ldsY, st, r->C, (long)ncp, (long)P * ncp, nc, r->tw);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_strided<NS, R, TXY, 1>), gY, bY, ldsY, st, r->C, (long)ncp, (long)P * ncp, nc, r->tw, flag);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_x_conv<NS, R>), dim3(P / 2 + 1, P / 2 + 1), dim3(NT8 * 4), ldsX, st, r->C, ncp,
-                           r->N * pf, r->tab, kTabN, r->nf, r->rnf, r->rs, r->tw);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_strided<NS, R, TXY, -1>), gY, bY, ldsY, st, r->C, (long)ncp, (long)P * ncp, nc, r->tw);
+                           r->N * pf, r->tab, kTabN, r->nf, r->rnf, r->rs, r->tw, flag);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_strided<NS, R, TXY, -1>), gY, bY, ldsY, st, r->C, (long)ncp, (long)P * ncp, nc, r->tw, flag);
         THX_CHECK(hipMemsetAsync(r->diff, 0, sizeof(unsigned), st));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, R, TXZ, false, TILED, WPS>), gZ, bZ, ldsZ, st, r->C, Wz, Tz, ncp, r2i, r->diff,
-                           r->tw);
+                           r->tw, flag);
+        if (devStop) {
+            hipLaunchKernelGGL(k_reco_stop_rule, dim3(1), dim3(1), 0, st, stop, r->diff, m, minIter);
+            continue;
+        }
         unsigned bits = 0;
         THX_CHECK(hipMemcpyAsync(&bits, r->diff, sizeof(unsigned), hipMemcpyDeviceToHost, st));
         THX_CHECK(hipStreamSynchronize(st));
@@ -604,6 +652,21 @@ static int balance_W_hand_t(thx_reco* r, const float* T, int maxRadius, int maxI
         THX_CHECK(hipMemcpyAsync(r->W, r->rl, nNat * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     THX_LAUNCH_CHECK();
+    if (devStop) {
+        if (resultDev) {   // the caller collects (iters, diffC) later: nothing is read back here
+            THX_CHECK(hipMemcpyAsync(resultDev, r->stop, sizeof(RecoStop), hipMemcpyDefault, st));
+            iters = -1;
+        } else {
+            RecoStop hs;
+            THX_CHECK(hipMemcpyAsync(&hs, r->stop, sizeof(RecoStop), hipMemcpyDeviceToHost, st));
+            THX_CHECK(hipStreamSynchronize(st));
+            iters = hs.iters; diffC = hs.diffC;
+        }
+    } else if (resultDev) {
+        RecoStop hs = {1, iters, nNoDec, diffC, diffCPrev};
+        THX_CHECK(hipMemcpyAsync(resultDev, &hs, sizeof(RecoStop), hipMemcpyDefault, st));
+        THX_CHECK(hipStreamSynchronize(st));   // (hs is a stack temporary)
+    }
     *itersOut = iters;
     *diffCOut = diffC;
     return 0;
@@ -611,12 +674,12 @@ static int balance_W_hand_t(thx_reco* r, const float* T, int maxRadius, int maxI
 
 template <int NS, int R>
 static int balance_W_hand(thx_reco* r, const float* T, int maxRadius, int maxIter, int minIter, int* itersOut, float* diffCOut,
-                          hipStream_t st)
+                          void* resultDev, hipStream_t st)
 {
     // THX_FFTZ_WAVES = 4 / 8 (A/B); default: 4 for the 1024-point instance (no spills), 8 otherwise
     const int wps = knobs().fftzWaves > 0 ? knobs().fftzWaves : ((NS == 3 && R == 2) ? 4 : 8);
     const bool nat = knobs().recoNatural;
-#define THX_BW(tiled, w) return balance_W_hand_t<NS, R, tiled, w>(r, T, maxRadius, maxIter, minIter, itersOut, diffCOut, st)
+#define THX_BW(tiled, w) return balance_W_hand_t<NS, R, tiled, w>(r, T, maxRadius, maxIter, minIter, itersOut, diffCOut, resultDev, st)
     if (wps <= 4) { if (nat) THX_BW(false, 4); THX_BW(true, 4); }
     if (nat) THX_BW(false, 8);
     THX_BW(true, 8);
@@ -628,7 +691,7 @@ extern "C" {
 // The gridding-weight iteration of Reconstructor::reconstruct (src/Reconstructor.cpp:1379-1551): W (r->W) must hold the
 // initial weights, T the floored T; the device-resident loop of C2R -> kernel multiply -> R2C -> W update + checkC.
 static int balance_W(thx_reco* r, const float* T, int maxRadius, int maxIter, int minIter, int* itersOut, float* diffCOut,
-                     hipStream_t st)
+                     void* resultDev, hipStream_t st)
 {
     const int PF = r->PF, pf = r->pf, ncpF = padded_nc(PF);
     int iters = 0, nNoDec = 0;
@@ -638,7 +701,7 @@ static int balance_W(thx_reco* r, const float* T, int maxRadius, int maxIter, in
     {
         // THX_FFT=rocfft (read once at load): library transforms for every size (A/B and fallback)
         if (r->handNS && pow2 && !knobs().fftRocfft) {
-#define THX_HAND(ns, rr) return balance_W_hand<ns, rr>(r, T, maxRadius, maxIter, minIter, itersOut, diffCOut, st)
+#define THX_HAND(ns, rr) return balance_W_hand<ns, rr>(r, T, maxRadius, maxIter, minIter, itersOut, diffCOut, resultDev, st)
             switch (PF) {
                 case 64: THX_HAND(2, 1);
                 case 128: THX_HAND(2, 2);
@@ -677,14 +740,39 @@ static int balance_W(thx_reco* r, const float* T, int maxRadius, int maxIter, in
         if (((double)diffC < 1e-2) || ((m >= minIter) && (nNoDec == 2))) break;
     }
     THX_LAUNCH_CHECK();
+    if (resultDev) {   // (library-transform path: the host drives the loop and knows the result)
+        RecoStop hs = {1, iters, nNoDec, diffC, diffCPrev};
+        THX_CHECK(hipMemcpyAsync(resultDev, &hs, sizeof(RecoStop), hipMemcpyDefault, st));
+        THX_CHECK(hipStreamSynchronize(st));
+    }
     *itersOut = iters;
     *diffCOut = diffC;
     return 0;
 }
 
+static int reconstruct_impl(thx_reco* r, const float* F, float* T, int maxRadius, const float* FSC_host, int nFSC, int joinHalf, int MAP,
+                            int gridCorr, float* dstRL, int* nIterOut, float* diffCOut, void* resultDev, void* stream);
+
 int thx_reco_reconstruct_dev(thx_reco* r, const float* F, float* T, int maxRadius, const float* FSC_host, int nFSC,
                              int joinHalf, int MAP, int gridCorr, float* dstRL, int* nIterOut, float* diffCOut,
                              void* stream)
+{
+    return reconstruct_impl(r, F, T, maxRadius, FSC_host, nFSC, joinHalf, MAP, gridCorr, dstRL, nIterOut, diffCOut, nullptr, stream);
+}
+
+// the same without a host synchronisation: result [5 words] (DEVICE or page-locked HOST memory) receives {done, rounds, -, diffC
+// (float bits), -} of the gridding loop when the stream gets there -- the iteration driver queues its 2 K reconstructions per half
+// back to back and reads the round counts once at the end
+int thx_reco_reconstruct_async_dev(thx_reco* r, const float* F, float* T, int maxRadius, const float* FSC_host, int nFSC,
+                                   int joinHalf, int MAP, int gridCorr, float* dstRL, void* result, void* stream)
+{
+    THX_REQUIRE(result, "result is NULL");
+    if (!gridCorr) THX_CHECK(hipMemsetAsync(result, 0, sizeof(RecoStop), as_stream(stream)));
+    return reconstruct_impl(r, F, T, maxRadius, FSC_host, nFSC, joinHalf, MAP, gridCorr, dstRL, nullptr, nullptr, result, stream);
+}
+
+static int reconstruct_impl(thx_reco* r, const float* F, float* T, int maxRadius, const float* FSC_host, int nFSC, int joinHalf, int MAP,
+                            int gridCorr, float* dstRL, int* nIterOut, float* diffCOut, void* resultDev, void* stream)
 {
     THX_REQUIRE(r && F && T && dstRL, "NULL pointer");
     THX_REQUIRE(!MAP || (FSC_host && nFSC > 0 && nFSC <= 4096), "MAP needs an FSC vector (<= 4096 shells)");
@@ -706,7 +794,7 @@ int thx_reco_reconstruct_dev(thx_reco* r, const float* F, float* T, int maxRadiu
     int iters = 0;
     float diffC = 3.402823466e+38f;
     if (gridCorr) {
-        THX_RC(balance_W(r, T, maxRadius, 30, 10, &iters, &diffC, st));  // MAX_N_ITER_BALANCE, MIN_N_ITER_BALANCE
+        THX_RC(balance_W(r, T, maxRadius, r->maxIter, r->minIter, &iters, &diffC, resultDev, st));  // MAX_N_ITER_BALANCE, MIN_N_ITER_BALANCE
     } else {
         hipLaunchKernelGGL(k_W_nogridcorr, dim3(nblk(nHalfF)), dim3(256), 0, st, r->W, T, PF, pf, maxRadius);
     }
@@ -848,7 +936,7 @@ int thx_ExposeWT_host(int gpuIdx, const float* T3D, float* W3D, const float* tab
         float diffC = 0.f;
         (void)hipfftSetStream(r->r2cF, nullptr);
         (void)hipfftSetStream(r->c2rF, nullptr);
-        rc = balance_W(r, dT.as<float>(), maxRadius, maxIter, minIter, &iters, &diffC, nullptr);
+        rc = balance_W(r, dT.as<float>(), maxRadius, maxIter, minIter, &iters, &diffC, nullptr, nullptr);
     }
     if (!rc) {
         e = hipMemcpy(W3D, r->W, half_grid(dim) * sizeof(float), hipMemcpyDeviceToHost);

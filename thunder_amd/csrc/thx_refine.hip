@@ -25,6 +25,11 @@ int thx_comm_size(const thx_comm* c);
 int thx_comm_allreduce_f32(thx_comm* c, float* buf, size_t count, void* stream);
 int thx_comm_allreduce_f64(thx_comm* c, double* buf, size_t count, void* stream);
 int thx_comm_allreduce_i32(thx_comm* c, int* buf, size_t count, void* stream);
+int thx_comm_allreduce_max_f64(thx_comm* c, double* buf, size_t count, void* stream);
+int thx_reco_reconstruct_async_dev(thx_reco* r, const float* F, float* T, int maxRadius, const float* FSC_host, int nFSC, int joinHalf,
+                                   int MAP, int gridCorr, float* dstRL, void* result, void* stream);
+int thx_reco_reduce_acc_class(thx_comm* hemi, void* acc, int nK, int k, int root, int dim, int maxRadius, int pf, void* workspace,
+                              void* stream);
 int thx_reco_allreduce_acc_class(thx_comm* hemi, void* acc, int nK, int k, double* O, int* counter, int dim, int maxRadius, int pf,
                                  void* workspace, void* stream);
 int thx_comm_broadcast(thx_comm* c, void* buf, size_t bytes, int root, void* stream);
@@ -199,6 +204,13 @@ __global__ void k_take_first_f32(float* __restrict__ dst, const float* __restric
     if (k < n) dst[k] = src[(size_t)k * stride];
 }
 
+// T(0,0,0) of the classes this rank does not reconstruct are partial sums: zeroed before the sum over the half's ranks
+__global__ void k_mask_owned(float* __restrict__ t0, int n, int nRanks, int rank)
+{
+    const int k = threadIdx.x;
+    if (k < n && (k % nRanks) != rank) t0[k] = 0.f;
+}
+
 __global__ void k_fill_nan(float* __restrict__ p, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -254,6 +266,7 @@ struct thx_refine {
     // particle-filter state and its initial copy
     double *r, *t, *wR, *wT, *k123, *s01, *topR, *topT, *r0, *t0, *pD;
     int *cls = nullptr, *clsD = nullptr, *clsCount = nullptr;   // class of every image; of every draw of a half; histogram
+    int* cls0 = nullptr;         // the classes the images were loaded with (thx_refine_set_classes; all 0 otherwise): what reset restores
     int clsCountHost[16];
     // point group
     int nSym = 0;
@@ -299,9 +312,11 @@ struct thx_refine {
     int lastRounds[4] = {0, 0, 0, 0};
     int lastRoundsK[64];
     int balanced[16];
+    int* recoRes = nullptr;      // page-locked HOST [2][2][16][8]: what the queued reconstructions report (thx_reco_reconstruct_async_dev)
     float* norm = nullptr;       // [nImg] normCorrection: the local norms; normAll [world total] + the median behind it
     float* normAll = nullptr;
     long nImgWorld = 0, worldOffset = 0;   // particles of the whole job; of the ranks before this one
+    long imgBase = -1;                     // Philox number of this rank's first image (-1: worldOffset; thx_refine_set_image_base)
     std::vector<long> worldCount;          // particles of every rank
     float lastNormMedian = 0.f, lastNormRadius = 0.f;
 };
@@ -366,10 +381,11 @@ int resolve_events(thx_refine* h)
 
 unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
 unsigned call_id(const thx_refine* h, unsigned slot) { return h->iterCount * (unsigned)kCallsPerIter + slot; }
+long img_base(const thx_refine* h) { return h->imgBase >= 0 ? h->imgBase : h->worldOffset; }
 thx_pf_ctx pf_ctx(const thx_refine* h, int b0)
 {
     thx_pf_ctx c;
-    c.symQuat = h->symQ; c.nSym = h->nSym; c.img0 = (unsigned)(h->worldOffset + b0);
+    c.symQuat = h->symQ; c.nSym = h->nSym; c.img0 = (unsigned)(img_base(h) + b0);
     return c;
 }
 size_t vol_n(const thx_refine* h) { return (size_t)h->P * h->P * (h->P / 2 + 1); }
@@ -378,6 +394,26 @@ size_t cell_stride(const thx_refine* h) { return thx_projector_packed_bytes(h->P
 float* vol_of(thx_refine* h, int vi, int k) { return h->vols + ((size_t)vi * h->nK + k) * vol_n(h) * 2; }
 float* cells_of(thx_refine* h, int vi, int k) { return h->cells + ((size_t)vi * h->nK + k) * cell_stride(h); }
 const int* vol_idx(const thx_refine* h, int b0) { return h->nK > 1 ? h->cls + b0 : nullptr; }
+
+// ---- who reconstructs what.  The reference's ranks of a hemisphere all-reduce F / T and then ALL run the same reconstruction
+// (src/Reconstructor.cpp:2383,2436).  Here class k of a half is reduced to ONE rank of the half -- rank k mod (ranks of the
+// half), numbered inside the half -- reconstructed there and the N^3 map broadcast: K classes on min(K, ranks) GPUs at once and
+// about half the ring traffic of an all-reduce.  THX_RECO_OWNERS=0 restores the reference's replicated form (A/B).
+int ranks_of_half(const thx_refine* h, int half)
+{
+    const int W = h->world ? thx_comm_size(h->world) : 1;
+    return W <= 1 ? 1 : (W - half + 1) / 2;
+}
+int owner_in_half(const thx_refine* h, int half, int k)
+{
+    const int H = ranks_of_half(h, half);
+    return (H > 1 && !knobs().recoReplicate) ? k % H : 0;
+}
+bool owns_class(const thx_refine* h, int vi, int k)
+{
+    const int H = h->hemi ? thx_comm_size(h->hemi) : 1;
+    return H <= 1 || knobs().recoReplicate || (k % H) == thx_comm_rank(h->hemi);
+}
 
 // Optimiser::allocPreCal rows of local half vi: _datP from the masked stack, _sigRcpP from the group's sigma table
 int sigrcp_rows(thx_refine* h, float* dst, int vi, int l0, int n, const int* iSig, int nPxl, hipStream_t st)
@@ -652,7 +688,7 @@ int insertion(thx_refine* h, int vi, hipStream_t st)
         hipLaunchKernelGGL(k_draw_reco, dim3(blocks_for((size_t)n * c.mReco)), dim3(256), 0, st, h->recoRot, h->recoTran,
                            ctf ? h->recoD : nullptr, h->r + (size_t)lo * c.mLR * 4, h->t + (size_t)lo * c.mLT * 2,
                            ctf ? h->dD + (size_t)lo * c.mLD : nullptr, n, c.mLR, c.mLT, ctf ? c.mLD : 0, c.mReco, c.seed,
-                           call_id(h, SLOT_DRAWS), (unsigned)(h->worldOffset + lo));
+                           call_id(h, SLOT_DRAWS), (unsigned)(img_base(h) + lo));
         if (h->nK > 1)   // every draw of an image goes to the image's class (src/Optimiser.cpp:7129-7150)
             hipLaunchKernelGGL(k_expand_cls, dim3(blocks_for((size_t)n * c.mReco)), dim3(256), 0, st, h->clsD, h->cls + lo, n, c.mReco);
         THX_LAUNCH_CHECK();
@@ -667,9 +703,12 @@ int insertion(thx_refine* h, int vi, hipStream_t st)
                                          ctf ? h->attr + b0 : nullptr, ctf ? h->recoD + (size_t)(b0 - lo) * c.mReco : nullptr, ctf ? 1 : 0,
                                          c.pixelSize, h->iColM, h->iRowM, h->pf, h->nPxlM, c.mReco, h->N, nb, st));
     }
-    // the half-set reduce on the integers, class by class through one workspace
-    for (int k = 0; k < h->nK && h->hemi; k++)
-        THX_RC(thx_reco_allreduce_acc_class(h->hemi, h->accInt, h->nK, k, nullptr, nullptr, h->P, h->rU, h->pf, h->wsReduce, st));
+    // the half-set reduce on the integers, class by class through one workspace, towards the rank that reconstructs the class
+    for (int k = 0; k < h->nK && h->hemi; k++) {
+        const int H = thx_comm_size(h->hemi);
+        const int root = (H > 1 && !knobs().recoReplicate) ? k % H : -1;
+        THX_RC(thx_reco_reduce_acc_class(h->hemi, h->accInt, h->nK, k, root, h->P, h->rU, h->pf, h->wsReduce, st));
+    }
     THX_RC(thx_insert_finish_dev(F, T, h->accInt, h->gexp, h->P, h->nK, st));
     return 0;
 }
@@ -779,6 +818,7 @@ int thx_refine_destroy(thx_refine* h)
     for (int v = 0; v < 2; v++)
         if (h->plans[v]) (void)thx_reco_destroy(h->plans[v]);
     for (void* p : h->owned) (void)hipFree(p);
+    if (h->recoRes) (void)hipHostFree(h->recoRes);
     delete h;
     return 0;
 }
@@ -808,6 +848,11 @@ int thx_refine_create(thx_refine** out, const thx_refine_config* cfg, thx_comm* 
     if (world && thx_comm_size(world) > 1) {
         THX_REQUIRE(c.halfOfRank >= 0, "halfOfRank = -1 (both halves on one rank) needs a one-rank world");
         THX_REQUIRE(c.halfOfRank == thx_comm_rank(world) % 2, "halfOfRank must equal the world rank mod 2 (rank r owns half r mod 2)");
+        // the ranks of a half are numbered in world order: world rank r is rank r / 2 of half r mod 2 (the maps of class k travel
+        // from world rank 2 x (k mod ranks of the half) + half)
+        const int W = thx_comm_size(world), wr = thx_comm_rank(world), Hh = (W - c.halfOfRank + 1) / 2;
+        THX_REQUIRE((hemi ? thx_comm_size(hemi) : 1) == Hh || (!hemi && Hh == 1), "hemi must span the world ranks of this rank's parity");
+        THX_REQUIRE(!hemi || thx_comm_rank(hemi) == wr / 2, "hemi rank must be world rank / 2");
     }
     thx_refine* h = new thx_refine;
     h->cfg = c;
@@ -862,8 +907,10 @@ int thx_refine_create(thx_refine** out, const thx_refine_config* cfg, thx_comm* 
     RC_OR_FREE(dalloc(h, &h->topR, n * 4)); RC_OR_FREE(dalloc(h, &h->topT, n * 2));
     RC_OR_FREE(dalloc(h, &h->active, n)); RC_OR_FREE(dalloc(h, &h->nP, n)); RC_OR_FREE(dalloc(h, &h->nActiveDev, (size_t)1));
     RC_OR_FREE(dalloc(h, &h->stopState, n * 8));
-    RC_OR_FREE(dalloc(h, &h->cls, n)); RC_OR_FREE(dalloc(h, &h->clsCount, (size_t)16));
-    if (hipMemset(h->cls, 0, n * sizeof(int)) != hipSuccess) { set_error("refine driver: hipMemset failed"); thx_refine_destroy(h); return -1; }
+    RC_OR_FREE(dalloc(h, &h->cls, n)); RC_OR_FREE(dalloc(h, &h->cls0, n)); RC_OR_FREE(dalloc(h, &h->clsCount, (size_t)16));
+    if (hipMemset(h->cls, 0, n * sizeof(int)) != hipSuccess || hipMemset(h->cls0, 0, n * sizeof(int)) != hipSuccess) {
+        set_error("refine driver: hipMemset failed"); thx_refine_destroy(h); return -1;
+    }
     if (h->nK > 1) RC_OR_FREE(dalloc(h, &h->clsD, (size_t)nmax * c.mReco));
     RC_OR_FREE(dalloc(h, &h->refRL, (size_t)h->nK * mapN));
     RC_OR_FREE(dalloc(h, &h->vols, nVol * volN * 2));
@@ -949,6 +996,10 @@ int thx_refine_create(thx_refine** out, const thx_refine_config* cfg, thx_comm* 
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill<double>), dim3(blocks_for(n * c.mLD)), dim3(256), 0, nullptr, h->dD, 1.0, n * c.mLD);
     }
     for (int v = 0; v < h->nV; v++) RC_OR_FREE(thx_reco_create(&h->plans[v], c.N, c.N, c.pf, 1.9f, 15.0f));
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->recoRes), 2 * 2 * 16 * 8 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        set_error("refine driver: hipHostMalloc failed"); h->recoRes = nullptr; thx_refine_destroy(h); return -1;
+    }
+    memset(h->recoRes, 0, 2 * 2 * 16 * 8 * sizeof(int));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill<double>), dim3(blocks_for(B)), dim3(256), 0, nullptr, h->pD, 1.0, B);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill<float>), dim3(blocks_for(n)), dim3(256), 0, nullptr, h->w, 1.0f / c.mReco, n);
     if (hipDeviceSynchronize() != hipSuccess) { set_error("refine driver: device error during create"); thx_refine_destroy(h); return -1; }
@@ -1009,6 +1060,20 @@ int thx_refine_set_particles(thx_refine* h, const float* imgOri, const thx_ctf_a
             THX_CHECK(hipMemcpyAsync(cnt.data(), d, (size_t)ws * sizeof(int), hipMemcpyDeviceToHost, st));
             THX_CHECK(hipStreamSynchronize(st));
         }
+        if (ws > 1) {   // determineBalanceClass and the FSC's random phases are evaluated on every rank from the SAME Philox streams
+                        // (the reference draws on the master and broadcasts, src/Optimiser.cpp:5518-5584): the seed must not depend on the rank
+            double* d = reinterpret_cast<double*>(scratch(st, 7, 4 * sizeof(double)));
+            THX_REQUIRE(d, "device scratch allocation failed");
+            const double lo = (double)(c.seed & 0xffffffffull), hi = (double)(c.seed >> 32);
+            double v[4] = {lo, -lo, hi, -hi};
+            THX_CHECK(hipMemcpyAsync(d, v, sizeof(v), hipMemcpyHostToDevice, st));
+            THX_CHECK(hipStreamSynchronize(st));
+            THX_RC(thx_comm_allreduce_max_f64(h->world, d, 4, st));
+            THX_CHECK(hipMemcpyAsync(v, d, sizeof(v), hipMemcpyDeviceToHost, st));
+            THX_CHECK(hipStreamSynchronize(st));
+            THX_REQUIRE(v[0] == lo && v[1] == -lo && v[2] == hi && v[3] == -hi,
+                        "thx_refine_config.seed differs between the ranks: it must be one number for the whole job (images are told apart by their index over all ranks)");
+        }
         h->nImgWorld = 0; h->worldOffset = 0;
         for (int r = 0; r < ws; r++) { if (r < wr) h->worldOffset += cnt[r]; h->nImgWorld += cnt[r]; h->worldCount.push_back(cnt[r]); }
         if (c.normCorrection) {
@@ -1017,6 +1082,13 @@ int thx_refine_set_particles(thx_refine* h, const float* imgOri, const thx_ctf_a
         }
     }
     THX_CHECK(hipStreamSynchronize(st));   // g0 is a host temporary
+    return 0;
+}
+
+int thx_refine_set_image_base(thx_refine* h, long long base)
+{
+    THX_REQUIRE(h && base >= -1 && base + h->nImg <= 0xffffffffll, "bad arguments");
+    h->imgBase = (long)base;
     return 0;
 }
 
@@ -1031,6 +1103,7 @@ int thx_refine_set_classes(thx_refine* h, const int* cls, void* stream)
 {
     THX_REQUIRE(h && cls, "NULL argument");
     THX_CHECK(hipMemcpyAsync(h->cls, cls, (size_t)h->nImg * sizeof(int), hipMemcpyDefault, as_stream(stream)));
+    THX_CHECK(hipMemcpyAsync(h->cls0, h->cls, (size_t)h->nImg * sizeof(int), hipMemcpyDeviceToDevice, as_stream(stream)));
     THX_CHECK(hipStreamSynchronize(as_stream(stream)));
     return 0;
 }
@@ -1081,6 +1154,14 @@ int thx_refine_reset(thx_refine* h, void* stream)
     THX_CHECK(hipMemcpyAsync(h->t, h->t0, n * c.mLT * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill<double>), dim3(blocks_for(n * c.mLR)), dim3(256), 0, st, h->wR, 1.0 / c.mLR, n * c.mLR);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill<double>), dim3(blocks_for(n * c.mLT)), dim3(256), 0, st, h->wT, 1.0 / c.mLT, n * c.mLT);
+    // the classes the particles were loaded with and the defocus search's state (Particle::load: d = 1)
+    THX_CHECK(hipMemcpyAsync(h->cls, h->cls0, n * sizeof(int), hipMemcpyDeviceToDevice, st));
+    if (c.mLD > 0) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill<double>), dim3(blocks_for(n)), dim3(256), 0, st, h->topD, 1.0, n);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill<double>), dim3(blocks_for(n * c.mLD)), dim3(256), 0, st, h->dD, 1.0, n * c.mLD);
+        THX_CHECK(hipMemsetAsync(h->sD, 0, n * sizeof(double), st));
+        THX_CHECK(hipMemsetAsync(h->wDD, 0, n * c.mLD * sizeof(double), st));
+    }
     THX_LAUNCH_CHECK();
     h->iterCount = 0;
     // Particle::load -> calVari: ACG concentration of the rotations (with a point group: of their counterparts next to a random
@@ -1140,8 +1221,6 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
     std::vector<float> fsc((size_t)K * (h->N / 2), 0.f);
     {
         Scope s(h, st, EV_STAGE0 + ST_RECO);
-        int iters = 0;
-        float diffC = 0;
         const bool multi = h->world && thx_comm_size(h->world) > 1;
         const double symR = (double)h->rU * h->pf + 1;   // _maxRadius * _pf + 1, src/Reconstructor.cpp:2676-2690
         // class distribution of the iteration and, after a global search, which empty class takes over which reference
@@ -1155,18 +1234,27 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
             h->clsCountHost[0] = h->nImg;
         }
         for (int k = 0; k < 16; k++) h->balanced[k] = bm[k];
+        const int Hh = h->hemi ? thx_comm_size(h->hemi) : 1;
+        const bool owners = Hh > 1 && !knobs().recoReplicate;
         float t0[2][16];
         for (int vi = 0; vi < h->nV; vi++) {
-            // T(0,0,0) of every class after the half-set reduce: a class no image of the half went to has nothing to normalise
+            // T(0,0,0) of every class after the half-set reduce: a class no image of the half went to has nothing to normalise.
+            // With owners only the reconstructing rank holds the sum: the others' partial sums are zeroed and the half's ranks add up
             hipLaunchKernelGGL(k_take_first_f32, dim3(1), dim3(64), 0, st, h->t0Dev, h->T + (size_t)vi * K * volN, K, volN);
+            if (owners) hipLaunchKernelGGL(k_mask_owned, dim3(1), dim3(64), 0, st, h->t0Dev, K, Hh, thx_comm_rank(h->hemi));
             THX_LAUNCH_CHECK();
+            if (owners) THX_RC(thx_comm_allreduce_f32(h->hemi, h->t0Dev, (size_t)K, st));
             THX_CHECK(hipMemcpyAsync(t0[vi], h->t0Dev, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, st));
         }
         THX_CHECK(hipStreamSynchronize(st));
         memset(h->lastRoundsK, 0, sizeof(h->lastRoundsK));
+        memset(h->recoRes, 0, 2 * 2 * 16 * 8 * sizeof(int));
+        // the reconstructions are QUEUED (the gridding loop's stop rule runs on the device, thx_reco.hip): their round counts
+        // land in page-locked memory and are read once the stream has been synchronised
+        auto res_of = [&](int map, int vi, int k) { return h->recoRes + (((size_t)map * 2 + vi) * 16 + k) * 8; };
         for (int vi = 0; vi < h->nV; vi++)
             for (int k = 0; k < K; k++) {
-                if (!(t0[vi][k] > 0.f)) continue;
+                if (!(t0[vi][k] > 0.f) || !owns_class(h, vi, k)) continue;
                 float* F = h->F + ((size_t)vi * K + k) * volN * 2;
                 float* T = h->T + ((size_t)vi * K + k) * volN;
                 // prepareTF, src/Reconstructor.cpp:1056-1091: [allReduceT: done on the integers] normalise T and F by 1 / T(0,0,0)
@@ -1181,28 +1269,32 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
                 if (h->cap.Fsym) THX_CHECK(hipMemcpyAsync(h->cap.Fsym + ((size_t)vi * K + k) * volN * 2, F, volN * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
                 if (h->cap.Tsym) THX_CHECK(hipMemcpyAsync(h->cap.Tsym + ((size_t)vi * K + k) * volN, T, volN * sizeof(float), hipMemcpyDeviceToDevice, st));
                 // setMAP(false); setJoinHalf(true) (OPTIMISER_RECONSTRUCT_JOIN_HALF); setGridCorr(true) (OPTIMISER_3D_GRID_CORR), :7326-7352
-                THX_RC(thx_reco_reconstruct_dev(h->plans[vi], F, T, h->rU, nullptr, 0, 1, 0, 1, h->maps + ((size_t)h->halves[vi] * K + k) * mapN,
-                                                &iters, &diffC, st));
-                h->recoRounds += iters;
-                h->lastRoundsK[(0 * 2 + vi) * 16 + k] = iters;
-                if (k == 0) h->lastRounds[vi] = iters;
+                THX_RC(thx_reco_reconstruct_async_dev(h->plans[vi], F, T, h->rU, nullptr, 0, 1, 0, 1, h->maps + ((size_t)h->halves[vi] * K + k) * mapN,
+                                                      res_of(0, vi, k), st));
             }
-        // balanceClass(bm), :5586-5593, 7510-7523: _model.ref(t) = _model.ref(j).copyVolume() on every rank, for its own half
-        auto balance = [&](float* m) -> int {
-            for (int vi = 0; vi < h->nV; vi++)
-                for (int t = 0; t < K; t++)
-                    if (bm[t] >= 0 && bm[t] != t)
-                        THX_CHECK(hipMemcpyAsync(m + ((size_t)h->halves[vi] * K + t) * mapN, m + ((size_t)h->halves[vi] * K + bm[t]) * mapN,
-                                                 mapN * sizeof(float), hipMemcpyDeviceToDevice, st));
+        // every rank ends up with every class's map of both halves (the reference sends them to the master, src/Model.cpp:375-391):
+        // class k of half hf is broadcast from the world rank that reconstructed it -- rank 2 x (its number inside the half) + hf
+        // (rank r owns half r mod 2, checked in thx_refine_create)
+        auto exchange = [&](float* m) -> int {
+            if (!multi) return 0;
+            for (int hf = 0; hf < 2; hf++)
+                for (int k = 0; k < K; k++)
+                    THX_RC(thx_comm_broadcast(h->world, m + ((size_t)hf * K + k) * mapN, mapN * sizeof(float), 2 * owner_in_half(h, hf, k) + hf, st));
             return 0;
         };
+        // balanceClass(bm), :5586-5593, 7510-7523: _model.ref(t) = _model.ref(j).copyVolume(), for every half whose maps are here
+        auto balance = [&](float* m) -> int {
+            for (int hf = 0; hf < 2; hf++) {
+                if (!multi && !(h->halves[0] == hf || (h->nV > 1 && h->halves[1] == hf))) continue;
+                for (int t = 0; t < K; t++)
+                    if (bm[t] >= 0 && bm[t] != t)
+                        THX_CHECK(hipMemcpyAsync(m + ((size_t)hf * K + t) * mapN, m + ((size_t)hf * K + bm[t]) * mapN, mapN * sizeof(float),
+                                                 hipMemcpyDeviceToDevice, st));
+            }
+            return 0;
+        };
+        THX_RC(exchange(h->maps));
         THX_RC(balance(h->maps));
-        // every rank ends up with both half maps (the reference sends them to the master, src/Model.cpp:375-391): broadcast
-        // from world ranks 0 and 1, which lead halves 0 and 1 (checked in thx_refine_create)
-        if (multi) {
-            THX_RC(thx_comm_broadcast(h->world, h->maps, (size_t)K * mapN * sizeof(float), 0, st));
-            THX_RC(thx_comm_broadcast(h->world, h->maps + (size_t)K * mapN, (size_t)K * mapN * sizeof(float), 1, st));
-        }
         if (h->cap.mapsFsc) THX_CHECK(hipMemcpyAsync(h->cap.mapsFsc, h->maps, 2 * (size_t)K * mapN * sizeof(float), hipMemcpyDeviceToDevice, st));
         // compareTwoHemispheres(true, false, ...), src/Optimiser.cpp:7547: FSC over _rU shells, core-mask corrected on request
         const float coreR = c.coreFSC ? (float)(int)rint((double)(c.maskRadiusPx)) : 0.f;   // AROUND(maskRadius / pixelSize), :188
@@ -1217,26 +1309,20 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
         }
         for (int vi = 0; vi < h->nV; vi++)
             for (int k = 0; k < K; k++) {
-                if (!(t0[vi][k] > 0.f)) continue;
+                if (!(t0[vi][k] > 0.f) || !owns_class(h, vi, k)) continue;
                 float* F = h->F + ((size_t)vi * K + k) * volN * 2;
                 float* T = h->T + ((size_t)vi * K + k) * volN;
                 float* m = h->mapsX + ((size_t)h->halves[vi] * K + k) * mapN;
                 // setMAP(true); setJoinHalf(true); setGridCorr(true), :7574-7600; Reconstructor::_FSC is last iteration's
-                THX_RC(thx_reco_reconstruct_dev(h->plans[vi], F, T, h->rU, h->fscReco.data() + (size_t)k * h->rU, h->rU, 1, 1, 1, m, &iters,
-                                                &diffC, st));
-                h->recoRounds += iters;
-                h->lastRoundsK[(1 * 2 + vi) * 16 + k] = iters;
-                if (k == 0) h->lastRounds[2 + vi] = iters;
+                THX_RC(thx_reco_reconstruct_async_dev(h->plans[vi], F, T, h->rU, h->fscReco.data() + (size_t)k * h->rU, h->rU, 1, 1, 1, m,
+                                                      res_of(1, vi, k), st));
             }
+        THX_RC(exchange(h->mapsX));
         THX_RC(balance(h->mapsX));   // :7727-7733
         if (c.goldenAverage) {
             // compareTwoHemispheres(false, true, AVERAGE_TWO_HEMISPHERE_THRES), :7747.  One class under the gold standard: A = B =
             // (A + B) / 2 inside r = Model::resolutionP(thres = 0.95, false) of the FSC just computed (MODEL_RESOLUTION_BASE_AVERAGE,
             // src/Model.cpp:616-674); several classes: everywhere (:688-696)
-            if (multi) {
-                THX_RC(thx_comm_broadcast(h->world, h->mapsX, (size_t)K * mapN * sizeof(float), 0, st));
-                THX_RC(thx_comm_broadcast(h->world, h->mapsX + (size_t)K * mapN, (size_t)K * mapN * sizeof(float), 1, st));
-            }
             int avgR = -1;
             if (K == 1 && c.goldenAverage == 1) {
                 int res = 1;   // resP(_FSC.col(0), 0.95, 1, 1, false), src/Functions/Spectrum.cpp:339-363
@@ -1262,8 +1348,19 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
                     THX_RC(thx_soft_mask_volume_dev(m, h->N, c.maskRadiusPx, 6.0f, 0.f, st));
                 THX_RC(refresh_projector(h, vi, k, m, st));
             }
+        // the round counts of the queued reconstructions (statistics only).  (The synchronisation also comes before fscReco
+        // changes: the queued MAP reconstructions copy it from host memory.)
+        THX_CHECK(hipStreamSynchronize(st));
         for (int k = 0; k < K; k++)   // Model::resetReco: _reco[l]->setFSC(_FSC.col(l)), src/Model.cpp:1122
             std::copy(fsc.begin() + (size_t)k * (h->N / 2), fsc.begin() + (size_t)k * (h->N / 2) + h->rU, h->fscReco.begin() + (size_t)k * h->rU);
+        for (int map = 0; map < 2; map++)
+            for (int vi = 0; vi < h->nV; vi++)
+                for (int k = 0; k < K; k++) {
+                    const int it = res_of(map, vi, k)[1];
+                    h->recoRounds += it;
+                    h->lastRoundsK[(map * 2 + vi) * 16 + k] = it;
+                    if (k == 0) h->lastRounds[map * 2 + vi] = it;
+                }
     }
     // ---- re-centre and re-mask the particle images with the top shift of the last phase; not after a global search
     // (OPTIMISER_RECENTRE_IMAGE_EACH_ITERATION: `if (_searchType != SEARCH_TYPE_GLOBAL)`, src/Optimiser.cpp:3790-3810) ----

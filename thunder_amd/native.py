@@ -107,7 +107,7 @@ class NativeRefine:
         cfg.pixelOrder, cfg.wgPerCU = pixel_order, s.wg_per_cu
         cfg.pixelSize, cfg.maskRadiusPx, cfg.sigma2Init = s.pixelSize, s.maskRadiusPx, s.sigma2
         cfg.transS, cfg.transQ, cfg.pfL, cfg.pfS, cfg.peakFactorR = s.transS, s.transQ, s.pfL, s.pfS, s.peakFactorR
-        cfg.seed = s.pf_seed
+        cfg.seed = g("job_seed", s.pf_seed)     # one seed for the whole job (thx_refine_set_particles checks it over `world`)
         cfg.coreFSC, cfg.goldenAverage, cfg.solventFlatten = int(s.coreFSC), int(s.goldenAverage), int(s.solventFlatten)
         cfg.normCorrection = 1 if norm_correction else 0   # Optimiser::normCorrection: rescales shard.imgOri IN PLACE from iteration 2 on
         # ---- classes, global search, point group, CTF search ----
@@ -132,6 +132,8 @@ class NativeRefine:
         capi.call("thx_refine_create", C.byref(h), C.byref(cfg), hemi.handle if hemi is not None else None,
                   world.handle if world is not None else None)
         self._h = h
+        if g("img_base") is not None:            # where this rank's shard starts in the job's image numbering (refine.take_shard)
+            capi.call("thx_refine_set_image_base", self._h, int(s.img_base))
         gid = np.ascontiguousarray(s.gid.astype(np.int32))
         capi.call("thx_refine_set_particles", self._h, ptr(s.imgOri), ptr(s.attr), gid.ctypes.data, ptr(s.pf0["r"]),
                   ptr(s.pf0["t"]), stream_ptr())

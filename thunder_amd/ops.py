@@ -489,6 +489,10 @@ class RecoPlan:
         except Exception:
             pass
 
+    def set_balance_rounds(self, max_iter=30, min_iter=10):
+        """bounds of the gridding loop (MAX_N_ITER_BALANCE / MIN_N_ITER_BALANCE) of the following reconstructions"""
+        capi.call("thx_reco_set_balance_rounds", self._h, int(max_iter), int(min_iter))
+
     def reconstruct(self, F, T, maxRadius, FSC=None, joinHalf=False, MAP=True, gridCorr=True):
         """Reconstructor::reconstruct (src/Reconstructor.cpp:1129-1831). T is modified in place (as the reference)."""
         _chk(F, _C64, "F"); _chk(T, _F32, "T")

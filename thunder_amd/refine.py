@@ -73,7 +73,8 @@ class RefineShard:
     def __init__(self, N, nImg, device, rank=0, world=1, pf=2, mLR=125, mLT=9, nPhase=3, mReco=100, seed=1000,
                  batch=10240, pixelSize=1.32, snr=0.01, rL=2, ops=None, oracle_pixel_list=None, nGroup=8, groupSig=True,
                  maskFrac=0.45, particle_filter=True, transS=2.0, data=None, allocate=True, sort_view=False, coreFSC=True,
-                 goldenAverage=True, solventFlatten=True, K=1, sym=None, scan=None, search="local", map_seed=20240601, nblob=40):
+                 goldenAverage=True, solventFlatten=True, K=1, sym=None, scan=None, search="local", map_seed=20240601, nblob=40,
+                 K_used=None):
         """data (optional): particles read from files instead of synthesised here -- dict(imgOri complex64 device stack
         [nImg][N][N/2+1] as Optimiser::initImg leaves _imgOri, attr float32 [nImg][7], quat [nImg][4], shift [nImg][2]
         (initial poses, e.g. the .thu columns), gid int32 [nImg] 1-based group ids, ref float32 [N]^3 initial map).
@@ -157,7 +158,8 @@ class RefineShard:
                 self.r_true, t_true = rng.integers(0, self.scan["nR"], nImg), rng.integers(0, self.scan["nT"], nImg)
                 self.quat, self.shift = self.scan["quat"][self.r_true].copy(), self.scan["shifts"][t_true].copy()
             if K > 1:
-                self.cls_true = rng.integers(0, K, nImg).astype(np.int32)
+                # (K_used < K leaves the last classes without particles: what OPTIMISER_BALANCE_CLASS exists for)
+                self.cls_true = rng.integers(0, K if K_used is None else K_used, nImg).astype(np.int32)
             if sort_view:   # shard layout: particles ordered by [class, then] view direction within each half (see view_order)
                 nA = (nImg + 1) // 2 if world == 1 else nImg
                 for lo, hi in ((0, nA), (nA, nImg)):
@@ -234,6 +236,7 @@ class RefineShard:
         self.use_pf = particle_filter
         self.wg_per_cu = 2 if particle_filter else 0
         self.pf_seed, self.pf_call = seed + 104729 * rank, 0
+        self.job_seed = seed  # the native driver's Philox seed: ONE number for the whole job (images are told apart by their index over all ranks)
         self.img_id0 = 0      # this rank's first image in the Philox numbering (the native driver: images of the ranks before it)
         if self.use_pf:
             q0 = synth.perturb_quats(self.quat, mLR, 0.02, rng)
@@ -633,6 +636,48 @@ def pixel_list(N, rU, rL, pf=2):
     a = lambda x: np.asarray(x, np.int32)
     return dict(iCol=a(iCol), iRow=a(iRow), iPxl=a(iPxl), iSig=a(iSig), iColPad=a(iCol) * pf, iRowPad=a(iRow) * pf,
                 nPxl=len(iCol))
+
+
+def half_part(nTotal, rank, world):
+    """[lo, hi) of `rank`'s particles in the ONE-RANK layout of a job of nTotal particles ([0, ceil(n / 2)) = half 0, the rest = half
+    1): rank r holds the (r // 2)-th contiguous part of half r mod 2.  Dealing a job this way -- and telling the native driver where
+    the shard starts (thx_refine_set_image_base) -- makes an N-rank run draw for every image what the one-rank run draws."""
+    if world == 1:
+        return 0, nTotal
+    nA = (nTotal + 1) // 2
+    h = rank % 2
+    lo, hi = (0, nA) if h == 0 else (nA, nTotal)
+    H = (world - h + 1) // 2
+    j, n = rank // 2, hi - lo
+    return lo + (n * j) // H, lo + (n * (j + 1)) // H
+
+
+def take_shard(full, rank, world):
+    """the part of a one-rank RefineShard (allocate=False) that `rank` of `world` owns (half_part): a shallow copy with the
+    per-particle arrays cut, for thunder_amd.native.NativeRefine -- tests/_rank_worker.py runs 2 and 4 ranks on the particles of a
+    one-rank job this way"""
+    import copy
+    import types
+    assert full.world == 1 and not full.allocated
+    lo, hi = half_part(full.nImg, rank, world)
+    s = copy.copy(full)
+    s.rank, s.world, s.nImg = rank, world, hi - lo
+    s.groups = types.SimpleNamespace(rank=rank, world=world, half=rank % 2, group=None)
+    s.halves = (rank % 2,) if world > 1 else (0, 1)
+    s.ranges = {rank % 2: (0, hi - lo)} if world > 1 else full.ranges
+    s.img_base = lo
+    for name in ("imgOri", "attr"):
+        setattr(s, name, getattr(full, name)[lo:hi].contiguous())
+    for name in ("gid", "quat", "shift", "cls_true"):
+        setattr(s, name, np.ascontiguousarray(getattr(full, name)[lo:hi]))
+    if getattr(full, "r_true", None) is not None:
+        s.r_true = full.r_true[lo:hi]
+    s.pf0 = {k: v[lo:hi].contiguous() for k, v in full.pf0.items()}
+    if getattr(full, "cls0", None) is not None:
+        s.cls0 = np.ascontiguousarray(full.cls0[lo:hi])
+    nb = max(1, -(-s.nImg // max(1, full.batch)))
+    s.batch = -(-s.nImg // nb)
+    return s
 
 
 def shard_count(nTotal, rank, world):
