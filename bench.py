@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 INIT_OUTSIDE_CONFIDENCE_AREA = 0.5   # include/Particle.h:59
 TRANS_SEARCH_FACTOR = 0.25           # script/demo_3D.json "Translation Search Factor"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-INSERT_BYTES_PER_PIXEL_SAMPLE = 204  # 12 B in + F 8x8 Bx(R+W) + T 8x4 Bx(R+W)
+INSERT_BYTES_PER_PIXEL_SAMPLE = 204  # 12 B in + F 8x8 Bx(R+W) + T 8x4 Bx(R+W) (kept for reference: the insertion merges draws and accumulates in LDS, so it is priced against the LDS atomic rate, not against these bytes)
 EXPECT_BYTES_PER_PIXEL_SAMPLE = 64   # 8 neighbours x 8 B
 EXPECT_BYTES_PER_PIXEL = 16          # dat 8 + ctf 4 + sigRcp 4, read once per image-phase
 
@@ -317,7 +317,8 @@ def bench_classification_iteration(args, dev, nImg=None, steps=None, warmup=None
                  "note": "exact-f32 contraction on v_mfma_f32_32x32x2_f32 (bit-equal to the fmaf chain); peak = f32 MFMA = f32 vector rate"}
     roof_local = {"bound": "hbm", "kernel": "k_expect_local<9, packed> with volIdx (K cell-packed references)", "achieved": loc_bytes / (loc_ms * 1e-3) / 1e9,
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": loc_bytes / (loc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                  "avg_launch_ms": loc_ms, "images_per_launch": loc_n}
+                  "avg_launch_ms": loc_ms, "images_per_launch": loc_n, "traffic_measured_in_run": False,
+                  "traffic_profile": "profiles/pmc_traffic.json"}
     out = {"metric": "images/sec through one 3-D classification iteration (K = 4, %d^3 box): global scan + class selection + %d local phases + "
                      "sigma update + multi-reference insertion + 2 reconstructions per class and half + per-class FSC / averaging / refresh" % (N, args.phases),
            "value": nImg * steps / dt, "unit": "images/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
@@ -458,6 +459,146 @@ def bench_config0(args, dev, small=False):
     return out
 
 
+def bench_staged(args, dev):
+    """--staged: the DROP-IN path timed -- what an UNCHANGED src/Optimiser.cpp drives through the reference's plug-in surface
+    (gpu/interface/Interface.h, here the thx_*_host twins): the local search ONE IMAGE PER CALL from `threads` host threads, each with its
+    own ManagedCalPoint and device slot (thx_ExpectLocalP / RTD / PreI3D / M_host, src/Optimiser.cpp:2180-3393), the insertion as
+    InsertFT on batches of host rows (src/Reconstructor.cpp:865-976) and ReconstructG_host on host volumes (:1835-2330), on a sample
+    of BASELINE configs[1] (256^3 box).  Host arrays in and out at every call, as the reference's interface has it: this is the
+    compatibility form, reported next to the native driver's number (the headline), never as `value` of the metric."""
+    import ctypes as C
+    import threading
+    import torch
+    from thunder_amd import capi, ops
+    from thunder_amd.refine import RefineShard
+    N, pf = args.box, 2
+    P = N * pf
+    n = int(args.staged_images)
+    threads = int(args.staged_threads)
+    sh = RefineShard(N, n, dev, mLR=args.mLR, mLT=args.mLT, nPhase=args.phases, mReco=args.mReco, batch=min(n, 2048),
+                     particle_filter=True, allocate=False)
+    vol = sh.vols[0].cpu().numpy()                                   # projector volume (host, as Projector::_projectee3D)
+    nPxl, nPxlM = sh.nPxl, sh.nPxlM
+    iCol, iRow = np.ascontiguousarray(sh.pl["iCol"]), np.ascontiguousarray(sh.pl["iRow"])
+    iColM, iRowM = np.ascontiguousarray(sh.plM["iCol"]), np.ascontiguousarray(sh.plM["iRow"])
+    ctfM = ops.ctf(sh.attr, sh.pixelSize, sh.iColM, sh.iRowM, N)
+    datM = ops.gather_pixels(sh.imgOri, sh.iPxlM, N)
+    pos = {(int(i), int(j)): k for k, (i, j) in enumerate(zip(iColM, iRowM))}
+    e2m = np.asarray([pos[(int(i), int(j))] for i, j in zip(iCol, iRow)], np.int64)
+    datP = np.ascontiguousarray(datM.cpu().numpy()[:, e2m])          # host rows, as Optimiser::_datP / _ctfP / _sigRcpP
+    ctfP = np.ascontiguousarray(ctfM.cpu().numpy()[:, e2m])
+    sigP = np.full((n, nPxl), np.float32(-0.5 / sh.sigma2), np.float32)
+    datMh, ctfMh = np.ascontiguousarray(datM.cpu().numpy()), np.ascontiguousarray(ctfM.cpu().numpy())
+    attr_h = np.ascontiguousarray(sh.attr.cpu().numpy())
+    quat = np.ascontiguousarray(sh.pf0["r"].cpu().numpy())           # [n][mLR][4] support points of every image
+    tran = np.ascontiguousarray(sh.pf0["t"].cpu().numpy())           # [n][mLT][2]
+    sh.release_generation_state()
+    del datM, ctfM
+    nR, nT = sh.mLR, sh.mLT
+    vp = C.c_void_p
+    deviCol, deviRow = vp(), vp()
+    capi.call("thx_ExpectPreidx_host", 0, C.byref(deviCol), C.byref(deviRow), iCol.ctypes.data, iRow.ctypes.data, nPxl)
+    devdatP, devctfP, devdefO, devsigP = vp(), vp(), vp(), vp()
+    capi.call("thx_ExpectLocalIn_host", 0, C.byref(devdatP), C.byref(devctfP), C.byref(devdefO), C.byref(devsigP), nPxl, threads, 0)
+    mgr = vp()
+    capi.call("thx_texture_create", C.byref(mgr), 1, P, 0)
+    capi.call("thx_ExpectLocalV3D_host", 0, mgr, vol.ctypes.data, P)
+    ctx = []
+    for t in range(threads):
+        mcp = vp()
+        capi.call("thx_calpoint_create", C.byref(mcp), 1, 0, 0, nR, nT, 1, nPxl)
+        hp = [vp() for _ in range(10)]
+        capi.call("thx_ExpectLocalHostA_host", 0, *[C.byref(q) for q in hp], nR, nT, 1, 0)
+        ctx.append((mcp, hp))
+
+    def host(ptr, cnt, dt):
+        ct = {np.float32: C.c_float, np.float64: C.c_double}[dt]
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(cnt,))
+    errors = []
+
+    def worker(t, images):
+        try:
+            mcp, hp = ctx[t]
+            oldR, oldT, oldD = host(hp[4], nR, np.float64), host(hp[5], nT, np.float64), host(hp[6], 1, np.float64)
+            h_tr, h_rot = host(hp[7], 2 * nT, np.float64), host(hp[8], 4 * nR, np.float64)
+            oldR[:] = 1.0 / nR; oldT[:] = 1.0 / nT; oldD[:] = 1.0
+            for l in images:
+                capi.call("thx_ExpectLocalP_host", 0, devdatP, devctfP, devdefO, devsigP, datP.ctypes.data, ctfP.ctypes.data, None,
+                          sigP.ctypes.data, t, int(l), nPxl, 0)
+                for ph in range(args.phases):       # (the same support points in every phase: the same work)
+                    h_tr[:] = tran[l].reshape(-1); h_rot[:] = quat[l].reshape(-1)
+                    capi.call("thx_ExpectLocalRTD_host", 0, mcp, hp[4], hp[5], hp[6], hp[7], hp[8], hp[9])
+                    capi.call("thx_ExpectLocalPreI3D_host", 0, t, mgr, mcp, devdefO, None, deviCol, deviRow, float(attr_h[l, 6]),
+                              float(attr_h[l, 5]), 0.0, 0.0, pf, N, P, nPxl, 1)
+                    capi.call("thx_ExpectLocalM_host", 0, t, mcp, devdatP, devctfP, devsigP, hp[0], hp[1], hp[2], hp[3], 1.0, nPxl)
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    def run_e(images):
+        th = [threading.Thread(target=worker, args=(t, images[t::threads])) for t in range(threads)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        if errors:
+            raise errors[0]
+    run_e(np.arange(min(n, 4 * threads)))                            # untimed: first touch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_e(np.arange(n))
+    torch.cuda.synchronize()
+    t_e = time.perf_counter() - t0
+    # ---- insertion: InsertFT on batches of host rows (quaternions / shifts of mReco draws per image) ----
+    rng = np.random.default_rng(3)
+    mReco = args.mReco
+    iR, iT = rng.integers(0, nR, size=(n, mReco)), rng.integers(0, nT, size=(n, mReco))
+    nRq = np.ascontiguousarray(np.take_along_axis(quat, iR[:, :, None], axis=1))
+    nTt = np.ascontiguousarray(np.take_along_axis(tran, iT[:, :, None], axis=1))
+    F = np.zeros((P, P, P // 2 + 1), np.complex64)
+    Tc = np.zeros((P, P, P // 2 + 1), np.complex64)                   # the reference's T3D is a complex Volume
+    O3, cnt = np.zeros(3), np.zeros(1, np.int32)
+    w = np.full(n, np.float32(1.0 / mReco), np.float32)
+    offS = np.zeros((n, 2))
+    B = int(args.staged_insert_batch)
+    t0 = time.perf_counter()
+    for b0 in range(0, n, B):
+        b1 = min(n, b0 + B)
+        capi.call("thx_InsertFT_host", F.ctypes.data, Tc.ctypes.data, O3.ctypes.data, cnt.ctypes.data, datMh[b0:b1].ctypes.data,
+                  ctfMh[b0:b1].ctypes.data, attr_h[b0:b1].ctypes.data, offS[b0:b1].ctypes.data, w[b0:b1].ctypes.data,
+                  nRq[b0:b1].ctypes.data, nTt[b0:b1].ctypes.data, None, None, iColM.ctypes.data, iRowM.ctypes.data,
+                  float(sh.pixelSize), 0, pf, nPxlM, mReco, N, P, 1, b1 - b0)
+    t_i = time.perf_counter() - t0
+    # ---- reconstruction: ReconstructG on host volumes ----
+    capi.call("thx_PrepareTF_host", 0, F.ctypes.data, Tc.ctypes.data, P, None, 0, sh.maxRadius, pf)
+    fscv = np.ones(N // 2 - 2, np.float32)
+    out = np.zeros((N, N, N), np.float32)
+    t0 = time.perf_counter()
+    capi.call("thx_ReconstructG_host", 0, F.ctypes.data, Tc.ctypes.data, N, N, pf, sh.maxRadius, 1.9, 15.0, fscv.ctypes.data, len(fscv), 1, 0, 1,
+              out.ctypes.data)
+    t_r = time.perf_counter() - t0
+    for mcp, hp in ctx:
+        capi.call("thx_ExpectLocalHostF_host", 0, *[C.byref(q) for q in hp], 0)
+        capi.call("thx_calpoint_destroy", mcp)
+    devfreQ = vp()
+    capi.call("thx_ExpectLocalFin_host", 0, C.byref(devdatP), C.byref(devctfP), C.byref(devdefO), C.byref(devfreQ), C.byref(devsigP), 0)
+    capi.call("thx_ExpectFreeIdx_host", 0, C.byref(deviCol), C.byref(deviRow))
+    capi.call("thx_texture_destroy", mgr)
+    total = args.particles
+    t_iter = total * (t_e + t_i) / n + 4 * t_r
+    return {"metric": "particles/sec per refinement iteration through the reference's plug-in surface (staged drop-in path; %d^3 box, %d particles)" % (N, total),
+            "value": total / t_iter, "unit": "particles/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "config": {"workload": "sample of %d of %d synthetic %d^3 particles: local search %d phases x %d rot x %d shifts one image per call "
+                                   "from %d host threads (thx_ExpectLocalP / RTD / PreI3D / M_host), InsertFT on batches of %d images x %d draws of host "
+                                   "rows, ReconstructG on host volumes x 4" % (n, total, N, args.phases, nR, nT, threads, B, mReco),
+                       "driver": "the thx_*_host twins of gpu/interface/Interface.h, as an unchanged Optimiser.cpp calls them"},
+            "e_step_us_per_image_phase": 1e6 * t_e / (n * args.phases), "e_step_images_per_s": n / t_e,
+            "insert_us_per_image": 1e6 * t_i / n, "reconstructG_s": t_r,
+            "seconds_per_iteration_scaled": t_iter, "roofline": None, "cpu_baseline": None,
+            "note": "compatibility form: one launch per image-phase and host staging at every call; the native driver "
+                    "(thx_refine_iterate) is the product path and the headline"}
+
+
 def refinement_line(args, dev, rank, world, box, particles, steps, warmup, batch, cpu=True, cpu_particles=0):
     """one refinement configuration through the native driver -> the result dict (rank 0; None on the other ranks)"""
     import torch
@@ -514,7 +655,6 @@ def refinement_line(args, dev, rank, world, box, particles, steps, warmup, batch
         nPxl, nPxlM = st.nPxl, st.nPxlM
         ins_ms = st.insertMs / max(1, st.insertLaunches)
         ins_n = st.insertImages / max(1, st.insertLaunches)
-        ins_bytes = ins_n * shard.mReco * nPxlM * INSERT_BYTES_PER_PIXEL_SAMPLE
         exp_ms = st.expectMs / max(1, st.expectLaunches)
         exp_n = st.expectImages / max(1, st.expectLaunches)
         exp_bytes = exp_n * nPxl * (EXPECT_BYTES_PER_PIXEL + EXPECT_BYTES_PER_PIXEL_SAMPLE * shard.mLR)
@@ -527,12 +667,15 @@ def refinement_line(args, dev, rank, world, box, particles, steps, warmup, batch
         # HBM traffic of that kernel from the committed PMC profile (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes,
         # FETCH_SIZE calibrated on a known-byte-count 64-byte gather in the same passes -- tools/pmc_traffic.sh), scaled
         # to this run's images per launch; null if absent
-        traffic, pmc_src = None, None
+        traffic, pmc_src, pmc_blob = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         lds_rate64 = None
         if os.path.exists(pmc):
             try:
-                j = json.load(open(pmc))
+                import hashlib
+                raw = open(pmc, "rb").read()
+                pmc_blob = hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest()      # = `git hash-object profiles/pmc_traffic.json`
+                j = json.loads(raw)
                 lds_rate64 = j.get("lds_add_u64_per_s")
                 per_box = j.get("per_box", {}).get(str(box))
                 if per_box:
@@ -571,14 +714,16 @@ def refinement_line(args, dev, rank, world, box, particles, steps, warmup, batch
                                       "native RCCL (thx_reco_allreduce_acc_class, ncclInt64)" % world},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kms,
-                         "images_per_launch": exp_n, "algorithmic_bytes_per_launch": kbytes, "traffic_source": pmc_src},
+                         "images_per_launch": exp_n, "algorithmic_bytes_per_launch": kbytes, "traffic_source": pmc_src,
+                         # PMC passes cannot ride in a timed run: `traffic` is the per-image-phase figure of the committed profile
+                         # (separate rocprofv3 --pmc passes over this same workload, tools/pmc_traffic.sh) scaled to this run's launch
+                         "traffic_measured_in_run": False, "traffic_profile": "profiles/pmc_traffic.json", "traffic_profile_git_blob": pmc_blob},
             "kernels": {"insertion (k_bin + segment sort + k_acc)": {
                             "avg_call_ms": ins_ms, "images_per_call": ins_n, "total_ms": t_ins,
                             "groups_per_image": groups_per_image, "us_per_image": ins_ms * 1e3 / max(1.0, ins_n),
                             "records_per_s": ins_records_per_s, "lds_adds_u64_per_s": ins_terms_per_s,
                             "lds_add_frac": (ins_terms_per_s / lds_rate64) if lds_rate64 else None,
-                            "record_GBps_written_plus_read": ins_records_per_s * 56 / 1e9,
-                            "GBps_algorithmic_204B_per_draw": ins_bytes / (ins_ms * 1e-3) / 1e9},
+                            "record_GBps_written_plus_read": ins_records_per_s * 56 / 1e9},
                         "k_expect_local": {"avg_launch_ms": exp_ms, "images_per_launch": exp_n,
                                            "GBps_algorithmic": exp_bytes / (exp_ms * 1e-3) / 1e9, "total_ms": t_exp}},
             "stages_ms_per_step": {k: round(st.stageMs[i] / steps, 2) for i, k in enumerate(STAGES)},
@@ -635,7 +780,13 @@ def main():
     ap.add_argument("--scan-only", action="store_true", help="with --classification: the global scanning stage on its own")
     ap.add_argument("--scan-images", type=int, default=0, help="images of the classification bench (default 6250 = 50 000 / 8 GPUs; 1024 with --scan-only)")
     ap.add_argument("--scan-cpu-images-per-core", type=int, default=2)
+    ap.add_argument("--config0-small", action="store_true", help="--config0 on toy sizes (tests)")
     ap.add_argument("--config0", action="store_true", help="BASELINE configs[0] on its own: script/demo_3D.json's run (K = 4, C4, global then local search) on 1 000 x 128^3 particles")
+    ap.add_argument("--staged", action="store_true", help="time the drop-in path instead: the per-image / per-stage thx_*_host entry points of the "
+                    "reference's plug-in surface on a sample of configs[1] (see bench_staged)")
+    ap.add_argument("--staged-images", type=int, default=2048)
+    ap.add_argument("--staged-threads", type=int, default=8)
+    ap.add_argument("--staged-insert-batch", type=int, default=512)
     ap.add_argument("--other-configs", choices=("auto", "on", "off"), default="auto",
                     help="after the headline line, also run BASELINE configs[1] (10 000 x 256^3), configs[3] (one GPU's share of the K = 4 "
                          "classification) and configs[4] (20 000 x 512^3) for 2 + 1 iterations each and report them under `other_configs` of the "
@@ -658,7 +809,12 @@ def main():
     capi.load()
 
     if args.config0:
-        print(json.dumps(bench_config0(args, dev)))
+        print(json.dumps(bench_config0(args, dev, small=args.config0_small)))
+        return
+    if args.staged:
+        if args.particles == 100000:
+            args.particles = 10000      # configs[1]
+        print(json.dumps(bench_staged(args, dev)))
         return
     if args.classification:
         if not args.scan_images:
@@ -674,35 +830,42 @@ def main():
     others = args.other_configs == "on" or (args.other_configs == "auto" and headline and world == 1)
     if others and world == 1:
         # the other BASELINE configs, driver-visible: 2 timed iterations after 1 warm-up each, every line with its own roofline and
-        # cpu_baseline (bounded samples)
+        # cpu_baseline (bounded samples).  Each runs in its OWN process, after this one has given its device memory back: a fresh
+        # allocator state per configuration (round 4's in-process run timed the 512^3 E-step launch 5 % slower than the standalone
+        # command: 34 GB of cell-packed volume allocated into a heap the earlier configurations had fragmented), and a failure there
+        # cannot cost the headline line, which is already measured.
+        import gc
+        import subprocess
+        from thunder_amd.capi import stream_ptr
+        gc.collect()
+        torch.cuda.synchronize()
+        capi.call("thx_release_stream", stream_ptr())
+        torch.cuda.empty_cache()
         oc = {}
         t0 = time.perf_counter()
         small = os.environ.get("THX_BENCH_SMALL_OTHERS") == "1"     # (tests/test_next_gpu.py: the same code path on toy sizes)
         b1, n1, b3, n3, b4, n4 = (32, 300, 64, 96, 64, 200) if small else (256, 10000, 256, 6250, 512, 20000)
-        a3 = argparse.Namespace(**vars(args))
-        a3.box, a3.scan_images, a3.steps, a3.warmup, a3.cpu_particles = b3, n3, 2, 1, 0
-
-        def between():
-            # everything the previous configuration left on the device goes: torch's cache and the library's per-stream scratch
-            # (the insertion's record buffers alone are 32 GiB; the 512^3 job needs the whole GPU)
-            import gc
-            from thunder_amd.capi import stream_ptr
-            gc.collect()
-            torch.cuda.synchronize()
-            capi.call("thx_release_stream", stream_ptr())
-            torch.cuda.empty_cache()
-        for name, run in (("configs[0] script/demo_3D.json as specified", lambda: bench_config0(args, dev, small)),
-                          ("configs[1] %d x %d^3 refinement" % (n1, b1),
-                           lambda: refinement_line(args, dev, 0, 1, b1, n1, 2, 1, args.batch, cpu=True, cpu_particles=256)),
-                          ("configs[3] K=4 classification, one GPU's share (%d of 50k images)" % n3, lambda: bench_classification_iteration(a3, dev)),
-                          ("configs[4] %d x %d^3 refinement" % (n4, b4),
-                           lambda: refinement_line(args, dev, 0, 1, b4, n4, 2, 1, args.batch, cpu=True, cpu_particles=64))):
-            between()
-            try:    # (a failure here must not cost the headline line, which is already measured)
-                oc[name] = run()
+        common = ["--mLR", str(args.mLR), "--mLT", str(args.mLT), "--phases", str(args.phases), "--mReco", str(args.mReco), "--batch", str(args.batch),
+                  "--wg-per-cu", str(args.wg_per_cu), "--cpu-groups", str(args.cpu_groups), "--other-configs", "off"]
+        if args.no_cpu_baseline:
+            common.append("--no-cpu-baseline")
+        runs = (("configs[0] script/demo_3D.json as specified", ["--config0"] + (["--config0-small"] if small else [])),
+                ("configs[1] %d x %d^3 refinement" % (n1, b1), ["--box", str(b1), "--particles", str(n1), "--steps", "2", "--warmup", "1", "--cpu-particles", "256"]),
+                ("configs[3] K=4 classification, one GPU's share (%d of 50k images)" % n3,
+                 ["--classification", "--box", str(b3), "--scan-images", str(n3), "--steps", "2", "--warmup", "1"]),
+                ("configs[4] %d x %d^3 refinement" % (n4, b4), ["--box", str(b4), "--particles", str(n4), "--steps", "2", "--warmup", "1", "--cpu-particles", "64"]))
+        if not small:
+            runs += (("configs[1] through the reference's plug-in surface (staged drop-in path)", ["--staged"]),)
+        for name, extra in runs:
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__)] + common + extra, capture_output=True, text=True, timeout=3600)
+                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode != 0 or not lines:
+                    oc[name] = {"error": "exit %d: %s" % (r.returncode, r.stderr[-300:])}
+                else:
+                    oc[name] = json.loads(lines[-1])
             except Exception as e:      # noqa: BLE001
                 oc[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-        between()
         out["other_configs"] = oc
         out["other_configs_wall_s"] = round(time.perf_counter() - t0, 1)
     if rank == 0:

@@ -7,6 +7,10 @@
 #pragma once
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "../thunder_amd.h"
@@ -83,6 +87,41 @@ public:
                  unsigned int /*nThread*/ = 1) const
     {
         projectBatch(dst, mat, 1, iCol, iRow, nPxl);
+    }
+
+    // The reference's OWN call syntax (include/Projector.h:293-299): `proj.project(priP, rot, _iCol, _iRow, _nPxl, nThread)` with
+    // the reference's `Complex*` and Eigen's `dmat33` (src/Optimiser.cpp:775-781,1294-1308) compiles against this overload -- any
+    // 8-byte complex type and any 3 x 3 matrix of doubles with a column-major .data() (Eigen's default) are taken as they are.
+    template <class C, class M, class = decltype(std::declval<const M&>().data())>
+    void project(C* dst, const M& mat, const int* iCol, const int* iRow, int nPxl, unsigned int nThread = 1) const
+    {
+        static_assert(sizeof(C) == 2 * sizeof(float), "dst must be a single-precision complex type (RFLOAT = float)");
+        static_assert(sizeof(M) == 9 * sizeof(double), "mat must be a 3 x 3 matrix of doubles");
+        project(reinterpret_cast<Complex*>(dst), static_cast<const double*>(mat.data()), iCol, iRow, nPxl, nThread);
+    }
+
+    // project(Image& dst, const dmat33& mat, nThread), include/Projector.h:257-268, src/Projector.cpp:274-292: every pixel of the
+    // half-plane with i^2 + j^2 < maxRadius^2 (IMAGE_FOR_PIXEL_R_FT(_maxRadius)) is set through Image::setFT; the rest of dst is
+    // left as it is.  dstFT = the image's Fourier half [N][N/2+1] in the reference's layout (row j < 0 at j + N).  What
+    // appsrc/thunder_project.cpp:146-236 calls.
+    template <class C>
+    void projectImage(C* dstFT, int N, const double* mat, unsigned int /*nThread*/ = 1) const
+    {
+        static_assert(sizeof(C) == 2 * sizeof(float), "dstFT must be a single-precision complex type");
+        std::vector<int> iCol, iRow, iPxl;
+        const int r = _maxRadius;
+        for (int j = -r; j < r; j++)
+            for (int i = 0; i <= r; i++)
+                if (i * i + j * j < r * r) { iCol.push_back(i); iRow.push_back(j); iPxl.push_back((j >= 0 ? j : j + N) * (N / 2 + 1) + i); }
+        std::vector<Complex> row(iCol.size());
+        projectBatch(row.data(), mat, 1, iCol.data(), iRow.data(), (int)iCol.size());
+        for (size_t p = 0; p < iCol.size(); p++) std::memcpy(&dstFT[iPxl[p]], &row[p], sizeof(Complex));
+    }
+    template <class C, class M, class = decltype(std::declval<const M&>().data())>
+    void projectImage(C* dstFT, int N, const M& mat, unsigned int nThread = 1) const
+    {
+        static_assert(sizeof(M) == 9 * sizeof(double), "mat must be a 3 x 3 matrix of doubles");
+        projectImage(dstFT, N, static_cast<const double*>(mat.data()), nThread);
     }
 
     // nR matrices at once (what ExpectProject does, Interface.h:210-219): dst [nR][nPxl]

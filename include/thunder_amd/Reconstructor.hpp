@@ -62,6 +62,7 @@ public:
         if (_T) thx_free_dev(_T);
         if (_iCol) thx_free_dev(_iCol);
         if (_iRow) thx_free_dev(_iRow);
+        for (int i = 0; i < kStage; i++) { if (_stage[i]) thx_free_dev(_stage[i]); _stage[i] = nullptr; _stageCap[i] = 0; }
         _plan = nullptr; _F = _T = nullptr; _iCol = _iRow = nullptr;
     }
     void resizeSpace(int size) { _size = size; }   // src/Reconstructor.cpp:162-176 (allocSpace must follow)
@@ -127,29 +128,65 @@ public:
         insertBatch(src, ctf, &w, rot, zero2, 1, 1);
     }
 
+    // The reference's OWN call syntax (include/Reconstructor.h:610): `reco.insertP(transImgP, ctfP, rot, w[, sig])` with the
+    // reference's `Complex*`, `RFLOAT*`, Eigen's `dmat33`, `const vec*` (src/Optimiser.cpp:7129-7232) compiles against this overload.
+    template <class C, class M, class V = void, class = decltype(std::declval<const M&>().data())>
+    void insertP(const C* src, const float* ctf, const M& rot, float w, const V* /*sig*/ = nullptr)
+    {
+        static_assert(sizeof(C) == 2 * sizeof(float), "src must be a single-precision complex type (RFLOAT = float)");
+        static_assert(sizeof(M) == 9 * sizeof(double), "rot must be a 3 x 3 matrix of doubles");
+        insertP(reinterpret_cast<const Complex*>(src), ctf, static_cast<const double*>(rot.data()), w);
+    }
+
+    // insert(const Image& src, const Image& ctf, const dmat33& rot, RFLOAT w), src/Reconstructor.cpp:493-567 (what
+    // appsrc/thunder_reconstruct.cpp:194-284 calls): EVERY pixel of the Fourier half [N][N/2+1] with i^2 + j^2 < maxRadius^2
+    // (IMAGE_FOR_EACH_PIXEL_FT -- column i = 0 with both signs of j, unlike the pixel list of allocPreCalIdx) adds
+    // src * Re(ctf) * w to F and Re(ctf)^2 * w to T.  srcFT / ctfFT in the reference's layout (row j < 0 at j + N).
+    template <class C>
+    void insert(const C* srcFT, const C* ctfFT, int N, const double* rot, float w)
+    {
+        static_assert(sizeof(C) == 2 * sizeof(float), "the images must be single-precision complex");
+        if (N != _size) { std::fprintf(stderr, "thunder_amd FATAL: INCORRECT SIZE OF INSERTING IMAGE\n"); std::abort(); }
+        std::vector<int> iCol, iRow;
+        std::vector<Complex> dat;
+        std::vector<float> ctf;
+        const float* s = reinterpret_cast<const float*>(srcFT);
+        const float* c = reinterpret_cast<const float*>(ctfFT);
+        for (int j = -N / 2; j < N / 2; j++)
+            for (int i = 0; i <= N / 2; i++)
+                if (i * i + j * j < _maxRadius * _maxRadius) {
+                    const size_t e = (size_t)(j >= 0 ? j : j + N) * (N / 2 + 1) + i;
+                    iCol.push_back(i); iRow.push_back(j);
+                    Complex v; v.dat[0] = s[2 * e]; v.dat[1] = s[2 * e + 1];
+                    dat.push_back(v);
+                    ctf.push_back(c[2 * e]);
+                }
+        std::lock_guard<std::mutex> g(_stageMtx);
+        const int n = (int)iCol.size();
+        int* dIdx = (int*)stage(5, 2 * (size_t)n * sizeof(int));
+        THX_ABORT_ON(thx_memcpy_h2d(dIdx, iCol.data(), n * sizeof(int)));
+        THX_ABORT_ON(thx_memcpy_h2d(dIdx + n, iRow.data(), n * sizeof(int)));
+        const double zero2[2] = {0, 0};
+        insert_staged(dat.data(), ctf.data(), &w, rot, zero2, 1, 1, dIdx, dIdx + n, n);
+    }
+    template <class C, class M, class = decltype(std::declval<const M&>().data())>
+    void insert(const C* srcFT, const C* ctfFT, int N, const M& rot, float w)
+    {
+        static_assert(sizeof(M) == 9 * sizeof(double), "rot must be a 3 x 3 matrix of doubles");
+        insert(srcFT, ctfFT, N, static_cast<const double*>(rot.data()), w);
+    }
+
     // nImg images x mReco draws in one launch (InsertFT): datP [nImg][nPxl] untranslated rows, rot [nImg][mReco][9],
-    // tran [nImg][mReco][2] (the image is shifted by -tran on the device), w [nImg] (already divided by mReco)
+    // tran [nImg][mReco][2] (the image is shifted by -tran on the device), w [nImg] (already divided by mReco).
+    // Staging: grow-only device buffers owned by the object (no hipMalloc / hipFree and no device-wide synchronisation per call:
+    // the blocking host-to-device copies of the NEXT call are ordered behind this call's kernels on the same stream); calls from
+    // several host threads -- the reference inserts from an OpenMP loop -- are serialised on the staging buffers.
     void insertBatch(const Complex* datP, const float* ctfP, const float* w, const double* rot, const double* tran,
                      int nImg, int mReco)
     {
         if (!_F || !_iCol) { std::fprintf(stderr, "thunder_amd FATAL: allocSpace/setPreCal not called\n"); std::abort(); }
-        void *dDat, *dCtf, *dW, *dRot, *dTran;
-        const size_t nd = (size_t)nImg * mReco;
-        THX_ABORT_ON(thx_malloc_dev(&dDat, (size_t)nImg * _nPxl * 2 * sizeof(float)));
-        THX_ABORT_ON(thx_malloc_dev(&dCtf, (size_t)nImg * _nPxl * sizeof(float)));
-        THX_ABORT_ON(thx_malloc_dev(&dW, nImg * sizeof(float)));
-        THX_ABORT_ON(thx_malloc_dev(&dRot, nd * 9 * sizeof(double)));
-        THX_ABORT_ON(thx_malloc_dev(&dTran, nd * 2 * sizeof(double)));
-        THX_ABORT_ON(thx_memcpy_h2d(dDat, datP, (size_t)nImg * _nPxl * 2 * sizeof(float)));
-        THX_ABORT_ON(thx_memcpy_h2d(dCtf, ctfP, (size_t)nImg * _nPxl * sizeof(float)));
-        THX_ABORT_ON(thx_memcpy_h2d(dW, w, nImg * sizeof(float)));
-        THX_ABORT_ON(thx_memcpy_h2d(dRot, rot, nd * 9 * sizeof(double)));
-        THX_ABORT_ON(thx_memcpy_h2d(dTran, tran, nd * 2 * sizeof(double)));
-        THX_ABORT_ON(thx_insert_dev(_F, _T, nullptr, nullptr, _pf * _size, 1, (const float*)dDat, (const float*)dCtf,
-                                    (const float*)dW, (const double*)dRot, (const double*)dTran, nullptr, nullptr, nullptr,
-                                    nullptr, 0, 1.0f, _iCol, _iRow, _pf, _nPxl, mReco, _N, nImg, nullptr));
-        THX_ABORT_ON(thx_device_sync());
-        thx_free_dev(dDat); thx_free_dev(dCtf); thx_free_dev(dW); thx_free_dev(dRot); thx_free_dev(dTran);
+        std::lock_guard<std::mutex> g(_stageMtx);
+        insert_staged(datP, ctfP, w, rot, tran, nImg, mReco, _iCol, _iRow, _nPxl);
     }
 
     // ---- members of the -DGPU_VERSION build (include/Reconstructor.h:611-659, 676-680) ----
@@ -257,6 +294,35 @@ public:
     }
 
 private:
+    enum { kStage = 6 };
+    void* stage(int slot, size_t bytes)   // (under _stageMtx)
+    {
+        if (bytes > _stageCap[slot]) {
+            if (_stage[slot]) { THX_ABORT_ON(thx_device_sync()); thx_free_dev(_stage[slot]); }
+            const size_t cap = bytes + bytes / 2 + 256;
+            THX_ABORT_ON(thx_malloc_dev(&_stage[slot], cap));
+            _stageCap[slot] = cap;
+        }
+        return _stage[slot];
+    }
+    void insert_staged(const Complex* datP, const float* ctfP, const float* w, const double* rot, const double* tran, int nImg, int mReco,
+                       const int* dCol, const int* dRow, int nPxl)
+    {
+        const size_t nd = (size_t)nImg * mReco;
+        void* dDat = stage(0, (size_t)nImg * nPxl * 2 * sizeof(float));
+        void* dCtf = stage(1, (size_t)nImg * nPxl * sizeof(float));
+        void* dW = stage(2, nImg * sizeof(float));
+        void* dRot = stage(3, nd * 9 * sizeof(double));
+        void* dTran = stage(4, nd * 2 * sizeof(double));
+        THX_ABORT_ON(thx_memcpy_h2d(dDat, datP, (size_t)nImg * nPxl * 2 * sizeof(float)));
+        THX_ABORT_ON(thx_memcpy_h2d(dCtf, ctfP, (size_t)nImg * nPxl * sizeof(float)));
+        THX_ABORT_ON(thx_memcpy_h2d(dW, w, nImg * sizeof(float)));
+        THX_ABORT_ON(thx_memcpy_h2d(dRot, rot, nd * 9 * sizeof(double)));
+        THX_ABORT_ON(thx_memcpy_h2d(dTran, tran, nd * 2 * sizeof(double)));
+        THX_ABORT_ON(thx_insert_dev(_F, _T, nullptr, nullptr, _pf * _size, 1, (const float*)dDat, (const float*)dCtf,
+                                    (const float*)dW, (const double*)dRot, (const double*)dTran, nullptr, nullptr, nullptr,
+                                    nullptr, 0, 1.0f, dCol, dRow, _pf, nPxl, mReco, _N, nImg, nullptr));
+    }
     size_t nVox() const { const size_t P = (size_t)_pf * _size; return P * P * (P / 2 + 1); }
     void defaults()
     {
@@ -284,7 +350,9 @@ private:
     std::vector<float> _FSC;
     AllReduce _allreduce;
     thx_comm* _hemi = nullptr;
-    std::mutex _mtx;
+    std::mutex _mtx, _stageMtx;
+    void* _stage[kStage] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t _stageCap[kStage] = {0, 0, 0, 0, 0, 0};
 };
 
 }  // namespace thunder_amd

@@ -121,6 +121,40 @@ int main()
         std::fprintf(stderr, "insertI/reconstructG vs insertP/reconstruct: max diff %.3g of %.3g\n", dmax, omax);
         if (!(dmax <= 1e-4 * omax)) { std::printf("FAIL insertI path differs %.3g\n", dmax); return 4; }
     }
+    // the Image forms the reference's own functional harness uses: projector.project(image, rot, nThread)
+    // (appsrc/thunder_project.cpp:146-236) -> reconstructor.insert(image, ctf, rot, 1) (appsrc/thunder_reconstruct.cpp:194-284)
+    // on whole Fourier half-images [N][N/2+1]; against the map again, and slice by slice against the pixel-list path
+    {
+        const int nc = N / 2 + 1;
+        Reconstructor reco3(1, N, N, pf, nullptr, 0, 1.9f, 15.0f);
+        reco3.setMaxRadius(rU);
+        reco3.allocSpace(1);
+        proj.setMaxRadius(rU);
+        std::vector<Complex> img((size_t)N * nc), ctfImg((size_t)N * nc);
+        for (Complex& c : ctfImg) { c.dat[0] = 1.0f; c.dat[1] = 0.0f; }
+        double worst = 0;
+        for (int l = 0; l < nImg; l++) {
+            for (Complex& c : img) { c.dat[0] = 0.f; c.dat[1] = 0.f; }
+            proj.projectImage(img.data(), N, &rot[(size_t)l * 9], 1);
+            if (l < 4)   // the same values as the pixel-list slices where both are defined (the list cuts at AROUND(NORM) < rU)
+                for (int p = 0; p < nPxl; p++) {
+                    const Complex a = img[(size_t)(iRow[p] >= 0 ? iRow[p] : iRow[p] + N) * nc + iCol[p]], b = slices[(size_t)l * nPxl + p];
+                    worst = std::fmax(worst, std::fmax(std::fabs((double)a.dat[0] - b.dat[0]), std::fabs((double)a.dat[1] - b.dat[1])));
+                }
+            reco3.insert(img.data(), ctfImg.data(), N, &rot[(size_t)l * 9], 1.0f);
+        }
+        if (worst != 0) { std::printf("FAIL project(Image) differs from project(Complex*) by %.3g\n", worst); return 5; }
+        reco3.prepareTF(1);
+        reco3.setMAP(false);
+        reco3.setGridCorr(true);
+        std::vector<float> out3((size_t)N * N * N);
+        reco3.reconstruct(out3.data(), 1);
+        double ab = 0, aa = 0, bb = 0;
+        for (size_t i = 0; i < out3.size(); i++) { ab += (double)out3[i] * ref[i]; aa += (double)out3[i] * out3[i]; bb += (double)ref[i] * ref[i]; }
+        const double cc3 = ab / std::sqrt(aa * bb);
+        std::fprintf(stderr, "project(Image) -> insert(Image) -> reconstruct: correlation %.5f\n", cc3);
+        if (!(cc3 > 0.99)) { std::printf("FAIL image-form round trip %.5f\n", cc3); return 6; }
+    }
     std::printf("OK %.5f\n", cc);
     return 0;
 }

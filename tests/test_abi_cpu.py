@@ -3,6 +3,9 @@
 import ctypes
 import os
 import re
+import subprocess
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -146,3 +149,16 @@ def test_ctypes_struct_mirrors_match_the_header(tmp_path):
         assert tok[0] == cname
         want = [C.sizeof(cls)] + [getattr(cls, f).offset for f, _ in cls._fields_]
         assert [int(x) for x in tok[1:]] == want, (cname, tok[1:], want)
+
+
+def test_boundary_lint_against_reference_headers():
+    """tools/boundary_lint.sh: `g++ -fsyntax-only` of the reference-side files (integration/Interface_thx.cpp -- the replacement of
+    gpu/interface/Interface.cpp -- and integration/callsite_lint.cpp -- the CPU build's hot-path calls in the reference's own types
+    against include/thunder_amd/*.hpp) against the reference's UNCHANGED headers.  A lint of the boundary, not parity evidence; runs
+    where the reference tree is present (the build container), skipped on the GPU box."""
+    import shutil
+    if not os.path.isdir("/root/reference/gpu/interface") or shutil.which("g++") is None:
+        pytest.skip("no reference tree / g++ here")
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "boundary_lint.sh"), "/root/reference"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert out.stdout.count("exit 0") == 2, out.stdout[-2000:]

@@ -121,3 +121,41 @@ def test_pixel_visit_order_is_a_local_permutation(monkeypatch):
         assert np.median(step) <= 1.5 and np.mean(step) < 4.0
     monkeypatch.setenv("THX_TILE_ORDER", "0")
     assert pixel_visit_order(pl, N) is None
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_half_part_deals_a_one_rank_job(world):
+    """refine.half_part: the contiguous part of the ONE-RANK layout ([0, ceil(n / 2)) = half 0, the rest = half 1) that rank r of
+    `world` holds -- rank r is in half r mod 2 (src/Parallel.cpp:26-36) and is rank r // 2 inside it; the parts of a half tile it
+    exactly, in rank order, so that a shard's image numbering (thx_refine_set_image_base) is the one-rank run's.  The owner of class
+    k of half h (thx_refine.hip: owner_in_half) is world rank 2 (k mod ranks of the half) + h, which must be a rank of that half."""
+    sys.path.insert(0, ROOT)
+    from thunder_amd.refine import half_part
+    for n in (7, 240, 384, 100000):
+        nA = (n + 1) // 2
+        seen = np.zeros(n, np.int32)
+        for h in (0, 1):
+            if world == 1 and h == 1:
+                continue
+            ranks = [r for r in range(world) if r % 2 == h] if world > 1 else [0]
+            edge = 0 if h == 0 else nA
+            for r in ranks:
+                lo, hi = half_part(n, r, world)
+                if world == 1:
+                    assert (lo, hi) == (0, n)
+                    seen[lo:hi] += 1
+                    continue
+                assert lo == edge and hi >= lo, (n, r, lo, hi, edge)     # contiguous, in rank order
+                assert (lo >= nA) == (h == 1) or hi == lo
+                edge = hi
+                seen[lo:hi] += 1
+            if world > 1:
+                assert edge == (nA if h == 0 else n)
+        if world > 1 or True:
+            assert np.all(seen == 1), (n, world)
+    for h in (0, 1):
+        H = (world - h + 1) // 2 if world > 1 else 1
+        for k in range(6):
+            owner = 2 * ((k % H) if H > 1 else 0) + h
+            if world > 1 and H > 0:
+                assert owner < world and owner % 2 == h

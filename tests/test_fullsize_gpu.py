@@ -476,6 +476,11 @@ def test_reconstruct_vs_oracle_p1024(oracle, dev):
     Tt = (1.0 / (1.0 + r / 8.0)).to(torch.float32).contiguous()
     Tt[r >= rU * 2 + 1] = 0
     del r
+    # (a white component on top of the blobs' transform: every shell up to rU carries signal, so that the per-shell FSC below compares
+    # maps and not the rounding noise of empty shells)
+    g = torch.Generator(device=dev).manual_seed(1024)
+    amp = float(vol.abs()[:8, :8, :8].mean()) * 1e-3
+    vol += torch.view_as_complex(torch.randn(vol.shape + (2,), generator=g, device=dev, dtype=torch.float32)) * amp
     F = (vol * Tt).contiguous()
     del vol
     fsc = np.clip(1.2 - np.arange(rU) / (0.6 * rU), 0.02, 1.0).astype(np.float32)

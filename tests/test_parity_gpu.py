@@ -804,6 +804,34 @@ def test_expect_local_split_form_is_bit_identical(oracle, dev, knob_env):
     knob_env("THX_EXPECT_SPLIT", None)
 
 
+def test_expect_local_cloud_order_is_bit_identical(oracle, dev, knob_env):
+    """THX_EXPECT_ORDER: lane <-> rotation of the local-search kernel follows a ranking of every image's cloud (k_cloud_order: by
+    the in-plane angle -- the default -- or one of the two tilt components); results go back to the rotation's own place, so every
+    weight and every log-likelihood is bit-identical to the storage order (0), for tight clouds, wide ones, a cloud of identical
+    rotations (all keys tie) and 70 / 125 / 200 rotations (one partial wave, two, four)"""
+    from thunder_amd import ops, synth
+    O = oracle
+    rng = np.random.default_rng(79)
+    N, P, nImg, nT = 64, 128, 6, 9
+    ref, vol, pl = make_case(O, N, rL=2)
+    im = make_images(O, vol, pl, N, nImg, rng)
+    spread = np.array([0.005, 0.02, 0.05, 0.2, 1.0, 0.0])
+    cells = ops.pack_projector(T(vol, dev)[None].contiguous(), P)
+    for nR in (70, 125, 200):
+        q = np.stack([synth.perturb_quats(im["quat"][l:l + 1], nR, spread[l], rng)[0] for l in range(nImg)])
+        rot = ops.rotmat(T(q.reshape(-1, 4), dev)).reshape(nImg, nR, 9)
+        tr = T(im["shift"][:, None, :] + rng.normal(0, 0.7, size=(nImg, nT, 2)), dev)
+        args = (P, 2, N, T(pl["iCol"], dev), T(pl["iRow"], dev), T(im["dat"], dev), T(im["ctf"], dev), T(im["sigRcp"], dev), rot, tr)
+        knob_env("THX_EXPECT_ORDER", "0")
+        a = ops.expect_local(cells, *args, want_logW=True, packed=True)
+        for m in ("1", "2", "3"):
+            knob_env("THX_EXPECT_ORDER", m)
+            b = ops.expect_local(cells, *args, want_logW=True, packed=True)
+            for k in ("wR", "wT", "wC", "baseLine", "logW"):
+                assert torch.equal(getattr(a, k), getattr(b, k)), (nR, m, k)
+    knob_env("THX_EXPECT_ORDER", None)
+
+
 def test_full_size_properties_n512(oracle, dev):
     """BASELINE config (4): 512^3 box (P = 1024, nPxl = 100941; 4.3 GB projector, 34 GB cell-packed, element offsets
     above 2^32).  Slices bit-exact against the oracle, packed == unpacked E-step, insertion mass / linearity, and a
@@ -912,9 +940,10 @@ def test_hand_fft_passes_match_rocfft(dev, knob_env, N):
     F = (vol * Tt).contiguous()
     fscv = np.clip(np.linspace(1.0, 0.1, N // 2), 0, 1).astype(np.float32)
     out = {}
-    for mode in ("rocfft", "hand", "hand_natural"):
+    for mode in ("rocfft", "hand", "hand_natural", "hand_hoststop"):
         knob_env("THX_FFT", "rocfft" if mode == "rocfft" else None)
         knob_env("THX_RECO_WT", "natural" if mode == "hand_natural" else None)
+        knob_env("THX_RECO_STOP", "host" if mode == "hand_hoststop" else None)
         m = plan.reconstruct(F.clone(), Tt.clone(), N // 2 - 2, FSC=fscv, MAP=True, gridCorr=True)
         out[mode] = (m, plan.last_iters, plan.last_diffC)
     (ma, ia, da), (mb, ib, db) = out["rocfft"], out["hand"]
@@ -923,6 +952,11 @@ def test_hand_fft_passes_match_rocfft(dev, knob_env, N):
     # W / T tiled by z column for the loop (the default) or in the volume's layout: the same arithmetic, bit for bit
     mc, ic, dc = out["hand_natural"]
     assert ic == ib and dc == db and torch.equal(mc, mb)
+    # the stop rule evaluated on the device (default: every round queued, the rounds after the stop fall through) or on the host
+    # with one read-back per round: the same round count, the same bits
+    md, id_, dd = out["hand_hoststop"]
+    assert id_ == ib and dd == db and torch.equal(md, mb)
+    knob_env("THX_RECO_STOP", None)
     plan.close()
 
 

@@ -56,8 +56,9 @@ struct Knobs {
     bool expectNdSweep;   // THX_EXPECT_ND=sweep: one launch per defocus factor instead of the fused kernel
     float expectSplit;    // THX_EXPECT_SPLIT=m: the near-slab / tail form of the local-search kernel (samples within m voxels of the cloud's
                           // mean slab are fetched one pixel ahead); 0 = the one-at-a-time form (default)
-    int expectOrder;      // THX_EXPECT_ORDER = 1 / 2 / 3: lane <-> rotation of the local-search kernel follows a ranking of the image's cloud by the
-                          // in-plane angle / the two tilt components relative to its first rotation (A/B; 0 = storage order; bit-identical results)
+    int expectOrder;      // THX_EXPECT_ORDER = 0 / 1 / 2 / 3: lane <-> rotation of the local-search kernel in storage order / following a ranking of the
+                          // image's cloud by the in-plane angle (default: -1.5 % per launch, round 5) / by one of the two tilt components, relative to
+                          // its first rotation; bit-identical results
     int expectWgLater;    // THX_EXPECT_WG_LATER: occupancy argument of the local-search kernel for phase indices >= 1 (-1 = as phase 0)
     bool scanSimple;      // THX_SCAN=simple: the rotation-per-thread global-scan kernel for every size (A/B)
     int scanTile;         // THX_SCAN=t42 / t24 / t44: wave tiles of the scan contraction (A/B; default 2 x 2)

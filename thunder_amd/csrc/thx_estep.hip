@@ -35,7 +35,7 @@ static Knobs read_knobs()
     v.expectNdSweep = e && e[0] == 's';
     v.expectSplit = 0.f;
     if ((e = getenv("THX_EXPECT_SPLIT"))) v.expectSplit = (float)atof(e);
-    v.expectOrder = 0;
+    v.expectOrder = 1;
     if ((e = getenv("THX_EXPECT_ORDER"))) v.expectOrder = atoi(e);
     v.expectWgLater = -1;
     if ((e = getenv("THX_EXPECT_WG_LATER"))) v.expectWgLater = atoi(e);
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_pack_cells(float4* __restrict__ cells, 
     cells[e] = make_float4(a.x, a.y, b.x, b.y);
 }
 
-// Ordering of an image's cloud of rotations for the lane <-> rotation mapping of k_expect_local (A/B, THX_EXPECT_ORDER).
+// Ordering of an image's cloud of rotations for the lane <-> rotation mapping of k_expect_local (THX_EXPECT_ORDER; default 1).
 // A listed pixel p = (x, y, 0) under R_i = R_0 d_i, d_i ~ 1 + [w_i]x, lands at R_0 (p + w_i x p): in the slice's own frame the
 // cloud of one pixel is spread by w_z (-y, x) IN the plane and by (w_x y - w_y x) off it.  Ranking the rotations by one of
 // the three components of w puts each of the kernel's 64-rotation waves on one half of the cloud along that direction.
