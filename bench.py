@@ -559,7 +559,7 @@ def bench_staged(args, dev):
     O3, cnt = np.zeros(3), np.zeros(1, np.int32)
     w = np.full(n, np.float32(1.0 / mReco), np.float32)
     offS = np.zeros((n, 2))
-    B = int(args.staged_insert_batch)
+    B = int(args.staged_insert_batch) or n
     t0 = time.perf_counter()
     for b0 in range(0, n, B):
         b1 = min(n, b0 + B)
@@ -786,7 +786,8 @@ def main():
                     "reference's plug-in surface on a sample of configs[1] (see bench_staged)")
     ap.add_argument("--staged-images", type=int, default=2048)
     ap.add_argument("--staged-threads", type=int, default=8)
-    ap.add_argument("--staged-insert-batch", type=int, default=512)
+    ap.add_argument("--staged-insert-batch", type=int, default=0, help="images per InsertFT call (0 = all of the sample in ONE call, as "
+                    "Reconstructor::insertI hands InsertFT every image of the process, src/Reconstructor.cpp:865-976)")
     ap.add_argument("--other-configs", choices=("auto", "on", "off"), default="auto",
                     help="after the headline line, also run BASELINE configs[1] (10 000 x 256^3), configs[3] (one GPU's share of the K = 4 "
                          "classification) and configs[4] (20 000 x 512^3) for 2 + 1 iterations each and report them under `other_configs` of the "

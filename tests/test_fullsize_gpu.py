@@ -428,13 +428,19 @@ def _expect_local_vs_oracle(O, dev, N, nImg, nR, nT, K, seed, spread):
         scale = np.abs(wl).max()
         e = np.abs(got - wl).max()
         print("expect_local N=%d K=%d image %d (class %d): |logW - oracle| %.2e of max|L|, oracle %.1f s" % (N, K, l, cls[l], e / scale, time.perf_counter() - t0))
-        assert e <= 1e-5 * scale, (e, scale)
+        # the oracle's (= the reference's scalar) SEQUENTIAL float sum drifts with the number of terms: 1e-5 max|L| is the bar the
+        # reference states between its own two summation orders (src/Optimiser.cpp:25-79) at the 24 742 pixels of a 256^3 box; a
+        # 512^3 box sums 100 941 terms (measured here: 1.1e-5), so the bar follows sqrt(terms).  What does NOT scale is the
+        # device's distance to the fp64 value of the same sum, held to 5e-7 |C| below -- and to the oracle's own distance.
+        bar = 1e-5 * max(1.0, np.sqrt(pl["nPxl"] / 24742.0))
+        assert e <= bar * scale, (e, scale, bar)
         Cabs = abs(float(np.sum(sig[l].astype(np.float64) * np.abs(dat[l].astype(np.complex128)) ** 2)))
         for (ir, it) in [(0, 0), (nR - 1, nT - 1), (nR // 2, 1)]:
             sl = O.project(vol_h[cls[l]], P, 2, rot_h[l, ir], pl["iCol"], pl["iRow"])
             ramp = O.translate(np.float32(tran_h[l, it, 0]), np.float32(tran_h[l, it, 1]), N, pl["iCol"], pl["iRow"])
             exact = O.logDataVSPrior_f64(dat[l], ramp * sl, ctf[l], sig[l])
             assert abs(got[it, ir] - exact) <= 5e-7 * Cabs, (got[it, ir], exact, Cabs)
+            assert abs(got[it, ir] - exact) <= abs(wl[it, ir] - exact) + 2e-7 * Cabs   # no worse than the reference's own sum
         tolw = max(2e-5 * scale, 1e-4)
         for name in ("wR", "wT", "wC"):
             g = getattr(res, name)[l].cpu().numpy().reshape(-1)
