@@ -1241,7 +1241,7 @@ class Iteration:
 
 class ClassifyStages:
     """The first three stages of one K-class classification iteration with a global search, chained as the reference runs them
-    (MODE_3D, C1, no CTF search), stage boundaries of thx_classify_iterate (thunder_amd/csrc/thx_classify.hip):
+    (MODE_3D, C1, no CTF search), stage boundaries of the native driver's global search (thunder_amd/csrc/thx_refine.hip:scan_and_select):
 
       scan      src/Optimiser.cpp:756-894    for every class k: slices of reference k at the nR scanned rotations (Projector::project at
                                              r = rScan), likelihood of every image at every (rotation, shift), weights and the running

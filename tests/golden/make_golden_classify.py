@@ -1,7 +1,9 @@
 """Generates tests/golden/classify_n16.npz -- REGRESSION vectors of the first three stages of a K-class classification iteration
 (scan weights, class of every image, support points of the local search) produced by this repo's own oracle
 (oracle/thunder_oracle.c through tests/_classify_util.py), NOT by the reference.  The CPU suite re-runs the
-oracle against them; the GPU suite runs thx_classify_iterate on the same inputs and compares (tests/test_classify_gpu.py).
+oracle against them (tests/test_pf_cpu.py); on the GPU the same stages of the native driver (thx_refine_iterate with THX_SEARCH_GLOBAL,
+thunder_amd/csrc/thx_refine.hip:scan_and_select) are held against the LIVE oracle chain (tests/test_iteration_gpu.py::
+test_classification_matches_oracle_chain), not against this file.
 
 Run from the repo root:  python tests/golden/make_golden_classify.py
 """

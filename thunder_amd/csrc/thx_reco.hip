@@ -635,6 +635,14 @@ static int balance_W_hand_t(thx_reco* r, const float* T, int maxRadius, int maxI
                            r->tw, flag);
         if (devStop) {
             hipLaunchKernelGGL(k_reco_stop_rule, dim3(1), dim3(1), 0, st, stop, r->diff, m, minIter);
+            // a queued round that falls through still costs its four launches (~ 60 us of empty 8 000-workgroup grids at 512^3):
+            // from the first round the rule can fire in (no-decrease twice: m >= minIter), every fourth round the host looks
+            if (m >= minIter && ((m - minIter) & 3) == 0 && m + 1 < maxIter) {
+                int done = 0;
+                THX_CHECK(hipMemcpyAsync(&done, &stop->done, sizeof(int), hipMemcpyDeviceToHost, st));
+                THX_CHECK(hipStreamSynchronize(st));
+                if (done) break;
+            }
             continue;
         }
         unsigned bits = 0;
