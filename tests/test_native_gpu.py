@@ -132,6 +132,23 @@ def test_cpp_iteration_driver(dev, tmp_path):
     print(out.stdout)
 
 
+def test_cpp_iteration_driver_two_ranks(dev, tmp_path):
+    """the same torch-free C++ program as TWO ranks (one half-set each) sharing the one GPU: THX_COMM_TRANSPORT=shm makes the id it
+    draws name a shared-memory segment (thx_comm.hip's test-only transport; RCCL refuses two ranks per device), the id travels
+    through a pipe as the reference's travels through MPI_Bcast (gpu/src/cuthunder.cu:4192-4206), and every rank runs the unchanged
+    multi-rank branches of thx_refine_iterate (sigma tables, norm vector, half-map broadcasts) from C++"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "iteration2")
+    libdir = os.path.join(root, "thunder_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "iteration.cpp"), "-o", exe, "-L" + libdir,
+                           "-lthunder_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    env = dict(os.environ, THX_COMM_TRANSPORT="shm", THX_COMM_SHM_TIMEOUT_S="240")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "two ranks on one GPU" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+    print(out.stdout)
+
+
 def test_cpp_classification_driver(dev, tmp_path):
     """tests/cpp/classify.cpp: torch-free C++ over the C ABI -- K = 2 synthetic references, images on the scanned grid,
     thx_refine_create (nK = 2, THX_SEARCH_GLOBAL) ... thx_refine_iterate (scan, class, support points, local phases, sigma update,

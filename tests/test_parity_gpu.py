@@ -940,7 +940,8 @@ def test_hand_fft_passes_match_rocfft(dev, knob_env, N):
     F = (vol * Tt).contiguous()
     fscv = np.clip(np.linspace(1.0, 0.1, N // 2), 0, 1).astype(np.float32)
     out = {}
-    for mode in ("rocfft", "hand", "hand_natural", "hand_hoststop"):
+    for mode in ("rocfft", "hand", "hand_natural", "hand_hoststop") + (("hand_x2",) if P == 1024 else ()):
+        knob_env("THX_FFTZ_WAVES", {"hand_x2": "16", "hand": "4" if P == 1024 else None}.get(mode))
         knob_env("THX_FFT", "rocfft" if mode == "rocfft" else None)
         knob_env("THX_RECO_WT", "natural" if mode == "hand_natural" else None)
         knob_env("THX_RECO_STOP", "host" if mode == "hand_hoststop" else None)
@@ -957,6 +958,10 @@ def test_hand_fft_passes_match_rocfft(dev, knob_env, N):
     md, id_, dd = out["hand_hoststop"]
     assert id_ == ib and dd == db and torch.equal(md, mb)
     knob_env("THX_RECO_STOP", None)
+    if P == 1024:   # the two forms of the z pass at P = 1024: eight points per thread in 1 024-thread workgroups ("hand" above, forced), sixteen in 512-thread ones
+        me, ie, de = out["hand_x2"]
+        assert ie == ib and de == db and torch.equal(me, mb)
+    knob_env("THX_FFTZ_WAVES", None)
     plan.close()
 
 

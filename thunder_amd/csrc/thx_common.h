@@ -67,7 +67,7 @@ struct Knobs {
     long insertSegCap;    // THX_INSERT_SEG_CAP: descriptor table size, to exercise the table-full path in tests (0 = records / 8)
     bool fftRocfft;       // THX_FFT=rocfft: library transforms in the gridding loop for every size
     bool recoTrace;       // THX_RECO_TRACE: print diffC per balancing round
-    int fftzWaves;        // THX_FFTZ_WAVES = 4 / 8: register budget of the fused z pass of the gridding loop (0 = per size)
+    int fftzWaves;        // THX_FFTZ_WAVES = 4 / 8: register budget of the fused z pass of the gridding loop; 16: its sixteen-points-per-thread form (P = 1024 only, the default there); 0 = per size
     bool recoNatural;     // THX_RECO_WT=natural: W / T of the hand-written gridding loop in the volume's own layout (A/B; default: tiled by z column)
     bool recoHostStop;    // THX_RECO_STOP=host: the gridding loop's stop rule on the host, one 4-byte read-back per round (A/B; default: on the device)
     bool recoReplicate;   // THX_RECO_OWNERS=0: every rank of a half reconstructs every class after an all-reduce, as the reference's ranks do

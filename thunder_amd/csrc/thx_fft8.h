@@ -376,6 +376,165 @@ __global__ __launch_bounds__((f8_n<NS, R>() / 8) * TX, WPS) void k_fft_z_update(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same pass with SIXTEEN points per thread (round 5; R = 2 grids, i.e. P = 1024): a physical thread T < P / 16 plays the two
+// threads tau = T and tau = T + P / 16 of the eight-point form, stage by stage, with the barriers shared -- the same loads, the same
+// LDS traffic, the same arithmetic in the same order (bit-identical results), but HALF the threads per workgroup: two workgroups
+// of 512 threads fit a CU (2 x 75 KB of LDS, 128 VGPRs each) where the 1 024-thread form runs alone, so one workgroup's loads
+// and stores overlap the other's transforms.  The 1 024-thread form alternates between memory and arithmetic with nothing to
+// cover either (7.0 ms per round at 1 024^3 = 2.2 TB/s against 4.9 TB/s for the y passes).
+// ---------------------------------------------------------------------------------------------
+template <int NS, int DIR, int TWS>
+__device__ __forceinline__ void fft8n_x2(float2 v[2][8], int t, int c, int pitch, float2* s, const float2* sTw, const int eoff[2])
+{
+    static_assert(NS == 3, "two-thread form: 512-point sub-transforms only");
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        fft8<DIR>(v[u]);
+        const int n1 = t >> 3;
+#pragma unroll
+        for (int k0 = 0; k0 < 8; k0++)
+            s[f8_slot(eoff[u] + k0 * 64 + t, c, pitch)] = cmul(v[u][k0], f8_tw<DIR>(sTw[((8 * n1 * k0) & 511) * TWS]));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int n0 = t & 7, k0 = t >> 3;
+#pragma unroll
+        for (int n1 = 0; n1 < 8; n1++) v[u][n1] = s[f8_slot(eoff[u] + k0 * 64 + n1 * 8 + n0, c, pitch)];
+        fft8<DIR>(v[u]);
+#pragma unroll
+        for (int k1 = 0; k1 < 8; k1++)
+            s[f8_slot(eoff[u] + k0 * 64 + k1 * 8 + n0, c, pitch)] = cmul(v[u][k1], f8_tw<DIR>(sTw[(n0 * (k0 + 8 * k1)) * TWS]));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int k0 = t & 7, k1 = t >> 3;
+#pragma unroll
+        for (int n0 = 0; n0 < 8; n0++) v[u][n0] = s[f8_slot(eoff[u] + k0 * 64 + k1 * 8 + n0, c, pitch)];
+        fft8<DIR>(v[u]);
+    }
+    __syncthreads();
+}
+
+// fftN<3, 2, DIR> for the two threads tau = T and T + 64 a physical thread T < 64 plays (M = 512, M / 8 = 64, N / 8 = 128)
+template <int DIR>
+__device__ __forceinline__ void fftN_x2(float2 v[2][8], int T, int c, int pitch, float2* s, const float2* sTw)
+{
+    constexpr int M = 512, TT = 128;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int tau = T + 64 * u;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float2* w = v[u] + 2 * i;
+            const float2 a0 = w[0], a1 = w[1];
+            w[0] = f8_add(a0, a1); w[1] = f8_sub(a0, a1);
+            const int b = tau + TT * i;
+#pragma unroll
+            for (int k0 = 0; k0 < 2; k0++) s[f8_slot(k0 * M + b, c, pitch)] = cmul(w[k0], f8_tw<DIR>(sTw[b * k0]));
+        }
+    }
+    __syncthreads();
+    // tau = T: k0 = 0, t = T; tau = T + 64: k0 = 1, t = T
+    const int eoff[2] = {0, M};
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int n = 0; n < 8; n++) v[u][n] = s[f8_slot(eoff[u] + T + 64 * n, c, pitch)];
+    fft8n_x2<3, DIR, 2>(v, T, c, pitch, s, sTw, eoff);
+}
+
+__device__ __forceinline__ void f8_rearrange_x2(float2 v[2][8], int T, int c, int pitch, float2* s)
+{
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[f8_slot(f8_eout<3, 2>(T + 64 * u, k), c, pitch)] = v[u][k];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[u][q] = s[f8_slot(f8_epre<3, 2>(T + 64 * u, q), c, pitch)];
+    __syncthreads();
+}
+
+template <int TX, bool FIRST, bool TILED>
+__global__ __launch_bounds__(64 * TX, 4) void k_fft_z_update_x2(float2* __restrict__ C, float* __restrict__ W, const float* __restrict__ T,
+                                                               int ncp, int r2i, unsigned* __restrict__ diffBits,
+                                                               const float2* __restrict__ tw, const int* __restrict__ stop)
+{
+    constexpr int P = 1024, nc = P / 2 + 1, NTHR = 64 * TX;
+    if (stop && *stop) return;
+    extern __shared__ float2 f8_lds[];
+    float2* sTw = f8_lds + f8_rows<3, 2>() * TX;
+    __shared__ float sred[16];
+    const int c = threadIdx.x % TX, t = threadIdx.x / TX;   // t < 64
+    int bx, jw;
+    f8_xcd_tile(bx, jw);
+    const int x = bx * TX + c;
+    const bool ok = x < nc;
+    for (int i = threadIdx.x; i < P; i += NTHR) sTw[i] = tw[i];
+    float2 v[2][8];
+    float d = 0.f;
+    const long strideE = (long)P * ncp;
+    float2* base = C + (long)jw * ncp + x;
+    if (!FIRST) {
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[u][q] = ok ? base[(long)f8_epre<3, 2>(t + 64 * u, q) * strideE] : make_float2(0.f, 0.f);
+        __syncthreads();
+        fftN_x2<-1>(v, t, c, TX, f8_lds, sTw);
+    } else {
+        __syncthreads();
+    }
+    {
+        const int j = jw >= P / 2 ? jw - P : jw;
+        const double qij = (double)x * x + (double)j * j;
+        const double r2 = (double)pow2f_((float)r2i);
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int n = 0; n < 8; n++) {
+                const int kw = f8_eout<3, 2>(t + 64 * u, n);
+                const int k = kw >= P / 2 ? kw - P : kw;
+                float2 o = make_float2(0.f, 0.f);
+                if (ok) {
+                    const size_t e = TILED ? ((((size_t)jw * gridDim.x + bx) * P + kw) * TX + c) : (((size_t)kw * P + jw) * nc + x);
+                    float w = W[e];
+                    if (!FIRST && (qij + (double)k * k < r2)) {
+                        const float a = ts_hypot(v[u][n].x, v[u][n].y);
+                        w = w / (a > (float)1e-6 ? a : (float)1e-6);
+                        W[e] = w;
+                        d = fmaxf(d, fabsf(a - 1));
+                    }
+                    o = make_float2(T[e] * w, 0.0f * w);
+                }
+                v[u][n] = o;
+            }
+    }
+    f8_rearrange_x2(v, t, c, TX, f8_lds);
+    fftN_x2<1>(v, t, c, TX, f8_lds, sTw);
+    if (ok) {
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int n = 0; n < 8; n++) base[(long)f8_eout<3, 2>(t + 64 * u, n) * strideE] = v[u][n];
+    }
+    if (!FIRST) {
+        d = wave_max(d);
+        if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = d;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < (NTHR + 63) / 64; w++) d = fmaxf(d, sred[w]);
+            const unsigned bitsd = __float_as_uint(d);
+            if (bitsd > __hip_atomic_load(diffBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(diffBits, bitsd);
+        }
+    }
+}
+
 // natural [kz][ky][nc] <-> tiled [ky][x tile][kz][TX] (columns beyond nc are zero), 16 z planes of one ky row per workgroup
 // through LDS so that both sides move whole lines.  grid (P / 16, P), 256 threads, LDS 16 nTx TX floats.
 template <int TX>

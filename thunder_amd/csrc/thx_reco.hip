@@ -11,6 +11,8 @@
 #include <utility>
 #include <vector>
 
+#include <type_traits>
+
 #include "thx_common.h"
 
 namespace thx {
@@ -587,11 +589,20 @@ static int balance_W_hand_t(thx_reco* r, const float* T, int maxRadius, int maxI
     const size_t ldsX = (size_t)(f8_rows<NS, R>() * 5 + P) * sizeof(float2) + (P / 2 + 1) * sizeof(float);
     constexpr int nTx = (nc + TXZ - 1) / TXZ;
     const size_t ldsT = (size_t)16 * nTx * TXZ * sizeof(float);
+    // WPS = 16 selects the sixteen-points-per-thread form of the z pass (512-thread workgroups, two per CU; P = 1024 only)
+    constexpr bool X2 = WPS == 16;
+    static_assert(!X2 || (NS == 3 && R == 2), "the sixteen-points-per-thread z pass exists for P = 1024");
+    auto zfn = [](bool first) -> const void* {
+        if constexpr (X2)
+            return first ? reinterpret_cast<const void*>(k_fft_z_update_x2<TXZ, true, TILED>) : reinterpret_cast<const void*>(k_fft_z_update_x2<TXZ, false, TILED>);
+        else
+            return first ? reinterpret_cast<const void*>(k_fft_z_update<NS, R, TXZ, true, TILED, WPS>)
+                         : reinterpret_cast<const void*>(k_fft_z_update<NS, R, TXZ, false, TILED, WPS>);
+    };
     static std::once_flag once;
     static hipError_t attrErr = hipSuccess;
     std::call_once(once, [&]() {
-        const void* fn[6] = {reinterpret_cast<const void*>(k_fft_z_update<NS, R, TXZ, true, TILED, WPS>),
-                             reinterpret_cast<const void*>(k_fft_z_update<NS, R, TXZ, false, TILED, WPS>),
+        const void* fn[6] = {zfn(true), zfn(false),
                              reinterpret_cast<const void*>(k_fft_strided<NS, R, TXY, 1>),
                              reinterpret_cast<const void*>(k_fft_strided<NS, R, TXY, -1>),
                              reinterpret_cast<const void*>(k_fft_x_conv<NS, R>),
@@ -601,7 +612,7 @@ static int balance_W_hand_t(thx_reco* r, const float* T, int maxRadius, int maxI
             attrErr = hipFuncSetAttribute(fn[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)sz[i]);
     });
     THX_CHECK(attrErr);
-    const dim3 gZ(nTx, P), bZ(NT8 * TXZ), gY((nc + TXY - 1) / TXY, P), bY(NT8 * TXY);
+    const dim3 gZ(nTx, P), bZ(X2 ? 64 * TXZ : NT8 * TXZ), gY((nc + TXY - 1) / TXY, P), bY(NT8 * TXY);
     const int r2i = maxRadius * pf;
     int iters = 0, nNoDec = 0;
     float diffC = 3.402823466e+38f, diffCPrev = 3.402823466e+38f;
@@ -623,16 +634,21 @@ static int balance_W_hand_t(thx_reco* r, const float* T, int maxRadius, int maxI
     RecoStop* stop = reinterpret_cast<RecoStop*>(r->stop);
     const int* flag = devStop ? &stop->done : nullptr;
     if (devStop) hipLaunchKernelGGL(k_reco_stop_init, dim3(1), dim3(1), 0, st, stop);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, R, TXZ, true, TILED, WPS>), gZ, bZ, ldsZ, st, r->C, Wz, Tz, ncp, r2i, r->diff, r->tw,
-                       (const int*)nullptr);
+    auto launchZ = [&](auto firstTag, const int* flg) {
+        constexpr bool FIRST = decltype(firstTag)::value;
+        if constexpr (X2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update_x2<TXZ, FIRST, TILED>), gZ, bZ, ldsZ, st, r->C, Wz, Tz, ncp, r2i, r->diff, r->tw, flg);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, R, TXZ, FIRST, TILED, WPS>), gZ, bZ, ldsZ, st, r->C, Wz, Tz, ncp, r2i, r->diff, r->tw, flg);
+    };
+    launchZ(std::true_type{}, (const int*)nullptr);
     for (int m = 0; m < maxIter; m++) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_strided<NS, R, TXY, 1>), gY, bY, ldsY, st, r->C, (long)ncp, (long)P * ncp, nc, r->tw, flag);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_x_conv<NS, R>), dim3(P / 2 + 1, P / 2 + 1), dim3(NT8 * 4), ldsX, st, r->C, ncp,
                            r->N * pf, r->tab, kTabN, r->nf, r->rnf, r->rs, r->tw, flag);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_strided<NS, R, TXY, -1>), gY, bY, ldsY, st, r->C, (long)ncp, (long)P * ncp, nc, r->tw, flag);
         THX_CHECK(hipMemsetAsync(r->diff, 0, sizeof(unsigned), st));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fft_z_update<NS, R, TXZ, false, TILED, WPS>), gZ, bZ, ldsZ, st, r->C, Wz, Tz, ncp, r2i, r->diff,
-                           r->tw, flag);
+        launchZ(std::false_type{}, flag);
         if (devStop) {
             hipLaunchKernelGGL(k_reco_stop_rule, dim3(1), dim3(1), 0, st, stop, r->diff, m, minIter);
             // a queued round that falls through still costs its four launches (~ 60 us of empty 8 000-workgroup grids at 512^3):
@@ -680,14 +696,20 @@ static int balance_W_hand_t(thx_reco* r, const float* T, int maxRadius, int maxI
     return 0;
 }
 
+constexpr int kFftzDefault1024 = 16;   // z pass at P = 1024: 16 = sixteen points per thread in 512-thread workgroups, two per CU (13.25 ms per round; bit-identical); 4 = eight points per thread in 1 024-thread workgroups, one per CU (14.06 ms); THX_FFTZ_WAVES overrides
+
 template <int NS, int R>
 static int balance_W_hand(thx_reco* r, const float* T, int maxRadius, int maxIter, int minIter, int* itersOut, float* diffCOut,
                           void* resultDev, hipStream_t st)
 {
     // THX_FFTZ_WAVES = 4 / 8 (A/B); default: 4 for the 1024-point instance (no spills), 8 otherwise
-    const int wps = knobs().fftzWaves > 0 ? knobs().fftzWaves : ((NS == 3 && R == 2) ? 4 : 8);
+    // THX_FFTZ_WAVES = 16: the sixteen-points-per-thread form (P = 1024 only)
+    const int wps = knobs().fftzWaves > 0 ? knobs().fftzWaves : ((NS == 3 && R == 2) ? kFftzDefault1024 : 8);
     const bool nat = knobs().recoNatural;
 #define THX_BW(tiled, w) return balance_W_hand_t<NS, R, tiled, w>(r, T, maxRadius, maxIter, minIter, itersOut, diffCOut, resultDev, st)
+    if constexpr (NS == 3 && R == 2) {
+        if (wps == 16) { if (nat) THX_BW(false, 16); THX_BW(true, 16); }
+    }
     if (wps <= 4) { if (nat) THX_BW(false, 4); THX_BW(true, 4); }
     if (nat) THX_BW(false, 8);
     THX_BW(true, 8);

@@ -16,9 +16,11 @@ Tt[r >= (N // 2 - 2) * 2 + 1] = 0
 F = (vol * Tt).contiguous()
 del r
 from thunder_amd import capi
-for mode in ("rocfft", "hand_natural", "hand", "hand_waves8", "hand_waves4"):
-    for k, v in (("THX_FFT", "rocfft" if mode == "rocfft" else None), ("THX_RECO_WT", "natural" if mode == "hand_natural" else None),
-                 ("THX_FFTZ_WAVES", {"hand_waves8": "8", "hand_waves4": "4"}.get(mode))):
+modes = ("rocfft", "hand_natural", "hand", "hand_waves8", "hand_waves4") + (("hand_x2", "hand_x2_natural") if N == 512 else ())
+ref = None
+for mode in modes:
+    for k, v in (("THX_FFT", "rocfft" if mode == "rocfft" else None), ("THX_RECO_WT", "natural" if mode in ("hand_natural", "hand_x2_natural") else None),
+                 ("THX_FFTZ_WAVES", {"hand_waves8": "8", "hand_waves4": "4", "hand_x2": "16", "hand_x2_natural": "16"}.get(mode))):
         if v is None:
             os.environ.pop(k, None)
         else:
@@ -27,7 +29,11 @@ for mode in ("rocfft", "hand_natural", "hand", "hand_waves8", "hand_waves4"):
     plan.reconstruct(F.clone(), Tt.clone(), N // 2 - 2, MAP=False, gridCorr=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    plan.reconstruct(F.clone(), Tt.clone(), N // 2 - 2, MAP=False, gridCorr=True)
+    m = plan.reconstruct(F.clone(), Tt.clone(), N // 2 - 2, MAP=False, gridCorr=True)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if mode == "hand":
+        ref = m
+    elif mode.startswith("hand") and ref is not None:
+        print("    %s == hand bit for bit: %s" % (mode, bool(torch.equal(m, ref))))
     print("N = %d  %s: %.1f ms, %d rounds -> %.2f ms per round" % (N, mode, dt * 1e3, plan.last_iters, dt * 1e3 / plan.last_iters))
