@@ -56,13 +56,14 @@ def main():
     ap.add_argument("--world", type=int, required=True)
     ap.add_argument("--dir", required=True)
     ap.add_argument("--case", default="k1")
+    ap.add_argument("--gpu-per-rank", action="store_true", help="rank r on device r and RCCL as the transport (needs `world` GPUs)")
     a = ap.parse_args()
     import torch
     from thunder_amd import capi
     from thunder_amd.native import NativeRefine, make_comms
     from thunder_amd.refine import RefineShard, take_shard
     capi.load()
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", a.rank if a.gpu_per_rank else 0)
     torch.cuda.set_device(dev)
     c = CASES[a.case]
     N, n, K = c["N"], c["n"], c["K"]
@@ -79,7 +80,7 @@ def main():
     if a.world > 1:
         hemi, wcomm = make_comms(a.rank, a.world, file_share(a.dir, a.rank))
         tp = capi.load().thx_comm_transport(wcomm.handle)
-        assert tp == b"shm", tp
+        assert tp == (b"rccl" if a.gpu_per_rank else b"shm"), tp
     nat = NativeRefine(sh, hemi, wcomm, norm_correction=c["norm"])
     cap = nat.capture(maps=True)
     nat.reset()

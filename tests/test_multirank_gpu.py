@@ -27,17 +27,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "_rank_worker.py")
 
 
-def run_ranks(world, case, extra_env=None, timeout=900):
+def run_ranks(world, case, extra_env=None, timeout=900, rccl=False):
     d = tempfile.mkdtemp(prefix="thx_ranks_%s_w%d_" % (case, world))
     env = dict(os.environ)
-    env["THX_COMM_TRANSPORT"] = "shm"
+    env["THX_COMM_TRANSPORT"] = "rccl" if rccl else "shm"
     env["THX_COMM_SHM_TIMEOUT_S"] = "240"
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.update(extra_env or {})
     procs = []
     for r in range(world):
         log = open(os.path.join(d, "rank%d.log" % r), "w")
-        procs.append((subprocess.Popen([sys.executable, WORKER, "--rank", str(r), "--world", str(world), "--dir", d, "--case", case],
+        procs.append((subprocess.Popen([sys.executable, WORKER, "--rank", str(r), "--world", str(world), "--dir", d, "--case", case] +
+                                       (["--gpu-per-rank"] if rccl else []),
                                        stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT), log))
     failed = None
     try:
@@ -198,3 +199,15 @@ def test_replicated_form_gives_the_same(dev):
     compare("k4", 4, ranks, ref, 2, 4, replicate=True)
     for g in ranks:
         assert (g["rounds0"][:, 0, :3] > 0).all()
+
+
+@pytest.mark.parametrize("world,case,K,nIter", [(2, "k1", 1, 3), (4, "k1", 1, 3), (4, "k4", 4, 2)])
+def test_n_ranks_equal_one_rank_over_rccl(dev, world, case, K, nIter):
+    """the same equality with RCCL as the transport and one GPU per rank -- ncclReduce / ncclAllReduce / ncclBroadcast themselves,
+    which the 1-GPU boxes of this environment cannot run (RCCL refuses two ranks per device): skipped unless `world` GPUs are visible"""
+    import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs" % world)
+    ref = one_rank(case)
+    ranks = run_ranks(world, case, rccl=True)
+    compare(case, world, ranks, ref, nIter, K)
