@@ -616,6 +616,9 @@ static int balance_W_hand_t(thx_reco* r, const float* T, int maxRadius, int maxI
     const int r2i = maxRadius * pf;
     int iters = 0, nNoDec = 0;
     float diffC = 3.402823466e+38f, diffCPrev = 3.402823466e+38f;
+    // (An error return from inside the loop leaves r->W in the tiled layout.  That is harmless by construction, not by discipline:
+    // every reconstruction starts with k_initW_floorT writing ALL of W in the natural layout before this function is entered, and the
+    // only reader of W after this function -- k_FW, thx_ExposeWT_host's copy -- runs on the success path alone.)
     // TILED: W moves into the z pass's layout for the duration of the loop (through the real-space scratch, which the
     // hand-written loop does not use), T's tiled copy stays in that scratch; W comes back in the volume's layout at the end
     const size_t nTiled = (size_t)P * P * nTx * TXZ, nNat = (size_t)P * P * nc;
