@@ -642,7 +642,7 @@ def refinement_line(args, dev, rank, world, box, particles, steps, warmup, batch
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     out = None
@@ -800,12 +800,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # THX_BENCH_ONE_DEVICE=1 (tests only, never a measurement): every rank on cuda:0 -- the launcher's process group over gloo and,
+    # with THX_COMM_TRANSPORT=shm, the native communicators over the library's shared-memory transport -- so that the N > 1 code path
+    # of this file (sharding, id exchange, communicators, max-over-ranks timing) runs on a 1-GPU box
+    one_dev = os.environ.get("THX_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if one_dev:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
     from thunder_amd import capi
     capi.load()
 

@@ -454,6 +454,35 @@ def test_multirank_bench_native_rccl(dev, world):
     assert all(f > 0.5 for f in j["fsc_half_maps"][1:4]), j["fsc_half_maps"]
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_multirank_bench_on_one_device(dev, world):
+    """bench.py's N > 1 path executed on the 1-GPU box: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` with
+    every rank on cuda:0 (THX_BENCH_ONE_DEVICE=1: the launcher's group over gloo, the native communicators over the library's
+    test-only shared-memory transport).  Sharding, the id exchange through the process group, hemi / world communicators, the reduce
+    towards the reconstructing rank (world 4), the half-map broadcasts, the barrier + max-over-ranks timing and the ONE JSON line
+    of rank 0 -- everything of the N-rank bench but RCCL itself.  Functional only: the value of such a run means nothing."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, THX_BENCH_ONE_DEVICE="1", THX_COMM_TRANSPORT="shm", THX_COMM_SHM_TIMEOUT_S="240")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "1",
+           "--warmup", "1", "--box", "32", "--particles", str(300 * world), "--mReco", "20"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 prints ONE line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == world and j["scaling"] == "strong" and j["value"] > 0 and j["cpu_baseline"] is None
+    assert j["config"]["particles"] == 300 * world and j["config"]["particles_per_gpu"] == 300
+    assert abs(j["value"] - 300 * world / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+    assert all(f > 0.5 for f in j["fsc_half_maps"][1:4]), j["fsc_half_maps"]
+
+
 def test_classification_k4_multi_reference(oracle, dev):
     """BASELINE config (3) in small: 3-D classification with K = 4 references.  Scanning phase over the classes
     (ExpectGlobal3D, wC carried from class to class) -> class assignment -> local phase against the assigned reference
