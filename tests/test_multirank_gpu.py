@@ -167,10 +167,11 @@ def test_n_ranks_equal_one_rank_refinement(dev, world):
         assert (rounds[:, 0, 0] > 0).all() == (r < 2), (r, rounds[:, :, 0])
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_n_ranks_equal_one_rank_classification(dev, world):
     """K = 4 with balanceClass (class 3 has no particles and takes over another class's reference -- the same one on every
-    rank): global search, then a local search.  With 4 ranks every rank of a half reconstructs two of its four classes."""
+    rank): global search, then a local search.  With 4 ranks every rank of a half reconstructs two of its four classes; with 8
+    -- the shape of BASELINE configs[3] on a node -- every rank reconstructs ONE class."""
     ref = one_rank("k4")
     assert ref["balanced0"][3] >= 0 and ref["balanced0"][3] != 3, ref["balanced0"][:4]
     ranks = run_ranks(world, "k4")
