@@ -7,9 +7,10 @@
 //                            (HOT LOOP C :7038-7241, prepareTF, reconstruct x 2 per half)
 //   Model::compareTwoHemispheres FSC (src/Model.cpp:424-551, src/Functions/Spectrum.cpp:302-337), Model::refreshProj
 //   (src/Model.cpp:1013-1044), Optimiser::reCentreImg / reMaskImg (:6065-6149), allocPreCalIdx / allocPreCal (:7991-8171)
-// One thx_refine handle = one rank's HBM-resident shard of particles (one process per GPU).  The only exchange between
-// ranks is the half-set reduction of F / T (thx_reco_allreduce, RCCL over xGMI), three small sigma tables, and the two
-// N^3 half maps for the FSC -- all through thx_comm (thx_comm.hip).  The handle BORROWS the caller's image stack
+// One thx_refine handle = one rank's HBM-resident shard of particles (one process per GPU).  The exchanges between ranks: the
+// half-set reduction of the 64-bit F / T accumulators of every class towards the rank that reconstructs it
+// (thx_reco_reduce_acc_class, RCCL over xGMI), three small sigma tables, the norm vector and the class histogram, and the N^3 half
+// maps of every class from their reconstructing ranks -- all through thx_comm (thx_comm.hip).  The handle BORROWS the caller's image stack
 // (_imgOri) and owns everything else.
 #include <algorithm>
 #include <cmath>
