@@ -188,7 +188,7 @@ def test_n_ranks_equal_one_rank_classification(dev, world):
 def test_n_ranks_equal_one_rank_point_group(dev):
     """C4: prepareTF's symmetrisation runs on the reduced sums of the reconstructing rank"""
     ref = one_rank("c4")
-    ranks = run_ranks(4, "c4")
+    ranks = run_ranks(4, "c4", {"THX_COMM_SHM_SLOT_MB": "1"})     # (1 MiB slots: the accumulators travel in four chunks)
     compare("c4", 4, ranks, ref, 2, 1)
 
 

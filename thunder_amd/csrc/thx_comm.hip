@@ -228,7 +228,7 @@ struct ShmTransport : Transport {
         rank = rank_; size = size_;
         snprintf(shmName, sizeof(shmName), "%s", nm);
         const char* e = getenv("THX_COMM_SHM_SLOT_MB");
-        slotBytes = (size_t)((e && atol(e) > 0) ? atol(e) : 16) << 20;
+        slotBytes = (size_t)((e && atol(e) > 0) ? atol(e) : 4) << 20;   // (small by default: container /dev/shm can be 64 MiB; buffers travel in chunks of a slot)
         if ((e = getenv("THX_COMM_SHM_TIMEOUT_S")) && atof(e) > 0) timeoutS = atof(e);
         const size_t hdrBytes = 4096;
         mapBytes = hdrBytes + (size_t)size * slotBytes;
