@@ -320,6 +320,9 @@ int thx_translate_volume_dev(float* dst, const float* src, int dim, float r, dou
 int thx_norm_residual_dev(float* norm, const float* volumes, const int* volIdx, int vdim, int pf, int idim, int projR, float rL,
                           float rNorm, const float* img, const thx_ctf_attr* attr, const double* dfac, float pixelSize,
                           const double* rotMat, const double* trans, int nImg, void* stream);
+int thx_norm_residual_packed_dev(float* norm, const float* cells, const int* volIdx, int vdim, int pf, int idim, int projR, float rL,
+                                 float rNorm, const float* img, const thx_ctf_attr* attr, const double* dfac, float pixelSize,
+                                 const double* rotMat, const double* trans, int nImg, void* stream);   /* cell-packed references; bit-identical */
 int thx_median_f32_dev(float* out, const float* values, int n, void* stream);
 int thx_norm_scale_dev(float* img, float* imgOri, const float* norm, const float* median, int idim, int nImg, void* stream);
 
@@ -335,6 +338,12 @@ int thx_sigma_spectra_dev(float* spec, const float* volumes, const int* volIdx, 
                           int rSig, const float* img, const float* imgOri, const thx_ctf_attr* attr,
                           const double* dfac, float pixelSize, const double* rotMat, const double* trans,
                           const double* offset, int nImg, void* stream);
+/* the same with `cells` = the cell-packed copies of the references (thx_projector_pack_dev): one 64-byte request per sample; the
+ * spectra are bit-identical (what the iteration driver calls) */
+int thx_sigma_spectra_packed_dev(float* spec, const float* cells, const int* volIdx, int vdim, int pf, int idim, int projR,
+                                 int rSig, const float* img, const float* imgOri, const thx_ctf_attr* attr,
+                                 const double* dfac, float pixelSize, const double* rotMat, const double* trans,
+                                 const double* offset, int nImg, void* stream);
 
 /* Group accumulation of allReduceSigma, src/Optimiser.cpp:6567-6597: sigM/sigN/svd [nGroup][rSig+1] (device,
  * READ-MODIFY-WRITE; last column = weight sum) += this rank's images.  groupID_host [nImg] is the HOST array

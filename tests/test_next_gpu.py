@@ -123,6 +123,11 @@ def test_sigma_update(oracle, dev, N, projR, rSig):
     got = spec.cpu().numpy()
     # shell sums of <= ~100 positive terms in a different order + 2-ulp ramps/CTF: 2e-5 relative
     assert np.all(np.abs(got - want) <= 2e-5 * np.abs(want) + 1e-12)
+    # on the cell-packed copy of the reference (what the iteration driver calls): the same bits
+    cells = ops.pack_projector(T(vol, dev)[None].contiguous(), P)
+    specP = ops.sigma_spectra(cells, P, 2, projR, rSig, T(im["img"], dev), T(im["imgOri"], dev), attr,
+                              im["pixelSize"], T(im["rot"], dev), T(im["tran"], dev), T(im["offset"], dev), packed=True)
+    assert torch.equal(specP, spec)
     # without the re-centring offset rows 2 and 3 use the same ramp
     spec0 = ops.sigma_spectra(T(vol, dev), P, 2, projR, rSig, T(im["img"], dev), T(im["img"], dev), attr,
                               im["pixelSize"], T(im["rot"], dev), T(im["tran"], dev), None).cpu().numpy()
@@ -163,6 +168,9 @@ def test_norm_correction(oracle, dev, N, projR, rL, rNorm):
     got = norm.cpu().numpy()
     # a sum of ~1e3 positive terms in another order + 2-ulp ramps / CTF
     assert np.all(np.abs(got - want) <= 2e-5 * want) and want.min() > 0
+    normP = ops.norm_residual(ops.pack_projector(T(vol, dev)[None].contiguous(), P), P, 2, projR, rL, rNorm, img, attr, im["pixelSize"],
+                              T(im["rot"], dev), T(im["tran"], dev), packed=True)
+    assert torch.equal(normP, norm)                  # the cell-packed form the iteration driver calls: the same bits
     # the ring really is a ring: pixels below rL and at or beyond rNorm do not count
     big = ops.norm_residual(T(vol, dev), P, 2, projR, 0.0, rNorm + 3, img, attr, im["pixelSize"], T(im["rot"], dev), T(im["tran"], dev))
     assert torch.all(big > norm)

@@ -185,6 +185,8 @@ SIGNATURES = {
     "thx_translate_volume_dev": (_i, [_vp, _vp, _i, _f, _d, _d, _d, _vp]),
     "thx_sigma_spectra_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i,
                                    _vp]),
+    "thx_sigma_spectra_packed_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i,
+                                   _vp]),
     "thx_sigma_accum_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "thx_sigma_final_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp]),
     "thx_mrc_info": (_i, [C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
@@ -218,6 +220,7 @@ SIGNATURES = {
     "thx_pf_update_d_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, C.c_ulonglong, C.c_uint, _vp, _vp]),
     "thx_pf_class_select_dev": (_i, [_vp, _vp, _vp, _i, _i, _d, C.c_ulonglong, C.c_uint, _vp]),
     "thx_norm_residual_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
+    "thx_norm_residual_packed_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
     "thx_median_f32_dev": (_i, [_vp, _vp, _i, _vp]),
     "thx_norm_scale_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "thx_pf_scan_support_dev": (_i, [_vp] * 13 + [_i] * 5 + [_d, _d, _d, C.c_ulonglong, C.c_uint, _vp]),

@@ -198,6 +198,9 @@ static int cached_shells(const ShellTable** out, int rSig)
 // (src/Optimiser.cpp:6443-6565 + powerSpectrum).  Lane-strided partial sums + a wave tree: deterministic, but a
 // different summation order from the reference's serial scan (tolerance in tests/test_parity_gpu.py).
 constexpr int kSigThreads = 256;
+// PACKED: `volumes` are cell-packed copies (thx_projector_pack_dev): one 64-byte request per sample instead of four 16-byte ones
+// (each of which costs the memory system a whole request); the same arithmetic, bit-identical spectra
+template <bool PACKED>
 __global__ __launch_bounds__(kSigThreads) void k_sigma_spectra(
     float* __restrict__ spec, const float2* __restrict__ volumes, const int* __restrict__ volIdx, int P, int pf,
     int idim, int projR, int rSig, const short2* __restrict__ ij, const int* __restrict__ shellStart,
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(kSigThreads) void k_sigma_spectra(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nc = idim / 2 + 1;
     const size_t imgSize = (size_t)idim * nc;
-    const float2* vol = volumes + (size_t)(volIdx ? volIdx[l] : 0) * P * P * (P / 2 + 1);
+    const float2* vol = volumes + (size_t)(volIdx ? volIdx[l] : 0) * P * P * (P / 2 + 1) * (PACKED ? 8 : 1);
     const float2* im = img + (size_t)l * imgSize;
     const float2* io = imgOri + (size_t)l * imgSize;
     const double* m = rotMat + 9 * (size_t)l;
@@ -233,7 +236,8 @@ __global__ __launch_bounds__(kSigThreads) void k_sigma_spectra(
             if (i * i + j * j < projR2) {
                 const double nx = (double)(i * pf), ny = (double)(j * pf);
                 const double ox = m[0] * nx + m[3] * ny, oy = m[1] * nx + m[4] * ny, oz = m[2] * nx + m[5] * ny;
-                const float2 s = interp_ft(vol, P, (float)ox, (float)oy, (float)oz);
+                const float2 s = PACKED ? interp_ft_packed(reinterpret_cast<const float4*>(vol), P, (float)ox, (float)oy, (float)oz)
+                                        : interp_ft(vol, P, (float)ox, (float)oy, (float)oz);
                 pM = cmul(s, ramp_value(rColM, rRowM, i, j));
                 pN = cmul(s, ramp_value(rColN, rRowN, i, j));
             }
@@ -263,6 +267,7 @@ __global__ __launch_bounds__(kSigThreads) void k_sigma_spectra(
 // not explain, norm_l = sum over rL^2 <= i^2 + j^2 < rNorm^2 of |img - ctf . P . ramp(t)|^2 (the masked image _img; P inside
 // Projector::_maxRadius).  One block per image over the half-image rows; lane-strided partial sums + a fixed tree (the
 // reference adds the pixels serially in RFLOAT: tolerance in tests/test_next_gpu.py).
+template <bool PACKED>
 __global__ __launch_bounds__(kSigThreads) void k_norm_residual(
     float* __restrict__ norm, const float2* __restrict__ volumes, const int* __restrict__ volIdx, int P, int pf, int idim,
     int projR, float rL2, float rNorm2, const float2* __restrict__ img, const thx_ctf_attr* __restrict__ attr,
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(kSigThreads) void k_norm_residual(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nc = idim / 2 + 1;
     const size_t imgSize = (size_t)idim * nc;
-    const float2* vol = volumes + (size_t)(volIdx ? volIdx[l] : 0) * P * P * (P / 2 + 1);
+    const float2* vol = volumes + (size_t)(volIdx ? volIdx[l] : 0) * P * P * (P / 2 + 1) * (PACKED ? 8 : 1);
     const float2* im = img + (size_t)l * imgSize;
     const double* m = rotMat + 9 * (size_t)l;
     const CtfConst cc = ctf_const(attr[l], dfac ? dfac[l] : 1.0);
@@ -290,7 +295,8 @@ __global__ __launch_bounds__(kSigThreads) void k_norm_residual(
         if (q < projR2) {
             const double nx = (double)(i * pf), ny = (double)(j * pf);
             const double ox = m[0] * nx + m[3] * ny, oy = m[1] * nx + m[4] * ny, oz = m[2] * nx + m[5] * ny;
-            p = cmul(interp_ft(vol, P, (float)ox, (float)oy, (float)oz), ramp_value(rCol, rRow, i, j));
+            p = cmul(PACKED ? interp_ft_packed(reinterpret_cast<const float4*>(vol), P, (float)ox, (float)oy, (float)oz)
+                            : interp_ft(vol, P, (float)ox, (float)oy, (float)oz), ramp_value(rCol, rRow, i, j));
         }
         const float c = ctf_value(cc, pixelSize, idim, idim, i, j);
         p.x *= c; p.y *= c;
@@ -441,10 +447,10 @@ int thx_translate_volume_dev(float* dst, const float* src, int dim, float r, dou
     return 0;
 }
 
-int thx_sigma_spectra_dev(float* spec, const float* volumes, const int* volIdx, int vdim, int pf, int idim, int projR,
-                          int rSig, const float* img, const float* imgOri, const thx_ctf_attr* attr,
-                          const double* dfac, float pixelSize, const double* rotMat, const double* trans,
-                          const double* offset, int nImg, void* stream)
+static int sigma_spectra_impl(float* spec, const float* volumes, const int* volIdx, int vdim, int pf, int idim, int projR,
+                              int rSig, const float* img, const float* imgOri, const thx_ctf_attr* attr,
+                              const double* dfac, float pixelSize, const double* rotMat, const double* trans,
+                              const double* offset, int nImg, void* stream, bool packed)
 {
     THX_REQUIRE(spec && volumes && img && imgOri && attr && rotMat && trans, "NULL pointer");
     THX_REQUIRE(rSig > 0 && rSig <= idim / 2 && projR >= 0 && projR * pf < vdim / 2 - 1, "radius out of range");
@@ -452,10 +458,53 @@ int thx_sigma_spectra_dev(float* spec, const float* volumes, const int* volIdx, 
     const ShellTable* t = nullptr;
     int rc = cached_shells(&t, rSig);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_sigma_spectra, dim3(nImg), dim3(kSigThreads), 0, as_stream(stream), spec,
-                       reinterpret_cast<const float2*>(volumes), volIdx, vdim, pf, idim, projR, rSig, t->ij, t->start,
-                       reinterpret_cast<const float2*>(img), reinterpret_cast<const float2*>(imgOri), attr, dfac,
-                       pixelSize, rotMat, trans, offset);
+    if (packed)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sigma_spectra<true>), dim3(nImg), dim3(kSigThreads), 0, as_stream(stream), spec,
+                           reinterpret_cast<const float2*>(volumes), volIdx, vdim, pf, idim, projR, rSig, t->ij, t->start,
+                           reinterpret_cast<const float2*>(img), reinterpret_cast<const float2*>(imgOri), attr, dfac,
+                           pixelSize, rotMat, trans, offset);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sigma_spectra<false>), dim3(nImg), dim3(kSigThreads), 0, as_stream(stream), spec,
+                           reinterpret_cast<const float2*>(volumes), volIdx, vdim, pf, idim, projR, rSig, t->ij, t->start,
+                           reinterpret_cast<const float2*>(img), reinterpret_cast<const float2*>(imgOri), attr, dfac,
+                           pixelSize, rotMat, trans, offset);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
+int thx_sigma_spectra_dev(float* spec, const float* volumes, const int* volIdx, int vdim, int pf, int idim, int projR,
+                          int rSig, const float* img, const float* imgOri, const thx_ctf_attr* attr,
+                          const double* dfac, float pixelSize, const double* rotMat, const double* trans,
+                          const double* offset, int nImg, void* stream)
+{
+    return sigma_spectra_impl(spec, volumes, volIdx, vdim, pf, idim, projR, rSig, img, imgOri, attr, dfac, pixelSize, rotMat, trans, offset,
+                              nImg, stream, false);
+}
+
+int thx_sigma_spectra_packed_dev(float* spec, const float* cells, const int* volIdx, int vdim, int pf, int idim, int projR,
+                                 int rSig, const float* img, const float* imgOri, const thx_ctf_attr* attr,
+                                 const double* dfac, float pixelSize, const double* rotMat, const double* trans,
+                                 const double* offset, int nImg, void* stream)
+{
+    return sigma_spectra_impl(spec, cells, volIdx, vdim, pf, idim, projR, rSig, img, imgOri, attr, dfac, pixelSize, rotMat, trans, offset,
+                              nImg, stream, true);
+}
+
+static int norm_residual_impl(float* norm, const float* volumes, const int* volIdx, int vdim, int pf, int idim, int projR, float rL,
+                              float rNorm, const float* img, const thx_ctf_attr* attr, const double* dfac, float pixelSize,
+                              const double* rotMat, const double* trans, int nImg, void* stream, bool packed)
+{
+    THX_REQUIRE(norm && volumes && img && attr && rotMat && trans, "NULL pointer");
+    THX_REQUIRE(projR >= 0 && projR * pf < vdim / 2 - 1 && rL >= 0 && rNorm >= 0, "radius out of range");
+    if (nImg <= 0) return 0;
+    if (packed)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_norm_residual<true>), dim3(nImg), dim3(kSigThreads), 0, as_stream(stream), norm,
+                           reinterpret_cast<const float2*>(volumes), volIdx, vdim, pf, idim, projR, pow2f_(rL), pow2f_(rNorm),
+                           reinterpret_cast<const float2*>(img), attr, dfac, pixelSize, rotMat, trans);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_norm_residual<false>), dim3(nImg), dim3(kSigThreads), 0, as_stream(stream), norm,
+                           reinterpret_cast<const float2*>(volumes), volIdx, vdim, pf, idim, projR, pow2f_(rL), pow2f_(rNorm),
+                           reinterpret_cast<const float2*>(img), attr, dfac, pixelSize, rotMat, trans);
     THX_LAUNCH_CHECK();
     return 0;
 }
@@ -464,14 +513,14 @@ int thx_norm_residual_dev(float* norm, const float* volumes, const int* volIdx, 
                           float rNorm, const float* img, const thx_ctf_attr* attr, const double* dfac, float pixelSize,
                           const double* rotMat, const double* trans, int nImg, void* stream)
 {
-    THX_REQUIRE(norm && volumes && img && attr && rotMat && trans, "NULL pointer");
-    THX_REQUIRE(projR >= 0 && projR * pf < vdim / 2 - 1 && rL >= 0 && rNorm >= 0, "radius out of range");
-    if (nImg <= 0) return 0;
-    hipLaunchKernelGGL(k_norm_residual, dim3(nImg), dim3(kSigThreads), 0, as_stream(stream), norm, reinterpret_cast<const float2*>(volumes),
-                       volIdx, vdim, pf, idim, projR, pow2f_(rL), pow2f_(rNorm), reinterpret_cast<const float2*>(img), attr, dfac, pixelSize,
-                       rotMat, trans);
-    THX_LAUNCH_CHECK();
-    return 0;
+    return norm_residual_impl(norm, volumes, volIdx, vdim, pf, idim, projR, rL, rNorm, img, attr, dfac, pixelSize, rotMat, trans, nImg, stream, false);
+}
+
+int thx_norm_residual_packed_dev(float* norm, const float* cells, const int* volIdx, int vdim, int pf, int idim, int projR, float rL,
+                                 float rNorm, const float* img, const thx_ctf_attr* attr, const double* dfac, float pixelSize,
+                                 const double* rotMat, const double* trans, int nImg, void* stream)
+{
+    return norm_residual_impl(norm, cells, volIdx, vdim, pf, idim, projR, rL, rNorm, img, attr, dfac, pixelSize, rotMat, trans, nImg, stream, true);
 }
 
 int thx_median_f32_dev(float* out, const float* values, int n, void* stream)

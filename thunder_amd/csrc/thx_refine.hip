@@ -607,7 +607,7 @@ int sigma_update(thx_refine* h, int vi, hipStream_t st)
     THX_RC(thx_rotmat_dev(h->topR + (size_t)lo * 4, h->rotTop, n, st));
     THX_CHECK(hipMemcpyAsync(h->tranTop, h->topT + (size_t)lo * 2, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
     const double* dfac = h->searchType == THX_SEARCH_CTF ? h->topD + lo : nullptr;
-    THX_RC(thx_sigma_spectra_dev(h->spec, vol_of(h, vi, 0), vol_idx(h, lo), h->P, h->pf, h->N, h->rU, h->rSig,
+    THX_RC(thx_sigma_spectra_packed_dev(h->spec, cells_of(h, vi, 0), vol_idx(h, lo), h->P, h->pf, h->N, h->rU, h->rSig,
                                  h->img + (size_t)lo * imgSize, h->imgOri + (size_t)lo * imgSize, h->attr + lo, dfac, c.pixelSize,
                                  h->rotTop, h->tranTop, h->offset + (size_t)lo * 2, n, st));
     const size_t tab = (size_t)c.nGroup * (h->rSig + 1);
@@ -643,7 +643,7 @@ int norm_correction(thx_refine* h, hipStream_t st)
         const int lo = h->lo[vi], n = h->hi[vi] - lo;
         if (n <= 0) continue;
         THX_RC(thx_rotmat_dev(h->topR + (size_t)lo * 4, h->rotTop, n, st));
-        THX_RC(thx_norm_residual_dev(h->norm + lo, vol_of(h, vi, 0), vol_idx(h, lo), h->P, h->pf, h->N, h->rU, (float)c.rL, rNorm,
+        THX_RC(thx_norm_residual_packed_dev(h->norm + lo, cells_of(h, vi, 0), vol_idx(h, lo), h->P, h->pf, h->N, h->rU, (float)c.rL, rNorm,
                                      h->img + (size_t)lo * imgSize, h->attr + lo, h->searchType == THX_SEARCH_CTF ? h->topD + lo : nullptr,
                                      c.pixelSize, h->rotTop, h->topT + (size_t)lo * 2, n, st));
     }

@@ -276,24 +276,25 @@ def translate_volume(vol, r, ox, oy, oz):
 
 
 def sigma_spectra(volumes, vdim, pf, projR, rSig, img, imgOri, attr, pixelSize, rotMat, trans, offset=None,
-                  dfac=None, volIdx=None):
-    """Per-image shell spectra of Optimiser::allReduceSigma (src/Optimiser.cpp:6443-6565) -> [nImg][4][rSig] f32"""
-    _chk(volumes, _C64, "volumes"); _chk(img, _C64, "img"); _chk(imgOri, _C64, "imgOri"); _chk(attr, _F32, "attr")
+                  dfac=None, volIdx=None, packed=False):
+    """Per-image shell spectra of Optimiser::allReduceSigma (src/Optimiser.cpp:6443-6565) -> [nImg][4][rSig] f32.
+    packed=True: `volumes` is the output of pack_projector (thx_sigma_spectra_packed_dev)."""
+    _chk(volumes, _F32 if packed else _C64, "volumes"); _chk(img, _C64, "img"); _chk(imgOri, _C64, "imgOri"); _chk(attr, _F32, "attr")
     _chk(rotMat, _F64, "rotMat"); _chk(trans, _F64, "trans")
     nImg, idim = img.shape[0], img.shape[1]
     spec = torch.empty((nImg, 4, rSig), dtype=_F32, device=img.device)
-    capi.call("thx_sigma_spectra_dev", ptr(spec), ptr(volumes), ptr(volIdx), vdim, pf, idim, projR, rSig, ptr(img),
+    capi.call("thx_sigma_spectra_packed_dev" if packed else "thx_sigma_spectra_dev", ptr(spec), ptr(volumes), ptr(volIdx), vdim, pf, idim, projR, rSig, ptr(img),
               ptr(imgOri), ptr(attr), ptr(dfac), float(pixelSize), ptr(rotMat), ptr(trans), ptr(offset), nImg,
               stream_ptr())
     return spec
 
 
-def norm_residual(volumes, vdim, pf, projR, rL, rNorm, img, attr, pixelSize, rotMat, trans, volIdx=None, dfac=None):
-    """per-image part of Optimiser::normCorrection (thx_norm_residual_dev): float32 [nImg]"""
-    _chk(volumes, _C64, "volumes"); _chk(img, _C64, "img"); _chk(rotMat, _F64, "rotMat"); _chk(trans, _F64, "trans")
+def norm_residual(volumes, vdim, pf, projR, rL, rNorm, img, attr, pixelSize, rotMat, trans, volIdx=None, dfac=None, packed=False):
+    """per-image part of Optimiser::normCorrection (thx_norm_residual_dev; packed=True: on pack_projector's cells): float32 [nImg]"""
+    _chk(volumes, _F32 if packed else _C64, "volumes"); _chk(img, _C64, "img"); _chk(rotMat, _F64, "rotMat"); _chk(trans, _F64, "trans")
     nImg, idim = img.shape[0], img.shape[1]
     norm = torch.empty((nImg,), dtype=_F32, device=img.device)
-    capi.call("thx_norm_residual_dev", ptr(norm), ptr(volumes), ptr(volIdx), vdim, pf, idim, int(projR), float(rL), float(rNorm), ptr(img),
+    capi.call("thx_norm_residual_packed_dev" if packed else "thx_norm_residual_dev", ptr(norm), ptr(volumes), ptr(volIdx), vdim, pf, idim, int(projR), float(rL), float(rNorm), ptr(img),
               ptr(attr), ptr(dfac), float(pixelSize), ptr(rotMat), ptr(trans), nImg, stream_ptr())
     return norm
 
