@@ -556,8 +556,8 @@ int expectation(thx_refine* h, int vi, hipStream_t st)
                                                        h->datP + (size_t)b0 * h->nPxl * 2, ctfRows, h->sigRcpP + (size_t)b0 * h->nPxl, h->rotB,
                                                        c.mLR, t, c.mLT, 1, nullptr, wR, wT, pDb, h->wC, h->uR, h->uT, h->wD, h->baseL, nullptr,
                                                        h->wsExpect, wg, act, st));
-                else
-                    THX_RC(thx_expect_local_dev(vol_of(h, vi, 0), vol_idx(h, b0), h->P, h->pf, h->N, h->iCol, h->iRow, h->nPxl, nb,
+                else   // (CTF search: the fused defocus kernel, on the cell-packed references as well since round 5)
+                    THX_RC(thx_expect_local_packed_dev(cells_of(h, vi, 0), vol_idx(h, b0), h->P, h->pf, h->N, h->iCol, h->iRow, h->nPxl, nb,
                                                 h->datP + (size_t)b0 * h->nPxl * 2, ctfRows, h->sigRcpP + (size_t)b0 * h->nPxl, h->rotB, c.mLR, t,
                                                 c.mLT, nD, nullptr, wR, wT, pDb, h->wC, h->uR, h->uT, h->uD, h->baseL, nullptr, h->wsExpect,
                                                 c.wgPerCU, act, st));
