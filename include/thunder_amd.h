@@ -269,6 +269,10 @@ int thx_reco_reconstruct_async_dev(thx_reco* r, const float* F, float* T, int ma
  * = 10, include/Reconstructor.h): two implementations are compared after the SAME number of rounds this way where the stop rule
  * -- a max norm against 0.95 x its previous value -- would let rounding decide (tests at P = 1024) */
 int thx_reco_set_balance_rounds(thx_reco* r, int maxIter, int minIter);
+/* T = max(T, 1e-25) (src/Reconstructor.cpp:1322-1324) alone: what a reconstruction leaves in the caller's T.  The iteration driver
+ * calls it on a rank that runs only the MAP-on reconstruction of a class (the MAP-off one having gone to another rank of the half),
+ * so that T sees the reference's sequence floor -> Wiener term -> floor.  Overwrites the plan's W. */
+int thx_reco_floor_T_dev(thx_reco* r, float* T, int maxRadius, void* stream);
 
 /* Projector::setProjectee(Volume src, nThread), src/Projector.cpp:123-148 + gridCorrection :524-606, starting from
  * the real-space map (the reference first fft.bw's the FT it is handed): zero-pad x pf, divide by TIK_RL,

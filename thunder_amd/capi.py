@@ -174,6 +174,7 @@ SIGNATURES = {
     "thx_reco_create": (_i, [C.POINTER(_vp), _i, _i, _i, _f, _f]),
     "thx_reco_destroy": (_i, [_vp]),
     "thx_reco_set_balance_rounds": (_i, [_vp, _i, _i]),
+    "thx_reco_floor_T_dev": (_i, [_vp, _vp, _i, _vp]),
     "thx_reco_reconstruct_dev": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, C.POINTER(_i), C.POINTER(_f),
                                       _vp]),
     "thx_reco_set_projectee_dev": (_i, [_vp, _vp, _vp, _vp]),

@@ -553,6 +553,18 @@ static int reco_fill(thx_reco* r, int size, int N, int pf, float a, float alpha)
     return 0;
 }
 
+// T = max(T, 1e-25) (src/Reconstructor.cpp:1322-1324) on its own: what a reconstruction leaves behind in the caller's T.  A rank
+// that runs only the SECOND reconstruction of an iteration (MAP on) on its own copy of T applies it first, so that its T goes
+// through exactly the modifications the reference's one T goes through (floor, Wiener term, floor).  r->W is overwritten.
+int thx_reco_floor_T_dev(thx_reco* r, float* T, int maxRadius, void* stream)
+{
+    THX_REQUIRE(r && T, "NULL pointer");
+    const size_t nHalfF = (size_t)r->PF * r->PF * (r->PF / 2 + 1);
+    hipLaunchKernelGGL(k_initW_floorT, dim3(nblk(nHalfF)), dim3(256), 0, as_stream(stream), r->W, T, r->PF, r->pf, maxRadius);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+
 int thx_reco_set_balance_rounds(thx_reco* r, int maxIter, int minIter)
 {
     THX_REQUIRE(r && maxIter >= 0 && maxIter <= 1000 && minIter >= 0, "bad arguments");

@@ -206,10 +206,10 @@ __global__ void k_take_first_f32(float* __restrict__ dst, const float* __restric
 }
 
 // T(0,0,0) of the classes this rank does not reconstruct are partial sums: zeroed before the sum over the half's ranks
-__global__ void k_mask_owned(float* __restrict__ t0, int n, int nRanks, int rank)
+__global__ void k_mask_owned(float* __restrict__ t0, int n, unsigned ownedMask)
 {
     const int k = threadIdx.x;
-    if (k < n && (k % nRanks) != rank) t0[k] = 0.f;
+    if (k < n && !((ownedMask >> k) & 1u)) t0[k] = 0.f;
 }
 
 __global__ void k_fill_nan(float* __restrict__ p, size_t n)
@@ -405,15 +405,28 @@ int ranks_of_half(const thx_refine* h, int half)
     const int W = h->world ? thx_comm_size(h->world) : 1;
     return W <= 1 ? 1 : (W - half + 1) / 2;
 }
-int owner_in_half(const thx_refine* h, int half, int k)
+// which = 0: the MAP-off reconstruction of class k, 1: the MAP-on one.  The two are independent -- the MAP-on pass uses the FSC
+// Model::resetReco handed over at the end of the PREVIOUS iteration -- so where a half has at least two ranks per class they go to
+// two different ranks (2 k and 2 k + 1) and run at the same time; otherwise rank k mod H does both.
+int owner_in_half(const thx_refine* h, int half, int k, int which)
 {
     const int H = ranks_of_half(h, half);
-    return (H > 1 && !knobs().recoReplicate) ? k % H : 0;
+    if (H <= 1 || knobs().recoReplicate) return 0;
+    return H >= 2 * h->nK ? 2 * k + which : k % H;
 }
-bool owns_class(const thx_refine* h, int vi, int k)
+bool owns_class(const thx_refine* h, int vi, int k, int which)
 {
     const int H = h->hemi ? thx_comm_size(h->hemi) : 1;
-    return H <= 1 || knobs().recoReplicate || (k % H) == thx_comm_rank(h->hemi);
+    if (H <= 1 || knobs().recoReplicate) return true;
+    return owner_in_half(h, h->halves[vi], k, which) == thx_comm_rank(h->hemi);
+}
+// where the sums of class k have to arrive: one rank (>= 0: ncclReduce) or, with two reconstructing ranks, everybody (-1: all-reduce)
+int reduce_root(const thx_refine* h, int k)
+{
+    const int H = h->hemi ? thx_comm_size(h->hemi) : 1;
+    if (H <= 1 || knobs().recoReplicate) return -1;
+    const int half = h->halves[0], a = owner_in_half(h, half, k, 0), b = owner_in_half(h, half, k, 1);
+    return a == b ? a : -1;
 }
 
 // Optimiser::allocPreCal rows of local half vi: _datP from the masked stack, _sigRcpP from the group's sigma table
@@ -705,11 +718,8 @@ int insertion(thx_refine* h, int vi, hipStream_t st)
                                          c.pixelSize, h->iColM, h->iRowM, h->pf, h->nPxlM, c.mReco, h->N, nb, st));
     }
     // the half-set reduce on the integers, class by class through one workspace, towards the rank that reconstructs the class
-    for (int k = 0; k < h->nK && h->hemi; k++) {
-        const int H = thx_comm_size(h->hemi);
-        const int root = (H > 1 && !knobs().recoReplicate) ? k % H : -1;
-        THX_RC(thx_reco_reduce_acc_class(h->hemi, h->accInt, h->nK, k, root, h->P, h->rU, h->pf, h->wsReduce, st));
-    }
+    for (int k = 0; k < h->nK && h->hemi; k++)
+        THX_RC(thx_reco_reduce_acc_class(h->hemi, h->accInt, h->nK, k, reduce_root(h, k), h->P, h->rU, h->pf, h->wsReduce, st));
     THX_RC(thx_insert_finish_dev(F, T, h->accInt, h->gexp, h->P, h->nK, st));
     return 0;
 }
@@ -1242,7 +1252,11 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
             // T(0,0,0) of every class after the half-set reduce: a class no image of the half went to has nothing to normalise.
             // With owners only the reconstructing rank holds the sum: the others' partial sums are zeroed and the half's ranks add up
             hipLaunchKernelGGL(k_take_first_f32, dim3(1), dim3(64), 0, st, h->t0Dev, h->T + (size_t)vi * K * volN, K, volN);
-            if (owners) hipLaunchKernelGGL(k_mask_owned, dim3(1), dim3(64), 0, st, h->t0Dev, K, Hh, thx_comm_rank(h->hemi));
+            if (owners) {   // (counted once: from the rank of the class's MAP-off reconstruction)
+                unsigned mask = 0;
+                for (int k = 0; k < K; k++) mask |= owns_class(h, vi, k, 0) ? (1u << k) : 0u;
+                hipLaunchKernelGGL(k_mask_owned, dim3(1), dim3(64), 0, st, h->t0Dev, K, mask);
+            }
             THX_LAUNCH_CHECK();
             if (owners) THX_RC(thx_comm_allreduce_f32(h->hemi, h->t0Dev, (size_t)K, st));
             THX_CHECK(hipMemcpyAsync(t0[vi], h->t0Dev, (size_t)K * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -1255,7 +1269,8 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
         auto res_of = [&](int map, int vi, int k) { return h->recoRes + (((size_t)map * 2 + vi) * 16 + k) * 8; };
         for (int vi = 0; vi < h->nV; vi++)
             for (int k = 0; k < K; k++) {
-                if (!(t0[vi][k] > 0.f) || !owns_class(h, vi, k)) continue;
+                const bool off = owns_class(h, vi, k, 0), on = owns_class(h, vi, k, 1);
+                if (!(t0[vi][k] > 0.f) || !(off || on)) continue;
                 float* F = h->F + ((size_t)vi * K + k) * volN * 2;
                 float* T = h->T + ((size_t)vi * K + k) * volN;
                 // prepareTF, src/Reconstructor.cpp:1056-1091: [allReduceT: done on the integers] normalise T and F by 1 / T(0,0,0)
@@ -1270,17 +1285,26 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
                 if (h->cap.Fsym) THX_CHECK(hipMemcpyAsync(h->cap.Fsym + ((size_t)vi * K + k) * volN * 2, F, volN * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
                 if (h->cap.Tsym) THX_CHECK(hipMemcpyAsync(h->cap.Tsym + ((size_t)vi * K + k) * volN, T, volN * sizeof(float), hipMemcpyDeviceToDevice, st));
                 // setMAP(false); setJoinHalf(true) (OPTIMISER_RECONSTRUCT_JOIN_HALF); setGridCorr(true) (OPTIMISER_3D_GRID_CORR), :7326-7352
-                THX_RC(thx_reco_reconstruct_async_dev(h->plans[vi], F, T, h->rU, nullptr, 0, 1, 0, 1, h->maps + ((size_t)h->halves[vi] * K + k) * mapN,
-                                                      res_of(0, vi, k), st));
+                if (off)
+                    THX_RC(thx_reco_reconstruct_async_dev(h->plans[vi], F, T, h->rU, nullptr, 0, 1, 0, 1, h->maps + ((size_t)h->halves[vi] * K + k) * mapN,
+                                                          res_of(0, vi, k), st));
+                else   // (the MAP-off pass runs on another rank: its one side effect on T, the 1e-25 floor, is applied here)
+                    THX_RC(thx_reco_floor_T_dev(h->plans[vi], T, h->rU, st));
+                // setMAP(true); setJoinHalf(true); setGridCorr(true), :7574-7600; Reconstructor::_FSC is LAST iteration's (Model::resetReco),
+                // so this pass does not wait for the FSC of the maps above: it is queued right behind them -- on another rank of
+                // the half where there is one to spare
+                if (on)
+                    THX_RC(thx_reco_reconstruct_async_dev(h->plans[vi], F, T, h->rU, h->fscReco.data() + (size_t)k * h->rU, h->rU, 1, 1, 1,
+                                                          h->mapsX + ((size_t)h->halves[vi] * K + k) * mapN, res_of(1, vi, k), st));
             }
         // every rank ends up with every class's map of both halves (the reference sends them to the master, src/Model.cpp:375-391):
         // class k of half hf is broadcast from the world rank that reconstructed it -- rank 2 x (its number inside the half) + hf
         // (rank r owns half r mod 2, checked in thx_refine_create)
-        auto exchange = [&](float* m) -> int {
+        auto exchange = [&](float* m, int which) -> int {
             if (!multi) return 0;
             for (int hf = 0; hf < 2; hf++)
                 for (int k = 0; k < K; k++)
-                    THX_RC(thx_comm_broadcast(h->world, m + ((size_t)hf * K + k) * mapN, mapN * sizeof(float), 2 * owner_in_half(h, hf, k) + hf, st));
+                    THX_RC(thx_comm_broadcast(h->world, m + ((size_t)hf * K + k) * mapN, mapN * sizeof(float), 2 * owner_in_half(h, hf, k, which) + hf, st));
             return 0;
         };
         // balanceClass(bm), :5586-5593, 7510-7523: _model.ref(t) = _model.ref(j).copyVolume(), for every half whose maps are here
@@ -1294,7 +1318,7 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
             }
             return 0;
         };
-        THX_RC(exchange(h->maps));
+        THX_RC(exchange(h->maps, 0));
         THX_RC(balance(h->maps));
         if (h->cap.mapsFsc) THX_CHECK(hipMemcpyAsync(h->cap.mapsFsc, h->maps, 2 * (size_t)K * mapN * sizeof(float), hipMemcpyDeviceToDevice, st));
         // compareTwoHemispheres(true, false, ...), src/Optimiser.cpp:7547: FSC over _rU shells, core-mask corrected on request
@@ -1308,17 +1332,7 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
             THX_RC(thx_compare_hemispheres_dev(h->ftA, h->ftB, h->N, h->rU, fsc.data() + (size_t)k * (h->N / 2), nullptr, coreR,
                                                6.0f /* EDGE_WIDTH_RL */, 0, 0, c.seed, fscCall, nullptr, st));
         }
-        for (int vi = 0; vi < h->nV; vi++)
-            for (int k = 0; k < K; k++) {
-                if (!(t0[vi][k] > 0.f) || !owns_class(h, vi, k)) continue;
-                float* F = h->F + ((size_t)vi * K + k) * volN * 2;
-                float* T = h->T + ((size_t)vi * K + k) * volN;
-                float* m = h->mapsX + ((size_t)h->halves[vi] * K + k) * mapN;
-                // setMAP(true); setJoinHalf(true); setGridCorr(true), :7574-7600; Reconstructor::_FSC is last iteration's
-                THX_RC(thx_reco_reconstruct_async_dev(h->plans[vi], F, T, h->rU, h->fscReco.data() + (size_t)k * h->rU, h->rU, 1, 1, 1, m,
-                                                      res_of(1, vi, k), st));
-            }
-        THX_RC(exchange(h->mapsX));
+        THX_RC(exchange(h->mapsX, 1));
         THX_RC(balance(h->mapsX));   // :7727-7733
         if (c.goldenAverage) {
             // compareTwoHemispheres(false, true, AVERAGE_TWO_HEMISPHERE_THRES), :7747.  One class under the gold standard: A = B =
