@@ -15,6 +15,7 @@ is everything computed from them by deterministic kernels (maps, FSC).  The sigm
 tests': weights move by 1e-6, a resampling threshold may flip for an image.
 """
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -58,7 +59,9 @@ def run_ranks(world, case, extra_env=None, timeout=900, rccl=False):
     if failed is not None:
         tail = open(os.path.join(d, "rank%d.log" % failed[0])).read()[-3000:]
         raise AssertionError("rank %d of %d exited with %d:\n%s" % (failed[0], world, failed[1], tail))
-    return [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(world)]
+    out = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(world)]
+    shutil.rmtree(d, ignore_errors=True)
+    return out
 
 
 _one_rank = {}
