@@ -68,6 +68,16 @@ public:
         _maxRadius = (_pf * N) / _pf / 2 - 1;   // floor(MIN_3(nCol,nRow,nSlc) / pf / 2 - 1), :131-133
     }
 
+    // setProjectee(Volume src, nThread) with the reference's own Volume (include/Projector.h:235; `_proj[l].setProjectee(_ref[l].copyVolume(),
+    // nThread)`, src/Model.cpp:1037): any volume type with nColRL() and operator[] onto its Fourier half [N][N][N/2+1] is taken as it is
+    // (the reference passes the Volume by value -- a moved temporary -- and its operator[] is not const: taken by forwarding reference)
+    template <class V, class = decltype(std::declval<V&>().nColRL())>
+    void setProjectee(V&& src, unsigned int nThread = 1)
+    {
+        static_assert(sizeof(src[0]) == 2 * sizeof(float), "the volume must be single-precision complex (RFLOAT = float)");
+        setProjectee(reinterpret_cast<const Complex*>(&src[0]), (int)src.nColRL(), nThread);
+    }
+
     // same, starting from the real-space map [N][N][N] (wrapped index layout)
     void setProjecteeRL(const float* srcRL, int N)
     {

@@ -120,6 +120,14 @@ public:
         _ox += ox; _oy += oy; _oz += oz; _counter += 1;
     }
 
+    // insertDir(const dvec3& dir), include/Reconstructor.h:545
+    template <class D, class = decltype(std::declval<const D&>().data())>
+    void insertDir(const D& dir)
+    {
+        static_assert(sizeof(D) == 3 * sizeof(double), "dir must be a vector of three doubles");
+        insertDir(dir.data()[0], dir.data()[1], dir.data()[2]);
+    }
+
     // insertP(const Complex* src, const RFLOAT* ctf, const dmat33& rot, RFLOAT w, const vec* sig = NULL),
     // src/Reconstructor.cpp:782-863: src is the ALREADY TRANSLATED image row on the pixel list.
     void insertP(const Complex* src, const float* ctf, const double* rot, float w)
@@ -291,6 +299,23 @@ public:
                                               _gridCorr ? 1 : 0, (float*)d, nullptr, nullptr, nullptr));
         THX_ABORT_ON(thx_memcpy_d2h(dstRL, d, (size_t)_N * _N * _N * sizeof(float)));
         thx_free_dev(d);
+    }
+
+    // reconstruct(Volume& dst, nThread) / reconstructG(Volume& dst, gpuIdx, nThread) with the reference's own Volume (include/Reconstructor.h:
+    // 720,728; `_model.reco(t).reconstruct(ref, _para.nThreadsPerProcess)`, src/Optimiser.cpp:7366-7371): dst is allocated in real
+    // space as the reference does (dst.alloc(_N, _N, _N, RL_SPACE), src/Reconstructor.cpp:1796) and filled through operator()
+    template <class V, class = decltype(std::declval<V&>().alloc(0L, 0L, 0L, 0))>
+    void reconstruct(V& dst, unsigned int nThread = 1)
+    {
+        dst.alloc((long)_N, (long)_N, (long)_N, 0 /* RL_SPACE, include/Image/ImageBase.h:48 */);
+        static_assert(sizeof(dst(0)) == sizeof(float), "the volume must be single precision (RFLOAT = float)");
+        reconstruct(reinterpret_cast<float*>(&dst(0)), nThread);
+    }
+    template <class V, class = decltype(std::declval<V&>().alloc(0L, 0L, 0L, 0))>
+    void reconstructG(V& dst, int gpuIdx, unsigned int nThread = 1)
+    {
+        THX_ABORT_ON(thx_set_device(gpuIdx));
+        reconstruct(dst, nThread);
     }
 
 private:

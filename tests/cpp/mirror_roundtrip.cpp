@@ -11,6 +11,24 @@
 
 using namespace thunder_amd;
 
+// a stand-in with the members of the reference's Volume the adapters use (include/Image/Volume.h:258-269, ImageBase.h:301-314): the
+// Volume forms of setProjectee / reconstruct are exercised through it (against the reference's real Volume they are compiled by
+// tools/boundary_lint.sh)
+struct MiniVolume {
+    std::vector<float> rl;
+    std::vector<Complex> ft;
+    long n = 0;
+    void alloc(long nCol, long nRow, long nSlc, int space)
+    {
+        n = nCol;
+        if (space == 0) rl.assign((size_t)nCol * nRow * nSlc, 0.f);
+        else ft.assign((size_t)(nCol / 2 + 1) * nRow * nSlc, Complex{{0.f, 0.f}});
+    }
+    float& operator()(size_t i) { return rl[i]; }
+    Complex& operator[](size_t i) { return ft[i]; }
+    long nColRL() const { return n; }
+};
+
 static void quat2mat(const double q[4], double* m)  // rotate3D, column-major
 {
     const double A[3][3] = {{0, -q[3], q[2]}, {q[3], 0, -q[1]}, {-q[2], q[1], 0}};
@@ -91,8 +109,39 @@ int main()
     for (size_t i = 0; i < out.size(); i++) { sab += (double)out[i] * ref[i]; saa += (double)out[i] * out[i]; sbb += (double)ref[i] * ref[i]; }
     const double cc = sab / std::sqrt(saa * sbb);
     if (!(cc > 0.99)) std::printf("FAIL %.5f\n", cc);
+    {   // reconstruct(Volume& dst, nThread): the same map again (T was floored by the first pass; nothing else changes), bit for bit
+        MiniVolume mv;
+        reco.reconstruct(mv, 1);
+        if (mv.rl.size() != out.size()) { std::printf("FAIL reconstruct(Volume&) size\n"); return 7; }
+        for (size_t i = 0; i < out.size(); i++)
+            if (mv.rl[i] != out[i]) { std::printf("FAIL reconstruct(Volume&) differs at %zu\n", i); return 7; }
+    }
     reco.freeSpace();
     if (!(cc > 0.99)) return 1;
+    {   // setProjectee(Volume src, nThread): from the FOURIER half of the map, against the projector set from the real-space map
+        MiniVolume mf;
+        mf.alloc(N, N, N, 1);
+        void *dRL = nullptr, *dFT = nullptr;
+        THX_ABORT_ON(thx_malloc_dev(&dRL, ref.size() * sizeof(float)));
+        THX_ABORT_ON(thx_malloc_dev(&dFT, mf.ft.size() * sizeof(Complex)));
+        THX_ABORT_ON(thx_memcpy_h2d(dRL, ref.data(), ref.size() * sizeof(float)));
+        THX_ABORT_ON(thx_fft3d_fw_dev((const float*)dRL, (float*)dFT, N, nullptr));
+        THX_ABORT_ON(thx_device_sync());
+        THX_ABORT_ON(thx_memcpy_d2h(mf.ft.data(), dFT, mf.ft.size() * sizeof(Complex)));
+        thx_free_dev(dRL); thx_free_dev(dFT);
+        Projector proj2;
+        proj2.setPf(pf);
+        proj2.setProjectee(mf, 1);
+        std::vector<Complex> s2(nPxl);
+        proj2.project(s2.data(), rot.data(), iCol.data(), iRow.data(), nPxl, 1);
+        double dmax = 0, smax = 0;
+        for (int p = 0; p < nPxl; p++) {
+            dmax = std::fmax(dmax, std::fmax(std::fabs((double)s2[p].dat[0] - slices[p].dat[0]), std::fabs((double)s2[p].dat[1] - slices[p].dat[1])));
+            smax = std::fmax(smax, std::fabs((double)slices[p].dat[0]));
+        }
+        std::fprintf(stderr, "setProjectee(Volume) vs setProjecteeRL: slice differs by %.3g of %.3g\n", dmax, smax);
+        if (!(dmax <= 1e-4 * smax)) { std::printf("FAIL setProjectee(Volume) %.3g\n", dmax); return 8; }
+    }
     // the -DGPU_VERSION members: insertI (quaternions, whole batch) -> prepareTFG -> reconstructG == the path above
     {
         Reconstructor reco2(1, N, N, pf, nullptr, 0, 1.9f, 15.0f);
