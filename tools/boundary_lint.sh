@@ -74,7 +74,7 @@ H
 cat > $S/boost/bind.hpp <<'H'
 #pragma once
 #include <functional>
-namespace boost { using std::bind; using std::ref; using std::cref; }
+namespace boost { using std::bind; using std::ref; using std::cref; namespace placeholders { using namespace std::placeholders; } }
 using namespace std::placeholders;
 H
 MPI_INC=""
@@ -104,4 +104,20 @@ rc2=$?
 grep -A3 "^$HERE/.*\(warning\|error\)" $S/callsite.log
 [ $rc2 -ne 0 ] && grep -B2 -A6 "error" $S/callsite.log | head -80
 echo "boundary lint: g++ -std=$STD -fsyntax-only integration/callsite_lint.cpp (reference call syntax against include/thunder_amd/*.hpp): exit $rc2"
-[ $rc -eq 0 ] && [ $rc2 -eq 0 ]
+# the reference's OWN, UNCHANGED callers of the plug-in surface -- src/Optimiser.cpp (ExpectLocal* / ExpectGlobal3D / ManagedArrayTexture /
+# ManagedCalPoint, :2180-3393) and src/Reconstructor.cpp (InsertFT / PrepareTF / Expose*, :865-2330) -- with -DGPU_VERSION against the
+# same header set, i.e. with gpu/include/Managed*.h replaced by integration/Managed*.h: they must still parse, since they are what
+# links against integration/Interface_thx.cpp
+rc3=0
+for unit in Optimiser Reconstructor; do
+    g++ -std=$STD -fsyntax-only -fopenmp -mavx2 -mfma -w -DGPU_VERSION \
+        -include $HERE/integration/ManagedArrayTexture.h -include $HERE/integration/ManagedCalPoint.h \
+        -I$HERE/integration -I$S $MPI_INC -I$HERE/include \
+        -I$REF/gpu/interface -I$REF/include -I$REF/include/Functions -I$REF/include/Geometry -I$REF/include/Image \
+        -I$REF/gpu/include -I$REF/external/Eigen3 -I$REF/external/easylogging -I$REF/external/jsoncpp \
+        -I$REF/external/packages/fftw-3.3.7/api $REF/src/$unit.cpp > $S/$unit.log 2>&1
+    r=$?
+    [ $r -ne 0 ] && { rc3=$r; grep -B2 -A6 "error" $S/$unit.log | head -60; }
+    echo "boundary lint: g++ -std=$STD -fsyntax-only -DGPU_VERSION <reference>/src/$unit.cpp (unchanged) with the replaced Managed*.h: exit $r"
+done
+[ $rc -eq 0 ] && [ $rc2 -eq 0 ] && [ $rc3 -eq 0 ]
