@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 INIT_OUTSIDE_CONFIDENCE_AREA = 0.5   # include/Particle.h:59
 TRANS_SEARCH_FACTOR = 0.25           # script/demo_3D.json "Translation Search Factor"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-INSERT_BYTES_PER_PIXEL_SAMPLE = 204  # 12 B in + F 8x8 Bx(R+W) + T 8x4 Bx(R+W) (kept for reference: the insertion merges draws and accumulates in LDS, so it is priced against the LDS atomic rate, not against these bytes)
+INSERT_ALGORITHMIC_BYTES_PER_PIXEL_DRAW = 204  # 12 B in + F 8x8 Bx(R+W) + T 8x4 Bx(R+W) per (listed pixel, draw); used ONLY for `step_algorithmic_TBps` (see there)
 EXPECT_BYTES_PER_PIXEL_SAMPLE = 64   # 8 neighbours x 8 B
 EXPECT_BYTES_PER_PIXEL = 16          # dat 8 + ctf 4 + sigRcp 4, read once per image-phase
 
@@ -85,11 +85,20 @@ def cpu_baseline(args, shard, nat, rounds_per_iteration):
     groups = max(1, min(int(args.cpu_groups), cores))
     F = np.zeros((groups, P, P, P // 2 + 1), np.complex64)
     T = np.zeros((groups, P, P, P // 2 + 1), np.float32)
-    t0 = time.perf_counter()
-    O.baseline_block(vol, P, shard.pf, N, pl, dat, ctf, sig, rot, tran, recoRot, recoTran, F, T, groups=groups)
-    Fsum, Tsum = F.sum(axis=0), T.sum(axis=0)      # the hemisphere all-reduce of the groups' volumes
-    t_em = time.perf_counter() - t0
-    em_rate = n / t_em
+    # the sample runs as THREE consecutive parts, each timed on its own: value = the median of the three rates, with their spread
+    # (one 256-thread run of a box shared with the GPU process moved by +-40 % between rounds 4 and 5)
+    parts = [p_ for p_ in np.array_split(np.arange(n), 3 if n >= 3 * groups else 1) if len(p_)]
+    rates, t_em = [], 0.0
+    for p_ in parts:
+        a_, b_ = int(p_[0]), int(p_[-1]) + 1
+        t0 = time.perf_counter()
+        O.baseline_block(vol, P, shard.pf, N, pl, dat[a_:b_], ctf[a_:b_], sig[a_:b_], rot[a_:b_], tran[a_:b_], recoRot[a_:b_],
+                         recoTran[a_:b_], F, T, groups=groups)
+        Fsum, Tsum = F.sum(axis=0), T.sum(axis=0)      # the hemisphere all-reduce of the groups' volumes
+        dt_ = time.perf_counter() - t0
+        rates.append((b_ - a_) / dt_)
+        t_em += dt_
+    em_rate = float(np.median(rates))
     shared = None
     if args.cpu_shared:
         n_sh = min(n, cores)
@@ -122,12 +131,14 @@ def cpu_baseline(args, shard, nat, rounds_per_iteration):
     n_total = args.particles
     t_iter = n_total / em_rate + (reco["seconds_per_iteration"] if reco else 0.0)
     return {"value": n_total / t_iter, "unit": "particles/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-            "em_particles_per_s": em_rate, "reconstruct": reco,
+            "em_particles_per_s": em_rate, "em_particles_per_s_runs": [round(r_, 3) for r_ in rates],
+            "em_spread": (max(rates) - min(rates)) / em_rate if em_rate > 0 else None, "reconstruct": reco,
             "thread_layout": "%d groups x %d threads, private F / T per group, summed at the end" % (groups, max(1, cores // groups)),
             "single_team_shared_FT": shared,
             "note": "a reported baseline, not the target: GPU / CPU says nothing about kernel quality, roofline.frac does",
             "sample": "E-step + insertion: %d particles x (%d phases x %d rot x %d shifts + %d inserts) through the oracle C "
-                      "port, OpenMP over images on %d threads in %d groups with private F / T, %.1f s; reconstruct leg: oracle gridding reconstruction on "
+                      "port, OpenMP over images on %d threads in %d groups with private F / T, in three consecutive parts timed separately "
+                      "(median rate, `em_spread` = (max - min) / median), %.1f s in all; reconstruct leg: oracle gridding reconstruction on "
                       "the %d^3 grid timed for 1 and 3 balancing rounds (scipy pocketfft, %d workers), scaled to 4 "
                       "reconstructions / %d rounds per iteration; value = %d particles / (particles / EM rate + "
                       "reconstruct seconds)" % (n, shard.nPhase, shard.mLR, shard.mLT, shard.mReco, cores, groups, t_em, P, cores,
@@ -726,6 +737,18 @@ def refinement_line(args, dev, rank, world, box, particles, steps, warmup, batch
                             "record_GBps_written_plus_read": ins_records_per_s * 56 / 1e9},
                         "k_expect_local": {"avg_launch_ms": exp_ms, "images_per_launch": exp_n,
                                            "GBps_algorithmic": exp_bytes / (exp_ms * 1e-3) / 1e9, "total_ms": t_exp}},
+            # ranks of the library's own communicators (thx_comm_size): what the collectives of this run actually spanned
+            "rccl_ranks": {"world": wcomm.size if wcomm is not None else 1, "hemi": hemi.size if hemi is not None else 1,
+                           "transport": os.environ.get("THX_COMM_TRANSPORT", "rccl") if world > 1 else None},
+            # SURVEY 8(d)'s whole-step algorithmic bytes (E-step: phases x nPxl x (16 + 64 mLR); insertion: nPxlM x mReco x 204 B)
+            # over the step time.  This EXCEEDS the HBM peak on purpose and is NOT a bandwidth: the insertion does not move those
+            # bytes -- draws that share a rotation are merged (distributivity) and the voxel sums are accumulated in LDS bricks,
+            # ~88 MB of real HBM traffic per image against 505 MB algorithmic at 256^3 (F / T parity at these settings:
+            # tests/test_fullsize_gpu.py::test_insert_vs_oracle_n256) -- and the E-step's cloud shares cells (traffic 0.44 x algorithmic)
+            "step_algorithmic_TBps": particles * (args.phases * nPxl * (EXPECT_BYTES_PER_PIXEL + EXPECT_BYTES_PER_PIXEL_SAMPLE * shard.mLR)
+                                                  + nPxlM * args.mReco * INSERT_ALGORITHMIC_BYTES_PER_PIXEL_DRAW) / (dt / steps) / 1e12,
+            "step_algorithmic_note": "exceeds the 8 TB/s peak because the insertion merges draws and accumulates in LDS (it never moves its "
+                                     "204 B per pixel-draw) and the E-step's rotations share cells; not a bandwidth claim -- roofline.frac is",
             "stages_ms_per_step": {k: round(st.stageMs[i] / steps, 2) for i, k in enumerate(STAGES)},
             "balancing_rounds_per_step": st.balancingRounds / max(1, steps),
             "fsc_half_maps": [round(float(x), 4) for x in fsc[: 8]],
@@ -794,10 +817,27 @@ def main():
                          "same JSON line (auto: when the command times the headline workload on one GPU)")
     args = ap.parse_args()
 
+    # --gpus N is the number of ranks of the job.  Under a launcher (WORLD_SIZE set) the two must agree; without one, N > 1
+    # re-executes this command under torch.distributed.run with N ranks on a free port -- `python bench.py --gpus 8` IS the 8-rank
+    # job, never a one-rank run that prints "n_gpus": 1.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): the two must agree" % (args.gpus, world))
+    if world > 1 and (args.config0 or args.staged or args.classification):
+        raise SystemExit("bench.py: --config0 / --staged / --classification are one-GPU lines; the N-rank job is the refinement line")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     # THX_BENCH_ONE_DEVICE=1 (tests only, never a measurement): every rank on cuda:0 -- the launcher's process group over gloo and,

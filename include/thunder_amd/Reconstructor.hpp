@@ -92,6 +92,8 @@ public:
     // counter over it in native code (thx_reco_allreduce), as the reference's GPU build does with ncclAllReduce
     // (gpu/src/cuthunder.cu:4972-5067).
     void setHemisphereComm(thx_comm* hemi) { _hemi = hemi; }
+    // (device pointers; the insert* methods are ASYNCHRONOUS -- call thx_device_sync(), or prepareTF, before reading through these
+    // from another stream or handing them to a GPU-aware MPI)
     float* getF_dev() { return _F; }
     float* getT_dev() { return _T; }
     int getModelDim() const { return _pf * _size; }
@@ -261,6 +263,9 @@ public:
     void prepareTF(unsigned int /*nThread*/ = 1)
     {
         const int dim = _pf * _size;
+        // insert / insertP / insertBatch leave their kernels queued (no device-wide wait per call): everything inserted so far must
+        // have landed in F / T before a caller-side all-reduce callback, a GPU-aware MPI or another stream reads them
+        THX_ABORT_ON(thx_device_sync());
         if (_hemi) {   // one collective for F and T (sphere rows only) + O + counter; order of the sums is immaterial
             void *ws = nullptr, *dO = nullptr, *dC = nullptr;
             THX_ABORT_ON(thx_malloc_dev(&ws, thx_reco_allreduce_workspace(dim, _maxRadius, _pf)));

@@ -162,3 +162,13 @@ def test_boundary_lint_against_reference_headers():
     out = subprocess.run(["bash", os.path.join(ROOT, "tools", "boundary_lint.sh"), "/root/reference"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert out.stdout.count("exit 0") == 4, out.stdout[-2000:]     # the stub, the call-site unit, the reference's Optimiser.cpp and Reconstructor.cpp
+
+
+def test_bench_refuses_a_rank_count_that_is_not_gpus():
+    """bench.py --gpus N under a launcher that started another number of ranks must refuse (no GPU needed: the check comes first)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and "must agree" in (out.stderr + out.stdout)

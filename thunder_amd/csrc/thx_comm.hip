@@ -390,6 +390,11 @@ int thx_comm_init(thx_comm** out, const void* id128, int rank, int size)
     c->size = size;
     if (hipGetDevice(&c->dev) != hipSuccess) { delete c; set_error("hipGetDevice failed"); return -1; }
     if (memcmp(id128, kShmMagic, sizeof(kShmMagic)) == 0) {
+        // loud, once per process: every collective of this communicator is a host-synchronous D2H + barrier + H2D (round-5 advisor)
+        static std::atomic<bool> warned{false};
+        if (!warned.exchange(true))
+            fprintf(stderr, "thunder_amd: WARNING: THX_COMM_TRANSPORT=shm -- the TEST-ONLY shared-memory transport carries this job's "
+                            "collectives through host memory; unset it to use RCCL\n");
         ShmTransport* t = new ShmTransport;
         const int rc = t->init(reinterpret_cast<const char*>(id128) + 8, rank, size);
         if (rc) { delete t; delete c; return rc; }

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_pack_cells(float4* __restrict__ cells, 
 __global__ __launch_bounds__(256) void k_cloud_order(unsigned char* __restrict__ order, const double* __restrict__ rotMat, int nR,
                                                      int key)
 {
-    __shared__ float sk[256];
+    __shared__ unsigned sk[256];
     const int img = blockIdx.x, i = threadIdx.x;
     const double* m0 = rotMat + (size_t)img * nR * 9;
     if (i < nR) {
@@ -344,11 +344,15 @@ __global__ __launch_bounds__(256) void k_cloud_order(unsigned char* __restrict__
         if (key == 2) w = dot(2, 1) - dot(1, 2);
         else if (key == 3) w = dot(0, 2) - dot(2, 0);
         else w = dot(1, 0) - dot(0, 1);
-        sk[i] = (float)w;
+        // a TOTAL order whatever the key holds: the float's bits mapped monotonically to an unsigned (negative values reversed), so a
+        // NaN key (a degenerate rotation matrix) ranks like any other value instead of comparing false against everything --
+        // every rotation gets its own rank and every order[] slot is written (round-5 advisor)
+        const unsigned b = __float_as_uint((float)w);
+        sk[i] = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
     }
     __syncthreads();
     if (i < nR) {
-        const float k = sk[i];
+        const unsigned k = sk[i];
         int rank = 0;
         for (int j = 0; j < nR; j++) rank += (sk[j] < k || (sk[j] == k && j < i)) ? 1 : 0;
         order[(size_t)img * nR + rank] = (unsigned char)i;

@@ -865,6 +865,10 @@ int thx_refine_create(thx_refine** out, const thx_refine_config* cfg, thx_comm* 
         THX_REQUIRE((hemi ? thx_comm_size(hemi) : 1) == Hh || (!hemi && Hh == 1), "hemi must span the world ranks of this rank's parity");
         THX_REQUIRE(!hemi || thx_comm_rank(hemi) == wr / 2, "hemi rank must be world rank / 2");
     }
+    // the owners of the classes are derived from `world` (ranks_of_half / owner_in_half) and the reduce's root from `hemi`: a half
+    // that spans several ranks needs the world they are numbered in, or nothing would be broadcast (round-5 advisor)
+    THX_REQUIRE(!hemi || thx_comm_size(hemi) <= 1 || (world && thx_comm_size(world) > 1),
+                "a hemisphere communicator of more than one rank needs the world communicator as well");
     thx_refine* h = new thx_refine;
     h->cfg = c;
     h->cfg.symMat = nullptr; h->cfg.symQuat = nullptr;   // (copied below; the caller's arrays are not kept)
