@@ -634,6 +634,8 @@ def refinement_line(args, dev, rank, world, box, particles, steps, warmup, batch
     if world > 1:
         hemi, wcomm = make_comms(rank, world, share_from)
     nat = NativeRefine(shard, hemi, wcomm, norm_correction=not args.no_norm_correction)
+    if args.cutoff:
+        nat.set_cutoff(*args.cutoff)     # (stays in force over reset and every iteration)
 
     def barrier():
         if world > 1:
@@ -715,7 +717,8 @@ def refinement_line(args, dev, rank, world, box, particles, steps, warmup, batch
                                    "phases x %d rot x %d shifts, normCorrection%s, %d inserts, 2 half-sets, 2x reconstruct per half, FSC, "
                                    "projector refresh)" % (particles, box, world, args.phases, args.mLR,
                                                            args.mLT, " off" if args.no_norm_correction else "", args.mReco),
-                       "box": box, "particles": particles, "particles_per_gpu": n_local, "nPxl": nPxl,
+                       "box": box, "particles": particles, "particles_per_gpu": n_local, "nPxl": nPxl, "nPxlM": nPxlM,
+                       "cutoff": dict(zip(("r", "rU", "reco_size", "rScan"), nat.cutoff())),
                        "hbm_in_use_GB": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9, 1),
                        "pf": 2,
                        "search_state": "device particle filter (perturb / resample every phase, Philox-seeded)",
@@ -753,7 +756,7 @@ def refinement_line(args, dev, rank, world, box, particles, steps, warmup, batch
             "balancing_rounds_per_step": st.balancingRounds / max(1, steps),
             "fsc_half_maps": [round(float(x), 4) for x in fsc[: 8]],
         }
-        if cpu and not args.no_cpu_baseline and world == 1:
+        if cpu and not args.no_cpu_baseline and world == 1 and not args.cutoff:
             args_c = argparse.Namespace(**vars(args))
             args_c.cpu_particles, args_c.particles = cpu_particles, particles
             if box >= 512:
@@ -792,6 +795,10 @@ def main():
     ap.add_argument("--cpu-no-reconstruct", action="store_true")
     ap.add_argument("--cpu-groups", type=int, default=16, help="CPU baseline: thread groups with private F / T (MPI ranks of the reference)")
     ap.add_argument("--cpu-shared", action="store_true", help="CPU baseline: also time the single-team form (one shared F / T)")
+    ap.add_argument("--cutoff", type=int, nargs=2, metavar=("R", "RU"), default=None,
+                    help="frequency cut-offs of the timed iterations (thx_refine_set_cutoff): r = Optimiser::_r (E-step list, projector radius), "
+                         "rU = Model::_rU (M-step list, Reconstructor::_maxRadius, reconstruction grid size min(N, (rU + 2) * 2)); default: Nyquist, "
+                         "N / 2 - 2 for both -- what the metric is quoted on")
     ap.add_argument("--no-norm-correction", action="store_true",
                     help="leave Optimiser::normCorrection (OPTIMISER_NORM_CORRECTION, on in the reference's Config.h) out of the iteration")
     ap.add_argument("--unsorted", action="store_true",
@@ -904,6 +911,11 @@ def main():
                 ("configs[3] K=4 classification, one GPU's share (%d of 50k images)" % n3,
                  ["--classification", "--box", str(b3), "--scan-images", str(n3), "--steps", "2", "--warmup", "1"]),
                 ("configs[4] %d x %d^3 refinement" % (n4, b4), ["--box", str(b4), "--particles", str(n4), "--steps", "2", "--warmup", "1", "--cpu-particles", "64"]))
+        # an iteration BELOW Nyquist, as a caller following Model::updateR runs most of them: r = rU = 48 of 126 at 256^3 -- E-step on the
+        # 3 600-pixel list, insertion / reduce / gridding loop on the resized 200^3 grid (Reconstructor::resizeSpace), 48 FSC shells
+        rc = max(6, b1 // 2 - 2 - (b1 * 78) // 256)
+        runs += (("configs[1] %d x %d^3 refinement at cut-offs r = rU = %d (resized reconstruction grid)" % (n1, b1, rc),
+                  ["--box", str(b1), "--particles", str(n1), "--steps", "2", "--warmup", "1", "--cutoff", str(rc), str(rc)]),)
         if not small:
             runs += (("configs[1] through the reference's plug-in surface (staged drop-in path)", ["--staged"]),)
         for name, extra in runs:

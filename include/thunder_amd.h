@@ -781,6 +781,24 @@ int thx_refine_set_classes(thx_refine* h, const int* cls, void* stream);
  * next to ANCHOR_POINT_2: the fold happens here */
 int thx_refine_set_grid(thx_refine* h, const double* quat, const double* shifts, void* stream);
 int thx_refine_set_search_type(thx_refine* h, int searchType);
+/* The frequency cut-offs of the NEXT iteration -- per-iteration inputs, as Model::updateR / updateRU leave them before it starts
+ * (the schedule is the caller's, SURVEY 2 out of scope).  Until the first call: r = rU = N / 2 - 2 (Nyquist, _size = _N).
+ *   r  = Optimiser::_r  (rL < r <= N / 2 - 1): the expectation's pixel list allocPreCalIdx(_r, _rL) (src/Optimiser.cpp:631,1693);
+ *        a global search scans on min(cfg.rScan, r); Projector::_maxRadius = _r (Model::refreshProj, src/Model.cpp:1042) ends the
+ *        slices of allReduceSigma and normCorrection; normCorrection's rNorm = min(_r, resolutionP(0.75)) (:6203).
+ *   rU = Model::_rU     (0 < rU <= N / 2 - 1): the reconstruction's list allocPreCalIdx(rU, 0) (:6722-6741),
+ *        Reconstructor::setMaxRadius(rU) and resizeSpace(min(N, (rU + ceil(a)) * 2)) (Model::resetReco, src/Model.cpp:1100-1125;
+ *        src/Reconstructor.cpp:184-198): insertion, the half-set reduce, prepareTF and the gridding loop run on the (pf size)^3 grid,
+ *        the last step of reconstruct pads F W into (pf N)^3 (:1677-1701); compareTwoHemispheres' FSC has rU shells, and the
+ *        curve handed to the NEXT iteration's MAP reconstruction keeps this iteration's rU entries (Model::resetReco's
+ *        setFSC(_FSC.col(l)); shells beyond count as FSC 0, src/Reconstructor.cpp:1244-1247).
+ * Re-cuts the M-step rows, both CTF row sets [, the defocus search's rows, the scan's ramps]; rebuilds the reconstruction plans when
+ * the size changes; before the first iteration it also resets the reconstructor's FSC to rU ones (Model::initProjReco,
+ * src/Model.cpp:1086).  Synchronises the stream.  Capture buffers Fraw / Traw / Fsym / Tsym are filled as [local halves][nK]
+ * volumes of the CURRENT (pf size)^3 half grid, contiguous. */
+int thx_refine_set_cutoff(thx_refine* h, int r, int rU, void* stream);
+/* any pointer may be NULL: r, rU as set; size = Reconstructor::_size; rScan = the radius a global search scans at */
+int thx_refine_get_cutoff(const thx_refine* h, int* r, int* rU, int* size, int* rScan);
 int thx_refine_reset(thx_refine* h, void* stream);     /* the state before the first iteration */
 /* one EM iteration in the reference's order (src/Optimiser.cpp:3595-4073): expectation ([global scan -> class -> support
  * points ->] local phases), [normCorrection,] allReduceSigma, insertion into the F / T of every image's class, prepareTF
@@ -816,7 +834,7 @@ typedef struct thx_refine_view {
     const double *r, *t, *wR, *wT;          /* particle filter: [nImg][mLR][4], [nImg][mLT][2], priors */
     const double *offset;                   /* [nImg][2] */
     const float *vols, *cells;              /* [nVol] projector FTs / their cell-packed copies */
-    const float *F, *T;                     /* [nVol] accumulators of the last iteration (after prepareTF / Wiener term) */
+    const float *F, *T;                     /* [nVol] accumulators of the last iteration (after prepareTF / Wiener term): fdim^3 half grids, contiguous */
     const float *sig;                       /* [local halves][nGroup][rSig] */
     const double *recoRot, *recoTran;       /* draws of the LAST inserted local half [n][mReco][9] / [n][mReco][2] */
     const int *nP;                          /* [nImg] phase index at which the stop rule ended the image's search (maxPhase > nPhase) */
@@ -826,6 +844,7 @@ typedef struct thx_refine_view {
     const double *d, *wD;                   /* [nImg][mLD] defocus factors and their priors (CTF search; NULL without) */
     const float *maps, *mapsMAP;            /* [2][nK][N]^3 MAP-off / final maps of the last iteration */
     int nK, nPxlS;
+    int fdim;                               /* grid of F / T: pf * Reconstructor::_size (= vdim at Nyquist; thx_refine_set_cutoff) */
 } thx_refine_view;
 int thx_refine_get_view(thx_refine* h, thx_refine_view* out);
 

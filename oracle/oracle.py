@@ -342,9 +342,13 @@ def set_projectee(ref_rl, pf=2):
 
 def reconstruct(F, T, P, N, pf, maxRadius, FSC=None, joinHalf=False, MAP=True, gridCorr=True, a=1.9, alpha=15.0,
                 return_iters=False, max_rounds=30, T_inplace=False, force_rounds=None):
-    """Reconstructor::reconstruct(Volume&) src/Reconstructor.cpp:1129-1831, MODE_3D, _size == _N.
-    F complex64 [P][P][P/2+1], T float32 same grid (both AFTER prepareTF); returns float32 [N][N][N]
-    (wrapped-index layout).  The reference changes _T3D in place (Wiener term :1242-1270, 1e-25 floor :1322-1324), so a
+    """Reconstructor::reconstruct(Volume&) src/Reconstructor.cpp:1129-1831, MODE_3D.
+    F complex64 [P][P][P/2+1], T float32 same grid (both AFTER prepareTF), P = PAD_SIZE = _pf * _size; returns float32 [N][N][N]
+    (wrapped-index layout).  _size == _N (P == N * pf) is the grid at Nyquist; after Reconstructor::resizeSpace (:184-198; every
+    iteration below Nyquist, src/Model.cpp:1113: _size = min(N, (rU + ceil(a)) * 2)) the four volumes and the gridding loop live on
+    the SMALL grid P < N * pf -- the FFT plans are PAD_SIZE^3 (:121-124), convoluteC still divides QUAD_3 by (_N * _pf)^2
+    (:2639-2645) -- and only the last step places F * W into an (_N * _pf)^3 padDst (:1677-1701) for the final c2r and
+    VOL_EXTRACT_RL.  The reference changes _T3D in place (Wiener term :1242-1270, 1e-25 floor :1322-1324), so a
     second reconstruct() of the same iteration starts from the first one's T: T_inplace=True does the same to the caller's
     array (float32, contiguous); the default works on a copy.  force_rounds = k runs exactly k balancing rounds whatever the
     stop rule of :1530-1551 says (tests use it to compare two implementations after the SAME round when the rule -- which
@@ -389,11 +393,16 @@ def reconstruct(F, T, P, N, pf, maxRadius, FSC=None, joinHalf=False, MAP=True, g
                 break
     else:
         L.orc_W_nogridcorr(_p(W, c_f), _p(T, c_f), C.c_int(P), C.c_int(pf), C.c_int(maxRadius))
-    pad = np.zeros((P, P, P // 2 + 1), np.complex64)
-    L.orc_FW(_p(pad, c_f), _p(F, c_f), _p(W, c_f), C.c_int(P), C.c_int(pf), C.c_int(maxRadius))
-    prl = np.ascontiguousarray(sfft.irfftn(pad, s=(P, P, P)).astype(np.float32))
+    PN = N * pf
+    assert P <= PN and P % 2 == 0
+    pad = np.zeros((PN, PN, PN // 2 + 1), np.complex64)
+    if P == PN:
+        L.orc_FW(_p(pad, c_f), _p(F, c_f), _p(W, c_f), C.c_int(P), C.c_int(pf), C.c_int(maxRadius))
+    else:
+        L.orc_FW_pad(_p(pad, c_f), C.c_int(PN), _p(F, c_f), _p(W, c_f), C.c_int(P), C.c_int(pf), C.c_int(maxRadius))
+    prl = np.ascontiguousarray(sfft.irfftn(pad, s=(PN, PN, PN)).astype(np.float32))
     dst = np.zeros((N, N, N), np.float32)
-    L.orc_extract_tik(_p(dst, c_f), _p(prl, c_f), C.c_int(P), C.c_int(N), C.c_int(pf), C.c_int(1))
+    L.orc_extract_tik(_p(dst, c_f), _p(prl, c_f), C.c_int(PN), C.c_int(N), C.c_int(pf), C.c_int(1))
     if return_iters:
         return dst, iters, diffs, W
     return dst
@@ -832,24 +841,46 @@ class Iteration:
         self.ref = f32(ref).reshape(self.K, N, N, N)
         self.symQ = None if not c["sym"] or c["sym"]["n"] == 0 else c["sym"]["quat"]
         self.symR = None if self.symQ is None else c["sym"]["R"]
-        self.pl = pixel_list(N, self.rU, c["rL"], pf)          # expectation: allocPreCalIdx(_r, _rL), :631
-        self.plM = pixel_list(N, self.rU, 0, pf)               # reconstruction: allocPreCalIdx(rU, 0), :6722
-        self.plS = pixel_list(N, c["rScan"], c["rL"], pf) if c["rScan"] else None
         nA = c["nHalfA"]
         self.ranges = [(0, nA), (nA, self.n)]
         self.mask2d = soft_mask(N, np.float32(c["maskRadiusPx"]), 6.0)
-        self.ctfM = np.stack([ctf(c["pixelSize"], *self.attr[l], N, self.plM["iCol"], self.plM["iRow"]) for l in range(self.n)])
-        self.ctfP = np.stack([ctf(c["pixelSize"], *self.attr[l], N, self.pl["iCol"], self.pl["iRow"]) for l in range(self.n)])
+        self.have_grid = grid is not None
         if grid is not None:   # Particle::reset(k, nR, nT, 1): the drawn rotations, symmetrise()d next to ANCHOR_POINT_2
             gq, gt = grid
             self.gridR = f64(gq) if self.symQ is None else symmetrise(gq, self.symQ, None)
             self.gridT = f64(gt)
-            self.ctfS = np.stack([ctf(c["pixelSize"], *self.attr[l], N, self.plS["iCol"], self.plS["iRow"]) for l in range(self.n)])
         self.cls0 = np.zeros(self.n, np.int32) if cls0 is None else i32(cls0)
         self.mLD = int(c.get("mLD", 0))
+        self.iterCount = 0
+        self.set_cutoff(self.rU, self.rU)                      # Nyquist: r = rU = N / 2 - 2, _size = _N
+        self.reset()
+
+    def set_cutoff(self, r, rU, a=1.9):
+        """The frequency cut-offs of the NEXT iteration, as Model::updateR / updateRU leave them before it starts (the schedule itself is
+        the caller's): r = Optimiser::_r -- the expectation's pixel list allocPreCalIdx(_r, _rL) (src/Optimiser.cpp:631,1693; a global
+        search scans on it too), Projector::_maxRadius (Model::refreshProj, src/Model.cpp:1042: what allReduceSigma's and
+        normCorrection's slices are cut at) and normCorrection's rNorm = min(_r, .) (:6203) --; rU = Model::_rU -- the
+        reconstruction's pixel list allocPreCalIdx(rU, 0) (:6722-6741), Reconstructor::_maxRadius and its grid
+        _size = min(N, (rU + ceil(a)) * 2) (Model::resetReco, src/Model.cpp:1100-1125, Reconstructor::resizeSpace
+        src/Reconstructor.cpp:184-198), the shells of compareTwoHemispheres' FSC.  thx_refine_set_cutoff's twin."""
+        c, N, pf = self.c, self.N, self.pf
+        assert c["rL"] < r <= N // 2 - 1 and 0 < rU <= N // 2 - 1
+        self.rE, self.rU = int(r), int(rU)
+        self.size = min(N, (self.rU + int(np.ceil(a))) * 2)
+        self.PF = pf * self.size
+        self.pl = pixel_list(N, self.rE, c["rL"], pf)          # expectation: allocPreCalIdx(_r, _rL), :631
+        self.plM = pixel_list(N, self.rU, 0, pf)               # reconstruction: allocPreCalIdx(rU, 0), :6722
+        self.ctfM = np.stack([ctf(c["pixelSize"], *self.attr[l], N, self.plM["iCol"], self.plM["iRow"]) for l in range(self.n)])
+        self.ctfP = np.stack([ctf(c["pixelSize"], *self.attr[l], N, self.pl["iCol"], self.pl["iRow"]) for l in range(self.n)])
+        self.plS = None
+        if self.have_grid:      # the scan runs on the expectation's list: the radius of the scan = min(cfg rScan, r)
+            self.rS = min(int(c["rScan"]), self.rE)
+            self.plS = pixel_list(N, self.rS, c["rL"], pf)
+            self.ctfS = np.stack([ctf(c["pixelSize"], *self.attr[l], N, self.plS["iCol"], self.plS["iRow"]) for l in range(self.n)])
         if self.mLD:   # allocPreCal(.., ctf = true): the pre-calculated rows of the defocus search, :8124-8169
             self.freqD, self.defD, self.K1, self.K2 = expect_precal(self.attr, N, c["pixelSize"], self.pl["iCol"], self.pl["iRow"])
-        self.reset()
+        if self.iterCount == 0:                                # Model::initProjReco: setFSC(vec::Constant(_rU, 1)), src/Model.cpp:1086
+            self.fscReco = np.ones((self.K, self.rU), np.float32)
 
     # -- helpers ------------------------------------------------------------------------------
     def _remask(self, imgs):
@@ -1055,11 +1086,11 @@ class Iteration:
         CTF-modulated slice over rL <= r < rNorm, median over ALL particles, both stacks rescaled, rows cut again"""
         c, N, P, pf = self.c, self.N, self.P, self.pf
         res = max(res_p(self.fscReco[k], 0.75, 1, 1, False) for k in range(self.K))   # Model::resolutionP(0.75, false), src/Model.cpp:984-994
-        rNorm = float(min(self.rU, res))
+        rNorm = float(min(self.rE, res))                        # TSGSL_MIN_RFLOAT(_r, _model.resolutionP(0.75, false)), :6203
         norm = np.zeros(self.n, np.float32)
         for vi, (lo, hi) in enumerate(self.ranges):
             for l in range(lo, hi):
-                norm[l] = norm_residual(self.vols[vi][self.cls[l]], P, pf, N, self.rU, float(c["rL"]), rNorm, rotate3D(self.topR[l]),
+                norm[l] = norm_residual(self.vols[vi][self.cls[l]], P, pf, N, self.rE, float(c["rL"]), rNorm, rotate3D(self.topR[l]),
                                         self.topT[l], c["pixelSize"], self.attr[l], self.img[l])
         m = median(norm)
         self.img, self.imgOri = norm_scale(self.img, self.imgOri, norm, m)
@@ -1070,7 +1101,7 @@ class Iteration:
         compareTwoHemispheres(fsc) -> reconstruct with MAP on (Reconstructor::_FSC of the previous iteration, joinHalf) ->
         balanceClass -> compareTwoHemispheres(avg) -> solventFlatten.  T [2][K] is changed in place as the reference changes
         _T3D.  force: None = the reference's stop rule, else the round counts to run [MAP off / on][half][class]."""
-        c, N, P, pf, K = self.c, self.N, self.P, self.pf, self.K
+        c, N, P, pf, K = self.c, self.N, self.PF, self.pf, self.K          # (P here: PAD_SIZE = _pf * _size of the reconstructors)
         empty = [[not (T[vi][k].flat[0] > 0) for k in range(K)] for vi in range(2)]
         maps = [[np.zeros((N, N, N), np.float32) for _ in range(K)] for _ in range(2)]
         rounds = np.zeros((2, 2, K), np.int64)
@@ -1143,13 +1174,14 @@ class Iteration:
         if c["normCorrection"] and self.iterCount != 0 and not glob:
             self._norm_correction(out)
         datM = np.ascontiguousarray(self.imgOri.reshape(self.n, -1)[:, plM["iPxl"]])
-        F = [[np.zeros((P, P, P // 2 + 1), np.complex64) for _ in range(K)] for _ in range(2)]
-        T = [[np.zeros((P, P, P // 2 + 1), np.float32) for _ in range(K)] for _ in range(2)]
+        PF = self.PF                                          # the reconstructors' grid: _pf * _size (Reconstructor::allocSpace after resizeSpace)
+        F = [[np.zeros((PF, PF, PF // 2 + 1), np.complex64) for _ in range(K)] for _ in range(2)]
+        T = [[np.zeros((PF, PF, PF // 2 + 1), np.float32) for _ in range(K)] for _ in range(2)]
         w = np.float32(np.float32(1.0) / np.float32(c["mReco"]))
         callD = self.call(SLOT_DRAWS)
         for vi, (lo, hi) in enumerate(self.ranges):
             # allReduceSigma (OPTIMISER_SIGMA_RANK1ST, OPTIMISER_SIGMA_WHOLE_FREQUENCY), :6395-6710
-            spec = np.stack([sigma_image(self.vols[vi][self.cls[l]], P, pf, N, self.rU, self.rSig, rotate3D(self.topR[l]), self.topT[l],
+            spec = np.stack([sigma_image(self.vols[vi][self.cls[l]], P, pf, N, self.rE, self.rSig, rotate3D(self.topR[l]), self.topT[l],
                                          self.offset[l], c["pixelSize"], self.attr_d(l, self.topD[l]) if ctfs else self.attr[l], self.img[l],
                                          self.imgOri[l])
                              for l in range(lo, hi)])
@@ -1169,7 +1201,7 @@ class Iteration:
                     cm = self.ctfM[l]
                     if ctfs:   # CTF(ctf, .., defocusU * d, defocusV * d, ..) of the draw's defocus factor, :7183-7202
                         cm = ctf(c["pixelSize"], *self.attr_d(l, self.d[l, iD[m]]), N, plM["iCol"], plM["iRow"])
-                    insertP(F[vi][kc], T[vi][kc], P, src, cm, rotate3D(self.q[l, iR[m]]), w, plM["iColPad"], plM["iRowPad"])
+                    insertP(F[vi][kc], T[vi][kc], PF, src, cm, rotate3D(self.q[l, iR[m]]), w, plM["iColPad"], plM["iRowPad"])
             self.sig[vi], self.sigRcp[vi] = sig, rcp
         out["F_raw"], out["T_raw"] = [[x.copy() for x in h] for h in F], [[x.copy() for x in h] for h in T]
         # prepareTF (one rank per half: the all-reduces are the identity), :7268 -> src/Reconstructor.cpp:1056-1091: normalise
@@ -1179,10 +1211,10 @@ class Iteration:
             for k in range(K):
                 if not T[vi][k].flat[0] > 0:
                     continue
-                normalise_TF(F[vi][k], T[vi][k], P)
+                normalise_TF(F[vi][k], T[vi][k], PF)
                 if self.symR is not None:
-                    T[vi][k] = symmetrize(T[vi][k], P, self.symR, symr)
-                    F[vi][k] = symmetrize(F[vi][k], P, self.symR, symr)
+                    T[vi][k] = symmetrize(T[vi][k], PF, self.symR, symr)
+                    F[vi][k] = symmetrize(F[vi][k], PF, self.symR, symr)
         out["F_sym"], out["T_sym"] = [[x.copy() for x in h] for h in F], [[x.copy() for x in h] for h in T]
         Tn = [[t.copy() for t in h] for h in T]
         # class distribution (refreshClassDistr, :5484-5516) and balanceClass after a global search

@@ -688,6 +688,26 @@ void orc_FW(RFLOAT* padDst, const RFLOAT* F, const RFLOAT* W, int P, int pf, int
             }
 }
 
+/* the same with Reconstructor::resizeSpace in effect (_size < _N, src/Reconstructor.cpp:184-198): F and W live on the PF = _pf *
+ * _size grid, padDst is the (_N * _pf)^3 half grid PN (:1677-1701: `Volume padDst(_N * _pf, ...)`, VOLUME_FOR_EACH_PIXEL_FT(_F3D)
+ * walks the SMALL grid and padDst.setFTHalf(.., i, j, k) places the voxel at the same integer frequency of the large one). */
+void orc_FW_pad(RFLOAT* padDst, int PN, const RFLOAT* F, const RFLOAT* W, int PF, int pf, int maxRadius)
+{
+    size_t n = (size_t)PN * PN * (PN / 2 + 1);
+    memset(padDst, 0, 2 * n * sizeof(RFLOAT));
+    for (long k = -PF / 2; k < PF / 2; k++)
+        for (long j = -PF / 2; j < PF / 2; j++)
+            for (long i = 0; i <= PF / 2; i++) {
+                double q = (double)i * i + (double)j * j + (double)k * k;
+                if (q < pow2f_((RFLOAT)(maxRadius * pf))) {
+                    size_t idx = iFTHalf3_(i, j, k, PF), odx = iFTHalf3_(i, j, k, PN);
+                    RFLOAT a0 = F[2 * idx], a1 = F[2 * idx + 1], b0 = W[idx], b1 = 0.0f;
+                    padDst[2 * odx] = a0 * b0 - a1 * b1;
+                    padDst[2 * odx + 1] = a0 * b1 + a1 * b0;
+                }
+            }
+}
+
 /* VOL_EXTRACT_RL (include/Image/ImageFunctions.h:51-64) followed by the TIK correction
  * (RECONSTRUCTOR_CORRECT_CONVOLUTION_KERNEL, :1781-1802): dst(i,j,k) = pad(i,j,k) /
  * TIK_RL(NORM_3(i,j,k) / (pf * N)).  pad: real P^3, dst: real N^3, both wrapped-index layout. */

@@ -121,7 +121,7 @@ class ReplayNative:
 
     def view(self):
         nP = self.d["s%d/nPxl" % self.step]
-        return types.SimpleNamespace(nPxl=int(nP[0]), nPxlM=int(nP[1]), **{k: k for k in VIEW_ARRAYS})
+        return types.SimpleNamespace(nPxl=int(nP[0]), nPxlM=int(nP[1]), fdim=2 * self.c["N"], **{k: k for k in VIEW_ARRAYS})
 
     def fetch(self, name, dtype, shape, offset_elems=0):
         a = self.d["s%d/view/%s" % (self.step, name)].reshape(-1)

@@ -232,3 +232,66 @@ def test_chain_per_image_stop_rule(oracle):
     # rows of phases an image did not run stay empty
     for l in range(n):
         assert not np.any(r["uR"][ran[l]:, l]) and np.all(r["uR"][:ran[l], l].sum(axis=1) > 0)
+
+
+def test_reconstruct_on_a_resized_grid(oracle):
+    """Reconstructor::resizeSpace (src/Reconstructor.cpp:184-198; Model::resetReco src/Model.cpp:1113): the same slices inserted into
+    the (pf size)^3 grid and into the (pf N)^3 grid, reconstructed on each.  The two are not the same computation -- convoluteC keeps
+    QUAD_3 / (N pf)^2 as the kernel's argument on the smaller grid (:2639-2645), so the balancing kernel differs -- but both are
+    reconstructions of the same data: they agree with each other and with the generating map inside the cut-off, and the small
+    grid's map has nothing beyond it that the large one lacks.  (Pins the placement of F W into the (N pf)^3 padDst, :1677-1701.)"""
+    from thunder_amd import synth
+    O = oracle
+    N, pf, rU = 32, 2, 8
+    rng = np.random.default_rng(3)
+    ref = synth.blob_map(N, nblob=10)
+    vol = O.set_projectee(ref, pf)
+    size = min(N, (rU + 2) * 2)
+    PF, PN = pf * size, pf * N
+    assert (size, PF) == (20, 40)
+    pl = O.pixel_list(N, rU, 0, pf)
+    quat = synth.random_quats(300, rng)
+    maps = {}
+    for P in (PF, PN):
+        F, T = np.zeros((P, P, P // 2 + 1), np.complex64), np.zeros((P, P, P // 2 + 1), np.float32)
+        for q in quat:
+            R = O.rotate3D(q)
+            O.insertP(F, T, P, O.project(vol, PN, pf, R, pl["iCol"], pl["iRow"]), np.ones(pl["nPxl"], np.float32), R, 1.0, pl["iColPad"], pl["iRowPad"])
+        O.normalise_TF(F, T, P)
+        maps[P], it, _, _ = O.reconstruct(F, T, P, N, pf, rU, MAP=False, gridCorr=True, return_iters=True)
+        assert 10 < it <= 30
+    f = U.fsc_curve(O, maps[PF], maps[PN], N, rU)
+    assert f.min() >= 0.995, f
+    fr = U.fsc_curve(O, maps[PF], ref, N, rU)
+    assert fr[:rU - 1].min() >= 0.99, fr
+    assert np.abs(maps[PF] - maps[PN]).max() <= 3e-2 * np.abs(maps[PN]).max()
+
+
+def test_iteration_chain_with_cutoffs(oracle):
+    """oracle.Iteration.set_cutoff(r, rU): the lists, the grid of F / T and the length of the FSC follow the cut-offs of every iteration;
+    the MAP reconstruction of an iteration uses the previous iteration's curve with the previous rU entries (Model::resetReco,
+    src/Model.cpp:1122); cut-offs at Nyquist are the chain without the call, bit for bit."""
+    O = oracle
+    N, n = 32, 60
+    inp = U.make_inputs(O, N, n, seed=21, mLR=30, mLT=4, nPhase=2, mReco=6, snr=2.0)
+    a, b = U.oracle_chain(O, inp), U.oracle_chain(O, inp)
+    b.set_cutoff(N // 2 - 2, N // 2 - 2)
+    oa, ob = a.iterate(), b.iterate()
+    assert np.array_equal(oa["fsc"], ob["fsc"]) and np.array_equal(oa["maps"][0][0], ob["maps"][0][0])
+    it = U.oracle_chain(O, inp)
+    it.set_cutoff(7, 8)
+    assert (it.rE, it.rU, it.size, it.PF) == (7, 8, 20, 40) and it.fscReco.shape == (1, 8)
+    assert (it.pl["nPxl"], it.plM["nPxl"]) == (O.pixel_list(N, 7, 2)["nPxl"], O.pixel_list(N, 8, 0)["nPxl"])
+    o1 = it.iterate()
+    assert o1["fsc"].shape == (1, 8) and o1["F"][0][0].shape == (40, 40, 21) and it.fscReco.shape == (1, 8)
+    it.set_cutoff(10, 12)
+    assert it.fscReco.shape == (1, 8) and it.PF == 56        # the reconstructor keeps the curve it was handed; the grid follows rU
+    o2 = it.iterate()
+    assert o2["fsc"].shape == (1, 12) and o2["T"][1][0].shape == (56, 56, 29)
+    for h in (0, 1):
+        f = U.fsc_curve(O, o2["maps"][h][0], inp["ref"], N, 6)
+        assert np.all(f[1:4] > 0.85), f
+    # nothing of the data beyond the cut-off reached the accumulators
+    k = np.fft.fftfreq(56, 1.0 / 56)
+    kk = np.sqrt(k[:, None, None] ** 2 + k[None, :, None] ** 2 + np.arange(29)[None, None, :] ** 2)
+    assert not np.any(o2["T_raw"][0][0][kk > 2 * 12 + 2])

@@ -57,9 +57,15 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / np.abs(b).max())
 
 
-def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, search="local", thin=False):
+def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, search="local", thin=False, cutoff=None):
     c = inp["cfg"]
-    N, n, P, rU, K = c["N"], c["nImg"], 2 * c["N"], c["N"] // 2 - 2, c["nK"]
+    N, n, K = c["N"], c["nImg"], c["nK"]
+    if cutoff is not None:     # the frequency cut-offs of this iteration (Optimiser::_r, Model::_rU): per-iteration inputs of both sides
+        nat.set_cutoff(*cutoff)
+        it.set_cutoff(*cutoff)
+        assert nat.cutoff()[:3] == (it.rE, it.rU, it.size)
+    # rU = Model::_rU of this iteration; P = the grid of F / T = pf * Reconstructor::_size (2 N at Nyquist)
+    P, rU = it.PF, it.rU
     glob = search == "global"
     nat.set_search(search)
     nat.stats(reset=True)
@@ -73,6 +79,10 @@ def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, s
         nat.recorder.record(nat, cap, fsc_dev, imgOri_before)
     v = nat.view()
     capn = {k: v_.cpu().numpy() for k, v_ in cap.items() if v_ is not None}
+    assert v.fdim == P and (v.nPxl, v.nPxlM) == (it.pl["nPxl"], it.plM["nPxl"])
+    for key in ("Fraw", "Traw", "Fsym", "Tsym"):      # [local halves][K] volumes of the CURRENT (pf size)^3 half grid, contiguous
+        if key in capn and capn[key].shape[-2] != P:
+            capn[key] = capn[key].reshape(-1)[:2 * K * P * P * (P // 2 + 1)].reshape(2, K, P, P, P // 2 + 1)
     capn["cls"] = nat.fetch(v.cls, np.int32, (n,))
     fol = U.Follower(O, capn, c)
     dev_rounds = nat.rounds()
@@ -256,12 +266,13 @@ def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, s
     if "avgR" in out and K == 1:   # MODEL_RESOLUTION_BASE_AVERAGE: the averaging radius follows the FSC just computed
         assert out["avgR"] == O.res_p(ref_["fsc"][0], 0.95, 1, 1, False)
     # ---- Model::refreshProj: the projector of the next iteration, from the device's own final maps ----
-    nv = P * P * (P // 2 + 1)
+    PN = 2 * N                                                # (the projector's grid does not follow the reconstructors' size)
+    nv = PN * PN * (PN // 2 + 1)
     for h in (0, 1):
         for k in range(K):
             if out["keep"][h][k] if "keep" in out else False:
                 continue
-            vd = nat.fetch(v.vols, np.complex64, (P, P, P // 2 + 1), offset_elems=(h * K + k) * nv)
+            vd = nat.fetch(v.vols, np.complex64, (PN, PN, PN // 2 + 1), offset_elems=(h * K + k) * nv)
             want = O.set_projectee(nat.map(h, k).cpu().numpy(), 2)
             assert _rel(vd, want) <= 2e-6
             if not loose:    # (the oracle chain's own projector: only where its map was held to the tight bar above)
@@ -277,7 +288,8 @@ def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, s
     return out
 
 
-def _run_chain(O, dev, inp, label, max_degenerate, max_adopted, searches=("local", "local"), scan_batch=0, sym_capture=True, thin=False):
+def _run_chain(O, dev, inp, label, max_degenerate, max_adopted, searches=("local", "local"), scan_batch=0, sym_capture=True, thin=False,
+               cutoffs=None):
     c = inp["cfg"]
     N, n, K = c["N"], c["nImg"], c["nK"]
     it = U.oracle_chain(O, inp)
@@ -308,7 +320,8 @@ def _run_chain(O, dev, inp, label, max_degenerate, max_adopted, searches=("local
     assert np.abs(nat.fetch(v.r, np.float64, (n, c["mLR"], 4)) - it.q).max() <= 1e-12
     outs = []
     for i, search in enumerate(searches):
-        outs.append(_check_iteration(O, nat, it, cap, inp, "%s iteration %d (%s)" % (label, i + 1, search), max_degenerate, max_adopted, search, thin))
+        outs.append(_check_iteration(O, nat, it, cap, inp, "%s iteration %d (%s)" % (label, i + 1, search), max_degenerate, max_adopted, search, thin,
+                                     cutoff=None if cutoffs is None else cutoffs[i]))
     return nat, it, outs
 
 

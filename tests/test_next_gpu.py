@@ -647,7 +647,9 @@ def test_bench_other_configs_small(dev):
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
     oc = d["other_configs"]
-    assert len(oc) == 4 and all("error" not in v and v["value"] > 0 for v in oc.values()), oc
+    assert len(oc) == 5 and all("error" not in v and v["value"] > 0 for v in oc.values()), oc
+    low = [v for k, v in oc.items() if "cut-offs" in k][0]               # the iteration below Nyquist: resized reconstruction grid
+    assert low["config"]["cutoff"] == {"r": 6, "rU": 6, "reco_size": 16, "rScan": 0} and low["config"]["nPxl"] < d["config"]["nPxl"]
     assert all(v["roofline"]["frac"] > 0 for k, v in oc.items() if not k.startswith("configs[0]"))
     assert any(v["unit"] == "images/s" for v in oc.values())
     c0 = [v for k, v in oc.items() if k.startswith("configs[0]")][0]     # demo_3D.json's run shape (K = 4, C4, global then local search)

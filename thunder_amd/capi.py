@@ -72,7 +72,7 @@ class RefineView(C.Structure):
                                           "datM", "ctfM", "r", "t", "wR", "wT", "offset", "vols", "cells", "F", "T", "sig",
                                           "recoRot", "recoTran", "nP", "norm", "cls", "topR", "topT", "k123", "s01", "d", "wD",
                                           "maps", "mapsMAP")] + \
-               [(n, C.c_int) for n in ("nK", "nPxlS")]
+               [(n, C.c_int) for n in ("nK", "nPxlS", "fdim")]
 
 
 _vp = C.c_void_p
@@ -136,6 +136,8 @@ SIGNATURES = {
     "thx_refine_set_classes": (_i, [_vp, _vp, _vp]),
     "thx_refine_set_grid": (_i, [_vp, _vp, _vp, _vp]),
     "thx_refine_set_search_type": (_i, [_vp, _i]),
+    "thx_refine_set_cutoff": (_i, [_vp, _i, _i, _vp]),
+    "thx_refine_get_cutoff": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "thx_reco_allreduce_acc_class": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "thx_reco_reduce_acc_class": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "thx_rotmat_dev": (_i, [_vp, _vp, _i, _vp]),

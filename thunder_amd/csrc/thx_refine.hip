@@ -249,6 +249,12 @@ struct thx_refine {
     thx_comm* hemi = nullptr;
     thx_comm* world = nullptr;
     int N, pf, P, nc, rU, rSig, nPxl, nPxlM, nPxlS = 0, nV, nK, nImg, batch, scanBatch = 0;
+    // frequency cut-offs of the next iteration (thx_refine_set_cutoff; Nyquist by default): rE = Optimiser::_r (expectation's list,
+    // Projector::_maxRadius), rU = Model::_rU (reconstruction's list, Reconstructor::_maxRadius), rS = the scan's radius = min(cfg.rScan,
+    // rE); size = Reconstructor::_size = min(N, (rU + ceil(a)) * 2) after resizeSpace, PF = pf * size = the grid of F / T / W / C.
+    // Capacities (what the buffers were allocated for): the lists of rCap = N / 2 - 1, the scan's list of cfg.rScan, the grid P.
+    int rE = 0, rS = 0, rCap = 0, size = 0, PF = 0, capPxl = 0, capPxlM = 0, capPxlS = 0;
+    bool haveParticles = false;
     int searchType = THX_SEARCH_LOCAL;
     int halves[2];
     int lo[2], hi[2];
@@ -301,7 +307,9 @@ struct thx_refine {
     int *active = nullptr, *nP = nullptr, *nActiveDev = nullptr;   // per-image stop rule
     double* stopState = nullptr;
     long imagePhases = 0;
-    std::vector<float> fscReco;          // [nK][rU] Reconstructor::_FSC: what Model::resetReco handed over at the end of the last iteration
+    std::vector<float> fscReco;          // [nK][N / 2], fscRecoN entries each: Reconstructor::_FSC, what Model::resetReco handed over at the
+                                         // end of the last iteration (the rU of THAT iteration: setFSC(_FSC.col(l)), src/Model.cpp:1122)
+    int fscRecoN = 0;
     thx_refine_capture cap = {};
     // timing (HIP events on the launch stream, resolved in thx_refine_stats)
     bool timed = false;
@@ -389,7 +397,8 @@ thx_pf_ctx pf_ctx(const thx_refine* h, int b0)
     c.symQuat = h->symQ; c.nSym = h->nSym; c.img0 = (unsigned)(img_base(h) + b0);
     return c;
 }
-size_t vol_n(const thx_refine* h) { return (size_t)h->P * h->P * (h->P / 2 + 1); }
+size_t vol_n(const thx_refine* h) { return (size_t)h->P * h->P * (h->P / 2 + 1); }       // projector volumes: (pf N)^3 half grid
+size_t volF_n(const thx_refine* h) { return (size_t)h->PF * h->PF * (h->PF / 2 + 1); }   // F / T: (pf size)^3 half grid (resizeSpace)
 size_t cell_stride(const thx_refine* h) { return thx_projector_packed_bytes(h->P) / sizeof(float); }
 // volumes are indexed [local half][class]
 float* vol_of(thx_refine* h, int vi, int k) { return h->vols + ((size_t)vi * h->nK + k) * vol_n(h) * 2; }
@@ -448,6 +457,69 @@ int refresh_rows(thx_refine* h, int vi, hipStream_t st)
     const size_t imgSize = (size_t)h->N * h->nc * 2;
     THX_RC(thx_gather_pixels_dev(h->datP + (size_t)lo * h->nPxl * 2, h->img + (size_t)lo * imgSize, h->iPxl, h->nPxl, h->N, n, st));
     THX_RC(sigrcp_rows(h, h->sigRcpP + (size_t)lo * h->nPxl, vi, lo, n, h->iSig, h->nPxl, st));
+    return 0;
+}
+
+// Everything cut from the image stacks / CTF parameters along the CURRENT pixel lists that does not change from iteration to
+// iteration: the M-step rows (the unmasked images on the rL = 0 list of rU, src/Optimiser.cpp:6722-6741) with their bounds, the CTF
+// rows of both lists, the defocus search's pre-calculated rows.  (datP / sigRcpP are cut at the head of every expectation.)
+int recut_rows(thx_refine* h, hipStream_t st)
+{
+    const thx_refine_config& c = h->cfg;
+    const int n = h->nImg;
+    THX_RC(thx_gather_pixels_dev(h->datM, h->imgOri, h->iPxlM, h->nPxlM, h->N, n, st));
+    THX_RC(thx_ctf_dev(h->ctfM, h->attr, nullptr, c.pixelSize, h->iColM, h->iRowM, h->nPxlM, h->N, n, st));
+    THX_RC(thx_ctf_dev(h->ctfP, h->attr, nullptr, c.pixelSize, h->iCol, h->iRow, h->nPxl, h->N, n, st));
+    THX_RC(thx_insert_bounds_dev(h->bounds, h->datM, h->ctfM, h->nPxlM, n, st));
+    if (c.mLD > 0)   // allocPreCal(.., ctf = true), src/Optimiser.cpp:8124-8169
+        THX_RC(thx_expect_precal_dev(h->freqD, h->defD, h->k1D, h->k2D, h->attr, h->N, c.pixelSize, h->iCol, h->iRow, h->nPxl, n, st));
+    return 0;
+}
+
+// The frequency cut-offs of the next iteration (thx_refine_set_cutoff; also how thx_refine_create sets up Nyquist).
+//   r  = Optimiser::_r : allocPreCalIdx(_r, _rL) for the expectation (src/Optimiser.cpp:631,1693) -- a global search scans on it as
+//        well: the scan's radius is min(cfg.rScan, r) --, Projector::_maxRadius (Model::refreshProj, src/Model.cpp:1042: where
+//        allReduceSigma's and normCorrection's slices end), normCorrection's rNorm = min(_r, .) (:6203);
+//   rU = Model::_rU   : allocPreCalIdx(rU, 0) for the reconstruction (:6722-6741), Reconstructor::setMaxRadius(rU) and
+//        resizeSpace(min(_size, (rU + ceil(a)) * 2)) (Model::resetReco, src/Model.cpp:1100-1125; src/Reconstructor.cpp:184-198):
+//        F / T / W / C and the gridding loop live on the (pf size)^3 grid, the last step pads F W into (pf N)^3 (:1677-1701);
+//        the FSC of compareTwoHemispheres has rU shells.
+int apply_cutoff(thx_refine* h, int r, int rU, hipStream_t st)
+{
+    const thx_refine_config& c = h->cfg;
+    THX_REQUIRE(r > c.rL && r <= h->rCap && rU > 0 && rU <= h->rCap, "cut-offs: rL < r <= N / 2 - 1, 0 < rU <= N / 2 - 1");
+    PixelList pl = pixel_list_host(c.N, r, c.rL), plM = pixel_list_host(c.N, rU, 0);
+    if (c.pixelOrder == 1) morton_order(pl, c.N);
+    THX_REQUIRE(pl.nPxl > 0 && pl.nPxl <= h->capPxl && plM.nPxl > 0 && plM.nPxl <= h->capPxlM, "pixel list outside the allocated capacity");
+    THX_CHECK(hipStreamSynchronize(st));   // (queued kernels may still read the lists)
+    auto put = [](int* d, const std::vector<int>& v) { return hipMemcpy(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice); };
+    THX_CHECK(put(h->iCol, pl.iCol)); THX_CHECK(put(h->iRow, pl.iRow)); THX_CHECK(put(h->iPxl, pl.iPxl)); THX_CHECK(put(h->iSig, pl.iSig));
+    THX_CHECK(put(h->iColM, plM.iCol)); THX_CHECK(put(h->iRowM, plM.iRow)); THX_CHECK(put(h->iPxlM, plM.iPxl));
+    h->rE = r; h->rU = rU; h->nPxl = pl.nPxl; h->nPxlM = plM.nPxl;
+    if (c.nR > 0) {   // the scan's list: allocPreCalIdx(_r, _rL) as well, never beyond the radius the scan buffers were sized for
+        h->rS = std::min(c.rScan, r);
+        PixelList plS = pixel_list_host(c.N, h->rS, c.rL);
+        if (c.pixelOrder == 1) morton_order(plS, c.N);
+        THX_REQUIRE(plS.nPxl > 0 && plS.nPxl <= h->capPxlS, "scan pixel list outside the allocated capacity");
+        THX_CHECK(put(h->iColS, plS.iCol)); THX_CHECK(put(h->iRowS, plS.iRow)); THX_CHECK(put(h->iPxlS, plS.iPxl)); THX_CHECK(put(h->iSigS, plS.iSig));
+        h->nPxlS = plS.nPxl;
+        if (h->haveGrid) THX_RC(thx_translate_dev(h->traS, h->gridT, c.nT, h->iColS, h->iRowS, h->nPxlS, h->N, st));
+    }
+    // Reconstructor::resizeSpace: _size = min(N, (rU + CEIL(_a)) * 2), a = 1.9; the plans (W, C, scratch, FFT plans) follow the size
+    const int size = std::min(c.N, (rU + 2) * 2);
+    if (size != h->size) {
+        for (int v = 0; v < h->nV; v++) {
+            if (h->plans[v]) { THX_RC(thx_reco_destroy(h->plans[v])); h->plans[v] = nullptr; }
+            THX_RC(thx_reco_create(&h->plans[v], size, c.N, c.pf, 1.9f, 15.0f));
+        }
+        h->size = size;
+        h->PF = c.pf * size;
+    }
+    if (h->haveParticles) THX_RC(recut_rows(h, st));
+    if (h->iterCount == 0) {   // Model::initProjReco: _reco[l]->setFSC(vec::Constant(_rU, 1)), src/Model.cpp:1086
+        h->fscReco.assign((size_t)h->nK * (c.N / 2), 1.0f);
+        h->fscRecoN = rU;
+    }
     return 0;
 }
 
@@ -620,7 +692,8 @@ int sigma_update(thx_refine* h, int vi, hipStream_t st)
     THX_RC(thx_rotmat_dev(h->topR + (size_t)lo * 4, h->rotTop, n, st));
     THX_CHECK(hipMemcpyAsync(h->tranTop, h->topT + (size_t)lo * 2, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
     const double* dfac = h->searchType == THX_SEARCH_CTF ? h->topD + lo : nullptr;
-    THX_RC(thx_sigma_spectra_packed_dev(h->spec, cells_of(h, vi, 0), vol_idx(h, lo), h->P, h->pf, h->N, h->rU, h->rSig,
+    // (the slice is cut at Projector::_maxRadius = _r, Model::refreshProj src/Model.cpp:1042; the spectra run over the whole frequency range)
+    THX_RC(thx_sigma_spectra_packed_dev(h->spec, cells_of(h, vi, 0), vol_idx(h, lo), h->P, h->pf, h->N, h->rE, h->rSig,
                                  h->img + (size_t)lo * imgSize, h->imgOri + (size_t)lo * imgSize, h->attr + lo, dfac, c.pixelSize,
                                  h->rotTop, h->tranTop, h->offset + (size_t)lo * 2, n, st));
     const size_t tab = (size_t)c.nGroup * (h->rSig + 1);
@@ -645,18 +718,18 @@ int norm_correction(thx_refine* h, hipStream_t st)
     // (src/Model.cpp:977-994, src/Functions/Spectrum.cpp:339-363) on the FSC the previous iteration left in the model
     int res = 0;
     for (int k = 0; k < h->nK; k++) {
-        const float* f = h->fscReco.data() + (size_t)k * h->rU;
+        const float* f = h->fscReco.data() + (size_t)k * (h->N / 2);
         int rk = 1;
-        for (; rk < h->rU; rk++)
+        for (; rk < h->fscRecoN; rk++)
             if (f[rk] < 0.75f) break;
         res = std::max(res, rk - 1);
     }
-    const float rNorm = std::min((float)h->rU, (float)res);
+    const float rNorm = std::min((float)h->rE, (float)res);   // TSGSL_MIN_RFLOAT(_r, _model.resolutionP(0.75, false)), :6203
     for (int vi = 0; vi < h->nV; vi++) {
         const int lo = h->lo[vi], n = h->hi[vi] - lo;
         if (n <= 0) continue;
         THX_RC(thx_rotmat_dev(h->topR + (size_t)lo * 4, h->rotTop, n, st));
-        THX_RC(thx_norm_residual_packed_dev(h->norm + lo, cells_of(h, vi, 0), vol_idx(h, lo), h->P, h->pf, h->N, h->rU, (float)c.rL, rNorm,
+        THX_RC(thx_norm_residual_packed_dev(h->norm + lo, cells_of(h, vi, 0), vol_idx(h, lo), h->P, h->pf, h->N, h->rE, (float)c.rL, rNorm,
                                      h->img + (size_t)lo * imgSize, h->attr + lo, h->searchType == THX_SEARCH_CTF ? h->topD + lo : nullptr,
                                      c.pixelSize, h->rotTop, h->topT + (size_t)lo * 2, n, st));
     }
@@ -687,7 +760,7 @@ int insertion(thx_refine* h, int vi, hipStream_t st)
 {
     const thx_refine_config& c = h->cfg;
     const int lo = h->lo[vi], n = h->hi[vi] - lo;
-    const size_t volN = vol_n(h);
+    const size_t volN = volF_n(h);   // F / T live on the reconstructors' grid PF = pf * size (Reconstructor::allocSpace after resizeSpace)
     const bool ctf = h->searchType == THX_SEARCH_CTF;
     float* F = h->F + (size_t)vi * h->nK * volN * 2;
     float* T = h->T + (size_t)vi * h->nK * volN;
@@ -697,7 +770,7 @@ int insertion(thx_refine* h, int vi, hipStream_t st)
     // all batches accumulate into them, the half-set reduce runs on the integers (N ranks == 1 rank, bit for bit), and only
     // then do they become the float F / T that prepareTF normalises
     THX_RC(thx_insert_scale_dev(h->gexp, h->bounds + (size_t)lo * 2, h->w + lo, n > 0 ? n : 0, c.mReco, ctf ? 1 : 0, h->nImgHemi, h->hemi, st));
-    THX_CHECK(hipMemsetAsync(h->accInt, 0, thx_insert_acc_bytes(h->P, h->nK), st));
+    THX_CHECK(hipMemsetAsync(h->accInt, 0, thx_insert_acc_bytes(h->PF, h->nK), st));
     if (n > 0) {
         hipLaunchKernelGGL(k_draw_reco, dim3(blocks_for((size_t)n * c.mReco)), dim3(256), 0, st, h->recoRot, h->recoTran,
                            ctf ? h->recoD : nullptr, h->r + (size_t)lo * c.mLR * 4, h->t + (size_t)lo * c.mLT * 2,
@@ -710,7 +783,7 @@ int insertion(thx_refine* h, int vi, hipStream_t st)
     for (int b0 = lo; b0 < h->hi[vi]; b0 += h->batch) {
         const int nb = std::min(h->batch, h->hi[vi] - b0);
         Scope ev(h, st, EV_INSERT, nb);
-        THX_RC(thx_insert_accumulate_dev(h->accInt, h->gexp, h->bounds + (size_t)b0 * 2, nullptr, nullptr, h->P, h->nK,
+        THX_RC(thx_insert_accumulate_dev(h->accInt, h->gexp, h->bounds + (size_t)b0 * 2, nullptr, nullptr, h->PF, h->nK,
                                          h->datM + (size_t)b0 * h->nPxlM * 2, h->ctfM + (size_t)b0 * h->nPxlM, h->w + b0,
                                          h->recoRot + (size_t)(b0 - lo) * c.mReco * 9, h->recoTran + (size_t)(b0 - lo) * c.mReco * 2,
                                          h->offset + (size_t)b0 * 2, h->nK > 1 ? h->clsD + (size_t)(b0 - lo) * c.mReco : nullptr,
@@ -719,8 +792,8 @@ int insertion(thx_refine* h, int vi, hipStream_t st)
     }
     // the half-set reduce on the integers, class by class through one workspace, towards the rank that reconstructs the class
     for (int k = 0; k < h->nK && h->hemi; k++)
-        THX_RC(thx_reco_reduce_acc_class(h->hemi, h->accInt, h->nK, k, reduce_root(h, k), h->P, h->rU, h->pf, h->wsReduce, st));
-    THX_RC(thx_insert_finish_dev(F, T, h->accInt, h->gexp, h->P, h->nK, st));
+        THX_RC(thx_reco_reduce_acc_class(h->hemi, h->accInt, h->nK, k, reduce_root(h, k), h->PF, h->rU, h->pf, h->wsReduce, st));
+    THX_RC(thx_insert_finish_dev(F, T, h->accInt, h->gexp, h->PF, h->nK, st));
     return 0;
 }
 
@@ -875,7 +948,8 @@ int thx_refine_create(thx_refine** out, const thx_refine_config* cfg, thx_comm* 
     h->hemi = hemi;
     h->world = world;
     h->N = c.N; h->pf = c.pf; h->P = c.N * c.pf; h->nc = c.N / 2 + 1;
-    h->rU = c.N / 2 - 2;
+    h->rU = h->rE = c.N / 2 - 2;   // the cut-offs until thx_refine_set_cutoff says otherwise: Nyquist, _size = _N
+    h->rCap = c.N / 2 - 1;         // Optimiser::maxR(): the largest cut-off a caller can ask for; the buffers are sized for its lists
     h->rSig = c.N / 2 - 1;
     h->nImg = c.nImg;
     h->nK = c.nK;
@@ -900,12 +974,13 @@ int thx_refine_create(thx_refine** out, const thx_refine_config* cfg, thx_comm* 
     const int nb = std::max(1, (nmax + c.batch - 1) / c.batch);
     h->batch = std::min(65535, std::max(1, (nmax + nb - 1) / nb));
 #define RC_OR_FREE(expr) do { int _rc = (expr); if (_rc) { thx_refine_destroy(h); return _rc; } } while (0)
-    PixelList pl = pixel_list_host(c.N, h->rU, c.rL), plM = pixel_list_host(c.N, h->rU, 0);
-    if (c.pixelOrder == 1) morton_order(pl, c.N);
-    h->nPxl = pl.nPxl; h->nPxlM = plM.nPxl;
-    RC_OR_FREE(upload(h, &h->iCol, pl.iCol)); RC_OR_FREE(upload(h, &h->iRow, pl.iRow));
-    RC_OR_FREE(upload(h, &h->iPxl, pl.iPxl)); RC_OR_FREE(upload(h, &h->iSig, pl.iSig));
-    RC_OR_FREE(upload(h, &h->iColM, plM.iCol)); RC_OR_FREE(upload(h, &h->iRowM, plM.iRow)); RC_OR_FREE(upload(h, &h->iPxlM, plM.iPxl));
+    // the pixel lists live in device arrays sized for the largest cut-off; apply_cutoff (below, and thx_refine_set_cutoff) fills them
+    h->capPxl = pixel_list_host(c.N, h->rCap, c.rL).nPxl;
+    h->capPxlM = pixel_list_host(c.N, h->rCap, 0).nPxl;
+    h->nPxl = h->capPxl; h->nPxlM = h->capPxlM;     // (row buffers below are allocated through these two)
+    RC_OR_FREE(dalloc(h, &h->iCol, (size_t)h->capPxl)); RC_OR_FREE(dalloc(h, &h->iRow, (size_t)h->capPxl));
+    RC_OR_FREE(dalloc(h, &h->iPxl, (size_t)h->capPxl)); RC_OR_FREE(dalloc(h, &h->iSig, (size_t)h->capPxl));
+    RC_OR_FREE(dalloc(h, &h->iColM, (size_t)h->capPxlM)); RC_OR_FREE(dalloc(h, &h->iRowM, (size_t)h->capPxlM)); RC_OR_FREE(dalloc(h, &h->iPxlM, (size_t)h->capPxlM));
     const size_t n = c.nImg, imgSize = (size_t)c.N * h->nc * 2, volN = vol_n(h), mapN = (size_t)c.N * c.N * c.N;
     const size_t nVol = (size_t)h->nV * h->nK;
     RC_OR_FREE(dalloc(h, &h->img, n * imgSize));
@@ -960,7 +1035,7 @@ int thx_refine_create(thx_refine** out, const thx_refine_config* cfg, thx_comm* 
         RC_OR_FREE(dalloc(h, &ws, thx_expect_local_workspace((int)B, c.mLR, c.mLT, nDmax)));
         h->wsExpect = ws;
         char* wr = nullptr;
-        RC_OR_FREE(dalloc(h, &wr, hemi ? thx_reco_allreduce_acc_workspace(h->P, h->rU, c.pf) : 16));
+        RC_OR_FREE(dalloc(h, &wr, hemi ? thx_reco_allreduce_acc_workspace(h->P, h->rCap, c.pf) : 16));
         h->wsReduce = wr;
         void* q = nullptr;
         hipError_t e = hipMalloc(&q, thx_insert_acc_bytes(h->P, h->nK));
@@ -977,11 +1052,10 @@ int thx_refine_create(thx_refine** out, const thx_refine_config* cfg, thx_comm* 
         RC_OR_FREE(dalloc(h, &h->symTmp, volN * 2));
     }
     if (scans) {   // the scan's pixel list and one batch of its rows, weights and workspace
-        PixelList plS = pixel_list_host(c.N, c.rScan, c.rL);
-        if (c.pixelOrder == 1) morton_order(plS, c.N);
-        h->nPxlS = plS.nPxl;
-        RC_OR_FREE(upload(h, &h->iColS, plS.iCol)); RC_OR_FREE(upload(h, &h->iRowS, plS.iRow));
-        RC_OR_FREE(upload(h, &h->iPxlS, plS.iPxl)); RC_OR_FREE(upload(h, &h->iSigS, plS.iSig));
+        PixelList plS = pixel_list_host(c.N, c.rScan, c.rL);   // capacity: the scan never runs beyond cfg.rScan (its radius = min(rScan, r))
+        h->capPxlS = h->nPxlS = plS.nPxl;
+        RC_OR_FREE(dalloc(h, &h->iColS, (size_t)plS.nPxl)); RC_OR_FREE(dalloc(h, &h->iRowS, (size_t)plS.nPxl));
+        RC_OR_FREE(dalloc(h, &h->iPxlS, (size_t)plS.nPxl)); RC_OR_FREE(dalloc(h, &h->iSigS, (size_t)plS.nPxl));
         const int sb0 = c.scanBatch > 0 ? c.scanBatch : 2048;
         const int nsb = std::max(1, (nmax + sb0 - 1) / sb0);
         h->scanBatch = std::min(65535, std::max(1, (nmax + nsb - 1) / nsb));
@@ -1010,7 +1084,7 @@ int thx_refine_create(thx_refine** out, const thx_refine_config* cfg, thx_comm* 
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill<double>), dim3(blocks_for(n)), dim3(256), 0, nullptr, h->topD, 1.0, n);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill<double>), dim3(blocks_for(n * c.mLD)), dim3(256), 0, nullptr, h->dD, 1.0, n * c.mLD);
     }
-    for (int v = 0; v < h->nV; v++) RC_OR_FREE(thx_reco_create(&h->plans[v], c.N, c.N, c.pf, 1.9f, 15.0f));
+    RC_OR_FREE(apply_cutoff(h, h->rE, h->rU, nullptr));   // the lists at Nyquist, the reconstruction plans at _size = _N
     if (hipHostMalloc(reinterpret_cast<void**>(&h->recoRes), 2 * 2 * 16 * 8 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
         set_error("refine driver: hipHostMalloc failed"); h->recoRes = nullptr; thx_refine_destroy(h); return -1;
     }
@@ -1019,7 +1093,6 @@ int thx_refine_create(thx_refine** out, const thx_refine_config* cfg, thx_comm* 
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill<float>), dim3(blocks_for(n)), dim3(256), 0, nullptr, h->w, 1.0f / c.mReco, n);
     if (hipDeviceSynchronize() != hipSuccess) { set_error("refine driver: device error during create"); thx_refine_destroy(h); return -1; }
 #undef RC_OR_FREE
-    h->fscReco.assign((size_t)h->nK * h->rU, 1.0f);
     *out = h;
     return 0;
 }
@@ -1042,13 +1115,8 @@ int thx_refine_set_particles(thx_refine* h, const float* imgOri, const thx_ctf_a
     THX_CHECK(hipMemcpyAsync(h->attr, attr, n * sizeof(thx_ctf_attr), hipMemcpyDeviceToDevice, st));
     THX_CHECK(hipMemcpyAsync(h->r0, quat0, n * c.mLR * 4 * sizeof(double), hipMemcpyDeviceToDevice, st));
     THX_CHECK(hipMemcpyAsync(h->t0, tran0, n * c.mLT * 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
-    // M-step rows (the unmasked images on the rL = 0 list, src/Optimiser.cpp:6722) and the CTF rows never change
-    THX_RC(thx_gather_pixels_dev(h->datM, imgOri, h->iPxlM, h->nPxlM, h->N, (int)n, st));
-    THX_RC(thx_ctf_dev(h->ctfM, h->attr, nullptr, c.pixelSize, h->iColM, h->iRowM, h->nPxlM, h->N, (int)n, st));
-    THX_RC(thx_ctf_dev(h->ctfP, h->attr, nullptr, c.pixelSize, h->iCol, h->iRow, h->nPxl, h->N, (int)n, st));
-    THX_RC(thx_insert_bounds_dev(h->bounds, h->datM, h->ctfM, h->nPxlM, (int)n, st));
-    if (c.mLD > 0)   // allocPreCal(.., ctf = true), src/Optimiser.cpp:8124-8169
-        THX_RC(thx_expect_precal_dev(h->freqD, h->defD, h->k1D, h->k2D, h->attr, h->N, c.pixelSize, h->iCol, h->iRow, h->nPxl, (int)n, st));
+    h->haveParticles = true;
+    THX_RC(recut_rows(h, st));
     {   // images of this rank's half over all of its ranks (the 64-bit sums' head-room, thx_insert_scale_dev)
         double* cnt = reinterpret_cast<double*>(scratch(st, 7, sizeof(double)));
         THX_REQUIRE(cnt, "device scratch allocation failed");
@@ -1140,6 +1208,22 @@ int thx_refine_set_grid(thx_refine* h, const double* quat, const double* shifts,
     return 0;
 }
 
+int thx_refine_set_cutoff(thx_refine* h, int r, int rU, void* stream)
+{
+    THX_REQUIRE(h, "NULL handle");
+    return apply_cutoff(h, r, rU, as_stream(stream));
+}
+
+int thx_refine_get_cutoff(const thx_refine* h, int* r, int* rU, int* size, int* rScan)
+{
+    THX_REQUIRE(h, "NULL handle");
+    if (r) *r = h->rE;
+    if (rU) *rU = h->rU;
+    if (size) *size = h->size;
+    if (rScan) *rScan = h->rS;
+    return 0;
+}
+
 int thx_refine_set_search_type(thx_refine* h, int searchType)
 {
     THX_REQUIRE(h, "NULL handle");
@@ -1190,7 +1274,8 @@ int thx_refine_reset(thx_refine* h, void* stream)
     hipLaunchKernelGGL(k_take_first, dim3(blocks_for(n * 4)), dim3(256), 0, st, h->topR, h->r, (int)n, c.mLR * 4, 4);
     hipLaunchKernelGGL(k_take_first, dim3(blocks_for(n * 2)), dim3(256), 0, st, h->topT, h->t, (int)n, c.mLT * 2, 2);
     THX_LAUNCH_CHECK();
-    h->fscReco.assign((size_t)h->nK * h->rU, 1.0f);   // Model::initProjReco: _reco[l]->setFSC(vec::Constant(_rU, 1)), src/Model.cpp:1086
+    h->fscReco.assign((size_t)h->nK * (h->N / 2), 1.0f);   // Model::initProjReco: _reco[l]->setFSC(vec::Constant(_rU, 1)), src/Model.cpp:1086
+    h->fscRecoN = h->rU;
     for (int v = 0; v < h->nV; v++) THX_RC(refresh_rows(h, v, st));
     return 0;
 }
@@ -1200,7 +1285,7 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
     THX_REQUIRE(h && h->imgOri, "thx_refine_set_particles has not been called");
     hipStream_t st = as_stream(stream);
     const thx_refine_config& c = h->cfg;
-    const size_t mapN = (size_t)h->N * h->N * h->N, volN = vol_n(h);
+    const size_t mapN = (size_t)h->N * h->N * h->N, volN = volF_n(h);   // (volN: one F / T volume on the reconstructors' grid PF)
     const size_t imgSize = (size_t)h->N * h->nc * 2;
     const int K = h->nK;
     const bool global = h->searchType == THX_SEARCH_GLOBAL;
@@ -1279,11 +1364,11 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
                 float* T = h->T + ((size_t)vi * K + k) * volN;
                 // prepareTF, src/Reconstructor.cpp:1056-1091: [allReduceT: done on the integers] normalise T and F by 1 / T(0,0,0)
                 // (:2455-2476), symmetrizeT, [allReduceF], symmetrizeF
-                THX_RC(thx_normalise_tf_dev(F, T, h->P, st));
+                THX_RC(thx_normalise_tf_dev(F, T, h->PF, st));
                 if (h->nSym > 0) {
-                    THX_RC(thx_symmetrize_dev(h->symTmp, T, h->P, 0, h->symMatHost.data(), h->nSym, symR, st));
+                    THX_RC(thx_symmetrize_dev(h->symTmp, T, h->PF, 0, h->symMatHost.data(), h->nSym, symR, st));
                     THX_CHECK(hipMemcpyAsync(T, h->symTmp, volN * sizeof(float), hipMemcpyDeviceToDevice, st));
-                    THX_RC(thx_symmetrize_dev(h->symTmp, F, h->P, 1, h->symMatHost.data(), h->nSym, symR, st));
+                    THX_RC(thx_symmetrize_dev(h->symTmp, F, h->PF, 1, h->symMatHost.data(), h->nSym, symR, st));
                     THX_CHECK(hipMemcpyAsync(F, h->symTmp, volN * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
                 }
                 if (h->cap.Fsym) THX_CHECK(hipMemcpyAsync(h->cap.Fsym + ((size_t)vi * K + k) * volN * 2, F, volN * 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1298,7 +1383,7 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
                 // so this pass does not wait for the FSC of the maps above: it is queued right behind them -- on another rank of
                 // the half where there is one to spare
                 if (on)
-                    THX_RC(thx_reco_reconstruct_async_dev(h->plans[vi], F, T, h->rU, h->fscReco.data() + (size_t)k * h->rU, h->rU, 1, 1, 1,
+                    THX_RC(thx_reco_reconstruct_async_dev(h->plans[vi], F, T, h->rU, h->fscReco.data() + (size_t)k * (h->N / 2), h->fscRecoN, 1, 1, 1,
                                                           h->mapsX + ((size_t)h->halves[vi] * K + k) * mapN, res_of(1, vi, k), st));
             }
         // every rank ends up with every class's map of both halves (the reference sends them to the master, src/Model.cpp:375-391):
@@ -1370,8 +1455,8 @@ int thx_refine_iterate(thx_refine* h, float* fscHost, int timed, void* stream)
         // the round counts of the queued reconstructions (statistics only).  (The synchronisation also comes before fscReco
         // changes: the queued MAP reconstructions copy it from host memory.)
         THX_CHECK(hipStreamSynchronize(st));
-        for (int k = 0; k < K; k++)   // Model::resetReco: _reco[l]->setFSC(_FSC.col(l)), src/Model.cpp:1122
-            std::copy(fsc.begin() + (size_t)k * (h->N / 2), fsc.begin() + (size_t)k * (h->N / 2) + h->rU, h->fscReco.begin() + (size_t)k * h->rU);
+        h->fscReco = fsc;             // Model::resetReco: _reco[l]->setFSC(_FSC.col(l)), src/Model.cpp:1122: this iteration's curve, _rU entries
+        h->fscRecoN = h->rU;
         for (int map = 0; map < 2; map++)
             for (int vi = 0; vi < h->nV; vi++)
                 for (int k = 0; k < K; k++) {
@@ -1438,6 +1523,7 @@ int thx_refine_get_view(thx_refine* h, thx_refine_view* v)
     THX_REQUIRE(h && v, "NULL argument");
     memset(v, 0, sizeof(*v));
     v->nImg = h->nImg; v->nPxl = h->nPxl; v->nPxlM = h->nPxlM; v->nVol = h->nV * h->nK; v->vdim = h->P; v->rSig = h->rSig;
+    v->fdim = h->PF;
     v->iCol = h->iCol; v->iRow = h->iRow; v->iPxl = h->iPxl; v->iSig = h->iSig; v->iColM = h->iColM; v->iRowM = h->iRowM;
     v->img = h->img; v->datP = h->datP; v->ctfP = h->ctfP; v->sigRcpP = h->sigRcpP; v->datM = h->datM; v->ctfM = h->ctfM;
     v->r = h->r; v->t = h->t; v->wR = h->wR; v->wT = h->wT; v->offset = h->offset;

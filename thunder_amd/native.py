@@ -154,6 +154,16 @@ class NativeRefine:
     def reset(self):
         capi.call("thx_refine_reset", self._h, stream_ptr())
 
+    def set_cutoff(self, r, rU):
+        """the frequency cut-offs of the next iteration (thx_refine_set_cutoff): r = Optimiser::_r, rU = Model::_rU"""
+        capi.call("thx_refine_set_cutoff", self._h, int(r), int(rU), stream_ptr())
+
+    def cutoff(self):
+        """(r, rU, Reconstructor::_size, scan radius) as set"""
+        v = [C.c_int(0) for _ in range(4)]
+        capi.call("thx_refine_get_cutoff", self._h, *[C.byref(x) for x in v])
+        return tuple(x.value for x in v)
+
     def capture(self, maps=True, scan=False, sym=False):
         """per-phase trace of the local search (thx_refine_set_capture): returns the dict of device tensors the following
         iterations fill -- uR, uT, r, t, k123, s01 indexed [phase][image], mapsFsc [2][K][N]^3; scan: the scan's weights and the
