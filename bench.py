@@ -472,13 +472,12 @@ def bench_config0(args, dev, small=False):
 
 def bench_staged(args, dev):
     """--staged: the DROP-IN path timed -- what an UNCHANGED src/Optimiser.cpp drives through the reference's plug-in surface
-    (gpu/interface/Interface.h, here the thx_*_host twins): the local search ONE IMAGE PER CALL from `threads` host threads, each with its
-    own ManagedCalPoint and device slot (thx_ExpectLocalP / RTD / PreI3D / M_host, src/Optimiser.cpp:2180-3393), the insertion as
-    InsertFT on batches of host rows (src/Reconstructor.cpp:865-976) and ReconstructG_host on host volumes (:1835-2330), on a sample
-    of BASELINE configs[1] (256^3 box).  Host arrays in and out at every call, as the reference's interface has it: this is the
+    (gpu/interface/Interface.h, here the thx_*_host twins): the local search ONE IMAGE PER CALL from a C++ OpenMP caller loop
+    (integration/expectationG_harness.cpp: thx_ExpectLocalP / RTD / PreI3D / M_host as src/Optimiser.cpp:2180-3393 calls them, with and
+    without the reference's per-GPU lock), the insertion as InsertFT on host rows (src/Reconstructor.cpp:865-976) and ReconstructG_host on
+    host volumes (:1835-2330), on a sample of BASELINE configs[1] (256^3 box).  Host arrays in and out at every call, as the reference's interface has it: this is the
     compatibility form, reported next to the native driver's number (the headline), never as `value` of the metric."""
     import ctypes as C
-    import threading
     import torch
     from thunder_amd import capi, ops
     from thunder_amd.refine import RefineShard
@@ -506,59 +505,38 @@ def bench_staged(args, dev):
     sh.release_generation_state()
     del datM, ctfM
     nR, nT = sh.mLR, sh.mLT
-    vp = C.c_void_p
-    deviCol, deviRow = vp(), vp()
-    capi.call("thx_ExpectPreidx_host", 0, C.byref(deviCol), C.byref(deviRow), iCol.ctypes.data, iRow.ctypes.data, nPxl)
-    devdatP, devctfP, devdefO, devsigP = vp(), vp(), vp(), vp()
-    capi.call("thx_ExpectLocalIn_host", 0, C.byref(devdatP), C.byref(devctfP), C.byref(devdefO), C.byref(devsigP), nPxl, threads, 0)
-    mgr = vp()
-    capi.call("thx_texture_create", C.byref(mgr), 1, P, 0)
-    capi.call("thx_ExpectLocalV3D_host", 0, mgr, vol.ctypes.data, P)
-    ctx = []
-    for t in range(threads):
-        mcp = vp()
-        capi.call("thx_calpoint_create", C.byref(mcp), 1, 0, 0, nR, nT, 1, nPxl)
-        hp = [vp() for _ in range(10)]
-        capi.call("thx_ExpectLocalHostA_host", 0, *[C.byref(q) for q in hp], nR, nT, 1, 0)
-        ctx.append((mcp, hp))
+    # ---- local search: the reference's caller loop (Optimiser::expectationG, src/Optimiser.cpp:2180-3393) restated in C++ over the C ABI
+    #      (integration/expectationG_harness.cpp): OpenMP threads over the images, each with its own staging arrays, device slot and
+    #      ManagedCalPoint; per image and phase ExpectLocalRTD -> ExpectLocalPreI3D -> ExpectLocalM.  lock = 1 takes the per-GPU lock the
+    #      reference holds over the three calls (:2960-3077): ONE image-phase in flight, what an UNCHANGED Optimiser.cpp gets;
+    #      lock = 0: the threads run free on their own streams (a caller that drops the lock) ----
+    from thunder_amd import build as _b
 
-    def host(ptr, cnt, dt):
-        ct = {np.float32: C.c_float, np.float64: C.c_double}[dt]
-        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(cnt,))
-    errors = []
+    class HArgs(C.Structure):
+        _fields_ = [(k, C.c_int) for k in ("gpu", "N", "pf", "nPxl", "nImg", "mLR", "mLT", "phases", "threads", "lock")] + \
+                   [(k, C.c_void_p) for k in ("volume", "iCol", "iRow", "datP", "ctfP", "sigP", "quat", "tran", "attr", "wR", "wT")] + \
+                   [("seconds", C.c_double)]
+    H = C.CDLL(_b.build_harness())
+    H.thx_harness_expectation_local.restype = C.c_int
+    wR_out = np.zeros((n, nR), np.float32)
 
-    def worker(t, images):
-        try:
-            mcp, hp = ctx[t]
-            oldR, oldT, oldD = host(hp[4], nR, np.float64), host(hp[5], nT, np.float64), host(hp[6], 1, np.float64)
-            h_tr, h_rot = host(hp[7], 2 * nT, np.float64), host(hp[8], 4 * nR, np.float64)
-            oldR[:] = 1.0 / nR; oldT[:] = 1.0 / nT; oldD[:] = 1.0
-            for l in images:
-                capi.call("thx_ExpectLocalP_host", 0, devdatP, devctfP, devdefO, devsigP, datP.ctypes.data, ctfP.ctypes.data, None,
-                          sigP.ctypes.data, t, int(l), nPxl, 0)
-                for ph in range(args.phases):       # (the same support points in every phase: the same work)
-                    h_tr[:] = tran[l].reshape(-1); h_rot[:] = quat[l].reshape(-1)
-                    capi.call("thx_ExpectLocalRTD_host", 0, mcp, hp[4], hp[5], hp[6], hp[7], hp[8], hp[9])
-                    capi.call("thx_ExpectLocalPreI3D_host", 0, t, mgr, mcp, devdefO, None, deviCol, deviRow, float(attr_h[l, 6]),
-                              float(attr_h[l, 5]), 0.0, 0.0, pf, N, P, nPxl, 1)
-                    capi.call("thx_ExpectLocalM_host", 0, t, mcp, devdatP, devctfP, devsigP, hp[0], hp[1], hp[2], hp[3], 1.0, nPxl)
-        except Exception as e:      # noqa: BLE001
-            errors.append(e)
-
-    def run_e(images):
-        th = [threading.Thread(target=worker, args=(t, images[t::threads])) for t in range(threads)]
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
-        if errors:
-            raise errors[0]
-    run_e(np.arange(min(n, 4 * threads)))                            # untimed: first touch
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_e(np.arange(n))
-    torch.cuda.synchronize()
-    t_e = time.perf_counter() - t0
+    def run_e(images, threads_, lock):
+        a = HArgs(gpu=0, N=N, pf=pf, nPxl=nPxl, nImg=int(images), mLR=nR, mLT=nT, phases=args.phases, threads=threads_, lock=lock,
+                  volume=vol.ctypes.data, iCol=iCol.ctypes.data, iRow=iRow.ctypes.data, datP=datP.ctypes.data, ctfP=ctfP.ctypes.data,
+                  sigP=sigP.ctypes.data, quat=quat.ctypes.data, tran=tran.ctypes.data, attr=attr_h.ctypes.data, wR=wR_out.ctypes.data, wT=None)
+        rc = H.thx_harness_expectation_local(C.byref(a))
+        if rc:
+            raise RuntimeError("staged local search failed: %s" % capi.load().thx_last_error().decode(errors="replace"))
+        return a.seconds
+    run_e(min(n, 4 * threads), threads, 0)                           # untimed: first touch
+    sweep = {}
+    for lock, ths in ((1, sorted({1, threads})), (0, sorted({threads, 4 * threads, 16 * threads}))):
+        for th in ths:
+            dt_ = run_e(n, th, lock)
+            sweep["%s, %d threads" % ("per-GPU lock as in Optimiser.cpp" if lock else "no lock", th)] = 1e6 * dt_ / (n * args.phases)
+    t_e_locked = min(v_ for k_, v_ in sweep.items() if k_.startswith("per-GPU")) * 1e-6 * n * args.phases
+    t_e_free = min(v_ for k_, v_ in sweep.items() if k_.startswith("no lock")) * 1e-6 * n * args.phases
+    assert np.all(np.isfinite(wR_out)) and wR_out.max() > 0
     # ---- insertion: InsertFT on batches of host rows (quaternions / shifts of mReco draws per image) ----
     rng = np.random.default_rng(3)
     mReco = args.mReco
@@ -570,15 +548,27 @@ def bench_staged(args, dev):
     O3, cnt = np.zeros(3), np.zeros(1, np.int32)
     w = np.full(n, np.float32(1.0 / mReco), np.float32)
     offS = np.zeros((n, 2))
-    B = int(args.staged_insert_batch) or n
-    t0 = time.perf_counter()
-    for b0 in range(0, n, B):
-        b1 = min(n, b0 + B)
+    # InsertFT stages the caller's HOST volumes in and out at every call: a fixed cost per call (1.5 GB of F / T each way at 512^3
+    # voxels of padded grid) next to a cost per image.  Reconstructor::insertI hands InsertFT every image of the process in ONE call
+    # (src/Reconstructor.cpp:865-976), so the two are measured apart -- a call over half the sample and a call over all of it -- and
+    # the iteration is priced as fixed + per_image x particles, not as (one small call) x particles / sample.
+    def insert_call(b0, b1):
+        t0_ = time.perf_counter()
         capi.call("thx_InsertFT_host", F.ctypes.data, Tc.ctypes.data, O3.ctypes.data, cnt.ctypes.data, datMh[b0:b1].ctypes.data,
                   ctfMh[b0:b1].ctypes.data, attr_h[b0:b1].ctypes.data, offS[b0:b1].ctypes.data, w[b0:b1].ctypes.data,
                   nRq[b0:b1].ctypes.data, nTt[b0:b1].ctypes.data, None, None, iColM.ctypes.data, iRowM.ctypes.data,
                   float(sh.pixelSize), 0, pf, nPxlM, mReco, N, P, 1, b1 - b0)
-    t_i = time.perf_counter() - t0
+        return time.perf_counter() - t0_
+    B = int(args.staged_insert_batch)
+    if B:
+        t_i = sum(insert_call(b0, min(n, b0 + B)) for b0 in range(0, n, B))
+        ins_fixed, ins_per_image = 0.0, t_i / n
+    else:
+        insert_call(0, min(n, 64))                                   # untimed: first touch of the host volumes
+        t_half, t_full = insert_call(0, n // 2), insert_call(0, n)
+        ins_per_image = max(0.0, (t_full - t_half) / (n - n // 2))
+        ins_fixed = max(0.0, t_full - ins_per_image * n)
+        t_i = t_full
     # ---- reconstruction: ReconstructG on host volumes ----
     capi.call("thx_PrepareTF_host", 0, F.ctypes.data, Tc.ctypes.data, P, None, 0, sh.maxRadius, pf)
     fscv = np.ones(N // 2 - 2, np.float32)
@@ -587,24 +577,23 @@ def bench_staged(args, dev):
     capi.call("thx_ReconstructG_host", 0, F.ctypes.data, Tc.ctypes.data, N, N, pf, sh.maxRadius, 1.9, 15.0, fscv.ctypes.data, len(fscv), 1, 0, 1,
               out.ctypes.data)
     t_r = time.perf_counter() - t0
-    for mcp, hp in ctx:
-        capi.call("thx_ExpectLocalHostF_host", 0, *[C.byref(q) for q in hp], 0)
-        capi.call("thx_calpoint_destroy", mcp)
-    devfreQ = vp()
-    capi.call("thx_ExpectLocalFin_host", 0, C.byref(devdatP), C.byref(devctfP), C.byref(devdefO), C.byref(devfreQ), C.byref(devsigP), 0)
-    capi.call("thx_ExpectFreeIdx_host", 0, C.byref(deviCol), C.byref(deviRow))
-    capi.call("thx_texture_destroy", mgr)
     total = args.particles
-    t_iter = total * (t_e + t_i) / n + 4 * t_r
+    t_ins_total = ins_fixed + ins_per_image * total
+    t_iter = total * t_e_locked / n + t_ins_total + 4 * t_r            # an UNCHANGED Optimiser.cpp: its own per-GPU lock around every image-phase
+    t_iter_free = total * t_e_free / n + t_ins_total + 4 * t_r
     return {"metric": "particles/sec per refinement iteration through the reference's plug-in surface (staged drop-in path; %d^3 box, %d particles)" % (N, total),
             "value": total / t_iter, "unit": "particles/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
             "vs_baseline": None,
-            "config": {"workload": "sample of %d of %d synthetic %d^3 particles: local search %d phases x %d rot x %d shifts one image per call "
-                                   "from %d host threads (thx_ExpectLocalP / RTD / PreI3D / M_host), InsertFT on batches of %d images x %d draws of host "
-                                   "rows, ReconstructG on host volumes x 4" % (n, total, N, args.phases, nR, nT, threads, B, mReco),
+            "value_without_the_callers_lock": total / t_iter_free,
+            "config": {"workload": "sample of %d of %d synthetic %d^3 particles: local search %d phases x %d rot x %d shifts ONE IMAGE PER CALL from a C++ "
+                                   "OpenMP caller loop over the C ABI (integration/expectationG_harness.cpp = Optimiser::expectationG's loop: "
+                                   "thx_ExpectLocalP / RTD / PreI3D / M_host), under the reference's per-GPU lock (`value`) and without it; InsertFT on "
+                                   "host rows x %d draws (fixed cost per call + cost per image, one call over all particles as Reconstructor::insertI "
+                                   "makes it), ReconstructG on host volumes x 4" % (n, total, N, args.phases, nR, nT, mReco),
                        "driver": "the thx_*_host twins of gpu/interface/Interface.h, as an unchanged Optimiser.cpp calls them"},
-            "e_step_us_per_image_phase": 1e6 * t_e / (n * args.phases), "e_step_images_per_s": n / t_e,
-            "insert_us_per_image": 1e6 * t_i / n, "reconstructG_s": t_r,
+            "e_step_us_per_image_phase": 1e6 * t_e_locked / (n * args.phases), "e_step_us_per_image_phase_sweep": {k_: round(v_, 1) for k_, v_ in sweep.items()},
+            "e_step_images_per_s": n / t_e_locked, "e_step_images_per_s_without_the_lock": n / t_e_free,
+            "insert_us_per_image": 1e6 * ins_per_image, "insert_fixed_s_per_call": ins_fixed, "insert_sample_call_s": t_i, "reconstructG_s": t_r,
             "seconds_per_iteration_scaled": t_iter, "roofline": None, "cpu_baseline": None,
             "note": "compatibility form: one launch per image-phase and host staging at every call; the native driver "
                     "(thx_refine_iterate) is the product path and the headline"}

@@ -242,3 +242,56 @@ def test_staged_no_gridcorr_weights(oracle, dev):
     W = np.zeros(P * P * (P // 2 + 1), np.float32)
     capi.call("thx_ExposeWT_plain_host", 0, Tt.ctypes.data, W.ctypes.data, maxRadius, pf, P)
     assert np.array_equal(W, W_want.reshape(-1))
+
+
+class _HArgs(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("gpu", "N", "pf", "nPxl", "nImg", "mLR", "mLT", "phases", "threads", "lock")] + \
+               [(k, C.c_void_p) for k in ("volume", "iCol", "iRow", "datP", "ctfP", "sigP", "quat", "tran", "attr", "wR", "wT")] + \
+               [("seconds", C.c_double)]
+
+
+@pytest.mark.parametrize("N,nImg,nR", [(32, 24, 20), (64, 12, 125)])
+def test_caller_loop_harness_matches_batched_and_oracle(oracle, dev, N, nImg, nR):
+    """The reference's CALLER loop over the plug-in surface (Optimiser::expectationG, src/Optimiser.cpp:2790-3100) as
+    integration/expectationG_harness.cpp restates it in C++ / OpenMP over the C ABI -- with the per-GPU lock the reference holds over
+    ExpectLocalRTD .. ExpectLocalM (2 threads) and without it (6 threads on their own ManagedCalPoints / streams) -- against the batched
+    kernel on the same inputs (same arithmetic, partial sums grouped differently: 1e-4) and the oracle (test_expect_local's bar).
+    nR = 125 at N = 64: two rotation groups per workgroup, one workgroup per 256-pixel chunk (8 chunks), cell-packed volume.  The two
+    harness runs are the same computation image by image: bit-identical to each other."""
+    import torch
+    from thunder_amd import build, ops, synth
+    O = oracle
+    rng = np.random.default_rng(900 + N)
+    nT, phases = 9, 2
+    P = 2 * N
+    ref, vol, pl = make_case(O, N, rL=1)
+    nPxl = pl["nPxl"]
+    im = make_images(O, vol, pl, N, nImg, rng, snr_sigma=2.0)
+    quat = np.ascontiguousarray(synth.perturb_quats(im["quat"], nR, 0.04, rng))
+    rot = np.stack([[O.rotate3D(q) for q in qs] for qs in quat])
+    tran = np.ascontiguousarray(im["shift"][:, None, :] + rng.normal(0, 0.5, size=(nImg, nT, 2)))
+    H = C.CDLL(build.build_harness())
+    H.thx_harness_expectation_local.restype = C.c_int
+    iCol, iRow = np.ascontiguousarray(pl["iCol"]), np.ascontiguousarray(pl["iRow"])
+    attr = np.ascontiguousarray(im["attr"], np.float32)
+    got = {}
+    for lock, threads in ((1, 2), (0, 6)):
+        wR, wT = np.zeros((nImg, nR), np.float32), np.zeros((nImg, nT), np.float32)
+        a = _HArgs(gpu=0, N=N, pf=2, nPxl=nPxl, nImg=nImg, mLR=nR, mLT=nT, phases=phases, threads=threads, lock=lock, volume=vol.ctypes.data,
+                   iCol=iCol.ctypes.data, iRow=iRow.ctypes.data, datP=im["dat"].ctypes.data, ctfP=im["ctf"].ctypes.data,
+                   sigP=im["sigRcp"].ctypes.data, quat=quat.ctypes.data, tran=tran.ctypes.data, attr=attr.ctypes.data, wR=wR.ctypes.data,
+                   wT=wT.ctypes.data)
+        assert H.thx_harness_expectation_local(C.byref(a)) == 0
+        assert a.seconds > 0
+        got[lock] = (wR, wT)
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    res = ops.expect_local(T(vol, dev), P, 2, N, T(iCol, dev), T(iRow, dev), T(im["dat"], dev), T(im["ctf"], dev), T(im["sigRcp"], dev),
+                           T(rot, dev), T(tran, dev), nD=1, pR=T(np.full((nImg, nR), 1.0 / nR), dev), pT=T(np.full((nImg, nT), 1.0 / nT), dev))
+    np.testing.assert_allclose(got[1][0], res.wR.cpu().numpy(), rtol=1e-4, atol=1e-30)
+    np.testing.assert_allclose(got[1][1], res.wT.cpu().numpy(), rtol=1e-4, atol=1e-30)
+    for l in range(0, nImg, 5):
+        want = O.expect_local(vol, P, 2, N, iCol, iRow, im["dat"][l], im["ctf"][l], im["sigRcp"][l], rot[l], tran[l], nD=1, pC=1.0,
+                              pR=np.full(nR, 1.0 / nR), pT=np.full(nT, 1.0 / nT))
+        np.testing.assert_allclose(got[1][0][l], want["wR"], rtol=2e-3, atol=1e-30)
+        np.testing.assert_allclose(got[1][1][l], want["wT"], rtol=2e-3, atol=1e-30)
+    torch.cuda.synchronize()

@@ -66,5 +66,24 @@ def build(force=False, verbose=False):
     return LIB
 
 
+HARNESS_SRC = os.path.join(HERE, "..", "integration", "expectationG_harness.cpp")
+HARNESS = os.path.join(LIBDIR, "libthx_harness.so")
+
+
+def build_harness(force=False):
+    """integration/expectationG_harness.cpp -> thunder_amd/lib/libthx_harness.so: the CALLER side of the reference's plug-in surface
+    (Optimiser::expectationG's OpenMP loop) over the C ABI -- test / bench infrastructure, plain g++ (no device code), linked against
+    libthunder_amd.so, never part of it."""
+    lib = build()
+    src = os.path.abspath(HARNESS_SRC)
+    if not force and os.path.exists(HARNESS) and os.path.getmtime(HARNESS) > max(os.path.getmtime(src), os.path.getmtime(lib)):
+        return HARNESS
+    cmd = ["g++", "-O2", "-std=c++14", "-fopenmp", "-shared", "-fPIC", "-Wall", "-I" + os.path.join(HERE, "..", "include"), src, "-o", HARNESS,
+           "-L" + LIBDIR, "-lthunder_amd", "-Wl,-rpath,$ORIGIN"]
+    subprocess.check_call(cmd)
+    return HARNESS
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_harness(force="--force" in sys.argv))

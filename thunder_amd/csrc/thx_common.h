@@ -382,4 +382,27 @@ struct DevBuf {
 
 #define THX_RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
+// one image per call (thx_estep.hip; what thx_ExpectLocalM_host runs): workspace bytes, and the fused gather + likelihood + weights
+// of ONE image split over every 256-pixel chunk.  volOrCells: the padded FT, or (packed) its cell-packed copy.
+size_t expect_local_single_workspace(int nPxl, int nR, int nT, int nD);
+int expect_local_single(const float* volOrCells, bool packed, int vdim, int pf, int idim, const int* iCol, const int* iRow, int nPxl,
+                        const float* datP, const float* ctfP, const float* sigRcpP, const double* rotMat, int nR, const double* trans,
+                        int nT, int nD, double pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR, float* wT,
+                        float* wD, float* baseLine, void* workspace, hipStream_t st);
+
+// rotate3D(quaternion), src/Geometry/Euler.cpp:181-189: R = I + 2 q0 A + 2 A A, column-major out.  ONE statement of the arithmetic for
+// the device kernel (k_rotmat) and for host callers that stage matrices themselves (thx_ExpectLocalRTD_host): IEEE double
+// multiplications and additions in a fixed order (-ffp-contract=off on both sides), so the two give the same bits.
+__host__ __device__ inline void rotate3d_colmajor(const double* q, double* mat)
+{
+    const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const double A[3][3] = {{0, -q3, q2}, {q3, 0, -q1}, {-q2, q1, 0}};
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += A[r][k] * A[k][c];
+            mat[c * 3 + r] = (r == c ? 1.0 : 0.0) + 2 * q0 * A[r][c] + 2 * s;
+        }
+}
+
 }  // namespace thx

@@ -160,14 +160,7 @@ __global__ void k_rotmat(const double* __restrict__ quat, double* __restrict__ m
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double q0 = quat[4 * i], q1 = quat[4 * i + 1], q2 = quat[4 * i + 2], q3 = quat[4 * i + 3];
-    const double A[3][3] = {{0, -q3, q2}, {q3, 0, -q1}, {-q2, q1, 0}};
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) {
-            double s = 0;
-            for (int k = 0; k < 3; k++) s += A[r][k] * A[k][c];
-            mat[9 * (size_t)i + c * 3 + r] = (r == c ? 1.0 : 0.0) + 2 * q0 * A[r][c] + 2 * s;
-        }
+    rotate3d_colmajor(quat + 4 * (size_t)i, mat + 9 * (size_t)i);
 }
 
 // translate(), src/Image/ImageFunctions.cpp:233-252, nT ramps at once: grid (ceil(nPxl/256), nT)
@@ -740,6 +733,7 @@ struct ExpectFinalArgs {
     const float* partC;
     int nSplit, nR, nRpad, nT, nD;
     const double* pC;
+    double pCval;      // the prior of the class when pC is NULL (1 unless a one-image caller hands it over by value)
     const double* pR;
     const double* pT;
     const double* pD;
@@ -795,7 +789,7 @@ __global__ __launch_bounds__(256) void k_expect_final(ExpectFinalArgs a)
     for (int e = tid; e < n; e += 256) sL[e] = expf(sL[e] - vmax);
     __syncthreads();
     const float base = sfred[4] + vmax;
-    const double pC = a.pC ? a.pC[img] : 1.0;
+    const double pC = a.pC ? a.pC[img] : a.pCval;
     const double* pR = a.pR + (size_t)img * a.nR;
     const double* pT = a.pT + (size_t)img * a.nT;
     const double* pD = a.pD + (size_t)img * a.nD;
@@ -1524,7 +1518,7 @@ static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, 
                              const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
                              const double* pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR,
                              float* wT, float* wD, float* baseLine, float* logW, void* workspace, int wgPerCU, const int* active, void* stream,
-                             bool packed)
+                             bool packed, int nSplitForce = 0, bool noOrder = false, double pCval = 1.0)
 {
     if (nImg <= 0) return 0;
     THX_REQUIRE(volumes && iCol && iRow && datP && ctfP && sigRcpP && rotMat && trans, "NULL input pointer");
@@ -1541,11 +1535,11 @@ static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, 
     a.iCol = iCol; a.iRow = iRow; a.nPxl = nPxl; a.nImg = nImg;
     a.datP = reinterpret_cast<const float2*>(datP);
     a.ctfP = ctfP; a.sigRcpP = sigRcpP; a.rotMat = rotMat; a.nR = nR; a.trans = trans; a.nT = nT; a.nD = nD;
-    a.nSplit = expect_local_nsplit(nImg);
+    a.nSplit = nSplitForce > 0 ? nSplitForce : expect_local_nsplit(nImg);
     a.active = active;
     a.splitM = 0.f;
     a.order = nullptr;
-    if (knobs().expectOrder > 0 && nR > 64 && nR <= 256 && nD == 1) {   // (one wave holds a cloud of <= 64 rotations whatever the order)
+    if (knobs().expectOrder > 0 && nR > 64 && nR <= 256 && nD == 1 && !noOrder) {   // (one wave holds a cloud of <= 64 rotations whatever the order)
         unsigned char* ord = reinterpret_cast<unsigned char*>(scratch(st, 18, (size_t)nImg * nR));
         THX_REQUIRE(ord, "device scratch allocation failed");
         hipLaunchKernelGGL(k_cloud_order, dim3(nImg), dim3(256), 0, st, ord, rotMat, nR, knobs().expectOrder);
@@ -1563,7 +1557,7 @@ static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, 
     else rc = launch_expect_local<32>(a, st, packed, wgPerCU);
     if (rc) return rc;
     f.nR = nR; f.nRpad = a.nRpad; f.nT = nT; f.nD = nD;
-    f.pC = pC; f.pR = pR; f.pT = pT; f.pD = pD; f.wC = wC; f.wR = wR; f.wT = wT; f.wD = wD; f.baseLine = baseLine;
+    f.pC = pC; f.pCval = pCval; f.pR = pR; f.pT = pT; f.pD = pD; f.wC = wC; f.wR = wR; f.wT = wT; f.wD = wD; f.baseLine = baseLine;
     f.logW = logW;
     f.active = active;
     hipLaunchKernelGGL(k_expect_final, dim3(nImg), dim3(256), (size_t)nD * nT * nR * sizeof(float), st, f);
@@ -1594,6 +1588,38 @@ int thx_expect_local_packed_dev(const float* cells, const int* volIdx, int vdim,
 }
 
 size_t thx_projector_packed_bytes(int vdim) { return (size_t)vdim * vdim * (vdim / 2 + 1) * 64; }
+
+}  // extern "C"
+
+// ONE image per call -- the granularity of the reference's plug-in surface (ExpectLocalM, gpu/interface/Interface.h:125-139, called
+// image by image under a per-GPU lock, src/Optimiser.cpp:2960-3080).  The batched launch gives an image 1 ... 16 workgroups; alone on
+// the chip it gets one per 256-pixel chunk (97 at 256^3), the lane <-> rotation ordering launch is left out (the results do not depend
+// on it) and the class prior travels by value: two launches per image-phase.  Same kernels, same arithmetic; the partial sums of the
+// chunks are added in chunk order (the batched form adds them in groups: equal to rounding, tests/test_iface_gpu.py).
+namespace thx {
+static int single_nsplit(int nPxl)
+{
+    const int nChunks = (nPxl + kChunk - 1) / kChunk;
+    if (knobs().expectNSplit) return knobs().expectNSplit;
+    return nChunks < 1 ? 1 : (nChunks > 512 ? 512 : nChunks);
+}
+size_t expect_local_single_workspace(int nPxl, int nR, int nT, int nD)
+{
+    const size_t nRpad = (size_t)((nR + 63) / 64) * 64, nSplit = (size_t)single_nsplit(nPxl);
+    return ((size_t)nD * nSplit * nT * nRpad + (size_t)nD * nSplit) * sizeof(float) + 256;
+}
+int expect_local_single(const float* volOrCells, bool packed, int vdim, int pf, int idim, const int* iCol, const int* iRow, int nPxl,
+                        const float* datP, const float* ctfP, const float* sigRcpP, const double* rotMat, int nR, const double* trans,
+                        int nT, int nD, double pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR, float* wT,
+                        float* wD, float* baseLine, void* workspace, hipStream_t st)
+{
+    return expect_local_impl(volOrCells, nullptr, vdim, pf, idim, iCol, iRow, nPxl, 1, datP, ctfP, sigRcpP, rotMat, nR, trans, nT, nD,
+                             nullptr, pR, pT, pD, wC, wR, wT, wD, baseLine, nullptr, workspace, 0 /* no occupancy cap: one image */, nullptr, st,
+                             packed, single_nsplit(nPxl), true, pC);
+}
+}  // namespace thx
+
+extern "C" {
 
 int thx_projector_pack_dev(float* cells, const float* volumes, int vdim, int nVol, void* stream)
 {

@@ -4,10 +4,16 @@
 // handles.  Optimiser::expectationG (src/Optimiser.cpp:2180-3393) drives them image by image from OpenMP threads; every
 // entry keeps the argument meaning of its twin, so a replacement Interface.cpp forwards one to one.
 //
-// The work itself is the batched kernel of thx_estep.hip run on a batch of one image: ExpectLocalPreI3D stages the
-// rotation matrices (and, in the defocus search, the CTF rows) and ExpectLocalM runs the fused gather + likelihood +
-// weight kernel -- the slices are never materialised.  This is the compatibility granularity; the batched
-// thx_expect_local_dev is the one to use for throughput.
+// The work itself is the fused kernel of thx_estep.hip on ONE image -- the slices are never materialised.  The reference's caller
+// holds a per-GPU lock over ExpectLocalRTD .. ExpectLocalM (omp_set_lock(&mtx[gpuIdx]), src/Optimiser.cpp:2960-3080) and reads the
+// weights right after ExpectLocalM returns: one image-phase is in flight per GPU and its LATENCY is what an unchanged Optimiser.cpp
+// pays.  So the chain is cut to the minimum (round 6): ExpectLocalV3D also builds the cell-packed copy of the volume (one 64-byte
+// request per sample); ExpectLocalRTD only stages -- priors, shifts, quaternions and the rotation matrices it forms on the host
+// (rotate3d_colmajor: the device kernel's arithmetic, same bits) -- into a page-locked block the handle owns; ExpectLocalPreI3D sends
+// that block with ONE copy (and, in a defocus search, runs the CTF-row kernel); ExpectLocalM launches the one-image form of the
+// kernel (a workgroup per 256-pixel chunk instead of 16 per image, class prior by value: expect_local_single) + the finalise kernel,
+// fetches wC / wR / wT / wD with ONE copy and waits ONCE.  Per image-phase: 1 H2D, 2 kernels, 1 D2H, 1 synchronisation (before: 5 - 7
+// H2D, 3 kernels, 4 D2H, 2 - 3 synchronisations and 16 workgroups).  The batched thx_expect_local_dev stays the throughput form.
 #include "thx_common.h"
 
 using namespace thx;
@@ -15,6 +21,7 @@ using namespace thx;
 struct thx_texture {      // ManagedArrayTexture (gpu/include/ManagedArrayTexture.h): a device-resident padded FT
     int mode, vdim, gpu;
     float* vol;           // [vdim][vdim][vdim/2+1] complex64
+    float* cells;         // its cell-packed copy (thx_projector_pack_dev), built by ExpectLocalV3D; NULL if it did not fit
 };
 
 struct thx_calpoint {     // ManagedCalPoint (gpu/include/ManagedCalPoint.h): per-stream search buffers
@@ -27,13 +34,17 @@ struct thx_calpoint {     // ManagedCalPoint (gpu/include/ManagedCalPoint.h): pe
     float* k12;                              // device k1, k2 of the current image
     void* ws;
     hipStream_t stream;
+    // page-locked host mirrors: hIn = the double block devR .. devRotm as ExpectLocalRTD stages it (ONE copy in ExpectLocalPreI3D),
+    // hOut = devwC .. devBaseL (ONE copy back in ExpectLocalM), hSmall = CTFAttr + k1, k2 of the current image (defocus search)
+    double* hIn;
+    float* hOut;
+    char* hSmall;
+    size_t nIn, nOut;
     // recorded by ExpectLocalPreI3D for ExpectLocalM
     const float* vol;
+    const float* cells;
     const int *iCol, *iRow;
     int pf, idim, vdim;
-    thx_ctf_attr hAttr;
-    float hK12[2];
-    double hC;
 };
 
 extern "C" {
@@ -45,9 +56,18 @@ int thx_texture_create(thx_texture** out, int mode, int vdim, int gpuIdx)
     THX_REQUIRE(mode == 1, "only MODE_3D (1) is implemented");
     THX_CHECK(hipSetDevice(gpuIdx));
     thx_texture* t = new thx_texture();
-    t->mode = mode; t->vdim = vdim; t->gpu = gpuIdx; t->vol = nullptr;
+    t->mode = mode; t->vdim = vdim; t->gpu = gpuIdx; t->vol = nullptr; t->cells = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&t->vol), (size_t)vdim * vdim * (vdim / 2 + 1) * 2 * sizeof(float));
     if (e != hipSuccess) { delete t; set_error("hipMalloc failed: %s", hipGetErrorString(e)); return (int)e; }
+    // the cell-packed copy is 8 x the volume (4.3 GB at 512^3 voxels of padded FT): taken when the device has it to spare (THX_IFACE_PACK=0: never)
+    {
+        size_t freeB = 0, totalB = 0;
+        const size_t need = thx_projector_packed_bytes(vdim);
+        const char* env = getenv("THX_IFACE_PACK");
+        if (!(env && env[0] == '0') && hipMemGetInfo(&freeB, &totalB) == hipSuccess && need < freeB / 2) {
+            if (hipMalloc(reinterpret_cast<void**>(&t->cells), need) != hipSuccess) { t->cells = nullptr; (void)hipGetLastError(); }
+        }
+    }
     *out = t;
     return 0;
 }
@@ -57,6 +77,7 @@ int thx_texture_destroy(thx_texture* t)
     if (!t) return 0;
     (void)hipSetDevice(t->gpu);
     (void)hipFree(t->vol);
+    (void)hipFree(t->cells);
     delete t;
     return 0;
 }
@@ -77,13 +98,21 @@ int thx_calpoint_create(thx_calpoint** out, int mode, int cSearch, int gpuIdx, i
     const size_t nFlt = 1 + (size_t)nR + nT + mD + 1 + (cSearch == 2 ? (size_t)mD * npxl : 0) + 2;
     double* d = nullptr;
     float* f = nullptr;
+    c->nIn = nDbl; c->nOut = 1 + (size_t)nR + nT + mD + 1;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), nDbl * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f), nFlt * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->attr), sizeof(thx_ctf_attr));
-    if (e == hipSuccess) e = hipMalloc(&c->ws, thx_expect_local_workspace(1, nR, nT, nD));
+    if (e == hipSuccess) e = hipMalloc(&c->ws, expect_local_single_workspace(npxl, nR, nT, nD));
     if (e == hipSuccess) e = hipStreamCreate(&c->stream);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->hIn), nDbl * sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->hOut), c->nOut * sizeof(float), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->hSmall), sizeof(thx_ctf_attr) + 2 * sizeof(float), hipHostMallocDefault);
     if (e != hipSuccess) {
         (void)hipFree(d); (void)hipFree(f); (void)hipFree(c->attr); (void)hipFree(c->ws);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        if (c->hIn) (void)hipHostFree(c->hIn);
+        if (c->hOut) (void)hipHostFree(c->hOut);
+        if (c->hSmall) (void)hipHostFree(c->hSmall);
         delete c;
         set_error("ManagedCalPoint allocation failed: %s", hipGetErrorString(e));
         return (int)e;
@@ -116,6 +145,7 @@ int thx_calpoint_destroy(thx_calpoint* c)
     (void)hipFree(c->devwC);   // base of the float block
     (void)hipFree(c->attr);
     (void)hipFree(c->ws);
+    (void)hipHostFree(c->hIn); (void)hipHostFree(c->hOut); (void)hipHostFree(c->hSmall);
     delete c;
     return 0;
 }
@@ -165,6 +195,10 @@ int thx_ExpectLocalV3D_host(int gpuIdx, thx_texture* mgr, const float* volume, i
     THX_REQUIRE(mgr && volume && vdim == mgr->vdim, "bad arguments (vdim must match ManagedArrayTexture::Init)");
     THX_CHECK(hipSetDevice(mgr->gpu));
     THX_CHECK(hipMemcpy(mgr->vol, volume, (size_t)vdim * vdim * (vdim / 2 + 1) * 2 * sizeof(float), hipMemcpyHostToDevice));
+    if (mgr->cells) {   // the 8 corners of every trilinear cell side by side: the local search's gather becomes one 64-byte request per sample
+        THX_RC(thx_projector_pack_dev(mgr->cells, mgr->vol, vdim, 1, nullptr));
+        THX_CHECK(hipStreamSynchronize(nullptr));   // (the search runs on the ManagedCalPoints' own streams)
+    }
     return 0;
 }
 
@@ -237,21 +271,25 @@ int thx_ExpectLocalRTD_host(int gpuIdx, thx_calpoint* mcp, const double* oldR, c
                             const double* trans, const double* rot, const double* dpara)
 {
     THX_REQUIRE(mcp && oldR && oldT && oldD && trans && rot, "bad arguments");
-    THX_CHECK(hipSetDevice(gpuIdx));
-    hipStream_t st = mcp->stream;
-    THX_CHECK(hipMemcpyAsync(mcp->devR, oldR, mcp->nR * sizeof(double), hipMemcpyHostToDevice, st));
-    THX_CHECK(hipMemcpyAsync(mcp->devT, oldT, mcp->nT * sizeof(double), hipMemcpyHostToDevice, st));
-    THX_CHECK(hipMemcpyAsync(mcp->devnR, rot, (size_t)mcp->nR * 4 * sizeof(double), hipMemcpyHostToDevice, st));
-    THX_CHECK(hipMemcpyAsync(mcp->devnT, trans, (size_t)mcp->nT * 2 * sizeof(double), hipMemcpyHostToDevice, st));
+    (void)gpuIdx;
+    // staged on the host, in the layout of the device block (devR | devT | devD | devC | devnR | devnT | devdP | devRotm): nothing
+    // touches the device here.  The caller's arrays may be rewritten as soon as this returns (they need not be page-locked).
+    double* h = mcp->hIn;
+    const int nR = mcp->nR, nT = mcp->nT, mD = mcp->mD;
+    memcpy(h, oldR, nR * sizeof(double)); h += nR;
+    memcpy(h, oldT, nT * sizeof(double)); h += nT;
+    if (mcp->cSearch == 2) memcpy(h, oldD, mD * sizeof(double)); else h[0] = oldD[0];
+    h += mD;
+    h[0] = 1.0; h += 1;                                       // (devC: the class prior travels by value in ExpectLocalM)
+    memcpy(h, rot, (size_t)nR * 4 * sizeof(double));
+    const double* q = h; h += 4 * (size_t)nR;
+    memcpy(h, trans, (size_t)nT * 2 * sizeof(double)); h += 2 * (size_t)nT;
     if (mcp->cSearch == 2) {
         THX_REQUIRE(dpara, "dpara is NULL");
-        THX_CHECK(hipMemcpyAsync(mcp->devdP, dpara, mcp->mD * sizeof(double), hipMemcpyHostToDevice, st));
-        THX_CHECK(hipMemcpyAsync(mcp->devD, oldD, mcp->mD * sizeof(double), hipMemcpyHostToDevice, st));
-    } else {
-        THX_CHECK(hipMemcpyAsync(mcp->devD, oldD, sizeof(double), hipMemcpyHostToDevice, st));
+        memcpy(h, dpara, mD * sizeof(double));
     }
-    // the caller reuses its staging arrays for the next image as soon as the phase returns; they need not be page-locked
-    THX_CHECK(hipStreamSynchronize(st));
+    h += mD;
+    for (int i = 0; i < nR; i++) rotate3d_colmajor(q + 4 * (size_t)i, h + 9 * (size_t)i);   // kernel_getRotMatL, gpu/src/cuthunder.cu:2851
     return 0;
 }
 
@@ -268,19 +306,22 @@ int thx_ExpectLocalPreI3D_host(int gpuIdx, int datShift, const thx_texture* mgr,
     THX_REQUIRE(interp == 1, "only LINEAR_INTERP (1) is implemented, as used by the 3D refinement path");
     THX_CHECK(hipSetDevice(gpuIdx));
     hipStream_t st = mcp->stream;
-    mcp->vol = mgr->vol; mcp->iCol = deviCol; mcp->iRow = deviRow; mcp->pf = pf; mcp->idim = idim; mcp->vdim = vdim;
-    THX_RC(thx_rotmat_dev(mcp->devnR, mcp->devRotm, mcp->nR, st));
+    mcp->vol = mgr->vol; mcp->cells = mgr->cells; mcp->iCol = deviCol; mcp->iRow = deviRow; mcp->pf = pf; mcp->idim = idim; mcp->vdim = vdim;
+    // the whole staged block -- priors, quaternions, shifts, defocus factors, rotation matrices -- in ONE copy from page-locked memory
+    THX_CHECK(hipMemcpyAsync(mcp->devR, mcp->hIn, mcp->nIn * sizeof(double), hipMemcpyHostToDevice, st));
     if (mcp->cSearch == 2) {
         THX_REQUIRE(devdefO && devfreQ, "defocus search needs devdefO and devfreQ");
-        memset(&mcp->hAttr, 0, sizeof(mcp->hAttr));
-        mcp->hAttr.amplitudeContrast = conT;
-        mcp->hAttr.phaseShift = phaseShift;
-        mcp->hK12[0] = k1; mcp->hK12[1] = k2;
-        THX_CHECK(hipMemcpyAsync(mcp->attr, &mcp->hAttr, sizeof(thx_ctf_attr), hipMemcpyHostToDevice, st));
-        THX_CHECK(hipMemcpyAsync(mcp->k12, mcp->hK12, 2 * sizeof(float), hipMemcpyHostToDevice, st));
+        // (page-locked and owned by this ManagedCalPoint: rewritten by its next ExpectLocalPreI3D only, i.e. after ExpectLocalM has waited)
+        thx_ctf_attr* hA = reinterpret_cast<thx_ctf_attr*>(mcp->hSmall);
+        float* hK = reinterpret_cast<float*>(mcp->hSmall + sizeof(thx_ctf_attr));
+        memset(hA, 0, sizeof(*hA));
+        hA->amplitudeContrast = conT;
+        hA->phaseShift = phaseShift;
+        hK[0] = k1; hK[1] = k2;
+        THX_CHECK(hipMemcpyAsync(mcp->attr, hA, sizeof(thx_ctf_attr), hipMemcpyHostToDevice, st));
+        THX_CHECK(hipMemcpyAsync(mcp->k12, hK, 2 * sizeof(float), hipMemcpyHostToDevice, st));
         THX_RC(thx_ctf_dsearch_dev(mcp->devctfD, devfreQ, devdefO + (size_t)datShift * npxl, mcp->k12, mcp->k12 + 1, mcp->attr,
                                    mcp->devdP, mcp->mD, npxl, 1, st));
-        THX_CHECK(hipStreamSynchronize(st));  // hAttr / hK12 may be rewritten by the next call
     }
     return 0;
 }
@@ -300,17 +341,17 @@ int thx_ExpectLocalM_host(int gpuIdx, int datShift, thx_calpoint* mcp, const flo
     const int nD = mcp->cSearch == 2 ? mcp->mD : 1;
     const float* ctf = mcp->cSearch == 2 ? mcp->devctfD : devctfP + slot;
     THX_REQUIRE(ctf, "devctfP is NULL");
-    mcp->hC = oldC;
-    THX_CHECK(hipMemcpyAsync(mcp->devC, &mcp->hC, sizeof(double), hipMemcpyHostToDevice, st));
-    THX_RC(thx_expect_local_dev(mcp->vol, nullptr, mcp->vdim, mcp->pf, mcp->idim, mcp->iCol, mcp->iRow, npxl, 1,
-                                devdatP + 2 * slot, ctf, devsigP + slot, mcp->devRotm, mcp->nR, mcp->devnT, mcp->nT, nD,
-                                mcp->devC, mcp->devR, mcp->devT, mcp->devD, mcp->devwC, mcp->devwR, mcp->devwT, mcp->devwD,
-                                mcp->devBaseL, nullptr, mcp->ws, -1, nullptr, st));
-    THX_CHECK(hipMemcpyAsync(wC, mcp->devwC, sizeof(float), hipMemcpyDeviceToHost, st));
-    THX_CHECK(hipMemcpyAsync(wR, mcp->devwR, mcp->nR * sizeof(float), hipMemcpyDeviceToHost, st));
-    THX_CHECK(hipMemcpyAsync(wT, mcp->devwT, mcp->nT * sizeof(float), hipMemcpyDeviceToHost, st));
-    THX_CHECK(hipMemcpyAsync(wD, mcp->devwD, nD * sizeof(float), hipMemcpyDeviceToHost, st));
+    // two launches (fused gather + likelihood over every 256-pixel chunk, finalise), one copy back, one wait
+    THX_RC(expect_local_single(mcp->cells ? mcp->cells : mcp->vol, mcp->cells != nullptr, mcp->vdim, mcp->pf, mcp->idim, mcp->iCol, mcp->iRow, npxl,
+                               devdatP + 2 * slot, ctf, devsigP + slot, mcp->devRotm, mcp->nR, mcp->devnT, mcp->nT, nD, oldC, mcp->devR,
+                               mcp->devT, mcp->devD, mcp->devwC, mcp->devwR, mcp->devwT, mcp->devwD, mcp->devBaseL, mcp->ws, st));
+    THX_CHECK(hipMemcpyAsync(mcp->hOut, mcp->devwC, mcp->nOut * sizeof(float), hipMemcpyDeviceToHost, st));
     THX_CHECK(hipStreamSynchronize(st));
+    const float* o = mcp->hOut;
+    wC[0] = o[0]; o += 1;
+    memcpy(wR, o, mcp->nR * sizeof(float)); o += mcp->nR;
+    memcpy(wT, o, mcp->nT * sizeof(float)); o += mcp->nT;
+    memcpy(wD, o, nD * sizeof(float));
     return 0;
 }
 

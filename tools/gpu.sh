@@ -6,6 +6,7 @@ cd "$(dirname "$0")/.."
 python -c "
 from thunder_amd import build, capi
 build.build()
+build.build_harness()
 h = capi.load()
 [getattr(h, n) for n in capi.SIGNATURES]
 from oracle import oracle as O
