@@ -138,18 +138,30 @@ public:
     void projectBatch(Complex* dst, const double* mats, int nR, const int* iCol, const int* iRow, int nPxl) const
     {
         if (!_vol) { std::fprintf(stderr, "thunder_amd FATAL: Projector has no projectee\n"); std::abort(); }
-        void *dOut = nullptr, *dMat = nullptr, *dCol = nullptr, *dRow = nullptr;
-        THX_ABORT_ON(thx_malloc_dev(&dOut, (size_t)nR * nPxl * 2 * sizeof(float)));
-        THX_ABORT_ON(thx_malloc_dev(&dMat, (size_t)nR * 9 * sizeof(double)));
-        THX_ABORT_ON(thx_malloc_dev(&dCol, (size_t)nPxl * sizeof(int)));
-        THX_ABORT_ON(thx_malloc_dev(&dRow, (size_t)nPxl * sizeof(int)));
+        // device staging from a pool the object owns: a calling thread takes a slot (grow-only buffers), uses it, hands it back -- no
+        // hipMalloc / hipFree per call (round-5 review: four of each before), and concurrent calls from the caller's OpenMP threads
+        // (`project` is const and called with nThread = 1 from every thread, src/Optimiser.cpp:758-781) do not share buffers
+        Slot* sl = take_slot();
+        void* dOut = sl->grow(0, (size_t)nR * nPxl * 2 * sizeof(float));
+        void* dMat = sl->grow(1, (size_t)nR * 9 * sizeof(double));
+        void* dCol = sl->grow(2, (size_t)nPxl * sizeof(int));
+        void* dRow = sl->grow(3, (size_t)nPxl * sizeof(int));
         THX_ABORT_ON(thx_memcpy_h2d(dMat, mats, (size_t)nR * 9 * sizeof(double)));
         THX_ABORT_ON(thx_memcpy_h2d(dCol, iCol, (size_t)nPxl * sizeof(int)));
         THX_ABORT_ON(thx_memcpy_h2d(dRow, iRow, (size_t)nPxl * sizeof(int)));
         THX_ABORT_ON(thx_project_dev(_vol, (float*)dOut, (const double*)dMat, (const int*)dCol, (const int*)dRow, nR, _pf,
                                      _pf * _N, nPxl, nullptr));
         THX_ABORT_ON(thx_memcpy_d2h(dst, dOut, (size_t)nR * nPxl * 2 * sizeof(float)));
-        thx_free_dev(dOut); thx_free_dev(dMat); thx_free_dev(dCol); thx_free_dev(dRow);
+        give_slot(sl);
+    }
+
+    // project(Image& dst, const dmat33& mat, const unsigned int nThread) const UNDER ITS OWN NAME (include/Projector.h:257-268;
+    // `proj.project(img, mat, nThread)`, appsrc/thunder_project.cpp:207): any image type with nColRL() and operator[] onto its Fourier
+    // half, any 3 x 3 matrix of doubles with .data()
+    template <class I, class M, class = decltype(std::declval<I&>().nColRL()), class = decltype(std::declval<const M&>().data())>
+    void project(I& dst, const M& mat, unsigned int nThread = 1) const
+    {
+        projectImage(&dst[0], (int)dst.nColRL(), mat, nThread);
     }
 
 private:
@@ -170,16 +182,50 @@ private:
         if (_plan) thx_reco_destroy(_plan);
         _vol = nullptr;
         _plan = nullptr;
+        std::lock_guard<std::mutex> g(_poolMtx);
+        for (Slot* sl : _pool) { for (int i = 0; i < 4; i++) if (sl->p[i]) thx_free_dev(sl->p[i]); delete sl; }
+        _pool.clear();
+    }
+    struct Slot {
+        void* p[4] = {nullptr, nullptr, nullptr, nullptr};
+        size_t cap[4] = {0, 0, 0, 0};
+        void* grow(int i, size_t bytes)
+        {
+            if (bytes > cap[i]) {
+                if (p[i]) thx_free_dev(p[i]);    // (the slot's last user waited for its copy back: nothing is in flight on it)
+                const size_t c = bytes + bytes / 2 + 256;
+                THX_ABORT_ON(thx_malloc_dev(&p[i], c));
+                cap[i] = c;
+            }
+            return p[i];
+        }
+    };
+    Slot* take_slot() const
+    {
+        std::lock_guard<std::mutex> g(_poolMtx);
+        if (_pool.empty()) return new Slot();
+        Slot* sl = _pool.back();
+        _pool.pop_back();
+        return sl;
+    }
+    void give_slot(Slot* sl) const
+    {
+        std::lock_guard<std::mutex> g(_poolMtx);
+        _pool.push_back(sl);
     }
     void steal(Projector& o)
     {
         _mode = o._mode; _maxRadius = o._maxRadius; _interp = o._interp; _pf = o._pf; _N = o._N;
         _vol = o._vol; _plan = o._plan;
         o._vol = nullptr; o._plan = nullptr;
+        std::lock_guard<std::mutex> g(o._poolMtx);
+        _pool.swap(o._pool);
     }
     int _mode, _maxRadius, _interp, _pf, _N;
     float* _vol;
     thx_reco* _plan;
+    mutable std::mutex _poolMtx;
+    mutable std::vector<Slot*> _pool;
 };
 
 }  // namespace thunder_amd

@@ -30,6 +30,55 @@ public:
         defaults();
         init(mode, size, N, pf, symMat, nSym, a, alpha);
     }
+    // The reference's OWN constructor (include/Reconstructor.h:336-349; `Reconstructor recon(MODE_3D, boxsize, boxsize, 2, &sym, 1.9, 15)`,
+    // appsrc/thunder_reconstruct.cpp:194): `sym` is any point-group type with nSymmetryElement() and get(L, R, i) (include/Geometry/
+    // Symmetry.h:180-190) -- its R matrices are read here, the object is not kept.  NULL: no symmetry.
+    template <class Sym, class = decltype(std::declval<const Sym&>().nSymmetryElement())>
+    Reconstructor(int mode, int size, int N, int pf, const Sym* sym, double a = 1.9, double alpha = 15)
+        : _plan(nullptr), _F(nullptr), _T(nullptr), _iCol(nullptr), _iRow(nullptr)
+    {
+        defaults();
+        init(mode, size, N, pf, sym, a, alpha);
+    }
+    template <class Sym, class = decltype(std::declval<const Sym&>().nSymmetryElement())>
+    void init(int mode, int size, int N, int pf, const Sym* sym, double a = 1.9, double alpha = 15)
+    {
+        init(mode, size, N, pf, (const double*)nullptr, 0, (float)a, (float)alpha);
+        setSymmetry(sym);
+    }
+    // setSymmetry(const Symmetry* sym), include/Reconstructor.h:438
+    template <class Sym, class = decltype(std::declval<const Sym&>().nSymmetryElement())>
+    void setSymmetry(const Sym* sym)
+    {
+        _sym.clear();
+        if (!sym) return;
+        typedef decltype(mat_of_(&Sym::get)) M;              // the reference's dmat33 (Eigen, column-major .data())
+        static_assert(sizeof(M) == 9 * sizeof(double), "Symmetry::get must hand out 3 x 3 matrices of doubles");
+        for (int i = 0; i < sym->nSymmetryElement(); i++) {
+            M L, R;
+            sym->get(L, R, i);                               // SYMMETRIZE_FT transforms with R (include/Geometry/Transformation.h:170-194)
+            const double* d = R.data();
+            _sym.insert(_sym.end(), d, d + 9);
+        }
+    }
+    // setFSC(const vec& FSC), include/Reconstructor.h:443: any vector type with size() and operator()(i) (Eigen's vec)
+    template <class V, class = decltype(std::declval<const V&>()(0)), class = decltype(std::declval<const V&>().size())>
+    void setFSC(const V& fsc)
+    {
+        _FSC.resize((size_t)fsc.size());
+        for (size_t i = 0; i < _FSC.size(); i++) _FSC[i] = (float)fsc((int)i);
+    }
+    // Parallel::setMPIEnv(commSize, commRank, hemi, slav), include/Parallel.h:164-168, src/Parallel.cpp:38-57: what the mirror keeps of
+    // it is WHO THE PROCESS IS -- rank 0 is the master (MASTER_ID, include/Parallel.h:42), and `IF_MASTER return;` opens prepareTF,
+    // prepareO and reconstruct (src/Reconstructor.cpp:1058,1106,1132).  The communicators themselves are MPI's: the sums over the
+    // hemisphere go through setAllReduce / setHemisphereComm.  Without the call the object is a hemisphere lead on its own (rank 1).
+    template <class Comm>
+    void setMPIEnv(int commSize, int commRank, const Comm& /*hemi*/, const Comm& /*slav*/) { _commSize = commSize; _commRank = commRank; }
+    void setMPIEnv(int commSize, int commRank) { _commSize = commSize; _commRank = commRank; }
+    bool isMaster() const { return _commRank == 0; }
+    int commSize() const { return _commSize; }
+    int commRank() const { return _commRank; }
+
     ~Reconstructor() { freeSpace(); }
     Reconstructor(const Reconstructor&) = delete;
     Reconstructor& operator=(const Reconstructor&) = delete;
@@ -63,7 +112,9 @@ public:
         if (_iCol) thx_free_dev(_iCol);
         if (_iRow) thx_free_dev(_iRow);
         for (int i = 0; i < kStage; i++) { if (_stage[i]) thx_free_dev(_stage[i]); _stage[i] = nullptr; _stageCap[i] = 0; }
-        _plan = nullptr; _F = _T = nullptr; _iCol = _iRow = nullptr;
+        if (_symF) thx_free_dev(_symF);
+        if (_symT) thx_free_dev(_symT);
+        _plan = nullptr; _F = _T = nullptr; _iCol = _iRow = nullptr; _symF = _symT = nullptr;
     }
     void resizeSpace(int size) { _size = size; }   // src/Reconstructor.cpp:162-176 (allocSpace must follow)
     // reset(nThread), src/Reconstructor.cpp:178-250
@@ -186,6 +237,16 @@ public:
         insert(srcFT, ctfFT, N, static_cast<const double*>(rot.data()), w);
     }
 
+    // insert(const Image& src, const Image& ctf, const dmat33& rot, const RFLOAT w) UNDER ITS OWN NAME (include/Reconstructor.h:561-566;
+    // `recon.insert(img, ctf, rot, 1)`, appsrc/thunder_reconstruct.cpp:262): any image type with nColRL() and operator[] onto its
+    // Fourier half (include/Image/ImageBase.h), any 3 x 3 matrix of doubles with .data()
+    // (the reference's ImageBase offers `const Complex* dataFT() const`, include/Image/ImageBase.h:265: read through it)
+    template <class I, class M, class = decltype(std::declval<const I&>().dataFT()), class = decltype(std::declval<const M&>().data())>
+    void insert(const I& src, const I& ctf, const M& rot, float w)
+    {
+        insert(src.dataFT(), ctf.dataFT(), (int)src.nColRL(), rot, w);
+    }
+
     // nImg images x mReco draws in one launch (InsertFT): datP [nImg][nPxl] untranslated rows, rot [nImg][mReco][9],
     // tran [nImg][mReco][2] (the image is shifted by -tran on the device), w [nImg] (already divided by mReco).
     // Staging: grow-only device buffers owned by the object (no hipMalloc / hipFree and no device-wide synchronisation per call:
@@ -210,23 +271,27 @@ public:
     {
         if (!_F || !_iCol) { std::fprintf(stderr, "thunder_amd FATAL: allocSpace/setPreCal not called\n"); std::abort(); }
         const size_t nd_ = (size_t)imgNum * mReco;
-        void *dDat, *dCtf, *dW, *dQ, *dRot, *dTran, *dOff = nullptr, *dAttr = nullptr, *dDf = nullptr, *dO, *dCnt;
-        auto up = [](void** d, const void* h, size_t bytes) {
-            THX_ABORT_ON(thx_malloc_dev(d, bytes));
-            THX_ABORT_ON(thx_memcpy_h2d(*d, h, bytes));
+        // staging: the object's grow-only device buffers (no hipMalloc / hipFree per call -- round-5 review: eleven of each before);
+        // calls from several host threads are serialised on them
+        std::lock_guard<std::mutex> g(_stageMtx);
+        auto up = [&](int slot, const void* h, size_t bytes) -> void* {
+            void* d = stage(slot, bytes);
+            THX_ABORT_ON(thx_memcpy_h2d(d, h, bytes));
+            return d;
         };
-        up(&dDat, datP, (size_t)imgNum * _nPxl * 2 * sizeof(float));
-        up(&dCtf, ctfP, (size_t)imgNum * _nPxl * sizeof(float));
-        up(&dW, w, imgNum * sizeof(float));
-        up(&dQ, nr, nd_ * 4 * sizeof(double));
-        up(&dTran, nt, nd_ * 2 * sizeof(double));
-        if (offS) up(&dOff, offS, (size_t)imgNum * 2 * sizeof(double));
-        if (cSearch) { up(&dAttr, ctfaData, imgNum * sizeof(thx_ctf_attr)); up(&dDf, nd, nd_ * sizeof(double)); }
-        THX_ABORT_ON(thx_malloc_dev(&dRot, nd_ * 9 * sizeof(double)));
-        THX_ABORT_ON(thx_malloc_dev(&dO, 3 * sizeof(double)));
-        THX_ABORT_ON(thx_malloc_dev(&dCnt, sizeof(int)));
-        THX_ABORT_ON(thx_memset_dev(dO, 0, 3 * sizeof(double)));
-        THX_ABORT_ON(thx_memset_dev(dCnt, 0, sizeof(int)));
+        void* dDat = up(0, datP, (size_t)imgNum * _nPxl * 2 * sizeof(float));
+        void* dCtf = up(1, ctfP, (size_t)imgNum * _nPxl * sizeof(float));
+        void* dW = up(2, w, imgNum * sizeof(float));
+        void* dRot = stage(3, nd_ * 9 * sizeof(double));
+        void* dTran = up(4, nt, nd_ * 2 * sizeof(double));
+        void* dQ = up(6, nr, nd_ * 4 * sizeof(double));
+        void* dOff = offS ? up(7, offS, (size_t)imgNum * 2 * sizeof(double)) : nullptr;
+        void* dAttr = cSearch ? up(8, ctfaData, imgNum * sizeof(thx_ctf_attr)) : nullptr;
+        void* dDf = cSearch ? up(9, nd, nd_ * sizeof(double)) : nullptr;
+        char* dSmall = (char*)stage(10, 3 * sizeof(double) + sizeof(int));
+        void* dO = dSmall;
+        void* dCnt = dSmall + 3 * sizeof(double);
+        THX_ABORT_ON(thx_memset_dev(dSmall, 0, 3 * sizeof(double) + sizeof(int)));
         THX_ABORT_ON(thx_rotmat_dev((const double*)dQ, (double*)dRot, (int)nd_, nullptr));
         THX_ABORT_ON(thx_insert_dev(_F, _T, (double*)dO, (int*)dCnt, _pf * _size, 1, (const float*)dDat, (const float*)dCtf,
                                     (const float*)dW, (const double*)dRot, (const double*)dTran, (const double*)dOff, nullptr,
@@ -237,10 +302,9 @@ public:
         THX_ABORT_ON(thx_memcpy_d2h(o, dO, sizeof(o)));
         THX_ABORT_ON(thx_memcpy_d2h(&c, dCnt, sizeof(int)));
         {
-            std::lock_guard<std::mutex> g(_mtx);
+            std::lock_guard<std::mutex> g2(_mtx);
             _ox += o[0]; _oy += o[1]; _oz += o[2]; _counter += c;
         }
-        for (void* q : {dDat, dCtf, dW, dQ, dRot, dTran, dOff, dAttr, dDf, dO, dCnt}) if (q) thx_free_dev(q);
     }
     void insertI(const Complex* datP, const float* ctfP, const float* sigP, const float* w, const double* offS,
                  const double* nr, const double* nt, const double* nd, const thx_ctf_attr* ctfaData, float pixelSize,
@@ -262,6 +326,7 @@ public:
     // allReduceF, symmetrizeF
     void prepareTF(unsigned int /*nThread*/ = 1)
     {
+        if (isMaster()) return;   // IF_MASTER return; src/Reconstructor.cpp:1058
         const int dim = _pf * _size;
         // insert / insertP / insertBatch leave their kernels queued (no device-wide wait per call): everything inserted so far must
         // have landed in F / T before a caller-side all-reduce callback, a GPU-aware MPI or another stream reads them
@@ -292,11 +357,12 @@ public:
     }
 
     // prepareO(), src/Reconstructor.cpp:1104-1127 (symmetry sweep of O omitted: C1 or caller-side)
-    void prepareO() { if (_counter) { _ox /= _counter; _oy /= _counter; _oz /= _counter; } }
+    void prepareO() { if (isMaster()) return; if (_counter) { _ox /= _counter; _oy /= _counter; _oz /= _counter; } }   // IF_MASTER return; :1106
 
     // reconstruct(Volume& dst, nThread), src/Reconstructor.cpp:1129-1831 -> dst [N][N][N] real, host
     void reconstruct(float* dstRL, unsigned int /*nThread*/ = 1)
     {
+        if (isMaster()) return;   // IF_MASTER return; src/Reconstructor.cpp:1132
         void* d = nullptr;
         THX_ABORT_ON(thx_malloc_dev(&d, (size_t)_N * _N * _N * sizeof(float)));
         THX_ABORT_ON(thx_reco_reconstruct_dev(_plan, _F, _T, _maxRadius, _FSC.empty() ? nullptr : _FSC.data(),
@@ -312,6 +378,7 @@ public:
     template <class V, class = decltype(std::declval<V&>().alloc(0L, 0L, 0L, 0))>
     void reconstruct(V& dst, unsigned int nThread = 1)
     {
+        if (isMaster()) return;   // (the reference's master returns before dst is touched)
         dst.alloc((long)_N, (long)_N, (long)_N, 0 /* RL_SPACE, include/Image/ImageBase.h:48 */);
         static_assert(sizeof(dst(0)) == sizeof(float), "the volume must be single precision (RFLOAT = float)");
         reconstruct(reinterpret_cast<float*>(&dst(0)), nThread);
@@ -324,7 +391,7 @@ public:
     }
 
 private:
-    enum { kStage = 6 };
+    enum { kStage = 11 };
     void* stage(int slot, size_t bytes)   // (under _stageMtx)
     {
         if (bytes > _stageCap[slot]) {
@@ -359,18 +426,23 @@ private:
         _size = _N = 0; _pf = 2; _a = 1.9f; _alpha = 15.0f; _maxRadius = 0; _nPxl = 0;
         _MAP = true; _gridCorr = true; _joinHalf = false; _ox = _oy = _oz = 0; _counter = 0;
     }
+    // SYMMETRIZE_FT into the object's second volume of the kind, then the two trade places: no allocation per call (round-5 review)
     void symm(float*& vol, size_t nFloats, int isComplex, double r)
     {
-        void* tmp = nullptr;
-        THX_ABORT_ON(thx_malloc_dev(&tmp, nFloats * sizeof(float)));
-        THX_ABORT_ON(thx_symmetrize_dev((float*)tmp, vol, _pf * _size, isComplex, _sym.data(), (int)(_sym.size() / 9), r,
-                                        nullptr));
-        THX_ABORT_ON(thx_device_sync());
-        thx_free_dev(vol);
-        vol = (float*)tmp;
+        float*& other = isComplex ? _symF : _symT;
+        if (!other) {
+            void* tmp = nullptr;
+            THX_ABORT_ON(thx_malloc_dev(&tmp, nFloats * sizeof(float)));
+            other = (float*)tmp;
+        }
+        THX_ABORT_ON(thx_symmetrize_dev(other, vol, _pf * _size, isComplex, _sym.data(), (int)(_sym.size() / 9), r, nullptr));
+        float* t = vol; vol = other; other = t;
     }
+    template <class S, class M> static M mat_of_(void (S::*)(M&, M&, int) const);
     thx_reco* _plan;
     float *_F, *_T;
+    float *_symF = nullptr, *_symT = nullptr;
+    int _commSize = 1, _commRank = 1;
     int *_iCol, *_iRow;
     int _size, _N, _pf, _maxRadius, _nPxl, _counter;
     float _a, _alpha;
@@ -381,8 +453,8 @@ private:
     AllReduce _allreduce;
     thx_comm* _hemi = nullptr;
     std::mutex _mtx, _stageMtx;
-    void* _stage[kStage] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t _stageCap[kStage] = {0, 0, 0, 0, 0, 0};
+    void* _stage[kStage] = {};
+    size_t _stageCap[kStage] = {};
 };
 
 }  // namespace thunder_amd

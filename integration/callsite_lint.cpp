@@ -33,3 +33,44 @@ void callsites_b(thunder_amd::Projector& proj, thunder_amd::Reconstructor& reco,
     reco.reconstruct(ref, nThread);                       // _model.reco(t).reconstruct(ref, _para.nThreadsPerProcess)
     reco.reconstructG(ref, gpu, 1);                       // _model.reco(t).reconstructG(ref, gpus[omp_get_thread_num()], 1)
 }
+
+// Round 6: the reference's OWN constructor and setters on the class mirrors, and the call lines of the two standalone applications
+// verbatim -- appsrc/thunder_reconstruct.cpp:194-284 and appsrc/thunder_project.cpp:146-236 -- with the reference's Symmetry, Image,
+// Volume, vec, dmat33 and MPI_Comm from its unchanged headers.  (`recon.setMPIEnv()` without arguments reads MPI_COMM_WORLD inside
+// Parallel, src/Parallel.cpp:26-36: a caller of the mirror states its rank with the four-argument form, as Model does for its
+// reconstructors, src/Model.cpp:1060-1100.)
+#include "Symmetry.h"
+#include "Image.h"
+#include <mpi.h>
+
+void callsites_apps(const char* symmetry, int boxsize, int maxRadius, unsigned int nThread, Image& img, Image& ctf, dmat33& rot, Volume& tarVol,
+                    Volume& ref, int commSize, int commRank, MPI_Comm hemi, MPI_Comm slav, const vec& FSC, const mat& fscMat, int l)
+{
+    Symmetry sym(symmetry);
+    thunder_amd::Reconstructor recon(MODE_3D, boxsize, boxsize, 2, &sym, 1.9, 15);      // Reconstructor recon(MODE_3D, boxsize, boxsize, 2, &sym, 1.9, 15), appsrc/thunder_reconstruct.cpp:194
+    recon.setMPIEnv(commSize, commRank, hemi, slav);                                    // _reco[l]->setMPIEnv(_commSize, _commRank, _hemi, _slav), src/Model.cpp:78
+    recon.allocSpace(nThread);                                                          // :198
+    recon.setMaxRadius(maxRadius);                                                      // :200
+    recon.insert(img, ctf, rot, 1);                                                     // recon.insert(img, ctf, rot, 1), :262
+    recon.prepareTF(nThread);                                                           // :271
+    recon.setMAP(false);                                                                // :277
+    recon.reconstruct(tarVol, nThread);                                                 // :279
+    recon.freeSpace();                                                                  // :303
+    // Model::initProjReco / refreshReco / resetReco, src/Model.cpp:1060-1125
+    thunder_amd::Reconstructor reco;
+    reco.init(MODE_3D, boxsize, boxsize, 2, &sym, 1.9, 15);                             // _reco[l]->init(_mode, _size, _size, _pf, _sym, _a, _alpha), :1062-1068
+    reco.setSymmetry(&sym);                                                             // include/Reconstructor.h:438
+    reco.resizeSpace((maxRadius + 2) * 2);                                              // _reco[l]->resizeSpace((_rU + CEIL(_a)) * 2), :1077
+    reco.setFSC(vec::Constant(maxRadius, 1));                                           // _reco[l]->setFSC(vec::Constant(_rU, 1)), :1086
+    reco.setFSC(FSC);
+    reco.setFSC(fscMat.col(l));                                                         // _reco[l]->setFSC(_FSC.col(l)), :1122
+    reco.setMaxRadius(maxRadius);                                                       // :1096,1124
+    reco.prepareO();
+    // appsrc/thunder_project.cpp:186-207
+    int N = ref.nColRL();
+    thunder_amd::Projector proj;
+    proj.setProjectee(ref.copyVolume(), nThread);                                       // proj.setProjectee(ref.copyVolume(), nThread), :188
+    Image pimg(N, N, FT_SPACE);
+    proj.project(pimg, rot, nThread);                                                   // proj.project(img, mat, nThread), :207
+    (void)N;
+}
