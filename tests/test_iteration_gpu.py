@@ -57,7 +57,7 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / np.abs(b).max())
 
 
-def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, search="local", thin=False, cutoff=None):
+def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, search="local", thin=False, cutoff=None, well_covered=False):
     c = inp["cfg"]
     N, n, K = c["N"], c["nImg"], c["nK"]
     if cutoff is not None:     # the frequency cut-offs of this iteration (Optimiser::_r, Model::_rU): per-iteration inputs of both sides
@@ -204,6 +204,15 @@ def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, s
     # (a loop that ran into MAX_N_ITER_BALANCE = 30 was still moving when it was cut off: same amplification of rounding noise as a
     # stop in different rounds)
     loose = (not same_rounds) or ("norm" in out) or bool(np.any(dev_rounds == 30))
+    chain_bar = 5e-3
+    if well_covered:
+        # the well-covered case (round-5 review #4): thousands of particles per half, so that the balancing loop converges instead of
+        # jittering -- normCorrection on is no longer a reason for the loose bars; where both stop rules fire in the same round the maps
+        # are held to 1e-3 of max and FSC >= 0.999 on every shell against the oracle's OWN chain
+        # (with 1 000 images per half the loop still runs into MAX_N_ITER_BALANCE = 30 on both sides -- the oracle alone does: it is
+        # cut off, not stopped by its rule -- so "the same round" is round 30 here, and a cut-off loop is held to the tight bars too)
+        loose = not same_rounds
+        chain_bar = 1e-3
     # STAGE RULE for the reconstructions.  The balancing loop of a thinly covered volume is ill-conditioned: W = 1 / (T * kernel)
     # runs away where T is 1e-6 of its maximum, so the 1 - 3e-6-of-max difference between the device's and the oracle's F / T
     # (above) -- of the order of T itself on the rim -- comes out as up to 7e-2 of the map's maximum with 48 images in a class and
@@ -229,11 +238,11 @@ def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, s
                 inner = f[:max(2, (3 * len(f)) // 5)]
                 if ond is None:    # (a capture without F / T after prepareTF: the bars of round 3)
                     print("%s: half %d class %d %s map %.2e of max, min FSC %.6f" % (label, h, k, name, e, f.min()))
-                    assert e <= (1e-1 if loose else 5e-3) and f.min() >= (0.5 if loose else 0.999) and inner.min() >= (0.95 if loose else 0.999)
+                    assert e <= (1e-1 if loose else chain_bar) and f.min() >= (0.5 if loose else 0.999) and inner.min() >= (0.95 if loose else 0.999)
                     continue
                 rows.append((h, k, name, key, _rel(dv, ond[key][h][k]), e, float(f.min()), float(inner.min())))
     # (the noise run only if some comparison is outside the bars that need no knowledge of the volume's conditioning)
-    tight = lambda r: r[4] <= 1e-3 and r[5] <= (1e-1 if loose else 5e-3) and r[6] >= (0.5 if loose else 0.999) and r[7] >= (0.95 if loose else 0.999)
+    tight = lambda r: r[4] <= 1e-3 and r[5] <= (1e-1 if loose else chain_bar) and r[6] >= (0.5 if loose else 0.999) and r[7] >= (0.95 if loose else 0.999)
     if rows and not all(tight(r) for r in rows):
         onn = out["onDeviceNoise"]()
     for h, k, name, key, e_same, e, fmin, fin in rows:
@@ -241,7 +250,8 @@ def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, s
         sens[h, k] = max(sens[h, k], s_)
         print("%s: half %d class %d %s map: %.2e of max from the oracle's reconstruction of the device's F / T, %.2e from the oracle's chain "
               "(min FSC %.6f, inner shells %.6f)%s" % (label, h, k, name, e_same, e, fmin, fin, "; the oracle under 1e-6 input noise %.2e" % s_ if onn is not None else ""))
-        ok = e_same <= max(1e-3, 30 * s_) and e <= max(1e-1 if loose else 5e-3, 30 * s_)
+        ok = e_same <= max(1e-3, 30 * s_) and e <= max(1e-1 if loose else chain_bar, 30 * s_)
+        out.setdefault("map_rows", []).append(dict(half=h, k=k, which=name, same_input=e_same, chain=e, sens=s_, fsc_min=fmin, fsc_inner=fin, loose=loose))
         if 10 * s_ <= 5e-3:
             ok = ok and fmin >= (0.5 if loose else 0.999) and fin >= (0.95 if loose else 0.999)
         if not ok:
@@ -289,7 +299,7 @@ def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, s
 
 
 def _run_chain(O, dev, inp, label, max_degenerate, max_adopted, searches=("local", "local"), scan_batch=0, sym_capture=True, thin=False,
-               cutoffs=None):
+               cutoffs=None, well_covered=False):
     c = inp["cfg"]
     N, n, K = c["N"], c["nImg"], c["nK"]
     it = U.oracle_chain(O, inp)
@@ -321,7 +331,7 @@ def _run_chain(O, dev, inp, label, max_degenerate, max_adopted, searches=("local
     outs = []
     for i, search in enumerate(searches):
         outs.append(_check_iteration(O, nat, it, cap, inp, "%s iteration %d (%s)" % (label, i + 1, search), max_degenerate, max_adopted, search, thin,
-                                     cutoff=None if cutoffs is None else cutoffs[i]))
+                                     cutoff=None if cutoffs is None else cutoffs[i], well_covered=well_covered))
     return nat, it, outs
 
 
@@ -359,6 +369,32 @@ def test_iteration_matches_oracle_chain_with_norm_correction(oracle, dev):
     for h in (0, 1):
         f = U.fsc_curve(O, outs[2]["maps"][h][0], inp["ref"], N, 6)
         assert np.all(f[1:4] > 0.9), f
+    nat.close()
+
+
+def test_iteration_well_covered_at_tight_bars(oracle, dev):
+    """One WELL-COVERED end-to-end case (round-5 review #4): N = 64, 2 000 particles (1 000 per half x 20 draws), K = 1,
+    Optimiser::normCorrection ON with per-image amplitude factors in the data -- the configuration bench.py times --, three iterations,
+    the oracle's chain on 8 threads.  With this coverage the balancing loop of Reconstructor::reconstruct converges, the two stop rules
+    fire in the same round, and the final maps are held to the oracle's OWN chain at 1e-3 of max and FSC >= 0.999 on every shell
+    (SURVEY 8c(9) asks 1e-4 for the reconstruction stage on identical inputs: that is `same_input` here, measured ~1e-6); an iteration
+    whose rounds differ is reported with the sensitivity that explains it and falls back to the loose bars."""
+    O = oracle
+    N, n = 64, 2000
+    inp = U.make_inputs(O, N, n, seed=2064, mReco=20, batch=512, snr=0.2, norm_correction=1, amp_spread=0.15)
+    nat, it, outs = _run_chain(O, dev, inp, "well covered N=%d n=%d" % (N, n), 0.05, 0.35, searches=("local", "local", "local"), well_covered=True)
+    assert "norm" not in outs[0] and "norm" in outs[1] and "norm" in outs[2]
+    rows = [r for o in outs for r in o.get("map_rows", [])]
+    print("well-covered chain: %d maps; chain error max %.2e, same-input error max %.2e, min FSC %.6f; tight-bar maps %d"
+          % (len(rows), max(r["chain"] for r in rows), max(r["same_input"] for r in rows), min(r["fsc_min"] for r in rows),
+             sum(1 for r in rows if not r["loose"])))
+    assert len(rows) == 12
+    # at least the first two iterations' maps sit in the tight regime (same rounds on both sides); all of them within the bars asserted
+    # inside the checker
+    assert sum(1 for r in rows if not r["loose"]) >= 8
+    for h in (0, 1):
+        f = U.fsc_curve(O, outs[2]["maps"][h][0], inp["ref"], N, 12)
+        assert np.all(f[1:10] > 0.95), f
     nat.close()
 
 
