@@ -515,7 +515,7 @@ def bench_staged(args, dev):
     class HArgs(C.Structure):
         _fields_ = [(k, C.c_int) for k in ("gpu", "N", "pf", "nPxl", "nImg", "mLR", "mLT", "phases", "threads", "lock")] + \
                    [(k, C.c_void_p) for k in ("volume", "iCol", "iRow", "datP", "ctfP", "sigP", "quat", "tran", "attr", "wR", "wT")] + \
-                   [("seconds", C.c_double)]
+                   [("seconds", C.c_double), ("callSeconds", C.c_double * 4)]
     H = C.CDLL(_b.build_harness())
     H.thx_harness_expectation_local.restype = C.c_int
     wR_out = np.zeros((n, nR), np.float32)
@@ -527,13 +527,17 @@ def bench_staged(args, dev):
         rc = H.thx_harness_expectation_local(C.byref(a))
         if rc:
             raise RuntimeError("staged local search failed: %s" % capi.load().thx_last_error().decode(errors="replace"))
+        calls.append([1e6 * x / (int(images) * args.phases) for x in a.callSeconds])
         return a.seconds
+    calls = []
     run_e(min(n, 4 * threads), threads, 0)                           # untimed: first touch
-    sweep = {}
+    sweep, call_us = {}, {}
     for lock, ths in ((1, sorted({1, threads})), (0, sorted({threads, 4 * threads, 16 * threads}))):
         for th in ths:
             dt_ = run_e(n, th, lock)
-            sweep["%s, %d threads" % ("per-GPU lock as in Optimiser.cpp" if lock else "no lock", th)] = 1e6 * dt_ / (n * args.phases)
+            key = "%s, %d threads" % ("per-GPU lock as in Optimiser.cpp" if lock else "no lock", th)
+            sweep[key] = 1e6 * dt_ / (n * args.phases)
+            call_us[key] = dict(zip(("ExpectLocalP", "ExpectLocalRTD", "ExpectLocalPreI3D", "ExpectLocalM"), [round(x, 1) for x in calls[-1]]))
     t_e_locked = min(v_ for k_, v_ in sweep.items() if k_.startswith("per-GPU")) * 1e-6 * n * args.phases
     t_e_free = min(v_ for k_, v_ in sweep.items() if k_.startswith("no lock")) * 1e-6 * n * args.phases
     assert np.all(np.isfinite(wR_out)) and wR_out.max() > 0
@@ -592,6 +596,7 @@ def bench_staged(args, dev):
                                    "makes it), ReconstructG on host volumes x 4" % (n, total, N, args.phases, nR, nT, mReco),
                        "driver": "the thx_*_host twins of gpu/interface/Interface.h, as an unchanged Optimiser.cpp calls them"},
             "e_step_us_per_image_phase": 1e6 * t_e_locked / (n * args.phases), "e_step_us_per_image_phase_sweep": {k_: round(v_, 1) for k_, v_ in sweep.items()},
+            "e_step_host_us_inside_each_call_per_image_phase": call_us,
             "e_step_images_per_s": n / t_e_locked, "e_step_images_per_s_without_the_lock": n / t_e_free,
             "insert_us_per_image": 1e6 * ins_per_image, "insert_fixed_s_per_call": ins_fixed, "insert_sample_call_s": t_i, "reconstructG_s": t_r,
             "seconds_per_iteration_scaled": t_iter, "roofline": None, "cpu_baseline": None,

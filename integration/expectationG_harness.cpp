@@ -31,6 +31,7 @@ struct thx_harness_args {
     float* wR;                    // host out [nImg][mLR]: the rotation weights of the LAST phase (for checks); may be NULL
     float* wT;                    // host out [nImg][mLT]; may be NULL
     double seconds;               // out: wall time of the parallel loop (setup / teardown excluded)
+    double callSeconds[4];        // out: host time inside ExpectLocalP / RTD / PreI3D / M, summed over the threads
 };
 
 #define H_RC(expr) do { int _rc = (expr); if (_rc) { std::fprintf(stderr, "harness: %s failed: %s\n", #expr, thx_last_error()); return _rc; } } while (0)
@@ -58,23 +59,36 @@ int thx_harness_expectation_local(thx_harness_args* a)
     omp_lock_t mtx;
     omp_init_lock(&mtx);
     int err = 0;
+    double acc[4] = {0, 0, 0, 0};
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     const auto t0 = std::chrono::steady_clock::now();
 #pragma omp parallel for num_threads(T) schedule(dynamic)
     for (int l = 0; l < a->nImg; l++) {
         if (err) continue;
         const int t = omp_get_thread_num();
         Ctx& c = ctx[t];
+        double loc[4] = {0, 0, 0, 0};
+        auto c0 = now();
         int rc = thx_ExpectLocalP_host(a->gpu, devdatP, devctfP, devdefO, devsigP, a->datP, a->ctfP, nullptr, a->sigP, t, l, nPxl, 0);
+        loc[0] += secs(c0, now());
         for (int ph = 0; ph < a->phases && !rc; ph++) {
             std::memcpy(c.trans, a->tran + (size_t)l * nT * 2, (size_t)nT * 2 * sizeof(double));
             std::memcpy(c.rot, a->quat + (size_t)l * nR * 4, (size_t)nR * 4 * sizeof(double));
             if (a->lock) omp_set_lock(&mtx);
+            auto c1 = now();
             rc = thx_ExpectLocalRTD_host(a->gpu, c.mcp, c.oldR, c.oldT, c.oldD, c.trans, c.rot, c.dpara);
+            auto c2 = now();
             if (!rc) rc = thx_ExpectLocalPreI3D_host(a->gpu, t, mgr, c.mcp, devdefO, devfreQ, deviCol, deviRow, a->attr[(size_t)l * 7 + 6],
                                                      a->attr[(size_t)l * 7 + 5], 0.f, 0.f, a->pf, a->N, P, nPxl, 1);
+            auto c3 = now();
             if (!rc) rc = thx_ExpectLocalM_host(a->gpu, t, c.mcp, devdatP, devctfP, devsigP, c.wC, c.wR, c.wT, c.wD, 1.0, nPxl);
+            auto c4 = now();
+            loc[1] += secs(c1, c2); loc[2] += secs(c2, c3); loc[3] += secs(c3, c4);
             if (a->lock) omp_unset_lock(&mtx);
         }
+#pragma omp critical(thx_harness_acc)
+        { for (int q = 0; q < 4; q++) acc[q] += loc[q]; }
         if (!rc) {
             if (a->wR) std::memcpy(a->wR + (size_t)l * nR, c.wR, nR * sizeof(float));
             if (a->wT) std::memcpy(a->wT + (size_t)l * nT, c.wT, nT * sizeof(float));
@@ -84,6 +98,7 @@ int thx_harness_expectation_local(thx_harness_args* a)
         }
     }
     a->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int q = 0; q < 4; q++) a->callSeconds[q] = acc[q];
     omp_destroy_lock(&mtx);
     for (int t = 0; t < T; t++) {
         Ctx& c = ctx[t];

@@ -247,7 +247,7 @@ def test_staged_no_gridcorr_weights(oracle, dev):
 class _HArgs(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("gpu", "N", "pf", "nPxl", "nImg", "mLR", "mLT", "phases", "threads", "lock")] + \
                [(k, C.c_void_p) for k in ("volume", "iCol", "iRow", "datP", "ctfP", "sigP", "quat", "tran", "attr", "wR", "wT")] + \
-               [("seconds", C.c_double)]
+               [("seconds", C.c_double), ("callSeconds", C.c_double * 4)]
 
 
 @pytest.mark.parametrize("N,nImg,nR", [(32, 24, 20), (64, 12, 125)])

@@ -375,6 +375,8 @@ struct ExpectLocalArgs {
     const int* active;   // [nImg] or NULL: images with active[img] == 0 are skipped (outputs untouched)
     const unsigned char* order;   // [nImg][nR] or NULL: lane slot s of an image works on rotation order[s] (k_cloud_order)
     float splitM;        // SPLIT form: half-thickness (voxels) of the slab around the wave's mean slice whose samples are fetched ahead
+    int fine;            // != 0: the nSplit workgroups of an image share its pixels in nSplit near-equal PIXEL ranges (the one-image form: a
+                         // range may be a fraction of a 256-pixel chunk); 0: in whole chunks (the batched form)
 };
 
 template <int NT, bool PACKED, bool SPLIT = false>
@@ -410,6 +412,9 @@ __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
     // this block's pixel range (whole chunks)
     const int nChunks = (a.nPxl + kChunk - 1) / kChunk;
     const int c0 = (int)(((long)nChunks * split) / a.nSplit), c1 = (int)(((long)nChunks * (split + 1)) / a.nSplit);
+    // [p0, p1): whole chunks (the batched form), or -- fine -- the split's share of the pixels themselves
+    const int p0 = a.fine ? (int)(((long)a.nPxl * split) / a.nSplit) : c0 * kChunk;
+    const int p1 = a.fine ? (int)(((long)a.nPxl * (split + 1)) / a.nSplit) : min(c1 * kChunk, a.nPxl);
 
     float cpart = 0.f;
 
@@ -429,9 +434,8 @@ __global__ __launch_bounds__(256) void k_expect_local(ExpectLocalArgs a)
 #pragma unroll
         for (int i = 0; i < (NT + 1) / 2; i++) accP[i] = thx_v2f{0.f, 0.f};
 
-        for (int c = c0; c < c1; c++) {
-            const int pbase = c * kChunk;
-            const int clen = min(kChunk, a.nPxl - pbase);
+        for (int pbase = p0; pbase < p1; pbase += kChunk) {
+            const int clen = min(kChunk, p1 - pbase);
             __syncthreads();  // previous chunk's readers are done
             // ---- stage the per-pixel table ----
             for (int e = tid; e < clen; e += 256) {
@@ -723,6 +727,39 @@ __global__ __launch_bounds__(256) void k_expect_local_nd(ExpectLocalArgs a)
     if (tid == 0) {
         const float cs = (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
         for (int d = 0; d < a.nD; d++) a.partC[((size_t)img * a.nD + d) * a.nSplit + split] = cs;
+    }
+}
+
+// The one-image form leaves hundreds of partial sums per (shift, rotation): added up here in a FIXED order before the finalise
+// kernel -- lane <-> element, the four waves of a workgroup take a quarter of the splits each (loads issued eight at a time), wave 0
+// adds the four quarter sums; the result overwrites split 0.  grid (ceil(nT nRpad / 64)), block 256.  partC likewise (workgroup 0).
+__global__ __launch_bounds__(256) void k_expect_reduce(float* __restrict__ partV, float* __restrict__ partC, int nSplit, int nElem)
+{
+    __shared__ float sq[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const int s0 = (int)(((long)nSplit * wave) / 4), s1 = (int)(((long)nSplit * (wave + 1)) / 4);
+    float v = 0.f;
+    if (e < nElem) {
+        for (int s = s0; s < s1; s += 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) x[u] = (s + u < s1) ? partV[(size_t)(s + u) * nElem + e] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; u++) v += x[u];
+        }
+    }
+    sq[wave][lane] = v;
+    __syncthreads();
+    if (wave == 0 && e < nElem) partV[e] = ((sq[0][lane] + sq[1][lane]) + sq[2][lane]) + sq[3][lane];
+    if (blockIdx.x == 0) {   // (partV's writers above touch other memory: no hazard; every reader of partC is this workgroup)
+        float c = 0.f;
+        for (int s = threadIdx.x; s < nSplit; s += 256) c += partC[s];
+        c = wave_sum(c);
+        __syncthreads();
+        if (lane == 0) sq[0][wave] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) partC[0] = (sq[0][0] + sq[0][1]) + (sq[0][2] + sq[0][3]);
     }
 }
 
@@ -1518,7 +1555,7 @@ static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, 
                              const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
                              const double* pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR,
                              float* wT, float* wD, float* baseLine, float* logW, void* workspace, int wgPerCU, const int* active, void* stream,
-                             bool packed, int nSplitForce = 0, bool noOrder = false, double pCval = 1.0)
+                             bool packed, int nSplitForce = 0, bool noOrder = false, double pCval = 1.0, bool fine = false)
 {
     if (nImg <= 0) return 0;
     THX_REQUIRE(volumes && iCol && iRow && datP && ctfP && sigRcpP && rotMat && trans, "NULL input pointer");
@@ -1539,6 +1576,7 @@ static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, 
     a.active = active;
     a.splitM = 0.f;
     a.order = nullptr;
+    a.fine = (fine && nD == 1) ? 1 : 0;
     if (knobs().expectOrder > 0 && nR > 64 && nR <= 256 && nD == 1 && !noOrder) {   // (one wave holds a cloud of <= 64 rotations whatever the order)
         unsigned char* ord = reinterpret_cast<unsigned char*>(scratch(st, 18, (size_t)nImg * nR));
         THX_REQUIRE(ord, "device scratch allocation failed");
@@ -1556,6 +1594,11 @@ static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, 
     else if (nT <= 16) rc = launch_expect_local<16>(a, st, packed, wgPerCU);
     else rc = launch_expect_local<32>(a, st, packed, wgPerCU);
     if (rc) return rc;
+    if (a.fine && a.nSplit > 1) {   // (one image, nD = 1: [nSplit][nT][nRpad] partial sums -> split 0)
+        const int nElem = nT * a.nRpad;
+        hipLaunchKernelGGL(k_expect_reduce, dim3((nElem + 63) / 64), dim3(256), 0, st, a.partV, a.partC, a.nSplit, nElem);
+        f.nSplit = 1;
+    }
     f.nR = nR; f.nRpad = a.nRpad; f.nT = nT; f.nD = nD;
     f.pC = pC; f.pCval = pCval; f.pR = pR; f.pT = pT; f.pD = pD; f.wC = wC; f.wR = wR; f.wT = wT; f.wD = wD; f.baseLine = baseLine;
     f.logW = logW;
@@ -1597,15 +1640,17 @@ size_t thx_projector_packed_bytes(int vdim) { return (size_t)vdim * vdim * (vdim
 // on it) and the class prior travels by value: two launches per image-phase.  Same kernels, same arithmetic; the partial sums of the
 // chunks are added in chunk order (the batched form adds them in groups: equal to rounding, tests/test_iface_gpu.py).
 namespace thx {
-static int single_nsplit(int nPxl)
+constexpr int kSinglePixelsPerWg = 64;   // the one-image form: pixels per workgroup (each of its waves then walks 16 - 32 of them)
+static int single_nsplit(int nPxl, int nD)
 {
-    const int nChunks = (nPxl + kChunk - 1) / kChunk;
     if (knobs().expectNSplit) return knobs().expectNSplit;
-    return nChunks < 1 ? 1 : (nChunks > 512 ? 512 : nChunks);
+    const int per = nD == 1 ? kSinglePixelsPerWg : kChunk;     // (the fused defocus kernel shares its pixels in whole chunks)
+    const int n = (nPxl + per - 1) / per;
+    return n < 1 ? 1 : (n > 1024 ? 1024 : n);
 }
 size_t expect_local_single_workspace(int nPxl, int nR, int nT, int nD)
 {
-    const size_t nRpad = (size_t)((nR + 63) / 64) * 64, nSplit = (size_t)single_nsplit(nPxl);
+    const size_t nRpad = (size_t)((nR + 63) / 64) * 64, nSplit = (size_t)single_nsplit(nPxl, nD);
     return ((size_t)nD * nSplit * nT * nRpad + (size_t)nD * nSplit) * sizeof(float) + 256;
 }
 int expect_local_single(const float* volOrCells, bool packed, int vdim, int pf, int idim, const int* iCol, const int* iRow, int nPxl,
@@ -1615,7 +1660,7 @@ int expect_local_single(const float* volOrCells, bool packed, int vdim, int pf, 
 {
     return expect_local_impl(volOrCells, nullptr, vdim, pf, idim, iCol, iRow, nPxl, 1, datP, ctfP, sigRcpP, rotMat, nR, trans, nT, nD,
                              nullptr, pR, pT, pD, wC, wR, wT, wD, baseLine, nullptr, workspace, 0 /* no occupancy cap: one image */, nullptr, st,
-                             packed, single_nsplit(nPxl), true, pC);
+                             packed, single_nsplit(nPxl, nD), true, pC, true);
 }
 }  // namespace thx
 
