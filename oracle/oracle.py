@@ -1247,23 +1247,6 @@ class Iteration:
                 finally:
                     self.fscReco, self.iterCount = keep
             out["onDeviceNoise"] = with_noise
-            # the chain comparison (oracle's own F / T against the device's) sees inputs that differ by an ABSOLUTE amount -- the
-            # device's fixed-point sums against float adds in another order: ~1e-6 of the largest value on EVERY voxel, i.e. per
-            # cent of the voxels on the rim of the sphere --, which relative noise does not model: here the device's F / T plus
-            # Gaussian noise whose amplitude is the measured largest difference between the two sides' volumes
-            def with_abs_noise():
-                keep = (self.fscReco, self.iterCount)
-                self.fscReco, self.iterCount = state
-                try:
-                    r2 = np.random.default_rng(20241)
-                    Fa = [[(Fd[vi][k] + (np.abs(Fd[vi][k] - out["F_sym"][vi][k]).max() / 3) * (r2.standard_normal(Fd[vi][k].shape) + 1j * r2.standard_normal(Fd[vi][k].shape))).astype(np.complex64)
-                           for k in range(K)] for vi in range(2)]
-                    Ta = [[np.where(Td[vi][k] > 0, np.maximum(Td[vi][k] + (np.abs(Td[vi][k] - Tn[vi][k]).max() / 3) * r2.standard_normal(Td[vi][k].shape), 0), 0).astype(np.float32)
-                           for k in range(K)] for vi in range(2)]
-                    return self._reconstruct_all(Fa, Ta, fr, bm)
-                finally:
-                    self.fscReco, self.iterCount = keep
-            out["onDeviceNoiseAbs"] = with_abs_noise
         out["mapsFsc"], out["mapsMAP"], fsc_, mapsX, rounds = rec["mapsFsc"], rec["mapsMAP"], rec["fsc"], rec["maps"], rec["rounds"]
         if "avgR" in rec:
             out["avgR"] = rec["avgR"]

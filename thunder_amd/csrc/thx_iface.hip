@@ -14,6 +14,10 @@
 // kernel (a workgroup per 256-pixel chunk instead of 16 per image, class prior by value: expect_local_single) + the finalise kernel,
 // fetches wC / wR / wT / wD with ONE copy and waits ONCE.  Per image-phase: 1 H2D, 2 kernels, 1 D2H, 1 synchronisation (before: 5 - 7
 // H2D, 3 kernels, 4 D2H, 2 - 3 synchronisations and 16 workgroups).  The batched thx_expect_local_dev stays the throughput form.
+#include <chrono>
+#include <map>
+#include <mutex>
+
 #include "thx_common.h"
 
 using namespace thx;
@@ -46,6 +50,41 @@ struct thx_calpoint {     // ManagedCalPoint (gpu/include/ManagedCalPoint.h): pe
     const int *iCol, *iRow;
     int pf, idim, vdim;
 };
+
+// The wait at the end of an image-phase.  hipStreamSynchronize may put the thread to sleep until an interrupt arrives (tens of
+// microseconds to wake up -- as long as the kernels it waits for); the image-phase is ~100 us of device work and the caller holds a
+// per-GPU lock over it, so the thread polls the stream for up to a millisecond first (THX_IFACE_SPIN=0: never).
+static int wait_stream(hipStream_t st)
+{
+    static const bool spin = []() { const char* e = getenv("THX_IFACE_SPIN"); return !(e && e[0] == '0'); }();
+    if (spin) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) return 0;
+            if (q != hipErrorNotReady) { set_error("stream error: %s", hipGetErrorString(q)); return (int)q; }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1)) break;
+        }
+    }
+    THX_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// copy streams of ExpectLocalP's device slots, one per (device, slot), created on first use and kept for the life of the process
+static int slot_stream(int gpu, int slot, hipStream_t* out)
+{
+    static std::mutex mtx;
+    static std::map<std::pair<int, int>, hipStream_t> streams;
+    std::lock_guard<std::mutex> g(mtx);
+    auto it = streams.find({gpu, slot});
+    if (it == streams.end()) {
+        hipStream_t st = nullptr;
+        THX_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        it = streams.emplace(std::make_pair(gpu, slot), st).first;
+    }
+    *out = it->second;
+    return 0;
+}
 
 extern "C" {
 
@@ -103,7 +142,8 @@ int thx_calpoint_create(thx_calpoint** out, int mode, int cSearch, int gpuIdx, i
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&f), nFlt * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->attr), sizeof(thx_ctf_attr));
     if (e == hipSuccess) e = hipMalloc(&c->ws, expect_local_single_workspace(npxl, nR, nT, nD));
-    if (e == hipSuccess) e = hipStreamCreate(&c->stream);
+    // (non-blocking: a copy another thread issues on the legacy default stream must not serialise the image-phases of every ManagedCalPoint)
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->hIn), nDbl * sizeof(double), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->hOut), c->nOut * sizeof(float), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->hSmall), sizeof(thx_ctf_attr) + 2 * sizeof(float), hipHostMallocDefault);
@@ -212,15 +252,20 @@ int thx_ExpectLocalP_host(int gpuIdx, float* devdatP, float* devctfP, float* dev
     THX_REQUIRE(devdatP && devsigP && datP && sigP && threadId >= 0 && imgId >= 0 && npxl > 0, "bad arguments");
     THX_CHECK(hipSetDevice(gpuIdx));
     const size_t shift = (size_t)imgId * npxl, slot = (size_t)threadId * npxl;
-    THX_CHECK(hipMemcpy(devdatP + 2 * slot, datP + 2 * shift, (size_t)npxl * 2 * sizeof(float), hipMemcpyHostToDevice));
+    // the slot's own (non-blocking) copy stream: a blocking hipMemcpy goes through the legacy default stream, which waits for -- and
+    // holds up -- every other host thread's work; the copies are complete when the call returns, as the reference's are
+    hipStream_t st = nullptr;
+    THX_RC(slot_stream(gpuIdx, threadId, &st));
+    THX_CHECK(hipMemcpyAsync(devdatP + 2 * slot, datP + 2 * shift, (size_t)npxl * 2 * sizeof(float), hipMemcpyHostToDevice, st));
     if (cSearch != 2) {
         THX_REQUIRE(devctfP && ctfP, "ctfP is NULL");
-        THX_CHECK(hipMemcpy(devctfP + slot, ctfP + shift, (size_t)npxl * sizeof(float), hipMemcpyHostToDevice));
+        THX_CHECK(hipMemcpyAsync(devctfP + slot, ctfP + shift, (size_t)npxl * sizeof(float), hipMemcpyHostToDevice, st));
     } else {
         THX_REQUIRE(devdefO && defO, "defO is NULL");
-        THX_CHECK(hipMemcpy(devdefO + slot, defO + shift, (size_t)npxl * sizeof(float), hipMemcpyHostToDevice));
+        THX_CHECK(hipMemcpyAsync(devdefO + slot, defO + shift, (size_t)npxl * sizeof(float), hipMemcpyHostToDevice, st));
     }
-    THX_CHECK(hipMemcpy(devsigP + slot, sigP + shift, (size_t)npxl * sizeof(float), hipMemcpyHostToDevice));
+    THX_CHECK(hipMemcpyAsync(devsigP + slot, sigP + shift, (size_t)npxl * sizeof(float), hipMemcpyHostToDevice, st));
+    THX_RC(wait_stream(st));
     return 0;
 }
 
@@ -346,7 +391,7 @@ int thx_ExpectLocalM_host(int gpuIdx, int datShift, thx_calpoint* mcp, const flo
                                devdatP + 2 * slot, ctf, devsigP + slot, mcp->devRotm, mcp->nR, mcp->devnT, mcp->nT, nD, oldC, mcp->devR,
                                mcp->devT, mcp->devD, mcp->devwC, mcp->devwR, mcp->devwT, mcp->devwD, mcp->devBaseL, mcp->ws, st));
     THX_CHECK(hipMemcpyAsync(mcp->hOut, mcp->devwC, mcp->nOut * sizeof(float), hipMemcpyDeviceToHost, st));
-    THX_CHECK(hipStreamSynchronize(st));
+    THX_RC(wait_stream(st));
     const float* o = mcp->hOut;
     wC[0] = o[0]; o += 1;
     memcpy(wR, o, mcp->nR * sizeof(float)); o += mcp->nR;
