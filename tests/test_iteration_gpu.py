@@ -305,7 +305,13 @@ def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, s
             want = O.set_projectee(nat.map(h, k).cpu().numpy(), 2)
             assert _rel(vd, want) <= 2e-6
             if not loose and not resized_used[h, k]:    # (the oracle chain's own projector: only where its map was held to the tight bar above)
-                assert _rel(vd, O.set_projectee(ref_["maps"][h][k], 2)) <= max(5e-3, 10 * sens[h, k])
+                wantc = O.set_projectee(ref_["maps"][h][k], 2)
+                if well_covered:
+                    # (in the L2 norm, which Parseval ties to the maps': the largest FT value is the DC term, a SUM over 64^3 voxels, so
+                    # a 6e-5-of-max difference spread over the box -- normCorrection's 2e-4 on the image scales -- shows as 1e-2 of it)
+                    assert np.linalg.norm(vd - wantc) <= 5e-3 * np.linalg.norm(wantc)
+                else:
+                    assert _rel(vd, wantc) <= max(5e-3, 10 * sens[h, k])
             it.vols[h][k] = want                               # the chain continues from the device's reference ...
     it.fscReco = fsc_dev[:, :rU].astype(np.float32).copy()     # ... and the device's FSC (Model::resetReco)
     # ---- reCentreImg + reMaskImg (not after a global search) ----
