@@ -4,6 +4,7 @@
 // Prints "OK <correlation>" when the reconstruction correlates with the input map.
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -203,6 +204,77 @@ int main()
         const double cc3 = ab / std::sqrt(aa * bb);
         std::fprintf(stderr, "project(Image) -> insert(Image) -> reconstruct: correlation %.5f\n", cc3);
         if (!(cc3 > 0.99)) { std::printf("FAIL image-form round trip %.5f\n", cc3); return 6; }
+    }
+    // Round 6: the reference's OWN constructor and setters (include/Reconstructor.h:336-470), through stand-ins that have the members the
+    // templates use (against the reference's real Symmetry / Image / vec they are compiled by tools/boundary_lint.sh):
+    //   Reconstructor(MODE_3D, N, N, 2, &sym, 1.9, 15) with a C2 group about z -> prepareTF symmetrises: the map must carry the two-fold;
+    //   setFSC(vec), setMPIEnv(.., rank 0, ..) -> prepareTF / reconstruct are no-ops (IF_MASTER return);
+    //   project(Image&, mat, nThread) / insert(Image, Image, mat, w) under their own names == the raw forms.
+    {
+        struct Mat33 { double d[9]; const double* data() const { return d; } double* data() { return d; } };
+        struct C2 {   // Symmetry: nSymmetryElement() elements beyond the identity, get(L, R, i)
+            int nSymmetryElement() const { return 1; }
+            void get(Mat33& L, Mat33& R, const int) const
+            {
+                const double rz[9] = {-1, 0, 0, 0, -1, 0, 0, 0, 1};   // a half turn about z (column-major; symmetric)
+                for (int e = 0; e < 9; e++) { L.d[e] = (e % 4 == 0) ? 1.0 : 0.0; R.d[e] = rz[e]; }
+            }
+        } sym;
+        struct Vec { std::vector<float> v; size_t size() const { return v.size(); } float operator()(int i) const { return v[i]; } } fscv;
+        fscv.v.assign(rU, 1.0f);
+        struct Img {   // Image: nColRL(), operator[] / dataFT() onto the Fourier half
+            std::vector<Complex> ft; long n;
+            long nColRL() const { return n; }
+            Complex& operator[](size_t i) { return ft[i]; }
+            const Complex* dataFT() const { return ft.data(); }
+        };
+        const int nc = N / 2 + 1;
+        Reconstructor r4(1, N, N, pf, &sym, 1.9, 15);
+        r4.setMPIEnv(3, 1, 0, 0);                 // a hemisphere lead
+        r4.setFSC(fscv);
+        r4.setMaxRadius(rU);
+        r4.allocSpace(1);
+        proj.setMaxRadius(rU);
+        Img img, ctfImg;
+        img.n = ctfImg.n = N;
+        img.ft.assign((size_t)N * nc, Complex{{0.f, 0.f}});
+        ctfImg.ft.assign((size_t)N * nc, Complex{{1.f, 0.f}});
+        std::vector<Complex> raw((size_t)N * nc);
+        for (int l = 0; l < 60; l++) {
+            Mat33 m;
+            for (int e = 0; e < 9; e++) m.d[e] = rot[(size_t)l * 9 + e];
+            for (Complex& c : img.ft) { c.dat[0] = 0.f; c.dat[1] = 0.f; }
+            proj.project(img, m, 1);                                   // Projector::project(Image&, const dmat33&, nThread)
+            if (l == 0) {
+                for (Complex& c : raw) { c.dat[0] = 0.f; c.dat[1] = 0.f; }
+                proj.projectImage(raw.data(), N, m.data(), 1);
+                if (std::memcmp(raw.data(), img.ft.data(), raw.size() * sizeof(Complex)) != 0) { std::printf("FAIL project(Image&) != projectImage\n"); return 9; }
+            }
+            r4.insert(img, ctfImg, m, 1.0f);                           // Reconstructor::insert(const Image&, const Image&, const dmat33&, RFLOAT)
+        }
+        r4.prepareTF(1);
+        r4.setMAP(false);
+        std::vector<float> o4((size_t)N * N * N);
+        r4.reconstruct(o4.data(), 1);
+        // the two-fold about z: map(-x, -y, z) == map(x, y, z)
+        double dsym = 0, omax = 0;
+        for (int k = 0; k < N; k++)
+            for (int j = 0; j < N; j++)
+                for (int i = 0; i < N; i++) {
+                    const float a = o4[((size_t)k * N + j) * N + i], b = o4[((size_t)k * N + (N - j) % N) * N + (N - i) % N];
+                    dsym = std::fmax(dsym, std::fabs((double)a - b)); omax = std::fmax(omax, std::fabs((double)a));
+                }
+        std::fprintf(stderr, "Reconstructor(.., &sym, ..) with C2: map differs from its half turn by %.3g of %.3g\n", dsym, omax);
+        if (!(omax > 0 && dsym <= 2e-2 * omax)) { std::printf("FAIL symmetry through the reference's constructor %.3g\n", dsym); return 10; }
+        // the master does nothing: IF_MASTER return
+        Reconstructor r5(1, N, N, pf, &sym, 1.9, 15);
+        r5.setMPIEnv(3, 0, 0, 0);
+        r5.allocSpace(1);
+        std::vector<float> o5((size_t)N * N * N, 7.0f);
+        r5.prepareTF(1);             // (T(0,0,0) = 0 here: the normalisation would divide by zero if it ran)
+        r5.prepareO();
+        r5.reconstruct(o5.data(), 1);
+        if (!r5.isMaster() || o5[0] != 7.0f || o5[o5.size() / 2] != 7.0f) { std::printf("FAIL master is not a no-op\n"); return 11; }
     }
     std::printf("OK %.5f\n", cc);
     return 0;

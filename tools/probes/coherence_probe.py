@@ -40,12 +40,15 @@ def run(name, r, perm=None):
     for rep in range(3):
         torch.cuda.synchronize(); t_ = time.perf_counter()
         ops.expect_local(sh.cells[0:1], sh.P, sh.pf, sh.N, sh.iCol, sh.iRow, dat, ctf, sig, rot, tt,
-                         pR=pR_, pT=pT_, workspace=sh.ws[0], packed=True, wg_per_cu=2)
+                         pR=pR_, pT=pT_, workspace=sh.ws[0], packed=True, wg_per_cu=int(os.environ.get("WG", "2")))
         torch.cuda.synchronize(); best = min(best, time.perf_counter() - t_)
     print("%-58s %7.1f ms for %d images = %6.2f us per image-phase" % (name, best * 1e3, m, best / m * 1e6), flush=True)
 
 
 run("A  the filter's own clouds (view-ordered images)", r0)
+if os.environ.get("E13") == "1":     # round 6, Appendix A E13: only A and B (the kernel's non-memory floor), for the counter passes
+    run("B  every image on image 0's cloud", r0[:1].expand(m, -1, -1).contiguous())
+    sys.exit(0)
 # E: the same images and clouds as A, stored so that the workgroups of ONE XCD (workgroup i -> XCD i mod 8, 64 resident per XCD at 2
 # per CU) are 64 view-neighbours: position 8 (64 q + r) + x holds image (8 q + x) 64 + r
 for blk in (64, 16):
