@@ -687,7 +687,9 @@ def refinement_line(args, dev, rank, world, box, particles, steps, warmup, batch
                 j = json.loads(raw)
                 lds_rate64 = j.get("lds_add_u64_per_s")
                 per_box = j.get("per_box", {}).get(str(box))
-                if per_box:
+                if args.cutoff:
+                    pass       # (the committed PMC passes ran at Nyquist: no traffic figure for a run below it)
+                elif per_box:
                     traffic, pmc_src = per_box["hbm_bytes_per_image_phase"] * exp_n, per_box.get("source")
                 elif j.get("box") == box:
                     traffic, pmc_src = j["hbm_bytes_per_image_phase"] * exp_n, j.get("source")
@@ -727,7 +729,9 @@ def refinement_line(args, dev, rank, world, box, particles, steps, warmup, batch
                          "images_per_launch": exp_n, "algorithmic_bytes_per_launch": kbytes, "traffic_source": pmc_src,
                          # PMC passes cannot ride in a timed run: `traffic` is the per-image-phase figure of the committed profile
                          # (separate rocprofv3 --pmc passes over this same workload, tools/pmc_traffic.sh) scaled to this run's launch
-                         "traffic_measured_in_run": False, "traffic_profile": "profiles/pmc_traffic.json", "traffic_profile_git_blob": pmc_blob},
+                         "traffic_measured_in_run": False, "traffic_profile": "profiles/pmc_traffic.json", "traffic_profile_git_blob": pmc_blob,
+                         "note": ("an EFFECTIVE rate (algorithmic bytes, no cache credit, over time): it can exceed the HBM peak -- below Nyquist the "
+                                  "rotations of a cloud land within a voxel of each other and share their cells inside L2") if achieved > HBM_PEAK_GBS else None},
             "kernels": {"insertion (k_bin + segment sort + k_acc)": {
                             "avg_call_ms": ins_ms, "images_per_call": ins_n, "total_ms": t_ins,
                             "groups_per_image": groups_per_image, "us_per_image": ins_ms * 1e3 / max(1.0, ins_n),

@@ -3,7 +3,7 @@ view-ordered images with (A) the filter's own clouds, (B) every image using imag
 cells at the same time: perfect coherence, the ceiling of any co-scheduling scheme), (C) groups of 8 consecutive images sharing a
 cloud, (D) image 0's cloud turned by a random angle of up to `deg` degrees per image.  usage: python tools/coherence_probe.py [n]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from thunder_amd import ops
 from thunder_amd.refine import RefineShard
