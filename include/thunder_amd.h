@@ -692,7 +692,10 @@ typedef struct thx_refine_config {
     int searchType;            /* THX_SEARCH_* of the next iteration (Optimiser::_searchType); thx_refine_set_search_type changes it */
     int nR, nT;                /* the scanned grid: nR = mS / (1 + nSym) rotations (src/Optimiser.cpp:652), nT >= 30 shifts (:663-667);
                                   0 = the handle never scans (no scan buffers) */
-    int rScan;                 /* frequency limit of the scan (Optimiser::_r of a global-search iteration) */
+    int rScan;                 /* frequency limit of the scan: the LARGEST radius a global search of this handle scans at (its buffers are
+                                  sized for that list); the scan of an iteration runs at min(rScan, r) with r the cut-off of
+                                  thx_refine_set_cutoff -- r at Nyquist: SURVEY 8d's configs[3] (scan at rScan, local phases on the full
+                                  list); rScan >= r: the reference's own form, scan and local phases both on allocPreCalIdx(_r, _rL) */
     int scanBatch;             /* images per scan launch, at most (0 = 2048): workspace nImg * nR * nT floats */
     double pfSGlobal;          /* perturbFactorSGlobal: EVERY local phase of a global-search iteration (phase index starts at 1,
                                   src/Optimiser.cpp:1185-1212; OPTIMISER_GLOBAL_PERTURB_LARGE is off) */
@@ -723,8 +726,10 @@ typedef struct thx_refine_capture {
     float *mapsFsc;            /* [2][nK][N]^3: the MAP-off half maps the FSC is computed from */
     double *rP, *tP;           /* [nPhase][nImg][mLR][4], [nPhase][nImg][mLT][2]: the support points after Particle::perturb */
     double *wRP, *wTP;         /* [nPhase][nImg][mLR], [nPhase][nImg][mLT]: their priors (Particle::balanceWeight) */
-    float *Fraw, *Traw;        /* [local halves][nK] complex / real (pf N)^3 half grids: the accumulators as the insertion session
-                                  left them (after the half-set reduce on the integers), before prepareTF's normalisation */
+    float *Fraw, *Traw;        /* [local halves][nK] complex / real half grids of the reconstructors' CURRENT size, (pf size)^3 (= (pf N)^3 at
+                                  Nyquist; thx_refine_set_cutoff), contiguous from the start of the buffer -- size the buffers for (pf N)^3:
+                                  the accumulators as the insertion session left them (after the half-set reduce on the integers), before
+                                  prepareTF's normalisation */
     /* global search: the scan's weights and what the filter made of them */
     float *scanUC, *scanUR, *scanUT;   /* [nImg][nK], [nImg][nK][nR], [nImg][nK][nT] */
     double *r0, *t0;           /* [nImg][mLR][4], [nImg][mLT][2]: the support points as thx_pf_scan_support_dev left them */
