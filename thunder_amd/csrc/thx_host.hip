@@ -2,11 +2,43 @@
 // (gpu/interface/Interface.h:199-219,267-326; Reconstructor::reconstructG src/Reconstructor.cpp:1835-2315).
 // Each one uploads, runs the *_dev path, and writes results back into the caller's arrays before returning,
 // which is the contract the reference's -DGPU_VERSION call sites rely on.
+#include <mutex>
 #include <vector>
 
 #include "thx_common.h"
 
 using namespace thx;
+
+namespace {
+// The reference's T volume is a complex Volume whose imaginary part is never written (src/Reconstructor.cpp:782-863): the device works on
+// the real part.  The (de)interleaving runs ON THE DEVICE -- the host loops over 67 M voxels it replaces cost 50 ms each way at 512^3.
+__global__ void k_take_real(float* __restrict__ dst, const float2* __restrict__ src, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i].x;
+}
+__global__ void k_put_real(float2* __restrict__ dst, const float* __restrict__ src, size_t n, int zeroImag)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { dst[i].x = src[i]; if (zeroImag) dst[i].y = 0.f; }
+}
+// host complex T -> device real T (dT) through a device copy of the complex volume (dTc, kept for the way back)
+int upload_T(DevBuf& dTc, DevBuf& dT, const float* T3D_complex, size_t n)
+{
+    THX_RC(dTc.upload(T3D_complex, n * 2 * sizeof(float)));
+    THX_RC(dT.alloc(n * sizeof(float)));
+    hipLaunchKernelGGL(k_take_real, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, dT.as<float>(), dTc.as<float2>(), n);
+    THX_LAUNCH_CHECK();
+    return 0;
+}
+int download_T(float* T3D_complex, DevBuf& dTc, const float* dT, size_t n, int zeroImag)
+{
+    hipLaunchKernelGGL(k_put_real, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, dTc.as<float2>(), dT, n, zeroImag);
+    THX_LAUNCH_CHECK();
+    THX_CHECK(hipMemcpy(T3D_complex, dTc.p, n * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+}  // namespace
 
 extern "C" {
 
@@ -85,13 +117,9 @@ static int insert_ft_host(thx_comm* hemi, int maxRadius, float* F3D, float* T3D_
     THX_REQUIRE(F3D && T3D_complex && datP && ctfP && w && nR && nT && iCol && iRow, "NULL pointer");
     const size_t nvol = (size_t)vdim * vdim * (vdim / 2 + 1);
     const size_t nd = (size_t)imgNum * mReco;
-    DevBuf dF, dT, dO, dCnt, dDat, dCtf, dW, dQuat, dMat, dTran, dOff, dCls, dAttr, dDf, dCol, dRow;
+    DevBuf dF, dT, dTc, dO, dCnt, dDat, dCtf, dW, dQuat, dMat, dTran, dOff, dCls, dAttr, dDf, dCol, dRow;
     THX_RC(dF.upload(F3D, nvol * nK * 2 * sizeof(float)));
-    {   // T: complex on the host (imaginary part unused) -> real on the device
-        std::vector<float> t(nvol * nK);
-        for (size_t i = 0; i < nvol * nK; i++) t[i] = T3D_complex[2 * i];
-        THX_RC(dT.upload(t.data(), nvol * nK * sizeof(float)));
-    }
+    THX_RC(upload_T(dTc, dT, T3D_complex, nvol * nK));   // T: complex on the host (imaginary part unused) -> real on the device
     double O0[3] = {0, 0, 0};
     int c0 = 0;
     THX_RC(dO.upload(O0, sizeof(O0)));
@@ -127,11 +155,7 @@ static int insert_ft_host(thx_comm* hemi, int maxRadius, float* F3D, float* T3D_
         THX_CHECK(hipDeviceSynchronize());
     }
     THX_CHECK(hipMemcpy(F3D, dF.p, nvol * nK * 2 * sizeof(float), hipMemcpyDeviceToHost));
-    {
-        std::vector<float> t(nvol * nK);
-        THX_CHECK(hipMemcpy(t.data(), dT.p, nvol * nK * sizeof(float), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < nvol * nK; i++) T3D_complex[2 * i] = t[i];
-    }
+    THX_RC(download_T(T3D_complex, dTc, dT.as<float>(), nvol * nK, 0));   // (imaginary parts as the caller had them)
     if (O3D) {
         double o[3];
         THX_CHECK(hipMemcpy(o, dO.p, sizeof(o), hipMemcpyDeviceToHost));
@@ -171,11 +195,9 @@ int thx_PrepareTF_host(int gpuIdx, float* F3D, float* T3D_complex, int vdim, con
 {
     THX_CHECK(hipSetDevice(gpuIdx));
     const size_t nvol = (size_t)vdim * vdim * (vdim / 2 + 1);
-    DevBuf dF, dT, dF2, dT2;
+    DevBuf dF, dT, dTc, dF2, dT2;
     THX_RC(dF.upload(F3D, nvol * 2 * sizeof(float)));
-    std::vector<float> t(nvol);
-    for (size_t i = 0; i < nvol; i++) t[i] = T3D_complex[2 * i];
-    THX_RC(dT.upload(t.data(), nvol * sizeof(float)));
+    THX_RC(upload_T(dTc, dT, T3D_complex, nvol));
     THX_RC(dF2.alloc(nvol * 2 * sizeof(float)));
     THX_RC(dT2.alloc(nvol * sizeof(float)));
     THX_RC(thx_normalise_tf_dev(dF.as<float>(), dT.as<float>(), vdim, nullptr));
@@ -183,8 +205,7 @@ int thx_PrepareTF_host(int gpuIdx, float* F3D, float* T3D_complex, int vdim, con
     THX_RC(thx_symmetrize_dev(dT2.as<float>(), dT.as<float>(), vdim, 0, symMat, nSymmetryElement, r, nullptr));
     THX_RC(thx_symmetrize_dev(dF2.as<float>(), dF.as<float>(), vdim, 1, symMat, nSymmetryElement, r, nullptr));
     THX_CHECK(hipMemcpy(F3D, dF2.p, nvol * 2 * sizeof(float), hipMemcpyDeviceToHost));
-    THX_CHECK(hipMemcpy(t.data(), dT2.p, nvol * sizeof(float), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < nvol; i++) { T3D_complex[2 * i] = t[i]; T3D_complex[2 * i + 1] = 0.f; }
+    THX_RC(download_T(T3D_complex, dTc, dT2.as<float>(), nvol, 1));
     return 0;
 }
 
@@ -195,21 +216,29 @@ int thx_ReconstructG_host(int gpuIdx, const float* F3D, const float* T3D_complex
     THX_CHECK(hipSetDevice(gpuIdx));
     const int PF = pf * size;
     const size_t nvol = (size_t)PF * PF * (PF / 2 + 1);
-    DevBuf dF, dT, dDst;
+    DevBuf dF, dT, dTc, dDst;
     THX_RC(dF.upload(F3D, nvol * 2 * sizeof(float)));
-    std::vector<float> t(nvol);
-    for (size_t i = 0; i < nvol; i++) t[i] = T3D_complex[2 * i];
-    THX_RC(dT.upload(t.data(), nvol * sizeof(float)));
+    THX_RC(upload_T(dTc, dT, T3D_complex, nvol));
     THX_RC(dDst.alloc((size_t)N * N * N * sizeof(float)));
-    thx_reco* r = nullptr;
-    THX_RC(thx_reco_create(&r, size, N, pf, a, alpha));
-    int rc = thx_reco_reconstruct_dev(r, dF.as<float>(), dT.as<float>(), maxRadius, FSC, nFSC, joinHalf, MAP, gridCorr,
+    // the plan (W, C, scratch, the FFT plans: tens of milliseconds to build at 512^3) is kept between calls -- the reference calls
+    // reconstructG four times per iteration with the same geometry (src/Optimiser.cpp:7366-7371,7600-7620); one cached plan per process,
+    // rebuilt when the geometry or the device changes, calls serialised on it
+    static std::mutex mtx;
+    static thx_reco* cached = nullptr;
+    static int key[4] = {0, 0, 0, -1};
+    static float keyf[2] = {0.f, 0.f};
+    std::lock_guard<std::mutex> g(mtx);
+    if (!cached || key[0] != size || key[1] != N || key[2] != pf || key[3] != gpuIdx || keyf[0] != a || keyf[1] != alpha) {
+        if (cached) { (void)thx_reco_destroy(cached); cached = nullptr; }
+        THX_RC(thx_reco_create(&cached, size, N, pf, a, alpha));
+        key[0] = size; key[1] = N; key[2] = pf; key[3] = gpuIdx; keyf[0] = a; keyf[1] = alpha;
+    }
+    int rc = thx_reco_reconstruct_dev(cached, dF.as<float>(), dT.as<float>(), maxRadius, FSC, nFSC, joinHalf, MAP, gridCorr,
                                       dDst.as<float>(), nullptr, nullptr, nullptr);
     if (!rc) {
         hipError_t e = hipMemcpy(dstRL, dDst.p, (size_t)N * N * N * sizeof(float), hipMemcpyDeviceToHost);
         if (e != hipSuccess) { set_error("hipMemcpy D2H failed: %s", hipGetErrorString(e)); rc = (int)e; }
     }
-    thx_reco_destroy(r);
     return rc;
 }
 
