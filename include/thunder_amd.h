@@ -798,7 +798,8 @@ int thx_refine_set_search_type(thx_refine* h, int searchType);
  *        curve handed to the NEXT iteration's MAP reconstruction keeps this iteration's rU entries (Model::resetReco's
  *        setFSC(_FSC.col(l)); shells beyond count as FSC 0, src/Reconstructor.cpp:1244-1247).
  * Re-cuts the M-step rows, both CTF row sets [, the defocus search's rows, the scan's ramps]; rebuilds the reconstruction plans when
- * the size changes; before the first iteration it also resets the reconstructor's FSC to rU ones (Model::initProjReco,
+ * the size changes (with several ranks EVERY rank of the job makes the same call: the half-set reduce and the owners' plans follow
+ * the size); before the first iteration it also resets the reconstructor's FSC to rU ones (Model::initProjReco,
  * src/Model.cpp:1086).  Synchronises the stream.  Capture buffers Fraw / Traw / Fsym / Tsym are filled as [local halves][nK]
  * volumes of the CURRENT (pf size)^3 half grid, contiguous. */
 int thx_refine_set_cutoff(thx_refine* h, int r, int rU, void* stream);

@@ -27,6 +27,10 @@ CASES = {
                kw=dict(mLR=40, mLT=4, mReco=16, K_used=3)),
     # point group C4, one class
     "c4": dict(N=32, n=200, K=1, sym="C4", scan=None, iters=("local", "local"), norm=False, kw=dict(mLR=40, mLT=5, mReco=16)),
+    # round 6: frequency cut-offs handed in before every iteration (thx_refine_set_cutoff on EVERY rank): the E-step list, the M-step list
+    # and the reconstructors' grid (44^3, 56^3, 64^3) change from iteration to iteration; the half-set reduce runs on the resized grid
+    "k1cut": dict(N=32, n=240, K=1, sym=None, scan=None, iters=("local", "local", "local"), norm=True, kw=dict(mLR=40, mLT=5, mReco=16),
+                  cut=((8, 9), (10, 12), (14, 14))),
 }
 
 
@@ -88,14 +92,19 @@ def main():
     nV = 2 if a.world == 1 else 1
     for it, search in enumerate(c["iters"]):
         nat.set_search(search)
+        if c.get("cut"):
+            nat.set_cutoff(*c["cut"][it])
         fsc = nat.iterate()
         torch.cuda.synchronize()
         st = nat.stats()
         v = nat.view()
         m = sh.nImg
         out["fsc%d" % it] = np.atleast_2d(fsc)
-        out["Fraw%d" % it] = cap["Fraw"].cpu().numpy()
-        out["Traw%d" % it] = cap["Traw"].cpu().numpy()
+        # (the accumulators are volumes of the reconstructors' CURRENT grid, contiguous from the start of the capture buffers)
+        PF = v.fdim
+        volF = PF * PF * (PF // 2 + 1)
+        out["Fraw%d" % it] = cap["Fraw"].cpu().numpy().reshape(-1)[:nV * K * volF].reshape(nV, K, PF, PF, PF // 2 + 1).copy()
+        out["Traw%d" % it] = cap["Traw"].cpu().numpy().reshape(-1)[:nV * K * volF].reshape(nV, K, PF, PF, PF // 2 + 1).copy()
         out["mapsFsc%d" % it] = cap["mapsFsc"].cpu().numpy()
         out["maps%d" % it] = np.stack([[nat.map(h, k).cpu().numpy() for k in range(K)] for h in (0, 1)])
         out["sig%d" % it] = nat.fetch(v.sig, np.float32, (nV, sh.nGroup, N // 2 - 1))

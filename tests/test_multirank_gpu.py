@@ -194,6 +194,20 @@ def test_n_ranks_equal_one_rank_classification(dev, world):
         assert all((rounds[:, k] == 0).all() for k in range(3) if k not in mine), (r, rounds)
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_n_ranks_equal_one_rank_with_cutoffs(dev, world):
+    """Round 6: the frequency cut-offs as per-iteration inputs on every rank -- (r, rU) = (8, 9) -> (10, 12) -> (14, 14) at N = 32 with
+    normCorrection on: the quanta, the integer accumulators and their half-set reduce live on the resized (pf size)^3 grids (44^3, 56^3,
+    64^3), the reconstructing rank builds its plans at the new size, the FSC has rU shells.  Held to the one-rank run with the same
+    cut-offs: iteration 1 bitwise."""
+    ref = one_rank("k1cut")
+    assert ref["Fraw0"].shape[-2] == 44 and ref["Fraw1"].shape[-2] == 56 and ref["Fraw2"].shape[-2] == 64
+    assert np.all(ref["fsc0"][:, 9:] == 0) and np.all(ref["fsc1"][:, 12:] == 0) and ref["fsc1"][0, 10] != 0
+    ranks = run_ranks(world, "k1cut")
+    rep = compare("k1cut", world, ranks, ref, 3, 1)
+    print("world %d, k1cut:" % world, rep)
+
+
 def test_n_ranks_equal_one_rank_point_group(dev):
     """C4: prepareTF's symmetrisation runs on the reduced sums of the reconstructing rank"""
     ref = one_rank("c4")
