@@ -264,3 +264,20 @@ def test_refinement_at_low_cutoff_n256(oracle, dev):
         f = _fsc_np(O, nat.map(h).cpu().numpy(), ref, N, 30)
         assert f[1:14].min() >= 0.8, f
     nat.close()
+
+
+def test_classification_chain_with_cutoffs(oracle, dev):
+    """A K = 2 classification below Nyquist: iteration 1 a GLOBAL search at r = 8 -- the scan runs on allocPreCalIdx(_r, _rL) itself
+    (radius min(cfg.rScan = 9, r) = 8: list, CTF rows and the grid shifts' ramps re-cut), the local phases on the same list, as the
+    reference has it (src/Optimiser.cpp:631) --, insertion routed per class into 44^3 grids (rU = 9); iteration 2 a local search at
+    (11, 12) in the assigned classes.  Every stage against oracle.Iteration with the same cut-offs."""
+    import test_iteration_gpu as TI
+    O = oracle
+    N, n, K = 32, 192, 2
+    inp = U.make_inputs(O, N, n, seed=702, mLR=40, mLT=4, nPhase=2, mReco=16, batch=64, snr=2.0, K=K, scan=dict(nR=150, nT=6, rScan=9), balance=1)
+    cut = [(8, 9), (11, 12)]
+    nat, it, (out1, out2) = TI._run_chain(O, dev, inp, "K=2 cut-offs", 0.3, 0.35, searches=("global", "local"), thin=True, cutoffs=cut)
+    assert nat.cutoff() == (11, 12, 28, 9) and it.rS == 9
+    assert (out1["cls"] == inp["cls_true"]).mean() >= 0.8 and np.array_equal(out2["cls"], out1["cls"])
+    assert out1["fsc"].shape == (K, 9) and out2["fsc"].shape == (K, 12)
+    nat.close()
