@@ -606,6 +606,37 @@ def bench_staged(args, dev):
                     "(thx_refine_iterate) is the product path and the headline"}
 
 
+def traffic_in_run(box, timeout_s=900):
+    """HBM traffic of the local-search kernel measured NOW, on this box: tools/pmc_traffic.sh (MI355X_MICROARCH.md's recipe: FETCH_SIZE
+    and WRITE_SIZE in separate --pmc passes, kernel-trace only, each calibrated on tools/pmc_calib's known-byte-count dispatches in the
+    same pass) over one iteration of 20 000 particles of the same workload -- 10 000 images per launch, as the timed run's.  Returns
+    (bytes per image-phase, source string) or (None, reason).  Runs in its own process group with a hard timeout: a failure here must
+    never cost the line that is already measured."""
+    import signal
+    import subprocess
+    env = dict(os.environ, GRAFT_REPO_ROOT=ROOT, THX_PROBE_PARTICLES="20000", THX_PROBE_BOX=str(box), PMC_SKIP_L2="1",
+               PMC_CMD="python bench.py --box %d --particles 20000 --steps 1 --warmup 0 --no-cpu-baseline --other-configs off --no-traffic-pass" % box)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        p = subprocess.Popen(["bash", os.path.join(ROOT, "tools", "pmc_traffic.sh")], cwd=ROOT, env=env, stdout=subprocess.DEVNULL,
+                             stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            rc = p.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)      # (exactly the process group started here)
+            p.wait()
+            return None, "in-run PMC passes timed out after %d s" % timeout_s
+        if rc != 0:
+            return None, "tools/pmc_traffic.sh exited with %d" % rc
+        j = json.load(open(os.path.join(ROOT, "gpurun_out", "pmc_traffic", "pmc_traffic.json")))
+        if j.get("box") != box or not j.get("hbm_bytes_per_image_phase"):
+            return None, "the PMC passes produced no figure for the local-search kernel"
+        return float(j["hbm_bytes_per_image_phase"]), j.get("source")
+    except Exception as e:      # noqa: BLE001
+        return None, "%s: %s" % (type(e).__name__, str(e)[:200])
+
+
 def refinement_line(args, dev, rank, world, box, particles, steps, warmup, batch, cpu=True, cpu_particles=0):
     """one refinement configuration through the native driver -> the result dict (rank 0; None on the other ranks)"""
     import torch
@@ -799,6 +830,10 @@ def main():
                     help="frequency cut-offs of the timed iterations (thx_refine_set_cutoff): r = Optimiser::_r (E-step list, projector radius), "
                          "rU = Model::_rU (M-step list, Reconstructor::_maxRadius, reconstruction grid size min(N, (rU + 2) * 2)); default: Nyquist, "
                          "N / 2 - 2 for both -- what the metric is quoted on")
+    ap.add_argument("--no-traffic-pass", action="store_true",
+                    help="skip the in-run PMC passes (headline workload on one GPU: after the timed iterations, tools/pmc_traffic.sh counts "
+                         "FETCH_SIZE / WRITE_SIZE of a 20 000-particle iteration of the same workload in separate rocprofv3 passes, calibrated in the "
+                         "same passes, and `roofline.traffic` becomes that run's figure; otherwise the committed profile's)")
     ap.add_argument("--no-norm-correction", action="store_true",
                     help="leave Optimiser::normCorrection (OPTIMISER_NORM_CORRECTION, on in the reference's Config.h) out of the iteration")
     ap.add_argument("--unsorted", action="store_true",
@@ -901,6 +936,19 @@ def main():
         oc = {}
         t0 = time.perf_counter()
         small = os.environ.get("THX_BENCH_SMALL_OTHERS") == "1"     # (tests/test_next_gpu.py: the same code path on toy sizes)
+        if headline and not small and not args.no_traffic_pass:
+            # roofline.traffic of THIS run (round-5 review: the committed profile's figure could not be contradicted by the driver's run)
+            per_phase, src = traffic_in_run(args.box)
+            rf = out["roofline"]
+            if per_phase is not None:
+                rf["traffic_committed_profile"] = rf["traffic"]
+                rf["traffic"] = per_phase * rf["images_per_launch"]
+                rf["traffic_measured_in_run"] = True
+                rf["traffic_source"] = "measured in this run, after the timed iterations: " + str(src)
+                rf["traffic_over_algorithmic"] = rf["traffic"] / rf["algorithmic_bytes_per_launch"]
+            else:
+                rf["traffic_in_run_failed"] = src
+            out["traffic_pass_wall_s"] = round(time.perf_counter() - t0, 1)
         b1, n1, b3, n3, b4, n4 = (32, 300, 64, 96, 64, 200) if small else (256, 10000, 256, 6250, 512, 20000)
         common = ["--mLR", str(args.mLR), "--mLT", str(args.mLT), "--phases", str(args.phases), "--mReco", str(args.mReco), "--batch", str(args.batch),
                   "--wg-per-cu", str(args.wg_per_cu), "--cpu-groups", str(args.cpu_groups), "--other-configs", "off"]

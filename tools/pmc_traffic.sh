@@ -4,7 +4,7 @@
 # access shape on gfx950, so every pass also profiles tools/pmc_calib: 1 GiB dispatches of known byte count in three
 # shapes (wide streaming copy, scattered 64-byte cells = the E-step's packed gathers, scattered 16-byte pairs).  A third
 # pass collects the L2's request / hit / miss counts for a cross-check (misses x 128-byte lines).
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$(dirname "$(readlink -f "$0")")/..}"
 OUT=gpurun_out/pmc_traffic
 rm -rf $OUT; mkdir -p $OUT
 [ -x tools/pmc_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/pmc_calib tools/pmc_calib.hip
@@ -17,6 +17,7 @@ tools/pmc_calib > $OUT/pmc_calib_unprofiled.txt 2>&1
 CMD="${PMC_CMD:-python tools/probes/traffic_probe.py}"
 for pass in fetch:FETCH_SIZE write:WRITE_SIZE l2:"TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum"; do
     name=${pass%%:*}; ctr=${pass#*:}
+    [ "$name" = l2 ] && [ "${PMC_SKIP_L2:-0}" = 1 ] && continue      # (bench.py's in-run pass: FETCH_SIZE and WRITE_SIZE only)
     rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/cal_$name -o p -- tools/pmc_calib > $OUT/cal_$name.log 2>&1
     rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/$name -o p -- $CMD > $OUT/$name.log 2>&1
 done
