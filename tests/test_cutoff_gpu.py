@@ -281,3 +281,24 @@ def test_classification_chain_with_cutoffs(oracle, dev):
     assert (out1["cls"] == inp["cls_true"]).mean() >= 0.8 and np.array_equal(out2["cls"], out1["cls"])
     assert out1["fsc"].shape == (K, 9) and out2["fsc"].shape == (K, 12)
     nat.close()
+
+
+def test_ctf_search_chain_with_cutoffs(oracle, dev):
+    """SEARCH_TYPE_CTF below Nyquist: the defocus search's pre-calculated rows (allocPreCal's ctf = true branch: frequency, defocus,
+    K1, K2 on the E-step list) are re-cut with the list -- iteration 1 a local search at (9, 10), iteration 2 a CTF search with nD = 9
+    at (12, 13); the draw's defocus factor enters the insertion on the resized grid.  Against oracle.Iteration with the same cut-offs."""
+    import test_iteration_gpu as TI
+    O = oracle
+    N, n = 32, 120
+    inp = U.make_inputs(O, N, n, seed=901, mReco=16, batch=40, snr=4.0)
+    rng = np.random.default_rng(77)
+    fac = 1.0 + 0.02 * rng.standard_normal(n)
+    inp["attr"] = inp["attr"].copy()
+    inp["attr"][:, 1] = (inp["attr"][:, 1] / fac).astype(np.float32)
+    inp["attr"][:, 2] = (inp["attr"][:, 2] / fac).astype(np.float32)
+    inp["cfg"].update(mLD=9, ctfRefineS=0.01, pfSCTF=0.5)
+    nat, it, (out1, out2) = TI._run_chain(O, dev, inp, "CTF cut-offs", 0.3, 0.3, searches=("local", "ctf"), cutoffs=[(9, 10), (12, 13)])
+    v = nat.view()
+    d = nat.fetch(v.d, np.float64, (n, 9))
+    assert np.abs(d - out2["d"]).max() <= 1e-12 and nat.cutoff()[:3] == (12, 13, 30)
+    nat.close()
