@@ -260,6 +260,9 @@ def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, s
         # MAP-off intermediates: measured <= 6e-5 and <= 1.9e-3)
         bar_k = chain_bar if (name == "final" or not well_covered) else 5e-3
         ok = e_same <= max(1e-3, 30 * s_) and e <= max(1e-1 if loose else bar_k, 30 * s_)
+        out.setdefault("map_rows", []).append(dict(half=h, k=k, which=name, same_input=e_same, chain=e, sens=s_, fsc_min=fmin, fsc_inner=fin, loose=loose))
+        if 10 * s_ <= 5e-3:
+            ok = ok and fmin >= (0.5 if loose else 0.999) and fin >= (0.95 if loose else 0.999)
         if not ok and resized_rule and e_same <= max(1e-3, 30 * s_) and e <= 1e-1 and fmin >= 0.99 and fin >= 0.999:
             # RESIZED-GRID RULE.  Below Nyquist the gridding loop runs on the (pf size)^3 grid with convoluteC's kernel still scaled by
             # N pf (src/Reconstructor.cpp:2639-2645) and is ended by its max-norm rule after 12 - 19 rounds, far from converged.  The
@@ -270,9 +273,6 @@ def _check_iteration(O, nat, it, cap, inp, label, max_degenerate, max_adopted, s
             print("      ... resized-grid rule: chain difference %.2e accepted (stage on identical inputs %.2e, FSC min %.4f, inner %.6f)" % (e, e_same, fmin, fin))
             ok = True
             resized_used[h, k] = True
-        out.setdefault("map_rows", []).append(dict(half=h, k=k, which=name, same_input=e_same, chain=e, sens=s_, fsc_min=fmin, fsc_inner=fin, loose=loose))
-        if 10 * s_ <= 5e-3:
-            ok = ok and fmin >= (0.5 if loose else 0.999) and fin >= (0.95 if loose else 0.999)
         if not ok:
             bad_maps.append((h, k, name, e_same, e, s_, fmin, fin))
     assert not bad_maps, "maps outside the conditioning rule's bars (half, class, which, same-input error, chain error, sensitivity, min FSC, inner FSC): %s" % bad_maps
