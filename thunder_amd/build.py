@@ -84,6 +84,19 @@ def build_harness(force=False):
     return HARNESS
 
 
+def build_tools(force=False):
+    """the two micro-benchmarks bench.py's in-run PMC pass needs (tools/pmc_traffic.sh: the calibration dispatches of known byte count and
+    the LDS atomic rates): built here so that they travel with the tree; the script builds them itself where they are missing"""
+    tools = os.path.join(HERE, "..", "tools")
+    out = []
+    for exe, src in (("pmc_calib", "pmc_calib.hip"), ("lds_atomic_bench", os.path.join("probes", "lds_atomic_bench.hip"))):
+        e, s_ = os.path.abspath(os.path.join(tools, exe)), os.path.abspath(os.path.join(tools, src))
+        if force or not os.path.exists(e) or os.path.getmtime(e) < os.path.getmtime(s_):
+            subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O3", "-o", e, s_])
+        out.append(e)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_harness(force="--force" in sys.argv))

@@ -7,6 +7,7 @@ python -c "
 from thunder_amd import build, capi
 build.build()
 build.build_harness()
+build.build_tools()
 h = capi.load()
 [getattr(h, n) for n in capi.SIGNATURES]
 from oracle import oracle as O
