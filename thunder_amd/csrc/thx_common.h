@@ -388,7 +388,8 @@ size_t expect_local_single_workspace(int nPxl, int nR, int nT, int nD);
 int expect_local_single(const float* volOrCells, bool packed, int vdim, int pf, int idim, const int* iCol, const int* iRow, int nPxl,
                         const float* datP, const float* ctfP, const float* sigRcpP, const double* rotMat, int nR, const double* trans,
                         int nT, int nD, double pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR, float* wT,
-                        float* wD, float* baseLine, void* workspace, hipStream_t st);
+                        float* wD, float* baseLine, void* workspace, hipStream_t st, unsigned* done = nullptr, unsigned doneVal = 0);
+// (done / doneVal: a host-visible word the finalise kernel sets, after a system-scope fence, once the image's outputs are written)
 
 // rotate3D(quaternion), src/Geometry/Euler.cpp:181-189: R = I + 2 q0 A + 2 A A, column-major out.  ONE statement of the arithmetic for
 // the device kernel (k_rotmat) and for host callers that stage matrices themselves (thx_ExpectLocalRTD_host): IEEE double

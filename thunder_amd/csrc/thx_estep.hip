@@ -791,6 +791,8 @@ struct ExpectFinalArgs {
     float* baseLine;
     float* logW;
     const int* active;
+    unsigned* done;    // (one-image form, may be NULL) host-visible word that receives doneVal once every output of the image is written and
+    unsigned doneVal;  // fenced at system scope: a caller that polls it need not wait for the stream's own completion signal
     int par;           // != 0 (the one-image form): the marginals' sums are spread over a wave each instead of walked by one thread --
                        // a launch of ONE workgroup has nothing else to hide a 1 125-term serial loop behind (68 us measured)
 };
@@ -899,6 +901,13 @@ __global__ __launch_bounds__(256) void k_expect_final(ExpectFinalArgs a)
     if (tid == 0) {
         a.wC[img] = (float)sc;
         a.baseLine[img] = base;
+    }
+    if (a.done) {   // (uniform)
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(a.done, a.doneVal, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1596,7 +1605,8 @@ static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, 
                              const float* sigRcpP, const double* rotMat, int nR, const double* trans, int nT, int nD,
                              const double* pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR,
                              float* wT, float* wD, float* baseLine, float* logW, void* workspace, int wgPerCU, const int* active, void* stream,
-                             bool packed, int nSplitForce = 0, bool noOrder = false, double pCval = 1.0, bool fine = false)
+                             bool packed, int nSplitForce = 0, bool noOrder = false, double pCval = 1.0, bool fine = false,
+                             unsigned* done = nullptr, unsigned doneVal = 0)
 {
     if (nImg <= 0) return 0;
     THX_REQUIRE(volumes && iCol && iRow && datP && ctfP && sigRcpP && rotMat && trans, "NULL input pointer");
@@ -1645,6 +1655,7 @@ static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, 
     f.logW = logW;
     f.active = active;
     f.par = fine ? 1 : 0;
+    f.done = done; f.doneVal = doneVal;
     hipLaunchKernelGGL(k_expect_final, dim3(nImg), dim3(256), (size_t)nD * nT * nR * sizeof(float), st, f);
     THX_LAUNCH_CHECK();
     return 0;
@@ -1698,11 +1709,11 @@ size_t expect_local_single_workspace(int nPxl, int nR, int nT, int nD)
 int expect_local_single(const float* volOrCells, bool packed, int vdim, int pf, int idim, const int* iCol, const int* iRow, int nPxl,
                         const float* datP, const float* ctfP, const float* sigRcpP, const double* rotMat, int nR, const double* trans,
                         int nT, int nD, double pC, const double* pR, const double* pT, const double* pD, float* wC, float* wR, float* wT,
-                        float* wD, float* baseLine, void* workspace, hipStream_t st)
+                        float* wD, float* baseLine, void* workspace, hipStream_t st, unsigned* done, unsigned doneVal)
 {
     return expect_local_impl(volOrCells, nullptr, vdim, pf, idim, iCol, iRow, nPxl, 1, datP, ctfP, sigRcpP, rotMat, nR, trans, nT, nD,
                              nullptr, pR, pT, pD, wC, wR, wT, wD, baseLine, nullptr, workspace, 0 /* no occupancy cap: one image */, nullptr, st,
-                             packed, single_nsplit(nPxl, nD), true, pC, true);
+                             packed, single_nsplit(nPxl, nD), true, pC, true, done, doneVal);
 }
 }  // namespace thx
 

@@ -11,9 +11,11 @@
 // request per sample); ExpectLocalRTD only stages -- priors, shifts, quaternions and the rotation matrices it forms on the host
 // (rotate3d_colmajor: the device kernel's arithmetic, same bits) -- into a page-locked block the handle owns; ExpectLocalPreI3D sends
 // that block with ONE copy (and, in a defocus search, runs the CTF-row kernel); ExpectLocalM launches the one-image form of the
-// kernel (a workgroup per 256-pixel chunk instead of 16 per image, class prior by value: expect_local_single) + the finalise kernel,
-// fetches wC / wR / wT / wD with ONE copy and waits ONCE.  Per image-phase: 1 H2D, 2 kernels, 1 D2H, 1 synchronisation (before: 5 - 7
-// H2D, 3 kernels, 4 D2H, 2 - 3 synchronisations and 16 workgroups).  The batched thx_expect_local_dev stays the throughput form.
+// kernel (a workgroup per 32 pixels instead of 16 per image, class prior by value: expect_local_single), the fixed-order reduce of
+// the partial sums and the finalise kernel, which writes wC / wR / wT / wD STRAIGHT into a page-locked host block and, behind a
+// system-scope fence, a completion word the calling thread polls.  Per image-phase: 1 H2D, 3 kernels, 1 wait on a host word -- no copy
+// back, no call into the runtime while waiting (before: 5 - 7 H2D, 3 kernels, 4 D2H, 2 - 3 synchronisations and 16 workgroups).  The
+// batched thx_expect_local_dev stays the throughput form.
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -39,11 +41,13 @@ struct thx_calpoint {     // ManagedCalPoint (gpu/include/ManagedCalPoint.h): pe
     void* ws;
     hipStream_t stream;
     // page-locked host mirrors: hIn = the double block devR .. devRotm as ExpectLocalRTD stages it (ONE copy in ExpectLocalPreI3D),
-    // hOut = devwC .. devBaseL (ONE copy back in ExpectLocalM), hSmall = CTFAttr + k1, k2 of the current image (defocus search)
+    // hOut = wC | wR | wT | wD | baseLine | completion word: written by ExpectLocalM's finalise kernel itself (THX_IFACE_ZEROCOPY=0: ONE copy back
+    // of devwC .. devBaseL), hSmall = CTFAttr + k1, k2 of the current image (defocus search)
     double* hIn;
     float* hOut;
     char* hSmall;
     size_t nIn, nOut;
+    unsigned seq;                            // image-phases run on this ManagedCalPoint: the value the finalise kernel leaves in hOut[nOut]
     // recorded by ExpectLocalPreI3D for ExpectLocalM
     const float* vol;
     const float* cells;
@@ -67,6 +71,24 @@ static int wait_stream(hipStream_t st)
         }
     }
     THX_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// The same wait on a word the last kernel of the image-phase writes into page-locked host memory (after a system-scope fence behind
+// its outputs): the thread sees it without a call into the runtime and without waiting for the stream's completion signal.  Falls back
+// to the stream after a millisecond -- or at once when a launch has failed (the word would never arrive).
+static int wait_flag(const unsigned* flag, unsigned val, hipStream_t st)
+{
+    static const bool spin = []() { const char* e = getenv("THX_IFACE_SPIN"); return !(e && e[0] == '0'); }();
+    if (spin) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int it = 0;; it++) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == val) return 0;
+            if ((it & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1)) break;
+        }
+    }
+    THX_RC(wait_stream(st));
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != val) { set_error("the image-phase finished without its completion word"); return -1; }
     return 0;
 }
 
@@ -145,7 +167,7 @@ int thx_calpoint_create(thx_calpoint** out, int mode, int cSearch, int gpuIdx, i
     // (non-blocking: a copy another thread issues on the legacy default stream must not serialise the image-phases of every ManagedCalPoint)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->hIn), nDbl * sizeof(double), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->hOut), c->nOut * sizeof(float), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->hOut), (c->nOut + 4) * sizeof(float), hipHostMallocCoherent | hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->hSmall), sizeof(thx_ctf_attr) + 2 * sizeof(float), hipHostMallocDefault);
     if (e != hipSuccess) {
         (void)hipFree(d); (void)hipFree(f); (void)hipFree(c->attr); (void)hipFree(c->ws);
@@ -157,6 +179,7 @@ int thx_calpoint_create(thx_calpoint** out, int mode, int cSearch, int gpuIdx, i
         set_error("ManagedCalPoint allocation failed: %s", hipGetErrorString(e));
         return (int)e;
     }
+    memset(c->hOut, 0, (c->nOut + 4) * sizeof(float));
     c->devR = d; d += nR;
     c->devT = d; d += nT;
     c->devD = d; d += mD;
@@ -386,12 +409,25 @@ int thx_ExpectLocalM_host(int gpuIdx, int datShift, thx_calpoint* mcp, const flo
     const int nD = mcp->cSearch == 2 ? mcp->mD : 1;
     const float* ctf = mcp->cSearch == 2 ? mcp->devctfD : devctfP + slot;
     THX_REQUIRE(ctf, "devctfP is NULL");
-    // two launches (fused gather + likelihood over every 256-pixel chunk, finalise), one copy back, one wait
-    THX_RC(expect_local_single(mcp->cells ? mcp->cells : mcp->vol, mcp->cells != nullptr, mcp->vdim, mcp->pf, mcp->idim, mcp->iCol, mcp->iRow, npxl,
-                               devdatP + 2 * slot, ctf, devsigP + slot, mcp->devRotm, mcp->nR, mcp->devnT, mcp->nT, nD, oldC, mcp->devR,
-                               mcp->devT, mcp->devD, mcp->devwC, mcp->devwR, mcp->devwT, mcp->devwD, mcp->devBaseL, mcp->ws, st));
-    THX_CHECK(hipMemcpyAsync(mcp->hOut, mcp->devwC, mcp->nOut * sizeof(float), hipMemcpyDeviceToHost, st));
-    THX_RC(wait_stream(st));
+    // three launches (fused gather + likelihood over ranges of 32 pixels, the reduce of the partial sums, finalise), one wait
+    static const bool zeroCopy = []() { const char* e = getenv("THX_IFACE_ZEROCOPY"); return !(e && e[0] == '0'); }();
+    if (zeroCopy) {
+        // the finalise kernel writes wC | wR | wT | wD | baseLine straight into the page-locked (device-visible, coherent) host block:
+        // one dependent operation less in the chain of an image-phase than a copy back (THX_IFACE_ZEROCOPY=0: the copy)
+        float* o = mcp->hOut;
+        unsigned* flag = reinterpret_cast<unsigned*>(mcp->hOut + mcp->nOut);
+        const unsigned val = ++mcp->seq ? mcp->seq : ++mcp->seq;   // (never 0, the word's initial value)
+        THX_RC(expect_local_single(mcp->cells ? mcp->cells : mcp->vol, mcp->cells != nullptr, mcp->vdim, mcp->pf, mcp->idim, mcp->iCol, mcp->iRow, npxl,
+                                   devdatP + 2 * slot, ctf, devsigP + slot, mcp->devRotm, mcp->nR, mcp->devnT, mcp->nT, nD, oldC, mcp->devR,
+                                   mcp->devT, mcp->devD, o, o + 1, o + 1 + mcp->nR, o + 1 + mcp->nR + mcp->nT, o + 1 + mcp->nR + mcp->nT + mcp->mD, mcp->ws, st, flag, val));
+        THX_RC(wait_flag(flag, val, st));
+    } else {
+        THX_RC(expect_local_single(mcp->cells ? mcp->cells : mcp->vol, mcp->cells != nullptr, mcp->vdim, mcp->pf, mcp->idim, mcp->iCol, mcp->iRow, npxl,
+                                   devdatP + 2 * slot, ctf, devsigP + slot, mcp->devRotm, mcp->nR, mcp->devnT, mcp->nT, nD, oldC, mcp->devR,
+                                   mcp->devT, mcp->devD, mcp->devwC, mcp->devwR, mcp->devwT, mcp->devwD, mcp->devBaseL, mcp->ws, st));
+        THX_CHECK(hipMemcpyAsync(mcp->hOut, mcp->devwC, mcp->nOut * sizeof(float), hipMemcpyDeviceToHost, st));
+        THX_RC(wait_stream(st));
+    }
     const float* o = mcp->hOut;
     wC[0] = o[0]; o += 1;
     memcpy(wR, o, mcp->nR * sizeof(float)); o += mcp->nR;

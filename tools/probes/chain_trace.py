@@ -20,31 +20,35 @@ def main():
     chains, cur, last_copy = [], None, None
     for s, e, name in rows:
         if "k_expect_local" in name:
-            cur = {"local": (s, e)}
-            # the copy in is the last copyBuffer before it
-            cur["in"] = last_copy
+            if cur is not None and "final" in cur:
+                chains.append(cur)
+            cur = {"local": (s, e), "in": last_copy}   # the copy in is the last copyBuffer before it
         elif "k_expect_reduce" in name and cur is not None:
             cur["reduce"] = (s, e)
         elif "k_expect_final" in name and cur is not None:
             cur["final"] = (s, e)
         elif "copyBuffer" in name:
+            if cur is not None and "final" in cur and "out" not in cur and s - cur["final"][1] < 3000:
+                cur["out"] = (s, e)     # a copy right behind the finalise kernel: the copy back (absent in the zero-copy form)
             last_copy = (s, e)
-            if cur is not None and "final" in cur and "out" not in cur:
-                cur["out"] = (s, e)
-                chains.append(cur)
-                cur = None
+    if cur is not None and "final" in cur:
+        chains.append(cur)
     lo = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     hi = int(sys.argv[3]) if len(sys.argv) > 3 else min(len(chains), 1500)
-    sel = [c for c in chains[lo:hi] if c.get("in")]
+    sel = [c for c in chains[lo:hi] if c.get("in") and "reduce" in c and "final" in c]
+    has_out = sum("out" in c for c in sel) > 0.8 * len(sel)
+    if has_out:
+        sel = [c for c in sel if "out" in c]
     med = lambda v: statistics.median(v) / 1e3
-    print("%d chains in the trace, %d .. %d used" % (len(chains), lo, hi))
-    order = ("in", "local", "reduce", "final", "out")
+    print("%d chains in the trace, %d .. %d used (%s)" % (len(chains), lo, hi, "copy out" if has_out else "zero-copy outputs: no copy out"))
+    order = ("in", "local", "reduce", "final") + (("out",) if has_out else ())
+    last = order[-1]
     for k in order:
         print("  %-7s duration %6.1f us" % (k, med([c[k][1] - c[k][0] for c in sel])))
     for a, b in zip(order[:-1], order[1:]):
         print("  gap %-7s -> %-7s %6.1f us" % (a, b, med([c[b][0] - c[a][1] for c in sel])))
-    print("  chain, copy in's start -> copy out's end %6.1f us" % med([c["out"][1] - c["in"][0] for c in sel]))
-    print("  between chains (copy out's end -> next copy in's start) %6.1f us" % med([b["in"][0] - a["out"][1] for a, b in zip(sel[:-1], sel[1:])]))
+    print("  chain, copy in's start -> %s's end %6.1f us" % (last, med([c[last][1] - c["in"][0] for c in sel])))
+    print("  between chains (%s's end -> next copy in's start) %6.1f us" % (last, med([b["in"][0] - a[last][1] for a, b in zip(sel[:-1], sel[1:])])))
     print("  chain period %6.1f us" % med([b["in"][0] - a["in"][0] for a, b in zip(sel[:-1], sel[1:])]))
 
 

@@ -6,6 +6,7 @@
 #   PART=d  the driver's own command line at this HEAD (+ its wall time) and the GPU suite's tail
 #   PART=e  round 6: an iteration BELOW Nyquist (configs[1] at r = rU = 48: resized reconstruction grid) -- line + kernel statistics;
 #           the drop-in path (bench.py --staged: C++ caller loop with / without the reference's per-GPU lock) -- line + kernel statistics
+#   PART=f  the drop-in path alone, + the kernel-by-kernel chain of a locked image-phase (tools/probes/chain_trace.py)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r06; mkdir -p $OUT
 stats() {   # stats <name> <bench args...>
@@ -49,4 +50,10 @@ e)
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st_staged -- python bench.py --staged --staged-images 512 > $OUT/bench_staged_under_rocprof.json 2> $OUT/st_staged.err
     cp $(find $OUT/st_staged -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_staged.csv; rm -rf $OUT/st_staged
     head -8 $OUT/kernel_stats_staged.csv | cut -c1-150 ;;
+f)  # the drop-in path alone (after the zero-copy outputs + completion word): line, kernel statistics, the chain of a locked image-phase
+    python bench.py --staged > $OUT/bench_staged.json 2> $OUT/bench_staged.err; head -c 500 $OUT/bench_staged.json; echo
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st_staged -- python bench.py --staged --staged-images 512 > $OUT/bench_staged_under_rocprof.json 2> $OUT/st_staged.err
+    cp $(find $OUT/st_staged -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_staged.csv
+    python tools/probes/chain_trace.py $(find $OUT/st_staged -name "*kernel_trace.csv" | head -1) 150 1500 | tee $OUT/dropin_chain_trace.txt
+    rm -rf $OUT/st_staged ;;
 esac
