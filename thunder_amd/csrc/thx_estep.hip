@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256) void k_expect_local_nd(ExpectLocalArgs a)
 }
 
 // The one-image form leaves hundreds of partial sums per (shift, rotation): added up here in a FIXED order before the finalise
-// kernel -- lane <-> element, the sixteen waves of a workgroup take a sixteenth of the splits each (loads issued eight at a time), wave 0
+// kernel -- lane <-> element, the sixteen waves of a workgroup take a sixteenth of the splits each (loads issued sixteen at a time), wave 0
 // adds the sixteen sums in wave order; the result overwrites split 0.  grid (ceil(nT nRpad / 64)), block 1024.  partC likewise (workgroup 0).
 constexpr int kReduceWaves = 16;
 __global__ __launch_bounds__(64 * kReduceWaves) void k_expect_reduce(float* __restrict__ partV, float* __restrict__ partC, int nSplit, int nElem)
@@ -742,12 +742,12 @@ __global__ __launch_bounds__(64 * kReduceWaves) void k_expect_reduce(float* __re
     const int s0 = (int)(((long)nSplit * wave) / kReduceWaves), s1 = (int)(((long)nSplit * (wave + 1)) / kReduceWaves);
     float v = 0.f;
     if (e < nElem) {
-        for (int s = s0; s < s1; s += 8) {
-            float x[8];
+        for (int s = s0; s < s1; s += 16) {   // (sixteen loads in flight: three round trips for a wave's ~48 splits)
+            float x[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) x[u] = (s + u < s1) ? partV[(size_t)(s + u) * nElem + e] : 0.f;
+            for (int u = 0; u < 16; u++) x[u] = (s + u < s1) ? partV[(size_t)(s + u) * nElem + e] : 0.f;
 #pragma unroll
-            for (int u = 0; u < 8; u++) v += x[u];
+            for (int u = 0; u < 16; u++) v += x[u];
         }
     }
     sq[wave][lane] = v;
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(64 * kReduceWaves) void k_expect_reduce(float* __re
 }
 
 // Finalise: L = C + V, per-image maximum, exp, marginals (src/Optimiser.cpp:1383-1402 in closed form).
-// grid (nImg), block 256, dynamic LDS nD*nT*nR floats.
+// grid (nImg), block 256, dynamic LDS nD*nT*nR floats + (nR + nT + nD) doubles.
 struct ExpectFinalArgs {
     const float* partV;
     const float* partC;
@@ -822,6 +822,18 @@ __global__ __launch_bounds__(256) void k_expect_final(ExpectFinalArgs a)
     const int img = blockIdx.x, tid = threadIdx.x;
     if (a.active && !a.active[img]) return;
     const int n = a.nD * a.nT * a.nR;
+    // the priors go to LDS first, their loads in flight with the partial sums': the marginals below then touch no global memory (a lone
+    // workgroup -- the one-image form -- pays every dependent round trip in full)
+    double* sPR = reinterpret_cast<double*>(smem_raw + (((size_t)n * sizeof(float) + 7) & ~(size_t)7));
+    double* sPT = sPR + a.nR;
+    double* sPD = sPT + a.nT;
+    {
+        const double* gR = a.pR + (size_t)img * a.nR;
+        const double* gT = a.pT + (size_t)img * a.nT;
+        const double* gD = a.pD + (size_t)img * a.nD;
+        for (int i = tid; i < a.nR + a.nT + a.nD; i += 256)
+            sPR[i] = i < a.nR ? gR[i] : (i < a.nR + a.nT ? gT[i - a.nR] : gD[i - a.nR - a.nT]);
+    }
     float lmax = -INFINITY, cconst = 0.f;
     for (int e = tid; e < n; e += 256) {
         const int r = e % a.nR, t = (e / a.nR) % a.nT, d = e / (a.nR * a.nT);
@@ -848,9 +860,7 @@ __global__ __launch_bounds__(256) void k_expect_final(ExpectFinalArgs a)
     __syncthreads();
     const float base = sfred[4] + vmax;
     const double pC = a.pC ? a.pC[img] : a.pCval;
-    const double* pR = a.pR + (size_t)img * a.nR;
-    const double* pT = a.pT + (size_t)img * a.nT;
-    const double* pD = a.pD + (size_t)img * a.nD;
+    const double *pR = sPR, *pT = sPT, *pD = sPD;
     // wR
     for (int r = tid; r < a.nR; r += 256) {
         double s = 0;
@@ -1656,7 +1666,7 @@ static int expect_local_impl(const float* volumes, const int* volIdx, int vdim, 
     f.active = active;
     f.par = fine ? 1 : 0;
     f.done = done; f.doneVal = doneVal;
-    hipLaunchKernelGGL(k_expect_final, dim3(nImg), dim3(256), (size_t)nD * nT * nR * sizeof(float), st, f);
+    hipLaunchKernelGGL(k_expect_final, dim3(nImg), dim3(256), (((size_t)nD * nT * nR * sizeof(float) + 7) & ~(size_t)7) + (size_t)(nR + nT + nD) * sizeof(double), st, f);
     THX_LAUNCH_CHECK();
     return 0;
 }
